@@ -1,0 +1,49 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE — builds oracle/_ref/librir_ref.so from the UNMODIFIED reference sources
+# where they lie under /root/reference (never copied into this repo; oracle/_ref/ is git-ignored).
+#
+# What is compiled: src/cpp/signal_processing/{BadPixels,Filters,signal_processing}.cpp and
+# src/cpp/tools/{SIMD,Misc,Log}.cpp, with the reference Release flags (-O3 -DNDEBUG, no OpenMP,
+# no -march: SURVEY.md §2 row 16), plus oracle/ref_driver.cpp (ours).
+#
+# Two things the reference build system would do that we do by hand, both stated in DESIGN.md:
+#  * rir_config.h is produced from the reference's own rir_config.h.in by substituting its five
+#    @PROJECT_*@ name/version tokens (cosmetic strings; no arithmetic depends on them);
+#  * tools.cpp (handle registry) needs zstd.h and minizip's unzip.h, which this image lacks, so it
+#    is NOT built and NOT replaced: the version script below keeps only the symbols we call and
+#    --gc-sections discards the three bad_pixels_{create,correct,destroy} wrappers that reference
+#    the registry. Their arithmetic (rir::BadPixels) is reached through ref_driver.cpp instead.
+#
+# The codec half of the reference (h264.cpp -> ffmpeg 7.1 + libx264) is unbuildable here.
+set -euo pipefail
+R=${RIR_REFERENCE:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+OUT=$HERE/_ref
+if [ ! -d "$R/src/cpp/signal_processing" ]; then
+	echo "build_ref: $R not present - skipping (prebuilt oracle/_ref is used if it exists)"
+	exit 0
+fi
+mkdir -p "$OUT"
+sed -e 's/@PROJECT_NAME@/librir/' -e 's/@PROJECT_VERSION@/6.1.2/' \
+	-e 's/@PROJECT_VERSION_MAJOR@/6/' -e 's/@PROJECT_VERSION_MINOR@/1/' \
+	-e 's/@PROJECT_VERSION_PATCH@/2/' "$R/rir_config.h.in" >"$OUT/rir_config.h"
+cat >"$OUT/exports.map" <<'EOF'
+{
+  global:
+    translate; gaussian_filter; find_median_pixel; find_median_pixel_mask; hash_bytes;
+    extract_times; resample_time_serie; label_image; keep_largest_area;
+    ref_*;
+  local: *;
+};
+EOF
+g++ -std=c++14 -O3 -DNDEBUG -fPIC -shared -ffunction-sections -fdata-sections \
+	-DBUILD_SIGNAL_PROCESSING_LIB -DBUILD_TOOLS_LIB \
+	-I"$OUT" -I"$R/src/cpp/tools" -I"$R/src/cpp/geometry" -I"$R/src/cpp/signal_processing" \
+	"$R/src/cpp/signal_processing/BadPixels.cpp" "$R/src/cpp/signal_processing/Filters.cpp" \
+	"$R/src/cpp/signal_processing/signal_processing.cpp" \
+	"$R/src/cpp/tools/SIMD.cpp" "$R/src/cpp/tools/Misc.cpp" "$R/src/cpp/tools/Log.cpp" \
+	"$HERE/ref_driver.cpp" \
+	-Wl,--gc-sections -Wl,--version-script="$OUT/exports.map" -Wl,--no-undefined \
+	-static-libstdc++ -static-libgcc -lpthread \
+	-o "$OUT/librir_ref.so"
+echo "build_ref: built $OUT/librir_ref.so"

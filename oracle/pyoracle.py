@@ -1,0 +1,252 @@
+"""TEST INFRASTRUCTURE — ctypes access to the CPU oracle and to oracle/_ref.
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module.  The product package (``librir_amd``) never does.
+
+``Oracle``  = oracle/librir_oracle.so, the plain-C restatement (oracle/rir_oracle.c).
+``Ref``     = oracle/_ref/librir_ref.so, the UNMODIFIED reference C++ compiled by
+              oracle/build_ref.sh (present only where it was built; never on a box without it).
+"""
+import ctypes as ct
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+DTYPE_CHARS = {
+    np.dtype(np.bool_): "?",
+    np.dtype(np.int8): "b",
+    np.dtype(np.uint8): "B",
+    np.dtype(np.int16): "h",
+    np.dtype(np.uint16): "H",
+    np.dtype(np.int32): "i",
+    np.dtype(np.uint32): "I",
+    np.dtype(np.int64): "l",
+    np.dtype(np.uint64): "L",
+    np.dtype(np.float32): "f",
+    np.dtype(np.float64): "d",
+}
+
+
+def _p(a):
+    return a.ctypes.data_as(ct.c_void_p)
+
+
+class _SignalProcessingMixin:
+    """Entry points whose signatures are identical in the oracle (orc_ prefix) and in _ref."""
+
+    _prefix = ""
+
+    def _fn(self, name):
+        return getattr(self.lib, self._prefix + name)
+
+    def translate(self, image, dx, dy, strategy="", background=0, prefill=None):
+        img = np.ascontiguousarray(image)
+        dst = np.array(img if prefill is None else prefill, copy=True, order="C")
+        back = np.zeros(1, dtype=img.dtype)
+        back[0] = background
+        f = self._fn("translate")
+        f.argtypes = [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_float, ct.c_float, ct.c_void_p, ct.c_char_p]
+        f.restype = ct.c_int
+        r = f(ord(DTYPE_CHARS[img.dtype]), _p(img), _p(dst), img.shape[1], img.shape[0],
+              np.float32(dx), np.float32(dy), _p(back), strategy.encode())
+        if r < 0:
+            raise RuntimeError("translate failed")
+        return dst
+
+    def gaussian_filter(self, image, sigma):
+        img = np.ascontiguousarray(image, dtype=np.float32)
+        dst = np.zeros_like(img)
+        f = self._fn("gaussian_filter")
+        f.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_float]
+        f.restype = ct.c_int
+        f(_p(img), _p(dst), img.shape[1], img.shape[0], np.float32(sigma))
+        return dst
+
+    def find_median_pixel(self, image, percent=0.5, mask=None):
+        img = np.ascontiguousarray(image, dtype=np.uint16)
+        if mask is None:
+            f = self._fn("find_median_pixel")
+            f.argtypes = [ct.c_void_p, ct.c_int, ct.c_float]
+            f.restype = ct.c_int
+            return f(_p(img), img.size, np.float32(percent))
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        f = self._fn("find_median_pixel_mask")
+        f.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_float]
+        f.restype = ct.c_int
+        return f(_p(img), _p(m), img.size, np.float32(percent))
+
+
+class Oracle(_SignalProcessingMixin):
+    _prefix = "orc_"
+
+    def __init__(self, path=None):
+        path = path or os.path.join(_HERE, "librir_oracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle library missing: run `make -C oracle` (or __graft_entry__.build())")
+        self.lib = ct.CDLL(path)
+        L = self.lib
+        L.orc_codec_ntiles.restype = ct.c_int
+        L.orc_codec_max_words.restype = ct.c_int64
+        L.orc_codec_encode_chunk.restype = ct.c_int64
+        L.orc_codec_encode_chunk.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p]
+        L.orc_codec_decode_chunk.restype = ct.c_int
+        L.orc_codec_decode_chunk.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_void_p]
+        L.orc_bad_pixels_detect.restype = ct.c_int
+        L.orc_bad_pixels_detect.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_double, ct.c_void_p, ct.c_int]
+        L.orc_bad_pixels_stats.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_double, ct.c_void_p, ct.c_void_p]
+        L.orc_bad_pixels_correct.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int]
+        L.orc_remove_bad_pixels.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p]
+        L.orc_remove_motion.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_float, ct.c_float]
+        L.orc_translate_u16_f32_nearest.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_float, ct.c_float]
+        L.orc_median_filter_u16.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int]
+        L.orc_gaussian_kernel.argtypes = [ct.c_float, ct.c_void_p, ct.c_int]
+        L.orc_gaussian_radius.argtypes = [ct.c_float]
+        L.orc_gaussian_radius.restype = ct.c_int
+        L.orc_clamp_min.argtypes = [ct.c_void_p, ct.c_int, ct.c_uint16]
+
+    # ---- bad pixels -------------------------------------------------------------------------
+    def bad_pixels_detect(self, image, std_factor=5.0):
+        img = np.ascontiguousarray(image, dtype=np.uint16)
+        h, w = img.shape
+        xy = np.zeros((img.size, 2), dtype=np.int32)
+        n = self.lib.orc_bad_pixels_detect(_p(img), w, h, float(std_factor), _p(xy), img.size)
+        return xy[:n].copy()
+
+    def bad_pixels_stats(self, image, std_factor=5.0):
+        img = np.ascontiguousarray(image, dtype=np.uint16)
+        h, w = img.shape
+        a, b = ct.c_int(0), ct.c_int(0)
+        self.lib.orc_bad_pixels_stats(_p(img), w, h, float(std_factor), ct.byref(a), ct.byref(b))
+        return a.value, b.value
+
+    def bad_pixels_correct(self, image, xy, floor_correct):
+        img = np.ascontiguousarray(image, dtype=np.uint16)
+        h, w = img.shape
+        out = np.zeros_like(img)
+        xy = np.ascontiguousarray(xy, dtype=np.int32)
+        self.lib.orc_bad_pixels_correct(_p(img), _p(out), w, h, _p(xy), len(xy), int(floor_correct))
+        return out
+
+    def remove_bad_pixels(self, image, xy, rows=None):
+        """IRFileLoader::removeBadPixels on the first `rows` rows (reference passes H-3)."""
+        img = np.array(image, dtype=np.uint16, order="C")
+        h, w = img.shape
+        rows = h if rows is None else rows
+        xy = np.ascontiguousarray(xy, dtype=np.int32)
+        bitmap = np.zeros((h, w), dtype=np.uint8)
+        if len(xy):
+            bitmap[xy[:, 1], xy[:, 0]] = 1
+        self.lib.orc_remove_bad_pixels(_p(img), w, rows, _p(xy), len(xy), _p(bitmap))
+        return img
+
+    def remove_motion(self, image, tx, ty, rows=None):
+        img = np.array(image, dtype=np.uint16, order="C")
+        h, w = img.shape
+        rows = h if rows is None else rows
+        self.lib.orc_remove_motion(_p(img), w, rows, np.float32(tx), np.float32(ty))
+        return img
+
+    def translate_u16_f32_nearest(self, image, dx, dy):
+        img = np.ascontiguousarray(image, dtype=np.uint16)
+        out = np.zeros(img.shape, dtype=np.float32)
+        self.lib.orc_translate_u16_f32_nearest(_p(img), _p(out), img.shape[1], img.shape[0], np.float32(dx), np.float32(dy))
+        return out
+
+    def median_filter(self, image):
+        img = np.ascontiguousarray(image, dtype=np.uint16)
+        out = np.zeros_like(img)
+        self.lib.orc_median_filter_u16(_p(img), _p(out), img.shape[1], img.shape[0])
+        return out
+
+    def gaussian_kernel(self, sigma):
+        r = self.lib.orc_gaussian_radius(np.float32(sigma))
+        k = np.zeros((2 * r + 1, 2 * r + 1), dtype=np.float32)
+        self.lib.orc_gaussian_kernel(np.float32(sigma), _p(k), r)
+        return k
+
+    # ---- codec ------------------------------------------------------------------------------
+    def codec_encode_chunk(self, frames):
+        """frames: (n, H, W) uint16 -> (sizes[ntiles, n] u8, tile_off[ntiles+1] u32, stream u64[words])."""
+        fr = np.ascontiguousarray(frames, dtype=np.uint16)
+        n, h, w = fr.shape
+        nt = self.lib.orc_codec_ntiles(w, h)
+        sizes = np.zeros((nt, n), dtype=np.uint8)
+        off = np.zeros(nt + 1, dtype=np.uint32)
+        stream = np.zeros(self.lib.orc_codec_max_words(w, h, n), dtype=np.uint64)
+        words = self.lib.orc_codec_encode_chunk(_p(fr), w, h, n, _p(sizes), _p(off), _p(stream))
+        return sizes, off, stream[:words].copy()
+
+    def codec_decode_chunk(self, sizes, tile_off, stream, w, h):
+        sizes = np.ascontiguousarray(sizes, dtype=np.uint8)
+        n = sizes.shape[1]
+        out = np.zeros((n, h, w), dtype=np.uint16)
+        st = np.ascontiguousarray(stream, dtype=np.uint64)
+        if st.size == 0:
+            st = np.zeros(1, dtype=np.uint64)
+        r = self.lib.orc_codec_decode_chunk(_p(sizes), _p(np.ascontiguousarray(tile_off, dtype=np.uint32)), _p(st), w, h, n, _p(out))
+        if r != 0:
+            raise RuntimeError("oracle decode: malformed stream")
+        return out
+
+
+class Ref(_SignalProcessingMixin):
+    """The reference C++ itself (oracle/_ref/librir_ref.so); raises if it was not built."""
+
+    _prefix = ""
+
+    def __init__(self, path=None):
+        path = path or os.path.join(_HERE, "_ref", "librir_ref.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = ct.CDLL(path)
+        L = self.lib
+        L.ref_bad_pixels_detect.restype = ct.c_int
+        L.ref_bad_pixels_detect.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int]
+        L.ref_bad_pixels_new.restype = ct.c_void_p
+        L.ref_bad_pixels_new.argtypes = [ct.c_void_p, ct.c_int, ct.c_int]
+        L.ref_bad_pixels_correct.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_void_p]
+        L.ref_bad_pixels_delete.argtypes = [ct.c_void_p]
+        L.ref_translate_u16_f32_nearest.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_float, ct.c_float]
+        L.ref_median_filter_u16.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int]
+
+    @staticmethod
+    def available():
+        return os.path.exists(os.path.join(_HERE, "_ref", "librir_ref.so"))
+
+    def bad_pixels_detect(self, image):
+        img = np.ascontiguousarray(image, dtype=np.uint16)
+        h, w = img.shape
+        xy = np.zeros((img.size, 2), dtype=np.int32)
+        n = self.lib.ref_bad_pixels_detect(_p(img), w, h, _p(xy), img.size)
+        return xy[:n].copy()
+
+    def bad_pixels_correct(self, first, image):
+        """BadPixels(first).correct(image) exactly as the reference object does it."""
+        first = np.ascontiguousarray(first, dtype=np.uint16)
+        img = np.ascontiguousarray(image, dtype=np.uint16)
+        h, w = first.shape
+        bp = self.lib.ref_bad_pixels_new(_p(first), w, h)
+        out = np.zeros_like(img)
+        self.lib.ref_bad_pixels_correct(bp, _p(img), _p(out))
+        self.lib.ref_bad_pixels_delete(bp)
+        return out
+
+    def bad_pixels_floor(self, first):
+        """m_median_value as observable from outside: correct() of an all-zero frame returns the
+        clamp floor everywhere when it is > 0 (BadPixels.cpp:62-65)."""
+        z = np.zeros_like(np.ascontiguousarray(first, dtype=np.uint16))
+        return int(self.bad_pixels_correct(first, z).flat[0])
+
+    def translate_u16_f32_nearest(self, image, dx, dy):
+        img = np.ascontiguousarray(image, dtype=np.uint16)
+        out = np.zeros(img.shape, dtype=np.float32)
+        self.lib.ref_translate_u16_f32_nearest(_p(img), _p(out), img.shape[1], img.shape[0], np.float32(dx), np.float32(dy))
+        return out
+
+    def median_filter(self, image):
+        img = np.ascontiguousarray(image, dtype=np.uint16)
+        out = np.zeros_like(img)
+        self.lib.ref_median_filter_u16(_p(img), _p(out), img.shape[1], img.shape[0])
+        return out

@@ -1,0 +1,774 @@
+/*
+ * TEST INFRASTRUCTURE — CPU oracle for the librir hot path.  NOT part of the product.
+ *
+ * Plain-C restatement (written from the behaviour of the reference, not copied) of the arithmetic
+ * on the path named by BASELINE.json `north_star`.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product (librir_amd/csrc) never does.
+ *
+ * Pinning: every function in the "signal_processing" half is checked bit-for-bit (integers) or
+ * bit-for-bit/1e-5 (float) against the UNMODIFIED reference C++ compiled into oracle/_ref
+ * (oracle/build_ref.sh) and against the golden vectors under tests/golden produced from it
+ * (tests/golden/make_golden.py).  The codec half restates THIS build's own bitstream format
+ *  because the reference codec (libx264 through ffmpeg) is third-party and
+ * unbuildable here; its parity contract is the reference tests' identity decode(encode(x)) == x
+ * (reference tests/python/test_IRMovie.py:40-49,60-99).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared  (no -ffast-math, no FMA: the reference Release
+ * build is plain x86-64 SSE2, so products and sums round separately).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define EXPORT __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------ */
+/* F1  translate<T,U>   reference: src/cpp/signal_processing/Filters.h:249-326                 */
+/*     C entry + dtype/strategy dispatch: src/cpp/signal_processing/signal_processing.cpp:14-73 */
+/* ------------------------------------------------------------------------------------------ */
+
+enum
+{
+	ORC_UNCHANGED = 0,
+	ORC_CONSTANT = 1,
+	ORC_WRAP = 2,
+	ORC_NEAREST = 3
+};
+
+/* (size_t)(float) as x86-64 gcc does it for |v| < 2^63: truncate toward zero through a signed
+ * 64-bit conversion, then reinterpret (negative values become 2^64 - k).  Filters.h:273-276. */
+static inline uint64_t f2sz(float v) { return (uint64_t)(int64_t)v; }
+/* detail::wrap, Filters.h:231 (unsigned wrap-around arithmetic on purpose). */
+static inline uint64_t wrap_sz(uint64_t value, uint64_t max) { return (value + max) % max; }
+
+/* double -> U as the reference's static_cast does on x86-64 (in-range values: truncation). */
+#define CAST_bool(v) ((uint8_t)((v) != 0))
+#define CAST_i8(v) ((int8_t)(int32_t)(v))
+#define CAST_u8(v) ((uint8_t)(int32_t)(v))
+#define CAST_i16(v) ((int16_t)(int32_t)(v))
+#define CAST_u16(v) ((uint16_t)(int32_t)(v))
+#define CAST_i32(v) ((int32_t)(v))
+#define CAST_u32(v) ((uint32_t)(int64_t)(v))
+#define CAST_i64(v) ((int64_t)(v))
+#define CAST_u64(v) ((uint64_t)(v))
+#define CAST_f32(v) ((float)(v))
+#define CAST_f64(v) ((double)(v))
+
+#define DEFINE_TRANSLATE(NAME, T, U, CAST)                                                       \
+	static void translate_##NAME(const T *src, U *dst, U background, int w_, int h_, float dx,     \
+								 float dy, int strategy)                                           \
+	{                                                                                              \
+		const uint64_t w = (uint64_t)w_, h = (uint64_t)h_;                                         \
+		for (int y = 0; y < h_; ++y)                                                               \
+			for (uint64_t x = 0; x < w; ++x)                                                       \
+			{                                                                                      \
+				float px = (float)x - dx; /* Filters.h:257-258: float coordinates */              \
+				float py = (float)y - dy;                                                          \
+				if (px < 0 || px >= (float)w || py < 0 || py >= (float)h)                          \
+				{                                                                                  \
+					if (strategy == ORC_UNCHANGED)                                                 \
+					{                                                                              \
+					}                                                                              \
+					else if (strategy == ORC_CONSTANT)                                             \
+						dst[x + (uint64_t)y * w] = background;                                     \
+					else if (strategy == ORC_WRAP)                                                 \
+					{ /* Filters.h:270-285 */                                                      \
+						uint64_t l = wrap_sz(f2sz(px), w), r = wrap_sz(f2sz(px + 1), w);           \
+						uint64_t t = wrap_sz(f2sz(py), h), b = wrap_sz(f2sz(py + 1), h);           \
+						const T p1 = src[b * w + l], p2 = src[t * w + l];                          \
+						const T p3 = src[b * w + r], p4 = src[t * w + r];                          \
+						const double u = fabsf(px - (float)(int)px);                               \
+						const double v = fabsf(py - (float)(int)py);                               \
+						double val = ((double)p1 * (1 - v) + (double)p2 * v) * (1 - u) +           \
+									 ((double)p3 * (1 - v) + (double)p4 * v) * u;                  \
+						dst[x + (uint64_t)y * w] = CAST(val);                                      \
+					}                                                                              \
+					else                                                                           \
+					{ /* nearest: clamp then truncate, Filters.h:286-303 */                        \
+						uint64_t _x, _y;                                                           \
+						if (px < 0)                                                                \
+							_x = 0;                                                                \
+						else if (px >= (float)w)                                                   \
+							_x = w - 1;                                                            \
+						else                                                                       \
+							_x = f2sz(px);                                                         \
+						if (py < 0)                                                                \
+							_y = 0;                                                                \
+						else if (py >= (float)h)                                                   \
+							_y = h - 1;                                                            \
+						else                                                                       \
+							_y = f2sz(py);                                                         \
+						dst[x + (uint64_t)y * w] = (U)src[_x + _y * w];                            \
+					}                                                                              \
+				}                                                                                  \
+				else                                                                               \
+				{ /* Filters.h:305-323 */                                                          \
+					const uint64_t l = f2sz(px);                                                   \
+					uint64_t r = f2sz(px + 1);                                                     \
+					if (r == w)                                                                    \
+						r = l;                                                                     \
+					const uint64_t t = f2sz(py);                                                   \
+					uint64_t b = f2sz(py + 1);                                                     \
+					if (b == h)                                                                    \
+						b = t;                                                                     \
+					const T p1 = src[b * w + l], p2 = src[t * w + l];                              \
+					const T p3 = src[b * w + r], p4 = src[t * w + r];                              \
+					const double u = (px - (float)l); /* float subtraction, then widened */        \
+					const double v = ((float)b - py);                                              \
+					double val = ((double)p1 * (1 - v) + (double)p2 * v) * (1 - u) +               \
+								 ((double)p3 * (1 - v) + (double)p4 * v) * u;                      \
+					dst[x + (uint64_t)y * w] = CAST(val);                                          \
+				}                                                                                  \
+			}                                                                                      \
+	}
+
+DEFINE_TRANSLATE(bool, uint8_t, uint8_t, CAST_bool)
+DEFINE_TRANSLATE(i8, int8_t, int8_t, CAST_i8)
+DEFINE_TRANSLATE(u8, uint8_t, uint8_t, CAST_u8)
+DEFINE_TRANSLATE(i16, int16_t, int16_t, CAST_i16)
+DEFINE_TRANSLATE(u16, uint16_t, uint16_t, CAST_u16)
+DEFINE_TRANSLATE(i32, int32_t, int32_t, CAST_i32)
+DEFINE_TRANSLATE(u32, uint32_t, uint32_t, CAST_u32)
+DEFINE_TRANSLATE(i64, int64_t, int64_t, CAST_i64)
+DEFINE_TRANSLATE(u64, uint64_t, uint64_t, CAST_u64)
+DEFINE_TRANSLATE(f32, float, float, CAST_f32)
+DEFINE_TRANSLATE(f64, double, double, CAST_f64)
+DEFINE_TRANSLATE(u16_f32, uint16_t, float, CAST_f32) /* IRFileLoader.cpp:624 instantiation */
+
+static int strategy_from_string(const char *s)
+{ /* signal_processing.cpp:20-41 */
+	if (!s || strlen(s) == 0 || strcmp(s, "noborder") == 0)
+		return ORC_UNCHANGED;
+	if (strcmp(s, "background") == 0)
+		return ORC_CONSTANT;
+	if (strcmp(s, "wrap") == 0)
+		return ORC_WRAP;
+	if (strcmp(s, "nearest") == 0)
+		return ORC_NEAREST;
+	return -1;
+}
+
+EXPORT int orc_translate(int type, const void *src, void *dst, int w, int h, float dx, float dy,
+						 const void *background, const char *strategy)
+{
+	int s = strategy_from_string(strategy);
+	if (s < 0)
+		return -1;
+	switch (type)
+	{
+#define CASE(CH, NAME, T)                                                                        \
+	case CH:                                                                                     \
+		translate_##NAME((const T *)src, (T *)dst, *(const T *)background, w, h, dx, dy, s);     \
+		return 0;
+		CASE('?', bool, uint8_t)
+		CASE('b', i8, int8_t)
+		CASE('B', u8, uint8_t)
+		CASE('h', i16, int16_t)
+		CASE('H', u16, uint16_t)
+		CASE('i', i32, int32_t)
+		CASE('I', u32, uint32_t)
+		CASE('l', i64, int64_t)
+		CASE('L', u64, uint64_t)
+		CASE('f', f32, float)
+		CASE('d', f64, double)
+#undef CASE
+	default:
+		return -1;
+	}
+}
+
+/* F6  removeMotionGeneric   reference: src/cpp/video_io/IRFileLoader.cpp:617-627
+ * translate<u16,float>(img, tmp, 0.f, w, h, -x, -y, Nearest) then a truncating float->u16 copy. */
+EXPORT void orc_remove_motion(uint16_t *img, int w, int h, float tx, float ty)
+{
+	float *tmp = (float *)malloc(sizeof(float) * (size_t)w * (size_t)h);
+	translate_u16_f32(img, tmp, 0.f, w, h, -tx, -ty, ORC_NEAREST);
+	for (size_t i = 0; i < (size_t)w * (size_t)h; ++i)
+		img[i] = (uint16_t)(int32_t)tmp[i];
+	free(tmp);
+}
+EXPORT void orc_translate_u16_f32_nearest(const uint16_t *src, float *dst, int w, int h, float dx, float dy)
+{
+	translate_u16_f32(src, dst, 0.f, w, h, dx, dy, ORC_NEAREST);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* F2  gaussian_filter   reference: src/cpp/signal_processing/signal_processing.cpp:79-148     */
+/* ------------------------------------------------------------------------------------------ */
+
+EXPORT int orc_gaussian_radius(float sigma)
+{ /* :103-105 */
+	int radius = (int)(sigma * 2);
+	return radius < 1 ? 1 : radius;
+}
+
+/* :79-99.  float exp of a float argument, divided in double by (pi * s), stored as float;
+ * float running sum in x-outer / y-inner order; float normalisation. */
+EXPORT void orc_gaussian_kernel(float sigma, float *dst, int radius)
+{
+	float s = 2.0f * sigma * sigma;
+	float sum = 0.0f;
+	int kw = radius * 2 + 1;
+	for (int x = -radius; x <= radius; x++)
+		for (int y = -radius; y <= radius; y++)
+		{
+			float r = (float)sqrt((double)(x * x + y * y));
+			float e = expf(-(r * r) / s);
+			float k = (float)((double)e / (3.14159265358979323846 * (double)s));
+			dst[x + radius + (y + radius) * kw] = k;
+			sum += k;
+		}
+	for (int i = 0; i < kw * kw; ++i)
+		dst[i] /= sum;
+}
+
+EXPORT int orc_gaussian_filter(const float *src, float *dst, int w, int h, float sigma)
+{
+	int radius = orc_gaussian_radius(sigma);
+	int kw = radius * 2 + 1;
+	float *kernel = (float *)malloc(sizeof(float) * (size_t)kw * (size_t)kw);
+	orc_gaussian_kernel(sigma, kernel, radius);
+	for (int y = 0; y < h; ++y)
+		for (int x = 0; x < w; ++x)
+		{
+			if (x >= radius && x < w - radius && y >= radius && y < h - radius)
+			{ /* :116-126 interior: dx outer, dy inner, separate multiply and add */
+				float res = 0;
+				for (int dx = -radius; dx <= radius; ++dx)
+					for (int dy = -radius; dy <= radius; ++dy)
+					{
+						float p = kernel[dx + radius + (dy + radius) * kw] * src[x + dx + (y + dy) * w];
+						res = res + p;
+					}
+				dst[x + y * w] = res;
+			}
+			else
+			{ /* :127-145 border: renormalise by the in-image weights */
+				float res = 0, sum = 0;
+				for (int dx = -radius; dx <= radius; ++dx)
+					for (int dy = -radius; dy <= radius; ++dy)
+					{
+						int _x = x + dx, _y = y + dy;
+						if (_x >= 0 && _x < w && _y >= 0 && _y < h)
+						{
+							float k = kernel[dx + radius + (dy + radius) * kw];
+							sum = sum + k;
+							float p = k * src[_x + _y * w];
+							res = res + p;
+						}
+					}
+				dst[x + y * w] = res / sum;
+			}
+		}
+	free(kernel);
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* F7  findMedianPixel / findMedianPixelMask   reference: Filters.cpp:56-101                   */
+/* ------------------------------------------------------------------------------------------ */
+
+#define ORC_HIST_BINS 65535 /* sic: 65 535 bins, value 65535 is out of range (Filters.cpp:59) */
+
+EXPORT int orc_find_median_pixel(const uint16_t *pixels, int size_, float percent)
+{
+	size_t size = (size_t)size_;
+	size_t *hist = (size_t *)calloc(ORC_HIST_BINS + 1, sizeof(size_t));
+	for (size_t i = 0; i < size; ++i)
+		hist[pixels[i]]++;
+	/* size_t * float -> float product, std::round(float) */
+	size_t s = (size_t)roundf((float)size * percent);
+	size_t count = 0;
+	int res = 0;
+	for (size_t i = 0; i < ORC_HIST_BINS; ++i)
+	{
+		count += hist[i];
+		if (count >= s)
+		{
+			res = (int)i;
+			break;
+		}
+	}
+	free(hist);
+	return res;
+}
+
+EXPORT int orc_find_median_pixel_mask(const uint16_t *pixels, const uint8_t *mask, int size_, float percent)
+{
+	size_t size = (size_t)size_;
+	size_t *hist = (size_t *)calloc(ORC_HIST_BINS + 1, sizeof(size_t));
+	size_t c = 0;
+	for (size_t i = 0; i < size; ++i)
+		if (mask[i])
+		{
+			hist[pixels[i]]++;
+			++c;
+		}
+	size_t s = (size_t)(int)roundf((float)c * percent);
+	size_t count = 0;
+	int res = 0;
+	for (size_t i = 0; i < ORC_HIST_BINS; ++i)
+	{
+		count += hist[i];
+		if (count >= s)
+		{
+			res = (int)i;
+			break;
+		}
+	}
+	free(hist);
+	return res;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* F3  badPixels<T> detector   reference: Filters.h:135-193                                    */
+/*     BadPixels::init         reference: BadPixels.cpp:13-32                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+static int cmp_u16(const void *a, const void *b)
+{
+	return (int)*(const uint16_t *)a - (int)*(const uint16_t *)b;
+}
+
+/* (a-b)*(a-b) with the reference's 32-bit int product (wraps for |a-b| > 46340). */
+static inline int32_t sq_i32(int32_t d) { return (int32_t)((uint32_t)d * (uint32_t)d); }
+
+/* Global statistics shared by the detector and BadPixels::init.
+ * floor_detect  = "median_value" after Filters.h:157-160 (T arithmetic, T = unsigned short)
+ * floor_correct = m_median_value after BadPixels.cpp:22-31 (int arithmetic)                  */
+EXPORT void orc_bad_pixels_stats(const uint16_t *src, int w, int h, double std_factor,
+								 int *floor_detect, int *floor_correct)
+{
+	size_t size = (size_t)w * (size_t)h;
+	uint16_t *tmp = (uint16_t *)malloc(size * 2);
+	memcpy(tmp, src, size * 2);
+	qsort(tmp, size, 2, cmp_u16);
+	uint16_t median = tmp[size / 2];
+	double sum = 0;
+	for (size_t i = 0; i < size; ++i)
+		sum += sq_i32((int32_t)tmp[i] - (int32_t)median);
+	free(tmp);
+	sum /= (double)(int)size;
+	sum = sqrt(sum);
+	uint16_t thr = (uint16_t)(int32_t)(sum * std_factor);
+	uint16_t fd = (median > thr) ? (uint16_t)(median - thr) : 0;
+	if (floor_detect)
+		*floor_detect = fd;
+	if (floor_correct)
+		*floor_correct = (int)median - (int)(sum * 2);
+}
+
+EXPORT int orc_bad_pixels_detect(const uint16_t *src, int w, int h, double std_factor, int *xy, int cap)
+{
+	int floor_detect = 0;
+	orc_bad_pixels_stats(src, w, h, std_factor, &floor_detect, NULL);
+	int n = 0;
+	uint16_t pixels[25];
+	for (int y = 0; y < h; ++y)
+		for (int x = 0; x < w; ++x)
+		{
+			int size = 0;
+			for (int dy = y - 2; dy <= y + 2; ++dy)
+				for (int dx = x - 2; dx <= x + 2; ++dx)
+					if (dx >= 0 && dy >= 0 && dx < w && dy < h)
+						pixels[size++] = src[dx + dy * w];
+			qsort(pixels, (size_t)size, 2, cmp_u16);
+			int64_t med = pixels[size / 2];
+			double sum2 = 0;
+			int64_t c = 0;
+			for (int i = size / 5; i < size * 4 / 5; ++i, ++c)
+			{
+				int64_t d = (int64_t)pixels[i] - med;
+				sum2 += (double)(d * d);
+			}
+			sum2 /= (double)c;
+			double sd = sqrt(sum2);
+			double lower = (double)med - std_factor * sd;
+			double upper = (double)med + std_factor * sd;
+			uint16_t v = src[x + y * w];
+			if ((double)v < lower || (double)v > upper || (int)v < floor_detect)
+			{
+				if (n < cap)
+				{
+					xy[2 * n] = x;
+					xy[2 * n + 1] = y;
+				}
+				++n;
+			}
+		}
+	return n;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* F4  BadPixels::correct + clampMin   reference: BadPixels.cpp:34-66, Filters.cpp:7-50        */
+/* ------------------------------------------------------------------------------------------ */
+
+/* element that std::nth_element(p, p + c/2, p + c) leaves at index c/2 */
+static uint16_t upper_median(uint16_t *p, int c)
+{
+	qsort(p, (size_t)c, 2, cmp_u16);
+	return p[c / 2];
+}
+
+EXPORT void orc_bad_pixels_correct(const uint16_t *in, uint16_t *out, int w, int h, const int *xy,
+								   int n, int floor_correct)
+{
+	uint16_t pixels[9];
+	if (in != out)
+		memcpy(out, in, (size_t)w * (size_t)h * 2);
+	for (int i = 0; i < n; ++i)
+	{
+		int x = xy[2 * i], y = xy[2 * i + 1];
+		int c = 0;
+		for (int dx = x - 1; dx <= x + 1; ++dx)
+			for (int dy = y - 1; dy <= y + 1; ++dy)
+				if (dx >= 0 && dy >= 0 && dx < w && dy < h)
+					pixels[c++] = in[dx + dy * w];
+		out[x + y * w] = upper_median(pixels, c);
+	}
+	if (floor_correct > 0)
+	{
+		uint16_t mv = (uint16_t)floor_correct;
+		for (size_t i = 0; i < (size_t)w * (size_t)h; ++i)
+			if (out[i] < mv)
+				out[i] = mv;
+	}
+}
+
+EXPORT void orc_clamp_min(uint16_t *img, int size, uint16_t mv)
+{
+	for (int i = 0; i < size; ++i)
+		if (img[i] < mv)
+			img[i] = mv;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* F5  IRFileLoader::removeBadPixels (read-back variant)  reference: IRFileLoader.cpp:722-802  */
+/*     in place on w x h (caller passes H-3), flagged neighbours excluded, window shifted      */
+/*     inward at the borders.  `bitmap` is w*h bytes, non-zero = flagged (:704-710).           */
+/*     Deviation (documented): when all 9 window pixels are flagged the reference reads an     */
+/*     uninitialised stack slot (:792-794); here the pixel is left unchanged.                  */
+/* ------------------------------------------------------------------------------------------ */
+EXPORT void orc_remove_bad_pixels(uint16_t *img, int w, int h, const int *xy, int n, const uint8_t *bitmap)
+{
+	uint16_t pixels[9];
+	if (w < 3 || h < 3)
+	{
+		for (int i = 0; i < n; ++i)
+		{
+			int x = xy[2 * i], y = xy[2 * i + 1];
+			int c = 0;
+			for (int dx = x - 1; dx <= x + 1; ++dx)
+				for (int dy = y - 1; dy <= y + 1; ++dy)
+					if (dx >= 0 && dy >= 0 && dx < w && dy < h)
+						pixels[c++] = img[dx + dy * w];
+			img[x + y * w] = upper_median(pixels, c);
+		}
+		return;
+	}
+	for (int i = 0; i < n; ++i)
+	{
+		int x = xy[2 * i], y = xy[2 * i + 1];
+		int dx_st = x - 1, dx_en = x + 1, dy_st = y - 1, dy_en = y + 1;
+		if (x == 0)
+		{
+			dx_st = 0;
+			dx_en = 2;
+		}
+		else if (x == w - 1)
+		{
+			dx_st = w - 3;
+			dx_en = w - 1;
+		}
+		if (y == 0)
+		{
+			dy_st = 0;
+			dy_en = 2;
+		}
+		else if (y == h - 1)
+		{
+			dy_st = h - 3;
+			dy_en = h - 1;
+		}
+		int c = 0;
+		for (int dx = dx_st; dx <= dx_en; ++dx)
+			for (int dy = dy_st; dy <= dy_en; ++dy)
+				if (!bitmap[dx + dy * w])
+					pixels[c++] = img[dx + dy * w];
+		if (c > 0)
+			img[x + y * w] = upper_median(pixels, c);
+	}
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* F8  medianFilter<T,U> 3x3   reference: Filters.h:71-129                                     */
+/* ------------------------------------------------------------------------------------------ */
+static inline uint16_t med3(uint16_t a, uint16_t b, uint16_t c)
+{
+	uint16_t lo = a < b ? a : b, hi = a < b ? b : a;
+	return c < lo ? lo : (c > hi ? hi : c);
+}
+EXPORT void orc_median_filter_u16(const uint16_t *src, uint16_t *out, int w, int h)
+{
+	const uint16_t *s;
+	uint16_t *o;
+	int rows[2] = {0, h - 1};
+	for (int k = 0; k < 2; ++k)
+	{ /* first and last row: min of 2 at the corners, median of 3 along the edge */
+		s = src + (size_t)rows[k] * w;
+		o = out + (size_t)rows[k] * w;
+		o[0] = s[0] < s[1] ? s[0] : s[1];
+		o[w - 1] = s[w - 2] < s[w - 1] ? s[w - 2] : s[w - 1];
+		for (int i = 1; i < w - 1; ++i)
+			o[i] = med3(s[i - 1], s[i], s[i + 1]);
+	}
+	for (int y = 1; y < h - 1; ++y)
+	{
+		out[(size_t)y * w] = med3(src[(size_t)(y - 1) * w], src[(size_t)y * w], src[(size_t)(y + 1) * w]);
+		out[(size_t)y * w + w - 1] = med3(src[(size_t)(y - 1) * w + w - 1], src[(size_t)y * w + w - 1], src[(size_t)(y + 1) * w + w - 1]);
+	}
+	for (int y = 1; y < h - 1; ++y)
+		for (int x = 1; x < w - 1; ++x)
+		{
+			uint16_t t[9];
+			int c = 0;
+			for (int yy = y - 1; yy <= y + 1; ++yy)
+				for (int xx = x - 1; xx <= x + 1; ++xx)
+					t[c++] = src[xx + (size_t)yy * w];
+			qsort(t, 9, 2, cmp_u16);
+			out[x + (size_t)y * w] = t[4];
+		}
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* C1/C2  byte-plane split / merge   reference: h264.cpp:1066-1082 and :3016-3051              */
+/*        U = v & 0xFF, V = v >> 8, Y = 0 (or the 8-bit IT image) ;  v = U | (V << 8)          */
+/* ------------------------------------------------------------------------------------------ */
+EXPORT void orc_split_planes(const uint16_t *img, int w, int h, uint8_t *Y, uint8_t *U, uint8_t *V, int linesize, const uint8_t *IT)
+{
+	for (int y = 0; y < h; ++y)
+		for (int x = 0; x < w; ++x)
+		{
+			uint16_t v = img[x + y * w];
+			Y[x + y * linesize] = IT ? IT[x + y * w] : 0;
+			U[x + y * linesize] = (uint8_t)(v & 0xFF);
+			V[x + y * linesize] = (uint8_t)(v >> 8);
+		}
+}
+EXPORT void orc_merge_planes(const uint8_t *Y, const uint8_t *U, const uint8_t *V, int linesize, int w, int h, uint16_t *img, uint8_t *IT)
+{
+	for (int y = 0; y < h; ++y)
+		for (int x = 0; x < w; ++x)
+		{
+			img[x + y * w] = (uint16_t)(U[x + y * linesize] | (V[x + y * linesize] << 8));
+			if (IT)
+				IT[x + y * w] = Y[x + y * linesize];
+		}
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Codec: this build's lossless block format "RIRB1" (DESIGN.md §3), sequential restatement.   */
+/*                                                                                            */
+/*  frame  = W*H uint16 row-major, seen as a flat array, cut in TILES of 512 consecutive       */
+/*           pixels (the last tile is zero-padded);  lane l of a tile holds pixels 8l..8l+7.   */
+/*  chunk  = up to G consecutive frames; frame 0 of a chunk is a key frame.                    */
+/*  record = one (tile, frame):  64-bit header word + payload words.                           */
+/*           residual z[i]:  mode 0 RAW      z = p                                             */
+/*                           mode 1 TEMPORAL z = zigzag16(p - p_prev_frame)                    */
+/*                           mode 2 LEFT     z = zigzag16(p[i] - p[i-1]), p[-1] = 0 per tile   */
+/*           block j (j = 0..7) = the 64 residuals z[8l + j], l = 0..63; width w_j = bit       */
+/*           length of their OR (0..16).  header byte j = w_j, mode in bits 5..6 of byte 0.    */
+/*           payload: for j = 0..7, for b = 0..w_j-1: one 64-bit word, bit l = bit b of        */
+/*           z[8l + j]  (exactly what a wavefront __ballot produces).                          */
+/*           A record whose residuals are all zero in the frame's default mode (key: RAW,      */
+/*           other: TEMPORAL) is elided: size 0, no header.                                    */
+/*  sizes  = uint8 [tile][G]  record length in words (0..129)                                  */
+/*  stream = per chunk, tiles in order, each tile's records in frame order (a "segment");      */
+/*           tile_off[t] = first word of segment t (exclusive scan), uint32, ntiles+1 entries. */
+/*  Key-frame mode choice: LEFT if strictly smaller than RAW, else RAW.                        */
+/* ------------------------------------------------------------------------------------------ */
+
+#define TILE_PX 512
+#define MODE_RAW 0
+#define MODE_TEMPORAL 1
+#define MODE_LEFT 2
+
+static inline uint16_t zigzag16(uint16_t d) { return (uint16_t)((uint16_t)(d << 1) ^ (uint16_t)(((int16_t)d) >> 15)); }
+static inline uint16_t unzigzag16(uint16_t z) { return (uint16_t)((z >> 1) ^ (uint16_t)(-(int16_t)(z & 1))); }
+static inline int bitlen16(uint16_t v)
+{
+	int n = 0;
+	while (v)
+	{
+		++n;
+		v >>= 1;
+	}
+	return n;
+}
+
+EXPORT int orc_codec_ntiles(int w, int h) { return (int)(((int64_t)w * h + TILE_PX - 1) / TILE_PX); }
+/* worst-case words of one chunk's stream */
+EXPORT int64_t orc_codec_max_words(int w, int h, int nframes) { return (int64_t)orc_codec_ntiles(w, h) * nframes * 129; }
+
+static int record_words(const uint16_t *z, int *widths)
+{
+	int total = 0;
+	for (int j = 0; j < 8; ++j)
+	{
+		uint16_t o = 0;
+		for (int l = 0; l < 64; ++l)
+			o |= z[8 * l + j];
+		widths[j] = bitlen16(o);
+		total += widths[j];
+	}
+	return total;
+}
+
+static int emit_record(const uint16_t *z, const int *widths, int mode, uint64_t *out)
+{
+	uint64_t hdr = 0;
+	for (int j = 0; j < 8; ++j)
+		hdr |= (uint64_t)widths[j] << (8 * j);
+	hdr |= (uint64_t)mode << 5;
+	int k = 0;
+	out[k++] = hdr;
+	for (int j = 0; j < 8; ++j)
+		for (int b = 0; b < widths[j]; ++b)
+		{
+			uint64_t m = 0;
+			for (int l = 0; l < 64; ++l)
+				m |= (uint64_t)((z[8 * l + j] >> b) & 1) << l;
+			out[k++] = m;
+		}
+	return k;
+}
+
+/* Encode one chunk of `nframes` frames.  sizes: uint8[ntiles*nframes] ([tile][frame]);
+ * tile_off: uint32[ntiles+1]; stream: >= orc_codec_max_words words.  Returns total words. */
+EXPORT int64_t orc_codec_encode_chunk(const uint16_t *frames, int w, int h, int nframes,
+									  uint8_t *sizes, uint32_t *tile_off, uint64_t *stream)
+{
+	const int64_t npx = (int64_t)w * h;
+	const int ntiles = orc_codec_ntiles(w, h);
+	int64_t pos = 0;
+	uint16_t cur[TILE_PX], prev[TILE_PX], z[TILE_PX], zl[TILE_PX];
+	int widths[8], widths_l[8];
+	for (int t = 0; t < ntiles; ++t)
+	{
+		tile_off[t] = (uint32_t)pos;
+		memset(prev, 0, sizeof(prev));
+		for (int f = 0; f < nframes; ++f)
+		{
+			for (int i = 0; i < TILE_PX; ++i)
+			{
+				int64_t p = (int64_t)t * TILE_PX + i;
+				cur[i] = p < npx ? frames[(int64_t)f * npx + p] : 0;
+			}
+			int mode, total;
+			if (f == 0)
+			{
+				for (int i = 0; i < TILE_PX; ++i)
+				{
+					z[i] = cur[i];
+					zl[i] = zigzag16((uint16_t)(cur[i] - (i ? cur[i - 1] : 0)));
+				}
+				total = record_words(z, widths);
+				int total_l = record_words(zl, widths_l);
+				mode = MODE_RAW;
+				if (total_l < total)
+				{
+					mode = MODE_LEFT;
+					total = total_l;
+					memcpy(z, zl, sizeof(z));
+					memcpy(widths, widths_l, sizeof(widths));
+				}
+			}
+			else
+			{
+				for (int i = 0; i < TILE_PX; ++i)
+					z[i] = zigzag16((uint16_t)(cur[i] - prev[i]));
+				total = record_words(z, widths);
+				mode = MODE_TEMPORAL;
+			}
+			int words = 0;
+			if (total > 0)
+				words = emit_record(z, widths, mode, stream + pos);
+			sizes[(int64_t)t * nframes + f] = (uint8_t)words;
+			pos += words;
+			memcpy(prev, cur, sizeof(prev));
+		}
+	}
+	tile_off[ntiles] = (uint32_t)pos;
+	return pos;
+}
+
+/* Decode one chunk.  Returns 0, or -1 on a malformed record. */
+EXPORT int orc_codec_decode_chunk(const uint8_t *sizes, const uint32_t *tile_off, const uint64_t *stream,
+								  int w, int h, int nframes, uint16_t *frames)
+{
+	const int64_t npx = (int64_t)w * h;
+	const int ntiles = orc_codec_ntiles(w, h);
+	uint16_t cur[TILE_PX], prev[TILE_PX], z[TILE_PX];
+	for (int t = 0; t < ntiles; ++t)
+	{
+		int64_t pos = tile_off[t];
+		memset(prev, 0, sizeof(prev));
+		for (int f = 0; f < nframes; ++f)
+		{
+			int words = sizes[(int64_t)t * nframes + f];
+			int mode = f == 0 ? MODE_RAW : MODE_TEMPORAL;
+			memset(z, 0, sizeof(z));
+			if (words)
+			{
+				uint64_t hdr = stream[pos];
+				mode = (int)((hdr >> 5) & 3);
+				int k = 1;
+				for (int j = 0; j < 8; ++j)
+				{
+					int wj = (int)((hdr >> (8 * j)) & 31);
+					if (wj > 16 || k + wj > words)
+						return -1;
+					for (int b = 0; b < wj; ++b)
+					{
+						uint64_t m = stream[pos + k++];
+						for (int l = 0; l < 64; ++l)
+							z[8 * l + j] |= (uint16_t)(((m >> l) & 1) << b);
+					}
+				}
+				if (k != words)
+					return -1;
+			}
+			if (mode == MODE_RAW)
+				memcpy(cur, z, sizeof(cur));
+			else if (mode == MODE_TEMPORAL)
+				for (int i = 0; i < TILE_PX; ++i)
+					cur[i] = (uint16_t)(prev[i] + unzigzag16(z[i]));
+			else if (mode == MODE_LEFT)
+			{
+				uint16_t acc = 0;
+				for (int i = 0; i < TILE_PX; ++i)
+				{
+					acc = (uint16_t)(acc + unzigzag16(z[i]));
+					cur[i] = acc;
+				}
+			}
+			else
+				return -1;
+			for (int i = 0; i < TILE_PX; ++i)
+			{
+				int64_t p = (int64_t)t * TILE_PX + i;
+				if (p < npx)
+					frames[(int64_t)f * npx + p] = cur[i];
+			}
+			memcpy(prev, cur, sizeof(prev));
+			pos += words;
+		}
+	}
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* C5  ZFile method 1 equivalent (CPU baseline only): one-shot zstd per raw frame is timed by  */
+/*     bench.py through dlopen("libzstd.so.1"); nothing to restate here (third-party).         */
+/* ------------------------------------------------------------------------------------------ */
