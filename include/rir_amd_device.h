@@ -1,0 +1,94 @@
+/* librir_amd — device-resident batch entry points (extension of the librir C ABI).
+ *
+ * The reference ABI moves one frame per call through host pointers (reference
+ * src/cpp/video_io/video_io.h:102,259 and src/cpp/signal_processing/signal_processing.h:29-88).
+ * These entry points are the same operations on batches that already live in HBM, laid out
+ * [n][h][w] row-major, asynchronous on a caller-supplied HIP stream (`stream` is a hipStream_t
+ * passed as void*; NULL = HIP's null stream).  The per-frame reference entry points in
+ * rir_amd_signal_processing.h / rir_amd_video_io.h are thin wrappers over these.
+ *
+ * All functions return 0 on success and -1 on error (reason via get_last_log_error) unless
+ * stated otherwise.  No function falls back to the CPU: without a HIP device they fail.
+ */
+#ifndef RIR_AMD_DEVICE_H
+#define RIR_AMD_DEVICE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C"
+{
+#endif
+
+	/* 1 when a HIP device is visible, else 0 (never logs). */
+	int rir_device_available(void);
+	int rir_stream_synchronize(void *stream);
+
+	/* ---- block codec (format RIRB1) ----------------------------------------------------------
+	 * Replaces, for device-resident batches, the encode/decode the reference delegates to
+	 * libx264 (reference src/cpp/video_io/h264.cpp:1022-1131 AddFrame, :3096-3229 GetFrame).
+	 * A batch of nframes frames is cut in chunks of `gop` frames (key frame first, reference
+	 * cadence h264.cpp:1052-1064); chunks and 512-pixel tiles are independent units. */
+	typedef struct rir_codec_layout
+	{
+		int width, height, nframes, gop;
+		int ntiles;				  /* ceil(width*height / 512) */
+		int nchunks;			  /* ceil(nframes / gop) */
+		int64_t sizes_bytes;	  /* uint8  [nchunks][ntiles][gop]   record lengths in words */
+		int64_t tile_off_bytes;	  /* uint32 [nchunks][ntiles+1]      first word of a tile segment */
+		int64_t chunk_off_bytes;  /* uint64 [nchunks+1]              first word of a chunk; last = total */
+		int64_t stream_max_bytes; /* worst-case size of the compact stream */
+		int64_t workspace_bytes;  /* scratch needed by rir_codec_encode_device */
+	} rir_codec_layout;
+
+	int rir_codec_layout_query(int width, int height, int nframes, int gop, rir_codec_layout *out);
+
+	/* d_frames: uint16 [nframes][height][width].  Outputs sized per rir_codec_layout. */
+	int rir_codec_encode_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned char *d_sizes,
+								unsigned int *d_tile_off, unsigned long long *d_chunk_off, unsigned long long *d_stream, void *d_workspace,
+								long long workspace_bytes, void *stream);
+
+	/* *d_error (device int, zero it first) becomes 1 when a malformed table/record was met. */
+	int rir_codec_decode_device(const unsigned char *d_sizes, const unsigned int *d_tile_off, const unsigned long long *d_chunk_off,
+								const unsigned long long *d_stream, int width, int height, int nframes, int gop, unsigned short *d_frames,
+								int *d_error, void *stream);
+
+	/* ---- frame-buffer kernels -------------------------------------------------------------------
+	 * translate: reference signal_processing.h:29 / Filters.h:249-326.  `type` is the numpy
+	 * dtype char ('?','b','B','h','H','i','I','l','L','f','d'); d_offsets holds float (dx,dy)
+	 * pairs - one pair per frame when per_frame_offsets != 0, else a single pair; background
+	 * is a HOST pointer to one element; d_dst must be pre-filled by the caller (strategy
+	 * "noborder" leaves border pixels as they are). */
+	int rir_translate_device(int type, const void *d_src, void *d_dst, int w, int h, int nframes, const float *d_offsets, int per_frame_offsets,
+							 const void *background, const char *strategy, void *stream);
+
+	/* gaussian_filter: reference signal_processing.h:33 / signal_processing.cpp:79-148. */
+	int rir_gaussian_filter_device(const float *d_src, float *d_dst, int w, int h, int nframes, float sigma, void *stream);
+
+	/* find_median_pixel[_mask]: reference signal_processing.h:39-44 / Filters.cpp:56-101.
+	 * d_result: int32[nframes]; d_hist: uint32[nframes*65536] workspace; d_mask may be NULL. */
+	int rir_find_median_pixel_device(const unsigned short *d_img, const unsigned char *d_mask, int size, int nframes, float percent, int *d_result,
+									 unsigned int *d_hist, void *stream);
+
+	/* bad pixels: reference signal_processing.h:80-88 / BadPixels.cpp:13-66.  The handle returned
+	 * by the *_create_* functions is in the same int namespace as every other librir object and
+	 * is released with bad_pixels_destroy().  Returns 0 on error. */
+	int rir_bad_pixels_create_device(const unsigned short *d_first_image, int width, int height, void *stream);
+	int rir_bad_pixels_correct_device(int handle, const unsigned short *d_in, unsigned short *d_out, int nframes, void *stream);
+	int rir_bad_pixels_info(int handle, int *info3, int *xy, int cap);
+
+	/* read-back path of the loader: reference IRFileLoader.cpp:693-716 (detector on the first
+	 * `rows` rows), :722-802 (in-place repair), :617-627 (motion removal, d_shifts = (x,y) float
+	 * pairs per frame; d_dst != d_src). */
+	int rir_bad_pixels_create_rows_device(const unsigned short *d_first_image, int width, int height, int rows, void *stream);
+	int rir_remove_bad_pixels_device(int handle, unsigned short *d_img, int rows, int nframes, void *stream);
+	int rir_remove_motion_device(const unsigned short *d_src, unsigned short *d_dst, int w, int h, int rows, int nframes, const float *d_shifts,
+								 void *stream);
+
+	/* 3x3 median filter: reference Filters.h:71-129 (template without C export upstream). */
+	int rir_median_filter_device(const unsigned short *d_src, unsigned short *d_dst, int w, int h, int nframes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIR_AMD_DEVICE_H */

@@ -1,0 +1,96 @@
+// C ABI of the block codec on device-resident batches (format RIRB1).
+// Host-pointer / file-level entry points (h264_add_image_lossless, load_image, ...) are in
+// video_io_abi.cpp and call these.
+#include <cstring>
+
+#include "codec_format.h"
+#include "filter_kernels.h"
+#include "rir_amd_device.h"
+#include "runtime.h"
+
+using namespace rir;
+
+namespace
+{
+	// the caller's stream, taken literally: NULL is HIP's null (legacy default) stream
+	hipStream_t as_stream(void *s) { return (hipStream_t)s; }
+	size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+} // namespace
+
+RIR_EXPORT int rir_codec_layout_query(int width, int height, int nframes, int gop, rir_codec_layout *out)
+{
+	if (!out || width <= 0 || height <= 0 || nframes <= 0 || gop <= 0)
+	{
+		log_error("rir_codec_layout_query: invalid argument");
+		return -1;
+	}
+	std::memset(out, 0, sizeof(*out));
+	const int64_t npx = (int64_t)width * height;
+	out->width = width;
+	out->height = height;
+	out->nframes = nframes;
+	out->gop = gop;
+	out->ntiles = (int)((npx + RIRB1_TILE_PX - 1) / RIRB1_TILE_PX);
+	out->nchunks = (nframes + gop - 1) / gop;
+	const int64_t slots = (int64_t)out->nchunks * out->ntiles;
+	out->sizes_bytes = slots * gop;
+	out->tile_off_bytes = (int64_t)out->nchunks * (out->ntiles + 1) * 4;
+	out->chunk_off_bytes = (int64_t)(out->nchunks + 1) * 8;
+	out->stream_max_bytes = slots * gop * RIRB1_REC_MAX_WORDS * 8;
+	// workspace = sparse slots + seg_words + chunk_words
+	out->workspace_bytes = (int64_t)(align256((size_t)out->stream_max_bytes) + align256((size_t)slots * 4) + align256((size_t)out->nchunks * 8));
+	return 0;
+}
+
+RIR_EXPORT int rir_codec_encode_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned char *d_sizes,
+									   unsigned int *d_tile_off, unsigned long long *d_chunk_off, unsigned long long *d_stream,
+									   void *d_workspace, long long workspace_bytes, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	rir_codec_layout L;
+	if (rir_codec_layout_query(width, height, nframes, gop, &L) != 0)
+		return -1;
+	if (!d_frames || !d_sizes || !d_tile_off || !d_chunk_off || !d_stream || !d_workspace || workspace_bytes < L.workspace_bytes)
+	{
+		log_error("rir_codec_encode_device: null buffer or workspace too small");
+		return -1;
+	}
+	if ((int64_t)L.ntiles * gop * RIRB1_REC_MAX_WORDS > 0xffffffffLL)
+	{
+		log_error("rir_codec_encode_device: chunk too large for 32-bit tile offsets");
+		return -1;
+	}
+	char *ws = static_cast<char *>(d_workspace);
+	uint64_t *d_sparse = reinterpret_cast<uint64_t *>(ws);
+	ws += align256((size_t)L.stream_max_bytes);
+	uint32_t *d_seg_words = reinterpret_cast<uint32_t *>(ws);
+	ws += align256((size_t)L.nchunks * L.ntiles * 4);
+	uint64_t *d_chunk_words = reinterpret_cast<uint64_t *>(ws);
+	return hip_ok(launch_encode(d_frames, (int64_t)width * height, L.ntiles, nframes, gop, d_sizes, d_seg_words, d_sparse, d_tile_off, d_chunk_words,
+								reinterpret_cast<uint64_t *>(d_chunk_off), reinterpret_cast<uint64_t *>(d_stream), as_stream(stream)),
+				  "codec encode")
+			   ? 0
+			   : -1;
+}
+
+RIR_EXPORT int rir_codec_decode_device(const unsigned char *d_sizes, const unsigned int *d_tile_off, const unsigned long long *d_chunk_off,
+									   const unsigned long long *d_stream, int width, int height, int nframes, int gop,
+									   unsigned short *d_frames, int *d_error, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	rir_codec_layout L;
+	if (rir_codec_layout_query(width, height, nframes, gop, &L) != 0)
+		return -1;
+	if (!d_frames || !d_sizes || !d_tile_off || !d_chunk_off || !d_stream || !d_error)
+	{
+		log_error("rir_codec_decode_device: null buffer");
+		return -1;
+	}
+	return hip_ok(launch_decode(d_sizes, d_tile_off, reinterpret_cast<const uint64_t *>(d_chunk_off), reinterpret_cast<const uint64_t *>(d_stream),
+								(int64_t)width * height, L.ntiles, nframes, gop, d_frames, d_error, as_stream(stream)),
+				  "codec decode")
+			   ? 0
+			   : -1;
+}

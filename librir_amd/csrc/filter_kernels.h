@@ -1,0 +1,38 @@
+// Host-side launchers of the frame-buffer kernels (filter_kernels.hip).  C++ linkage, internal.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rir
+{
+	enum
+	{
+		TRANSLATE_UNCHANGED = 0, // reference TranslateUnchanged, Filters.h:238-244
+		TRANSLATE_CONSTANT = 1,
+		TRANSLATE_WRAP = 2,
+		TRANSLATE_NEAREST = 3
+	};
+
+	hipError_t launch_translate(int type, const void *src, void *dst, const void *background, int w, int h, int nframes, const float *d_offsets,
+								int per_frame, int strategy, hipStream_t st);
+	hipError_t launch_remove_motion(const uint16_t *src, uint16_t *dst, int w, int h, int rows, int nframes, const float *d_shifts, hipStream_t st);
+	hipError_t launch_gaussian(const float *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st);
+	hipError_t launch_bad_pixels_correct(const uint16_t *in, uint16_t *out, int w, int h, int nframes, const int *d_xy, int nbad, int floor_v,
+										 hipStream_t st);
+	hipError_t launch_remove_bad_pixels(uint16_t *img, int w, int h, int rows, int nframes, const int *d_xy, int nbad, const uint8_t *d_bitmap,
+										hipStream_t st);
+	hipError_t launch_histogram(const uint16_t *img, const uint8_t *mask, int64_t npx, int nframes, uint32_t *d_hist, hipStream_t st);
+	hipError_t launch_quantile_scan(const uint32_t *d_hist, uint64_t size, float percent, int masked, int nbins, int nframes, int *d_result,
+									hipStream_t st);
+	hipError_t launch_bad_pixels_stats(const uint32_t *d_hist, uint64_t size, int64_t *d_out, hipStream_t st);
+	hipError_t launch_bad_pixels_detect(const uint16_t *src, int w, int h, double std_factor, int floor_detect, uint8_t *d_flags, hipStream_t st);
+	hipError_t launch_median3x3(const uint16_t *src, uint16_t *dst, int w, int h, int nframes, hipStream_t st);
+	hipError_t launch_u16_to_f32(const uint16_t *src, float *dst, int64_t total, hipStream_t st);
+
+	// codec_kernels.hip
+	hipError_t launch_encode(const uint16_t *d_frames, int64_t npx, int ntiles, int nframes, int gop, uint8_t *d_sizes, uint32_t *d_seg_words,
+							 uint64_t *d_sparse, uint32_t *d_tile_off, uint64_t *d_chunk_words, uint64_t *d_chunk_off, uint64_t *d_stream,
+							 hipStream_t st);
+	hipError_t launch_decode(const uint8_t *d_sizes, const uint32_t *d_tile_off, const uint64_t *d_chunk_off, const uint64_t *d_stream,
+							 int64_t npx, int ntiles, int nframes, int gop, uint16_t *d_frames, int *d_error, hipStream_t st);
+} // namespace rir

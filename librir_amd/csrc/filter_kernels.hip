@@ -1,0 +1,735 @@
+// Frame-buffer image kernels of the librir hot path — gfx950 (CDNA4).
+//
+// Each kernel is batched over N independent frames laid out [n][h][w] row-major (index = x + y*w,
+// the reference layout) and reproduces the reference arithmetic exactly: integer results are
+// bit-exact, float results are computed with the same operation order, separate multiply and add
+// (this file is compiled with -ffp-contract=off; the reference x86-64 build has no FMA).
+//
+//   translate          reference src/cpp/signal_processing/Filters.h:249-326
+//   gaussian_filter    reference src/cpp/signal_processing/signal_processing.cpp:101-148
+//   bad pixel detector reference src/cpp/signal_processing/Filters.h:135-193
+//   bad pixel correct  reference src/cpp/signal_processing/BadPixels.cpp:34-66, Filters.cpp:7-50
+//   read-back repair   reference src/cpp/video_io/IRFileLoader.cpp:722-802
+//   motion removal     reference src/cpp/video_io/IRFileLoader.cpp:617-627
+//   quantile           reference src/cpp/signal_processing/Filters.cpp:56-101
+//   3x3 median filter  reference src/cpp/signal_processing/Filters.h:71-129
+//
+// All of them are HBM-bound byte/integer work: loads and stores are coalesced
+// along x, no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "filter_kernels.h"
+
+namespace rir
+{
+
+	// ---- translate ------------------------------------------------------------------------------
+
+	template <class U>
+	struct CastTo
+	{
+		// in-range values: truncation toward zero like static_cast on the host
+		__device__ static U from(double v) { return static_cast<U>(v); }
+	};
+	template <>
+	struct CastTo<bool>
+	{
+		__device__ static bool from(double v) { return v != 0; }
+	};
+	// sub-int integer types convert through int32 on the host (cvttsd2si + truncation)
+	template <>
+	struct CastTo<int8_t>
+	{
+		__device__ static int8_t from(double v) { return (int8_t)(int32_t)v; }
+	};
+	template <>
+	struct CastTo<uint8_t>
+	{
+		__device__ static uint8_t from(double v) { return (uint8_t)(int32_t)v; }
+	};
+	template <>
+	struct CastTo<int16_t>
+	{
+		__device__ static int16_t from(double v) { return (int16_t)(int32_t)v; }
+	};
+	template <>
+	struct CastTo<uint16_t>
+	{
+		__device__ static uint16_t from(double v) { return (uint16_t)(int32_t)v; }
+	};
+	template <>
+	struct CastTo<uint32_t>
+	{
+		__device__ static uint32_t from(double v) { return (uint32_t)(int64_t)v; }
+	};
+
+	__device__ __forceinline__ uint64_t f2sz(float v) { return (uint64_t)(int64_t)v; }
+	__device__ __forceinline__ uint64_t wrap_sz(uint64_t value, uint64_t max) { return (value + max) % max; }
+
+	// One thread per output pixel; x is the fast index so stores are coalesced, the four taps are
+	// neighbouring reads served by L1/L2.  offsets: per-frame (dx,dy) pairs, or a single pair.
+	template <class T, class U>
+	__global__ __launch_bounds__(256) void translate_kernel(const T *__restrict__ src, U *__restrict__ dst, U background, int w_, int h_,
+															int nframes, const float *__restrict__ offsets, int per_frame_offsets,
+															float sign, int strategy, int rows)
+	{
+		const int x_ = blockIdx.x * blockDim.x + threadIdx.x;
+		const int y = blockIdx.y;
+		const int n = blockIdx.z;
+		if (x_ >= w_ || y >= rows)
+			return;
+		const uint64_t w = (uint64_t)w_, h = (uint64_t)rows, x = (uint64_t)x_;
+		const int64_t fbase = (int64_t)n * w_ * h_;
+		const T *s = src + fbase;
+		U *d = dst + fbase;
+		const float dx = sign * offsets[per_frame_offsets ? 2 * n : 0];
+		const float dy = sign * offsets[per_frame_offsets ? 2 * n + 1 : 1];
+
+		const float px = (float)x - dx;
+		const float py = (float)y - dy;
+		const uint64_t o = x + (uint64_t)y * w;
+		if (px < 0 || px >= (float)w || py < 0 || py >= (float)h)
+		{
+			if (strategy == TRANSLATE_UNCHANGED)
+			{
+			}
+			else if (strategy == TRANSLATE_CONSTANT)
+				d[o] = background;
+			else if (strategy == TRANSLATE_WRAP)
+			{
+				const uint64_t l = wrap_sz(f2sz(px), w), r = wrap_sz(f2sz(px + 1), w);
+				const uint64_t t = wrap_sz(f2sz(py), h), b = wrap_sz(f2sz(py + 1), h);
+				const T p1 = s[b * w + l], p2 = s[t * w + l], p3 = s[b * w + r], p4 = s[t * w + r];
+				const double u = fabsf(px - (float)(int)px);
+				const double v = fabsf(py - (float)(int)py);
+				const double val = ((double)p1 * (1 - v) + (double)p2 * v) * (1 - u) + ((double)p3 * (1 - v) + (double)p4 * v) * u;
+				d[o] = CastTo<U>::from(val);
+			}
+			else
+			{
+				uint64_t _x, _y;
+				if (px < 0)
+					_x = 0;
+				else if (px >= (float)w)
+					_x = w - 1;
+				else
+					_x = f2sz(px);
+				if (py < 0)
+					_y = 0;
+				else if (py >= (float)h)
+					_y = h - 1;
+				else
+					_y = f2sz(py);
+				d[o] = (U)s[_x + _y * w];
+			}
+		}
+		else
+		{
+			const uint64_t l = f2sz(px);
+			uint64_t r = f2sz(px + 1);
+			if (r == w)
+				r = l;
+			const uint64_t t = f2sz(py);
+			uint64_t b = f2sz(py + 1);
+			if (b == h)
+				b = t;
+			const T p1 = s[b * w + l], p2 = s[t * w + l], p3 = s[b * w + r], p4 = s[t * w + r];
+			const double u = (px - (float)l);
+			const double v = ((float)b - py);
+			const double val = ((double)p1 * (1 - v) + (double)p2 * v) * (1 - u) + ((double)p3 * (1 - v) + (double)p4 * v) * u;
+			d[o] = CastTo<U>::from(val);
+		}
+	}
+
+	template <class T, class U>
+	static hipError_t launch_translate_t(const void *src, void *dst, const void *background, int w, int h, int nframes, const float *d_offsets,
+										 int per_frame, float sign, int strategy, int rows, hipStream_t st)
+	{
+		U back = *reinterpret_cast<const U *>(background);
+		dim3 block(256), grid((w + 255) / 256, rows, nframes);
+		hipLaunchKernelGGL((translate_kernel<T, U>), grid, block, 0, st, (const T *)src, (U *)dst, back, w, h, nframes, d_offsets, per_frame, sign,
+						   strategy, rows);
+		return hipGetLastError();
+	}
+
+	hipError_t launch_translate(int type, const void *src, void *dst, const void *background, int w, int h, int nframes, const float *d_offsets,
+								int per_frame, int strategy, hipStream_t st)
+	{
+		switch (type)
+		{
+		case '?':
+			return launch_translate_t<bool, bool>(src, dst, background, w, h, nframes, d_offsets, per_frame, 1.f, strategy, h, st);
+		case 'b':
+			return launch_translate_t<int8_t, int8_t>(src, dst, background, w, h, nframes, d_offsets, per_frame, 1.f, strategy, h, st);
+		case 'B':
+			return launch_translate_t<uint8_t, uint8_t>(src, dst, background, w, h, nframes, d_offsets, per_frame, 1.f, strategy, h, st);
+		case 'h':
+			return launch_translate_t<int16_t, int16_t>(src, dst, background, w, h, nframes, d_offsets, per_frame, 1.f, strategy, h, st);
+		case 'H':
+			return launch_translate_t<uint16_t, uint16_t>(src, dst, background, w, h, nframes, d_offsets, per_frame, 1.f, strategy, h, st);
+		case 'i':
+			return launch_translate_t<int32_t, int32_t>(src, dst, background, w, h, nframes, d_offsets, per_frame, 1.f, strategy, h, st);
+		case 'I':
+			return launch_translate_t<uint32_t, uint32_t>(src, dst, background, w, h, nframes, d_offsets, per_frame, 1.f, strategy, h, st);
+		case 'l':
+			return launch_translate_t<int64_t, int64_t>(src, dst, background, w, h, nframes, d_offsets, per_frame, 1.f, strategy, h, st);
+		case 'L':
+			return launch_translate_t<uint64_t, uint64_t>(src, dst, background, w, h, nframes, d_offsets, per_frame, 1.f, strategy, h, st);
+		case 'f':
+			return launch_translate_t<float, float>(src, dst, background, w, h, nframes, d_offsets, per_frame, 1.f, strategy, h, st);
+		case 'd':
+			return launch_translate_t<double, double>(src, dst, background, w, h, nframes, d_offsets, per_frame, 1.f, strategy, h, st);
+		default:
+			return hipErrorInvalidValue;
+		}
+	}
+
+	// ---- motion removal (read-back) -----------------------------------------------------------
+	// translate<u16 -> float>(img, tmp, 0, w, rows, -x[pos], -y[pos], nearest) then the truncating
+	// float -> u16 copy, fused: the float never leaves registers.  Rows >= `rows` are copied.
+	__global__ __launch_bounds__(256) void remove_motion_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w_, int h_,
+																int rows, const float *__restrict__ shifts)
+	{
+		const int x_ = blockIdx.x * blockDim.x + threadIdx.x;
+		const int y = blockIdx.y;
+		const int n = blockIdx.z;
+		if (x_ >= w_)
+			return;
+		const int64_t fbase = (int64_t)n * w_ * h_;
+		const uint16_t *s = src + fbase;
+		uint16_t *d = dst + fbase;
+		const uint64_t w = (uint64_t)w_, h = (uint64_t)rows, x = (uint64_t)x_;
+		const uint64_t o = x + (uint64_t)y * w;
+		if (y >= rows)
+		{
+			d[o] = s[o];
+			return;
+		}
+		const float dx = -shifts[2 * n], dy = -shifts[2 * n + 1];
+		const float px = (float)x - dx;
+		const float py = (float)y - dy;
+		float val;
+		if (px < 0 || px >= (float)w || py < 0 || py >= (float)h)
+		{
+			uint64_t _x, _y;
+			if (px < 0)
+				_x = 0;
+			else if (px >= (float)w)
+				_x = w - 1;
+			else
+				_x = f2sz(px);
+			if (py < 0)
+				_y = 0;
+			else if (py >= (float)h)
+				_y = h - 1;
+			else
+				_y = f2sz(py);
+			val = (float)s[_x + _y * w];
+		}
+		else
+		{
+			const uint64_t l = f2sz(px);
+			uint64_t r = f2sz(px + 1);
+			if (r == w)
+				r = l;
+			const uint64_t t = f2sz(py);
+			uint64_t b = f2sz(py + 1);
+			if (b == h)
+				b = t;
+			const uint16_t p1 = s[b * w + l], p2 = s[t * w + l], p3 = s[b * w + r], p4 = s[t * w + r];
+			const double u = (px - (float)l);
+			const double v = ((float)b - py);
+			val = (float)(((double)p1 * (1 - v) + (double)p2 * v) * (1 - u) + ((double)p3 * (1 - v) + (double)p4 * v) * u);
+		}
+		d[o] = (uint16_t)(int32_t)val;
+	}
+
+	hipError_t launch_remove_motion(const uint16_t *src, uint16_t *dst, int w, int h, int rows, int nframes, const float *d_shifts, hipStream_t st)
+	{
+		dim3 block(256), grid((w + 255) / 256, h, nframes);
+		hipLaunchKernelGGL(remove_motion_kernel, grid, block, 0, st, src, dst, w, h, rows, d_shifts);
+		return hipGetLastError();
+	}
+
+	// ---- gaussian ------------------------------------------------------------------------------
+	// The (2r+1)^2 table is built on the host with the reference's own float sequence and uploaded.
+	// Accumulation order = dx outer, dy inner, res = res + k*src (two roundings), exactly as the host.
+	__global__ __launch_bounds__(256) void gaussian_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+														   const float *__restrict__ kern, int radius)
+	{
+		const int x = blockIdx.x * blockDim.x + threadIdx.x;
+		const int y = blockIdx.y;
+		const int n = blockIdx.z;
+		if (x >= w)
+			return;
+		const int64_t fbase = (int64_t)n * w * h;
+		const float *s = src + fbase;
+		const int kw = 2 * radius + 1;
+		if (x >= radius && x < w - radius && y >= radius && y < h - radius)
+		{
+			float res = 0;
+			for (int dx = -radius; dx <= radius; ++dx)
+				for (int dy = -radius; dy <= radius; ++dy)
+				{
+					const float p = __fmul_rn(kern[dx + radius + (dy + radius) * kw], s[x + dx + (int64_t)(y + dy) * w]);
+					res = __fadd_rn(res, p);
+				}
+			dst[fbase + x + (int64_t)y * w] = res;
+		}
+		else
+		{
+			float res = 0, sum = 0;
+			for (int dx = -radius; dx <= radius; ++dx)
+				for (int dy = -radius; dy <= radius; ++dy)
+				{
+					const int _x = x + dx, _y = y + dy;
+					if (_x >= 0 && _x < w && _y >= 0 && _y < h)
+					{
+						const float k = kern[dx + radius + (dy + radius) * kw];
+						sum = __fadd_rn(sum, k);
+						res = __fadd_rn(res, __fmul_rn(k, s[_x + (int64_t)_y * w]));
+					}
+				}
+			dst[fbase + x + (int64_t)y * w] = __fdiv_rn(res, sum);
+		}
+	}
+
+	hipError_t launch_gaussian(const float *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st)
+	{
+		dim3 block(256), grid((w + 255) / 256, h, nframes);
+		hipLaunchKernelGGL(gaussian_kernel, grid, block, 0, st, src, dst, w, h, d_kernel, radius);
+		return hipGetLastError();
+	}
+
+	// ---- small sorted-window helpers ---------------------------------------------------------
+
+	// value that std::nth_element(p, p+c/2, p+c) leaves at index c/2: the element of rank c/2
+	// (rank = number of smaller elements, ties broken by index).  c <= 9.
+	__device__ __forceinline__ uint16_t rank_select9(const uint32_t *v, int c)
+	{
+		const int want = c >> 1;
+		uint32_t res = 0;
+#pragma unroll
+		for (int i = 0; i < 9; ++i)
+		{
+			int rank = 0;
+#pragma unroll
+			for (int j = 0; j < 9; ++j)
+				rank += (j < c) && ((v[j] < v[i]) || (v[j] == v[i] && j < i));
+			if (i < c && rank == want)
+				res = v[i];
+		}
+		return (uint16_t)res;
+	}
+
+	// ---- bad pixel correction (BadPixels::correct) ------------------------------------------
+	// pass 1: out = max(in, floor)   (copy + clampMin fused; 16 B per lane)
+	__global__ __launch_bounds__(256) void clamp_copy_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, int64_t total, uint32_t floor_v)
+	{
+		const int64_t i8 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+		if (i8 >= total)
+			return;
+		const uint32_t f2 = floor_v | (floor_v << 16);
+		if (i8 + 8 <= total && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0)
+		{
+			uint4 v = *reinterpret_cast<const uint4 *>(in + i8);
+			uint32_t *p = reinterpret_cast<uint32_t *>(&v);
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+			{
+				const uint32_t lo = max(p[k] & 0xffffu, f2 & 0xffffu), hi = max(p[k] >> 16, f2 >> 16);
+				p[k] = lo | (hi << 16);
+			}
+			*reinterpret_cast<uint4 *>(out + i8) = v;
+		}
+		else
+		{
+			for (int64_t i = i8; i < total && i < i8 + 8; ++i)
+				out[i] = (uint16_t)max((uint32_t)in[i], floor_v);
+		}
+	}
+
+	// pass 2: one thread per (flagged pixel, frame): upper median of the in-bounds 3x3 (centre
+	// included, gathered from `in`), then the clamp.  xy = int32 pairs.
+	__global__ __launch_bounds__(64) void bad_pixels_fix_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, int w, int h,
+																const int *__restrict__ xy, int nbad, uint32_t floor_v)
+	{
+		const int i = blockIdx.x * blockDim.x + threadIdx.x;
+		const int n = blockIdx.y;
+		if (i >= nbad)
+			return;
+		const int64_t fbase = (int64_t)n * w * h;
+		const int x = xy[2 * i], y = xy[2 * i + 1];
+		uint32_t v[9];
+		int c = 0;
+#pragma unroll
+		for (int ddx = -1; ddx <= 1; ++ddx)
+#pragma unroll
+			for (int ddy = -1; ddy <= 1; ++ddy)
+			{
+				const int xx = x + ddx, yy = y + ddy;
+				const bool ok = xx >= 0 && yy >= 0 && xx < w && yy < h;
+				const uint32_t val = ok ? in[fbase + xx + (int64_t)yy * w] : 0u;
+				// compact the in-bounds values to the front, keeping gather order
+#pragma unroll
+				for (int k = 0; k < 9; ++k)
+					if (ok && k == c)
+						v[k] = val;
+				c += ok;
+			}
+#pragma unroll
+		for (int k = 0; k < 9; ++k)
+			if (k >= c)
+				v[k] = 0xffffffffu;
+		const uint32_t m = rank_select9(v, c);
+		out[fbase + x + (int64_t)y * w] = (uint16_t)max(m, floor_v);
+	}
+
+	hipError_t launch_bad_pixels_correct(const uint16_t *in, uint16_t *out, int w, int h, int nframes, const int *d_xy, int nbad, int floor_v,
+										 hipStream_t st)
+	{
+		const uint32_t fl = floor_v > 0 ? (uint32_t)(uint16_t)floor_v : 0u;
+		const int64_t total = (int64_t)w * h * nframes;
+		if (in != out || fl > 0)
+		{
+			const int64_t threads = (total + 7) / 8;
+			hipLaunchKernelGGL(clamp_copy_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, in, out, total, fl);
+		}
+		if (nbad > 0)
+			hipLaunchKernelGGL(bad_pixels_fix_kernel, dim3((nbad + 63) / 64, nframes), dim3(64), 0, st, in, out, w, h, d_xy, nbad, fl);
+		return hipGetLastError();
+	}
+
+	// ---- read-back repair (IRFileLoader::removeBadPixels) ---------------------------------------
+	// in place; window shifted inward at the borders, flagged neighbours excluded through the
+	// bitmap, so no flagged pixel is ever read: the in-place update has no ordering dependence.
+	__global__ __launch_bounds__(64) void remove_bad_pixels_kernel(uint16_t *__restrict__ img, int w, int h, int rows, const int *__restrict__ xy,
+																   int nbad, const uint8_t *__restrict__ bitmap)
+	{
+		const int i = blockIdx.x * blockDim.x + threadIdx.x;
+		const int n = blockIdx.y;
+		if (i >= nbad)
+			return;
+		uint16_t *f = img + (int64_t)n * w * h;
+		const int x = xy[2 * i], y = xy[2 * i + 1];
+		uint32_t v[9];
+		int c = 0;
+		const bool small = (w < 3 || rows < 3);
+		int dx_st = x - 1, dy_st = y - 1;
+		if (!small)
+		{
+			if (x == 0)
+				dx_st = 0;
+			else if (x == w - 1)
+				dx_st = w - 3;
+			if (y == 0)
+				dy_st = 0;
+			else if (y == rows - 1)
+				dy_st = rows - 3;
+		}
+#pragma unroll
+		for (int a = 0; a < 3; ++a)
+#pragma unroll
+			for (int b = 0; b < 3; ++b)
+			{
+				const int xx = dx_st + a, yy = dy_st + b;
+				bool ok;
+				if (small)
+					ok = xx >= 0 && yy >= 0 && xx < w && yy < rows;
+				else
+					ok = bitmap[xx + yy * w] == 0;
+				const uint32_t val = ok ? f[xx + (int64_t)yy * w] : 0u;
+#pragma unroll
+				for (int k = 0; k < 9; ++k)
+					if (ok && k == c)
+						v[k] = val;
+				c += ok;
+			}
+		if (c == 0)
+			return; // reference reads an uninitialised slot here (IRFileLoader.cpp:792-794): leave the pixel
+#pragma unroll
+		for (int k = 0; k < 9; ++k)
+			if (k >= c)
+				v[k] = 0xffffffffu;
+		f[x + (int64_t)y * w] = rank_select9(v, c);
+	}
+
+	hipError_t launch_remove_bad_pixels(uint16_t *img, int w, int h, int rows, int nframes, const int *d_xy, int nbad, const uint8_t *d_bitmap,
+										hipStream_t st)
+	{
+		if (nbad > 0)
+			hipLaunchKernelGGL(remove_bad_pixels_kernel, dim3((nbad + 63) / 64, nframes), dim3(64), 0, st, img, w, h, rows, d_xy, nbad, d_bitmap);
+		return hipGetLastError();
+	}
+
+	// ---- histogram / quantile --------------------------------------------------------------------
+	// hist: uint32[nframes][65536].  Integer atomics execute in L2; 8 pixels per lane per load.
+	__global__ __launch_bounds__(256) void histogram_kernel(const uint16_t *__restrict__ img, const uint8_t *__restrict__ mask, int64_t npx,
+															uint32_t *__restrict__ hist)
+	{
+		const int n = blockIdx.y;
+		const uint16_t *f = img + (int64_t)n * npx;
+		const uint8_t *m = mask ? mask + (int64_t)n * npx : nullptr;
+		uint32_t *hh = hist + (int64_t)n * 65536;
+		for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (int64_t)gridDim.x * blockDim.x)
+			if (!m || m[i])
+				atomicAdd(&hh[f[i]], 1u);
+	}
+
+	// one block per frame: first bin (of `nbins`) whose cumulative count >= s, 0 when none, with
+	//   s = (size_t)round((float)size * percent)            (Filters.cpp:63, float product)
+	//   s = (size_t)(int)round((float)population * percent)   (masked, Filters.cpp:92)
+	__global__ __launch_bounds__(1024) void quantile_scan_kernel(const uint32_t *__restrict__ hist, uint64_t size, float percent, int masked,
+																 int nbins, int *__restrict__ result)
+	{
+		__shared__ uint64_t part[1024];
+		__shared__ uint64_t total_s;
+		__shared__ int best;
+		const int n = blockIdx.x, tid = threadIdx.x;
+		const uint32_t *hh = hist + (int64_t)n * 65536;
+		const int per = 64; // 1024 threads x 64 bins
+		uint64_t s = 0;
+		for (int k = 0; k < per; ++k)
+			s += hh[tid * per + k];
+		part[tid] = s;
+		if (tid == 0)
+			best = 0x7fffffff;
+		__syncthreads();
+		if (tid == 0)
+		{ // exclusive prefix over the 1024 partial sums (tiny)
+			uint64_t acc = 0;
+			for (int k = 0; k < 1024; ++k)
+			{
+				const uint64_t t = part[k];
+				part[k] = acc;
+				acc += t;
+			}
+			total_s = acc;
+		}
+		__syncthreads();
+		uint64_t tg;
+		if (masked)
+			tg = (uint64_t)(int64_t)(int)roundf(__fmul_rn((float)total_s, percent));
+		else
+			tg = (uint64_t)roundf(__fmul_rn((float)size, percent));
+		uint64_t count = part[tid];
+		for (int k = 0; k < per; ++k)
+		{
+			const int b = tid * per + k;
+			if (b >= nbins)
+				break;
+			count += hh[b];
+			if (count >= tg)
+			{
+				atomicMin(&best, b);
+				break;
+			}
+		}
+		__syncthreads();
+		if (tid == 0)
+			result[n] = best == 0x7fffffff ? 0 : best;
+	}
+
+	hipError_t launch_histogram(const uint16_t *img, const uint8_t *mask, int64_t npx, int nframes, uint32_t *d_hist, hipStream_t st)
+	{
+		hipError_t e = hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * 65536 * (size_t)nframes, st);
+		if (e != hipSuccess)
+			return e;
+		int blocks = (int)(((npx + 255) / 256) < 1024 ? ((npx + 255) / 256) : 1024);
+		hipLaunchKernelGGL(histogram_kernel, dim3(blocks, nframes), dim3(256), 0, st, img, mask, npx, d_hist);
+		return hipGetLastError();
+	}
+
+	hipError_t launch_quantile_scan(const uint32_t *d_hist, uint64_t size, float percent, int masked, int nbins, int nframes, int *d_result,
+									hipStream_t st)
+	{
+		hipLaunchKernelGGL(quantile_scan_kernel, dim3(nframes), dim3(1024), 0, st, d_hist, size, percent, masked, nbins, d_result);
+		return hipGetLastError();
+	}
+
+	// ---- bad pixel detector ------------------------------------------------------------------
+	// global statistics from the 65536-bin histogram of the frame (single block):
+	//   median = sorted[size/2]; sum = sum hist[v] * (int32)(v-median)^2   (exact in int64)
+	// out[0] = median, out[1..2] = sum as int64 (lo, hi)
+	__global__ __launch_bounds__(1024) void bad_pixels_stats_kernel(const uint32_t *__restrict__ hist, uint64_t size, int64_t *__restrict__ out)
+	{
+		__shared__ uint64_t part[1024];
+		__shared__ int med_s;
+		__shared__ unsigned long long sum_s;
+		const int tid = threadIdx.x;
+		uint64_t s = 0;
+		for (int k = 0; k < 64; ++k)
+			s += hist[tid * 64 + k];
+		part[tid] = s;
+		if (tid == 0)
+		{
+			med_s = 0;
+			sum_s = 0;
+		}
+		__syncthreads();
+		if (tid == 0)
+		{
+			uint64_t acc = 0;
+			for (int k = 0; k < 1024; ++k)
+			{
+				const uint64_t t = part[k];
+				part[k] = acc;
+				acc += t;
+			}
+		}
+		__syncthreads();
+		// sorted[size/2] = the value v with cum_before(v) <= size/2 < cum_before(v) + hist[v]
+		const uint64_t want = size / 2;
+		uint64_t count = part[tid];
+		for (int k = 0; k < 64; ++k)
+		{
+			const int b = tid * 64 + k;
+			const uint64_t hb = hist[b];
+			if (hb && want >= count && want < count + hb)
+				med_s = b;
+			count += hb;
+		}
+		__syncthreads();
+		const int med = med_s;
+		long long acc = 0;
+		for (int k = 0; k < 64; ++k)
+		{
+			const int b = tid * 64 + k;
+			const int32_t d = b - med;
+			const int32_t sq = (int32_t)((uint32_t)d * (uint32_t)d); // the reference's 32-bit int product
+			acc += (long long)sq * (long long)hist[b];
+		}
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1)
+			acc += __shfl_xor(acc, d, 64);
+		if ((tid & 63) == 0)
+			atomicAdd(&sum_s, (unsigned long long)acc);
+		__syncthreads();
+		if (tid == 0)
+		{
+			out[0] = med;
+			out[1] = (int64_t)sum_s;
+		}
+	}
+
+	hipError_t launch_bad_pixels_stats(const uint32_t *d_hist, uint64_t size, int64_t *d_out, hipStream_t st)
+	{
+		hipLaunchKernelGGL(bad_pixels_stats_kernel, dim3(1), dim3(1024), 0, st, d_hist, size, d_out);
+		return hipGetLastError();
+	}
+
+	// per-pixel test: sorted in-bounds 5x5 window, median = win[size/2], trimmed std over ranks
+	// [size/5, 4*size/5), flag if v < med - f*std, v > med + f*std or v < floor_detect.
+	// Ranks are computed by counting (ties by index) - no sort, no scratch.
+	__global__ __launch_bounds__(256) void bad_pixels_detect_kernel(const uint16_t *__restrict__ src, int w, int h, double std_factor,
+																	int floor_detect, uint8_t *__restrict__ flags)
+	{
+		const int x = blockIdx.x * blockDim.x + threadIdx.x;
+		const int y = blockIdx.y;
+		if (x >= w)
+			return;
+		uint32_t v[25];
+		int size = 0;
+#pragma unroll
+		for (int ddy = -2; ddy <= 2; ++ddy)
+#pragma unroll
+			for (int ddx = -2; ddx <= 2; ++ddx)
+			{
+				const int xx = x + ddx, yy = y + ddy;
+				const bool ok = xx >= 0 && yy >= 0 && xx < w && yy < h;
+				v[(ddy + 2) * 5 + (ddx + 2)] = ok ? (uint32_t)src[xx + (int64_t)yy * w] : 0xffffffffu;
+				size += ok;
+			}
+		const int r_med = size / 2, r_lo = size / 5, r_hi = size * 4 / 5;
+		int rank[25];
+		long long med = 0;
+#pragma unroll
+		for (int i = 0; i < 25; ++i)
+		{
+			int r = 0;
+#pragma unroll
+			for (int j = 0; j < 25; ++j)
+				r += (v[j] < v[i]) || (v[j] == v[i] && j < i);
+			rank[i] = r;
+			if (r == r_med && v[i] != 0xffffffffu)
+				med = (long long)v[i];
+		}
+		long long sum2 = 0;
+#pragma unroll
+		for (int i = 0; i < 25; ++i)
+			if (v[i] != 0xffffffffu && rank[i] >= r_lo && rank[i] < r_hi)
+			{
+				const long long d = (long long)v[i] - med;
+				sum2 += d * d;
+			}
+		const long long c = r_hi - r_lo;
+		const double var = (double)sum2 / (double)c;
+		const double sd = sqrt(var);
+		const double lower = (double)med - std_factor * sd;
+		const double upper = (double)med + std_factor * sd;
+		const uint32_t pv = src[x + (int64_t)y * w];
+		flags[x + (int64_t)y * w] = ((double)pv < lower || (double)pv > upper || (int)pv < floor_detect) ? 1 : 0;
+	}
+
+	hipError_t launch_bad_pixels_detect(const uint16_t *src, int w, int h, double std_factor, int floor_detect, uint8_t *d_flags, hipStream_t st)
+	{
+		hipLaunchKernelGGL(bad_pixels_detect_kernel, dim3((w + 255) / 256, h), dim3(256), 0, st, src, w, h, std_factor, floor_detect, d_flags);
+		return hipGetLastError();
+	}
+
+	// ---- 3x3 median filter (medianFilter<u16,u16>) -----------------------------------------------
+	__device__ __forceinline__ uint32_t med3(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
+
+	__global__ __launch_bounds__(256) void median3x3_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w, int h)
+	{
+		const int x = blockIdx.x * blockDim.x + threadIdx.x;
+		const int y = blockIdx.y;
+		const int n = blockIdx.z;
+		if (x >= w)
+			return;
+		const uint16_t *s = src + (int64_t)n * w * h;
+		uint16_t *d = dst + (int64_t)n * w * h;
+		const int64_t o = x + (int64_t)y * w;
+		const bool row_edge = (y == 0 || y == h - 1), col_edge = (x == 0 || x == w - 1);
+		if (row_edge && col_edge)
+		{ // corners: min of the two pixels along the row
+			const int xn = x == 0 ? 1 : w - 2;
+			d[o] = min(s[o], s[xn + (int64_t)y * w]);
+		}
+		else if (row_edge)
+			d[o] = (uint16_t)med3(s[o - 1], s[o], s[o + 1]);
+		else if (col_edge)
+			d[o] = (uint16_t)med3(s[o - w], s[o], s[o + w]);
+		else
+		{
+			uint32_t v[9];
+#pragma unroll
+			for (int a = 0; a < 3; ++a)
+#pragma unroll
+				for (int b = 0; b < 3; ++b)
+					v[a * 3 + b] = s[o + (a - 1) * (int64_t)w + (b - 1)];
+			d[o] = rank_select9(v, 9);
+		}
+	}
+
+	hipError_t launch_median3x3(const uint16_t *src, uint16_t *dst, int w, int h, int nframes, hipStream_t st)
+	{
+		hipLaunchKernelGGL(median3x3_kernel, dim3((w + 255) / 256, h, nframes), dim3(256), 0, st, src, dst, w, h);
+		return hipGetLastError();
+	}
+
+	// ---- u16 -> f32 (load_imageF) ---------------------------------------------------------------
+	__global__ __launch_bounds__(256) void u16_to_f32_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, int64_t total)
+	{
+		for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+			dst[i] = (float)src[i];
+	}
+	hipError_t launch_u16_to_f32(const uint16_t *src, float *dst, int64_t total, hipStream_t st)
+	{
+		int blocks = (int)(((total + 255) / 256) < 4096 ? ((total + 255) / 256) : 4096);
+		hipLaunchKernelGGL(u16_to_f32_kernel, dim3(blocks), dim3(256), 0, st, src, dst, total);
+		return hipGetLastError();
+	}
+
+} // namespace rir

@@ -1,0 +1,243 @@
+// Log, handle registry and HIP device context (see runtime.h).  Also exports the matching part of
+// the reference `tools` C ABI: set_print_function / disable_print / reset_print_functions /
+// get_last_log_error (tools.h:39-55) and set_void_ptr / get_void_ptr / rm_void_ptr (tools.h:67-78).
+#include "runtime.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace rir
+{
+	namespace
+	{
+		std::mutex &log_mutex()
+		{
+			static std::mutex m;
+			return m;
+		}
+		struct LogState
+		{
+			print_function fn = nullptr;
+			bool enabled = true;
+			std::string last_error;
+		};
+		LogState &log_state()
+		{
+			static LogState s;
+			return s;
+		}
+	} // namespace
+
+	void log_message(int level, const char *text)
+	{
+		std::lock_guard<std::mutex> g(log_mutex());
+		LogState &s = log_state();
+		if (level == LOG_ERROR)
+			s.last_error = text ? text : "";
+		if (!s.enabled)
+			return;
+		if (s.fn)
+			s.fn(level, text);
+		else
+		{
+			static const char *prefix[3] = {"Info: ", "Warning: ", "Error: "};
+			std::printf("%s%s\n", prefix[level < 0 || level > 2 ? 0 : level], text ? text : "");
+			std::fflush(stdout);
+		}
+	}
+
+	// ---- registry ----------------------------------------------------------------------------
+	namespace
+	{
+		std::mutex &reg_mutex()
+		{
+			static std::mutex m;
+			return m;
+		}
+		std::map<int, std::shared_ptr<Object>> &reg_map()
+		{
+			static std::map<int, std::shared_ptr<Object>> m;
+			return m;
+		}
+	} // namespace
+
+	int register_object(const std::shared_ptr<Object> &obj)
+	{
+		if (!obj)
+			return -1;
+		std::lock_guard<std::mutex> g(reg_mutex());
+		auto &m = reg_map();
+		int i = 1; // smallest free slot, starting at 1 (tools.cpp:57-67)
+		for (auto it = m.begin(); it != m.end() && it->first == i; ++it)
+			++i;
+		m[i] = obj;
+		return i;
+	}
+	std::shared_ptr<Object> lookup_object(int handle)
+	{
+		std::lock_guard<std::mutex> g(reg_mutex());
+		auto it = reg_map().find(handle);
+		return it == reg_map().end() ? std::shared_ptr<Object>() : it->second;
+	}
+	void remove_object(int handle)
+	{
+		std::shared_ptr<Object> keep; // destroy outside the lock
+		{
+			std::lock_guard<std::mutex> g(reg_mutex());
+			auto it = reg_map().find(handle);
+			if (it != reg_map().end())
+			{
+				keep = it->second;
+				reg_map().erase(it);
+			}
+		}
+	}
+
+	// ---- device --------------------------------------------------------------------------------
+	bool hip_ok(hipError_t e, const char *what)
+	{
+		if (e == hipSuccess)
+			return true;
+		log_error(std::string("librir_amd: ") + what + ": " + hipGetErrorString(e));
+		return false;
+	}
+
+	namespace
+	{
+		struct Device
+		{
+			bool probed = false, ok = false;
+			hipStream_t stream = nullptr;
+		};
+		Device &device()
+		{
+			static Device d;
+			return d;
+		}
+		std::mutex &dev_mutex()
+		{
+			static std::mutex m;
+			return m;
+		}
+	} // namespace
+
+	bool device_ready()
+	{
+		std::lock_guard<std::mutex> g(dev_mutex());
+		Device &d = device();
+		if (!d.probed)
+		{
+			d.probed = true;
+			int n = 0;
+			hipError_t e = hipGetDeviceCount(&n);
+			if (e == hipSuccess && n > 0)
+			{
+				e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
+				d.ok = (e == hipSuccess);
+			}
+			if (!d.ok)
+				(void)hipGetLastError();
+		}
+		if (!d.ok)
+			log_message(LOG_ERROR, "librir_amd: no usable HIP device (this library has no CPU fallback)");
+		return d.ok;
+	}
+	hipStream_t default_stream() { return device().stream; }
+
+	DeviceBuffer::~DeviceBuffer()
+	{
+		if (ptr)
+			(void)hipFree(ptr);
+	}
+	void *DeviceBuffer::reserve(size_t bytes)
+	{
+		if (bytes <= cap && ptr)
+			return ptr;
+		if (ptr)
+		{
+			(void)hipFree(ptr);
+			ptr = nullptr;
+			cap = 0;
+		}
+		size_t want = bytes < 256 ? 256 : bytes;
+		if (!hip_ok(hipMalloc(&ptr, want), "hipMalloc"))
+		{
+			ptr = nullptr;
+			return nullptr;
+		}
+		cap = want;
+		return ptr;
+	}
+	PinnedBuffer::~PinnedBuffer()
+	{
+		if (ptr)
+			(void)hipHostFree(ptr);
+	}
+	void *PinnedBuffer::reserve(size_t bytes)
+	{
+		if (bytes <= cap && ptr)
+			return ptr;
+		if (ptr)
+		{
+			(void)hipHostFree(ptr);
+			ptr = nullptr;
+			cap = 0;
+		}
+		size_t want = bytes < 256 ? 256 : bytes;
+		if (!hip_ok(hipHostMalloc(&ptr, want, hipHostMallocDefault), "hipHostMalloc"))
+		{
+			ptr = nullptr;
+			return nullptr;
+		}
+		cap = want;
+		return ptr;
+	}
+
+} // namespace rir
+
+// ---- exported `tools` symbols ---------------------------------------------------------------------
+
+RIR_EXPORT void set_print_function(rir::print_function function)
+{
+	std::lock_guard<std::mutex> g(rir::log_mutex());
+	rir::log_state().fn = function;
+	rir::log_state().enabled = true;
+}
+RIR_EXPORT void disable_print()
+{
+	std::lock_guard<std::mutex> g(rir::log_mutex());
+	rir::log_state().enabled = false;
+}
+RIR_EXPORT void reset_print_functions()
+{
+	std::lock_guard<std::mutex> g(rir::log_mutex());
+	rir::log_state().fn = nullptr;
+	rir::log_state().enabled = true;
+}
+// -1 and *len = required length when the buffer is too small; no terminator is written (Log.cpp:72-85)
+RIR_EXPORT int get_last_log_error(char *text, int *len)
+{
+	std::lock_guard<std::mutex> g(rir::log_mutex());
+	const std::string &e = rir::log_state().last_error;
+	if (!len)
+		return -1;
+	if (*len < (int)e.size() || !text)
+	{
+		*len = (int)e.size();
+		return -1;
+	}
+	*len = (int)e.size();
+	std::memcpy(text, e.data(), e.size());
+	return 0;
+}
+
+// The reference stores any BaseShared-derived object; here only objects created by this library
+// (rir::Object) can be registered.
+RIR_EXPORT int set_void_ptr(void *obj)
+{
+	if (!obj)
+		return -1;
+	return rir::register_object(static_cast<rir::Object *>(obj)->shared_from_this());
+}
+RIR_EXPORT void *get_void_ptr(int index) { return rir::lookup_object(index).get(); }
+RIR_EXPORT void rm_void_ptr(int index) { rir::remove_object(index); }

@@ -1,0 +1,560 @@
+// C ABI of the signal_processing half of the hot path.
+//
+// Two layers, both extern "C":
+//   * the reference's own entry points, same names / arguments / return codes
+//     (reference src/cpp/signal_processing/signal_processing.h:29-94): host pointers in, host
+//     pointers out, synchronous.  They stage through device buffers and call the layer below.
+//   * rir_*_device: the same operations on device-resident batches [n][h][w] (no PCIe in the
+//     path, asynchronous on the caller's HIP stream) - what pipelines and bench.py use.
+// There is no CPU fallback: without a HIP device every entry point logs and returns its error code.
+#include <cmath>
+#include <cstring>
+#include <map>
+
+#include "filter_kernels.h"
+#include "runtime.h"
+
+using namespace rir;
+
+namespace
+{
+	// the caller's stream, taken literally: NULL is HIP's null (legacy default) stream
+	hipStream_t as_stream(void *s) { return (hipStream_t)s; }
+
+	int strategy_from_string(const char *s)
+	{ // signal_processing.cpp:20-41: NULL, "" and "noborder" leave border pixels untouched
+		if (!s || std::strlen(s) == 0 || std::strcmp(s, "noborder") == 0)
+			return TRANSLATE_UNCHANGED;
+		if (std::strcmp(s, "background") == 0)
+			return TRANSLATE_CONSTANT;
+		if (std::strcmp(s, "wrap") == 0)
+			return TRANSLATE_WRAP;
+		if (std::strcmp(s, "nearest") == 0)
+			return TRANSLATE_NEAREST;
+		return -1;
+	}
+
+	int dtype_size(int type)
+	{
+		switch (type)
+		{
+		case '?':
+		case 'b':
+		case 'B':
+			return 1;
+		case 'h':
+		case 'H':
+			return 2;
+		case 'i':
+		case 'I':
+		case 'f':
+			return 4;
+		case 'l':
+		case 'L':
+		case 'd':
+			return 8;
+		default:
+			return 0;
+		}
+	}
+
+	// Gaussian table, built exactly as the reference does (signal_processing.cpp:79-99): float exp
+	// of a float argument, division by (pi*s) in double, float running sum in x-outer/y-inner
+	// order, float normalisation.  Host libm, like the reference.
+	int gaussian_radius(float sigma)
+	{
+		int radius = (int)(sigma * 2);
+		return radius < 1 ? 1 : radius;
+	}
+	std::vector<float> gaussian_table(float sigma, int radius)
+	{
+		const int kw = 2 * radius + 1;
+		std::vector<float> k((size_t)kw * kw);
+		const float s = 2.0f * sigma * sigma;
+		float sum = 0.0f;
+		for (int x = -radius; x <= radius; x++)
+			for (int y = -radius; y <= radius; y++)
+			{
+				const float r = (float)std::sqrt((double)(x * x + y * y));
+				const float e = std::exp(-(r * r) / s); // float overload
+				const float v = (float)((double)e / (3.14159265358979323846 * (double)s));
+				k[x + radius + (y + radius) * kw] = v;
+				sum += v;
+			}
+		for (auto &v : k)
+			v /= sum;
+		return k;
+	}
+
+	struct GaussCache
+	{
+		std::mutex mu;
+		std::map<uint32_t, std::shared_ptr<DeviceBuffer>> tables; // key = float bits of sigma
+	};
+	GaussCache &gauss_cache()
+	{
+		static GaussCache c;
+		return c;
+	}
+	const float *gaussian_table_device(float sigma, int radius)
+	{
+		uint32_t key;
+		std::memcpy(&key, &sigma, 4);
+		GaussCache &c = gauss_cache();
+		std::lock_guard<std::mutex> g(c.mu);
+		auto it = c.tables.find(key);
+		if (it != c.tables.end())
+			return it->second->as<float>();
+		std::vector<float> k = gaussian_table(sigma, radius);
+		auto buf = std::make_shared<DeviceBuffer>();
+		if (!buf->reserve(k.size() * sizeof(float)))
+			return nullptr;
+		if (!hip_ok(hipMemcpy(buf->ptr, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice), "gaussian table upload"))
+			return nullptr;
+		if (c.tables.size() > 64)
+			c.tables.clear();
+		c.tables[key] = buf;
+		return buf->as<float>();
+	}
+
+	// Scratch for the host-pointer entry points (one call at a time per process; the reference's
+	// objects are not re-entrant either).
+	struct HostScratch
+	{
+		std::mutex mu;
+		DeviceBuffer a, b, c, d;
+	};
+	HostScratch &scratch()
+	{
+		static HostScratch s;
+		return s;
+	}
+
+	// Bad-pixel object: reference rir::BadPixels (BadPixels.h:14-35) + the loader-side bitmap
+	// (IRFileLoader.cpp:704-710).
+	struct BadPixelsObject : public Object
+	{
+		const char *type_name() const override { return "BadPixels"; }
+		int width = 0, height = 0;
+		int floor_detect = 0;  // Filters.h:157-160
+		int floor_correct = 0; // m_median_value, BadPixels.cpp:22-31
+		std::vector<int> xy;   // raster order (x,y) pairs
+		DeviceBuffer d_xy, d_bitmap;
+		int count() const { return (int)(xy.size() / 2); }
+	};
+
+	// Detector on a device-resident frame.  rows = number of rows taken into account.
+	bool detect_bad_pixels(const uint16_t *d_img, int w, int rows, double std_factor, BadPixelsObject &bp, hipStream_t st)
+	{
+		DeviceBuffer hist, stats, flags;
+		const int64_t npx = (int64_t)w * rows;
+		if (!hist.reserve(65536 * sizeof(uint32_t)) || !stats.reserve(2 * sizeof(int64_t)) || !flags.reserve((size_t)npx))
+			return false;
+		if (!hip_ok(launch_histogram(d_img, nullptr, npx, 1, hist.as<uint32_t>(), st), "histogram"))
+			return false;
+		if (!hip_ok(launch_bad_pixels_stats(hist.as<uint32_t>(), (uint64_t)npx, stats.as<int64_t>(), st), "bad_pixels_stats"))
+			return false;
+		int64_t h_stats[2];
+		if (!hip_ok(hipMemcpyAsync(h_stats, stats.ptr, sizeof(h_stats), hipMemcpyDeviceToHost, st), "stats D2H") ||
+			!hip_ok(hipStreamSynchronize(st), "sync"))
+			return false;
+		// Filters.h:151-160 and BadPixels.cpp:25-31: the sums are exact integers, the rest is the
+		// same double sequence as the host code.
+		const int median = (int)h_stats[0];
+		double sum = (double)h_stats[1];
+		sum /= (double)(int)npx;
+		sum = std::sqrt(sum);
+		const uint16_t thr = (uint16_t)(int32_t)(sum * std_factor);
+		bp.floor_detect = ((uint16_t)median > thr) ? (int)(uint16_t)((uint16_t)median - thr) : 0;
+		bp.floor_correct = median - (int)(sum * 2);
+
+		if (!hip_ok(launch_bad_pixels_detect(d_img, w, rows, std_factor, bp.floor_detect, flags.as<uint8_t>(), st), "bad_pixels_detect"))
+			return false;
+		std::vector<uint8_t> h_flags((size_t)npx);
+		if (!hip_ok(hipMemcpyAsync(h_flags.data(), flags.ptr, (size_t)npx, hipMemcpyDeviceToHost, st), "flags D2H") ||
+			!hip_ok(hipStreamSynchronize(st), "sync"))
+			return false;
+		bp.xy.clear();
+		for (int y = 0; y < rows; ++y)
+			for (int x = 0; x < w; ++x)
+				if (h_flags[(size_t)y * w + x])
+				{
+					bp.xy.push_back(x);
+					bp.xy.push_back(y);
+				}
+		return true;
+	}
+
+	bool upload_bad_pixels(BadPixelsObject &bp, hipStream_t st)
+	{
+		const size_t npx = (size_t)bp.width * bp.height;
+		if (!bp.d_xy.reserve(bp.xy.size() * sizeof(int) + 8) || !bp.d_bitmap.reserve(npx))
+			return false;
+		std::vector<uint8_t> bitmap(npx, 0);
+		for (int i = 0; i < bp.count(); ++i)
+			bitmap[(size_t)bp.xy[2 * i + 1] * bp.width + bp.xy[2 * i]] = 1;
+		if (bp.count() && !hip_ok(hipMemcpyAsync(bp.d_xy.ptr, bp.xy.data(), bp.xy.size() * sizeof(int), hipMemcpyHostToDevice, st), "xy H2D"))
+			return false;
+		if (!hip_ok(hipMemcpyAsync(bp.d_bitmap.ptr, bitmap.data(), npx, hipMemcpyHostToDevice, st), "bitmap H2D"))
+			return false;
+		return hip_ok(hipStreamSynchronize(st), "sync");
+	}
+} // namespace
+
+// =====================================================================================================
+// Device-resident batch layer
+// =====================================================================================================
+
+RIR_EXPORT int rir_device_available(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess)
+	{
+		(void)hipGetLastError();
+		return 0;
+	}
+	return n > 0 ? 1 : 0;
+}
+
+RIR_EXPORT int rir_stream_synchronize(void *stream)
+{
+	if (!device_ready())
+		return -1;
+	return hip_ok(hipStreamSynchronize(as_stream(stream)), "hipStreamSynchronize") ? 0 : -1;
+}
+
+RIR_EXPORT int rir_translate_device(int type, const void *d_src, void *d_dst, int w, int h, int nframes, const float *d_offsets,
+									int per_frame_offsets, const void *background, const char *strategy, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	const int s = strategy_from_string(strategy);
+	if (s < 0 || dtype_size(type) == 0 || w <= 0 || h <= 0 || nframes <= 0 || !d_src || !d_dst || !d_offsets || !background)
+	{
+		log_error("rir_translate_device: invalid argument");
+		return -1;
+	}
+	return hip_ok(launch_translate(type, d_src, d_dst, background, w, h, nframes, d_offsets, per_frame_offsets, s, as_stream(stream)), "translate") ? 0 : -1;
+}
+
+RIR_EXPORT int rir_gaussian_filter_device(const float *d_src, float *d_dst, int w, int h, int nframes, float sigma, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (w <= 0 || h <= 0 || nframes <= 0 || !d_src || !d_dst || !(sigma > 0))
+	{
+		log_error("rir_gaussian_filter_device: invalid argument");
+		return -1;
+	}
+	const int radius = gaussian_radius(sigma);
+	const float *d_k = gaussian_table_device(sigma, radius);
+	if (!d_k)
+		return -1;
+	return hip_ok(launch_gaussian(d_src, d_dst, w, h, nframes, d_k, radius, as_stream(stream)), "gaussian_filter") ? 0 : -1;
+}
+
+// result: int32[nframes] on the device.  d_hist: uint32[nframes*65536] workspace.
+RIR_EXPORT int rir_find_median_pixel_device(const unsigned short *d_img, const unsigned char *d_mask, int size, int nframes, float percent,
+											int *d_result, unsigned int *d_hist, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (size <= 0 || nframes <= 0 || !d_img || !d_result || !d_hist)
+	{
+		log_error("rir_find_median_pixel_device: invalid argument");
+		return -1;
+	}
+	hipStream_t st = as_stream(stream);
+	if (!hip_ok(launch_histogram(d_img, d_mask, size, nframes, d_hist, st), "histogram"))
+		return -1;
+	// 65 535 bins, as the reference (Filters.cpp:59)
+	return hip_ok(launch_quantile_scan(d_hist, (uint64_t)size, percent, d_mask ? 1 : 0, 65535, nframes, d_result, st), "quantile") ? 0 : -1;
+}
+
+RIR_EXPORT int rir_bad_pixels_create_device(const unsigned short *d_first_image, int width, int height, void *stream)
+{
+	if (!device_ready())
+		return 0;
+	if (!d_first_image || width <= 0 || height <= 0)
+	{
+		log_error("rir_bad_pixels_create_device: invalid argument");
+		return 0;
+	}
+	auto bp = std::make_shared<BadPixelsObject>();
+	bp->width = width;
+	bp->height = height;
+	hipStream_t st = as_stream(stream);
+	if (!detect_bad_pixels(d_first_image, width, height, 5.0, *bp, st) || !upload_bad_pixels(*bp, st))
+		return 0;
+	return register_object(bp);
+}
+
+RIR_EXPORT int rir_bad_pixels_correct_device(int handle, const unsigned short *d_in, unsigned short *d_out, int nframes, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	auto bp = lookup_as<BadPixelsObject>(handle);
+	if (!bp || !d_in || !d_out || nframes <= 0)
+	{
+		log_error("rir_bad_pixels_correct_device: invalid handle or argument");
+		return -1;
+	}
+	return hip_ok(launch_bad_pixels_correct(d_in, d_out, bp->width, bp->height, nframes, bp->d_xy.as<int>(), bp->count(), bp->floor_correct,
+											as_stream(stream)),
+				  "bad_pixels_correct")
+			   ? 0
+			   : -1;
+}
+
+// info[0] = number of flagged pixels, info[1] = clamp floor (m_median_value), info[2] = detector floor;
+// xy (may be NULL) receives up to cap (x,y) pairs in raster order.
+RIR_EXPORT int rir_bad_pixels_info(int handle, int *info, int *xy, int cap)
+{
+	auto bp = lookup_as<BadPixelsObject>(handle);
+	if (!bp || !info)
+		return -1;
+	info[0] = bp->count();
+	info[1] = bp->floor_correct;
+	info[2] = bp->floor_detect;
+	if (xy)
+		std::memcpy(xy, bp->xy.data(), sizeof(int) * 2 * (size_t)std::min(cap, bp->count()));
+	return 0;
+}
+
+// Read-back variant (IRFileLoader::removeBadPixels): in place, first `rows` rows, flagged
+// neighbours excluded.  The handle must have been created on a (width x rows) detector window.
+RIR_EXPORT int rir_remove_bad_pixels_device(int handle, unsigned short *d_img, int rows, int nframes, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	auto bp = lookup_as<BadPixelsObject>(handle);
+	if (!bp || !d_img || nframes <= 0 || rows <= 0 || rows > bp->height)
+	{
+		log_error("rir_remove_bad_pixels_device: invalid handle or argument");
+		return -1;
+	}
+	return hip_ok(launch_remove_bad_pixels(d_img, bp->width, bp->height, rows, nframes, bp->d_xy.as<int>(), bp->count(), bp->d_bitmap.as<uint8_t>(),
+										   as_stream(stream)),
+				  "remove_bad_pixels")
+			   ? 0
+			   : -1;
+}
+
+// Detector restricted to the first `rows` rows of a (width x height) frame, list expressed in
+// full-frame coordinates: what IRFileLoader::setBadPixelsEnabled builds (IRFileLoader.cpp:693-716).
+RIR_EXPORT int rir_bad_pixels_create_rows_device(const unsigned short *d_first_image, int width, int height, int rows, void *stream)
+{
+	if (!device_ready())
+		return 0;
+	if (!d_first_image || width <= 0 || height <= 0 || rows <= 0 || rows > height)
+	{
+		log_error("rir_bad_pixels_create_rows_device: invalid argument");
+		return 0;
+	}
+	auto bp = std::make_shared<BadPixelsObject>();
+	bp->width = width;
+	bp->height = height;
+	hipStream_t st = as_stream(stream);
+	if (!detect_bad_pixels(d_first_image, width, rows, 5.0, *bp, st) || !upload_bad_pixels(*bp, st))
+		return 0;
+	return register_object(bp);
+}
+
+// Motion removal on read-back (IRFileLoader.cpp:617-627): d_shifts = float pairs (x[pos], y[pos]).
+RIR_EXPORT int rir_remove_motion_device(const unsigned short *d_src, unsigned short *d_dst, int w, int h, int rows, int nframes,
+										const float *d_shifts, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (!d_src || !d_dst || d_src == d_dst || w <= 0 || h <= 0 || rows <= 0 || rows > h || nframes <= 0 || !d_shifts)
+	{
+		log_error("rir_remove_motion_device: invalid argument");
+		return -1;
+	}
+	return hip_ok(launch_remove_motion(d_src, d_dst, w, h, rows, nframes, d_shifts, as_stream(stream)), "remove_motion") ? 0 : -1;
+}
+
+RIR_EXPORT int rir_median_filter_device(const unsigned short *d_src, unsigned short *d_dst, int w, int h, int nframes, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (!d_src || !d_dst || w < 3 || h < 3 || nframes <= 0)
+	{
+		log_error("rir_median_filter_device: invalid argument (needs w,h >= 3)");
+		return -1;
+	}
+	return hip_ok(launch_median3x3(d_src, d_dst, w, h, nframes, as_stream(stream)), "median_filter") ? 0 : -1;
+}
+
+// =====================================================================================================
+// Reference entry points (host pointers, synchronous)
+// =====================================================================================================
+
+RIR_EXPORT int translate(int type, void *src, void *dst, int w, int h, float dx, float dy, void *background, const char *strategy)
+{
+	const int es = dtype_size(type);
+	if (es == 0 || strategy_from_string(strategy) < 0) // signal_processing.cpp:40-41,70-71
+		return -1;
+	if (!device_ready())
+		return -1;
+	if (!src || !dst || !background || w <= 0 || h <= 0)
+		return -1;
+	HostScratch &s = scratch();
+	std::lock_guard<std::mutex> g(s.mu);
+	const size_t bytes = (size_t)w * h * es;
+	hipStream_t st = default_stream();
+	if (!s.a.reserve(bytes) || !s.b.reserve(bytes) || !s.c.reserve(8))
+		return -1;
+	const float off[2] = {dx, dy};
+	// dst is an in/out buffer: "noborder" keeps whatever the caller put there (Filters.h:261-264)
+	if (!hip_ok(hipMemcpyAsync(s.a.ptr, src, bytes, hipMemcpyHostToDevice, st), "H2D") ||
+		!hip_ok(hipMemcpyAsync(s.b.ptr, dst, bytes, hipMemcpyHostToDevice, st), "H2D") ||
+		!hip_ok(hipMemcpyAsync(s.c.ptr, off, sizeof(off), hipMemcpyHostToDevice, st), "H2D"))
+		return -1;
+	if (rir_translate_device(type, s.a.ptr, s.b.ptr, w, h, 1, s.c.as<float>(), 0, background, strategy, st) != 0)
+		return -1;
+	if (!hip_ok(hipMemcpyAsync(dst, s.b.ptr, bytes, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(hipStreamSynchronize(st), "sync"))
+		return -1;
+	return 0;
+}
+
+RIR_EXPORT int gaussian_filter(float *src, float *dst, int w, int h, float sigma)
+{
+	if (!device_ready())
+		return -1;
+	if (!src || !dst || w <= 0 || h <= 0)
+		return -1;
+	HostScratch &s = scratch();
+	std::lock_guard<std::mutex> g(s.mu);
+	const size_t bytes = (size_t)w * h * sizeof(float);
+	hipStream_t st = default_stream();
+	if (!s.a.reserve(bytes) || !s.b.reserve(bytes))
+		return -1;
+	if (!hip_ok(hipMemcpyAsync(s.a.ptr, src, bytes, hipMemcpyHostToDevice, st), "H2D"))
+		return -1;
+	if (rir_gaussian_filter_device(s.a.as<float>(), s.b.as<float>(), w, h, 1, sigma, st) != 0)
+		return -1;
+	if (!hip_ok(hipMemcpyAsync(dst, s.b.ptr, bytes, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(hipStreamSynchronize(st), "sync"))
+		return -1;
+	return 0;
+}
+
+static int find_median_host(unsigned short *pixels, unsigned char *mask, int size, float percent)
+{
+	if (!device_ready())
+		return -1;
+	if (!pixels || size <= 0)
+		return 0;
+	HostScratch &s = scratch();
+	std::lock_guard<std::mutex> g(s.mu);
+	hipStream_t st = default_stream();
+	if (!s.a.reserve((size_t)size * 2) || !s.b.reserve(65536 * sizeof(uint32_t)) || !s.c.reserve(sizeof(int)) || (mask && !s.d.reserve((size_t)size)))
+		return -1;
+	if (!hip_ok(hipMemcpyAsync(s.a.ptr, pixels, (size_t)size * 2, hipMemcpyHostToDevice, st), "H2D"))
+		return -1;
+	if (mask && !hip_ok(hipMemcpyAsync(s.d.ptr, mask, (size_t)size, hipMemcpyHostToDevice, st), "H2D"))
+		return -1;
+	if (rir_find_median_pixel_device(s.a.as<unsigned short>(), mask ? s.d.as<unsigned char>() : nullptr, size, 1, percent, s.c.as<int>(),
+									 s.b.as<unsigned int>(), st) != 0)
+		return -1;
+	int res = 0;
+	if (!hip_ok(hipMemcpyAsync(&res, s.c.ptr, sizeof(int), hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(hipStreamSynchronize(st), "sync"))
+		return -1;
+	return res;
+}
+
+RIR_EXPORT int find_median_pixel(unsigned short *pixels, int size, float percent) { return find_median_host(pixels, nullptr, size, percent); }
+RIR_EXPORT int find_median_pixel_mask(unsigned short *pixels, unsigned char *mask, int size, float percent)
+{
+	return find_median_host(pixels, mask, size, percent);
+}
+
+// returns the object handle, 0 on error (signal_processing.h:77-80)
+RIR_EXPORT int bad_pixels_create(unsigned short *first_image, int width, int height)
+{
+	if (!device_ready())
+		return 0;
+	if (!first_image || width <= 0 || height <= 0)
+		return 0;
+	HostScratch &s = scratch();
+	std::lock_guard<std::mutex> g(s.mu);
+	hipStream_t st = default_stream();
+	const size_t bytes = (size_t)width * height * 2;
+	if (!s.a.reserve(bytes) || !hip_ok(hipMemcpyAsync(s.a.ptr, first_image, bytes, hipMemcpyHostToDevice, st), "H2D"))
+		return 0;
+	return rir_bad_pixels_create_device(s.a.as<unsigned short>(), width, height, st);
+}
+
+RIR_EXPORT int bad_pixels_correct(int handle, unsigned short *in, unsigned short *out)
+{
+	auto bp = lookup_as<BadPixelsObject>(handle);
+	if (!bp) // signal_processing.cpp:209-211
+		return -1;
+	if (!device_ready())
+		return -1;
+	if (!in || !out)
+		return -1;
+	HostScratch &s = scratch();
+	std::lock_guard<std::mutex> g(s.mu);
+	hipStream_t st = default_stream();
+	const size_t bytes = (size_t)bp->width * bp->height * 2;
+	if (!s.a.reserve(bytes) || !s.b.reserve(bytes))
+		return -1;
+	if (!hip_ok(hipMemcpyAsync(s.a.ptr, in, bytes, hipMemcpyHostToDevice, st), "H2D"))
+		return -1;
+	if (rir_bad_pixels_correct_device(handle, s.a.as<unsigned short>(), s.b.as<unsigned short>(), 1, st) != 0)
+		return -1;
+	if (!hip_ok(hipMemcpyAsync(out, s.b.ptr, bytes, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(hipStreamSynchronize(st), "sync"))
+		return -1;
+	return 0;
+}
+
+RIR_EXPORT void bad_pixels_destroy(int handle)
+{
+	if (lookup_as<BadPixelsObject>(handle))
+		remove_object(handle);
+}
+
+// hash_bytes (signal_processing.cpp:337-392): 64-bit multiply/xor-shift hash used by the Python
+// cache helpers.  Host-side utility, restated here so the symbol exists in the drop-in library.
+RIR_EXPORT size_t hash_bytes(void *_ptr, size_t len)
+{
+	const uint64_t m = 14313749767032793493ULL, seed = 3782874213ULL, r = 47ULL;
+	const unsigned char *ptr = static_cast<const unsigned char *>(_ptr);
+	uint64_t h = seed ^ (len * m);
+	const size_t nblocks = len / 8;
+	for (size_t i = 0; i < nblocks; ++i, ptr += 8)
+	{
+		uint64_t k;
+		std::memcpy(&k, ptr, 8);
+		k *= m;
+		k ^= k >> r;
+		k *= m;
+		h ^= k;
+		h *= m;
+	}
+	const size_t tail = len & 7U;
+	if (tail)
+	{
+		for (size_t i = tail; i-- > 0;)
+			h ^= (uint64_t)ptr[i] << (8 * i);
+		h *= m;
+	}
+	h ^= h >> r;
+	h *= m;
+	h ^= h >> r;
+	return (size_t)h;
+}
+
+// Out of the hot path (SURVEY.md §8, rows marked out of scope): sequential 1-D time-series and
+// connected-component utilities.  The symbols exist so that the drop-in library resolves them;
+// they report an error instead of computing.
+static int out_of_scope(const char *name)
+{
+	log_error(std::string(name) + ": not provided by the MI355X hot-path library (CPU utility outside the accelerated path)");
+	return -1;
+}
+RIR_EXPORT int extract_times(double *, int, int *, int, double *, int *) { return out_of_scope("extract_times"); }
+RIR_EXPORT int resample_time_serie(double *, double *, int, double *, int, int, double, double *, int *) { return out_of_scope("resample_time_serie"); }
+RIR_EXPORT int label_image(int, void *, int *, int, int, void *, double *, int *) { return out_of_scope("label_image"); }
+RIR_EXPORT int keep_largest_area(int, void *, int *, int, int, void *, int) { return out_of_scope("keep_largest_area"); }

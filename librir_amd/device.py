@@ -1,0 +1,280 @@
+"""Device-resident batch API over the C ABI in ``include/rir_amd_device.h``.
+
+Inputs and outputs are ``torch`` CUDA(HIP) tensors; torch is plumbing only (device memory and
+streams) - every operation is one call into ``librir_amd.so`` on torch's current HIP stream.
+"""
+import ctypes as ct
+
+import numpy as np
+import torch
+
+from .low_level.misc import _lib, last_error
+
+DEFAULT_GOP = 50  # reference key-frame cadence, src/cpp/video_io/h264.cpp:1662-1665
+
+_DTYPE_CHARS = {
+    torch.bool: "?",
+    torch.int8: "b",
+    torch.uint8: "B",
+    torch.int16: "h",
+    torch.uint16: "H",
+    torch.int32: "i",
+    torch.uint32: "I",
+    torch.int64: "l",
+    torch.uint64: "L",
+    torch.float32: "f",
+    torch.float64: "d",
+}
+_NP_OF = {
+    torch.bool: np.bool_,
+    torch.int8: np.int8,
+    torch.uint8: np.uint8,
+    torch.int16: np.int16,
+    torch.uint16: np.uint16,
+    torch.int32: np.int32,
+    torch.uint32: np.uint32,
+    torch.int64: np.int64,
+    torch.uint64: np.uint64,
+    torch.float32: np.float32,
+    torch.float64: np.float64,
+}
+
+
+class CodecLayout(ct.Structure):
+    _fields_ = [
+        ("width", ct.c_int),
+        ("height", ct.c_int),
+        ("nframes", ct.c_int),
+        ("gop", ct.c_int),
+        ("ntiles", ct.c_int),
+        ("nchunks", ct.c_int),
+        ("sizes_bytes", ct.c_int64),
+        ("tile_off_bytes", ct.c_int64),
+        ("chunk_off_bytes", ct.c_int64),
+        ("stream_max_bytes", ct.c_int64),
+        ("workspace_bytes", ct.c_int64),
+    ]
+
+
+_vp = ct.c_void_p
+_lib.rir_device_available.restype = ct.c_int
+_lib.rir_stream_synchronize.argtypes = [_vp]
+_lib.rir_codec_layout_query.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(CodecLayout)]
+_lib.rir_codec_encode_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, _vp, ct.c_longlong, _vp]
+_lib.rir_codec_decode_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
+_lib.rir_translate_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp, ct.c_int, _vp, ct.c_char_p, _vp]
+_lib.rir_gaussian_filter_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_float, _vp]
+_lib.rir_find_median_pixel_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_float, _vp, _vp, _vp]
+_lib.rir_bad_pixels_create_device.argtypes = [_vp, ct.c_int, ct.c_int, _vp]
+_lib.rir_bad_pixels_create_rows_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, _vp]
+_lib.rir_bad_pixels_correct_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, _vp]
+_lib.rir_bad_pixels_info.argtypes = [ct.c_int, _vp, _vp, ct.c_int]
+_lib.rir_remove_bad_pixels_device.argtypes = [ct.c_int, _vp, ct.c_int, ct.c_int, _vp]
+_lib.rir_remove_motion_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp]
+_lib.rir_median_filter_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp]
+_lib.bad_pixels_destroy.argtypes = [ct.c_int]
+_lib.bad_pixels_destroy.restype = None
+
+
+def device_available():
+    return bool(_lib.rir_device_available())
+
+
+def _stream():
+    return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check(r, what):
+    if r != 0:
+        raise RuntimeError("%s failed: %s" % (what, last_error()))
+
+
+def _frames3(t, dtype=None):
+    if t.dim() == 2:
+        t = t.unsqueeze(0)
+    if t.dim() != 3 or not t.is_cuda:
+        raise RuntimeError("expected a CUDA tensor of shape (n, h, w)")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError("expected dtype %s" % dtype)
+    return t.contiguous()
+
+
+def codec_layout(width, height, nframes, gop=DEFAULT_GOP):
+    L = CodecLayout()
+    _check(_lib.rir_codec_layout_query(width, height, nframes, gop, ct.byref(L)), "rir_codec_layout_query")
+    return L
+
+
+class EncodedBatch:
+    """Device-resident compressed batch (tables + compact stream), format RIRB1."""
+
+    def __init__(self, layout, sizes, tile_off, chunk_off, stream):
+        self.layout = layout
+        self.sizes = sizes  # uint8  [nchunks, ntiles, gop]
+        self.tile_off = tile_off  # int32(bit pattern uint32) [nchunks, ntiles+1]
+        self.chunk_off = chunk_off  # int64 [nchunks+1]
+        self.stream = stream  # int64 words (capacity = worst case)
+
+    def total_words(self):
+        return int(self.chunk_off[-1].item())
+
+    def compressed_bytes(self):
+        """stream + tables: what a container has to store"""
+        L = self.layout
+        return self.total_words() * 8 + L.sizes_bytes + L.tile_off_bytes + L.chunk_off_bytes
+
+
+class CodecContext:
+    """Pre-allocated buffers for repeated encode/decode of one batch geometry (no allocation in
+    the timed path)."""
+
+    def __init__(self, width, height, nframes, gop=DEFAULT_GOP, device="cuda"):
+        self.layout = L = codec_layout(width, height, nframes, gop)
+        dev = torch.device(device)
+        self.sizes = torch.zeros((L.nchunks, L.ntiles, L.gop), dtype=torch.uint8, device=dev)
+        self.tile_off = torch.zeros((L.nchunks, L.ntiles + 1), dtype=torch.int32, device=dev)
+        self.chunk_off = torch.zeros((L.nchunks + 1,), dtype=torch.int64, device=dev)
+        self.stream = torch.empty((L.stream_max_bytes // 8,), dtype=torch.int64, device=dev)
+        self.workspace = torch.empty((L.workspace_bytes,), dtype=torch.uint8, device=dev)
+        self.error = torch.zeros((1,), dtype=torch.int32, device=dev)
+
+    def encode(self, frames):
+        L = self.layout
+        fr = _frames3(frames, torch.uint16)
+        if tuple(fr.shape) != (L.nframes, L.height, L.width):
+            raise RuntimeError("encode: frames do not match the context geometry")
+        _check(
+            _lib.rir_codec_encode_device(
+                fr.data_ptr(), L.width, L.height, L.nframes, L.gop, self.sizes.data_ptr(), self.tile_off.data_ptr(),
+                self.chunk_off.data_ptr(), self.stream.data_ptr(), self.workspace.data_ptr(), L.workspace_bytes, _stream(),
+            ),
+            "rir_codec_encode_device",
+        )
+        return EncodedBatch(L, self.sizes, self.tile_off, self.chunk_off, self.stream)
+
+    def decode(self, enc, out=None, check=True):
+        L = self.layout
+        if out is None:
+            out = torch.empty((L.nframes, L.height, L.width), dtype=torch.uint16, device=self.sizes.device)
+        if check:
+            self.error.zero_()
+        _check(
+            _lib.rir_codec_decode_device(
+                enc.sizes.data_ptr(), enc.tile_off.data_ptr(), enc.chunk_off.data_ptr(), enc.stream.data_ptr(), L.width, L.height,
+                L.nframes, L.gop, out.data_ptr(), self.error.data_ptr(), _stream(),
+            ),
+            "rir_codec_decode_device",
+        )
+        if check and int(self.error.item()) != 0:
+            raise RuntimeError("rir_codec_decode_device: malformed stream")
+        return out
+
+
+def translate(frames, offsets, strategy="", background=0):
+    """frames (n,h,w) any supported dtype; offsets: (dx,dy) or tensor (n,2) of float32 per-frame shifts."""
+    fr = _frames3(frames)
+    n, h, w = fr.shape
+    ch = _DTYPE_CHARS.get(fr.dtype)
+    if ch is None:
+        raise RuntimeError("translate: unsupported dtype")
+    off = torch.as_tensor(offsets, dtype=torch.float32, device=fr.device).contiguous()
+    per_frame = 1 if off.dim() == 2 else 0
+    if per_frame and off.shape[0] != n:
+        raise RuntimeError("translate: one (dx,dy) pair per frame expected")
+    dst = fr.clone()
+    back = np.zeros(1, dtype=_NP_OF[fr.dtype])
+    back[0] = background
+    if strategy == "constant":
+        strategy = "background"
+    _check(
+        _lib.rir_translate_device(ord(ch), fr.data_ptr(), dst.data_ptr(), w, h, n, off.data_ptr(), per_frame, back.ctypes.data,
+                                  strategy.encode(), _stream()),
+        "rir_translate_device",
+    )
+    return dst
+
+
+def gaussian_filter(frames, sigma):
+    fr = _frames3(frames, torch.float32)
+    n, h, w = fr.shape
+    dst = torch.empty_like(fr)
+    _check(_lib.rir_gaussian_filter_device(fr.data_ptr(), dst.data_ptr(), w, h, n, float(sigma), _stream()), "rir_gaussian_filter_device")
+    return dst
+
+
+def find_median_pixel(frames, percent=0.5, mask=None):
+    fr = _frames3(frames, torch.uint16)
+    n, h, w = fr.shape
+    res = torch.zeros((n,), dtype=torch.int32, device=fr.device)
+    hist = torch.empty((n, 65536), dtype=torch.int32, device=fr.device)
+    mptr = None
+    if mask is not None:
+        mask = _frames3(mask, torch.uint8)
+        mptr = mask.data_ptr()
+    _check(_lib.rir_find_median_pixel_device(fr.data_ptr(), mptr, h * w, n, float(percent), res.data_ptr(), hist.data_ptr(), _stream()),
+           "rir_find_median_pixel_device")
+    return res
+
+
+class BadPixels:
+    """Device-side counterpart of librir's BadPixels (reference src/python/librir/signal_processing/BadPixels.py)."""
+
+    def __init__(self, first_image, rows=None):
+        img = _frames3(first_image, torch.uint16)
+        _, h, w = img.shape
+        if rows is None:
+            self.handle = _lib.rir_bad_pixels_create_device(img.data_ptr(), w, h, _stream())
+        else:
+            self.handle = _lib.rir_bad_pixels_create_rows_device(img.data_ptr(), w, h, int(rows), _stream())
+        if self.handle <= 0:
+            raise RuntimeError("bad_pixels_create failed: %s" % last_error())
+        self.shape = (h, w)
+        info = (ct.c_int * 3)()
+        _lib.rir_bad_pixels_info(self.handle, info, None, 0)
+        self.count, self.floor_correct, self.floor_detect = info[0], info[1], info[2]
+
+    def positions(self):
+        xy = np.zeros((max(self.count, 1), 2), dtype=np.int32)
+        info = (ct.c_int * 3)()
+        _lib.rir_bad_pixels_info(self.handle, info, xy.ctypes.data, self.count)
+        return xy[: self.count]
+
+    def correct(self, frames):
+        fr = _frames3(frames, torch.uint16)
+        out = torch.empty_like(fr)
+        _check(_lib.rir_bad_pixels_correct_device(self.handle, fr.data_ptr(), out.data_ptr(), fr.shape[0], _stream()), "rir_bad_pixels_correct_device")
+        return out
+
+    def remove_inplace(self, frames, rows):
+        fr = _frames3(frames, torch.uint16)
+        _check(_lib.rir_remove_bad_pixels_device(self.handle, fr.data_ptr(), int(rows), fr.shape[0], _stream()), "rir_remove_bad_pixels_device")
+        return fr
+
+    def close(self):
+        if getattr(self, "handle", 0) > 0:
+            _lib.bad_pixels_destroy(self.handle)
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def remove_motion(frames, shifts, rows=None):
+    fr = _frames3(frames, torch.uint16)
+    n, h, w = fr.shape
+    sh = torch.as_tensor(shifts, dtype=torch.float32, device=fr.device).contiguous()
+    out = torch.empty_like(fr)
+    _check(_lib.rir_remove_motion_device(fr.data_ptr(), out.data_ptr(), w, h, h if rows is None else int(rows), n, sh.data_ptr(), _stream()),
+           "rir_remove_motion_device")
+    return out
+
+
+def median_filter(frames):
+    fr = _frames3(frames, torch.uint16)
+    n, h, w = fr.shape
+    out = torch.empty_like(fr)
+    _check(_lib.rir_median_filter_device(fr.data_ptr(), out.data_ptr(), w, h, n, _stream()), "rir_median_filter_device")
+    return out

@@ -1,0 +1,67 @@
+"""Library loading, mirroring librir's ``low_level.misc`` (reference
+src/python/librir/low_level/misc.py:98-139): the four handles ``_tools``, ``_geometry``,
+``_signal_processing`` and ``_video_io`` exist, but here they all resolve to the one HIP shared
+object ``libs/librir_amd.so`` (built in-tree by ``librir_amd.build``).
+
+There is no CPU implementation behind this package: if the shared object is missing, importing
+fails with an explicit message; if no HIP device is present, the compute entry points return their
+error codes and the Python wrappers raise ``RuntimeError``.
+"""
+import ctypes as ct
+import os
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB_PATH = os.path.join(_HERE, "libs", "librir_amd.so")
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            "librir_amd: %s is missing - build it with `python -m librir_amd.build` "
+            "(or __graft_entry__.build()); there is no CPU fallback" % _LIB_PATH
+        )
+    return ct.CDLL(_LIB_PATH)
+
+
+_lib = _load()
+# same module-level names as the reference wrapper
+_tools = _lib
+_geometry = _lib
+_signal_processing = _lib
+_video_io = _lib
+
+
+def toString(ar):
+    """bytes / char array -> str (stops at the first NUL), like the reference helper."""
+    if isinstance(ar, str):
+        return ar
+    b = bytes(ar)
+    i = b.find(b"\x00")
+    if i >= 0:
+        b = b[:i]
+    return b.decode("utf-8", errors="replace")
+
+
+def toBytes(s):
+    if isinstance(s, bytes):
+        return s
+    return str(s).encode("utf-8")
+
+
+def toCharP(s):
+    return toBytes(s)
+
+
+def toArray(s):
+    """str -> mutable char buffer"""
+    return ct.create_string_buffer(toBytes(s))
+
+
+def last_error():
+    buf = ct.create_string_buffer(1024)
+    n = ct.c_int(1024)
+    _lib.get_last_log_error.argtypes = [ct.c_char_p, ct.POINTER(ct.c_int)]
+    if _lib.get_last_log_error(buf, ct.byref(n)) != 0:
+        buf = ct.create_string_buffer(n.value + 1)
+        _lib.get_last_log_error(buf, ct.byref(n))
+    return buf.raw[: n.value].decode("utf-8", errors="replace")
