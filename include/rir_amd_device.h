@@ -34,7 +34,7 @@ extern "C"
 		int width, height, nframes, gop;
 		int ntiles;				  /* ceil(width*height / 512) */
 		int nchunks;			  /* ceil(nframes / gop) */
-		int64_t sizes_bytes;	  /* uint8  [nchunks][ntiles][gop]   record lengths in words */
+		int64_t hdr_bytes;		  /* uint64 [nchunks][ntiles][gop]   record headers (widths|mode|base) */
 		int64_t tile_off_bytes;	  /* uint32 [nchunks][ntiles+1]      first word of a tile segment */
 		int64_t chunk_off_bytes;  /* uint64 [nchunks+1]              first word of a chunk; last = total */
 		int64_t stream_max_bytes; /* worst-case size of the compact stream */
@@ -44,12 +44,12 @@ extern "C"
 	int rir_codec_layout_query(int width, int height, int nframes, int gop, rir_codec_layout *out);
 
 	/* d_frames: uint16 [nframes][height][width].  Outputs sized per rir_codec_layout. */
-	int rir_codec_encode_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned char *d_sizes,
+	int rir_codec_encode_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned long long *d_hdr,
 								unsigned int *d_tile_off, unsigned long long *d_chunk_off, unsigned long long *d_stream, void *d_workspace,
 								long long workspace_bytes, void *stream);
 
 	/* *d_error (device int, zero it first) becomes 1 when a malformed table/record was met. */
-	int rir_codec_decode_device(const unsigned char *d_sizes, const unsigned int *d_tile_off, const unsigned long long *d_chunk_off,
+	int rir_codec_decode_device(const unsigned long long *d_hdr, const unsigned int *d_tile_off, const unsigned long long *d_chunk_off,
 								const unsigned long long *d_stream, int width, int height, int nframes, int gop, unsigned short *d_frames,
 								int *d_error, void *stream);
 

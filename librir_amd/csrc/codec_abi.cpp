@@ -33,7 +33,7 @@ RIR_EXPORT int rir_codec_layout_query(int width, int height, int nframes, int go
 	out->ntiles = (int)((npx + RIRB1_TILE_PX - 1) / RIRB1_TILE_PX);
 	out->nchunks = (nframes + gop - 1) / gop;
 	const int64_t slots = (int64_t)out->nchunks * out->ntiles;
-	out->sizes_bytes = slots * gop;
+	out->hdr_bytes = slots * gop * 8;
 	out->tile_off_bytes = (int64_t)out->nchunks * (out->ntiles + 1) * 4;
 	out->chunk_off_bytes = (int64_t)(out->nchunks + 1) * 8;
 	out->stream_max_bytes = slots * gop * RIRB1_REC_MAX_WORDS * 8;
@@ -42,7 +42,7 @@ RIR_EXPORT int rir_codec_layout_query(int width, int height, int nframes, int go
 	return 0;
 }
 
-RIR_EXPORT int rir_codec_encode_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned char *d_sizes,
+RIR_EXPORT int rir_codec_encode_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned long long *d_hdr,
 									   unsigned int *d_tile_off, unsigned long long *d_chunk_off, unsigned long long *d_stream,
 									   void *d_workspace, long long workspace_bytes, void *stream)
 {
@@ -51,7 +51,7 @@ RIR_EXPORT int rir_codec_encode_device(const unsigned short *d_frames, int width
 	rir_codec_layout L;
 	if (rir_codec_layout_query(width, height, nframes, gop, &L) != 0)
 		return -1;
-	if (!d_frames || !d_sizes || !d_tile_off || !d_chunk_off || !d_stream || !d_workspace || workspace_bytes < L.workspace_bytes)
+	if (!d_frames || !d_hdr || !d_tile_off || !d_chunk_off || !d_stream || !d_workspace || workspace_bytes < L.workspace_bytes)
 	{
 		log_error("rir_codec_encode_device: null buffer or workspace too small");
 		return -1;
@@ -67,14 +67,14 @@ RIR_EXPORT int rir_codec_encode_device(const unsigned short *d_frames, int width
 	uint32_t *d_seg_words = reinterpret_cast<uint32_t *>(ws);
 	ws += align256((size_t)L.nchunks * L.ntiles * 4);
 	uint64_t *d_chunk_words = reinterpret_cast<uint64_t *>(ws);
-	return hip_ok(launch_encode(d_frames, (int64_t)width * height, L.ntiles, nframes, gop, d_sizes, d_seg_words, d_sparse, d_tile_off, d_chunk_words,
+	return hip_ok(launch_encode(d_frames, (int64_t)width * height, L.ntiles, nframes, gop, reinterpret_cast<uint64_t *>(d_hdr), d_seg_words, d_sparse, d_tile_off, d_chunk_words,
 								reinterpret_cast<uint64_t *>(d_chunk_off), reinterpret_cast<uint64_t *>(d_stream), as_stream(stream)),
 				  "codec encode")
 			   ? 0
 			   : -1;
 }
 
-RIR_EXPORT int rir_codec_decode_device(const unsigned char *d_sizes, const unsigned int *d_tile_off, const unsigned long long *d_chunk_off,
+RIR_EXPORT int rir_codec_decode_device(const unsigned long long *d_hdr, const unsigned int *d_tile_off, const unsigned long long *d_chunk_off,
 									   const unsigned long long *d_stream, int width, int height, int nframes, int gop,
 									   unsigned short *d_frames, int *d_error, void *stream)
 {
@@ -83,12 +83,12 @@ RIR_EXPORT int rir_codec_decode_device(const unsigned char *d_sizes, const unsig
 	rir_codec_layout L;
 	if (rir_codec_layout_query(width, height, nframes, gop, &L) != 0)
 		return -1;
-	if (!d_frames || !d_sizes || !d_tile_off || !d_chunk_off || !d_stream || !d_error)
+	if (!d_frames || !d_hdr || !d_tile_off || !d_chunk_off || !d_stream || !d_error)
 	{
 		log_error("rir_codec_decode_device: null buffer");
 		return -1;
 	}
-	return hip_ok(launch_decode(d_sizes, d_tile_off, reinterpret_cast<const uint64_t *>(d_chunk_off), reinterpret_cast<const uint64_t *>(d_stream),
+	return hip_ok(launch_decode(reinterpret_cast<const uint64_t *>(d_hdr), d_tile_off, reinterpret_cast<const uint64_t *>(d_chunk_off), reinterpret_cast<const uint64_t *>(d_stream),
 								(int64_t)width * height, L.ntiles, nframes, gop, d_frames, d_error, as_stream(stream)),
 				  "codec decode")
 			   ? 0

@@ -48,7 +48,7 @@ class CodecLayout(ct.Structure):
         ("gop", ct.c_int),
         ("ntiles", ct.c_int),
         ("nchunks", ct.c_int),
-        ("sizes_bytes", ct.c_int64),
+        ("hdr_bytes", ct.c_int64),
         ("tile_off_bytes", ct.c_int64),
         ("chunk_off_bytes", ct.c_int64),
         ("stream_max_bytes", ct.c_int64),
@@ -108,9 +108,9 @@ def codec_layout(width, height, nframes, gop=DEFAULT_GOP):
 class EncodedBatch:
     """Device-resident compressed batch (tables + compact stream), format RIRB1."""
 
-    def __init__(self, layout, sizes, tile_off, chunk_off, stream):
+    def __init__(self, layout, hdr, tile_off, chunk_off, stream):
         self.layout = layout
-        self.sizes = sizes  # uint8  [nchunks, ntiles, gop]
+        self.hdr = hdr  # int64(bit pattern uint64) [nchunks, ntiles, gop]
         self.tile_off = tile_off  # int32(bit pattern uint32) [nchunks, ntiles+1]
         self.chunk_off = chunk_off  # int64 [nchunks+1]
         self.stream = stream  # int64 words (capacity = worst case)
@@ -121,7 +121,7 @@ class EncodedBatch:
     def compressed_bytes(self):
         """stream + tables: what a container has to store"""
         L = self.layout
-        return self.total_words() * 8 + L.sizes_bytes + L.tile_off_bytes + L.chunk_off_bytes
+        return self.total_words() * 8 + L.hdr_bytes + L.tile_off_bytes + L.chunk_off_bytes
 
 
 class CodecContext:
@@ -131,7 +131,7 @@ class CodecContext:
     def __init__(self, width, height, nframes, gop=DEFAULT_GOP, device="cuda"):
         self.layout = L = codec_layout(width, height, nframes, gop)
         dev = torch.device(device)
-        self.sizes = torch.zeros((L.nchunks, L.ntiles, L.gop), dtype=torch.uint8, device=dev)
+        self.hdr = torch.zeros((L.nchunks, L.ntiles, L.gop), dtype=torch.int64, device=dev)
         self.tile_off = torch.zeros((L.nchunks, L.ntiles + 1), dtype=torch.int32, device=dev)
         self.chunk_off = torch.zeros((L.nchunks + 1,), dtype=torch.int64, device=dev)
         self.stream = torch.empty((L.stream_max_bytes // 8,), dtype=torch.int64, device=dev)
@@ -145,22 +145,22 @@ class CodecContext:
             raise RuntimeError("encode: frames do not match the context geometry")
         _check(
             _lib.rir_codec_encode_device(
-                fr.data_ptr(), L.width, L.height, L.nframes, L.gop, self.sizes.data_ptr(), self.tile_off.data_ptr(),
+                fr.data_ptr(), L.width, L.height, L.nframes, L.gop, self.hdr.data_ptr(), self.tile_off.data_ptr(),
                 self.chunk_off.data_ptr(), self.stream.data_ptr(), self.workspace.data_ptr(), L.workspace_bytes, _stream(),
             ),
             "rir_codec_encode_device",
         )
-        return EncodedBatch(L, self.sizes, self.tile_off, self.chunk_off, self.stream)
+        return EncodedBatch(L, self.hdr, self.tile_off, self.chunk_off, self.stream)
 
     def decode(self, enc, out=None, check=True):
         L = self.layout
         if out is None:
-            out = torch.empty((L.nframes, L.height, L.width), dtype=torch.uint16, device=self.sizes.device)
+            out = torch.empty((L.nframes, L.height, L.width), dtype=torch.uint16, device=self.hdr.device)
         if check:
             self.error.zero_()
         _check(
             _lib.rir_codec_decode_device(
-                enc.sizes.data_ptr(), enc.tile_off.data_ptr(), enc.chunk_off.data_ptr(), enc.stream.data_ptr(), L.width, L.height,
+                enc.hdr.data_ptr(), enc.tile_off.data_ptr(), enc.chunk_off.data_ptr(), enc.stream.data_ptr(), L.width, L.height,
                 L.nframes, L.gop, out.data_ptr(), self.error.data_ptr(), _stream(),
             ),
             "rir_codec_decode_device",

@@ -168,24 +168,24 @@ class Oracle(_SignalProcessingMixin):
 
     # ---- codec ------------------------------------------------------------------------------
     def codec_encode_chunk(self, frames):
-        """frames: (n, H, W) uint16 -> (sizes[ntiles, n] u8, tile_off[ntiles+1] u32, stream u64[words])."""
+        """frames: (n, H, W) uint16 -> (hdr[ntiles, n] u64, tile_off[ntiles+1] u32, stream u64[words])."""
         fr = np.ascontiguousarray(frames, dtype=np.uint16)
         n, h, w = fr.shape
         nt = self.lib.orc_codec_ntiles(w, h)
-        sizes = np.zeros((nt, n), dtype=np.uint8)
+        hdr = np.zeros((nt, n), dtype=np.uint64)
         off = np.zeros(nt + 1, dtype=np.uint32)
-        stream = np.zeros(self.lib.orc_codec_max_words(w, h, n), dtype=np.uint64)
-        words = self.lib.orc_codec_encode_chunk(_p(fr), w, h, n, _p(sizes), _p(off), _p(stream))
-        return sizes, off, stream[:words].copy()
+        stream = np.zeros(max(1, self.lib.orc_codec_max_words(w, h, n)), dtype=np.uint64)
+        words = self.lib.orc_codec_encode_chunk(_p(fr), w, h, n, _p(hdr), _p(off), _p(stream))
+        return hdr, off, stream[:words].copy()
 
-    def codec_decode_chunk(self, sizes, tile_off, stream, w, h):
-        sizes = np.ascontiguousarray(sizes, dtype=np.uint8)
-        n = sizes.shape[1]
+    def codec_decode_chunk(self, hdr, tile_off, stream, w, h):
+        hdr = np.ascontiguousarray(hdr, dtype=np.uint64)
+        n = hdr.shape[1]
         out = np.zeros((n, h, w), dtype=np.uint16)
         st = np.ascontiguousarray(stream, dtype=np.uint64)
         if st.size == 0:
             st = np.zeros(1, dtype=np.uint64)
-        r = self.lib.orc_codec_decode_chunk(_p(sizes), _p(np.ascontiguousarray(tile_off, dtype=np.uint32)), _p(st), w, h, n, _p(out))
+        r = self.lib.orc_codec_decode_chunk(_p(hdr), _p(np.ascontiguousarray(tile_off, dtype=np.uint32)), _p(st), w, h, n, _p(out))
         if r != 0:
             raise RuntimeError("oracle decode: malformed stream")
         return out

@@ -573,29 +573,31 @@ EXPORT void orc_merge_planes(const uint8_t *Y, const uint8_t *U, const uint8_t *
 /*  frame  = W*H uint16 row-major, seen as a flat array, cut in TILES of 512 consecutive       */
 /*           pixels (the last tile is zero-padded);  lane l of a tile holds pixels 8l..8l+7.   */
 /*  chunk  = up to G consecutive frames; frame 0 of a chunk is a key frame.                    */
-/*  record = one (tile, frame):  64-bit header word + payload words.                           */
-/*           residual z[i]:  mode 0 RAW      z = p                                             */
-/*                           mode 1 TEMPORAL z = zigzag16(p - p_prev_frame)                    */
-/*                           mode 2 LEFT     z = zigzag16(p[i] - p[i-1]), p[-1] = 0 per tile   */
-/*           block j (j = 0..7) = the 64 residuals z[8l + j], l = 0..63; width w_j = bit       */
-/*           length of their OR (0..16).  header byte j = w_j, mode in bits 5..6 of byte 0.    */
+/*  record = one (tile, frame): a 64-bit HEADER kept in a side table + payload words.          */
+/*           prediction d[i] (mod 2^16):                                                       */
+/*                 mode 0 RAW      d = p                       (compared as unsigned)          */
+/*                 mode 1 TEMPORAL d = p - p_prev_frame        (compared as signed int16)      */
+/*                 mode 2 LEFT     d = p[i] - p[i-1], p[-1]=0  (compared as signed int16)      */
+/*           base = min(d) over the 512 pixels of the tile; residual r = d - base (mod 2^16),  */
+/*           so r is in [0, max-min] and a constant step between frames costs nothing.         */
+/*           block j (j = 0..7) = the 64 residuals r[8l + j], l = 0..63; width w_j = bit       */
+/*           length of their OR (0..16).                                                       */
+/*           header: bits [5j,5j+5) = w_j, bits [40,42) = mode, bits [48,64) = base.           */
 /*           payload: for j = 0..7, for b = 0..w_j-1: one 64-bit word, bit l = bit b of        */
-/*           z[8l + j]  (exactly what a wavefront __ballot produces).                          */
-/*           A record whose residuals are all zero in the frame's default mode (key: RAW,      */
-/*           other: TEMPORAL) is elided: size 0, no header.                                    */
-/*  sizes  = uint8 [tile][G]  record length in words (0..129)                                  */
-/*  stream = per chunk, tiles in order, each tile's records in frame order (a "segment");      */
+/*           r[8l + j]  (a 64x64 bit-matrix transpose across the wavefront).                   */
+/*  hdr    = uint64 [tile][G]   (zero for the unused frames of a short last chunk)             */
+/*  stream = per chunk, tiles in order, each tile's payload in frame order (a "segment");      */
 /*           tile_off[t] = first word of segment t (exclusive scan), uint32, ntiles+1 entries. */
-/*  Key-frame mode choice: LEFT if strictly smaller than RAW, else RAW.                        */
+/*  Key-frame mode choice: LEFT if its payload is strictly smaller than RAW's, else RAW;       */
+/*  every other frame is TEMPORAL.                                                             */
 /* ------------------------------------------------------------------------------------------ */
 
 #define TILE_PX 512
 #define MODE_RAW 0
 #define MODE_TEMPORAL 1
 #define MODE_LEFT 2
+#define REC_MAX_WORDS 128
 
-static inline uint16_t zigzag16(uint16_t d) { return (uint16_t)((uint16_t)(d << 1) ^ (uint16_t)(((int16_t)d) >> 15)); }
-static inline uint16_t unzigzag16(uint16_t z) { return (uint16_t)((z >> 1) ^ (uint16_t)(-(int16_t)(z & 1))); }
 static inline int bitlen16(uint16_t v)
 {
 	int n = 0;
@@ -609,51 +611,66 @@ static inline int bitlen16(uint16_t v)
 
 EXPORT int orc_codec_ntiles(int w, int h) { return (int)(((int64_t)w * h + TILE_PX - 1) / TILE_PX); }
 /* worst-case words of one chunk's stream */
-EXPORT int64_t orc_codec_max_words(int w, int h, int nframes) { return (int64_t)orc_codec_ntiles(w, h) * nframes * 129; }
+EXPORT int64_t orc_codec_max_words(int w, int h, int nframes) { return (int64_t)orc_codec_ntiles(w, h) * nframes * REC_MAX_WORDS; }
 
-static int record_words(const uint16_t *z, int *widths)
+/* d -> (base, r, widths); returns the payload length in words */
+static int residual_widths(const uint16_t *d, int is_signed, uint16_t *base_out, uint16_t *r, int *widths)
 {
+	uint16_t base = d[0];
+	for (int i = 1; i < TILE_PX; ++i)
+	{
+		if (is_signed ? ((int16_t)d[i] < (int16_t)base) : (d[i] < base))
+			base = d[i];
+	}
 	int total = 0;
+	for (int i = 0; i < TILE_PX; ++i)
+		r[i] = (uint16_t)(d[i] - base);
 	for (int j = 0; j < 8; ++j)
 	{
 		uint16_t o = 0;
 		for (int l = 0; l < 64; ++l)
-			o |= z[8 * l + j];
+			o |= r[8 * l + j];
 		widths[j] = bitlen16(o);
 		total += widths[j];
 	}
+	*base_out = base;
 	return total;
 }
 
-static int emit_record(const uint16_t *z, const int *widths, int mode, uint64_t *out)
+static int emit_payload(const uint16_t *r, const int *widths, uint64_t *out)
 {
-	uint64_t hdr = 0;
-	for (int j = 0; j < 8; ++j)
-		hdr |= (uint64_t)widths[j] << (8 * j);
-	hdr |= (uint64_t)mode << 5;
 	int k = 0;
-	out[k++] = hdr;
 	for (int j = 0; j < 8; ++j)
 		for (int b = 0; b < widths[j]; ++b)
 		{
 			uint64_t m = 0;
 			for (int l = 0; l < 64; ++l)
-				m |= (uint64_t)((z[8 * l + j] >> b) & 1) << l;
+				m |= (uint64_t)((r[8 * l + j] >> b) & 1) << l;
 			out[k++] = m;
 		}
 	return k;
 }
 
-/* Encode one chunk of `nframes` frames.  sizes: uint8[ntiles*nframes] ([tile][frame]);
+static uint64_t make_header(const int *widths, int mode, uint16_t base)
+{
+	uint64_t hdr = 0;
+	for (int j = 0; j < 8; ++j)
+		hdr |= (uint64_t)widths[j] << (5 * j);
+	hdr |= (uint64_t)mode << 40;
+	hdr |= (uint64_t)base << 48;
+	return hdr;
+}
+
+/* Encode one chunk of `nframes` frames.  hdr: uint64[ntiles*nframes] ([tile][frame]);
  * tile_off: uint32[ntiles+1]; stream: >= orc_codec_max_words words.  Returns total words. */
 EXPORT int64_t orc_codec_encode_chunk(const uint16_t *frames, int w, int h, int nframes,
-									  uint8_t *sizes, uint32_t *tile_off, uint64_t *stream)
+									  uint64_t *hdr, uint32_t *tile_off, uint64_t *stream)
 {
 	const int64_t npx = (int64_t)w * h;
 	const int ntiles = orc_codec_ntiles(w, h);
 	int64_t pos = 0;
-	uint16_t cur[TILE_PX], prev[TILE_PX], z[TILE_PX], zl[TILE_PX];
-	int widths[8], widths_l[8];
+	uint16_t cur[TILE_PX], prev[TILE_PX], d[TILE_PX], r[TILE_PX], r2[TILE_PX];
+	int widths[8], widths2[8];
 	for (int t = 0; t < ntiles; ++t)
 	{
 		tile_off[t] = (uint32_t)pos;
@@ -666,36 +683,34 @@ EXPORT int64_t orc_codec_encode_chunk(const uint16_t *frames, int w, int h, int 
 				cur[i] = p < npx ? frames[(int64_t)f * npx + p] : 0;
 			}
 			int mode, total;
+			uint16_t base;
 			if (f == 0)
 			{
+				uint16_t base2;
+				total = residual_widths(cur, 0, &base, r, widths);
 				for (int i = 0; i < TILE_PX; ++i)
-				{
-					z[i] = cur[i];
-					zl[i] = zigzag16((uint16_t)(cur[i] - (i ? cur[i - 1] : 0)));
-				}
-				total = record_words(z, widths);
-				int total_l = record_words(zl, widths_l);
+					d[i] = (uint16_t)(cur[i] - (i ? cur[i - 1] : 0));
+				int total2 = residual_widths(d, 1, &base2, r2, widths2);
 				mode = MODE_RAW;
-				if (total_l < total)
+				if (total2 < total)
 				{
 					mode = MODE_LEFT;
-					total = total_l;
-					memcpy(z, zl, sizeof(z));
-					memcpy(widths, widths_l, sizeof(widths));
+					total = total2;
+					base = base2;
+					memcpy(r, r2, sizeof(r));
+					memcpy(widths, widths2, sizeof(widths));
 				}
 			}
 			else
 			{
 				for (int i = 0; i < TILE_PX; ++i)
-					z[i] = zigzag16((uint16_t)(cur[i] - prev[i]));
-				total = record_words(z, widths);
+					d[i] = (uint16_t)(cur[i] - prev[i]);
+				total = residual_widths(d, 1, &base, r, widths);
 				mode = MODE_TEMPORAL;
 			}
-			int words = 0;
-			if (total > 0)
-				words = emit_record(z, widths, mode, stream + pos);
-			sizes[(int64_t)t * nframes + f] = (uint8_t)words;
-			pos += words;
+			hdr[(int64_t)t * nframes + f] = make_header(widths, mode, base);
+			pos += emit_payload(r, widths, stream + pos);
+			(void)total;
 			memcpy(prev, cur, sizeof(prev));
 		}
 	}
@@ -703,53 +718,48 @@ EXPORT int64_t orc_codec_encode_chunk(const uint16_t *frames, int w, int h, int 
 	return pos;
 }
 
-/* Decode one chunk.  Returns 0, or -1 on a malformed record. */
-EXPORT int orc_codec_decode_chunk(const uint8_t *sizes, const uint32_t *tile_off, const uint64_t *stream,
+/* Decode one chunk.  Returns 0, or -1 on a malformed header / table. */
+EXPORT int orc_codec_decode_chunk(const uint64_t *hdr, const uint32_t *tile_off, const uint64_t *stream,
 								  int w, int h, int nframes, uint16_t *frames)
 {
 	const int64_t npx = (int64_t)w * h;
 	const int ntiles = orc_codec_ntiles(w, h);
-	uint16_t cur[TILE_PX], prev[TILE_PX], z[TILE_PX];
+	uint16_t cur[TILE_PX], prev[TILE_PX], r[TILE_PX];
 	for (int t = 0; t < ntiles; ++t)
 	{
 		int64_t pos = tile_off[t];
+		const int64_t end = tile_off[t + 1];
 		memset(prev, 0, sizeof(prev));
 		for (int f = 0; f < nframes; ++f)
 		{
-			int words = sizes[(int64_t)t * nframes + f];
-			int mode = f == 0 ? MODE_RAW : MODE_TEMPORAL;
-			memset(z, 0, sizeof(z));
-			if (words)
+			const uint64_t H = hdr[(int64_t)t * nframes + f];
+			const int mode = (int)((H >> 40) & 3);
+			const uint16_t base = (uint16_t)(H >> 48);
+			memset(r, 0, sizeof(r));
+			for (int j = 0; j < 8; ++j)
 			{
-				uint64_t hdr = stream[pos];
-				mode = (int)((hdr >> 5) & 3);
-				int k = 1;
-				for (int j = 0; j < 8; ++j)
-				{
-					int wj = (int)((hdr >> (8 * j)) & 31);
-					if (wj > 16 || k + wj > words)
-						return -1;
-					for (int b = 0; b < wj; ++b)
-					{
-						uint64_t m = stream[pos + k++];
-						for (int l = 0; l < 64; ++l)
-							z[8 * l + j] |= (uint16_t)(((m >> l) & 1) << b);
-					}
-				}
-				if (k != words)
+				int wj = (int)((H >> (5 * j)) & 31);
+				if (wj > 16 || pos + wj > end)
 					return -1;
+				for (int b = 0; b < wj; ++b)
+				{
+					uint64_t m = stream[pos++];
+					for (int l = 0; l < 64; ++l)
+						r[8 * l + j] |= (uint16_t)(((m >> l) & 1) << b);
+				}
 			}
 			if (mode == MODE_RAW)
-				memcpy(cur, z, sizeof(cur));
+				for (int i = 0; i < TILE_PX; ++i)
+					cur[i] = (uint16_t)(r[i] + base);
 			else if (mode == MODE_TEMPORAL)
 				for (int i = 0; i < TILE_PX; ++i)
-					cur[i] = (uint16_t)(prev[i] + unzigzag16(z[i]));
+					cur[i] = (uint16_t)(prev[i] + r[i] + base);
 			else if (mode == MODE_LEFT)
 			{
 				uint16_t acc = 0;
 				for (int i = 0; i < TILE_PX; ++i)
 				{
-					acc = (uint16_t)(acc + unzigzag16(z[i]));
+					acc = (uint16_t)(acc + r[i] + base);
 					cur[i] = acc;
 				}
 			}
@@ -762,8 +772,9 @@ EXPORT int orc_codec_decode_chunk(const uint8_t *sizes, const uint32_t *tile_off
 					frames[(int64_t)f * npx + p] = cur[i];
 			}
 			memcpy(prev, cur, sizeof(prev));
-			pos += words;
 		}
+		if (pos != end)
+			return -1;
 	}
 	return 0;
 }

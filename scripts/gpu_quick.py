@@ -18,12 +18,12 @@ for (n,h,w,gop) in [(5,67,83,3),(7,48,64,50),(3,20,20,2),(130,16,32,128),(4,64,6
     ok = np.array_equal(dec.cpu().numpy(), fr)
     # bitstream vs oracle per chunk
     L = ctx.layout
-    sizes = enc.sizes.cpu().numpy(); toff = enc.tile_off.cpu().numpy().view(np.uint32); coff = enc.chunk_off.cpu().numpy(); st = enc.stream.cpu().numpy().view(np.uint64)
+    hdr = enc.hdr.cpu().numpy().view(np.uint64); toff = enc.tile_off.cpu().numpy().view(np.uint32); coff = enc.chunk_off.cpu().numpy(); st = enc.stream.cpu().numpy().view(np.uint64)
     same = True
     for c in range(L.nchunks):
         f0 = c*gop; nf = min(gop, n-f0)
-        s_o, o_o, st_o = O.codec_encode_chunk(fr[f0:f0+nf])
-        same &= np.array_equal(sizes[c][:, :nf], s_o) and np.array_equal(toff[c], o_o) and np.array_equal(st[coff[c]:coff[c+1]], st_o) and (sizes[c][:, nf:]==0).all()
+        h_o, o_o, st_o = O.codec_encode_chunk(fr[f0:f0+nf])
+        same &= np.array_equal(hdr[c][:, :nf], h_o) and np.array_equal(toff[c], o_o) and np.array_equal(st[coff[c]:coff[c+1]], st_o) and (hdr[c][:, nf:]==0).all()
     chk(f"codec {n}x{h}x{w} gop{gop} roundtrip", ok); chk(f"codec {n}x{h}x{w} gop{gop} bitstream==oracle", same)
 # --- codec full size timing
 n,h,w=1000,512,640

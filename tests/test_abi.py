@@ -1,0 +1,113 @@
+"""CPU: the C-ABI shared object loads, exports every symbol include/*.h declares, and fails loudly
+(no CPU fallback) when no HIP device is present."""
+import ctypes as ct
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    names = set()
+    for hdr in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = open(hdr).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        text = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", "", text, flags=re.S)
+        text = re.sub(r"typedef[^;]*;", "", text)
+        for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_]*)\s*\(", text):
+            n = m.group(1)
+            if n not in ("defined", "__attribute__", "sizeof", "visibility", "void"):
+                names.add(n)
+    return sorted(names)
+
+
+def test_headers_declare_something():
+    syms = declared_symbols()
+    for must in ["translate", "gaussian_filter", "bad_pixels_create", "rir_codec_encode_device", "rir_codec_decode_device"]:
+        assert must in syms
+
+
+def test_every_declared_symbol_is_exported(lib):
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, "declared in include/*.h but not exported: %s" % missing
+
+
+def test_aliases_resolve_to_one_object():
+    libs = os.path.join(ROOT, "librir_amd", "libs")
+    for alias in ["libtools.so", "libsignal_processing.so", "libvideo_io.so"]:
+        assert os.path.realpath(os.path.join(libs, alias)) == os.path.realpath(os.path.join(libs, "librir_amd.so"))
+
+
+def test_layout_query_is_pure_host(lib):
+    from librir_amd.device import codec_layout
+
+    L = codec_layout(640, 512, 1000, 50)
+    assert (L.ntiles, L.nchunks) == (640, 20)
+    assert L.hdr_bytes == 640 * 20 * 50 * 8 and L.tile_off_bytes == 20 * 641 * 4 and L.chunk_off_bytes == 21 * 8
+    L = codec_layout(83, 67, 5, 3)
+    assert (L.ntiles, L.nchunks) == ((83 * 67 + 511) // 512, 2)
+    with pytest.raises(RuntimeError):
+        codec_layout(0, 512, 10, 50)
+
+
+def test_argument_errors_do_not_need_a_device(lib):
+    # reference conventions: unknown dtype char / strategy -> -1 (signal_processing.cpp:40-41,70-71)
+    a = np.zeros((4, 4), np.uint16)
+    b = a.copy()
+    bg = np.zeros(1, np.uint16)
+    lib.translate.argtypes = [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_float, ct.c_float, ct.c_void_p, ct.c_char_p]
+    assert lib.translate(ord("H"), a.ctypes.data, b.ctypes.data, 4, 4, 0.0, 0.0, bg.ctypes.data, b"bogus") == -1
+    assert lib.translate(ord("Z"), a.ctypes.data, b.ctypes.data, 4, 4, 0.0, 0.0, bg.ctypes.data, b"wrap") == -1
+    lib.bad_pixels_correct.argtypes = [ct.c_int, ct.c_void_p, ct.c_void_p]
+    assert lib.bad_pixels_correct(12345, a.ctypes.data, b.ctypes.data) == -1
+
+
+def test_no_cpu_fallback_without_device(lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from librir_amd.low_level.misc import last_error
+
+    assert lib.rir_device_available() == 0
+    a = np.arange(16, dtype=np.uint16).reshape(4, 4)
+    b = a.copy()
+    bg = np.zeros(1, np.uint16)
+    lib.translate.argtypes = [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_float, ct.c_float, ct.c_void_p, ct.c_char_p]
+    assert lib.translate(ord("H"), a.ctypes.data, b.ctypes.data, 4, 4, 1.0, 0.0, bg.ctypes.data, b"nearest") == -1
+    assert "no usable HIP device" in last_error()
+    assert np.array_equal(a, b)  # nothing was computed anywhere
+    lib.bad_pixels_create.argtypes = [ct.c_void_p, ct.c_int, ct.c_int]
+    assert lib.bad_pixels_create(a.ctypes.data, 4, 4) == 0
+
+
+def test_handle_registry_and_log(lib):
+    from librir_amd.low_level.misc import last_error
+
+    assert lib.get_void_ptr(987654) in (None, 0)
+    lib.rm_void_ptr(987654)  # unknown handle: no-op
+    lib.bad_pixels_destroy(987654)
+    n = ct.c_int(0)
+    lib.rir_codec_layout_query(0, 0, 0, 0, None)
+    assert "rir_codec_layout_query" in last_error()
+    assert lib.get_last_log_error(None, ct.byref(n)) == -1 and n.value > 0
+
+
+def test_hash_bytes_matches_reference(lib):
+    from oracle.pyoracle import Ref
+
+    if not Ref.available():
+        pytest.skip("oracle/_ref not built here")
+    r = Ref()
+    for f in (lib.hash_bytes, r.lib.hash_bytes):
+        f.argtypes = [ct.c_void_p, ct.c_size_t]
+        f.restype = ct.c_size_t
+    rng = np.random.default_rng(0)
+    for n in [0, 1, 7, 8, 9, 15, 16, 31, 1000]:
+        buf = rng.integers(0, 256, max(n, 1)).astype(np.uint8)
+        assert lib.hash_bytes(buf.ctypes.data, n) == r.lib.hash_bytes(buf.ctypes.data, n)
