@@ -48,6 +48,14 @@ extern "C"
 								unsigned int *d_tile_off, unsigned long long *d_chunk_off, unsigned long long *d_stream, void *d_workspace,
 								long long workspace_bytes, void *stream);
 
+	/* The two stages of rir_codec_encode_device, callable separately (same workspace): stage 1 is
+	 * the single pass over the raw frames (headers + sparse payload), stage 2 computes the
+	 * offsets and gathers the payload into the dense stream. */
+	int rir_codec_encode_tiles_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned long long *d_hdr,
+									  void *d_workspace, long long workspace_bytes, void *stream);
+	int rir_codec_encode_compact_device(int width, int height, int nframes, int gop, unsigned int *d_tile_off, unsigned long long *d_chunk_off,
+										unsigned long long *d_stream, void *d_workspace, long long workspace_bytes, void *stream);
+
 	/* *d_error (device int, zero it first) becomes 1 when a malformed table/record was met. */
 	int rir_codec_decode_device(const unsigned long long *d_hdr, const unsigned int *d_tile_off, const unsigned long long *d_chunk_off,
 								const unsigned long long *d_stream, int width, int height, int nframes, int gop, unsigned short *d_frames,

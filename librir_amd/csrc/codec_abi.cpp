@@ -42,36 +42,89 @@ RIR_EXPORT int rir_codec_layout_query(int width, int height, int nframes, int go
 	return 0;
 }
 
-RIR_EXPORT int rir_codec_encode_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned long long *d_hdr,
-									   unsigned int *d_tile_off, unsigned long long *d_chunk_off, unsigned long long *d_stream,
-									   void *d_workspace, long long workspace_bytes, void *stream)
+namespace
+{
+	struct Workspace
+	{
+		uint64_t *sparse;
+		uint32_t *seg_words;
+		uint64_t *chunk_words;
+	};
+	bool carve(const rir_codec_layout &L, void *d_workspace, long long workspace_bytes, Workspace &w)
+	{
+		if (!d_workspace || workspace_bytes < L.workspace_bytes)
+			return false;
+		char *ws = static_cast<char *>(d_workspace);
+		w.sparse = reinterpret_cast<uint64_t *>(ws);
+		ws += align256((size_t)L.stream_max_bytes);
+		w.seg_words = reinterpret_cast<uint32_t *>(ws);
+		ws += align256((size_t)L.nchunks * L.ntiles * 4);
+		w.chunk_words = reinterpret_cast<uint64_t *>(ws);
+		return true;
+	}
+	bool check_geometry(const rir_codec_layout &L)
+	{
+		if ((int64_t)L.ntiles * L.gop * RIRB1_REC_MAX_WORDS > 0xffffffffLL)
+		{
+			log_error("rir_codec_encode: chunk too large for 32-bit tile offsets");
+			return false;
+		}
+		return true;
+	}
+} // namespace
+
+// Stage 1 of the encoder: the single pass over the raw frames (headers + sparse payload).
+RIR_EXPORT int rir_codec_encode_tiles_device(const unsigned short *d_frames, int width, int height, int nframes, int gop,
+											 unsigned long long *d_hdr, void *d_workspace, long long workspace_bytes, void *stream)
 {
 	if (!device_ready())
 		return -1;
 	rir_codec_layout L;
-	if (rir_codec_layout_query(width, height, nframes, gop, &L) != 0)
+	Workspace w;
+	if (rir_codec_layout_query(width, height, nframes, gop, &L) != 0 || !check_geometry(L))
 		return -1;
-	if (!d_frames || !d_hdr || !d_tile_off || !d_chunk_off || !d_stream || !d_workspace || workspace_bytes < L.workspace_bytes)
+	if (!d_frames || !d_hdr || !carve(L, d_workspace, workspace_bytes, w))
 	{
-		log_error("rir_codec_encode_device: null buffer or workspace too small");
+		log_error("rir_codec_encode_tiles_device: null buffer or workspace too small");
 		return -1;
 	}
-	if ((int64_t)L.ntiles * gop * RIRB1_REC_MAX_WORDS > 0xffffffffLL)
-	{
-		log_error("rir_codec_encode_device: chunk too large for 32-bit tile offsets");
-		return -1;
-	}
-	char *ws = static_cast<char *>(d_workspace);
-	uint64_t *d_sparse = reinterpret_cast<uint64_t *>(ws);
-	ws += align256((size_t)L.stream_max_bytes);
-	uint32_t *d_seg_words = reinterpret_cast<uint32_t *>(ws);
-	ws += align256((size_t)L.nchunks * L.ntiles * 4);
-	uint64_t *d_chunk_words = reinterpret_cast<uint64_t *>(ws);
-	return hip_ok(launch_encode(d_frames, (int64_t)width * height, L.ntiles, nframes, gop, reinterpret_cast<uint64_t *>(d_hdr), d_seg_words, d_sparse, d_tile_off, d_chunk_words,
-								reinterpret_cast<uint64_t *>(d_chunk_off), reinterpret_cast<uint64_t *>(d_stream), as_stream(stream)),
-				  "codec encode")
+	return hip_ok(launch_encode_tiles(d_frames, (int64_t)width * height, L.ntiles, nframes, gop, reinterpret_cast<uint64_t *>(d_hdr), w.seg_words,
+									  w.sparse, as_stream(stream)),
+				  "codec encode (tiles)")
 			   ? 0
 			   : -1;
+}
+
+// Stage 2 of the encoder: offsets + compaction of the sparse payload into the dense stream.
+RIR_EXPORT int rir_codec_encode_compact_device(int width, int height, int nframes, int gop, unsigned int *d_tile_off,
+											   unsigned long long *d_chunk_off, unsigned long long *d_stream, void *d_workspace,
+											   long long workspace_bytes, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	rir_codec_layout L;
+	Workspace w;
+	if (rir_codec_layout_query(width, height, nframes, gop, &L) != 0 || !check_geometry(L))
+		return -1;
+	if (!d_tile_off || !d_chunk_off || !d_stream || !carve(L, d_workspace, workspace_bytes, w))
+	{
+		log_error("rir_codec_encode_compact_device: null buffer or workspace too small");
+		return -1;
+	}
+	return hip_ok(launch_encode_compact(L.ntiles, nframes, gop, w.seg_words, w.sparse, d_tile_off, w.chunk_words,
+										reinterpret_cast<uint64_t *>(d_chunk_off), reinterpret_cast<uint64_t *>(d_stream), as_stream(stream)),
+				  "codec encode (compact)")
+			   ? 0
+			   : -1;
+}
+
+RIR_EXPORT int rir_codec_encode_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned long long *d_hdr,
+									   unsigned int *d_tile_off, unsigned long long *d_chunk_off, unsigned long long *d_stream,
+									   void *d_workspace, long long workspace_bytes, void *stream)
+{
+	if (rir_codec_encode_tiles_device(d_frames, width, height, nframes, gop, d_hdr, d_workspace, workspace_bytes, stream) != 0)
+		return -1;
+	return rir_codec_encode_compact_device(width, height, nframes, gop, d_tile_off, d_chunk_off, d_stream, d_workspace, workspace_bytes, stream);
 }
 
 RIR_EXPORT int rir_codec_decode_device(const unsigned long long *d_hdr, const unsigned int *d_tile_off, const unsigned long long *d_chunk_off,

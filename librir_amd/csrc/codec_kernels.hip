@@ -594,13 +594,22 @@ namespace rir
 
 	// ---- host launchers --------------------------------------------------------------------------------
 
-	hipError_t launch_encode(const uint16_t *d_frames, int64_t npx, int ntiles, int nframes, int gop, uint64_t *d_hdr, uint32_t *d_seg_words,
-							 uint64_t *d_sparse, uint32_t *d_tile_off, uint64_t *d_chunk_words, uint64_t *d_chunk_off, uint64_t *d_stream,
-							 hipStream_t st)
+	// stage 1: one pass over the raw frames -> headers, per-tile segment lengths, sparse payload
+	hipError_t launch_encode_tiles(const uint16_t *d_frames, int64_t npx, int ntiles, int nframes, int gop, uint64_t *d_hdr,
+								   uint32_t *d_seg_words, uint64_t *d_sparse, hipStream_t st)
 	{
 		const int nchunks = (nframes + gop - 1) / gop;
 		dim3 grid((ntiles + 3) / 4, nchunks), block(256);
 		hipLaunchKernelGGL(rirb1_encode_tiles, grid, block, 0, st, d_frames, npx, ntiles, nframes, gop, d_hdr, d_seg_words, d_sparse);
+		return hipGetLastError();
+	}
+
+	// stage 2: offsets (exclusive scans) + gather of the sparse slots into the compact stream
+	hipError_t launch_encode_compact(int ntiles, int nframes, int gop, const uint32_t *d_seg_words, const uint64_t *d_sparse,
+									 uint32_t *d_tile_off, uint64_t *d_chunk_words, uint64_t *d_chunk_off, uint64_t *d_stream, hipStream_t st)
+	{
+		const int nchunks = (nframes + gop - 1) / gop;
+		dim3 block(256);
 		hipLaunchKernelGGL(rirb1_scan_tiles, dim3(nchunks), block, 0, st, d_seg_words, ntiles, d_tile_off, d_chunk_words);
 		hipLaunchKernelGGL(rirb1_compact, dim3(ntiles, nchunks), block, 0, st, d_sparse, d_tile_off, d_chunk_words, ntiles, nchunks, gop,
 						   d_chunk_off, d_stream);

@@ -61,6 +61,8 @@ _lib.rir_device_available.restype = ct.c_int
 _lib.rir_stream_synchronize.argtypes = [_vp]
 _lib.rir_codec_layout_query.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(CodecLayout)]
 _lib.rir_codec_encode_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, _vp, ct.c_longlong, _vp]
+_lib.rir_codec_encode_tiles_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, ct.c_longlong, _vp]
+_lib.rir_codec_encode_compact_device.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, ct.c_longlong, _vp]
 _lib.rir_codec_decode_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.rir_translate_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp, ct.c_int, _vp, ct.c_char_p, _vp]
 _lib.rir_gaussian_filter_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_float, _vp]
@@ -150,6 +152,22 @@ class CodecContext:
             ),
             "rir_codec_encode_device",
         )
+        return EncodedBatch(L, self.hdr, self.tile_off, self.chunk_off, self.stream)
+
+    def encode_tiles(self, frames):
+        """stage 1 only (single pass over the raw frames); finish with encode_compact()"""
+        L = self.layout
+        fr = _frames3(frames, torch.uint16)
+        if tuple(fr.shape) != (L.nframes, L.height, L.width):
+            raise RuntimeError("encode: frames do not match the context geometry")
+        _check(_lib.rir_codec_encode_tiles_device(fr.data_ptr(), L.width, L.height, L.nframes, L.gop, self.hdr.data_ptr(),
+                                                  self.workspace.data_ptr(), L.workspace_bytes, _stream()), "rir_codec_encode_tiles_device")
+
+    def encode_compact(self):
+        L = self.layout
+        _check(_lib.rir_codec_encode_compact_device(L.width, L.height, L.nframes, L.gop, self.tile_off.data_ptr(), self.chunk_off.data_ptr(),
+                                                    self.stream.data_ptr(), self.workspace.data_ptr(), L.workspace_bytes, _stream()),
+               "rir_codec_encode_compact_device")
         return EncodedBatch(L, self.hdr, self.tile_off, self.chunk_off, self.stream)
 
     def decode(self, enc, out=None, check=True):

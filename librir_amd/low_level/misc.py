@@ -15,6 +15,14 @@ _LIB_PATH = os.path.join(_HERE, "libs", "librir_amd.so")
 
 
 def _load():
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and must map it before
+    # this library's dependency on the system one is resolved (same SONAME -> the loader then
+    # reuses the copy already mapped).  torch is optional plumbing; without it the system runtime
+    # under /opt/rocm is used.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(_LIB_PATH):
         raise ImportError(
             "librir_amd: %s is missing - build it with `python -m librir_amd.build` "
