@@ -111,30 +111,37 @@ namespace rir
 		c.a1 = (lane & 1) ? 1 : 31;
 		return c;
 	}
-	__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (mask & a) | (~mask & b); }
+	// (mask & a) | (~mask & b) in one VALU op: v_bitop3_b32 with the truth table of a 3-input mux
+	__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xCA); }
 
 #define RIR_XOR16(x) ((uint32_t)__builtin_amdgcn_ds_swizzle((int)(x), (16 << 10) | 0x1f))
-#define RIR_XOR8(x) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x128, 0xf, 0xf, false)) /* row_ror:8 */
+#define RIR_XOR8(x) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(x), 0x128, 0xf, 0xf, false)) /* row_ror:8 */
 #define RIR_XOR4(x) ((uint32_t)__builtin_amdgcn_ds_swizzle((int)(x), (4 << 10) | 0x1f))
-#define RIR_XOR2(x) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0x4e, 0xf, 0xf, false)) /* quad_perm:[2,3,0,1] */
-#define RIR_XOR1(x) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), 0xb1, 0xf, 0xf, false)) /* quad_perm:[1,0,3,2] */
-#define RIR_TSTAGE(X, K, A)                                   \
-	{                                                         \
-		const uint32_t tl = X(lo), th = X(hi);                \
-		lo = bfi(K, __builtin_amdgcn_alignbit(tl, tl, A), lo); \
-		hi = bfi(K, __builtin_amdgcn_alignbit(th, th, A), hi); \
+#define RIR_XOR2(x) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(x), 0x4e, 0xf, 0xf, false)) /* quad_perm:[2,3,0,1] */
+#define RIR_XOR1(x) ((uint32_t)__builtin_amdgcn_mov_dpp((int)(x), 0xb1, 0xf, 0xf, false)) /* quad_perm:[1,0,3,2] */
+#define RIR_TSTAGE2(X, K, A)                                    \
+	{                                                           \
+		const uint32_t t0 = X(a0), t1 = X(a1), t2 = X(b0), t3 = X(b1); \
+		a0 = bfi(K, __builtin_amdgcn_alignbit(t0, t0, A), a0);   \
+		a1 = bfi(K, __builtin_amdgcn_alignbit(t1, t1, A), a1);   \
+		b0 = bfi(K, __builtin_amdgcn_alignbit(t2, t2, A), b0);   \
+		b1 = bfi(K, __builtin_amdgcn_alignbit(t3, t3, A), b1);   \
 	}
 
-	__device__ __forceinline__ void transpose64(uint32_t &lo, uint32_t &hi, const TransposeConsts &c)
+	// two independent transposes, stage by stage (4 independent dword chains fill the DPP/LDS latency)
+	__device__ __forceinline__ void transpose64x2(uint32_t &a0, uint32_t &a1, uint32_t &b0, uint32_t &b1, const TransposeConsts &c)
 	{
-		auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false); // lo[32..63] <-> hi[0..31]
-		lo = r[0];
-		hi = r[1];
-		RIR_TSTAGE(RIR_XOR16, c.k16, c.a16)
-		RIR_TSTAGE(RIR_XOR8, c.k8, c.a8)
-		RIR_TSTAGE(RIR_XOR4, c.k4, c.a4)
-		RIR_TSTAGE(RIR_XOR2, c.k2, c.a2)
-		RIR_TSTAGE(RIR_XOR1, c.k1, c.a1)
+		auto ra = __builtin_amdgcn_permlane32_swap(a0, a1, false, false); // lo[32..63] <-> hi[0..31]
+		auto rb = __builtin_amdgcn_permlane32_swap(b0, b1, false, false);
+		a0 = ra[0];
+		a1 = ra[1];
+		b0 = rb[0];
+		b1 = rb[1];
+		RIR_TSTAGE2(RIR_XOR16, c.k16, c.a16)
+		RIR_TSTAGE2(RIR_XOR8, c.k8, c.a8)
+		RIR_TSTAGE2(RIR_XOR4, c.k4, c.a4)
+		RIR_TSTAGE2(RIR_XOR2, c.k2, c.a2)
+		RIR_TSTAGE2(RIR_XOR1, c.k1, c.a1)
 	}
 
 	// ---- tile I/O ------------------------------------------------------------------------------------
@@ -194,6 +201,44 @@ namespace rir
 		}
 	}
 
+	// ---- buffer-resource addressing -------------------------------------------------------------
+	// Every vector-memory operation of the steady-state loops is an UNCONDITIONAL raw-buffer access:
+	// lanes that must not touch memory get an out-of-range offset (the hardware drops the store /
+	// returns 0 for the load), so no branch surrounds a memory instruction and the compiler can keep
+	// exact s_waitcnt vmcnt(N) counts - which is what lets three frames stay in flight per wave.
+	typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
+	typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
+#define RIR_BUF_FLAGS 0x00020000 /* raw buffer, 32-bit data format (gfx942/gfx950 descriptor word 3) */
+#define RIR_OOB 0x40000000u		 /* beyond any num_records used here */
+
+	__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes)
+	{
+		// the base is wave-uniform by construction; readfirstlane makes that provable
+		const uint64_t b = (uint64_t)base;
+		const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+		const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+		return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)bytes, RIR_BUF_FLAGS);
+	}
+	__device__ __forceinline__ Px8 buf_load8(const void *tile_base, uint32_t lane_off)
+	{
+		const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(tile_base, RIRB1_TILE_PX * 2), lane_off, 0, 0);
+		Px8 r;
+		r.d[0] = v.x;
+		r.d[1] = v.y;
+		r.d[2] = v.z;
+		r.d[3] = v.w;
+		return r;
+	}
+	__device__ __forceinline__ void buf_store8(void *tile_base, uint32_t lane_off, const Px8 &r)
+	{
+		v4u32 v;
+		v.x = r.d[0];
+		v.y = r.d[1];
+		v.z = r.d[2];
+		v.w = r.d[3];
+		__builtin_amdgcn_raw_buffer_store_b128(v, make_rsrc(tile_base, RIRB1_TILE_PX * 2), lane_off, 0, 0);
+	}
+
 	// tile minimum of the 8 packed values of every lane -> wave-uniform 16-bit base
 	__device__ __forceinline__ uint32_t tile_base(const Px8 &d, bool is_signed)
 	{
@@ -238,80 +283,105 @@ namespace rir
 		return tot;
 	}
 
-	// slot placement word (first word | width << 16) of this lane's 16-lane group
-	__device__ __forceinline__ uint32_t select4(uint32_t s0, uint32_t s1, uint32_t s2, uint32_t s3, int grp)
+	// ---- per-lane bookkeeping of a record (no scalar-unit work) ---------------------------------
+	// After the transposes lane 16q+k holds plane k of slot q (half A) and of slot 4+q (half B).
+	struct LaneConsts
 	{
-		return grp == 0 ? s0 : (grp == 1 ? s1 : (grp == 2 ? s2 : s3));
+		uint32_t bit;	 // k = lane & 15
+		uint32_t bitp1;	 // k + 1
+		uint32_t onehot; // 1 << k
+		uint32_t sh4;	 // 4 * q   (base nibble of this row)
+		uint32_t sh16;	 // 16 * (q & 1)
+		bool row_hi;	 // q >= 2 : this row's header field is in the high dword
+		bool row0;		 // q == 0
+	};
+	__device__ __forceinline__ LaneConsts make_lane_consts(int lane)
+	{
+		LaneConsts c;
+		const uint32_t q = (uint32_t)lane >> 4;
+		c.bit = lane & 15;
+		c.bitp1 = c.bit + 1;
+		c.onehot = 1u << c.bit;
+		c.sh4 = 4 * q;
+		c.sh16 = 16 * (q & 1);
+		c.row_hi = q >= 2;
+		c.row0 = q == 0;
+		return c;
 	}
 
-	// Emit the payload of one record: residuals r (packed pairs) -> plane words at out[0..words).
-	// Returns the header (widths | mode | base).
-	__device__ __forceinline__ uint64_t emit_record(const Px8 &r, uint32_t mode, uint32_t base, uint64_t *__restrict__ out, int grp, uint32_t bit,
-													const TransposeConsts &tc, uint32_t *words)
+	// max over the 16 lanes of a row, result in every lane (4 DPP rotations)
+	__device__ __forceinline__ uint32_t row_allmax(uint32_t v)
+	{
+		v = max(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x121, 0xf, 0xf, false)); // row_ror:1
+		v = max(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x122, 0xf, 0xf, false)); // row_ror:2
+		v = max(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x124, 0xf, 0xf, false)); // row_ror:4
+		v = max(v, (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, false)); // row_ror:8
+		return v;
+	}
+	// w: row-uniform value.  Returns the inclusive sum over rows 0..q (row-uniform); row 3 holds the total.
+	__device__ __forceinline__ uint32_t rows_inclusive_sum(uint32_t w)
+	{
+		const uint32_t s = w + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1,3
+		return s + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x143, 0xc, 0xf, false);			  // row_bcast:31 -> rows 2,3
+	}
+
+	// Emit the payload of one record: residuals r (packed pairs) -> plane words at out[pos..pos+words).
+	// Returns the header; `modebits` = mode << 14 in row 0, zero elsewhere.
+	__device__ __forceinline__ uint64_t emit_record(const Px8 &r, uint32_t modebits, uint32_t base, __amdgpu_buffer_rsrc_t out, uint32_t pos,
+													const LaneConsts &lc, const TransposeConsts &tc, uint32_t *words)
 	{
 		uint32_t alo = r.d[0], ahi = r.d[1], blo = r.d[2], bhi = r.d[3];
-		transpose64(alo, ahi, tc); // lane 16j+b: plane b of slot j
-		transpose64(blo, bhi, tc); // lane 16j+b: plane b of slot 4+j
-		const uint64_t nza = __ballot((alo | ahi) != 0);
-		const uint64_t nzb = __ballot((blo | bhi) != 0);
-		uint32_t s[8];
-		uint32_t pos = 0;
-		uint64_t hdr = ((uint64_t)mode << 40) | ((uint64_t)base << 48);
-#pragma unroll
-		for (int j = 0; j < 8; ++j)
-		{
-			const uint32_t field = (uint32_t)((j < 4 ? nza : nzb) >> (16 * (j & 3))) & 0xffffu;
-			const uint32_t w = bitlen32(field);
-			s[j] = pos | (w << 16);
-			hdr |= (uint64_t)w << (5 * j);
-			pos += w;
-		}
-		const uint32_t sa = select4(s[0], s[1], s[2], s[3], grp);
-		const uint32_t sb = select4(s[4], s[5], s[6], s[7], grp);
-		if (bit < (sa >> 16))
-			out[(sa & 0xffffu) + bit] = (uint64_t)alo | ((uint64_t)ahi << 32);
-		if (bit < (sb >> 16))
-			out[(sb & 0xffffu) + bit] = (uint64_t)blo | ((uint64_t)bhi << 32);
-		*words = pos;
-		return hdr;
+		transpose64x2(alo, ahi, blo, bhi, tc); // lane 16q+k: plane k of slot q (a) / slot 4+q (b)
+		const uint32_t wa = row_allmax((alo | ahi) != 0 ? lc.bitp1 : 0u); // width of slot q
+		const uint32_t wb = row_allmax((blo | bhi) != 0 ? lc.bitp1 : 0u); // width of slot 4+q
+		const uint32_t ia = rows_inclusive_sum(wa), ib = rows_inclusive_sum(wb);
+		const uint32_t tot_a = (uint32_t)__builtin_amdgcn_readlane((int)ia, 63);
+		const uint32_t tot_b = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
+		// one unconditional 8-byte store per half; lanes without a plane point out of range
+		v2u32 va, vb;
+		va.x = alo, va.y = ahi, vb.x = blo, vb.y = bhi;
+		const uint32_t oa = lc.bit < wa ? (pos + ia - wa + lc.bit) * 8u : RIR_OOB;
+		const uint32_t ob = lc.bit < wb ? (pos + tot_a + ib - wb + lc.bit) * 8u : RIR_OOB;
+		__builtin_amdgcn_raw_buffer_store_b64(va, out, oa, 0, 0);
+		__builtin_amdgcn_raw_buffer_store_b64(vb, out, ob, 0, 0);
+		*words = tot_a + tot_b;
+		// header = ballot of the row's 16-bit field (w_q | w_{4+q} << 5 | base nibble q << 10 | mode << 14)
+		const uint32_t nib = (base >> lc.sh4) & 15u;
+		const uint32_t field = ((nib << 10) | modebits) | ((wb << 5) | wa);
+		return __ballot((field & lc.onehot) != 0);
 	}
 
-	// ---- encode -----------------------------------------------------------------------------
-	//
-	// grid  = (ceil(ntiles/4), nchunks), block = 256 (4 independent waves)
-	// hdr       [nchunks][ntiles][gop]      u64  record headers
-	// seg_words [nchunks][ntiles]           u32  segment length (sum over the chunk's frames)
-	// sparse    [nchunks][ntiles][gop*128]  u64, only the first seg_words words of a slot are written
-	__global__ __launch_bounds__(256) void rirb1_encode_tiles(const uint16_t *__restrict__ frames, int64_t npx, int ntiles,
-															 int nframes, int gop, uint64_t *__restrict__ hdr_table,
-															 uint32_t *__restrict__ seg_words, uint64_t *__restrict__ sparse)
+	// One wave = one tile over the frames of one chunk (see the kernel below).
+	template <bool FAST>
+	__device__ __forceinline__ void encode_tile(const uint16_t *__restrict__ frames, int64_t npx, int nf, int64_t frame0, int tile, int lane,
+												uint64_t *__restrict__ my_hdr, uint64_t *__restrict__ out_ptr, uint32_t out_bytes,
+												uint32_t *__restrict__ seg_words_slot, int gop)
 	{
-		const int lane = threadIdx.x & 63;
-		const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-		if (tile >= ntiles)
-			return;
-		const int chunk = blockIdx.y;
-		const int f_begin = chunk * gop;
-		const int nf = min(gop, nframes - f_begin);
 		const int64_t p0 = (int64_t)tile * RIRB1_TILE_PX + lane * 8;
-		// lanes of a full tile take the 16-byte path; ragged sizes take the element path
-		const bool vec_ok = ((npx & 7) == 0) && (p0 + 8 <= npx);
-		const int64_t slot = (int64_t)chunk * ntiles + tile;
-		uint64_t *my_hdr = hdr_table + slot * gop;
-		uint64_t *out = sparse + slot * (int64_t)gop * RIRB1_REC_MAX_WORDS;
 		const TransposeConsts tc = make_transpose_consts(lane);
-		const int grp = lane >> 4;
-		const uint32_t bit = lane & 15;
+		const LaneConsts lc = make_lane_consts(lane);
+		const __amdgpu_buffer_rsrc_t out = make_rsrc(out_ptr, out_bytes);
+		const uint32_t lane_off = (uint32_t)lane * 16u;
+		const uint16_t *tile0 = frames + frame0 * npx + (int64_t)tile * RIRB1_TILE_PX; // tile of the chunk's first frame
+		// FAST: whole tile inside the frame and 16-byte aligned rows -> raw-buffer loads, unconditional;
+		// past the end of the chunk the prefetch re-reads the last frame (an L2 hit, no HBM traffic).
+		auto load = [&](int f) -> Px8 {
+			if (FAST)
+				return buf_load8(tile0 + (int64_t)min(f, nf - 1) * npx, lane_off);
+			return load8(frames, frame0 + min(f, nf - 1), npx, p0, false);
+		};
 
 		uint32_t pos = 0;
 		uint64_t hdr_reg = 0; // lane (f & 63) keeps the header of frame f until the 64-frame flush
 
+		// Ring of 4 frame slots: frame f lives in slot f % 4, three frames are in flight ahead of the
+		// one being packed.  The loop is unrolled by 4 so that slots are fixed registers (a register
+		// copy of a loaded value would force an early wait on the load).
+		Px8 s0 = load(0), s1 = load(1), s2 = load(2), s3 = load(3);
+
 		// ---- key frame: RAW, or LEFT when its payload is strictly smaller ----
-		Px8 cur = load8(frames, f_begin, npx, p0, vec_ok);
-		Px8 nxt = cur;
-		if (nf > 1)
-			nxt = load8(frames, f_begin + 1, npx, p0, vec_ok);
 		{
+			const Px8 cur = s0;
 			const uint32_t base_raw = tile_base(cur, false);
 			const uint32_t b2 = base_raw | (base_raw << 16);
 			Px8 r_raw;
@@ -331,40 +401,44 @@ namespace rir
 			for (int k = 0; k < 4; ++k)
 				r_sel.d[k] = use_left ? r_left.d[k] : r_raw.d[k];
 			uint32_t words;
-			const uint64_t h =
-				emit_record(r_sel, use_left ? RIRB1_MODE_LEFT : RIRB1_MODE_RAW, use_left ? base_left : base_raw, out, grp, bit, tc, &words);
+			const uint32_t key_mode = use_left ? RIRB1_MODE_LEFT : RIRB1_MODE_RAW;
+			const uint64_t h = emit_record(r_sel, lc.row0 ? (key_mode << 14) : 0u, use_left ? base_left : base_raw, out, pos, lc, tc, &words);
 			if (lane == 0)
 				hdr_reg = h;
 			pos += words;
 		}
 
 		// ---- temporal frames ----
-		for (int f = 1; f < nf; ++f)
+		const uint32_t temporal_bits = lc.row0 ? ((uint32_t)RIRB1_MODE_TEMPORAL << 14) : 0u;
+#define RIR_ENC_STEP(F, CUR, PREV)                                                             \
+	if ((F) < nf)                                                                              \
+	{                                                                                          \
+		const int f = (F);                                                                     \
+		Px8 d;                                                                                 \
+		_Pragma("unroll") for (int k = 0; k < 4; ++k) d.d[k] = pk_sub16(CUR.d[k], PREV.d[k]); \
+		PREV = load(f + 3); /* the slot of frame f-1 is free: prefetch frame f+3 into it */    \
+		const uint32_t base = tile_base(d, true);                                              \
+		const uint32_t b2 = base | (base << 16);                                               \
+		_Pragma("unroll") for (int k = 0; k < 4; ++k) d.d[k] = pk_sub16(d.d[k], b2);          \
+		uint32_t words;                                                                        \
+		const uint64_t h = emit_record(d, temporal_bits, base, out, pos, lc, tc, &words);      \
+		if ((f & 63) == 0)                                                                     \
+		{ /* flush the previous 64 headers (one coalesced 8-byte store per lane) */            \
+			my_hdr[f - 64 + lane] = hdr_reg;                                                   \
+			hdr_reg = 0;                                                                       \
+		}                                                                                      \
+		if (lane == (f & 63))                                                                  \
+			hdr_reg = h;                                                                       \
+		pos += words;                                                                          \
+	}
+		for (int fb = 1; fb < nf; fb += 4)
 		{
-			const Px8 prev = cur;
-			cur = nxt;
-			if (f + 1 < nf)
-				nxt = load8(frames, f_begin + f + 1, npx, p0, vec_ok); // prefetch, consumed next iteration
-			Px8 d;
-#pragma unroll
-			for (int k = 0; k < 4; ++k)
-				d.d[k] = pk_sub16(cur.d[k], prev.d[k]);
-			const uint32_t base = tile_base(d, true);
-			const uint32_t b2 = base | (base << 16);
-#pragma unroll
-			for (int k = 0; k < 4; ++k)
-				d.d[k] = pk_sub16(d.d[k], b2);
-			uint32_t words;
-			const uint64_t h = emit_record(d, RIRB1_MODE_TEMPORAL, base, out + pos, grp, bit, tc, &words);
-			if ((f & 63) == 0)
-			{ // flush the previous 64 headers (one coalesced 8-byte store per lane)
-				my_hdr[f - 64 + lane] = hdr_reg;
-				hdr_reg = 0;
-			}
-			if (lane == (f & 63))
-				hdr_reg = h;
-			pos += words;
+			RIR_ENC_STEP(fb, s1, s0)
+			RIR_ENC_STEP(fb + 1, s2, s1)
+			RIR_ENC_STEP(fb + 2, s3, s2)
+			RIR_ENC_STEP(fb + 3, s0, s3)
 		}
+#undef RIR_ENC_STEP
 		{
 			const int fb = (nf - 1) & ~63;
 			if (fb + lane < nf)
@@ -373,7 +447,35 @@ namespace rir
 		for (int f = nf + lane; f < gop; f += 64)
 			my_hdr[f] = 0; // short last chunk: the unused table entries are defined
 		if (lane == 0)
-			seg_words[slot] = pos;
+			*seg_words_slot = pos;
+	}
+
+	// ---- encode -----------------------------------------------------------------------------
+	//
+	// grid  = (ceil(ntiles/4), nchunks), block = 256 (4 independent waves)
+	// hdr       [nchunks][ntiles][gop]      u64  record headers
+	// seg_words [nchunks][ntiles]           u32  segment length (sum over the chunk's frames)
+	// sparse    [nchunks][ntiles][gop*128]  u64, only the first seg_words words of a slot are written
+	__global__ __launch_bounds__(256) void rirb1_encode_tiles(const uint16_t *__restrict__ frames, int64_t npx, int ntiles,
+															 int nframes, int gop, uint64_t *__restrict__ hdr_table,
+															 uint32_t *__restrict__ seg_words, uint64_t *__restrict__ sparse)
+	{
+		const int lane = threadIdx.x & 63;
+		const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+		if (tile >= ntiles)
+			return;
+		const int chunk = blockIdx.y;
+		const int f_begin = chunk * gop;
+		const int nf = min(gop, nframes - f_begin);
+		const int64_t slot = (int64_t)chunk * ntiles + tile;
+		uint64_t *my_hdr = hdr_table + slot * gop;
+		uint64_t *out = sparse + slot * (int64_t)gop * RIRB1_REC_MAX_WORDS;
+		const uint32_t out_bytes = (uint32_t)gop * RIRB1_REC_MAX_WORDS * 8u;
+		const bool fast = ((npx & 7) == 0) && ((int64_t)(tile + 1) * RIRB1_TILE_PX <= npx) && ((((uintptr_t)frames) & 15) == 0);
+		if (fast)
+			encode_tile<true>(frames, npx, nf, f_begin, tile, lane, my_hdr, out, out_bytes, seg_words + slot, gop);
+		else
+			encode_tile<false>(frames, npx, nf, f_begin, tile, lane, my_hdr, out, out_bytes, seg_words + slot, gop);
 	}
 
 	// ---- offsets ------------------------------------------------------------------------------
@@ -461,33 +563,28 @@ namespace rir
 		bool bad;
 	};
 
-	__device__ __forceinline__ Fetched fetch_record(uint64_t hdr, const uint64_t *__restrict__ in, uint32_t pos, uint32_t seg_len, int grp, uint32_t bit)
+	__device__ __forceinline__ Fetched fetch_record(uint64_t hdr, __amdgpu_buffer_rsrc_t in, uint32_t pos, uint32_t seg_len, const LaneConsts &lc)
 	{
 		Fetched r;
 		r.hdr = hdr;
-		uint32_t s[8];
-		uint32_t p = 0, wmax = 0;
-#pragma unroll
-		for (int j = 0; j < 8; ++j)
-		{
-			const uint32_t w = (uint32_t)(hdr >> (5 * j)) & 31u;
-			s[j] = p | (w << 16);
-			p += w;
-			wmax = max(wmax, w);
-		}
-		r.words = p;
-		r.bad = (wmax > 16) || (pos + p > seg_len) || (((hdr >> 40) & 3u) == 3u);
-		r.a = 0;
-		r.b = 0;
-		if (!r.bad)
-		{ // never read outside the segment
-			const uint32_t sa = select4(s[0], s[1], s[2], s[3], grp);
-			const uint32_t sb = select4(s[4], s[5], s[6], s[7], grp);
-			if (bit < (sa >> 16))
-				r.a = in[pos + (sa & 0xffffu) + bit];
-			if (bit < (sb >> 16))
-				r.b = in[pos + (sb & 0xffffu) + bit];
-		}
+		// this row's header field: w_q | w_{4+q} << 5 | base nibble << 10 | mode << 14
+		const uint32_t field = ((lc.row_hi ? (uint32_t)(hdr >> 32) : (uint32_t)hdr) >> lc.sh16) & 0xffffu;
+		const uint32_t wa = field & 31u, wb = (field >> 5) & 31u;
+		const uint32_t ia = rows_inclusive_sum(wa), ib = rows_inclusive_sum(wb);
+		const uint32_t tot_a = (uint32_t)__builtin_amdgcn_readlane((int)ia, 63);
+		const uint32_t tot_b = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
+		r.words = tot_a + tot_b;
+		const bool wide = __ballot(wa > 16u || wb > 16u) != 0;
+		r.bad = wide || (pos + r.words > seg_len) || ((hdr & 0xC000C000C0000000ull) != 0) || (((hdr >> 14) & 3u) == 3u);
+		// unconditional loads; lanes without a plane (and every lane of a malformed record) point out
+		// of range and read 0 - the descriptor's num_records is the segment length, so nothing outside
+		// the segment is ever touched
+		const uint32_t oa = (!r.bad && lc.bit < wa) ? (pos + ia - wa + lc.bit) * 8u : RIR_OOB;
+		const uint32_t ob = (!r.bad && lc.bit < wb) ? (pos + tot_a + ib - wb + lc.bit) * 8u : RIR_OOB;
+		const v2u32 va = __builtin_amdgcn_raw_buffer_load_b64(in, oa, 0, 0);
+		const v2u32 vb = __builtin_amdgcn_raw_buffer_load_b64(in, ob, 0, 0);
+		r.a = (uint64_t)va.x | ((uint64_t)va.y << 32);
+		r.b = (uint64_t)vb.x | ((uint64_t)vb.y << 32);
 		return r;
 	}
 
@@ -497,6 +594,111 @@ namespace rir
 			   ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32);
 	}
 
+	// MODE_LEFT reconstruction: inclusive prefix sum (mod 2^16) over the tile, lane-local then across lanes
+	__device__ __forceinline__ Px8 left_integrate(const Px8 &d, int lane)
+	{
+		uint32_t a[8];
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+		{
+			a[2 * k] = d.d[k] & 0xffffu;
+			a[2 * k + 1] = d.d[k] >> 16;
+		}
+#pragma unroll
+		for (int i = 1; i < 8; ++i)
+			a[i] = (a[i] + a[i - 1]) & 0xffffu;
+		const uint32_t incl = wave_scan_add(a[7], lane);
+		const uint32_t carry = (incl - a[7]) & 0xffffu;
+		Px8 o;
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+			o.d[k] = ((a[2 * k] + carry) & 0xffffu) | (((a[2 * k + 1] + carry) & 0xffffu) << 16);
+		return o;
+	}
+
+	template <bool FAST>
+	__device__ __forceinline__ void decode_tile(const uint64_t *__restrict__ my_hdr, const uint64_t *__restrict__ in_ptr, uint32_t seg_len,
+												int64_t npx, int nf, int64_t frame0, int tile, int lane, uint16_t *__restrict__ frames,
+												int *__restrict__ error_flag)
+	{
+		const int64_t p0 = (int64_t)tile * RIRB1_TILE_PX + lane * 8;
+		const TransposeConsts tc = make_transpose_consts(lane);
+		const LaneConsts lc = make_lane_consts(lane);
+		const __amdgpu_buffer_rsrc_t in = make_rsrc(in_ptr, seg_len * 8u);
+		const uint32_t lane_off = (uint32_t)lane * 16u;
+		uint16_t *tile0 = frames + frame0 * npx + (int64_t)tile * RIRB1_TILE_PX;
+
+		Px8 prev;
+		prev.d[0] = prev.d[1] = prev.d[2] = prev.d[3] = 0;
+		uint32_t pos = 0;  // fetch position: words of every record requested so far
+		bool err = false; // malformed input seen (wave-uniform); reported once, at the end
+		for (int f0 = 0; f0 < nf; f0 += 64)
+		{
+			const int nr = min(64, nf - f0);
+			const uint64_t my_h = lane < nr ? my_hdr[f0 + lane] : 0ull; // 64 headers, one coalesced load
+			// Ring of 4 records in flight (fixed registers, loop unrolled by 4, see the encoder).
+			// Requests past the end of the round use an all-zero header = empty record (no memory
+			// touched); a malformed record points every lane out of range, so the loop body has no
+			// data-dependent branch and the compiler keeps counted s_waitcnt vmcnt(N).
+			Fetched r0 = fetch_record(readlane64(my_h, 0), in, pos, seg_len, lc);
+			pos += r0.words;
+			Fetched r1 = fetch_record(nr > 1 ? readlane64(my_h, 1) : 0ull, in, pos, seg_len, lc);
+			pos += r1.words;
+			Fetched r2 = fetch_record(nr > 2 ? readlane64(my_h, 2) : 0ull, in, pos, seg_len, lc);
+			pos += r2.words;
+			Fetched r3 = fetch_record(nr > 3 ? readlane64(my_h, 3) : 0ull, in, pos, seg_len, lc);
+			pos += r3.words;
+#define RIR_DEC_STEP(FR, R)                                                                                          \
+	if ((FR) < nr)                                                                                                   \
+	{                                                                                                                \
+		const int fr = (FR);                                                                                         \
+		const uint64_t hdr = R.hdr;                                                                                  \
+		err |= R.bad;                                                                                                \
+		uint32_t alo = (uint32_t)R.a, ahi = (uint32_t)(R.a >> 32), blo = (uint32_t)R.b, bhi = (uint32_t)(R.b >> 32); \
+		/* refill the slot with the record four frames ahead */                                                       \
+		R = fetch_record(fr + 4 < nr ? readlane64(my_h, fr + 4) : 0ull, in, pos, seg_len, lc);                        \
+		pos += R.words;                                                                                              \
+		transpose64x2(alo, ahi, blo, bhi, tc);                                                                       \
+		const uint32_t mode = (uint32_t)(hdr >> 14) & 3u;                                                            \
+		const uint32_t base = ((uint32_t)(hdr >> 10) & 0xfu) | ((uint32_t)(hdr >> 22) & 0xf0u) |                     \
+							  ((uint32_t)(hdr >> 34) & 0xf00u) | ((uint32_t)(hdr >> 46) & 0xf000u);                  \
+		const uint32_t b2 = base | (base << 16);                                                                     \
+		Px8 o;                                                                                                       \
+		o.d[0] = pk_add16(alo, b2);                                                                                  \
+		o.d[1] = pk_add16(ahi, b2);                                                                                  \
+		o.d[2] = pk_add16(blo, b2);                                                                                  \
+		o.d[3] = pk_add16(bhi, b2);                                                                                  \
+		if (f0 + fr == 0)                                                                                            \
+		{ /* key frame: RAW or LEFT */                                                                               \
+			if (mode == RIRB1_MODE_LEFT)                                                                             \
+				o = left_integrate(o, lane);                                                                         \
+			err |= (mode == RIRB1_MODE_TEMPORAL);                                                                    \
+		}                                                                                                            \
+		else                                                                                                         \
+		{ /* TEMPORAL (or RAW); LEFT is only legal on the key frame */                                               \
+			const uint32_t keep = (mode == RIRB1_MODE_TEMPORAL) ? 0xffffffffu : 0u;                                  \
+			_Pragma("unroll") for (int k = 0; k < 4; ++k) o.d[k] = pk_add16(prev.d[k] & keep, o.d[k]);              \
+			err |= (mode == RIRB1_MODE_LEFT);                                                                        \
+		}                                                                                                            \
+		if (FAST)                                                                                                    \
+			buf_store8(tile0 + (int64_t)(f0 + fr) * npx, lane_off, o);                                               \
+		else                                                                                                         \
+			store8(frames, frame0 + f0 + fr, npx, p0, false, o);                                                     \
+		prev = o;                                                                                                    \
+	}
+			for (int fb = 0; fb < nr; fb += 4)
+			{
+				RIR_DEC_STEP(fb, r0)
+				RIR_DEC_STEP(fb + 1, r1)
+				RIR_DEC_STEP(fb + 2, r2)
+				RIR_DEC_STEP(fb + 3, r3)
+			}
+#undef RIR_DEC_STEP
+		}
+		if ((err || pos != seg_len) && lane == 0)
+			atomicExch(error_flag, 1);
+	}
+
 	// grid = (ceil(ntiles/4), nchunks), block = 256 (4 independent waves)
 	__global__ __launch_bounds__(256) void rirb1_decode_tiles(const uint64_t *__restrict__ hdr_table, const uint32_t *__restrict__ tile_off,
 															 const uint64_t *__restrict__ chunk_off, const uint64_t *__restrict__ stream,
@@ -504,92 +706,29 @@ namespace rir
 															 int *__restrict__ error_flag)
 	{
 		const int lane = threadIdx.x & 63;
-		const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+		const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 		if (tile >= ntiles)
 			return;
 		const int chunk = blockIdx.y;
 		const int f_begin = chunk * gop;
 		const int nf = min(gop, nframes - f_begin);
-		const int64_t p0 = (int64_t)tile * RIRB1_TILE_PX + lane * 8;
-		const bool vec_ok = ((npx & 7) == 0) && (p0 + 8 <= npx);
 		const int64_t slot = (int64_t)chunk * ntiles + tile;
 		const uint64_t *my_hdr = hdr_table + slot * gop;
 		const uint32_t t0 = tile_off[(int64_t)chunk * (ntiles + 1) + tile];
-		const uint32_t seg_len = tile_off[(int64_t)chunk * (ntiles + 1) + tile + 1] - t0;
-		const uint64_t *in = stream + chunk_off[chunk] + t0;
-		const TransposeConsts tc = make_transpose_consts(lane);
-		const int grp = lane >> 4;
-		const uint32_t bit = lane & 15;
-
-		Px8 prev;
-		prev.d[0] = prev.d[1] = prev.d[2] = prev.d[3] = 0;
-		uint32_t pos = 0;
-		for (int f0 = 0; f0 < nf; f0 += 64)
-		{
-			const int nr = min(64, nf - f0);
-			const uint64_t my_h = lane < nr ? my_hdr[f0 + lane] : 0ull; // 64 headers, one coalesced load
-			Fetched cur = fetch_record(readlane64(my_h, 0), in, pos, seg_len, grp, bit);
-			for (int fr = 0; fr < nr; ++fr)
-			{
-				if (cur.bad)
-				{
-					if (lane == 0)
-						atomicExch(error_flag, 1);
-					return;
-				}
-				pos += cur.words;
-				Fetched nxt = cur;
-				if (fr + 1 < nr) // prefetch the next record while this one is transposed
-					nxt = fetch_record(readlane64(my_h, fr + 1), in, pos, seg_len, grp, bit);
-
-				uint32_t alo = (uint32_t)cur.a, ahi = (uint32_t)(cur.a >> 32), blo = (uint32_t)cur.b, bhi = (uint32_t)(cur.b >> 32);
-				transpose64(alo, ahi, tc);
-				transpose64(blo, bhi, tc);
-				const uint32_t mode = (uint32_t)(cur.hdr >> 40) & 3u;
-				const uint32_t base = (uint32_t)(cur.hdr >> 48) & 0xffffu;
-				const uint32_t b2 = base | (base << 16);
-				Px8 d;
-				d.d[0] = pk_add16(alo, b2);
-				d.d[1] = pk_add16(ahi, b2);
-				d.d[2] = pk_add16(blo, b2);
-				d.d[3] = pk_add16(bhi, b2);
-
-				Px8 out;
-				if (mode == RIRB1_MODE_TEMPORAL)
-				{
-#pragma unroll
-					for (int k = 0; k < 4; ++k)
-						out.d[k] = pk_add16(prev.d[k], d.d[k]);
-				}
-				else if (mode == RIRB1_MODE_LEFT)
-				{ // inclusive prefix sum (mod 2^16) over the tile: lane-local, then across lanes
-					uint32_t a[8];
-#pragma unroll
-					for (int k = 0; k < 4; ++k)
-					{
-						a[2 * k] = d.d[k] & 0xffffu;
-						a[2 * k + 1] = d.d[k] >> 16;
-					}
-#pragma unroll
-					for (int i = 1; i < 8; ++i)
-						a[i] = (a[i] + a[i - 1]) & 0xffffu;
-					const uint32_t incl = wave_scan_add(a[7], lane);
-					const uint32_t carry = (incl - a[7]) & 0xffffu;
-#pragma unroll
-					for (int k = 0; k < 4; ++k)
-						out.d[k] = ((a[2 * k] + carry) & 0xffffu) | (((a[2 * k + 1] + carry) & 0xffffu) << 16);
-				}
-				else
-				{
-					out = d;
-				}
-				store8(frames, f_begin + f0 + fr, npx, p0, vec_ok, out);
-				prev = out;
-				cur = nxt;
-			}
+		const uint32_t t1 = tile_off[(int64_t)chunk * (ntiles + 1) + tile + 1];
+		if (t1 < t0)
+		{ // malformed offsets table
+			if (lane == 0)
+				atomicExch(error_flag, 1);
+			return;
 		}
-		if (pos != seg_len && lane == 0)
-			atomicExch(error_flag, 1);
+		const uint32_t seg_len = min(t1 - t0, (uint32_t)gop * RIRB1_REC_MAX_WORDS);
+		const uint64_t *in = stream + chunk_off[chunk] + t0;
+		const bool fast = ((npx & 7) == 0) && ((int64_t)(tile + 1) * RIRB1_TILE_PX <= npx) && ((((uintptr_t)frames) & 15) == 0);
+		if (fast)
+			decode_tile<true>(my_hdr, in, seg_len, npx, nf, f_begin, tile, lane, frames, error_flag);
+		else
+			decode_tile<false>(my_hdr, in, seg_len, npx, nf, f_begin, tile, lane, frames, error_flag);
 	}
 
 	// ---- host launchers --------------------------------------------------------------------------------

@@ -582,14 +582,18 @@ EXPORT void orc_merge_planes(const uint8_t *Y, const uint8_t *U, const uint8_t *
 /*           so r is in [0, max-min] and a constant step between frames costs nothing.         */
 /*           block j (j = 0..7) = the 64 residuals r[8l + j], l = 0..63; width w_j = bit       */
 /*           length of their OR (0..16).                                                       */
-/*           header: bits [5j,5j+5) = w_j, bits [40,42) = mode, bits [48,64) = base.           */
+/*           header = four 16-bit fields, field q (q = 0..3) at bits [16q, 16q+16):            */
+/*                 bits 0-4 w_q, bits 5-9 w_{4+q}, bits 10-13 base nibble q (base bits 4q..),   */
+/*                 bits 14-15 mode (field 0 only, zero elsewhere)                              */
+/*           (bit 16q+k is owned by wavefront lane 16q+k: the header is one ballot).           */
 /*           payload: for j = 0..7, for b = 0..w_j-1: one 64-bit word, bit l = bit b of        */
 /*           r[8l + j]  (a 64x64 bit-matrix transpose across the wavefront).                   */
 /*  hdr    = uint64 [tile][G]   (zero for the unused frames of a short last chunk)             */
 /*  stream = per chunk, tiles in order, each tile's payload in frame order (a "segment");      */
 /*           tile_off[t] = first word of segment t (exclusive scan), uint32, ntiles+1 entries. */
 /*  Key-frame mode choice: LEFT if its payload is strictly smaller than RAW's, else RAW;       */
-/*  every other frame is TEMPORAL.                                                             */
+/*  every other frame is TEMPORAL.  A decoder accepts RAW anywhere, LEFT only on the key       */
+/*  frame, TEMPORAL only on the others.                                                        */
 /* ------------------------------------------------------------------------------------------ */
 
 #define TILE_PX 512
@@ -654,12 +658,26 @@ static int emit_payload(const uint16_t *r, const int *widths, uint64_t *out)
 static uint64_t make_header(const int *widths, int mode, uint16_t base)
 {
 	uint64_t hdr = 0;
-	for (int j = 0; j < 8; ++j)
-		hdr |= (uint64_t)widths[j] << (5 * j);
-	hdr |= (uint64_t)mode << 40;
-	hdr |= (uint64_t)base << 48;
+	for (int q = 0; q < 4; ++q)
+	{
+		uint64_t field = (uint64_t)widths[q] | ((uint64_t)widths[4 + q] << 5) | ((uint64_t)((base >> (4 * q)) & 15) << 10);
+		if (q == 0)
+			field |= (uint64_t)mode << 14;
+		hdr |= field << (16 * q);
+	}
 	return hdr;
 }
+static int header_width(uint64_t H, int j) { return (int)((H >> (16 * (j & 3) + (j < 4 ? 0 : 5))) & 31); }
+static int header_mode(uint64_t H) { return (int)((H >> 14) & 3); }
+static uint16_t header_base(uint64_t H)
+{
+	uint16_t b = 0;
+	for (int q = 0; q < 4; ++q)
+		b |= (uint16_t)(((H >> (16 * q + 10)) & 15) << (4 * q));
+	return b;
+}
+/* bits a well-formed header never sets: bits 14-15 of fields 1..3 */
+static int header_reserved_ok(uint64_t H) { return (H & 0xC000C000C0000000ull) == 0; }
 
 /* Encode one chunk of `nframes` frames.  hdr: uint64[ntiles*nframes] ([tile][frame]);
  * tile_off: uint32[ntiles+1]; stream: >= orc_codec_max_words words.  Returns total words. */
@@ -733,12 +751,16 @@ EXPORT int orc_codec_decode_chunk(const uint64_t *hdr, const uint32_t *tile_off,
 		for (int f = 0; f < nframes; ++f)
 		{
 			const uint64_t H = hdr[(int64_t)t * nframes + f];
-			const int mode = (int)((H >> 40) & 3);
-			const uint16_t base = (uint16_t)(H >> 48);
+			const int mode = header_mode(H);
+			const uint16_t base = header_base(H);
+			if (!header_reserved_ok(H))
+				return -1;
+			if ((f == 0 && mode == MODE_TEMPORAL) || (f != 0 && mode == MODE_LEFT))
+				return -1; /* key frames are RAW or LEFT, the others TEMPORAL (or RAW) */
 			memset(r, 0, sizeof(r));
 			for (int j = 0; j < 8; ++j)
 			{
-				int wj = (int)((H >> (5 * j)) & 31);
+				int wj = header_width(H, j);
 				if (wj > 16 || pos + wj > end)
 					return -1;
 				for (int b = 0; b < wj; ++b)

@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc counter_collection.csv files: per kernel, mean counter value per dispatch."""
+import csv, glob, sys, collections, json, os
+root = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"].split("(")[0].replace("rir::", "")
+        if not k.startswith("rirb1"):
+            continue
+        agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+out = {}
+for k, cs in sorted(agg.items()):
+    out[k] = {c: sum(v) / len(v) for c, v in sorted(cs.items())}
+    out[k]["_dispatches"] = len(next(iter(cs.values())))
+print(json.dumps(out, indent=1))

@@ -21,11 +21,16 @@ def roundtrip(oracle, frames):
 def widths(hdr):
     """(ntiles, n, 8) bit-plane counts out of the header table"""
     h = hdr.astype(np.uint64)
-    return np.stack([(h >> np.uint64(5 * j)) & np.uint64(31) for j in range(8)], axis=-1).astype(np.int64)
+    return np.stack([(h >> np.uint64(16 * (j & 3) + (0 if j < 4 else 5))) & np.uint64(31) for j in range(8)], axis=-1).astype(np.int64)
 
 
 def modes(hdr):
-    return ((hdr.astype(np.uint64) >> np.uint64(40)) & np.uint64(3)).astype(np.int64)
+    return ((hdr.astype(np.uint64) >> np.uint64(14)) & np.uint64(3)).astype(np.int64)
+
+
+def bases(hdr):
+    h = hdr.astype(np.uint64)
+    return sum((((h >> np.uint64(16 * q + 10)) & np.uint64(15)) << np.uint64(4 * q)) for q in range(4)).astype(np.int64)
 
 
 @pytest.mark.parametrize("shape", [(1, 512, 640), (10, 240, 320), (10, 256, 320), (3, 20, 20), (2, 1, 1), (4, 7, 9), (5, 67, 83), (1, 3, 1025)])
@@ -76,9 +81,9 @@ def test_header_layout(oracle):
     f[1] += 7
     f[1, 0, 0] += 5  # one pixel of slot 0 deviates by 5 -> 3 planes in slot 0 only
     hdr, off, stream = roundtrip(oracle, f)
-    h0, h1 = int(hdr[0, 0]), int(hdr[0, 1])
-    assert (h0 >> 48) == 1000 and (h0 >> 40) & 3 == 0 and h0 & ((1 << 40) - 1) == 0
-    assert (h1 >> 48) == 7 and (h1 >> 40) & 3 == 1 and h1 & ((1 << 40) - 1) == 3
+    assert bases(hdr)[0].tolist() == [1000, 7] and modes(hdr)[0].tolist() == [0, 1]
+    assert widths(hdr)[0, 0].tolist() == [0] * 8 and widths(hdr)[0, 1].tolist() == [3, 0, 0, 0, 0, 0, 0, 0]
+    assert int(hdr[0, 1]) == 3 | (7 << 10) | (1 << 14)
     assert stream.tolist() == [1, 0, 1]  # bit-planes of the value 5 in lane 0
 
 
@@ -99,6 +104,10 @@ def test_malformed_stream_is_rejected(oracle):
     hdr, off, stream = oracle.codec_encode_chunk(f)
     bad = hdr.copy()
     bad[0, 0] = np.uint64(int(bad[0, 0]) | 0x1F)  # width 31 > 16
+    with pytest.raises(RuntimeError):
+        oracle.codec_decode_chunk(bad, off, stream, 64, 8)
+    bad = hdr.copy()
+    bad[0, 1] = np.uint64(int(bad[0, 1]) | (1 << 31))  # reserved bit
     with pytest.raises(RuntimeError):
         oracle.codec_decode_chunk(bad, off, stream, 64, 8)
     short = off.copy()
