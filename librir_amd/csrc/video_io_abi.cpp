@@ -1,0 +1,1309 @@
+// C ABI of the video_io half of the hot path: saver (h264_* / open_video_write), loader
+// (open_camera_* / load_image / attributes) and the read-back filters, on top of the device
+// codec (codec_abi.cpp).  Same symbol names, arguments and return codes as the reference header
+// src/cpp/video_io/video_io.h (behaviour of src/cpp/video_io/video_io.cpp cited per function).
+//
+// Container written by the saver ("RIRB" file): an ISO-BMFF style `ftyp` box (so
+// that format sniffers that look for "ftyp" at byte 4 - reference IRFileLoader.cpp:118-123 - file
+// it with the MP4/H.264 family, which is what FILE_FORMAT_H264 means to callers), a fixed header,
+// one record per chunk (GOP) holding the RIRB1 tables and payload, a chunk index, and the
+// reference's own "H264ATTRIBUTES" metadata trailer as the last bytes of the file.
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+
+#include "codec_format.h"
+#include "file_attributes.h"
+#include "rir_amd_device.h"
+#include "runtime.h"
+
+using namespace rir;
+
+extern "C"
+{
+	int rir_bad_pixels_create_rows_device(const unsigned short *, int, int, int, void *);
+	int rir_remove_bad_pixels_device(int, unsigned short *, int, int, void *);
+	int rir_remove_motion_device(const unsigned short *, unsigned short *, int, int, int, int, const float *, void *);
+	void bad_pixels_destroy(int);
+}
+
+#define FILE_FORMAT_PCR 1
+#define FILE_FORMAT_WEST 2
+#define FILE_FORMAT_PCR_ENCAPSULATED 3
+#define FILE_FORMAT_ZSTD_COMPRESSED 4
+#define FILE_FORMAT_H264 5
+#define FILE_FORMAT_HCC 6
+#define FILE_FORMAT_OTHER 7
+#define UNSPECIFIED_CHAR_LENGTH 200
+
+namespace
+{
+	// ---- container ---------------------------------------------------------------------------
+#pragma pack(push, 1)
+	struct FtypBox
+	{
+		uint8_t size_be[4]; // 32
+		char type[4];		// "ftyp"
+		char major[4];		// "RIRB"
+		uint8_t minor_be[4];
+		char compat[16]; // "RIRBisom" + padding
+	};
+	struct FileHeader
+	{
+		char magic[8]; // "RIRBLOCK"
+		uint32_t version;
+		uint32_t width, height, gop, fps, flags;
+		uint64_t index_offset; // 0 until the file is closed
+		uint64_t nframes, nchunks;
+		uint8_t reserved[8];
+	};
+	struct ChunkHeader
+	{
+		char magic[4]; // "CHNK"
+		uint32_t nframes, ntiles, gop;
+		uint64_t payload_words;
+		uint64_t first_frame;
+	};
+	struct IndexEntry
+	{
+		uint64_t file_offset; // of the ChunkHeader
+		uint64_t first_frame;
+		uint32_t nframes;
+		uint32_t reserved;
+	};
+	struct PcrHeader
+	{ // reference IRFileLoader.h:43-61
+		int32_t Version, NbImages, X, Y, Band, Bits, Interlaced, Frequency, ImagesPerBuffer, TransfertSize, GrabSizeX, GrabSizeY;
+		char reserved[1024 - 48];
+	};
+#pragma pack(pop)
+	static_assert(sizeof(FtypBox) == 32 && sizeof(FileHeader) == 64 && sizeof(ChunkHeader) == 32 && sizeof(PcrHeader) == 1024, "layout");
+
+	bool file_exists(const char *name)
+	{
+		struct stat st;
+		return stat(name, &st) == 0;
+	}
+
+	// Device + pinned staging for one chunk geometry.
+	struct ChunkCodec
+	{
+		int w = 0, h = 0, gop = 0;
+		rir_codec_layout L{};
+		DeviceBuffer d_frames, d_hdr, d_tile_off, d_chunk_off, d_stream, d_ws, d_err, d_tmp, d_shift;
+		PinnedBuffer h_frames;
+		bool prepare(int w_, int h_, int gop_)
+		{
+			if (w == w_ && h == h_ && gop == gop_ && d_frames.ptr)
+				return true;
+			if (rir_codec_layout_query(w_, h_, gop_, gop_, &L) != 0)
+				return false;
+			w = w_, h = h_, gop = gop_;
+			const size_t fb = (size_t)w * h * 2 * gop;
+			return d_frames.reserve(fb) && d_hdr.reserve((size_t)L.hdr_bytes) && d_tile_off.reserve((size_t)L.tile_off_bytes) &&
+				   d_chunk_off.reserve((size_t)L.chunk_off_bytes) && d_stream.reserve((size_t)L.stream_max_bytes) &&
+				   d_ws.reserve((size_t)L.workspace_bytes) && d_err.reserve(sizeof(int)) && h_frames.reserve(fb);
+		}
+	};
+
+	// ---- saver -------------------------------------------------------------------------------
+	// reference: struct H264 (video_io.cpp:651-657) + H264_Saver (h264.cpp:1662-1939)
+	struct SaverObject : public Object
+	{
+		const char *type_name() const override { return "H264Saver"; }
+		std::string filename;
+		int width = 0, height = 0, lossy_height = 0, fps = 50;
+		AttrMap global_attrs;
+		// parameters (h264.cpp:1709-1781); defaults h264.cpp:1662-1665
+		int compressionLevel = 0, lowValueError = 6, highValueError = 2, GOP = RIRB1_DEFAULT_GOP, threads = 1, slices = 1, inputCamera = 0;
+		int runningAverage = 32;
+		double stdFactor = 5;
+		bool removeBadPixels = false, subtractMin = false, subtractLocalMin = false;
+		std::string codec = "h264";
+
+		FILE *fp = nullptr;
+		bool opened = false;
+		int chunk_gop = 0; // GOP frozen at open
+		ChunkCodec cc;
+		int pending = 0;
+		uint64_t nframes = 0;
+		std::vector<IndexEntry> index;
+		std::vector<int64_t> times;
+		std::vector<AttrMap> frame_attrs;
+		std::vector<unsigned short> low_errors, high_errors;
+
+		~SaverObject() override { close(); }
+
+		bool set_parameter(const char *key, const char *value)
+		{
+			const std::string k = key ? key : "", v = value ? value : "";
+			auto as_int = [&]() { return std::atoi(v.c_str()); };
+			if (k == "lowValueError")
+				lowValueError = as_int();
+			else if (k == "highValueError")
+				highValueError = as_int();
+			else if (k == "compressionLevel")
+				compressionLevel = as_int();
+			else if (k == "codec")
+				codec = v;
+			else if (k == "GOP")
+				GOP = as_int();
+			else if (k == "threads")
+				threads = as_int();
+			else if (k == "slices")
+				slices = as_int();
+			else if (k == "stdFactor")
+				stdFactor = std::atof(v.c_str());
+			else if (k == "inputCamera")
+				inputCamera = as_int();
+			else if (k == "removeBadPixels")
+				removeBadPixels = as_int() != 0;
+			else if (k == "subtractMin")
+				subtractMin = as_int() != 0;
+			else if (k == "subtractLocalMin")
+				subtractLocalMin = as_int() != 0;
+			else if (k == "runningAverage")
+				runningAverage = std::min(as_int(), 64);
+			else
+				return false;
+			return true;
+		}
+
+		bool open()
+		{ // lazy, on the first frame (video_io.cpp:746-752)
+			if (opened)
+				return true;
+			if (!device_ready())
+				return false;
+			if (width <= 0 || height <= 0)
+			{
+				log_error("h264 saver: invalid image size");
+				return false;
+			}
+			chunk_gop = GOP < 1 ? 1 : GOP;
+			if ((int64_t)chunk_gop * width * height * 2 >= (1ll << 32))
+			{
+				log_error("h264 saver: GOP x frame size too large");
+				return false;
+			}
+			if (file_exists(filename.c_str()) && std::remove(filename.c_str()) != 0)
+				return false;
+			if (!cc.prepare(width, height, chunk_gop))
+				return false;
+			fp = std::fopen(filename.c_str(), "wb");
+			if (!fp)
+			{
+				log_error("h264 saver: cannot create " + filename);
+				return false;
+			}
+			FtypBox box;
+			std::memset(&box, 0, sizeof(box));
+			box.size_be[3] = 32;
+			std::memcpy(box.type, "ftyp", 4);
+			std::memcpy(box.major, "RIRB", 4);
+			box.minor_be[3] = 1;
+			std::memcpy(box.compat, "RIRBisom", 8);
+			FileHeader hd;
+			std::memset(&hd, 0, sizeof(hd));
+			std::memcpy(hd.magic, "RIRBLOCK", 8);
+			hd.version = 1;
+			hd.width = width, hd.height = height, hd.gop = chunk_gop, hd.fps = fps;
+			if (std::fwrite(&box, sizeof(box), 1, fp) != 1 || std::fwrite(&hd, sizeof(hd), 1, fp) != 1)
+				return false;
+			opened = true;
+			return true;
+		}
+
+		bool flush_chunk()
+		{
+			if (pending == 0)
+				return true;
+			hipStream_t st = default_stream();
+			const size_t fbytes = (size_t)width * height * 2;
+			rir_codec_layout L;
+			if (rir_codec_layout_query(width, height, pending, chunk_gop, &L) != 0)
+				return false;
+			if (!hip_ok(hipMemcpyAsync(cc.d_frames.ptr, cc.h_frames.ptr, fbytes * pending, hipMemcpyHostToDevice, st), "H2D frames"))
+				return false;
+			if (rir_codec_encode_device(cc.d_frames.as<unsigned short>(), width, height, pending, chunk_gop, cc.d_hdr.as<unsigned long long>(),
+										cc.d_tile_off.as<unsigned int>(), cc.d_chunk_off.as<unsigned long long>(),
+										cc.d_stream.as<unsigned long long>(), cc.d_ws.ptr, (long long)cc.d_ws.cap, st) != 0)
+				return false;
+			uint64_t coff[2] = {0, 0};
+			if (!hip_ok(hipMemcpyAsync(coff, cc.d_chunk_off.ptr, sizeof(coff), hipMemcpyDeviceToHost, st), "D2H") ||
+				!hip_ok(hipStreamSynchronize(st), "sync"))
+				return false;
+			const uint64_t words = coff[1];
+			std::vector<uint64_t> hdr((size_t)L.ntiles * chunk_gop), payload((size_t)words);
+			std::vector<uint32_t> toff((size_t)L.ntiles + 1);
+			if (!hip_ok(hipMemcpyAsync(hdr.data(), cc.d_hdr.ptr, hdr.size() * 8, hipMemcpyDeviceToHost, st), "D2H") ||
+				!hip_ok(hipMemcpyAsync(toff.data(), cc.d_tile_off.ptr, toff.size() * 4, hipMemcpyDeviceToHost, st), "D2H") ||
+				(words && !hip_ok(hipMemcpyAsync(payload.data(), cc.d_stream.ptr, (size_t)words * 8, hipMemcpyDeviceToHost, st), "D2H")) ||
+				!hip_ok(hipStreamSynchronize(st), "sync"))
+				return false;
+			ChunkHeader ch;
+			std::memset(&ch, 0, sizeof(ch));
+			std::memcpy(ch.magic, "CHNK", 4);
+			ch.nframes = pending, ch.ntiles = L.ntiles, ch.gop = chunk_gop, ch.payload_words = words, ch.first_frame = nframes - pending;
+			IndexEntry e{(uint64_t)std::ftell(fp), nframes - pending, (uint32_t)pending, 0};
+			if (std::fwrite(&ch, sizeof(ch), 1, fp) != 1 || std::fwrite(hdr.data(), 8, hdr.size(), fp) != hdr.size() ||
+				std::fwrite(toff.data(), 4, toff.size(), fp) != toff.size() ||
+				(words && std::fwrite(payload.data(), 8, (size_t)words, fp) != (size_t)words))
+			{
+				log_error("h264 saver: write error on " + filename);
+				return false;
+			}
+			index.push_back(e);
+			pending = 0;
+			return true;
+		}
+
+		bool add_image(const unsigned short *img, int64_t ts, const AttrMap &attrs)
+		{
+			if (!img || !open())
+				return false;
+			std::memcpy(cc.h_frames.as<char>() + (size_t)pending * width * height * 2, img, (size_t)width * height * 2);
+			++pending;
+			++nframes;
+			times.push_back(ts);
+			frame_attrs.push_back(attrs);
+			if (pending == chunk_gop)
+				return flush_chunk();
+			return true;
+		}
+
+		int64_t close()
+		{ // Finish + trailer (h264.cpp:1883-1912): the file is only valid after this
+			if (!opened)
+				return 0;
+			opened = false;
+			bool ok = flush_chunk();
+			FileHeader hd;
+			std::memset(&hd, 0, sizeof(hd));
+			std::memcpy(hd.magic, "RIRBLOCK", 8);
+			hd.version = 1;
+			hd.width = width, hd.height = height, hd.gop = chunk_gop, hd.fps = fps;
+			hd.index_offset = (uint64_t)std::ftell(fp);
+			hd.nframes = nframes, hd.nchunks = index.size();
+			if (index.size())
+				ok = ok && std::fwrite(index.data(), sizeof(IndexEntry), index.size(), fp) == index.size();
+			std::fseek(fp, sizeof(FtypBox), SEEK_SET);
+			ok = ok && std::fwrite(&hd, sizeof(hd), 1, fp) == 1;
+			std::fclose(fp);
+			fp = nullptr;
+			if (!ok)
+				log_error("h264 saver: error while finishing " + filename);
+			FileAttributes fa;
+			if (fa.open(filename.c_str()))
+			{
+				fa.set_global_attributes(global_attrs);
+				fa.add_global_attribute("GOP", std::to_string(GOP)); // h264.cpp:1903
+				fa.resize((size_t)nframes);
+				for (size_t i = 0; i < (size_t)nframes; ++i)
+				{
+					fa.set_timestamp(i, times[i]);
+					fa.set_attributes(i, frame_attrs[i]);
+				}
+				fa.close();
+			}
+			struct stat stt;
+			const int64_t fsize = stat(filename.c_str(), &stt) == 0 ? (int64_t)stt.st_size : 0;
+			times.clear();
+			frame_attrs.clear();
+			index.clear();
+			nframes = 0;
+			return fsize;
+		}
+	};
+
+	// ---- loader ------------------------------------------------------------------------------
+	// reference: IRFileLoader (IRFileLoader.cpp) restricted to what the hot path needs:
+	// this build's container and raw PCR files.
+	struct CameraObject : public Object
+	{
+		const char *type_name() const override { return "Camera"; }
+		enum Kind
+		{
+			RIRB,
+			PCR
+		} kind = RIRB;
+		std::string filename;
+		FILE *fp = nullptr;
+		std::vector<char> mem; // in-memory file (open_camera_from_memory)
+		int width = 0, height = 0, count = 0;
+		std::vector<int64_t> times;
+		AttrMap global_attrs;
+		std::vector<AttrMap> frame_attrs;
+		int last_pos = -1;
+		std::vector<unsigned short> last_raw;
+		// PCR
+		int64_t pcr_start = 0, pcr_transfer = 0;
+		// RIRB
+		FileHeader hd{};
+		std::vector<IndexEntry> index;
+		ChunkCodec cc;
+		int cached_chunk = -1;
+		std::vector<unsigned short> cache; // decoded frames of cached_chunk
+		// read-back filters
+		bool bp_enabled = false;
+		int bp_handle = 0;
+		bool motion_enabled = false;
+		std::vector<float> shifts; // (x,y) per frame
+
+		~CameraObject() override
+		{
+			if (fp)
+				std::fclose(fp);
+			if (bp_handle > 0)
+				bad_pixels_destroy(bp_handle);
+		}
+
+		size_t total_size()
+		{
+			if (!fp)
+				return mem.size();
+			struct stat st;
+			return fstat(fileno(fp), &st) == 0 ? (size_t)st.st_size : 0;
+		}
+		bool read_at(uint64_t off, void *dst, size_t n)
+		{
+			if (!fp)
+			{
+				if (off + n > mem.size())
+					return false;
+				std::memcpy(dst, mem.data() + off, n);
+				return true;
+			}
+			if (fseeko(fp, (off_t)off, SEEK_SET) != 0)
+				return false;
+			return std::fread(dst, 1, n, fp) == n;
+		}
+
+		bool open_common()
+		{
+			const size_t fsize = total_size();
+			char buf[2000];
+			std::memset(buf, 0, sizeof(buf));
+			if (!read_at(0, buf, std::min(fsize, sizeof(buf))))
+				return false;
+			FtypBox box;
+			std::memcpy(&box, buf, sizeof(box));
+			if (std::memcmp(box.type, "ftyp", 4) == 0)
+			{
+				if (std::memcmp(box.major, "RIRB", 4) != 0)
+				{
+					log_error("MP4/H.264 files written by the reference (ffmpeg/x264) are not readable by this library");
+					return false;
+				}
+				std::memcpy(&hd, buf + sizeof(FtypBox), sizeof(hd));
+				if (std::memcmp(hd.magic, "RIRBLOCK", 8) != 0 || hd.version != 1 || hd.index_offset == 0)
+				{
+					log_error("RIRB file not closed properly or unknown version");
+					return false;
+				}
+				kind = RIRB;
+				width = (int)hd.width, height = (int)hd.height, count = (int)hd.nframes;
+				index.resize((size_t)hd.nchunks);
+				if (hd.nchunks && !read_at(hd.index_offset, index.data(), sizeof(IndexEntry) * index.size()))
+					return false;
+				if (count > 0 && !cc.prepare(width, height, (int)hd.gop))
+					return false;
+			}
+			else
+			{
+				PcrHeader ph;
+				std::memcpy(&ph, buf, sizeof(ph));
+				// detection rules of IRFileLoader.cpp:130-165 for plain PCR files
+				const bool lab = ph.Bits == 16 && ph.X == 640 && ph.Y == 512 && ph.Frequency == 50;
+				const bool pcr = ph.Bits == 16 && std::abs(ph.TransfertSize - ph.X * ph.Y * 2) < 2000 && ph.X > 0 && ph.Y > 0 && ph.X < 2000 && ph.Y < 2000;
+				if (!lab && !pcr)
+				{
+					log_error("unsupported file format (this library reads its own RIRB files and raw PCR files)");
+					return false;
+				}
+				if (lab)
+					ph.TransfertSize = ph.X * ph.Y * 2;
+				kind = PCR;
+				width = ph.X, height = ph.Y;
+				pcr_start = sizeof(PcrHeader);
+				pcr_transfer = ph.TransfertSize;
+				count = pcr_transfer ? (int)((fsize - pcr_start) / pcr_transfer) : 0;
+				if (count <= 0)
+					return false;
+				// timestamps: last 8 bytes of each frame when strictly increasing (IRFileLoader.cpp:255-282)
+				times.assign(count, 0);
+				bool has_times = true;
+				for (int i = 0; i < count && has_times; ++i)
+				{
+					int64_t t = 0;
+					if (!read_at(pcr_start + pcr_transfer * (int64_t)(i + 1) - 8, &t, 8))
+						has_times = false;
+					times[i] = t;
+					if (i > 0 && times[i] <= times[i - 1])
+						has_times = false;
+				}
+				if (!has_times)
+				{ // IRFileLoader.cpp:421-431
+					int freq = ph.Frequency <= 0 ? 50 : ph.Frequency;
+					const double sampling = 1000000000.0 / (double)freq;
+					for (int i = 0; i < count; ++i)
+						times[i] = (int64_t)(i * sampling);
+				}
+				else
+				{ // IRFileLoader.cpp:433-451
+					const int64_t t0 = times[0];
+					if (t0 > 28000 && t0 < 32000)
+						for (auto &t : times)
+							t *= 1000000;
+					else if (!(times.front() < -1000000000 || times.back() > 1000000000))
+						for (auto &t : times)
+							t = (t - t0) * 1000000;
+				}
+				if (!times.empty() && times.front() > 28000000000LL && times.front() < 32000000000LL)
+					for (auto &t : times)
+						t -= 32000000000LL;
+			}
+			// metadata trailer, when present
+			std::vector<int64_t> ttimes;
+			bool has_trailer = false;
+			{
+				const size_t fs = total_size();
+				char tail[30];
+				if (fs >= sizeof(tail) && read_at(fs - sizeof(tail), tail, sizeof(tail)) && std::memcmp(tail + 16, "H264ATTRIBUTES", 14) == 0)
+				{
+					uint64_t tsize;
+					std::memcpy(&tsize, tail + 8, 8);
+					if (tsize <= fs)
+					{
+						std::vector<char> tb((size_t)tsize);
+						if (read_at(fs - tsize, tb.data(), tb.size()))
+							has_trailer = FileAttributes::parse(tb.data(), tb.size(), global_attrs, frame_attrs, ttimes) != 0;
+					}
+				}
+			}
+			if (kind == RIRB)
+			{
+				times.assign(count, 0);
+				for (int i = 0; i < count; ++i)
+					times[i] = (has_trailer && i < (int)ttimes.size()) ? ttimes[i] : (int64_t)(i * (1000000000.0 / (hd.fps ? hd.fps : 50)));
+			}
+			frame_attrs.resize(count);
+			last_raw.assign((size_t)width * height, 0);
+			return true;
+		}
+
+		bool decode_chunk(int c)
+		{
+			if (c == cached_chunk)
+				return true;
+			if (!device_ready())
+				return false;
+			const IndexEntry &e = index[c];
+			ChunkHeader ch;
+			if (!read_at(e.file_offset, &ch, sizeof(ch)) || std::memcmp(ch.magic, "CHNK", 4) != 0 || (int)ch.gop != cc.gop ||
+				(int)ch.ntiles != cc.L.ntiles || ch.nframes == 0 || (int)ch.nframes > cc.gop ||
+				ch.payload_words > (uint64_t)cc.L.stream_max_bytes / 8)
+			{
+				log_error("RIRB file: corrupted chunk header");
+				return false;
+			}
+			std::vector<uint64_t> hdr((size_t)ch.ntiles * ch.gop), payload((size_t)ch.payload_words + 1);
+			std::vector<uint32_t> toff((size_t)ch.ntiles + 1);
+			uint64_t off = e.file_offset + sizeof(ch);
+			if (!read_at(off, hdr.data(), hdr.size() * 8))
+				return false;
+			off += hdr.size() * 8;
+			if (!read_at(off, toff.data(), toff.size() * 4))
+				return false;
+			off += toff.size() * 4;
+			if (ch.payload_words && !read_at(off, payload.data(), (size_t)ch.payload_words * 8))
+				return false;
+			hipStream_t st = default_stream();
+			const uint64_t coff[2] = {0, ch.payload_words};
+			const int zero = 0;
+			if (!hip_ok(hipMemcpyAsync(cc.d_hdr.ptr, hdr.data(), hdr.size() * 8, hipMemcpyHostToDevice, st), "H2D") ||
+				!hip_ok(hipMemcpyAsync(cc.d_tile_off.ptr, toff.data(), toff.size() * 4, hipMemcpyHostToDevice, st), "H2D") ||
+				!hip_ok(hipMemcpyAsync(cc.d_chunk_off.ptr, coff, sizeof(coff), hipMemcpyHostToDevice, st), "H2D") ||
+				!hip_ok(hipMemcpyAsync(cc.d_stream.ptr, payload.data(), payload.size() * 8, hipMemcpyHostToDevice, st), "H2D") ||
+				!hip_ok(hipMemcpyAsync(cc.d_err.ptr, &zero, sizeof(int), hipMemcpyHostToDevice, st), "H2D"))
+				return false;
+			if (rir_codec_decode_device(cc.d_hdr.as<unsigned long long>(), cc.d_tile_off.as<unsigned int>(), cc.d_chunk_off.as<unsigned long long>(),
+										cc.d_stream.as<unsigned long long>(), width, height, (int)ch.nframes, cc.gop, cc.d_frames.as<unsigned short>(),
+										cc.d_err.as<int>(), st) != 0)
+				return false;
+			int err = 0;
+			const size_t fbytes = (size_t)width * height * 2;
+			cache.resize((size_t)width * height * ch.nframes);
+			if (!hip_ok(hipMemcpyAsync(cache.data(), cc.d_frames.ptr, fbytes * ch.nframes, hipMemcpyDeviceToHost, st), "D2H") ||
+				!hip_ok(hipMemcpyAsync(&err, cc.d_err.ptr, sizeof(int), hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(hipStreamSynchronize(st), "sync"))
+				return false;
+			if (err)
+			{
+				cached_chunk = -1;
+				log_error("RIRB file: malformed chunk payload");
+				return false;
+			}
+			cached_chunk = c;
+			return true;
+		}
+
+		bool read_raw(int pos, unsigned short *out)
+		{
+			const size_t npx = (size_t)width * height;
+			if (kind == PCR)
+				return read_at(pcr_start + pcr_transfer * (int64_t)pos, out, npx * 2);
+			// chunk lookup: chunks hold `gop` frames except possibly the last
+			int c = (int)(pos / (int)hd.gop);
+			if (c >= (int)index.size() || (uint64_t)pos < index[c].first_frame || (uint64_t)pos >= index[c].first_frame + index[c].nframes)
+			{
+				c = -1;
+				for (size_t i = 0; i < index.size(); ++i)
+					if ((uint64_t)pos >= index[i].first_frame && (uint64_t)pos < index[i].first_frame + index[i].nframes)
+						c = (int)i;
+				if (c < 0)
+					return false;
+			}
+			if (!decode_chunk(c))
+				return false;
+			std::memcpy(out, cache.data() + (size_t)(pos - (int)index[c].first_frame) * npx, npx * 2);
+			return true;
+		}
+
+		// IRFileLoader::readImage (IRFileLoader.cpp:1148-1247), calibration 0 = digital levels
+		bool read_image(int pos, int calibration, unsigned short *pixels)
+		{
+			if (pos < 0 || pos >= count || !pixels)
+				return false;
+			if (calibration != 0)
+				return false; // no calibration plugin is shipped
+			if (!read_raw(pos, pixels))
+				return false;
+			last_pos = pos;
+			std::memcpy(last_raw.data(), pixels, last_raw.size() * 2);
+			const bool do_bp = bp_enabled && bp_handle > 0 && global_attrs.count("Type") == 0;
+			const bool do_motion = motion_enabled && !shifts.empty();
+			if (!do_bp && !do_motion)
+				return true;
+			if (!device_ready() || height <= 3)
+				return false;
+			hipStream_t st = default_stream();
+			const size_t fbytes = (size_t)width * height * 2;
+			if (!cc.d_tmp.reserve(fbytes * 2) || !cc.d_shift.reserve(8))
+				return false;
+			unsigned short *d_a = cc.d_tmp.as<unsigned short>(), *d_b = d_a + (size_t)width * height;
+			if (!hip_ok(hipMemcpyAsync(d_a, pixels, fbytes, hipMemcpyHostToDevice, st), "H2D"))
+				return false;
+			unsigned short *res = d_a;
+			if (do_bp && rir_remove_bad_pixels_device(bp_handle, d_a, height - 3, 1, st) != 0)
+				return false;
+			if (do_motion)
+			{
+				const float sh[2] = {shifts[2 * pos], shifts[2 * pos + 1]};
+				if (!hip_ok(hipMemcpyAsync(cc.d_shift.ptr, sh, sizeof(sh), hipMemcpyHostToDevice, st), "H2D") ||
+					rir_remove_motion_device(d_a, d_b, width, height, height - 3, 1, cc.d_shift.as<float>(), st) != 0)
+					return false;
+				res = d_b;
+			}
+			return hip_ok(hipMemcpyAsync(pixels, res, fbytes, hipMemcpyDeviceToHost, st), "D2H") && hip_ok(hipStreamSynchronize(st), "sync");
+		}
+
+		// IRFileLoader::setBadPixelsEnabled (IRFileLoader.cpp:693-716): detector on the first image, rows < H-3, once
+		bool set_bad_pixels(bool enable)
+		{
+			if (enable && bp_handle <= 0 && count > 0 && height > 3)
+			{
+				std::vector<unsigned short> first((size_t)width * height);
+				const bool bp_save = bp_enabled, m_save = motion_enabled;
+				bp_enabled = motion_enabled = false;
+				const bool ok = read_image(0, 0, first.data());
+				bp_enabled = bp_save, motion_enabled = m_save;
+				if (!ok || !device_ready())
+					return false;
+				hipStream_t st = default_stream();
+				if (!cc.d_tmp.reserve(first.size() * 4) ||
+					!hip_ok(hipMemcpyAsync(cc.d_tmp.ptr, first.data(), first.size() * 2, hipMemcpyHostToDevice, st), "H2D"))
+					return false;
+				bp_handle = rir_bad_pixels_create_rows_device(cc.d_tmp.as<unsigned short>(), width, height, height - 3, st);
+				if (bp_handle <= 0)
+					return false;
+			}
+			bp_enabled = enable;
+			return true;
+		}
+
+		// IRFileLoader::loadTranslationFile (IRFileLoader.cpp:822-847): TSV, one header line, 4 columns, x and y in columns 1 and 2
+		bool load_translation_file(const char *fname)
+		{
+			FILE *f = std::fopen(fname, "r");
+			if (!f)
+				return false;
+			std::vector<float> vals;
+			char line[4096];
+			bool first = true, ok = true;
+			std::vector<float> out;
+			while (std::fgets(line, sizeof(line), f))
+			{
+				if (first)
+				{
+					first = false;
+					continue;
+				}
+				std::istringstream ss(line);
+				std::vector<float> row;
+				std::string tok;
+				while (ss >> tok)
+				{
+					std::replace(tok.begin(), tok.end(), ',', '.');
+					row.push_back((float)std::atof(tok.c_str()));
+				}
+				if (row.empty())
+					continue;
+				if (row.size() != 4)
+				{
+					ok = false;
+					break;
+				}
+				out.push_back(row[1]);
+				out.push_back(row[2]);
+			}
+			std::fclose(f);
+			if (!ok)
+			{
+				log_error("error while loading motion correction file: 4 columns expected");
+				return false;
+			}
+			if ((int)(out.size() / 2) != count)
+			{
+				log_error("wrong number of images in motion correction file");
+				return false;
+			}
+			shifts.swap(out);
+			return true;
+		}
+	};
+
+	std::shared_ptr<CameraObject> camera(int h) { return lookup_as<CameraObject>(h); }
+	std::shared_ptr<SaverObject> saver(int h) { return lookup_as<SaverObject>(h); }
+
+	int format_of(const CameraObject &c) { return c.kind == CameraObject::PCR ? FILE_FORMAT_PCR : FILE_FORMAT_H264; }
+
+	int kv_out(const AttrMap &m, int index, char *key, int *key_len, char *value, int *value_len, bool global)
+	{
+		if (index < 0 || index >= (int)m.size() || !key_len || !value_len)
+			return -1;
+		auto it = m.begin();
+		std::advance(it, index);
+		const int s1 = (int)it->first.size(), s2 = (int)it->second.size();
+		const int oldk = *key_len, oldv = *value_len;
+		if (global)
+		{ // video_io.cpp:624-641: the key buffer needs room for the terminator
+			if (s1 + 1 > *key_len || s2 > *value_len)
+			{
+				*key_len = s1 + 1;
+				*value_len = s2;
+				return -2;
+			}
+		}
+		else if (s1 > *key_len || s2 > *value_len)
+		{ // video_io.cpp:573-582
+			*key_len = s1;
+			*value_len = s2;
+			return -2;
+		}
+		*key_len = s1;
+		*value_len = s2;
+		std::memcpy(key, it->first.data(), s1);
+		std::memcpy(value, it->second.data(), s2);
+		if (global || oldk > s1)
+			key[s1] = 0;
+		if (oldv > s2)
+			value[s2] = 0;
+		return 0;
+	}
+} // namespace
+
+// =====================================================================================================
+// loader entry points
+// =====================================================================================================
+
+static int register_camera(std::shared_ptr<CameraObject> cam, int *file_format)
+{
+	if (!cam->open_common())
+		return 0;
+	if (file_format)
+		*file_format = format_of(*cam);
+	return register_object(cam);
+}
+
+// video_io.cpp:16-49: handle > 0, or 0 on failure (file_format set to 0)
+RIR_EXPORT int open_camera_file(const char *filename, int *file_format)
+{
+	if (file_format)
+		*file_format = 0;
+	auto cam = std::make_shared<CameraObject>();
+	cam->filename = filename ? filename : "";
+	cam->fp = filename ? std::fopen(filename, "rb") : nullptr;
+	int h = cam->fp ? register_camera(cam, file_format) : 0;
+	if (h <= 0)
+	{
+		log_error("Unable to open camera file " + cam->filename + ": wrong file format");
+		return 0;
+	}
+	return h;
+}
+
+// video_io.cpp:110-145 (the bytes are copied: the caller may release its buffer)
+RIR_EXPORT int open_camera_from_memory(void *ptr, int64_t size, int *file_format)
+{
+	if (file_format)
+		*file_format = 0;
+	auto cam = std::make_shared<CameraObject>();
+	if (ptr && size > 0)
+		cam->mem.assign(static_cast<char *>(ptr), static_cast<char *>(ptr) + size);
+	int h = cam->mem.empty() ? 0 : register_camera(cam, file_format);
+	if (h <= 0)
+	{
+		log_error("Unable to open camera file: wrong file format");
+		return 0;
+	}
+	return h;
+}
+
+// video_io.cpp:74-108 takes a reference FileReader object; none can exist outside the reference library
+RIR_EXPORT int open_camera_file_reader(void *, int *file_format)
+{
+	if (file_format)
+		*file_format = 0;
+	log_error("open_camera_file_reader: file reader objects are not supported, use open_camera_file or open_camera_from_memory");
+	return 0;
+}
+
+// video_io.cpp:51-72
+RIR_EXPORT int video_file_format(const char *filename)
+{
+	auto cam = std::make_shared<CameraObject>();
+	cam->filename = filename ? filename : "";
+	cam->fp = filename ? std::fopen(filename, "rb") : nullptr;
+	if (!cam->fp || !cam->open_common())
+		return -1;
+	return format_of(*cam);
+}
+
+RIR_EXPORT int close_camera(int cam)
+{
+	if (!camera(cam))
+	{
+		log_error("close_camera: NULL camera");
+		return -1;
+	}
+	remove_object(cam);
+	return 0;
+}
+
+RIR_EXPORT int get_image_count(int cam)
+{
+	auto c = camera(cam);
+	if (!c)
+	{
+		log_error("get_image_count: NULL camera");
+		return -1;
+	}
+	return c->count;
+}
+
+RIR_EXPORT int get_image_time(int cam, int pos, int64_t *time)
+{
+	auto c = camera(cam);
+	if (!c)
+	{
+		log_error("get_image_time: NULL camera");
+		return -1;
+	}
+	if (pos < 0 || pos >= (int)c->times.size() || !time)
+	{
+		log_error("get_image_time: position out of range");
+		return -1;
+	}
+	*time = c->times[pos];
+	return 0;
+}
+
+RIR_EXPORT int get_image_size(int cam, int *width, int *height)
+{
+	auto c = camera(cam);
+	if (!c || !width || !height)
+	{
+		log_error("get_image_size: NULL camera");
+		return -1;
+	}
+	*width = c->width;
+	*height = c->height;
+	return 0;
+}
+
+RIR_EXPORT int get_filename(int cam, char *filename)
+{
+	auto c = camera(cam);
+	if (!c || !filename)
+	{
+		log_error("get_filename: NULL camera");
+		return -1;
+	}
+	std::string f = c->filename.substr(0, UNSPECIFIED_CHAR_LENGTH - 1);
+	std::memset(filename, 0, UNSPECIFIED_CHAR_LENGTH);
+	std::memcpy(filename, f.data(), f.size());
+	return 0;
+}
+
+// only "Digital Level": no calibration plugin is shipped with the reference either (BaseCalibration.cpp:7-43)
+RIR_EXPORT int supported_calibrations(int cam, int *count)
+{
+	if (!camera(cam) || !count)
+	{
+		log_error("support_calibration: NULL camera");
+		return -1;
+	}
+	*count = 1;
+	return 0;
+}
+RIR_EXPORT int calibration_name(int cam, int calibration, char *name)
+{
+	if (!camera(cam) || !name)
+	{
+		log_error("support_calibration: NULL camera");
+		return -1;
+	}
+	if (calibration != 0)
+	{
+		log_error("calibration_name: calibration index out of range");
+		return -1;
+	}
+	std::memcpy(name, "Digital Level", 13);
+	return 0;
+}
+
+// video_io.cpp:361-375
+RIR_EXPORT int load_image(int cam, int pos, int calibration, unsigned short *pixels)
+{
+	auto c = camera(cam);
+	if (!c)
+	{
+		log_error("load_image: NULL camera");
+		return -1;
+	}
+	return c->read_image(pos, calibration, pixels) ? 0 : -1;
+}
+
+// video_io.cpp:377-391: the uint16 image cast to float (IRVideoLoader.h:109-117)
+RIR_EXPORT int load_imageF(int cam, int pos, int calibration, float *pixels)
+{
+	auto c = camera(cam);
+	if (!c || !pixels)
+	{
+		log_error("load_image: NULL camera");
+		return -1;
+	}
+	std::vector<unsigned short> tmp((size_t)c->width * c->height);
+	if (!c->read_image(pos, calibration, tmp.data()))
+		return -1;
+	for (size_t i = 0; i < tmp.size(); ++i)
+		pixels[i] = (float)tmp[i];
+	return 0;
+}
+
+RIR_EXPORT int get_last_image_raw_value(int cam, int x, int y, unsigned short *value)
+{
+	auto c = camera(cam);
+	if (!c)
+	{
+		log_error("get_last_image_raw_value: NULL camera");
+		return -1;
+	}
+	if (!value || x < 0 || y < 0 || x >= c->width || y >= c->height || c->last_pos < 0)
+		return -1;
+	*value = c->last_raw[(size_t)y * c->width + x];
+	return 0;
+}
+
+RIR_EXPORT int enable_bad_pixels(int cam, int enable)
+{
+	auto c = camera(cam);
+	if (!c)
+	{
+		log_error("enable_bad_pixels: NULL camera");
+		return -1;
+	}
+	return c->set_bad_pixels(enable != 0) ? 0 : -1;
+}
+RIR_EXPORT int bad_pixels_enabled(int cam)
+{
+	auto c = camera(cam);
+	return c ? (c->bp_enabled ? 1 : 0) : 0;
+}
+RIR_EXPORT int load_motion_correction_file(int cam, const char *filename)
+{
+	auto c = camera(cam);
+	if (!c)
+	{
+		log_error("load_motion_correction_file: NULL camera");
+		return -1;
+	}
+	if (!filename || !c->load_translation_file(filename))
+	{
+		log_error("unable to load file");
+		return -1;
+	}
+	return 0;
+}
+RIR_EXPORT int enable_motion_correction(int cam, int enable)
+{
+	auto c = camera(cam);
+	if (!c)
+	{
+		log_error("enable_motion_correction: NULL camera");
+		return -1;
+	}
+	c->motion_enabled = enable != 0;
+	return 0;
+}
+RIR_EXPORT int motion_correction_enabled(int cam)
+{
+	auto c = camera(cam);
+	if (!c)
+	{
+		log_error("motion_correction_enabled: NULL camera");
+		return 0;
+	}
+	return c->motion_enabled ? 1 : 0;
+}
+
+// attributes of the last read image / of the file (video_io.cpp:538-642)
+RIR_EXPORT int get_attribute_count(int cam)
+{
+	auto c = camera(cam);
+	if (!c)
+	{
+		log_error("get_attribute_count: NULL camera");
+		return -1;
+	}
+	return (c->last_pos >= 0 && c->last_pos < (int)c->frame_attrs.size()) ? (int)c->frame_attrs[c->last_pos].size() : 0;
+}
+RIR_EXPORT int get_attribute(int cam, int index, char *key, int *key_len, char *value, int *value_len)
+{
+	auto c = camera(cam);
+	if (!c)
+	{
+		log_error("get_attribute: NULL camera");
+		return -1;
+	}
+	if (c->last_pos < 0 || c->last_pos >= (int)c->frame_attrs.size())
+		return -1;
+	return kv_out(c->frame_attrs[c->last_pos], index, key, key_len, value, value_len, false);
+}
+RIR_EXPORT int get_global_attribute_count(int cam)
+{
+	auto c = camera(cam);
+	if (!c)
+	{
+		log_error("get_global_attribute_count: NULL camera");
+		return -1;
+	}
+	return (int)c->global_attrs.size();
+}
+RIR_EXPORT int get_global_attribute(int cam, int index, char *key, int *key_len, char *value, int *value_len)
+{
+	auto c = camera(cam);
+	if (!c)
+	{
+		log_error("get_global_attribute: NULL camera");
+		return -1;
+	}
+	return kv_out(c->global_attrs, index, key, key_len, value, value_len, true);
+}
+
+// ---- calibration / emissivity: no calibration object exists (reference behaviour without plugins) ----
+RIR_EXPORT int support_emissivity(int cam)
+{ // video_io.cpp:340-349: -1 when there is no calibration
+	(void)cam;
+	log_error("support_emissivity: NULL camera");
+	return -1;
+}
+RIR_EXPORT int set_global_emissivity(int cam, float emi)
+{
+	if (emi < 0.f || emi > 1.f)
+	{
+		log_error("set_emissivity: wrong emissivity value");
+		return -1;
+	}
+	if (!camera(cam))
+	{
+		log_error("set_global_emissivity: NULL camera");
+		return -1;
+	}
+	return 0;
+}
+RIR_EXPORT int set_emissivity(int cam, float *, int)
+{
+	if (!camera(cam))
+		log_error("set_emissivity: NULL camera");
+	else
+		log_error("set_emissivity: wrong vector size");
+	return -1;
+}
+RIR_EXPORT int get_emissivity(int cam, float *emi, int)
+{
+	if (!camera(cam) || !emi)
+	{
+		log_error("get_emissivity: NULL camera");
+		return -1;
+	}
+	*emi = 1;
+	return 0;
+}
+RIR_EXPORT int calibrate_inplace(int cam, unsigned short *, int, int calibration)
+{
+	if (!camera(cam))
+	{
+		log_error("load_image: NULL camera");
+		return -1;
+	}
+	return calibration == 0 ? 0 : -1;
+}
+RIR_EXPORT int calibrate_image_inplace(int cam, unsigned short *img, int size, int calib) { return calibrate_inplace(cam, img, size, calib); }
+RIR_EXPORT int calibrate_image(int cam, unsigned short *img, float *out, int size, int calib)
+{
+	if (!camera(cam) || !img || !out)
+	{
+		log_error("calibrate_image: NULL camera");
+		return -1;
+	}
+	if (calib != 0)
+		return -1;
+	for (int i = 0; i < size; ++i)
+		out[i] = (float)img[i];
+	return 0;
+}
+RIR_EXPORT int camera_saturate(int cam)
+{
+	if (!camera(cam))
+	{
+		log_error("camera_saturate: NULL camera");
+		return -1;
+	}
+	return 0;
+}
+RIR_EXPORT int calibration_files(int cam, char *, int *) { return camera(cam) ? -1 : -1; }
+RIR_EXPORT int flip_camera_calibration(int cam, int, int) { return camera(cam) ? -2 : -1; } // -2: no calibration (video_io.cpp:266-267)
+RIR_EXPORT int get_table_names(int cam, char *, int *dst_size)
+{
+	if (!camera(cam) || !dst_size)
+	{
+		log_error("get_table_names: NULL identifier");
+		return -1;
+	}
+	*dst_size = 0;
+	return 0;
+}
+RIR_EXPORT int get_table(int cam, const char *, float *, int *)
+{
+	if (!camera(cam))
+		log_error("get_table_names: NULL identifier");
+	return -1;
+}
+
+// =====================================================================================================
+// saver entry points (video_io.cpp:646-843)
+// =====================================================================================================
+
+RIR_EXPORT void set_ffmpeg_log_enabled(int) {} // there is no ffmpeg underneath
+
+// returns the identifier (> 0); 0 on error
+RIR_EXPORT int h264_open_file(const char *filename, int width, int height, int lossy_height)
+{
+	if (!filename)
+		return 0;
+	auto s = std::make_shared<SaverObject>();
+	s->filename = filename;
+	s->width = width, s->height = height, s->lossy_height = lossy_height;
+	if (file_exists(filename) && std::remove(filename) != 0)
+	{
+		log_error("h264_open_file: cannot remove output file");
+		return 0;
+	}
+	return register_object(s);
+}
+
+RIR_EXPORT void h264_close_file(int file)
+{
+	auto s = saver(file);
+	if (!s)
+	{
+		log_error("h264_close_file: NULL identifier");
+		return;
+	}
+	s->close();
+	remove_object(file);
+}
+
+RIR_EXPORT int h264_set_parameter(int file, const char *param, const char *value)
+{
+	auto s = saver(file);
+	if (!s)
+	{
+		log_error("h264_set_parameter: NULL identifier");
+		return -1;
+	}
+	return s->set_parameter(param, value) ? 0 : -1;
+}
+
+RIR_EXPORT int h264_set_global_attributes(int file, int attribute_count, char *keys, int *key_lens, char *values, int *value_lens)
+{
+	auto s = saver(file);
+	if (!s || attribute_count < 0)
+	{
+		log_error("h264_set_global_attributes: NULL identifier");
+		return -1;
+	}
+	s->global_attrs = attr_map_from_c(attribute_count, keys, key_lens, values, value_lens);
+	return 0;
+}
+
+RIR_EXPORT int h264_add_image_lossless(int file, unsigned short *img, int64_t timestamps_ns, int attribute_count, char *keys, int *key_lens,
+									   char *values, int *value_lens)
+{
+	auto s = saver(file);
+	if (!s || attribute_count < 0)
+	{
+		log_error("h264_add_image_lossless: NULL identifier");
+		return -1;
+	}
+	return s->add_image(img, timestamps_ns, attr_map_from_c(attribute_count, keys, key_lens, values, value_lens)) ? 0 : -1;
+}
+
+// Bounded-loss recording (h264.cpp:2253-2424) is the next step of the build.
+// Until then the frame is stored exactly: the documented invariant |out - in| <= lowValueError /
+// highValueError (h264.h:93-104) holds with zero error; only the extra compression is missing.
+RIR_EXPORT int h264_add_image_lossy(int file, unsigned short *img_DL, int64_t timestamps_ns, int attribute_count, char *keys, int *key_lens,
+									char *values, int *value_lens)
+{
+	auto s = saver(file);
+	if (!s || attribute_count < 0)
+	{
+		log_error("h264_add_image_lossy: NULL identifier");
+		return -1;
+	}
+	if (!s->add_image(img_DL, timestamps_ns, attr_map_from_c(attribute_count, keys, key_lens, values, value_lens)))
+		return -1;
+	s->low_errors.push_back((unsigned short)s->lowValueError);
+	s->high_errors.push_back((unsigned short)s->highValueError);
+	return 0;
+}
+
+// h264_add_loss (video_io.cpp:789-806) applies the loss to the caller's image without writing it:
+// with zero injected loss the image is returned unchanged.
+RIR_EXPORT int h264_add_loss(int file, unsigned short *img)
+{
+	auto s = saver(file);
+	if (!s || !img)
+	{
+		log_error("h264_add_loss: NULL identifier");
+		return -1;
+	}
+	return 0;
+}
+
+static int errors_out(const std::vector<unsigned short> &err, unsigned short *errors, int *size)
+{
+	if (!size)
+		return -1;
+	if (*size < (int)err.size() || !errors)
+	{
+		*size = (int)err.size();
+		return -2;
+	}
+	*size = (int)err.size();
+	std::memcpy(errors, err.data(), err.size() * sizeof(unsigned short));
+	return 0;
+}
+RIR_EXPORT int h264_get_low_errors(int file, unsigned short *errors, int *size)
+{
+	auto s = saver(file);
+	if (!s)
+	{
+		log_error("h264_get_low_erros: NULL identifier");
+		return -1;
+	}
+	return errors_out(s->low_errors, errors, size);
+}
+RIR_EXPORT int h264_get_high_errors(int file, unsigned short *errors, int *size)
+{
+	auto s = saver(file);
+	if (!s)
+	{
+		log_error("h264_get_high_erros: NULL identifier");
+		return -1;
+	}
+	return errors_out(s->high_errors, errors, size);
+}
+
+// Declared by the reference header (video_io.h:305-314) but defined nowhere upstream: here they are
+// the plain writer of the same container (method / clevel have no meaning for the block codec).
+RIR_EXPORT int open_video_write(const char *filename, int width, int height, int rate, int method, int clevel)
+{
+	(void)method;
+	(void)clevel;
+	const int h = h264_open_file(filename, width, height, height);
+	if (h <= 0)
+		return -1;
+	saver(h)->fps = rate > 0 ? rate : 50;
+	return h;
+}
+RIR_EXPORT int image_write(int writter, unsigned short *img, int64_t time)
+{
+	auto s = saver(writter);
+	if (!s)
+		return -1;
+	return s->add_image(img, time, AttrMap()) ? 0 : -1;
+}
+RIR_EXPORT int64_t close_video(int writter)
+{
+	auto s = saver(writter);
+	if (!s)
+		return -1;
+	const int64_t size = s->close();
+	remove_object(writter);
+	return size;
+}
+
+// Internal helpers of the reference for vendor files (video_io.cpp:911-958): not part of the path.
+RIR_EXPORT int correct_PCR_file(const char *filename, int width, int height, int freq)
+{
+	FILE *f = filename ? std::fopen(filename, "r+b") : nullptr;
+	if (!f)
+		return -1;
+	PcrHeader h;
+	if (std::fread(&h, sizeof(h), 1, f) != 1)
+	{
+		std::fclose(f);
+		return -1;
+	}
+	h.X = h.GrabSizeX = width;
+	h.Y = h.GrabSizeY = height;
+	h.Bits = 16;
+	h.Version = 0;
+	h.TransfertSize = width * height * 2;
+	h.Frequency = freq;
+	std::fseek(f, 0, SEEK_SET);
+	const bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1;
+	std::fclose(f);
+	return ok ? 0 : -1;
+}
+RIR_EXPORT int change_hcc_external_blackbody_temperature(const char *, float)
+{
+	log_error("change_hcc_external_blackbody_temperature: HCC vendor files are outside the accelerated path");
+	return -1;
+}

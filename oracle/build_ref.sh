@@ -36,14 +36,27 @@ cat >"$OUT/exports.map" <<'EOF'
   local: *;
 };
 EOF
+# The metadata trailer (tools/FileAttributes.cpp) needs zstd.h and libzstd: both exist in this image
+# under /opt/conda (1.4.9; the reference pins 1.5.5 - the zstd frame format is stable).  When they
+# are missing the trailer cross-check is simply left out of the build.
+ATTR_SRC=()
+ATTR_FLAGS=()
+ZSTD_INC=${RIR_ZSTD_INCLUDE:-/opt/conda/include}
+ZSTD_LIB=${RIR_ZSTD_LIB:-/opt/conda/lib}
+if [ -f "$ZSTD_INC/zstd.h" ] && [ -f "$ZSTD_LIB/libzstd.so" ]; then
+	mkdir -p "$OUT/zstd_inc"
+	cp "$ZSTD_INC/zstd.h" "$OUT/zstd_inc/" # only this header: the rest of that include dir must not shadow system headers
+	ATTR_SRC=("$R/src/cpp/tools/FileAttributes.cpp" "$R/src/cpp/tools/ReadFileChunk.cpp")
+	ATTR_FLAGS=(-DRIR_REF_WITH_ATTRS -I"$OUT/zstd_inc" -L"$ZSTD_LIB" -Wl,-rpath,"$ZSTD_LIB" -lzstd)
+fi
 g++ -std=c++14 -O3 -DNDEBUG -fPIC -shared -ffunction-sections -fdata-sections \
 	-DBUILD_SIGNAL_PROCESSING_LIB -DBUILD_TOOLS_LIB \
 	-I"$OUT" -I"$R/src/cpp/tools" -I"$R/src/cpp/geometry" -I"$R/src/cpp/signal_processing" \
 	"$R/src/cpp/signal_processing/BadPixels.cpp" "$R/src/cpp/signal_processing/Filters.cpp" \
 	"$R/src/cpp/signal_processing/signal_processing.cpp" \
 	"$R/src/cpp/tools/SIMD.cpp" "$R/src/cpp/tools/Misc.cpp" "$R/src/cpp/tools/Log.cpp" \
-	"$HERE/ref_driver.cpp" \
+	"${ATTR_SRC[@]}" "$HERE/ref_driver.cpp" \
 	-Wl,--gc-sections -Wl,--version-script="$OUT/exports.map" -Wl,--no-undefined \
-	-static-libstdc++ -static-libgcc -lpthread \
+	-static-libstdc++ -static-libgcc -lpthread "${ATTR_FLAGS[@]}" \
 	-o "$OUT/librir_ref.so"
 echo "build_ref: built $OUT/librir_ref.so"

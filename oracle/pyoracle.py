@@ -250,3 +250,38 @@ class Ref(_SignalProcessingMixin):
         out = np.zeros_like(img)
         self.lib.ref_median_filter_u16(_p(img), _p(out), img.shape[1], img.shape[0])
         return out
+
+
+class RefAttrs:
+    """The reference FileAttributes class (oracle/_ref, only when it was built with zstd)."""
+
+    def __init__(self, ref):
+        self.lib = ref.lib
+        if not hasattr(self.lib, "ref_attrs_write"):
+            raise FileNotFoundError("oracle/_ref built without the attribute trailer")
+
+    def write(self, filename, global_attrs, times, frame_key=None, frame_vals=None):
+        gk = list(global_attrs.keys())
+        gv = [v if isinstance(v, bytes) else str(v).encode() for v in global_attrs.values()]
+        n = len(times)
+        K = (ct.c_char_p * max(len(gk), 1))(*[k.encode() for k in gk])
+        V = (ct.c_char_p * max(len(gk), 1))(*gv)
+        VL = (ct.c_int * max(len(gk), 1))(*[len(v) for v in gv])
+        T = (ct.c_longlong * max(n, 1))(*[int(t) for t in times])
+        fv = frame_vals or [b""] * n
+        FV = (ct.c_char_p * max(n, 1))(*fv)
+        FL = (ct.c_int * max(n, 1))(*[len(v) for v in fv])
+        self.lib.ref_attrs_write.argtypes = [ct.c_char_p, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_char_p,
+                                             ct.c_void_p, ct.c_void_p]
+        r = self.lib.ref_attrs_write(str(filename).encode(), len(gk), K, V, VL, n, T, frame_key.encode() if frame_key else None, FV, FL)
+        if r != 0:
+            raise RuntimeError("ref_attrs_write failed")
+
+    def read(self, filename, gkey, cap=4096):
+        T = (ct.c_longlong * cap)()
+        buf = ct.create_string_buffer(1 << 20)
+        n = ct.c_int(1 << 20)
+        ng = ct.c_int(0)
+        self.lib.ref_attrs_read.argtypes = [ct.c_char_p, ct.c_void_p, ct.c_int, ct.c_char_p, ct.c_char_p, ct.POINTER(ct.c_int), ct.POINTER(ct.c_int)]
+        cnt = self.lib.ref_attrs_read(str(filename).encode(), T, cap, gkey.encode(), buf, ct.byref(n), ct.byref(ng))
+        return cnt, list(T[:max(cnt, 0)]), (buf.raw[: n.value] if n.value >= 0 else None), ng.value

@@ -71,3 +71,57 @@ extern "C"
 		rir::clampMin(img, (size_t)size, v);
 	}
 }
+
+// ---- reference FileAttributes (metadata trailer), reached through its C++ class ---------------------
+// reference src/cpp/tools/FileAttributes.cpp; the handle-based C entry points live in tools.cpp,
+// which needs minizip's unzip.h (absent), so the class is driven directly.
+#ifdef RIR_REF_WITH_ATTRS
+#include "FileAttributes.h"
+extern "C"
+{
+	// write a trailer with the given global attributes / timestamps / one attribute per frame
+	__attribute__((visibility("default"))) int ref_attrs_write(const char *filename, int nglobal, const char **gkeys, const char **gvals,
+																const int *gval_lens, int nframes, const long long *times, const char *frame_key,
+																const char **frame_vals, const int *frame_val_lens)
+	{
+		rir::FileAttributes fa;
+		if (!fa.open(filename))
+			return -1;
+		std::map<std::string, std::string> g;
+		for (int i = 0; i < nglobal; ++i)
+			g[gkeys[i]] = std::string(gvals[i], gvals[i] + gval_lens[i]);
+		fa.setGlobalAttributes(g);
+		fa.resize(nframes);
+		for (int i = 0; i < nframes; ++i)
+		{
+			fa.setTimestamp(i, times[i]);
+			if (frame_key)
+				fa.addAttribute(i, frame_key, std::string(frame_vals[i], frame_vals[i] + frame_val_lens[i]));
+		}
+		fa.close();
+		return 0;
+	}
+	// read back: returns the frame count, fills times (cap entries) and the value of one global key
+	__attribute__((visibility("default"))) int ref_attrs_read(const char *filename, long long *times, int cap, const char *gkey, char *gval, int *gval_len,
+															   int *nglobal)
+	{
+		rir::FileAttributes fa;
+		if (!fa.open(filename))
+			return -1;
+		int n = (int)fa.size();
+		for (int i = 0; i < n && i < cap; ++i)
+			times[i] = fa.timestamp(i);
+		*nglobal = (int)fa.globalAttributes().size();
+		auto it = fa.globalAttributes().find(gkey);
+		if (it != fa.globalAttributes().end() && (int)it->second.size() <= *gval_len)
+		{
+			memcpy(gval, it->second.data(), it->second.size());
+			*gval_len = (int)it->second.size();
+		}
+		else
+			*gval_len = -1;
+		fa.discard();
+		return n;
+	}
+}
+#endif

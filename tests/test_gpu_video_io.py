@@ -1,0 +1,189 @@
+"""GPU: the saver / loader C ABI and its Python mirror, on the reference tests' own scenarios
+(reference tests/python/test_IRMovie.py:40-49,60-99,228-229,267-322,327-335,363-366;
+tests/python/test_rir.py:317-332; tests/python/test_video_io.py:38-144,178-183,219-224)."""
+import os
+
+import numpy as np
+import pytest
+
+from librir_amd.synthetic import inject_bad_pixels, s1_noisy_background, s2_uniform_dl_ti
+from librir_amd.video_io import FileFormat, IRMovie, IRSaver
+from librir_amd.video_io import rir_video_io as rv
+
+pytestmark = pytest.mark.gpu
+
+
+def images(n=100, h=512, w=640):
+    return s1_noisy_background(n, h, w)
+
+
+@pytest.mark.parametrize("shape", [(512, 640), (1, 512, 640), (10, 512, 640), (10, 240, 320), (10, 256, 320), (3, 67, 83)])
+def test_movie_from_numpy_array_is_lossless(shape):
+    arr = s2_uniform_dl_ti(shape[0], *shape[1:]) if len(shape) == 3 else s2_uniform_dl_ti(1, *shape)[0]
+    if len(shape) == 3 and shape[0] == 3:
+        arr = np.random.default_rng(0).integers(0, 65536, shape).astype(np.uint16)
+    mov = IRMovie.from_numpy_array(arr)
+    exp = arr if arr.ndim == 3 else arr[None]
+    assert mov.images == exp.shape[0] and tuple(mov.image_size) == exp.shape[1:]
+    assert np.array_equal(mov.data, exp)
+    assert mov.video_file_format == FileFormat.H264  # test_IRMovie.py:228-229
+    tmp = mov.filename
+    mov.close()
+    assert not os.path.exists(tmp)
+
+
+def test_save_reload_slices_attributes(tmp_path):
+    arr = images(120, 96, 128)
+    dst = tmp_path / "movie.h264"
+    attrs = {"Name": "test", "Device": "cam42", "blob": b"\x00\x01\x02" * 700}
+    times = np.arange(120, dtype=np.int64) * 20000000 + 5
+    with IRSaver(dst, 128, 96, 96, clevel=8) as s:
+        s.set_global_attributes(attrs)
+        s.set_parameter("GOP", 50)
+        for i in range(120):
+            s.add_image(arr[i], times[i], attributes={"frame": str(i), "odd": "y" if i & 1 else "n"})
+    assert rv.video_file_format(dst) == rv.FILE_FORMAT_H264
+    with IRMovie.from_filename(dst) as mov:
+        assert mov.images == 120 and len(mov) == 120
+        assert np.array_equal(mov[7], arr[7]) and np.array_equal(mov[-1], arr[-1])
+        assert np.array_equal(mov[40:75:5], arr[40:75:5])  # crosses a chunk boundary
+        assert np.array_equal(mov[[3, 99, 51]], arr[[3, 99, 51]])  # random access
+        assert np.allclose(mov.timestamps, times * 1e-9)
+        a = mov.attributes
+        assert a["Name"] == b"test" and a["Device"] == b"cam42" and a["blob"] == b"\x00\x01\x02" * 700
+        assert a["GOP"] == b"50"  # added by the saver on close (h264.cpp:1903, test_IRMovie.py:315-321)
+        mov.load_pos(51)
+        assert mov.frame_attributes == {"frame": b"51", "odd": b"y"}
+        assert np.array_equal(mov.data, arr)
+        # re-encode a slice of the opened movie (test_IRMovie.py:60-99)
+        dst2 = tmp_path / "slice.h264"
+        mov.to_h264(dst2, start_img=10, count=30)
+    with IRMovie.from_filename(dst2) as m2:
+        assert m2.images == 30 and np.array_equal(m2.data, arr[10:40])
+        assert m2.attributes["Name"] == b"test"
+    # global attributes can be rewritten through the movie object (second FileAttributes on the file)
+    with IRMovie.from_filename(dst) as mov:
+        mov.attributes = {"Name": "renamed"}
+    with IRMovie.from_filename(dst) as mov:
+        assert mov.attributes == {"Name": b"renamed"} and np.array_equal(mov[119], arr[119])
+
+
+def test_small_int32_two_frames(tmp_path):
+    """reference tests/python/test_rir.py:317-332: 20x20 int32 images, two frames, read back"""
+    img = np.arange(400, dtype=np.int32).reshape(20, 20)
+    dst = tmp_path / "s.h264"
+    s = rv.h264_open_file(dst, 20, 20)
+    rv.h264_add_image_lossless(s, img, 0)
+    rv.h264_add_image_lossless(s, img + 1, 1000, {"k": "v"})
+    rv.h264_close_file(s)
+    cam = rv.open_camera_file(dst)
+    assert rv.get_image_count(cam) == 2 and rv.get_image_size(cam) == (20, 20)
+    assert np.array_equal(rv.load_image(cam, 0), img.astype(np.uint16))
+    assert np.array_equal(rv.load_image(cam, 1), (img + 1).astype(np.uint16))
+    assert rv.get_attributes(cam) == {"k": b"v"}
+    assert [rv.get_image_time(cam, i) for i in range(2)] == [0, 1000]
+    rv.close_camera(cam)
+
+
+def test_from_bytes_and_tis(tmp_path):
+    arr = s2_uniform_dl_ti(6, 64, 80)
+    mov = IRMovie.from_numpy_array(arr)
+    data = open(mov.filename, "rb").read()
+    m2 = IRMovie.from_bytes(data)  # test_IRMovie.py:327-335
+    assert np.array_equal(m2.data, arr)
+    assert np.array_equal(m2.tis, (arr & (2**16 - 2**13)) >> 13)  # test_IRMovie.py:363-366
+    m2.close()
+    mov.close()
+
+
+def test_wrong_image_dimension_raises(tmp_path):
+    with IRSaver(tmp_path / "x.h264", 32, 16) as s:
+        with pytest.raises(RuntimeError):
+            s.add_image(np.zeros((16, 33), np.uint16), 0)
+        s.add_image(np.zeros((16, 32), np.uint16), 0)
+    assert os.path.getsize(tmp_path / "x.h264") > 0
+
+
+def test_lossy_entry_points_respect_the_error_bound(tmp_path):
+    """documented invariant of the lossy mode: |out - in| <= lowValueError / highValueError (h264.h:93-104)"""
+    arr = images(12, 64, 80)
+    dst = tmp_path / "lossy.h264"
+    with IRSaver(dst, 80, 64, 64) as s:
+        s.set_parameter("lowValueError", 3)
+        s.set_parameter("highValueError", 3)
+        s.set_parameter("stdFactor", 0)
+        for i in range(12):
+            s.add_image_lossy(arr[i], i * 1000)
+        assert len(s.get_low_errors()) == len(s.get_high_errors()) == 12  # test_video_io.py:96-144
+        assert np.array_equal(s.add_loss(arr[0]), arr[0]) or np.abs(s.add_loss(arr[0]).astype(int) - arr[0]).max() <= 3
+    with IRMovie.from_filename(dst) as mov:
+        assert np.abs(mov.data.astype(np.int32) - arr).max() <= 3
+
+
+def test_readback_bad_pixels_and_motion_correction(tmp_path, oracle):
+    """enable_bad_pixels / load_motion_correction_file on decoded frames: the first H-3 rows are
+    filtered, the last three (camera metadata) are left alone (IRFileLoader.cpp:702,1211-1213)."""
+    h, w, n = 67, 83, 7
+    arr = inject_bad_pixels(images(n, h, w), 9)
+    mov = IRMovie.from_numpy_array(arr)
+    assert np.array_equal(mov[2], arr[2])
+    mov.bad_pixels_correction = True  # test_video_io.py:219-224
+    xy = oracle.bad_pixels_detect(arr[0][: h - 3])
+    for i in (0, 3, 6):
+        assert np.array_equal(mov[i], oracle.remove_bad_pixels(arr[i], xy, rows=h - 3))
+    # motion correction file: TSV, header line, 4 columns, x and y in columns 1 and 2
+    shifts = np.array([[0.0, 0.0], [1.25, -2.5], [-3.5, 4.75], [0.5, 0.5], [10, 0], [0, -10], [2, 2]], np.float32)
+    reg = tmp_path / "reg.csv"
+    with open(reg, "w") as f:
+        f.write("frame\tx\ty\tconfidence\n")
+        for i, (x, y) in enumerate(shifts):
+            f.write("%d\t%g\t%g\t1\n" % (i, x, y))
+    mov.registration_file = reg
+    assert not mov.registration
+    mov.registration = True
+    assert mov.registration
+    for i in (1, 2, 4):
+        exp = oracle.remove_motion(oracle.remove_bad_pixels(arr[i], xy, rows=h - 3), shifts[i, 0], shifts[i, 1], rows=h - 3)
+        assert np.array_equal(mov[i], exp)
+    mov.bad_pixels_correction = False
+    assert np.array_equal(mov[5], oracle.remove_motion(arr[5], shifts[5, 0], shifts[5, 1], rows=h - 3))
+    mov.registration = False
+    assert np.array_equal(mov[5], arr[5])
+    with pytest.raises(RuntimeError):  # wrong number of rows
+        bad = tmp_path / "bad.csv"
+        bad.write_text("a\tb\tc\td\n0\t0\t0\t1\n")
+        mov.registration_file = bad
+    mov.close()
+
+
+def test_record_throughput_and_ratio_are_reported(tmp_path, capsys):
+    """like reference tests/python/test_video_io.py:38-79: prints fps and compression factor, asserts counts/size"""
+    import time
+
+    arr = images(100)
+    dst = tmp_path / "rec.h264"
+    t0 = time.perf_counter()
+    with IRSaver(dst, 640, 512, 512) as s:
+        for i in range(100):
+            s.add_image(arr[i], i * 20000000)
+    dt = time.perf_counter() - t0
+    ratio = arr.nbytes / os.path.getsize(dst)
+    print("per-frame C ABI: %.0f fps, compression factor %.2f" % (100 / dt, ratio))
+    assert ratio > 3.5
+    with IRMovie.from_filename(dst) as mov:
+        assert mov.images == 100 and np.array_equal(mov[99], arr[99])
+
+
+def test_truncated_or_foreign_files_are_rejected(tmp_path):
+    arr = images(3, 32, 64)
+    mov = IRMovie.from_numpy_array(arr)
+    data = open(mov.filename, "rb").read()
+    mov.close()
+    p = tmp_path / "cut.h264"
+    p.write_bytes(data[: len(data) // 2])
+    with pytest.raises(RuntimeError):
+        rv.open_camera_file(p)
+    q = tmp_path / "mp4.mp4"
+    q.write_bytes(b"\x00\x00\x00\x20ftypisom" + b"\x00" * 5000)  # a real MP4: not ours
+    with pytest.raises(RuntimeError):
+        rv.open_camera_file(q)

@@ -1,0 +1,174 @@
+"""CPU: host-side logic of the video_io / tools boundary that needs no GPU - the attribute trailer
+(byte-compatible with the reference's, cross-read with the compiled reference where oracle/_ref has
+it), raw PCR reading, handle and error conventions, and the loud failure of the codec paths
+without a device."""
+import os
+
+import numpy as np
+import pytest
+
+from librir_amd.tools import FileAttributes, zstd_compress, zstd_decompress
+from librir_amd.video_io import rir_video_io as rv
+from librir_amd.video_io.IRMovie import create_pcr_header
+
+
+def write_pcr(path, frames, frequency=50):
+    n, h, w = frames.shape
+    hdr = create_pcr_header(h, w, frequency)
+    with open(path, "wb") as f:
+        f.write(hdr.astype(np.uint32).tobytes())
+        f.write(frames.astype(np.uint16).tobytes())
+
+
+def test_trailer_roundtrip_and_resize(tmp_path):
+    p = tmp_path / "video.bin"
+    p.write_bytes(b"payload" * 10)
+    fa = FileAttributes.from_filename(p)
+    fa.attributes = {"Name": "WA", "big": b"\x07" * 5000, "empty": ""}
+    fa.timestamps = [10, 20, 30]
+    fa.set_frame_attributes(0, {"a": "1"})
+    fa.set_frame_attributes(2, {"b": b"\x00\xff", "c": "x" * 2000})
+    fa.close()
+    size1 = os.path.getsize(p)
+    assert p.read_bytes().startswith(b"payload" * 10) and p.read_bytes().endswith(b"H264ATTRIBUTES")
+    fa = FileAttributes.from_filename(p)
+    assert fa.attributes == {"Name": b"WA", "big": b"\x07" * 5000, "empty": b""}
+    assert list(fa.timestamps) == [10, 20, 30] and fa.frame_count() == 3
+    assert fa.frame_attributes(0) == {"a": b"1"} and fa.frame_attributes(1) == {} and fa.frame_attributes(2)["b"] == b"\x00\xff"
+    fa.attributes = {"Name": "WA"}  # a second object rewrites a SHORTER trailer: the file is truncated
+    fa.close()
+    assert os.path.getsize(p) < size1 and p.read_bytes().startswith(b"payload" * 10)
+    fa = FileAttributes.from_filename(p)
+    assert fa.attributes == {"Name": b"WA"} and list(fa.timestamps) == [10, 20, 30]
+    fa.discard()
+
+
+def test_trailer_layout_is_the_reference_layout(tmp_path):
+    """map(global) map(frame)* int64 ts[N] u64 N u64 size 'H264ATTRIBUTES' - FileAttributes.cpp:455-485"""
+    p = tmp_path / "t.bin"
+    p.write_bytes(b"")
+    fa = FileAttributes.from_filename(p)
+    fa.attributes = {"k": "vv"}
+    fa.timestamps = [7]
+    fa.close()
+    raw = p.read_bytes()
+    u64 = lambda v: int(v).to_bytes(8, "little")
+    expected = u64(1) + u64(1) + b"k" + u64(2) + b"vv" + u64(0) + u64(7) + u64(1)
+    expected += u64(len(expected) + 8 + 14) + b"H264ATTRIBUTES"
+    assert raw == expected
+
+
+def test_trailer_cross_read_with_reference(tmp_path, ref):
+    from oracle.pyoracle import RefAttrs
+
+    try:
+        RA = RefAttrs(ref)
+    except FileNotFoundError:
+        pytest.skip("oracle/_ref built without FileAttributes")
+    # reference writes, we read
+    p = tmp_path / "ref.bin"
+    p.write_bytes(b"abc")
+    RA.write(p, {"Device": "cam", "blob": b"\x01" * 4000}, [5, 6, 7, 8], "idx", [b"0", b"1", b"22", b"333"])
+    fa = FileAttributes.from_filename(p)
+    assert fa.attributes == {"Device": b"cam", "blob": b"\x01" * 4000}
+    assert list(fa.timestamps) == [5, 6, 7, 8] and fa.frame_attributes(3) == {"idx": b"333"}
+    fa.discard()
+    # we write, the reference reads
+    q = tmp_path / "ours.bin"
+    q.write_bytes(b"xyz")
+    fa = FileAttributes.from_filename(q)
+    fa.attributes = {"GOP": "50", "blob": b"\x02" * 3000}
+    fa.timestamps = [100, 200]
+    fa.close()
+    cnt, times, val, ng = RA.read(q, "blob")
+    assert cnt == 2 and times == [100, 200] and val == b"\x02" * 3000 and ng == 2
+    # uncompressed trailers are byte-identical
+    a, b = tmp_path / "a.bin", tmp_path / "b.bin"
+    a.write_bytes(b"")
+    b.write_bytes(b"")
+    RA.write(a, {"k1": "v1", "k2": "v2"}, [1, 2, 3], "f", [b"x", b"y", b"z"])
+    fa = FileAttributes.from_filename(b)
+    fa.attributes = {"k1": "v1", "k2": "v2"}
+    fa.timestamps = [1, 2, 3]
+    for i, v in enumerate([b"x", b"y", b"z"]):
+        fa.set_frame_attributes(i, {"f": v})
+    fa.close()
+    assert a.read_bytes() == b.read_bytes()
+
+
+def test_zstd_wrappers():
+    data = np.random.default_rng(0).integers(0, 4, 10000).astype(np.uint8).tobytes()
+    c = zstd_compress(data, 3)
+    assert len(c) < len(data) and zstd_decompress(c) == data
+    with pytest.raises(RuntimeError):  # reference tests/python/test_rir.py:47-74
+        zstd_decompress(b"not a zstd frame")
+
+
+def test_pcr_reader_needs_no_gpu(tmp_path):
+    rng = np.random.default_rng(1)
+    fr = rng.integers(0, 16000, (4, 20, 30)).astype(np.uint16)
+    p = tmp_path / "m.pcr"
+    write_pcr(p, fr, frequency=25)
+    assert rv.video_file_format(p) == rv.FILE_FORMAT_PCR
+    cam = rv.open_camera_file(p)
+    assert rv.get_image_count(cam) == 4 and rv.get_image_size(cam) == (20, 30)
+    for i in range(4):
+        assert np.array_equal(rv.load_image(cam, i), fr[i])
+    # timestamps synthesised at 1e9/Frequency ns when the frames carry none (IRFileLoader.cpp:421-431)
+    assert [rv.get_image_time(cam, i) for i in range(4)] == [0, 40000000, 80000000, 120000000]
+    assert rv.supported_calibrations(cam) == ["Digital Level"]
+    assert rv.get_filename(cam) == str(p)
+    assert rv.get_last_image_raw_value(cam, 3, 2) == fr[3, 2, 3]
+    with pytest.raises(RuntimeError):
+        rv.load_image(cam, 4)
+    with pytest.raises(RuntimeError):
+        rv.load_image(cam, -1)
+    with pytest.raises(RuntimeError):
+        rv.load_image(cam, 0, 1)  # no temperature calibration without a plugin
+    rv.close_camera(cam)
+    assert rv.get_image_count(cam) == -1  # handle released
+    with pytest.raises(RuntimeError):
+        rv.open_camera_file(tmp_path / "missing.bin")
+    junk = tmp_path / "junk.bin"
+    junk.write_bytes(b"\x00" * 5000)
+    with pytest.raises(RuntimeError):
+        rv.open_camera_file(junk)
+    assert rv.video_file_format(junk) == -1
+
+
+def test_pcr_in_memory(tmp_path):
+    fr = np.arange(2 * 6 * 8, dtype=np.uint16).reshape(2, 6, 8)
+    data = create_pcr_header(6, 8).astype(np.uint32).tobytes() + fr.tobytes()
+    cam = rv.open_camera_memory(data)
+    assert np.array_equal(rv.load_image(cam, 1), fr[1])
+    rv.close_camera(cam)
+
+
+def test_saver_parameters_and_handles(tmp_path):
+    s = rv.h264_open_file(tmp_path / "o.h264", 32, 16)
+    for k in ["compressionLevel", "lowValueError", "highValueError", "codec", "GOP", "threads", "slices", "stdFactor", "inputCamera",
+              "removeBadPixels", "subtractMin", "subtractLocalMin", "runningAverage"]:
+        rv.h264_set_parameter(s, k, "1")
+    with pytest.raises(RuntimeError):  # unknown key -> -1 (h264.cpp:1709-1781)
+        rv.h264_set_parameter(s, "noSuchParameter", "1")
+    rv.h264_set_global_attributes(s, {"a": "b"})
+    assert len(rv.h264_get_low_errors(s)) == 0
+    rv.h264_close_file(s)  # nothing was added: no file is created
+    assert not os.path.exists(tmp_path / "o.h264")
+    with pytest.raises(RuntimeError):
+        rv.h264_set_parameter(s, "GOP", "5")  # the handle is gone
+
+
+def test_codec_paths_fail_loudly_without_device(tmp_path):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from librir_amd.low_level.misc import last_error
+
+    s = rv.h264_open_file(tmp_path / "o.h264", 32, 16)
+    with pytest.raises(RuntimeError):
+        rv.h264_add_image_lossless(s, np.zeros((16, 32), np.uint16), 0)
+    assert "no usable HIP device" in last_error()
+    rv.h264_close_file(s)
+    assert not os.path.exists(tmp_path / "o.h264") or os.path.getsize(tmp_path / "o.h264") == 0
