@@ -144,6 +144,24 @@ namespace rir
 		RIR_TSTAGE2(RIR_XOR1, c.k1, c.a1)
 	}
 
+	// 32x32 bit-matrix transpose inside each 32-lane half of the wave (one dword per lane): lane q of a
+	// half ends with bit l = bit q of that half's lane l.  Same butterfly, without the 32-lane stage.
+	__device__ __forceinline__ uint32_t transpose32(uint32_t x, const TransposeConsts &c)
+	{
+		uint32_t t;
+		t = RIR_XOR16(x);
+		x = bfi(c.k16, __builtin_amdgcn_alignbit(t, t, c.a16), x);
+		t = RIR_XOR8(x);
+		x = bfi(c.k8, __builtin_amdgcn_alignbit(t, t, c.a8), x);
+		t = RIR_XOR4(x);
+		x = bfi(c.k4, __builtin_amdgcn_alignbit(t, t, c.a4), x);
+		t = RIR_XOR2(x);
+		x = bfi(c.k2, __builtin_amdgcn_alignbit(t, t, c.a2), x);
+		t = RIR_XOR1(x);
+		x = bfi(c.k1, __builtin_amdgcn_alignbit(t, t, c.a1), x);
+		return x;
+	}
+
 	// ---- tile I/O ------------------------------------------------------------------------------------
 	struct Px8
 	{
@@ -294,6 +312,15 @@ namespace rir
 		uint32_t sh16;	 // 16 * (q & 1)
 		bool row_hi;	 // q >= 2 : this row's header field is in the high dword
 		bool row0;		 // q == 0
+		// narrow tier (all widths <= 4): lane (lane & 31) = 4*slot + plane, the two 32-lane halves
+		// hold the low / high dword of the plane word
+		uint32_t n_bit;	   // plane = lane & 3
+		uint32_t n_sh;	   // 4 * slot : position of the slot's planes in the 32-bit non-zero mask
+		uint32_t n_half;   // byte offset of this half inside the 64-bit word (0 or 4)
+		uint32_t n_hsh;	   // bit position of the slot's width inside its header dword
+		bool n_hhi;		   // the slot's width lives in the high header dword
+		bool n_first;	   // plane 0 of its slot
+		uint32_t h_sha, h_shb; // header lanes (16q+k): positions of slots q and 4+q in the non-zero mask
 	};
 	__device__ __forceinline__ LaneConsts make_lane_consts(int lane)
 	{
@@ -306,6 +333,15 @@ namespace rir
 		c.sh16 = 16 * (q & 1);
 		c.row_hi = q >= 2;
 		c.row0 = q == 0;
+		const uint32_t slot = ((uint32_t)lane & 31u) >> 2;
+		c.n_bit = lane & 3;
+		c.n_sh = 4 * slot;
+		c.n_half = ((uint32_t)lane >> 5) * 4;
+		c.n_hsh = 16 * (slot & 1) + (slot >= 4 ? 5 : 0);
+		c.n_hhi = (slot & 2) != 0;
+		c.n_first = (lane & 3) == 0;
+		c.h_sha = 4 * q;
+		c.h_shb = 16 + 4 * q;
 		return c;
 	}
 
@@ -325,13 +361,56 @@ namespace rir
 		return s + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x143, 0xc, 0xf, false);			  // row_bcast:31 -> rows 2,3
 	}
 
-	// Emit the payload of one record: residuals r (packed pairs) -> plane words at out[pos..pos+words).
-	// Returns the header; `modebits` = mode << 14 in row 0, zero elsewhere.
-	__device__ __forceinline__ uint64_t emit_record(const Px8 &r, uint32_t modebits, uint32_t base, __amdgpu_buffer_rsrc_t out, uint32_t pos,
-													const LaneConsts &lc, const TransposeConsts &tc, uint32_t *words)
+	// inclusive sum over the 32 lanes of each half (DPP row shifts + one row broadcast)
+	__device__ __forceinline__ uint32_t half_inclusive_sum(uint32_t v)
+	{
+		v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); // row_shr:1
+		v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true); // row_shr:2
+		v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true); // row_shr:4
+		v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true); // row_shr:8
+		v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1,3
+		return v;
+	}
+	// bit length of a value < 2^31 without a zero test: bitlen(2f+1) = bitlen(f)+1
+	__device__ __forceinline__ uint32_t bitlen_nz(uint32_t f) { return 31u - (uint32_t)__builtin_clz((f << 1) | 1u); }
+
+	// Narrow tier: every residual < 16.  The 8 nibbles of a lane are packed in one dword and ONE
+	// 32x32 transpose per half-wave produces the 32 candidate planes (lane 4j+b: plane b of slot j;
+	// the upper half holds bits 32..63 of the same plane word).
+	__device__ __forceinline__ uint64_t emit_record_narrow(const Px8 &r, uint32_t modebits, uint32_t base, __amdgpu_buffer_rsrc_t out, uint32_t pos,
+														   const LaneConsts &lc, const TransposeConsts &tc, uint32_t *words)
+	{
+		// bytes r0..r3 / r4..r7, then nibbles
+		const uint32_t p01 = __builtin_amdgcn_perm(r.d[1], r.d[0], 0x06040200u);
+		const uint32_t p23 = __builtin_amdgcn_perm(r.d[3], r.d[2], 0x06040200u);
+		const uint32_t x01 = p01 | (p01 >> 4), x23 = p23 | (p23 >> 4);
+		uint32_t x = __builtin_amdgcn_perm(x23, x01, 0x06040200u); // nibble j = r_j
+		x = transpose32(x, tc);
+		const uint64_t nz64 = __ballot(x != 0);
+		const uint32_t nz = (uint32_t)nz64 | (uint32_t)(nz64 >> 32); // bit 4j+b: plane b of slot j is not empty
+		const uint32_t w = bitlen_nz((nz >> lc.n_sh) & 15u);		  // width of this lane's slot
+		const uint32_t incl = half_inclusive_sum(lc.n_first ? w : 0u); // words of slots 0..j
+		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+		// lower-half lanes assemble the 64-bit plane word (their dword | the partner lane's dword << 32)
+		auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false); // sw[1] lower lanes = x of lane + 32
+		v2u32 v;
+		v.x = x, v.y = sw[1];
+		const uint32_t off = (lc.n_half == 0 && lc.n_bit < w) ? (pos + incl - w + lc.n_bit) * 8u : RIR_OOB;
+		__builtin_amdgcn_raw_buffer_store_b64(v, out, off, 0, 0);
+		*words = total;
+		// header, assembled by the lanes 16q+k from the same non-zero mask
+		const uint32_t wa = bitlen_nz((nz >> lc.h_sha) & 15u), wb = bitlen_nz((nz >> lc.h_shb) & 15u);
+		const uint32_t nib = (base >> lc.sh4) & 15u;
+		const uint32_t field = ((nib << 10) | modebits) | ((wb << 5) | wa);
+		return __ballot((field & lc.onehot) != 0);
+	}
+
+	// Wide tier (any width up to 16): two 64x64 transposes, lane 16q+k holds plane k of slots q and 4+q.
+	__device__ __forceinline__ uint64_t emit_record_wide(const Px8 &r, uint32_t modebits, uint32_t base, __amdgpu_buffer_rsrc_t out, uint32_t pos,
+														 const LaneConsts &lc, const TransposeConsts &tc, uint32_t *words)
 	{
 		uint32_t alo = r.d[0], ahi = r.d[1], blo = r.d[2], bhi = r.d[3];
-		transpose64x2(alo, ahi, blo, bhi, tc); // lane 16q+k: plane k of slot q (a) / slot 4+q (b)
+		transpose64x2(alo, ahi, blo, bhi, tc);
 		const uint32_t wa = row_allmax((alo | ahi) != 0 ? lc.bitp1 : 0u); // width of slot q
 		const uint32_t wb = row_allmax((blo | bhi) != 0 ? lc.bitp1 : 0u); // width of slot 4+q
 		const uint32_t ia = rows_inclusive_sum(wa), ib = rows_inclusive_sum(wb);
@@ -351,6 +430,18 @@ namespace rir
 		return __ballot((field & lc.onehot) != 0);
 	}
 
+	// Emit the payload of one record: residuals r (packed pairs) -> plane words at out[pos..pos+words).
+	// Returns the header; `modebits` = mode << 14 in row 0, zero elsewhere.  The tier is a property of
+	// the data (wave-uniform branch), the bitstream is the same either way.
+	__device__ __forceinline__ uint64_t emit_record(const Px8 &r, uint32_t modebits, uint32_t base, __amdgpu_buffer_rsrc_t out, uint32_t pos,
+													const LaneConsts &lc, const TransposeConsts &tc, uint32_t *words)
+	{
+		const uint32_t any = (r.d[0] | r.d[1]) | (r.d[2] | r.d[3]);
+		if (__ballot((any & 0xfff0fff0u) != 0) == 0)
+			return emit_record_narrow(r, modebits, base, out, pos, lc, tc, words);
+		return emit_record_wide(r, modebits, base, out, pos, lc, tc, words);
+	}
+
 	// One wave = one tile over the frames of one chunk (see the kernel below).
 	template <bool FAST>
 	__device__ __forceinline__ void encode_tile(const uint16_t *__restrict__ frames, int64_t npx, int nf, int64_t frame0, int tile, int lane,
@@ -365,10 +456,30 @@ namespace rir
 		const uint16_t *tile0 = frames + frame0 * npx + (int64_t)tile * RIRB1_TILE_PX; // tile of the chunk's first frame
 		// FAST: whole tile inside the frame and 16-byte aligned rows -> raw-buffer loads, unconditional;
 		// past the end of the chunk the prefetch re-reads the last frame (an L2 hit, no HBM traffic).
-		auto load = [&](int f) -> Px8 {
+		// Frame loads: unconditional raw-buffer loads (FAST) so that the ring keeps frames in flight.
+		// On top of the compiler's own counted waits, each step adds a wait that only relies on loads
+		// returning in order among themselves: with the loads of frames f+1 and f+2 behind it, frame f
+		// has landed once at most 2 vector-memory operations are outstanding.  (A tighter count that
+		// also relied on the position of the stores raced at full size.)
+		auto load = [&](int f, v4u32 &dst) {
 			if (FAST)
-				return buf_load8(tile0 + (int64_t)min(f, nf - 1) * npx, lane_off);
-			return load8(frames, frame0 + min(f, nf - 1), npx, p0, false);
+			{
+				const Px8 p = buf_load8(tile0 + (int64_t)min(f, nf - 1) * npx, lane_off);
+				dst.x = p.d[0], dst.y = p.d[1], dst.z = p.d[2], dst.w = p.d[3];
+			}
+			else
+			{
+				const Px8 p = load8(frames, frame0 + min(f, nf - 1), npx, p0, false);
+				dst.x = p.d[0], dst.y = p.d[1], dst.z = p.d[2], dst.w = p.d[3];
+			}
+		};
+#define RIR_WAIT_SLOT(SLOT, N)                                   \
+	if (FAST)                                                    \
+		asm volatile("s_waitcnt vmcnt(" #N ")" : : : "memory");
+		auto as_px8 = [](const v4u32 &v) {
+			Px8 p;
+			p.d[0] = v.x, p.d[1] = v.y, p.d[2] = v.z, p.d[3] = v.w;
+			return p;
 		};
 
 		uint32_t pos = 0;
@@ -377,11 +488,16 @@ namespace rir
 		// Ring of 4 frame slots: frame f lives in slot f % 4, three frames are in flight ahead of the
 		// one being packed.  The loop is unrolled by 4 so that slots are fixed registers (a register
 		// copy of a loaded value would force an early wait on the load).
-		Px8 s0 = load(0), s1 = load(1), s2 = load(2), s3 = load(3);
+		v4u32 s0, s1, s2, s3;
+		load(0, s0);
+		load(1, s1);
+		load(2, s2);
+		load(3, s3);
 
 		// ---- key frame: RAW, or LEFT when its payload is strictly smaller ----
 		{
-			const Px8 cur = s0;
+			RIR_WAIT_SLOT(s0, 3) // the three younger loads may stay in flight
+			const Px8 cur = as_px8(s0);
 			const uint32_t base_raw = tile_base(cur, false);
 			const uint32_t b2 = base_raw | (base_raw << 16);
 			Px8 r_raw;
@@ -410,13 +526,18 @@ namespace rir
 
 		// ---- temporal frames ----
 		const uint32_t temporal_bits = lc.row0 ? ((uint32_t)RIRB1_MODE_TEMPORAL << 14) : 0u;
+		// Two younger loads are always behind the load of frame f when step f starts.
 #define RIR_ENC_STEP(F, CUR, PREV)                                                             \
 	if ((F) < nf)                                                                              \
 	{                                                                                          \
 		const int f = (F);                                                                     \
+		RIR_WAIT_SLOT(CUR, 2)                                                                  \
 		Px8 d;                                                                                 \
-		_Pragma("unroll") for (int k = 0; k < 4; ++k) d.d[k] = pk_sub16(CUR.d[k], PREV.d[k]); \
-		PREV = load(f + 3); /* the slot of frame f-1 is free: prefetch frame f+3 into it */    \
+		{                                                                                      \
+			const Px8 c_ = as_px8(CUR), p_ = as_px8(PREV);                                     \
+			_Pragma("unroll") for (int k = 0; k < 4; ++k) d.d[k] = pk_sub16(c_.d[k], p_.d[k]); \
+		}                                                                                      \
+		load(f + 3, PREV); /* the slot of frame f-1 is free: prefetch frame f+3 into it */     \
 		const uint32_t base = tile_base(d, true);                                              \
 		const uint32_t b2 = base | (base << 16);                                               \
 		_Pragma("unroll") for (int k = 0; k < 4; ++k) d.d[k] = pk_sub16(d.d[k], b2);          \
@@ -439,6 +560,7 @@ namespace rir
 			RIR_ENC_STEP(fb + 3, s0, s3)
 		}
 #undef RIR_ENC_STEP
+#undef RIR_WAIT_SLOT
 		{
 			const int fb = (nf - 1) & ~63;
 			if (fb + lane < nf)
@@ -558,33 +680,82 @@ namespace rir
 	struct Fetched
 	{
 		uint64_t hdr;
-		uint64_t a, b;
+		v2u32 a, b; // wide tier: the two plane words of this lane; narrow tier: a = plane word (lanes 0..31)
 		uint32_t words;
 		bool bad;
+		bool narrow; // every width <= 4 (wave-uniform)
 	};
+
+	// true when every 5-bit width field of the header is <= 4 (scalar-unit arithmetic on the uniform header)
+	__device__ __forceinline__ bool header_is_narrow(uint64_t hdr)
+	{
+		const uint64_t m0 = 0x0021002100210021ull; // bit 0 of w_q and of w_{4+q} in each 16-bit field
+		const uint64_t hi = hdr & (m0 * 0x18u);	   // bits 3,4 of any width
+		const uint64_t b2 = (hdr >> 2) & m0;
+		const uint64_t lo = (hdr | (hdr >> 1)) & m0;
+		return (hi | (b2 & lo)) == 0;
+	}
 
 	__device__ __forceinline__ Fetched fetch_record(uint64_t hdr, __amdgpu_buffer_rsrc_t in, uint32_t pos, uint32_t seg_len, const LaneConsts &lc)
 	{
 		Fetched r;
 		r.hdr = hdr;
-		// this row's header field: w_q | w_{4+q} << 5 | base nibble << 10 | mode << 14
-		const uint32_t field = ((lc.row_hi ? (uint32_t)(hdr >> 32) : (uint32_t)hdr) >> lc.sh16) & 0xffffu;
-		const uint32_t wa = field & 31u, wb = (field >> 5) & 31u;
-		const uint32_t ia = rows_inclusive_sum(wa), ib = rows_inclusive_sum(wb);
-		const uint32_t tot_a = (uint32_t)__builtin_amdgcn_readlane((int)ia, 63);
-		const uint32_t tot_b = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
-		r.words = tot_a + tot_b;
-		const bool wide = __ballot(wa > 16u || wb > 16u) != 0;
-		r.bad = wide || (pos + r.words > seg_len) || ((hdr & 0xC000C000C0000000ull) != 0) || (((hdr >> 14) & 3u) == 3u);
-		// unconditional loads; lanes without a plane (and every lane of a malformed record) point out
-		// of range and read 0 - the descriptor's num_records is the segment length, so nothing outside
-		// the segment is ever touched
-		const uint32_t oa = (!r.bad && lc.bit < wa) ? (pos + ia - wa + lc.bit) * 8u : RIR_OOB;
-		const uint32_t ob = (!r.bad && lc.bit < wb) ? (pos + tot_a + ib - wb + lc.bit) * 8u : RIR_OOB;
-		const v2u32 va = __builtin_amdgcn_raw_buffer_load_b64(in, oa, 0, 0);
-		const v2u32 vb = __builtin_amdgcn_raw_buffer_load_b64(in, ob, 0, 0);
-		r.a = (uint64_t)va.x | ((uint64_t)va.y << 32);
-		r.b = (uint64_t)vb.x | ((uint64_t)vb.y << 32);
+		r.narrow = header_is_narrow(hdr);
+		const bool hdr_bad = ((hdr & 0xC000C000C0000000ull) != 0) || (((hdr >> 14) & 3u) == 3u);
+		// Offsets depend on the tier; the two loads below do not (no branch around a memory operation,
+		// no copy of an in-flight load result: the ring keeps its counted waits).  Lanes without a plane
+		// - and every lane of a malformed record - point out of range and read 0; the descriptor's
+		// num_records is the segment length, so nothing outside the segment is ever touched.
+		uint32_t oa, ob;
+		if (r.narrow)
+		{ // lanes 0..31: lane 4*slot + plane reads the whole 64-bit plane word
+			const uint32_t w = ((lc.n_hhi ? (uint32_t)(hdr >> 32) : (uint32_t)hdr) >> lc.n_hsh) & 31u;
+			const uint32_t incl = half_inclusive_sum(lc.n_first ? w : 0u);
+			r.words = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+			r.bad = hdr_bad || (pos + r.words > seg_len);
+			oa = (!r.bad && lc.n_half == 0 && lc.n_bit < w) ? (pos + incl - w + lc.n_bit) * 8u : RIR_OOB;
+			ob = RIR_OOB;
+		}
+		else
+		{ // wide tier: this row's header field is w_q | w_{4+q} << 5 | base nibble << 10 | mode << 14
+			const uint32_t field = ((lc.row_hi ? (uint32_t)(hdr >> 32) : (uint32_t)hdr) >> lc.sh16) & 0xffffu;
+			const uint32_t wa = field & 31u, wb = (field >> 5) & 31u;
+			const uint32_t ia = rows_inclusive_sum(wa), ib = rows_inclusive_sum(wb);
+			const uint32_t tot_a = (uint32_t)__builtin_amdgcn_readlane((int)ia, 63);
+			const uint32_t tot_b = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
+			r.words = tot_a + tot_b;
+			const bool too_wide = __ballot(wa > 16u || wb > 16u) != 0;
+			r.bad = hdr_bad || too_wide || (pos + r.words > seg_len);
+			oa = (!r.bad && lc.bit < wa) ? (pos + ia - wa + lc.bit) * 8u : RIR_OOB;
+			ob = (!r.bad && lc.bit < wb) ? (pos + tot_a + ib - wb + lc.bit) * 8u : RIR_OOB;
+		}
+		// exactly two loads per record, whatever the tier (the consumer's wait counts younger loads)
+		r.a = __builtin_amdgcn_raw_buffer_load_b64(in, oa, 0, 0);
+		r.b = __builtin_amdgcn_raw_buffer_load_b64(in, ob, 0, 0);
+		return r;
+	}
+
+	// residuals of one record back in pixel order (packed pairs), from the fetched plane words
+	__device__ __forceinline__ Px8 planes_to_residuals(v2u32 a, v2u32 b, bool narrow, const TransposeConsts &tc)
+	{
+		Px8 r;
+		if (narrow)
+		{
+			// upper-half lanes take the high dword of their partner's plane word
+			auto sw = __builtin_amdgcn_permlane32_swap(a.x, a.y, false, false);
+			const uint32_t x = transpose32(sw[0], tc); // nibble j = residual of pixel j
+			const uint32_t lo = x & 0x0f0f0f0fu, hi = (x >> 4) & 0x0f0f0f0fu; // bytes r0,r2,r4,r6 / r1,r3,r5,r7
+			r.d[0] = __builtin_amdgcn_perm(hi, lo, 0x0c040c00u);
+			r.d[1] = __builtin_amdgcn_perm(hi, lo, 0x0c050c01u);
+			r.d[2] = __builtin_amdgcn_perm(hi, lo, 0x0c060c02u);
+			r.d[3] = __builtin_amdgcn_perm(hi, lo, 0x0c070c03u);
+		}
+		else
+		{
+			uint32_t alo = a.x, ahi = a.y, blo = b.x, bhi = b.y;
+			transpose64x2(alo, ahi, blo, bhi, tc);
+			r.d[0] = alo, r.d[1] = ahi, r.d[2] = blo, r.d[3] = bhi;
+		}
 		return r;
 	}
 
@@ -654,20 +825,21 @@ namespace rir
 		const int fr = (FR);                                                                                         \
 		const uint64_t hdr = R.hdr;                                                                                  \
 		err |= R.bad;                                                                                                \
-		uint32_t alo = (uint32_t)R.a, ahi = (uint32_t)(R.a >> 32), blo = (uint32_t)R.b, bhi = (uint32_t)(R.b >> 32); \
+		/* Belt and braces on top of the compiler's own counted wait: loads return in order among themselves, the    \
+		   six loads of the three younger records are the only operations allowed to be outstanding here. */         \
+		asm volatile("s_waitcnt vmcnt(6)" : : : "memory");                                                           \
+		const v2u32 wa_ = R.a, wb_ = R.b;                                                                             \
+		const bool narrow_ = R.narrow;                                                                               \
 		/* refill the slot with the record four frames ahead */                                                       \
 		R = fetch_record(fr + 4 < nr ? readlane64(my_h, fr + 4) : 0ull, in, pos, seg_len, lc);                        \
 		pos += R.words;                                                                                              \
-		transpose64x2(alo, ahi, blo, bhi, tc);                                                                       \
+		const Px8 res = planes_to_residuals(wa_, wb_, narrow_, tc);                                                  \
 		const uint32_t mode = (uint32_t)(hdr >> 14) & 3u;                                                            \
 		const uint32_t base = ((uint32_t)(hdr >> 10) & 0xfu) | ((uint32_t)(hdr >> 22) & 0xf0u) |                     \
 							  ((uint32_t)(hdr >> 34) & 0xf00u) | ((uint32_t)(hdr >> 46) & 0xf000u);                  \
 		const uint32_t b2 = base | (base << 16);                                                                     \
 		Px8 o;                                                                                                       \
-		o.d[0] = pk_add16(alo, b2);                                                                                  \
-		o.d[1] = pk_add16(ahi, b2);                                                                                  \
-		o.d[2] = pk_add16(blo, b2);                                                                                  \
-		o.d[3] = pk_add16(bhi, b2);                                                                                  \
+		_Pragma("unroll") for (int k = 0; k < 4; ++k) o.d[k] = pk_add16(res.d[k], b2);                              \
 		if (f0 + fr == 0)                                                                                            \
 		{ /* key frame: RAW or LEFT */                                                                               \
 			if (mode == RIRB1_MODE_LEFT)                                                                             \
