@@ -67,78 +67,120 @@ namespace rir
 	__device__ __forceinline__ uint64_t f2sz(float v) { return (uint64_t)(int64_t)v; }
 	__device__ __forceinline__ uint64_t wrap_sz(uint64_t value, uint64_t max) { return (value + max) % max; }
 
-	// One thread per output pixel; x is the fast index so stores are coalesced, the four taps are
-	// neighbouring reads served by L1/L2.  offsets: per-frame (dx,dy) pairs, or a single pair.
-	template <class T, class U>
-	__global__ __launch_bounds__(256) void translate_kernel(const T *__restrict__ src, U *__restrict__ dst, U background, int w_, int h_,
-															int nframes, const float *__restrict__ offsets, int per_frame_offsets,
-															float sign, int strategy, int rows)
+	// One output pixel (x, y) of translate<T,U>; returns false when the pixel is left untouched
+	// (strategy "noborder" outside the source).  Arithmetic exactly as the reference: float
+	// coordinates, double blend, truncating cast.
+	// SMALL: |dx|, |dy| < 2^30, so every coordinate fits an int32 and the float -> size_t conversions
+	// (a long software sequence for 64 bits) are done in 32 bits, sign-extended: same values.
+	template <bool SMALL>
+	__device__ __forceinline__ uint64_t f2szT(float v)
 	{
-		const int x_ = blockIdx.x * blockDim.x + threadIdx.x;
-		const int y = blockIdx.y;
-		const int n = blockIdx.z;
-		if (x_ >= w_ || y >= rows)
-			return;
-		const uint64_t w = (uint64_t)w_, h = (uint64_t)rows, x = (uint64_t)x_;
-		const int64_t fbase = (int64_t)n * w_ * h_;
-		const T *s = src + fbase;
-		U *d = dst + fbase;
-		const float dx = sign * offsets[per_frame_offsets ? 2 * n : 0];
-		const float dy = sign * offsets[per_frame_offsets ? 2 * n + 1 : 1];
+		return SMALL ? (uint64_t)(int64_t)(int32_t)v : (uint64_t)(int64_t)v;
+	}
 
+	template <class T, class U, bool SMALL = false>
+	__device__ __forceinline__ bool translate_px(const T *__restrict__ s, uint64_t w, uint64_t h, uint64_t x, int y, float dx, float dy, int strategy,
+												 U background, U &out)
+	{
 		const float px = (float)x - dx;
 		const float py = (float)y - dy;
-		const uint64_t o = x + (uint64_t)y * w;
 		if (px < 0 || px >= (float)w || py < 0 || py >= (float)h)
 		{
 			if (strategy == TRANSLATE_UNCHANGED)
+				return false;
+			if (strategy == TRANSLATE_CONSTANT)
 			{
+				out = background;
+				return true;
 			}
-			else if (strategy == TRANSLATE_CONSTANT)
-				d[o] = background;
-			else if (strategy == TRANSLATE_WRAP)
+			if (strategy == TRANSLATE_WRAP)
 			{
-				const uint64_t l = wrap_sz(f2sz(px), w), r = wrap_sz(f2sz(px + 1), w);
-				const uint64_t t = wrap_sz(f2sz(py), h), b = wrap_sz(f2sz(py + 1), h);
+				const uint64_t l = wrap_sz(f2szT<SMALL>(px), w), r = wrap_sz(f2szT<SMALL>(px + 1), w);
+				const uint64_t t = wrap_sz(f2szT<SMALL>(py), h), b = wrap_sz(f2szT<SMALL>(py + 1), h);
 				const T p1 = s[b * w + l], p2 = s[t * w + l], p3 = s[b * w + r], p4 = s[t * w + r];
 				const double u = fabsf(px - (float)(int)px);
 				const double v = fabsf(py - (float)(int)py);
-				const double val = ((double)p1 * (1 - v) + (double)p2 * v) * (1 - u) + ((double)p3 * (1 - v) + (double)p4 * v) * u;
-				d[o] = CastTo<U>::from(val);
+				out = CastTo<U>::from(((double)p1 * (1 - v) + (double)p2 * v) * (1 - u) + ((double)p3 * (1 - v) + (double)p4 * v) * u);
+				return true;
 			}
+			uint64_t _x, _y;
+			if (px < 0)
+				_x = 0;
+			else if (px >= (float)w)
+				_x = w - 1;
 			else
-			{
-				uint64_t _x, _y;
-				if (px < 0)
-					_x = 0;
-				else if (px >= (float)w)
-					_x = w - 1;
-				else
-					_x = f2sz(px);
-				if (py < 0)
-					_y = 0;
-				else if (py >= (float)h)
-					_y = h - 1;
-				else
-					_y = f2sz(py);
-				d[o] = (U)s[_x + _y * w];
-			}
+				_x = f2szT<SMALL>(px);
+			if (py < 0)
+				_y = 0;
+			else if (py >= (float)h)
+				_y = h - 1;
+			else
+				_y = f2szT<SMALL>(py);
+			out = (U)s[_x + _y * w];
+			return true;
 		}
+		const uint64_t l = f2szT<SMALL>(px);
+		uint64_t r = f2szT<SMALL>(px + 1);
+		if (r == w)
+			r = l;
+		const uint64_t t = f2szT<SMALL>(py);
+		uint64_t b = f2szT<SMALL>(py + 1);
+		if (b == h)
+			b = t;
+		const T p1 = s[b * w + l], p2 = s[t * w + l], p3 = s[b * w + r], p4 = s[t * w + r];
+		const double u = (px - (float)l);
+		const double v = ((float)b - py);
+		out = CastTo<U>::from(((double)p1 * (1 - v) + (double)p2 * v) * (1 - u) + ((double)p3 * (1 - v) + (double)p4 * v) * u);
+		return true;
+	}
+
+	template <class U, int VEC>
+	struct alignas(sizeof(U) * VEC) PixVec
+	{
+		U v[VEC];
+	};
+
+	// Each thread produces VEC consecutive pixels of a row and writes them with one vector store
+	// (8 or 16 bytes per lane) when the run is aligned and fully written; the four taps per pixel are
+	// neighbouring reads served by L1/L2.  offsets: per-frame (dx,dy) pairs, or a single pair.
+	template <class T, class U, int VEC>
+	__global__ __launch_bounds__(256) void translate_kernel(const T *__restrict__ src, U *__restrict__ dst, U background, int w_, int h_,
+															const float *__restrict__ offsets, int per_frame_offsets, int strategy, int rows)
+	{
+		const int cpr = (w_ + VEC - 1) / VEC; // chunks per row
+		const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+		if (idx >= (int64_t)cpr * rows)
+			return;
+		const int y = (int)(idx / cpr);
+		const int x0 = (int)(idx - (int64_t)y * cpr) * VEC;
+		const int n = blockIdx.y;
+		const uint64_t w = (uint64_t)w_, h = (uint64_t)rows;
+		const int64_t fbase = (int64_t)n * w_ * h_;
+		const T *s = src + fbase;
+		U *d = dst + fbase + (int64_t)y * w_ + x0;
+		const float dx = offsets[per_frame_offsets ? 2 * n : 0];
+		const float dy = offsets[per_frame_offsets ? 2 * n + 1 : 1];
+		const bool small = fabsf(dx) < 1.0e9f && fabsf(dy) < 1.0e9f; // wave-uniform
+		PixVec<U, VEC> o;
+		bool wr[VEC];
+		bool all = true;
+#pragma unroll
+		for (int k = 0; k < VEC; ++k)
+		{
+			if (small)
+				wr[k] = (x0 + k < w_) && translate_px<T, U, true>(s, w, h, (uint64_t)(x0 + k), y, dx, dy, strategy, background, o.v[k]);
+			else
+				wr[k] = (x0 + k < w_) && translate_px<T, U, false>(s, w, h, (uint64_t)(x0 + k), y, dx, dy, strategy, background, o.v[k]);
+			all = all && wr[k];
+		}
+		if (all && (((uintptr_t)d) & (sizeof(U) * VEC - 1)) == 0)
+			*reinterpret_cast<PixVec<U, VEC> *>(d) = o;
 		else
 		{
-			const uint64_t l = f2sz(px);
-			uint64_t r = f2sz(px + 1);
-			if (r == w)
-				r = l;
-			const uint64_t t = f2sz(py);
-			uint64_t b = f2sz(py + 1);
-			if (b == h)
-				b = t;
-			const T p1 = s[b * w + l], p2 = s[t * w + l], p3 = s[b * w + r], p4 = s[t * w + r];
-			const double u = (px - (float)l);
-			const double v = ((float)b - py);
-			const double val = ((double)p1 * (1 - v) + (double)p2 * v) * (1 - u) + ((double)p3 * (1 - v) + (double)p4 * v) * u;
-			d[o] = CastTo<U>::from(val);
+#pragma unroll
+			for (int k = 0; k < VEC; ++k)
+				if (wr[k])
+					d[k] = o.v[k];
 		}
 	}
 
@@ -146,10 +188,13 @@ namespace rir
 	static hipError_t launch_translate_t(const void *src, void *dst, const void *background, int w, int h, int nframes, const float *d_offsets,
 										 int per_frame, float sign, int strategy, int rows, hipStream_t st)
 	{
+		(void)sign;
+		constexpr int VEC = sizeof(U) >= 8 ? 2 : 4;
 		U back = *reinterpret_cast<const U *>(background);
-		dim3 block(256), grid((w + 255) / 256, rows, nframes);
-		hipLaunchKernelGGL((translate_kernel<T, U>), grid, block, 0, st, (const T *)src, (U *)dst, back, w, h, nframes, d_offsets, per_frame, sign,
-						   strategy, rows);
+		const int64_t chunks = (int64_t)((w + VEC - 1) / VEC) * rows;
+		dim3 block(256), grid((unsigned)((chunks + 255) / 256), nframes);
+		hipLaunchKernelGGL((translate_kernel<T, U, VEC>), grid, block, 0, st, (const T *)src, (U *)dst, back, w, h, d_offsets, per_frame, strategy,
+						   rows);
 		return hipGetLastError();
 	}
 
@@ -191,63 +236,49 @@ namespace rir
 	__global__ __launch_bounds__(256) void remove_motion_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w_, int h_,
 																int rows, const float *__restrict__ shifts)
 	{
-		const int x_ = blockIdx.x * blockDim.x + threadIdx.x;
-		const int y = blockIdx.y;
-		const int n = blockIdx.z;
-		if (x_ >= w_)
+		constexpr int VEC = 4;
+		const int cpr = (w_ + VEC - 1) / VEC;
+		const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+		if (idx >= (int64_t)cpr * h_)
 			return;
+		const int y = (int)(idx / cpr);
+		const int x0 = (int)(idx - (int64_t)y * cpr) * VEC;
+		const int n = blockIdx.y;
 		const int64_t fbase = (int64_t)n * w_ * h_;
 		const uint16_t *s = src + fbase;
-		uint16_t *d = dst + fbase;
-		const uint64_t w = (uint64_t)w_, h = (uint64_t)rows, x = (uint64_t)x_;
-		const uint64_t o = x + (uint64_t)y * w;
-		if (y >= rows)
-		{
-			d[o] = s[o];
-			return;
-		}
+		uint16_t *d = dst + fbase + (int64_t)y * w_ + x0;
 		const float dx = -shifts[2 * n], dy = -shifts[2 * n + 1];
-		const float px = (float)x - dx;
-		const float py = (float)y - dy;
-		float val;
-		if (px < 0 || px >= (float)w || py < 0 || py >= (float)h)
+		PixVec<uint16_t, VEC> o;
+#pragma unroll
+		for (int k = 0; k < VEC; ++k)
 		{
-			uint64_t _x, _y;
-			if (px < 0)
-				_x = 0;
-			else if (px >= (float)w)
-				_x = w - 1;
-			else
-				_x = f2sz(px);
-			if (py < 0)
-				_y = 0;
-			else if (py >= (float)h)
-				_y = h - 1;
-			else
-				_y = f2sz(py);
-			val = (float)s[_x + _y * w];
+			o.v[k] = 0;
+			if (x0 + k < w_)
+			{
+				if (y >= rows)
+					o.v[k] = s[(int64_t)y * w_ + x0 + k]; // the last rows (camera metadata) are copied
+				else
+				{
+					float val = 0;
+					if (fabsf(dx) < 1.0e9f && fabsf(dy) < 1.0e9f)
+						translate_px<uint16_t, float, true>(s, (uint64_t)w_, (uint64_t)rows, (uint64_t)(x0 + k), y, dx, dy, TRANSLATE_NEAREST, 0.f, val);
+					else
+						translate_px<uint16_t, float, false>(s, (uint64_t)w_, (uint64_t)rows, (uint64_t)(x0 + k), y, dx, dy, TRANSLATE_NEAREST, 0.f, val);
+					o.v[k] = (uint16_t)(int32_t)val;
+				}
+			}
 		}
+		if (x0 + VEC <= w_ && (((uintptr_t)d) & 7) == 0)
+			*reinterpret_cast<PixVec<uint16_t, VEC> *>(d) = o;
 		else
-		{
-			const uint64_t l = f2sz(px);
-			uint64_t r = f2sz(px + 1);
-			if (r == w)
-				r = l;
-			const uint64_t t = f2sz(py);
-			uint64_t b = f2sz(py + 1);
-			if (b == h)
-				b = t;
-			const uint16_t p1 = s[b * w + l], p2 = s[t * w + l], p3 = s[b * w + r], p4 = s[t * w + r];
-			const double u = (px - (float)l);
-			const double v = ((float)b - py);
-			val = (float)(((double)p1 * (1 - v) + (double)p2 * v) * (1 - u) + ((double)p3 * (1 - v) + (double)p4 * v) * u);
-		}
-		d[o] = (uint16_t)(int32_t)val;
+			for (int k = 0; k < VEC && x0 + k < w_; ++k)
+				d[k] = o.v[k];
 	}
 
 	hipError_t launch_remove_motion(const uint16_t *src, uint16_t *dst, int w, int h, int rows, int nframes, const float *d_shifts, hipStream_t st)
 	{
-		dim3 block(256), grid((w + 255) / 256, h, nframes);
+		const int64_t chunks = (int64_t)((w + 3) / 4) * h;
+		dim3 block(256), grid((unsigned)((chunks + 255) / 256), nframes);
 		hipLaunchKernelGGL(remove_motion_kernel, grid, block, 0, st, src, dst, w, h, rows, d_shifts);
 		return hipGetLastError();
 	}
@@ -295,10 +326,96 @@ namespace rir
 		}
 	}
 
+	// LDS-tiled version for radius 1..4: a 256-thread workgroup produces a 64 x 16 output tile from a
+	// (64+2R) x (16+2R) input tile staged once in LDS (coalesced row loads, zero outside the image).
+	// Each output keeps the reference's accumulation order (dx outer, dy inner; separate multiply and
+	// add), so results are bit-identical to the direct kernel above; the weights sit in LDS too
+	// (same address for the whole wave = broadcast read).  Lanes of a wave read consecutive floats of
+	// one tile row: no bank conflicts.
+	template <int R>
+	__global__ __launch_bounds__(256) void gaussian_tile_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+																const float *__restrict__ kern)
+	{
+		constexpr int TX = 64, TY = 16, KW = 2 * R + 1, LW = TX + 2 * R, LH = TY + 2 * R;
+		__shared__ float tile[LH][LW];
+		__shared__ float kk[KW * KW];
+		const int tid = threadIdx.x;
+		const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+		const int64_t fbase = (int64_t)blockIdx.z * w * h;
+		const float *s = src + fbase;
+		for (int i = tid; i < LW * LH; i += 256)
+		{
+			const int ly = i / LW, lx = i - ly * LW;
+			const int gx = x0 - R + lx, gy = y0 - R + ly;
+			tile[ly][lx] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? s[gx + (int64_t)gy * w] : 0.f;
+		}
+		if (tid < KW * KW)
+			kk[tid] = kern[tid];
+		__syncthreads();
+		const int tx = tid & 63, ty = tid >> 6;
+		const int x = x0 + tx;
+		if (x >= w)
+			return;
+#pragma unroll
+		for (int j = 0; j < 4; ++j)
+		{
+			const int ly = ty + 4 * j, y = y0 + ly;
+			if (y >= h)
+				break;
+			float res = 0;
+			if (x >= R && x < w - R && y >= R && y < h - R)
+			{
+#pragma unroll
+				for (int dx = -R; dx <= R; ++dx)
+#pragma unroll
+					for (int dy = -R; dy <= R; ++dy)
+						res = __fadd_rn(res, __fmul_rn(kk[dx + R + (dy + R) * KW], tile[ly + R + dy][tx + R + dx]));
+			}
+			else
+			{
+				float sum = 0;
+#pragma unroll
+				for (int dx = -R; dx <= R; ++dx)
+#pragma unroll
+					for (int dy = -R; dy <= R; ++dy)
+					{
+						const int _x = x + dx, _y = y + dy;
+						if (_x >= 0 && _x < w && _y >= 0 && _y < h)
+						{
+							const float k = kk[dx + R + (dy + R) * KW];
+							sum = __fadd_rn(sum, k);
+							res = __fadd_rn(res, __fmul_rn(k, tile[ly + R + dy][tx + R + dx]));
+						}
+					}
+				res = __fdiv_rn(res, sum);
+			}
+			dst[fbase + x + (int64_t)y * w] = res;
+		}
+	}
+
 	hipError_t launch_gaussian(const float *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st)
 	{
-		dim3 block(256), grid((w + 255) / 256, h, nframes);
-		hipLaunchKernelGGL(gaussian_kernel, grid, block, 0, st, src, dst, w, h, d_kernel, radius);
+		dim3 block(256), tgrid((w + 63) / 64, (h + 15) / 16, nframes);
+		switch (radius)
+		{
+		case 1:
+			hipLaunchKernelGGL(gaussian_tile_kernel<1>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			break;
+		case 2:
+			hipLaunchKernelGGL(gaussian_tile_kernel<2>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			break;
+		case 3:
+			hipLaunchKernelGGL(gaussian_tile_kernel<3>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			break;
+		case 4:
+			hipLaunchKernelGGL(gaussian_tile_kernel<4>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			break;
+		default:
+		{
+			dim3 grid((w + 255) / 256, h, nframes);
+			hipLaunchKernelGGL(gaussian_kernel, grid, block, 0, st, src, dst, w, h, d_kernel, radius);
+		}
+		}
 		return hipGetLastError();
 	}
 
@@ -464,17 +581,38 @@ namespace rir
 	}
 
 	// ---- histogram / quantile --------------------------------------------------------------------
-	// hist: uint32[nframes][65536].  Integer atomics execute in L2; 8 pixels per lane per load.
-	__global__ __launch_bounds__(256) void histogram_kernel(const uint16_t *__restrict__ img, const uint8_t *__restrict__ mask, int64_t npx,
-															uint32_t *__restrict__ hist)
+	// hist: uint32[nframes][65536].  Each 1024-thread workgroup counts a run of 32 768 pixels in a
+	// privatised LDS histogram of 65 536 16-bit counters (128 KiB, two counters per dword: a run
+	// cannot overflow 16 bits), then adds its non-empty bins to the frame's histogram in L2.
+#define RIR_HIST_RUN 32768
+	__global__ __launch_bounds__(1024) void histogram_kernel(const uint16_t *__restrict__ img, const uint8_t *__restrict__ mask, int64_t npx,
+															 uint32_t *__restrict__ hist)
 	{
-		const int n = blockIdx.y;
+		__shared__ uint32_t lh[32768];
+		const int n = blockIdx.y, tid = threadIdx.x;
 		const uint16_t *f = img + (int64_t)n * npx;
 		const uint8_t *m = mask ? mask + (int64_t)n * npx : nullptr;
 		uint32_t *hh = hist + (int64_t)n * 65536;
-		for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (int64_t)gridDim.x * blockDim.x)
+		for (int i = tid; i < 32768; i += 1024)
+			lh[i] = 0;
+		__syncthreads();
+		const int64_t i0 = (int64_t)blockIdx.x * RIR_HIST_RUN;
+		const int64_t i1 = i0 + RIR_HIST_RUN < npx ? i0 + RIR_HIST_RUN : npx;
+		for (int64_t i = i0 + tid; i < i1; i += 1024)
 			if (!m || m[i])
-				atomicAdd(&hh[f[i]], 1u);
+			{
+				const uint32_t v = f[i];
+				atomicAdd(&lh[v >> 1], 1u << (16 * (v & 1)));
+			}
+		__syncthreads();
+		for (int i = tid; i < 32768; i += 1024)
+		{
+			const uint32_t c = lh[i];
+			if (c & 0xffffu)
+				atomicAdd(&hh[2 * i], c & 0xffffu);
+			if (c >> 16)
+				atomicAdd(&hh[2 * i + 1], c >> 16);
+		}
 	}
 
 	// one block per frame: first bin (of `nbins`) whose cumulative count >= s, 0 when none, with
@@ -536,8 +674,8 @@ namespace rir
 		hipError_t e = hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * 65536 * (size_t)nframes, st);
 		if (e != hipSuccess)
 			return e;
-		int blocks = (int)(((npx + 255) / 256) < 1024 ? ((npx + 255) / 256) : 1024);
-		hipLaunchKernelGGL(histogram_kernel, dim3(blocks, nframes), dim3(256), 0, st, img, mask, npx, d_hist);
+		const int blocks = (int)((npx + RIR_HIST_RUN - 1) / RIR_HIST_RUN);
+		hipLaunchKernelGGL(histogram_kernel, dim3(blocks, nframes), dim3(1024), 0, st, img, mask, npx, d_hist);
 		return hipGetLastError();
 	}
 

@@ -199,7 +199,8 @@ def translate(frames, offsets, strategy="", background=0):
     per_frame = 1 if off.dim() == 2 else 0
     if per_frame and off.shape[0] != n:
         raise RuntimeError("translate: one (dx,dy) pair per frame expected")
-    dst = fr.clone()
+    # "noborder" leaves the pixels without a source as they are: the wrapper pre-fills with the input
+    dst = fr.clone() if strategy in ("", "noborder") else torch.empty_like(fr)
     back = np.zeros(1, dtype=_NP_OF[fr.dtype])
     back[0] = background
     if strategy == "constant":
