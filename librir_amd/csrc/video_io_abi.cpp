@@ -18,6 +18,7 @@
 
 #include "codec_format.h"
 #include "file_attributes.h"
+#include "lossy_kernels.h"
 #include "rir_amd_device.h"
 #include "runtime.h"
 
@@ -25,6 +26,8 @@ using namespace rir;
 
 extern "C"
 {
+	int rir_bad_pixels_create_device(const unsigned short *, int, int, void *);
+	int rir_bad_pixels_correct_device(int, const unsigned short *, unsigned short *, int, void *);
 	int rir_bad_pixels_create_rows_device(const unsigned short *, int, int, int, void *);
 	int rir_remove_bad_pixels_device(int, unsigned short *, int, int, void *);
 	int rir_remove_motion_device(const unsigned short *, unsigned short *, int, int, int, int, const float *, void *);
@@ -110,6 +113,165 @@ namespace
 		}
 	};
 
+	// ---- bounded-loss step ---------------------------------------------------------------------
+	// Host side of H264_Saver::addImageLossyNoCamera / addLoss (h264.cpp:2253-2424, :2426-2607): the
+	// per-pixel work runs in lossy_kernels.hip; the error budget (40-frame window of the quirky
+	// "stdDev" statistics, h264.cpp:2335-2385) is scalar double arithmetic done here from the exact
+	// integer sums the GPU returns.
+	struct LossyState
+	{
+		int w = 0, h = 0, hl = 0;
+		int frames = 0;
+		DeviceBuffer d_img, d_tmp, d_out, d_ref, d_prev, d_last, d_sums, d_cval, d_ccnt, d_ring, d_hist, d_stats, d_min;
+		LossyDeviceState dev{};
+		double first_std[2] = {0, 0};
+		int n_first = 0;
+		double win[40][2];
+		int n_win = 0;
+		int bp_handle = 0;
+
+		~LossyState()
+		{
+			if (bp_handle > 0)
+				bad_pixels_destroy(bp_handle);
+		}
+
+		bool prepare(int w_, int h_, int hl_, int running_average, bool subtract_min)
+		{
+			w = w_, h = h_, hl = std::max(0, std::min(hl_, h_));
+			const size_t full = (size_t)w * h, s = (size_t)w * hl;
+			const int ra = std::max(0, std::min(running_average, 64));
+			if (!d_img.reserve(full * 2) || !d_tmp.reserve(full * 2) || !d_out.reserve(full * 2) || !d_ref.reserve(full * 2) ||
+				!d_prev.reserve(full * 2) || !d_last.reserve(full * 2) || !d_sums.reserve(s * 4 + 4) || !d_cval.reserve(s * 2 + 4) ||
+				!d_ccnt.reserve(s * 2 + 4) || !d_ring.reserve((size_t)std::max(ra, 1) * s * 2 + 4) || !d_hist.reserve(16384 * 4) ||
+				!d_stats.reserve(8 * sizeof(long long)) || !d_min.reserve(4))
+				return false;
+			hipStream_t st = default_stream();
+			if (!hip_ok(hipMemsetAsync(d_sums.ptr, 0, s * 4 + 4, st), "memset") || !hip_ok(hipMemsetAsync(d_cval.ptr, 0, s * 2 + 4, st), "memset") ||
+				!hip_ok(hipMemsetAsync(d_ccnt.ptr, 0, s * 2 + 4, st), "memset"))
+				return false;
+			dev.refT = d_ref.as<uint16_t>(), dev.prevT = d_prev.as<uint16_t>(), dev.lastDL = d_last.as<uint16_t>();
+			dev.ra_sums = d_sums.as<uint32_t>(), dev.ra_const_value = d_cval.as<uint16_t>(), dev.ra_const_count = d_ccnt.as<int16_t>();
+			dev.ra_images = d_ring.as<uint16_t>();
+			dev.ra_count = 0, dev.ra_head = 0, dev.running_average = ra;
+			dev.subtract_min = subtract_min ? 1 : 0;
+			dev.min = 0;
+			frames = 0, n_first = 0, n_win = 0;
+			return true;
+		}
+
+		// img (host, full frame) -> out (host, full frame).  Returns false on a device error.
+		bool step(const unsigned short *img, unsigned short *out, bool add_loss, bool remove_bad_pixels, int low_value_error, int high_value_error,
+				  double std_factor, int &low_error, int &high_error)
+		{
+			hipStream_t st = default_stream();
+			const int full = w * h, s = w * hl;
+			if (!hip_ok(hipMemcpyAsync(d_img.ptr, img, (size_t)full * 2, hipMemcpyHostToDevice, st), "H2D"))
+				return false;
+			const uint16_t *d_src = d_img.as<uint16_t>();
+			uint16_t *tmp = d_tmp.as<uint16_t>();
+			if (remove_bad_pixels && hl > 0)
+			{ // bp.init on the first image (rows < lossy_height), bp.correct on every image (h264.cpp:2259-2266)
+				if (frames == 0 && bp_handle <= 0)
+					bp_handle = rir_bad_pixels_create_device(d_src, w, hl, st);
+				if (bp_handle <= 0 || rir_bad_pixels_correct_device(bp_handle, d_src, tmp, 1, st) != 0)
+					return false;
+				if (full > s && !hip_ok(hipMemcpyAsync(tmp + s, d_src + s, (size_t)(full - s) * 2, hipMemcpyDeviceToDevice, st), "D2D"))
+					return false;
+			}
+			else if (!hip_ok(hipMemcpyAsync(tmp, d_src, (size_t)full * 2, hipMemcpyDeviceToDevice, st), "D2D"))
+				return false;
+
+			low_error = low_value_error, high_error = high_value_error;
+			if (frames == 0)
+			{
+				if (dev.subtract_min && s > 0)
+				{
+					unsigned int mn = 65535;
+					if (!hip_ok(launch_lossy_min(tmp, s, d_min.as<unsigned int>(), st), "lossy min") ||
+						!hip_ok(hipMemcpyAsync(&mn, d_min.ptr, 4, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(hipStreamSynchronize(st), "sync"))
+						return false;
+					dev.min = mn;
+				}
+				if (!hip_ok(launch_lossy_first(tmp, d_out.as<uint16_t>(), dev, s, full, st), "lossy first"))
+					return false;
+			}
+			else
+			{
+				long long stats[8];
+				if (!hip_ok(launch_lossy_stats(dev.prevT, tmp, d_src, s, dev.min, dev.subtract_min, d_hist.as<uint32_t>(), d_stats.as<long long>(), st),
+							"lossy stats") ||
+					!hip_ok(hipMemcpyAsync(stats, d_stats.ptr, sizeof(stats), hipMemcpyDeviceToHost, st), "D2H") ||
+					!hip_ok(hipStreamSynchronize(st), "sync"))
+					return false;
+				const unsigned background = (unsigned)stats[0];
+				// stdDev (h264.cpp:1993-2036): sqrt((sum d)^2 - sum d^2) / n, unsplit for the first 40 frames
+				double sd[2];
+				if (n_win < 40)
+				{
+					const double sum_diff = (double)(stats[1] + stats[4]), sum_diff2 = (double)(stats[2] + stats[5]);
+					sd[0] = sd[1] = std::sqrt(sum_diff * sum_diff - sum_diff2) / s;
+				}
+				else
+				{
+					const double fd = (double)stats[1], fd2 = (double)stats[2], bd = (double)stats[4], bd2 = (double)stats[5];
+					sd[0] = std::sqrt(bd * bd - bd2) / (int)stats[6];
+					sd[1] = std::sqrt(fd * fd - fd2) / (int)stats[3];
+				}
+				if (n_first < 1)
+				{
+					first_std[0] = sd[0], first_std[1] = sd[1];
+					n_first = 1;
+				}
+				if (n_win < 40)
+				{
+					win[n_win][0] = sd[0], win[n_win][1] = sd[1];
+					++n_win;
+				}
+				else
+				{
+					std::memmove(win, win + 1, sizeof(double) * 2 * 39);
+					win[39][0] = sd[0], win[39][1] = sd[1];
+				}
+				double mean[2] = {first_std[0], first_std[1]};
+				for (int i = 0; i < n_win; ++i)
+				{
+					mean[0] += win[i][0];
+					mean[1] += win[i][1];
+				}
+				mean[0] /= (double)(n_win + n_first);
+				mean[1] /= (double)(n_win + n_first);
+				if (add_loss)
+				{ // one-sided (h264.cpp:2544-2548)
+					const double dh = sd[1] < mean[1] ? 0 : sd[1] - mean[1], dl = sd[0] < mean[0] ? 0 : sd[0] - mean[0];
+					high_error -= (int)std::round(dh * std_factor);
+					low_error -= (int)std::round(dl * std_factor);
+				}
+				else
+				{ // two-sided (h264.cpp:2366-2367)
+					high_error -= (int)std::round(std::abs(sd[1] - mean[1]) * std_factor);
+					low_error -= (int)std::round(std::abs(sd[0] - mean[0]) * std_factor);
+				}
+				if (high_error < 0)
+					high_error = 0;
+				if (low_error < high_error)
+					low_error = high_error;
+				if (!hip_ok(launch_lossy_update(tmp, d_out.as<uint16_t>(), dev, s, full, background, low_error, high_error, add_loss ? 1 : 0, st),
+							"lossy update"))
+					return false;
+				if (dev.running_average > 0)
+				{
+					if (dev.ra_count == dev.running_average)
+						dev.ra_head = (dev.ra_head + 1) % dev.running_average;
+					else
+						++dev.ra_count;
+				}
+			}
+			++frames;
+			return hip_ok(hipMemcpyAsync(out, d_out.ptr, (size_t)full * 2, hipMemcpyDeviceToHost, st), "D2H") && hip_ok(hipStreamSynchronize(st), "sync");
+		}
+	};
+
 	// ---- saver -------------------------------------------------------------------------------
 	// reference: struct H264 (video_io.cpp:651-657) + H264_Saver (h264.cpp:1662-1939)
 	struct SaverObject : public Object
@@ -135,8 +297,68 @@ namespace
 		std::vector<int64_t> times;
 		std::vector<AttrMap> frame_attrs;
 		std::vector<unsigned short> low_errors, high_errors;
+		std::unique_ptr<LossyState> lossy;
+		std::vector<unsigned short> lossy_out;
 
 		~SaverObject() override { close(); }
+
+		// the loss-injection state is created on the first lossy call (after the lazy open)
+		bool lossy_ready()
+		{
+			if (lossy)
+				return true;
+			lossy.reset(new LossyState());
+			lossy_out.resize((size_t)width * height);
+			if (!lossy->prepare(width, height, lossy_height, runningAverage, subtractMin))
+			{
+				lossy.reset();
+				return false;
+			}
+			return true;
+		}
+
+		// H264_Saver::addImageLossyNoCamera (h264.cpp:2253-2424)
+		bool add_image_lossy(const unsigned short *img, int64_t ts, AttrMap attrs)
+		{
+			if (!img || !open() || !lossy_ready())
+				return false;
+			int lo = 0, hi = 0;
+			const bool first = lossy->frames == 0;
+			if (!lossy->step(img, lossy_out.data(), false, removeBadPixels, lowValueError, highValueError, stdFactor, lo, hi))
+				return false;
+			if (first)
+			{
+				if (subtractMin)
+				{
+					global_attrs["MIN_T"] = std::to_string(lossy->dev.min);
+					global_attrs["MIN_T_HEIGHT"] = std::to_string(lossy_height);
+				}
+				global_attrs["GlobalBackgroundError"] = std::to_string(lowValueError);
+				global_attrs["GlobalForegroundError"] = std::to_string(highValueError);
+			}
+			else
+			{
+				attrs["BackgroundError"] = std::to_string(lo);
+				attrs["ForegroundError"] = std::to_string(hi);
+			}
+			low_errors.push_back((unsigned short)lo);
+			high_errors.push_back((unsigned short)hi);
+			return add_image(lossy_out.data(), ts, attrs);
+		}
+
+		// H264_Saver::addLoss (h264.cpp:2426-2607): the loss is applied to the caller's image, nothing is written
+		bool add_loss(unsigned short *img)
+		{
+			if (!img || !open() || !lossy_ready())
+				return false;
+			int lo = 0, hi = 0;
+			if (!lossy->step(img, lossy_out.data(), true, removeBadPixels, lowValueError, highValueError, stdFactor, lo, hi))
+				return false;
+			low_errors.push_back((unsigned short)lo);
+			high_errors.push_back((unsigned short)hi);
+			std::memcpy(img, lossy_out.data(), (size_t)width * std::max(0, std::min(lossy_height, height)) * 2);
+			return true;
+		}
 
 		bool set_parameter(const char *key, const char *value)
 		{
@@ -353,6 +575,7 @@ namespace
 		int bp_handle = 0;
 		bool motion_enabled = false;
 		std::vector<float> shifts; // (x,y) per frame
+		int min_T = 0, min_T_rows = 0; // global attributes MIN_T / MIN_T_HEIGHT (IRFileLoader.cpp:905-921)
 
 		~CameraObject() override
 		{
@@ -493,6 +716,18 @@ namespace
 			}
 			frame_attrs.resize(count);
 			last_raw.assign((size_t)width * height, 0);
+			min_T = min_T_rows = 0;
+			if (kind == RIRB)
+			{ // IRFileLoader::open (IRFileLoader.cpp:905-921)
+				auto it = global_attrs.find("MIN_T");
+				if (it != global_attrs.end())
+					min_T = std::atoi(it->second.c_str());
+				it = global_attrs.find("MIN_T_HEIGHT");
+				if (it != global_attrs.end())
+					min_T_rows = std::atoi(it->second.c_str());
+				if (min_T_rows == 0)
+					min_T_rows = height - 3;
+			}
 			return true;
 		}
 
@@ -534,6 +769,12 @@ namespace
 			if (rir_codec_decode_device(cc.d_hdr.as<unsigned long long>(), cc.d_tile_off.as<unsigned int>(), cc.d_chunk_off.as<unsigned long long>(),
 										cc.d_stream.as<unsigned long long>(), width, height, (int)ch.nframes, cc.gop, cc.d_frames.as<unsigned short>(),
 										cc.d_err.as<int>(), st) != 0)
+				return false;
+			// frames recorded with subtractMin: add the stored minimum back (IRFileLoader.cpp:1173-1179)
+			if (min_T && min_T_rows > 0 &&
+				!hip_ok(launch_lossy_add_min(cc.d_frames.as<uint16_t>(), (int64_t)width * height, width * std::min(min_T_rows, height), (int)ch.nframes,
+											 (uint32_t)min_T, st),
+						"add min"))
 				return false;
 			int err = 0;
 			const size_t fbytes = (size_t)width * height * 2;
@@ -1184,9 +1425,8 @@ RIR_EXPORT int h264_add_image_lossless(int file, unsigned short *img, int64_t ti
 	return s->add_image(img, timestamps_ns, attr_map_from_c(attribute_count, keys, key_lens, values, value_lens)) ? 0 : -1;
 }
 
-// Bounded-loss recording (h264.cpp:2253-2424) is the next step of the build.
-// Until then the frame is stored exactly: the documented invariant |out - in| <= lowValueError /
-// highValueError (h264.h:93-104) holds with zero error; only the extra compression is missing.
+// Bounded-loss recording: reference H264_Saver::addImageLossy (h264.cpp:2038-2046) without an input
+// camera, i.e. addImageLossyNoCamera (:2253-2424) - the only variant reachable without a calibration plugin.
 RIR_EXPORT int h264_add_image_lossy(int file, unsigned short *img_DL, int64_t timestamps_ns, int attribute_count, char *keys, int *key_lens,
 									char *values, int *value_lens)
 {
@@ -1196,24 +1436,19 @@ RIR_EXPORT int h264_add_image_lossy(int file, unsigned short *img_DL, int64_t ti
 		log_error("h264_add_image_lossy: NULL identifier");
 		return -1;
 	}
-	if (!s->add_image(img_DL, timestamps_ns, attr_map_from_c(attribute_count, keys, key_lens, values, value_lens)))
-		return -1;
-	s->low_errors.push_back((unsigned short)s->lowValueError);
-	s->high_errors.push_back((unsigned short)s->highValueError);
-	return 0;
+	return s->add_image_lossy(img_DL, timestamps_ns, attr_map_from_c(attribute_count, keys, key_lens, values, value_lens)) ? 0 : -1;
 }
 
-// h264_add_loss (video_io.cpp:789-806) applies the loss to the caller's image without writing it:
-// with zero injected loss the image is returned unchanged.
+// h264_add_loss (video_io.cpp:789-806): adds the loss to the caller's image without writing it
 RIR_EXPORT int h264_add_loss(int file, unsigned short *img)
 {
 	auto s = saver(file);
-	if (!s || !img)
+	if (!s)
 	{
 		log_error("h264_add_loss: NULL identifier");
 		return -1;
 	}
-	return 0;
+	return s->add_loss(img) ? 0 : -1;
 }
 
 static int errors_out(const std::vector<unsigned short> &err, unsigned short *errors, int *size)

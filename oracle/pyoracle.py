@@ -285,3 +285,35 @@ class RefAttrs:
         self.lib.ref_attrs_read.argtypes = [ct.c_char_p, ct.c_void_p, ct.c_int, ct.c_char_p, ct.c_char_p, ct.POINTER(ct.c_int), ct.POINTER(ct.c_int)]
         cnt = self.lib.ref_attrs_read(str(filename).encode(), T, cap, gkey.encode(), buf, ct.byref(n), ct.byref(ng))
         return cnt, list(T[:max(cnt, 0)]), (buf.raw[: n.value] if n.value >= 0 else None), ng.value
+
+
+class OracleLossy:
+    """Stateful loss injection of the lossy saver (oracle/rir_oracle.c: orc_lossy_*)."""
+
+    def __init__(self, oracle, w, h, lossy_height=None, low_err=6, high_err=2, std_factor=5.0, running_average=32, subtract_min=False):
+        self.lib = oracle.lib
+        self.w, self.h = w, h
+        self.lib.orc_lossy_create.restype = ct.c_void_p
+        self.lib.orc_lossy_create.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_double, ct.c_int, ct.c_int]
+        self.lib.orc_lossy_step.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int]
+        self.lib.orc_lossy_free.argtypes = [ct.c_void_p]
+        self.lib.orc_lossy_last_errors.argtypes = [ct.c_void_p, ct.POINTER(ct.c_int), ct.POINTER(ct.c_int), ct.POINTER(ct.c_uint)]
+        self.p = self.lib.orc_lossy_create(w, h, h if lossy_height is None else lossy_height, low_err, high_err, float(std_factor),
+                                           running_average, int(subtract_min))
+
+    def step(self, img, add_loss=False):
+        img = np.ascontiguousarray(img, dtype=np.uint16)
+        out = np.zeros_like(img)
+        self.lib.orc_lossy_step(self.p, _p(img), _p(out), int(add_loss))
+        return out
+
+    def last_errors(self):
+        lo, hi, bg = ct.c_int(0), ct.c_int(0), ct.c_uint(0)
+        self.lib.orc_lossy_last_errors(self.p, ct.byref(lo), ct.byref(hi), ct.byref(bg))
+        return lo.value, hi.value, bg.value
+
+    def __del__(self):
+        try:
+            self.lib.orc_lossy_free(self.p)
+        except Exception:
+            pass

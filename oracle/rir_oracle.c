@@ -802,6 +802,264 @@ EXPORT int orc_codec_decode_chunk(const uint64_t *hdr, const uint32_t *tile_off,
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* L1-L4  bounded-loss recording ("lossy" saver)   reference: src/cpp/video_io/h264.cpp         */
+/*   L1 get_background      :1955-1991   mode of (v >> 2) over 16 384 bins, lowest bin wins     */
+/*   L2 stdDev              :1993-2036   sqrt((sum d)^2 - sum d^2) / n   (sic), optional split   */
+/*   L3 RunningAverage2     :1526-1615   sliding integer mean with per-pixel reset              */
+/*   L4 addImageLossyNoCamera :2253-2424 and addLoss :2426-2607 (decision loop + error budget)  */
+/* Only rows < lossy_height are altered.  No reference test pins values (parity unpinned        */
+/* upstream): this is a restatement of the source text; the documented invariant is             */
+/* |out - in| <= lowValueError / highValueError.                                                */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct orc_lossy
+{
+	int w, h, hl; /* hl = stop_lossy_height */
+	int low_value_error, high_value_error, running_average, subtract_min;
+	double std_factor;
+	int frames; /* frames processed so far */
+	uint16_t min;
+	uint16_t *refT, *prevT, *lastDL;
+	/* RunningAverage2 */
+	int ra_count; /* images.size() */
+	uint16_t *ra_images; /* ring, oldest first after rotation: stored [slot][s] with ra_head */
+	int ra_head;
+	uint32_t *ra_sums;
+	uint16_t *ra_const_value;
+	int16_t *ra_const_count;
+	/* error budget */
+	double std_first[2];
+	int n_first;
+	double std_win[40][2];
+	int n_win;
+	int last_low, last_high;
+	unsigned last_background;
+} orc_lossy;
+
+EXPORT orc_lossy *orc_lossy_create(int w, int h, int lossy_height, int low_err, int high_err, double std_factor, int running_average, int subtract_min)
+{
+	orc_lossy *L = (orc_lossy *)calloc(1, sizeof(orc_lossy));
+	L->w = w, L->h = h, L->hl = lossy_height;
+	L->low_value_error = low_err, L->high_value_error = high_err, L->std_factor = std_factor;
+	L->running_average = running_average > 64 ? 64 : running_average;
+	L->subtract_min = subtract_min;
+	size_t s = (size_t)w * lossy_height, full = (size_t)w * h;
+	L->refT = (uint16_t *)calloc(full, 2);
+	L->prevT = (uint16_t *)calloc(full, 2);
+	L->lastDL = (uint16_t *)calloc(full, 2);
+	L->ra_images = (uint16_t *)calloc((size_t)(L->running_average > 0 ? L->running_average : 1) * s, 2);
+	L->ra_sums = (uint32_t *)calloc(s, 4);
+	L->ra_const_value = (uint16_t *)calloc(s, 2);
+	L->ra_const_count = (int16_t *)calloc(s, 2);
+	return L;
+}
+EXPORT void orc_lossy_free(orc_lossy *L)
+{
+	if (!L)
+		return;
+	free(L->refT), free(L->prevT), free(L->lastDL), free(L->ra_images), free(L->ra_sums), free(L->ra_const_value), free(L->ra_const_count);
+	free(L);
+}
+EXPORT void orc_lossy_last_errors(const orc_lossy *L, int *low, int *high, unsigned *background)
+{
+	*low = L->last_low, *high = L->last_high, *background = L->last_background;
+}
+
+static unsigned lossy_background(const uint16_t *im, int size)
+{ /* h264.cpp:1955-1991 */
+	static unsigned hist[16384];
+	memset(hist, 0, sizeof(hist));
+	for (int i = 0; i < size; ++i)
+		hist[im[i] >> 2]++;
+	unsigned max = hist[0], index = 0;
+	for (int i = 1; i < 16384; ++i)
+		if (hist[i] > max)
+		{
+			max = hist[i];
+			index = i;
+		}
+	return (index << 2) + 1;
+}
+
+/* h264.cpp:1993-2036 ; int products like the reference (wrap for |d| > 46340) */
+static void lossy_stddev(const uint16_t *prev, const uint16_t *img, int s, const uint16_t *img_dl, const unsigned *back, double *first, double *second)
+{
+	if (!back || !img_dl)
+	{
+		double sum_diff2 = 0, sum_diff = 0;
+		for (int i = 0; i < s; ++i)
+		{
+			int diff = abs((int)img[i] - (int)prev[i]);
+			sum_diff2 += sq_i32(diff);
+			sum_diff += diff;
+		}
+		double res = sqrt(sum_diff * sum_diff - sum_diff2) / s;
+		*first = *second = res;
+		return;
+	}
+	double sum_diff2 = 0, sum_diff = 0, b_sum_diff2 = 0, b_sum_diff = 0;
+	int b_sum = 0, sum = 0;
+	for (int i = 0; i < s; ++i)
+	{
+		int diff = abs((int)img[i] - (int)prev[i]);
+		if (img_dl[i] > *back)
+		{
+			sum_diff2 += sq_i32(diff);
+			sum_diff += diff;
+			sum++;
+		}
+		else
+		{
+			b_sum_diff2 += sq_i32(diff);
+			b_sum_diff += diff;
+			b_sum++;
+		}
+	}
+	*first = sqrt(b_sum_diff * b_sum_diff - b_sum_diff2) / b_sum;
+	*second = sqrt(sum_diff * sum_diff - sum_diff2) / sum;
+}
+
+/* One frame through the loss injection.  `out` receives the frame that the saver then stores
+ * losslessly (all rows).  add_loss != 0 selects the addLoss variant (:2426-2607): one-sided error
+ * reduction and no integration-time test.  Returns 0. */
+EXPORT int orc_lossy_step(orc_lossy *L, const uint16_t *img, uint16_t *out, int add_loss)
+{
+	const int w = L->w, h = L->h, s = w * L->hl, full = w * h;
+	uint16_t *tmp = (uint16_t *)malloc((size_t)full * 2);
+	uint16_t *tmpT = out;
+	memcpy(tmp, img, (size_t)full * 2);
+	if (L->frames == 0)
+	{ /* first image: stored as is (minus the optional minimum), seeds refT / prevT (:2274-2313) */
+		memcpy(L->lastDL, tmp, (size_t)full * 2);
+		if (L->subtract_min)
+		{
+			L->min = 65535;
+			for (int i = 0; i < s; ++i)
+				if (tmp[i] < L->min)
+					L->min = tmp[i];
+			for (int i = 0; i < s; ++i)
+				tmp[i] = tmp[i] < L->min ? 0 : (uint16_t)(tmp[i] - L->min);
+		}
+		L->last_low = L->low_value_error, L->last_high = L->high_value_error;
+		memcpy(out, tmp, (size_t)full * 2);
+		memcpy(L->refT, tmp, (size_t)s * 2);
+		memcpy(L->prevT, tmp, (size_t)s * 2);
+		L->frames = 1;
+		free(tmp);
+		return 0;
+	}
+	memcpy(tmpT, tmp, (size_t)full * 2);
+	if (L->subtract_min)
+		for (int i = 0; i < s; ++i)
+			tmpT[i] = tmpT[i] < L->min ? 0 : (uint16_t)(tmpT[i] - L->min);
+	unsigned background = lossy_background(tmp, s);
+	L->last_background = background;
+	int lowError = L->low_value_error, highError = L->high_value_error;
+	double st[2];
+	if (L->n_win < 40)
+		lossy_stddev(L->prevT, tmpT, s, NULL, NULL, &st[0], &st[1]);
+	else
+		lossy_stddev(L->prevT, tmpT, s, img, &background, &st[0], &st[1]);
+	if (L->n_first < 1)
+	{
+		L->std_first[0] = st[0], L->std_first[1] = st[1];
+		L->n_first = 1;
+	}
+	if (L->n_win < 40)
+	{
+		L->std_win[L->n_win][0] = st[0], L->std_win[L->n_win][1] = st[1];
+		L->n_win++;
+	}
+	else
+	{
+		memmove(L->std_win, L->std_win + 1, sizeof(double) * 2 * 39);
+		L->std_win[39][0] = st[0], L->std_win[39][1] = st[1];
+	}
+	double mean[2] = {L->std_first[0], L->std_first[1]};
+	for (int i = 0; i < L->n_win; ++i)
+	{
+		mean[0] += L->std_win[i][0];
+		mean[1] += L->std_win[i][1];
+	}
+	mean[0] /= (double)(L->n_win + L->n_first);
+	mean[1] /= (double)(L->n_win + L->n_first);
+	if (add_loss)
+	{
+		double diff_high = st[1] < mean[1] ? 0 : st[1] - mean[1];
+		double diff_low = st[0] < mean[0] ? 0 : st[0] - mean[0];
+		highError -= (int)round(diff_high * L->std_factor);
+		lowError -= (int)round(diff_low * L->std_factor);
+	}
+	else
+	{
+		highError -= (int)round(fabs(st[1] - mean[1]) * L->std_factor);
+		lowError -= (int)round(fabs(st[0] - mean[0]) * L->std_factor);
+	}
+	if (highError < 0)
+		highError = 0;
+	if (lowError < highError)
+		lowError = highError;
+	L->last_low = lowError, L->last_high = highError;
+
+	const int ra = L->running_average;
+	if (ra > 0)
+	{ /* RunningAverage2::addImage (:1559-1594) */
+		const int full_ring = (L->ra_count == ra);
+		const uint16_t *oldest = L->ra_images + (size_t)L->ra_head * s;
+		for (int i = 0; i < s; ++i)
+		{
+			L->ra_sums[i] += tmpT[i];
+			if (full_ring)
+			{
+				if (L->ra_const_count[i])
+				{
+					--L->ra_const_count[i];
+					L->ra_sums[i] -= L->ra_const_value[i];
+				}
+				else if (L->ra_count > 0)
+					L->ra_sums[i] -= oldest[i];
+			}
+		}
+		if (!full_ring)
+		{
+			memcpy(L->ra_images + (size_t)((L->ra_head + L->ra_count) % ra) * s, tmpT, (size_t)s * 2);
+			L->ra_count++;
+		}
+		else
+		{
+			memcpy(L->ra_images + (size_t)L->ra_head * s, tmpT, (size_t)s * 2);
+			L->ra_head = (L->ra_head + 1) % ra;
+		}
+	}
+	for (int i = 0; i < s; ++i)
+	{ /* decision loop (:2397-2413 / :2574-2590) */
+		int diff = abs((int)tmpT[i] - (int)L->refT[i]);
+		int max_error = tmp[i] > background ? highError : lowError;
+		int keep = diff <= max_error;
+		if (!add_loss)
+			keep = keep && ((L->lastDL[i] >> 13) == (tmp[i] >> 13));
+		if (keep)
+			tmpT[i] = ra > 0 ? (uint16_t)(L->ra_sums[i] / (unsigned)L->ra_count) : L->refT[i];
+		else
+		{
+			L->refT[i] = tmpT[i];
+			if (ra > 0)
+			{
+				L->ra_const_value[i] = tmpT[i];
+				L->ra_const_count[i] = (int16_t)L->ra_count;
+				L->ra_sums[i] = (unsigned)tmpT[i] * (unsigned)L->ra_count;
+			}
+		}
+	}
+	memcpy(L->prevT, tmpT, (size_t)s * 2);
+	memcpy(L->lastDL, tmp, (size_t)full * 2);
+	memcpy(tmpT + s, tmp + s, (size_t)(full - s) * 2);
+	L->frames++;
+	free(tmp);
+	return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* C5  ZFile method 1 equivalent (CPU baseline only): one-shot zstd per raw frame is timed by  */
 /*     bench.py through dlopen("libzstd.so.1"); nothing to restate here (third-party).         */
 /* ------------------------------------------------------------------------------------------ */

@@ -1,0 +1,117 @@
+"""GPU: bounded-loss recording (h264_add_image_lossy / h264_add_loss) against the oracle's restatement of
+reference h264.cpp:2253-2607, bit-exact frame by frame, plus the files' attributes and error vectors
+(reference tests/python/test_video_io.py:96-144)."""
+import numpy as np
+import pytest
+
+from librir_amd.synthetic import inject_bad_pixels, s1_noisy_background
+from librir_amd.video_io import IRMovie, IRSaver
+from oracle.pyoracle import OracleLossy
+
+pytestmark = pytest.mark.gpu
+
+
+def run_saver(path, arr, hl, params, add_loss_from=None):
+    n, h, w = arr.shape
+    losses = []
+    with IRSaver(path, w, h, hl) as s:
+        for k, v in params.items():
+            s.set_parameter(k, v)
+        for i in range(n):
+            if add_loss_from is not None and i >= add_loss_from:
+                losses.append(s.add_loss(arr[i]))
+            else:
+                s.add_image_lossy(arr[i], i * 1000, {"idx": str(i)})
+        low, high = np.array(s.get_low_errors()), np.array(s.get_high_errors())
+    return low, high, losses
+
+
+CASES = {
+    "defaults_60_frames": dict(n=60, h=64, w=80, hl=64, p={}),
+    "flat_budget": dict(n=20, h=64, w=80, hl=61, p={"lowValueError": 3, "highValueError": 3, "stdFactor": 0}),
+    "no_average": dict(n=20, h=35, w=83, hl=32, p={"runningAverage": 0, "lowValueError": 5, "highValueError": 1}),
+    "short_ring": dict(n=30, h=48, w=96, hl=45, p={"runningAverage": 3, "stdFactor": 2.5}),
+    "subtract_min": dict(n=20, h=64, w=80, hl=61, p={"subtractMin": 1, "lowValueError": 4, "highValueError": 2}),
+    "full_frame_640x512": dict(n=45, h=512, w=640, hl=509, p={}),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_add_image_lossy_matches_oracle(tmp_path, oracle, name):
+    c = CASES[name]
+    arr = s1_noisy_background(c["n"], c["h"], c["w"], seed=11)
+    p = c["p"]
+    L = OracleLossy(oracle, c["w"], c["h"], c["hl"], low_err=int(p.get("lowValueError", 6)), high_err=int(p.get("highValueError", 2)),
+                    std_factor=float(p.get("stdFactor", 5.0)), running_average=int(p.get("runningAverage", 32)),
+                    subtract_min=bool(p.get("subtractMin", 0)))
+    exp, elow, ehigh = [], [], []
+    for i in range(c["n"]):
+        exp.append(L.step(arr[i]))
+        lo, hi, _ = L.last_errors()
+        elow.append(lo)
+        ehigh.append(hi)
+    exp = np.stack(exp)
+    dst = tmp_path / "lossy.h264"
+    low, high, _ = run_saver(dst, arr, c["hl"], p)
+    assert low.tolist() == elow and high.tolist() == ehigh
+    with IRMovie.from_filename(dst) as mov:
+        got = mov.data
+        assert int(mov.attributes["GlobalBackgroundError"]) == int(p.get("lowValueError", 6))
+    if p.get("subtractMin"):
+        # the loader adds MIN_T back on the first MIN_T_HEIGHT rows (IRFileLoader.cpp:1173-1179)
+        mn = int(arr[0, : c["hl"]].min())
+        exp = exp.copy()
+        exp[:, : c["hl"]] += np.uint16(mn)
+    assert np.array_equal(got, exp)
+    bound = (1 if int(p.get("runningAverage", 32)) == 0 else 2) * int(p.get("lowValueError", 6))
+    if not p.get("subtractMin"):
+        assert np.abs(got.astype(np.int32) - arr).max() <= bound
+    assert np.array_equal(got[:, c["hl"]:], arr[:, c["hl"]:])
+
+
+def test_add_loss_matches_oracle_and_leaves_the_file_alone(tmp_path, oracle):
+    n, h, w, hl = 50, 40, 72, 37
+    arr = s1_noisy_background(n, h, w, seed=13)
+    L = OracleLossy(oracle, w, h, hl, low_err=6, high_err=2, std_factor=5.0, running_average=32)
+    exp = [L.step(arr[i], add_loss=(i >= 1)) for i in range(n)]
+    dst = tmp_path / "loss.h264"
+    low, high, losses = run_saver(dst, arr, hl, {}, add_loss_from=1)
+    assert len(low) == len(high) == n
+    for i in range(1, n):
+        assert np.array_equal(losses[i - 1], exp[i]), i
+    with IRMovie.from_filename(dst) as mov:  # only the first image went through add_image_lossy
+        assert mov.images == 1 and np.array_equal(mov[0], arr[0])
+
+
+def test_remove_bad_pixels_option(tmp_path, oracle):
+    """removeBadPixels: detector initialised on the first image's lossy rows, every image corrected before
+    the loss is injected (h264.cpp:2259-2266)."""
+    n, h, w, hl = 12, 67, 83, 64
+    arr = inject_bad_pixels(s1_noisy_background(n, h, w, seed=17), 9)
+    xy = oracle.bad_pixels_detect(arr[0, :hl])
+    _, fc = oracle.bad_pixels_stats(arr[0, :hl])
+    assert len(xy) > 0
+    L = OracleLossy(oracle, w, h, hl, low_err=3, high_err=3, std_factor=0.0, running_average=4)
+    exp = []
+    for i in range(n):
+        f = arr[i].copy()
+        f[:hl] = oracle.bad_pixels_correct(arr[i, :hl], xy, fc)
+        exp.append(L.step(f))
+    dst = tmp_path / "bp.h264"
+    run_saver(dst, arr, hl, {"removeBadPixels": 1, "lowValueError": 3, "highValueError": 3, "stdFactor": 0, "runningAverage": 4})
+    with IRMovie.from_filename(dst) as mov:
+        assert np.array_equal(mov.data, np.stack(exp))
+
+
+def test_per_frame_error_attributes(tmp_path):
+    arr = s1_noisy_background(6, 32, 64, seed=19)
+    dst = tmp_path / "attrs.h264"
+    low, high, _ = run_saver(dst, arr, 32, {})
+    with IRMovie.from_filename(dst) as mov:
+        mov.load_pos(0)
+        a0 = mov.frame_attributes
+        assert "BackgroundError" not in a0 and a0["idx"] in ("0", b"0")
+        mov.load_pos(3)
+        a3 = mov.frame_attributes
+        assert int(a3["BackgroundError"]) == low[3] and int(a3["ForegroundError"]) == high[3]
+        assert int(mov.attributes["GlobalForegroundError"]) == 2

@@ -105,7 +105,8 @@ def test_wrong_image_dimension_raises(tmp_path):
 
 
 def test_lossy_entry_points_respect_the_error_bound(tmp_path):
-    """documented invariant of the lossy mode: |out - in| <= lowValueError / highValueError (h264.h:93-104)"""
+    """documented invariant of the lossy mode (h264.h:93-104): each pixel stays within the error of its reference
+    value; with the default 32-frame running average the stored mean is within 2*err of the input."""
     arr = images(12, 64, 80)
     dst = tmp_path / "lossy.h264"
     with IRSaver(dst, 80, 64, 64) as s:
@@ -115,9 +116,10 @@ def test_lossy_entry_points_respect_the_error_bound(tmp_path):
         for i in range(12):
             s.add_image_lossy(arr[i], i * 1000)
         assert len(s.get_low_errors()) == len(s.get_high_errors()) == 12  # test_video_io.py:96-144
-        assert np.array_equal(s.add_loss(arr[0]), arr[0]) or np.abs(s.add_loss(arr[0]).astype(int) - arr[0]).max() <= 3
+        assert np.abs(s.add_loss(arr[0]).astype(int) - arr[0]).max() <= 6
     with IRMovie.from_filename(dst) as mov:
-        assert np.abs(mov.data.astype(np.int32) - arr).max() <= 3
+        assert np.array_equal(mov[0], arr[0])
+        assert np.abs(mov.data.astype(np.int32) - arr).max() <= 6
 
 
 def test_readback_bad_pixels_and_motion_correction(tmp_path, oracle):
