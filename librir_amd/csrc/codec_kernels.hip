@@ -25,6 +25,35 @@
 #include "codec_format.h"
 #include "filter_kernels.h"
 
+// Cache policy of each traffic class (aux operand of the buffer instructions: 2 = nt, "streaming").
+// Raw frames are read once by the encoder and written once by the decoder, the sparse slots are read once by
+// the compaction: marking those accesses non-temporal keeps them from evicting what the NEXT kernel of the
+// pipeline reads (the dense stream, which should stay in L2 / Infinity Cache between compaction and decode).
+// Measured on the headline workload (scripts/variants.py): all-default 438 us per encode+decode pass,
+// frames nt 391 us, + compaction loads nt 351 us; nt on the stream loads or the sparse stores is worse.
+#ifndef RIR_FRAME_LOAD_AUX
+#define RIR_FRAME_LOAD_AUX 2
+#endif
+#ifndef RIR_FRAME_STORE_AUX
+#define RIR_FRAME_STORE_AUX 2
+#endif
+#ifndef RIR_SPARSE_STORE_AUX
+#define RIR_SPARSE_STORE_AUX 0
+#endif
+#ifndef RIR_STREAM_LOAD_AUX
+#define RIR_STREAM_LOAD_AUX 0
+#endif
+#ifndef RIR_COMPACT_NT_LOAD
+#define RIR_COMPACT_NT_LOAD 1
+#endif
+#ifndef RIR_COMPACT_NT_STORE
+#define RIR_COMPACT_NT_STORE 0
+#endif
+// 1 adds explicit loads-only s_waitcnt on top of the compiler's counted waits (development switch)
+#ifndef RIR_MANUAL_WAITS
+#define RIR_MANUAL_WAITS 0
+#endif
+
 namespace rir
 {
 
@@ -239,7 +268,7 @@ namespace rir
 	}
 	__device__ __forceinline__ Px8 buf_load8(const void *tile_base, uint32_t lane_off)
 	{
-		const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(tile_base, RIRB1_TILE_PX * 2), lane_off, 0, 0);
+		const v4u32 v = __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(tile_base, RIRB1_TILE_PX * 2), lane_off, 0, RIR_FRAME_LOAD_AUX);
 		Px8 r;
 		r.d[0] = v.x;
 		r.d[1] = v.y;
@@ -254,7 +283,7 @@ namespace rir
 		v.y = r.d[1];
 		v.z = r.d[2];
 		v.w = r.d[3];
-		__builtin_amdgcn_raw_buffer_store_b128(v, make_rsrc(tile_base, RIRB1_TILE_PX * 2), lane_off, 0, 0);
+		__builtin_amdgcn_raw_buffer_store_b128(v, make_rsrc(tile_base, RIRB1_TILE_PX * 2), lane_off, 0, RIR_FRAME_STORE_AUX);
 	}
 
 	// tile minimum of the 8 packed values of every lane -> wave-uniform 16-bit base
@@ -377,7 +406,17 @@ namespace rir
 	// Narrow tier: every residual < 16.  The 8 nibbles of a lane are packed in one dword and ONE
 	// 32x32 transpose per half-wave produces the 32 candidate planes (lane 4j+b: plane b of slot j;
 	// the upper half holds bits 32..63 of the same plane word).
-	__device__ __forceinline__ uint64_t emit_record_narrow(const Px8 &r, uint32_t modebits, uint32_t base, __amdgpu_buffer_rsrc_t out, uint32_t pos,
+	// The two 8-byte stores of a record (offsets are out of range for lanes without a plane).  They are issued
+	// by the caller, outside the wave-uniform tier branch: with every vector-memory operation of the frame loop
+	// unconditional the compiler keeps exact s_waitcnt vmcnt(N) counts (a store inside the branch made it fall
+	// back to vmcnt(0) on half of the steps, i.e. no prefetch overlap).
+	struct RecordStores
+	{
+		v2u32 va, vb;
+		uint32_t oa, ob;
+	};
+
+	__device__ __forceinline__ uint64_t emit_record_narrow(const Px8 &r, uint32_t modebits, uint32_t base, RecordStores &rs, uint32_t pos,
 														   const LaneConsts &lc, const TransposeConsts &tc, uint32_t *words)
 	{
 		// bytes r0..r3 / r4..r7, then nibbles
@@ -396,7 +435,8 @@ namespace rir
 		v2u32 v;
 		v.x = x, v.y = sw[1];
 		const uint32_t off = (lc.n_half == 0 && lc.n_bit < w) ? (pos + incl - w + lc.n_bit) * 8u : RIR_OOB;
-		__builtin_amdgcn_raw_buffer_store_b64(v, out, off, 0, 0);
+		rs.va = v, rs.oa = off;
+		rs.vb = v, rs.ob = RIR_OOB;
 		*words = total;
 		// header, assembled by the lanes 16q+k from the same non-zero mask
 		const uint32_t wa = bitlen_nz((nz >> lc.h_sha) & 15u), wb = bitlen_nz((nz >> lc.h_shb) & 15u);
@@ -406,7 +446,7 @@ namespace rir
 	}
 
 	// Wide tier (any width up to 16): two 64x64 transposes, lane 16q+k holds plane k of slots q and 4+q.
-	__device__ __forceinline__ uint64_t emit_record_wide(const Px8 &r, uint32_t modebits, uint32_t base, __amdgpu_buffer_rsrc_t out, uint32_t pos,
+	__device__ __forceinline__ uint64_t emit_record_wide(const Px8 &r, uint32_t modebits, uint32_t base, RecordStores &rs, uint32_t pos,
 														 const LaneConsts &lc, const TransposeConsts &tc, uint32_t *words)
 	{
 		uint32_t alo = r.d[0], ahi = r.d[1], blo = r.d[2], bhi = r.d[3];
@@ -421,8 +461,8 @@ namespace rir
 		va.x = alo, va.y = ahi, vb.x = blo, vb.y = bhi;
 		const uint32_t oa = lc.bit < wa ? (pos + ia - wa + lc.bit) * 8u : RIR_OOB;
 		const uint32_t ob = lc.bit < wb ? (pos + tot_a + ib - wb + lc.bit) * 8u : RIR_OOB;
-		__builtin_amdgcn_raw_buffer_store_b64(va, out, oa, 0, 0);
-		__builtin_amdgcn_raw_buffer_store_b64(vb, out, ob, 0, 0);
+		rs.va = va, rs.oa = oa;
+		rs.vb = vb, rs.ob = ob;
 		*words = tot_a + tot_b;
 		// header = ballot of the row's 16-bit field (w_q | w_{4+q} << 5 | base nibble q << 10 | mode << 14)
 		const uint32_t nib = (base >> lc.sh4) & 15u;
@@ -437,9 +477,15 @@ namespace rir
 													const LaneConsts &lc, const TransposeConsts &tc, uint32_t *words)
 	{
 		const uint32_t any = (r.d[0] | r.d[1]) | (r.d[2] | r.d[3]);
+		RecordStores rs;
+		uint64_t h;
 		if (__ballot((any & 0xfff0fff0u) != 0) == 0)
-			return emit_record_narrow(r, modebits, base, out, pos, lc, tc, words);
-		return emit_record_wide(r, modebits, base, out, pos, lc, tc, words);
+			h = emit_record_narrow(r, modebits, base, rs, pos, lc, tc, words);
+		else
+			h = emit_record_wide(r, modebits, base, rs, pos, lc, tc, words);
+		__builtin_amdgcn_raw_buffer_store_b64(rs.va, out, rs.oa, 0, RIR_SPARSE_STORE_AUX);
+		__builtin_amdgcn_raw_buffer_store_b64(rs.vb, out, rs.ob, 0, RIR_SPARSE_STORE_AUX);
+		return h;
 	}
 
 	// One wave = one tile over the frames of one chunk (see the kernel below).
@@ -474,7 +520,7 @@ namespace rir
 			}
 		};
 #define RIR_WAIT_SLOT(SLOT, N)                                   \
-	if (FAST)                                                    \
+	if (FAST && RIR_MANUAL_WAITS)                                \
 		asm volatile("s_waitcnt vmcnt(" #N ")" : : : "memory");
 		auto as_px8 = [](const v4u32 &v) {
 			Px8 p;
@@ -520,15 +566,17 @@ namespace rir
 			const uint32_t key_mode = use_left ? RIRB1_MODE_LEFT : RIRB1_MODE_RAW;
 			const uint64_t h = emit_record(r_sel, lc.row0 ? (key_mode << 14) : 0u, use_left ? base_left : base_raw, out, pos, lc, tc, &words);
 			if (lane == 0)
-				hdr_reg = h;
+				my_hdr[0] = h;
 			pos += words;
 		}
 
 		// ---- temporal frames ----
+		// Steps come in groups of 64 (one header per lane of hdr_reg, flushed with one coalesced store per
+		// group) and the steady-state loop runs whole iterations of 4 steps with NO condition around any
+		// vector-memory operation: that is what lets the compiler keep counted waits, i.e. keeps the loads
+		// of the next frames in flight across the packing of the current one.
 		const uint32_t temporal_bits = lc.row0 ? ((uint32_t)RIRB1_MODE_TEMPORAL << 14) : 0u;
-		// Two younger loads are always behind the load of frame f when step f starts.
 #define RIR_ENC_STEP(F, CUR, PREV)                                                             \
-	if ((F) < nf)                                                                              \
 	{                                                                                          \
 		const int f = (F);                                                                     \
 		RIR_WAIT_SLOT(CUR, 2)                                                                  \
@@ -543,29 +591,38 @@ namespace rir
 		_Pragma("unroll") for (int k = 0; k < 4; ++k) d.d[k] = pk_sub16(d.d[k], b2);          \
 		uint32_t words;                                                                        \
 		const uint64_t h = emit_record(d, temporal_bits, base, out, pos, lc, tc, &words);      \
-		if ((f & 63) == 0)                                                                     \
-		{ /* flush the previous 64 headers (one coalesced 8-byte store per lane) */            \
-			my_hdr[f - 64 + lane] = hdr_reg;                                                   \
-			hdr_reg = 0;                                                                       \
-		}                                                                                      \
-		if (lane == (f & 63))                                                                  \
+		if (lane == ((f - 1) & 63))                                                            \
 			hdr_reg = h;                                                                       \
 		pos += words;                                                                          \
 	}
-		for (int fb = 1; fb < nf; fb += 4)
+		int fb = 1;
+		while (fb < nf)
 		{
-			RIR_ENC_STEP(fb, s1, s0)
-			RIR_ENC_STEP(fb + 1, s2, s1)
-			RIR_ENC_STEP(fb + 2, s3, s2)
-			RIR_ENC_STEP(fb + 3, s0, s3)
+			const int g0 = fb, gend = min(fb + 64, nf); // this group: frames [g0, gend), header of frame f in lane f - g0
+			for (; fb + 3 < gend; fb += 4)
+			{
+				RIR_ENC_STEP(fb, s1, s0)
+				RIR_ENC_STEP(fb + 1, s2, s1)
+				RIR_ENC_STEP(fb + 2, s3, s2)
+				RIR_ENC_STEP(fb + 3, s0, s3)
+			}
+			if (fb < gend)
+			{ // up to three left-over steps of the chunk's last group (64 % 4 == 0: the slot rotation stays aligned)
+				RIR_ENC_STEP(fb, s1, s0)
+				if (fb + 1 < gend)
+				{
+					RIR_ENC_STEP(fb + 1, s2, s1)
+					if (fb + 2 < gend)
+						RIR_ENC_STEP(fb + 2, s3, s2)
+				}
+				fb = gend;
+			}
+			if (g0 + lane < gend)
+				my_hdr[g0 + lane] = hdr_reg;
+			hdr_reg = 0;
 		}
 #undef RIR_ENC_STEP
 #undef RIR_WAIT_SLOT
-		{
-			const int fb = (nf - 1) & ~63;
-			if (fb + lane < nf)
-				my_hdr[fb + lane] = hdr_reg;
-		}
 		for (int f = nf + lane; f < gop; f += 64)
 			my_hdr[f] = 0; // short last chunk: the unused table entries are defined
 		if (lane == 0)
@@ -672,7 +729,13 @@ namespace rir
 		const uint64_t *src = sparse + ((int64_t)c * ntiles + t) * (int64_t)gop * RIRB1_REC_MAX_WORDS;
 		uint64_t *dst = stream + base_s + o0;
 		for (uint32_t i = tid; i < n; i += 256)
-			dst[i] = src[i];
+		{
+			const uint64_t v = RIR_COMPACT_NT_LOAD ? __builtin_nontemporal_load(src + i) : src[i];
+			if (RIR_COMPACT_NT_STORE)
+				__builtin_nontemporal_store(v, dst + i);
+			else
+				dst[i] = v;
+		}
 	}
 
 	// ---- decode -----------------------------------------------------------------------------
@@ -730,8 +793,8 @@ namespace rir
 			ob = (!r.bad && lc.bit < wb) ? (pos + tot_a + ib - wb + lc.bit) * 8u : RIR_OOB;
 		}
 		// exactly two loads per record, whatever the tier (the consumer's wait counts younger loads)
-		r.a = __builtin_amdgcn_raw_buffer_load_b64(in, oa, 0, 0);
-		r.b = __builtin_amdgcn_raw_buffer_load_b64(in, ob, 0, 0);
+		r.a = __builtin_amdgcn_raw_buffer_load_b64(in, oa, 0, RIR_STREAM_LOAD_AUX);
+		r.b = __builtin_amdgcn_raw_buffer_load_b64(in, ob, 0, RIR_STREAM_LOAD_AUX);
 		return r;
 	}
 
@@ -827,7 +890,7 @@ namespace rir
 		err |= R.bad;                                                                                                \
 		/* Belt and braces on top of the compiler's own counted wait: loads return in order among themselves, the    \
 		   six loads of the three younger records are the only operations allowed to be outstanding here. */         \
-		asm volatile("s_waitcnt vmcnt(6)" : : : "memory");                                                           \
+		if (RIR_MANUAL_WAITS) asm volatile("s_waitcnt vmcnt(6)" : : : "memory");                                                           \
 		const v2u32 wa_ = R.a, wb_ = R.b;                                                                             \
 		const bool narrow_ = R.narrow;                                                                               \
 		/* refill the slot with the record four frames ahead */                                                       \

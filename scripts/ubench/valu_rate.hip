@@ -31,6 +31,12 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed)
 			if (OP == 15) { a0 = a0 << sh; a1 = a1 >> sh; a2 = a2 << sh; a3 = a3 >> sh; a0 += 3; a1 += 5; a2 += 7; a3 += 9; }
 			if (OP == 16) { a0 = max(a0, a1); a1 = max(a1, a2); a2 = max(a2, a3); a3 = max(a3, a0 + 1); }
 			if (OP == 17) { a0 = __builtin_amdgcn_update_dpp(a0, a1, 0x4e, 0xf, 0xf, false) + 1; a1 = __builtin_amdgcn_update_dpp(a1, a2, 0x4e, 0xf, 0xf, false) + 1; a2 = __builtin_amdgcn_update_dpp(a2, a3, 0x4e, 0xf, 0xf, false) + 1; a3 = __builtin_amdgcn_update_dpp(a3, a0, 0x4e, 0xf, 0xf, false) + 1; }
+			if (OP == 18) { a0 = min((int)a0, __builtin_amdgcn_update_dpp(0x7fffffff, (int)a0, 0x111, 0xf, 0xf, false)); a1 = min((int)a1, __builtin_amdgcn_update_dpp(0x7fffffff, (int)a1, 0x112, 0xf, 0xf, false)); a2 = min((int)a2, __builtin_amdgcn_update_dpp(0x7fffffff, (int)a2, 0x114, 0xf, 0xf, false)); a3 = min((int)a3, __builtin_amdgcn_update_dpp(0x7fffffff, (int)a3, 0x142, 0xa, 0xf, false)); }
+			if (OP == 19) { a0 = __builtin_popcount(a0 & m) + a1; a1 = __builtin_popcount(a1 & m) + a2; a2 = __builtin_popcount(a2 & m) + a3; a3 = __builtin_popcount(a3 & m) + a0; }
+			if (OP == 20) { a0 = __builtin_amdgcn_ubfe(a1, sh, 8) + a0; a1 = __builtin_amdgcn_ubfe(a2, sh, 8) + a1; a2 = __builtin_amdgcn_ubfe(a3, sh, 8) + a2; a3 = __builtin_amdgcn_ubfe(a0, sh, 8) + a3; }
+			if (OP == 21) { a0 = min((int)a0, (int)a1); a1 = min((int)a1, (int)a2); a2 = min((int)a2, (int)a3); a3 = min((int)a3, (int)a0 + 1); }
+			if (OP == 22) { a0 = min((int)a0, __builtin_amdgcn_ds_swizzle((int)a0, (1 << 10) | 0x1f)); a1 = min((int)a1, __builtin_amdgcn_ds_swizzle((int)a1, (2 << 10) | 0x1f)); a2 = min((int)a2, __builtin_amdgcn_ds_swizzle((int)a2, (4 << 10) | 0x1f)); a3 = min((int)a3, __builtin_amdgcn_ds_swizzle((int)a3, (8 << 10) | 0x1f)); }
+			if (OP == 23) { typedef short s2 __attribute__((ext_vector_type(2))); a0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s2, a0), __builtin_bit_cast(s2, a1))); a1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s2, a1), __builtin_bit_cast(s2, a2))); a2 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s2, a2), __builtin_bit_cast(s2, a3))); a3 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(s2, a3), __builtin_bit_cast(s2, a0 + 1))); }
 			if (OP == 9) { a0 = max(a0, (uint32_t)__builtin_amdgcn_mov_dpp(a0, 0x121, 0xf, 0xf, false)); a1 = max(a1, (uint32_t)__builtin_amdgcn_mov_dpp(a1, 0x121, 0xf, 0xf, false)); a2 = max(a2, (uint32_t)__builtin_amdgcn_mov_dpp(a2, 0x121, 0xf, 0xf, false)); a3 = max(a3, (uint32_t)__builtin_amdgcn_mov_dpp(a3, 0x121, 0xf, 0xf, false)); }
 		}
 	}
@@ -78,5 +84,11 @@ int main()
 	run<15>("shift var + add (2)", d);
 	run<16>("v_max_u32 (+1 add in 4th)", d);
 	run<17>("mov_dpp + add (2)", d);
+	run<18>("v_min_i32_dpp (fused)", d);
+	run<19>("v_and + v_bcnt (2)", d);
+	run<20>("v_bfe + add (2)", d);
+	run<21>("v_min_i32 (+1 add in 4th)", d);
+	run<22>("ds_swizzle + v_min (1+lds)", d);
+	run<23>("v_pk_min_i16 (+1 add)", d);
 	return 0;
 }

@@ -1,0 +1,66 @@
+"""Development aid: build variants of the codec kernels with different -D switches and time them on
+the GPU box in one gpurun call.
+
+    python scripts/variants.py build  NAME="-DA=1 -DB=2" NAME2="..."     (here: cross-compile)
+    python scripts/variants.py run                                        (on the GPU box)
+Variants live in librir_amd/libs/variants/NAME.so (git-ignored like every .so)."""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from librir_amd import build as B  # noqa: E402
+
+VDIR = os.path.join(B.LIBS, "variants")
+
+
+def build(specs):
+    B.build(verbose=False)
+    if os.path.isdir(VDIR):
+        shutil.rmtree(VDIR)
+    os.makedirs(VDIR)
+    objdir = os.path.join(B.HERE, "build")
+    procs = []
+    for spec in specs:
+        name, flags = spec.split("=", 1)
+        obj = os.path.join(VDIR, name + ".o")
+        cmd = [B.HIPCC] + B.COMMON + flags.split() + ["-c", os.path.join(B.CSRC, "codec_kernels.hip"), "-o", obj]
+        procs.append((name, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for name, obj, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise SystemExit("variant %s failed" % name)
+        objs = [obj if f == "codec_kernels.hip.o" else os.path.join(objdir, f) for f in sorted(os.listdir(objdir)) if f.endswith(".o")]
+        subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(VDIR, name + ".so")] + objs + ["-ldl", "-lpthread"])
+        os.remove(obj)
+        print("built", name)
+
+
+def run(args):
+    main = os.path.join(B.LIBS, B.LIB_NAME)
+    keep = main + ".keep"
+    shutil.copy(main, keep)
+    env = dict(os.environ, RIR_SKIP_CHECK=os.environ.get("RIR_SKIP_CHECK", "1"))
+    try:
+        for f in sorted(os.listdir(VDIR)):
+            if not f.endswith(".so"):
+                continue
+            shutil.copy(os.path.join(VDIR, f), main)
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "codec_time.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+            lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith(("encode_tiles", "alone", "FAIL"))]
+            print("== %-24s rc=%d" % (f[:-3], r.returncode))
+            for ln in lines:
+                print("   " + ln)
+            sys.stdout.flush()
+    finally:
+        shutil.move(keep, main)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build(sys.argv[2:])
+    else:
+        run(sys.argv[2:])
