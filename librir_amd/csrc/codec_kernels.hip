@@ -350,6 +350,11 @@ namespace rir
 		bool n_hhi;		   // the slot's width lives in the high header dword
 		bool n_first;	   // plane 0 of its slot
 		uint32_t h_sha, h_shb; // header lanes (16q+k): positions of slots q and 4+q in the non-zero mask
+		// narrow tier, packed-nibble order (see emit_record_narrow): nibble n of the packed dword holds slot
+		// NIB_SLOT[n] = {0,4,2,6,1,5,3,7}; lane (lane & 31) = 4n + b holds plane b of that slot
+		uint32_t p_before; // mask of the lanes whose plane words precede this lane's word in the stream
+		uint32_t p_hshw;   // header lane 16q+k: left shift that brings its bit of the width word W to bit 31
+		uint32_t p_hshb;   // same for the base/mode word
 	};
 	__device__ __forceinline__ LaneConsts make_lane_consts(int lane)
 	{
@@ -371,6 +376,30 @@ namespace rir
 		c.n_first = (lane & 3) == 0;
 		c.h_sha = 4 * q;
 		c.h_shb = 16 + 4 * q;
+		{
+			const uint32_t nib_slot[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+			const uint32_t n = ((uint32_t)lane & 31u) >> 2, b = lane & 3;
+			uint32_t before = ((1u << b) - 1u) << (4 * n);
+			for (uint32_t m = 0; m < 8; ++m)
+				if (nib_slot[m] < nib_slot[n])
+					before |= 0xfu << (4 * m);
+			c.p_before = before;
+			// header field q = w_q | w_{4+q} << 5 | base nibble q << 10 | mode << 14 (q == 0); lane 16q+k tests bit k.
+			// Slot q sits in nibble nq = {0,4,2,6}[q] of W, slot 4+q in nibble nq+1; widths are <= 4 (3 bits).
+			const uint32_t k = lane & 15, nq = (q & 1) * 4 + (q >> 1) * 2;
+			uint32_t bw = 3; // a bit of W that is always 0
+			if (k < 3)
+				bw = 4 * nq + k;
+			else if (k >= 5 && k < 8)
+				bw = 4 * (nq + 1) + (k - 5);
+			c.p_hshw = 31 - bw;
+			uint32_t bb = 31; // a bit of (base | mode << 16) that is always 0
+			if (k >= 10 && k < 14)
+				bb = 4 * q + (k - 10);
+			else if (k >= 14 && q == 0)
+				bb = 16 + (k - 14);
+			c.p_hshb = 31 - bb;
+		}
 		return c;
 	}
 
@@ -403,50 +432,49 @@ namespace rir
 	// bit length of a value < 2^31 without a zero test: bitlen(2f+1) = bitlen(f)+1
 	__device__ __forceinline__ uint32_t bitlen_nz(uint32_t f) { return 31u - (uint32_t)__builtin_clz((f << 1) | 1u); }
 
-	// Narrow tier: every residual < 16.  The 8 nibbles of a lane are packed in one dword and ONE
-	// 32x32 transpose per half-wave produces the 32 candidate planes (lane 4j+b: plane b of slot j;
-	// the upper half holds bits 32..63 of the same plane word).
 	// The two 8-byte stores of a record (offsets are out of range for lanes without a plane).  They are issued
 	// by the caller, outside the wave-uniform tier branch: with every vector-memory operation of the frame loop
 	// unconditional the compiler keeps exact s_waitcnt vmcnt(N) counts (a store inside the branch made it fall
-	// back to vmcnt(0) on half of the steps, i.e. no prefetch overlap).
+	// back to vmcnt(0) on half of the steps).
 	struct RecordStores
 	{
 		v2u32 va, vb;
 		uint32_t oa, ob;
 	};
 
-	__device__ __forceinline__ uint64_t emit_record_narrow(const Px8 &r, uint32_t modebits, uint32_t base, RecordStores &rs, uint32_t pos,
+	// Narrow tier: every residual < 16.  The 8 nibbles of a lane are packed in one dword (3 shift-ors, nibble
+	// order r0 r4 r2 r6 r1 r5 r3 r7) and ONE 32x32 transpose per half-wave produces the 32 candidate planes
+	// (lane 4n+b: plane b of the slot in nibble n; the upper half holds bits 32..63 of the same plane word).
+	// Everything after the ballot is wave-uniform and runs on the scalar unit: M = the mask of stored planes
+	// (non-zero mask smeared down inside each nibble), W = per-nibble popcount of M = the 8 widths.  A lane's
+	// word index is a popcount of M under a per-lane constant mask; the header is two ballots of per-lane
+	// bit tests of W and of (base | mode << 16).
+	__device__ __forceinline__ uint64_t emit_record_narrow(const Px8 &r, uint32_t mode, uint32_t base, RecordStores &rs, uint32_t pos,
 														   const LaneConsts &lc, const TransposeConsts &tc, uint32_t *words)
 	{
-		// bytes r0..r3 / r4..r7, then nibbles
-		const uint32_t p01 = __builtin_amdgcn_perm(r.d[1], r.d[0], 0x06040200u);
-		const uint32_t p23 = __builtin_amdgcn_perm(r.d[3], r.d[2], 0x06040200u);
-		const uint32_t x01 = p01 | (p01 >> 4), x23 = p23 | (p23 >> 4);
-		uint32_t x = __builtin_amdgcn_perm(x23, x01, 0x06040200u); // nibble j = r_j
+		uint32_t x = (r.d[0] | (r.d[1] << 8)) | ((r.d[2] | (r.d[3] << 8)) << 4);
 		x = transpose32(x, tc);
 		const uint64_t nz64 = __ballot(x != 0);
-		const uint32_t nz = (uint32_t)nz64 | (uint32_t)(nz64 >> 32); // bit 4j+b: plane b of slot j is not empty
-		const uint32_t w = bitlen_nz((nz >> lc.n_sh) & 15u);		  // width of this lane's slot
-		const uint32_t incl = half_inclusive_sum(lc.n_first ? w : 0u); // words of slots 0..j
-		const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+		const uint32_t nz = (uint32_t)nz64 | (uint32_t)(nz64 >> 32); // bit 4n+b: plane b of nibble n is not empty
+		uint32_t M = nz | ((nz >> 1) & 0x77777777u);
+		M |= (M >> 2) & 0x33333333u; // nibble n = (1 << w) - 1
+		uint32_t W = M - ((M >> 1) & 0x55555555u);
+		W = (W & 0x33333333u) + ((W >> 2) & 0x33333333u); // nibble n = w (0..4)
+		*words = (uint32_t)__builtin_popcount(M);
 		// lower-half lanes assemble the 64-bit plane word (their dword | the partner lane's dword << 32)
 		auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false); // sw[1] lower lanes = x of lane + 32
-		v2u32 v;
-		v.x = x, v.y = sw[1];
-		const uint32_t off = (lc.n_half == 0 && lc.n_bit < w) ? (pos + incl - w + lc.n_bit) * 8u : RIR_OOB;
-		rs.va = v, rs.oa = off;
-		rs.vb = v, rs.ob = RIR_OOB;
-		*words = total;
-		// header, assembled by the lanes 16q+k from the same non-zero mask
-		const uint32_t wa = bitlen_nz((nz >> lc.h_sha) & 15u), wb = bitlen_nz((nz >> lc.h_shb) & 15u);
-		const uint32_t nib = (base >> lc.sh4) & 15u;
-		const uint32_t field = ((nib << 10) | modebits) | ((wb << 5) | wa);
-		return __ballot((field & lc.onehot) != 0);
+		rs.va.x = x, rs.va.y = sw[1];
+		const uint32_t off = (pos + (uint32_t)__builtin_popcount(M & lc.p_before)) * 8u;
+		rs.oa = __builtin_amdgcn_inverse_ballot_w64((uint64_t)M) ? off : RIR_OOB; // lane l < 32 stores iff bit l of M
+		rs.vb = rs.va, rs.ob = RIR_OOB;
+		const uint32_t B = base | (mode << 16);
+		const uint64_t hw = __ballot((int32_t)(W << lc.p_hshw) < 0) & 0x00E700E700E700E7ull;
+		const uint64_t hb = __ballot((int32_t)(B << lc.p_hshb) < 0) & 0x3C003C003C00FC00ull;
+		return hw | hb;
 	}
 
 	// Wide tier (any width up to 16): two 64x64 transposes, lane 16q+k holds plane k of slots q and 4+q.
-	__device__ __forceinline__ uint64_t emit_record_wide(const Px8 &r, uint32_t modebits, uint32_t base, RecordStores &rs, uint32_t pos,
+	__device__ __forceinline__ uint64_t emit_record_wide(const Px8 &r, uint32_t mode, uint32_t base, RecordStores &rs, uint32_t pos,
 														 const LaneConsts &lc, const TransposeConsts &tc, uint32_t *words)
 	{
 		uint32_t alo = r.d[0], ahi = r.d[1], blo = r.d[2], bhi = r.d[3];
@@ -466,23 +494,23 @@ namespace rir
 		*words = tot_a + tot_b;
 		// header = ballot of the row's 16-bit field (w_q | w_{4+q} << 5 | base nibble q << 10 | mode << 14)
 		const uint32_t nib = (base >> lc.sh4) & 15u;
-		const uint32_t field = ((nib << 10) | modebits) | ((wb << 5) | wa);
+		const uint32_t field = ((nib << 10) | (lc.row0 ? mode << 14 : 0u)) | ((wb << 5) | wa);
 		return __ballot((field & lc.onehot) != 0);
 	}
 
 	// Emit the payload of one record: residuals r (packed pairs) -> plane words at out[pos..pos+words).
-	// Returns the header; `modebits` = mode << 14 in row 0, zero elsewhere.  The tier is a property of
+	// Returns the header.  The tier is a property of
 	// the data (wave-uniform branch), the bitstream is the same either way.
-	__device__ __forceinline__ uint64_t emit_record(const Px8 &r, uint32_t modebits, uint32_t base, __amdgpu_buffer_rsrc_t out, uint32_t pos,
+	__device__ __forceinline__ uint64_t emit_record(const Px8 &r, uint32_t mode, uint32_t base, __amdgpu_buffer_rsrc_t out, uint32_t pos,
 													const LaneConsts &lc, const TransposeConsts &tc, uint32_t *words)
 	{
 		const uint32_t any = (r.d[0] | r.d[1]) | (r.d[2] | r.d[3]);
 		RecordStores rs;
 		uint64_t h;
 		if (__ballot((any & 0xfff0fff0u) != 0) == 0)
-			h = emit_record_narrow(r, modebits, base, rs, pos, lc, tc, words);
+			h = emit_record_narrow(r, mode, base, rs, pos, lc, tc, words);
 		else
-			h = emit_record_wide(r, modebits, base, rs, pos, lc, tc, words);
+			h = emit_record_wide(r, mode, base, rs, pos, lc, tc, words);
 		__builtin_amdgcn_raw_buffer_store_b64(rs.va, out, rs.oa, 0, RIR_SPARSE_STORE_AUX);
 		__builtin_amdgcn_raw_buffer_store_b64(rs.vb, out, rs.ob, 0, RIR_SPARSE_STORE_AUX);
 		return h;
@@ -564,7 +592,7 @@ namespace rir
 				r_sel.d[k] = use_left ? r_left.d[k] : r_raw.d[k];
 			uint32_t words;
 			const uint32_t key_mode = use_left ? RIRB1_MODE_LEFT : RIRB1_MODE_RAW;
-			const uint64_t h = emit_record(r_sel, lc.row0 ? (key_mode << 14) : 0u, use_left ? base_left : base_raw, out, pos, lc, tc, &words);
+			const uint64_t h = emit_record(r_sel, key_mode, use_left ? base_left : base_raw, out, pos, lc, tc, &words);
 			if (lane == 0)
 				my_hdr[0] = h;
 			pos += words;
@@ -575,7 +603,6 @@ namespace rir
 		// group) and the steady-state loop runs whole iterations of 4 steps with NO condition around any
 		// vector-memory operation: that is what lets the compiler keep counted waits, i.e. keeps the loads
 		// of the next frames in flight across the packing of the current one.
-		const uint32_t temporal_bits = lc.row0 ? ((uint32_t)RIRB1_MODE_TEMPORAL << 14) : 0u;
 #define RIR_ENC_STEP(F, CUR, PREV)                                                             \
 	{                                                                                          \
 		const int f = (F);                                                                     \
@@ -590,7 +617,7 @@ namespace rir
 		const uint32_t b2 = base | (base << 16);                                               \
 		_Pragma("unroll") for (int k = 0; k < 4; ++k) d.d[k] = pk_sub16(d.d[k], b2);          \
 		uint32_t words;                                                                        \
-		const uint64_t h = emit_record(d, temporal_bits, base, out, pos, lc, tc, &words);      \
+		const uint64_t h = emit_record(d, RIRB1_MODE_TEMPORAL, base, out, pos, lc, tc, &words);      \
 		if (lane == ((f - 1) & 63))                                                            \
 			hdr_reg = h;                                                                       \
 		pos += words;                                                                          \

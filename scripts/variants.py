@@ -26,7 +26,14 @@ def build(specs):
     for spec in specs:
         name, flags = spec.split("=", 1)
         obj = os.path.join(VDIR, name + ".o")
-        cmd = [B.HIPCC] + B.COMMON + flags.split() + ["-c", os.path.join(B.CSRC, "codec_kernels.hip"), "-o", obj]
+        src = os.path.join(B.CSRC, "codec_kernels.hip")
+        fl = []
+        for f in flags.split():
+            if f.startswith("--src="):
+                src = f[6:]  # e.g. an older revision: git show REV:librir_amd/csrc/codec_kernels.hip > /tmp/x.hip
+            else:
+                fl.append(f)
+        cmd = [B.HIPCC] + B.COMMON + fl + ["-c", src, "-o", obj]
         procs.append((name, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for name, obj, p in procs:
         out, _ = p.communicate()
@@ -45,7 +52,8 @@ def run(args):
     shutil.copy(main, keep)
     env = dict(os.environ, RIR_SKIP_CHECK=os.environ.get("RIR_SKIP_CHECK", "1"))
     try:
-        for f in sorted(os.listdir(VDIR)):
+        reps = int(os.environ.get("RIR_VARIANT_REPS", "2"))
+        for f in sorted(os.listdir(VDIR)) * reps:
             if not f.endswith(".so"):
                 continue
             shutil.copy(os.path.join(VDIR, f), main)
