@@ -535,11 +535,19 @@ namespace rir
 		// returning in order among themselves: with the loads of frames f+1 and f+2 behind it, frame f
 		// has landed once at most 2 vector-memory operations are outstanding.  (A tighter count that
 		// also relied on the position of the stores raced at full size.)
+		// Frames are loaded strictly in order (0,1,2,3 up front, then frame f+3 at step f), so the address is a
+		// running wave-uniform pointer (2 scalar adds per load instead of a 64-bit multiply chain); past the end
+		// of the chunk it stays on the last frame.
+		const uint16_t *next_ptr = tile0;
+		int next_f = 0;
 		auto load = [&](int f, v4u32 &dst) {
 			if (FAST)
 			{
-				const Px8 p = buf_load8(tile0 + (int64_t)min(f, nf - 1) * npx, lane_off);
+				const Px8 p = buf_load8(next_ptr, lane_off);
 				dst.x = p.d[0], dst.y = p.d[1], dst.z = p.d[2], dst.w = p.d[3];
+				const bool more = next_f < nf - 1;
+				next_ptr += more ? npx : 0;
+				next_f += more ? 1 : 0;
 			}
 			else
 			{
@@ -729,40 +737,37 @@ namespace rir
 														const uint64_t *__restrict__ chunk_words, int ntiles, int nchunks, int gop,
 														uint64_t *__restrict__ chunk_off, uint64_t *__restrict__ stream)
 	{
-		__shared__ uint64_t base_s;
 		const int t = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
-		if (tid < 64)
-		{ // first wave: sum of the preceding chunks' lengths
-			uint64_t s = 0;
-			for (int i = tid; i < c; i += 64)
-				s += chunk_words[i];
-#pragma unroll
-			for (int d = 32; d >= 1; d >>= 1)
-				s += (uint64_t)__shfl_xor((long long)s, d, 64);
-			if (tid == 0)
-			{
-				base_s = s;
-				if (t == 0)
-				{
-					chunk_off[c] = s;
-					if (c == nchunks - 1)
-						chunk_off[nchunks] = s + chunk_words[c];
-				}
-			}
-		}
-		__syncthreads();
+		// every wave derives the chunk's base itself (sum of the preceding chunks' lengths): no LDS, no barrier,
+		// and the loads of the table entries are in flight while the reduction runs
 		const uint32_t *off = tile_off + (int64_t)c * (ntiles + 1);
-		const uint32_t o0 = off[t], n = off[t + 1] - o0;
-		const uint64_t *src = sparse + ((int64_t)c * ntiles + t) * (int64_t)gop * RIRB1_REC_MAX_WORDS;
-		uint64_t *dst = stream + base_s + o0;
-		for (uint32_t i = tid; i < n; i += 256)
+		const uint32_t o0 = off[t], o1 = off[t + 1];
+		uint64_t s = 0;
+		for (int i = tid & 63; i < c; i += 64)
+			s += chunk_words[i];
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1)
+			s += (uint64_t)__shfl_xor((long long)s, d, 64);
+		if (t == 0 && tid == 0)
 		{
-			const uint64_t v = RIR_COMPACT_NT_LOAD ? __builtin_nontemporal_load(src + i) : src[i];
-			if (RIR_COMPACT_NT_STORE)
-				__builtin_nontemporal_store(v, dst + i);
-			else
-				dst[i] = v;
+			chunk_off[c] = s;
+			if (c == nchunks - 1)
+				chunk_off[nchunks] = s + chunk_words[c];
 		}
+		const uint32_t n = o1 - o0;
+		const uint64_t *src = sparse + ((int64_t)c * ntiles + t) * (int64_t)gop * RIRB1_REC_MAX_WORDS;
+		uint64_t *dst = stream + s + o0;
+		uint32_t i = tid;
+		for (; i + 768 < n; i += 1024)
+		{ // four independent 8-byte copies per thread and iteration
+			const uint64_t v0 = RIR_COMPACT_NT_LOAD ? __builtin_nontemporal_load(src + i) : src[i];
+			const uint64_t v1 = RIR_COMPACT_NT_LOAD ? __builtin_nontemporal_load(src + i + 256) : src[i + 256];
+			const uint64_t v2 = RIR_COMPACT_NT_LOAD ? __builtin_nontemporal_load(src + i + 512) : src[i + 512];
+			const uint64_t v3 = RIR_COMPACT_NT_LOAD ? __builtin_nontemporal_load(src + i + 768) : src[i + 768];
+			dst[i] = v0, dst[i + 256] = v1, dst[i + 512] = v2, dst[i + 768] = v3;
+		}
+		for (; i < n; i += 256)
+			dst[i] = RIR_COMPACT_NT_LOAD ? __builtin_nontemporal_load(src + i) : src[i];
 	}
 
 	// ---- decode -----------------------------------------------------------------------------
