@@ -562,6 +562,7 @@ namespace
 		std::vector<AttrMap> frame_attrs;
 		int last_pos = -1;
 		std::vector<unsigned short> last_raw;
+		int last_raw_pos = -1; // frame held by last_raw (fetched on demand after a filtered read)
 		// PCR
 		int64_t pcr_start = 0, pcr_transfer = 0;
 		// RIRB
@@ -569,7 +570,6 @@ namespace
 		std::vector<IndexEntry> index;
 		ChunkCodec cc;
 		int cached_chunk = -1;
-		std::vector<unsigned short> cache; // decoded frames of cached_chunk
 		// read-back filters
 		bool bp_enabled = false;
 		int bp_handle = 0;
@@ -776,11 +776,10 @@ namespace
 											 (uint32_t)min_T, st),
 						"add min"))
 				return false;
+			// the decoded chunk stays in HBM (cc.d_frames): frames are filtered there and only the requested
+			// frame crosses PCIe (IRFileLoader::readImage hands out one frame per call)
 			int err = 0;
-			const size_t fbytes = (size_t)width * height * 2;
-			cache.resize((size_t)width * height * ch.nframes);
-			if (!hip_ok(hipMemcpyAsync(cache.data(), cc.d_frames.ptr, fbytes * ch.nframes, hipMemcpyDeviceToHost, st), "D2H") ||
-				!hip_ok(hipMemcpyAsync(&err, cc.d_err.ptr, sizeof(int), hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(hipStreamSynchronize(st), "sync"))
+			if (!hip_ok(hipMemcpyAsync(&err, cc.d_err.ptr, sizeof(int), hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(hipStreamSynchronize(st), "sync"))
 				return false;
 			if (err)
 			{
@@ -792,13 +791,10 @@ namespace
 			return true;
 		}
 
-		bool read_raw(int pos, unsigned short *out)
+		// Device address of decoded frame `pos` (RIRB files; decodes its chunk when it is not the cached one).
+		const unsigned short *device_frame(int pos)
 		{
-			const size_t npx = (size_t)width * height;
-			if (kind == PCR)
-				return read_at(pcr_start + pcr_transfer * (int64_t)pos, out, npx * 2);
-			// chunk lookup: chunks hold `gop` frames except possibly the last
-			int c = (int)(pos / (int)hd.gop);
+			int c = (int)(pos / (int)hd.gop); // chunks hold `gop` frames except possibly the last
 			if (c >= (int)index.size() || (uint64_t)pos < index[c].first_frame || (uint64_t)pos >= index[c].first_frame + index[c].nframes)
 			{
 				c = -1;
@@ -806,38 +802,77 @@ namespace
 					if ((uint64_t)pos >= index[i].first_frame && (uint64_t)pos < index[i].first_frame + index[i].nframes)
 						c = (int)i;
 				if (c < 0)
-					return false;
+					return nullptr;
 			}
 			if (!decode_chunk(c))
+				return nullptr;
+			return cc.d_frames.as<unsigned short>() + (size_t)(pos - (int)index[c].first_frame) * width * height;
+		}
+
+		// Unfiltered frame `pos` into host memory.
+		bool read_raw(int pos, unsigned short *out)
+		{
+			const size_t npx = (size_t)width * height;
+			if (kind == PCR)
+				return read_at(pcr_start + pcr_transfer * (int64_t)pos, out, npx * 2);
+			const unsigned short *d = device_frame(pos);
+			hipStream_t st = default_stream();
+			return d && hip_ok(hipMemcpyAsync(out, d, npx * 2, hipMemcpyDeviceToHost, st), "D2H") && hip_ok(hipStreamSynchronize(st), "sync");
+		}
+
+		// get_last_image_raw_value: the unfiltered last image is fetched on demand
+		bool ensure_last_raw()
+		{
+			if (last_pos < 0)
 				return false;
-			std::memcpy(out, cache.data() + (size_t)(pos - (int)index[c].first_frame) * npx, npx * 2);
+			if (last_raw_pos == last_pos)
+				return true;
+			if (!read_raw(last_pos, last_raw.data()))
+				return false;
+			last_raw_pos = last_pos;
 			return true;
 		}
 
-		// IRFileLoader::readImage (IRFileLoader.cpp:1148-1247), calibration 0 = digital levels
+		// IRFileLoader::readImage (IRFileLoader.cpp:1148-1247), calibration 0 = digital levels.  Decode, bad-pixel
+		// repair and motion correction all run on the device; one D2H copy hands the finished frame over.
 		bool read_image(int pos, int calibration, unsigned short *pixels)
 		{
 			if (pos < 0 || pos >= count || !pixels)
 				return false;
 			if (calibration != 0)
 				return false; // no calibration plugin is shipped
-			if (!read_raw(pos, pixels))
-				return false;
-			last_pos = pos;
-			std::memcpy(last_raw.data(), pixels, last_raw.size() * 2);
 			const bool do_bp = bp_enabled && bp_handle > 0 && global_attrs.count("Type") == 0;
 			const bool do_motion = motion_enabled && !shifts.empty();
 			if (!do_bp && !do_motion)
+			{
+				if (!read_raw(pos, pixels))
+					return false;
+				last_pos = pos;
+				std::memcpy(last_raw.data(), pixels, last_raw.size() * 2);
+				last_raw_pos = pos;
 				return true;
+			}
 			if (!device_ready() || height <= 3)
 				return false;
 			hipStream_t st = default_stream();
-			const size_t fbytes = (size_t)width * height * 2;
+			const size_t npx = (size_t)width * height, fbytes = npx * 2;
 			if (!cc.d_tmp.reserve(fbytes * 2) || !cc.d_shift.reserve(8))
 				return false;
-			unsigned short *d_a = cc.d_tmp.as<unsigned short>(), *d_b = d_a + (size_t)width * height;
-			if (!hip_ok(hipMemcpyAsync(d_a, pixels, fbytes, hipMemcpyHostToDevice, st), "H2D"))
-				return false;
+			unsigned short *d_a = cc.d_tmp.as<unsigned short>(), *d_b = d_a + npx;
+			if (kind == PCR)
+			{ // raw file: the frame comes from the host
+				if (!read_raw(pos, pixels) || !hip_ok(hipMemcpyAsync(d_a, pixels, fbytes, hipMemcpyHostToDevice, st), "H2D"))
+					return false;
+				std::memcpy(last_raw.data(), pixels, last_raw.size() * 2);
+				last_raw_pos = pos;
+			}
+			else
+			{ // the repair works in place: on a copy, the decoded chunk stays intact for the next calls
+				const unsigned short *d = device_frame(pos);
+				if (!d || !hip_ok(hipMemcpyAsync(d_a, d, fbytes, hipMemcpyDeviceToDevice, st), "D2D"))
+					return false;
+			}
+			last_pos = pos;
 			unsigned short *res = d_a;
 			if (do_bp && rir_remove_bad_pixels_device(bp_handle, d_a, height - 3, 1, st) != 0)
 				return false;
@@ -857,18 +892,24 @@ namespace
 		{
 			if (enable && bp_handle <= 0 && count > 0 && height > 3)
 			{
-				std::vector<unsigned short> first((size_t)width * height);
-				const bool bp_save = bp_enabled, m_save = motion_enabled;
-				bp_enabled = motion_enabled = false;
-				const bool ok = read_image(0, 0, first.data());
-				bp_enabled = bp_save, motion_enabled = m_save;
-				if (!ok || !device_ready())
+				if (!device_ready())
 					return false;
 				hipStream_t st = default_stream();
-				if (!cc.d_tmp.reserve(first.size() * 4) ||
-					!hip_ok(hipMemcpyAsync(cc.d_tmp.ptr, first.data(), first.size() * 2, hipMemcpyHostToDevice, st), "H2D"))
+				const unsigned short *d_first = nullptr;
+				if (kind == PCR)
+				{
+					std::vector<unsigned short> first((size_t)width * height);
+					if (!read_raw(0, first.data()) || !cc.d_tmp.reserve(first.size() * 4) ||
+						!hip_ok(hipMemcpyAsync(cc.d_tmp.ptr, first.data(), first.size() * 2, hipMemcpyHostToDevice, st), "H2D") ||
+						!hip_ok(hipStreamSynchronize(st), "sync"))
+						return false;
+					d_first = cc.d_tmp.as<unsigned short>();
+				}
+				else
+					d_first = device_frame(0); // already in HBM
+				if (!d_first)
 					return false;
-				bp_handle = rir_bad_pixels_create_rows_device(cc.d_tmp.as<unsigned short>(), width, height, height - 3, st);
+				bp_handle = rir_bad_pixels_create_rows_device(d_first, width, height, height - 3, st);
 				if (bp_handle <= 0)
 					return false;
 			}
@@ -1164,7 +1205,7 @@ RIR_EXPORT int get_last_image_raw_value(int cam, int x, int y, unsigned short *v
 		log_error("get_last_image_raw_value: NULL camera");
 		return -1;
 	}
-	if (!value || x < 0 || y < 0 || x >= c->width || y >= c->height || c->last_pos < 0)
+	if (!value || x < 0 || y < 0 || x >= c->width || y >= c->height || !c->ensure_last_raw())
 		return -1;
 	*value = c->last_raw[(size_t)y * c->width + x];
 	return 0;

@@ -189,3 +189,29 @@ def test_truncated_or_foreign_files_are_rejected(tmp_path):
     q.write_bytes(b"\x00\x00\x00\x20ftypisom" + b"\x00" * 5000)  # a real MP4: not ours
     with pytest.raises(RuntimeError):
         rv.open_camera_file(q)
+
+
+def test_filtered_reads_leave_the_device_chunk_intact(tmp_path, oracle):
+    """The decoded chunk stays in HBM and the read-back filters work on a copy: reads with filters on,
+    then off, then random access across chunks return the right frames; get_last_image_raw_value answers
+    with the UNfiltered last image (IRFileLoader.cpp:1190-1192 keeps the raw copy)."""
+    h, w, n = 40, 96, 23
+    arr = inject_bad_pixels(images(n, h, w), 7)
+    dst = tmp_path / "chunks.h264"
+    with IRSaver(dst, w, h, h) as s:
+        s.set_parameter("GOP", 5)  # 5 chunks
+        for i in range(n):
+            s.add_image(arr[i], i * 1000)
+    cam = rv.open_camera_file(dst)
+    xy = oracle.bad_pixels_detect(arr[0][: h - 3])
+    assert len(xy) > 0
+    rv.enable_bad_pixels(cam, True)
+    for i in (0, 1, 22, 7, 6, 13):
+        assert np.array_equal(rv.load_image(cam, i), oracle.remove_bad_pixels(arr[i], xy, rows=h - 3)), i
+        x, y = int(xy[0][0]), int(xy[0][1])
+        assert rv.get_last_image_raw_value(cam, x, y) == arr[i, y, x]
+    rv.enable_bad_pixels(cam, False)
+    for i in (6, 7, 0, 22):
+        assert np.array_equal(rv.load_image(cam, i), arr[i]), i
+        assert rv.get_last_image_raw_value(cam, 5, 4) == arr[i, 4, 5]
+    rv.close_camera(cam)
