@@ -37,3 +37,37 @@ def inject_bad_pixels(frames, count=200, seed=7):
     out = frames.copy()
     out[:, xy[:, 1], xy[:, 0]] = vals[None, :]
     return out
+
+
+def _fill_polygon(h, w, poly, value):
+    """Even-odd scan-line fill of a polygon given as [[x, y], ...] (pixel centres)."""
+    img = np.zeros((h, w), dtype=np.float64)
+    pts = np.asarray(poly, dtype=np.float64)
+    xs, ys = pts[:, 0], pts[:, 1]
+    xx = np.arange(w)[None, :]
+    for y in range(h):
+        inside = np.zeros((1, w), dtype=bool)
+        for i in range(len(pts)):
+            j = (i + 1) % len(pts)
+            if (ys[i] > y) != (ys[j] > y):
+                xc = xs[i] + (y - ys[i]) * (xs[j] - xs[i]) / (ys[j] - ys[i])
+                inside ^= xx < xc
+        img[y, inside[0]] = value
+    return img
+
+
+def s3_registration(n, h=512, w=640, seed=99):
+    """Registration stream (reference tests/python/test_registration.py:20-59 made deterministic): a polygon of
+    value 10 on a flat background, frame i shifted by (i, i) pixels (edge-replicated), plus the level 10 + i
+    and N(0,1) noise.  Returns (float32 frames, int shifts (n,2) as (dx, dy))."""
+    rng = np.random.default_rng(seed)
+    poly = _fill_polygon(h, w, [[42, 42], [100, 42], [200, 200], [80, 300]], 10.0)
+    out = np.empty((n, h, w), dtype=np.float32)
+    shifts = np.empty((n, 2), dtype=np.int32)
+    yy, xx = np.arange(h)[:, None], np.arange(w)[None, :]
+    for i in range(n):
+        d = i % 100
+        src = poly[np.clip(yy - d, 0, h - 1), np.clip(xx - d, 0, w - 1)]
+        out[i] = (src + 10 + d + rng.normal(0, 1, (h, w))).astype(np.float32)
+        shifts[i] = (d, d)
+    return out, shifts

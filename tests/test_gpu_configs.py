@@ -1,0 +1,121 @@
+"""GPU: the BASELINE.json configurations as parity cases (configs[1] is also the bench line).
+
+ configs[0]  one 640x512 frame through the per-frame ctypes ABI
+ configs[2]  bad_pixels + gaussian_filter + translate before encode (200 injected bad pixels,
+             sigma 0.75, (dx,dy) = (1.25,-2.5), "nearest"), chain checked stage by stage against the oracle
+ configs[3]  1024x768 stream sharded over ranks at chunk boundaries: shards encode independently to the very
+             bytes the whole stream gives, and re-assembling the decoded shards is the identity
+ configs[4]  float32 stream, motion correction with the known shifts, then bounded-loss recording
+"""
+import numpy as np
+import pytest
+import torch
+
+from librir_amd import device as D
+from librir_amd.distributed import shard_plan
+from librir_amd.synthetic import inject_bad_pixels, s1_noisy_background, s3_registration
+from librir_amd.video_io import IRMovie, IRSaver
+from librir_amd.video_io import rir_video_io as rv
+from oracle.pyoracle import OracleLossy
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config0_single_frame_roundtrip_through_ctypes(tmp_path):
+    img = s1_noisy_background(1, 512, 640)[0]
+    dst = tmp_path / "one.h264"
+    s = rv.h264_open_file(dst, 640, 512)
+    rv.h264_add_image_lossless(s, img, 123456789)
+    rv.h264_close_file(s)
+    cam = rv.open_camera_file(dst)
+    assert rv.get_image_count(cam) == 1 and rv.get_image_size(cam) == (512, 640)
+    assert np.array_equal(rv.load_image(cam, 0), img) and rv.get_image_time(cam, 0) == 123456789
+    rv.close_camera(cam)
+
+
+def test_config2_filter_chain_then_encode(dev, oracle):
+    n, h, w = 6, 512, 640
+    arr = inject_bad_pixels(s1_noisy_background(n, h, w), 200)
+    t16 = torch.from_numpy(arr).to("cuda")
+    # stage 1: bad pixels (detector on the first image, correction of every image)
+    bp = D.BadPixels(t16[0])
+    xy = oracle.bad_pixels_detect(arr[0])
+    _, fc = oracle.bad_pixels_stats(arr[0])
+    assert np.array_equal(bp.positions(), xy) and bp.floor_correct == fc
+    c_gpu = bp.correct(t16)
+    c_ref = np.stack([oracle.bad_pixels_correct(arr[i], xy, fc) for i in range(n)])
+    assert np.array_equal(c_gpu.cpu().numpy(), c_ref)
+    # stage 2: gaussian on float32 (north_star tolerance 1e-5 relative; this build is bit-exact)
+    g_gpu = D.gaussian_filter(c_gpu.to(torch.float32), 0.75)
+    g_ref = np.stack([oracle.gaussian_filter(c_ref[i].astype(np.float32), 0.75) for i in range(n)])
+    np.testing.assert_allclose(g_gpu.cpu().numpy(), g_ref, rtol=1e-5, atol=0)
+    # stage 3: translate
+    t_gpu = D.translate(g_gpu, (1.25, -2.5), "nearest")
+    t_ref = np.stack([oracle.translate(g_gpu[i].cpu().numpy(), 1.25, -2.5, "nearest") for i in range(n)])
+    np.testing.assert_allclose(t_gpu.cpu().numpy(), t_ref, rtol=1e-5, atol=0)
+    # stage 4: lossless encode of the filtered stream, bit-exact round trip and stream == oracle
+    u16 = t_gpu.to(torch.uint16)
+    ctx = D.CodecContext(w, h, n, 50, device="cuda")
+    enc = ctx.encode(u16)
+    dec = ctx.decode(enc)
+    assert torch.equal(dec.view(torch.int16), u16.view(torch.int16))
+    h_o, o_o, st_o = oracle.codec_encode_chunk(u16.cpu().numpy())
+    coff = enc.chunk_off.cpu().numpy()
+    assert np.array_equal(enc.hdr.cpu().numpy().view(np.uint64)[0][:, :n], h_o)
+    assert np.array_equal(enc.stream.cpu().numpy().view(np.uint64)[coff[0]:coff[1]], st_o)
+
+
+def test_config3_shards_are_independent_and_reassemble(dev):
+    h, w, gop, n, world = 768, 1024, 50, 400, 8
+    arr = s1_noisy_background(n, h, w, seed=5)
+    whole = torch.from_numpy(arr).to("cuda")
+    ctx = D.CodecContext(w, h, n, gop, device="cuda")
+    enc = ctx.encode(whole)
+    coff = enc.chunk_off.cpu().numpy()
+    stream = enc.stream.cpu().numpy().view(np.uint64)
+    hdr = enc.hdr.cpu().numpy().view(np.uint64)
+    out = torch.empty_like(whole)
+    plan = shard_plan(n, gop, world)
+    assert sum(c for _, c in plan) == n
+    for f0, cnt in plan:
+        f1 = f0 + cnt
+        if cnt == 0:
+            continue
+        assert f0 % gop == 0
+        sctx = D.CodecContext(w, h, f1 - f0, gop, device="cuda")
+        senc = sctx.encode(whole[f0:f1])
+        c0, c1 = f0 // gop, (f1 + gop - 1) // gop
+        scoff = senc.chunk_off.cpu().numpy()
+        # the shard's stream is byte-identical to that run of chunks in the whole-stream encode
+        assert np.array_equal(senc.stream.cpu().numpy().view(np.uint64)[: scoff[-1]], stream[coff[c0]:coff[c1]])
+        assert np.array_equal(senc.hdr.cpu().numpy().view(np.uint64), hdr[c0:c1])
+        out[f0:f1] = sctx.decode(senc)
+    assert torch.equal(out.view(torch.int16), whole.view(torch.int16))
+
+
+def test_config4_motion_correction_then_bounded_loss(tmp_path, dev, oracle):
+    n, h, w = 45, 128, 160
+    f32, shifts = s3_registration(n, h, w)
+    # float32 stream -> digital levels (truncation, like the wrapper's astype(np.uint16))
+    u16 = np.clip(f32, 0, 65535).astype(np.uint16)
+    sh = shifts.astype(np.float32)
+    reg_gpu = D.remove_motion(torch.from_numpy(u16).to("cuda"), torch.from_numpy(sh).to("cuda"), rows=h - 3).cpu().numpy()
+    reg_ref = np.stack([oracle.remove_motion(u16[i], float(sh[i, 0]), float(sh[i, 1]), rows=h - 3) for i in range(n)])
+    assert np.array_equal(reg_gpu, reg_ref)
+    # after the correction the polygon stands still: the first frames, where the shifted-in border is small, agree
+    poly0, poly5 = reg_ref[0][50:100, 60:90].astype(int) - 10, reg_ref[5][50:100, 60:90].astype(int) - 15
+    assert abs(np.median(poly0 - poly5)) <= 1
+    # bounded-loss recording with the reference test's parameters (tests/python/test_video_io.py:112-116)
+    L = OracleLossy(oracle, w, h, h - 3, low_err=3, high_err=3, std_factor=0.0, running_average=32)
+    exp = np.stack([L.step(reg_ref[i]) for i in range(n)])
+    dst = tmp_path / "cfg4.h264"
+    with IRSaver(dst, w, h, h - 3) as s:
+        s.set_parameter("lowValueError", 3)
+        s.set_parameter("highValueError", 3)
+        s.set_parameter("stdFactor", 0)
+        for i in range(n):
+            s.add_image_lossy(reg_gpu[i], i * 1000)
+    with IRMovie.from_filename(dst) as mov:
+        got = mov.data
+    assert np.array_equal(got, exp)
+    assert np.abs(got.astype(np.int32) - reg_ref).max() <= 6
