@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""The BASELINE.json configurations, three numbers each:
+  (i)   device-resident kernel fps (frames already in HBM),
+  (ii)  batched host -> device -> host fps (pinned host memory, PCIe inclusive),
+  (iii) per-frame C-ABI fps (host pointers, one frame per call, as the librir wrapper drives it),
+next to the CPU path on the host cores (the compiled reference oracle/_ref for the filters, the oracle
+port for the codec; single thread, like the reference's own execution).  One JSON document on stdout.
+
+    python scripts/bench_configs.py [--quick]
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from librir_amd import device as D  # noqa: E402
+from librir_amd.signal_processing import rir_signal_processing as sp  # noqa: E402
+from librir_amd.synthetic import inject_bad_pixels, s1_noisy_background, s3_registration  # noqa: E402
+from librir_amd.video_io import IRMovie, IRSaver  # noqa: E402
+from oracle.pyoracle import Oracle, OracleLossy, Ref  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--quick", action="store_true")
+args = ap.parse_args()
+O = Oracle()
+R = Ref() if Ref.available() else None
+dev = torch.device("cuda")
+out = {"host_cores": os.cpu_count(), "gpu": torch.cuda.get_device_name(0), "cpu_reference_built": R is not None}
+
+
+def gpu_ms(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def cpu_fps(fn, nframes, budget=6.0):
+    t0 = time.perf_counter()
+    done = 0
+    while True:
+        fn()
+        done += nframes
+        if time.perf_counter() - t0 > budget:
+            break
+    return done / (time.perf_counter() - t0)
+
+
+# ------------------------------------------------------------------ configs[1]: lossless codec, 640x512
+n, h, w, gop = (200 if args.quick else 1000), 512, 640, 50
+fr = s1_noisy_background(n, h, w)
+t = torch.from_numpy(fr).to(dev)
+ctx = D.CodecContext(w, h, n, gop, device=dev)
+dec = torch.empty_like(t)
+
+
+def dev_roundtrip():
+    ctx.decode(ctx.encode(t), out=dec, check=False)
+
+
+ms = gpu_ms(dev_roundtrip, 10)
+assert torch.equal(dec.view(torch.int16), t.view(torch.int16))
+c1 = {"workload": "%d x %dx%d u16, S1, GOP %d, encode+decode" % (n, w, h, gop), "device_resident_fps": n / ms * 1e3}
+pin_in = torch.from_numpy(fr).pin_memory()
+pin_out = torch.empty_like(pin_in)
+enc0 = ctx.encode(t)
+words = int(enc0.total_words())
+pin_stream = torch.empty((words,), dtype=torch.int64).pin_memory()
+
+
+def batched_roundtrip():
+    t.copy_(pin_in, non_blocking=True)
+    enc = ctx.encode(t)
+    nw = int(enc.total_words())  # sync: the host needs the size to fetch the stream
+    pin_stream[:nw].copy_(enc.stream.view(torch.int64)[:nw], non_blocking=True)
+    enc.stream.view(torch.int64)[:nw].copy_(pin_stream[:nw], non_blocking=True)  # the stream comes back from the host
+    ctx.decode(enc, out=dec, check=False)
+    pin_out.copy_(dec, non_blocking=True)
+
+
+ms = gpu_ms(batched_roundtrip, 5)
+assert np.array_equal(pin_out.numpy(), fr)
+c1["batched_h2d_d2h_fps"] = n / ms * 1e3
+nabi = 100 if args.quick else 300
+with tempfile.TemporaryDirectory() as d:
+    dst = os.path.join(d, "abi.h264")
+    t0 = time.perf_counter()
+    with IRSaver(dst, w, h, h) as s:
+        for i in range(nabi):
+            s.add_image(fr[i], i * 1000)
+    te = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    with IRMovie.from_filename(dst) as mov:
+        for i in range(nabi):
+            img = mov[i]
+    td = time.perf_counter() - t0
+    assert np.array_equal(img, fr[nabi - 1])
+    c1["per_frame_abi_fps"] = nabi / (te + td)
+    c1["per_frame_abi_detail"] = {"record_fps": nabi / te, "read_fps": nabi / td, "file_ratio": fr[:nabi].nbytes / os.path.getsize(dst)}
+ncpu = 100
+
+
+def cpu_codec():
+    for c in range(0, ncpu, gop):
+        hd, of, st = O.codec_encode_chunk(fr[c:c + gop])
+        O.codec_decode_chunk(hd, of, st, w, h)
+
+
+c1["cpu_port_fps_1thread"] = cpu_fps(cpu_codec, ncpu)
+out["configs[1]"] = c1
+
+# ------------------------------------------------------------------ configs[2]: filters before encode
+n2 = 64 if args.quick else 256
+fr2 = inject_bad_pixels(s1_noisy_background(n2, h, w), 200)
+t2 = torch.from_numpy(fr2).to(dev)
+bp = D.BadPixels(t2[0])
+ctx2 = D.CodecContext(w, h, n2, gop, device=dev)
+offs = torch.tensor([1.25, -2.5], dtype=torch.float32, device=dev)
+
+
+def chain(x):
+    a = bp.correct(x)
+    g = D.gaussian_filter(a.to(torch.float32), 0.75)
+    tr = D.translate(g, offs, "nearest")
+    return ctx2.encode(tr.to(torch.uint16))
+
+
+ms = gpu_ms(lambda: chain(t2), 5)
+c2 = {"workload": "%d x %dx%d u16, S1 + 200 bad pixels: bad_pixels_correct -> gaussian(0.75) -> translate(1.25,-2.5,nearest) -> encode (unfused kernels)" % (n2, w, h),
+      "device_resident_fps": n2 / ms * 1e3}
+pin2 = torch.from_numpy(fr2).pin_memory()
+
+
+def batched_chain():
+    t2.copy_(pin2, non_blocking=True)
+    enc = chain(t2)
+    nw = int(enc.total_words())
+    pin_stream[:nw].copy_(enc.stream.view(torch.int64)[:nw], non_blocking=True)
+
+
+ms = gpu_ms(batched_chain, 5)
+c2["batched_h2d_d2h_fps"] = n2 / ms * 1e3
+nabi2 = 20 if args.quick else 60
+with tempfile.TemporaryDirectory() as d:
+    dst = os.path.join(d, "abi2.h264")
+    hbp = sp.bad_pixels_create(fr2[0])
+    t0 = time.perf_counter()
+    with IRSaver(dst, w, h, h) as s:
+        for i in range(nabi2):
+            a = sp.bad_pixels_correct(hbp, fr2[i])
+            g = sp.gaussian_filter(a.astype(np.float32), 0.75)
+            tr = sp.translate(g, 1.25, -2.5, "nearest")
+            s.add_image(tr.astype(np.uint16), i * 1000)
+    c2["per_frame_abi_fps"] = nabi2 / (time.perf_counter() - t0)
+    sp.bad_pixels_destroy(hbp)
+if R is not None:
+    import ctypes as ct
+
+    first = np.ascontiguousarray(fr2[0])
+    rbp = R.lib.ref_bad_pixels_new(first.ctypes.data, w, h)
+    tmp = np.zeros_like(first)
+
+    def cpu_chain():
+        for i in range(4):
+            img = np.ascontiguousarray(fr2[i])
+            R.lib.ref_bad_pixels_correct(rbp, img.ctypes.data, tmp.ctypes.data)
+            g = R.gaussian_filter(tmp.astype(np.float32), 0.75)
+            R.translate(g, 1.25, -2.5, "nearest")
+
+    c2["cpu_reference_filters_fps_1thread"] = cpu_fps(cpu_chain, 4)
+    R.lib.ref_bad_pixels_delete(ct.c_void_p(rbp))
+out["configs[2]"] = c2
+
+# ------------------------------------------------------------------ configs[3]: 1024x768, one rank's shard of the 8-GPU job
+n3, h3, w3 = (100 if args.quick else 1250), 768, 1024
+base = s1_noisy_background(250 if not args.quick else n3, h3, w3, seed=77)
+t3 = torch.from_numpy(base).to(dev)
+if n3 > base.shape[0]:
+    t3 = t3.repeat((n3 + base.shape[0] - 1) // base.shape[0], 1, 1)[:n3].contiguous()  # 250 distinct frames tiled
+ctx3 = D.CodecContext(w3, h3, n3, gop, device=dev)
+dec3 = torch.empty_like(t3)
+ms = gpu_ms(lambda: ctx3.decode(ctx3.encode(t3), out=dec3, check=False), 5)
+assert torch.equal(dec3.view(torch.int16), t3.view(torch.int16))
+out["configs[3]"] = {"workload": "per-GPU shard of the 10 000-frame job: %d x %dx%d u16 (250 distinct S1 frames tiled), encode+decode" % (n3, w3, h3),
+                     "device_resident_fps": n3 / ms * 1e3, "raw_GBs": n3 * 4.0 * h3 * w3 / ms / 1e6,
+                     "note": "all-gather of the decoded stream is timed by bench.py --gpus N (allgather_decoded_stream)"}
+del t3, dec3, ctx3
+torch.cuda.empty_cache()
+
+# ------------------------------------------------------------------ configs[4]: float32 stream, motion correction + bounded loss
+n4 = 60 if args.quick else 300
+f32, shifts = s3_registration(n4, h, w)
+u16 = np.clip(f32, 0, 65535).astype(np.uint16)
+t4 = torch.from_numpy(u16).to(dev)
+sh = torch.from_numpy(shifts.astype(np.float32)).to(dev)
+ms = gpu_ms(lambda: D.remove_motion(t4, sh, rows=h - 3), 5)
+c4 = {"workload": "%d x %dx%d float32 S3 (known shifts): motion correction, then bounded-loss recording (low=high=3, stdFactor 0)" % (n4, w, h),
+      "motion_correction_device_resident_fps": n4 / ms * 1e3}
+reg = D.remove_motion(t4, sh, rows=h - 3).cpu().numpy()
+with tempfile.TemporaryDirectory() as d:
+    dst = os.path.join(d, "lossy.h264")
+    t0 = time.perf_counter()
+    with IRSaver(dst, w, h, h - 3) as s:
+        s.set_parameter("lowValueError", 3)
+        s.set_parameter("highValueError", 3)
+        s.set_parameter("stdFactor", 0)
+        for i in range(n4):
+            s.add_image_lossy(reg[i], i * 1000)
+    c4["lossy_record_per_frame_abi_fps"] = n4 / (time.perf_counter() - t0)
+    c4["lossy_file_ratio"] = reg.nbytes / os.path.getsize(dst)
+    dst2 = os.path.join(d, "lossless.h264")
+    with IRSaver(dst2, w, h, h) as s:
+        for i in range(n4):
+            s.add_image(reg[i], i * 1000)
+    c4["lossless_file_ratio_same_frames"] = reg.nbytes / os.path.getsize(dst2)
+L = OracleLossy(O, w, h, h - 3, low_err=3, high_err=3, std_factor=0.0, running_average=32)
+c4["cpu_port_lossy_step_fps_1thread"] = cpu_fps(lambda: [L.step(reg[i]) for i in range(10)], 10, budget=4.0)
+out["configs[4]"] = c4
+print(json.dumps(out, indent=1))
