@@ -96,6 +96,17 @@ extern "C"
 	/* 3x3 median filter: reference Filters.h:71-129 (template without C export upstream). */
 	int rir_median_filter_device(const unsigned short *d_src, unsigned short *d_dst, int w, int h, int nframes, void *stream);
 
+	/* ---- registration ---------------------------------------------------------------------------
+	 * Translation-only ECC alignment, the arithmetic the reference obtains from OpenCV:
+	 * cv2.findTransformECC(templ, image, warp, MOTION_TRANSLATION, (EPS|COUNT, max_iterations, eps), mask, 1)
+	 * at src/python/librir/registration/masked_registration_ecc.py:166-168.  warp is a HOST float[2] = (tx, ty),
+	 * start value in, result out: image(x + tx, y + ty) ~ templ(x, y).  *cc = correlation coefficient.
+	 * Returns -1 where OpenCV raises (no overlap / no convergence). */
+	int rir_ecc_translation_device(const float *d_templ, const float *d_image, const unsigned char *d_mask, int w, int h, float *warp,
+								   int max_iterations, double eps, double *cc, int *iterations, void *stream);
+	int find_transform_ecc_translation(const float *templ, const float *image, const unsigned char *mask, int w, int h, float *warp,
+									   int max_iterations, double eps, double *cc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,30 @@
+// Translation-only ECC image alignment on the device (ecc_kernels.hip).  Internal, C++ linkage.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rir
+{
+	enum
+	{
+		ECC_NSUMS = 15,
+		ECC_BLOCK = 256
+	};
+	// Lives in device memory; one per alignment in flight.
+	struct EccState
+	{
+		float tx, ty;		   // current translation (map = [1 0 tx; 0 1 ty], applied as src = dst + t)
+		double rho, last_rho;  // correlation coefficient of this / the previous iteration
+		int iter;			   // iterations done
+		int done;			   // 1 = converged or iteration limit, 2 = failed (empty overlap / lambda_d <= 0 / NaN)
+		unsigned int ticket;   // blocks finished in the current iteration
+		int max_iter;
+		double eps;
+	};
+	size_t ecc_workspace_bytes(int w, int h);
+	hipError_t launch_ecc_prepare(const float *d_image, int w, int h, float *d_gx, float *d_gy, EccState *d_state, float tx, float ty, int max_iter,
+								  double eps, hipStream_t st);
+	// one iteration (no-op once d_state->done != 0)
+	hipError_t launch_ecc_iterate(const float *d_templ, const float *d_image, const float *d_gx, const float *d_gy, const uint8_t *d_mask, int w,
+								  int h, double *d_partials, EccState *d_state, hipStream_t st);
+} // namespace rir

@@ -1,0 +1,197 @@
+// Translation-only ECC alignment (enhanced correlation coefficient maximisation) — gfx950 kernels.
+//
+// Replaces, for the registration step of the path, the call the reference makes into OpenCV:
+// cv2.findTransformECC(template, image, start_mat, MOTION_TRANSLATION, (EPS|COUNT, 500, 1e-3), mask, 1)
+// at reference src/python/librir/registration/masked_registration_ecc.py:166-168.  OpenCV is a third-party
+// dependency that is not under /root/reference (constraint opencv-python >= 4.11, pyproject.toml.in:21); what
+// is implemented here is the published algorithm (Evangelidis & Psarakis, "Parametric image alignment using
+// enhanced correlation coefficient maximization", PAMI 2008, forward additive scheme) in the arrangement of
+// its well-known implementation: gradients of the input image by the central difference [-1/2 0 1/2] with
+// reflected borders, image and gradients sampled at x + t by bilinear interpolation (zero outside), a
+// validity mask sampled at the nearest pixel, zero-mean correlation under that mask, 2x2 normal equations.
+// The arithmetic is HBM/L2-bound reductions (15 sums per iteration), not a GEMM: no MFMA.
+//
+// One launch per iteration; blocks write their partial sums, the last block to finish adds them in a fixed
+// order (deterministic), solves the 2x2 system and updates the state in device memory, so iterations queue
+// back to back without a host round trip.
+#include "ecc_kernels.h"
+
+namespace rir
+{
+	size_t ecc_workspace_bytes(int w, int h)
+	{
+		const size_t blocks = ((size_t)w * h + ECC_BLOCK - 1) / ECC_BLOCK;
+		return blocks * ECC_NSUMS * sizeof(double);
+	}
+
+	// central difference with reflect-101 borders: g(0) = g(n-1) = 0
+	__global__ __launch_bounds__(256) void ecc_gradient_kernel(const float *__restrict__ img, int w, int h, float *__restrict__ gx,
+															  float *__restrict__ gy)
+	{
+		const int i = blockIdx.x * 256 + threadIdx.x;
+		if (i >= w * h)
+			return;
+		const int y = i / w, x = i - y * w;
+		const int xl = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xr = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
+		const int yu = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yd = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
+		gx[i] = 0.5f * img[y * w + xr] - 0.5f * img[y * w + xl];
+		gy[i] = 0.5f * img[yd * w + x] - 0.5f * img[yu * w + x];
+	}
+
+	__global__ void ecc_init_kernel(EccState *s, float tx, float ty, int max_iter, double eps)
+	{
+		s->tx = tx, s->ty = ty;
+		s->rho = -1.0, s->last_rho = -eps;
+		s->iter = 0, s->done = 0, s->ticket = 0;
+		s->max_iter = max_iter, s->eps = eps;
+	}
+
+	__device__ __forceinline__ float bilinear0(const float *__restrict__ p, int w, int h, int x0, int y0, float fx, float fy)
+	{
+		// zero outside the image (constant border)
+		const bool xa = x0 >= 0 && x0 < w, xb = x0 + 1 >= 0 && x0 + 1 < w, ya = y0 >= 0 && y0 < h, yb = y0 + 1 >= 0 && y0 + 1 < h;
+		const float v00 = (xa && ya) ? p[y0 * w + x0] : 0.f, v01 = (xb && ya) ? p[y0 * w + x0 + 1] : 0.f;
+		const float v10 = (xa && yb) ? p[(y0 + 1) * w + x0] : 0.f, v11 = (xb && yb) ? p[(y0 + 1) * w + x0 + 1] : 0.f;
+		const float top = v00 + fx * (v01 - v00), bot = v10 + fx * (v11 - v10);
+		return top + fy * (bot - top);
+	}
+
+	__global__ __launch_bounds__(ECC_BLOCK) void ecc_iterate_kernel(const float *__restrict__ templ, const float *__restrict__ image,
+																	const float *__restrict__ gximg, const float *__restrict__ gyimg,
+																	const uint8_t *__restrict__ mask, int w, int h, double *__restrict__ partials,
+																	EccState *__restrict__ state)
+	{
+		if (state->done)
+			return;
+		__shared__ double red[ECC_BLOCK / 64][ECC_NSUMS];
+		__shared__ bool last;
+		const float tx = state->tx, ty = state->ty;
+		const int i = blockIdx.x * ECC_BLOCK + threadIdx.x;
+		double s[ECC_NSUMS];
+#pragma unroll
+		for (int k = 0; k < ECC_NSUMS; ++k)
+			s[k] = 0.0;
+		if (i < w * h)
+		{
+			const int y = i / w, x = i - y * w;
+			const float sx = (float)x + tx, sy = (float)y + ty;
+			// validity: the nearest source pixel lies inside the image and inside the caller's mask
+			const int nx = (int)rintf(sx), ny = (int)rintf(sy);
+			bool valid = nx >= 0 && nx < w && ny >= 0 && ny < h;
+			if (valid && mask)
+				valid = mask[ny * w + nx] != 0;
+			if (valid)
+			{
+				const float flx = floorf(sx), fly = floorf(sy);
+				const int x0 = (int)flx, y0 = (int)fly;
+				const float fx = sx - flx, fy = sy - fly;
+				const double I = bilinear0(image, w, h, x0, y0, fx, fy);
+				const double gx = bilinear0(gximg, w, h, x0, y0, fx, fy);
+				const double gy = bilinear0(gyimg, w, h, x0, y0, fx, fy);
+				const double T = templ[i];
+				s[0] = 1.0, s[1] = I, s[2] = I * I, s[3] = T, s[4] = T * T, s[5] = T * I;
+				s[6] = gx, s[7] = gy, s[8] = gx * gx, s[9] = gx * gy, s[10] = gy * gy;
+				s[11] = gx * I, s[12] = gy * I, s[13] = gx * T, s[14] = gy * T;
+			}
+		}
+		// wave reduction (fixed butterfly), then the four waves of the block in order
+#pragma unroll
+		for (int k = 0; k < ECC_NSUMS; ++k)
+		{
+			double v = s[k];
+#pragma unroll
+			for (int d = 32; d >= 1; d >>= 1)
+				v += __shfl_xor(v, d, 64);
+			if ((threadIdx.x & 63) == 0)
+				red[threadIdx.x >> 6][k] = v;
+		}
+		__syncthreads();
+		if (threadIdx.x < ECC_NSUMS)
+		{
+			double v = red[0][threadIdx.x];
+			for (int wv = 1; wv < ECC_BLOCK / 64; ++wv)
+				v += red[wv][threadIdx.x];
+			partials[(size_t)blockIdx.x * ECC_NSUMS + threadIdx.x] = v;
+		}
+		__threadfence();
+		__syncthreads();
+		if (threadIdx.x == 0)
+			last = atomicAdd(&state->ticket, 1u) == gridDim.x - 1;
+		__syncthreads();
+		if (!last)
+			return;
+		// ---- last block: total in block order, then the 2x2 solve ----
+		__threadfence();
+		__shared__ double tot[ECC_NSUMS];
+		if (threadIdx.x < ECC_NSUMS)
+		{
+			double v = 0.0;
+			for (unsigned b = 0; b < gridDim.x; ++b)
+				v += __builtin_nontemporal_load(partials + (size_t)b * ECC_NSUMS + threadIdx.x);
+			tot[threadIdx.x] = v;
+		}
+		__syncthreads();
+		if (threadIdx.x != 0)
+			return;
+		state->ticket = 0;
+		const double n = tot[0];
+		int done = 0;
+		double rho = -1.0;
+		if (n < 1.0)
+			done = 2;
+		else
+		{
+			const double mI = tot[1] / n, mT = tot[3] / n;
+			const double imgNorm2 = tot[2] - n * mI * mI, tmpNorm2 = tot[4] - n * mT * mT;
+			const double corr = tot[5] - n * mT * mI;
+			const double h00 = tot[8], h01 = tot[9], h11 = tot[10];
+			const double ip0 = tot[11] - mI * tot[6], ip1 = tot[12] - mI * tot[7];
+			const double tp0 = tot[13] - mT * tot[6], tp1 = tot[14] - mT * tot[7];
+			const double det = h00 * h11 - h01 * h01;
+			rho = corr / (sqrt(imgNorm2) * sqrt(tmpNorm2));
+			if (!(det != 0.0) || isnan(rho))
+				done = 2;
+			else
+			{
+				const double i00 = h11 / det, i01 = -h01 / det, i11 = h00 / det;
+				const double iph0 = i00 * ip0 + i01 * ip1, iph1 = i01 * ip0 + i11 * ip1;
+				const double lambda_n = imgNorm2 - (ip0 * iph0 + ip1 * iph1);
+				const double lambda_d = corr - (tp0 * iph0 + tp1 * iph1);
+				if (lambda_d <= 0.0)
+					done = 2;
+				else
+				{
+					const double lambda = lambda_n / lambda_d;
+					const double e0 = lambda * tp0 - ip0, e1 = lambda * tp1 - ip1;
+					state->tx = (float)((double)state->tx + (i00 * e0 + i01 * e1));
+					state->ty = (float)((double)state->ty + (i01 * e0 + i11 * e1));
+				}
+			}
+		}
+		const double prev = state->rho;
+		state->last_rho = prev;
+		state->rho = rho;
+		const int it = state->iter + 1;
+		state->iter = it;
+		if (!done && (it >= state->max_iter || fabs(rho - prev) < state->eps))
+			done = 1;
+		__threadfence();
+		state->done = done;
+	}
+
+	hipError_t launch_ecc_prepare(const float *d_image, int w, int h, float *d_gx, float *d_gy, EccState *d_state, float tx, float ty, int max_iter,
+								  double eps, hipStream_t st)
+	{
+		hipLaunchKernelGGL(ecc_gradient_kernel, dim3((w * h + 255) / 256), dim3(256), 0, st, d_image, w, h, d_gx, d_gy);
+		hipLaunchKernelGGL(ecc_init_kernel, dim3(1), dim3(1), 0, st, d_state, tx, ty, max_iter, eps);
+		return hipGetLastError();
+	}
+
+	hipError_t launch_ecc_iterate(const float *d_templ, const float *d_image, const float *d_gx, const float *d_gy, const uint8_t *d_mask, int w,
+								  int h, double *d_partials, EccState *d_state, hipStream_t st)
+	{
+		hipLaunchKernelGGL(ecc_iterate_kernel, dim3((w * h + ECC_BLOCK - 1) / ECC_BLOCK), dim3(ECC_BLOCK), 0, st, d_templ, d_image, d_gx, d_gy,
+						   d_mask, w, h, d_partials, d_state);
+		return hipGetLastError();
+	}
+} // namespace rir

@@ -1,0 +1,1 @@
+from .masked_registration_ecc import MaskedRegistratorECC, find_transform_ecc_translation  # noqa: F401

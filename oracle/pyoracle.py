@@ -106,6 +106,23 @@ class Oracle(_SignalProcessingMixin):
         L.orc_gaussian_radius.restype = ct.c_int
         L.orc_clamp_min.argtypes = [ct.c_void_p, ct.c_int, ct.c_uint16]
 
+    # ---- registration ---------------------------------------------------------------------------
+    def ecc_translation(self, templ, image, warp=(0.0, 0.0), mask=None, max_iter=500, eps=1e-3):
+        """-> (tx, ty, cc, iterations); raises RuntimeError where OpenCV would."""
+        t = np.ascontiguousarray(templ, dtype=np.float32)
+        im = np.ascontiguousarray(image, dtype=np.float32)
+        h, w = t.shape
+        wp = np.array(warp, dtype=np.float32)
+        cc, it = ct.c_double(0), ct.c_int(0)
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        self.lib.orc_ecc_translation.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int, ct.c_double,
+                                                 ct.POINTER(ct.c_double), ct.POINTER(ct.c_int)]
+        rc = self.lib.orc_ecc_translation(_p(t), _p(im), None if m is None else _p(m), w, h, _p(wp), int(max_iter), float(eps), ct.byref(cc),
+                                          ct.byref(it))
+        if rc != 0:
+            raise RuntimeError("ECC did not converge")
+        return float(wp[0]), float(wp[1]), cc.value, it.value
+
     # ---- bad pixels -------------------------------------------------------------------------
     def bad_pixels_detect(self, image, std_factor=5.0):
         img = np.ascontiguousarray(image, dtype=np.uint16)

@@ -1060,6 +1060,110 @@ EXPORT int orc_lossy_step(orc_lossy *L, const uint16_t *img, uint16_t *out, int 
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* R1  translation-only ECC alignment.  The reference calls OpenCV here                        */
+/*     (src/python/librir/registration/masked_registration_ecc.py:166-168,                      */
+/*     cv2.findTransformECC, MOTION_TRANSLATION, gaussFiltSize 1); OpenCV is a third-party       */
+/*     dependency that is NOT under /root/reference (opencv-python >= 4.11,                      */
+/*     src/python/pyproject.toml.in:21) and is not installed here.  This is a restatement of the */
+/*     published algorithm (Evangelidis & Psarakis, PAMI 2008, forward additive ECC): central    */
+/*     difference gradients with reflected borders, bilinear sampling at x + t (zero outside),  */
+/*     nearest-pixel validity mask, zero-mean correlation, 2x2 normal equations.  The reference  */
+/*     tests pin no value at this boundary (tests/python/test_registration.py:90-108 has every   */
+/*     assert commented out): PARITY UNPINNED - checked on the reference's synthetic recipe.    */
+/* ------------------------------------------------------------------------------------------ */
+static float ecc_bilinear0(const float *p, int w, int h, int x0, int y0, float fx, float fy)
+{
+	const int xa = x0 >= 0 && x0 < w, xb = x0 + 1 >= 0 && x0 + 1 < w, ya = y0 >= 0 && y0 < h, yb = y0 + 1 >= 0 && y0 + 1 < h;
+	const float v00 = (xa && ya) ? p[y0 * w + x0] : 0.f, v01 = (xb && ya) ? p[y0 * w + x0 + 1] : 0.f;
+	const float v10 = (xa && yb) ? p[(y0 + 1) * w + x0] : 0.f, v11 = (xb && yb) ? p[(y0 + 1) * w + x0 + 1] : 0.f;
+	const float top = v00 + fx * (v01 - v00), bot = v10 + fx * (v11 - v10);
+	return top + fy * (bot - top);
+}
+
+/* warp[2] = (tx, ty) in/out; returns 0 and *cc, or -1 where OpenCV raises. */
+EXPORT int orc_ecc_translation(const float *templ, const float *image, const uint8_t *mask, int w, int h, float *warp, int max_iter, double eps,
+							   double *cc, int *iterations)
+{
+	const int n_px = w * h;
+	float *gx = (float *)malloc((size_t)n_px * 4), *gy = (float *)malloc((size_t)n_px * 4);
+	for (int y = 0; y < h; ++y)
+		for (int x = 0; x < w; ++x)
+		{
+			const int xl = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xr = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
+			const int yu = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yd = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
+			gx[y * w + x] = 0.5f * image[y * w + xr] - 0.5f * image[y * w + xl];
+			gy[y * w + x] = 0.5f * image[yd * w + x] - 0.5f * image[yu * w + x];
+		}
+	float tx = warp[0], ty = warp[1];
+	double rho = -1.0, last_rho = -eps;
+	int it = 0, rc = 0;
+	while (it < max_iter && fabs(rho - last_rho) >= eps)
+	{
+		double s[15];
+		for (int k = 0; k < 15; ++k)
+			s[k] = 0.0;
+		for (int y = 0; y < h; ++y)
+			for (int x = 0; x < w; ++x)
+			{
+				const float sx = (float)x + tx, sy = (float)y + ty;
+				const int nx = (int)rintf(sx), ny = (int)rintf(sy);
+				if (nx < 0 || nx >= w || ny < 0 || ny >= h || (mask && !mask[ny * w + nx]))
+					continue;
+				const float flx = floorf(sx), fly = floorf(sy);
+				const int x0 = (int)flx, y0 = (int)fly;
+				const float fx = sx - flx, fy = sy - fly;
+				const double I = ecc_bilinear0(image, w, h, x0, y0, fx, fy);
+				const double dX = ecc_bilinear0(gx, w, h, x0, y0, fx, fy), dY = ecc_bilinear0(gy, w, h, x0, y0, fx, fy);
+				const double T = templ[y * w + x];
+				s[0] += 1.0, s[1] += I, s[2] += I * I, s[3] += T, s[4] += T * T, s[5] += T * I;
+				s[6] += dX, s[7] += dY, s[8] += dX * dX, s[9] += dX * dY, s[10] += dY * dY;
+				s[11] += dX * I, s[12] += dY * I, s[13] += dX * T, s[14] += dY * T;
+			}
+		++it;
+		last_rho = rho;
+		const double n = s[0];
+		if (n < 1.0)
+		{
+			rc = -1;
+			break;
+		}
+		const double mI = s[1] / n, mT = s[3] / n;
+		const double imgNorm2 = s[2] - n * mI * mI, tmpNorm2 = s[4] - n * mT * mT, corr = s[5] - n * mT * mI;
+		const double h00 = s[8], h01 = s[9], h11 = s[10];
+		const double ip0 = s[11] - mI * s[6], ip1 = s[12] - mI * s[7], tp0 = s[13] - mT * s[6], tp1 = s[14] - mT * s[7];
+		const double det = h00 * h11 - h01 * h01;
+		rho = corr / (sqrt(imgNorm2) * sqrt(tmpNorm2));
+		if (!(det != 0.0) || isnan(rho))
+		{
+			rc = -1;
+			break;
+		}
+		const double i00 = h11 / det, i01 = -h01 / det, i11 = h00 / det;
+		const double iph0 = i00 * ip0 + i01 * ip1, iph1 = i01 * ip0 + i11 * ip1;
+		const double lambda_n = imgNorm2 - (ip0 * iph0 + ip1 * iph1), lambda_d = corr - (tp0 * iph0 + tp1 * iph1);
+		if (lambda_d <= 0.0)
+		{
+			rc = -1;
+			break;
+		}
+		const double lambda = lambda_n / lambda_d;
+		const double e0 = lambda * tp0 - ip0, e1 = lambda * tp1 - ip1;
+		tx = (float)((double)tx + (i00 * e0 + i01 * e1));
+		ty = (float)((double)ty + (i01 * e0 + i11 * e1));
+	}
+	free(gx), free(gy);
+	if (iterations)
+		*iterations = it;
+	if (rc == 0)
+	{
+		warp[0] = tx, warp[1] = ty;
+		if (cc)
+			*cc = rho;
+	}
+	return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* C5  ZFile method 1 equivalent (CPU baseline only): one-shot zstd per raw frame is timed by  */
 /*     bench.py through dlopen("libzstd.so.1"); nothing to restate here (third-party).         */
 /* ------------------------------------------------------------------------------------------ */
