@@ -74,7 +74,7 @@ extern "C"
 	int rir_gaussian_filter_device(const float *d_src, float *d_dst, int w, int h, int nframes, float sigma, void *stream);
 
 	/* find_median_pixel[_mask]: reference signal_processing.h:39-44 / Filters.cpp:56-101.
-	 * d_result: int32[nframes]; d_hist: uint32[nframes*65536] workspace; d_mask may be NULL. */
+	 * d_result: int32[nframes]; d_hist: unused, may be NULL (the counting happens in LDS); d_mask may be NULL. */
 	int rir_find_median_pixel_device(const unsigned short *d_img, const unsigned char *d_mask, int size, int nframes, float percent, int *d_result,
 									 unsigned int *d_hist, void *stream);
 

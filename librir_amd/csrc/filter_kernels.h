@@ -22,6 +22,8 @@ namespace rir
 	hipError_t launch_remove_bad_pixels(uint16_t *img, int w, int h, int rows, int nframes, const int *d_xy, int nbad, const uint8_t *d_bitmap,
 										hipStream_t st);
 	hipError_t launch_histogram(const uint16_t *img, const uint8_t *mask, int64_t npx, int nframes, uint32_t *d_hist, hipStream_t st);
+	hipError_t launch_quantile_select(const uint16_t *img, const uint8_t *mask, int64_t npx, int nframes, float percent, int nbins, int *d_result,
+									  hipStream_t st);
 	hipError_t launch_quantile_scan(const uint32_t *d_hist, uint64_t size, float percent, int masked, int nbins, int nframes, int *d_result,
 									hipStream_t st);
 	hipError_t launch_bad_pixels_stats(const uint32_t *d_hist, uint64_t size, int64_t *d_out, hipStream_t st);

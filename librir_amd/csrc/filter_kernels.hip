@@ -326,89 +326,117 @@ namespace rir
 		}
 	}
 
-	// LDS-tiled version for radius 1..4: a 256-thread workgroup produces a 64 x 16 output tile from a
-	// (64+2R) x (16+2R) input tile staged once in LDS (coalesced row loads, zero outside the image).
-	// Each output keeps the reference's accumulation order (dx outer, dy inner; separate multiply and
-	// add), so results are bit-identical to the direct kernel above; the weights sit in LDS too
-	// (same address for the whole wave = broadcast read).  Lanes of a wave read consecutive floats of
-	// one tile row: no bank conflicts.
+	// Radius 1..4: separable form through LDS.  The reference table is k[dx][dy] = g(dx) g(dy) / sum, i.e. the
+	// outer product of a 1-D factor a[d] (uploaded behind the 2-D table): a row pass and a column pass of
+	// 2R+1 taps each replace the (2R+1)^2-tap sum, which turns the kernel from compute-bound (162 flop per
+	// pixel at R = 4) into a streaming one.  Same mathematics as the reference, different rounding: results
+	// agree to a few 1e-7 relative (the parity bar for float32 filters is 1e-5, BASELINE.json); border pixels
+	// are renormalised by the in-image weight, Sx(x) * Sy(y), as the reference does with its 2-D sum.
+	// A 256-thread workgroup produces a 64 x 32 output tile from a (64+2R) x (32+2R) input tile staged in LDS.
 	template <int R>
-	__global__ __launch_bounds__(256) void gaussian_tile_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
-																const float *__restrict__ kern)
+	__global__ __launch_bounds__(256) void gaussian_sep_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+															   const float *__restrict__ kern)
 	{
-		constexpr int TX = 64, TY = 16, KW = 2 * R + 1, LW = TX + 2 * R, LH = TY + 2 * R;
+		constexpr int TX = 64, TY = 32, KW = 2 * R + 1, LW = TX + 2 * R, LH = TY + 2 * R;
 		__shared__ float tile[LH][LW];
-		__shared__ float kk[KW * KW];
+		__shared__ float rowp[LH][TX];
+		__shared__ float a[KW];
 		const int tid = threadIdx.x;
+		const int tx = tid & 63, ty = tid >> 6;
 		const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
 		const int64_t fbase = (int64_t)blockIdx.z * w * h;
 		const float *s = src + fbase;
-		for (int i = tid; i < LW * LH; i += 256)
+		// stage the input tile: each wave walks rows, lane = column (coalesced 256-byte rows), the first 2R lanes
+		// also fetch the right-hand halo columns
+		for (int ly = ty; ly < LH; ly += 4)
 		{
-			const int ly = i / LW, lx = i - ly * LW;
-			const int gx = x0 - R + lx, gy = y0 - R + ly;
-			tile[ly][lx] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? s[gx + (int64_t)gy * w] : 0.f;
+			const int gy = y0 - R + ly;
+			const bool yin = gy >= 0 && gy < h;
+			const float *row = s + (int64_t)gy * w;
+			const int gx = x0 - R + tx;
+			tile[ly][tx] = (yin && gx >= 0 && gx < w) ? row[gx] : 0.f;
+			if (tx < 2 * R)
+			{
+				const int gx2 = gx + TX;
+				tile[ly][tx + TX] = (yin && gx2 >= 0 && gx2 < w) ? row[gx2] : 0.f;
+			}
 		}
-		if (tid < KW * KW)
-			kk[tid] = kern[tid];
+		if (tid < KW)
+			a[tid] = kern[KW * KW + tid];
 		__syncthreads();
-		const int tx = tid & 63, ty = tid >> 6;
+		// row pass: LH rows x TX columns (zeros outside the image add nothing)
+		for (int ly = ty; ly < LH; ly += 4)
+		{
+			float acc = 0.f;
+#pragma unroll
+			for (int d = 0; d < KW; ++d)
+				acc = fmaf(a[d], tile[ly][tx + d], acc);
+			rowp[ly][tx] = acc;
+		}
+		__syncthreads();
 		const int x = x0 + tx;
 		if (x >= w)
 			return;
+		// in-image weight of the row taps of this column (1 in the interior)
+		float sx = 1.f;
+		const bool xb = x < R || x >= w - R;
+		if (xb)
+		{
+			sx = 0.f;
 #pragma unroll
-		for (int j = 0; j < 4; ++j)
+			for (int d = -R; d <= R; ++d)
+				if (x + d >= 0 && x + d < w)
+					sx += a[d + R];
+		}
+#pragma unroll
+		for (int j = 0; j < TY / 4; ++j)
 		{
 			const int ly = ty + 4 * j, y = y0 + ly;
 			if (y >= h)
 				break;
-			float res = 0;
-			if (x >= R && x < w - R && y >= R && y < h - R)
+			float acc = 0.f;
+#pragma unroll
+			for (int d = 0; d < KW; ++d)
+				acc = fmaf(a[d], rowp[ly + d][tx], acc);
+			const bool yb = y < R || y >= h - R;
+			if (xb || yb)
 			{
+				float sy = 1.f;
+				if (yb)
+				{
+					sy = 0.f;
 #pragma unroll
-				for (int dx = -R; dx <= R; ++dx)
+					for (int d = -R; d <= R; ++d)
+						if (y + d >= 0 && y + d < h)
+							sy += a[d + R];
+				}
+				// interior rows / columns of a border pixel still carry the full 1-D weight sum, which is not exactly 1
+				float full = 0.f;
 #pragma unroll
-					for (int dy = -R; dy <= R; ++dy)
-						res = __fadd_rn(res, __fmul_rn(kk[dx + R + (dy + R) * KW], tile[ly + R + dy][tx + R + dx]));
+				for (int d = 0; d < KW; ++d)
+					full += a[d];
+				acc = acc / ((xb ? sx : full) * (yb ? sy : full));
 			}
-			else
-			{
-				float sum = 0;
-#pragma unroll
-				for (int dx = -R; dx <= R; ++dx)
-#pragma unroll
-					for (int dy = -R; dy <= R; ++dy)
-					{
-						const int _x = x + dx, _y = y + dy;
-						if (_x >= 0 && _x < w && _y >= 0 && _y < h)
-						{
-							const float k = kk[dx + R + (dy + R) * KW];
-							sum = __fadd_rn(sum, k);
-							res = __fadd_rn(res, __fmul_rn(k, tile[ly + R + dy][tx + R + dx]));
-						}
-					}
-				res = __fdiv_rn(res, sum);
-			}
-			dst[fbase + x + (int64_t)y * w] = res;
+			dst[fbase + x + (int64_t)y * w] = acc;
 		}
 	}
 
 	hipError_t launch_gaussian(const float *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st)
 	{
-		dim3 block(256), tgrid((w + 63) / 64, (h + 15) / 16, nframes);
+		dim3 block(256), tgrid((w + 63) / 64, (h + 31) / 32, nframes);
 		switch (radius)
 		{
 		case 1:
-			hipLaunchKernelGGL(gaussian_tile_kernel<1>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			hipLaunchKernelGGL(gaussian_sep_kernel<1>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
 			break;
 		case 2:
-			hipLaunchKernelGGL(gaussian_tile_kernel<2>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			hipLaunchKernelGGL(gaussian_sep_kernel<2>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
 			break;
 		case 3:
-			hipLaunchKernelGGL(gaussian_tile_kernel<3>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			hipLaunchKernelGGL(gaussian_sep_kernel<3>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
 			break;
 		case 4:
-			hipLaunchKernelGGL(gaussian_tile_kernel<4>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			hipLaunchKernelGGL(gaussian_sep_kernel<4>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
 			break;
 		default:
 		{
@@ -667,6 +695,136 @@ namespace rir
 		__syncthreads();
 		if (tid == 0)
 			result[n] = best == 0x7fffffff ? 0 : best;
+	}
+
+	// find_median_pixel[_mask] without a histogram in memory: one 1024-thread workgroup per frame counts the
+	// frame in LDS, one quarter of the value range at a time (16 384 32-bit counters = 64 KiB), carries the
+	// cumulative count from quarter to quarter and stops at the quarter that holds the answer - for 14-bit IR
+	// data that is the first one, i.e. a single pass over the frame.  Pixels are fetched 8 per lane (16 bytes).
+	// Result: first bin b < nbins whose cumulative count >= target, 0 when none (Filters.cpp:56-101), with
+	//   target = (size_t)round((float)size * percent)               (Filters.cpp:63, float product)
+	//   target = (size_t)(int)round((float)population * percent)     (masked, Filters.cpp:92)
+	__device__ __forceinline__ uint32_t block_exclusive_scan_1024(uint32_t v, uint32_t *wave_tot /*[16]*/, uint32_t *total)
+	{
+		const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+		uint32_t inc = v;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1)
+		{
+			const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
+			if (lane >= d)
+				inc += o;
+		}
+		if (lane == 63)
+			wave_tot[wv] = inc;
+		__syncthreads();
+		uint32_t pre = 0, tot = 0;
+#pragma unroll
+		for (int k = 0; k < 16; ++k)
+		{
+			const uint32_t t = wave_tot[k];
+			pre += k < wv ? t : 0u;
+			tot += t;
+		}
+		__syncthreads();
+		*total = tot;
+		return pre + inc - v;
+	}
+
+	__global__ __launch_bounds__(1024) void quantile_select_kernel(const uint16_t *__restrict__ img, const uint8_t *__restrict__ mask, int64_t npx,
+																   float percent, int nbins, int *__restrict__ result)
+	{
+		__shared__ uint32_t cnt[16384];
+		__shared__ uint32_t wave_tot[16];
+		__shared__ int found;
+		const int n = blockIdx.x, tid = threadIdx.x;
+		const uint16_t *f = img + (int64_t)n * npx;
+		const uint8_t *m = mask ? mask + (int64_t)n * npx : nullptr;
+		uint64_t target;
+		if (m)
+		{
+			uint32_t c = 0;
+			for (int64_t i = tid; i < npx; i += 1024)
+				c += m[i] != 0;
+			uint32_t pop;
+			(void)block_exclusive_scan_1024(c, wave_tot, &pop);
+			target = (uint64_t)(int64_t)(int)roundf(__fmul_rn((float)pop, percent));
+		}
+		else
+			target = (uint64_t)roundf(__fmul_rn((float)(uint64_t)npx, percent));
+		const bool vec = !m && ((((uintptr_t)f) & 15) == 0);
+		const int64_t nvec = vec ? (npx >> 3) : 0;
+		uint64_t cum = 0;
+		for (uint32_t q = 0; q < 4; ++q)
+		{
+			for (int i = tid; i < 16384; i += 1024)
+				cnt[i] = 0;
+			if (tid == 0)
+				found = 0x7fffffff;
+			__syncthreads();
+			const uint4 *f4 = reinterpret_cast<const uint4 *>(f);
+			for (int64_t i = tid; i < nvec; i += 1024)
+			{
+				const uint4 v = f4[i];
+				const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+				for (int k = 0; k < 4; ++k)
+				{
+					const uint32_t lo = d[k] & 0xffffu, hi = d[k] >> 16;
+					if ((lo >> 14) == q)
+						atomicAdd(&cnt[lo & 16383u], 1u);
+					if ((hi >> 14) == q)
+						atomicAdd(&cnt[hi & 16383u], 1u);
+				}
+			}
+			for (int64_t i = nvec * 8 + tid; i < npx; i += 1024)
+				if (!m || m[i])
+				{
+					const uint32_t v = f[i];
+					if ((v >> 14) == q)
+						atomicAdd(&cnt[v & 16383u], 1u);
+				}
+			__syncthreads();
+			// 16 consecutive bins per thread
+			uint32_t loc = 0;
+#pragma unroll
+			for (int k = 0; k < 16; ++k)
+				loc += cnt[tid * 16 + k];
+			uint32_t tot;
+			const uint32_t pre = block_exclusive_scan_1024(loc, wave_tot, &tot);
+			uint64_t count = cum + pre;
+			for (int k = 0; k < 16; ++k)
+			{
+				const int b = (int)(q * 16384u) + tid * 16 + k;
+				if (b >= nbins)
+					break;
+				count += cnt[tid * 16 + k];
+				if (count >= target)
+				{
+					atomicMin(&found, b);
+					break;
+				}
+			}
+			__syncthreads();
+			const int fb = found;
+			if (fb != 0x7fffffff)
+			{
+				if (tid == 0)
+					result[n] = fb;
+				return;
+			}
+			cum += tot;
+			__syncthreads();
+		}
+		if (tid == 0)
+			result[n] = 0;
+	}
+
+	hipError_t launch_quantile_select(const uint16_t *img, const uint8_t *mask, int64_t npx, int nframes, float percent, int nbins, int *d_result,
+									  hipStream_t st)
+	{
+		hipLaunchKernelGGL(quantile_select_kernel, dim3(nframes), dim3(1024), 0, st, img, mask, npx, percent, nbins, d_result);
+		return hipGetLastError();
 	}
 
 	hipError_t launch_histogram(const uint16_t *img, const uint8_t *mask, int64_t npx, int nframes, uint32_t *d_hist, hipStream_t st)

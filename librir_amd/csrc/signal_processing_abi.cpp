@@ -106,6 +106,12 @@ namespace
 		if (it != c.tables.end())
 			return it->second->as<float>();
 		std::vector<float> k = gaussian_table(sigma, radius);
+		{ // 1-D factors a[-r..r] of the (separable) table, appended after it: k[dx][dy] ~ a[dx] * a[dy]
+			const int kw = 2 * radius + 1;
+			const double a0 = std::sqrt((double)k[(size_t)radius * kw + radius]);
+			for (int d = 0; d < kw; ++d)
+				k.push_back((float)((double)k[(size_t)radius * kw + d] / a0));
+		}
 		auto buf = std::make_shared<DeviceBuffer>();
 		if (!buf->reserve(k.size() * sizeof(float)))
 			return nullptr;
@@ -253,22 +259,20 @@ RIR_EXPORT int rir_gaussian_filter_device(const float *d_src, float *d_dst, int 
 	return hip_ok(launch_gaussian(d_src, d_dst, w, h, nframes, d_k, radius, as_stream(stream)), "gaussian_filter") ? 0 : -1;
 }
 
-// result: int32[nframes] on the device.  d_hist: uint32[nframes*65536] workspace.
+// result: int32[nframes] on the device.  d_hist: unused (kept in the signature; may be NULL).
 RIR_EXPORT int rir_find_median_pixel_device(const unsigned short *d_img, const unsigned char *d_mask, int size, int nframes, float percent,
 											int *d_result, unsigned int *d_hist, void *stream)
 {
 	if (!device_ready())
 		return -1;
-	if (size <= 0 || nframes <= 0 || !d_img || !d_result || !d_hist)
+	if (size <= 0 || nframes <= 0 || !d_img || !d_result)
 	{
 		log_error("rir_find_median_pixel_device: invalid argument");
 		return -1;
 	}
-	hipStream_t st = as_stream(stream);
-	if (!hip_ok(launch_histogram(d_img, d_mask, size, nframes, d_hist, st), "histogram"))
-		return -1;
+	(void)d_hist; // the counting happens in LDS, one quarter of the value range at a time: no histogram in memory
 	// 65 535 bins, as the reference (Filters.cpp:59)
-	return hip_ok(launch_quantile_scan(d_hist, (uint64_t)size, percent, d_mask ? 1 : 0, 65535, nframes, d_result, st), "quantile") ? 0 : -1;
+	return hip_ok(launch_quantile_select(d_img, d_mask, size, nframes, percent, 65535, d_result, as_stream(stream)), "find_median_pixel") ? 0 : -1;
 }
 
 RIR_EXPORT int rir_bad_pixels_create_device(const unsigned short *d_first_image, int width, int height, void *stream)

@@ -25,8 +25,9 @@ def rec(name, ms, bytes_per_frame):
     res[name] = {"ms": ms, "fps": n / ms * 1e3, "GBs": bytes_per_frame * n / ms / 1e6, "frac_of_8TBs": bytes_per_frame * n / ms / 1e6 / 8000}
     print("%-34s %8.3f ms  %10.0f fps  %7.1f GB/s  %5.1f %% of HBM peak" % (name, ms, res[name]["fps"], res[name]["GBs"], 100 * res[name]["frac_of_8TBs"]))
 offs = torch.tensor([1.25, -2.5], dtype=torch.float32, device="cuda")
-rec("translate u16 nearest", timeit(lambda: D.translate(t16, offs, "nearest")), 4 * WH + 2 * WH)  # + clone prefill
-rec("translate f32 nearest", timeit(lambda: D.translate(f32, offs, "nearest")), 8 * WH + 4 * WH)
+rec("translate u16 nearest", timeit(lambda: D.translate(t16, offs, "nearest")), 4 * WH)
+rec("translate f32 nearest", timeit(lambda: D.translate(f32, offs, "nearest")), 8 * WH)
+rec("translate u16 noborder (+prefill)", timeit(lambda: D.translate(t16, offs, "")), 4 * WH)
 for s in (0.75, 1.0, 2.0):
     rec("gaussian sigma=%g" % s, timeit(lambda: D.gaussian_filter(f32, s)), 8 * WH)
 bp = D.BadPixels(t16[0])

@@ -26,21 +26,25 @@ def build(specs):
     for spec in specs:
         name, flags = spec.split("=", 1)
         obj = os.path.join(VDIR, name + ".o")
-        src = os.path.join(B.CSRC, "codec_kernels.hip")
+        unit = "codec_kernels.hip"
+        src = None
         fl = []
         for f in flags.split():
             if f.startswith("--src="):
                 src = f[6:]  # e.g. an older revision: git show REV:librir_amd/csrc/codec_kernels.hip > /tmp/x.hip
+            elif f.startswith("--unit="):
+                unit = f[7:]  # the translation unit the variant replaces (default codec_kernels.hip)
             else:
                 fl.append(f)
+        src = src or os.path.join(B.CSRC, unit)
         cmd = [B.HIPCC] + B.COMMON + fl + ["-c", src, "-o", obj]
-        procs.append((name, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for name, obj, p in procs:
+        procs.append((name, obj, unit, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for name, obj, unit, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise SystemExit("variant %s failed" % name)
-        objs = [obj if f == "codec_kernels.hip.o" else os.path.join(objdir, f) for f in sorted(os.listdir(objdir)) if f.endswith(".o")]
+        objs = [obj if f == unit + ".o" else os.path.join(objdir, f) for f in sorted(os.listdir(objdir)) if f.endswith(".o")]
         subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(VDIR, name + ".so")] + objs + ["-ldl", "-lpthread"])
         os.remove(obj)
         print("built", name)
@@ -57,8 +61,10 @@ def run(args):
             if not f.endswith(".so"):
                 continue
             shutil.copy(os.path.join(VDIR, f), main)
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "codec_time.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
-            lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith(("encode_tiles", "alone", "FAIL"))]
+            script = os.environ.get("RIR_VARIANT_SCRIPT", "codec_time.py")
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script)] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+            keep_prefix = tuple(os.environ.get("RIR_VARIANT_GREP", "encode_tiles,alone,FAIL").split(","))
+            lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith(keep_prefix)]
             print("== %-24s rc=%d" % (f[:-3], r.returncode))
             for ln in lines:
                 print("   " + ln)

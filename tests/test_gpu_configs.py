@@ -45,7 +45,7 @@ def test_config2_filter_chain_then_encode(dev, oracle):
     c_gpu = bp.correct(t16)
     c_ref = np.stack([oracle.bad_pixels_correct(arr[i], xy, fc) for i in range(n)])
     assert np.array_equal(c_gpu.cpu().numpy(), c_ref)
-    # stage 2: gaussian on float32 (north_star tolerance 1e-5 relative; this build is bit-exact)
+    # stage 2: gaussian on float32 (north_star tolerance: 1e-5 relative)
     g_gpu = D.gaussian_filter(c_gpu.to(torch.float32), 0.75)
     g_ref = np.stack([oracle.gaussian_filter(c_ref[i].astype(np.float32), 0.75) for i in range(n)])
     np.testing.assert_allclose(g_gpu.cpu().numpy(), g_ref, rtol=1e-5, atol=0)

@@ -42,7 +42,7 @@ def test_translate_abi_golden(lib, golden, shape, dtype):
 
 
 @pytest.mark.parametrize("shape", GAUSS_SHAPES)
-def test_gaussian_abi_golden(lib, golden, shape):
+def test_gaussian_abi_golden(lib, golden, oracle, shape):
     from librir_amd.signal_processing import gaussian_filter
 
     h, w = shape
@@ -51,11 +51,15 @@ def test_gaussian_abi_golden(lib, golden, shape):
         out = gaussian_filter(img, s)
         arrays, hashes = golden
         key = "ga_%dx%d_%g" % (h, w, s)
-        if key in arrays.files:  # tolerance stated by north_star: 1e-5 relative; we are bit-exact
-            assert np.allclose(out, arrays[key], rtol=1e-5, atol=0)
-            assert np.array_equal(out, arrays[key])
-        else:
-            assert hashes[key] == sha(out)
+        # tolerance stated by north_star for float32 filters: 1e-5 relative (the separable device kernel rounds
+        # differently from the reference's 2-D sum: a few 1e-7 in practice, asserted below)
+        if key in arrays.files:
+            ref = arrays[key]
+        else:  # full-size cases are pinned by hash: the oracle reproduces the hash, the device is compared with it
+            ref = oracle.gaussian_filter(img, s)
+            assert hashes[key] == sha(ref)
+        assert np.allclose(out, ref, rtol=1e-5, atol=0)
+        assert np.abs(out - ref).max() <= 2e-6 * np.abs(ref).max()
 
 
 @pytest.mark.parametrize("case", BADPIX_SHAPES)
@@ -126,7 +130,7 @@ def test_device_batch_vs_oracle(dev, oracle, shape):
     for s in [0.5, 0.75, 1.0, 2.0]:
         g = dev.gaussian_filter(tf, s).cpu().numpy()
         r = np.stack([oracle.gaussian_filter(f32[i], s) for i in range(2)])
-        assert np.allclose(g, r, rtol=1e-5, atol=0) and np.array_equal(g, r), s
+        assert np.allclose(g, r, rtol=1e-5, atol=0) and np.abs(g - r).max() <= 2e-6 * np.abs(r).max(), s
     bad = inject_bad_pixels(img16, max(2, (h * w) // 1600))
     tb = torch.from_numpy(bad).cuda()
     bp = dev.BadPixels(tb[0])
