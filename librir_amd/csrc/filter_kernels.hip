@@ -134,6 +134,92 @@ namespace rir
 		return true;
 	}
 
+	// ---- interior fast path of translate ------------------------------------------------------------
+	// A chunk of VEC consecutive outputs of one row whose taps all lie inside the image, with no clamping, uses
+	// the VEC+1 consecutive source columns l0..l0+VEC of the two rows t and b.  They are fetched with a few
+	// dword loads per row (instead of 4 scalar loads per output: the kernel was bound by the address rate of the
+	// texture unit) and the vertical blends c_j = p_b[j]*(1-v) + p_t[j]*v are shared by neighbouring outputs -
+	// the very expressions of the reference (Filters.h:310-322), evaluated once.  Same float coordinates, same
+	// double blend, same truncating cast: bit-identical to the per-pixel path.
+	template <class T, int N>
+	__device__ __forceinline__ void load_taps(const T *__restrict__ p, T (&out)[N])
+	{
+		if constexpr (sizeof(T) == 2)
+		{
+			constexpr int NW = (N + 2) / 2; // dwords covering N elements from an even or an odd element index
+			const uint32_t a = (uint32_t)(((uintptr_t)p) >> 1) & 1u;
+			const uint32_t *q = reinterpret_cast<const uint32_t *>(p - a);
+			uint32_t d[NW + 1];
+#pragma unroll
+			for (int i = 0; i < NW; ++i)
+				d[i] = q[i];
+			d[NW] = 0;
+#pragma unroll
+			for (int i = 0; i < NW; ++i)
+				d[i] = a ? __builtin_amdgcn_alignbyte(d[i + 1], d[i], 2) : d[i];
+#pragma unroll
+			for (int j = 0; j < N; ++j)
+			{
+				const uint16_t e = (uint16_t)(d[j >> 1] >> (16 * (j & 1)));
+				out[j] = __builtin_bit_cast(T, e);
+			}
+		}
+		else
+		{
+#pragma unroll
+			for (int j = 0; j < N; ++j)
+				out[j] = p[j];
+		}
+	}
+
+	template <class T, class U, int VEC>
+	__device__ __forceinline__ bool translate_chunk_interior(const T *__restrict__ s, int w, int h, int x0, int y, float dx, float dy, U (&out)[VEC])
+	{
+		if constexpr (sizeof(T) != 2 && sizeof(T) != 4)
+			return false;
+		else
+		{
+			const float py = (float)y - dy;
+			const float px0 = (float)x0 - dx, pxl = (float)(x0 + VEC - 1) - dx;
+			if (!(py >= 0.f && py < (float)h && px0 >= 0.f && pxl < (float)w))
+				return false;
+			const int l0 = (int)px0;
+			// the dword fetch of 16-bit rows may touch one element past the last tap: keep it inside the row
+			if (l0 + VEC + (sizeof(T) == 2 ? 2 : 1) > w)
+				return false;
+			float px[VEC];
+			bool regular = true;
+#pragma unroll
+			for (int k = 0; k < VEC; ++k)
+			{
+				px[k] = (float)(x0 + k) - dx;
+				regular = regular && ((int)px[k] == l0 + k) && ((int)(px[k] + 1.f) == l0 + k + 1);
+			}
+			if (!regular)
+				return false;
+			const int t = (int)py;
+			int b = (int)(py + 1.f);
+			if (b == h)
+				b = t;
+			T pt[VEC + 1], pb[VEC + 1];
+			load_taps<T, VEC + 1>(s + (int64_t)t * w + l0, pt);
+			load_taps<T, VEC + 1>(s + (int64_t)b * w + l0, pb);
+			const double v = (double)((float)b - py);
+			const double v1 = 1 - v;
+			double c[VEC + 1];
+#pragma unroll
+			for (int j = 0; j <= VEC; ++j)
+				c[j] = (double)pb[j] * v1 + (double)pt[j] * v;
+#pragma unroll
+			for (int k = 0; k < VEC; ++k)
+			{
+				const double u = (double)(px[k] - (float)(l0 + k));
+				out[k] = CastTo<U>::from(c[k] * (1 - u) + c[k + 1] * u);
+			}
+			return true;
+		}
+	}
+
 	template <class U, int VEC>
 	struct alignas(sizeof(U) * VEC) PixVec
 	{
@@ -162,6 +248,12 @@ namespace rir
 		const float dy = offsets[per_frame_offsets ? 2 * n + 1 : 1];
 		const bool small = fabsf(dx) < 1.0e9f && fabsf(dy) < 1.0e9f; // wave-uniform
 		PixVec<U, VEC> o;
+		if (small && x0 + VEC <= w_ && (((uintptr_t)d) & (sizeof(U) * VEC - 1)) == 0 &&
+			translate_chunk_interior<T, U, VEC>(s, w_, rows, x0, y, dx, dy, o.v))
+		{
+			*reinterpret_cast<PixVec<U, VEC> *>(d) = o;
+			return;
+		}
 		bool wr[VEC];
 		bool all = true;
 #pragma unroll
@@ -189,7 +281,7 @@ namespace rir
 										 int per_frame, float sign, int strategy, int rows, hipStream_t st)
 	{
 		(void)sign;
-		constexpr int VEC = sizeof(U) >= 8 ? 2 : 4;
+		constexpr int VEC = sizeof(U) >= 8 ? 2 : (sizeof(U) == 2 ? 8 : 4);
 		U back = *reinterpret_cast<const U *>(background);
 		const int64_t chunks = (int64_t)((w + VEC - 1) / VEC) * rows;
 		dim3 block(256), grid((unsigned)((chunks + 255) / 256), nframes);
@@ -236,7 +328,7 @@ namespace rir
 	__global__ __launch_bounds__(256) void remove_motion_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w_, int h_,
 																int rows, const float *__restrict__ shifts)
 	{
-		constexpr int VEC = 4;
+		constexpr int VEC = 8;
 		const int cpr = (w_ + VEC - 1) / VEC;
 		const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
 		if (idx >= (int64_t)cpr * h_)
@@ -249,6 +341,18 @@ namespace rir
 		uint16_t *d = dst + fbase + (int64_t)y * w_ + x0;
 		const float dx = -shifts[2 * n], dy = -shifts[2 * n + 1];
 		PixVec<uint16_t, VEC> o;
+		if (y < rows && x0 + VEC <= w_ && (((uintptr_t)d) & 15) == 0 && fabsf(dx) < 1.0e9f && fabsf(dy) < 1.0e9f)
+		{
+			float val[VEC];
+			if (translate_chunk_interior<uint16_t, float, VEC>(s, w_, rows, x0, y, dx, dy, val))
+			{
+#pragma unroll
+				for (int k = 0; k < VEC; ++k)
+					o.v[k] = (uint16_t)(int32_t)val[k];
+				*reinterpret_cast<PixVec<uint16_t, VEC> *>(d) = o;
+				return;
+			}
+		}
 #pragma unroll
 		for (int k = 0; k < VEC; ++k)
 		{
@@ -268,7 +372,7 @@ namespace rir
 				}
 			}
 		}
-		if (x0 + VEC <= w_ && (((uintptr_t)d) & 7) == 0)
+		if (x0 + VEC <= w_ && (((uintptr_t)d) & 15) == 0)
 			*reinterpret_cast<PixVec<uint16_t, VEC> *>(d) = o;
 		else
 			for (int k = 0; k < VEC && x0 + k < w_; ++k)
@@ -277,7 +381,7 @@ namespace rir
 
 	hipError_t launch_remove_motion(const uint16_t *src, uint16_t *dst, int w, int h, int rows, int nframes, const float *d_shifts, hipStream_t st)
 	{
-		const int64_t chunks = (int64_t)((w + 3) / 4) * h;
+		const int64_t chunks = (int64_t)((w + 7) / 8) * h;
 		dim3 block(256), grid((unsigned)((chunks + 255) / 256), nframes);
 		hipLaunchKernelGGL(remove_motion_kernel, grid, block, 0, st, src, dst, w, h, rows, d_shifts);
 		return hipGetLastError();
