@@ -118,11 +118,27 @@ def main():
         if rank == 0:
             sys.stderr.write("bench.py: WORLD_SIZE=%d but --gpus %d\n" % (world, args.gpus))
         sys.exit(2)
+    # Rehearsal switches (never set by the driver): RIR_BENCH_BACKEND=gloo runs the N>1 control flow without RCCL,
+    # RIR_BENCH_SHARE_GPU=1 lets every rank use GPU 0 of a one-GPU box.
+    backend = os.environ.get("RIR_BENCH_BACKEND", "nccl")
+    if os.environ.get("RIR_BENCH_SHARE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    def all_gather_u8(dst_u8, src_u8):
+        if backend == "nccl":
+            dist.all_gather_into_tensor(dst_u8, src_u8)
+        else:  # rehearsal: gloo moves host memory
+            host = torch.empty(dst_u8.shape, dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, src_u8.cpu())
+            dst_u8.copy_(host)
 
     from librir_amd import device as D
     from librir_amd.synthetic import s1_noisy_background
@@ -164,7 +180,7 @@ def main():
         ev[k][3].record()
     barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -185,15 +201,15 @@ def main():
     allgather = None
     if world > 1:
         gathered = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), dtype=torch.uint16, device=dev)
-        dist.all_gather_into_tensor(gathered.view(torch.uint8), out.view(torch.uint8))  # warm-up / communicator setup
+        all_gather_u8(gathered.view(torch.uint8), out.view(torch.uint8))  # warm-up / communicator setup
         barrier()
         t1 = time.perf_counter()
-        dist.all_gather_into_tensor(gathered.view(torch.uint8), out.view(torch.uint8))
+        all_gather_u8(gathered.view(torch.uint8), out.view(torch.uint8))
         barrier()
         ag = time.perf_counter() - t1
         same = bool(torch.equal(gathered[rank * out.shape[0]:(rank + 1) * out.shape[0]].view(torch.int16), out.view(torch.int16)))
         allgather = {"ms": ag * 1e3, "bytes_per_rank": out.numel() * 2 * world, "algbw_GBs": out.numel() * 2 * world / ag / 1e9,
-                     "own_shard_intact": same, "backend": "rccl"}
+                     "own_shard_intact": same, "backend": "rccl" if backend == "nccl" else backend}
 
     if rank == 0:
         raw = 2.0 * h * w * n  # bytes of raw uint16 per batch
