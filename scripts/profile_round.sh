@@ -10,5 +10,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $GR
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 cd $GRAFT_REPO_ROOT && bash scripts/pmc.sh $TAG > /dev/null 2>&1
 python scripts/pmc_summary.py gpurun_out/pmc_$TAG > $OUT/pmc_summary.json
+python scripts/pmc_traffic.py $OUT/pmc_summary.json > $OUT/pmc_traffic.json
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 tail -c 600 $OUT/bench.json
