@@ -49,10 +49,6 @@
 #ifndef RIR_COMPACT_NT_STORE
 #define RIR_COMPACT_NT_STORE 0
 #endif
-// 1 adds explicit loads-only s_waitcnt on top of the compiler's counted waits (development switch)
-#ifndef RIR_MANUAL_WAITS
-#define RIR_MANUAL_WAITS 0
-#endif
 
 namespace rir
 {
@@ -349,7 +345,6 @@ namespace rir
 		uint32_t n_hsh;	   // bit position of the slot's width inside its header dword
 		bool n_hhi;		   // the slot's width lives in the high header dword
 		bool n_first;	   // plane 0 of its slot
-		uint32_t h_sha, h_shb; // header lanes (16q+k): positions of slots q and 4+q in the non-zero mask
 		// narrow tier, packed-nibble order (see emit_record_narrow): nibble n of the packed dword holds slot
 		// NIB_SLOT[n] = {0,4,2,6,1,5,3,7}; lane (lane & 31) = 4n + b holds plane b of that slot
 		uint32_t p_before; // mask of the lanes whose plane words precede this lane's word in the stream
@@ -374,8 +369,6 @@ namespace rir
 		c.n_hsh = 16 * (slot & 1) + (slot >= 4 ? 5 : 0);
 		c.n_hhi = (slot & 2) != 0;
 		c.n_first = (lane & 3) == 0;
-		c.h_sha = 4 * q;
-		c.h_shb = 16 + 4 * q;
 		{
 			const uint32_t nib_slot[8] = {0, 4, 2, 6, 1, 5, 3, 7};
 			const uint32_t n = ((uint32_t)lane & 31u) >> 2, b = lane & 3;
@@ -530,11 +523,8 @@ namespace rir
 		const uint16_t *tile0 = frames + frame0 * npx + (int64_t)tile * RIRB1_TILE_PX; // tile of the chunk's first frame
 		// FAST: whole tile inside the frame and 16-byte aligned rows -> raw-buffer loads, unconditional;
 		// past the end of the chunk the prefetch re-reads the last frame (an L2 hit, no HBM traffic).
-		// Frame loads: unconditional raw-buffer loads (FAST) so that the ring keeps frames in flight.
-		// On top of the compiler's own counted waits, each step adds a wait that only relies on loads
-		// returning in order among themselves: with the loads of frames f+1 and f+2 behind it, frame f
-		// has landed once at most 2 vector-memory operations are outstanding.  (A tighter count that
-		// also relied on the position of the stores raced at full size.)
+		// Frame loads are compiler-visible builtins: the waits are the compiler's own counted s_waitcnt, which
+		// stay exact because no vector-memory operation of the frame loop sits inside a branch.
 		// Frames are loaded strictly in order (0,1,2,3 up front, then frame f+3 at step f), so the address is a
 		// running wave-uniform pointer (2 scalar adds per load instead of a 64-bit multiply chain); past the end
 		// of the chunk it stays on the last frame.
@@ -555,9 +545,6 @@ namespace rir
 				dst.x = p.d[0], dst.y = p.d[1], dst.z = p.d[2], dst.w = p.d[3];
 			}
 		};
-#define RIR_WAIT_SLOT(SLOT, N)                                   \
-	if (FAST && RIR_MANUAL_WAITS)                                \
-		asm volatile("s_waitcnt vmcnt(" #N ")" : : : "memory");
 		auto as_px8 = [](const v4u32 &v) {
 			Px8 p;
 			p.d[0] = v.x, p.d[1] = v.y, p.d[2] = v.z, p.d[3] = v.w;
@@ -578,7 +565,6 @@ namespace rir
 
 		// ---- key frame: RAW, or LEFT when its payload is strictly smaller ----
 		{
-			RIR_WAIT_SLOT(s0, 3) // the three younger loads may stay in flight
 			const Px8 cur = as_px8(s0);
 			const uint32_t base_raw = tile_base(cur, false);
 			const uint32_t b2 = base_raw | (base_raw << 16);
@@ -614,7 +600,6 @@ namespace rir
 #define RIR_ENC_STEP(F, CUR, PREV)                                                             \
 	{                                                                                          \
 		const int f = (F);                                                                     \
-		RIR_WAIT_SLOT(CUR, 2)                                                                  \
 		Px8 d;                                                                                 \
 		{                                                                                      \
 			const Px8 c_ = as_px8(CUR), p_ = as_px8(PREV);                                     \
@@ -657,7 +642,6 @@ namespace rir
 			hdr_reg = 0;
 		}
 #undef RIR_ENC_STEP
-#undef RIR_WAIT_SLOT
 		for (int f = nf + lane; f < gop; f += 64)
 			my_hdr[f] = 0; // short last chunk: the unused table entries are defined
 		if (lane == 0)
@@ -920,9 +904,6 @@ namespace rir
 		const int fr = (FR);                                                                                         \
 		const uint64_t hdr = R.hdr;                                                                                  \
 		err |= R.bad;                                                                                                \
-		/* Belt and braces on top of the compiler's own counted wait: loads return in order among themselves, the    \
-		   six loads of the three younger records are the only operations allowed to be outstanding here. */         \
-		if (RIR_MANUAL_WAITS) asm volatile("s_waitcnt vmcnt(6)" : : : "memory");                                                           \
 		const v2u32 wa_ = R.a, wb_ = R.b;                                                                             \
 		const bool narrow_ = R.narrow;                                                                               \
 		/* refill the slot with the record four frames ahead */                                                       \

@@ -24,8 +24,6 @@ namespace rir
 	hipError_t launch_histogram(const uint16_t *img, const uint8_t *mask, int64_t npx, int nframes, uint32_t *d_hist, hipStream_t st);
 	hipError_t launch_quantile_select(const uint16_t *img, const uint8_t *mask, int64_t npx, int nframes, float percent, int nbins, int *d_result,
 									  hipStream_t st);
-	hipError_t launch_quantile_scan(const uint32_t *d_hist, uint64_t size, float percent, int masked, int nbins, int nframes, int *d_result,
-									hipStream_t st);
 	hipError_t launch_bad_pixels_stats(const uint32_t *d_hist, uint64_t size, int64_t *d_out, hipStream_t st);
 	hipError_t launch_bad_pixels_detect(const uint16_t *src, int w, int h, double std_factor, int floor_detect, uint8_t *d_flags, hipStream_t st);
 	hipError_t launch_median3x3(const uint16_t *src, uint16_t *dst, int w, int h, int nframes, hipStream_t st);

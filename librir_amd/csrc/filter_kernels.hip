@@ -747,60 +747,6 @@ namespace rir
 		}
 	}
 
-	// one block per frame: first bin (of `nbins`) whose cumulative count >= s, 0 when none, with
-	//   s = (size_t)round((float)size * percent)            (Filters.cpp:63, float product)
-	//   s = (size_t)(int)round((float)population * percent)   (masked, Filters.cpp:92)
-	__global__ __launch_bounds__(1024) void quantile_scan_kernel(const uint32_t *__restrict__ hist, uint64_t size, float percent, int masked,
-																 int nbins, int *__restrict__ result)
-	{
-		__shared__ uint64_t part[1024];
-		__shared__ uint64_t total_s;
-		__shared__ int best;
-		const int n = blockIdx.x, tid = threadIdx.x;
-		const uint32_t *hh = hist + (int64_t)n * 65536;
-		const int per = 64; // 1024 threads x 64 bins
-		uint64_t s = 0;
-		for (int k = 0; k < per; ++k)
-			s += hh[tid * per + k];
-		part[tid] = s;
-		if (tid == 0)
-			best = 0x7fffffff;
-		__syncthreads();
-		if (tid == 0)
-		{ // exclusive prefix over the 1024 partial sums (tiny)
-			uint64_t acc = 0;
-			for (int k = 0; k < 1024; ++k)
-			{
-				const uint64_t t = part[k];
-				part[k] = acc;
-				acc += t;
-			}
-			total_s = acc;
-		}
-		__syncthreads();
-		uint64_t tg;
-		if (masked)
-			tg = (uint64_t)(int64_t)(int)roundf(__fmul_rn((float)total_s, percent));
-		else
-			tg = (uint64_t)roundf(__fmul_rn((float)size, percent));
-		uint64_t count = part[tid];
-		for (int k = 0; k < per; ++k)
-		{
-			const int b = tid * per + k;
-			if (b >= nbins)
-				break;
-			count += hh[b];
-			if (count >= tg)
-			{
-				atomicMin(&best, b);
-				break;
-			}
-		}
-		__syncthreads();
-		if (tid == 0)
-			result[n] = best == 0x7fffffff ? 0 : best;
-	}
-
 	// find_median_pixel[_mask] without a histogram in memory: one 1024-thread workgroup per frame counts the
 	// frame in LDS, one quarter of the value range at a time (16 384 32-bit counters = 64 KiB), carries the
 	// cumulative count from quarter to quarter and stops at the quarter that holds the answer - for 14-bit IR
@@ -938,13 +884,6 @@ namespace rir
 			return e;
 		const int blocks = (int)((npx + RIR_HIST_RUN - 1) / RIR_HIST_RUN);
 		hipLaunchKernelGGL(histogram_kernel, dim3(blocks, nframes), dim3(1024), 0, st, img, mask, npx, d_hist);
-		return hipGetLastError();
-	}
-
-	hipError_t launch_quantile_scan(const uint32_t *d_hist, uint64_t size, float percent, int masked, int nbins, int nframes, int *d_result,
-									hipStream_t st)
-	{
-		hipLaunchKernelGGL(quantile_scan_kernel, dim3(nframes), dim3(1024), 0, st, d_hist, size, percent, masked, nbins, d_result);
 		return hipGetLastError();
 	}
 
