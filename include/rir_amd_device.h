@@ -73,6 +73,14 @@ extern "C"
 	/* gaussian_filter: reference signal_processing.h:33 / signal_processing.cpp:79-148. */
 	int rir_gaussian_filter_device(const float *d_src, float *d_dst, int w, int h, int nframes, float sigma, void *stream);
 
+	/* The same two filters with the dtype conversions the Python callers do around them folded in (no
+	 * converted copy of the frames in memory): gaussian_filter(img.astype(float32)) for uint16 frames
+	 * (sigma < 2.5), and translate(float32 img, ...).astype(uint16) - the value is rounded to float first,
+	 * then truncated, exactly as the two-step form.  background: HOST pointer to one uint16. */
+	int rir_gaussian_filter_u16_device(const unsigned short *d_src, float *d_dst, int w, int h, int nframes, float sigma, void *stream);
+	int rir_translate_f32_u16_device(const float *d_src, unsigned short *d_dst, int w, int h, int nframes, const float *d_offsets,
+									 int per_frame_offsets, const void *background, const char *strategy, void *stream);
+
 	/* find_median_pixel[_mask]: reference signal_processing.h:39-44 / Filters.cpp:56-101.
 	 * d_result: int32[nframes]; d_hist: unused, may be NULL (the counting happens in LDS); d_mask may be NULL. */
 	int rir_find_median_pixel_device(const unsigned short *d_img, const unsigned char *d_mask, int size, int nframes, float percent, int *d_result,

@@ -17,6 +17,7 @@ namespace rir
 								int per_frame, int strategy, hipStream_t st);
 	hipError_t launch_remove_motion(const uint16_t *src, uint16_t *dst, int w, int h, int rows, int nframes, const float *d_shifts, hipStream_t st);
 	hipError_t launch_gaussian(const float *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st);
+	hipError_t launch_gaussian_u16(const uint16_t *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st);
 	hipError_t launch_bad_pixels_correct(const uint16_t *in, uint16_t *out, int w, int h, int nframes, const int *d_xy, int nbad, int floor_v,
 										 hipStream_t st);
 	hipError_t launch_remove_bad_pixels(uint16_t *img, int w, int h, int rows, int nframes, const int *d_xy, int nbad, const uint8_t *d_bitmap,

@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "filter_kernels.h"
 
 namespace rir
@@ -63,6 +65,28 @@ namespace rir
 	{
 		__device__ static uint32_t from(double v) { return (uint32_t)(int64_t)v; }
 	};
+
+	// uint16 output of a float translate: the value is first rounded to float (what translate<float,float> stores)
+	// and then truncated, i.e. exactly "translate, then convert", without the intermediate frame in memory
+	struct u16_via_f32
+	{
+		uint16_t v;
+	};
+	template <>
+	struct CastTo<u16_via_f32>
+	{
+		__device__ static u16_via_f32 from(double v) { return u16_via_f32{(uint16_t)(int32_t)(float)v}; }
+	};
+	template <class T, class U>
+	__device__ __forceinline__ U tap_as(T p)
+	{
+		if constexpr (std::is_same<T, U>::value)
+			return p;
+		else if constexpr (std::is_same<U, u16_via_f32>::value)
+			return CastTo<U>::from((double)p);
+		else
+			return (U)p;
+	}
 
 	__device__ __forceinline__ uint64_t f2sz(float v) { return (uint64_t)(int64_t)v; }
 	__device__ __forceinline__ uint64_t wrap_sz(uint64_t value, uint64_t max) { return (value + max) % max; }
@@ -116,7 +140,7 @@ namespace rir
 				_y = h - 1;
 			else
 				_y = f2szT<SMALL>(py);
-			out = (U)s[_x + _y * w];
+			out = tap_as<T, U>(s[_x + _y * w]);
 			return true;
 		}
 		const uint64_t l = f2szT<SMALL>(px);
@@ -317,6 +341,8 @@ namespace rir
 			return launch_translate_t<float, float>(src, dst, background, w, h, nframes, d_offsets, per_frame, 1.f, strategy, h, st);
 		case 'd':
 			return launch_translate_t<double, double>(src, dst, background, w, h, nframes, d_offsets, per_frame, 1.f, strategy, h, st);
+		case 'F': // float32 frames in, uint16 frames out ("translate, then astype(uint16)" in one pass); background is a uint16
+			return launch_translate_t<float, u16_via_f32>(src, dst, background, w, h, nframes, d_offsets, per_frame, 1.f, strategy, h, st);
 		default:
 			return hipErrorInvalidValue;
 		}
@@ -437,8 +463,9 @@ namespace rir
 	// agree to a few 1e-7 relative (the parity bar for float32 filters is 1e-5, BASELINE.json); border pixels
 	// are renormalised by the in-image weight, Sx(x) * Sy(y), as the reference does with its 2-D sum.
 	// A 256-thread workgroup produces a 64 x 32 output tile from a (64+2R) x (32+2R) input tile staged in LDS.
-	template <int R>
-	__global__ __launch_bounds__(256) void gaussian_sep_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+	// TIN = float, or uint16_t (the integer -> float conversion of a u16 frame folded into the tile load).
+	template <int R, class TIN>
+	__global__ __launch_bounds__(256) void gaussian_sep_kernel(const TIN *__restrict__ src, float *__restrict__ dst, int w, int h,
 															   const float *__restrict__ kern)
 	{
 		constexpr int TX = 64, TY = 32, KW = 2 * R + 1, LW = TX + 2 * R, LH = TY + 2 * R;
@@ -449,20 +476,20 @@ namespace rir
 		const int tx = tid & 63, ty = tid >> 6;
 		const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
 		const int64_t fbase = (int64_t)blockIdx.z * w * h;
-		const float *s = src + fbase;
+		const TIN *s = src + fbase;
 		// stage the input tile: each wave walks rows, lane = column (coalesced 256-byte rows), the first 2R lanes
 		// also fetch the right-hand halo columns
 		for (int ly = ty; ly < LH; ly += 4)
 		{
 			const int gy = y0 - R + ly;
 			const bool yin = gy >= 0 && gy < h;
-			const float *row = s + (int64_t)gy * w;
+			const TIN *row = s + (int64_t)gy * w;
 			const int gx = x0 - R + tx;
-			tile[ly][tx] = (yin && gx >= 0 && gx < w) ? row[gx] : 0.f;
+			tile[ly][tx] = (yin && gx >= 0 && gx < w) ? (float)row[gx] : 0.f;
 			if (tx < 2 * R)
 			{
 				const int gx2 = gx + TX;
-				tile[ly][tx + TX] = (yin && gx2 >= 0 && gx2 < w) ? row[gx2] : 0.f;
+				tile[ly][tx + TX] = (yin && gx2 >= 0 && gx2 < w) ? (float)row[gx2] : 0.f;
 			}
 		}
 		if (tid < KW)
@@ -525,29 +552,44 @@ namespace rir
 		}
 	}
 
-	hipError_t launch_gaussian(const float *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st)
+	template <class TIN>
+	static bool launch_gaussian_sep(const TIN *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st)
 	{
 		dim3 block(256), tgrid((w + 63) / 64, (h + 31) / 32, nframes);
 		switch (radius)
 		{
 		case 1:
-			hipLaunchKernelGGL(gaussian_sep_kernel<1>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
-			break;
+			hipLaunchKernelGGL((gaussian_sep_kernel<1, TIN>), tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			return true;
 		case 2:
-			hipLaunchKernelGGL(gaussian_sep_kernel<2>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
-			break;
+			hipLaunchKernelGGL((gaussian_sep_kernel<2, TIN>), tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			return true;
 		case 3:
-			hipLaunchKernelGGL(gaussian_sep_kernel<3>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
-			break;
+			hipLaunchKernelGGL((gaussian_sep_kernel<3, TIN>), tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			return true;
 		case 4:
-			hipLaunchKernelGGL(gaussian_sep_kernel<4>, tgrid, block, 0, st, src, dst, w, h, d_kernel);
-			break;
+			hipLaunchKernelGGL((gaussian_sep_kernel<4, TIN>), tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			return true;
 		default:
-		{
-			dim3 grid((w + 255) / 256, h, nframes);
+			return false;
+		}
+	}
+
+	hipError_t launch_gaussian(const float *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st)
+	{
+		if (!launch_gaussian_sep<float>(src, dst, w, h, nframes, d_kernel, radius, st))
+		{ // radius > 4: the direct 2-D form
+			dim3 block(256), grid((w + 255) / 256, h, nframes);
 			hipLaunchKernelGGL(gaussian_kernel, grid, block, 0, st, src, dst, w, h, d_kernel, radius);
 		}
-		}
+		return hipGetLastError();
+	}
+
+	// uint16 frames in, float out (radius <= 4 only: hipErrorInvalidValue otherwise)
+	hipError_t launch_gaussian_u16(const uint16_t *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st)
+	{
+		if (!launch_gaussian_sep<uint16_t>(src, dst, w, h, nframes, d_kernel, radius, st))
+			return hipErrorInvalidValue;
 		return hipGetLastError();
 	}
 

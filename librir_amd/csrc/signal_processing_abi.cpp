@@ -259,6 +259,39 @@ RIR_EXPORT int rir_gaussian_filter_device(const float *d_src, float *d_dst, int 
 	return hip_ok(launch_gaussian(d_src, d_dst, w, h, nframes, d_k, radius, as_stream(stream)), "gaussian_filter") ? 0 : -1;
 }
 
+// uint16 frames in, float32 out: gaussian_filter(frame.astype(float32)) without the converted copy in memory (sigma < 2.5).
+RIR_EXPORT int rir_gaussian_filter_u16_device(const unsigned short *d_src, float *d_dst, int w, int h, int nframes, float sigma, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (w <= 0 || h <= 0 || nframes <= 0 || !d_src || !d_dst || !(sigma > 0) || gaussian_radius(sigma) > 4)
+	{
+		log_error("rir_gaussian_filter_u16_device: invalid argument (sigma must be < 2.5 for the uint16 entry)");
+		return -1;
+	}
+	const int radius = gaussian_radius(sigma);
+	const float *d_k = gaussian_table_device(sigma, radius);
+	if (!d_k)
+		return -1;
+	return hip_ok(launch_gaussian_u16(d_src, d_dst, w, h, nframes, d_k, radius, as_stream(stream)), "gaussian_filter") ? 0 : -1;
+}
+
+// float32 frames in, uint16 out: translate(...) followed by the truncating astype(uint16) of the wrapper, in one pass
+// (each value is rounded to float first, exactly as the two-step form does).  background: HOST pointer to one uint16.
+RIR_EXPORT int rir_translate_f32_u16_device(const float *d_src, unsigned short *d_dst, int w, int h, int nframes, const float *d_offsets,
+											int per_frame_offsets, const void *background, const char *strategy, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	const int s = strategy_from_string(strategy);
+	if (s < 0 || w <= 0 || h <= 0 || nframes <= 0 || !d_src || !d_dst || !d_offsets || !background)
+	{
+		log_error("rir_translate_f32_u16_device: invalid argument");
+		return -1;
+	}
+	return hip_ok(launch_translate('F', d_src, d_dst, background, w, h, nframes, d_offsets, per_frame_offsets, s, as_stream(stream)), "translate") ? 0 : -1;
+}
+
 // result: int32[nframes] on the device.  d_hist: unused (kept in the signature; may be NULL).
 RIR_EXPORT int rir_find_median_pixel_device(const unsigned short *d_img, const unsigned char *d_mask, int size, int nframes, float percent,
 											int *d_result, unsigned int *d_hist, void *stream)

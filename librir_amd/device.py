@@ -66,6 +66,8 @@ _lib.rir_codec_encode_compact_device.argtypes = [ct.c_int, ct.c_int, ct.c_int, c
 _lib.rir_codec_decode_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.rir_translate_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp, ct.c_int, _vp, ct.c_char_p, _vp]
 _lib.rir_gaussian_filter_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_float, _vp]
+_lib.rir_gaussian_filter_u16_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_float, _vp]
+_lib.rir_translate_f32_u16_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp, ct.c_int, _vp, ct.c_char_p, _vp]
 _lib.rir_find_median_pixel_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_float, _vp, _vp, _vp]
 _lib.rir_bad_pixels_create_device.argtypes = [_vp, ct.c_int, ct.c_int, _vp]
 _lib.rir_bad_pixels_create_rows_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, _vp]
@@ -214,10 +216,36 @@ def translate(frames, offsets, strategy="", background=0):
 
 
 def gaussian_filter(frames, sigma):
+    """float32 frames, or uint16 frames (converted on the fly: same result as frames.float(), sigma < 2.5)."""
+    if frames.dtype == torch.uint16:
+        fr = _frames3(frames, torch.uint16)
+        n, h, w = fr.shape
+        dst = torch.empty((n, h, w), dtype=torch.float32, device=fr.device)
+        _check(_lib.rir_gaussian_filter_u16_device(fr.data_ptr(), dst.data_ptr(), w, h, n, float(sigma), _stream()), "rir_gaussian_filter_u16_device")
+        return dst
     fr = _frames3(frames, torch.float32)
     n, h, w = fr.shape
     dst = torch.empty_like(fr)
     _check(_lib.rir_gaussian_filter_device(fr.data_ptr(), dst.data_ptr(), w, h, n, float(sigma), _stream()), "rir_gaussian_filter_device")
+    return dst
+
+
+def translate_to_u16(frames, offsets, strategy="nearest", background=0):
+    """translate(float32 frames).to(uint16) in one pass (strategies that write every pixel)."""
+    fr = _frames3(frames, torch.float32)
+    n, h, w = fr.shape
+    if strategy in ("", "noborder"):
+        raise RuntimeError("translate_to_u16: 'noborder' needs a pre-filled destination, use translate()")
+    off = torch.as_tensor(offsets, dtype=torch.float32, device=fr.device).contiguous()
+    per_frame = 1 if off.dim() == 2 else 0
+    if per_frame and off.shape[0] != n:
+        raise RuntimeError("translate: one (dx,dy) pair per frame expected")
+    dst = torch.empty((n, h, w), dtype=torch.uint16, device=fr.device)
+    back = np.array([background], dtype=np.uint16)
+    if strategy == "constant":
+        strategy = "background"
+    _check(_lib.rir_translate_f32_u16_device(fr.data_ptr(), dst.data_ptr(), w, h, n, off.data_ptr(), per_frame, back.ctypes.data,
+                                             strategy.encode(), _stream()), "rir_translate_f32_u16_device")
     return dst
 
 

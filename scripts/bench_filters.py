@@ -41,8 +41,7 @@ t0 = time.perf_counter(); bp2 = D.BadPixels(t16[0]); torch.cuda.synchronize(); p
 ctx = D.CodecContext(w, h, n, 50)
 def pipeline():
     a_ = bp.correct(t16)
-    g = D.gaussian_filter(a_.to(torch.float32), 0.75)
-    t = D.translate(g, offs, "nearest")
-    return ctx.encode(t.to(torch.uint16))
-rec("config3 unfused chain + encode", timeit(pipeline, 5), 2 * WH)
+    g = D.gaussian_filter(a_, 0.75)
+    return ctx.encode(D.translate_to_u16(g, offs, "nearest"))
+rec("config3 chain + encode (4 kernels)", timeit(pipeline, 5), 2 * WH)
 print(json.dumps(res))

@@ -53,6 +53,15 @@ def test_config2_filter_chain_then_encode(dev, oracle):
     t_gpu = D.translate(g_gpu, (1.25, -2.5), "nearest")
     t_ref = np.stack([oracle.translate(g_gpu[i].cpu().numpy(), 1.25, -2.5, "nearest") for i in range(n)])
     np.testing.assert_allclose(t_gpu.cpu().numpy(), t_ref, rtol=1e-5, atol=0)
+    # the same chain with the dtype conversions folded into the kernels gives the very same frames
+    g2 = D.gaussian_filter(c_gpu, 0.75)  # uint16 in
+    assert torch.equal(g2, g_gpu)
+    u16_fused = D.translate_to_u16(g2, (1.25, -2.5), "nearest")
+    assert torch.equal(u16_fused.view(torch.int16), t_gpu.to(torch.uint16).view(torch.int16))
+    for strat, (dx, dy) in (("background", (300.5, -2.25)), ("wrap", (-3.75, 600.0)), ("nearest", (0.0, 0.0))):
+        a = D.translate_to_u16(g2[:2], (dx, dy), strat, background=7)
+        b = D.translate(g2[:2], (dx, dy), strat, background=7).to(torch.uint16)
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), strat
     # stage 4: lossless encode of the filtered stream, bit-exact round trip and stream == oracle
     u16 = t_gpu.to(torch.uint16)
     ctx = D.CodecContext(w, h, n, 50, device="cuda")
