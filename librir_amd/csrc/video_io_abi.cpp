@@ -160,7 +160,7 @@ namespace
 			return true;
 		}
 
-		// img (host, full frame) -> out (host, full frame).  Returns false on a device error.
+		// img (host, full frame) -> d_out (device, full frame), copied to `out` (host) when it is not NULL.
 		bool step(const unsigned short *img, unsigned short *out, bool add_loss, bool remove_bad_pixels, int low_value_error, int high_value_error,
 				  double std_factor, int &low_error, int &high_error)
 		{
@@ -268,6 +268,8 @@ namespace
 				}
 			}
 			++frames;
+			if (!out)
+				return true; // the caller consumes d_out on the same stream
 			return hip_ok(hipMemcpyAsync(out, d_out.ptr, (size_t)full * 2, hipMemcpyDeviceToHost, st), "D2H") && hip_ok(hipStreamSynchronize(st), "sync");
 		}
 	};
@@ -324,7 +326,7 @@ namespace
 				return false;
 			int lo = 0, hi = 0;
 			const bool first = lossy->frames == 0;
-			if (!lossy->step(img, lossy_out.data(), false, removeBadPixels, lowValueError, highValueError, stdFactor, lo, hi))
+			if (!lossy->step(img, nullptr, false, removeBadPixels, lowValueError, highValueError, stdFactor, lo, hi))
 				return false;
 			if (first)
 			{
@@ -343,7 +345,7 @@ namespace
 			}
 			low_errors.push_back((unsigned short)lo);
 			high_errors.push_back((unsigned short)hi);
-			return add_image(lossy_out.data(), ts, attrs);
+			return add_image_device(lossy->d_out.as<unsigned short>(), ts, attrs); // stays in HBM: no trip through the host
 		}
 
 		// H264_Saver::addLoss (h264.cpp:2426-2607): the loss is applied to the caller's image, nothing is written
@@ -445,12 +447,10 @@ namespace
 			if (pending == 0)
 				return true;
 			hipStream_t st = default_stream();
-			const size_t fbytes = (size_t)width * height * 2;
 			rir_codec_layout L;
 			if (rir_codec_layout_query(width, height, pending, chunk_gop, &L) != 0)
 				return false;
-			if (!hip_ok(hipMemcpyAsync(cc.d_frames.ptr, cc.h_frames.ptr, fbytes * pending, hipMemcpyHostToDevice, st), "H2D frames"))
-				return false;
+			// the frames are already in cc.d_frames: each one was uploaded (or produced there) when it was added
 			if (rir_codec_encode_device(cc.d_frames.as<unsigned short>(), width, height, pending, chunk_gop, cc.d_hdr.as<unsigned long long>(),
 										cc.d_tile_off.as<unsigned int>(), cc.d_chunk_off.as<unsigned long long>(),
 										cc.d_stream.as<unsigned long long>(), cc.d_ws.ptr, (long long)cc.d_ws.cap, st) != 0)
@@ -488,7 +488,31 @@ namespace
 		{
 			if (!img || !open())
 				return false;
-			std::memcpy(cc.h_frames.as<char>() + (size_t)pending * width * height * 2, img, (size_t)width * height * 2);
+			// the caller's buffer is only valid during the call: copy it into the chunk's pinned slot, then upload that
+			// slot asynchronously - the transfer overlaps with the caller preparing its next frame
+			const size_t fbytes = (size_t)width * height * 2;
+			char *slot = cc.h_frames.as<char>() + (size_t)pending * fbytes;
+			std::memcpy(slot, img, fbytes);
+			if (!hip_ok(hipMemcpyAsync(cc.d_frames.as<char>() + (size_t)pending * fbytes, slot, fbytes, hipMemcpyHostToDevice, default_stream()),
+						"H2D frame"))
+				return false;
+			return frame_added(ts, attrs);
+		}
+
+		// a frame that is already in device memory (bounded-loss path): device-to-device into the chunk
+		bool add_image_device(const unsigned short *d_img, int64_t ts, const AttrMap &attrs)
+		{
+			if (!d_img || !open())
+				return false;
+			const size_t fbytes = (size_t)width * height * 2;
+			if (!hip_ok(hipMemcpyAsync(cc.d_frames.as<char>() + (size_t)pending * fbytes, d_img, fbytes, hipMemcpyDeviceToDevice, default_stream()),
+						"D2D frame"))
+				return false;
+			return frame_added(ts, attrs);
+		}
+
+		bool frame_added(int64_t ts, const AttrMap &attrs)
+		{
 			++pending;
 			++nframes;
 			times.push_back(ts);
