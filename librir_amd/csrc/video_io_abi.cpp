@@ -488,9 +488,11 @@ namespace
 		{
 			if (!img || !open())
 				return false;
-			// the caller's buffer is only valid during the call: copy it into the chunk's pinned slot, then upload that
-			// slot asynchronously - the transfer overlaps with the caller preparing its next frame
 			const size_t fbytes = (size_t)width * height * 2;
+			// The caller owns its buffer again when this call returns, whatever kind of host memory it is:
+			// copy it into the chunk's page-locked slot, then upload that slot asynchronously - the transfer overlaps
+			// with the caller preparing its next frame.  (Uploading straight from the caller's pointer saves 13 us per
+			// 640x512 frame but leans on how the runtime treats pageable / pinned sources; not worth the risk.)
 			char *slot = cc.h_frames.as<char>() + (size_t)pending * fbytes;
 			std::memcpy(slot, img, fbytes);
 			if (!hip_ok(hipMemcpyAsync(cc.d_frames.as<char>() + (size_t)pending * fbytes, slot, fbytes, hipMemcpyHostToDevice, default_stream()),

@@ -215,3 +215,22 @@ def test_filtered_reads_leave_the_device_chunk_intact(tmp_path, oracle):
         assert np.array_equal(rv.load_image(cam, i), arr[i]), i
         assert rv.get_last_image_raw_value(cam, 5, 4) == arr[i, 4, 5]
     rv.close_camera(cam)
+
+
+def test_caller_may_reuse_its_buffer_immediately(tmp_path):
+    """The C ABI copies synchronously (ownership): the caller's buffer may be overwritten as soon as
+    h264_add_image_lossless returns, also in the middle of a chunk and with pinned (torch) host memory."""
+    import torch
+
+    n, h, w = 60, 1024, 1280  # 2.6 MB frames: long enough a DMA for a missing wait to show
+    arr = images(n, h, w)
+    for kind in ("pageable", "pinned"):
+        dst = tmp_path / ("reuse_%s.h264" % kind)
+        buf = np.empty((h, w), np.uint16) if kind == "pageable" else torch.empty((h, w), dtype=torch.uint16).pin_memory().numpy()
+        with IRSaver(dst, w, h, h) as s:
+            for i in range(n):
+                buf[:] = arr[i]
+                s.add_image(buf, i)
+                buf[:] = 0xABCD
+        with IRMovie.from_filename(dst) as mov:
+            assert np.array_equal(mov.data, arr), kind
