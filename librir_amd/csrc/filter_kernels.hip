@@ -259,10 +259,9 @@ namespace rir
 	{
 		const int cpr = (w_ + VEC - 1) / VEC; // chunks per row
 		const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-		if (idx >= (int64_t)cpr * rows)
-			return;
-		const int y = (int)(idx / cpr);
-		const int x0 = (int)(idx - (int64_t)y * cpr) * VEC;
+		const bool valid = idx < (int64_t)cpr * rows;
+		const int y = valid ? (int)(idx / cpr) : 0;
+		const int x0 = valid ? (int)(idx - (int64_t)y * cpr) * VEC : 0;
 		const int n = blockIdx.y;
 		const uint64_t w = (uint64_t)w_, h = (uint64_t)rows;
 		const int64_t fbase = (int64_t)n * w_ * h_;
@@ -271,32 +270,47 @@ namespace rir
 		const float dx = offsets[per_frame_offsets ? 2 * n : 0];
 		const float dy = offsets[per_frame_offsets ? 2 * n + 1 : 1];
 		const bool small = fabsf(dx) < 1.0e9f && fabsf(dy) < 1.0e9f; // wave-uniform
-		PixVec<U, VEC> o;
-		if (small && x0 + VEC <= w_ && (((uintptr_t)d) & (sizeof(U) * VEC - 1)) == 0 &&
-			translate_chunk_interior<T, U, VEC>(s, w_, rows, x0, y, dx, dy, o.v))
+		bool done = !valid;
+		if (valid && small && x0 + VEC <= w_ && (((uintptr_t)d) & (sizeof(U) * VEC - 1)) == 0)
 		{
-			*reinterpret_cast<PixVec<U, VEC> *>(d) = o;
+			PixVec<U, VEC> o;
+			if (translate_chunk_interior<T, U, VEC>(s, w_, rows, x0, y, dx, dy, o.v))
+			{
+				*reinterpret_cast<PixVec<U, VEC> *>(d) = o;
+				done = true;
+			}
+		}
+		// Border chunks (a handful per wave: the ends of a row, the first / last rows) take the general per-pixel
+		// path.  Left to their own lanes they would run it 8 pixels in sequence while the other lanes of the wave
+		// wait; instead the wave handles them one chunk at a time with one pixel per lane.
+		const int lane = threadIdx.x & 63;
+		uint64_t todo = __ballot(!done);
+		if (__builtin_popcountll(todo) >= VEC)
+		{ // a wave full of border chunks (first / last rows): every lane walks its own chunk
+			if (!done)
+				for (int k = 0; k < VEC && x0 + k < w_; ++k)
+				{
+					U val;
+					const bool wr = small ? translate_px<T, U, true>(s, w, h, (uint64_t)(x0 + k), y, dx, dy, strategy, background, val)
+										  : translate_px<T, U, false>(s, w, h, (uint64_t)(x0 + k), y, dx, dy, strategy, background, val);
+					if (wr)
+						d[k] = val;
+				}
 			return;
 		}
-		bool wr[VEC];
-		bool all = true;
-#pragma unroll
-		for (int k = 0; k < VEC; ++k)
+		while (todo)
 		{
-			if (small)
-				wr[k] = (x0 + k < w_) && translate_px<T, U, true>(s, w, h, (uint64_t)(x0 + k), y, dx, dy, strategy, background, o.v[k]);
-			else
-				wr[k] = (x0 + k < w_) && translate_px<T, U, false>(s, w, h, (uint64_t)(x0 + k), y, dx, dy, strategy, background, o.v[k]);
-			all = all && wr[k];
-		}
-		if (all && (((uintptr_t)d) & (sizeof(U) * VEC - 1)) == 0)
-			*reinterpret_cast<PixVec<U, VEC> *>(d) = o;
-		else
-		{
-#pragma unroll
-			for (int k = 0; k < VEC; ++k)
-				if (wr[k])
-					d[k] = o.v[k];
+			const int src_lane = __builtin_ctzll(todo);
+			todo &= todo - 1;
+			const int cx = __shfl(x0, src_lane, 64) + lane, cy = __shfl(y, src_lane, 64);
+			if (lane < VEC && cx < w_)
+			{
+				U val;
+				const bool wr = small ? translate_px<T, U, true>(s, w, h, (uint64_t)cx, cy, dx, dy, strategy, background, val)
+									  : translate_px<T, U, false>(s, w, h, (uint64_t)cx, cy, dx, dy, strategy, background, val);
+				if (wr)
+					dst[fbase + (int64_t)cy * w_ + cx] = val;
+			}
 		}
 	}
 
@@ -357,52 +371,88 @@ namespace rir
 		constexpr int VEC = 8;
 		const int cpr = (w_ + VEC - 1) / VEC;
 		const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-		if (idx >= (int64_t)cpr * h_)
-			return;
-		const int y = (int)(idx / cpr);
-		const int x0 = (int)(idx - (int64_t)y * cpr) * VEC;
+		const bool valid = idx < (int64_t)cpr * h_;
+		const int y = valid ? (int)(idx / cpr) : 0;
+		const int x0 = valid ? (int)(idx - (int64_t)y * cpr) * VEC : 0;
 		const int n = blockIdx.y;
 		const int64_t fbase = (int64_t)n * w_ * h_;
 		const uint16_t *s = src + fbase;
 		uint16_t *d = dst + fbase + (int64_t)y * w_ + x0;
 		const float dx = -shifts[2 * n], dy = -shifts[2 * n + 1];
-		PixVec<uint16_t, VEC> o;
-		if (y < rows && x0 + VEC <= w_ && (((uintptr_t)d) & 15) == 0 && fabsf(dx) < 1.0e9f && fabsf(dy) < 1.0e9f)
+		const bool small = fabsf(dx) < 1.0e9f && fabsf(dy) < 1.0e9f;
+		bool done = !valid;
+		if (valid && x0 + VEC <= w_ && (((uintptr_t)d) & 15) == 0)
 		{
-			float val[VEC];
-			if (translate_chunk_interior<uint16_t, float, VEC>(s, w_, rows, x0, y, dx, dy, val))
-			{
-#pragma unroll
-				for (int k = 0; k < VEC; ++k)
-					o.v[k] = (uint16_t)(int32_t)val[k];
-				*reinterpret_cast<PixVec<uint16_t, VEC> *>(d) = o;
-				return;
-			}
-		}
-#pragma unroll
-		for (int k = 0; k < VEC; ++k)
-		{
-			o.v[k] = 0;
-			if (x0 + k < w_)
-			{
-				if (y >= rows)
-					o.v[k] = s[(int64_t)y * w_ + x0 + k]; // the last rows (camera metadata) are copied
-				else
+			PixVec<uint16_t, VEC> o;
+			if (y >= rows)
+			{ // the last rows (camera metadata) are copied
+				const uint16_t *sp = s + (int64_t)y * w_ + x0;
+				if ((((uintptr_t)sp) & 15) == 0)
 				{
-					float val = 0;
-					if (fabsf(dx) < 1.0e9f && fabsf(dy) < 1.0e9f)
-						translate_px<uint16_t, float, true>(s, (uint64_t)w_, (uint64_t)rows, (uint64_t)(x0 + k), y, dx, dy, TRANSLATE_NEAREST, 0.f, val);
-					else
-						translate_px<uint16_t, float, false>(s, (uint64_t)w_, (uint64_t)rows, (uint64_t)(x0 + k), y, dx, dy, TRANSLATE_NEAREST, 0.f, val);
-					o.v[k] = (uint16_t)(int32_t)val;
+					o = *reinterpret_cast<const PixVec<uint16_t, VEC> *>(sp);
+					*reinterpret_cast<PixVec<uint16_t, VEC> *>(d) = o;
+					done = true;
+				}
+			}
+			else if (small)
+			{
+				float val[VEC];
+				if (translate_chunk_interior<uint16_t, float, VEC>(s, w_, rows, x0, y, dx, dy, val))
+				{
+#pragma unroll
+					for (int k = 0; k < VEC; ++k)
+						o.v[k] = (uint16_t)(int32_t)val[k];
+					*reinterpret_cast<PixVec<uint16_t, VEC> *>(d) = o;
+					done = true;
 				}
 			}
 		}
-		if (x0 + VEC <= w_ && (((uintptr_t)d) & 15) == 0)
-			*reinterpret_cast<PixVec<uint16_t, VEC> *>(d) = o;
-		else
-			for (int k = 0; k < VEC && x0 + k < w_; ++k)
-				d[k] = o.v[k];
+		// border chunks: one chunk at a time, one pixel per lane (see translate_kernel)
+		const int lane = threadIdx.x & 63;
+		uint64_t todo = __ballot(!done);
+		if (__builtin_popcountll(todo) >= VEC)
+		{ // a wave full of border chunks: every lane walks its own chunk
+			if (!done)
+				for (int k = 0; k < VEC && x0 + k < w_; ++k)
+				{
+					uint16_t out;
+					if (y >= rows)
+						out = s[(int64_t)y * w_ + x0 + k];
+					else
+					{
+						float val = 0;
+						if (small)
+							translate_px<uint16_t, float, true>(s, (uint64_t)w_, (uint64_t)rows, (uint64_t)(x0 + k), y, dx, dy, TRANSLATE_NEAREST, 0.f, val);
+						else
+							translate_px<uint16_t, float, false>(s, (uint64_t)w_, (uint64_t)rows, (uint64_t)(x0 + k), y, dx, dy, TRANSLATE_NEAREST, 0.f, val);
+						out = (uint16_t)(int32_t)val;
+					}
+					d[k] = out;
+				}
+			return;
+		}
+		while (todo)
+		{
+			const int src_lane = __builtin_ctzll(todo);
+			todo &= todo - 1;
+			const int cx = __shfl(x0, src_lane, 64) + lane, cy = __shfl(y, src_lane, 64);
+			if (lane < VEC && cx < w_)
+			{
+				uint16_t out;
+				if (cy >= rows)
+					out = s[(int64_t)cy * w_ + cx];
+				else
+				{
+					float val = 0;
+					if (small)
+						translate_px<uint16_t, float, true>(s, (uint64_t)w_, (uint64_t)rows, (uint64_t)cx, cy, dx, dy, TRANSLATE_NEAREST, 0.f, val);
+					else
+						translate_px<uint16_t, float, false>(s, (uint64_t)w_, (uint64_t)rows, (uint64_t)cx, cy, dx, dy, TRANSLATE_NEAREST, 0.f, val);
+					out = (uint16_t)(int32_t)val;
+				}
+				dst[fbase + (int64_t)cy * w_ + cx] = out;
+			}
+		}
 	}
 
 	hipError_t launch_remove_motion(const uint16_t *src, uint16_t *dst, int w, int h, int rows, int nframes, const float *d_shifts, hipStream_t st)
@@ -1062,41 +1112,77 @@ namespace rir
 	// ---- 3x3 median filter (medianFilter<u16,u16>) -----------------------------------------------
 	__device__ __forceinline__ uint32_t med3(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
 
-	__global__ __launch_bounds__(256) void median3x3_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w, int h)
+	// one output pixel, any position (interior: median of 9; edges: median of 3 along the edge; corners: min of 2)
+	__device__ __forceinline__ uint16_t median3x3_px(const uint16_t *__restrict__ s, int w, int h, int x, int y)
 	{
-		const int x = blockIdx.x * blockDim.x + threadIdx.x;
-		const int y = blockIdx.y;
-		const int n = blockIdx.z;
-		if (x >= w)
-			return;
-		const uint16_t *s = src + (int64_t)n * w * h;
-		uint16_t *d = dst + (int64_t)n * w * h;
 		const int64_t o = x + (int64_t)y * w;
 		const bool row_edge = (y == 0 || y == h - 1), col_edge = (x == 0 || x == w - 1);
 		if (row_edge && col_edge)
-		{ // corners: min of the two pixels along the row
-			const int xn = x == 0 ? 1 : w - 2;
-			d[o] = min(s[o], s[xn + (int64_t)y * w]);
-		}
-		else if (row_edge)
-			d[o] = (uint16_t)med3(s[o - 1], s[o], s[o + 1]);
-		else if (col_edge)
-			d[o] = (uint16_t)med3(s[o - w], s[o], s[o + w]);
-		else
 		{
-			uint32_t v[9];
-#pragma unroll
-			for (int a = 0; a < 3; ++a)
-#pragma unroll
-				for (int b = 0; b < 3; ++b)
-					v[a * 3 + b] = s[o + (a - 1) * (int64_t)w + (b - 1)];
-			d[o] = rank_select9(v, 9);
+			const int xn = x == 0 ? 1 : w - 2;
+			return min(s[o], s[xn + (int64_t)y * w]);
 		}
+		if (row_edge)
+			return (uint16_t)med3(s[o - 1], s[o], s[o + 1]);
+		if (col_edge)
+			return (uint16_t)med3(s[o - w], s[o], s[o + w]);
+		uint32_t lo[3], mi[3], hi[3];
+#pragma unroll
+		for (int j = 0; j < 3; ++j)
+		{
+			const uint32_t a = s[o - w + j - 1], b = s[o + j - 1], c = s[o + w + j - 1];
+			lo[j] = min(min(a, b), c);
+			hi[j] = max(max(a, b), c);
+			mi[j] = med3(a, b, c);
+		}
+		return (uint16_t)med3(max(max(lo[0], lo[1]), lo[2]), med3(mi[0], mi[1], mi[2]), min(min(hi[0], hi[1]), hi[2]));
+	}
+
+	// 8 consecutive outputs per thread.  Interior chunks fetch their 3 x 10 window with dword loads, sort every
+	// column once (min / median / max of 3) and share the sorted columns between neighbouring outputs:
+	// median of 9 = med3(max of the column minima, median of the column medians, min of the column maxima).
+	__global__ __launch_bounds__(256) void median3x3_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w, int h)
+	{
+		constexpr int VEC = 8;
+		const int cpr = (w + VEC - 1) / VEC;
+		const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+		if (idx >= (int64_t)cpr * h)
+			return;
+		const int y = (int)(idx / cpr);
+		const int x0 = (int)(idx - (int64_t)y * cpr) * VEC;
+		const int64_t fbase = (int64_t)blockIdx.y * w * h;
+		const uint16_t *s = src + fbase;
+		uint16_t *d = dst + fbase + (int64_t)y * w + x0;
+		if (y >= 1 && y < h - 1 && x0 >= 1 && x0 + VEC + 3 <= w && (((uintptr_t)d) & 15) == 0)
+		{
+			uint16_t r0[VEC + 2], r1[VEC + 2], r2[VEC + 2];
+			load_taps<uint16_t, VEC + 2>(s + (int64_t)(y - 1) * w + x0 - 1, r0);
+			load_taps<uint16_t, VEC + 2>(s + (int64_t)y * w + x0 - 1, r1);
+			load_taps<uint16_t, VEC + 2>(s + (int64_t)(y + 1) * w + x0 - 1, r2);
+			uint32_t lo[VEC + 2], mi[VEC + 2], hi[VEC + 2];
+#pragma unroll
+			for (int j = 0; j < VEC + 2; ++j)
+			{
+				const uint32_t a = r0[j], b = r1[j], c = r2[j];
+				lo[j] = min(min(a, b), c);
+				hi[j] = max(max(a, b), c);
+				mi[j] = med3(a, b, c);
+			}
+			PixVec<uint16_t, VEC> o;
+#pragma unroll
+			for (int k = 0; k < VEC; ++k)
+				o.v[k] = (uint16_t)med3(max(max(lo[k], lo[k + 1]), lo[k + 2]), med3(mi[k], mi[k + 1], mi[k + 2]), min(min(hi[k], hi[k + 1]), hi[k + 2]));
+			*reinterpret_cast<PixVec<uint16_t, VEC> *>(d) = o;
+			return;
+		}
+		for (int k = 0; k < VEC && x0 + k < w; ++k)
+			d[k] = median3x3_px(s, w, h, x0 + k, y);
 	}
 
 	hipError_t launch_median3x3(const uint16_t *src, uint16_t *dst, int w, int h, int nframes, hipStream_t st)
 	{
-		hipLaunchKernelGGL(median3x3_kernel, dim3((w + 255) / 256, h, nframes), dim3(256), 0, st, src, dst, w, h);
+		const int64_t chunks = (int64_t)((w + 7) / 8) * h;
+		hipLaunchKernelGGL(median3x3_kernel, dim3((unsigned)((chunks + 255) / 256), nframes), dim3(256), 0, st, src, dst, w, h);
 		return hipGetLastError();
 	}
 
