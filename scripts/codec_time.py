@@ -52,7 +52,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 h, w = 512, 640
 fr = s1_noisy_background(n, h, w)
 t = torch.from_numpy(fr).cuda()
-ctx = D.CodecContext(w, h, n, 50)
+ctx = D.CodecContext(w, h, n, int(os.environ.get("RIR_GOP", "50")))
 out = torch.empty_like(t)
 for _ in range(3):
     enc = ctx.encode(t)
