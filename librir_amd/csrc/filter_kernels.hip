@@ -512,55 +512,62 @@ namespace rir
 	// pixel at R = 4) into a streaming one.  Same mathematics as the reference, different rounding: results
 	// agree to a few 1e-7 relative (the parity bar for float32 filters is 1e-5, BASELINE.json); border pixels
 	// are renormalised by the in-image weight, Sx(x) * Sy(y), as the reference does with its 2-D sum.
-	// A 256-thread workgroup produces a 64 x 32 output tile from a (64+2R) x (32+2R) input tile staged in LDS.
-	// TIN = float, or uint16_t (the integer -> float conversion of a u16 frame folded into the tile load).
+	// Each WAVE works alone on a tile of 64 columns (the outer R on each side are halo) x TY rows: every lane
+	// owns one column, fetches its TY + 2R values with back-to-back independent loads (row-coalesced across the
+	// lanes) and does the COLUMN pass in registers; the column sums go to a wave-private LDS strip and the ROW
+	// pass reads the 2R+1 neighbours from there.  No workgroup barrier, no staged copy of the input: the time
+	// of the earlier tile-staging version was set by its load / barrier / compute phases (0.25 ms per 256
+	// frames whatever the radius).
+#ifndef RIR_GAUSS_TY
+#define RIR_GAUSS_TY 16 /* output rows per wave tile */
+#endif
+	// TIN = float, or uint16_t (the integer -> float conversion of a u16 frame folded into the load).
 	template <int R, class TIN>
 	__global__ __launch_bounds__(256) void gaussian_sep_kernel(const TIN *__restrict__ src, float *__restrict__ dst, int w, int h,
 															   const float *__restrict__ kern)
 	{
-		constexpr int TX = 64, TY = 32, KW = 2 * R + 1, LW = TX + 2 * R, LH = TY + 2 * R;
-		__shared__ float tile[LH][LW];
-		__shared__ float rowp[LH][TX];
-		__shared__ float a[KW];
-		const int tid = threadIdx.x;
-		const int tx = tid & 63, ty = tid >> 6;
-		const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+		constexpr int TY = RIR_GAUSS_TY, KW = 2 * R + 1, OUTW = 64 - 2 * R;
+		__shared__ float colp[4][TY][64];
+		const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+		const int x = blockIdx.x * OUTW - R + lane;			 // this lane's column (halo lanes may fall outside the image)
+		const int y0 = (blockIdx.y * 4 + wv) * TY;			 // first output row of this wave
+		if (y0 >= h)
+			return;
 		const int64_t fbase = (int64_t)blockIdx.z * w * h;
 		const TIN *s = src + fbase;
-		// stage the input tile: each wave walks rows, lane = column (coalesced 256-byte rows), the first 2R lanes
-		// also fetch the right-hand halo columns
-		for (int ly = ty; ly < LH; ly += 4)
+		float a[KW];
+#pragma unroll
+		for (int d = 0; d < KW; ++d)
+			a[d] = kern[KW * KW + d];
+		const bool xin = x >= 0 && x < w;
+		float v[TY + 2 * R];
+#pragma unroll
+		for (int i = 0; i < TY + 2 * R; ++i)
 		{
-			const int gy = y0 - R + ly;
-			const bool yin = gy >= 0 && gy < h;
-			const TIN *row = s + (int64_t)gy * w;
-			const int gx = x0 - R + tx;
-			tile[ly][tx] = (yin && gx >= 0 && gx < w) ? (float)row[gx] : 0.f;
-			if (tx < 2 * R)
-			{
-				const int gx2 = gx + TX;
-				tile[ly][tx + TX] = (yin && gx2 >= 0 && gx2 < w) ? (float)row[gx2] : 0.f;
-			}
+			const int gy = y0 - R + i;
+			v[i] = (xin && gy >= 0 && gy < h) ? (float)s[x + (int64_t)gy * w] : 0.f; // zeros outside the image add nothing
 		}
-		if (tid < KW)
-			a[tid] = kern[KW * KW + tid];
-		__syncthreads();
-		// row pass: LH rows x TX columns (zeros outside the image add nothing)
-		for (int ly = ty; ly < LH; ly += 4)
+#pragma unroll
+		for (int j = 0; j < TY; ++j)
 		{
 			float acc = 0.f;
 #pragma unroll
 			for (int d = 0; d < KW; ++d)
-				acc = fmaf(a[d], tile[ly][tx + d], acc);
-			rowp[ly][tx] = acc;
+				acc = fmaf(a[d], v[j + d], acc);
+			colp[wv][j][lane] = acc;
 		}
-		__syncthreads();
-		const int x = x0 + tx;
-		if (x >= w)
-			return;
-		// in-image weight of the row taps of this column (1 in the interior)
-		float sx = 1.f;
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (lane < R || lane >= 64 - R || x >= w)
+			return; // halo lanes, and columns past the right edge, have no output
+		// in-image weight of the row taps of this column, and the full 1-D sum (not exactly 1)
+		float full = 0.f;
+#pragma unroll
+		for (int d = 0; d < KW; ++d)
+			full += a[d];
 		const bool xb = x < R || x >= w - R;
+		float sx = full;
 		if (xb)
 		{
 			sx = 0.f;
@@ -570,19 +577,19 @@ namespace rir
 					sx += a[d + R];
 		}
 #pragma unroll
-		for (int j = 0; j < TY / 4; ++j)
+		for (int j = 0; j < TY; ++j)
 		{
-			const int ly = ty + 4 * j, y = y0 + ly;
+			const int y = y0 + j;
 			if (y >= h)
 				break;
 			float acc = 0.f;
 #pragma unroll
 			for (int d = 0; d < KW; ++d)
-				acc = fmaf(a[d], rowp[ly + d][tx], acc);
+				acc = fmaf(a[d], colp[wv][j][lane - R + d], acc);
 			const bool yb = y < R || y >= h - R;
 			if (xb || yb)
-			{
-				float sy = 1.f;
+			{ // border pixels are renormalised by the weight of the taps that fall inside the image
+				float sy = full;
 				if (yb)
 				{
 					sy = 0.f;
@@ -591,12 +598,7 @@ namespace rir
 						if (y + d >= 0 && y + d < h)
 							sy += a[d + R];
 				}
-				// interior rows / columns of a border pixel still carry the full 1-D weight sum, which is not exactly 1
-				float full = 0.f;
-#pragma unroll
-				for (int d = 0; d < KW; ++d)
-					full += a[d];
-				acc = acc / ((xb ? sx : full) * (yb ? sy : full));
+				acc = acc / (sx * sy);
 			}
 			dst[fbase + x + (int64_t)y * w] = acc;
 		}
@@ -605,7 +607,10 @@ namespace rir
 	template <class TIN>
 	static bool launch_gaussian_sep(const TIN *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st)
 	{
-		dim3 block(256), tgrid((w + 63) / 64, (h + 31) / 32, nframes);
+		if (radius < 1 || radius > 4)
+			return false;
+		const int outw = 64 - 2 * radius;
+		dim3 block(256), tgrid((w + outw - 1) / outw, (h + 4 * RIR_GAUSS_TY - 1) / (4 * RIR_GAUSS_TY), nframes);
 		switch (radius)
 		{
 		case 1:
@@ -617,11 +622,9 @@ namespace rir
 		case 3:
 			hipLaunchKernelGGL((gaussian_sep_kernel<3, TIN>), tgrid, block, 0, st, src, dst, w, h, d_kernel);
 			return true;
-		case 4:
+		default:
 			hipLaunchKernelGGL((gaussian_sep_kernel<4, TIN>), tgrid, block, 0, st, src, dst, w, h, d_kernel);
 			return true;
-		default:
-			return false;
 		}
 	}
 
