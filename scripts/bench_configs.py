@@ -206,6 +206,26 @@ sh = torch.from_numpy(shifts.astype(np.float32)).to(dev)
 ms = gpu_ms(lambda: D.remove_motion(t4, sh, rows=h - 3), 5)
 c4 = {"workload": "%d x %dx%d float32 S3 (known shifts): motion correction, then bounded-loss recording (low=high=3, stdFactor 0)" % (n4, w, h),
       "motion_correction_device_resident_fps": n4 / ms * 1e3}
+# registration itself: MaskedRegistratorECC (gaussian + normalisation on the host side, ECC iterations on the device)
+from librir_amd.registration import MaskedRegistratorECC  # noqa: E402
+
+nreg = 30 if args.quick else 100
+regr = MaskedRegistratorECC(1, 1)
+regr.start(f32[0])
+t0 = time.perf_counter()
+for i in range(1, nreg):
+    regr.compute(f32[i])
+c4["registration_ecc_per_frame_fps"] = (nreg - 1) / (time.perf_counter() - t0)
+c4["registration_max_error_px"] = float(max(np.abs(np.array(regr.x) - shifts[:nreg, 0]).max(), np.abs(np.array(regr.y) - shifts[:nreg, 1]).max()))
+
+
+def _norm(a):
+    return (a - a.min()) / (a.max() - a.min())
+
+
+_ref0 = _norm(O.gaussian_filter(f32[0], 0.5))
+_im1 = _norm(O.gaussian_filter(f32[1], 0.5))
+c4["cpu_port_ecc_fps_1thread"] = cpu_fps(lambda: O.ecc_translation(_ref0, _im1, (0.0, 0.0)), 1, budget=4.0)
 reg = D.remove_motion(t4, sh, rows=h - 3).cpu().numpy()
 with tempfile.TemporaryDirectory() as d:
     dst = os.path.join(d, "lossy.h264")
