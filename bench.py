@@ -222,8 +222,11 @@ def main():
             kv["GBs"] = kv["alg_bytes"] / (kv["ms"] * 1e-3) / 1e9
         dom = max(("rirb1_encode_tiles", "rirb1_decode_tiles"), key=lambda k_: kernels[k_]["ms"])
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):
+        import glob
+
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))  # the latest round's PMC pass
+        tpath = tfiles[-1] if tfiles else ""
+        if tpath:
             try:
                 traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:

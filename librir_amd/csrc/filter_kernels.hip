@@ -25,6 +25,17 @@
 
 namespace rir
 {
+	// XCD-aware workgroup order.  The dispatcher deals workgroups round-robin to the 8 XCDs of the MI355X, each
+	// with its own L2: neighbours in the launch order never share a cache.  Re-reading the linear id "XCD-major"
+	// (XCD k owns the k-th eighth of the logical order) makes logical neighbours - tiles that share halo rows -
+	// run on the same XCD one after the other.  Measured on gaussian_filter: 0.173 -> 0.131 ms per 256 frames; the
+	// VALU-bound kernels (translate, median) gain nothing from it and keep the plain order.
+	__device__ __forceinline__ unsigned xcd_major(unsigned id, unsigned total)
+	{
+		const unsigned per = total / 8u;
+		return id < per * 8u ? (id % 8u) * per + id / 8u : id;
+	}
+
 
 	// ---- translate ------------------------------------------------------------------------------
 
@@ -529,11 +540,21 @@ namespace rir
 		constexpr int TY = RIR_GAUSS_TY, KW = 2 * R + 1, OUTW = 64 - 2 * R;
 		__shared__ float colp[4][TY][64];
 		const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-		const int x = blockIdx.x * OUTW - R + lane;			 // this lane's column (halo lanes may fall outside the image)
-		const int y0 = (blockIdx.y * 4 + wv) * TY;			 // first output row of this wave
+		// XCD-aware tile order (xcd_major), then (frame, column strip, row band) with the row band fastest:
+		// vertically adjacent tiles, which share 2R halo rows, run on the same XCD back to back.
+		int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+		{
+			const unsigned gx = gridDim.x, gy = gridDim.y;
+			const unsigned id2 = xcd_major(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+			by = (int)(id2 % gy);
+			bx = (int)((id2 / gy) % gx);
+			bz = (int)(id2 / (gy * gx));
+		}
+		const int x = bx * OUTW - R + lane;			 // this lane's column (halo lanes may fall outside the image)
+		const int y0 = (by * 4 + wv) * TY;			 // first output row of this wave
 		if (y0 >= h)
 			return;
-		const int64_t fbase = (int64_t)blockIdx.z * w * h;
+		const int64_t fbase = (int64_t)bz * w * h;
 		const TIN *s = src + fbase;
 		float a[KW];
 #pragma unroll
