@@ -104,6 +104,16 @@ extern "C"
 	/* 3x3 median filter: reference Filters.h:71-129 (template without C export upstream). */
 	int rir_median_filter_device(const unsigned short *d_src, unsigned short *d_dst, int w, int h, int nframes, void *stream);
 
+	/* ---- byte planes ------------------------------------------------------------------------------
+	 * H264Capture::AddFrame (reference src/cpp/video_io/h264.cpp:1066-1082): U = v & 0xFF, V = v >> 8, Y = 0 or
+	 * the 8-bit integration-time image, rows padded to `linesize`; VideoGrabber::toArray (:3016-3051) is the
+	 * inverse.  Not on this build's own codec path (the block codec works on the 16-bit values); provided for
+	 * callers that feed / read an external 8-bit plane codec.  Planes: [nframes][h][linesize]; d_it may be NULL. */
+	int rir_split_planes_device(const unsigned short *d_img, const unsigned char *d_it, int w, int h, int nframes, int linesize,
+								unsigned char *d_Y, unsigned char *d_U, unsigned char *d_V, void *stream);
+	int rir_merge_planes_device(const unsigned char *d_Y, const unsigned char *d_U, const unsigned char *d_V, int linesize, int w, int h,
+								int nframes, unsigned short *d_img, unsigned char *d_it, void *stream);
+
 	/* ---- registration ---------------------------------------------------------------------------
 	 * Translation-only ECC alignment, the arithmetic the reference obtains from OpenCV:
 	 * cv2.findTransformECC(templ, image, warp, MOTION_TRANSLATION, (EPS|COUNT, max_iterations, eps), mask, 1)

@@ -28,6 +28,10 @@ namespace rir
 	hipError_t launch_bad_pixels_stats(const uint32_t *d_hist, uint64_t size, int64_t *d_out, hipStream_t st);
 	hipError_t launch_bad_pixels_detect(const uint16_t *src, int w, int h, double std_factor, int floor_detect, uint8_t *d_flags, hipStream_t st);
 	hipError_t launch_median3x3(const uint16_t *src, uint16_t *dst, int w, int h, int nframes, hipStream_t st);
+	hipError_t launch_split_planes(const uint16_t *img, const uint8_t *it, int w, int h, int nframes, int linesize, uint8_t *Y, uint8_t *U,
+								   uint8_t *V, hipStream_t st);
+	hipError_t launch_merge_planes(const uint8_t *Y, const uint8_t *U, const uint8_t *V, int linesize, int w, int h, int nframes, uint16_t *img,
+								   uint8_t *it, hipStream_t st);
 	hipError_t launch_u16_to_f32(const uint16_t *src, float *dst, int64_t total, hipStream_t st);
 
 	// codec_kernels.hip

@@ -1210,6 +1210,82 @@ namespace rir
 		return hipGetLastError();
 	}
 
+	// ---- byte-plane split / merge (H264Capture::AddFrame h264.cpp:1066-1082, VideoGrabber::toArray :3016-3051) ----
+	// The reference hands a 16-bit frame to its video codec as three 8-bit planes with a row stride (`linesize`):
+	// U = v & 0xFF, V = v >> 8, Y = 0 or the 8-bit integration-time image.  This build's codec does not need the
+	// planes; the two kernels exist for callers that feed / read an external 8-bit plane codec.  8 pixels per lane.
+	__global__ __launch_bounds__(256) void split_planes_kernel(const uint16_t *__restrict__ img, const uint8_t *__restrict__ it, int w, int h,
+															   int linesize, uint8_t *__restrict__ Y, uint8_t *__restrict__ U, uint8_t *__restrict__ V)
+	{
+		const int cpr = (w + 7) / 8;
+		const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+		if (idx >= (int64_t)cpr * h)
+			return;
+		const int y = (int)(idx / cpr), x0 = (int)(idx - (int64_t)y * cpr) * 8;
+		const int64_t fi = (int64_t)blockIdx.y * w * h, fo = (int64_t)blockIdx.y * linesize * h;
+		const uint16_t *s = img + fi + (int64_t)y * w + x0;
+		const int64_t o = fo + (int64_t)y * linesize + x0;
+		if (x0 + 8 <= w && ((((uintptr_t)s) & 15) == 0) && ((o & 7) == 0) && (((uintptr_t)U | (uintptr_t)V | (uintptr_t)Y) & 7) == 0 &&
+			(!it || ((((uintptr_t)(it + fi + (int64_t)y * w + x0)) & 7) == 0)))
+		{
+			const uint4 v = *reinterpret_cast<const uint4 *>(s);
+			const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+			uint32_t lo[2] = {0, 0}, hi[2] = {0, 0};
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+			{
+				// bytes (b0 b1 | b2 b3) of a dword = (lo0 hi0 | lo1 hi1): gather the low and the high bytes of 4 dwords
+				lo[k >> 1] |= ((d[k] & 0xffu) | ((d[k] >> 8) & 0xff00u)) << (16 * (k & 1));
+				hi[k >> 1] |= (((d[k] >> 8) & 0xffu) | ((d[k] >> 16) & 0xff00u)) << (16 * (k & 1));
+			}
+			*reinterpret_cast<uint2 *>(U + o) = make_uint2(lo[0], lo[1]);
+			*reinterpret_cast<uint2 *>(V + o) = make_uint2(hi[0], hi[1]);
+			*reinterpret_cast<uint2 *>(Y + o) = it ? *reinterpret_cast<const uint2 *>(it + fi + (int64_t)y * w + x0) : make_uint2(0, 0);
+			return;
+		}
+		for (int k = 0; k < 8 && x0 + k < w; ++k)
+		{
+			const uint16_t v = s[k];
+			U[o + k] = (uint8_t)(v & 0xff);
+			V[o + k] = (uint8_t)(v >> 8);
+			Y[o + k] = it ? it[fi + (int64_t)y * w + x0 + k] : (uint8_t)0;
+		}
+	}
+
+	__global__ __launch_bounds__(256) void merge_planes_kernel(const uint8_t *__restrict__ Y, const uint8_t *__restrict__ U, const uint8_t *__restrict__ V,
+															   int linesize, int w, int h, uint16_t *__restrict__ img, uint8_t *__restrict__ it)
+	{
+		const int cpr = (w + 7) / 8;
+		const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+		if (idx >= (int64_t)cpr * h)
+			return;
+		const int y = (int)(idx / cpr), x0 = (int)(idx - (int64_t)y * cpr) * 8;
+		const int64_t fo = (int64_t)blockIdx.y * w * h, fi = (int64_t)blockIdx.y * linesize * h;
+		const int64_t i = fi + (int64_t)y * linesize + x0;
+		uint16_t *d = img + fo + (int64_t)y * w + x0;
+		for (int k = 0; k < 8 && x0 + k < w; ++k)
+		{
+			d[k] = (uint16_t)(U[i + k] | (V[i + k] << 8));
+			if (it)
+				it[fo + (int64_t)y * w + x0 + k] = Y[i + k];
+		}
+	}
+
+	hipError_t launch_split_planes(const uint16_t *img, const uint8_t *it, int w, int h, int nframes, int linesize, uint8_t *Y, uint8_t *U,
+								   uint8_t *V, hipStream_t st)
+	{
+		const int64_t chunks = (int64_t)((w + 7) / 8) * h;
+		hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((chunks + 255) / 256), nframes), dim3(256), 0, st, img, it, w, h, linesize, Y, U, V);
+		return hipGetLastError();
+	}
+	hipError_t launch_merge_planes(const uint8_t *Y, const uint8_t *U, const uint8_t *V, int linesize, int w, int h, int nframes, uint16_t *img,
+								   uint8_t *it, hipStream_t st)
+	{
+		const int64_t chunks = (int64_t)((w + 7) / 8) * h;
+		hipLaunchKernelGGL(merge_planes_kernel, dim3((unsigned)((chunks + 255) / 256), nframes), dim3(256), 0, st, Y, U, V, linesize, w, h, img, it);
+		return hipGetLastError();
+	}
+
 	// ---- u16 -> f32 (load_imageF) ---------------------------------------------------------------
 	__global__ __launch_bounds__(256) void u16_to_f32_kernel(const uint16_t *__restrict__ src, float *__restrict__ dst, int64_t total)
 	{

@@ -292,6 +292,33 @@ RIR_EXPORT int rir_translate_f32_u16_device(const float *d_src, unsigned short *
 	return hip_ok(launch_translate('F', d_src, d_dst, background, w, h, nframes, d_offsets, per_frame_offsets, s, as_stream(stream)), "translate") ? 0 : -1;
 }
 
+// Byte planes of 16-bit frames as the reference hands them to its video codec (h264.cpp:1066-1082) and back (:3016-3051).
+// Planes are [nframes][h][linesize] bytes, linesize >= w; d_it (8-bit integration-time image, [nframes][h][w]) may be NULL.
+RIR_EXPORT int rir_split_planes_device(const unsigned short *d_img, const unsigned char *d_it, int w, int h, int nframes, int linesize,
+									   unsigned char *d_Y, unsigned char *d_U, unsigned char *d_V, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (!d_img || !d_Y || !d_U || !d_V || w <= 0 || h <= 0 || nframes <= 0 || linesize < w)
+	{
+		log_error("rir_split_planes_device: invalid argument");
+		return -1;
+	}
+	return hip_ok(launch_split_planes(d_img, d_it, w, h, nframes, linesize, d_Y, d_U, d_V, as_stream(stream)), "split_planes") ? 0 : -1;
+}
+RIR_EXPORT int rir_merge_planes_device(const unsigned char *d_Y, const unsigned char *d_U, const unsigned char *d_V, int linesize, int w, int h,
+									   int nframes, unsigned short *d_img, unsigned char *d_it, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (!d_img || !d_U || !d_V || (d_it && !d_Y) || w <= 0 || h <= 0 || nframes <= 0 || linesize < w)
+	{
+		log_error("rir_merge_planes_device: invalid argument");
+		return -1;
+	}
+	return hip_ok(launch_merge_planes(d_Y, d_U, d_V, linesize, w, h, nframes, d_img, d_it, as_stream(stream)), "merge_planes") ? 0 : -1;
+}
+
 // result: int32[nframes] on the device.  d_hist: unused (kept in the signature; may be NULL).
 RIR_EXPORT int rir_find_median_pixel_device(const unsigned short *d_img, const unsigned char *d_mask, int size, int nframes, float percent,
 											int *d_result, unsigned int *d_hist, void *stream)

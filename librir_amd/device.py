@@ -77,6 +77,8 @@ _lib.rir_remove_bad_pixels_device.argtypes = [ct.c_int, _vp, ct.c_int, ct.c_int,
 _lib.rir_remove_motion_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp]
 _lib.rir_median_filter_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp]
 _lib.bad_pixels_destroy.argtypes = [ct.c_int]
+_lib.rir_split_planes_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp]
+_lib.rir_merge_planes_device.argtypes = [_vp, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.bad_pixels_destroy.restype = None
 
 
@@ -325,3 +327,30 @@ def median_filter(frames):
     out = torch.empty_like(fr)
     _check(_lib.rir_median_filter_device(fr.data_ptr(), out.data_ptr(), w, h, n, _stream()), "rir_median_filter_device")
     return out
+
+
+def split_planes(frames, linesize=None, it=None):
+    """uint16 frames -> (Y, U, V) byte planes [n][h][linesize] (reference h264.cpp:1066-1082)."""
+    fr = _frames3(frames, torch.uint16)
+    n, h, w = fr.shape
+    ls = w if linesize is None else int(linesize)
+    Y, U, V = (torch.zeros((n, h, ls), dtype=torch.uint8, device=fr.device) for _ in range(3))
+    itp = None
+    if it is not None:
+        it = _frames3(it, torch.uint8)
+        itp = it.data_ptr()
+    _check(_lib.rir_split_planes_device(fr.data_ptr(), itp, w, h, n, ls, Y.data_ptr(), U.data_ptr(), V.data_ptr(), _stream()), "rir_split_planes_device")
+    return Y, U, V
+
+
+def merge_planes(Y, U, V, width, with_it=False):
+    """(Y, U, V) byte planes -> uint16 frames (and the 8-bit image carried by Y) (reference h264.cpp:3016-3051)."""
+    U = _frames3(U, torch.uint8)
+    V = _frames3(V, torch.uint8)
+    n, h, ls = U.shape
+    img = torch.empty((n, h, width), dtype=torch.uint16, device=U.device)
+    it = torch.empty((n, h, width), dtype=torch.uint8, device=U.device) if with_it else None
+    Yp = _frames3(Y, torch.uint8).data_ptr() if Y is not None else None
+    _check(_lib.rir_merge_planes_device(Yp, U.data_ptr(), V.data_ptr(), ls, width, h, n, img.data_ptr(), it.data_ptr() if with_it else None,
+                                        _stream()), "rir_merge_planes_device")
+    return (img, it) if with_it else img

@@ -106,6 +106,28 @@ class Oracle(_SignalProcessingMixin):
         L.orc_gaussian_radius.restype = ct.c_int
         L.orc_clamp_min.argtypes = [ct.c_void_p, ct.c_int, ct.c_uint16]
 
+    # ---- byte planes (C1 / C2) -------------------------------------------------------------------
+    def split_planes(self, image, linesize=None, it=None):
+        img = np.ascontiguousarray(image, dtype=np.uint16)
+        h, w = img.shape
+        ls = w if linesize is None else int(linesize)
+        Y, U, V = (np.zeros((h, ls), np.uint8) for _ in range(3))
+        itp = None if it is None else _p(np.ascontiguousarray(it, dtype=np.uint8))
+        self.lib.orc_split_planes.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_void_p]
+        self.lib.orc_split_planes(_p(img), w, h, _p(Y), _p(U), _p(V), ls, itp)
+        return Y, U, V
+
+    def merge_planes(self, Y, U, V, width, with_it=False):
+        U = np.ascontiguousarray(U, dtype=np.uint8)
+        V = np.ascontiguousarray(V, dtype=np.uint8)
+        Y = np.ascontiguousarray(Y, dtype=np.uint8)
+        h, ls = U.shape
+        img = np.zeros((h, width), np.uint16)
+        it = np.zeros((h, width), np.uint8)
+        self.lib.orc_merge_planes.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p]
+        self.lib.orc_merge_planes(_p(Y), _p(U), _p(V), ls, width, h, _p(img), _p(it) if with_it else None)
+        return (img, it) if with_it else img
+
     # ---- registration ---------------------------------------------------------------------------
     def ecc_translation(self, templ, image, warp=(0.0, 0.0), mask=None, max_iter=500, eps=1e-3):
         """-> (tx, ty, cc, iterations); raises RuntimeError where OpenCV would."""

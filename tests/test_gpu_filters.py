@@ -172,3 +172,24 @@ def test_translate_all_dtypes_vs_oracle(dev, oracle):
             for (dx, dy) in [(0.4, -0.6), (-w - 2.5, h + 1.5), (2, 2)]:
                 g = dev.translate(t, (dx, dy), strat, background=1).cpu().numpy()[0]
                 assert np.array_equal(g, oracle.translate(img, dx, dy, strat, background=1)), (dt, strat, dx, dy)
+
+
+@pytest.mark.parametrize("shape,linesize", [((512, 640), 640), ((67, 83), 96), ((48, 64), 64)])
+def test_byte_planes_vs_oracle(dev, oracle, shape, linesize):
+    """C1 / C2: split into the codec's 8-bit planes and back (reference h264.cpp:1066-1082, :3016-3051)."""
+    import torch
+
+    h, w = shape
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 65536, (3, h, w)).astype(np.uint16)
+    it = rng.integers(0, 256, (3, h, w)).astype(np.uint8)
+    t, ti = torch.from_numpy(img).cuda(), torch.from_numpy(it).cuda()
+    for use_it in (False, True):
+        Y, U, V = dev.split_planes(t, linesize, ti if use_it else None)
+        for i in range(3):
+            Yo, Uo, Vo = oracle.split_planes(img[i], linesize, it[i] if use_it else None)
+            assert np.array_equal(Y[i].cpu().numpy(), Yo) and np.array_equal(U[i].cpu().numpy(), Uo) and np.array_equal(V[i].cpu().numpy(), Vo)
+        back, it2 = dev.merge_planes(Y, U, V, w, with_it=True)
+        assert torch.equal(back.view(torch.int16), t.view(torch.int16))
+        if use_it:
+            assert torch.equal(it2, ti)

@@ -174,3 +174,15 @@ def test_oracle_vs_ref_misc(oracle, ref):
     _, fc = oracle.bad_pixels_stats(first)
     assert np.array_equal(oracle.bad_pixels_correct(second, xy, fc), ref.bad_pixels_correct(first, second))
     assert max(fc, 0) == ref.bad_pixels_floor(first)
+
+
+def test_byte_plane_split_merge_known_answer(oracle):
+    """C1 / C2 (h264.cpp:1066-1082, :3016-3051): U = v & 0xFF, V = v >> 8, Y = 0 or the 8-bit IT image, rows padded."""
+    img = np.array([[0x0102, 0xFFFE, 0x8000], [0x00FF, 0x1234, 0x0000]], np.uint16)
+    Y, U, V = oracle.split_planes(img, linesize=5)
+    assert U[:, :3].tolist() == [[0x02, 0xFE, 0x00], [0xFF, 0x34, 0x00]] and V[:, :3].tolist() == [[0x01, 0xFF, 0x80], [0x00, 0x12, 0x00]]
+    assert not Y.any() and not U[:, 3:].any()
+    it = np.array([[1, 2, 3], [4, 5, 6]], np.uint8)
+    Y, U, V = oracle.split_planes(img, linesize=4, it=it)
+    back, it2 = oracle.merge_planes(Y, U, V, 3, with_it=True)
+    assert np.array_equal(back, img) and np.array_equal(it2, it)
