@@ -114,3 +114,26 @@ def test_malformed_stream_is_rejected(oracle):
     short[-1] -= 1  # table says the last segment is one word shorter than its headers need
     with pytest.raises(RuntimeError):
         oracle.codec_decode_chunk(hdr, short, stream, 64, 8)
+
+
+def test_format_is_frozen(oracle):
+    """tests/golden/codec_format.json pins the RIRB1 bitstream across rounds (not a reference output: the format is
+    this build's own): the oracle must reproduce the stored hashes and the verbatim tiny stream."""
+    import json
+    import os
+    import sys
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, here)
+    import make_codec_golden as G
+
+    fix = json.load(open(os.path.join(here, "codec_format.json")))
+    for name, fr in G.streams():
+        hdr, off, st = oracle.codec_encode_chunk(fr)
+        c = fix["cases"][name]
+        assert (G.digest(hdr), G.digest(off), G.digest(st), int(st.size)) == (c["hdr"], c["tile_off"], c["stream"], c["words"]), name
+    t = fix["tiny_2x1x4"]
+    hdr, off, st = oracle.codec_encode_chunk(np.array(t["frames"], np.uint16))
+    assert [int(x) for x in hdr.ravel()] == t["hdr"] and [int(x) for x in off.ravel()] == t["tile_off"] and [int(x) for x in st.ravel()] == t["stream"]
+    dec = oracle.codec_decode_chunk(np.array(t["hdr"], np.uint64).reshape(hdr.shape), np.array(t["tile_off"], np.uint32), np.array(t["stream"], np.uint64), 4, 1)
+    assert dec.tolist() == t["frames"]

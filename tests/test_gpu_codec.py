@@ -146,3 +146,28 @@ def test_argument_errors(dev):
         ctx.encode(torch.zeros((4, 32, 65), dtype=torch.uint16, device="cuda"))
     with pytest.raises(RuntimeError):
         ctx.encode(torch.zeros((4, 32, 64), dtype=torch.int16, device="cuda"))
+
+
+def test_gpu_encoder_reproduces_the_frozen_format(dev):
+    """The GPU encoder against tests/golden/codec_format.json directly (hashes of tables and payload)."""
+    import json
+    import os
+    import sys
+
+    import torch
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, here)
+    import make_codec_golden as G
+
+    fix = json.load(open(os.path.join(here, "codec_format.json")))
+    for name, fr in G.streams():
+        n, h, w = fr.shape
+        ctx = dev.CodecContext(w, h, n, max(n, 1))
+        enc = ctx.encode(torch.from_numpy(fr).cuda())
+        words = int(enc.total_words())
+        hdr = enc.hdr.cpu().numpy().view(np.uint64)[0][:, :n]
+        off = enc.tile_off.cpu().numpy().view(np.uint32)[0]
+        st = enc.stream.cpu().numpy().view(np.uint64)[:words]
+        c = fix["cases"][name]
+        assert (G.digest(hdr), G.digest(off), G.digest(st), words) == (c["hdr"], c["tile_off"], c["stream"], c["words"]), name
