@@ -2,8 +2,9 @@
  * TEST INFRASTRUCTURE — CPU oracle for the librir hot path.  NOT part of the product.
  *
  * Plain-C restatement (written from the behaviour of the reference, not copied) of the arithmetic
- * on the path named by BASELINE.json `north_star`.  Only tests/, __graft_entry__.smoke() and
- * bench.py's cpu_baseline leg may load this library; the product (librir_amd/csrc) never does.
+ * on the path named by BASELINE.json `north_star`.  Only tests/ (the parity tests and the measurement
+ * scripts under tests/perf), __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (librir_amd/) and the tools under scripts/ never do.
  *
  * Pinning: every function in the "signal_processing" half is checked bit-for-bit (integers) or
  * bit-for-bit/1e-5 (float) against the UNMODIFIED reference C++ compiled into oracle/_ref

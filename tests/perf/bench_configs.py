@@ -6,7 +6,7 @@
 next to the CPU path on the host cores (the compiled reference oracle/_ref for the filters, the oracle
 port for the codec; single thread, like the reference's own execution).  One JSON document on stdout.
 
-    python scripts/bench_configs.py [--quick]
+    python tests/perf/bench_configs.py [--quick]
 """
 import argparse
 import json
@@ -18,7 +18,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from librir_amd import device as D  # noqa: E402
 from librir_amd.signal_processing import rir_signal_processing as sp  # noqa: E402

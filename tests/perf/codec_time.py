@@ -1,5 +1,5 @@
 """Quick codec timing + correctness on the GPU box (development aid, not a test):
-    python scripts/codec_time.py [frames]
+    python tests/perf/codec_time.py [frames]
 Prints per-kernel HIP-event times (median of 10) for the headline workload and checks the
 round trip and, on small cases, bit-equality of the stream with the oracle."""
 import os
@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from librir_amd import device as D  # noqa: E402
 from librir_amd.synthetic import s1_noisy_background, s2_uniform_dl_ti  # noqa: E402
 from oracle.pyoracle import Oracle  # noqa: E402

@@ -1,5 +1,5 @@
 import sys, time, numpy as np, torch
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from librir_amd import device as D
 from librir_amd.synthetic import s1_noisy_background, inject_bad_pixels
 from oracle.pyoracle import Oracle
