@@ -259,7 +259,7 @@ def main():
         }
         if allgather:
             res["allgather_decoded_stream"] = allgather
-        if not args.no_cpu_baseline and world >= 1:
+        if not args.no_cpu_baseline and world == 1:  # the CPU path is timed beside the N=1 run only
             res["cpu_baseline"] = cpu_baseline(frames_np, gop, args.cpu_frames, args.cpu_seconds)
         print(json.dumps(res))
     if world > 1:
