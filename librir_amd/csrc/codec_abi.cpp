@@ -37,8 +37,9 @@ RIR_EXPORT int rir_codec_layout_query(int width, int height, int nframes, int go
 	out->tile_off_bytes = (int64_t)out->nchunks * (out->ntiles + 1) * 4;
 	out->chunk_off_bytes = (int64_t)(out->nchunks + 1) * 8;
 	out->stream_max_bytes = slots * gop * RIRB1_REC_MAX_WORDS * 8;
-	// workspace = sparse slots + seg_words + chunk_words
-	out->workspace_bytes = (int64_t)(align256((size_t)out->stream_max_bytes) + align256((size_t)slots * 4) + align256((size_t)out->nchunks * 8));
+	// workspace = sparse slots (padded stride, codec_format.h) + seg_words + chunk_words
+	out->workspace_bytes = (int64_t)(align256((size_t)(slots * RIRB1_SLOT_WORDS(gop) * 8)) + align256((size_t)slots * 4) +
+									 align256((size_t)out->nchunks * 8));
 	return 0;
 }
 
@@ -56,7 +57,7 @@ namespace
 			return false;
 		char *ws = static_cast<char *>(d_workspace);
 		w.sparse = reinterpret_cast<uint64_t *>(ws);
-		ws += align256((size_t)L.stream_max_bytes);
+		ws += align256((size_t)((int64_t)L.nchunks * L.ntiles * RIRB1_SLOT_WORDS(L.gop) * 8));
 		w.seg_words = reinterpret_cast<uint32_t *>(ws);
 		ws += align256((size_t)L.nchunks * L.ntiles * 4);
 		w.chunk_words = reinterpret_cast<uint64_t *>(ws);

@@ -669,7 +669,7 @@ namespace rir
 		const int nf = min(gop, nframes - f_begin);
 		const int64_t slot = (int64_t)chunk * ntiles + tile;
 		uint64_t *my_hdr = hdr_table + slot * gop;
-		uint64_t *out = sparse + slot * (int64_t)gop * RIRB1_REC_MAX_WORDS;
+		uint64_t *out = sparse + slot * RIRB1_SLOT_WORDS(gop);
 		const uint32_t out_bytes = (uint32_t)gop * RIRB1_REC_MAX_WORDS * 8u;
 		const bool fast = ((npx & 7) == 0) && ((int64_t)(tile + 1) * RIRB1_TILE_PX <= npx) && ((((uintptr_t)frames) & 15) == 0);
 		if (fast)
@@ -741,7 +741,7 @@ namespace rir
 				chunk_off[nchunks] = s + chunk_words[c];
 		}
 		const uint32_t n = o1 - o0;
-		const uint64_t *src = sparse + ((int64_t)c * ntiles + t) * (int64_t)gop * RIRB1_REC_MAX_WORDS;
+		const uint64_t *src = sparse + ((int64_t)c * ntiles + t) * RIRB1_SLOT_WORDS(gop);
 		uint64_t *dst = stream + s + o0;
 		uint32_t i = tid;
 		for (; i + 768 < n; i += 1024)
