@@ -104,6 +104,17 @@ extern "C"
 	/* 3x3 median filter: reference Filters.h:71-129 (template without C export upstream). */
 	int rir_median_filter_device(const unsigned short *d_src, unsigned short *d_dst, int w, int h, int nframes, void *stream);
 
+	/* ---- bounded-loss step on a device-resident stream -------------------------------------------------
+	 * The loss injection of H264_Saver::addImageLossyNoCamera / addLoss (reference src/cpp/video_io/h264.cpp:2253-2607)
+	 * as a stream operator: uint16 frames [n][h][w] in HBM in and out (distinct buffers), one state object per
+	 * stream, frames taken in order.  rir_lossy_create returns a handle > 0 (0 on failure); low_errors /
+	 * high_errors are HOST int[nframes] (the per-frame budgets, as h264_get_low/high_errors), may be NULL. */
+	int rir_lossy_create(int width, int height, int lossy_height, int low_value_error, int high_value_error, double std_factor,
+						 int running_average, int subtract_min, int remove_bad_pixels);
+	int rir_lossy_step_device(int handle, const unsigned short *d_in, unsigned short *d_out, int nframes, int add_loss, int *low_errors,
+							  int *high_errors, void *stream);
+	void rir_lossy_destroy(int handle);
+
 	/* ---- byte planes ------------------------------------------------------------------------------
 	 * H264Capture::AddFrame (reference src/cpp/video_io/h264.cpp:1066-1082): U = v & 0xFF, V = v >> 8, Y = 0 or
 	 * the 8-bit integration-time image, rows padded to `linesize`; VideoGrabber::toArray (:3016-3051) is the

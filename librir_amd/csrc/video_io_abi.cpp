@@ -157,7 +157,7 @@ namespace
 			dev.subtract_min = subtract_min ? 1 : 0;
 			dev.min = 0;
 			frames = 0, n_first = 0, n_win = 0;
-			return true;
+			return hip_ok(hipStreamSynchronize(st), "sync"); // the state is ready whatever stream the steps run on
 		}
 
 		// img (host, full frame) -> d_out (device, full frame), copied to `out` (host) when it is not NULL.
@@ -165,22 +165,34 @@ namespace
 				  double std_factor, int &low_error, int &high_error)
 		{
 			hipStream_t st = default_stream();
-			const int full = w * h, s = w * hl;
-			if (!hip_ok(hipMemcpyAsync(d_img.ptr, img, (size_t)full * 2, hipMemcpyHostToDevice, st), "H2D"))
+			const int full = w * h;
+			if (!hip_ok(hipMemcpyAsync(d_img.ptr, img, (size_t)full * 2, hipMemcpyHostToDevice, st), "H2D") ||
+				!step_device(d_img.as<uint16_t>(), d_out.as<uint16_t>(), add_loss, remove_bad_pixels, low_value_error, high_value_error, std_factor,
+							 low_error, high_error, st))
 				return false;
-			const uint16_t *d_src = d_img.as<uint16_t>();
-			uint16_t *tmp = d_tmp.as<uint16_t>();
+			if (!out)
+				return true; // the caller consumes d_out on the same stream
+			return hip_ok(hipMemcpyAsync(out, d_out.ptr, (size_t)full * 2, hipMemcpyDeviceToHost, st), "D2H") && hip_ok(hipStreamSynchronize(st), "sync");
+		}
+
+		// One frame, device to device (d_src and d_dst: full frames, distinct).  The statistics come back to the
+		// host once per frame (56 bytes): the error budget is sequential scalar arithmetic.
+		bool step_device(const uint16_t *d_src, uint16_t *d_dst, bool add_loss, bool remove_bad_pixels, int low_value_error, int high_value_error,
+						 double std_factor, int &low_error, int &high_error, hipStream_t st)
+		{
+			const int full = w * h, s = w * hl;
+			const uint16_t *tmp = d_src; // without bad-pixel repair the frame is used as it is
 			if (remove_bad_pixels && hl > 0)
 			{ // bp.init on the first image (rows < lossy_height), bp.correct on every image (h264.cpp:2259-2266)
 				if (frames == 0 && bp_handle <= 0)
 					bp_handle = rir_bad_pixels_create_device(d_src, w, hl, st);
-				if (bp_handle <= 0 || rir_bad_pixels_correct_device(bp_handle, d_src, tmp, 1, st) != 0)
+				uint16_t *fixed = d_tmp.as<uint16_t>();
+				if (bp_handle <= 0 || rir_bad_pixels_correct_device(bp_handle, d_src, fixed, 1, st) != 0)
 					return false;
-				if (full > s && !hip_ok(hipMemcpyAsync(tmp + s, d_src + s, (size_t)(full - s) * 2, hipMemcpyDeviceToDevice, st), "D2D"))
+				if (full > s && !hip_ok(hipMemcpyAsync(fixed + s, d_src + s, (size_t)(full - s) * 2, hipMemcpyDeviceToDevice, st), "D2D"))
 					return false;
+				tmp = fixed;
 			}
-			else if (!hip_ok(hipMemcpyAsync(tmp, d_src, (size_t)full * 2, hipMemcpyDeviceToDevice, st), "D2D"))
-				return false;
 
 			low_error = low_value_error, high_error = high_value_error;
 			if (frames == 0)
@@ -193,7 +205,7 @@ namespace
 						return false;
 					dev.min = mn;
 				}
-				if (!hip_ok(launch_lossy_first(tmp, d_out.as<uint16_t>(), dev, s, full, st), "lossy first"))
+				if (!hip_ok(launch_lossy_first(tmp, d_dst, dev, s, full, st), "lossy first"))
 					return false;
 			}
 			else
@@ -256,8 +268,7 @@ namespace
 					high_error = 0;
 				if (low_error < high_error)
 					low_error = high_error;
-				if (!hip_ok(launch_lossy_update(tmp, d_out.as<uint16_t>(), dev, s, full, background, low_error, high_error, add_loss ? 1 : 0, st),
-							"lossy update"))
+				if (!hip_ok(launch_lossy_update(tmp, d_dst, dev, s, full, background, low_error, high_error, add_loss ? 1 : 0, st), "lossy update"))
 					return false;
 				if (dev.running_average > 0)
 				{
@@ -268,10 +279,18 @@ namespace
 				}
 			}
 			++frames;
-			if (!out)
-				return true; // the caller consumes d_out on the same stream
-			return hip_ok(hipMemcpyAsync(out, d_out.ptr, (size_t)full * 2, hipMemcpyDeviceToHost, st), "D2H") && hip_ok(hipStreamSynchronize(st), "sync");
+			return true;
 		}
+	};
+
+	// handle for the device-resident form of the bounded-loss step (rir_lossy_*)
+	struct LossyObject : public Object
+	{
+		const char *type_name() const override { return "LossyStream"; }
+		LossyState st;
+		int low = 6, high = 2;
+		double std_factor = 5;
+		bool remove_bad_pixels = false;
 	};
 
 	// ---- saver -------------------------------------------------------------------------------
@@ -1516,6 +1535,58 @@ RIR_EXPORT int h264_add_loss(int file, unsigned short *img)
 		return -1;
 	}
 	return s->add_loss(img) ? 0 : -1;
+}
+
+// ---- bounded-loss step on a device-resident stream ---------------------------------------------------------------
+// The loss injection of H264_Saver::addImageLossyNoCamera / addLoss (h264.cpp:2253-2607) without the saver around it:
+// frames in HBM in, frames in HBM out, one state object per stream.
+RIR_EXPORT int rir_lossy_create(int width, int height, int lossy_height, int low_value_error, int high_value_error, double std_factor,
+								int running_average, int subtract_min, int remove_bad_pixels)
+{
+	if (!device_ready())
+		return 0;
+	if (width <= 0 || height <= 0 || lossy_height < 0)
+	{
+		log_error("rir_lossy_create: invalid argument");
+		return 0;
+	}
+	auto o = std::make_shared<LossyObject>();
+	o->low = low_value_error, o->high = high_value_error, o->std_factor = std_factor, o->remove_bad_pixels = remove_bad_pixels != 0;
+	if (!o->st.prepare(width, height, lossy_height, running_average, subtract_min != 0))
+		return 0;
+	return register_object(o);
+}
+
+// d_in, d_out: uint16 [nframes][height][width], distinct buffers; low_errors / high_errors: HOST int[nframes] (may be NULL).
+// Frames are processed in order (the state is sequential); add_loss != 0 selects the addLoss variant.
+RIR_EXPORT int rir_lossy_step_device(int handle, const unsigned short *d_in, unsigned short *d_out, int nframes, int add_loss, int *low_errors,
+									 int *high_errors, void *stream)
+{
+	auto o = lookup_as<LossyObject>(handle);
+	if (!o || !d_in || !d_out || d_in == d_out || nframes <= 0)
+	{
+		log_error("rir_lossy_step_device: invalid argument");
+		return -1;
+	}
+	const size_t npx = (size_t)o->st.w * o->st.h;
+	for (int i = 0; i < nframes; ++i)
+	{
+		int lo = 0, hi = 0;
+		if (!o->st.step_device(d_in + (size_t)i * npx, d_out + (size_t)i * npx, add_loss != 0, o->remove_bad_pixels, o->low, o->high, o->std_factor, lo,
+							   hi, (hipStream_t)stream))
+			return -1;
+		if (low_errors)
+			low_errors[i] = lo;
+		if (high_errors)
+			high_errors[i] = hi;
+	}
+	return 0;
+}
+
+RIR_EXPORT void rir_lossy_destroy(int handle)
+{
+	if (lookup_as<LossyObject>(handle))
+		remove_object(handle);
 }
 
 static int errors_out(const std::vector<unsigned short> &err, unsigned short *errors, int *size)

@@ -77,6 +77,9 @@ _lib.rir_remove_bad_pixels_device.argtypes = [ct.c_int, _vp, ct.c_int, ct.c_int,
 _lib.rir_remove_motion_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp]
 _lib.rir_median_filter_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp]
 _lib.bad_pixels_destroy.argtypes = [ct.c_int]
+_lib.rir_lossy_create.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_double, ct.c_int, ct.c_int, ct.c_int]
+_lib.rir_lossy_step_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, _vp, _vp, _vp]
+_lib.rir_lossy_destroy.argtypes = [ct.c_int]
 _lib.rir_split_planes_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp]
 _lib.rir_merge_planes_device.argtypes = [_vp, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.bad_pixels_destroy.restype = None
@@ -354,3 +357,40 @@ def merge_planes(Y, U, V, width, with_it=False):
     _check(_lib.rir_merge_planes_device(Yp, U.data_ptr(), V.data_ptr(), ls, width, h, n, img.data_ptr(), it.data_ptr() if with_it else None,
                                         _stream()), "rir_merge_planes_device")
     return (img, it) if with_it else img
+
+
+class LossyStream:
+    """Bounded-loss step on device-resident frames (reference H264_Saver::addImageLossyNoCamera / addLoss)."""
+
+    def __init__(self, width, height, lossy_height=None, low_value_error=6, high_value_error=2, std_factor=5.0, running_average=32,
+                 subtract_min=False, remove_bad_pixels=False):
+        self.shape = (height, width)
+        self.handle = _lib.rir_lossy_create(width, height, height if lossy_height is None else int(lossy_height), int(low_value_error),
+                                            int(high_value_error), float(std_factor), int(running_average), int(bool(subtract_min)),
+                                            int(bool(remove_bad_pixels)))
+        if self.handle <= 0:
+            raise RuntimeError("rir_lossy_create failed: %s" % last_error())
+
+    def step(self, frames, add_loss=False):
+        """frames (n,h,w) uint16 on the device -> (processed frames, low_errors, high_errors)"""
+        fr = _frames3(frames, torch.uint16)
+        n = fr.shape[0]
+        if tuple(fr.shape[1:]) != self.shape:
+            raise RuntimeError("LossyStream.step: wrong frame size")
+        out = torch.empty_like(fr)
+        lo = np.zeros(n, np.int32)
+        hi = np.zeros(n, np.int32)
+        _check(_lib.rir_lossy_step_device(self.handle, fr.data_ptr(), out.data_ptr(), n, int(bool(add_loss)), lo.ctypes.data, hi.ctypes.data,
+                                          _stream()), "rir_lossy_step_device")
+        return out, lo, hi
+
+    def close(self):
+        if getattr(self, "handle", 0) > 0:
+            _lib.rir_lossy_destroy(self.handle)
+            self.handle = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -227,6 +227,21 @@ _ref0 = _norm(O.gaussian_filter(f32[0], 0.5))
 _im1 = _norm(O.gaussian_filter(f32[1], 0.5))
 c4["cpu_port_ecc_fps_1thread"] = cpu_fps(lambda: O.ecc_translation(_ref0, _im1, (0.0, 0.0)), 1, budget=4.0)
 reg = D.remove_motion(t4, sh, rows=h - 3).cpu().numpy()
+# bounded loss on the device-resident, motion-corrected stream (rir_lossy_step_device), then the lossless encode of it
+treg = torch.from_numpy(reg).to(dev)
+ctx4 = D.CodecContext(w, h, n4, gop, device=dev)
+
+
+def lossy_dev():
+    ls = D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32)
+    out4, _, _ = ls.step(treg)
+    enc4 = ctx4.encode(out4)
+    ls.close()
+    return enc4
+
+
+ms = gpu_ms(lossy_dev, 3)
+c4["lossy_then_encode_device_resident_fps"] = n4 / ms * 1e3
 with tempfile.TemporaryDirectory() as d:
     dst = os.path.join(d, "lossy.h264")
     t0 = time.perf_counter()

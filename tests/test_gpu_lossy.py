@@ -115,3 +115,30 @@ def test_per_frame_error_attributes(tmp_path):
         a3 = mov.frame_attributes
         assert int(a3["BackgroundError"]) == low[3] and int(a3["ForegroundError"]) == high[3]
         assert int(mov.attributes["GlobalForegroundError"]) == 2
+
+
+@pytest.mark.parametrize("add_loss", [False, True])
+def test_device_resident_stream_matches_oracle(oracle, add_loss):
+    """rir_lossy_step_device: the same arithmetic on frames that never leave HBM, in two batches (state carries over)."""
+    import torch
+
+    from librir_amd import device as D
+
+    n, h, w, hl = 64, 64, 96, 61
+    arr = s1_noisy_background(n, h, w, seed=23)
+    L = OracleLossy(oracle, w, h, hl, low_err=5, high_err=2, std_factor=2.5, running_average=8)
+    exp, elo, ehi = [], [], []
+    for i in range(n):
+        exp.append(L.step(arr[i], add_loss=add_loss and i > 0))
+        lo, hi, _ = L.last_errors()
+        elo.append(lo)
+        ehi.append(hi)
+    ls = D.LossyStream(w, h, hl, 5, 2, 2.5, 8)
+    t = torch.from_numpy(arr).cuda()
+    a, lo_a, hi_a = ls.step(t[:1], add_loss=False)
+    b, lo_b, hi_b = ls.step(t[1:40], add_loss=add_loss)
+    c, lo_c, hi_c = ls.step(t[40:], add_loss=add_loss)
+    got = torch.cat([a, b, c]).cpu().numpy()
+    assert np.array_equal(got, np.stack(exp))
+    assert np.concatenate([lo_a, lo_b, lo_c]).tolist() == elo and np.concatenate([hi_a, hi_b, hi_c]).tolist() == ehi
+    ls.close()
