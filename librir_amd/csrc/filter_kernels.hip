@@ -1170,14 +1170,14 @@ namespace rir
 		constexpr int VEC = 8;
 		const int cpr = (w + VEC - 1) / VEC;
 		const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-		if (idx >= (int64_t)cpr * h)
-			return;
-		const int y = (int)(idx / cpr);
-		const int x0 = (int)(idx - (int64_t)y * cpr) * VEC;
+		const bool valid = idx < (int64_t)cpr * h;
+		const int y = valid ? (int)(idx / cpr) : 0;
+		const int x0 = valid ? (int)(idx - (int64_t)y * cpr) * VEC : 0;
 		const int64_t fbase = (int64_t)blockIdx.y * w * h;
 		const uint16_t *s = src + fbase;
 		uint16_t *d = dst + fbase + (int64_t)y * w + x0;
-		if (y >= 1 && y < h - 1 && x0 >= 1 && x0 + VEC + 3 <= w && (((uintptr_t)d) & 15) == 0)
+		bool done = !valid;
+		if (valid && y >= 1 && y < h - 1 && x0 >= 1 && x0 + VEC + 3 <= w && (((uintptr_t)d) & 15) == 0)
 		{
 			uint16_t r0[VEC + 2], r1[VEC + 2], r2[VEC + 2];
 			load_taps<uint16_t, VEC + 2>(s + (int64_t)(y - 1) * w + x0 - 1, r0);
@@ -1197,10 +1197,26 @@ namespace rir
 			for (int k = 0; k < VEC; ++k)
 				o.v[k] = (uint16_t)med3(max(max(lo[k], lo[k + 1]), lo[k + 2]), med3(mi[k], mi[k + 1], mi[k + 2]), min(min(hi[k], hi[k + 1]), hi[k + 2]));
 			*reinterpret_cast<PixVec<uint16_t, VEC> *>(d) = o;
+			done = true;
+		}
+		// border chunks (row ends, first / last rows): wave-cooperative when there are few of them, see translate_kernel
+		const int lane = threadIdx.x & 63;
+		uint64_t todo = __ballot(!done);
+		if (__builtin_popcountll(todo) >= VEC)
+		{
+			if (!done)
+				for (int k = 0; k < VEC && x0 + k < w; ++k)
+					d[k] = median3x3_px(s, w, h, x0 + k, y);
 			return;
 		}
-		for (int k = 0; k < VEC && x0 + k < w; ++k)
-			d[k] = median3x3_px(s, w, h, x0 + k, y);
+		while (todo)
+		{
+			const int src_lane = __builtin_ctzll(todo);
+			todo &= todo - 1;
+			const int cx = __shfl(x0, src_lane, 64) + lane, cy = __shfl(y, src_lane, 64);
+			if (lane < VEC && cx < w)
+				dst[fbase + (int64_t)cy * w + cx] = median3x3_px(s, w, h, cx, cy);
+		}
 	}
 
 	hipError_t launch_median3x3(const uint16_t *src, uint16_t *dst, int w, int h, int nframes, hipStream_t st)
