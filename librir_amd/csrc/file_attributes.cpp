@@ -160,7 +160,8 @@ namespace rir
 		uint64_t count, tsize;
 		std::memcpy(&count, tail, 8);
 		std::memcpy(&tsize, tail + 8, 8);
-		if (tsize > size || tsize < 16 + TAG_LEN + 8 || count > (1ull << 31))
+		// every frame costs at least 16 bytes of trailer (an empty map + its timestamp): a larger count is corrupt
+		if (tsize > size || tsize < 16 + TAG_LEN + 8 || count > (1ull << 31) || count > tsize / 16)
 			return 0;
 		Cursor c{data + size - tsize, tail};
 		global = c.map();

@@ -673,11 +673,26 @@ namespace
 					log_error("RIRB file not closed properly or unknown version");
 					return false;
 				}
+				// the header comes from a file: nothing in it is trusted before it has been checked against the file size
+				if (hd.width == 0 || hd.height == 0 || hd.width > 65535 || hd.height > 65535 || hd.gop == 0 || hd.gop > (1u << 20) ||
+					hd.nframes > 0x7fffffffull || hd.nchunks > fsize / sizeof(IndexEntry) || hd.index_offset > fsize ||
+					hd.nchunks * sizeof(IndexEntry) > fsize - hd.index_offset || hd.nframes > hd.nchunks * (uint64_t)hd.gop)
+				{
+					log_error("RIRB file: inconsistent header");
+					return false;
+				}
 				kind = RIRB;
 				width = (int)hd.width, height = (int)hd.height, count = (int)hd.nframes;
 				index.resize((size_t)hd.nchunks);
 				if (hd.nchunks && !read_at(hd.index_offset, index.data(), sizeof(IndexEntry) * index.size()))
 					return false;
+				for (const IndexEntry &e : index)
+					if (e.file_offset > fsize || e.nframes == 0 || e.nframes > hd.gop || e.first_frame > hd.nframes ||
+						e.nframes > hd.nframes - e.first_frame)
+					{
+						log_error("RIRB file: inconsistent chunk index");
+						return false;
+					}
 				if (count > 0 && !cc.prepare(width, height, (int)hd.gop))
 					return false;
 			}
@@ -1071,13 +1086,23 @@ RIR_EXPORT int open_camera_file(const char *filename, int *file_format)
 {
 	if (file_format)
 		*file_format = 0;
-	auto cam = std::make_shared<CameraObject>();
-	cam->filename = filename ? filename : "";
-	cam->fp = filename ? std::fopen(filename, "rb") : nullptr;
-	int h = cam->fp ? register_camera(cam, file_format) : 0;
+	int h = 0;
+	std::string name = filename ? filename : "";
+	try
+	{
+		auto cam = std::make_shared<CameraObject>();
+		cam->filename = name;
+		cam->fp = filename ? std::fopen(filename, "rb") : nullptr;
+		h = cam->fp ? register_camera(cam, file_format) : 0;
+	}
+	catch (const std::exception &e)
+	{ // nothing may be thrown across the C boundary
+		log_error(std::string("open_camera_file: ") + e.what());
+		h = 0;
+	}
 	if (h <= 0)
 	{
-		log_error("Unable to open camera file " + cam->filename + ": wrong file format");
+		log_error("Unable to open camera file " + name + ": wrong file format");
 		return 0;
 	}
 	return h;
@@ -1088,10 +1113,19 @@ RIR_EXPORT int open_camera_from_memory(void *ptr, int64_t size, int *file_format
 {
 	if (file_format)
 		*file_format = 0;
-	auto cam = std::make_shared<CameraObject>();
-	if (ptr && size > 0)
-		cam->mem.assign(static_cast<char *>(ptr), static_cast<char *>(ptr) + size);
-	int h = cam->mem.empty() ? 0 : register_camera(cam, file_format);
+	int h = 0;
+	try
+	{
+		auto cam = std::make_shared<CameraObject>();
+		if (ptr && size > 0)
+			cam->mem.assign(static_cast<char *>(ptr), static_cast<char *>(ptr) + size);
+		h = cam->mem.empty() ? 0 : register_camera(cam, file_format);
+	}
+	catch (const std::exception &e)
+	{
+		log_error(std::string("open_camera_from_memory: ") + e.what());
+		h = 0;
+	}
 	if (h <= 0)
 	{
 		log_error("Unable to open camera file: wrong file format");
@@ -1112,12 +1146,20 @@ RIR_EXPORT int open_camera_file_reader(void *, int *file_format)
 // video_io.cpp:51-72
 RIR_EXPORT int video_file_format(const char *filename)
 {
-	auto cam = std::make_shared<CameraObject>();
-	cam->filename = filename ? filename : "";
-	cam->fp = filename ? std::fopen(filename, "rb") : nullptr;
-	if (!cam->fp || !cam->open_common())
+	try
+	{
+		auto cam = std::make_shared<CameraObject>();
+		cam->filename = filename ? filename : "";
+		cam->fp = filename ? std::fopen(filename, "rb") : nullptr;
+		if (!cam->fp || !cam->open_common())
+			return -1;
+		return format_of(*cam);
+	}
+	catch (const std::exception &e)
+	{
+		log_error(std::string("video_file_format: ") + e.what());
 		return -1;
-	return format_of(*cam);
+	}
 }
 
 RIR_EXPORT int close_camera(int cam)

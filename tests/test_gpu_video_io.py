@@ -234,3 +234,42 @@ def test_caller_may_reuse_its_buffer_immediately(tmp_path):
                 buf[:] = 0xABCD
         with IRMovie.from_filename(dst) as mov:
             assert np.array_equal(mov.data, arr), kind
+
+
+def test_corrupted_files_never_crash(tmp_path):
+    """Byte flips anywhere in a real recording (headers, tables, payload, index, trailer): opening and reading either
+    fails with an error or returns frames; tables and payload are bounds-checked on the device."""
+    n, h, w = 23, 40, 96
+    arr = images(n, h, w)
+    src = tmp_path / "ok.h264"
+    with IRSaver(src, w, h, h) as s:
+        s.set_parameter("GOP", 5)
+        for i in range(n):
+            s.add_image(arr[i], i * 1000, {"k": "v" * 10})
+    blob = bytearray(open(src, "rb").read())
+    rng = np.random.default_rng(5)
+    errors = good = 0
+    for trial in range(120):
+        b = bytearray(blob)
+        region = trial % 4
+        lo, hi = [(0, 96), (96, len(b) // 2), (len(b) // 2, len(b) - 400), (max(len(b) - 400, 0), len(b))][region]
+        for _ in range(int(rng.integers(1, 8))):
+            b[int(rng.integers(lo, max(hi, lo + 1)))] = int(rng.integers(0, 256))
+        p = tmp_path / "bad.h264"
+        p.write_bytes(bytes(b))
+        try:
+            cam = rv.open_camera_file(p)
+        except RuntimeError:
+            errors += 1
+            continue
+        try:
+            for i in (0, rv.get_image_count(cam) - 1, 7):
+                if 0 <= i < rv.get_image_count(cam):
+                    rv.load_image(cam, i)
+            good += 1
+        except RuntimeError:
+            errors += 1
+        rv.close_camera(cam)
+    assert errors + good == 120 and errors > 0
+    with IRMovie.from_filename(src) as mov:  # the library is still healthy afterwards
+        assert np.array_equal(mov.data, arr)

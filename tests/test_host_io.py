@@ -172,3 +172,54 @@ def test_codec_paths_fail_loudly_without_device(tmp_path):
     assert "no usable HIP device" in last_error()
     rv.h264_close_file(s)
     assert not os.path.exists(tmp_path / "o.h264") or os.path.getsize(tmp_path / "o.h264") == 0
+
+
+def _minimal_rirb(nframes=0, nchunks=0, width=8, height=4, gop=50, index_offset=96, index=b"", version=1):
+    """A hand-built container: ftyp box (32 B) + file header (64 B) + chunk index."""
+    import struct
+
+    ftyp = struct.pack(">I", 32) + b"ftyp" + b"RIRB" + struct.pack(">I", 1) + b"RIRBisom" + b"\0" * 8
+    hdr = b"RIRBLOCK" + struct.pack("<IIIIII", version, width, height, gop, 50, 0) + struct.pack("<QQQ", index_offset, nframes, nchunks) + b"\0" * 8
+    assert len(ftyp) == 32 and len(hdr) == 64
+    return ftyp + hdr + index
+
+
+def test_hostile_container_headers_are_rejected_not_crashed_on(tmp_path):
+    """Sizes read from a file are checked against the file before anything is allocated from them; nothing is thrown
+    across the C boundary.  Runs without a GPU: opening only parses."""
+    import struct
+
+    from librir_amd.video_io import rir_video_io as rv
+
+    def opens(blob):
+        p = tmp_path / "f.bin"
+        p.write_bytes(blob)
+        try:
+            cam = rv.open_camera_file(p)
+        except RuntimeError:
+            return None
+        n = rv.get_image_count(cam)
+        rv.close_camera(cam)
+        return n
+
+    assert opens(_minimal_rirb()) == 0  # a closed, empty recording is a valid file
+    huge = 0xFFFFFFFFFFFFFFF
+    for kw in (dict(nchunks=huge), dict(nframes=huge, nchunks=1), dict(width=0), dict(height=10 ** 6), dict(gop=0), dict(index_offset=10 ** 12),
+               dict(nchunks=3), dict(nframes=10, nchunks=0), dict(version=7), dict(index_offset=0)):
+        assert opens(_minimal_rirb(**kw)) is None, kw
+    # a chunk index whose entries point outside the file / outside the frame range
+    bad_index = struct.pack("<QQII", 10 ** 9, 0, 5, 0)
+    assert opens(_minimal_rirb(nframes=5, nchunks=1, index=bad_index)) is None
+    bad_index = struct.pack("<QQII", 96, 3, 50, 0)
+    assert opens(_minimal_rirb(nframes=5, nchunks=1, index=bad_index)) is None
+    # a trailer that announces more frames than it can hold
+    trailer = struct.pack("<Q", 0) + struct.pack("<QQ", 2 ** 30, 16 + 14 + 8) + b"H264ATTRIBUTES"
+    assert opens(_minimal_rirb() + trailer) == 0
+    # random garbage and truncations
+    rng = np.random.default_rng(0)
+    base = bytearray(_minimal_rirb())
+    for _ in range(200):
+        b = bytearray(base)
+        for _ in range(int(rng.integers(1, 6))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        opens(bytes(b[: int(rng.integers(1, len(b) + 1))]))
