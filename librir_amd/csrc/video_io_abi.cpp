@@ -422,7 +422,7 @@ namespace
 				return true;
 			if (!device_ready())
 				return false;
-			if (width <= 0 || height <= 0)
+			if (width <= 0 || height <= 0 || width > 65535 || height > 65535)
 			{
 				log_error("h264 saver: invalid image size");
 				return false;
