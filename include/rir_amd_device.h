@@ -133,6 +133,9 @@ extern "C"
 	 * Returns -1 where OpenCV raises (no overlap / no convergence). */
 	int rir_ecc_translation_device(const float *d_templ, const float *d_image, const unsigned char *d_mask, int w, int h, float *warp,
 								   int max_iterations, double eps, double *cc, int *iterations, void *stream);
+	/* (im - min) / (max - min) in float32 on a w x h window of a device image with row stride src_stride (the
+	 * normalisation of masked_registration_ecc.py:162-166, crop folded in); d_dst dense [h][w]. */
+	int rir_minmax_normalize_device(const float *d_src, int w, int h, int src_stride, float *d_dst, void *stream);
 	int find_transform_ecc_translation(const float *templ, const float *image, const unsigned char *mask, int w, int h, float *warp,
 									   int max_iterations, double eps, double *cc);
 

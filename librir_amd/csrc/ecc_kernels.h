@@ -27,4 +27,5 @@ namespace rir
 	// one iteration (no-op once d_state->done != 0)
 	hipError_t launch_ecc_iterate(const float *d_templ, const float *d_image, const float *d_gx, const float *d_gy, const uint8_t *d_mask, int w,
 								  int h, double *d_partials, EccState *d_state, hipStream_t st);
+	hipError_t launch_minmax_normalize(const float *d_src, int w, int h, int src_stride, float *d_dst, float *d_part, hipStream_t st);
 } // namespace rir

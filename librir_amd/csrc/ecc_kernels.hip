@@ -18,11 +18,12 @@
 
 namespace rir
 {
-	size_t ecc_workspace_bytes(int w, int h)
+	static int ecc_blocks(int w, int h)
 	{
-		const size_t blocks = ((size_t)w * h + ECC_BLOCK - 1) / ECC_BLOCK;
-		return blocks * ECC_NSUMS * sizeof(double);
+		const int64_t b = ((int64_t)w * h + ECC_BLOCK - 1) / ECC_BLOCK;
+		return (int)(b < 256 ? b : 256);
 	}
+	size_t ecc_workspace_bytes(int w, int h) { return (size_t)ecc_blocks(w, h) * ECC_NSUMS * sizeof(double); }
 
 	// central difference with reflect-101 borders: g(0) = g(n-1) = 0
 	__global__ __launch_bounds__(256) void ecc_gradient_kernel(const float *__restrict__ img, int w, int h, float *__restrict__ gx,
@@ -66,12 +67,13 @@ namespace rir
 		__shared__ double red[ECC_BLOCK / 64][ECC_NSUMS];
 		__shared__ bool last;
 		const float tx = state->tx, ty = state->ty;
-		const int i = blockIdx.x * ECC_BLOCK + threadIdx.x;
 		double s[ECC_NSUMS];
 #pragma unroll
 		for (int k = 0; k < ECC_NSUMS; ++k)
 			s[k] = 0.0;
-		if (i < w * h)
+		// grid-stride over the pixels: a few hundred workgroups whatever the image size (one ticket atomic and one
+		// row of partials per workgroup - 1 280 of them on one address cost ~60 us per iteration at 512x640)
+		for (int i = blockIdx.x * ECC_BLOCK + threadIdx.x; i < w * h; i += gridDim.x * ECC_BLOCK)
 		{
 			const int y = i / w, x = i - y * w;
 			const float sx = (float)x + tx, sy = (float)y + ty;
@@ -89,9 +91,9 @@ namespace rir
 				const double gx = bilinear0(gximg, w, h, x0, y0, fx, fy);
 				const double gy = bilinear0(gyimg, w, h, x0, y0, fx, fy);
 				const double T = templ[i];
-				s[0] = 1.0, s[1] = I, s[2] = I * I, s[3] = T, s[4] = T * T, s[5] = T * I;
-				s[6] = gx, s[7] = gy, s[8] = gx * gx, s[9] = gx * gy, s[10] = gy * gy;
-				s[11] = gx * I, s[12] = gy * I, s[13] = gx * T, s[14] = gy * T;
+				s[0] += 1.0, s[1] += I, s[2] += I * I, s[3] += T, s[4] += T * T, s[5] += T * I;
+				s[6] += gx, s[7] += gy, s[8] += gx * gx, s[9] += gx * gy, s[10] += gy * gy;
+				s[11] += gx * I, s[12] += gy * I, s[13] += gx * T, s[14] += gy * T;
 			}
 		}
 		// wave reduction (fixed butterfly), then the four waves of the block in order
@@ -120,15 +122,40 @@ namespace rir
 		__syncthreads();
 		if (!last)
 			return;
-		// ---- last block: total in block order, then the 2x2 solve ----
+		// ---- last block: total of the partials (fixed tree: thread t takes blocks t, t+256, ...; then the same
+		// butterfly / wave order as above - deterministic), then the 2x2 solve.  (A single thread per sum walking all
+		// the partials cost ~0.6 ms per iteration at 512x640: 1 280 dependent loads.) ----
 		__threadfence();
 		__shared__ double tot[ECC_NSUMS];
-		if (threadIdx.x < ECC_NSUMS)
 		{
-			double v = 0.0;
-			for (unsigned b = 0; b < gridDim.x; ++b)
-				v += __builtin_nontemporal_load(partials + (size_t)b * ECC_NSUMS + threadIdx.x);
-			tot[threadIdx.x] = v;
+			double acc[ECC_NSUMS];
+#pragma unroll
+			for (int k = 0; k < ECC_NSUMS; ++k)
+				acc[k] = 0.0;
+			for (unsigned b = threadIdx.x; b < gridDim.x; b += ECC_BLOCK)
+			{
+#pragma unroll
+				for (int k = 0; k < ECC_NSUMS; ++k)
+					acc[k] += __builtin_nontemporal_load(partials + (size_t)b * ECC_NSUMS + k);
+			}
+#pragma unroll
+			for (int k = 0; k < ECC_NSUMS; ++k)
+			{
+				double v = acc[k];
+#pragma unroll
+				for (int d = 32; d >= 1; d >>= 1)
+					v += __shfl_xor(v, d, 64);
+				if ((threadIdx.x & 63) == 0)
+					red[threadIdx.x >> 6][k] = v;
+			}
+			__syncthreads();
+			if (threadIdx.x < ECC_NSUMS)
+			{
+				double v = red[0][threadIdx.x];
+				for (int wv = 1; wv < ECC_BLOCK / 64; ++wv)
+					v += red[wv][threadIdx.x];
+				tot[threadIdx.x] = v;
+			}
 		}
 		__syncthreads();
 		if (threadIdx.x != 0)
@@ -190,8 +217,69 @@ namespace rir
 	hipError_t launch_ecc_iterate(const float *d_templ, const float *d_image, const float *d_gx, const float *d_gy, const uint8_t *d_mask, int w,
 								  int h, double *d_partials, EccState *d_state, hipStream_t st)
 	{
-		hipLaunchKernelGGL(ecc_iterate_kernel, dim3((w * h + ECC_BLOCK - 1) / ECC_BLOCK), dim3(ECC_BLOCK), 0, st, d_templ, d_image, d_gx, d_gy,
+		hipLaunchKernelGGL(ecc_iterate_kernel, dim3(ecc_blocks(w, h)), dim3(ECC_BLOCK), 0, st, d_templ, d_image, d_gx, d_gy,
 						   d_mask, w, h, d_partials, d_state);
+		return hipGetLastError();
+	}
+} // namespace rir
+
+// ---- min-max normalisation (MaskedRegistratorECC.compute, masked_registration_ecc.py:162-166) ----------------
+// im = (im - min) / (max - min) in float32, exactly the two numpy operations of the reference; the crop to the
+// registration window is folded into the read (row stride `src_stride` elements, output dense w x h).
+namespace rir
+{
+	__global__ __launch_bounds__(256) void minmax_partial_kernel(const float *__restrict__ src, int w, int h, int src_stride, float *__restrict__ part)
+	{
+		float mn = 3.402823466e38f, mx = -3.402823466e38f;
+		const int n = w * h;
+		for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+		{
+			const int y = i / w, x = i - y * w;
+			const float v = src[(int64_t)y * src_stride + x];
+			mn = fminf(mn, v);
+			mx = fmaxf(mx, v);
+		}
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1)
+		{
+			mn = fminf(mn, __shfl_xor(mn, d, 64));
+			mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+		}
+		__shared__ float smn[4], smx[4];
+		if ((threadIdx.x & 63) == 0)
+			smn[threadIdx.x >> 6] = mn, smx[threadIdx.x >> 6] = mx;
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			part[2 * blockIdx.x] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+			part[2 * blockIdx.x + 1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+		}
+	}
+
+	__global__ __launch_bounds__(256) void minmax_apply_kernel(const float *__restrict__ src, int w, int h, int src_stride, const float *__restrict__ part,
+															   int nparts, float *__restrict__ dst)
+	{
+		float mn = part[0], mx = part[1];
+		for (int k = 1; k < nparts; ++k)
+		{
+			mn = fminf(mn, part[2 * k]);
+			mx = fmaxf(mx, part[2 * k + 1]);
+		}
+		const float range = mx - mn;
+		const int n = w * h;
+		for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+		{
+			const int y = i / w, x = i - y * w;
+			dst[i] = (src[(int64_t)y * src_stride + x] - mn) / range;
+		}
+	}
+
+	hipError_t launch_minmax_normalize(const float *d_src, int w, int h, int src_stride, float *d_dst, float *d_part /* >= 2*64 floats */, hipStream_t st)
+	{
+		const int nparts = 64;
+		hipLaunchKernelGGL(minmax_partial_kernel, dim3(nparts), dim3(256), 0, st, d_src, w, h, src_stride, d_part);
+		hipLaunchKernelGGL(minmax_apply_kernel, dim3((w * h + 255) / 256 < 1024 ? (w * h + 255) / 256 : 1024), dim3(256), 0, st, d_src, w, h, src_stride,
+						   d_part, nparts, d_dst);
 		return hipGetLastError();
 	}
 } // namespace rir

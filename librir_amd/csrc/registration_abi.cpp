@@ -17,7 +17,7 @@ namespace
 	struct EccScratch
 	{
 		std::mutex mu;
-		DeviceBuffer gx, gy, partials, state, templ, image, mask;
+		DeviceBuffer gx, gy, partials, state, templ, image, mask, mm;
 	};
 	EccScratch &scratch()
 	{
@@ -44,7 +44,7 @@ namespace
 		int launched = 0;
 		while (true)
 		{
-			const int batch = std::min(8, max_iter - launched);
+			const int batch = std::min(launched == 0 ? 4 : 8, max_iter - launched); // most alignments of a tracked sequence settle within 4
 			for (int i = 0; i < batch; ++i)
 				if (!hip_ok(launch_ecc_iterate(d_templ, d_image, sc.gx.as<float>(), sc.gy.as<float>(), d_mask, w, h, sc.partials.as<double>(),
 											   d_state, st),
@@ -111,4 +111,23 @@ RIR_EXPORT int find_transform_ecc_translation(const float *templ, const float *i
 		return -1;
 	return run_ecc(sc, sc.templ.as<float>(), sc.image.as<float>(), mask ? sc.mask.as<uint8_t>() : nullptr, w, h, warp, max_iterations, eps, cc,
 				   nullptr, st);
+}
+
+// (im - min(im)) / (max(im) - min(im)) in float32 on a window of a device image: the normalisation MaskedRegistratorECC
+// applies to both images before the alignment (masked_registration_ecc.py:162-166).  d_src: float rows of `src_stride`
+// elements, the window starts at d_src; d_dst: dense [h][w].
+RIR_EXPORT int rir_minmax_normalize_device(const float *d_src, int w, int h, int src_stride, float *d_dst, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (!d_src || !d_dst || w <= 0 || h <= 0 || src_stride < w)
+	{
+		log_error("rir_minmax_normalize_device: invalid argument");
+		return -1;
+	}
+	EccScratch &sc = scratch();
+	std::lock_guard<std::mutex> lock(sc.mu);
+	if (!sc.mm.reserve(2 * 64 * sizeof(float)))
+		return -1;
+	return hip_ok(launch_minmax_normalize(d_src, w, h, src_stride, d_dst, sc.mm.as<float>(), (hipStream_t)stream), "minmax_normalize") ? 0 : -1;
 }

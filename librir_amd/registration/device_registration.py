@@ -1,0 +1,96 @@
+"""``MaskedRegistratorECC`` for frames that already live in HBM (torch tensors on the device).
+
+Same steps and arithmetic as ``masked_registration_ecc.MaskedRegistratorECC`` (reference
+src/python/librir/registration/masked_registration_ecc.py:88-191) - gaussian pre-filter, centred crop, min-max
+normalisation, translation-only ECC with the previous result as start value, change of reference image on a
+confidence drop - with every pixel operation on the device: per frame one gaussian, two small normalisation
+kernels, the ECC iterations and a read-back of (tx, ty, cc).  The static / percentile masks of the host class
+are not offered here."""
+import ctypes as ct
+
+import numpy as np
+import torch
+
+from .. import device as D
+from ..low_level.misc import _lib, last_error
+
+_vp = ct.c_void_p
+_lib.rir_minmax_normalize_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, _vp, _vp]
+_lib.rir_ecc_translation_device.argtypes = [_vp, _vp, _vp, ct.c_int, ct.c_int, _vp, ct.c_int, ct.c_double, ct.POINTER(ct.c_double),
+                                            ct.POINTER(ct.c_int), _vp]
+
+
+def _stream():
+    return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class DeviceRegistratorECC:
+    def __init__(self, window_factorh=0.7, window_factorv=0.7, sigma=0.5, shape=(512, 640)):
+        self.sigma = sigma
+        self.x, self.y, self.confidences = [], [], []
+        self.subW = int(shape[1] * window_factorh)
+        self.subH = int(shape[0] * window_factorv)
+        self.startX = int((shape[1] - self.subW) / 2)
+        self.startY = int((shape[0] - self.subH) / 2)
+        self.conf_thresh = None
+        self.number_of_iterations = 500
+        self.termination_eps = 1e-3
+        self.warp = np.zeros(2, np.float32)
+        self._ref_n = None
+
+    def _filtered(self, img):
+        img = img if img.dim() == 2 else img[0]
+        if img.dtype != torch.float32 and img.dtype != torch.uint16:
+            img = img.to(torch.float32)
+        return D.gaussian_filter(img, self.sigma)[0] if self.sigma > 0 else img.to(torch.float32)
+
+    def _normalised_window(self, full):
+        """dense float32 (subH, subW): the min-max normalised registration window of a full filtered frame"""
+        w = full.shape[1]
+        win = full[self.startY:self.startY + self.subH, self.startX:self.startX + self.subW]  # strided view, not copied
+        out = torch.empty((self.subH, self.subW), dtype=torch.float32, device=full.device)
+        if _lib.rir_minmax_normalize_device(win.data_ptr(), self.subW, self.subH, w, out.data_ptr(), _stream()) != 0:
+            raise RuntimeError("rir_minmax_normalize_device: %s" % last_error())
+        return out
+
+    def start(self, img):
+        g = self._filtered(img)
+        self._ref_full = g
+        self._ref_n = self._normalised_window(g)
+        self.x.append(0)
+        self.y.append(0)
+        self.confidences.append(1)
+
+    def compute(self, img):
+        g = self._filtered(img)
+        im_n = self._normalised_window(g)
+        cc = ct.c_double(0)
+        if _lib.rir_ecc_translation_device(self._ref_n.data_ptr(), im_n.data_ptr(), None, self.subW, self.subH, self.warp.ctypes.data,
+                                           self.number_of_iterations, self.termination_eps, ct.byref(cc), None, _stream()) != 0:
+            raise RuntimeError("ECC: %s" % last_error())
+        shift = [float(self.warp[1]), float(self.warp[0])]
+        self.confidences.append(cc.value)
+        self.x.append(shift[1])
+        self.y.append(shift[0])
+        if len(self.confidences) > 20:
+            if self.conf_thresh is None:
+                self.conf_thresh = np.min(self.confidences) - 2 * np.std(self.confidences)
+            if cc.value < self.conf_thresh:  # change of reference image: the current window, shifted back
+                win = g[self.startY:self.startY + self.subH, self.startX:self.startX + self.subW].contiguous()
+                moved = D.translate(win, (-shift[1], -shift[0]), "")[0]
+                out = torch.empty_like(moved)
+                if _lib.rir_minmax_normalize_device(moved.data_ptr(), self.subW, self.subH, self.subW, out.data_ptr(), _stream()) != 0:
+                    raise RuntimeError("rir_minmax_normalize_device: %s" % last_error())
+                self._ref_n = out
+                self.warp[:] = 0
+        return shift
+
+    def return_coordinates_and_confidence_values(self):
+        return np.array([self.x, self.y, self.confidences]).T
+
+    def to_reg_file(self, dest_file):
+        arr = self.return_coordinates_and_confidence_values()
+        with open(dest_file, "w") as f:
+            f.write("\tx-axis translations\ty-axis translations\tConfidence level\n")
+            for i, (x, y, c) in enumerate(arr):
+                f.write("%d\t%s\t%s\t%s\n" % (i, repr(float(x)), repr(float(y)), repr(float(c))))

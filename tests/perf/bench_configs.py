@@ -216,6 +216,16 @@ t0 = time.perf_counter()
 for i in range(1, nreg):
     regr.compute(f32[i])
 c4["registration_ecc_per_frame_fps"] = (nreg - 1) / (time.perf_counter() - t0)
+from librir_amd.registration import DeviceRegistratorECC  # noqa: E402
+
+tf32 = torch.from_numpy(f32[:nreg]).to(dev)
+dreg = DeviceRegistratorECC(1, 1)
+dreg.start(tf32[0])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(1, nreg):
+    dreg.compute(tf32[i])
+c4["registration_ecc_device_resident_fps"] = (nreg - 1) / (time.perf_counter() - t0)
 c4["registration_max_error_px"] = float(max(np.abs(np.array(regr.x) - shifts[:nreg, 0]).max(), np.abs(np.array(regr.y) - shifts[:nreg, 1]).max()))
 
 

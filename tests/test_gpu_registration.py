@@ -77,3 +77,23 @@ def test_registrator_on_the_reference_recipe(tmp_path, oracle):
     exp = oracle.remove_motion(u16[i], np.float32(reg.x[i]), np.float32(reg.y[i]), rows=512 - 3)
     assert np.array_equal(mov[i], exp)
     mov.close()
+
+
+def test_device_resident_registrator_equals_the_host_class():
+    """DeviceRegistratorECC keeps the frames in HBM; same kernels, same float32 normalisation: same track."""
+    import torch
+
+    from librir_amd.registration import DeviceRegistratorECC
+
+    n = 40
+    f, s = s3_registration(n)
+    host = MaskedRegistratorECC(0.7, 0.7)
+    host.start(f[0])
+    dev = DeviceRegistratorECC(0.7, 0.7)
+    t = torch.from_numpy(f).cuda()
+    dev.start(t[0])
+    for i in range(1, n):
+        host.compute(f[i])
+        dev.compute(t[i])
+    assert np.allclose(dev.x, host.x, rtol=0, atol=1e-5) and np.allclose(dev.y, host.y, rtol=0, atol=1e-5)
+    assert np.allclose(dev.confidences, host.confidences, rtol=0, atol=1e-7)
