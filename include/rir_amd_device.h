@@ -66,7 +66,9 @@ extern "C"
 	 * dtype char ('?','b','B','h','H','i','I','l','L','f','d'); d_offsets holds float (dx,dy)
 	 * pairs - one pair per frame when per_frame_offsets != 0, else a single pair; background
 	 * is a HOST pointer to one element; d_dst must be pre-filled by the caller (strategy
-	 * "noborder" leaves border pixels as they are). */
+	 * "noborder" leaves border pixels as they are).  The extra strategy "noborder_source" gives the result of
+	 * "noborder" on a destination pre-filled with a copy of the input - what the Python wrappers do
+	 * (rir_signal_processing.py:54-55) - without that copy: d_dst need not be initialised. */
 	int rir_translate_device(int type, const void *d_src, void *d_dst, int w, int h, int nframes, const float *d_offsets, int per_frame_offsets,
 							 const void *background, const char *strategy, void *stream);
 

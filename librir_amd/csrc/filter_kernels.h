@@ -10,7 +10,10 @@ namespace rir
 		TRANSLATE_UNCHANGED = 0, // reference TranslateUnchanged, Filters.h:238-244
 		TRANSLATE_CONSTANT = 1,
 		TRANSLATE_WRAP = 2,
-		TRANSLATE_NEAREST = 3
+		TRANSLATE_NEAREST = 3,
+		TRANSLATE_SOURCE = 4 // device layer only: pixels without a source take the input pixel at the same position, i.e.
+							 // "noborder" on a destination pre-filled with a copy of the input (what the wrappers do,
+							 // reference rir_signal_processing.py:54-55) without the copy
 	};
 
 	hipError_t launch_translate(int type, const void *src, void *dst, const void *background, int w, int h, int nframes, const float *d_offsets,

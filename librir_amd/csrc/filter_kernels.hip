@@ -123,6 +123,11 @@ namespace rir
 		{
 			if (strategy == TRANSLATE_UNCHANGED)
 				return false;
+			if (strategy == TRANSLATE_SOURCE)
+			{
+				out = tap_as<T, U>(s[x + (uint64_t)y * w]);
+				return true;
+			}
 			if (strategy == TRANSLATE_CONSTANT)
 			{
 				out = background;

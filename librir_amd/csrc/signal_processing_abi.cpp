@@ -31,6 +31,8 @@ namespace
 			return TRANSLATE_WRAP;
 		if (std::strcmp(s, "nearest") == 0)
 			return TRANSLATE_NEAREST;
+		if (std::strcmp(s, "noborder_source") == 0) // device layer: "noborder" over an implicit copy of the input
+			return TRANSLATE_SOURCE;
 		return -1;
 	}
 

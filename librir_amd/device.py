@@ -206,8 +206,11 @@ def translate(frames, offsets, strategy="", background=0):
     per_frame = 1 if off.dim() == 2 else 0
     if per_frame and off.shape[0] != n:
         raise RuntimeError("translate: one (dx,dy) pair per frame expected")
-    # "noborder" leaves the pixels without a source as they are: the wrapper pre-fills with the input
-    dst = fr.clone() if strategy in ("", "noborder") else torch.empty_like(fr)
+    # "noborder" leaves the pixels without a source as they are and the wrapper pre-fills with the input
+    # (reference rir_signal_processing.py:54-55): "noborder_source" is that, without the copy
+    dst = torch.empty_like(fr)
+    if strategy in ("", "noborder"):
+        strategy = "noborder_source"
     back = np.zeros(1, dtype=_NP_OF[fr.dtype])
     back[0] = background
     if strategy == "constant":
