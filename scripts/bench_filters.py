@@ -27,7 +27,7 @@ def rec(name, ms, bytes_per_frame):
 offs = torch.tensor([1.25, -2.5], dtype=torch.float32, device="cuda")
 rec("translate u16 nearest", timeit(lambda: D.translate(t16, offs, "nearest")), 4 * WH)
 rec("translate f32 nearest", timeit(lambda: D.translate(f32, offs, "nearest")), 8 * WH)
-rec("translate u16 noborder (+prefill)", timeit(lambda: D.translate(t16, offs, "")), 4 * WH)
+rec("translate u16 noborder", timeit(lambda: D.translate(t16, offs, "")), 4 * WH)
 for s in (0.75, 1.0, 2.0):
     rec("gaussian sigma=%g" % s, timeit(lambda: D.gaussian_filter(f32, s)), 8 * WH)
 bp = D.BadPixels(t16[0])
