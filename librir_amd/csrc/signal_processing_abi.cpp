@@ -472,9 +472,10 @@ RIR_EXPORT int translate(int type, void *src, void *dst, int w, int h, float dx,
 	if (!s.a.reserve(bytes) || !s.b.reserve(bytes) || !s.c.reserve(8))
 		return -1;
 	const float off[2] = {dx, dy};
-	// dst is an in/out buffer: "noborder" keeps whatever the caller put there (Filters.h:261-264)
+	// dst is an in/out buffer: "noborder" keeps whatever the caller put there (Filters.h:261-264), so only that
+	// strategy needs the caller's dst on the device; the others write every pixel
 	if (!hip_ok(hipMemcpyAsync(s.a.ptr, src, bytes, hipMemcpyHostToDevice, st), "H2D") ||
-		!hip_ok(hipMemcpyAsync(s.b.ptr, dst, bytes, hipMemcpyHostToDevice, st), "H2D") ||
+		(strategy_from_string(strategy) == TRANSLATE_UNCHANGED && !hip_ok(hipMemcpyAsync(s.b.ptr, dst, bytes, hipMemcpyHostToDevice, st), "H2D")) ||
 		!hip_ok(hipMemcpyAsync(s.c.ptr, off, sizeof(off), hipMemcpyHostToDevice, st), "H2D"))
 		return -1;
 	if (rir_translate_device(type, s.a.ptr, s.b.ptr, w, h, 1, s.c.as<float>(), 0, background, strategy, st) != 0)
