@@ -171,3 +171,32 @@ def test_gpu_encoder_reproduces_the_frozen_format(dev):
         st = enc.stream.cpu().numpy().view(np.uint64)[:words]
         c = fix["cases"][name]
         assert (G.digest(hdr), G.digest(off), G.digest(st), words) == (c["hdr"], c["tile_off"], c["stream"], c["words"]), name
+
+
+def test_identity_with_offsets_beyond_4_gib(dev):
+    """3 000 frames of 1024x768 = 4.7 GB of raw frames in one batch: every frame / slot / stream offset of the second
+    half needs 64-bit arithmetic (the MI355X holds 288 GB: batches of this size are the intended use)."""
+    import torch
+
+    n, h, w = 3000, 768, 1024
+    base = torch.from_numpy(s1_noisy_background(250, h, w, seed=3)).cuda()
+    t = base.repeat(n // 250, 1, 1).contiguous()
+    t.view(torch.int16)[1::250] += 3
+    ctx = dev.CodecContext(w, h, n, 50)
+    enc = ctx.encode(t)
+    out = ctx.decode(enc)
+    assert torch.equal(out.view(torch.int16), t.view(torch.int16))
+    assert t.numel() * 2 / enc.compressed_bytes() > 4
+    # the last chunk alone decodes to the last 50 frames: tables of a late chunk are self-contained
+    last = ctx.layout.nchunks - 1
+    coff = enc.chunk_off.cpu().numpy()
+    sub = dev.CodecContext(w, h, 50, 50)
+    sub.hdr.copy_(enc.hdr[last:last + 1])
+    sub.tile_off.copy_(enc.tile_off[last:last + 1])
+    sub.chunk_off.copy_(torch.tensor([0, coff[last + 1] - coff[last]], dtype=torch.int64))
+    nw = int(coff[last + 1] - coff[last])
+    sub.stream[:nw].copy_(enc.stream[int(coff[last]):int(coff[last + 1])])
+    from librir_amd.device import EncodedBatch
+
+    dec = sub.decode(EncodedBatch(sub.layout, sub.hdr, sub.tile_off, sub.chunk_off, sub.stream))
+    assert torch.equal(dec.view(torch.int16), t[-50:].view(torch.int16))
