@@ -44,88 +44,87 @@ def find_transform_ecc_translation(template, image, warp_matrix=None, max_iterat
 
 
 class MaskedRegistratorECC:
-    """First image through ``start()``, the following ones through ``compute()``; the translations from the
-    very first image accumulate in ``x`` / ``y``, the correlation coefficients in ``confidences``."""
+    """Tracks the translation of every image of a sequence with respect to the first one.
+
+    ``start(first_image)`` once, then ``compute(image)`` per image; results accumulate in ``x``, ``y`` (pixels, with
+    respect to the very first image) and ``confidences`` (correlation coefficients).  Constructor arguments as upstream:
+    the window factors pick a centred sub-window, ``sigma`` pre-filters with a gaussian (0 = off), ``mask`` is a static
+    0/1 image, ``median`` < 1 keeps only that fraction of the lowest pixels (dynamic mask), ``ref`` fixes the reference
+    image, ``pre_process`` is applied to every image first."""
+
+    CAMERA_SHAPE = (512, 640)  # upstream defines the window on the camera format, whatever the image size (:78)
+    HISTORY_BEFORE_RESET = 20  # confidences collected before a drop may trigger a change of reference (:177)
 
     def __init__(self, window_factorh=0.7, window_factorv=0.7, sigma=0.5, mask=None, median=1, ref=None, pre_process=None, view=None):
-        self.sigma = sigma
-        self.x = []
-        self.y = []
-        self.confidences = []
-        self.ref_img = None
-        self.ref = ref
-        if ref is not None and pre_process is not None:
-            self.ref = pre_process(ref)
-        if sigma > 0 and self.ref is not None:
-            self.ref = gaussian_filter(self.ref, sigma)
+        self.sigma, self.mask, self.median, self.pre_process, self.view = sigma, mask, median, pre_process, view
+        self.window_factorH, self.window_factorV = window_factorh, window_factorv
+        rows, columns = self.CAMERA_SHAPE
+        self.subW, self.subH = int(columns * window_factorh), int(rows * window_factorv)
+        self.startX, self.startY = int((columns - self.subW) / 2), int((rows - self.subH) / 2)
+        self.x, self.y, self.confidences = [], [], []
+        self.ref_img = None       # registration window of the current reference image
         self.mask_ref_img = None
-        self.window_factorH = window_factorh
-        self.window_factorV = window_factorv
-        shape = (512, 640)  # the crop window is defined on the camera format, like upstream (:78)
-        self.subW = int(shape[1] * self.window_factorH)
-        self.subH = int(shape[0] * self.window_factorV)
-        self.startX = int((shape[1] - self.subW) / 2)
-        self.startY = int((shape[0] - self.subH) / 2)
-        self.mask = mask
-        self.conf_thresh = None
-        self.pre_process = pre_process
-        self.view = view
-        self.median = median
+        self.conf_thresh = None   # fixed the first time HISTORY_BEFORE_RESET is exceeded: min - 2 std of the history
         self.start_mat = np.eye(2, 3, dtype=np.float32)
-        self.number_of_iterations = 500  # :133
-        self.termination_eps = 1e-3      # :137
+        self.number_of_iterations = 500   # criteria of the upstream call (:133-137)
+        self.termination_eps = 1e-3
+        self.ref = None
+        if ref is not None:
+            self.ref = self._prepared(ref)
+
+    # ---- pieces ------------------------------------------------------------------------------------------------------
+    def _prepared(self, img):
+        """user pre-processing, then the gaussian pre-filter"""
+        if self.pre_process is not None:
+            img = self.pre_process(img)
+        return gaussian_filter(img, self.sigma) if self.sigma > 0 else img
 
     def _window(self, img):
         return img[self.startY:self.startY + self.subH, self.startX:self.startX + self.subW]
 
+    @staticmethod
+    def _unit_range(im):
+        lowest, highest = np.min(im), np.max(im)
+        return (im - lowest) / (highest - lowest)
+
+    def _record(self, tx, ty, confidence):
+        self.x.append(tx)
+        self.y.append(ty)
+        self.confidences.append(confidence)
+
+    # ---- the two calls ---------------------------------------------------------------------------------------------------
     def start(self, img):
-        if self.pre_process is not None:
-            img = self.pre_process(img)
-        if self.sigma > 0:
-            img = gaussian_filter(img, self.sigma)
-        self.ref_img = self._window(img)
+        self.ref_img = self._window(self._prepared(img))
         if self.mask is not None:
             self.mask = self._window(self.mask)
-        self.x.append(0)
-        self.y.append(0)
-        self.confidences.append(1)
+        self._record(0, 0, 1)
 
     def compute(self, img):
-        if self.pre_process is not None:
-            img = self.pre_process(img)
-        if self.sigma > 0:
-            img = gaussian_filter(img, self.sigma)
-        new_im = self._window(img).copy()
-        im1 = np.array(self.ref_img if self.ref is None else self.ref, dtype=np.float32)
-        im2 = np.array(new_im, dtype=np.float32)
-        mask = self.mask
-        if self.median < 1:  # dynamic mask: clip everything above the chosen percentile (:152-160)
-            thresh = max(find_median_pixel(new_im, self.median, mask), find_median_pixel(self.ref_img, self.median, mask))
-            sel = (im1 > thresh) | (im2 > thresh)
-            im1[sel] = thresh
-            im2[sel] = thresh
-        mi, ma = np.min(im1), np.max(im1)
-        im1 = (im1 - mi) / (ma - mi)
-        mi, ma = np.min(im2), np.max(im2)
-        im2 = (im2 - mi) / (ma - mi)
-        cc, warp_matrix = find_transform_ecc_translation(im1, im2, self.start_mat, self.number_of_iterations, self.termination_eps, mask)
-        self.start_mat = warp_matrix
-        shift = [warp_matrix[1, 2], warp_matrix[0, 2]]
-        self.confidences.append(cc)
-        self.x.append(shift[1])
-        self.y.append(shift[0])
-        if len(self.confidences) > 20 and self.ref is None:  # change of reference image on a confidence drop (:177-189)
+        current = self._window(self._prepared(img)).copy()
+        template = np.array(self.ref_img if self.ref is None else self.ref, dtype=np.float32)
+        moving = np.array(current, dtype=np.float32)
+        if self.median < 1:  # dynamic mask (:152-160): everything above the chosen percentile of either image is clipped
+            level = max(find_median_pixel(current, self.median, self.mask), find_median_pixel(self.ref_img, self.median, self.mask))
+            too_bright = (template > level) | (moving > level)
+            template[too_bright] = level
+            moving[too_bright] = level
+        cc, warp = find_transform_ecc_translation(self._unit_range(template), self._unit_range(moving), self.start_mat,
+                                                  self.number_of_iterations, self.termination_eps, self.mask)
+        self.start_mat = warp  # the next image starts from this one's result
+        shift = [warp[1, 2], warp[0, 2]]  # (dy, dx), the order upstream returns
+        self._record(shift[1], shift[0], cc)
+        if self.ref is None and len(self.confidences) > self.HISTORY_BEFORE_RESET:
             if self.conf_thresh is None:
                 self.conf_thresh = np.min(self.confidences) - 2 * np.std(self.confidences)
-            if cc < self.conf_thresh:
-                self.ref_img = translate(new_im, -shift[1], -shift[0])
+            if cc < self.conf_thresh:  # the scene changed too much: this image, shifted back, becomes the reference (:179-189)
+                self.ref_img = translate(current, -shift[1], -shift[0])
                 self.start_mat = np.eye(2, 3, dtype=np.float32)
         return shift
 
+    # ---- results -------------------------------------------------------------------------------------------------------------
     def append_last_coordinates_and_confidence(self):
-        self.x.append(self.x[-1])
-        self.y.append(self.y[-1])
-        self.confidences.append(self.confidences[-1])
+        """Repeat the last result (an image that could not be registered keeps its predecessor's translation)."""
+        self._record(self.x[-1], self.y[-1], self.confidences[-1])
 
     def return_coordinates_and_confidence_values(self):
         return np.array([self.x, self.y, self.confidences]).T
@@ -138,10 +137,11 @@ class MaskedRegistratorECC:
                             columns=["x-axis translations", "y-axis translations", "Confidence level"])
 
     def to_reg_file(self, dest_file):
-        """Tab-separated, one header line, index + 3 columns: what ``load_motion_correction_file`` parses
-        (IRFileLoader.cpp:822-847) and what pandas' ``to_csv(sep="\\t")`` writes upstream (:214-215)."""
-        arr = self.return_coordinates_and_confidence_values()
-        with open(dest_file, "w") as f:
-            f.write("\tx-axis translations\ty-axis translations\tConfidence level\n")
-            for i, (x, y, c) in enumerate(arr):
-                f.write("%d\t%s\t%s\t%s\n" % (i, repr(float(x)), repr(float(y)), repr(float(c))))
+        """Tab-separated text, one header line, then ``index x y confidence`` per image: the layout pandas'
+        ``to_csv(sep="\t")`` gives upstream (:214-215) and ``load_motion_correction_file`` parses
+        (IRFileLoader.cpp:822-847: columns 1 and 2 are x and y)."""
+        rows = self.return_coordinates_and_confidence_values()
+        with open(dest_file, "w") as out:
+            out.write("\t".join(["", "x-axis translations", "y-axis translations", "Confidence level"]) + "\n")
+            for index, (tx, ty, confidence) in enumerate(rows):
+                out.write("\t".join([str(index), repr(float(tx)), repr(float(ty)), repr(float(confidence))]) + "\n")

@@ -1,6 +1,12 @@
-"""IRMovie: reader object over a video file (reference src/python/librir/video_io/IRMovie.py:72-676,
-the part used by the hot path: construction from a file / bytes / numpy array, indexing, slicing,
-timestamps, attributes, bad-pixel and motion correction on read-back, re-encoding)."""
+"""Reading side of the Python interface: ``IRMovie`` gives array-like access to the images of a recording.
+
+Public interface (class methods ``from_filename`` / ``from_bytes`` / ``from_numpy_array``, indexing and slicing,
+``data``, ``timestamps``, ``attributes``, ``frame_attributes``, ``bad_pixels_correction``, ``registration*``,
+``to_h264`` ...) as the reference class ``librir.video_io.IRMovie`` (reference
+src/python/librir/video_io/IRMovie.py:72-676) for the part the hot path needs; the implementation is this build's:
+frames are decoded on the MI355X a chunk at a time, the read-back filters run there as well, and one image crosses
+PCIe per ``load_pos``.  Only digital levels are offered (no calibration plugin is shipped).
+"""
 import math
 import os
 import tempfile
@@ -10,14 +16,14 @@ from pathlib import Path
 import numpy as np
 
 from ..tools.FileAttributes import FileAttributes
+from . import rir_video_io as _abi
 from .IRSaver import IRSaver
-from .rir_video_io import (close_camera, enable_bad_pixels, enable_motion_correction, flip_camera_calibration, get_attributes,
-                           get_filename, get_global_attributes, get_image_count, get_image_size, get_image_time, load_image,
-                           load_motion_correction_file, motion_correction_enabled, open_camera_file, open_camera_memory, support_emissivity,
-                           supported_calibrations, video_file_format)
+
+_TI_MASK, _TI_SHIFT = 0xE000, 13  # the three top bits of a digital level carry the integration-time index
 
 
 class FileFormat(Enum):
+    """``video_file_format`` codes (reference src/cpp/video_io/video_io.h FILE_FORMAT_*)"""
     PCR = 1
     WEST = 2
     PCR_ENCAPSULATED = 3
@@ -32,83 +38,101 @@ class InvalidMovie(Exception):
 
 
 def create_pcr_header(rows, columns, frequency=50, bits=16):
-    """1024-byte PCR header as 256 uint32 (reference IRMovie.py:60-69)"""
-    header = np.zeros((256,), dtype=np.uint32)
-    header[2] = columns
-    header[3] = rows
-    header[5] = bits
-    header[7] = frequency
-    header[9] = rows * columns * 2
-    header[10] = columns
-    header[11] = rows
-    return header
+    """The 1024-byte header of a raw PCR file as 256 little-endian uint32 (layout: reference IRFileLoader.h:43-61;
+    words 2/3 = X/Y, 5 = Bits, 7 = Frequency, 9 = bytes per image, 10/11 = grab size)."""
+    words = np.zeros(256, dtype=np.uint32)
+    for index, value in ((2, columns), (3, rows), (5, bits), (7, frequency), (9, rows * columns * 2), (10, columns), (11, rows)):
+        words[index] = value
+    return words
+
+
+def _remove_quietly(path):
+    try:
+        if path and os.path.exists(str(path)):
+            os.unlink(str(path))
+    except OSError:
+        pass
 
 
 class IRMovie(object):
-    _file_attributes = None
+    _file_attributes = None  # second, independent object on the same file: global attributes can be rewritten through it
+
+    # ---- construction ------------------------------------------------------------------------------------------------
+    def __init__(self, handle):
+        if _abi.get_image_count(handle) < 0:
+            raise InvalidMovie("Invalid ir_movie descriptor")
+        self.handle = handle
+        self.times = None  # seconds, filled on the first load_secs
+        self._calibration_index = 0
+        self._seconds = None
+        self._bp_on = False
+        self._reg_file = None
+        self._per_frame = {}  # position -> attributes of that image, as read
+        self._current = -1
+        self._owned_file = None  # temporary file this object must delete on close
+
+    @classmethod
+    def _attach_attributes(cls, movie, opener, source, optional):
+        try:
+            fa = opener(source)
+            fa.attributes = _abi.get_global_attributes(movie.handle)
+            movie._file_attributes = fa
+        except RuntimeError:
+            if not optional:
+                movie.close()
+                raise
+            movie._file_attributes = None  # a movie in memory may carry no trailer: read-only attributes then
+        return movie
 
     @classmethod
     def from_filename(cls, filename):
-        handle = open_camera_file(str(filename))
-        instance = cls(handle)
-        instance._file_attributes = FileAttributes.from_filename(filename)
-        instance._file_attributes.attributes = get_global_attributes(handle)
-        return instance
+        return cls._attach_attributes(cls(_abi.open_camera_file(str(filename))), FileAttributes.from_filename, filename, False)
 
     @classmethod
     def from_bytes(cls, data):
-        handle = open_camera_memory(data)
-        instance = cls(handle)
-        try:
-            instance._file_attributes = FileAttributes.from_buffer(data)
-            instance._file_attributes.attributes = get_global_attributes(handle)
-        except RuntimeError:
-            instance._file_attributes = None
-        return instance
+        return cls._attach_attributes(cls(_abi.open_camera_memory(data)), FileAttributes.from_buffer, data, True)
 
     @classmethod
     def from_numpy_array(cls, arr, attrs=None, times=None, cthreads=8):
-        """Writes the array as a raw PCR file, re-encodes it (round trip through the codec) and
-        opens the result, like the reference (IRMovie.py:108-144)."""
-        arr = np.asarray(arr)
-        if arr.ndim == 2:
-            rows, columns = arr.shape
-        elif arr.ndim == 3:
-            _, rows, columns = arr.shape
-        else:
+        """The array goes through the codec: it is written as a raw PCR file, re-encoded, and the encoded file is what
+        the returned movie reads (both temporary files are cleaned up), like the reference (IRMovie.py:108-144)."""
+        frames = np.asarray(arr)
+        if frames.ndim not in (2, 3):
             raise ValueError("mismatch array shape. Must be 2D or 3D")
-        data = create_pcr_header(rows, columns).astype(np.uint32).tobytes() + arr.astype(np.uint16).tobytes()
-        with tempfile.NamedTemporaryFile("wb", delete=False) as f:
-            filename = Path(f.name)
-            f.write(data)
-        with cls.from_filename(filename) as _instance:
-            _instance.__tempfile__ = filename
-            dst = Path(filename).parent / (filename.stem + ".h264")
-            _instance.to_h264(dst, times=times, cthreads=cthreads)
-        instance = cls.from_filename(dst)
-        instance.__tempfile__ = dst
+        rows, columns = frames.shape[-2:]
+        with tempfile.NamedTemporaryFile("wb", suffix=".pcr", delete=False) as raw:
+            raw.write(create_pcr_header(rows, columns).tobytes())
+            raw.write(np.ascontiguousarray(frames, dtype=np.uint16).tobytes())
+        raw_path = Path(raw.name)
+        encoded = raw_path.with_suffix(".h264")
+        with cls.from_filename(raw_path) as source:
+            source._owned_file = raw_path
+            source.to_h264(encoded, times=times, cthreads=cthreads)
+        movie = cls.from_filename(encoded)
+        movie._owned_file = encoded
         if attrs is not None:
-            instance.attributes = attrs
-            instance._file_attributes.flush()
-        return instance
+            movie.attributes = attrs
+            movie._file_attributes.flush()
+        return movie
 
-    def __init__(self, handle):
-        if get_image_count(handle) < 0:
-            raise InvalidMovie("Invalid ir_movie descriptor")
-        self.handle = handle
-        self.times = None
-        self._bad_pixels_correction = False
-        self.__tempfile__ = ""
-        self._calibration_index = 0
-        self._timestamps = None
-        self._frame_attributes_d = {}
-        self._registration_file = None
+    # ---- life cycle ----------------------------------------------------------------------------------------------------
+    def close(self):
+        fa, self._file_attributes = self._file_attributes, None
+        if fa is not None:
+            try:
+                fa.close()
+            except Exception:
+                pass
+        handle, self.handle = getattr(self, "handle", 0), 0
+        if handle > 0:
+            _abi.close_camera(handle)
+        owned, self._owned_file = getattr(self, "_owned_file", None), None
+        _remove_quietly(owned)
 
-    # ---- life cycle ----
     def __enter__(self):
         return self
 
-    def __exit__(self, exc_type, exc_val, exc_tb):
+    def __exit__(self, *exc):
         self.close()
 
     def __del__(self):
@@ -117,28 +141,26 @@ class IRMovie(object):
         except Exception:
             pass
 
-    def close(self):
-        if self._file_attributes is not None:
-            try:
-                self._file_attributes.close()
-            except Exception:
-                pass
-            self._file_attributes = None
-        if getattr(self, "handle", 0) > 0:
-            close_camera(self.handle)
-            self.handle = 0
-        tmp = getattr(self, "__tempfile__", "")
-        if tmp and os.path.exists(str(tmp)):
-            try:
-                os.unlink(str(tmp))
-            except OSError:
-                pass
-            self.__tempfile__ = ""
+    def __repr__(self):
+        return "IRMovie({})".format(self.filename)
 
-    # ---- calibration (only digital levels: no calibration plugin) ----
+    # ---- calibration: digital levels only --------------------------------------------------------------------------------
     @property
     def calibrations(self):
-        return supported_calibrations(self.handle)
+        return _abi.supported_calibrations(self.handle)
+
+    def _calibration_number(self, which):
+        names = self.calibrations
+        if isinstance(which, str):
+            if which in ("DL", "Digital Level"):
+                return 0
+            if which not in names:
+                raise RuntimeError("calibration not found: %s" % which)
+            return names.index(which)
+        number = int(which)
+        if not 0 <= number < len(names):
+            raise RuntimeError("calibration index out of range")
+        return number
 
     @property
     def calibration(self):
@@ -146,100 +168,83 @@ class IRMovie(object):
 
     @calibration.setter
     def calibration(self, value):
-        self._calibration_index = self._parse_calibration_index(value)
-
-    def _parse_calibration_index(self, value):
-        names = self.calibrations
-        if isinstance(value, str):
-            if value in ("DL", "Digital Level"):
-                return 0
-            if value in names:
-                return names.index(value)
-            raise RuntimeError("calibration not found: %s" % value)
-        value = int(value)
-        if value < 0 or value >= len(names):
-            raise RuntimeError("calibration index out of range")
-        return value
+        self._calibration_index = self._calibration_number(value)
 
     def flip_calibration(self, flip_rl, flip_ud):
-        flip_camera_calibration(self.handle, flip_rl, flip_ud)
+        _abi.flip_camera_calibration(self.handle, flip_rl, flip_ud)
 
     @property
     def support_emissivity(self):
-        return support_emissivity(self.handle)
+        return _abi.support_emissivity(self.handle)
 
-    # ---- geometry / access ----
+    # ---- geometry ----------------------------------------------------------------------------------------------------------
     @property
     def images(self):
-        return get_image_count(self.handle)
+        return _abi.get_image_count(self.handle)
+
+    def __len__(self):
+        return self.images
 
     @property
     def image_size(self):
-        return get_image_size(self.handle)
+        return _abi.get_image_size(self.handle)
 
-    @property
-    def width(self):
-        return self.image_size[1]
-
-    @property
-    def height(self):
-        return self.image_size[0]
+    height = property(lambda self: self.image_size[0])
+    width = property(lambda self: self.image_size[1])
 
     @property
     def filename(self):
-        return get_filename(self.handle)
+        return _abi.get_filename(self.handle)
 
     @property
     def video_file_format(self):
-        return FileFormat(video_file_format(self.filename))
+        return FileFormat(_abi.video_file_format(self.filename))
 
     @property
     def is_file_uncompressed(self):
         return self.video_file_format in (FileFormat.PCR, FileFormat.WEST, FileFormat.PCR_ENCAPSULATED)
 
+    # ---- images --------------------------------------------------------------------------------------------------------------
     def load_pos(self, pos, calibration=None):
-        if calibration is None:
-            calibration = 0
-        idx = self._parse_calibration_index(calibration)
-        res = load_image(self.handle, int(pos), idx)
-        self._frame_attributes_d[int(pos)] = get_attributes(self.handle)
-        self._last_pos = int(pos)
-        return res
+        """Image number ``pos`` (bad-pixel repair and motion correction applied when enabled)."""
+        pos = int(pos)
+        image = _abi.load_image(self.handle, pos, self._calibration_number(0 if calibration is None else calibration))
+        self._per_frame[pos] = _abi.get_attributes(self.handle)
+        self._current = pos
+        return image
 
     def load_secs(self, time, calibration=None):
+        """The image whose time stamp is closest to ``time`` (seconds)."""
         if self.times is None:
             self.times = np.array(list(self.timestamps), dtype=np.float64)
-        index = int(np.argmin(np.abs(self.times - time)))
-        return self.load_pos(index, calibration)
+        return self.load_pos(int(np.abs(self.times - time).argmin()), calibration)
+
+    def _positions(self, selection):
+        total = self.images
+        first = selection.start or 0
+        last = total if selection.stop is None or selection.stop == 0 else selection.stop
+        stride = selection.step or 1
+        first = first + total if first < 0 else first
+        last = last + total if last < 0 else last
+        return range(first, last, stride), math.ceil((last - first) / stride)
 
     def __getitem__(self, item):
         if isinstance(item, slice):
-            start, stop, step = item.start or 0, item.stop or self.images, item.step or 1
-            if stop < 0:
-                stop = self.images + stop
-            if start < 0:
-                start = self.images + start
-            shape = (math.ceil((stop - start) / step),) + tuple(self.image_size)
-            arr = np.empty(shape, dtype=np.uint16)
-            for idx, i in enumerate(range(start, stop, step)):
-                arr[idx] = self.load_pos(i, self._calibration_index)
-            return arr
+            positions, count = self._positions(item)
+            stack = np.empty((count,) + tuple(self.image_size), dtype=np.uint16)
+            for row, pos in enumerate(positions):
+                stack[row] = self.load_pos(pos, self._calibration_index)
+            return stack
         if isinstance(item, (int, np.integer)):
-            if item < 0:
-                item = self.images + item
-            return self.load_pos(int(item), self._calibration_index)
+            return self.load_pos(int(item) + (self.images if item < 0 else 0), self._calibration_index)
         if isinstance(item, float):
             return self.load_secs(item, self._calibration_index)
         if isinstance(item, list) or (isinstance(item, np.ndarray) and item.ndim == 1):
-            return np.array([self.__getitem__(e) for e in item])
+            return np.array([self[e] for e in item])
         raise TypeError("unsupported index type")
 
     def __iter__(self):
-        for i in range(self.images):
-            yield self.load_pos(i, self._calibration_index)
-
-    def __len__(self):
-        return self.images
+        return (self.load_pos(pos, self._calibration_index) for pos in range(self.images))
 
     @property
     def data(self):
@@ -247,18 +252,19 @@ class IRMovie(object):
 
     @property
     def tis(self):
-        return (self.data & (2**16 - 2**13)) >> 13
+        return (self.data & _TI_MASK) >> _TI_SHIFT
 
-    # ---- time ----
+    # ---- time --------------------------------------------------------------------------------------------------------------------
     @property
     def timestamps(self):
-        if self._timestamps is None:
-            self._timestamps = np.array([get_image_time(self.handle, i) * 1e-9 for i in range(self.images)], dtype=np.float64)
-        return self._timestamps
+        """seconds"""
+        if self._seconds is None:
+            self._seconds = np.fromiter((_abi.get_image_time(self.handle, pos) for pos in range(self.images)), dtype=np.float64) * 1e-9
+        return self._seconds
 
     @timestamps.setter
-    def timestamps(self, value):
-        self._timestamps = np.array(value) * 1e-9
+    def timestamps(self, nanoseconds):
+        self._seconds = np.array(nanoseconds) * 1e-9
 
     @property
     def frame_period(self):
@@ -266,14 +272,13 @@ class IRMovie(object):
 
     @property
     def duration(self):
-        return (get_image_time(self.handle, self.images - 1) - get_image_time(self.handle, 0)) * 1e-9
+        return (_abi.get_image_time(self.handle, self.images - 1) - _abi.get_image_time(self.handle, 0)) * 1e-9
 
-    # ---- attributes ----
+    # ---- attributes -----------------------------------------------------------------------------------------------------------------
     @property
     def attributes(self):
-        if self._file_attributes is None:
-            return get_global_attributes(self.handle)
-        return self._file_attributes.attributes
+        fa = self._file_attributes
+        return _abi.get_global_attributes(self.handle) if fa is None else fa.attributes
 
     @attributes.setter
     def attributes(self, value):
@@ -282,71 +287,61 @@ class IRMovie(object):
 
     @property
     def frame_attributes(self):
-        """attributes of the last read image"""
-        return self._frame_attributes_d.get(getattr(self, "_last_pos", -1), {})
+        """attributes of the image read last"""
+        return self._per_frame.get(self._current, {})
 
-    # ---- read-back filters ----
+    # ---- filters applied while reading -----------------------------------------------------------------------------------------------
     @property
     def bad_pixels_correction(self):
-        return self._bad_pixels_correction
+        return self._bp_on
 
     @bad_pixels_correction.setter
     def bad_pixels_correction(self, value):
-        self._bad_pixels_correction = bool(value)
-        enable_bad_pixels(self.handle, self._bad_pixels_correction)
+        self._bp_on = bool(value)
+        _abi.enable_bad_pixels(self.handle, self._bp_on)
 
     @property
     def registration_file(self):
-        return self._registration_file
+        return self._reg_file
 
     @registration_file.setter
     def registration_file(self, value):
-        load_motion_correction_file(self.handle, str(value))
-        self._registration_file = Path(value)
+        _abi.load_motion_correction_file(self.handle, str(value))
+        self._reg_file = Path(value)
 
     @property
     def registration(self):
-        return motion_correction_enabled(self.handle)
+        return _abi.motion_correction_enabled(self.handle)
 
     @registration.setter
     def registration(self, value):
-        enable_motion_correction(self.handle, bool(value))
+        _abi.enable_motion_correction(self.handle, bool(value))
 
-    # ---- re-encoding ----
+    # ---- writing a (part of a) movie again ---------------------------------------------------------------------------------------------
     def to_h264(self, dst_filename, start_img=0, count=-1, clevel=8, attrs=None, times=None, frame_attributes=None, cthreads=8, cfiles=None):
-        if count < 0:
-            count = self.images
-        if start_img + count > self.images:
-            count = self.images - start_img
+        """Record images ``start_img .. start_img + count`` into a new file, with their attributes and time stamps."""
+        available = self.images - start_img
+        count = available if count < 0 else min(count, available)
         if count == 0:
             raise RuntimeError("No images in selected range to save")
-        if attrs is None:
-            attrs = dict(self.attributes)
         if frame_attributes is not None and len(frame_attributes) != count:
             raise RuntimeError("Given frame attributes are not equal to the number of saved images")
-        for k in ("MIN_T", "MIN_T_HEIGHT", "STORE_IT"):
-            attrs.pop(k, None)
-        h, w = self.image_size
-        if times is None:
-            times = list(t * 1e9 for t in self.timestamps)
-        with IRSaver(str(dst_filename), w, h, h, clevel) as s:
-            s.set_global_attributes(attrs)
-            s.set_parameter("threads", cthreads)
-            s.set_parameter("codec", "h264")
-            saved = 0
-            for i in range(start_img, start_img + count):
-                img = self.load_pos(i, 0)
-                fa = self.frame_attributes if frame_attributes is None else frame_attributes[saved]
-                s.add_image(img, times[i], attributes=fa)
-                saved += 1
+        global_attrs = dict(self.attributes) if attrs is None else attrs
+        for stale in ("MIN_T", "MIN_T_HEIGHT", "STORE_IT"):  # they describe how THIS file stores its pixels
+            global_attrs.pop(stale, None)
+        stamps = [t * 1e9 for t in self.timestamps] if times is None else times
+        rows, columns = self.image_size
+        with IRSaver(str(dst_filename), columns, rows, rows, clevel) as saver:
+            saver.set_global_attributes(global_attrs)
+            saver.set_parameter("threads", cthreads)
+            saver.set_parameter("codec", "h264")
+            for written, pos in enumerate(range(start_img, start_img + count)):
+                image = self.load_pos(pos, 0)
+                saver.add_image(image, stamps[pos], attributes=self.frame_attributes if frame_attributes is None else frame_attributes[written])
 
     def pcr2h264(self, outfile=None, overwrite=False, **kwargs):
-        if outfile is None:
-            outfile = str(Path(self.filename).with_suffix(".h264"))
-        if os.path.exists(outfile) and not overwrite:
-            raise RuntimeError("file exists: %s" % outfile)
-        self.to_h264(outfile, **kwargs)
-        return IRMovie.from_filename(outfile)
-
-    def __repr__(self):
-        return "IRMovie({})".format(self.filename)
+        target = str(Path(self.filename).with_suffix(".h264")) if outfile is None else outfile
+        if os.path.exists(target) and not overwrite:
+            raise RuntimeError("file exists: %s" % target)
+        self.to_h264(target, **kwargs)
+        return IRMovie.from_filename(target)
