@@ -507,6 +507,8 @@ namespace
 		{
 			if (!img || !open())
 				return false;
+			if (pending >= chunk_gop && !flush_chunk())
+				return false; // an earlier chunk could not be written: no slot is free, never write past the staging buffers
 			const size_t fbytes = (size_t)width * height * 2;
 			// The caller owns its buffer again when this call returns, whatever kind of host memory it is:
 			// copy it into the chunk's page-locked slot, then upload that slot asynchronously - the transfer overlaps
@@ -524,6 +526,8 @@ namespace
 		bool add_image_device(const unsigned short *d_img, int64_t ts, const AttrMap &attrs)
 		{
 			if (!d_img || !open())
+				return false;
+			if (pending >= chunk_gop && !flush_chunk())
 				return false;
 			const size_t fbytes = (size_t)width * height * 2;
 			if (!hip_ok(hipMemcpyAsync(cc.d_frames.as<char>() + (size_t)pending * fbytes, d_img, fbytes, hipMemcpyDeviceToDevice, default_stream()),
