@@ -24,6 +24,21 @@
 
 using namespace rir;
 
+// Nothing may be thrown across the C boundary: entry points that allocate run through this.
+template <class F>
+static int guarded(const char *what, int on_error, F &&body)
+{
+	try
+	{
+		return body();
+	}
+	catch (const std::exception &e)
+	{
+		log_error(std::string(what) + ": " + e.what());
+		return on_error;
+	}
+}
+
 extern "C"
 {
 	int rir_bad_pixels_create_device(const unsigned short *, int, int, void *);
@@ -1268,7 +1283,7 @@ RIR_EXPORT int load_image(int cam, int pos, int calibration, unsigned short *pix
 		log_error("load_image: NULL camera");
 		return -1;
 	}
-	return c->read_image(pos, calibration, pixels) ? 0 : -1;
+	return guarded("load_image", -1, [&] { return c->read_image(pos, calibration, pixels) ? 0 : -1; });
 }
 
 // video_io.cpp:377-391: the uint16 image cast to float (IRVideoLoader.h:109-117)
@@ -1280,12 +1295,14 @@ RIR_EXPORT int load_imageF(int cam, int pos, int calibration, float *pixels)
 		log_error("load_image: NULL camera");
 		return -1;
 	}
-	std::vector<unsigned short> tmp((size_t)c->width * c->height);
-	if (!c->read_image(pos, calibration, tmp.data()))
-		return -1;
-	for (size_t i = 0; i < tmp.size(); ++i)
-		pixels[i] = (float)tmp[i];
-	return 0;
+	return guarded("load_imageF", -1, [&] {
+		std::vector<unsigned short> tmp((size_t)c->width * c->height);
+		if (!c->read_image(pos, calibration, tmp.data()))
+			return -1;
+		for (size_t i = 0; i < tmp.size(); ++i)
+			pixels[i] = (float)tmp[i];
+		return 0;
+	});
 }
 
 RIR_EXPORT int get_last_image_raw_value(int cam, int x, int y, unsigned short *value)
@@ -1518,7 +1535,10 @@ RIR_EXPORT void h264_close_file(int file)
 		log_error("h264_close_file: NULL identifier");
 		return;
 	}
-	s->close();
+	guarded("h264_close_file", 0, [&] {
+		s->close();
+		return 0;
+	});
 	remove_object(file);
 }
 
@@ -1554,7 +1574,8 @@ RIR_EXPORT int h264_add_image_lossless(int file, unsigned short *img, int64_t ti
 		log_error("h264_add_image_lossless: NULL identifier");
 		return -1;
 	}
-	return s->add_image(img, timestamps_ns, attr_map_from_c(attribute_count, keys, key_lens, values, value_lens)) ? 0 : -1;
+	return guarded("h264_add_image_lossless", -1,
+				   [&] { return s->add_image(img, timestamps_ns, attr_map_from_c(attribute_count, keys, key_lens, values, value_lens)) ? 0 : -1; });
 }
 
 // Bounded-loss recording: reference H264_Saver::addImageLossy (h264.cpp:2038-2046) without an input
@@ -1568,7 +1589,8 @@ RIR_EXPORT int h264_add_image_lossy(int file, unsigned short *img_DL, int64_t ti
 		log_error("h264_add_image_lossy: NULL identifier");
 		return -1;
 	}
-	return s->add_image_lossy(img_DL, timestamps_ns, attr_map_from_c(attribute_count, keys, key_lens, values, value_lens)) ? 0 : -1;
+	return guarded("h264_add_image_lossy", -1,
+				   [&] { return s->add_image_lossy(img_DL, timestamps_ns, attr_map_from_c(attribute_count, keys, key_lens, values, value_lens)) ? 0 : -1; });
 }
 
 // h264_add_loss (video_io.cpp:789-806): adds the loss to the caller's image without writing it
@@ -1580,7 +1602,7 @@ RIR_EXPORT int h264_add_loss(int file, unsigned short *img)
 		log_error("h264_add_loss: NULL identifier");
 		return -1;
 	}
-	return s->add_loss(img) ? 0 : -1;
+	return guarded("h264_add_loss", -1, [&] { return s->add_loss(img) ? 0 : -1; });
 }
 
 // ---- bounded-loss step on a device-resident stream ---------------------------------------------------------------
