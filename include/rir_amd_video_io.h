@@ -83,7 +83,12 @@ extern "C"
 	int h264_get_low_errors(int file, unsigned short *errors, int *size);						/* video_io.h:279 */
 	int h264_get_high_errors(int file, unsigned short *errors, int *size);						/* video_io.h:280 */
 
-	/* declared upstream (video_io.h:305-314) but defined nowhere: the plain writer of the container */
+	/* declared upstream (video_io.h:305-314) but defined nowhere; arguments as z_open_file_write (ZFile.cpp:325).
+	 * method 1: the reference's ZFile container - 256 bytes of headers, one [int64 ts][u32 csize][zstd frame]
+	 * record per image (host-side libzstd, level clevel), trailer attribute "positions" (ZFile.cpp:18-46,
+	 * 410-447, 483-542); readable by open_camera_file here (FILE_FORMAT_ZSTD_COMPRESSED) and by a reference
+	 * build with ZFile enabled.  Any other method: this build's block-codec container.
+	 * open_video_write -> handle > 0 or -1; image_write -> 0 / -1; close_video -> bytes of image data or -1. */
 	int open_video_write(const char *filename, int width, int height, int rate, int method, int clevel);
 	int image_write(int writter, unsigned short *img, int64_t time);
 	int64_t close_video(int writter);

@@ -98,7 +98,21 @@ namespace
 		int32_t Version, NbImages, X, Y, Band, Bits, Interlaced, Frequency, ImagesPerBuffer, TransfertSize, GrabSizeX, GrabSizeY;
 		char reserved[1024 - 48];
 	};
+	// ZFile container of the reference (ZFile.cpp:18-46): two 128-byte blocks, then one record per image
+	//   [int64 timestamp][u32 csize][csize bytes: ZSTD_compress(frame)]      (compression == 1)
+	// and the metadata trailer with the global attribute "positions" (ZFile.cpp:434-447).
+	struct ZHeader
+	{
+		uint8_t version, triggers, compression;
+		char reserved[125];
+	};
+	struct ZTrigger
+	{
+		uint64_t date, rate, samples, samples_pre_trigger, type, nb_channels, data_type, data_format, data_repetition, data_size_x, data_size_y;
+		char reserved[128 - 88];
+	};
 #pragma pack(pop)
+	static_assert(sizeof(ZHeader) == 128 && sizeof(ZTrigger) == 128, "layout");
 	static_assert(sizeof(FtypBox) == 32 && sizeof(FileHeader) == 64 && sizeof(ChunkHeader) == 32 && sizeof(PcrHeader) == 1024, "layout");
 
 	bool file_exists(const char *name)
@@ -615,7 +629,8 @@ namespace
 		enum Kind
 		{
 			RIRB,
-			PCR
+			PCR,
+			ZFILE
 		} kind = RIRB;
 		std::string filename;
 		FILE *fp = nullptr;
@@ -629,6 +644,9 @@ namespace
 		int last_raw_pos = -1; // frame held by last_raw (fetched on demand after a filtered read)
 		// PCR
 		int64_t pcr_start = 0, pcr_transfer = 0;
+		// ZFile: record offsets, scratch for one compressed frame
+		std::vector<int64_t> z_positions;
+		std::vector<char> z_buf;
 		// RIRB
 		FileHeader hd{};
 		std::vector<IndexEntry> index;
@@ -722,56 +740,38 @@ namespace
 				// detection rules of IRFileLoader.cpp:130-165 for plain PCR files
 				const bool lab = ph.Bits == 16 && ph.X == 640 && ph.Y == 512 && ph.Frequency == 50;
 				const bool pcr = ph.Bits == 16 && std::abs(ph.TransfertSize - ph.X * ph.Y * 2) < 2000 && ph.X > 0 && ph.Y > 0 && ph.X < 2000 && ph.Y < 2000;
-				if (!lab && !pcr)
+				ZHeader zh;
+				ZTrigger zt;
+				std::memcpy(&zh, buf, sizeof(zh));
+				std::memcpy(&zt, buf + sizeof(zh), sizeof(zt));
+				// IRFileLoader.cpp:213-236, tested after the PCR rules like there
+				const bool zfile = !lab && !pcr && zh.version == 1 && zh.compression >= 1 && zh.compression <= 3 && zh.triggers == 1 && zt.data_size_x > 0 &&
+								   zt.data_size_x < 3000 && zt.data_size_y > 0 && zt.data_size_y < 3000 && zt.rate > 0 && zt.rate < 1000;
+				if (zfile)
 				{
-					log_error("unsupported file format (this library reads its own RIRB files and raw PCR files)");
-					return false;
+					if (zh.compression != 1)
+					{
+						log_error("ZFile: only compression method 1 (zstd) is readable, blosc methods are not");
+						return false;
+					}
+					kind = ZFILE;
+					width = (int)zt.data_size_x, height = (int)zt.data_size_y;
+					count = (int)std::min<uint64_t>(zt.samples, 0x7fffffffull);
 				}
-				if (lab)
-					ph.TransfertSize = ph.X * ph.Y * 2;
-				kind = PCR;
-				width = ph.X, height = ph.Y;
-				pcr_start = sizeof(PcrHeader);
-				pcr_transfer = ph.TransfertSize;
-				count = pcr_transfer ? (int)((fsize - pcr_start) / pcr_transfer) : 0;
-				if (count <= 0)
-					return false;
-				// timestamps: last 8 bytes of each frame when strictly increasing (IRFileLoader.cpp:255-282)
-				times.assign(count, 0);
-				bool has_times = true;
-				for (int i = 0; i < count && has_times; ++i)
+				else if (!lab && !pcr)
 				{
-					int64_t t = 0;
-					if (!read_at(pcr_start + pcr_transfer * (int64_t)(i + 1) - 8, &t, 8))
-						has_times = false;
-					times[i] = t;
-					if (i > 0 && times[i] <= times[i - 1])
-						has_times = false;
-				}
-				if (!has_times)
-				{ // IRFileLoader.cpp:421-431
-					int freq = ph.Frequency <= 0 ? 50 : ph.Frequency;
-					const double sampling = 1000000000.0 / (double)freq;
-					for (int i = 0; i < count; ++i)
-						times[i] = (int64_t)(i * sampling);
+					log_error("unsupported file format (this library reads its own RIRB files, ZFile (zstd) files and raw PCR files)");
+					return false;
 				}
 				else
-				{ // IRFileLoader.cpp:433-451
-					const int64_t t0 = times[0];
-					if (t0 > 28000 && t0 < 32000)
-						for (auto &t : times)
-							t *= 1000000;
-					else if (!(times.front() < -1000000000 || times.back() > 1000000000))
-						for (auto &t : times)
-							t = (t - t0) * 1000000;
-				}
-				if (!times.empty() && times.front() > 28000000000LL && times.front() < 32000000000LL)
-					for (auto &t : times)
-						t -= 32000000000LL;
+					open_pcr(ph, lab, fsize);
+				if (kind == PCR && count <= 0)
+					return false;
 			}
 			// metadata trailer, when present
 			std::vector<int64_t> ttimes;
 			bool has_trailer = false;
+			size_t trailer_size = 0;
 			{
 				const size_t fs = total_size();
 				char tail[30];
@@ -784,9 +784,13 @@ namespace
 						std::vector<char> tb((size_t)tsize);
 						if (read_at(fs - tsize, tb.data(), tb.size()))
 							has_trailer = FileAttributes::parse(tb.data(), tb.size(), global_attrs, frame_attrs, ttimes) != 0;
+						if (has_trailer)
+							trailer_size = (size_t)tsize;
 					}
 				}
 			}
+			if (kind == ZFILE && !open_zfile(fsize, has_trailer, trailer_size, ttimes))
+				return false;
 			if (kind == RIRB)
 			{
 				times.assign(count, 0);
@@ -808,6 +812,120 @@ namespace
 					min_T_rows = height - 3;
 			}
 			return true;
+		}
+
+		// raw PCR file (IRFileLoader.cpp:130-165 detection, :255-282 / :421-451 timestamps)
+		void open_pcr(PcrHeader ph, bool lab, size_t fsize)
+		{
+			if (lab)
+				ph.TransfertSize = ph.X * ph.Y * 2;
+			kind = PCR;
+			width = ph.X, height = ph.Y;
+			pcr_start = sizeof(PcrHeader);
+			pcr_transfer = ph.TransfertSize;
+			count = pcr_transfer ? (int)((fsize - pcr_start) / pcr_transfer) : 0;
+			if (count <= 0)
+				return;
+			// timestamps: last 8 bytes of each frame when strictly increasing (IRFileLoader.cpp:255-282)
+			times.assign(count, 0);
+			bool has_times = true;
+			for (int i = 0; i < count && has_times; ++i)
+			{
+				int64_t t = 0;
+				if (!read_at(pcr_start + pcr_transfer * (int64_t)(i + 1) - 8, &t, 8))
+					has_times = false;
+				times[i] = t;
+				if (i > 0 && times[i] <= times[i - 1])
+					has_times = false;
+			}
+			if (!has_times)
+			{ // IRFileLoader.cpp:421-431
+				int freq = ph.Frequency <= 0 ? 50 : ph.Frequency;
+				const double sampling = 1000000000.0 / (double)freq;
+				for (int i = 0; i < count; ++i)
+					times[i] = (int64_t)(i * sampling);
+			}
+			else
+			{ // IRFileLoader.cpp:433-451
+				const int64_t t0 = times[0];
+				if (t0 > 28000 && t0 < 32000)
+					for (auto &t : times)
+						t *= 1000000;
+				else if (!(times.front() < -1000000000 || times.back() > 1000000000))
+					for (auto &t : times)
+						t = (t - t0) * 1000000;
+			}
+			if (!times.empty() && times.front() > 28000000000LL && times.front() < 32000000000LL)
+				for (auto &t : times)
+					t -= 32000000000LL;
+		}
+
+		// ZFile index (ZFile.cpp:113-262): offsets from the trailer attribute "positions" when it is there and
+		// consistent, else by walking the records; timestamps converted as IRFileLoader.cpp:355-376 does.
+		bool open_zfile(size_t fsize, bool has_trailer, size_t trailer_size, const std::vector<int64_t> &ttimes)
+		{
+			if (!ZstdApi::get().ok)
+			{
+				log_error("ZFile: libzstd is not available on this host");
+				return false;
+			}
+			const size_t npx = (size_t)width * height;
+			const size_t data_end = fsize - (has_trailer ? trailer_size : 0);
+			z_positions.clear();
+			times.clear();
+			auto it = global_attrs.find("positions");
+			if (has_trailer && it != global_attrs.end() && it->second.size() == ttimes.size() * 8 && !ttimes.empty())
+			{
+				z_positions.resize(ttimes.size());
+				std::memcpy(z_positions.data(), it->second.data(), it->second.size());
+				times = ttimes;
+			}
+			else
+			{
+				const uint64_t declared = (uint64_t)count; // 0 = unknown: walk to the end of the data
+				uint64_t pos = sizeof(ZHeader) + sizeof(ZTrigger);
+				while (pos + 12 <= data_end && (declared == 0 || z_positions.size() < declared))
+				{
+					int64_t t = 0;
+					uint32_t csize = 0;
+					if (!read_at(pos, &t, 8) || !read_at(pos + 8, &csize, 4) || pos + 12 + csize > data_end)
+						break;
+					z_positions.push_back((int64_t)pos);
+					times.push_back(t);
+					pos += 12 + (uint64_t)csize;
+				}
+			}
+			for (int64_t p : z_positions)
+				if (p < (int64_t)(sizeof(ZHeader) + sizeof(ZTrigger)) || (uint64_t)p + 12 > fsize)
+				{
+					log_error("ZFile: inconsistent image positions");
+					return false;
+				}
+			count = (int)z_positions.size();
+			if (count == 0)
+				return false;
+			z_buf.resize(ZstdApi::get().compressBound(npx * 2));
+			const int64_t t0 = times[0];
+			if (t0 > 28000 && t0 < 32000)
+				for (auto &t : times)
+					t = t * 1000000 - 10000000;
+			else if (!(times.front() < -1000000000 || times.back() > 1000000000))
+				for (auto &t : times)
+					t = (t - t0) * 1000000;
+			return true;
+		}
+
+		// one ZFile record -> one frame (ZFile.cpp:544-629)
+		bool read_zfile(int pos, unsigned short *out)
+		{
+			const size_t npx = (size_t)width * height;
+			const uint64_t off = (uint64_t)z_positions[pos];
+			uint32_t csize = 0;
+			if (!read_at(off + 8, &csize, 4) || csize > z_buf.size() || !read_at(off + 12, z_buf.data(), csize))
+				return false;
+			const ZstdApi &z = ZstdApi::get();
+			const size_t r = z.decompress(out, npx * 2, z_buf.data(), csize);
+			return !z.isError(r) && r == npx * 2;
 		}
 
 		bool decode_chunk(int c)
@@ -894,6 +1012,8 @@ namespace
 			const size_t npx = (size_t)width * height;
 			if (kind == PCR)
 				return read_at(pcr_start + pcr_transfer * (int64_t)pos, out, npx * 2);
+			if (kind == ZFILE)
+				return read_zfile(pos, out);
 			const unsigned short *d = device_frame(pos);
 			hipStream_t st = default_stream();
 			return d && hip_ok(hipMemcpyAsync(out, d, npx * 2, hipMemcpyDeviceToHost, st), "D2H") && hip_ok(hipStreamSynchronize(st), "sync");
@@ -938,8 +1058,8 @@ namespace
 			if (!cc.d_tmp.reserve(fbytes * 2) || !cc.d_shift.reserve(8))
 				return false;
 			unsigned short *d_a = cc.d_tmp.as<unsigned short>(), *d_b = d_a + npx;
-			if (kind == PCR)
-			{ // raw file: the frame comes from the host
+			if (kind != RIRB)
+			{ // raw / zstd file: the frame comes from the host
 				if (!read_raw(pos, pixels) || !hip_ok(hipMemcpyAsync(d_a, pixels, fbytes, hipMemcpyHostToDevice, st), "H2D"))
 					return false;
 				std::memcpy(last_raw.data(), pixels, last_raw.size() * 2);
@@ -975,7 +1095,7 @@ namespace
 					return false;
 				hipStream_t st = default_stream();
 				const unsigned short *d_first = nullptr;
-				if (kind == PCR)
+				if (kind != RIRB)
 				{
 					std::vector<unsigned short> first((size_t)width * height);
 					if (!read_raw(0, first.data()) || !cc.d_tmp.reserve(first.size() * 4) ||
@@ -1047,10 +1167,95 @@ namespace
 		}
 	};
 
+	// ---- ZFile writer ------------------------------------------------------------------------------
+	// reference: z_open_file_write / z_write_image / z_close_file (ZFile.cpp:325-365, 483-542, 410-447) with
+	// compression method 1: every image is one ZSTD_compress of the raw frame on the host (the host's libzstd),
+	// so files written here are readable by a reference build that has ZFile enabled, and the reverse.
+	struct ZWriterObject : public Object
+	{
+		const char *type_name() const override { return "ZWriter"; }
+		FILE *fp = nullptr;
+		std::string filename;
+		ZHeader zh{};
+		ZTrigger zt{};
+		int clevel = 0;
+		std::vector<char> buf;
+		std::vector<int64_t> times, positions;
+
+		~ZWriterObject() override
+		{
+			if (fp)
+				close();
+		}
+		bool open(const char *name, int width, int height, int rate, int level)
+		{
+			const ZstdApi &z = ZstdApi::get();
+			if (!z.ok)
+			{
+				log_error("open_video_write: libzstd is not available on this host");
+				return false;
+			}
+			if (width <= 0 || height <= 0 || width >= 3000 || height >= 3000 || rate <= 0 || rate >= 1000)
+			{ // the limits the readers test (ZFile.cpp:149, IRFileLoader.cpp:222)
+				log_error("open_video_write: image size must be below 3000x3000 and rate in 1..999 for a ZFile");
+				return false;
+			}
+			fp = std::fopen(name, "wb");
+			if (!fp)
+				return false;
+			filename = name;
+			clevel = level;
+			zh.version = 1, zh.triggers = 1, zh.compression = 1;
+			zt.rate = (uint64_t)rate;
+			zt.type = 1; // continuous acquisition
+			zt.nb_channels = 1;
+			zt.data_format = 3; // u16
+			zt.data_repetition = 1;
+			zt.data_size_x = (uint64_t)width, zt.data_size_y = (uint64_t)height;
+			buf.resize(z.compressBound((size_t)width * height * 2));
+			return std::fwrite(&zh, sizeof(zh), 1, fp) == 1 && std::fwrite(&zt, sizeof(zt), 1, fp) == 1;
+		}
+		bool add(const unsigned short *img, int64_t timestamp)
+		{
+			if (!fp || !img)
+				return false;
+			const ZstdApi &z = ZstdApi::get();
+			const size_t c = z.compress(buf.data(), buf.size(), img, (size_t)zt.data_size_x * zt.data_size_y * 2, clevel);
+			if (z.isError(c))
+				return false;
+			const int64_t pos = (int64_t)ftello(fp);
+			const uint32_t csize = (uint32_t)c;
+			if (std::fwrite(&timestamp, 8, 1, fp) != 1 || std::fwrite(&csize, 4, 1, fp) != 1 || std::fwrite(buf.data(), 1, c, fp) != c)
+				return false;
+			zt.samples++;
+			times.push_back(timestamp);
+			positions.push_back(pos);
+			return true;
+		}
+		// size of the image data (the trailer comes after it), as z_close_file returns
+		int64_t close()
+		{
+			if (!fp)
+				return -1;
+			const int64_t data_end = (int64_t)ftello(fp);
+			bool ok = fseeko(fp, sizeof(ZHeader), SEEK_SET) == 0 && std::fwrite(&zt, sizeof(zt), 1, fp) == 1 && fseeko(fp, 0, SEEK_END) == 0;
+			AttrMap global;
+			global["positions"] = std::string(reinterpret_cast<const char *>(positions.data()), positions.size() * 8);
+			const std::string trailer = FileAttributes::serialize(global, std::vector<AttrMap>(times.size()), times);
+			ok = ok && std::fwrite(trailer.data(), 1, trailer.size(), fp) == trailer.size();
+			ok = (std::fclose(fp) == 0) && ok;
+			fp = nullptr;
+			return ok ? data_end : -1;
+		}
+	};
+
 	std::shared_ptr<CameraObject> camera(int h) { return lookup_as<CameraObject>(h); }
 	std::shared_ptr<SaverObject> saver(int h) { return lookup_as<SaverObject>(h); }
 
-	int format_of(const CameraObject &c) { return c.kind == CameraObject::PCR ? FILE_FORMAT_PCR : FILE_FORMAT_H264; }
+	int format_of(const CameraObject &c)
+	{
+		return c.kind == CameraObject::PCR ? FILE_FORMAT_PCR : c.kind == CameraObject::ZFILE ? FILE_FORMAT_ZSTD_COMPRESSED : FILE_FORMAT_H264;
+	}
 
 	int kv_out(const AttrMap &m, int index, char *key, int *key_len, char *value, int *value_len, bool global)
 	{
@@ -1691,12 +1896,20 @@ RIR_EXPORT int h264_get_high_errors(int file, unsigned short *errors, int *size)
 	return errors_out(s->high_errors, errors, size);
 }
 
-// Declared by the reference header (video_io.h:305-314) but defined nowhere upstream: here they are
-// the plain writer of the same container (method / clevel have no meaning for the block codec).
+// Declared by the reference header (video_io.h:305-314) but defined nowhere upstream; the arguments are those of
+// z_open_file_write (ZFile.cpp:325).  method 1 writes the reference's ZFile container (one zstd frame per image, host
+// side); any other method writes this build's block-codec container (clevel has no meaning there).
 RIR_EXPORT int open_video_write(const char *filename, int width, int height, int rate, int method, int clevel)
 {
-	(void)method;
-	(void)clevel;
+	if (!filename)
+		return -1;
+	if (method == 1)
+		return guarded("open_video_write", -1, [&] {
+			auto w = std::make_shared<ZWriterObject>();
+			if (!w->open(filename, width, height, rate, clevel))
+				return -1;
+			return register_object(w);
+		});
 	const int h = h264_open_file(filename, width, height, height);
 	if (h <= 0)
 		return -1;
@@ -1705,18 +1918,28 @@ RIR_EXPORT int open_video_write(const char *filename, int width, int height, int
 }
 RIR_EXPORT int image_write(int writter, unsigned short *img, int64_t time)
 {
-	auto s = saver(writter);
-	if (!s)
-		return -1;
-	return s->add_image(img, time, AttrMap()) ? 0 : -1;
+	return guarded("image_write", -1, [&] {
+		if (auto z = lookup_as<ZWriterObject>(writter))
+			return z->add(img, time) ? 0 : -1;
+		auto s = saver(writter);
+		if (!s)
+			return -1;
+		return s->add_image(img, time, AttrMap()) ? 0 : -1;
+	});
 }
 RIR_EXPORT int64_t close_video(int writter)
 {
-	auto s = saver(writter);
-	if (!s)
-		return -1;
-	const int64_t size = s->close();
-	remove_object(writter);
+	int64_t size = -1;
+	guarded("close_video", -1, [&] {
+		if (auto z = lookup_as<ZWriterObject>(writter))
+			size = z->close();
+		else if (auto s = saver(writter))
+			size = s->close();
+		else
+			return -1;
+		remove_object(writter);
+		return 0;
+	});
 	return size;
 }
 

@@ -279,3 +279,29 @@ def h264_get_low_errors(saver):
 
 def h264_get_high_errors(saver):
     return _errors(_v.h264_get_high_errors, "h264_get_high_errors", saver)
+
+
+# ---- plain writer (reference video_io.h:305-314; method 1 = the reference's ZFile container, zstd per image) -------
+METHOD_ZSTD = 1
+METHOD_BLOCK_CODEC = 0
+
+
+def open_video_write(filename, width, height, rate=50, method=METHOD_BLOCK_CODEC, clevel=0):
+    h = _v.open_video_write(toBytes(str(filename)), int(width), int(height), int(rate), int(method), int(clevel))
+    if h <= 0:
+        _fail("open_video_write")
+    return h
+
+
+def image_write(writer, image, timestamp):
+    img = np.ascontiguousarray(image, dtype=np.uint16)
+    if _v.image_write(writer, img.ctypes.data, int(timestamp)) < 0:
+        _fail("image_write")
+
+
+def close_video(writer):
+    """Finishes the file; returns the size in bytes of the image data written."""
+    size = _v.close_video(writer)
+    if size < 0:
+        _fail("close_video")
+    return size

@@ -273,3 +273,30 @@ def test_corrupted_files_never_crash(tmp_path):
     assert errors + good == 120 and errors > 0
     with IRMovie.from_filename(src) as mov:  # the library is still healthy afterwards
         assert np.array_equal(mov.data, arr)
+
+
+def test_zfile_readback_filters_run_on_the_device(tmp_path, oracle):
+    """A ZFile (zstd per image, host side) read through IRMovie: plain frames are identical, and the read-back
+    filters (bad pixels, motion correction) give what they give on this library's own container."""
+    h, w, n = 67, 83, 5
+    arr = inject_bad_pixels(images(n, h, w), 9)
+    p = tmp_path / "z.bin"
+    wr = rv.open_video_write(p, w, h, rate=50, method=rv.METHOD_ZSTD, clevel=1)
+    for i in range(n):
+        rv.image_write(wr, arr[i], 3_000_000_000 + i * 20_000_000)
+    assert rv.close_video(wr) > 256
+    mov = IRMovie.from_filename(p)
+    assert mov.video_file_format == FileFormat.ZSTD_COMPRESSED and mov.images == n and mov.image_size == (h, w)
+    assert np.array_equal(mov[:], arr)
+    assert np.allclose(mov.timestamps, [3.0 + i * 0.02 for i in range(n)], rtol=0, atol=1e-12)
+    mov.bad_pixels_correction = True
+    xy = oracle.bad_pixels_detect(arr[0][: h - 3])
+    for i in (0, 2, 4):
+        assert np.array_equal(mov[i], oracle.remove_bad_pixels(arr[i], xy, rows=h - 3))
+    reg = tmp_path / "reg.csv"
+    reg.write_text("frame\tx\ty\tc\n" + "".join("%d\t%g\t%g\t1\n" % (i, 1.25 * i, -0.5 * i) for i in range(n)))
+    mov.registration_file = reg
+    mov.registration = True
+    exp = oracle.remove_motion(oracle.remove_bad_pixels(arr[3], xy, rows=h - 3), np.float32(3.75), np.float32(-1.5), rows=h - 3)
+    assert np.array_equal(mov[3], exp)
+    mov.close()

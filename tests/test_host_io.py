@@ -223,3 +223,106 @@ def test_hostile_container_headers_are_rejected_not_crashed_on(tmp_path):
         for _ in range(int(rng.integers(1, 6))):
             b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
         opens(bytes(b[: int(rng.integers(1, len(b) + 1))]))
+
+
+# ---- ZFile container (reference ZFile.cpp: 128-byte header blocks, [int64 ts][u32 csize][zstd frame] records, --------
+# ---- trailer attribute "positions"); host-side zstd, so none of this needs a GPU ----------------------------------
+def parse_zfile(raw):
+    """Independent reader of the layout stated in reference ZFile.cpp:18-46 (headers) and :483-542 (records)."""
+    version, triggers, compression = raw[0], raw[1], raw[2]
+    trig = np.frombuffer(raw[128:128 + 88], dtype="<u8")
+    info = dict(version=version, triggers=triggers, compression=compression, rate=int(trig[1]), samples=int(trig[2]), type=int(trig[4]),
+                nb_channels=int(trig[5]), data_format=int(trig[7]), w=int(trig[9]), h=int(trig[10]))
+    frames, times, positions = [], [], []
+    pos = 256
+    for _ in range(info["samples"]):
+        t = int(np.frombuffer(raw[pos:pos + 8], "<i8")[0])
+        csize = int(np.frombuffer(raw[pos + 8:pos + 12], "<u4")[0])
+        data = zstd_decompress(raw[pos + 12:pos + 12 + csize])
+        frames.append(np.frombuffer(data, "<u2").reshape(info["h"], info["w"]))
+        times.append(t)
+        positions.append(pos)
+        pos += 12 + csize
+    return info, np.array(frames), times, positions, pos
+
+
+def build_zfile(frames, times, rate=50, samples=None, level=1):
+    n, h, w = frames.shape
+    head = bytearray(256)
+    head[0:3] = bytes([1, 1, 1])
+    trig = np.zeros(11, "<u8")
+    trig[1], trig[2], trig[4], trig[5], trig[7], trig[8], trig[9], trig[10] = rate, n if samples is None else samples, 1, 1, 3, 1, w, h
+    head[128:128 + 88] = trig.tobytes()
+    body = b""
+    for f, t in zip(frames, times):
+        c = zstd_compress(f.tobytes(), level)
+        body += np.int64(t).tobytes() + np.uint32(len(c)).tobytes() + c
+    return bytes(head) + body
+
+
+def test_zfile_written_here_has_the_reference_layout(tmp_path):
+    rng = np.random.default_rng(5)
+    fr = (rng.random((5, 24, 40)) * 900 + np.arange(5)[:, None, None]).astype(np.uint16)
+    ts = [2_000_000_000 + 20_000_000 * i for i in range(5)]  # ns, beyond the "milliseconds" window of the loader
+    p = tmp_path / "m.bin"
+    w = rv.open_video_write(p, 40, 24, rate=50, method=rv.METHOD_ZSTD, clevel=3)
+    for f, t in zip(fr, ts):
+        rv.image_write(w, f, t)
+    data_size = rv.close_video(w)
+    raw = p.read_bytes()
+    info, frames, times, positions, end = parse_zfile(raw)
+    assert info == dict(version=1, triggers=1, compression=1, rate=50, samples=5, type=1, nb_channels=1, data_format=3, w=40, h=24)
+    assert np.array_equal(frames, fr) and times == ts and end == data_size
+    # trailer: timestamps + global attribute "positions" = the record offsets as int64 (ZFile.cpp:434-447)
+    a = FileAttributes.from_filename(p)
+    assert list(a.timestamps) == ts
+    assert np.frombuffer(a.attributes["positions"], "<i8").tolist() == positions
+    a.discard()
+    # and the loader of this library reads it back, as format 4
+    assert rv.video_file_format(p) == rv.FILE_FORMAT_ZSTD_COMPRESSED
+    cam = rv.open_camera_file(p)
+    assert rv.get_image_count(cam) == 5 and rv.get_image_size(cam) == (24, 40)
+    for i in (3, 0, 4, 1, 2):
+        assert np.array_equal(rv.load_image(cam, i), fr[i])
+        assert rv.get_image_time(cam, i) == ts[i]
+    assert rv.get_last_image_raw_value(cam, 7, 5) == fr[2, 5, 7]
+    with pytest.raises(RuntimeError):
+        rv.load_image(cam, 5)
+    rv.close_camera(cam)
+    with pytest.raises(RuntimeError):  # the ZFile readers accept sizes below 3000 only
+        rv.open_video_write(tmp_path / "big.bin", 3000, 10, method=rv.METHOD_ZSTD)
+
+
+@pytest.mark.parametrize("samples", [None, 0])
+def test_zfile_without_trailer_is_walked_record_by_record(tmp_path, samples):
+    """Files from a writer that stored no trailer (or no image count): the index comes from walking the records
+    (ZFile.cpp:196-245).  Timestamps in milliseconds are rebased to 0 and converted to ns (IRFileLoader.cpp:355-376)."""
+    fr = np.random.default_rng(6).integers(0, 16000, (4, 10, 12)).astype(np.uint16)
+    raw = build_zfile(fr, [100, 120, 140, 160], rate=25, samples=samples)
+    p = tmp_path / "z.bin"
+    p.write_bytes(raw)
+    for cam in (rv.open_camera_file(p), rv.open_camera_memory(raw)):
+        assert rv.get_image_count(cam) == 4
+        assert [rv.get_image_time(cam, i) for i in range(4)] == [0, 20_000_000, 40_000_000, 60_000_000]
+        for i in range(4):
+            assert np.array_equal(rv.load_image(cam, i), fr[i])
+        rv.close_camera(cam)
+
+
+def test_zfile_damaged_files_fail_cleanly(tmp_path):
+    fr = np.random.default_rng(7).integers(0, 16000, (3, 10, 12)).astype(np.uint16)
+    raw = bytearray(build_zfile(fr, [0, 1, 2]))
+    blosc = bytes(raw[:2]) + b"\x02" + bytes(raw[3:])
+    with pytest.raises(RuntimeError):  # blosc methods are not readable here
+        rv.open_camera_memory(blosc)
+    cut = bytes(raw[:len(raw) - 7])  # last record truncated: the first two images stay readable
+    cam = rv.open_camera_memory(cut)
+    assert rv.get_image_count(cam) == 2 and np.array_equal(rv.load_image(cam, 1), fr[1])
+    rv.close_camera(cam)
+    bad = bytearray(raw)
+    bad[256 + 12 + 5] ^= 0xFF  # damage inside the first compressed frame
+    cam = rv.open_camera_memory(bytes(bad))
+    with pytest.raises(RuntimeError):
+        rv.load_image(cam, 0)
+    assert np.array_equal(rv.load_image(cam, 2), fr[2])
+    rv.close_camera(cam)
