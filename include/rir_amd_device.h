@@ -83,6 +83,16 @@ extern "C"
 	int rir_translate_f32_u16_device(const float *d_src, unsigned short *d_dst, int w, int h, int nframes, const float *d_offsets,
 									 int per_frame_offsets, const void *background, const char *strategy, void *stream);
 
+	/* The filter chain callers run before recording (reference tests/python/test_rir.py and BASELINE configs[2]:
+	 * BadPixels.correct (BadPixels.cpp:34-66) -> gaussian_filter (signal_processing.cpp:101-148) -> translate
+	 * (Filters.h:249-326) -> astype(uint16)) fused into ONE pass over the frames: 4 bytes of HBM traffic per pixel
+	 * instead of 14.  Output bit-identical to rir_bad_pixels_correct_device + rir_gaussian_filter_u16_device +
+	 * rir_translate_f32_u16_device.  bad_pixels_handle: from rir_bad_pixels_create_device, or 0 to skip that stage.
+	 * strategy "nearest" or "background"/"constant" (background: HOST pointer to one uint16); sigma < 2.5;
+	 * d_src != d_dst; offsets as for rir_translate_device. */
+	int rir_filter_chain_device(int bad_pixels_handle, const unsigned short *d_src, unsigned short *d_dst, int w, int h, int nframes, float sigma,
+								const float *d_offsets, int per_frame_offsets, const void *background, const char *strategy, void *stream);
+
 	/* find_median_pixel[_mask]: reference signal_processing.h:39-44 / Filters.cpp:56-101.
 	 * d_result: int32[nframes]; d_hist: unused, may be NULL (the counting happens in LDS); d_mask may be NULL. */
 	int rir_find_median_pixel_device(const unsigned short *d_img, const unsigned char *d_mask, int size, int nframes, float percent, int *d_result,

@@ -23,6 +23,9 @@ namespace rir
 	hipError_t launch_gaussian_u16(const uint16_t *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st);
 	hipError_t launch_bad_pixels_correct(const uint16_t *in, uint16_t *out, int w, int h, int nframes, const int *d_xy, int nbad, int floor_v,
 										 hipStream_t st);
+	hipError_t launch_filter_chain(const uint16_t *src, uint16_t *dst, int w, int h, int nframes, const int *d_xy, const int *d_row_start, int nbad,
+								   int floor_v, uint32_t *d_fix, const float *d_kernel, int radius, const float *d_offsets, int per_frame,
+								   int strategy, uint16_t background, hipStream_t st);
 	hipError_t launch_remove_bad_pixels(uint16_t *img, int w, int h, int rows, int nframes, const int *d_xy, int nbad, const uint8_t *d_bitmap,
 										hipStream_t st);
 	hipError_t launch_histogram(const uint16_t *img, const uint8_t *mask, int64_t npx, int nframes, uint32_t *d_hist, hipStream_t st);

@@ -566,12 +566,16 @@ namespace rir
 		for (int d = 0; d < KW; ++d)
 			a[d] = kern[KW * KW + d];
 		const bool xin = x >= 0 && x < w;
+		// every load is issued, at an address clamped into the frame, and the value dropped afterwards when the pixel
+		// lies outside: a load under a condition becomes a branch with its own wait, i.e. TY + 2R serial latencies
+		const TIN *col = s + min(max(x, 0), w - 1);
 		float v[TY + 2 * R];
 #pragma unroll
 		for (int i = 0; i < TY + 2 * R; ++i)
 		{
 			const int gy = y0 - R + i;
-			v[i] = (xin && gy >= 0 && gy < h) ? (float)s[x + (int64_t)gy * w] : 0.f; // zeros outside the image add nothing
+			const float val = (float)col[(int64_t)min(max(gy, 0), h - 1) * w];
+			v[i] = (xin && gy >= 0 && gy < h) ? val : 0.f; // zeros outside the image add nothing
 		}
 #pragma unroll
 		for (int j = 0; j < TY; ++j)
@@ -722,8 +726,10 @@ namespace rir
 
 	// pass 2: one thread per (flagged pixel, frame): upper median of the in-bounds 3x3 (centre
 	// included, gathered from `in`), then the clamp.  xy = int32 pairs.
+	// table != NULL: the repaired values go to table[n][i] (uint32 each) instead of the frame - the fused filter chain
+	// below patches them into its tiles.
 	__global__ __launch_bounds__(64) void bad_pixels_fix_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, int w, int h,
-																const int *__restrict__ xy, int nbad, uint32_t floor_v)
+																const int *__restrict__ xy, int nbad, uint32_t floor_v, uint32_t *__restrict__ table)
 	{
 		const int i = blockIdx.x * blockDim.x + threadIdx.x;
 		const int n = blockIdx.y;
@@ -753,7 +759,10 @@ namespace rir
 			if (k >= c)
 				v[k] = 0xffffffffu;
 		const uint32_t m = rank_select9(v, c);
-		out[fbase + x + (int64_t)y * w] = (uint16_t)max(m, floor_v);
+		if (table)
+			table[(int64_t)n * nbad + i] = (uint32_t)(uint16_t)max(m, floor_v);
+		else
+			out[fbase + x + (int64_t)y * w] = (uint16_t)max(m, floor_v);
 	}
 
 	hipError_t launch_bad_pixels_correct(const uint16_t *in, uint16_t *out, int w, int h, int nframes, const int *d_xy, int nbad, int floor_v,
@@ -767,7 +776,381 @@ namespace rir
 			hipLaunchKernelGGL(clamp_copy_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, in, out, total, fl);
 		}
 		if (nbad > 0)
-			hipLaunchKernelGGL(bad_pixels_fix_kernel, dim3((nbad + 63) / 64, nframes), dim3(64), 0, st, in, out, w, h, d_xy, nbad, fl);
+			hipLaunchKernelGGL(bad_pixels_fix_kernel, dim3((nbad + 63) / 64, nframes), dim3(64), 0, st, in, out, w, h, d_xy, nbad, fl, (uint32_t *)nullptr);
+		return hipGetLastError();
+	}
+
+	// ---- fused filter chain: bad_pixels_correct -> gaussian_filter -> translate, one pass over the frame ------
+	// The chain of BASELINE configs[2] run as three kernels writes a uint16 frame, reads it, writes a
+	// float frame, reads it with four taps per pixel and writes the final uint16 frame: 14 bytes per pixel of HBM
+	// traffic for an algorithmic 4 (uint16 in, uint16 out).  Here a WAVE produces a tile of OW x OH output pixels
+	// on its own: it finds the block of gaussian-filtered pixels the tile's bilinear taps fall on (translation is
+	// uniform, so that block is the tile shifted by (dx, dy), at most OW+2 x OH+2 pixels), loads the raw pixels
+	// under it (+R halo) straight into registers with the clamp of BadPixels::correct applied, patches the repaired
+	// values of flagged pixels in (a table filled by bad_pixels_fix_kernel beforehand: ~200 values per frame), runs
+	// the separable gaussian exactly as gaussian_sep_kernel does - same column sums, same row sums, same border
+	// renormalisation, so every filtered value has the bits the stand-alone kernel would have stored - keeps the
+	// result in a wave-private LDS tile and evaluates translate_px's expressions on it.  The output is bit-identical
+	// to the three-kernel chain.  Strategies whose border pixels are not local to the tile (wrap, noborder) are not
+	// offered; a tap outside the wave's block (possible only through float rounding of px + 1) is recomputed from
+	// global memory by chain_gauss_point.
+#ifndef RIR_CHAIN_TY
+#define RIR_CHAIN_TY 16 /* rows of the gaussian block per wave; OH = TY - 2 output rows */
+#endif
+	struct ChainBadPixels
+	{
+		const int *xy;			  // flagged (x, y) pairs, raster order
+		const int *row_start;	  // [h + 1]: index of the first flagged pixel of row >= y
+		const uint32_t *fix;	  // [nframes][nbad] repaired values
+		int nbad;
+		uint32_t floor_v;		  // clamp floor (0 = none)
+	};
+
+	template <int R>
+	__device__ __noinline__ float chain_gauss_point(const uint16_t *__restrict__ s, int w, int h, int c, int r, ChainBadPixels bp, int64_t fix_base,
+													const float *__restrict__ kern)
+	{
+		constexpr int KW = 2 * R + 1;
+		if (c < 0 || c >= w || r < 0 || r >= h)
+			return 0.f;
+		float a[KW];
+#pragma unroll
+		for (int d = 0; d < KW; ++d)
+			a[d] = kern[KW * KW + d];
+		float cs[KW];
+#pragma unroll
+		for (int dc = 0; dc < KW; ++dc)
+		{
+			const int col = c - R + dc;
+			float acc = 0.f;
+#pragma unroll
+			for (int d = 0; d < KW; ++d)
+			{
+				const int rr = r - R + d;
+				float val = 0.f;
+				if (col >= 0 && col < w && rr >= 0 && rr < h)
+				{
+					uint32_t p = max((uint32_t)s[col + (int64_t)rr * w], bp.floor_v);
+					if (bp.nbad > 0)
+						for (int i = bp.row_start[rr]; i < bp.row_start[rr + 1]; ++i)
+							if (bp.xy[2 * i] == col)
+								p = bp.fix[fix_base + i];
+					val = (float)p;
+				}
+				acc = fmaf(a[d], val, acc);
+			}
+			cs[dc] = acc;
+		}
+		float acc = 0.f;
+#pragma unroll
+		for (int d = 0; d < KW; ++d)
+			acc = fmaf(a[d], cs[d], acc);
+		float full = 0.f;
+#pragma unroll
+		for (int d = 0; d < KW; ++d)
+			full += a[d];
+		const bool xb = c < R || c >= w - R, yb = r < R || r >= h - R;
+		if (xb || yb)
+		{
+			float sx = full, sy = full;
+			if (xb)
+			{
+				sx = 0.f;
+#pragma unroll
+				for (int d = -R; d <= R; ++d)
+					if (c + d >= 0 && c + d < w)
+						sx += a[d + R];
+			}
+			if (yb)
+			{
+				sy = 0.f;
+#pragma unroll
+				for (int d = -R; d <= R; ++d)
+					if (r + d >= 0 && r + d < h)
+						sy += a[d + R];
+			}
+			acc = acc / (sx * sy);
+		}
+		return acc;
+	}
+
+	// first source column / row an output column / row can touch (monotone in x / y)
+	__device__ __forceinline__ int chain_anchor(int x, float d, int size)
+	{
+		const float p = (float)x - d;
+		return p < 0 ? 0 : (p >= (float)size ? size - 1 : (int)p);
+	}
+
+	template <int R>
+	__global__ __launch_bounds__(256) void filter_chain_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w, int h,
+															   ChainBadPixels bp, const float *__restrict__ kern, const float *__restrict__ offsets,
+															   int per_frame_offsets, int strategy, uint32_t background)
+	{
+		constexpr int TY = RIR_CHAIN_TY, KW = 2 * R + 1, OUTW = 64 - 2 * R, OW = OUTW - 2, OH = TY - 2, NR = TY + 2 * R;
+		__shared__ float tile[4][TY][64];
+		const int lane = threadIdx.x & 63;
+		const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+		int bx, by, bz;
+		{ // XCD-major tile order, row bands fastest (see gaussian_sep_kernel)
+			const unsigned gx = gridDim.x, gy = gridDim.y;
+			const unsigned id2 = xcd_major(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+			by = (int)(id2 % gy);
+			bx = (int)((id2 / gy) % gx);
+			bz = (int)(id2 / (gy * gx));
+		}
+		const int x0 = bx * OW, y0 = (by * 4 + wv) * OH;
+		if (y0 >= h)
+			return;
+		const int n = bz;
+		const int64_t fbase = (int64_t)n * w * h;
+		const uint16_t *s = src + fbase;
+		const float dx = offsets[per_frame_offsets ? 2 * n : 0];
+		const float dy = offsets[per_frame_offsets ? 2 * n + 1 : 1];
+		const int gx0 = chain_anchor(x0, dx, w), gy0 = chain_anchor(y0, dy, h); // top-left filtered pixel of the block
+		const int cx = gx0 - R + lane;											 // this lane's source column
+		const bool xin = cx >= 0 && cx < w;
+		const int64_t fix_base = (int64_t)n * bp.nbad;
+
+		float a[KW];
+#pragma unroll
+		for (int d = 0; d < KW; ++d)
+			a[d] = kern[KW * KW + d];
+		// raw pixels of the column, clamped like BadPixels::correct does (Filters.cpp:7-50)
+		// (all loads issued, at addresses clamped into the frame; values outside the image are dropped afterwards)
+		const uint16_t *col = s + min(max(cx, 0), w - 1);
+		float v[NR];
+#pragma unroll
+		for (int i = 0; i < NR; ++i)
+		{
+			const int gy = gy0 - R + i;
+			const float val = (float)max((uint32_t)col[(int64_t)min(max(gy, 0), h - 1) * w], bp.floor_v);
+			v[i] = (xin && gy >= 0 && gy < h) ? val : 0.f;
+		}
+		// flagged pixels under the block take their repaired value.  The list is in raster order, so the rows of the
+		// block own one run of it: the lanes look at 64 entries at a time (one coalesced load - a scalar walk over the
+		// run would be a chain of dependent load latencies) and the few that fall on the block's columns are patched in.
+		if (bp.nbad > 0)
+		{
+			const int ra = max(gy0 - R, 0), rb = min(gy0 - R + NR, h);
+			const int i0 = ra < rb ? bp.row_start[ra] : 0, i1 = ra < rb ? bp.row_start[rb] : 0;
+			for (int base = i0; base < i1; base += 64)
+			{
+				const int i = base + lane;
+				const bool has = i < i1;
+				const int2 f = has ? reinterpret_cast<const int2 *>(bp.xy)[i] : make_int2(-(1 << 30), 0);
+				const int rel = f.x - (gx0 - R);
+				uint64_t m = __ballot(has && rel >= 0 && rel < 64);
+				while (m)
+				{
+					const int k = __builtin_ctzll(m);
+					m &= m - 1;
+					const int rel_k = __builtin_amdgcn_readlane(rel, k);
+					const int ridx = __builtin_amdgcn_readlane(f.y, k) - (gy0 - R);
+					const float fv = (float)bp.fix[fix_base + base + k];
+#pragma unroll
+					for (int q = 0; q < NR; ++q)
+						v[q] = (lane == rel_k && q == ridx) ? fv : v[q];
+				}
+			}
+		}
+		// gaussian, column pass: in registers
+		float cs[TY];
+#pragma unroll
+		for (int j = 0; j < TY; ++j)
+		{
+			float acc = 0.f;
+#pragma unroll
+			for (int d = 0; d < KW; ++d)
+				acc = fmaf(a[d], v[j + d], acc);
+			cs[j] = acc;
+		}
+		// this lane's output column and its taps (expressions of translate_px / Filters.h:249-326)
+		const int x = x0 + lane;
+		const bool act_x = lane < OW && x < w;
+		const float px = (float)x - dx;
+		const bool out_x = px < 0 || px >= (float)w;
+		const int l = out_x ? (px < 0 ? 0 : w - 1) : (int)px;
+		int r = out_x ? l : (int)(px + 1.f);
+		if (r == w)
+			r = l;
+		const double u = (double)(px - (float)l);
+
+		if constexpr (R == 1)
+		{
+			// ---- regular tiles (all but the image borders): no LDS at all --------------------------------------------
+			// When the block lies inside the image by R on every side (no renormalisation), lane i's taps are the
+			// columns gx0 + i and gx0 + i + 1 (no clamp, px + 1 not rounded across an integer) and output row j's taps
+			// are the rows gy0 + j and gy0 + j + 1, then every operand sits in a NEIGHBOUR lane's registers: the row
+			// pass of the gaussian takes its left / right column sums through DPP wave shifts, and so do the two tap
+			// columns of the blend; the vertical blend of the right column IS the left-column blend of lane i + 1.
+			// Same expressions, same order, same bits as the general path below.
+			const int yj = y0 + lane; // lane j looks at output row j
+			const bool act_y = lane < OH && yj < h;
+			const float pyj = (float)yj - dy;
+			const bool out_yj = pyj < 0 || pyj >= (float)h;
+			const int tj = (int)pyj, bj = (int)(pyj + 1.f);
+			const bool row_ok = !act_y || (!out_yj && tj == gy0 + lane && bj == tj + 1 && bj < h);
+			const bool col_ok = !act_x || (!out_x && l == gx0 + lane && r == l + 1);
+			const float vvj = (float)bj - pyj;
+			const bool interior = gx0 >= R && gx0 + OUTW - 1 < w - R && gy0 >= R && gy0 + TY - 1 < h - R;
+			if (interior && __ballot(!(row_ok && col_ok)) == 0)
+			{
+				auto shl1 = [](float f) -> float
+				{ return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x130, 0xf, 0xf, false)); }; // lane i <- i + 1
+				auto shr1 = [](float f) -> float
+				{ return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x138, 0xf, 0xf, false)); }; // lane i <- i - 1
+				double dl[TY]; // filtered pixel (gx0 + lane, gy0 + j) = this lane's left tap column
+#pragma unroll
+				for (int j = 0; j < TY; ++j)
+				{
+					float acc = fmaf(a[0], shr1(cs[j]), 0.f);
+					acc = fmaf(a[1], cs[j], acc);
+					acc = fmaf(a[2], shl1(cs[j]), acc);
+					dl[j] = (double)shl1(acc); // lane i owns column gx0 - 1 + i: column gx0 + i is one lane up
+				}
+				const double u1 = 1 - u;
+				uint16_t *d = dst + fbase + x + (int64_t)y0 * w;
+#pragma unroll
+				for (int j = 0; j < OH; ++j)
+				{
+					if (y0 + j >= h)
+						break;
+					const double vv = (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vvj), j));
+					const double cl = dl[j + 1] * (1 - vv) + dl[j] * vv;
+					const uint64_t clb = __builtin_bit_cast(uint64_t, cl);
+					const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)clb, 0x130, 0xf, 0xf, false);
+					const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(clb >> 32), 0x130, 0xf, 0xf, false);
+					const double cr = __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+					const uint16_t res = CastTo<u16_via_f32>::from(cl * u1 + cr * u).v;
+					if (act_x)
+						d[(int64_t)j * w] = res;
+				}
+				return;
+			}
+		}
+
+		// ---- general path: row pass through the wave's LDS strip (in place), taps read from it ----------------------
+#pragma unroll
+		for (int j = 0; j < TY; ++j)
+			tile[wv][j][lane] = cs[j];
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		{
+			float full = 0.f;
+#pragma unroll
+			for (int d = 0; d < KW; ++d)
+				full += a[d];
+			const bool xb = cx < R || cx >= w - R;
+			float sx = full;
+			if (xb)
+			{
+				sx = 0.f;
+#pragma unroll
+				for (int d = -R; d <= R; ++d)
+					if (cx + d >= 0 && cx + d < w)
+						sx += a[d + R];
+			}
+			const bool owner = lane >= R && lane < 64 - R && xin;
+#pragma unroll
+			for (int j = 0; j < TY; ++j)
+			{
+				const int gy = gy0 + j;
+				if (gy >= h)
+					break;
+				float acc = 0.f;
+#pragma unroll
+				for (int d = 0; d < KW; ++d)
+					acc = fmaf(a[d], tile[wv][j][(lane - R + d) & 63], acc);
+				const bool yb = gy < R || gy >= h - R;
+				if (xb || yb)
+				{
+					float sy = full;
+					if (yb)
+					{
+						sy = 0.f;
+#pragma unroll
+						for (int d = -R; d <= R; ++d)
+							if (gy + d >= 0 && gy + d < h)
+								sy += a[d + R];
+					}
+					acc = acc / (sx * sy);
+				}
+				if (owner)
+					tile[wv][j][lane] = acc; // every lane has read row j before any lane writes it (one wave, in order)
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+		// translate<float -> uint16> on the filtered block
+		if (!act_x)
+			return;
+		// a filtered pixel of the block: LDS address clamped into the strip (always readable); `ok` says whether it is the
+		// pixel asked for - when not (float rounding of px + 1 only), the pixel is recomputed from global memory
+		auto in_block = [&](int c, int rr) -> bool { return c >= gx0 && c < gx0 + OUTW && rr >= gy0 && rr < gy0 + TY; };
+		auto block_px = [&](int c, int rr) -> float { return tile[wv][min(max(rr - gy0, 0), TY - 1)][min(max(c - gx0 + R, 0), 63)]; };
+		uint16_t *d = dst + fbase + x;
+		for (int j = 0; j < OH; ++j)
+		{
+			const int y = y0 + j;
+			if (y >= h)
+				break;
+			const float py = (float)y - dy;
+			const bool out_y = py < 0 || py >= (float)h;
+			const bool outside = out_x || out_y;
+			// taps: inside -> (l,b) (l,t) (r,b) (r,t); outside with "nearest" -> the clamped pixel, four times
+			int t = out_y ? (py < 0 ? 0 : h - 1) : (int)py;
+			int b = out_y ? t : (int)(py + 1.f);
+			if (b == h)
+				b = t;
+			const int rr = outside ? l : r, bb = outside ? t : b;
+			float p1 = block_px(l, bb), p2 = block_px(l, t), p3 = block_px(rr, bb), p4 = block_px(rr, t);
+			if (!(in_block(l, t) && in_block(rr, bb)))
+			{
+				p1 = chain_gauss_point<R>(s, w, h, l, bb, bp, fix_base, kern);
+				p2 = chain_gauss_point<R>(s, w, h, l, t, bp, fix_base, kern);
+				p3 = chain_gauss_point<R>(s, w, h, rr, bb, bp, fix_base, kern);
+				p4 = chain_gauss_point<R>(s, w, h, rr, t, bp, fix_base, kern);
+			}
+			const double vv = (double)((float)b - py);
+			const uint16_t blend =
+				CastTo<u16_via_f32>::from(((double)p1 * (1 - vv) + (double)p2 * vv) * (1 - u) + ((double)p3 * (1 - vv) + (double)p4 * vv) * u).v;
+			const uint16_t near = CastTo<u16_via_f32>::from((double)p2).v;
+			d[(int64_t)y * w] = outside ? (strategy == TRANSLATE_CONSTANT ? (uint16_t)background : near) : blend;
+		}
+	}
+
+	// d_fix: [nframes][nbad] uint32 scratch (unused when nbad == 0).  radius 1..4, strategy CONSTANT or NEAREST.
+	hipError_t launch_filter_chain(const uint16_t *src, uint16_t *dst, int w, int h, int nframes, const int *d_xy, const int *d_row_start, int nbad,
+								   int floor_v, uint32_t *d_fix, const float *d_kernel, int radius, const float *d_offsets, int per_frame,
+								   int strategy, uint16_t background, hipStream_t st)
+	{
+		if (radius < 1 || radius > 4 || (strategy != TRANSLATE_CONSTANT && strategy != TRANSLATE_NEAREST))
+			return hipErrorInvalidValue;
+		const uint32_t fl = floor_v > 0 ? (uint32_t)(uint16_t)floor_v : 0u;
+		if (nbad > 0)
+			hipLaunchKernelGGL(bad_pixels_fix_kernel, dim3((nbad + 63) / 64, nframes), dim3(64), 0, st, src, (uint16_t *)nullptr, w, h, d_xy, nbad, fl,
+							   d_fix);
+		ChainBadPixels bp{d_xy, d_row_start, d_fix, nbad, fl};
+		const int ow = 64 - 2 * radius - 2, oh = RIR_CHAIN_TY - 2;
+		dim3 block(256), grid((w + ow - 1) / ow, (h + 4 * oh - 1) / (4 * oh), nframes);
+		switch (radius)
+		{
+		case 1:
+			hipLaunchKernelGGL((filter_chain_kernel<1>), grid, block, 0, st, src, dst, w, h, bp, d_kernel, d_offsets, per_frame, strategy, (uint32_t)background);
+			break;
+		case 2:
+			hipLaunchKernelGGL((filter_chain_kernel<2>), grid, block, 0, st, src, dst, w, h, bp, d_kernel, d_offsets, per_frame, strategy, (uint32_t)background);
+			break;
+		case 3:
+			hipLaunchKernelGGL((filter_chain_kernel<3>), grid, block, 0, st, src, dst, w, h, bp, d_kernel, d_offsets, per_frame, strategy, (uint32_t)background);
+			break;
+		default:
+			hipLaunchKernelGGL((filter_chain_kernel<4>), grid, block, 0, st, src, dst, w, h, bp, d_kernel, d_offsets, per_frame, strategy, (uint32_t)background);
+			break;
+		}
 		return hipGetLastError();
 	}
 

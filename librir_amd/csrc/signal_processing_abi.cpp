@@ -148,6 +148,8 @@ namespace
 		int floor_correct = 0; // m_median_value, BadPixels.cpp:22-31
 		std::vector<int> xy;   // raster order (x,y) pairs
 		DeviceBuffer d_xy, d_bitmap;
+		DeviceBuffer d_row_start; // [height + 1]: first flagged index of row >= y (the list is in raster order)
+		DeviceBuffer d_fix;		  // scratch of the fused filter chain: repaired values, [nframes][count]
 		int count() const { return (int)(xy.size() / 2); }
 	};
 
@@ -204,6 +206,14 @@ namespace
 		if (bp.count() && !hip_ok(hipMemcpyAsync(bp.d_xy.ptr, bp.xy.data(), bp.xy.size() * sizeof(int), hipMemcpyHostToDevice, st), "xy H2D"))
 			return false;
 		if (!hip_ok(hipMemcpyAsync(bp.d_bitmap.ptr, bitmap.data(), npx, hipMemcpyHostToDevice, st), "bitmap H2D"))
+			return false;
+		std::vector<int> row_start((size_t)bp.height + 1, bp.count());
+		for (int i = bp.count() - 1; i >= 0; --i)
+			row_start[bp.xy[2 * i + 1]] = i;
+		for (int y = bp.height - 1; y >= 0; --y) // rows without flagged pixels point at the next row's run
+			row_start[y] = std::min(row_start[y], row_start[y + 1]);
+		if (!bp.d_row_start.reserve(row_start.size() * sizeof(int)) ||
+			!hip_ok(hipMemcpyAsync(bp.d_row_start.ptr, row_start.data(), row_start.size() * sizeof(int), hipMemcpyHostToDevice, st), "row_start H2D"))
 			return false;
 		return hip_ok(hipStreamSynchronize(st), "sync");
 	}
@@ -368,6 +378,50 @@ RIR_EXPORT int rir_bad_pixels_correct_device(int handle, const unsigned short *d
 	return hip_ok(launch_bad_pixels_correct(d_in, d_out, bp->width, bp->height, nframes, bp->d_xy.as<int>(), bp->count(), bp->floor_correct,
 											as_stream(stream)),
 				  "bad_pixels_correct")
+			   ? 0
+			   : -1;
+}
+
+// The filter chain of BASELINE configs[2] in one pass over the frames: bad_pixels_correct (handle > 0; 0 = skip) ->
+// gaussian_filter(sigma) -> translate(offsets, strategy) -> uint16 (truncation, like astype(uint16)).  Bit-identical to
+// rir_bad_pixels_correct_device + rir_gaussian_filter_u16_device + rir_translate_f32_u16_device, without the two
+// intermediate frames in HBM.  strategy: "nearest", "background" / "constant"; sigma < 2.5; d_src != d_dst.
+// background: HOST pointer to one uint16 (may be NULL for "nearest").
+RIR_EXPORT int rir_filter_chain_device(int bad_pixels_handle, const unsigned short *d_src, unsigned short *d_dst, int w, int h, int nframes,
+									   float sigma, const float *d_offsets, int per_frame_offsets, const void *background, const char *strategy,
+									   void *stream)
+{
+	if (!device_ready())
+		return -1;
+	const int s = strategy_from_string(strategy);
+	if ((s != TRANSLATE_NEAREST && s != TRANSLATE_CONSTANT) || w <= 0 || h <= 0 || nframes <= 0 || !d_src || !d_dst || d_src == d_dst || !d_offsets ||
+		!(sigma > 0) || gaussian_radius(sigma) > 4 || (s == TRANSLATE_CONSTANT && !background))
+	{
+		log_error("rir_filter_chain_device: invalid argument (strategies: nearest, background; sigma < 2.5; out of place)");
+		return -1;
+	}
+	std::shared_ptr<BadPixelsObject> bp;
+	if (bad_pixels_handle > 0)
+	{
+		bp = lookup_as<BadPixelsObject>(bad_pixels_handle);
+		if (!bp || bp->width != w || bp->height != h)
+		{
+			log_error("rir_filter_chain_device: invalid bad pixels handle, or created for another image size");
+			return -1;
+		}
+	}
+	const int nbad = bp ? bp->count() : 0;
+	if (nbad > 0 && !bp->d_fix.reserve((size_t)nbad * nframes * sizeof(uint32_t)))
+		return -1;
+	const int radius = gaussian_radius(sigma);
+	const float *d_k = gaussian_table_device(sigma, radius);
+	if (!d_k)
+		return -1;
+	const uint16_t back = background ? *static_cast<const uint16_t *>(background) : (uint16_t)0;
+	return hip_ok(launch_filter_chain(d_src, d_dst, w, h, nframes, bp ? bp->d_xy.as<int>() : nullptr, bp ? bp->d_row_start.as<int>() : nullptr, nbad,
+									  bp ? bp->floor_correct : 0, nbad > 0 ? bp->d_fix.as<uint32_t>() : nullptr, d_k, radius, d_offsets,
+									  per_frame_offsets, s, back, as_stream(stream)),
+				  "filter_chain")
 			   ? 0
 			   : -1;
 }

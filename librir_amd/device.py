@@ -68,6 +68,7 @@ _lib.rir_translate_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, ct
 _lib.rir_gaussian_filter_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_float, _vp]
 _lib.rir_gaussian_filter_u16_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_float, _vp]
 _lib.rir_translate_f32_u16_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp, ct.c_int, _vp, ct.c_char_p, _vp]
+_lib.rir_filter_chain_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_float, _vp, ct.c_int, _vp, ct.c_char_p, _vp]
 _lib.rir_find_median_pixel_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_float, _vp, _vp, _vp]
 _lib.rir_bad_pixels_create_device.argtypes = [_vp, ct.c_int, ct.c_int, _vp]
 _lib.rir_bad_pixels_create_rows_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, _vp]
@@ -254,6 +255,28 @@ def translate_to_u16(frames, offsets, strategy="nearest", background=0):
         strategy = "background"
     _check(_lib.rir_translate_f32_u16_device(fr.data_ptr(), dst.data_ptr(), w, h, n, off.data_ptr(), per_frame, back.ctypes.data,
                                              strategy.encode(), _stream()), "rir_translate_f32_u16_device")
+    return dst
+
+
+def filter_chain(frames, bad_pixels, sigma, offsets, strategy="nearest", background=0):
+    """``bad_pixels.correct`` -> ``gaussian_filter(sigma)`` -> ``translate(offsets, strategy)`` -> uint16, in ONE pass over the
+    uint16 frames (4 bytes of HBM traffic per pixel instead of 14); bit-identical to the three calls.  ``bad_pixels``: a
+    ``BadPixels`` object or None.  Strategies "nearest" and "background"; for the others run the three calls."""
+    fr = _frames3(frames, torch.uint16)
+    n, h, w = fr.shape
+    if strategy == "constant":
+        strategy = "background"
+    if strategy not in ("nearest", "background"):
+        raise RuntimeError("filter_chain: strategy must be 'nearest' or 'background'")
+    off = torch.as_tensor(offsets, dtype=torch.float32, device=fr.device).contiguous()
+    per_frame = 1 if off.dim() == 2 else 0
+    if per_frame and off.shape[0] != n:
+        raise RuntimeError("filter_chain: one (dx,dy) pair per frame expected")
+    dst = torch.empty((n, h, w), dtype=torch.uint16, device=fr.device)
+    back = np.array([background], dtype=np.uint16)
+    handle = bad_pixels.handle if bad_pixels is not None else 0
+    _check(_lib.rir_filter_chain_device(handle, fr.data_ptr(), dst.data_ptr(), w, h, n, float(sigma), off.data_ptr(), per_frame, back.ctypes.data,
+                                        strategy.encode(), _stream()), "rir_filter_chain_device")
     return dst
 
 
