@@ -746,7 +746,8 @@ namespace rir
 			{
 				const int xx = x + ddx, yy = y + ddy;
 				const bool ok = xx >= 0 && yy >= 0 && xx < w && yy < h;
-				const uint32_t val = ok ? in[fbase + xx + (int64_t)yy * w] : 0u;
+				// (always loaded, from an address clamped into the frame: nine independent loads instead of nine branches)
+				const uint32_t val = in[fbase + min(max(xx, 0), w - 1) + (int64_t)min(max(yy, 0), h - 1) * w];
 				// compact the in-bounds values to the front, keeping gather order
 #pragma unroll
 				for (int k = 0; k < 9; ++k)
@@ -916,15 +917,50 @@ namespace rir
 		for (int d = 0; d < KW; ++d)
 			a[d] = kern[KW * KW + d];
 		// raw pixels of the column, clamped like BadPixels::correct does (Filters.cpp:7-50)
-		// (all loads issued, at addresses clamped into the frame; values outside the image are dropped afterwards)
-		const uint16_t *col = s + min(max(cx, 0), w - 1);
 		float v[NR];
-#pragma unroll
-		for (int i = 0; i < NR; ++i)
+		if ((int64_t)w * h < (1 << 30))
 		{
-			const int gy = gy0 - R + i;
-			const float val = (float)max((uint32_t)col[(int64_t)min(max(gy, 0), h - 1) * w], bp.floor_v);
-			v[i] = (xin && gy >= 0 && gy < h) ? val : 0.f;
+			// Raw-buffer loads over the frame: the byte offset of a pixel outside the image is out of the buffer's range
+			// (rows above: negative, i.e. >= 2^31 unsigned; rows below: past the end; columns outside: forced there) and
+			// the hardware returns 0 for it - the value such a pixel contributes.  One add per row, no branch, no select.
+			const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)s);
+			const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)s >> 32));
+			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, w * h * 2, 0x00020000);
+			uint32_t off = xin ? (uint32_t)(((gy0 - R) * w + cx) * 2) : 0x80000000u;
+			const uint32_t step = (uint32_t)w * 2u;
+			uint32_t raw[NR];
+#pragma unroll
+			for (int i = 0; i < NR; ++i)
+			{
+				raw[i] = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, 0, 0);
+				off += step;
+			}
+			if (gx0 - R >= 0 && gx0 - R + 63 < w && gy0 - R >= 0 && gy0 - R + NR <= h)
+			{ // the usual case: every pixel under the block is in the image
+#pragma unroll
+				for (int i = 0; i < NR; ++i)
+					v[i] = (float)max(raw[i], bp.floor_v);
+			}
+			else
+			{ // (the clamp floor must not lift the zeros of pixels outside the image)
+#pragma unroll
+				for (int i = 0; i < NR; ++i)
+				{
+					const int gy = gy0 - R + i;
+					v[i] = (float)((xin && gy >= 0 && gy < h) ? max(raw[i], bp.floor_v) : 0u);
+				}
+			}
+		}
+		else
+		{ // frames of 2 GiB and more: plain loads at addresses clamped into the frame, values outside dropped afterwards
+			const uint16_t *col = s + min(max(cx, 0), w - 1);
+#pragma unroll
+			for (int i = 0; i < NR; ++i)
+			{
+				const int gy = gy0 - R + i;
+				const float val = (float)max((uint32_t)col[(int64_t)min(max(gy, 0), h - 1) * w], bp.floor_v);
+				v[i] = (xin && gy >= 0 && gy < h) ? val : 0.f;
+			}
 		}
 		// flagged pixels under the block take their repaired value.  The list is in raster order, so the rows of the
 		// block own one run of it: the lanes look at 64 entries at a time (one coalesced load - a scalar walk over the
@@ -996,9 +1032,9 @@ namespace rir
 			if (interior && __ballot(!(row_ok && col_ok)) == 0)
 			{
 				auto shl1 = [](float f) -> float
-				{ return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x130, 0xf, 0xf, false)); }; // lane i <- i + 1
+				{ return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x130, 0xf, 0xf, true)); }; // lane i <- i + 1
 				auto shr1 = [](float f) -> float
-				{ return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x138, 0xf, 0xf, false)); }; // lane i <- i - 1
+				{ return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x138, 0xf, 0xf, true)); }; // lane i <- i - 1
 				double dl[TY]; // filtered pixel (gx0 + lane, gy0 + j) = this lane's left tap column
 #pragma unroll
 				for (int j = 0; j < TY; ++j)
@@ -1012,17 +1048,15 @@ namespace rir
 				uint16_t *d = dst + fbase + x + (int64_t)y0 * w;
 #pragma unroll
 				for (int j = 0; j < OH; ++j)
-				{
-					if (y0 + j >= h)
-						break;
+				{ // (rows past the end of the image are computed and not stored: no early exit, the loop unrolls)
 					const double vv = (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vvj), j));
 					const double cl = dl[j + 1] * (1 - vv) + dl[j] * vv;
 					const uint64_t clb = __builtin_bit_cast(uint64_t, cl);
-					const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)clb, 0x130, 0xf, 0xf, false);
-					const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(clb >> 32), 0x130, 0xf, 0xf, false);
+					const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)clb, 0x130, 0xf, 0xf, true);
+					const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(clb >> 32), 0x130, 0xf, 0xf, true);
 					const double cr = __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
 					const uint16_t res = CastTo<u16_via_f32>::from(cl * u1 + cr * u).v;
-					if (act_x)
+					if (act_x && y0 + j < h)
 						d[(int64_t)j * w] = res;
 				}
 				return;
