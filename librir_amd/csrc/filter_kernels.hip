@@ -522,29 +522,40 @@ namespace rir
 		}
 	}
 
-	// Radius 1..4: separable form through LDS.  The reference table is k[dx][dy] = g(dx) g(dy) / sum, i.e. the
-	// outer product of a 1-D factor a[d] (uploaded behind the 2-D table): a row pass and a column pass of
+	// Radius 1..4: separable form, entirely in registers.  The reference table is k[dx][dy] = g(dx) g(dy) / sum, i.e.
+	// the outer product of a 1-D factor a[d] (uploaded behind the 2-D table): a row pass and a column pass of
 	// 2R+1 taps each replace the (2R+1)^2-tap sum, which turns the kernel from compute-bound (162 flop per
 	// pixel at R = 4) into a streaming one.  Same mathematics as the reference, different rounding: results
 	// agree to a few 1e-7 relative (the parity bar for float32 filters is 1e-5, BASELINE.json); border pixels
 	// are renormalised by the in-image weight, Sx(x) * Sy(y), as the reference does with its 2-D sum.
 	// Each WAVE works alone on a tile of 64 columns (the outer R on each side are halo) x TY rows: every lane
-	// owns one column, fetches its TY + 2R values with back-to-back independent loads (row-coalesced across the
-	// lanes) and does the COLUMN pass in registers; the column sums go to a wave-private LDS strip and the ROW
-	// pass reads the 2R+1 neighbours from there.  No workgroup barrier, no staged copy of the input: the time
-	// of the earlier tile-staging version was set by its load / barrier / compute phases (0.25 ms per 256
-	// frames whatever the radius).
+	// owns one column, fetches its TY + 2R values with back-to-back independent raw-buffer loads (row-coalesced
+	// across the lanes; pixels outside the image read as 0 through the buffer's range check) and does the COLUMN
+	// pass in registers with packed FMAs; the ROW pass takes the 2R neighbouring column sums from the neighbouring
+	// lanes with DPP wave shifts.  No LDS, no barrier.  (History: the tile-staging version took 0.25 ms per 256
+	// frames whatever the radius, set by its load / barrier / compute phases; the version with a wave-private LDS
+	// strip for the row pass and loads under conditions 0.136 ms.)
 #ifndef RIR_GAUSS_TY
 #define RIR_GAUSS_TY 16 /* output rows per wave tile */
 #endif
 	// TIN = float, or uint16_t (the integer -> float conversion of a u16 frame folded into the load).
+	typedef float v2f __attribute__((ext_vector_type(2)));
+	__device__ __forceinline__ float wave_shl1(float f) // lane i <- lane i + 1 (0 into lane 63)
+	{
+		return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x130, 0xf, 0xf, true));
+	}
+	__device__ __forceinline__ float wave_shr1(float f) // lane i <- lane i - 1 (0 into lane 0)
+	{
+		return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x138, 0xf, 0xf, true));
+	}
+
 	template <int R, class TIN>
 	__global__ __launch_bounds__(256) void gaussian_sep_kernel(const TIN *__restrict__ src, float *__restrict__ dst, int w, int h,
 															   const float *__restrict__ kern)
 	{
-		constexpr int TY = RIR_GAUSS_TY, KW = 2 * R + 1, OUTW = 64 - 2 * R;
-		__shared__ float colp[4][TY][64];
-		const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+		constexpr int TY = RIR_GAUSS_TY, HY = TY / 2, KW = 2 * R + 1, OUTW = 64 - 2 * R, NR = TY + 2 * R;
+		const int lane = threadIdx.x & 63;
+		const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 		// XCD-aware tile order (xcd_major), then (frame, column strip, row band) with the row band fastest:
 		// vertically adjacent tiles, which share 2R halo rows, run on the same XCD back to back.
 		int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -555,8 +566,9 @@ namespace rir
 			bx = (int)((id2 / gy) % gx);
 			bz = (int)(id2 / (gy * gx));
 		}
-		const int x = bx * OUTW - R + lane;			 // this lane's column (halo lanes may fall outside the image)
-		const int y0 = (by * 4 + wv) * TY;			 // first output row of this wave
+		const int x0 = bx * OUTW - R;
+		const int x = x0 + lane;				 // this lane's column (halo lanes may fall outside the image)
+		const int y0 = (by * 4 + wv) * TY;		 // first output row of this wave
 		if (y0 >= h)
 			return;
 		const int64_t fbase = (int64_t)bz * w * h;
@@ -566,29 +578,88 @@ namespace rir
 		for (int d = 0; d < KW; ++d)
 			a[d] = kern[KW * KW + d];
 		const bool xin = x >= 0 && x < w;
-		// every load is issued, at an address clamped into the frame, and the value dropped afterwards when the pixel
-		// lies outside: a load under a condition becomes a branch with its own wait, i.e. TY + 2R serial latencies
-		const TIN *col = s + min(max(x, 0), w - 1);
-		float v[TY + 2 * R];
-#pragma unroll
-		for (int i = 0; i < TY + 2 * R; ++i)
+		float v[NR];
+		if ((int64_t)w * h * (int64_t)sizeof(TIN) < (int64_t)1 << 31)
 		{
-			const int gy = y0 - R + i;
-			const float val = (float)col[(int64_t)min(max(gy, 0), h - 1) * w];
-			v[i] = (xin && gy >= 0 && gy < h) ? val : 0.f; // zeros outside the image add nothing
+			// Raw-buffer loads over the frame: a pixel outside the image has a byte offset outside the buffer (rows above:
+			// negative = huge unsigned; rows below: past the end; columns outside: forced there) and reads as 0 - exactly
+			// what such a pixel adds to the sums.  No branch, no select, and all TY + 2R loads are in flight together
+			// (a load under a condition becomes a branch with its own wait: that many serial latencies).
+			const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)s);
+			const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)s >> 32));
+			const __amdgpu_buffer_rsrc_t rs =
+				__builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, w * h * (int)sizeof(TIN), 0x00020000);
+			const uint32_t step = (uint32_t)w * (uint32_t)sizeof(TIN);
+			if (x0 >= 0 && x0 + 63 < w && y0 - R >= 0 && y0 - R + NR <= h)
+			{ // block inside the image: one lane offset, the row steps on the scalar side
+				const uint32_t off = (uint32_t)(((y0 - R) * w + x) * (int)sizeof(TIN));
+#pragma unroll
+				for (int i = 0; i < NR; ++i)
+				{
+					if constexpr (sizeof(TIN) == 2)
+						v[i] = (float)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, (int)((uint32_t)i * step), 0);
+					else
+						v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, (int)((uint32_t)i * step), 0));
+				}
+			}
+			else
+			{
+				uint32_t off = xin ? (uint32_t)(((y0 - R) * w + x) * (int)sizeof(TIN)) : 0x80000000u;
+#pragma unroll
+				for (int i = 0; i < NR; ++i)
+				{
+					if constexpr (sizeof(TIN) == 2)
+						v[i] = (float)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, 0, 0);
+					else
+						v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+					off += step;
+				}
+			}
 		}
+		else
+		{ // frames of 2 GiB and more: plain loads at addresses clamped into the frame, values outside dropped afterwards
+			const TIN *col = s + min(max(x, 0), w - 1);
 #pragma unroll
-		for (int j = 0; j < TY; ++j)
+			for (int i = 0; i < NR; ++i)
+			{
+				const int gy = y0 - R + i;
+				const float val = (float)col[(int64_t)min(max(gy, 0), h - 1) * w];
+				v[i] = (xin && gy >= 0 && gy < h) ? val : 0.f; // zeros outside the image add nothing
+			}
+		}
+		// column pass, in registers: rows j and j + TY/2 side by side in packed FMAs (two IEEE fmas per instruction)
+		float cs[TY];
+#pragma unroll
+		for (int j = 0; j < HY; ++j)
 		{
-			float acc = 0.f;
+			v2f acc = {0.f, 0.f};
 #pragma unroll
 			for (int d = 0; d < KW; ++d)
-				acc = fmaf(a[d], v[j + d], acc);
-			colp[wv][j][lane] = acc;
+				acc = __builtin_elementwise_fma((v2f){a[d], a[d]}, (v2f){v[j + d], v[j + HY + d]}, acc);
+			cs[j] = acc.x;
+			cs[j + HY] = acc.y;
 		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		// row pass: the 2R neighbouring column sums come from the neighbouring LANES through DPP wave shifts - no LDS,
+		// no barrier (all 64 lanes are still active here: the shifts read every lane)
+		float g[TY];
+#pragma unroll
+		for (int j = 0; j < HY; ++j)
+		{
+			v2f t[KW]; // t[d] = column sums of lane - R + d
+			t[R] = (v2f){cs[j], cs[j + HY]};
+#pragma unroll
+			for (int d = 1; d <= R; ++d)
+			{
+				t[R - d] = (v2f){wave_shr1(t[R - d + 1].x), wave_shr1(t[R - d + 1].y)};
+				t[R + d] = (v2f){wave_shl1(t[R + d - 1].x), wave_shl1(t[R + d - 1].y)};
+			}
+			v2f acc = {0.f, 0.f};
+#pragma unroll
+			for (int d = 0; d < KW; ++d)
+				acc = __builtin_elementwise_fma((v2f){a[d], a[d]}, t[d], acc);
+			g[j] = acc.x;
+			g[j + HY] = acc.y;
+		}
 		if (lane < R || lane >= 64 - R || x >= w)
 			return; // halo lanes, and columns past the right edge, have no output
 		// in-image weight of the row taps of this column, and the full 1-D sum (not exactly 1)
@@ -606,16 +677,14 @@ namespace rir
 				if (x + d >= 0 && x + d < w)
 					sx += a[d + R];
 		}
+		float *o = dst + fbase + x + (int64_t)y0 * w;
 #pragma unroll
 		for (int j = 0; j < TY; ++j)
 		{
 			const int y = y0 + j;
 			if (y >= h)
 				break;
-			float acc = 0.f;
-#pragma unroll
-			for (int d = 0; d < KW; ++d)
-				acc = fmaf(a[d], colp[wv][j][lane - R + d], acc);
+			float acc = g[j];
 			const bool yb = y < R || y >= h - R;
 			if (xb || yb)
 			{ // border pixels are renormalised by the weight of the taps that fall inside the image
@@ -630,7 +699,7 @@ namespace rir
 				}
 				acc = acc / (sx * sy);
 			}
-			dst[fbase + x + (int64_t)y * w] = acc;
+			o[(int64_t)j * w] = acc;
 		}
 	}
 
@@ -798,6 +867,7 @@ namespace rir
 #ifndef RIR_CHAIN_TY
 #define RIR_CHAIN_TY 16 /* rows of the gaussian block per wave; OH = TY - 2 output rows */
 #endif
+	typedef unsigned int v2u32 __attribute__((ext_vector_type(2)));
 	struct ChainBadPixels
 	{
 		const int *xy;			  // flagged (x, y) pairs, raster order
@@ -917,6 +987,26 @@ namespace rir
 		for (int d = 0; d < KW; ++d)
 			a[d] = kern[KW * KW + d];
 		// raw pixels of the column, clamped like BadPixels::correct does (Filters.cpp:7-50)
+		// The run of the flagged-pixel list that lies under the block's rows (the list is in raster order): its bounds, and
+		// its first 64 entries - one per lane, position and repaired value - are fetched here, ahead of the pixels, so
+		// that their latency overlaps the pixel loads instead of following them.  Buffer loads: with no flagged pixels
+		// the buffers are empty and everything reads as 0 (an empty run) without a branch.
+		int li0, li1;
+		int2 lf;
+		uint32_t lfix;
+		{
+			const __amdgpu_buffer_rsrc_t r_rows = __builtin_amdgcn_make_buffer_rsrc((void *)bp.row_start, 0, bp.nbad > 0 ? (h + 1) * 4 : 0, 0x00020000);
+			const __amdgpu_buffer_rsrc_t r_xy = __builtin_amdgcn_make_buffer_rsrc((void *)bp.xy, 0, bp.nbad * 8, 0x00020000);
+			const __amdgpu_buffer_rsrc_t r_fix = __builtin_amdgcn_make_buffer_rsrc((void *)(bp.fix + fix_base), 0, bp.nbad * 4, 0x00020000);
+			const int ra = max(gy0 - R, 0), rb = min(gy0 - R + NR, h);
+			li0 = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_raw_buffer_load_b32(r_rows, ra * 4, 0, 0));
+			li1 = __builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_raw_buffer_load_b32(r_rows, rb * 4, 0, 0));
+			const int i = li0 + lane;
+			const uint32_t eo = i < li1 ? (uint32_t)i : 0x10000000u; // (out of range -> zeros)
+			const v2u32 e = __builtin_amdgcn_raw_buffer_load_b64(r_xy, (int)(eo * 8u), 0, 0);
+			lf = i < li1 ? make_int2((int)e.x, (int)e.y) : make_int2(-(1 << 30), 0);
+			lfix = __builtin_amdgcn_raw_buffer_load_b32(r_fix, (int)(eo * 4u), 0, 0);
+		}
 		float v[NR];
 		if ((int64_t)w * h < (1 << 30))
 		{
@@ -926,26 +1016,30 @@ namespace rir
 			const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)s);
 			const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)s >> 32));
 			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, w * h * 2, 0x00020000);
-			uint32_t off = xin ? (uint32_t)(((gy0 - R) * w + cx) * 2) : 0x80000000u;
 			const uint32_t step = (uint32_t)w * 2u;
 			uint32_t raw[NR];
-#pragma unroll
-			for (int i = 0; i < NR; ++i)
-			{
-				raw[i] = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, 0, 0);
-				off += step;
-			}
 			if (gx0 - R >= 0 && gx0 - R + 63 < w && gy0 - R >= 0 && gy0 - R + NR <= h)
-			{ // the usual case: every pixel under the block is in the image
+			{ // the usual case, every pixel under the block is in the image: one lane offset, the row steps on the scalar side
+				const uint32_t off = (uint32_t)(((gy0 - R) * w + cx) * 2);
+#pragma unroll
+				for (int i = 0; i < NR; ++i)
+					raw[i] = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, (int)((uint32_t)i * step), 0);
 #pragma unroll
 				for (int i = 0; i < NR; ++i)
 					v[i] = (float)max(raw[i], bp.floor_v);
 			}
 			else
-			{ // (the clamp floor must not lift the zeros of pixels outside the image)
+			{
+				uint32_t off = xin ? (uint32_t)(((gy0 - R) * w + cx) * 2) : 0x80000000u;
 #pragma unroll
 				for (int i = 0; i < NR; ++i)
 				{
+					raw[i] = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, 0, 0);
+					off += step;
+				}
+#pragma unroll
+				for (int i = 0; i < NR; ++i)
+				{ // (the clamp floor must not lift the zeros of pixels outside the image)
 					const int gy = gy0 - R + i;
 					v[i] = (float)((xin && gy >= 0 && gy < h) ? max(raw[i], bp.floor_v) : 0u);
 				}
@@ -962,43 +1056,46 @@ namespace rir
 				v[i] = (xin && gy >= 0 && gy < h) ? val : 0.f;
 			}
 		}
-		// flagged pixels under the block take their repaired value.  The list is in raster order, so the rows of the
-		// block own one run of it: the lanes look at 64 entries at a time (one coalesced load - a scalar walk over the
-		// run would be a chain of dependent load latencies) and the few that fall on the block's columns are patched in.
-		if (bp.nbad > 0)
+		// flagged pixels under the block take their repaired value (first 64 entries of the run: fetched above)
 		{
-			const int ra = max(gy0 - R, 0), rb = min(gy0 - R + NR, h);
-			const int i0 = ra < rb ? bp.row_start[ra] : 0, i1 = ra < rb ? bp.row_start[rb] : 0;
-			for (int base = i0; base < i1; base += 64)
+			const int ridx0 = gy0 - R;
+			for (int base = li0; base < li1; base += 64)
 			{
-				const int i = base + lane;
-				const bool has = i < i1;
-				const int2 f = has ? reinterpret_cast<const int2 *>(bp.xy)[i] : make_int2(-(1 << 30), 0);
-				const int rel = f.x - (gx0 - R);
-				uint64_t m = __ballot(has && rel >= 0 && rel < 64);
+				if (base != li0)
+				{ // (more than 64 flagged pixels in the rows of one block: rare)
+					const int i = base + lane;
+					const bool has = i < li1;
+					lf = has ? reinterpret_cast<const int2 *>(bp.xy)[i] : make_int2(-(1 << 30), 0);
+					lfix = has ? bp.fix[fix_base + i] : 0u;
+				}
+				const int rel = lf.x - (gx0 - R);
+				uint64_t m = __ballot(base + lane < li1 && rel >= 0 && rel < 64);
 				while (m)
 				{
 					const int k = __builtin_ctzll(m);
 					m &= m - 1;
 					const int rel_k = __builtin_amdgcn_readlane(rel, k);
-					const int ridx = __builtin_amdgcn_readlane(f.y, k) - (gy0 - R);
-					const float fv = (float)bp.fix[fix_base + base + k];
+					const int ridx = __builtin_amdgcn_readlane(lf.y, k) - ridx0;
+					const float fv = (float)(uint32_t)__builtin_amdgcn_readlane((int)lfix, k);
 #pragma unroll
 					for (int q = 0; q < NR; ++q)
 						v[q] = (lane == rel_k && q == ridx) ? fv : v[q];
 				}
 			}
 		}
-		// gaussian, column pass: in registers
+		// gaussian, column pass: in registers, rows j and j + TY/2 side by side in packed FMAs (two IEEE fmas per
+		// instruction: the same values as the scalar form, half the instructions)
+		constexpr int HY = TY / 2;
 		float cs[TY];
 #pragma unroll
-		for (int j = 0; j < TY; ++j)
+		for (int j = 0; j < HY; ++j)
 		{
-			float acc = 0.f;
+			v2f acc = {0.f, 0.f};
 #pragma unroll
 			for (int d = 0; d < KW; ++d)
-				acc = fmaf(a[d], v[j + d], acc);
-			cs[j] = acc;
+				acc = __builtin_elementwise_fma((v2f){a[d], a[d]}, (v2f){v[j + d], v[j + HY + d]}, acc);
+			cs[j] = acc.x;
+			cs[j + HY] = acc.y;
 		}
 		// this lane's output column and its taps (expressions of translate_px / Filters.h:249-326)
 		const int x = x0 + lane;
@@ -1025,9 +1122,11 @@ namespace rir
 			const float pyj = (float)yj - dy;
 			const bool out_yj = pyj < 0 || pyj >= (float)h;
 			const int tj = (int)pyj, bj = (int)(pyj + 1.f);
-			const bool row_ok = !act_y || (!out_yj && tj == gy0 + lane && bj == tj + 1 && bj < h);
+			bool row_ok = !act_y || (!out_yj && tj == gy0 + lane && bj == tj + 1 && bj < h);
 			const bool col_ok = !act_x || (!out_x && l == gx0 + lane && r == l + 1);
 			const float vvj = (float)bj - pyj;
+			const float vv0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vvj))); // row 0 (y0 < h)
+			row_ok = row_ok && (!act_y || __builtin_bit_cast(int, vvj) == __builtin_bit_cast(int, vv0)); // one vertical weight for the tile
 			const bool interior = gx0 >= R && gx0 + OUTW - 1 < w - R && gy0 >= R && gy0 + TY - 1 < h - R;
 			if (interior && __ballot(!(row_ok && col_ok)) == 0)
 			{
@@ -1037,27 +1136,65 @@ namespace rir
 				{ return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x138, 0xf, 0xf, true)); }; // lane i <- i - 1
 				double dl[TY]; // filtered pixel (gx0 + lane, gy0 + j) = this lane's left tap column
 #pragma unroll
-				for (int j = 0; j < TY; ++j)
+				for (int j = 0; j < HY; ++j)
 				{
-					float acc = fmaf(a[0], shr1(cs[j]), 0.f);
-					acc = fmaf(a[1], cs[j], acc);
-					acc = fmaf(a[2], shl1(cs[j]), acc);
-					dl[j] = (double)shl1(acc); // lane i owns column gx0 - 1 + i: column gx0 + i is one lane up
+					v2f acc = __builtin_elementwise_fma((v2f){a[0], a[0]}, (v2f){shr1(cs[j]), shr1(cs[j + HY])}, (v2f){0.f, 0.f});
+					acc = __builtin_elementwise_fma((v2f){a[1], a[1]}, (v2f){cs[j], cs[j + HY]}, acc);
+					acc = __builtin_elementwise_fma((v2f){a[2], a[2]}, (v2f){shl1(cs[j]), shl1(cs[j + HY])}, acc);
+					dl[j] = (double)shl1(acc.x); // lane i owns column gx0 - 1 + i: column gx0 + i is one lane up
+					dl[j + HY] = (double)shl1(acc.y);
 				}
 				const double u1 = 1 - u;
-				uint16_t *d = dst + fbase + x + (int64_t)y0 * w;
+				const double vv = (double)vv0, v1 = 1 - vv;
+				// Results leave through raw-buffer stores with the streaming policy (written once, not read again here).
+				// The vector-memory path handles one wave instruction per few cycles whatever the bytes per lane, and 14
+				// two-byte stores per tile were a quarter of the kernel's time: when rows are 8-byte aligned (w % 4 == 0)
+				// the tile is turned through the wave's LDS strip so that a lane writes 4 neighbouring pixels at once -
+				// 15 pieces per row, OH rows, 4 store instructions instead of OH.
+				const uint64_t db = (uint64_t)(dst + fbase);
+				const uint32_t dlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)db);
+				const uint32_t dhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(db >> 32));
+				const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)dhi << 32) | dlo), 0, w * h * 2, 0x00020000);
+				const uint32_t dstep = (uint32_t)w * 2u;
+				const bool wide = (w & 3) == 0;
+				uint16_t *ot = reinterpret_cast<uint16_t *>(&tile[wv][0][0]); // [OH][64] uint16
+				uint16_t res[OH];
 #pragma unroll
 				for (int j = 0; j < OH; ++j)
 				{ // (rows past the end of the image are computed and not stored: no early exit, the loop unrolls)
-					const double vv = (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vvj), j));
-					const double cl = dl[j + 1] * (1 - vv) + dl[j] * vv;
+					const double cl = dl[j + 1] * v1 + dl[j] * vv;
 					const uint64_t clb = __builtin_bit_cast(uint64_t, cl);
 					const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)clb, 0x130, 0xf, 0xf, true);
 					const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(clb >> 32), 0x130, 0xf, 0xf, true);
 					const double cr = __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
-					const uint16_t res = CastTo<u16_via_f32>::from(cl * u1 + cr * u).v;
-					if (act_x && y0 + j < h)
-						d[(int64_t)j * w] = res;
+					res[j] = CastTo<u16_via_f32>::from(cl * u1 + cr * u).v;
+				}
+				if (!wide)
+				{
+#pragma unroll
+					for (int j = 0; j < OH; ++j)
+						__builtin_amdgcn_raw_buffer_store_b16(res[j], rd,
+															  (int)((act_x && y0 + j < h) ? (uint32_t)((y0 * w + x) * 2) + (uint32_t)j * dstep : 0x80000000u), 0, 2);
+				}
+				else
+				{
+#pragma unroll
+					for (int j = 0; j < OH; ++j)
+						ot[j * 64 + lane] = res[j];
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier();
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+					constexpr int PPR = OW / 4; // 4-pixel pieces per row
+#pragma unroll
+					for (int q = 0; q < (PPR * OH + 63) / 64; ++q)
+					{
+						const int c = q * 64 + lane;
+						const int row = c / PPR, k = c - row * PPR;
+						const int ox = x0 + 4 * k, oy = y0 + row; // x0 and w are multiples of 4: a piece is inside the row or outside, never across
+						const v2u32 px4 = *reinterpret_cast<const v2u32 *>(ot + (row < OH ? row : 0) * 64 + 4 * k);
+						const bool st = c < PPR * OH && ox < w && oy < h;
+						__builtin_amdgcn_raw_buffer_store_b64(px4, rd, (int)(st ? (uint32_t)((oy * w + ox) * 2) : 0x80000000u), 0, 2);
+					}
 				}
 				return;
 			}

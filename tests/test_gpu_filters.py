@@ -193,3 +193,57 @@ def test_byte_planes_vs_oracle(dev, oracle, shape, linesize):
         assert torch.equal(back.view(torch.int16), t.view(torch.int16))
         if use_it:
             assert torch.equal(it2, ti)
+
+
+# ---- fused filter chain (bad pixels -> gaussian -> translate -> uint16 in one pass) ---------------------------------
+CHAIN_CASES = [((6, 512, 640), 0.75, (1.25, -2.5), "nearest"), ((3, 67, 83), 0.75, (-3.5, 4.75), "nearest"), ((3, 67, 83), 1.0, (0.5, 0.5), "background"),
+               ((2, 20, 30), 2.0, (0.0, 0.0), "nearest"), ((2, 130, 61), 0.3, (100.0, -200.0), "nearest"), ((2, 3, 5), 0.75, (0.25, 0.75), "nearest"),
+               ((4, 240, 320), 1.49, (-0.99999994, 7.0000005), "background"), ((2, 100, 700), 0.75, (650.5, 0.0), "nearest"),
+               ((2, 64, 66), 0.75, (0.0, 0.0), "nearest"), ((3, 33, 130), 0.5, (-0.5, 31.5), "background")]
+
+
+@pytest.mark.parametrize("shape,sigma,off,strategy", CHAIN_CASES)
+def test_filter_chain_equals_the_three_kernels(dev, oracle, shape, sigma, off, strategy):
+    """rir_filter_chain_device against bad_pixels_correct -> gaussian_filter -> translate -> uint16 run as three kernels (each of
+    them oracle-checked above): bit-identical, with and without the bad-pixel stage, single and per-frame offsets.  Against the
+    whole chain on the oracle the result may differ by one level where the float32 gaussian (1e-5 parity) sits next to an
+    integer boundary of the truncation - and only there."""
+    import torch
+
+    n, h, w = shape
+    arr = inject_bad_pixels(s1_noisy_background(n, h, w, seed=11), min(200, h * w // 20))
+    x = torch.from_numpy(arr).cuda()
+    for bp in (dev.BadPixels(x[0]), None):
+        a = bp.correct(x) if bp is not None else x
+        g = dev.gaussian_filter(a, sigma)
+        ref = dev.translate_to_u16(g, off, strategy, background=7)
+        out = dev.filter_chain(x, bp, sigma, off, strategy, background=7)
+        assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), (shape, bp is not None)
+    offs = np.random.default_rng(1).uniform(-5, 5, (n, 2)).astype(np.float32)
+    bp = dev.BadPixels(x[0])
+    ref = dev.translate_to_u16(dev.gaussian_filter(bp.correct(x), sigma), torch.from_numpy(offs).cuda(), strategy, background=7)
+    out = dev.filter_chain(x, bp, sigma, torch.from_numpy(offs).cuda(), strategy, background=7)
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    # the oracle, end to end, on the first frame
+    xy = oracle.bad_pixels_detect(arr[0])
+    _, fc = oracle.bad_pixels_stats(arr[0])
+    c = oracle.bad_pixels_correct(arr[0], xy, fc)
+    t = oracle.translate(oracle.gaussian_filter(c.astype(np.float32), sigma), float(offs[0, 0]), float(offs[0, 1]), "background" if strategy == "background" else strategy,
+                         background=7.0)
+    d = np.abs(t.astype(np.int64).clip(0, 65535) - out[0].cpu().numpy().astype(np.int64))
+    assert d.max() <= 1 and (d != 0).mean() < 2e-3, (d.max(), (d != 0).mean())
+
+
+def test_filter_chain_argument_errors(dev):
+    import torch
+
+    x = torch.zeros((2, 16, 16), dtype=torch.uint16, device="cuda")
+    for strat in ("wrap", "noborder"):
+        with pytest.raises(RuntimeError):
+            dev.filter_chain(x, None, 0.75, (1.0, 1.0), strat)
+    with pytest.raises(RuntimeError):
+        dev.filter_chain(x, None, 3.0, (1.0, 1.0), "nearest")  # radius 6: not offered fused
+    with pytest.raises(RuntimeError):
+        dev.filter_chain(x, dev.BadPixels(torch.zeros((8, 8), dtype=torch.uint16, device="cuda")), 0.75, (0.0, 0.0))  # handle of another size
+    with pytest.raises(RuntimeError):
+        dev.filter_chain(x, None, 0.75, torch.zeros((3, 2)))  # one pair per frame
