@@ -27,9 +27,10 @@ namespace rir
 {
 	// XCD-aware workgroup order.  The dispatcher deals workgroups round-robin to the 8 XCDs of the MI355X, each
 	// with its own L2: neighbours in the launch order never share a cache.  Re-reading the linear id "XCD-major"
-	// (XCD k owns the k-th eighth of the logical order) makes logical neighbours - tiles that share halo rows -
-	// run on the same XCD one after the other.  Measured on gaussian_filter: 0.173 -> 0.131 ms per 256 frames; the
-	// VALU-bound kernels (translate, median) gain nothing from it and keep the plain order.
+	// (XCD k owns the k-th eighth of the logical order) makes logical neighbours - tiles that share halo rows or
+	// split cache lines - run on the same XCD one after the other.  Measured: gaussian_filter 0.173 -> 0.131 ms per
+	// 256 frames, translate (63-pixel tile rows, never line-aligned) 0.109 -> 0.097 ms; the 3x3 median, bound by
+	// its instruction count, gains nothing and keeps the plain order.
 	__device__ __forceinline__ unsigned xcd_major(unsigned id, unsigned total)
 	{
 		const unsigned per = total / 8u;
@@ -174,13 +175,8 @@ namespace rir
 		return true;
 	}
 
-	// ---- interior fast path of translate ------------------------------------------------------------
-	// A chunk of VEC consecutive outputs of one row whose taps all lie inside the image, with no clamping, uses
-	// the VEC+1 consecutive source columns l0..l0+VEC of the two rows t and b.  They are fetched with a few
-	// dword loads per row (instead of 4 scalar loads per output: the kernel was bound by the address rate of the
-	// texture unit) and the vertical blends c_j = p_b[j]*(1-v) + p_t[j]*v are shared by neighbouring outputs -
-	// the very expressions of the reference (Filters.h:310-322), evaluated once.  Same float coordinates, same
-	// double blend, same truncating cast: bit-identical to the per-pixel path.
+	// N consecutive 16-bit elements from an address of any 2-byte alignment: a few dword loads per row (instead of one
+	// scalar load per element - the texture unit's address rate is what bounds such gathers) and a byte alignment.
 	template <class T, int N>
 	__device__ __forceinline__ void load_taps(const T *__restrict__ p, T (&out)[N])
 	{
@@ -212,121 +208,237 @@ namespace rir
 		}
 	}
 
-	template <class T, class U, int VEC>
-	__device__ __forceinline__ bool translate_chunk_interior(const T *__restrict__ s, int w, int h, int x0, int y, float dx, float dy, U (&out)[VEC])
-	{
-		if constexpr (sizeof(T) != 2 && sizeof(T) != 4)
-			return false;
-		else
-		{
-			const float py = (float)y - dy;
-			const float px0 = (float)x0 - dx, pxl = (float)(x0 + VEC - 1) - dx;
-			if (!(py >= 0.f && py < (float)h && px0 >= 0.f && pxl < (float)w))
-				return false;
-			const int l0 = (int)px0;
-			// the dword fetch of 16-bit rows may touch one element past the last tap: keep it inside the row
-			if (l0 + VEC + (sizeof(T) == 2 ? 2 : 1) > w)
-				return false;
-			float px[VEC];
-			bool regular = true;
-#pragma unroll
-			for (int k = 0; k < VEC; ++k)
-			{
-				px[k] = (float)(x0 + k) - dx;
-				regular = regular && ((int)px[k] == l0 + k) && ((int)(px[k] + 1.f) == l0 + k + 1);
-			}
-			if (!regular)
-				return false;
-			const int t = (int)py;
-			int b = (int)(py + 1.f);
-			if (b == h)
-				b = t;
-			T pt[VEC + 1], pb[VEC + 1];
-			load_taps<T, VEC + 1>(s + (int64_t)t * w + l0, pt);
-			load_taps<T, VEC + 1>(s + (int64_t)b * w + l0, pb);
-			const double v = (double)((float)b - py);
-			const double v1 = 1 - v;
-			double c[VEC + 1];
-#pragma unroll
-			for (int j = 0; j <= VEC; ++j)
-				c[j] = (double)pb[j] * v1 + (double)pt[j] * v;
-#pragma unroll
-			for (int k = 0; k < VEC; ++k)
-			{
-				const double u = (double)(px[k] - (float)(l0 + k));
-				out[k] = CastTo<U>::from(c[k] * (1 - u) + c[k + 1] * u);
-			}
-			return true;
-		}
-	}
-
 	template <class U, int VEC>
 	struct alignas(sizeof(U) * VEC) PixVec
 	{
 		U v[VEC];
 	};
 
-	// Each thread produces VEC consecutive pixels of a row and writes them with one vector store
-	// (8 or 16 bytes per lane) when the run is aligned and fully written; the four taps per pixel are
-	// neighbouring reads served by L1/L2.  offsets: per-frame (dx,dy) pairs, or a single pair.
-	template <class T, class U, int VEC>
-	__global__ __launch_bounds__(256) void translate_kernel(const T *__restrict__ src, U *__restrict__ dst, U background, int w_, int h_,
-															const float *__restrict__ offsets, int per_frame_offsets, int strategy, int rows)
+	// ---- translate, one wave per tile --------------------------------------------------------------------------
+	// A kernel that gives every lane a run of 8 output pixels (the first version) spends ~46 vector instructions per pixel, nearly all of them the reference's
+	// double-precision blend and the conversions around it: it is bound by the VALU at a third of the memory rate.
+	// A translation is uniform, so neighbouring outputs share their operands: here lane i of a wave owns output column
+	// x0 + i of a tile of OW x OH pixels and LOADS source column l0 + i for the OH + 1 source rows under the tile (one
+	// coalesced raw-buffer load per row).  Then for every row the vertical blend of the lane's own column,
+	// c = p_b (1 - v) + p_t v, is computed once; the blend of the right tap column is lane i + 1's c (a DPP wave
+	// shift), and the pixel is c (1 - u) + c_right u - the reference's expression (Filters.h:310-322) with every
+	// product computed once instead of twice and no per-pixel address arithmetic: ~12 instructions per pixel.
+	// That holds for "regular" tiles (every output inside the source, taps at l0 + i / l0 + i + 1 and t0 + j / t0 + j + 1,
+	// one vertical weight - checked per tile with the reference's own float expressions, so rounding quirks of
+	// px + 1 or of the weights send a tile to the general path, never to a wrong result); the last source column /
+	// row (r == w -> l, b == h -> t) and columns left or right of the source under "nearest" / "background" /
+	// "noborder" are handled in place.  Every other tile (rows above / below the source, "wrap", ...) runs
+	// translate_px pixel by pixel.  Bit-identical to the reference.  (0.135 -> 0.097 ms per 256 frames 640x512 uint16; the XCD-major order is a quarter of that.)
+#ifndef RIR_TR_TY
+#define RIR_TR_TY 16
+#endif
+	template <class T>
+	__device__ __forceinline__ T buffer_load_px(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
 	{
-		const int cpr = (w_ + VEC - 1) / VEC; // chunks per row
-		const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-		const bool valid = idx < (int64_t)cpr * rows;
-		const int y = valid ? (int)(idx / cpr) : 0;
-		const int x0 = valid ? (int)(idx - (int64_t)y * cpr) * VEC : 0;
-		const int n = blockIdx.y;
-		const uint64_t w = (uint64_t)w_, h = (uint64_t)rows;
-		const int64_t fbase = (int64_t)n * w_ * h_;
-		const T *s = src + fbase;
-		U *d = dst + fbase + (int64_t)y * w_ + x0;
-		const float dx = offsets[per_frame_offsets ? 2 * n : 0];
-		const float dy = offsets[per_frame_offsets ? 2 * n + 1 : 1];
-		const bool small = fabsf(dx) < 1.0e9f && fabsf(dy) < 1.0e9f; // wave-uniform
-		bool done = !valid;
-		if (valid && small && x0 + VEC <= w_ && (((uintptr_t)d) & (sizeof(U) * VEC - 1)) == 0)
-		{
-			PixVec<U, VEC> o;
-			if (translate_chunk_interior<T, U, VEC>(s, w_, rows, x0, y, dx, dy, o.v))
-			{
-				*reinterpret_cast<PixVec<U, VEC> *>(d) = o;
-				done = true;
-			}
-		}
-		// Border chunks (a handful per wave: the ends of a row, the first / last rows) take the general per-pixel
-		// path.  Left to their own lanes they would run it 8 pixels in sequence while the other lanes of the wave
-		// wait; instead the wave handles them one chunk at a time with one pixel per lane.
+		if constexpr (sizeof(T) == 1)
+			return __builtin_bit_cast(T, (uint8_t)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)voff, (int)soff, 0));
+		else if constexpr (sizeof(T) == 2)
+			return __builtin_bit_cast(T, (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)voff, (int)soff, 0));
+		else if constexpr (sizeof(T) == 4)
+			return __builtin_bit_cast(T, (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)soff, 0));
+		else
+			return __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, (int)soff, 0));
+	}
+	__device__ __forceinline__ double wave_shl1_f64(double v) // lane i <- lane i + 1
+	{
+		const uint64_t b = __builtin_bit_cast(uint64_t, v);
+		const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x130, 0xf, 0xf, true);
+		const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x130, 0xf, 0xf, true);
+		return __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+	}
+
+	// rows: rows of the image the translation applies to (h_ for translate; h_ - 3 for the read-back motion removal, whose
+	// last rows are copied: copy_tail).  sign: -1 for the motion removal (it shifts by -x, -y).
+	template <class T, class U>
+	__global__ __launch_bounds__(256) void translate_tile_kernel(const T *__restrict__ src, U *__restrict__ dst, U background, int w, int h_,
+																 const float *__restrict__ offsets, int per_frame_offsets, float sign, int strategy, int rows,
+																 int copy_tail)
+	{
+		constexpr int OW = 63, OH = RIR_TR_TY;
 		const int lane = threadIdx.x & 63;
-		uint64_t todo = __ballot(!done);
-		if (__builtin_popcountll(todo) >= VEC)
-		{ // a wave full of border chunks (first / last rows): every lane walks its own chunk
-			if (!done)
-				for (int k = 0; k < VEC && x0 + k < w_; ++k)
-				{
-					U val;
-					const bool wr = small ? translate_px<T, U, true>(s, w, h, (uint64_t)(x0 + k), y, dx, dy, strategy, background, val)
-										  : translate_px<T, U, false>(s, w, h, (uint64_t)(x0 + k), y, dx, dy, strategy, background, val);
-					if (wr)
-						d[k] = val;
-				}
-			return;
-		}
-		while (todo)
+		const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+		// XCD-major tile order with the column index fastest: tiles that are neighbours along x split cache lines of the
+		// same rows (63-pixel rows are not line-aligned) - on one XCD, one after the other, the second half of a line is
+		// an L2 hit and the two halves of a written line merge before they leave for HBM
+		int bx, by, n;
 		{
-			const int src_lane = __builtin_ctzll(todo);
-			todo &= todo - 1;
-			const int cx = __shfl(x0, src_lane, 64) + lane, cy = __shfl(y, src_lane, 64);
-			if (lane < VEC && cx < w_)
+			const unsigned gx = gridDim.x, gy = gridDim.y;
+			const unsigned id2 = xcd_major(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+			bx = (int)(id2 % gx);
+			by = (int)((id2 / gx) % gy);
+			n = (int)(id2 / (gx * gy));
+		}
+		const int x0 = bx * OW, y0 = (by * 4 + wv) * OH;
+		if (y0 >= h_)
+			return;
+		const int64_t fbase = (int64_t)n * w * h_;
+		const T *s = src + fbase;
+		U *d = dst + fbase;
+		const float dx = sign * offsets[per_frame_offsets ? 2 * n : 0];
+		const float dy = sign * offsets[per_frame_offsets ? 2 * n + 1 : 1];
+		const bool small = fabsf(dx) < 1.0e9f && fabsf(dy) < 1.0e9f; // wave-uniform
+		const int x = x0 + lane;
+		const bool act_x = lane < OW && x < w;
+		const int nrows = min(OH, rows - y0); // translated rows of this tile (<= 0: only copied rows)
+
+		if (small && nrows > 0 && (int64_t)w * h_ * (int64_t)sizeof(T) < ((int64_t)1 << 31))
+		{
+			// columns (this lane), with the reference's expressions
+			const float px = (float)x - dx;
+			const bool out_x = px < 0 || px >= (float)w;
+			const int l = out_x ? 0 : (int)px;
+			int r = out_x ? 0 : (int)(px + 1.f);
+			const bool r_is_l = r == w; // last source column: the right tap is the left one
+			if (r_is_l)
+				r = l;
+			// the tile's source window starts at the column of lane 0's left tap; when lane 0 lies left of the source the
+			// window is extrapolated from the first lane inside (columns < 0 then read as 0 and are never used)
+			const uint64_t inside = __ballot(act_x && !out_x);
+			const int first = inside ? __builtin_ctzll(inside) : 0;
+			const int l0 = __builtin_amdgcn_readlane(l, first) - first;
+			const bool col_ok = !act_x || out_x || (l == l0 + lane && (r_is_l || r == l + 1));
+			// rows (lane j looks at output row y0 + j)
+			const int yj = y0 + lane;
+			const bool act_y = lane < nrows;
+			const float pyj = (float)yj - dy;
+			const bool out_yj = pyj < 0 || pyj >= (float)rows;
+			const int tj = out_yj ? 0 : (int)pyj;
+			const int bj = out_yj ? 0 : (int)(pyj + 1.f);
+			const int t0 = __builtin_amdgcn_readfirstlane(tj);
+			const float vvj = (float)(bj == rows ? tj : bj) - pyj;
+			const float vv0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vvj)));
+			// regular rows: t = t0 + j, b = t + 1, one vertical weight; the row whose bottom tap falls on the last source row
+			// (b == rows -> t, Filters.h:306-309; at most one per tile) has its own weight (float)t - py
+			const bool is_last = bj == rows;
+			const uint64_t last_rows = __ballot(act_y && !out_yj && is_last);
+			const bool row_ok = !act_y || (!out_yj && tj == t0 + lane && (is_last || (bj == tj + 1 && __builtin_bit_cast(int, vvj) == __builtin_bit_cast(int, vv0))));
+			const bool x_border_ok = strategy == TRANSLATE_NEAREST || strategy == TRANSLATE_CONSTANT || strategy == TRANSLATE_UNCHANGED;
+			const uint64_t outs = __ballot(act_x && out_x);
+			const bool one_side = (outs & 1) == 0 || (outs >> first) == 0; // columns outside on the left OR on the right of the tile
+			if (inside != 0 && __ballot(!(col_ok && row_ok)) == 0 && (outs == 0 || (x_border_ok && one_side)) && l0 > -64 && (last_rows & 1) == 0)
 			{
-				U val;
-				const bool wr = small ? translate_px<T, U, true>(s, w, h, (uint64_t)cx, cy, dx, dy, strategy, background, val)
-									  : translate_px<T, U, false>(s, w, h, (uint64_t)cx, cy, dx, dy, strategy, background, val);
-				if (wr)
-					dst[fbase + (int64_t)cy * w_ + cx] = val;
+				const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)s);
+				const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)s >> 32));
+				const __amdgpu_buffer_rsrc_t rs =
+					__builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, w * h_ * (int)sizeof(T), 0x00020000);
+				const int col = l0 + lane;
+				// (columns outside [0, w) would alias pixels of the neighbouring rows: they are sent out of range -> 0)
+				const uint32_t voff = (col >= 0 && col < w) ? (uint32_t)((t0 * w + col) * (int)sizeof(T)) : 0x80000000u;
+				const uint32_t step = (uint32_t)w * (uint32_t)sizeof(T);
+				T tap[OH + 1];
+				if (t0 + OH < h_)
+				{ // all OH + 1 rows are in the frame: the row steps on the scalar side (the scalar offset is NOT range-checked)
+#pragma unroll
+					for (int i = 0; i <= OH; ++i)
+						tap[i] = buffer_load_px<T>(rs, voff, (uint32_t)i * step);
+				}
+				else
+				{ // bottom of the frame: per-lane offsets, rows past the end read as 0 and are never used
+					uint32_t vo = voff;
+#pragma unroll
+					for (int i = 0; i <= OH; ++i)
+					{
+						tap[i] = buffer_load_px<T>(rs, vo, 0);
+						vo += step;
+					}
+				}
+				double dl[OH + 1];
+#pragma unroll
+				for (int i = 0; i <= OH; ++i)
+					dl[i] = (double)tap[i];
+				const double u = (double)(px - (float)l), u1 = 1 - u;
+				const double vv = (double)vv0, v1 = 1 - vv;
+				U *o = d + (int64_t)y0 * w + x;
+				if (outs == 0 && last_rows == 0)
+				{ // the plain tile
+#pragma unroll
+					for (int j = 0; j < OH; ++j)
+					{
+						const double cl = dl[j + 1] * v1 + dl[j] * vv;
+						const double cs = wave_shl1_f64(cl);
+						const double cr = r_is_l ? cl : cs;
+						const U res = CastTo<U>::from(cl * u1 + cr * u);
+						if (act_x && j < nrows)
+							o[(int64_t)j * w] = res;
+					}
+				}
+				else
+				{
+					// edge tiles.  "nearest" left / right of the source: the value of the first / last source column, which one
+					// lane of the wave holds
+					const int edge_lane = outs ? ((outs & 1) ? -l0 : w - 1 - l0) : 0;
+					if (outs != 0 && strategy == TRANSLATE_NEAREST && (edge_lane < 0 || edge_lane > 63))
+						goto general;
+					const int jl = last_rows ? __builtin_ctzll(last_rows) : -1;
+					const double vvl = (double)__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vvj), jl & 63));
+					const double v1l = 1 - vvl;
+#pragma unroll
+					for (int j = 0; j < OH; ++j)
+					{
+						const bool last = j == jl; // wave-uniform
+						const double cl = (last ? dl[j] : dl[j + 1]) * (last ? v1l : v1) + dl[j] * (last ? vvl : vv);
+						const double cs = wave_shl1_f64(cl);
+						const double cr = r_is_l ? cl : cs;
+						U res = CastTo<U>::from(cl * u1 + cr * u);
+						bool wr = act_x && j < nrows;
+						if (strategy == TRANSLATE_NEAREST)
+						{
+							T e;
+							if constexpr (sizeof(T) == 8)
+							{
+								const uint64_t b = __builtin_bit_cast(uint64_t, tap[j]);
+								const uint32_t elo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, edge_lane & 63);
+								const uint32_t ehi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), edge_lane & 63);
+								e = __builtin_bit_cast(T, (uint64_t)elo | ((uint64_t)ehi << 32));
+							}
+							else
+							{
+								uint32_t b = 0;
+								__builtin_memcpy(&b, &tap[j], sizeof(T));
+								b = (uint32_t)__builtin_amdgcn_readlane((int)b, edge_lane & 63);
+								__builtin_memcpy(&e, &b, sizeof(T));
+							}
+							res = out_x ? tap_as<T, U>(e) : res;
+						}
+						else if (strategy == TRANSLATE_CONSTANT)
+							res = out_x ? background : res;
+						else
+							wr = wr && !out_x; // noborder: left untouched
+						if (wr)
+							o[(int64_t)j * w] = res;
+					}
+				}
+				if (copy_tail && act_x)
+					for (int y = max(y0, rows); y < min(y0 + OH, h_); ++y)
+						d[(int64_t)y * w + x] = tap_as<T, U>(s[(int64_t)y * w + x]);
+				return;
 			}
+		}
+	general:
+		// general path: pixel by pixel
+		if (!act_x)
+			return;
+		for (int j = 0; j < OH; ++j)
+		{
+			const int y = y0 + j;
+			if (y >= h_)
+				break;
+			if (y >= rows)
+			{
+				if (copy_tail)
+					d[(int64_t)y * w + x] = tap_as<T, U>(s[(int64_t)y * w + x]);
+				continue;
+			}
+			U val;
+			const bool wr = small ? translate_px<T, U, true>(s, (uint64_t)w, (uint64_t)rows, (uint64_t)x, y, dx, dy, strategy, background, val)
+								  : translate_px<T, U, false>(s, (uint64_t)w, (uint64_t)rows, (uint64_t)x, y, dx, dy, strategy, background, val);
+			if (wr)
+				d[(int64_t)y * w + x] = val;
 		}
 	}
 
@@ -334,13 +446,10 @@ namespace rir
 	static hipError_t launch_translate_t(const void *src, void *dst, const void *background, int w, int h, int nframes, const float *d_offsets,
 										 int per_frame, float sign, int strategy, int rows, hipStream_t st)
 	{
-		(void)sign;
-		constexpr int VEC = sizeof(U) >= 8 ? 2 : (sizeof(U) == 2 ? 8 : 4);
 		U back = *reinterpret_cast<const U *>(background);
-		const int64_t chunks = (int64_t)((w + VEC - 1) / VEC) * rows;
-		dim3 block(256), grid((unsigned)((chunks + 255) / 256), nframes);
-		hipLaunchKernelGGL((translate_kernel<T, U, VEC>), grid, block, 0, st, (const T *)src, (U *)dst, back, w, h, d_offsets, per_frame, strategy,
-						   rows);
+		dim3 block(256), grid((unsigned)((w + 62) / 63), (unsigned)((rows + 4 * RIR_TR_TY - 1) / (4 * RIR_TR_TY)), nframes);
+		hipLaunchKernelGGL((translate_tile_kernel<T, U>), grid, block, 0, st, (const T *)src, (U *)dst, back, w, h, d_offsets, per_frame, sign, strategy, rows,
+						   0);
 		return hipGetLastError();
 	}
 
@@ -379,103 +488,14 @@ namespace rir
 	}
 
 	// ---- motion removal (read-back) -----------------------------------------------------------
-	// translate<u16 -> float>(img, tmp, 0, w, rows, -x[pos], -y[pos], nearest) then the truncating
-	// float -> u16 copy, fused: the float never leaves registers.  Rows >= `rows` are copied.
-	__global__ __launch_bounds__(256) void remove_motion_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w_, int h_,
-																int rows, const float *__restrict__ shifts)
-	{
-		constexpr int VEC = 8;
-		const int cpr = (w_ + VEC - 1) / VEC;
-		const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-		const bool valid = idx < (int64_t)cpr * h_;
-		const int y = valid ? (int)(idx / cpr) : 0;
-		const int x0 = valid ? (int)(idx - (int64_t)y * cpr) * VEC : 0;
-		const int n = blockIdx.y;
-		const int64_t fbase = (int64_t)n * w_ * h_;
-		const uint16_t *s = src + fbase;
-		uint16_t *d = dst + fbase + (int64_t)y * w_ + x0;
-		const float dx = -shifts[2 * n], dy = -shifts[2 * n + 1];
-		const bool small = fabsf(dx) < 1.0e9f && fabsf(dy) < 1.0e9f;
-		bool done = !valid;
-		if (valid && x0 + VEC <= w_ && (((uintptr_t)d) & 15) == 0)
-		{
-			PixVec<uint16_t, VEC> o;
-			if (y >= rows)
-			{ // the last rows (camera metadata) are copied
-				const uint16_t *sp = s + (int64_t)y * w_ + x0;
-				if ((((uintptr_t)sp) & 15) == 0)
-				{
-					o = *reinterpret_cast<const PixVec<uint16_t, VEC> *>(sp);
-					*reinterpret_cast<PixVec<uint16_t, VEC> *>(d) = o;
-					done = true;
-				}
-			}
-			else if (small)
-			{
-				float val[VEC];
-				if (translate_chunk_interior<uint16_t, float, VEC>(s, w_, rows, x0, y, dx, dy, val))
-				{
-#pragma unroll
-					for (int k = 0; k < VEC; ++k)
-						o.v[k] = (uint16_t)(int32_t)val[k];
-					*reinterpret_cast<PixVec<uint16_t, VEC> *>(d) = o;
-					done = true;
-				}
-			}
-		}
-		// border chunks: one chunk at a time, one pixel per lane (see translate_kernel)
-		const int lane = threadIdx.x & 63;
-		uint64_t todo = __ballot(!done);
-		if (__builtin_popcountll(todo) >= VEC)
-		{ // a wave full of border chunks: every lane walks its own chunk
-			if (!done)
-				for (int k = 0; k < VEC && x0 + k < w_; ++k)
-				{
-					uint16_t out;
-					if (y >= rows)
-						out = s[(int64_t)y * w_ + x0 + k];
-					else
-					{
-						float val = 0;
-						if (small)
-							translate_px<uint16_t, float, true>(s, (uint64_t)w_, (uint64_t)rows, (uint64_t)(x0 + k), y, dx, dy, TRANSLATE_NEAREST, 0.f, val);
-						else
-							translate_px<uint16_t, float, false>(s, (uint64_t)w_, (uint64_t)rows, (uint64_t)(x0 + k), y, dx, dy, TRANSLATE_NEAREST, 0.f, val);
-						out = (uint16_t)(int32_t)val;
-					}
-					d[k] = out;
-				}
-			return;
-		}
-		while (todo)
-		{
-			const int src_lane = __builtin_ctzll(todo);
-			todo &= todo - 1;
-			const int cx = __shfl(x0, src_lane, 64) + lane, cy = __shfl(y, src_lane, 64);
-			if (lane < VEC && cx < w_)
-			{
-				uint16_t out;
-				if (cy >= rows)
-					out = s[(int64_t)cy * w_ + cx];
-				else
-				{
-					float val = 0;
-					if (small)
-						translate_px<uint16_t, float, true>(s, (uint64_t)w_, (uint64_t)rows, (uint64_t)cx, cy, dx, dy, TRANSLATE_NEAREST, 0.f, val);
-					else
-						translate_px<uint16_t, float, false>(s, (uint64_t)w_, (uint64_t)rows, (uint64_t)cx, cy, dx, dy, TRANSLATE_NEAREST, 0.f, val);
-					out = (uint16_t)(int32_t)val;
-				}
-				dst[fbase + (int64_t)cy * w_ + cx] = out;
-			}
-		}
-	}
-
+	// translate<u16 -> float>(img, tmp, 0, w, rows, -x[pos], -y[pos], nearest) then the truncating float -> u16 copy
+	// (IRFileLoader.cpp:617-627) is translate<u16 -> u16 through float>: the float never leaves registers.  Rows >= `rows`
+	// are copied.
 	hipError_t launch_remove_motion(const uint16_t *src, uint16_t *dst, int w, int h, int rows, int nframes, const float *d_shifts, hipStream_t st)
 	{
-		const int64_t chunks = (int64_t)((w + 7) / 8) * h;
-		dim3 block(256), grid((unsigned)((chunks + 255) / 256), nframes);
-		hipLaunchKernelGGL(remove_motion_kernel, grid, block, 0, st, src, dst, w, h, rows, d_shifts);
+		dim3 block(256), grid((unsigned)((w + 62) / 63), (unsigned)((h + 4 * RIR_TR_TY - 1) / (4 * RIR_TR_TY)), nframes);
+		hipLaunchKernelGGL((translate_tile_kernel<uint16_t, u16_via_f32>), grid, block, 0, st, src, reinterpret_cast<u16_via_f32 *>(dst), u16_via_f32{0}, w, h,
+						   d_shifts, 1, -1.f, (int)TRANSLATE_NEAREST, rows, 1);
 		return hipGetLastError();
 	}
 
