@@ -160,13 +160,15 @@ namespace rir
 			out = tap_as<T, U>(s[_x + _y * w]);
 			return true;
 		}
+		// (reference: r == w, b == h.  px + 1 can round up to w + 1 - w a power of two, px one ulp below w - and the
+		// reference then reads out of bounds; nothing here may, so that tap is the left / top one as well)
 		const uint64_t l = f2szT<SMALL>(px);
 		uint64_t r = f2szT<SMALL>(px + 1);
-		if (r == w)
+		if (r >= w)
 			r = l;
 		const uint64_t t = f2szT<SMALL>(py);
 		uint64_t b = f2szT<SMALL>(py + 1);
-		if (b == h)
+		if (b >= h)
 			b = t;
 		const T p1 = s[b * w + l], p2 = s[t * w + l], p3 = s[b * w + r], p4 = s[t * w + r];
 		const double u = (px - (float)l);
@@ -1124,7 +1126,7 @@ namespace rir
 		const bool out_x = px < 0 || px >= (float)w;
 		const int l = out_x ? (px < 0 ? 0 : w - 1) : (int)px;
 		int r = out_x ? l : (int)(px + 1.f);
-		if (r == w)
+		if (r >= w)
 			r = l;
 		const double u = (double)(px - (float)l);
 
@@ -1294,7 +1296,7 @@ namespace rir
 			// taps: inside -> (l,b) (l,t) (r,b) (r,t); outside with "nearest" -> the clamped pixel, four times
 			int t = out_y ? (py < 0 ? 0 : h - 1) : (int)py;
 			int b = out_y ? t : (int)(py + 1.f);
-			if (b == h)
+			if (b >= h)
 				b = t;
 			const int rr = outside ? l : r, bb = outside ? t : b;
 			float p1 = block_px(l, bb), p2 = block_px(l, t), p3 = block_px(rr, bb), p4 = block_px(rr, t);

@@ -107,11 +107,11 @@ static inline uint64_t wrap_sz(uint64_t value, uint64_t max) { return (value + m
 				{ /* Filters.h:305-323 */                                                          \
 					const uint64_t l = f2sz(px);                                                   \
 					uint64_t r = f2sz(px + 1);                                                     \
-					if (r == w)                                                                    \
-						r = l;                                                                     \
+					if (r >= w) /* reference: r == w.  px + 1 can round to w + 1 (w a power of two, px one ulp  */ \
+						r = l;  /* below w): the reference then reads out of bounds; here that tap is l too. */ \
 					const uint64_t t = f2sz(py);                                                   \
 					uint64_t b = f2sz(py + 1);                                                     \
-					if (b == h)                                                                    \
+					if (b >= h) /* likewise */                                                     \
 						b = t;                                                                     \
 					const T p1 = src[b * w + l], p2 = src[t * w + l];                              \
 					const T p3 = src[b * w + r], p4 = src[t * w + r];                              \

@@ -18,6 +18,8 @@ for k in range(cases):
     h, w = int(rng.integers(1, 70)), int(rng.integers(1, 200))
     if rng.random() < 0.3:
         w = int(rng.choice([8, 16, 64, 640, 641, 320])); h = int(rng.choice([2, 3, 5, 33, 64]))
+    elif rng.random() < 0.25:  # several tiles in both directions: the regular-tile paths of translate / gaussian / filter_chain
+        w = int(rng.integers(130, 400)); h = int(rng.integers(40, 150))
     n = int(rng.integers(1, 4))
     dt = DT[int(rng.integers(0, len(DT)))]
     if np.issubdtype(dt, np.floating):
@@ -30,6 +32,8 @@ for k in range(cases):
     dx, dy = float(np.float32(rng.normal(0, mag))), float(np.float32(rng.normal(0, mag)))
     if rng.random() < 0.2:
         dx, dy = float(int(dx)), float(int(dy))
+    elif rng.random() < 0.15:  # just below an integer: px + 1 rounds across it (Filters.h:303)
+        dx, dy = float(np.nextafter(np.float32(int(dx)), np.float32(-1e9))), float(np.nextafter(np.float32(int(dy)), np.float32(1e9)))
     t = torch.from_numpy(img).cuda()
     g = D.translate(t, (dx, dy), strat, background=7).cpu().numpy()
     r = np.stack([O.translate(img[i], dx, dy, strat, background=7) for i in range(n)])
@@ -55,6 +59,14 @@ for k in range(cases):
         rm = [O.find_median_pixel(img[i], p, m[i]) for i in range(n)]
         if g != r or gm != rm:
             fail("find_median", k, (n, h, w), p, g, r, gm, rm)
+        if strat in ("nearest", "background"):  # the fused chain against its three kernels (bit-identical)
+            sig = float(rng.choice([0.3, 0.75, 1.0, 1.49, 2.0, 2.4]))
+            bp = D.BadPixels(t[0]) if rng.random() < 0.7 else None
+            a = bp.correct(t) if bp is not None else t
+            ref = D.translate_to_u16(D.gaussian_filter(a, sig), (dx, dy), strat, background=7)
+            out = D.filter_chain(t, bp, sig, (dx, dy), strat, background=7)
+            if not torch.equal(out.view(torch.int16), ref.view(torch.int16)):
+                fail("filter_chain", k, (n, h, w), sig, strat, dx, dy, int((out.view(torch.int16) != ref.view(torch.int16)).sum()))
         Y, U, V = D.split_planes(t, w + int(rng.integers(0, 9)))
         if not torch.equal(D.merge_planes(Y, U, V, w).view(torch.int16), t.view(torch.int16)):
             fail("planes", k, (n, h, w))

@@ -199,7 +199,8 @@ def test_byte_planes_vs_oracle(dev, oracle, shape, linesize):
 CHAIN_CASES = [((6, 512, 640), 0.75, (1.25, -2.5), "nearest"), ((3, 67, 83), 0.75, (-3.5, 4.75), "nearest"), ((3, 67, 83), 1.0, (0.5, 0.5), "background"),
                ((2, 20, 30), 2.0, (0.0, 0.0), "nearest"), ((2, 130, 61), 0.3, (100.0, -200.0), "nearest"), ((2, 3, 5), 0.75, (0.25, 0.75), "nearest"),
                ((4, 240, 320), 1.49, (-0.99999994, 7.0000005), "background"), ((2, 100, 700), 0.75, (650.5, 0.0), "nearest"),
-               ((2, 64, 66), 0.75, (0.0, 0.0), "nearest"), ((3, 33, 130), 0.5, (-0.5, 31.5), "background")]
+               ((2, 64, 66), 0.75, (0.0, 0.0), "nearest"), ((3, 33, 130), 0.5, (-0.5, 31.5), "background"),
+               ((2, 64, 64), 0.75, (32.999996185302734, -45.999996185302734), "nearest")]  # px + 1 rounds to w + 1, see below
 
 
 @pytest.mark.parametrize("shape,sigma,off,strategy", CHAIN_CASES)
@@ -247,3 +248,18 @@ def test_filter_chain_argument_errors(dev):
         dev.filter_chain(x, dev.BadPixels(torch.zeros((8, 8), dtype=torch.uint16, device="cuda")), 0.75, (0.0, 0.0))  # handle of another size
     with pytest.raises(RuntimeError):
         dev.filter_chain(x, None, 0.75, torch.zeros((3, 2)))  # one pair per frame
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32, np.float64])
+def test_translate_where_the_reference_reads_out_of_bounds(dev, oracle, dtype):
+    """w = h = 64 and offsets one ulp below an integer: for the last in-source pixel px + 1 rounds to w + 1, the reference's
+    `r == w` test (Filters.h:306) misses it and it reads one element past the row (past the image for the last row).  Neither the
+    oracle nor the kernels may do that: both take the left / top tap there, and agree everywhere."""
+    import torch
+
+    img = (np.random.default_rng(3).random((2, 64, 64)) * 1000).astype(dtype)
+    for dx, dy, strat in ((32.999996185302734, -45.999996185302734, "nearest"), (5.999999523162842, -44.999996185302734, "background"),
+                          (-0.9999999403953552, 0.9999999403953552, "")):
+        g = dev.translate(torch.from_numpy(img).cuda(), (dx, dy), strat, background=7).cpu().numpy()
+        r = np.stack([oracle.translate(img[i], dx, dy, strat, background=7) for i in range(2)])
+        assert np.array_equal(g, r), (dtype, dx, dy, strat)
