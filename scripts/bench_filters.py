@@ -44,4 +44,8 @@ def pipeline():
     g = D.gaussian_filter(a_, 0.75)
     return ctx.encode(D.translate_to_u16(g, offs, "nearest"))
 rec("config3 chain + encode (4 kernels)", timeit(pipeline, 5), 2 * WH)
+rec("filter_chain (3 filters fused)", timeit(lambda: D.filter_chain(t16, bp, 0.75, offs, "nearest")), 4 * WH)
+rec("filter_chain + encode", timeit(lambda: ctx.encode(D.filter_chain(t16, bp, 0.75, offs, "nearest")), 5), 2 * WH)
+for s in (0.75, 1.0, 2.0):
+    rec("gaussian u16 in, sigma=%g" % s, timeit(lambda: D.gaussian_filter(t16, s)), 6 * WH)
 print(json.dumps(res))
