@@ -120,7 +120,9 @@ extern "C"
 	 * The loss injection of H264_Saver::addImageLossyNoCamera / addLoss (reference src/cpp/video_io/h264.cpp:2253-2607)
 	 * as a stream operator: uint16 frames [n][h][w] in HBM in and out (distinct buffers), one state object per
 	 * stream, frames taken in order.  rir_lossy_create returns a handle > 0 (0 on failure); low_errors /
-	 * high_errors are HOST int[nframes] (the per-frame budgets, as h264_get_low/high_errors), may be NULL. */
+	 * high_errors are HOST int[nframes] (the per-frame budgets, as h264_get_low/high_errors), may be NULL.
+	 * Statistics, error budget and update all run on the device: the frames of a call are queued on `stream`
+	 * back to back; with both arrays NULL the call returns without waiting, else it waits once, at the end. */
 	int rir_lossy_create(int width, int height, int lossy_height, int low_value_error, int high_value_error, double std_factor,
 						 int running_average, int subtract_min, int remove_bad_pixels);
 	int rir_lossy_step_device(int handle, const unsigned short *d_in, unsigned short *d_out, int nframes, int add_loss, int *low_errors,

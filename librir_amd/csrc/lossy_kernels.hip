@@ -30,7 +30,7 @@ namespace rir
 	}
 
 	// mode of the histogram, lowest bin wins ties; stats[0] = background = (bin << 2) + 1
-	__global__ __launch_bounds__(1024) void lossy_mode_kernel(const uint32_t *__restrict__ hist, long long *__restrict__ stats)
+	__global__ __launch_bounds__(1024) void lossy_mode_kernel(uint32_t *__restrict__ hist, long long *__restrict__ stats)
 	{
 		__shared__ uint32_t best_v[1024];
 		__shared__ uint32_t best_i[1024];
@@ -39,6 +39,7 @@ namespace rir
 		for (int k = 0; k < 16; ++k)
 		{ // contiguous range of 16 bins per thread, ascending: strict > keeps the lowest bin
 			const uint32_t b = tid * 16 + k, v = hist[b];
+			hist[b] = 0; // ready for the next frame (the histogram is cleared once, when the state is created)
 			if (k == 0 || v > bv)
 			{
 				bv = v;
@@ -105,14 +106,99 @@ namespace rir
 		}
 	}
 
+	// The error budget of the frame (h264.cpp:2335-2385, :2544-2548 for addLoss): the reference's statistic
+	// sqrt((sum d)^2 - sum d^2) / n of this frame against its mean over a 40-frame window, scaled by stdFactor, is
+	// taken off lowValueError / highValueError.  Sequential scalar double arithmetic on exact integer sums - one
+	// thread, same operations in the same order as the host code it replaces (sqrt, division and round of doubles
+	// are IEEE-exact on the device: scripts/ubench/sqrt_f64_check.hip, 1.3e8 samples; this file is compiled with
+	// -ffp-contract=off).  Keeping it here means no statistics travel to the host between the kernels of a frame.
+	// (int) of a double as the reference's x86-64 build converts it (cvttsd2si): NaN and values outside int32 give
+	// INT_MIN.  It matters: with an empty foreground or background the statistic is 0/0, the NaN stays in the 40-frame
+	// window, and the budgets of those frames are whatever this conversion and the wrapping subtraction below make of it
+	// (0 / 0 errors: lossless frames) - the device's own conversion (NaN -> 0) would leave the configured errors instead.
+	__device__ __forceinline__ int int_of_double_x86(double v) { return (v >= -2147483648.0 && v < 2147483648.0) ? (int)v : (int)0x80000000; }
+	__device__ __forceinline__ int sub_wrap(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+
+	__global__ void lossy_budget_kernel(long long *__restrict__ stats, LossyBudget *__restrict__ bs, int s, int add_loss, double std_factor,
+										int low_value_error, int high_value_error, LossyDecision *__restrict__ decision, int *__restrict__ errors_out)
+	{
+		if (threadIdx.x != 0 || blockIdx.x != 0)
+			return;
+		LossyBudget &b = *bs;
+		// stdDev (h264.cpp:1993-2036): unsplit for the first 40 frames
+		double sd[2];
+		if (b.n_win < 40)
+		{
+			const double sum_diff = (double)(stats[1] + stats[4]), sum_diff2 = (double)(stats[2] + stats[5]);
+			sd[0] = sd[1] = sqrt(sum_diff * sum_diff - sum_diff2) / s;
+		}
+		else
+		{
+			const double fd = (double)stats[1], fd2 = (double)stats[2], bd = (double)stats[4], bd2 = (double)stats[5];
+			sd[0] = sqrt(bd * bd - bd2) / (int)stats[6];
+			sd[1] = sqrt(fd * fd - fd2) / (int)stats[3];
+		}
+		if (b.n_first < 1)
+		{
+			b.first_std[0] = sd[0], b.first_std[1] = sd[1];
+			b.n_first = 1;
+		}
+		if (b.n_win < 40)
+		{
+			b.win[b.n_win][0] = sd[0], b.win[b.n_win][1] = sd[1];
+			++b.n_win;
+		}
+		else
+		{
+			for (int i = 0; i < 39; ++i)
+				b.win[i][0] = b.win[i + 1][0], b.win[i][1] = b.win[i + 1][1];
+			b.win[39][0] = sd[0], b.win[39][1] = sd[1];
+		}
+		double mean[2] = {b.first_std[0], b.first_std[1]};
+		for (int i = 0; i < b.n_win; ++i)
+		{
+			mean[0] += b.win[i][0];
+			mean[1] += b.win[i][1];
+		}
+		mean[0] /= (double)(b.n_win + b.n_first);
+		mean[1] /= (double)(b.n_win + b.n_first);
+		int low_error = low_value_error, high_error = high_value_error;
+		if (add_loss)
+		{ // one-sided
+			const double dh = sd[1] < mean[1] ? 0 : sd[1] - mean[1], dl = sd[0] < mean[0] ? 0 : sd[0] - mean[0];
+			high_error = sub_wrap(high_error, int_of_double_x86(round(dh * std_factor)));
+			low_error = sub_wrap(low_error, int_of_double_x86(round(dl * std_factor)));
+		}
+		else
+		{ // two-sided
+			high_error = sub_wrap(high_error, int_of_double_x86(round(fabs(sd[1] - mean[1]) * std_factor)));
+			low_error = sub_wrap(low_error, int_of_double_x86(round(fabs(sd[0] - mean[0]) * std_factor)));
+		}
+		if (high_error < 0)
+			high_error = 0;
+		if (low_error < high_error)
+			low_error = high_error;
+		decision->background = (uint32_t)stats[0];
+		decision->low_error = low_error;
+		decision->high_error = high_error;
+		if (errors_out)
+		{
+			errors_out[0] = low_error;
+			errors_out[1] = high_error;
+		}
+		for (int i = 1; i < 8; ++i) // the sums are accumulated with atomics: cleared for the next frame
+			stats[i] = 0;
+	}
+
 	// L3 + L4: running average update and decision loop, one thread per pixel of the whole frame.
 	__global__ __launch_bounds__(256) void lossy_update_kernel(const uint16_t *__restrict__ tmp, uint16_t *__restrict__ out, LossyDeviceState st,
-																int s, int full, uint32_t background, int low_error, int high_error,
-																int add_loss)
+																int s, int full, const LossyDecision *__restrict__ decision, int add_loss)
 	{
 		const int i = blockIdx.x * blockDim.x + threadIdx.x;
 		if (i >= full)
 			return;
+		const uint32_t background = decision->background;
+		const int low_error = decision->low_error, high_error = decision->high_error;
 		const uint32_t v = tmp[i];
 		if (i >= s)
 		{ // rows past lossy_height: stored as they are
@@ -212,15 +298,11 @@ namespace rir
 		}
 	}
 
+	// d_hist (16 384 bins) and d_stats[1..7] must be zero on entry: they are when the state is created, and every frame
+	// leaves them so (lossy_mode_kernel / lossy_budget_kernel clear what they have read).
 	hipError_t launch_lossy_stats(const uint16_t *d_prevT, const uint16_t *d_tmp, const uint16_t *d_img, int s, uint32_t mn, int subtract_min,
 								  uint32_t *d_hist, long long *d_stats, hipStream_t st)
 	{
-		hipError_t e = hipMemsetAsync(d_hist, 0, 16384 * sizeof(uint32_t), st);
-		if (e != hipSuccess)
-			return e;
-		e = hipMemsetAsync(d_stats, 0, 8 * sizeof(long long), st);
-		if (e != hipSuccess)
-			return e;
 		hipLaunchKernelGGL(lossy_hist_kernel, dim3((s + 32767) / 32768), dim3(1024), 0, st, d_tmp, s, d_hist);
 		hipLaunchKernelGGL(lossy_mode_kernel, dim3(1), dim3(1024), 0, st, d_hist, d_stats);
 		int blocks = (s + 2047) / 2048; // 8 pixels per thread
@@ -230,11 +312,18 @@ namespace rir
 		return hipGetLastError();
 	}
 
-	hipError_t launch_lossy_update(const uint16_t *d_tmp, uint16_t *d_out, const LossyDeviceState &state, int s, int full, uint32_t background,
-								   int low_error, int high_error, int add_loss, hipStream_t st)
+	hipError_t launch_lossy_budget(long long *d_stats, LossyBudget *d_budget, int s, int add_loss, double std_factor, int low_value_error,
+								   int high_value_error, LossyDecision *d_decision, int *d_errors_out, hipStream_t st)
 	{
-		hipLaunchKernelGGL(lossy_update_kernel, dim3((full + 255) / 256), dim3(256), 0, st, d_tmp, d_out, state, s, full, background, low_error,
-						   high_error, add_loss);
+		hipLaunchKernelGGL(lossy_budget_kernel, dim3(1), dim3(1), 0, st, d_stats, d_budget, s, add_loss, std_factor, low_value_error, high_value_error,
+						   d_decision, d_errors_out);
+		return hipGetLastError();
+	}
+
+	hipError_t launch_lossy_update(const uint16_t *d_tmp, uint16_t *d_out, const LossyDeviceState &state, int s, int full,
+								   const LossyDecision *d_decision, int add_loss, hipStream_t st)
+	{
+		hipLaunchKernelGGL(lossy_update_kernel, dim3((full + 255) / 256), dim3(256), 0, st, d_tmp, d_out, state, s, full, d_decision, add_loss);
 		return hipGetLastError();
 	}
 

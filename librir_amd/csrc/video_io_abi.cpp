@@ -151,12 +151,8 @@ namespace
 	{
 		int w = 0, h = 0, hl = 0;
 		int frames = 0;
-		DeviceBuffer d_img, d_tmp, d_out, d_ref, d_prev, d_last, d_sums, d_cval, d_ccnt, d_ring, d_hist, d_stats, d_min;
+		DeviceBuffer d_img, d_tmp, d_out, d_ref, d_prev, d_last, d_sums, d_cval, d_ccnt, d_ring, d_hist, d_stats, d_min, d_budget, d_decision, d_errs;
 		LossyDeviceState dev{};
-		double first_std[2] = {0, 0};
-		int n_first = 0;
-		double win[40][2];
-		int n_win = 0;
 		int bp_handle = 0;
 
 		~LossyState()
@@ -173,11 +169,15 @@ namespace
 			if (!d_img.reserve(full * 2) || !d_tmp.reserve(full * 2) || !d_out.reserve(full * 2) || !d_ref.reserve(full * 2) ||
 				!d_prev.reserve(full * 2) || !d_last.reserve(full * 2) || !d_sums.reserve(s * 4 + 4) || !d_cval.reserve(s * 2 + 4) ||
 				!d_ccnt.reserve(s * 2 + 4) || !d_ring.reserve((size_t)std::max(ra, 1) * s * 2 + 4) || !d_hist.reserve(16384 * 4) ||
-				!d_stats.reserve(8 * sizeof(long long)) || !d_min.reserve(4))
+				!d_stats.reserve(8 * sizeof(long long)) || !d_min.reserve(4) || !d_budget.reserve(sizeof(LossyBudget)) ||
+				!d_decision.reserve(sizeof(LossyDecision)) || !d_errs.reserve(2 * sizeof(int)))
 				return false;
 			hipStream_t st = default_stream();
+			// histogram, sums and budget start at zero; afterwards every frame leaves the first two cleared (lossy_kernels.hip)
 			if (!hip_ok(hipMemsetAsync(d_sums.ptr, 0, s * 4 + 4, st), "memset") || !hip_ok(hipMemsetAsync(d_cval.ptr, 0, s * 2 + 4, st), "memset") ||
-				!hip_ok(hipMemsetAsync(d_ccnt.ptr, 0, s * 2 + 4, st), "memset"))
+				!hip_ok(hipMemsetAsync(d_ccnt.ptr, 0, s * 2 + 4, st), "memset") || !hip_ok(hipMemsetAsync(d_hist.ptr, 0, 16384 * 4, st), "memset") ||
+				!hip_ok(hipMemsetAsync(d_stats.ptr, 0, 8 * sizeof(long long), st), "memset") ||
+				!hip_ok(hipMemsetAsync(d_budget.ptr, 0, sizeof(LossyBudget), st), "memset"))
 				return false;
 			dev.refT = d_ref.as<uint16_t>(), dev.prevT = d_prev.as<uint16_t>(), dev.lastDL = d_last.as<uint16_t>();
 			dev.ra_sums = d_sums.as<uint32_t>(), dev.ra_const_value = d_cval.as<uint16_t>(), dev.ra_const_count = d_ccnt.as<int16_t>();
@@ -185,7 +185,7 @@ namespace
 			dev.ra_count = 0, dev.ra_head = 0, dev.running_average = ra;
 			dev.subtract_min = subtract_min ? 1 : 0;
 			dev.min = 0;
-			frames = 0, n_first = 0, n_win = 0;
+			frames = 0;
 			return hip_ok(hipStreamSynchronize(st), "sync"); // the state is ready whatever stream the steps run on
 		}
 
@@ -195,19 +195,39 @@ namespace
 		{
 			hipStream_t st = default_stream();
 			const int full = w * h;
+			int e[2] = {0, 0};
 			if (!hip_ok(hipMemcpyAsync(d_img.ptr, img, (size_t)full * 2, hipMemcpyHostToDevice, st), "H2D") ||
-				!step_device(d_img.as<uint16_t>(), d_out.as<uint16_t>(), add_loss, remove_bad_pixels, low_value_error, high_value_error, std_factor,
-							 low_error, high_error, st))
+				!queue_frame(d_img.as<uint16_t>(), d_out.as<uint16_t>(), add_loss, remove_bad_pixels, low_value_error, high_value_error, std_factor,
+							 d_errs.as<int>(), st) ||
+				!hip_ok(hipMemcpyAsync(e, d_errs.ptr, sizeof(e), hipMemcpyDeviceToHost, st), "D2H"))
 				return false;
-			if (!out)
-				return true; // the caller consumes d_out on the same stream
-			return hip_ok(hipMemcpyAsync(out, d_out.ptr, (size_t)full * 2, hipMemcpyDeviceToHost, st), "D2H") && hip_ok(hipStreamSynchronize(st), "sync");
+			// (when out is NULL the caller consumes d_out on the same stream)
+			if (out && !hip_ok(hipMemcpyAsync(out, d_out.ptr, (size_t)full * 2, hipMemcpyDeviceToHost, st), "D2H"))
+				return false;
+			if (!hip_ok(hipStreamSynchronize(st), "sync"))
+				return false;
+			low_error = e[0], high_error = e[1];
+			return true;
 		}
 
-		// One frame, device to device (d_src and d_dst: full frames, distinct).  The statistics come back to the
-		// host once per frame (56 bytes): the error budget is sequential scalar arithmetic.
+		// One frame, device to device, and its budget back on the host (one 8-byte read-back and a synchronisation).
 		bool step_device(const uint16_t *d_src, uint16_t *d_dst, bool add_loss, bool remove_bad_pixels, int low_value_error, int high_value_error,
 						 double std_factor, int &low_error, int &high_error, hipStream_t st)
+		{
+			int e[2] = {0, 0};
+			if (!queue_frame(d_src, d_dst, add_loss, remove_bad_pixels, low_value_error, high_value_error, std_factor, d_errs.as<int>(), st) ||
+				!hip_ok(hipMemcpyAsync(e, d_errs.ptr, sizeof(e), hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(hipStreamSynchronize(st), "sync"))
+				return false;
+			low_error = e[0], high_error = e[1];
+			return true;
+		}
+
+		// One frame, device to device (d_src and d_dst: full frames, distinct), queued on `st` without waiting: statistics,
+		// error budget (lossy_budget_kernel) and update all run on the device.  d_errors: device int[2] that receives the
+		// frame's low / high error (may be NULL).  Only the very first frame of a subtractMin stream waits (its minimum
+		// becomes a parameter of every later launch).
+		bool queue_frame(const uint16_t *d_src, uint16_t *d_dst, bool add_loss, bool remove_bad_pixels, int low_value_error, int high_value_error,
+						 double std_factor, int *d_errors, hipStream_t st)
 		{
 			const int full = w * h, s = w * hl;
 			const uint16_t *tmp = d_src; // without bad-pixel repair the frame is used as it is
@@ -222,8 +242,6 @@ namespace
 					return false;
 				tmp = fixed;
 			}
-
-			low_error = low_value_error, high_error = high_value_error;
 			if (frames == 0)
 			{
 				if (dev.subtract_min && s > 0)
@@ -236,68 +254,19 @@ namespace
 				}
 				if (!hip_ok(launch_lossy_first(tmp, d_dst, dev, s, full, st), "lossy first"))
 					return false;
+				// the first image is stored as it is: its errors are the configured ones (h264.cpp:2290-2333)
+				if (d_errors && (!hip_ok(hipMemsetD32Async((hipDeviceptr_t)d_errors, low_value_error, 1, st), "errors") ||
+								 !hip_ok(hipMemsetD32Async((hipDeviceptr_t)(d_errors + 1), high_value_error, 1, st), "errors")))
+					return false;
 			}
 			else
 			{
-				long long stats[8];
 				if (!hip_ok(launch_lossy_stats(dev.prevT, tmp, d_src, s, dev.min, dev.subtract_min, d_hist.as<uint32_t>(), d_stats.as<long long>(), st),
 							"lossy stats") ||
-					!hip_ok(hipMemcpyAsync(stats, d_stats.ptr, sizeof(stats), hipMemcpyDeviceToHost, st), "D2H") ||
-					!hip_ok(hipStreamSynchronize(st), "sync"))
-					return false;
-				const unsigned background = (unsigned)stats[0];
-				// stdDev (h264.cpp:1993-2036): sqrt((sum d)^2 - sum d^2) / n, unsplit for the first 40 frames
-				double sd[2];
-				if (n_win < 40)
-				{
-					const double sum_diff = (double)(stats[1] + stats[4]), sum_diff2 = (double)(stats[2] + stats[5]);
-					sd[0] = sd[1] = std::sqrt(sum_diff * sum_diff - sum_diff2) / s;
-				}
-				else
-				{
-					const double fd = (double)stats[1], fd2 = (double)stats[2], bd = (double)stats[4], bd2 = (double)stats[5];
-					sd[0] = std::sqrt(bd * bd - bd2) / (int)stats[6];
-					sd[1] = std::sqrt(fd * fd - fd2) / (int)stats[3];
-				}
-				if (n_first < 1)
-				{
-					first_std[0] = sd[0], first_std[1] = sd[1];
-					n_first = 1;
-				}
-				if (n_win < 40)
-				{
-					win[n_win][0] = sd[0], win[n_win][1] = sd[1];
-					++n_win;
-				}
-				else
-				{
-					std::memmove(win, win + 1, sizeof(double) * 2 * 39);
-					win[39][0] = sd[0], win[39][1] = sd[1];
-				}
-				double mean[2] = {first_std[0], first_std[1]};
-				for (int i = 0; i < n_win; ++i)
-				{
-					mean[0] += win[i][0];
-					mean[1] += win[i][1];
-				}
-				mean[0] /= (double)(n_win + n_first);
-				mean[1] /= (double)(n_win + n_first);
-				if (add_loss)
-				{ // one-sided (h264.cpp:2544-2548)
-					const double dh = sd[1] < mean[1] ? 0 : sd[1] - mean[1], dl = sd[0] < mean[0] ? 0 : sd[0] - mean[0];
-					high_error -= (int)std::round(dh * std_factor);
-					low_error -= (int)std::round(dl * std_factor);
-				}
-				else
-				{ // two-sided (h264.cpp:2366-2367)
-					high_error -= (int)std::round(std::abs(sd[1] - mean[1]) * std_factor);
-					low_error -= (int)std::round(std::abs(sd[0] - mean[0]) * std_factor);
-				}
-				if (high_error < 0)
-					high_error = 0;
-				if (low_error < high_error)
-					low_error = high_error;
-				if (!hip_ok(launch_lossy_update(tmp, d_dst, dev, s, full, background, low_error, high_error, add_loss ? 1 : 0, st), "lossy update"))
+					!hip_ok(launch_lossy_budget(d_stats.as<long long>(), d_budget.as<LossyBudget>(), s, add_loss ? 1 : 0, std_factor, low_value_error,
+												high_value_error, d_decision.as<LossyDecision>(), d_errors, st),
+							"lossy budget") ||
+					!hip_ok(launch_lossy_update(tmp, d_dst, dev, s, full, d_decision.as<LossyDecision>(), add_loss ? 1 : 0, st), "lossy update"))
 					return false;
 				if (dev.running_average > 0)
 				{
@@ -320,6 +289,7 @@ namespace
 		int low = 6, high = 2;
 		double std_factor = 5;
 		bool remove_bad_pixels = false;
+		DeviceBuffer batch_errs; // int[nframes][2] of the last rir_lossy_step_device call
 	};
 
 	// ---- saver -------------------------------------------------------------------------------
@@ -1841,17 +1811,30 @@ RIR_EXPORT int rir_lossy_step_device(int handle, const unsigned short *d_in, uns
 		log_error("rir_lossy_step_device: invalid argument");
 		return -1;
 	}
+	// every frame is queued without waiting (statistics, budget and update all run on the device); the budgets of the batch
+	// come back in one copy at the end - or not at all when the caller does not ask for them: then nothing here waits
 	const size_t npx = (size_t)o->st.w * o->st.h;
+	hipStream_t st = (hipStream_t)stream;
+	const bool want = low_errors || high_errors;
+	if (want && !o->batch_errs.reserve((size_t)nframes * 2 * sizeof(int)))
+		return -1;
 	for (int i = 0; i < nframes; ++i)
-	{
-		int lo = 0, hi = 0;
-		if (!o->st.step_device(d_in + (size_t)i * npx, d_out + (size_t)i * npx, add_loss != 0, o->remove_bad_pixels, o->low, o->high, o->std_factor, lo,
-							   hi, (hipStream_t)stream))
+		if (!o->st.queue_frame(d_in + (size_t)i * npx, d_out + (size_t)i * npx, add_loss != 0, o->remove_bad_pixels, o->low, o->high, o->std_factor,
+							   want ? o->batch_errs.as<int>() + 2 * i : nullptr, st))
 			return -1;
-		if (low_errors)
-			low_errors[i] = lo;
-		if (high_errors)
-			high_errors[i] = hi;
+	if (want)
+	{
+		std::vector<int> e((size_t)nframes * 2);
+		if (!hip_ok(hipMemcpyAsync(e.data(), o->batch_errs.ptr, e.size() * sizeof(int), hipMemcpyDeviceToHost, st), "D2H") ||
+			!hip_ok(hipStreamSynchronize(st), "sync"))
+			return -1;
+		for (int i = 0; i < nframes; ++i)
+		{
+			if (low_errors)
+				low_errors[i] = e[2 * i];
+			if (high_errors)
+				high_errors[i] = e[2 * i + 1];
+		}
 	}
 	return 0;
 }
