@@ -12,7 +12,11 @@ namespace rir
 	__device__ __forceinline__ uint32_t sub_min(uint32_t v, uint32_t mn) { return v < mn ? 0u : v - mn; }
 
 	// L1: histogram of (v >> 2) over 16 384 bins, privatised in LDS (64 KiB), 1024-thread workgroups,
-	// 32 768 pixels per workgroup.
+	// RIR_LOSSY_HIST_PX pixels per workgroup (one frame is a small job: 32 768 pixels per workgroup left it on ten CUs
+	// and took 17 us; the merge only touches the bins a workgroup has filled, a few hundred for thermal images).
+#ifndef RIR_LOSSY_HIST_PX
+#define RIR_LOSSY_HIST_PX 4096
+#endif
 	__global__ __launch_bounds__(1024) void lossy_hist_kernel(const uint16_t *__restrict__ tmp, int s, uint32_t *__restrict__ hist)
 	{
 		__shared__ uint32_t lh[16384];
@@ -20,7 +24,7 @@ namespace rir
 		for (int i = tid; i < 16384; i += 1024)
 			lh[i] = 0;
 		__syncthreads();
-		const int i0 = blockIdx.x * 32768, i1 = min(i0 + 32768, s);
+		const int i0 = blockIdx.x * RIR_LOSSY_HIST_PX, i1 = min(i0 + RIR_LOSSY_HIST_PX, s);
 		for (int i = i0 + tid; i < i1; i += 1024)
 			atomicAdd(&lh[tmp[i] >> 2], 1u);
 		__syncthreads();
@@ -303,7 +307,7 @@ namespace rir
 	hipError_t launch_lossy_stats(const uint16_t *d_prevT, const uint16_t *d_tmp, const uint16_t *d_img, int s, uint32_t mn, int subtract_min,
 								  uint32_t *d_hist, long long *d_stats, hipStream_t st)
 	{
-		hipLaunchKernelGGL(lossy_hist_kernel, dim3((s + 32767) / 32768), dim3(1024), 0, st, d_tmp, s, d_hist);
+		hipLaunchKernelGGL(lossy_hist_kernel, dim3((s + RIR_LOSSY_HIST_PX - 1) / RIR_LOSSY_HIST_PX), dim3(1024), 0, st, d_tmp, s, d_hist);
 		hipLaunchKernelGGL(lossy_mode_kernel, dim3(1), dim3(1024), 0, st, d_hist, d_stats);
 		int blocks = (s + 2047) / 2048; // 8 pixels per thread
 		if (blocks > 256)
