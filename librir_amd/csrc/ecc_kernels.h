@@ -5,10 +5,16 @@
 
 namespace rir
 {
+#ifndef RIR_ECC_BLOCK
+#define RIR_ECC_BLOCK 256
+#endif
+#ifndef RIR_ECC_MAX_BLOCKS
+#define RIR_ECC_MAX_BLOCKS 64 /* the iteration is a chain of short latency-bound phases: fewer, longer waves win (64: 241 us per alignment of 512x640, 256: 285, 16: 395) */
+#endif
 	enum
 	{
 		ECC_NSUMS = 15,
-		ECC_BLOCK = 256
+		ECC_BLOCK = RIR_ECC_BLOCK
 	};
 	// Lives in device memory; one per alignment in flight.
 	struct EccState

@@ -21,7 +21,7 @@ namespace rir
 	static int ecc_blocks(int w, int h)
 	{
 		const int64_t b = ((int64_t)w * h + ECC_BLOCK - 1) / ECC_BLOCK;
-		return (int)(b < 256 ? b : 256);
+		return (int)(b < RIR_ECC_MAX_BLOCKS ? b : RIR_ECC_MAX_BLOCKS);
 	}
 	size_t ecc_workspace_bytes(int w, int h) { return (size_t)ecc_blocks(w, h) * ECC_NSUMS * sizeof(double); }
 
@@ -51,8 +51,12 @@ namespace rir
 	{
 		// zero outside the image (constant border)
 		const bool xa = x0 >= 0 && x0 < w, xb = x0 + 1 >= 0 && x0 + 1 < w, ya = y0 >= 0 && y0 < h, yb = y0 + 1 >= 0 && y0 + 1 < h;
-		const float v00 = (xa && ya) ? p[y0 * w + x0] : 0.f, v01 = (xb && ya) ? p[y0 * w + x0 + 1] : 0.f;
-		const float v10 = (xa && yb) ? p[(y0 + 1) * w + x0] : 0.f, v11 = (xb && yb) ? p[(y0 + 1) * w + x0 + 1] : 0.f;
+		// (every tap is loaded, from an address clamped into the image, and dropped afterwards when it lies outside: a load
+		// under a condition is a branch with its own wait - twelve serial latencies per pixel for the three images)
+		const int xc0 = min(max(x0, 0), w - 1), xc1 = min(max(x0 + 1, 0), w - 1), yc0 = min(max(y0, 0), h - 1), yc1 = min(max(y0 + 1, 0), h - 1);
+		const float l00 = p[yc0 * w + xc0], l01 = p[yc0 * w + xc1], l10 = p[yc1 * w + xc0], l11 = p[yc1 * w + xc1];
+		const float v00 = (xa && ya) ? l00 : 0.f, v01 = (xb && ya) ? l01 : 0.f;
+		const float v10 = (xa && yb) ? l10 : 0.f, v11 = (xb && yb) ? l11 : 0.f;
 		const float top = v00 + fx * (v01 - v00), bot = v10 + fx * (v11 - v10);
 		return top + fy * (bot - top);
 	}
@@ -80,17 +84,18 @@ namespace rir
 			// validity: the nearest source pixel lies inside the image and inside the caller's mask
 			const int nx = (int)rintf(sx), ny = (int)rintf(sy);
 			bool valid = nx >= 0 && nx < w && ny >= 0 && ny < h;
-			if (valid && mask)
-				valid = mask[ny * w + nx] != 0;
+			const uint8_t mv = mask ? mask[min(max(ny, 0), h - 1) * w + min(max(nx, 0), w - 1)] : (uint8_t)1;
+			valid = valid && mv != 0;
+			// (all loads before the test, see bilinear0)
+			const float flx = floorf(sx), fly = floorf(sy);
+			const int x0 = (int)flx, y0 = (int)fly;
+			const float fx = sx - flx, fy = sy - fly;
+			const double I = bilinear0(image, w, h, x0, y0, fx, fy);
+			const double gx = bilinear0(gximg, w, h, x0, y0, fx, fy);
+			const double gy = bilinear0(gyimg, w, h, x0, y0, fx, fy);
+			const double T = templ[i];
 			if (valid)
 			{
-				const float flx = floorf(sx), fly = floorf(sy);
-				const int x0 = (int)flx, y0 = (int)fly;
-				const float fx = sx - flx, fy = sy - fly;
-				const double I = bilinear0(image, w, h, x0, y0, fx, fy);
-				const double gx = bilinear0(gximg, w, h, x0, y0, fx, fy);
-				const double gy = bilinear0(gyimg, w, h, x0, y0, fx, fy);
-				const double T = templ[i];
 				s[0] += 1.0, s[1] += I, s[2] += I * I, s[3] += T, s[4] += T * T, s[5] += T * I;
 				s[6] += gx, s[7] += gy, s[8] += gx * gx, s[9] += gx * gy, s[10] += gy * gy;
 				s[11] += gx * I, s[12] += gy * I, s[13] += gx * T, s[14] += gy * T;

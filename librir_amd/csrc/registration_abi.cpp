@@ -25,6 +25,9 @@ namespace
 		return s;
 	}
 
+#ifndef RIR_ECC_FIRST_BATCH
+#define RIR_ECC_FIRST_BATCH 6 /* alignments of a tracked sequence settle within 4-6 iterations: one read-back of the state instead of two */
+#endif
 	// runs the iterations; the caller holds the scratch mutex
 	int run_ecc(EccScratch &sc, const float *d_templ, const float *d_image, const uint8_t *d_mask, int w, int h, float *warp, int max_iter,
 				double eps, double *cc, int *iterations, hipStream_t st)
@@ -44,7 +47,7 @@ namespace
 		int launched = 0;
 		while (true)
 		{
-			const int batch = std::min(launched == 0 ? 4 : 8, max_iter - launched); // most alignments of a tracked sequence settle within 4
+			const int batch = std::min(launched == 0 ? RIR_ECC_FIRST_BATCH : 8, max_iter - launched);
 			for (int i = 0; i < batch; ++i)
 				if (!hip_ok(launch_ecc_iterate(d_templ, d_image, sc.gx.as<float>(), sc.gy.as<float>(), d_mask, w, h, sc.partials.as<double>(),
 											   d_state, st),
