@@ -576,6 +576,7 @@ namespace rir
 															   const float *__restrict__ kern)
 	{
 		constexpr int TY = RIR_GAUSS_TY, HY = TY / 2, KW = 2 * R + 1, OUTW = 64 - 2 * R, NR = TY + 2 * R;
+		static_assert(TY % 2 == 0, "rows are processed in pairs (packed FMAs)");
 		const int lane = threadIdx.x & 63;
 		const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 		// XCD-aware tile order (xcd_major), then (frame, column strip, row band) with the row band fastest:
@@ -980,6 +981,7 @@ namespace rir
 															   int per_frame_offsets, int strategy, uint32_t background)
 	{
 		constexpr int TY = RIR_CHAIN_TY, KW = 2 * R + 1, OUTW = 64 - 2 * R, OW = OUTW - 2, OH = TY - 2, NR = TY + 2 * R;
+		static_assert(TY % 2 == 0 && (R != 1 || OW % 4 == 0), "rows in pairs (packed FMAs); 4-pixel output pieces in the register path");
 		__shared__ float tile[4][TY][64];
 		const int lane = threadIdx.x & 63;
 		const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
