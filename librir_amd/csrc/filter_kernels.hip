@@ -177,45 +177,6 @@ namespace rir
 		return true;
 	}
 
-	// N consecutive 16-bit elements from an address of any 2-byte alignment: a few dword loads per row (instead of one
-	// scalar load per element - the texture unit's address rate is what bounds such gathers) and a byte alignment.
-	template <class T, int N>
-	__device__ __forceinline__ void load_taps(const T *__restrict__ p, T (&out)[N])
-	{
-		if constexpr (sizeof(T) == 2)
-		{
-			constexpr int NW = (N + 2) / 2; // dwords covering N elements from an even or an odd element index
-			const uint32_t a = (uint32_t)(((uintptr_t)p) >> 1) & 1u;
-			const uint32_t *q = reinterpret_cast<const uint32_t *>(p - a);
-			uint32_t d[NW + 1];
-#pragma unroll
-			for (int i = 0; i < NW; ++i)
-				d[i] = q[i];
-			d[NW] = 0;
-#pragma unroll
-			for (int i = 0; i < NW; ++i)
-				d[i] = a ? __builtin_amdgcn_alignbyte(d[i + 1], d[i], 2) : d[i];
-#pragma unroll
-			for (int j = 0; j < N; ++j)
-			{
-				const uint16_t e = (uint16_t)(d[j >> 1] >> (16 * (j & 1)));
-				out[j] = __builtin_bit_cast(T, e);
-			}
-		}
-		else
-		{
-#pragma unroll
-			for (int j = 0; j < N; ++j)
-				out[j] = p[j];
-		}
-	}
-
-	template <class U, int VEC>
-	struct alignas(sizeof(U) * VEC) PixVec
-	{
-		U v[VEC];
-	};
-
 	// ---- translate, one wave per tile --------------------------------------------------------------------------
 	// A kernel that gives every lane a run of 8 output pixels (the first version) spends ~46 vector instructions per pixel, nearly all of them the reference's
 	// double-precision blend and the conversions around it: it is bound by the VALU at a third of the memory rate.
@@ -366,7 +327,17 @@ namespace rir
 						const double cr = r_is_l ? cl : cs;
 						const U res = CastTo<U>::from(cl * u1 + cr * u);
 						if (act_x && j < nrows)
-							o[(int64_t)j * w] = res;
+						{
+							// streaming stores for 1- and 2-byte pixels (0.099 -> 0.084 ms per 256 uint16 frames: the partial
+							// lines of the 63-pixel rows leave L2 early instead of waiting for their neighbours); for 4-byte
+							// pixels the same policy costs 30 % - their rows fill whole lines - and the plain store stays
+							if constexpr (sizeof(U) == 1)
+								__builtin_nontemporal_store(__builtin_bit_cast(uint8_t, res), reinterpret_cast<uint8_t *>(o + (int64_t)j * w));
+							else if constexpr (sizeof(U) == 2)
+								__builtin_nontemporal_store(__builtin_bit_cast(uint16_t, res), reinterpret_cast<uint16_t *>(o + (int64_t)j * w));
+							else
+								o[(int64_t)j * w] = res;
+						}
 					}
 				}
 				else
@@ -1745,67 +1716,123 @@ namespace rir
 		return (uint16_t)med3(max(max(lo[0], lo[1]), lo[2]), med3(mi[0], mi[1], mi[2]), min(min(hi[0], hi[1]), hi[2]));
 	}
 
-	// 8 consecutive outputs per thread.  Interior chunks fetch their 3 x 10 window with dword loads, sort every
-	// column once (min / median / max of 3) and share the sorted columns between neighbouring outputs:
-	// median of 9 = med3(max of the column minima, median of the column medians, min of the column maxima).
+	// One wave per tile of 60 x TY outputs, lane per column (as translate / gaussian_filter): lane i loads column x0 - 1 + i
+	// for the TY + 2 rows under the tile (raw-buffer loads, one per row), sorts its column triple of every output row once
+	// (min / median / max of 3) and takes the sorted triples of the two neighbouring columns from lanes i - 1 and i + 1 by
+	// DPP wave shifts: median of 9 = med3(max of the column minima, median of the column medians, min of the column
+	// maxima) - 11 vector instructions per pixel.  Pixels on the image border (median of 3 along the edge, min of 2 in the
+	// corners) take median3x3_px.  XCD-major tile order with x fastest (60-pixel rows are not line-aligned).
+	// (The first version - 8 consecutive outputs per thread, 3 x 10 windows fetched with dword loads - was bound by its
+	// instruction count at 0.134 ms per 256 frames 640x512.)
+#ifndef RIR_MEDIAN_TY
+#define RIR_MEDIAN_TY 16
+#endif
+	__device__ __forceinline__ uint32_t wave_shl1_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
+	__device__ __forceinline__ uint32_t wave_shr1_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
+
 	__global__ __launch_bounds__(256) void median3x3_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w, int h)
 	{
-		constexpr int VEC = 8;
-		const int cpr = (w + VEC - 1) / VEC;
-		const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-		const bool valid = idx < (int64_t)cpr * h;
-		const int y = valid ? (int)(idx / cpr) : 0;
-		const int x0 = valid ? (int)(idx - (int64_t)y * cpr) * VEC : 0;
-		const int64_t fbase = (int64_t)blockIdx.y * w * h;
-		const uint16_t *s = src + fbase;
-		uint16_t *d = dst + fbase + (int64_t)y * w + x0;
-		bool done = !valid;
-		if (valid && y >= 1 && y < h - 1 && x0 >= 1 && x0 + VEC + 3 <= w && (((uintptr_t)d) & 15) == 0)
-		{
-			uint16_t r0[VEC + 2], r1[VEC + 2], r2[VEC + 2];
-			load_taps<uint16_t, VEC + 2>(s + (int64_t)(y - 1) * w + x0 - 1, r0);
-			load_taps<uint16_t, VEC + 2>(s + (int64_t)y * w + x0 - 1, r1);
-			load_taps<uint16_t, VEC + 2>(s + (int64_t)(y + 1) * w + x0 - 1, r2);
-			uint32_t lo[VEC + 2], mi[VEC + 2], hi[VEC + 2];
-#pragma unroll
-			for (int j = 0; j < VEC + 2; ++j)
-			{
-				const uint32_t a = r0[j], b = r1[j], c = r2[j];
-				lo[j] = min(min(a, b), c);
-				hi[j] = max(max(a, b), c);
-				mi[j] = med3(a, b, c);
-			}
-			PixVec<uint16_t, VEC> o;
-#pragma unroll
-			for (int k = 0; k < VEC; ++k)
-				o.v[k] = (uint16_t)med3(max(max(lo[k], lo[k + 1]), lo[k + 2]), med3(mi[k], mi[k + 1], mi[k + 2]), min(min(hi[k], hi[k + 1]), hi[k + 2]));
-			*reinterpret_cast<PixVec<uint16_t, VEC> *>(d) = o;
-			done = true;
-		}
-		// border chunks (row ends, first / last rows): wave-cooperative when there are few of them, see translate_kernel
+		constexpr int TY = RIR_MEDIAN_TY, OW = 60; // (62 outputs fit a wave; 60 keeps the tiles 8-byte aligned for the stores)
+		__shared__ uint16_t strip[4][TY][64];
 		const int lane = threadIdx.x & 63;
-		uint64_t todo = __ballot(!done);
-		if (__builtin_popcountll(todo) >= VEC)
+		const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+		int bx, by, n;
 		{
-			if (!done)
-				for (int k = 0; k < VEC && x0 + k < w; ++k)
-					d[k] = median3x3_px(s, w, h, x0 + k, y);
-			return;
+			const unsigned gx = gridDim.x, gy = gridDim.y;
+			const unsigned id2 = xcd_major(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+			bx = (int)(id2 % gx);
+			by = (int)((id2 / gx) % gy);
+			n = (int)(id2 / (gx * gy));
 		}
-		while (todo)
+		const int x0 = bx * OW, y0 = (by * 4 + wv) * TY;
+		if (y0 >= h)
+			return;
+		const int64_t fbase = (int64_t)n * w * h;
+		const uint16_t *s = src + fbase;
+		uint16_t *d = dst + fbase;
+		const int x = x0 - 1 + lane; // this lane's column
+		const bool xin = x >= 0 && x < w;
+		uint32_t v[TY + 2];
+		if ((int64_t)w * h < (1 << 30))
+		{ // pixels outside the image read as 0 through the buffer's range check (they are never used by an interior output)
+			const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)s);
+			const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)s >> 32));
+			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, w * h * 2, 0x00020000);
+			const uint32_t step = (uint32_t)w * 2u;
+			if (x0 - 1 >= 0 && x0 + 62 < w && y0 - 1 >= 0 && y0 + TY < h)
+			{ // block inside the image: the row steps on the scalar side (the scalar offset is not range-checked)
+				const uint32_t off = (uint32_t)(((y0 - 1) * w + x) * 2);
+#pragma unroll
+				for (int i = 0; i < TY + 2; ++i)
+					v[i] = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, (int)((uint32_t)i * step), 0);
+			}
+			else
+			{
+				uint32_t off = xin ? (uint32_t)(((y0 - 1) * w + x) * 2) : 0x80000000u;
+#pragma unroll
+				for (int i = 0; i < TY + 2; ++i)
+				{
+					v[i] = __builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, 0, 0);
+					off += step;
+				}
+			}
+		}
+		else
 		{
-			const int src_lane = __builtin_ctzll(todo);
-			todo &= todo - 1;
-			const int cx = __shfl(x0, src_lane, 64) + lane, cy = __shfl(y, src_lane, 64);
-			if (lane < VEC && cx < w)
-				dst[fbase + (int64_t)cy * w + cx] = median3x3_px(s, w, h, cx, cy);
+			const uint16_t *col = s + min(max(x, 0), w - 1);
+#pragma unroll
+			for (int i = 0; i < TY + 2; ++i)
+				v[i] = col[(int64_t)min(max(y0 - 1 + i, 0), h - 1) * w];
+		}
+		const bool out_lane = lane >= 1 && lane <= OW && x < w;
+		const bool x_interior = x >= 1 && x < w - 1;
+		const bool wide = (w & 3) == 0 && (int64_t)w * h < (1 << 30);
+#pragma unroll
+		for (int j = 0; j < TY; ++j)
+		{
+			const int y = y0 + j;
+			// (all 64 lanes take part in the shifts; rows past the image are computed and not stored)
+			const uint32_t a = v[j], b = v[j + 1], c = v[j + 2];
+			const uint32_t lo = min(min(a, b), c), hi = max(max(a, b), c), mi = med3(a, b, c);
+			const uint32_t m_lo = max(max(lo, wave_shr1_u32(lo)), wave_shl1_u32(lo));
+			const uint32_t m_hi = min(min(hi, wave_shr1_u32(hi)), wave_shl1_u32(hi));
+			const uint32_t m_mi = med3(wave_shr1_u32(mi), mi, wave_shl1_u32(mi));
+			uint32_t res = med3(m_lo, m_mi, m_hi);
+			if (out_lane && y < h && !(x_interior && y >= 1 && y < h - 1))
+				res = median3x3_px(s, w, h, x, y);
+			if (wide)
+				strip[wv][j][(lane - 1) & 63] = (uint16_t)res; // strip column = output column - x0
+			else if (out_lane && y < h)
+				d[(int64_t)y * w + x] = (uint16_t)res;
+		}
+		if (wide)
+		{ // rows of 8-byte aligned width: the tile leaves in 4-pixel pieces through the wave's LDS strip, with the streaming
+		  // policy (0.112 -> 0.090 ms per 256 frames; 2-byte stores with the same policy: 0.098)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			const uint64_t db = (uint64_t)d;
+			const uint32_t dlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)db);
+			const uint32_t dhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(db >> 32));
+			const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)dhi << 32) | dlo), 0, w * h * 2, 0x00020000);
+			constexpr int PPR = OW / 4;
+#pragma unroll
+			for (int q = 0; q < (PPR * TY + 63) / 64; ++q)
+			{
+				const int c = q * 64 + lane;
+				const int row = c / PPR, k = c - row * PPR;
+				const int ox = x0 + 4 * k, oy = y0 + row;
+				const v2u32 px4 = *reinterpret_cast<const v2u32 *>(&strip[wv][row < TY ? row : 0][4 * k]);
+				const bool st = c < PPR * TY && ox < w && oy < h;
+				__builtin_amdgcn_raw_buffer_store_b64(px4, rd, (int)(st ? (uint32_t)((oy * w + ox) * 2) : 0x80000000u), 0, 2);
+			}
 		}
 	}
 
 	hipError_t launch_median3x3(const uint16_t *src, uint16_t *dst, int w, int h, int nframes, hipStream_t st)
 	{
-		const int64_t chunks = (int64_t)((w + 7) / 8) * h;
-		hipLaunchKernelGGL(median3x3_kernel, dim3((unsigned)((chunks + 255) / 256), nframes), dim3(256), 0, st, src, dst, w, h);
+		dim3 block(256), grid((unsigned)((w + 59) / 60), (unsigned)((h + 4 * RIR_MEDIAN_TY - 1) / (4 * RIR_MEDIAN_TY)), nframes);
+		hipLaunchKernelGGL(median3x3_kernel, grid, block, 0, st, src, dst, w, h);
 		return hipGetLastError();
 	}
 
