@@ -328,15 +328,10 @@ namespace rir
 						const U res = CastTo<U>::from(cl * u1 + cr * u);
 						if (act_x && j < nrows)
 						{
-							// streaming stores for 1- and 2-byte pixels (0.099 -> 0.084 ms per 256 uint16 frames: the partial
-							// lines of the 63-pixel rows leave L2 early instead of waiting for their neighbours); for 4-byte
-							// pixels the same policy costs 30 % - their rows fill whole lines - and the plain store stays
-							if constexpr (sizeof(U) == 1)
-								__builtin_nontemporal_store(__builtin_bit_cast(uint8_t, res), reinterpret_cast<uint8_t *>(o + (int64_t)j * w));
-							else if constexpr (sizeof(U) == 2)
-								__builtin_nontemporal_store(__builtin_bit_cast(uint16_t, res), reinterpret_cast<uint16_t *>(o + (int64_t)j * w));
-							else
-								o[(int64_t)j * w] = res;
+							// (plain stores: the streaming policy makes this kernel faster on its own - 0.099 -> 0.084 ms per 256
+							// uint16 frames - but the frames are what the next kernel reads, and an encoder that finds them in the
+							// Infinity Cache gains four times what the policy saves here)
+							o[(int64_t)j * w] = res;
 						}
 					}
 				}
@@ -858,6 +853,9 @@ namespace rir
 	// to the three-kernel chain.  Strategies whose border pixels are not local to the tile (wrap, noborder) are not
 	// offered; a tap outside the wave's block (possible only through float rounding of px + 1) is recomputed from
 	// global memory by chain_gauss_point.
+#ifndef RIR_CHAIN_STORE_AUX
+#define RIR_CHAIN_STORE_AUX 2
+#endif
 #ifndef RIR_CHAIN_TY
 #define RIR_CHAIN_TY 16 /* rows of the gaussian block per wave; OH = TY - 2 output rows */
 #endif
@@ -1169,7 +1167,7 @@ namespace rir
 #pragma unroll
 					for (int j = 0; j < OH; ++j)
 						__builtin_amdgcn_raw_buffer_store_b16(res[j], rd,
-															  (int)((act_x && y0 + j < h) ? (uint32_t)((y0 * w + x) * 2) + (uint32_t)j * dstep : 0x80000000u), 0, 2);
+															  (int)((act_x && y0 + j < h) ? (uint32_t)((y0 * w + x) * 2) + (uint32_t)j * dstep : 0x80000000u), 0, RIR_CHAIN_STORE_AUX);
 				}
 				else
 				{
@@ -1188,7 +1186,7 @@ namespace rir
 						const int ox = x0 + 4 * k, oy = y0 + row; // x0 and w are multiples of 4: a piece is inside the row or outside, never across
 						const v2u32 px4 = *reinterpret_cast<const v2u32 *>(ot + (row < OH ? row : 0) * 64 + 4 * k);
 						const bool st = c < PPR * OH && ox < w && oy < h;
-						__builtin_amdgcn_raw_buffer_store_b64(px4, rd, (int)(st ? (uint32_t)((oy * w + ox) * 2) : 0x80000000u), 0, 2);
+						__builtin_amdgcn_raw_buffer_store_b64(px4, rd, (int)(st ? (uint32_t)((oy * w + ox) * 2) : 0x80000000u), 0, RIR_CHAIN_STORE_AUX);
 					}
 				}
 				return;
