@@ -1120,7 +1120,8 @@ namespace rir
 			const float vvj = (float)bj - pyj;
 			const float vv0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vvj))); // row 0 (y0 < h)
 			row_ok = row_ok && (!act_y || __builtin_bit_cast(int, vvj) == __builtin_bit_cast(int, vv0)); // one vertical weight for the tile
-			const bool interior = gx0 >= R && gx0 + OUTW - 1 < w - R && gy0 >= R && gy0 + TY - 1 < h - R;
+			// (frames of 2 GiB and more do not fit a buffer descriptor: they take the general path)
+			const bool interior = gx0 >= R && gx0 + OUTW - 1 < w - R && gy0 >= R && gy0 + TY - 1 < h - R && (int64_t)w * h < (1 << 30);
 			if (interior && __ballot(!(row_ok && col_ok)) == 0)
 			{
 				auto shl1 = [](float f) -> float
