@@ -89,7 +89,8 @@ extern "C"
 	 * instead of 14.  Output bit-identical to rir_bad_pixels_correct_device + rir_gaussian_filter_u16_device +
 	 * rir_translate_f32_u16_device.  bad_pixels_handle: from rir_bad_pixels_create_device, or 0 to skip that stage.
 	 * strategy "nearest" or "background"/"constant" (background: HOST pointer to one uint16); sigma < 2.5;
-	 * d_src != d_dst; offsets as for rir_translate_device. */
+	 * d_src != d_dst; offsets as for rir_translate_device.  The repair table lives in the bad-pixels object: one call at a
+	 * time per handle. */
 	int rir_filter_chain_device(int bad_pixels_handle, const unsigned short *d_src, unsigned short *d_dst, int w, int h, int nframes, float sigma,
 								const float *d_offsets, int per_frame_offsets, const void *background, const char *strategy, void *stream);
 
