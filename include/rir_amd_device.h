@@ -151,6 +151,13 @@ extern "C"
 	/* (im - min) / (max - min) in float32 on a w x h window of a device image with row stride src_stride (the
 	 * normalisation of masked_registration_ecc.py:162-166, crop folded in); d_dst dense [h][w]. */
 	int rir_minmax_normalize_device(const float *d_src, int w, int h, int src_stride, float *d_dst, void *stream);
+	/* One frame of a tracked sequence in one call - the steps of MaskedRegistratorECC.compute (masked_registration_ecc.py:88-168):
+	 * gaussian pre-filter (sigma > 0), min-max normalisation of the registration window and the alignment against the
+	 * already normalised reference window d_ref_norm [win_h][win_w], queued back to back with one read-back at the end.
+	 * d_img: uint16 (dtype 'H') or float32 ('f') frame [h][w]. */
+	int rir_ecc_register_frame_device(const void *d_img, int dtype, int w, int h, float sigma, int win_x, int win_y, int win_w, int win_h,
+									  const float *d_ref_norm, float *warp, int max_iterations, double eps, double *cc, int *iterations,
+									  void *stream);
 	int find_transform_ecc_translation(const float *templ, const float *image, const unsigned char *mask, int w, int h, float *warp,
 									   int max_iterations, double eps, double *cc);
 

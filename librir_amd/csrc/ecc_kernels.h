@@ -9,12 +9,13 @@ namespace rir
 #define RIR_ECC_BLOCK 256
 #endif
 #ifndef RIR_ECC_MAX_BLOCKS
-#define RIR_ECC_MAX_BLOCKS 64 /* the iteration is a chain of short latency-bound phases: fewer, longer waves win (64: 241 us per alignment of 512x640, 256: 285, 16: 395) */
+#define RIR_ECC_MAX_BLOCKS 256
 #endif
 	enum
 	{
 		ECC_NSUMS = 15,
-		ECC_BLOCK = RIR_ECC_BLOCK
+		ECC_BLOCK = RIR_ECC_BLOCK,
+		ECC_SOLVE_BLOCK = 256
 	};
 	// Lives in device memory; one per alignment in flight.
 	struct EccState
@@ -27,11 +28,22 @@ namespace rir
 		int max_iter;
 		double eps;
 	};
+	// What the host needs of the state, in page-locked host memory the device writes directly (coherent): the host polls
+	// `iter` / `done` instead of queueing a copy and waiting for the stream - a stream wait costs ~50 us of wake-up latency
+	// per frame, the poll a few.
+	struct EccHostView
+	{
+		float tx, ty;
+		double rho;
+		volatile int iter; // iterations finished (written after the fields above)
+		volatile int done; // as EccState::done
+	};
 	size_t ecc_workspace_bytes(int w, int h);
 	hipError_t launch_ecc_prepare(const float *d_image, int w, int h, float *d_gx, float *d_gy, EccState *d_state, float tx, float ty, int max_iter,
 								  double eps, hipStream_t st);
 	// one iteration (no-op once d_state->done != 0)
+	// host_view: device-visible address of an EccHostView, or NULL
 	hipError_t launch_ecc_iterate(const float *d_templ, const float *d_image, const float *d_gx, const float *d_gy, const uint8_t *d_mask, int w,
-								  int h, double *d_partials, EccState *d_state, hipStream_t st);
+								  int h, double *d_partials, EccState *d_state, EccHostView *host_view, hipStream_t st);
 	hipError_t launch_minmax_normalize(const float *d_src, int w, int h, int src_stride, float *d_dst, float *d_part, hipStream_t st);
 } // namespace rir

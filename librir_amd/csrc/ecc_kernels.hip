@@ -11,9 +11,9 @@
 // validity mask sampled at the nearest pixel, zero-mean correlation under that mask, 2x2 normal equations.
 // The arithmetic is HBM/L2-bound reductions (15 sums per iteration), not a GEMM: no MFMA.
 //
-// One launch per iteration; blocks write their partial sums, the last block to finish adds them in a fixed
-// order (deterministic), solves the 2x2 system and updates the state in device memory, so iterations queue
-// back to back without a host round trip.
+// Two launches per iteration: workgroups write their partial sums, one workgroup adds them in a fixed order
+// (deterministic), solves the 2x2 system and updates the state in device memory, so iterations queue back to back
+// without a host round trip; the host follows the state through a few words of coherent host memory.
 #include "ecc_kernels.h"
 
 namespace rir
@@ -61,22 +61,25 @@ namespace rir
 		return top + fy * (bot - top);
 	}
 
-	__global__ __launch_bounds__(ECC_BLOCK) void ecc_iterate_kernel(const float *__restrict__ templ, const float *__restrict__ image,
-																	const float *__restrict__ gximg, const float *__restrict__ gyimg,
-																	const uint8_t *__restrict__ mask, int w, int h, double *__restrict__ partials,
-																	EccState *__restrict__ state)
+	// One iteration = two launches.  ecc_sums_kernel: up to 1 024 workgroups, every thread a pixel or two, each workgroup
+	// leaves one row of 15 partial sums (fixed butterfly inside the wave, waves in order).  ecc_solve_kernel: one
+	// workgroup adds the rows in a fixed tree (deterministic), solves the 2x2 system and updates the state in device memory.
+	// (As ONE kernel whose last workgroup - found through a ticket atomic - did the second half, the iteration was a chain of
+	// short latency-bound phases on few workgroups: 32 us at 512x640 whatever the grid; split, 11 us.)
+	__global__ __launch_bounds__(ECC_BLOCK) void ecc_sums_kernel(const float *__restrict__ templ, const float *__restrict__ image,
+																 const float *__restrict__ gximg, const float *__restrict__ gyimg,
+																 const uint8_t *__restrict__ mask, int w, int h, double *__restrict__ partials,
+																 const EccState *__restrict__ state)
 	{
 		if (state->done)
 			return;
 		__shared__ double red[ECC_BLOCK / 64][ECC_NSUMS];
-		__shared__ bool last;
 		const float tx = state->tx, ty = state->ty;
 		double s[ECC_NSUMS];
 #pragma unroll
 		for (int k = 0; k < ECC_NSUMS; ++k)
 			s[k] = 0.0;
-		// grid-stride over the pixels: a few hundred workgroups whatever the image size (one ticket atomic and one
-		// row of partials per workgroup - 1 280 of them on one address cost ~60 us per iteration at 512x640)
+		// grid-stride over the pixels (at most RIR_ECC_MAX_BLOCKS workgroups: one row of partials each)
 		for (int i = blockIdx.x * ECC_BLOCK + threadIdx.x; i < w * h; i += gridDim.x * ECC_BLOCK)
 		{
 			const int y = i / w, x = i - y * w;
@@ -101,7 +104,7 @@ namespace rir
 				s[11] += gx * I, s[12] += gy * I, s[13] += gx * T, s[14] += gy * T;
 			}
 		}
-		// wave reduction (fixed butterfly), then the four waves of the block in order
+		// wave reduction (fixed butterfly), then the waves of the block in order
 #pragma unroll
 		for (int k = 0; k < ECC_NSUMS; ++k)
 		{
@@ -120,28 +123,25 @@ namespace rir
 				v += red[wv][threadIdx.x];
 			partials[(size_t)blockIdx.x * ECC_NSUMS + threadIdx.x] = v;
 		}
-		__threadfence();
-		__syncthreads();
-		if (threadIdx.x == 0)
-			last = atomicAdd(&state->ticket, 1u) == gridDim.x - 1;
-		__syncthreads();
-		if (!last)
+	}
+
+	__global__ __launch_bounds__(ECC_SOLVE_BLOCK) void ecc_solve_kernel(const double *__restrict__ partials, int nrows, EccState *__restrict__ state,
+																		EccHostView *host_view)
+	{
+		if (state->done)
 			return;
-		// ---- last block: total of the partials (fixed tree: thread t takes blocks t, t+256, ...; then the same
-		// butterfly / wave order as above - deterministic), then the 2x2 solve.  (A single thread per sum walking all
-		// the partials cost ~0.6 ms per iteration at 512x640: 1 280 dependent loads.) ----
-		__threadfence();
+		__shared__ double red[ECC_SOLVE_BLOCK / 64][ECC_NSUMS];
 		__shared__ double tot[ECC_NSUMS];
-		{
+		{ // thread t takes rows t, t + ECC_SOLVE_BLOCK, ...; then the butterfly and the waves in order
 			double acc[ECC_NSUMS];
 #pragma unroll
 			for (int k = 0; k < ECC_NSUMS; ++k)
 				acc[k] = 0.0;
-			for (unsigned b = threadIdx.x; b < gridDim.x; b += ECC_BLOCK)
+			for (int b = threadIdx.x; b < nrows; b += ECC_SOLVE_BLOCK)
 			{
 #pragma unroll
 				for (int k = 0; k < ECC_NSUMS; ++k)
-					acc[k] += __builtin_nontemporal_load(partials + (size_t)b * ECC_NSUMS + k);
+					acc[k] += partials[(size_t)b * ECC_NSUMS + k];
 			}
 #pragma unroll
 			for (int k = 0; k < ECC_NSUMS; ++k)
@@ -157,7 +157,7 @@ namespace rir
 			if (threadIdx.x < ECC_NSUMS)
 			{
 				double v = red[0][threadIdx.x];
-				for (int wv = 1; wv < ECC_BLOCK / 64; ++wv)
+				for (int wv = 1; wv < ECC_SOLVE_BLOCK / 64; ++wv)
 					v += red[wv][threadIdx.x];
 				tot[threadIdx.x] = v;
 			}
@@ -165,7 +165,6 @@ namespace rir
 		__syncthreads();
 		if (threadIdx.x != 0)
 			return;
-		state->ticket = 0;
 		const double n = tot[0];
 		int done = 0;
 		double rho = -1.0;
@@ -209,6 +208,15 @@ namespace rir
 			done = 1;
 		__threadfence();
 		state->done = done;
+		if (host_view)
+		{ // results first, then (release, system scope) the two words the host polls
+			host_view->tx = state->tx;
+			host_view->ty = state->ty;
+			host_view->rho = rho;
+			__threadfence_system();
+			__hip_atomic_store(const_cast<int *>(&host_view->done), done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(const_cast<int *>(&host_view->iter), it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
 	}
 
 	hipError_t launch_ecc_prepare(const float *d_image, int w, int h, float *d_gx, float *d_gy, EccState *d_state, float tx, float ty, int max_iter,
@@ -220,10 +228,11 @@ namespace rir
 	}
 
 	hipError_t launch_ecc_iterate(const float *d_templ, const float *d_image, const float *d_gx, const float *d_gy, const uint8_t *d_mask, int w,
-								  int h, double *d_partials, EccState *d_state, hipStream_t st)
+								  int h, double *d_partials, EccState *d_state, EccHostView *host_view, hipStream_t st)
 	{
-		hipLaunchKernelGGL(ecc_iterate_kernel, dim3(ecc_blocks(w, h)), dim3(ECC_BLOCK), 0, st, d_templ, d_image, d_gx, d_gy,
-						   d_mask, w, h, d_partials, d_state);
+		const int nblk = ecc_blocks(w, h);
+		hipLaunchKernelGGL(ecc_sums_kernel, dim3(nblk), dim3(ECC_BLOCK), 0, st, d_templ, d_image, d_gx, d_gy, d_mask, w, h, d_partials, d_state);
+		hipLaunchKernelGGL(ecc_solve_kernel, dim3(1), dim3(ECC_SOLVE_BLOCK), 0, st, d_partials, nblk, d_state, host_view);
 		return hipGetLastError();
 	}
 } // namespace rir

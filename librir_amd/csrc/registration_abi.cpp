@@ -3,10 +3,13 @@
 // The reference computes sub-pixel translations in Python by calling OpenCV
 // (src/python/librir/registration/masked_registration_ecc.py:166-168, cv2.findTransformECC with
 // MOTION_TRANSLATION); these two entry points are what that call binds to here.
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
 #include "ecc_kernels.h"
+#include "filter_kernels.h"
 #include "rir_amd_device.h"
 #include "runtime.h"
 
@@ -17,7 +20,9 @@ namespace
 	struct EccScratch
 	{
 		std::mutex mu;
-		DeviceBuffer gx, gy, partials, state, templ, image, mask, mm;
+		DeviceBuffer gx, gy, partials, state, templ, image, mask, mm, full;
+		EccHostView *view = nullptr; // coherent page-locked host memory (64 bytes, kept for the life of the process), written by
+									  // ecc_solve_kernel, polled by run_ecc
 	};
 	EccScratch &scratch()
 	{
@@ -40,22 +45,42 @@ namespace
 		if (!hip_ok(launch_ecc_prepare(d_image, w, h, sc.gx.as<float>(), sc.gy.as<float>(), d_state, warp[0], warp[1], max_iter, eps, st),
 					"ecc prepare"))
 			return -1;
+		if (!sc.view && !hip_ok(hipHostMalloc(reinterpret_cast<void **>(&sc.view), sizeof(EccHostView), hipHostMallocCoherent | hipHostMallocMapped),
+								"hipHostMalloc"))
+			return -1;
+		EccHostView *view = sc.view;
+		view->iter = 0, view->done = 0; // (host writes before the launches below: ordered by the submission)
+		EccHostView *d_view = nullptr;
+		if (!hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&d_view), view, 0), "hipHostGetDevicePointer"))
+			return -1;
+		// iterations are queued in batches (a finished alignment turns the remaining launches into no-ops); the host
+		// polls the view until the alignment is done or the batch is through
 		EccState hs;
 		std::memset(&hs, 0, sizeof(hs));
-		// iterations are queued in batches (a finished alignment turns the remaining launches into no-ops);
-		// the state comes back once per batch
 		int launched = 0;
 		while (true)
 		{
 			const int batch = std::min(launched == 0 ? RIR_ECC_FIRST_BATCH : 8, max_iter - launched);
 			for (int i = 0; i < batch; ++i)
 				if (!hip_ok(launch_ecc_iterate(d_templ, d_image, sc.gx.as<float>(), sc.gy.as<float>(), d_mask, w, h, sc.partials.as<double>(),
-											   d_state, st),
+											   d_state, d_view, st),
 							"ecc iterate"))
 					return -1;
 			launched += batch;
-			if (!hip_ok(hipMemcpyAsync(&hs, d_state, sizeof(hs), hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(hipStreamSynchronize(st), "sync"))
-				return -1;
+			const auto t0 = std::chrono::steady_clock::now();
+			long spins = 0;
+			while (view->done == 0 && view->iter < launched)
+			{
+				if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
+				{ // (a device fault would leave the words unwritten)
+					log_error("ECC: the device did not report back");
+					(void)hipStreamSynchronize(st);
+					return -1;
+				}
+				__builtin_ia32_pause();
+			}
+			std::atomic_thread_fence(std::memory_order_acquire);
+			hs.done = view->done, hs.iter = view->iter, hs.tx = view->tx, hs.ty = view->ty, hs.rho = view->rho;
 			if (hs.done || launched >= max_iter)
 				break;
 		}
@@ -88,6 +113,50 @@ RIR_EXPORT int rir_ecc_translation_device(const float *d_templ, const float *d_i
 	EccScratch &sc = scratch();
 	std::lock_guard<std::mutex> lock(sc.mu);
 	return run_ecc(sc, d_templ, d_image, d_mask, w, h, warp, max_iterations, eps, cc, iterations, (hipStream_t)stream);
+}
+
+// One frame of a tracked sequence, from the raw frame to the shift, in one call: gaussian pre-filter (sigma > 0), min-max
+// normalisation of the registration window [win_y, win_y + win_h) x [win_x, win_x + win_w) and the alignment against the
+// (already normalised) reference window d_ref_norm [win_h][win_w] - the steps of MaskedRegistratorECC.compute
+// (masked_registration_ecc.py:88-168) queued back to back, with one read-back at the end.  d_img: uint16 (dtype 'H') or
+// float32 ('f') frame [h][w] in device memory.  warp: HOST float[2] (tx, ty), start value in, result out.
+RIR_EXPORT int rir_ecc_register_frame_device(const void *d_img, int dtype, int w, int h, float sigma, int win_x, int win_y, int win_w, int win_h,
+											 const float *d_ref_norm, float *warp, int max_iterations, double eps, double *cc, int *iterations,
+											 void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (!d_img || (dtype != 'H' && dtype != 'f') || !d_ref_norm || !warp || w < 2 || h < 2 || win_x < 0 || win_y < 0 || win_w < 2 || win_h < 2 ||
+		win_x + win_w > w || win_y + win_h > h || max_iterations <= 0 || !(eps >= 0))
+	{
+		log_error("rir_ecc_register_frame_device: invalid argument");
+		return -1;
+	}
+	hipStream_t st = (hipStream_t)stream;
+	EccScratch &sc = scratch();
+	std::lock_guard<std::mutex> lock(sc.mu);
+	if (!sc.full.reserve((size_t)w * h * 4) || !sc.image.reserve((size_t)win_w * win_h * 4) || !sc.mm.reserve(2 * 64 * sizeof(float)))
+		return -1;
+	const float *g = nullptr;
+	if (sigma > 0)
+	{
+		const int r = dtype == 'H' ? rir_gaussian_filter_u16_device(static_cast<const unsigned short *>(d_img), sc.full.as<float>(), w, h, 1, sigma, stream)
+								   : rir_gaussian_filter_device(static_cast<const float *>(d_img), sc.full.as<float>(), w, h, 1, sigma, stream);
+		if (r != 0)
+			return -1;
+		g = sc.full.as<float>();
+	}
+	else if (dtype == 'f')
+		g = static_cast<const float *>(d_img);
+	else
+	{
+		if (!hip_ok(launch_u16_to_f32(static_cast<const uint16_t *>(d_img), sc.full.as<float>(), (int64_t)w * h, st), "u16_to_f32"))
+			return -1;
+		g = sc.full.as<float>();
+	}
+	if (!hip_ok(launch_minmax_normalize(g + (size_t)win_y * w + win_x, win_w, win_h, w, sc.image.as<float>(), sc.mm.as<float>(), st), "minmax_normalize"))
+		return -1;
+	return run_ecc(sc, d_ref_norm, sc.image.as<float>(), nullptr, win_w, win_h, warp, max_iterations, eps, cc, iterations, st);
 }
 
 // Host-pointer form, the drop-in for cv2.findTransformECC(templ, image, warp, MOTION_TRANSLATION, criteria, mask, 1):

@@ -20,6 +20,10 @@ _lib.rir_ecc_translation_device.argtypes = [_vp, _vp, _vp, ct.c_int, ct.c_int, _
                                             ct.POINTER(ct.c_int), _vp]
 
 
+_lib.rir_ecc_register_frame_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_float, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp,
+                                               ct.c_int, ct.c_double, ct.POINTER(ct.c_double), ct.POINTER(ct.c_int), _vp]
+
+
 def _stream():
     return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -62,11 +66,16 @@ class DeviceRegistratorECC:
         self.confidences.append(1)
 
     def compute(self, img):
-        g = self._filtered(img)
-        im_n = self._normalised_window(g)
+        img = img if img.dim() == 2 else img[0]
+        if img.dtype != torch.float32 and img.dtype != torch.uint16:
+            img = img.to(torch.float32)
+        img = img.contiguous()
         cc = ct.c_double(0)
-        if _lib.rir_ecc_translation_device(self._ref_n.data_ptr(), im_n.data_ptr(), None, self.subW, self.subH, self.warp.ctypes.data,
-                                           self.number_of_iterations, self.termination_eps, ct.byref(cc), None, _stream()) != 0:
+        # pre-filter, window normalisation and alignment in one library call (no host work between the kernels)
+        if _lib.rir_ecc_register_frame_device(img.data_ptr(), ord("H") if img.dtype == torch.uint16 else ord("f"), img.shape[1], img.shape[0],
+                                              float(self.sigma), self.startX, self.startY, self.subW, self.subH, self._ref_n.data_ptr(),
+                                              self.warp.ctypes.data, self.number_of_iterations, self.termination_eps, ct.byref(cc), None,
+                                              _stream()) != 0:
             raise RuntimeError("ECC: %s" % last_error())
         shift = [float(self.warp[1]), float(self.warp[0])]
         self.confidences.append(cc.value)
@@ -76,6 +85,7 @@ class DeviceRegistratorECC:
             if self.conf_thresh is None:
                 self.conf_thresh = np.min(self.confidences) - 2 * np.std(self.confidences)
             if cc.value < self.conf_thresh:  # change of reference image: the current window, shifted back
+                g = self._filtered(img)
                 win = g[self.startY:self.startY + self.subH, self.startX:self.startX + self.subW].contiguous()
                 moved = D.translate(win, (-shift[1], -shift[0]), "")[0]
                 out = torch.empty_like(moved)
