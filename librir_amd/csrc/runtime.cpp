@@ -3,9 +3,13 @@
 // get_last_log_error (tools.h:39-55) and set_void_ptr / get_void_ptr / rm_void_ptr (tools.h:67-78).
 #include "runtime.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 
+#ifndef RIR_SPIN_WAIT
+#define RIR_SPIN_WAIT 1
+#endif
 namespace rir
 {
 	namespace
@@ -100,6 +104,25 @@ namespace rir
 			return true;
 		log_error(std::string("librir_amd: ") + what + ": " + hipGetErrorString(e));
 		return false;
+	}
+
+	// Waits for a stream by polling it: the per-frame entry points wait for a few tens of microseconds of work, and a
+	// blocking wait adds its wake-up latency (20-50 us here) to every call.  Falls back to the blocking wait after 2 ms.
+	hipError_t wait_stream(hipStream_t st)
+	{
+#if RIR_SPIN_WAIT
+		const auto t0 = std::chrono::steady_clock::now();
+		for (long spins = 1;; ++spins)
+		{
+			const hipError_t e = hipStreamQuery(st);
+			if (e != hipErrorNotReady)
+				return e;
+			if ((spins & 0x3f) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
+				break;
+			__builtin_ia32_pause();
+		}
+#endif
+		return hipStreamSynchronize(st);
 	}
 
 	namespace

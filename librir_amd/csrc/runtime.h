@@ -77,5 +77,6 @@ namespace rir
 	};
 
 	bool hip_ok(hipError_t e, const char *what); // logs "what: hipGetErrorString" on failure
+	hipError_t wait_stream(hipStream_t st);		  // polls the stream (short waits without the wake-up latency of a blocking one)
 
 } // namespace rir

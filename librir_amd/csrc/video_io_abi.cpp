@@ -186,7 +186,7 @@ namespace
 			dev.subtract_min = subtract_min ? 1 : 0;
 			dev.min = 0;
 			frames = 0;
-			return hip_ok(hipStreamSynchronize(st), "sync"); // the state is ready whatever stream the steps run on
+			return hip_ok(wait_stream(st), "sync"); // the state is ready whatever stream the steps run on
 		}
 
 		// img (host, full frame) -> d_out (device, full frame), copied to `out` (host) when it is not NULL.
@@ -204,7 +204,7 @@ namespace
 			// (when out is NULL the caller consumes d_out on the same stream)
 			if (out && !hip_ok(hipMemcpyAsync(out, d_out.ptr, (size_t)full * 2, hipMemcpyDeviceToHost, st), "D2H"))
 				return false;
-			if (!hip_ok(hipStreamSynchronize(st), "sync"))
+			if (!hip_ok(wait_stream(st), "sync"))
 				return false;
 			low_error = e[0], high_error = e[1];
 			return true;
@@ -216,7 +216,7 @@ namespace
 		{
 			int e[2] = {0, 0};
 			if (!queue_frame(d_src, d_dst, add_loss, remove_bad_pixels, low_value_error, high_value_error, std_factor, d_errs.as<int>(), st) ||
-				!hip_ok(hipMemcpyAsync(e, d_errs.ptr, sizeof(e), hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(hipStreamSynchronize(st), "sync"))
+				!hip_ok(hipMemcpyAsync(e, d_errs.ptr, sizeof(e), hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
 				return false;
 			low_error = e[0], high_error = e[1];
 			return true;
@@ -248,7 +248,7 @@ namespace
 				{
 					unsigned int mn = 65535;
 					if (!hip_ok(launch_lossy_min(tmp, s, d_min.as<unsigned int>(), st), "lossy min") ||
-						!hip_ok(hipMemcpyAsync(&mn, d_min.ptr, 4, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(hipStreamSynchronize(st), "sync"))
+						!hip_ok(hipMemcpyAsync(&mn, d_min.ptr, 4, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
 						return false;
 					dev.min = mn;
 				}
@@ -475,7 +475,7 @@ namespace
 				return false;
 			uint64_t coff[2] = {0, 0};
 			if (!hip_ok(hipMemcpyAsync(coff, cc.d_chunk_off.ptr, sizeof(coff), hipMemcpyDeviceToHost, st), "D2H") ||
-				!hip_ok(hipStreamSynchronize(st), "sync"))
+				!hip_ok(wait_stream(st), "sync"))
 				return false;
 			const uint64_t words = coff[1];
 			std::vector<uint64_t> hdr((size_t)L.ntiles * chunk_gop), payload((size_t)words);
@@ -483,7 +483,7 @@ namespace
 			if (!hip_ok(hipMemcpyAsync(hdr.data(), cc.d_hdr.ptr, hdr.size() * 8, hipMemcpyDeviceToHost, st), "D2H") ||
 				!hip_ok(hipMemcpyAsync(toff.data(), cc.d_tile_off.ptr, toff.size() * 4, hipMemcpyDeviceToHost, st), "D2H") ||
 				(words && !hip_ok(hipMemcpyAsync(payload.data(), cc.d_stream.ptr, (size_t)words * 8, hipMemcpyDeviceToHost, st), "D2H")) ||
-				!hip_ok(hipStreamSynchronize(st), "sync"))
+				!hip_ok(wait_stream(st), "sync"))
 				return false;
 			ChunkHeader ch;
 			std::memset(&ch, 0, sizeof(ch));
@@ -946,7 +946,7 @@ namespace
 			// the decoded chunk stays in HBM (cc.d_frames): frames are filtered there and only the requested
 			// frame crosses PCIe (IRFileLoader::readImage hands out one frame per call)
 			int err = 0;
-			if (!hip_ok(hipMemcpyAsync(&err, cc.d_err.ptr, sizeof(int), hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(hipStreamSynchronize(st), "sync"))
+			if (!hip_ok(hipMemcpyAsync(&err, cc.d_err.ptr, sizeof(int), hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
 				return false;
 			if (err)
 			{
@@ -986,7 +986,7 @@ namespace
 				return read_zfile(pos, out);
 			const unsigned short *d = device_frame(pos);
 			hipStream_t st = default_stream();
-			return d && hip_ok(hipMemcpyAsync(out, d, npx * 2, hipMemcpyDeviceToHost, st), "D2H") && hip_ok(hipStreamSynchronize(st), "sync");
+			return d && hip_ok(hipMemcpyAsync(out, d, npx * 2, hipMemcpyDeviceToHost, st), "D2H") && hip_ok(wait_stream(st), "sync");
 		}
 
 		// get_last_image_raw_value: the unfiltered last image is fetched on demand
@@ -1053,7 +1053,7 @@ namespace
 					return false;
 				res = d_b;
 			}
-			return hip_ok(hipMemcpyAsync(pixels, res, fbytes, hipMemcpyDeviceToHost, st), "D2H") && hip_ok(hipStreamSynchronize(st), "sync");
+			return hip_ok(hipMemcpyAsync(pixels, res, fbytes, hipMemcpyDeviceToHost, st), "D2H") && hip_ok(wait_stream(st), "sync");
 		}
 
 		// IRFileLoader::setBadPixelsEnabled (IRFileLoader.cpp:693-716): detector on the first image, rows < H-3, once
@@ -1070,7 +1070,7 @@ namespace
 					std::vector<unsigned short> first((size_t)width * height);
 					if (!read_raw(0, first.data()) || !cc.d_tmp.reserve(first.size() * 4) ||
 						!hip_ok(hipMemcpyAsync(cc.d_tmp.ptr, first.data(), first.size() * 2, hipMemcpyHostToDevice, st), "H2D") ||
-						!hip_ok(hipStreamSynchronize(st), "sync"))
+						!hip_ok(wait_stream(st), "sync"))
 						return false;
 					d_first = cc.d_tmp.as<unsigned short>();
 				}
@@ -1826,7 +1826,7 @@ RIR_EXPORT int rir_lossy_step_device(int handle, const unsigned short *d_in, uns
 	{
 		std::vector<int> e((size_t)nframes * 2);
 		if (!hip_ok(hipMemcpyAsync(e.data(), o->batch_errs.ptr, e.size() * sizeof(int), hipMemcpyDeviceToHost, st), "D2H") ||
-			!hip_ok(hipStreamSynchronize(st), "sync"))
+			!hip_ok(wait_stream(st), "sync"))
 			return -1;
 		for (int i = 0; i < nframes; ++i)
 		{
