@@ -1855,7 +1855,8 @@ static int errors_out(const std::vector<unsigned short> &err, unsigned short *er
 		return -2;
 	}
 	*size = (int)err.size();
-	std::memcpy(errors, err.data(), err.size() * sizeof(unsigned short));
+	if (!err.empty())
+		std::memcpy(errors, err.data(), err.size() * sizeof(unsigned short));
 	return 0;
 }
 RIR_EXPORT int h264_get_low_errors(int file, unsigned short *errors, int *size)
