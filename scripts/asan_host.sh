@@ -21,3 +21,11 @@ cp librir_amd/libs/librir_amd.so $OUT/librir_amd.so.keep
 trap 'cp $OUT/librir_amd.so.keep librir_amd/libs/librir_amd.so' EXIT
 cp $OUT/librir_amd_asan.so librir_amd/libs/librir_amd.so
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 LD_PRELOAD=$RT python -m pytest tests/test_host_io.py tests/test_abi.py -x -q -s
+# the CPU oracle (plain C) under both sanitizers with its own tests
+cp oracle/librir_oracle.so $OUT/oracle_keep.so
+trap 'cp $OUT/librir_amd.so.keep librir_amd/libs/librir_amd.so; cp $OUT/oracle_keep.so oracle/librir_oracle.so' EXIT
+gcc -O1 -g -std=c11 -ffp-contract=off -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -o oracle/librir_oracle.so oracle/rir_oracle.c -lm
+cp $OUT/librir_amd.so.keep librir_amd/libs/librir_amd.so
+ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
+  LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) \
+  python -m pytest tests/test_oracle_golden.py tests/test_codec_oracle.py tests/test_lossy_oracle.py tests/test_registration_oracle.py -x -q
