@@ -24,6 +24,7 @@ from librir_amd import device as D  # noqa: E402
 from librir_amd.signal_processing import rir_signal_processing as sp  # noqa: E402
 from librir_amd.synthetic import inject_bad_pixels, s1_noisy_background, s3_registration  # noqa: E402
 from librir_amd.video_io import IRMovie, IRSaver  # noqa: E402
+from librir_amd.video_io import rir_video_io as rv  # noqa: E402
 from oracle.pyoracle import Oracle, OracleLossy, Ref  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -117,6 +118,26 @@ def cpu_codec():
 
 
 c1["cpu_port_fps_1thread"] = cpu_fps(cpu_codec, ncpu)
+# the reference's own CPU codec that is reachable here: its ZFile container, one zstd frame per image on one host core
+# (method 1, level 0 - SURVEY §8d item 2), written and read back through this library's C ABI
+with tempfile.TemporaryDirectory() as d:
+    p = os.path.join(d, "c1.bin")
+    nz = min(200, n)
+    t0 = time.perf_counter()
+    zw = rv.open_video_write(p, w, h, rate=50, method=rv.METHOD_ZSTD, clevel=0)
+    for i in range(nz):
+        rv.image_write(zw, fr[i], 3_000_000_000 + i * 20_000_000)
+    zsize = rv.close_video(zw)
+    tw = time.perf_counter() - t0
+    cam = rv.open_camera_file(p)
+    t0 = time.perf_counter()
+    for i in range(nz):
+        img = rv.load_image(cam, i)
+    tr = time.perf_counter() - t0
+    rv.close_camera(cam)
+    assert np.array_equal(img, fr[nz - 1])
+    c1["cpu_zfile_zstd_1thread"] = {"record_fps": nz / tw, "read_fps": nz / tr, "roundtrip_fps": nz / (tw + tr),
+                                    "file_ratio": fr[:nz].nbytes / zsize}
 out["configs[1]"] = c1
 
 # ------------------------------------------------------------------ configs[2]: filters before encode
