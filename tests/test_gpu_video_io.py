@@ -300,3 +300,28 @@ def test_zfile_readback_filters_run_on_the_device(tmp_path, oracle):
     exp = oracle.remove_motion(oracle.remove_bad_pixels(arr[3], xy, rows=h - 3), np.float32(3.75), np.float32(-1.5), rows=h - 3)
     assert np.array_equal(mov[3], exp)
     mov.close()
+
+
+def test_sequential_read_ahead_is_transparent(tmp_path):
+    """Sequential reads switch to a chunk-wide copy into page-locked memory after three consecutive images; jumps, repeated
+    reads, raw-value queries and filtered reads in between must see exactly the recorded images."""
+    n, h, w = 37, 40, 64
+    arr = images(n, h, w)
+    p = tmp_path / "seq.h264"
+    with IRSaver(p, w, h, h) as s:
+        s.set_parameter("GOP", 8)  # chunks of 8: several boundaries, a short last chunk
+        for i in range(n):
+            s.add_image(arr[i], i * 1000)
+    cam = rv.open_camera_file(p)
+    order = list(range(n)) + [5, 6, 7, 8, 9, 3, 4, 5, 6, 30, 31, 32, 33, 34, 35, 36, 0, 1, 2, 2, 3, 4, 5]
+    for k, i in enumerate(order):
+        assert np.array_equal(rv.load_image(cam, i), arr[i]), (k, i)
+        if k % 5 == 0:
+            assert rv.get_last_image_raw_value(cam, 3, 2) == arr[i, 2, 3]
+    rv.enable_bad_pixels(cam, True)
+    a = rv.load_image(cam, 6)
+    rv.enable_bad_pixels(cam, False)
+    for i in (7, 8, 9, 10, 11, 12):
+        assert np.array_equal(rv.load_image(cam, i), arr[i])
+    assert a.shape == (h, w)
+    rv.close_camera(cam)
