@@ -14,6 +14,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <sstream>
 
 #include "codec_format.h"
@@ -311,6 +314,60 @@ namespace
 		bool opened = false;
 		int chunk_gop = 0; // GOP frozen at open
 		ChunkCodec cc;
+		// Chunks are written by a background thread: the call that completes a chunk encodes it, brings tables and payload
+		// back into one of two page-locked buffers and hands them over - the 7 MB write into the page cache (most of the
+		// 1 ms such a call used to take) overlaps with the caller's next frames.  One job in flight at most.
+		struct WriteJob
+		{
+			ChunkHeader ch;
+			size_t hdr_n = 0, toff_n = 0, hdr_b = 0, toff_b = 0;
+			uint64_t words = 0;
+			int buf = 0;
+		};
+		PinnedBuffer h_out[2];
+		int next_buf = 0;
+		uint64_t file_pos = 0; // where the next chunk goes (the writer thread owns fp between open and close)
+		std::thread writer;
+		std::mutex wmu;
+		std::condition_variable wcv;
+		WriteJob job;
+		bool job_ready = false, writer_busy = false, writer_stop = false, write_failed = false;
+
+		void writer_loop()
+		{
+			std::unique_lock<std::mutex> lk(wmu);
+			while (true)
+			{
+				wcv.wait(lk, [&] { return job_ready || writer_stop; });
+				if (!job_ready)
+					return;
+				const WriteJob j = job;
+				job_ready = false, writer_busy = true;
+				lk.unlock();
+				const char *hb = h_out[j.buf].as<char>();
+				const bool ok = std::fwrite(&j.ch, sizeof(j.ch), 1, fp) == 1 && std::fwrite(hb, 8, j.hdr_n, fp) == j.hdr_n &&
+								std::fwrite(hb + j.hdr_b, 4, j.toff_n, fp) == j.toff_n &&
+								(!j.words || std::fwrite(hb + j.hdr_b + j.toff_b, 8, (size_t)j.words, fp) == (size_t)j.words);
+				lk.lock();
+				writer_busy = false;
+				if (!ok)
+					write_failed = true;
+				wcv.notify_all();
+			}
+		}
+		void stop_writer()
+		{
+			if (!writer.joinable())
+				return;
+			{
+				std::unique_lock<std::mutex> lk(wmu);
+				wcv.wait(lk, [&] { return !job_ready && !writer_busy; });
+				writer_stop = true;
+			}
+			wcv.notify_all();
+			writer.join();
+			writer_stop = false;
+		}
 		int pending = 0;
 		uint64_t nframes = 0;
 		std::vector<IndexEntry> index;
@@ -320,7 +377,11 @@ namespace
 		std::unique_ptr<LossyState> lossy;
 		std::vector<unsigned short> lossy_out;
 
-		~SaverObject() override { close(); }
+		~SaverObject() override
+		{
+			close();
+			stop_writer();
+		}
 
 		// the loss-injection state is created on the first lossy call (after the lazy open)
 		bool lossy_ready()
@@ -456,6 +517,8 @@ namespace
 			hd.width = width, hd.height = height, hd.gop = chunk_gop, hd.fps = fps;
 			if (std::fwrite(&box, sizeof(box), 1, fp) != 1 || std::fwrite(&hd, sizeof(hd), 1, fp) != 1)
 				return false;
+			file_pos = sizeof(box) + sizeof(hd);
+			write_failed = false;
 			opened = true;
 			return true;
 		}
@@ -478,25 +541,42 @@ namespace
 				!hip_ok(wait_stream(st), "sync"))
 				return false;
 			const uint64_t words = coff[1];
-			std::vector<uint64_t> hdr((size_t)L.ntiles * chunk_gop), payload((size_t)words);
-			std::vector<uint32_t> toff((size_t)L.ntiles + 1);
-			if (!hip_ok(hipMemcpyAsync(hdr.data(), cc.d_hdr.ptr, hdr.size() * 8, hipMemcpyDeviceToHost, st), "D2H") ||
-				!hip_ok(hipMemcpyAsync(toff.data(), cc.d_tile_off.ptr, toff.size() * 4, hipMemcpyDeviceToHost, st), "D2H") ||
-				(words && !hip_ok(hipMemcpyAsync(payload.data(), cc.d_stream.ptr, (size_t)words * 8, hipMemcpyDeviceToHost, st), "D2H")) ||
+			// tables and payload come back into page-locked memory (a pageable destination is staged by the runtime at a
+			// fraction of the PCIe rate, and a fresh 7 MB vector per chunk costs its page faults) and are written from there
+			WriteJob j;
+			j.hdr_n = (size_t)L.ntiles * chunk_gop, j.toff_n = (size_t)L.ntiles + 1;
+			j.hdr_b = j.hdr_n * 8, j.toff_b = (j.toff_n * 4 + 7) & ~(size_t)7, j.words = words;
+			j.buf = next_buf;
+			const size_t pay_b = (size_t)words * 8;
+			PinnedBuffer &hob = h_out[j.buf]; // (the job in flight, if any, reads the other buffer)
+			if (pay_b > (size_t)cc.L.stream_max_bytes || !hob.reserve(j.hdr_b + j.toff_b + (size_t)cc.L.stream_max_bytes))
+				return false;
+			char *hb = hob.as<char>();
+			if (!hip_ok(hipMemcpyAsync(hb, cc.d_hdr.ptr, j.hdr_b, hipMemcpyDeviceToHost, st), "D2H") ||
+				!hip_ok(hipMemcpyAsync(hb + j.hdr_b, cc.d_tile_off.ptr, j.toff_n * 4, hipMemcpyDeviceToHost, st), "D2H") ||
+				(words && !hip_ok(hipMemcpyAsync(hb + j.hdr_b + j.toff_b, cc.d_stream.ptr, pay_b, hipMemcpyDeviceToHost, st), "D2H")) ||
 				!hip_ok(wait_stream(st), "sync"))
 				return false;
-			ChunkHeader ch;
-			std::memset(&ch, 0, sizeof(ch));
-			std::memcpy(ch.magic, "CHNK", 4);
-			ch.nframes = pending, ch.ntiles = L.ntiles, ch.gop = chunk_gop, ch.payload_words = words, ch.first_frame = nframes - pending;
-			IndexEntry e{(uint64_t)std::ftell(fp), nframes - pending, (uint32_t)pending, 0};
-			if (std::fwrite(&ch, sizeof(ch), 1, fp) != 1 || std::fwrite(hdr.data(), 8, hdr.size(), fp) != hdr.size() ||
-				std::fwrite(toff.data(), 4, toff.size(), fp) != toff.size() ||
-				(words && std::fwrite(payload.data(), 8, (size_t)words, fp) != (size_t)words))
+			std::memset(&j.ch, 0, sizeof(j.ch));
+			std::memcpy(j.ch.magic, "CHNK", 4);
+			j.ch.nframes = pending, j.ch.ntiles = L.ntiles, j.ch.gop = chunk_gop, j.ch.payload_words = words, j.ch.first_frame = nframes - pending;
+			IndexEntry e{file_pos, nframes - pending, (uint32_t)pending, 0};
+			file_pos += sizeof(j.ch) + j.hdr_n * 8 + j.toff_n * 4 + pay_b;
 			{
-				log_error("h264 saver: write error on " + filename);
-				return false;
+				std::unique_lock<std::mutex> lk(wmu);
+				if (!writer.joinable())
+					writer = std::thread([this] { writer_loop(); });
+				wcv.wait(lk, [&] { return !job_ready && !writer_busy; }); // one job in flight: the previous chunk is on disk before this one is queued
+				if (write_failed)
+				{
+					log_error("h264 saver: write error on " + filename);
+					return false;
+				}
+				job = j;
+				job_ready = true;
 			}
+			wcv.notify_all();
+			next_buf ^= 1;
 			index.push_back(e);
 			pending = 0;
 			return true;
@@ -552,6 +632,8 @@ namespace
 				return 0;
 			opened = false;
 			bool ok = flush_chunk();
+			stop_writer(); // every chunk is in the file from here on
+			ok = ok && !write_failed;
 			FileHeader hd;
 			std::memset(&hd, 0, sizeof(hd));
 			std::memcpy(hd.magic, "RIRBLOCK", 8);
