@@ -397,17 +397,19 @@ class LossyStream:
         if self.handle <= 0:
             raise RuntimeError("rir_lossy_create failed: %s" % last_error())
 
-    def step(self, frames, add_loss=False):
-        """frames (n,h,w) uint16 on the device -> (processed frames, low_errors, high_errors)"""
+    def step(self, frames, add_loss=False, errors=True):
+        """frames (n,h,w) uint16 on the device -> (processed frames, low_errors, high_errors).  With ``errors=False`` the
+        frames are only queued on the current stream (nothing waits) and the two error arrays are None."""
         fr = _frames3(frames, torch.uint16)
         n = fr.shape[0]
         if tuple(fr.shape[1:]) != self.shape:
             raise RuntimeError("LossyStream.step: wrong frame size")
         out = torch.empty_like(fr)
-        lo = np.zeros(n, np.int32)
-        hi = np.zeros(n, np.int32)
-        _check(_lib.rir_lossy_step_device(self.handle, fr.data_ptr(), out.data_ptr(), n, int(bool(add_loss)), lo.ctypes.data, hi.ctypes.data,
-                                          _stream()), "rir_lossy_step_device")
+        lo = np.zeros(n, np.int32) if errors else None
+        hi = np.zeros(n, np.int32) if errors else None
+        _check(_lib.rir_lossy_step_device(self.handle, fr.data_ptr(), out.data_ptr(), n, int(bool(add_loss)),
+                                          lo.ctypes.data if errors else None, hi.ctypes.data if errors else None, _stream()),
+               "rir_lossy_step_device")
         return out, lo, hi
 
     def close(self):

@@ -142,3 +142,10 @@ def test_device_resident_stream_matches_oracle(oracle, add_loss):
     assert np.array_equal(got, np.stack(exp))
     assert np.concatenate([lo_a, lo_b, lo_c]).tolist() == elo and np.concatenate([hi_a, hi_b, hi_c]).tolist() == ehi
     ls.close()
+    # the queue-only form (no error arrays, nothing waits inside the call): same frames
+    ls = D.LossyStream(w, h, hl, 5, 2, 2.5, 8)
+    a, lo_a, _ = ls.step(t[:1], add_loss=False, errors=False)
+    b, _, _ = ls.step(t[1:], add_loss=add_loss, errors=False)
+    assert lo_a is None
+    assert np.array_equal(torch.cat([a, b]).cpu().numpy(), np.stack(exp))
+    ls.close()
