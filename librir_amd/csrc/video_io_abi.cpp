@@ -213,6 +213,17 @@ namespace
 			return true;
 		}
 
+		// pinned_img (PAGE-LOCKED host memory that stays untouched until the stream has passed this point) -> d_out (device),
+		// queued without waiting; the frame's low / high error goes to d_errors (device int[2]).
+		bool queue_host_frame(const unsigned short *pinned_img, bool add_loss, bool remove_bad_pixels, int low_value_error, int high_value_error,
+							  double std_factor, int *d_errors)
+		{
+			hipStream_t st = default_stream();
+			return hip_ok(hipMemcpyAsync(d_img.ptr, pinned_img, (size_t)w * h * 2, hipMemcpyHostToDevice, st), "H2D") &&
+				   queue_frame(d_img.as<uint16_t>(), d_out.as<uint16_t>(), add_loss, remove_bad_pixels, low_value_error, high_value_error, std_factor,
+							   d_errors, st);
+		}
+
 		// One frame, device to device, and its budget back on the host (one 8-byte read-back and a synchronisation).
 		bool step_device(const uint16_t *d_src, uint16_t *d_dst, bool add_loss, bool remove_bad_pixels, int low_value_error, int high_value_error,
 						 double std_factor, int &low_error, int &high_error, hipStream_t st)
@@ -403,9 +414,21 @@ namespace
 		{
 			if (!img || !open() || !lossy_ready())
 				return false;
-			int lo = 0, hi = 0;
+			// The frame is uploaded and its kernels queued; nothing waits here.  Its error budget is decided on the device and
+			// collected later, for all the frames since the last collection at once (resolve_errors: when a chunk is written,
+			// when the errors are asked for, at close) - a read-back and a wait per frame cost more than the kernels.
 			const bool first = lossy->frames == 0;
-			if (!lossy->step(img, nullptr, false, removeBadPixels, lowValueError, highValueError, stdFactor, lo, hi))
+			if (deferred.size() >= (size_t)ERR_SLOTS && !resolve_errors())
+				return false;
+			if (pending >= chunk_gop && !flush_chunk())
+				return false;
+			// the caller owns its buffer again on return: the image goes through this chunk's page-locked slot (see add_image;
+			// the slot is not reused before the chunk has been flushed, i.e. after a wait on the stream)
+			const size_t fbytes = (size_t)width * height * 2;
+			unsigned short *slot = reinterpret_cast<unsigned short *>(cc.h_frames.as<char>() + (size_t)pending * fbytes);
+			std::memcpy(slot, img, fbytes);
+			if (!d_err_slots.reserve((size_t)ERR_SLOTS * 2 * sizeof(int)) ||
+				!lossy->queue_host_frame(slot, false, removeBadPixels, lowValueError, highValueError, stdFactor, d_err_slots.as<int>() + 2 * deferred.size()))
 				return false;
 			if (first)
 			{
@@ -417,14 +440,45 @@ namespace
 				global_attrs["GlobalBackgroundError"] = std::to_string(lowValueError);
 				global_attrs["GlobalForegroundError"] = std::to_string(highValueError);
 			}
-			else
-			{
-				attrs["BackgroundError"] = std::to_string(lo);
-				attrs["ForegroundError"] = std::to_string(hi);
-			}
-			low_errors.push_back((unsigned short)lo);
-			high_errors.push_back((unsigned short)hi);
+			deferred.push_back(Deferred{(size_t)nframes, low_errors.size(), !first});
+			low_errors.push_back(0);
+			high_errors.push_back(0);
 			return add_image_device(lossy->d_out.as<unsigned short>(), ts, attrs); // stays in HBM: no trip through the host
+		}
+
+		// errors of the frames recorded since the last call: into the error lists and the per-frame attributes
+		struct Deferred
+		{
+			size_t frame, slot;
+			bool with_attrs;
+		};
+		enum
+		{
+			ERR_SLOTS = 256
+		};
+		std::vector<Deferred> deferred;
+		DeviceBuffer d_err_slots;
+		bool resolve_errors()
+		{
+			if (deferred.empty())
+				return true;
+			std::vector<int> e(deferred.size() * 2);
+			hipStream_t st = default_stream();
+			if (!hip_ok(hipMemcpyAsync(e.data(), d_err_slots.ptr, e.size() * sizeof(int), hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
+				return false;
+			for (size_t i = 0; i < deferred.size(); ++i)
+			{
+				const Deferred &d = deferred[i];
+				low_errors[d.slot] = (unsigned short)e[2 * i];
+				high_errors[d.slot] = (unsigned short)e[2 * i + 1];
+				if (d.with_attrs && d.frame < frame_attrs.size())
+				{
+					frame_attrs[d.frame]["BackgroundError"] = std::to_string(e[2 * i]);
+					frame_attrs[d.frame]["ForegroundError"] = std::to_string(e[2 * i + 1]);
+				}
+			}
+			deferred.clear();
+			return true;
 		}
 
 		// H264_Saver::addLoss (h264.cpp:2426-2607): the loss is applied to the caller's image, nothing is written
@@ -433,7 +487,7 @@ namespace
 			if (!img || !open() || !lossy_ready())
 				return false;
 			int lo = 0, hi = 0;
-			if (!lossy->step(img, lossy_out.data(), true, removeBadPixels, lowValueError, highValueError, stdFactor, lo, hi))
+			if (!resolve_errors() || !lossy->step(img, lossy_out.data(), true, removeBadPixels, lowValueError, highValueError, stdFactor, lo, hi))
 				return false;
 			low_errors.push_back((unsigned short)lo);
 			high_errors.push_back((unsigned short)hi);
@@ -525,6 +579,8 @@ namespace
 
 		bool flush_chunk()
 		{
+			if (!resolve_errors())
+				return false;
 			if (pending == 0)
 				return true;
 			hipStream_t st = default_stream();
@@ -1982,6 +2038,8 @@ RIR_EXPORT int h264_get_low_errors(int file, unsigned short *errors, int *size)
 		log_error("h264_get_low_erros: NULL identifier");
 		return -1;
 	}
+	if (!s->resolve_errors())
+		return -1;
 	return errors_out(s->low_errors, errors, size);
 }
 RIR_EXPORT int h264_get_high_errors(int file, unsigned short *errors, int *size)
@@ -1992,6 +2050,8 @@ RIR_EXPORT int h264_get_high_errors(int file, unsigned short *errors, int *size)
 		log_error("h264_get_high_erros: NULL identifier");
 		return -1;
 	}
+	if (!s->resolve_errors())
+		return -1;
 	return errors_out(s->high_errors, errors, size);
 }
 
