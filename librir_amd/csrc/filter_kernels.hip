@@ -970,7 +970,14 @@ namespace rir
 		const uint16_t *s = src + fbase;
 		const float dx = offsets[per_frame_offsets ? 2 * n : 0];
 		const float dy = offsets[per_frame_offsets ? 2 * n + 1 : 1];
-		const int gx0 = chain_anchor(x0, dx, w), gy0 = chain_anchor(y0, dy, h); // top-left filtered pixel of the block
+		int gx0 = chain_anchor(x0, dx, w);
+		const int gy0 = chain_anchor(y0, dy, h); // (gx0, gy0): top-left filtered pixel of the block
+		{ // a tile whose first columns fall left of the source keeps the anchor its own columns would have (negative): lane i's
+		  // taps stay at gx0 + i, the columns < 0 of the block read as 0 and the clamped taps (column 0) are still inside it
+			const float p0 = (float)x0 - dx;
+			if (p0 < 0.f && p0 > -61.f)
+				gx0 = (int)floorf(p0);
+		}
 		const int cx = gx0 - R + lane;											 // this lane's source column
 		const bool xin = cx >= 0 && cx < w;
 		const int64_t fix_base = (int64_t)n * bp.nbad;
@@ -1097,14 +1104,15 @@ namespace rir
 		const bool out_x = px < 0 || px >= (float)w;
 		const int l = out_x ? (px < 0 ? 0 : w - 1) : (int)px;
 		int r = out_x ? l : (int)(px + 1.f);
+		const bool r_is_l = !out_x && r >= w; // last source column: the right tap is the left one
 		if (r >= w)
 			r = l;
 		const double u = (double)(px - (float)l);
 
 		if constexpr (R == 1)
 		{
-			// ---- regular tiles (all but the image borders): no LDS at all --------------------------------------------
-			// When the block lies inside the image by R on every side (no renormalisation), lane i's taps are the
+			// ---- regular tiles (all but the first / last row bands of the image): no LDS at all -------------------------
+			// When the block does not touch the first / last R rows, lane i's taps are the
 			// columns gx0 + i and gx0 + i + 1 (no clamp, px + 1 not rounded across an integer) and output row j's taps
 			// are the rows gy0 + j and gy0 + j + 1, then every operand sits in a NEIGHBOUR lane's registers: the row
 			// pass of the gaussian takes its left / right column sums through DPP wave shifts, and so do the two tap
@@ -1116,18 +1124,42 @@ namespace rir
 			const bool out_yj = pyj < 0 || pyj >= (float)h;
 			const int tj = (int)pyj, bj = (int)(pyj + 1.f);
 			bool row_ok = !act_y || (!out_yj && tj == gy0 + lane && bj == tj + 1 && bj < h);
-			const bool col_ok = !act_x || (!out_x && l == gx0 + lane && r == l + 1);
+			// columns: regular taps, the last source column (right tap = left tap), or outside the source on ONE side of the
+			// tile ("nearest": the first / last source column, held by one lane of the block; "background": the constant)
+			const uint64_t outs = __ballot(act_x && out_x);
+			const int edge_lane = outs ? ((outs & 1) ? -gx0 : w - 1 - gx0) : 0; // lane whose left tap column is the clamped column
+			const uint64_t ins = __ballot(act_x && !out_x);
+			const bool one_side = outs == 0 || (((outs & 1) == 0 || ins == 0 || (outs >> __builtin_ctzll(ins)) == 0) && edge_lane >= 0 && edge_lane <= 61);
+			const bool col_ok = !act_x || out_x || (l == gx0 + lane && (r_is_l || r == l + 1));
 			const float vvj = (float)bj - pyj;
 			const float vv0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vvj))); // row 0 (y0 < h)
 			row_ok = row_ok && (!act_y || __builtin_bit_cast(int, vvj) == __builtin_bit_cast(int, vv0)); // one vertical weight for the tile
 			// (frames of 2 GiB and more do not fit a buffer descriptor: they take the general path)
-			const bool interior = gx0 >= R && gx0 + OUTW - 1 < w - R && gy0 >= R && gy0 + TY - 1 < h - R && (int64_t)w * h < (1 << 30);
-			if (interior && __ballot(!(row_ok && col_ok)) == 0)
+			// rows: the block must not touch the first / last R rows (their renormalisation depends on the row); columns may -
+			// the renormalisation of the first / last R columns is a per-lane factor, applied below where a tile needs it
+			const bool rows_interior = gy0 >= R && gy0 + TY - 1 < h - R && (int64_t)w * h < (1 << 30);
+			const bool xb = xin && (cx < R || cx >= w - R);
+			const bool needs_norm = __ballot(xb) != 0;
+			if (rows_interior && one_side && __ballot(!(row_ok && col_ok)) == 0)
 			{
 				auto shl1 = [](float f) -> float
 				{ return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x130, 0xf, 0xf, true)); }; // lane i <- i + 1
 				auto shr1 = [](float f) -> float
 				{ return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, f), 0x138, 0xf, 0xf, true)); }; // lane i <- i - 1
+				float norm_den = 1.f;
+				if (needs_norm)
+				{ // sx * sy of the general path with sy = the full 1-D sum (no row of the block is a border row)
+					float full = 0.f;
+#pragma unroll
+					for (int d = 0; d < KW; ++d)
+						full += a[d];
+					float sx = 0.f;
+#pragma unroll
+					for (int d = -R; d <= R; ++d)
+						if (cx + d >= 0 && cx + d < w)
+							sx += a[d + R];
+					norm_den = sx * full;
+				}
 				double dl[TY]; // filtered pixel (gx0 + lane, gy0 + j) = this lane's left tap column
 #pragma unroll
 				for (int j = 0; j < HY; ++j)
@@ -1135,6 +1167,11 @@ namespace rir
 					v2f acc = __builtin_elementwise_fma((v2f){a[0], a[0]}, (v2f){shr1(cs[j]), shr1(cs[j + HY])}, (v2f){0.f, 0.f});
 					acc = __builtin_elementwise_fma((v2f){a[1], a[1]}, (v2f){cs[j], cs[j + HY]}, acc);
 					acc = __builtin_elementwise_fma((v2f){a[2], a[2]}, (v2f){shl1(cs[j]), shl1(cs[j + HY])}, acc);
+					if (needs_norm)
+					{ // (wave-uniform) first / last R columns of the image: renormalised by the weight of the taps inside it
+						acc.x = xb ? acc.x / norm_den : acc.x;
+						acc.y = xb ? acc.y / norm_den : acc.y;
+					}
 					dl[j] = (double)shl1(acc.x); // lane i owns column gx0 - 1 + i: column gx0 + i is one lane up
 					dl[j + HY] = (double)shl1(acc.y);
 				}
@@ -1160,8 +1197,17 @@ namespace rir
 					const uint64_t clb = __builtin_bit_cast(uint64_t, cl);
 					const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)clb, 0x130, 0xf, 0xf, true);
 					const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(clb >> 32), 0x130, 0xf, 0xf, true);
-					const double cr = __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+					const double cs1 = __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
+					const double cr = r_is_l ? cl : cs1;
 					res[j] = CastTo<u16_via_f32>::from(cl * u1 + cr * u).v;
+					if (outs != 0)
+					{ // (wave-uniform) columns outside the source: the constant, or the first / last source column of row t_j
+						const uint64_t eb = __builtin_bit_cast(uint64_t, dl[j]);
+						const uint32_t elo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)eb, edge_lane & 63);
+						const uint32_t ehi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(eb >> 32), edge_lane & 63);
+						const uint16_t near = CastTo<u16_via_f32>::from(__builtin_bit_cast(double, (uint64_t)elo | ((uint64_t)ehi << 32))).v;
+						res[j] = out_x ? (strategy == TRANSLATE_CONSTANT ? (uint16_t)background : near) : res[j];
+					}
 				}
 				if (!wide)
 				{
