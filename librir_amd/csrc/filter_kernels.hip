@@ -944,8 +944,13 @@ namespace rir
 		return p < 0 ? 0 : (p >= (float)size ? size - 1 : (int)p);
 	}
 
+	// register budget for 7 waves per SIMD (73 VGPRs; the compiler's own choice, 76, leaves 6: 0.156 -> 0.145 ms)
+#ifndef RIR_CHAIN_WAVES
+#define RIR_CHAIN_WAVES 7
+#endif
+#define RIR_CHAIN_OCC __attribute__((amdgpu_waves_per_eu(R <= 2 ? RIR_CHAIN_WAVES : 1, R <= 2 ? RIR_CHAIN_WAVES : 8))) /* wider kernels: the compiler's choice */
 	template <int R>
-	__global__ __launch_bounds__(256) void filter_chain_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w, int h,
+	RIR_CHAIN_OCC __global__ __launch_bounds__(256) void filter_chain_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w, int h,
 															   ChainBadPixels bp, const float *__restrict__ kern, const float *__restrict__ offsets,
 															   int per_frame_offsets, int strategy, uint32_t background)
 	{
