@@ -280,7 +280,7 @@ namespace rir
 			const bool is_last = bj == rows;
 			const uint64_t last_rows = __ballot(act_y && !out_yj && is_last);
 			const bool row_ok = !act_y || (!out_yj && tj == t0 + lane && (is_last || (bj == tj + 1 && __builtin_bit_cast(int, vvj) == __builtin_bit_cast(int, vv0))));
-			const bool x_border_ok = strategy == TRANSLATE_NEAREST || strategy == TRANSLATE_CONSTANT || strategy == TRANSLATE_UNCHANGED;
+			const bool x_border_ok = strategy == TRANSLATE_NEAREST || strategy == TRANSLATE_CONSTANT || strategy == TRANSLATE_UNCHANGED || strategy == TRANSLATE_SOURCE;
 			const uint64_t outs = __ballot(act_x && out_x);
 			const bool one_side = (outs & 1) == 0 || (outs >> first) == 0; // columns outside on the left OR on the right of the tile
 			if (inside != 0 && __ballot(!(col_ok && row_ok)) == 0 && (outs == 0 || (x_border_ok && one_side)) && l0 > -64 && (last_rows & 1) == 0)
@@ -375,6 +375,11 @@ namespace rir
 						}
 						else if (strategy == TRANSLATE_CONSTANT)
 							res = out_x ? background : res;
+						else if (strategy == TRANSLATE_SOURCE)
+						{ // the input pixel at the output position (clamped address: the load is unconditional)
+							const T sp = s[(int64_t)min(y0 + j, h_ - 1) * w + min(x, w - 1)];
+							res = out_x ? tap_as<T, U>(sp) : res;
+						}
 						else
 							wr = wr && !out_x; // noborder: left untouched
 						if (wr)
