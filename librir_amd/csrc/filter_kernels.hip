@@ -272,18 +272,26 @@ namespace rir
 			const bool out_yj = pyj < 0 || pyj >= (float)rows;
 			const int tj = out_yj ? 0 : (int)pyj;
 			const int bj = out_yj ? 0 : (int)(pyj + 1.f);
-			const int t0 = __builtin_amdgcn_readfirstlane(tj);
+			// (rows above / below the source are handled in place too: the window is anchored on the first row inside)
+			const uint64_t in_rows = __ballot(act_y && !out_yj);
+			const int frow = in_rows ? __builtin_ctzll(in_rows) : 0;
+			const int t0 = __builtin_amdgcn_readlane(tj, frow) - frow;
 			const float vvj = (float)(bj == rows ? tj : bj) - pyj;
-			const float vv0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, vvj)));
+			const float vv0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vvj), frow));
 			// regular rows: t = t0 + j, b = t + 1, one vertical weight; the row whose bottom tap falls on the last source row
 			// (b == rows -> t, Filters.h:306-309; at most one per tile) has its own weight (float)t - py
 			const bool is_last = bj == rows;
 			const uint64_t last_rows = __ballot(act_y && !out_yj && is_last);
-			const bool row_ok = !act_y || (!out_yj && tj == t0 + lane && (is_last || (bj == tj + 1 && __builtin_bit_cast(int, vvj) == __builtin_bit_cast(int, vv0))));
+			const bool row_ok = !act_y || out_yj || (tj == t0 + lane && (is_last || (bj == tj + 1 && __builtin_bit_cast(int, vvj) == __builtin_bit_cast(int, vv0))));
 			const bool x_border_ok = strategy == TRANSLATE_NEAREST || strategy == TRANSLATE_CONSTANT || strategy == TRANSLATE_UNCHANGED || strategy == TRANSLATE_SOURCE;
 			const uint64_t outs = __ballot(act_x && out_x);
 			const bool one_side = (outs & 1) == 0 || (outs >> first) == 0; // columns outside on the left OR on the right of the tile
-			if (inside != 0 && __ballot(!(col_ok && row_ok)) == 0 && (outs == 0 || (x_border_ok && one_side)) && l0 > -64 && (last_rows & 1) == 0)
+			// rows outside the source: "nearest" takes source row 0 / rows - 1, which must be one of the OH + 1 rows loaded
+			const uint64_t out_rows = __ballot(act_y && out_yj), above_rows = __ballot(act_y && pyj < 0);
+			const int i_top = -t0, i_bot = rows - 1 - t0;
+			const bool rows_fit = (above_rows == 0 || (i_top >= 0 && i_top <= OH)) && ((out_rows & ~above_rows) == 0 || (i_bot >= 0 && i_bot <= OH));
+			if (inside != 0 && in_rows != 0 && __ballot(!(col_ok && row_ok)) == 0 && ((outs == 0 && out_rows == 0) || x_border_ok) && one_side && rows_fit &&
+				l0 > -64 && t0 > -64 && ((last_rows >> frow) & 1) == 0)
 			{
 				const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)s);
 				const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)s >> 32));
@@ -294,7 +302,7 @@ namespace rir
 				const uint32_t voff = (col >= 0 && col < w) ? (uint32_t)((t0 * w + col) * (int)sizeof(T)) : 0x80000000u;
 				const uint32_t step = (uint32_t)w * (uint32_t)sizeof(T);
 				T tap[OH + 1];
-				if (t0 + OH < h_)
+				if (t0 >= 0 && t0 + OH < h_)
 				{ // all OH + 1 rows are in the frame: the row steps on the scalar side (the scalar offset is NOT range-checked)
 #pragma unroll
 					for (int i = 0; i <= OH; ++i)
@@ -317,7 +325,7 @@ namespace rir
 				const double u = (double)(px - (float)l), u1 = 1 - u;
 				const double vv = (double)vv0, v1 = 1 - vv;
 				U *o = d + (int64_t)y0 * w + x;
-				if (outs == 0 && last_rows == 0)
+				if (outs == 0 && last_rows == 0 && out_rows == 0)
 				{ // the plain tile
 #pragma unroll
 					for (int j = 0; j < OH; ++j)
@@ -354,12 +362,22 @@ namespace rir
 						const double cr = r_is_l ? cl : cs;
 						U res = CastTo<U>::from(cl * u1 + cr * u);
 						bool wr = act_x && j < nrows;
+						const bool row_out = (out_rows >> j) & 1; // wave-uniform
+						T own = tap[j]; // the lane's own column at the row "nearest" reads: t_j, or the first / last source row
+						if (row_out)
+						{
+							const int ridx = ((above_rows >> j) & 1) ? i_top : i_bot;
+#pragma unroll
+							for (int i = 0; i <= OH; ++i)
+								own = (i == ridx) ? tap[i] : own;
+						}
+						const bool px_out = out_x || row_out;
 						if (strategy == TRANSLATE_NEAREST)
 						{
 							T e;
 							if constexpr (sizeof(T) == 8)
 							{
-								const uint64_t b = __builtin_bit_cast(uint64_t, tap[j]);
+								const uint64_t b = __builtin_bit_cast(uint64_t, own);
 								const uint32_t elo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, edge_lane & 63);
 								const uint32_t ehi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), edge_lane & 63);
 								e = __builtin_bit_cast(T, (uint64_t)elo | ((uint64_t)ehi << 32));
@@ -367,21 +385,22 @@ namespace rir
 							else
 							{
 								uint32_t b = 0;
-								__builtin_memcpy(&b, &tap[j], sizeof(T));
+								__builtin_memcpy(&b, &own, sizeof(T));
 								b = (uint32_t)__builtin_amdgcn_readlane((int)b, edge_lane & 63);
 								__builtin_memcpy(&e, &b, sizeof(T));
 							}
-							res = out_x ? tap_as<T, U>(e) : res;
+							// columns outside: the clamped column (one lane holds it); inside, on a row outside: the lane's own column
+							res = out_x ? tap_as<T, U>(e) : (row_out ? tap_as<T, U>(own) : res);
 						}
 						else if (strategy == TRANSLATE_CONSTANT)
-							res = out_x ? background : res;
+							res = px_out ? background : res;
 						else if (strategy == TRANSLATE_SOURCE)
 						{ // the input pixel at the output position (clamped address: the load is unconditional)
 							const T sp = s[(int64_t)min(y0 + j, h_ - 1) * w + min(x, w - 1)];
-							res = out_x ? tap_as<T, U>(sp) : res;
+							res = px_out ? tap_as<T, U>(sp) : res;
 						}
 						else
-							wr = wr && !out_x; // noborder: left untouched
+							wr = wr && !px_out; // noborder: left untouched
 						if (wr)
 							o[(int64_t)j * w] = res;
 					}
