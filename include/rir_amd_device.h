@@ -56,10 +56,12 @@ extern "C"
 	int rir_codec_encode_compact_device(int width, int height, int nframes, int gop, unsigned int *d_tile_off, unsigned long long *d_chunk_off,
 										unsigned long long *d_stream, void *d_workspace, long long workspace_bytes, void *stream);
 
-	/* *d_error (device int, zero it first) becomes 1 when a malformed table/record was met. */
+	/* *d_error (device int, zero it first) becomes 1 when a malformed table/record was met.  stream_words = number of
+	 * 64-bit words readable at d_stream: the tables are untrusted (they may come from a file) and a (chunk, tile)
+	 * segment that does not lie inside [0, stream_words) is rejected before anything is read through it. */
 	int rir_codec_decode_device(const unsigned long long *d_hdr, const unsigned int *d_tile_off, const unsigned long long *d_chunk_off,
-								const unsigned long long *d_stream, int width, int height, int nframes, int gop, unsigned short *d_frames,
-								int *d_error, void *stream);
+								const unsigned long long *d_stream, long long stream_words, int width, int height, int nframes, int gop,
+								unsigned short *d_frames, int *d_error, void *stream);
 
 	/* ---- frame-buffer kernels -------------------------------------------------------------------
 	 * translate: reference signal_processing.h:29 / Filters.h:249-326.  `type` is the numpy

@@ -129,21 +129,21 @@ RIR_EXPORT int rir_codec_encode_device(const unsigned short *d_frames, int width
 }
 
 RIR_EXPORT int rir_codec_decode_device(const unsigned long long *d_hdr, const unsigned int *d_tile_off, const unsigned long long *d_chunk_off,
-									   const unsigned long long *d_stream, int width, int height, int nframes, int gop,
-									   unsigned short *d_frames, int *d_error, void *stream)
+									   const unsigned long long *d_stream, long long stream_words, int width, int height, int nframes,
+									   int gop, unsigned short *d_frames, int *d_error, void *stream)
 {
 	if (!device_ready())
 		return -1;
 	rir_codec_layout L;
 	if (rir_codec_layout_query(width, height, nframes, gop, &L) != 0)
 		return -1;
-	if (!d_frames || !d_hdr || !d_tile_off || !d_chunk_off || !d_stream || !d_error)
+	if (!d_frames || !d_hdr || !d_tile_off || !d_chunk_off || !d_stream || !d_error || stream_words < 0)
 	{
-		log_error("rir_codec_decode_device: null buffer");
+		log_error("rir_codec_decode_device: null buffer or negative stream length");
 		return -1;
 	}
 	return hip_ok(launch_decode(reinterpret_cast<const uint64_t *>(d_hdr), d_tile_off, reinterpret_cast<const uint64_t *>(d_chunk_off), reinterpret_cast<const uint64_t *>(d_stream),
-								(int64_t)width * height, L.ntiles, nframes, gop, d_frames, d_error, as_stream(stream)),
+								(uint64_t)stream_words, (int64_t)width * height, L.ntiles, nframes, gop, d_frames, d_error, as_stream(stream)),
 				  "codec decode")
 			   ? 0
 			   : -1;

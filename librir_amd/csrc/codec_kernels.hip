@@ -952,8 +952,8 @@ namespace rir
 	// grid = (ceil(ntiles/4), nchunks), block = 256 (4 independent waves)
 	__global__ __launch_bounds__(256) void rirb1_decode_tiles(const uint64_t *__restrict__ hdr_table, const uint32_t *__restrict__ tile_off,
 															 const uint64_t *__restrict__ chunk_off, const uint64_t *__restrict__ stream,
-															 int64_t npx, int ntiles, int nframes, int gop, uint16_t *__restrict__ frames,
-															 int *__restrict__ error_flag)
+															 uint64_t stream_words, int64_t npx, int ntiles, int nframes, int gop,
+															 uint16_t *__restrict__ frames, int *__restrict__ error_flag)
 	{
 		const int lane = threadIdx.x & 63;
 		const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -966,14 +966,18 @@ namespace rir
 		const uint64_t *my_hdr = hdr_table + slot * gop;
 		const uint32_t t0 = tile_off[(int64_t)chunk * (ntiles + 1) + tile];
 		const uint32_t t1 = tile_off[(int64_t)chunk * (ntiles + 1) + tile + 1];
-		if (t1 < t0)
-		{ // malformed offsets table
+		const uint64_t c0 = chunk_off[chunk], c1 = chunk_off[chunk + 1];
+		// The tables are untrusted (they come from a file): the segment [c0 + t0, c0 + t1) must lie inside the chunk
+		// [c0, c1) and the chunk inside the stream allocation BEFORE a descriptor is built on it - the descriptor's
+		// num_records only bounds accesses relative to its base.
+		if (c0 > c1 || c1 > stream_words || t1 < t0 || (uint64_t)t1 > c1 - c0)
+		{ // malformed offsets tables
 			if (lane == 0)
 				atomicExch(error_flag, 1);
 			return;
 		}
 		const uint32_t seg_len = min(t1 - t0, (uint32_t)gop * RIRB1_REC_MAX_WORDS);
-		const uint64_t *in = stream + chunk_off[chunk] + t0;
+		const uint64_t *in = stream + c0 + t0;
 		const bool fast = ((npx & 7) == 0) && ((int64_t)(tile + 1) * RIRB1_TILE_PX <= npx) && ((((uintptr_t)frames) & 15) == 0);
 		if (fast)
 			decode_tile<true>(my_hdr, in, seg_len, npx, nf, f_begin, tile, lane, frames, error_flag);
@@ -1006,12 +1010,12 @@ namespace rir
 	}
 
 	hipError_t launch_decode(const uint64_t *d_hdr, const uint32_t *d_tile_off, const uint64_t *d_chunk_off, const uint64_t *d_stream,
-							 int64_t npx, int ntiles, int nframes, int gop, uint16_t *d_frames, int *d_error, hipStream_t st)
+							 uint64_t stream_words, int64_t npx, int ntiles, int nframes, int gop, uint16_t *d_frames, int *d_error, hipStream_t st)
 	{
 		const int nchunks = (nframes + gop - 1) / gop;
 		dim3 grid((ntiles + 3) / 4, nchunks), block(256);
-		hipLaunchKernelGGL(rirb1_decode_tiles, grid, block, 0, st, d_hdr, d_tile_off, d_chunk_off, d_stream, npx, ntiles, nframes, gop, d_frames,
-						   d_error);
+		hipLaunchKernelGGL(rirb1_decode_tiles, grid, block, 0, st, d_hdr, d_tile_off, d_chunk_off, d_stream, stream_words, npx, ntiles, nframes, gop,
+						   d_frames, d_error);
 		return hipGetLastError();
 	}
 } // namespace rir

@@ -1048,8 +1048,8 @@ namespace
 			const IndexEntry &e = index[c];
 			ChunkHeader ch;
 			if (!read_at(e.file_offset, &ch, sizeof(ch)) || std::memcmp(ch.magic, "CHNK", 4) != 0 || (int)ch.gop != cc.gop ||
-				(int)ch.ntiles != cc.L.ntiles || ch.nframes == 0 || (int)ch.nframes > cc.gop ||
-				ch.payload_words > (uint64_t)cc.L.stream_max_bytes / 8)
+				(int)ch.ntiles != cc.L.ntiles || ch.nframes == 0 || (int)ch.nframes > cc.gop || ch.nframes != e.nframes ||
+				ch.first_frame != e.first_frame || ch.payload_words > (uint64_t)cc.L.stream_max_bytes / 8)
 			{
 				log_error("RIRB file: corrupted chunk header");
 				return false;
@@ -1065,6 +1065,16 @@ namespace
 			off += toff.size() * 4;
 			if (ch.payload_words && !read_at(off, payload.data(), (size_t)ch.payload_words * 8))
 				return false;
+			// the offsets table comes from the file: monotone and ending exactly at the payload length, or the chunk is
+			// refused before anything reaches the device (the kernel checks again against the stream length it is given)
+			bool toff_ok = toff[0] == 0 && (uint64_t)toff[ch.ntiles] == ch.payload_words;
+			for (size_t t = 0; t < (size_t)ch.ntiles && toff_ok; ++t)
+				toff_ok = toff[t] <= toff[t + 1];
+			if (!toff_ok)
+			{
+				log_error("RIRB file: corrupted tile offsets");
+				return false;
+			}
 			hipStream_t st = default_stream();
 			const uint64_t coff[2] = {0, ch.payload_words};
 			const int zero = 0;
@@ -1075,7 +1085,7 @@ namespace
 				!hip_ok(hipMemcpyAsync(cc.d_err.ptr, &zero, sizeof(int), hipMemcpyHostToDevice, st), "H2D"))
 				return false;
 			if (rir_codec_decode_device(cc.d_hdr.as<unsigned long long>(), cc.d_tile_off.as<unsigned int>(), cc.d_chunk_off.as<unsigned long long>(),
-										cc.d_stream.as<unsigned long long>(), width, height, (int)ch.nframes, cc.gop, cc.d_frames.as<unsigned short>(),
+										cc.d_stream.as<unsigned long long>(), (long long)ch.payload_words, width, height, (int)ch.nframes, cc.gop, cc.d_frames.as<unsigned short>(),
 										cc.d_err.as<int>(), st) != 0)
 				return false;
 			// frames recorded with subtractMin: add the stored minimum back (IRFileLoader.cpp:1173-1179)

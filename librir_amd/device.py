@@ -63,7 +63,7 @@ _lib.rir_codec_layout_query.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, 
 _lib.rir_codec_encode_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, _vp, ct.c_longlong, _vp]
 _lib.rir_codec_encode_tiles_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, ct.c_longlong, _vp]
 _lib.rir_codec_encode_compact_device.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, ct.c_longlong, _vp]
-_lib.rir_codec_decode_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
+_lib.rir_codec_decode_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.rir_translate_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp, ct.c_int, _vp, ct.c_char_p, _vp]
 _lib.rir_gaussian_filter_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_float, _vp]
 _lib.rir_gaussian_filter_u16_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_float, _vp]
@@ -186,7 +186,7 @@ class CodecContext:
             self.error.zero_()
         _check(
             _lib.rir_codec_decode_device(
-                enc.hdr.data_ptr(), enc.tile_off.data_ptr(), enc.chunk_off.data_ptr(), enc.stream.data_ptr(), L.width, L.height,
+                enc.hdr.data_ptr(), enc.tile_off.data_ptr(), enc.chunk_off.data_ptr(), enc.stream.data_ptr(), enc.stream.numel(), L.width, L.height,
                 L.nframes, L.gop, out.data_ptr(), self.error.data_ptr(), _stream(),
             ),
             "rir_codec_decode_device",

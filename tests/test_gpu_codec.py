@@ -138,6 +138,44 @@ def test_malformed_tables_are_rejected_not_read_out_of_bounds(dev):
     assert torch.equal(ctx.decode(enc).view(torch.int16), fr.view(torch.int16))
 
 
+def test_offsets_that_point_outside_the_stream_are_rejected_before_any_read(dev):
+    """Tables come from files: a segment is only read when [chunk_off + tile_off[t], chunk_off + tile_off[t+1]) lies
+    inside its chunk and the chunk inside the `stream_words` the caller vouches for (two consecutive huge
+    tile_off entries used to put the buffer descriptor's base gigabytes past the allocation)."""
+    import torch
+
+    n, h, w, gop = 6, 32, 64, 3
+    fr = torch.from_numpy(np.random.default_rng(1).integers(0, 65536, (n, h, w)).astype(np.uint16)).cuda()
+    ctx = dev.CodecContext(w, h, n, gop)
+    enc = ctx.encode(fr)
+    torch.cuda.synchronize()
+    good_toff, good_coff = enc.tile_off.clone(), enc.chunk_off.clone()
+    words = enc.total_words()
+
+    def rejected():
+        with pytest.raises(RuntimeError):
+            ctx.decode(enc)
+        enc.tile_off.copy_(good_toff)
+        enc.chunk_off.copy_(good_coff)
+
+    # two consecutive huge entries: monotone (t1 >= t0), far outside the chunk
+    enc.tile_off[0, 1] = np.int32(-0x100)  # 0xFFFFFF00 as uint32
+    enc.tile_off[0, 2] = np.int32(-0x80)
+    rejected()
+    # a huge chunk offset (would move every segment of chunk 1 ~ 2^40 words away), and a decreasing pair
+    enc.chunk_off[1] = 1 << 40
+    enc.chunk_off[2] = (1 << 40) + int(good_coff[2] - good_coff[1])
+    rejected()
+    enc.chunk_off[1] = int(good_coff[2]) + 5
+    rejected()
+    # the caller's stream length is the bound: the same tables against a shorter stream are refused
+    short = dev.EncodedBatch(enc.layout, enc.hdr, enc.tile_off, enc.chunk_off, enc.stream[:words - 1])
+    with pytest.raises(RuntimeError):
+        ctx.decode(short)
+    exact = dev.EncodedBatch(enc.layout, enc.hdr, enc.tile_off, enc.chunk_off, enc.stream[:words])
+    assert torch.equal(ctx.decode(exact).view(torch.int16), fr.view(torch.int16))
+
+
 def test_argument_errors(dev):
     import torch
 
