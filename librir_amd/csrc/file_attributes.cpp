@@ -17,6 +17,10 @@ namespace rir
 	static const size_t MIN_SIZE_FOR_COMPRESSION = 1000;
 	static const uint64_t COMPRESSED_FLAG = 1ull << 63;
 
+	// zstd.h: ZSTD_CONTENTSIZE_UNKNOWN = 0ULL - 1, ZSTD_CONTENTSIZE_ERROR = 0ULL - 2
+	static const unsigned long long kZstdContentSizeUnknown = 0ULL - 1, kZstdContentSizeError = 0ULL - 2;
+	static const uint64_t kMaxAttributeBytes = 64ull << 20; // one attribute value, uncompressed
+
 	const ZstdApi &ZstdApi::get()
 	{
 		static ZstdApi api = []
@@ -113,8 +117,16 @@ namespace rir
 			const size_t clen = (size_t)s - 8;
 			p += s;
 			const ZstdApi &z = ZstdApi::get();
-			if (!z.ok || raw > (1ull << 32))
+			if (!z.ok)
 				return std::string();
+			// the declared size comes from the file: nothing is allocated from it before it has been checked against what
+			// the zstd frame itself says (when it says) and against a cap no attribute value comes near
+			const unsigned long long fcs = z.getFrameContentSize ? z.getFrameContentSize(c, clen) : kZstdContentSizeUnknown;
+			if (raw > kMaxAttributeBytes || fcs == kZstdContentSizeError || (fcs != kZstdContentSizeUnknown && fcs != raw))
+			{
+				ok = false;
+				return std::string();
+			}
 			std::string r((size_t)raw, '\0');
 			const size_t got = z.decompress(&r[0], r.size(), c, clen);
 			if (z.isError(got) || got != raw)

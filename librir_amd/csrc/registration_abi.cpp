@@ -23,12 +23,39 @@ namespace
 		DeviceBuffer gx, gy, partials, state, templ, image, mask, mm, full;
 		EccHostView *view = nullptr; // coherent page-locked host memory (64 bytes, kept for the life of the process), written by
 									  // ecc_solve_kernel, polled by run_ecc
+		// run_ecc returns as soon as the host view says "done", with the rest of its batch (no-op launches that still READ the
+		// shared state) queued on the caller's stream: the next call - possibly on another stream - waits for this event
+		// before it resets the state
+		hipEvent_t tail = nullptr;
+		bool tail_recorded = false;
 	};
 	EccScratch &scratch()
 	{
 		static EccScratch s;
 		return s;
 	}
+
+	// Stream ordering of the shared scratch (the host mutex only orders the CALLS): constructed, under the mutex, before an
+	// entry point queues anything that touches the scratch; makes `st` wait for everything the previous call queued and, on
+	// every exit, leaves the event behind the last launch of this call.
+	struct ScratchOrder
+	{
+		EccScratch &sc;
+		hipStream_t st;
+		bool ok = true;
+		ScratchOrder(EccScratch &s, hipStream_t stream) : sc(s), st(stream)
+		{
+			if (!sc.tail && !hip_ok(hipEventCreateWithFlags(&sc.tail, hipEventDisableTiming), "hipEventCreate"))
+				ok = false;
+			else if (sc.tail_recorded && !hip_ok(hipStreamWaitEvent(st, sc.tail, 0), "hipStreamWaitEvent"))
+				ok = false;
+		}
+		~ScratchOrder()
+		{
+			if (sc.tail)
+				sc.tail_recorded = hipEventRecord(sc.tail, st) == hipSuccess;
+		}
+	};
 
 #ifndef RIR_ECC_FIRST_BATCH
 #define RIR_ECC_FIRST_BATCH 6 /* alignments of a tracked sequence settle within 4-6 iterations: one read-back of the state instead of two */
@@ -112,6 +139,9 @@ RIR_EXPORT int rir_ecc_translation_device(const float *d_templ, const float *d_i
 	}
 	EccScratch &sc = scratch();
 	std::lock_guard<std::mutex> lock(sc.mu);
+	ScratchOrder order(sc, (hipStream_t)stream);
+	if (!order.ok)
+		return -1;
 	return run_ecc(sc, d_templ, d_image, d_mask, w, h, warp, max_iterations, eps, cc, iterations, (hipStream_t)stream);
 }
 
@@ -135,6 +165,9 @@ RIR_EXPORT int rir_ecc_register_frame_device(const void *d_img, int dtype, int w
 	hipStream_t st = (hipStream_t)stream;
 	EccScratch &sc = scratch();
 	std::lock_guard<std::mutex> lock(sc.mu);
+	ScratchOrder order(sc, st);
+	if (!order.ok)
+		return -1;
 	if (!sc.full.reserve((size_t)w * h * 4) || !sc.image.reserve((size_t)win_w * win_h * 4) || !sc.mm.reserve(2 * 64 * sizeof(float)))
 		return -1;
 	const float *g = nullptr;
@@ -174,6 +207,9 @@ RIR_EXPORT int find_transform_ecc_translation(const float *templ, const float *i
 	EccScratch &sc = scratch();
 	std::lock_guard<std::mutex> lock(sc.mu);
 	hipStream_t st = default_stream();
+	ScratchOrder order(sc, st);
+	if (!order.ok)
+		return -1;
 	const size_t npx = (size_t)w * h;
 	if (!sc.templ.reserve(npx * 4) || !sc.image.reserve(npx * 4) || (mask && !sc.mask.reserve(npx)))
 		return -1;
@@ -199,7 +235,8 @@ RIR_EXPORT int rir_minmax_normalize_device(const float *d_src, int w, int h, int
 	}
 	EccScratch &sc = scratch();
 	std::lock_guard<std::mutex> lock(sc.mu);
-	if (!sc.mm.reserve(2 * 64 * sizeof(float)))
+	ScratchOrder order(sc, (hipStream_t)stream);
+	if (!order.ok || !sc.mm.reserve(2 * 64 * sizeof(float)))
 		return -1;
 	return hip_ok(launch_minmax_normalize(d_src, w, h, src_stride, d_dst, sc.mm.as<float>(), (hipStream_t)stream), "minmax_normalize") ? 0 : -1;
 }

@@ -88,25 +88,37 @@ namespace
 		return k;
 	}
 
+	// Tables are cached per (device, sigma).  A caller keeps the shared_ptr until its kernel has been QUEUED; freeing a
+	// DeviceBuffer is a hipFree, which waits for the work already queued on the device - so an evicted table is never
+	// released under a kernel that reads it, whichever thread and stream that kernel runs on.
+	typedef std::shared_ptr<DeviceBuffer> GaussTable;
 	struct GaussCache
 	{
 		std::mutex mu;
-		std::map<uint32_t, std::shared_ptr<DeviceBuffer>> tables; // key = float bits of sigma
+		std::map<uint64_t, std::pair<GaussTable, uint64_t>> tables; // key = device id << 32 | float bits of sigma -> (table, last use)
+		uint64_t tick = 0;
 	};
 	GaussCache &gauss_cache()
 	{
 		static GaussCache c;
 		return c;
 	}
-	const float *gaussian_table_device(float sigma, int radius)
+	GaussTable gaussian_table_device(float sigma, int radius)
 	{
-		uint32_t key;
-		std::memcpy(&key, &sigma, 4);
+		uint32_t bits;
+		std::memcpy(&bits, &sigma, 4);
+		int dev = 0;
+		if (!hip_ok(hipGetDevice(&dev), "hipGetDevice"))
+			return nullptr;
+		const uint64_t key = ((uint64_t)(uint32_t)dev << 32) | bits;
 		GaussCache &c = gauss_cache();
 		std::lock_guard<std::mutex> g(c.mu);
 		auto it = c.tables.find(key);
 		if (it != c.tables.end())
-			return it->second->as<float>();
+		{
+			it->second.second = ++c.tick;
+			return it->second.first;
+		}
 		std::vector<float> k = gaussian_table(sigma, radius);
 		{ // 1-D factors a[-r..r] of the (separable) table, appended after it: k[dx][dy] ~ a[dx] * a[dy]
 			const int kw = 2 * radius + 1;
@@ -119,10 +131,16 @@ namespace
 			return nullptr;
 		if (!hip_ok(hipMemcpy(buf->ptr, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice), "gaussian table upload"))
 			return nullptr;
-		if (c.tables.size() > 64)
-			c.tables.clear();
-		c.tables[key] = buf;
-		return buf->as<float>();
+		if (c.tables.size() >= 64)
+		{ // least recently used entry out (its memory goes when the last holder drops it)
+			auto lru = c.tables.begin();
+			for (auto i = c.tables.begin(); i != c.tables.end(); ++i)
+				if (i->second.second < lru->second.second)
+					lru = i;
+			c.tables.erase(lru);
+		}
+		c.tables[key] = std::make_pair(buf, ++c.tick);
+		return buf;
 	}
 
 	// Scratch for the host-pointer entry points (one call at a time per process; the reference's
@@ -265,9 +283,10 @@ RIR_EXPORT int rir_gaussian_filter_device(const float *d_src, float *d_dst, int 
 		return -1;
 	}
 	const int radius = gaussian_radius(sigma);
-	const float *d_k = gaussian_table_device(sigma, radius);
-	if (!d_k)
+	const GaussTable table = gaussian_table_device(sigma, radius); // held until the launch below has been queued
+	if (!table)
 		return -1;
+	const float *d_k = table->as<float>();
 	return hip_ok(launch_gaussian(d_src, d_dst, w, h, nframes, d_k, radius, as_stream(stream)), "gaussian_filter") ? 0 : -1;
 }
 
@@ -282,9 +301,10 @@ RIR_EXPORT int rir_gaussian_filter_u16_device(const unsigned short *d_src, float
 		return -1;
 	}
 	const int radius = gaussian_radius(sigma);
-	const float *d_k = gaussian_table_device(sigma, radius);
-	if (!d_k)
+	const GaussTable table = gaussian_table_device(sigma, radius); // held until the launch below has been queued
+	if (!table)
 		return -1;
+	const float *d_k = table->as<float>();
 	return hip_ok(launch_gaussian_u16(d_src, d_dst, w, h, nframes, d_k, radius, as_stream(stream)), "gaussian_filter") ? 0 : -1;
 }
 
@@ -414,9 +434,10 @@ RIR_EXPORT int rir_filter_chain_device(int bad_pixels_handle, const unsigned sho
 	if (nbad > 0 && !bp->d_fix.reserve((size_t)nbad * nframes * sizeof(uint32_t)))
 		return -1;
 	const int radius = gaussian_radius(sigma);
-	const float *d_k = gaussian_table_device(sigma, radius);
-	if (!d_k)
+	const GaussTable table = gaussian_table_device(sigma, radius); // held until the launch below has been queued
+	if (!table)
 		return -1;
+	const float *d_k = table->as<float>();
 	const uint16_t back = background ? *static_cast<const uint16_t *>(background) : (uint16_t)0;
 	return hip_ok(launch_filter_chain(d_src, d_dst, w, h, nframes, bp ? bp->d_xy.as<int>() : nullptr, bp ? bp->d_row_start.as<int>() : nullptr, nbad,
 									  bp ? bp->floor_correct : 0, nbad > 0 ? bp->d_fix.as<uint32_t>() : nullptr, d_k, radius, d_offsets,
