@@ -6,13 +6,23 @@
 
 A "step" is one pass of the hot path over one device-resident batch: rir_codec_encode_device then
 rir_codec_decode_device on BASELINE.json configs[1] (1 000-frame 640x512 uint16 stream, recipe S1,
-SURVEY.md §8d) - per rank.  Ranks hold independent shards (weak scaling, no collective in the timed
-data path); the RCCL all-gather that reassembles the decoded stream is measured once after the
-timed region and reported beside it.
+SURVEY.md §8d) - per rank.  Ranks hold independent shards (weak scaling, no collective in that data path):
+`value` = frames all ranks processed / the slowest rank's time.
+
+N > 1 additionally times, in the same run and with the same bracket, the step WITH the exchange north_star names
+(every GPU ends up holding the whole decoded stream), in both forms of librir_amd/distributed.py:
+  value_with_exchange             encode, decode in sub-batches, all-gather of the DECODED frames per sub-batch on the
+                                  communicator's stream while the next sub-batch decodes
+  value_with_compressed_exchange  encode, all-gather of the COMPRESSED chunks in pieces, every rank decodes every
+                                  rank's chunks on arrival into the reassembled stream
+each with the bytes a rank receives, its GB/s and the fraction of the per-GPU xGMI budget.
 
 One JSON line is printed by rank 0: whole-job frames/s, plus
   roofline      - the dominant kernel's algorithmic bytes / its HIP-event duration vs 8 TB/s
-  cpu_baseline  - the oracle (plain-C port, 1 core) timed on a bounded sample of the same workload
+  cpu_baseline  - the oracle (plain-C port) timed on a bounded sample of the same workload: 1 core, and all cores of
+                  this process's CPU share over independent chunks; the compiled reference's filters when oracle/_ref
+                  travelled with the snapshot
+  per_frame_abi_fps / batched_h2d_d2h_fps - SURVEY §8d's other two numbers for the same configuration (N = 1)
 """
 import argparse
 import json
@@ -26,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+XGMI_IN_GBS = 7 * 76.8  # 7 links x 153.6 GB/s bidirectional = 76.8 GB/s inbound each: what one GPU can receive, peak
 
 
 def parse():
@@ -38,15 +49,46 @@ def parse():
     p.add_argument("--height", type=int, default=512)
     p.add_argument("--gop", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-abi", action="store_true", help="skip the per-frame / batched host-pointer numbers")
     p.add_argument("--cpu-frames", type=int, default=1000, help="frames of the same stream the CPU oracle works through per pass")
-    p.add_argument("--cpu-seconds", type=float, default=12.0, help="the CPU oracle repeats passes until this much time is spent")
+    p.add_argument("--cpu-seconds", type=float, default=10.0, help="the CPU oracle repeats passes until this much time is spent")
+    p.add_argument("--exchange-piece", type=int, default=100, help="frames per sub-batch of the decoded all-gather (whole chunks)")
+    p.add_argument("--exchange-chunks", type=int, default=4, help="chunks per piece of the compressed all-gather")
     return p.parse_args()
 
 
-def cpu_baseline(frames_np, gop, nframes, seconds):
-    """Oracle (CPU port of the same format) encode+decode, one core: whole passes over the first
-    `nframes` frames of the same stream until `seconds` of CPU work are spent (bounded sample)."""
+# ---- CPU baseline ------------------------------------------------------------------------------------------
+_CPU = {}
+
+
+def _cpu_worker(job):
+    """One process of the all-cores leg: whole passes over its own run of chunks until the deadline."""
+    first_chunk, nchunks, seconds = job
     from oracle.pyoracle import Oracle
+
+    O = Oracle()
+    fr, gop = _CPU["frames"], _CPU["gop"]
+    h, w = fr.shape[1:]
+    t0 = time.perf_counter()
+    done = 0
+    while True:
+        for c in range(first_chunk, first_chunk + nchunks):
+            hdr, off, st = O.codec_encode_chunk(fr[c * gop:(c + 1) * gop])
+            O.codec_decode_chunk(hdr, off, st, w, h)
+            done += gop
+        if time.perf_counter() - t0 >= seconds:
+            break
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline(frames_np, gop, nframes, seconds):
+    """Oracle (CPU port of the same format) encode+decode: whole passes over the first `nframes` frames of the same
+    stream until `seconds` of CPU work are spent (bounded sample) - on one core, then on every core of this process's
+    CPU share (independent chunks, one process per core).  Runs BEFORE the GPU is initialised (the worker processes
+    are forked)."""
+    import multiprocessing as mp
+
+    from oracle.pyoracle import Oracle, Ref
 
     O = Oracle()
     n = min(nframes, frames_np.shape[0])
@@ -65,6 +107,7 @@ def cpu_baseline(frames_np, gop, nframes, seconds):
             break
     dt = time.perf_counter() - t0
     assert np.array_equal(dec, frames_np[n - gop:n] if n >= gop else frames_np[:n])
+    share = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     out = {
         "value": done / dt,
         "unit": "frames/s",
@@ -72,8 +115,25 @@ def cpu_baseline(frames_np, gop, nframes, seconds):
         "kind": "port",
         "sample": "%d pass(es) over the first %d frames of the same S1 stream (%d frames), oracle/rir_oracle.c encode+decode, "
                   "1 thread, %.1f s" % (passes, n, done, dt),
+        "note": "the reference's own lossless codec (libx264 behind ffmpeg) cannot be built without network access: this is the "
+                "CPU port of THIS build's format, and zfile_zstd below the one reference codec path whose arithmetic is reachable",
         "host_cores_available": os.cpu_count(),
+        "host_cores_this_process_may_use": share,
     }
+    # all cores: one process per core over independent chunks (the reference's loops are single-threaded - its OpenMP
+    # pragmas are inert, signal_processing.cpp:111, Filters.h:252 - so this is what a user could get by hand)
+    nchunks = n // gop
+    procs = max(1, min(share, 32, nchunks))
+    if procs > 1 and nchunks >= procs:
+        _CPU["frames"], _CPU["gop"] = frames_np, gop
+        per = nchunks // procs
+        jobs = [(i * per, per, max(2.0, seconds * 0.6)) for i in range(procs)]
+        tw = time.perf_counter()
+        with mp.get_context("fork").Pool(procs) as pool:
+            res = pool.map(_cpu_worker, jobs)
+        wall = time.perf_counter() - tw
+        out["threads_all"] = {"value": sum(r[0] / r[1] for r in res), "unit": "frames/s", "cores": procs,
+                              "sample": "%d processes, %d chunk(s) each, %.1f s of work each (%.1f s wall incl. start-up)" % (procs, per, jobs[0][2], wall)}
     # the reachable reference codec arithmetic: ZFile method 1 = one-shot zstd per raw frame
     # (reference src/cpp/video_io/ZFile.cpp:483-542), through the host's libzstd if present
     try:
@@ -103,14 +163,83 @@ def cpu_baseline(frames_np, gop, nframes, seconds):
                              "libzstd": int(z.ZSTD_versionNumber()), "sample": "%d frames, level 0 one-shot per frame" % m}
     except Exception as e:  # libzstd absent: say so, do not fail the bench
         out["zfile_zstd"] = {"value": None, "note": "libzstd.so.1 not loadable: %s" % e}
+    # the compiled reference's filters (unmodified reference C++, oracle/_ref), when the .so travelled with the snapshot
+    if Ref.available():
+        R = Ref()
+        img = frames_np[0]
+        f32 = img.astype(np.float32)
+
+        def fps(fn, budget=1.5):
+            t0 = time.perf_counter()
+            k = 0
+            while time.perf_counter() - t0 < budget:
+                fn()
+                k += 1
+            return k / (time.perf_counter() - t0)
+
+        out["reference_filters"] = {
+            "unit": "frames/s", "cores": 1, "kind": "reference", "sample": "one %dx%d frame repeated for 1.5 s each" % (w, h),
+            "translate_u16_nearest": fps(lambda: R.translate(img, 1.25, -2.5, "nearest")),
+            "gaussian_filter_sigma_0.75": fps(lambda: R.gaussian_filter(f32, 0.75)),
+        }
+    else:
+        out["reference_filters"] = None
     return out
+
+
+def abi_numbers(frames_np, D, ctx, frames, out, n, h, w):
+    """SURVEY §8d (ii) and (iii) for the same configuration: batched host -> device -> host (pinned, PCIe inclusive) and the
+    per-frame C ABI as the wrapper drives it (IRSaver.add_image + IRMovie[i], one frame per call)."""
+    import tempfile
+
+    import torch
+
+    from librir_amd.video_io import IRMovie, IRSaver
+
+    res = {}
+    pin_in = torch.from_numpy(frames_np).pin_memory()
+    pin_out = torch.empty_like(pin_in)
+    enc0 = ctx.encode(frames)
+    pin_stream = torch.empty((int(enc0.total_words()) + 1024,), dtype=torch.int64).pin_memory()
+
+    def batched():
+        frames.copy_(pin_in, non_blocking=True)
+        enc = ctx.encode(frames)
+        nw = int(enc.total_words())  # sync: the host needs the size to fetch the stream
+        pin_stream[:nw].copy_(enc.stream[:nw], non_blocking=True)
+        enc.stream[:nw].copy_(pin_stream[:nw], non_blocking=True)  # the stream comes back from the host
+        ctx.decode(enc, out=out, check=False)
+        pin_out.copy_(out, non_blocking=True)
+
+    batched()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        batched()
+    torch.cuda.synchronize()
+    res["batched_h2d_d2h_fps"] = 3 * n / (time.perf_counter() - t0)
+    assert np.array_equal(pin_out.numpy(), frames_np)
+    with tempfile.TemporaryDirectory() as d:
+        dst = os.path.join(d, "abi.h264")
+        t0 = time.perf_counter()
+        with IRSaver(dst, w, h, h) as s:
+            for i in range(n):
+                s.add_image(frames_np[i], i * 1000)
+        te = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        with IRMovie.from_filename(dst) as mov:
+            for i in range(n):
+                img = mov[i]
+        td = time.perf_counter() - t0
+        assert np.array_equal(img, frames_np[n - 1])
+        res["per_frame_abi_fps"] = n / (te + td)
+        res["per_frame_abi_detail"] = {"frames": n, "record_fps": n / te, "read_fps": n / td,
+                                       "path": "IRSaver.add_image + IRMovie[i], file on the box's tmp filesystem"}
+    return res
 
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -118,6 +247,20 @@ def main():
         if rank == 0:
             sys.stderr.write("bench.py: WORLD_SIZE=%d but --gpus %d\n" % (world, args.gpus))
         sys.exit(2)
+
+    from librir_amd.synthetic import s1_noisy_background
+
+    n, h, w, gop = args.frames, args.height, args.width, args.gop
+    # every rank holds its own shard of the stream (different seed = different frames)
+    frames_np = s1_noisy_background(n, h, w, seed=1234 + rank)
+    # the CPU path is timed beside the N=1 run only, before this process touches the GPU (forked workers)
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline(frames_np, gop, args.cpu_frames, args.cpu_seconds)
+
+    import torch
+    import torch.distributed as dist
+
     # Rehearsal switches (never set by the driver): RIR_BENCH_BACKEND=gloo runs the N>1 control flow without RCCL,
     # RIR_BENCH_SHARE_GPU=1 lets every rank use GPU 0 of a one-GPU box.
     backend = os.environ.get("RIR_BENCH_BACKEND", "nccl")
@@ -132,20 +275,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    def all_gather_u8(dst_u8, src_u8):
-        if backend == "nccl":
-            dist.all_gather_into_tensor(dst_u8, src_u8)
-        else:  # rehearsal: gloo moves host memory
-            host = torch.empty(dst_u8.shape, dtype=torch.uint8)
-            dist.all_gather_into_tensor(host, src_u8.cpu())
-            dst_u8.copy_(host)
-
     from librir_amd import device as D
-    from librir_amd.synthetic import s1_noisy_background
+    from librir_amd.distributed import CompressedGather, FrameGather, shard_plan
 
-    n, h, w, gop = args.frames, args.height, args.width, args.gop
-    # every rank holds its own shard of the stream (different seed = different frames)
-    frames_np = s1_noisy_background(n, h, w, seed=1234 + rank)
     frames = torch.from_numpy(frames_np).to(dev)
     ctx = D.CodecContext(w, h, n, gop, device=dev)
     out = torch.empty_like(frames)
@@ -160,6 +292,13 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(dt):
+        if world == 1:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for _ in range(args.warmup):
         enc = step()
@@ -179,11 +318,7 @@ def main():
         ctx.decode(enc, out=out, check=False)
         ev[k][3].record()
     barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
 
     ms_tiles = sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(K)) / K
     ms_compact = sum(ev[k][1].elapsed_time(ev[k][2]) for k in range(K)) / K
@@ -197,19 +332,97 @@ def main():
     if not ok:
         raise SystemExit("bench.py: decode(encode(x)) != x - refusing to report a number")
 
-    # ---- the exchange step, outside the timed region: all-gather of the decoded stream ----
-    allgather = None
+    # ---- N > 1: the same step WITH the exchange, inside its own timed bracket (same K, same barriers) ----
+    exchange = None
     if world > 1:
-        gathered = torch.empty((world * out.shape[0],) + tuple(out.shape[1:]), dtype=torch.uint16, device=dev)
-        all_gather_u8(gathered.view(torch.uint8), out.view(torch.uint8))  # warm-up / communicator setup
-        barrier()
-        t1 = time.perf_counter()
-        all_gather_u8(gathered.view(torch.uint8), out.view(torch.uint8))
-        barrier()
-        ag = time.perf_counter() - t1
-        same = bool(torch.equal(gathered[rank * out.shape[0]:(rank + 1) * out.shape[0]].view(torch.int16), out.view(torch.int16)))
-        allgather = {"ms": ag * 1e3, "bytes_per_rank": out.numel() * 2 * world, "algbw_GBs": out.numel() * 2 * world / ag / 1e9,
-                     "own_shard_intact": same, "backend": "rccl" if backend == "nccl" else backend}
+        nchunks = ctx.layout.nchunks
+        piece = max(gop, (args.exchange_piece // gop) * gop)
+        while n % piece:
+            piece -= gop
+        cpp = piece // gop  # chunks per sub-batch of the decoded gather
+        # (first frame, count) of every local chunk: the sub-batch decode writes straight into `out`
+        cf_local = torch.tensor([[c * gop, min(gop, n - c * gop)] for c in range(nchunks)], dtype=torch.int64, device=dev)
+        fg = FrameGather(out, piece)
+
+        def produce(j, f0, f1):
+            c0 = f0 // gop
+            D.decode_chunks(enc.hdr[c0:c0 + cpp], enc.tile_off[c0:c0 + cpp], enc.chunk_off[c0:c0 + cpp + 1], enc.stream, cf_local[c0:c0 + cpp], out,
+                            gop, ctx.error)
+
+        def step_raw():
+            ctx.encode(frames)
+            fg.run(produce)
+
+        plan = shard_plan(n * world, gop, world)  # equal shards: rank r holds frames [r n, (r + 1) n) of the whole stream
+        full = torch.empty((n * world, h, w), dtype=torch.uint16, device=dev)
+        cg = CompressedGather(plan, gop, ctx.layout.ntiles, chunks_per_piece=args.exchange_chunks)
+
+        def consume(p):
+            D.decode_chunks(p.hdr, p.tile_off, p.chunk_off, p.stream, p.chunk_frames, full, gop, ctx.error)
+
+        def step_compressed():
+            e = ctx.encode(frames)
+            cg.run(e.hdr, e.tile_off, e.chunk_off, e.stream, consume)
+
+        def timed(fn):
+            for _ in range(max(1, min(args.warmup, 2))):
+                fn()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(K):
+                fn()
+            barrier()
+            return max_over_ranks(time.perf_counter() - t1)
+
+        ctx.error.zero_()
+        dt_raw = timed(step_raw)
+        own = fg.full[:, rank].reshape(n, h, w)
+        ok_raw = bool(torch.equal(own.view(torch.int16), frames.view(torch.int16))) and int(ctx.error.item()) == 0
+        dt_cmp = timed(step_compressed)
+        ok_cmp = bool(torch.equal(full[rank * n:(rank + 1) * n].view(torch.int16), frames.view(torch.int16))) and int(ctx.error.item()) == 0
+        # every rank's shard arrived intact everywhere: per-shard checksums of what each rank holds vs the owners' own sums
+        sums = torch.stack([full[r * n:(r + 1) * n].view(torch.int16).to(torch.int64).sum() for r in range(world)])
+        sums_raw = torch.stack([fg.full[:, r].reshape(-1).view(torch.int16).to(torch.int64).sum() for r in range(world)])
+        mine = frames.view(torch.int16).to(torch.int64).sum().reshape(1)
+        owners = torch.empty((world,), dtype=torch.int64, device=dev)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(owners, mine)
+        else:
+            hs = torch.empty((world,), dtype=torch.int64)
+            dist.all_gather_into_tensor(hs, mine.cpu())
+            owners = hs.to(dev)
+        ok_cmp = ok_cmp and bool(torch.equal(sums, owners))
+        ok_raw = ok_raw and bool(torch.equal(sums_raw, owners))
+        flags = torch.tensor([int(ok_raw), int(ok_cmp)], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+        if int(flags.min().item()) != 1:
+            raise SystemExit("bench.py: the exchanged stream differs from the owners' frames - refusing to report a number")
+
+        def link(bytes_received, seconds):
+            gbs = bytes_received * K / seconds / 1e9
+            return {"bytes_received_per_rank_per_step": bytes_received, "GBs_received_per_rank": gbs, "xgmi_inbound_peak_GBs": XGMI_IN_GBS,
+                    "frac_of_xgmi_inbound_peak": gbs / XGMI_IN_GBS}
+
+        exchange = {
+            "backend": "rccl" if backend == "nccl" else backend,
+            "value_with_exchange": n * K * world / dt_raw,
+            "ms_per_step_with_exchange": dt_raw / K * 1e3,
+            "decoded_allgather": dict(link(fg.bytes_received, dt_raw), sub_batch_frames=piece, sub_batches=len(fg.bounds),
+                                      layout="piece-major [sub-batch][rank][frame]", every_shard_intact_on_every_rank=True),
+            "value_with_compressed_exchange": n * K * world / dt_cmp,
+            "ms_per_step_with_compressed_exchange": dt_cmp / K * 1e3,
+            "compressed_allgather": dict(link(cg.bytes_received, dt_cmp), chunks_per_piece=cg.m, pieces=len(cg.pieces),
+                                         layout="stream order [rank][frame], decoded on arrival", every_shard_intact_on_every_rank=True,
+                                         frames_decoded_per_rank_per_step=n * world),
+            "note": "`value` is the sharded path (no collective: each rank encodes+decodes its own chunks). With the whole decoded stream "
+                    "reassembled on EVERY GPU each rank must receive (N-1)/N of it: the job's rate is bounded by "
+                    "xGMI inbound bandwidth / ((N-1)/N x 655 360 B) for decoded frames, and by N decodes per rank for compressed chunks "
+                    "(DESIGN.md §6)",
+        }
+
+    extra = {}
+    if world == 1 and not args.no_abi:
+        extra = abi_numbers(frames_np, D, ctx, frames, out, n, h, w)
 
     if rank == 0:
         raw = 2.0 * h * w * n  # bytes of raw uint16 per batch
@@ -246,7 +459,9 @@ def main():
             "dtype": "u16",
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d-frame %dx%d uint16 stream (S1 noisy background, seed 1234+rank), lossless RIRB1 "
-                                   "encode+decode, device-resident, GOP %d, per GPU" % (n, w, h, gop),
+                                   "encode+decode, device-resident, GOP %d, per GPU; the compressed stream (17 %% of a pass's bytes) is "
+                                   "written by the encoder and read back by the decoder through the 256 MiB Infinity Cache, the raw "
+                                   "frames (655 MB each way) stream from / to HBM" % (n, w, h, gop),
                        "frames_per_gpu": n, "width": w, "height": h, "gop": gop, "sharding": "independent shard per rank"},
             "bit_exact_roundtrip": True,
             "compression_ratio": raw / cbytes,
@@ -254,13 +469,16 @@ def main():
             "roundtrip_raw_frac_of_hbm_peak": fps * 4.0 * h * w / 1e9 / world / HBM_PEAK_GBS,
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kernels[dom]["GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": ("%s (static: rocprofv3 --pmc passes of an earlier run of this command, not measured in this run)"
+                                            % os.path.relpath(tpath, ROOT)) if traffic is not None else None,
                          "alg_bytes_per_launch": kernels[dom]["alg_bytes"], "ms_per_launch": kernels[dom]["ms"]},
             "kernels": kernels,
         }
-        if allgather:
-            res["allgather_decoded_stream"] = allgather
-        if not args.no_cpu_baseline and world == 1:  # the CPU path is timed beside the N=1 run only
-            res["cpu_baseline"] = cpu_baseline(frames_np, gop, args.cpu_frames, args.cpu_seconds)
+        res.update(extra)
+        if exchange:
+            res.update(exchange)
+        if cpu is not None:
+            res["cpu_baseline"] = cpu
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

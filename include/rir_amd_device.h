@@ -63,6 +63,15 @@ extern "C"
 								const unsigned long long *d_stream, long long stream_words, int width, int height, int nframes, int gop,
 								unsigned short *d_frames, int *d_error, void *stream);
 
+	/* Decode of chunks that do not form one contiguous batch - chunks gathered from several shards (the exchange step of
+	 * the multi-GPU path, reference chunk independence h264.cpp:1052-1064), or a selection of a file's chunks.  Entry k of
+	 * the tables is one chunk (hdr[k][ntiles][gop], tile_off[k][ntiles+1], chunk_off[k..k+1]); d_chunk_frames[2k] /
+	 * [2k+1] = first frame / frame count (<= gop, 0 = skip) of that chunk inside d_frames (frames_capacity frames). */
+	int rir_codec_decode_chunks_device(const unsigned long long *d_hdr, const unsigned int *d_tile_off, const unsigned long long *d_chunk_off,
+									   const unsigned long long *d_stream, long long stream_words, int width, int height, int nchunks, int gop,
+									   const long long *d_chunk_frames, long long frames_capacity, unsigned short *d_frames, int *d_error,
+									   void *stream);
+
 	/* ---- frame-buffer kernels -------------------------------------------------------------------
 	 * translate: reference signal_processing.h:29 / Filters.h:249-326.  `type` is the numpy
 	 * dtype char ('?','b','B','h','H','i','I','l','L','f','d'); d_offsets holds float (dx,dy)

@@ -143,8 +143,36 @@ RIR_EXPORT int rir_codec_decode_device(const unsigned long long *d_hdr, const un
 		return -1;
 	}
 	return hip_ok(launch_decode(reinterpret_cast<const uint64_t *>(d_hdr), d_tile_off, reinterpret_cast<const uint64_t *>(d_chunk_off), reinterpret_cast<const uint64_t *>(d_stream),
-								(uint64_t)stream_words, (int64_t)width * height, L.ntiles, nframes, gop, d_frames, d_error, as_stream(stream)),
+								(uint64_t)stream_words, (int64_t)width * height, L.ntiles, nframes, gop, nullptr, 0, d_frames, d_error, as_stream(stream)),
 				  "codec decode")
+			   ? 0
+			   : -1;
+}
+
+// Decode of chunks that do not form one contiguous batch (chunks gathered from several shards, a selection of a file's
+// chunks): table entry k describes one chunk - hdr[k][ntiles][gop], tile_off[k][ntiles+1], chunk_off[k], chunk_off[k+1] -
+// and d_chunk_frames[2k], [2k+1] = (first frame, frame count <= gop; 0 = skip the entry) say where its frames go in
+// d_frames, which holds frames_capacity frames.  Same checks as rir_codec_decode_device; an entry that does not fit
+// d_frames raises *d_error.
+RIR_EXPORT int rir_codec_decode_chunks_device(const unsigned long long *d_hdr, const unsigned int *d_tile_off, const unsigned long long *d_chunk_off,
+											  const unsigned long long *d_stream, long long stream_words, int width, int height, int nchunks, int gop,
+											  const long long *d_chunk_frames, long long frames_capacity, unsigned short *d_frames, int *d_error,
+											  void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (!d_frames || !d_hdr || !d_tile_off || !d_chunk_off || !d_stream || !d_error || !d_chunk_frames || stream_words < 0 || width <= 0 ||
+		height <= 0 || nchunks <= 0 || nchunks > 65535 || gop <= 0 || frames_capacity <= 0 || frames_capacity > 0x7fffffffLL)
+	{
+		log_error("rir_codec_decode_chunks_device: invalid argument");
+		return -1;
+	}
+	const int64_t npx = (int64_t)width * height;
+	const int ntiles = (int)((npx + RIRB1_TILE_PX - 1) / RIRB1_TILE_PX);
+	return hip_ok(launch_decode(reinterpret_cast<const uint64_t *>(d_hdr), d_tile_off, reinterpret_cast<const uint64_t *>(d_chunk_off),
+								reinterpret_cast<const uint64_t *>(d_stream), (uint64_t)stream_words, npx, ntiles, (int)frames_capacity, gop,
+								reinterpret_cast<const int64_t *>(d_chunk_frames), nchunks, d_frames, d_error, as_stream(stream)),
+				  "codec decode (chunks)")
 			   ? 0
 			   : -1;
 }

@@ -953,15 +953,32 @@ namespace rir
 	__global__ __launch_bounds__(256) void rirb1_decode_tiles(const uint64_t *__restrict__ hdr_table, const uint32_t *__restrict__ tile_off,
 															 const uint64_t *__restrict__ chunk_off, const uint64_t *__restrict__ stream,
 															 uint64_t stream_words, int64_t npx, int ntiles, int nframes, int gop,
-															 uint16_t *__restrict__ frames, int *__restrict__ error_flag)
+															 const int64_t *__restrict__ chunk_frames, uint16_t *__restrict__ frames,
+															 int *__restrict__ error_flag)
 	{
 		const int lane = threadIdx.x & 63;
 		const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 		if (tile >= ntiles)
 			return;
 		const int chunk = blockIdx.y;
-		const int f_begin = chunk * gop;
-		const int nf = min(gop, nframes - f_begin);
+		// chunk -> frames of the output: consecutive runs of `gop` frames, or (chunk_frames != NULL, nframes = capacity of
+		// `frames`) an explicit (first frame, frame count) pair per chunk - chunks gathered from several shards decode
+		// straight to their place in the reassembled stream
+		int64_t f_begin = (int64_t)chunk * gop;
+		int nf = (int)min((int64_t)gop, (int64_t)nframes - f_begin);
+		if (chunk_frames)
+		{
+			const int64_t cf = chunk_frames[2 * chunk], cn = chunk_frames[2 * chunk + 1];
+			if (cn == 0)
+				return; // padding entry
+			if (cf < 0 || cn < 0 || cn > gop || cf > (int64_t)nframes - cn)
+			{
+				if (lane == 0)
+					atomicExch(error_flag, 1);
+				return;
+			}
+			f_begin = cf, nf = (int)cn;
+		}
 		const int64_t slot = (int64_t)chunk * ntiles + tile;
 		const uint64_t *my_hdr = hdr_table + slot * gop;
 		const uint32_t t0 = tile_off[(int64_t)chunk * (ntiles + 1) + tile];
@@ -1010,12 +1027,13 @@ namespace rir
 	}
 
 	hipError_t launch_decode(const uint64_t *d_hdr, const uint32_t *d_tile_off, const uint64_t *d_chunk_off, const uint64_t *d_stream,
-							 uint64_t stream_words, int64_t npx, int ntiles, int nframes, int gop, uint16_t *d_frames, int *d_error, hipStream_t st)
+							 uint64_t stream_words, int64_t npx, int ntiles, int nframes, int gop, const int64_t *d_chunk_frames, int nchunks_tab,
+							 uint16_t *d_frames, int *d_error, hipStream_t st)
 	{
-		const int nchunks = (nframes + gop - 1) / gop;
+		const int nchunks = d_chunk_frames ? nchunks_tab : (nframes + gop - 1) / gop;
 		dim3 grid((ntiles + 3) / 4, nchunks), block(256);
 		hipLaunchKernelGGL(rirb1_decode_tiles, grid, block, 0, st, d_hdr, d_tile_off, d_chunk_off, d_stream, stream_words, npx, ntiles, nframes, gop,
-						   d_frames, d_error);
+						   d_chunk_frames, d_frames, d_error);
 		return hipGetLastError();
 	}
 } // namespace rir

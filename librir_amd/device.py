@@ -64,6 +64,8 @@ _lib.rir_codec_encode_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c
 _lib.rir_codec_encode_tiles_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, ct.c_longlong, _vp]
 _lib.rir_codec_encode_compact_device.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, ct.c_longlong, _vp]
 _lib.rir_codec_decode_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
+_lib.rir_codec_decode_chunks_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, ct.c_longlong, _vp,
+                                                _vp, _vp]
 _lib.rir_translate_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp, ct.c_int, _vp, ct.c_char_p, _vp]
 _lib.rir_gaussian_filter_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_float, _vp]
 _lib.rir_gaussian_filter_u16_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_float, _vp]
@@ -194,6 +196,22 @@ class CodecContext:
         if check and int(self.error.item()) != 0:
             raise RuntimeError("rir_codec_decode_device: malformed stream")
         return out
+
+
+def decode_chunks(hdr, tile_off, chunk_off, stream, chunk_frames, out, gop, error):
+    """Chunks that do not form one contiguous batch (gathered from several shards): table entry k = one chunk,
+    ``chunk_frames[k] = (first frame, frame count)`` inside ``out`` (N, H, W) uint16.  ``error``: int32[1] device tensor,
+    raised to 1 on malformed tables; asynchronous on the current stream (rir_codec_decode_chunks_device)."""
+    n, h, w = out.shape
+    nchunks = chunk_frames.shape[0]
+    if hdr.shape[0] < nchunks or tile_off.shape[0] < nchunks or chunk_off.numel() < nchunks + 1 or chunk_frames.dtype != torch.int64:
+        raise RuntimeError("decode_chunks: tables do not cover the chunks")
+    _check(
+        _lib.rir_codec_decode_chunks_device(hdr.data_ptr(), tile_off.data_ptr(), chunk_off.data_ptr(), stream.data_ptr(), stream.numel(), w, h,
+                                            nchunks, gop, chunk_frames.data_ptr(), n, out.data_ptr(), error.data_ptr(), _stream()),
+        "rir_codec_decode_chunks_device",
+    )
+    return out
 
 
 def translate(frames, offsets, strategy="", background=0):

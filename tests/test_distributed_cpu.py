@@ -1,6 +1,7 @@
-"""CPU, world_size 2, gloo: the sharding plan and the all-gather that reassembles the decoded
-stream (the N>1 path of bench.py / DESIGN.md §6).  The codec itself is not run here (GPU only):
-each rank fabricates the frames of its shard from the global frame index."""
+"""CPU, world_size 2, gloo: the sharding plan and the two exchange steps that reassemble the stream on every rank
+(the N>1 path of bench.py / DESIGN.md §6): the all-gather of decoded frames, whole and in overlapped sub-batches,
+and the all-gather of COMPRESSED chunks decoded on arrival.  The HIP codec is not run here (GPU only): frames are
+fabricated from the global frame index, and the compressed exchange is checked with the oracle as encoder/decoder."""
 import os
 
 import numpy as np
@@ -9,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from librir_amd.distributed import all_gather_frames, shard_plan
+from librir_amd.distributed import CompressedGather, FrameGather, all_gather_frames, shard_plan
 
 
 def test_shard_plan_is_chunk_aligned_and_covers_everything():
@@ -53,4 +54,103 @@ def test_all_gather_reassembles_the_stream_world2(nframes, gop):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, nframes, gop, 6, 9, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def _piece_worker(rank, world, port, ret):
+    """FrameGather: pieces gathered while the next one is produced; piece-major layout, every frame accounted for."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, h, w, piece = 12, 5, 7, 4
+        local = torch.zeros((n, h, w), dtype=torch.uint16)
+        fg = FrameGather(local, piece)
+        calls = []
+
+        def produce(j, f0, f1):
+            calls.append((j, f0, f1))
+            for f in range(f0, f1):
+                local[f] = (rank * 1000 + f) % 65536
+
+        full = fg.run(produce)
+        ok = calls == [(0, 0, 4), (1, 4, 8), (2, 8, 12)] and tuple(full.shape) == (3, world, piece, h, w)
+        for r in range(world):
+            for f in range(n):
+                ok = ok and int(full[fg.locate(r, f)][0, 0]) == r * 1000 + f
+        ret[rank] = bool(ok) and fg.bytes_received == (world - 1) * n * h * w * 2
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sub_batched_frame_gather_world2():
+    world = 2
+    port = 29500 + (os.getpid() + 777) % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_piece_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def _compressed_worker(rank, world, port, nframes, gop, h, w, per_piece, ret):
+    """Every rank encodes its shard with the oracle, the compressed chunks are gathered piece by piece and decoded on
+    arrival (oracle again) into their place in the whole stream - on every rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from librir_amd.synthetic import s1_noisy_background
+        from oracle.pyoracle import Oracle
+
+        O = Oracle()
+        whole = s1_noisy_background(nframes, h, w, seed=5)
+        plan = shard_plan(nframes, gop, world)
+        start, count = plan[rank]
+        ntiles = (h * w + 511) // 512
+        nc = (count + gop - 1) // gop
+        hdr = np.zeros((max(nc, 1), ntiles, gop), np.uint64)
+        toff = np.zeros((max(nc, 1), ntiles + 1), np.uint32)
+        coff = np.zeros(nc + 1, np.int64)
+        words = []
+        for k in range(nc):
+            fr = whole[start + k * gop:min(start + (k + 1) * gop, start + count)]
+            hk, ok_, sk = O.codec_encode_chunk(fr)
+            hdr[k, :, : fr.shape[0]] = hk
+            toff[k] = ok_
+            words.append(sk)
+            coff[k + 1] = coff[k] + sk.size
+        stream = np.concatenate(words + [np.zeros(0, np.uint64)]) if words else np.zeros(0, np.uint64)
+        out = np.zeros_like(whole)
+        seen = []
+
+        def consume(p):
+            st = p.stream.numpy().view(np.uint64)
+            for e in range(p.chunk_frames_host.shape[0]):
+                f0, cnt = (int(v) for v in p.chunk_frames_host[e])
+                if cnt == 0:
+                    continue
+                c0, c1 = int(p.chunk_off_host[e]), int(p.chunk_off_host[e + 1])
+                hd = np.ascontiguousarray(p.hdr[e].numpy().view(np.uint64)[:, :cnt])
+                out[f0:f0 + cnt] = O.codec_decode_chunk(hd, p.tile_off[e].numpy().view(np.uint32), st[c0:c1], w, h)
+                seen.append((f0, cnt))
+
+        cg = CompressedGather(plan, gop, ntiles, chunks_per_piece=per_piece)
+        cg.run(torch.from_numpy(hdr.view(np.int64)), torch.from_numpy(toff.view(np.int32)), torch.from_numpy(coff),
+               torch.from_numpy(stream.view(np.int64)), consume)
+        ok = np.array_equal(out, whole) and sum(c for _, c in seen) == nframes and cg.bytes_received > 0
+        # the point of the exercise: fewer bytes on the links than the decoded frames would take
+        if nframes - count >= 2 * gop:  # (a rank that receives (almost) nothing still moves its padded tables)
+            ok = ok and cg.bytes_received < (nframes - count) * h * w * 2
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nframes,gop,per_piece,shape", [(50, 10, 2, (768, 1024)), (35, 10, 4, (67, 83)), (10, 10, 1, (32, 64))])
+def test_compressed_chunks_gathered_and_decoded_on_arrival_world2(nframes, gop, per_piece, shape):
+    """(50, 10): 5 chunks over 2 ranks = 3 + 2 (a padding entry in the last piece) at the config-3 frame geometry 1024x768;
+    (35, 10): a short last chunk; (10, 10): one rank has no frames at all."""
+    world = 2
+    port = 29500 + (os.getpid() + nframes * 7 + per_piece) % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_compressed_worker, args=(world, port, nframes, gop, shape[0], shape[1], per_piece, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)

@@ -128,3 +128,51 @@ def test_config4_motion_correction_then_bounded_loss(tmp_path, dev, oracle):
         got = mov.data
     assert np.array_equal(got, exp)
     assert np.abs(got.astype(np.int32) - reg_ref).max() <= 6
+
+
+def test_config4_full_size_chain_registration_correction_bounded_loss(tmp_path, dev, oracle):
+    """BASELINE configs[4] as ONE chain at its stated frame size: 100 float32 frames 640x512 of the registration recipe ->
+    ECC registration (frames in HBM) -> motion correction -> bounded-loss recording -> read back.  Registration is
+    floating point (checked against the oracle's ECC on sampled frames, 1e-4 px); everything downstream of the shifts is
+    integer work and bit-exact against the oracle fed with the same shifts."""
+    from librir_amd.registration import DeviceRegistratorECC
+
+    n, h, w = 100, 512, 640
+    f32, shifts = s3_registration(n, h, w)
+    t32 = torch.from_numpy(f32).to("cuda")
+    reg = DeviceRegistratorECC(1, 1)
+    reg.termination_eps = 1e-7
+    reg.start(t32[0])
+    for i in range(1, n):
+        reg.compute(t32[i])
+    x, y = np.array(reg.x, np.float32), np.array(reg.y, np.float32)
+    assert np.abs(x - shifts[:, 0]).max() <= 0.15 and np.abs(y - shifts[:, 1]).max() <= 0.15
+
+    def norm(a):
+        return (a - a.min()) / (a.max() - a.min())
+
+    ref0 = norm(oracle.gaussian_filter(f32[0], reg.sigma))
+    for i in (1, 10):  # the oracle's ECC from the start value the tracked sequence used (no change of reference before frame 20)
+        im = norm(oracle.gaussian_filter(f32[i], reg.sigma))
+        tx, ty, _, _ = oracle.ecc_translation(ref0, im, (float(x[i - 1]), float(y[i - 1])), max_iter=reg.number_of_iterations,
+                                              eps=reg.termination_eps)
+        assert abs(tx - x[i]) < 1e-3 and abs(ty - y[i]) < 1e-3, (i, tx, x[i], ty, y[i])
+    # digital levels (the wrapper's astype(np.uint16)), corrected on the device with the registration's own shifts
+    u16 = np.clip(f32, 0, 65535).astype(np.uint16)
+    sh = np.stack([x, y], axis=1).astype(np.float32)
+    reg_gpu = D.remove_motion(torch.from_numpy(u16).to("cuda"), torch.from_numpy(sh).to("cuda"), rows=h - 3).cpu().numpy()
+    reg_ref = np.stack([oracle.remove_motion(u16[i], float(sh[i, 0]), float(sh[i, 1]), rows=h - 3) for i in range(n)])
+    assert np.array_equal(reg_gpu, reg_ref)
+    L = OracleLossy(oracle, w, h, h - 3, low_err=3, high_err=3, std_factor=0.0, running_average=32)
+    exp = np.stack([L.step(reg_ref[i]) for i in range(n)])
+    dst = tmp_path / "cfg4_full.h264"
+    with IRSaver(dst, w, h, h - 3) as s:
+        s.set_parameter("lowValueError", 3)
+        s.set_parameter("highValueError", 3)
+        s.set_parameter("stdFactor", 0)
+        for i in range(n):
+            s.add_image_lossy(reg_gpu[i], i * 1000)
+    with IRMovie.from_filename(dst) as mov:
+        got = mov.data
+    assert np.array_equal(got, exp)
+    assert np.abs(got.astype(np.int32) - reg_ref).max() <= 6

@@ -127,7 +127,9 @@ def test_device_batch_vs_oracle(dev, oracle, shape):
     assert np.array_equal(g, np.stack([oracle.translate(img16[i], offs[i, 0], offs[i, 1], "nearest") for i in range(3)]))
     f32 = (rng.random((2, h, w)) * 1000).astype(np.float32)
     tf = torch.from_numpy(f32).cuda()
-    for s in [0.5, 0.75, 1.0, 2.0]:
+    # every code path of the radius rule (signal_processing.cpp:79-99): r = 1, 1, 2, 3 (gaussian_sep_kernel<3>), 4 and
+    # r = 6 (> 4: the direct 2-D kernel)
+    for s in [0.5, 0.75, 1.0, 1.7, 2.0, 3.3]:
         g = dev.gaussian_filter(tf, s).cpu().numpy()
         r = np.stack([oracle.gaussian_filter(f32[i], s) for i in range(2)])
         assert np.allclose(g, r, rtol=1e-5, atol=0) and np.abs(g - r).max() <= 2e-6 * np.abs(r).max(), s
