@@ -28,7 +28,7 @@ COMMON = [
     "-Wno-unused-function",
     "-I" + CSRC,
     "-I" + os.path.join(ROOT, "include"),
-]
+] + os.environ.get("RIR_EXTRA_CFLAGS", "").split()
 
 
 def sources():

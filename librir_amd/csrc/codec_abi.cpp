@@ -1,6 +1,7 @@
 // C ABI of the block codec on device-resident batches (format RIRB1).
 // Host-pointer / file-level entry points (h264_add_image_lossless, load_image, ...) are in
 // video_io_abi.cpp and call these.
+#include <cstdlib>
 #include <cstring>
 
 #include "codec_format.h"
@@ -37,9 +38,10 @@ RIR_EXPORT int rir_codec_layout_query(int width, int height, int nframes, int go
 	out->tile_off_bytes = (int64_t)out->nchunks * (out->ntiles + 1) * 4;
 	out->chunk_off_bytes = (int64_t)(out->nchunks + 1) * 8;
 	out->stream_max_bytes = slots * gop * RIRB1_REC_MAX_WORDS * 8;
-	// workspace = sparse slots (padded stride, codec_format.h) + seg_words + chunk_words
-	out->workspace_bytes = (int64_t)(align256((size_t)(slots * RIRB1_SLOT_WORDS(gop) * 8)) + align256((size_t)slots * 4) +
-									 align256((size_t)out->nchunks * 8));
+	// workspace = look-back control block (first: it is zeroed by a memset before every launch) + spill slots (padded stride,
+	// codec_format.h) + seg_words + chunk_words
+	out->workspace_bytes = (int64_t)(align256((size_t)encode_ctrl_bytes(out->nchunks, out->ntiles)) + align256((size_t)(slots * RIRB1_SLOT_WORDS(gop) * 8)) +
+									 align256((size_t)slots * 4) + align256((size_t)out->nchunks * 8));
 	return 0;
 }
 
@@ -47,6 +49,7 @@ namespace
 {
 	struct Workspace
 	{
+		uint64_t *ctrl;
 		uint64_t *sparse;
 		uint32_t *seg_words;
 		uint64_t *chunk_words;
@@ -56,6 +59,8 @@ namespace
 		if (!d_workspace || workspace_bytes < L.workspace_bytes)
 			return false;
 		char *ws = static_cast<char *>(d_workspace);
+		w.ctrl = reinterpret_cast<uint64_t *>(ws);
+		ws += align256((size_t)encode_ctrl_bytes(L.nchunks, L.ntiles));
 		w.sparse = reinterpret_cast<uint64_t *>(ws);
 		ws += align256((size_t)((int64_t)L.nchunks * L.ntiles * RIRB1_SLOT_WORDS(L.gop) * 8));
 		w.seg_words = reinterpret_cast<uint32_t *>(ws);
@@ -123,9 +128,29 @@ RIR_EXPORT int rir_codec_encode_device(const unsigned short *d_frames, int width
 									   unsigned int *d_tile_off, unsigned long long *d_chunk_off, unsigned long long *d_stream,
 									   void *d_workspace, long long workspace_bytes, void *stream)
 {
-	if (rir_codec_encode_tiles_device(d_frames, width, height, nframes, gop, d_hdr, d_workspace, workspace_bytes, stream) != 0)
+	static const bool legacy = getenv("RIR_ENCODER") && std::strcmp(getenv("RIR_ENCODER"), "legacy") == 0;
+	if (legacy)
+	{
+		if (rir_codec_encode_tiles_device(d_frames, width, height, nframes, gop, d_hdr, d_workspace, workspace_bytes, stream) != 0)
+			return -1;
+		return rir_codec_encode_compact_device(width, height, nframes, gop, d_tile_off, d_chunk_off, d_stream, d_workspace, workspace_bytes, stream);
+	}
+	if (!device_ready())
 		return -1;
-	return rir_codec_encode_compact_device(width, height, nframes, gop, d_tile_off, d_chunk_off, d_stream, d_workspace, workspace_bytes, stream);
+	rir_codec_layout L;
+	Workspace w;
+	if (rir_codec_layout_query(width, height, nframes, gop, &L) != 0 || !check_geometry(L))
+		return -1;
+	if (!d_frames || !d_hdr || !d_tile_off || !d_chunk_off || !d_stream || !carve(L, d_workspace, workspace_bytes, w))
+	{
+		log_error("rir_codec_encode_device: null buffer or workspace too small");
+		return -1;
+	}
+	return hip_ok(launch_encode_dense(d_frames, (int64_t)width * height, L.ntiles, nframes, gop, reinterpret_cast<uint64_t *>(d_hdr), d_tile_off,
+									  reinterpret_cast<uint64_t *>(d_chunk_off), reinterpret_cast<uint64_t *>(d_stream), w.ctrl, w.sparse, as_stream(stream)),
+				  "codec encode")
+			   ? 0
+			   : -1;
 }
 
 RIR_EXPORT int rir_codec_decode_device(const unsigned long long *d_hdr, const unsigned int *d_tile_off, const unsigned long long *d_chunk_off,

@@ -21,6 +21,7 @@
 //   * 4 independent waves per 256-thread workgroup; grid = (ntiles/4) x nchunks >> 256 CUs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "codec_format.h"
 #include "filter_kernels.h"
@@ -756,6 +757,499 @@ namespace rir
 			dst[i] = RIR_COMPACT_NT_LOAD ? __builtin_nontemporal_load(src + i) : src[i];
 	}
 
+	// ==== single-pass dense encoder ===================================================================
+	//
+	// One WORKGROUP owns one (chunk, tile) segment; its WAVES waves split the chunk's frames in time (wave 0 takes the
+	// key frame, a later wave loads the frame before its first one as its starting `prev`).  The payload words of the
+	// segment are staged in LDS (R words per wave; what does not fit goes to a spill slot in the workspace - noisy data
+	// degrades to the traffic of a two-pass layout, the reference's recipe never spills).  When a workgroup has packed
+	// its frames it knows the length of its segment, publishes it, and looks back for the lengths of the segments in
+	// front of it (decoupled look-back): the sum is its place in the dense stream, to which it copies its words from LDS.
+	// The stream, tile_off and chunk_off are bit-identical to the two-pass layout (scan + gather) this replaces.
+	//
+	// Look-back state (control block in the workspace, zeroed by a memset node before every launch):
+	//   gran   [chunk][tile]    u64  TAG | segment length                        published by the segment's workgroup
+	//   gtotal [chunk][tile/64] u64  TAG | sum of the lengths of a group of 64   published by the group's last arriver
+	//   P      [chunk]          u64  TAG | first word of the chunk in the stream published by the previous chunk's last arriver
+	//   gcount [chunk][tile/64], ccount [chunk]  u64  arrivals << 40 | sum: returning agent-scope atomic adds that find the
+	//          last arriver of a group / of a chunk; on lines of their own, never polled
+	// Every POLLED word is written once, by one sc1 store, and carries its own data (granule = flag).  What is polled is
+	// never what is added to (counters that 64 workgroups add to while hundreds poll them serialise on their cache line:
+	// 60 ns per add, 770 us per launch), and no published word depends on another one except P[c + 1] on P[c] (prefixes
+	// chained through the groups cost 200 hops of 2.5 us).
+	// Workgroup (c, t) needs  A = sum of lengths of tiles < t in chunk c  (= its tile_off) and P[c]: it polls the granules of
+	// the tiles in front of it in its own group of 64, the totals of the groups in front and P[c] - 63 + ntiles / 64 + 1
+	// words at most, by ONE wave, with relaxed agent-scope loads (sc1: served by L2 / memory, never a stale L1 line).  No
+	// payload is handed between workgroups inside the launch (the stream is read by the NEXT kernel).
+	// Forward progress: segments are dealt by tickets (8 heads, head = blockIdx % 8, segment = ticket * 8 + head), so a
+	// workgroup only ever waits for segments whose workgroups have taken their ticket earlier on the same head or are
+	// not behind it in dispatch; every spin is bounded by a 2 s clock and a shared error word, a wait that gives up
+	// raises the error instead of hanging.
+#define RIR_LB_TAG (1ull << 63)
+#define RIR_LB_TIMEOUT_TICKS 200000000ull /* s_memrealtime runs at 100 MHz: 2 s */
+#define RIR_NONE 0xffffffffu
+
+	struct RecordWords
+	{
+		v2u32 va, vb;
+		uint32_t ia, ib; // word index inside the wave's payload, RIR_NONE for a lane without a plane
+	};
+
+	__device__ __forceinline__ uint64_t emit_words_narrow(const Px8 &r, uint32_t mode, uint32_t base, RecordWords &rw, uint32_t pos, const LaneConsts &lc,
+														  const TransposeConsts &tc, uint32_t *words)
+	{
+		uint32_t x = (r.d[0] | (r.d[1] << 8)) | ((r.d[2] | (r.d[3] << 8)) << 4);
+		x = transpose32(x, tc);
+		const uint64_t nz64 = __ballot(x != 0);
+		const uint32_t nz = (uint32_t)nz64 | (uint32_t)(nz64 >> 32);
+		uint32_t M = nz | ((nz >> 1) & 0x77777777u);
+		M |= (M >> 2) & 0x33333333u;
+		uint32_t W = M - ((M >> 1) & 0x55555555u);
+		W = (W & 0x33333333u) + ((W >> 2) & 0x33333333u);
+		*words = (uint32_t)__builtin_popcount(M);
+		auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+		rw.va.x = x, rw.va.y = sw[1];
+		rw.ia = __builtin_amdgcn_inverse_ballot_w64((uint64_t)M) ? pos + (uint32_t)__builtin_popcount(M & lc.p_before) : RIR_NONE;
+		rw.vb = rw.va, rw.ib = RIR_NONE;
+		const uint32_t B = base | (mode << 16);
+		const uint64_t hw = __ballot((int32_t)(W << lc.p_hshw) < 0) & 0x00E700E700E700E7ull;
+		const uint64_t hb = __ballot((int32_t)(B << lc.p_hshb) < 0) & 0x3C003C003C00FC00ull;
+		return hw | hb;
+	}
+
+	__device__ __forceinline__ uint64_t emit_words_wide(const Px8 &r, uint32_t mode, uint32_t base, RecordWords &rw, uint32_t pos, const LaneConsts &lc,
+														const TransposeConsts &tc, uint32_t *words)
+	{
+		uint32_t alo = r.d[0], ahi = r.d[1], blo = r.d[2], bhi = r.d[3];
+		transpose64x2(alo, ahi, blo, bhi, tc);
+		const uint32_t wa = row_allmax((alo | ahi) != 0 ? lc.bitp1 : 0u);
+		const uint32_t wb = row_allmax((blo | bhi) != 0 ? lc.bitp1 : 0u);
+		const uint32_t ia = rows_inclusive_sum(wa), ib = rows_inclusive_sum(wb);
+		const uint32_t tot_a = (uint32_t)__builtin_amdgcn_readlane((int)ia, 63);
+		const uint32_t tot_b = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
+		rw.va.x = alo, rw.va.y = ahi, rw.vb.x = blo, rw.vb.y = bhi;
+		rw.ia = lc.bit < wa ? pos + ia - wa + lc.bit : RIR_NONE;
+		rw.ib = lc.bit < wb ? pos + tot_a + ib - wb + lc.bit : RIR_NONE;
+		*words = tot_a + tot_b;
+		const uint32_t nib = (base >> lc.sh4) & 15u;
+		const uint32_t field = ((nib << 10) | (lc.row0 ? mode << 14 : 0u)) | ((wb << 5) | wa);
+		return __ballot((field & lc.onehot) != 0);
+	}
+
+	// Where a wave's payload goes: the first records into its LDS region, from the first record that does not fit
+	// (wave-uniform decision) everything into its spill area in the workspace.
+	struct Staging
+	{
+		uint64_t *lds;	   // this wave's region
+		uint32_t cap;	   // its capacity in words
+		uint32_t lds_used; // words in LDS once spilling has started
+		bool spilling;
+		__amdgpu_buffer_rsrc_t spill;
+	};
+
+	__device__ __forceinline__ uint64_t emit_staged(const Px8 &r, uint32_t mode, uint32_t base, Staging &sg, uint32_t pos, const LaneConsts &lc,
+													const TransposeConsts &tc, uint32_t *words)
+	{
+		const uint32_t any = (r.d[0] | r.d[1]) | (r.d[2] | r.d[3]);
+		RecordWords rw;
+		uint64_t h;
+		if (__ballot((any & 0xfff0fff0u) != 0) == 0)
+			h = emit_words_narrow(r, mode, base, rw, pos, lc, tc, words);
+		else
+			h = emit_words_wide(r, mode, base, rw, pos, lc, tc, words);
+		if (!sg.spilling && pos + *words > sg.cap)
+			sg.spilling = true, sg.lds_used = pos;
+		if (!sg.spilling)
+		{ // LDS operations only inside this (wave-uniform) branch: the vector-memory stream below stays unconditional
+			if (rw.ia != RIR_NONE)
+				sg.lds[rw.ia] = ((uint64_t)rw.va.y << 32) | rw.va.x;
+			if (rw.ib != RIR_NONE)
+				sg.lds[rw.ib] = ((uint64_t)rw.vb.y << 32) | rw.vb.x;
+		}
+		// two stores per record whatever happens (counted waits, see RecordStores): out of range unless the wave spills
+		const uint32_t add = sg.spilling ? 0u - sg.lds_used * 8u : RIR_OOB;
+		const uint32_t oa = rw.ia != RIR_NONE ? rw.ia * 8u + add : RIR_OOB;
+		const uint32_t ob = rw.ib != RIR_NONE ? rw.ib * 8u + add : RIR_OOB;
+		__builtin_amdgcn_raw_buffer_store_b64(rw.va, sg.spill, oa, 0, RIR_SPARSE_STORE_AUX);
+		__builtin_amdgcn_raw_buffer_store_b64(rw.vb, sg.spill, ob, 0, RIR_SPARSE_STORE_AUX);
+		return h;
+	}
+
+	// One wave packs the records of frames [rec0, rec0 + nrec) of a chunk for one tile.  `first` points at the tile in the
+	// first frame the wave LOADS: the key frame when has_key, else the frame before its first record.  hdr_first: table
+	// entry of that loaded frame (headers of records go to hdr_first[1..] / hdr_first[0] for the key frame).
+	// Returns the number of payload words produced.
+	template <bool FAST>
+	__device__ __forceinline__ uint32_t encode_run(const uint16_t *__restrict__ frames, int64_t npx, int nload, int64_t frame_first, bool has_key,
+												   int tile, int lane, uint64_t *__restrict__ hdr_first, Staging &sg)
+	{
+		const int64_t p0 = (int64_t)tile * RIRB1_TILE_PX + lane * 8;
+		const TransposeConsts tc = make_transpose_consts(lane);
+		const LaneConsts lc = make_lane_consts(lane);
+		const uint32_t lane_off = (uint32_t)lane * 16u;
+		const uint16_t *next_ptr = frames + frame_first * npx + (int64_t)tile * RIRB1_TILE_PX;
+		int next_f = 0;
+		// frames are loaded strictly in order; a request past the wave's last frame is an out-of-range offset: the
+		// instruction is issued (the waits stay counted) and touches no memory
+		auto load = [&](int f, v4u32 &dst) {
+			if (FAST)
+			{
+				const Px8 p = buf_load8(next_ptr, next_f < nload ? lane_off : RIR_OOB);
+				dst.x = p.d[0], dst.y = p.d[1], dst.z = p.d[2], dst.w = p.d[3];
+				next_ptr += npx;
+				next_f += 1;
+			}
+			else
+			{
+				const Px8 p = load8(frames, frame_first + min(f, nload - 1), npx, p0, false);
+				dst.x = p.d[0], dst.y = p.d[1], dst.z = p.d[2], dst.w = p.d[3];
+			}
+		};
+		auto as_px8 = [](const v4u32 &v) {
+			Px8 p;
+			p.d[0] = v.x, p.d[1] = v.y, p.d[2] = v.z, p.d[3] = v.w;
+			return p;
+		};
+		uint32_t pos = 0;
+		uint64_t hdr_reg = 0;
+		v4u32 s0, s1, s2, s3;
+		load(0, s0);
+		load(1, s1);
+		load(2, s2);
+		load(3, s3);
+		if (has_key)
+		{ // key frame: RAW, or LEFT when its payload is strictly smaller
+			const Px8 cur = as_px8(s0);
+			const uint32_t base_raw = tile_base(cur, false);
+			const uint32_t b2 = base_raw | (base_raw << 16);
+			Px8 r_raw;
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+				r_raw.d[k] = pk_sub16(cur.d[k], b2);
+			const Px8 dl = left_delta(cur, lane);
+			const uint32_t base_left = tile_base(dl, true);
+			const uint32_t bl2 = base_left | (base_left << 16);
+			Px8 r_left;
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+				r_left.d[k] = pk_sub16(dl.d[k], bl2);
+			const bool use_left = payload_words(r_left) < payload_words(r_raw);
+			Px8 r_sel;
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+				r_sel.d[k] = use_left ? r_left.d[k] : r_raw.d[k];
+			uint32_t words;
+			const uint32_t key_mode = use_left ? RIRB1_MODE_LEFT : RIRB1_MODE_RAW;
+			const uint64_t h = emit_staged(r_sel, key_mode, use_left ? base_left : base_raw, sg, pos, lc, tc, &words);
+			if (lane == 0)
+				hdr_first[0] = h;
+			pos += words;
+		}
+#define RIR_ENC2_STEP(F, CUR, PREV)                                                            \
+	{                                                                                          \
+		const int f = (F);                                                                     \
+		Px8 d;                                                                                 \
+		{                                                                                      \
+			const Px8 c_ = as_px8(CUR), p_ = as_px8(PREV);                                     \
+			_Pragma("unroll") for (int k = 0; k < 4; ++k) d.d[k] = pk_sub16(c_.d[k], p_.d[k]); \
+		}                                                                                      \
+		load(f + 3, PREV);                                                                     \
+		const uint32_t base = tile_base(d, true);                                              \
+		const uint32_t b2 = base | (base << 16);                                               \
+		_Pragma("unroll") for (int k = 0; k < 4; ++k) d.d[k] = pk_sub16(d.d[k], b2);          \
+		uint32_t words;                                                                        \
+		const uint64_t h = emit_staged(d, RIRB1_MODE_TEMPORAL, base, sg, pos, lc, tc, &words); \
+		if (lane == ((f - 1) & 63))                                                            \
+			hdr_reg = h;                                                                       \
+		pos += words;                                                                          \
+	}
+		int fb = 1;
+		while (fb < nload)
+		{
+			const int g0 = fb, gend = min(fb + 64, nload);
+			for (; fb + 3 < gend; fb += 4)
+			{
+				RIR_ENC2_STEP(fb, s1, s0)
+				RIR_ENC2_STEP(fb + 1, s2, s1)
+				RIR_ENC2_STEP(fb + 2, s3, s2)
+				RIR_ENC2_STEP(fb + 3, s0, s3)
+			}
+			if (fb < gend)
+			{
+				RIR_ENC2_STEP(fb, s1, s0)
+				if (fb + 1 < gend)
+				{
+					RIR_ENC2_STEP(fb + 1, s2, s1)
+					if (fb + 2 < gend)
+						RIR_ENC2_STEP(fb + 2, s3, s2)
+				}
+				fb = gend;
+			}
+			if (g0 + lane < gend)
+				hdr_first[g0 + lane] = hdr_reg;
+			hdr_reg = 0;
+		}
+#undef RIR_ENC2_STEP
+		return pos;
+	}
+
+	__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v)
+	{
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1)
+			v += (uint64_t)__shfl_xor((long long)v, d, 64);
+		return v;
+	}
+
+	// Look-back of workgroup (c, t), run by ONE wave.  A = sum of the lengths of tiles < t of chunk c, Pc = first word of
+	// chunk c.  false: gave up (clock or error word); the error word is raised.
+	__device__ __noinline__ bool encode_lookback(const uint64_t *P, const uint64_t *gtotal, const uint64_t *gran, uint32_t *error_word, int c, int t,
+												 int ntiles, int ngroups, int lane, uint64_t *A_out, uint64_t *P_out, uint64_t *dbg_words)
+	{
+		const int g = t >> 6, e1 = t & 63, E = e1 + g + (c > 0 ? 1 : 0);
+		uint64_t accA = 0, accP = 0;
+		const uint64_t t_start = __builtin_amdgcn_s_memrealtime();
+		for (int e0 = 0; e0 < E; e0 += 64)
+		{
+			const int e = e0 + lane;
+			const bool valid = e < E;
+			int kind = 2;
+			const uint64_t *ptr = P + c;
+			if (e < e1)
+				kind = 0, ptr = gran + (int64_t)c * ntiles + ((int64_t)g << 6) + e;
+			else if (e < e1 + g)
+				kind = 1, ptr = gtotal + (int64_t)c * ngroups + (e - e1);
+			uint64_t v = 0;
+			bool done = !valid;
+			for (uint32_t spins = 0;; ++spins)
+			{
+				if (!done)
+				{
+					v = __hip_atomic_load(ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					done = (v >> 63) != 0;
+				}
+				if (__ballot(!done) == 0)
+					break;
+				if ((spins & 15u) == 15u)
+				{
+					const uint32_t err = __hip_atomic_load(error_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (err != 0 || __builtin_amdgcn_s_memrealtime() - t_start > RIR_LB_TIMEOUT_TICKS)
+					{
+						if (lane == 0)
+							__hip_atomic_store(error_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						return false;
+					}
+				}
+#ifndef RIR_LB_SLEEP
+#define RIR_LB_SLEEP 8
+#endif
+				__builtin_amdgcn_s_sleep(RIR_LB_SLEEP);
+			}
+			if (valid)
+			{
+				if (kind == 2)
+					accP = v & ~RIR_LB_TAG;
+				else
+					accA += v & ~RIR_LB_TAG;
+			}
+		}
+#ifdef RIR_DIAG_LB_STATS
+		if (lane == 0)
+		{ // diagnostic build only: time spent looking back, into the pad at the end of the control block (nothing reads it in the kernel)
+			dbg_words[0] = __builtin_amdgcn_s_memrealtime() - t_start; // (the pad word of this segment's spill slot)
+			dbg_words[1] = t_start;
+		}
+#endif
+		*A_out = wave_sum_u64(accA);
+		*P_out = wave_sum_u64(accP);
+		return true;
+	}
+
+	// frames of wave w when nf frames are split over `waves` waves with the key frame counted twice: [enc_split(w), enc_split(w + 1))
+	__device__ __host__ __forceinline__ int enc_split(int w, int waves, int nf)
+	{
+		if (w <= 0)
+			return 0;
+		if (w >= waves)
+			return nf;
+		const int b = (w * (nf + 1) + waves / 2) / waves - 1;
+		return b < 1 ? (nf < 1 ? nf : 1) : (b > nf ? nf : b);
+	}
+
+	// control block: 8 ticket heads on lines of their own, the error word, then P / group / gran
+	__device__ __host__ __forceinline__ int64_t enc_ctrl_words64(int nchunks, int ntiles)
+	{
+		const int64_t ngroups = (ntiles + 63) / 64;
+		return 8 * 16 + 16 + ((int64_t)nchunks + 1) + (int64_t)nchunks * ngroups + (((int64_t)nchunks * ntiles + 15) & ~(int64_t)15) +
+			   (int64_t)nchunks * ngroups + nchunks + 16;
+	}
+
+	template <int WAVES>
+	__attribute__((amdgpu_waves_per_eu(8, 8))) __global__ __launch_bounds__(WAVES * 64) void rirb1_encode_dense(
+		const uint16_t *__restrict__ frames, int64_t npx, int ntiles, int nframes, int gop, int nchunks, uint64_t *__restrict__ hdr_table,
+		uint32_t *__restrict__ tile_off, uint64_t *__restrict__ chunk_off, uint64_t *__restrict__ stream, uint64_t *__restrict__ ctrl,
+		uint64_t *__restrict__ spill, int cap)
+	{
+		extern __shared__ __attribute__((aligned(16))) uint64_t enc_lds[];
+		uint64_t *sh_base = enc_lds + (size_t)WAVES * cap;				   // [0] segment's first word in the stream
+		uint32_t *sh_u32 = reinterpret_cast<uint32_t *>(sh_base + 1); // [0..WAVES) words of each wave, [WAVES] segment index, [WAVES + 2..] words of each wave in LDS
+		const int lane = threadIdx.x & 63;
+		const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+		const int ngroups = (ntiles + 63) >> 6;
+		uint32_t *heads = reinterpret_cast<uint32_t *>(ctrl);
+		uint32_t *error_word = reinterpret_cast<uint32_t *>(ctrl + 8 * 16);
+		uint64_t *P = ctrl + 8 * 16 + 16;
+		uint64_t *gtotal = P + nchunks + 1;
+		uint64_t *gran = gtotal + (int64_t)nchunks * ngroups;
+		uint64_t *gcount = gran + (((int64_t)nchunks * ntiles + 15) & ~(int64_t)15); // counters: on lines of their own
+		uint64_t *ccount = gcount + (int64_t)nchunks * ngroups;
+
+#ifdef RIR_DIAG_NO_TICKET
+		const int seg = blockIdx.x;
+#else
+		if (threadIdx.x == 0)
+		{
+			const uint32_t head = blockIdx.x & 7u;
+			const uint32_t ticket = __hip_atomic_fetch_add(heads + head * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			sh_u32[WAVES] = ticket * 8u + head;
+		}
+		__syncthreads();
+		const int seg = __builtin_amdgcn_readfirstlane((int)sh_u32[WAVES]);
+#endif
+#ifdef RIR_DIAG_LB_STATS
+		const uint64_t dbg_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+		const int chunk = seg / ntiles, tile = seg - chunk * ntiles;
+		const int f_begin = chunk * gop;
+		const int nf = min(gop, nframes - f_begin);
+		uint64_t *my_hdr = hdr_table + (int64_t)seg * gop;
+
+		// this wave's share of the chunk
+		const int rec0 = enc_split(w, WAVES, nf), rec1 = enc_split(w + 1, WAVES, nf);
+		const int nrec = rec1 - rec0;
+		const bool has_key = w == 0;
+		const int first_load = has_key ? 0 : rec0 - 1;
+		const int nload = nrec > 0 ? rec1 - first_load : 0;
+		Staging sg;
+		sg.lds = enc_lds + (size_t)w * cap;
+		sg.cap = (uint32_t)cap;
+		sg.lds_used = 0;
+		sg.spilling = false;
+		uint64_t *my_spill = spill + (int64_t)seg * RIRB1_SLOT_WORDS(gop) + (int64_t)rec0 * RIRB1_REC_MAX_WORDS;
+		sg.spill = make_rsrc(my_spill, (uint32_t)(nrec > 0 ? nrec : 0) * RIRB1_REC_MAX_WORDS * 8u);
+		uint32_t pos = 0;
+		if (nrec > 0)
+		{
+			const bool fast = ((npx & 7) == 0) && ((int64_t)(tile + 1) * RIRB1_TILE_PX <= npx) && ((((uintptr_t)frames) & 15) == 0);
+			if (fast)
+				pos = encode_run<true>(frames, npx, nload, (int64_t)f_begin + first_load, has_key, tile, lane, my_hdr + first_load, sg);
+			else
+				pos = encode_run<false>(frames, npx, nload, (int64_t)f_begin + first_load, has_key, tile, lane, my_hdr + first_load, sg);
+		}
+		for (int f = nf + (int)threadIdx.x; f < gop; f += WAVES * 64)
+			my_hdr[f] = 0; // short last chunk: the unused table entries are defined
+		if (lane == 0)
+		{
+			sh_u32[w] = pos;
+			sh_u32[WAVES + 2 + w] = sg.spilling ? sg.lds_used : pos; // words of this wave that are in LDS
+		}
+		if (sg.spilling)
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the spilled words have left this wave before wave 0 is told of them
+		__syncthreads();
+		// Only wave 0 goes on: the segment is complete in LDS (+ spill), what is left is to wait for its place in the stream and
+		// to copy it there.  The other waves END here - a workgroup that waits holds one wave slot, not four, so the CU can
+		// start the next workgroup's waves while this one looks back.
+		if (w != 0)
+			return;
+		uint32_t total = 0;
+#pragma unroll
+		for (int i = 0; i < WAVES; ++i)
+			total += sh_u32[i];
+		bool chunk_last = false; // this workgroup completed its chunk (lane 0 knows)
+		uint64_t chunk_words = 0;
+		if (lane == 0)
+		{ // publish first, then look back
+			__hip_atomic_store(gran + (int64_t)chunk * ntiles + tile, RIR_LB_TAG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const int g = tile >> 6, gsize = min(64, ntiles - (g << 6));
+			const uint64_t one = 1ull << 40, sum_mask = one - 1ull;
+			const uint64_t og = __hip_atomic_fetch_add(gcount + (int64_t)chunk * ngroups + g, one | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if ((int)(og >> 40) == gsize - 1)
+			{ // last arriver of its group: the group's total becomes visible; it may complete the chunk too
+				const uint64_t gsum = (og & sum_mask) + total;
+				__hip_atomic_store(gtotal + (int64_t)chunk * ngroups + g, RIR_LB_TAG | gsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const uint64_t oc = __hip_atomic_fetch_add(ccount + chunk, one | gsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((int)(oc >> 40) == ngroups - 1)
+					chunk_last = true, chunk_words = (oc & sum_mask) + gsum;
+			}
+		}
+		uint64_t A = 0, Pc = 0;
+#ifdef RIR_DIAG_NO_LOOKBACK
+		const bool ok = true;
+#else
+		const bool ok = encode_lookback(P, gtotal, gran, error_word, chunk, tile, ntiles, ngroups, lane, &A, &Pc,
+										spill + (int64_t)seg * RIRB1_SLOT_WORDS(gop) + (int64_t)gop * RIRB1_REC_MAX_WORDS);
+#endif
+		if (!ok)
+			return; // the look-back gave up: the error word is raised, nothing is copied
+#ifdef RIR_DIAG_LB_STATS
+		const uint64_t dbg_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
+		if (lane == 0)
+		{
+			tile_off[(int64_t)chunk * (ntiles + 1) + tile] = (uint32_t)A;
+			if (seg == 0)
+				chunk_off[0] = 0;
+			if (chunk_last)
+			{ // the chunk's length is known and so is its first word: the next chunk's first word follows
+				tile_off[(int64_t)chunk * (ntiles + 1) + ntiles] = (uint32_t)chunk_words;
+				__hip_atomic_store(P + chunk + 1, RIR_LB_TAG | (Pc + chunk_words), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				chunk_off[chunk + 1] = Pc + chunk_words;
+			}
+		}
+#ifdef RIR_DIAG_NO_COPY
+		return;
+#endif
+		uint64_t *dst = stream + (Pc + A);
+		for (int i = 0; i < WAVES; ++i)
+		{
+			const uint64_t *src = enc_lds + (size_t)i * cap;
+			const uint32_t n_all = sh_u32[i], n_lds = sh_u32[WAVES + 2 + i];
+			uint32_t j = (uint32_t)lane;
+			for (; j + 192 < n_lds; j += 256)
+			{
+				const uint64_t v0 = src[j], v1 = src[j + 64], v2 = src[j + 128], v3 = src[j + 192];
+				dst[j] = v0, dst[j + 64] = v1, dst[j + 128] = v2, dst[j + 192] = v3;
+			}
+			for (; j < n_lds; j += 64)
+				dst[j] = src[j];
+			if (n_all > n_lds)
+			{ // what wave i spilled comes back from its area of the workspace (sc1 loads: from L2, where its stores went)
+				const int r0 = enc_split(i, WAVES, nf), r1 = enc_split(i + 1, WAVES, nf);
+				const __amdgpu_buffer_rsrc_t sp =
+					make_rsrc(spill + (int64_t)seg * RIRB1_SLOT_WORDS(gop) + (int64_t)r0 * RIRB1_REC_MAX_WORDS, (uint32_t)(r1 - r0) * RIRB1_REC_MAX_WORDS * 8u);
+				for (uint32_t q = (uint32_t)lane; q < n_all - n_lds; q += 64)
+				{
+					const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(sp, q * 8u, 0, 16 /* sc1 */);
+					dst[n_lds + q] = ((uint64_t)v.y << 32) | v.x;
+				}
+			}
+			dst += n_all;
+		}
+#ifdef RIR_DIAG_LB_STATS
+		if (lane == 0)
+		{
+			uint64_t *dbg = spill + (int64_t)seg * RIRB1_SLOT_WORDS(gop) + (int64_t)gop * RIRB1_REC_MAX_WORDS;
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			dbg[2] = dbg_t0, dbg[3] = dbg_t2, dbg[4] = __builtin_amdgcn_s_memrealtime();
+			unsigned xcc;
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+			unsigned hwid;
+			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 32)" : "=s"(hwid));
+			dbg[5] = ((uint64_t)xcc << 32) | hwid;
+		}
+#endif
+	}
+
 	// ---- decode -----------------------------------------------------------------------------
 	// One record in flight: header + the two plane words of this lane.
 	struct Fetched
@@ -1023,6 +1517,39 @@ namespace rir
 		hipLaunchKernelGGL(rirb1_scan_tiles, dim3(nchunks), block, 0, st, d_seg_words, ntiles, d_tile_off, d_chunk_words);
 		hipLaunchKernelGGL(rirb1_compact, dim3(ntiles, nchunks), block, 0, st, d_sparse, d_tile_off, d_chunk_words, ntiles, nchunks, gop,
 						   d_chunk_off, d_stream);
+		return hipGetLastError();
+	}
+
+	// single-pass dense encode: control block zeroed by a memset node, then one kernel.  d_ctrl: enc_ctrl_words64() x 8 bytes at
+	// the start of an allocation; d_spill: one RIRB1_SLOT_WORDS(gop) slot per (chunk, tile).
+	int64_t encode_ctrl_bytes(int nchunks, int ntiles) { return enc_ctrl_words64(nchunks, ntiles) * 8; }
+	hipError_t launch_encode_dense(const uint16_t *d_frames, int64_t npx, int ntiles, int nframes, int gop, uint64_t *d_hdr, uint32_t *d_tile_off,
+								   uint64_t *d_chunk_off, uint64_t *d_stream, uint64_t *d_ctrl, uint64_t *d_spill, hipStream_t st)
+	{
+		const int nchunks = (nframes + gop - 1) / gop;
+		const int64_t ctrl_bytes = (encode_ctrl_bytes(nchunks, ntiles) + 15) & ~(int64_t)15;
+		hipError_t e = hipMemsetAsync(d_ctrl, 0, (size_t)ctrl_bytes, st);
+		if (e != hipSuccess)
+			return e;
+		constexpr int WAVES = 4;
+		// LDS words per wave: what 8 workgroups per CU leave (160 KiB / 8 = 20 KiB per workgroup), never more than the
+		// worst case of the wave's share of the chunk
+		const int share = (gop + 1 + WAVES - 1) / WAVES + 1;
+		int cap = 448; // 14.4 KB per workgroup: 11 workgroups per CU, 7 packing (28 waves) while 4 wait for their offsets (1 wave each)
+		if (cap > share * RIRB1_REC_MAX_WORDS)
+			cap = share * RIRB1_REC_MAX_WORDS;
+		static int cap_env = -1;
+		if (cap_env < 0)
+		{
+			const char *ev = getenv("RIR_ENC_LDS_WORDS");
+			cap_env = ev ? atoi(ev) : 0;
+		}
+		if (cap_env > 0)
+			cap = cap_env;
+		const size_t lds = (size_t)WAVES * cap * 8 + 8 + (2 * WAVES + 2) * 4;
+		const int64_t total = (int64_t)nchunks * ntiles;
+		hipLaunchKernelGGL(rirb1_encode_dense<WAVES>, dim3((unsigned)total), dim3(WAVES * 64), lds, st, d_frames, npx, ntiles, nframes, gop, nchunks, d_hdr,
+						   d_tile_off, d_chunk_off, d_stream, d_ctrl, d_spill, cap);
 		return hipGetLastError();
 	}
 

@@ -45,6 +45,9 @@ namespace rir
 								   uint32_t *d_seg_words, uint64_t *d_sparse, hipStream_t st);
 	hipError_t launch_encode_compact(int ntiles, int nframes, int gop, const uint32_t *d_seg_words, const uint64_t *d_sparse,
 									 uint32_t *d_tile_off, uint64_t *d_chunk_words, uint64_t *d_chunk_off, uint64_t *d_stream, hipStream_t st);
+	int64_t encode_ctrl_bytes(int nchunks, int ntiles);
+	hipError_t launch_encode_dense(const uint16_t *d_frames, int64_t npx, int ntiles, int nframes, int gop, uint64_t *d_hdr, uint32_t *d_tile_off,
+								   uint64_t *d_chunk_off, uint64_t *d_stream, uint64_t *d_ctrl, uint64_t *d_spill, hipStream_t st);
 	hipError_t launch_decode(const uint64_t *d_hdr, const uint32_t *d_tile_off, const uint64_t *d_chunk_off, const uint64_t *d_stream,
 							 uint64_t stream_words, int64_t npx, int ntiles, int nframes, int gop, const int64_t *d_chunk_frames, int nchunks_tab,
 							 uint16_t *d_frames, int *d_error, hipStream_t st);
