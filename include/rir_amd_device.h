@@ -56,6 +56,14 @@ extern "C"
 	int rir_codec_encode_compact_device(int width, int height, int nframes, int gop, unsigned int *d_tile_off, unsigned long long *d_chunk_off,
 										unsigned long long *d_stream, void *d_workspace, long long workspace_bytes, void *stream);
 
+	/* The encode as one kernel that writes the dense stream directly (segments staged in LDS, decoupled look-back): same
+	 * outputs bit for bit, fewer bytes through HBM, not faster on MI355X.  rir_codec_encode_status (waits for the
+	 * stream): 0 = the last single-pass encode on this workspace completed, 1 = a look-back gave up, the stream is incomplete. */
+	int rir_codec_encode_single_pass_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned long long *d_hdr,
+											unsigned int *d_tile_off, unsigned long long *d_chunk_off, unsigned long long *d_stream,
+											void *d_workspace, long long workspace_bytes, void *stream);
+	int rir_codec_encode_status(const void *d_workspace, void *stream);
+
 	/* *d_error (device int, zero it first) becomes 1 when a malformed table/record was met.  stream_words = number of
 	 * 64-bit words readable at d_stream: the tables are untrusted (they may come from a file) and a (chunk, tile)
 	 * segment that does not lie inside [0, stream_words) is rejected before anything is read through it. */

@@ -651,20 +651,27 @@ namespace rir
 
 	// ---- encode -----------------------------------------------------------------------------
 	//
-	// grid  = (ceil(ntiles/4), nchunks), block = 256 (4 independent waves)
+	// grid  = (ceil(tile_count/4), nchunks), block = 256 (4 independent waves); tiles [tile_first, tile_first + tile_count)
 	// hdr       [nchunks][ntiles][gop]      u64  record headers
 	// seg_words [nchunks][ntiles]           u32  segment length (sum over the chunk's frames)
 	// sparse    [nchunks][ntiles][gop*128]  u64, only the first seg_words words of a slot are written
+	// Two kernels: FAST for tiles that lie whole inside 16-byte aligned frames (every tile but the last one of a frame whose
+	// size is not a multiple of 512 pixels) - unconditional raw-buffer loads, 64 registers, no scratch - and the ragged form
+	// (element-wise loads with bounds tests) for the rest; as one kernel the ragged instantiation's spills cost the fast path
+	// its scratch set-up.
 	// 8 waves per SIMD (<= 64 VGPRs; the allocator's natural choice was 71 -> 7 waves): 12 800 waves then take 1.56
 	// rounds instead of 1.79 and the run-to-run spread of the kernel (141 / 154 us) collapses onto the fast mode
+	template <bool FAST>
 	__attribute__((amdgpu_waves_per_eu(8, 8))) __global__ __launch_bounds__(256) void rirb1_encode_tiles(const uint16_t *__restrict__ frames, int64_t npx, int ntiles,
-															 int nframes, int gop, uint64_t *__restrict__ hdr_table,
-															 uint32_t *__restrict__ seg_words, uint64_t *__restrict__ sparse)
+																 int tile_first, int tile_count, int nframes, int gop,
+																 uint64_t *__restrict__ hdr_table, uint32_t *__restrict__ seg_words,
+																 uint64_t *__restrict__ sparse)
 	{
 		const int lane = threadIdx.x & 63;
-		const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-		if (tile >= ntiles)
+		const int ti = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+		if (ti >= tile_count)
 			return;
+		const int tile = tile_first + ti;
 		const int chunk = blockIdx.y;
 		const int f_begin = chunk * gop;
 		const int nf = min(gop, nframes - f_begin);
@@ -672,11 +679,7 @@ namespace rir
 		uint64_t *my_hdr = hdr_table + slot * gop;
 		uint64_t *out = sparse + slot * RIRB1_SLOT_WORDS(gop);
 		const uint32_t out_bytes = (uint32_t)gop * RIRB1_REC_MAX_WORDS * 8u;
-		const bool fast = ((npx & 7) == 0) && ((int64_t)(tile + 1) * RIRB1_TILE_PX <= npx) && ((((uintptr_t)frames) & 15) == 0);
-		if (fast)
-			encode_tile<true>(frames, npx, nf, f_begin, tile, lane, my_hdr, out, out_bytes, seg_words + slot, gop);
-		else
-			encode_tile<false>(frames, npx, nf, f_begin, tile, lane, my_hdr, out, out_bytes, seg_words + slot, gop);
+		encode_tile<FAST>(frames, npx, nf, f_begin, tile, lane, my_hdr, out, out_bytes, seg_words + slot, gop);
 	}
 
 	// ---- offsets ------------------------------------------------------------------------------
@@ -1503,8 +1506,15 @@ namespace rir
 								   uint32_t *d_seg_words, uint64_t *d_sparse, hipStream_t st)
 	{
 		const int nchunks = (nframes + gop - 1) / gop;
-		dim3 grid((ntiles + 3) / 4, nchunks), block(256);
-		hipLaunchKernelGGL(rirb1_encode_tiles, grid, block, 0, st, d_frames, npx, ntiles, nframes, gop, d_hdr, d_seg_words, d_sparse);
+		const bool aligned = ((npx & 7) == 0) && ((((uintptr_t)d_frames) & 15) == 0);
+		const int nfast = aligned ? (int)(npx / RIRB1_TILE_PX) : 0; // tiles that lie whole inside the frame
+		dim3 block(256);
+		if (nfast > 0)
+			hipLaunchKernelGGL(rirb1_encode_tiles<true>, dim3((nfast + 3) / 4, nchunks), block, 0, st, d_frames, npx, ntiles, 0, nfast, nframes, gop, d_hdr,
+							   d_seg_words, d_sparse);
+		if (ntiles > nfast)
+			hipLaunchKernelGGL(rirb1_encode_tiles<false>, dim3((ntiles - nfast + 3) / 4, nchunks), block, 0, st, d_frames, npx, ntiles, nfast, ntiles - nfast,
+							   nframes, gop, d_hdr, d_seg_words, d_sparse);
 		return hipGetLastError();
 	}
 
@@ -1541,7 +1551,7 @@ namespace rir
 		static int cap_env = -1;
 		if (cap_env < 0)
 		{
-			const char *ev = getenv("RIR_ENC_LDS_WORDS");
+			const char *ev = getenv("RIR_ENC_LDS_WORDS"); // tuning aid (tests/perf/enc_ab.py)
 			cap_env = ev ? atoi(ev) : 0;
 		}
 		if (cap_env > 0)

@@ -61,6 +61,8 @@ _lib.rir_device_available.restype = ct.c_int
 _lib.rir_stream_synchronize.argtypes = [_vp]
 _lib.rir_codec_layout_query.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(CodecLayout)]
 _lib.rir_codec_encode_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, _vp, ct.c_longlong, _vp]
+_lib.rir_codec_encode_single_pass_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, _vp, ct.c_longlong, _vp]
+_lib.rir_codec_encode_status.argtypes = [_vp, _vp]
 _lib.rir_codec_encode_tiles_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, ct.c_longlong, _vp]
 _lib.rir_codec_encode_compact_device.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, ct.c_longlong, _vp]
 _lib.rir_codec_decode_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
@@ -150,19 +152,24 @@ class CodecContext:
         self.workspace = torch.empty((L.workspace_bytes,), dtype=torch.uint8, device=dev)
         self.error = torch.zeros((1,), dtype=torch.int32, device=dev)
 
-    def encode(self, frames):
+    def encode(self, frames, single_pass=False):
+        """single_pass: the one-kernel encoder (dense stream written directly, decoupled look-back) - same outputs"""
         L = self.layout
         fr = _frames3(frames, torch.uint16)
         if tuple(fr.shape) != (L.nframes, L.height, L.width):
             raise RuntimeError("encode: frames do not match the context geometry")
         _check(
-            _lib.rir_codec_encode_device(
+            (_lib.rir_codec_encode_single_pass_device if single_pass else _lib.rir_codec_encode_device)(
                 fr.data_ptr(), L.width, L.height, L.nframes, L.gop, self.hdr.data_ptr(), self.tile_off.data_ptr(),
                 self.chunk_off.data_ptr(), self.stream.data_ptr(), self.workspace.data_ptr(), L.workspace_bytes, _stream(),
             ),
             "rir_codec_encode_device",
         )
         return EncodedBatch(L, self.hdr, self.tile_off, self.chunk_off, self.stream)
+
+    def encode_status(self):
+        """0 when the last single-pass encode completed, 1 when one of its look-backs gave up (waits for the stream)"""
+        return int(_lib.rir_codec_encode_status(self.workspace.data_ptr(), _stream()))
 
     def encode_tiles(self, frames):
         """stage 1 only (single pass over the raw frames); finish with encode_compact()"""

@@ -7,6 +7,6 @@ for v in "${VS[@]}"; do
   RIR_EXTRA_CFLAGS="$v" python -c "from librir_amd import build; build.build(verbose=False)" > /dev/null 2>&1 || { echo "build failed: $v"; continue; }
   for c in ${CAPS:-0}; do
     echo "== variant: [$v] cap=$c"
-    RIR_ENC_LDS_WORDS=$c timeout -k 10 120 python tests/perf/enc_ab.py 2>/dev/null | grep -v "slow:\|alone\|segs " | head -${LINES_MAX:-16}
+    RIR_SINGLE_PASS=1 RIR_ENC_LDS_WORDS=$c timeout -k 10 120 python tests/perf/enc_ab.py 2>/dev/null | grep -v "slow:\|alone\|segs " | head -${LINES_MAX:-16}
   done
 done

@@ -1,5 +1,6 @@
 """Development aid: time the codec step on the headline workload (HIP events, median of K):
-    python tests/perf/enc_ab.py [frames]      (RIR_ENCODER=legacy for the two-pass encoder while it exists)
+    python tests/perf/enc_ab.py [frames]      (RIR_SINGLE_PASS=1: the single-pass look-back encoder instead of the two-pass one;
+                                               RIR_DIAG_STATS=1 with a -DRIR_DIAG_LB_STATS build: its per-workgroup timeline)
 Prints encode / decode / step times in the pipeline and alone."""
 import os
 import sys
@@ -18,16 +19,17 @@ if os.environ.get("RIR_NOISE"):
     fr = (fr.astype(np.int64) + np.random.default_rng(1).integers(0, int(os.environ["RIR_NOISE"]), fr.shape)).astype(np.uint16)
 t = torch.from_numpy(fr).cuda()
 ctx = D.CodecContext(w, h, n, int(os.environ.get("RIR_GOP", "50")))
+SP = bool(os.environ.get("RIR_SINGLE_PASS"))
 out = torch.empty_like(t)
 for _ in range(5):
-    enc = ctx.encode(t)
+    enc = ctx.encode(t, single_pass=SP)
     ctx.decode(enc, out=out, check=False)
 torch.cuda.synchronize()
 K = 20
 ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
 for k in range(K):
     ev[k][0].record()
-    enc = ctx.encode(t)
+    enc = ctx.encode(t, single_pass=SP)
     ev[k][1].record()
     ctx.decode(enc, out=out, check=False)
     ev[k][2].record()
@@ -36,7 +38,7 @@ med = lambda a, b: float(np.median([ev[k][a].elapsed_time(ev[k][b]) for k in ran
 te, td = med(0, 1), med(1, 2)
 rt = bool(torch.equal(out.view(torch.int16), t.view(torch.int16)))
 print("%s: encode %.1f us  decode %.1f us  step %.1f us  fps %.0f  ratio %.3f  roundtrip %s  err %d" %
-      (os.environ.get("RIR_ENCODER", "dense"), te, td, te + td, n / ((te + td) * 1e-6), fr.nbytes / enc.compressed_bytes(), rt, int(ctx.error.item())))
+      ("single-pass" if SP else "two-pass", te, td, te + td, n / ((te + td) * 1e-6), fr.nbytes / enc.compressed_bytes(), rt, int(ctx.error.item())))
 
 
 def alone(fn, reps=20):
@@ -93,5 +95,5 @@ if os.environ.get("RIR_DIAG_STATS"):
         started = ((t0 >= lo) & (t0 < hi)).sum()
         dur = (t1 - t0)[(t0 >= lo) & (t0 < hi)]
         print("  t=%5.0f us: walking %4d  waiting %4d  copying %4d  started %4d  walk dur of those %.1f" % (mid, walking, waiting, copying, started, dur.mean() if dur.size else 0))
-print("alone: encode %.1f us  decode %.1f us" % (alone(lambda: ctx.encode(t)), alone(lambda: ctx.decode(enc, out=out, check=False))))
+print("alone: encode %.1f us  decode %.1f us" % (alone(lambda: ctx.encode(t, single_pass=SP)), alone(lambda: ctx.decode(enc, out=out, check=False))))
 sys.exit(0 if rt else 1)

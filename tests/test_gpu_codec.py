@@ -13,15 +13,17 @@ def to_np(enc):
             enc.stream.cpu().numpy().view(np.uint64))
 
 
-def encode_decode(dev, frames, gop):
+def encode_decode(dev, frames, gop, single_pass=False):
     import torch
 
     n, h, w = frames.shape
     ctx = dev.CodecContext(w, h, n, gop)
     t = torch.from_numpy(frames).cuda()
-    enc = ctx.encode(t)
+    enc = ctx.encode(t, single_pass=single_pass)
     dec = ctx.decode(enc)
     torch.cuda.synchronize()
+    if single_pass:
+        assert ctx.encode_status() == 0
     return ctx, enc, dec.cpu().numpy()
 
 
@@ -39,8 +41,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("single_pass", [False, True], ids=["two_pass", "single_pass"])
 @pytest.mark.parametrize("name,shape,gop", CASES)
-def test_bitstream_equals_oracle(dev, oracle, name, shape, gop):
+def test_bitstream_equals_oracle(dev, oracle, name, shape, gop, single_pass):
+    """Both encoders (the two-pass one behind rir_codec_encode_device and the single-pass look-back one) against the oracle:
+    header table, tile offsets, chunk offsets and stream bit for bit."""
     n, h, w = shape
     rng = np.random.default_rng(abs(hash(name)) % 1000)
     if name == "noisy_small":
@@ -53,7 +58,7 @@ def test_bitstream_equals_oracle(dev, oracle, name, shape, gop):
         fr = s1_noisy_background(n, h, w, seed=9)
     else:
         fr = rng.integers(0, 65536, shape).astype(np.uint16)
-    ctx, enc, dec = encode_decode(dev, fr, gop)
+    ctx, enc, dec = encode_decode(dev, fr, gop, single_pass)
     assert np.array_equal(dec, fr)
     hdr, toff, coff, st = to_np(enc)
     L = ctx.layout
@@ -117,6 +122,31 @@ def test_identity_at_baseline_sizes(dev, shape, n):
     assert torch.equal(enc2.hdr, hdr1) and enc2.total_words() == words1
     ratio = fr.numel() * 2 / enc.compressed_bytes()
     assert ratio > 4.0, ratio  # reference claims "about 5" on its own recipe (docs/video_io.md:13)
+
+
+def test_single_pass_encoder_equals_two_pass_at_baseline_size_and_when_it_spills(dev):
+    """1 000 x 640x512 (12 800 segments, several rounds of workgroups, look-back across 20 chunks) and a noisy stream whose
+    segments overflow their LDS staging (spill path): tables and stream equal the two-pass encoder's, word for word."""
+    import torch
+
+    for n, h, w, noise in ((1000, 512, 640, 0), (150, 256, 320, 3000), (70, 67, 83, 60000)):
+        fr = s1_noisy_background(n, h, w, seed=11).astype(np.int64)
+        if noise:
+            fr = fr + np.random.default_rng(2).integers(0, noise, fr.shape)
+        t = torch.from_numpy((fr % 65536).astype(np.uint16)).cuda()
+        ctx = dev.CodecContext(w, h, n, 50)
+        a = ctx.encode(t)
+        ref = [x.clone() for x in (a.hdr, a.tile_off, a.chunk_off)]
+        words = a.total_words()
+        ref_stream = a.stream[:words].clone()
+        for x in (a.hdr, a.tile_off, a.chunk_off):
+            x.zero_()
+        a.stream[:words].zero_()
+        b = ctx.encode(t, single_pass=True)
+        assert ctx.encode_status() == 0
+        assert torch.equal(b.hdr, ref[0]) and torch.equal(b.tile_off, ref[1]) and torch.equal(b.chunk_off, ref[2]), (n, h, w)
+        assert b.total_words() == words and torch.equal(b.stream[:words], ref_stream), (n, h, w)
+        assert torch.equal(ctx.decode(b).view(torch.int16), t.view(torch.int16))
 
 
 def test_malformed_tables_are_rejected_not_read_out_of_bounds(dev):
