@@ -9,6 +9,7 @@
 // one record per chunk (GOP) holding the RIRB1 tables and payload, a chunk index, and the
 // reference's own "H264ATTRIBUTES" metadata trailer as the last bytes of the file.
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -130,9 +131,9 @@ namespace
 		int w = 0, h = 0, gop = 0;
 		rir_codec_layout L{};
 		DeviceBuffer d_frames, d_hdr, d_tile_off, d_chunk_off, d_stream, d_ws, d_err, d_tmp, d_shift;
-		PinnedBuffer h_frames;
-		bool prepare(int w_, int h_, int gop_)
-		{
+		PinnedBuffer h_frames, h_in; // h_in: a chunk's tables and payload as read from the file (loader)
+		bool prepare(int w_, int h_, int gop_, bool encoder = true)
+		{ // encoder: the encode workspace is needed too (the loader only decodes)
 			if (w == w_ && h == h_ && gop == gop_ && d_frames.ptr)
 				return true;
 			if (rir_codec_layout_query(w_, h_, gop_, gop_, &L) != 0)
@@ -141,7 +142,18 @@ namespace
 			const size_t fb = (size_t)w * h * 2 * gop;
 			return d_frames.reserve(fb) && d_hdr.reserve((size_t)L.hdr_bytes) && d_tile_off.reserve((size_t)L.tile_off_bytes) &&
 				   d_chunk_off.reserve((size_t)L.chunk_off_bytes) && d_stream.reserve((size_t)L.stream_max_bytes) &&
-				   d_ws.reserve((size_t)L.workspace_bytes) && d_err.reserve(sizeof(int)) && h_frames.reserve(fb);
+				   (!encoder || d_ws.reserve((size_t)L.workspace_bytes)) && d_err.reserve(sizeof(int)) && h_frames.reserve(fb);
+		}
+		// the buffers change owner (the structs hold raw pointers and free them when they die: member-wise, never by copy)
+		void swap_with(ChunkCodec &o)
+		{
+			std::swap(w, o.w), std::swap(h, o.h), std::swap(gop, o.gop), std::swap(L, o.L);
+			DeviceBuffer *a[] = {&d_frames, &d_hdr, &d_tile_off, &d_chunk_off, &d_stream, &d_ws, &d_err, &d_tmp, &d_shift};
+			DeviceBuffer *b[] = {&o.d_frames, &o.d_hdr, &o.d_tile_off, &o.d_chunk_off, &o.d_stream, &o.d_ws, &o.d_err, &o.d_tmp, &o.d_shift};
+			for (int i = 0; i < 9; ++i)
+				std::swap(a[i]->ptr, b[i]->ptr), std::swap(a[i]->cap, b[i]->cap);
+			std::swap(h_frames.ptr, o.h_frames.ptr), std::swap(h_frames.cap, o.h_frames.cap);
+			std::swap(h_in.ptr, o.h_in.ptr), std::swap(h_in.cap, o.h_in.cap);
 		}
 	};
 
@@ -587,7 +599,9 @@ namespace
 			rir_codec_layout L;
 			if (rir_codec_layout_query(width, height, pending, chunk_gop, &L) != 0)
 				return false;
-			// the frames are already in cc.d_frames: each one was uploaded (or produced there) when it was added
+			// the frames are in cc.d_frames: uploaded in groups (or produced there) as they were added; the last group goes now
+			if (!upload_staged(pending))
+				return false;
 			if (rir_codec_encode_device(cc.d_frames.as<unsigned short>(), width, height, pending, chunk_gop, cc.d_hdr.as<unsigned long long>(),
 										cc.d_tile_off.as<unsigned int>(), cc.d_chunk_off.as<unsigned long long>(),
 										cc.d_stream.as<unsigned long long>(), cc.d_ws.ptr, (long long)cc.d_ws.cap, st) != 0)
@@ -635,6 +649,23 @@ namespace
 			next_buf ^= 1;
 			index.push_back(e);
 			pending = 0;
+			uploaded = 0;
+			return true;
+		}
+
+		// frames [uploaded, upto) of the chunk being assembled: page-locked staging -> device
+		static constexpr int kUploadGroup = 5;
+		int uploaded = 0;
+		bool upload_staged(int upto)
+		{
+			if (upto <= uploaded)
+				return true;
+			const size_t fbytes = (size_t)width * height * 2;
+			if (!hip_ok(hipMemcpyAsync(cc.d_frames.as<char>() + (size_t)uploaded * fbytes, cc.h_frames.as<char>() + (size_t)uploaded * fbytes,
+									   (size_t)(upto - uploaded) * fbytes, hipMemcpyHostToDevice, default_stream()),
+						"H2D frames"))
+				return false;
+			uploaded = upto;
 			return true;
 		}
 
@@ -651,8 +682,9 @@ namespace
 			// 640x512 frame but leans on how the runtime treats pageable / pinned sources; not worth the risk.)
 			char *slot = cc.h_frames.as<char>() + (size_t)pending * fbytes;
 			std::memcpy(slot, img, fbytes);
-			if (!hip_ok(hipMemcpyAsync(cc.d_frames.as<char>() + (size_t)pending * fbytes, slot, fbytes, hipMemcpyHostToDevice, default_stream()),
-						"H2D frame"))
+			// uploads go in groups of a few frames (one asynchronous copy each: the call overhead of a copy per frame was a sixth
+			// of the time of this function); what is left of a chunk goes when the chunk is flushed
+			if (pending + 1 - uploaded >= kUploadGroup && !upload_staged(pending + 1))
 				return false;
 			return frame_added(ts, attrs);
 		}
@@ -665,9 +697,12 @@ namespace
 			if (pending >= chunk_gop && !flush_chunk())
 				return false;
 			const size_t fbytes = (size_t)width * height * 2;
+			if (!upload_staged(pending)) // frames staged on the host before this one go first: `uploaded` is a prefix of the chunk
+				return false;
 			if (!hip_ok(hipMemcpyAsync(cc.d_frames.as<char>() + (size_t)pending * fbytes, d_img, fbytes, hipMemcpyDeviceToDevice, default_stream()),
 						"D2D frame"))
 				return false;
+			uploaded = pending + 1;
 			return frame_added(ts, attrs);
 		}
 
@@ -760,6 +795,21 @@ namespace
 		std::vector<IndexEntry> index;
 		ChunkCodec cc;
 		int cached_chunk = -1;
+		// Sequential readers: while the images of chunk k are handed out from page-locked memory, a helper thread reads chunk
+		// k + 1 from the file, decodes it on a second stream into the buffers of `nx` and brings its images to the host; when
+		// the reader gets there the two buffer sets are swapped.
+		ChunkCodec nx;
+		struct Prefetch
+		{
+			std::thread th;
+			std::mutex mu;
+			std::condition_variable cv;
+			int want = -1;	  // chunk the helper should fetch (-1: none)
+			int have = -1;	  // chunk whose images are in nx (valid when ok)
+			bool busy = false, ok = false, quit = false;
+			hipStream_t stream = nullptr;
+			int device = 0;
+		} pf;
 		// sequential read-ahead: images [host_first, host_end) of chunk host_chunk are (being) copied to cc.h_frames
 		int seq_run = 0, host_chunk = -1, host_base = 0, host_first = 0, host_end = 0;
 		bool host_pending = false;
@@ -772,6 +822,7 @@ namespace
 
 		~CameraObject() override
 		{
+			stop_prefetch();
 			if (fp)
 				std::fclose(fp);
 			if (bp_handle > 0)
@@ -794,9 +845,17 @@ namespace
 				std::memcpy(dst, mem.data() + off, n);
 				return true;
 			}
-			if (fseeko(fp, (off_t)off, SEEK_SET) != 0)
-				return false;
-			return std::fread(dst, 1, n, fp) == n;
+			// pread: no shared file position, so the read-ahead thread and the caller's thread may both read
+			char *d = static_cast<char *>(dst);
+			const int fd = fileno(fp);
+			while (n > 0)
+			{
+				const ssize_t r = pread(fd, d, n, (off_t)off);
+				if (r <= 0)
+					return false;
+				d += r, off += (uint64_t)r, n -= (size_t)r;
+			}
+			return true;
 		}
 
 		bool open_common()
@@ -841,7 +900,7 @@ namespace
 						log_error("RIRB file: inconsistent chunk index");
 						return false;
 					}
-				if (count > 0 && !cc.prepare(width, height, (int)hd.gop))
+				if (count > 0 && !cc.prepare(width, height, (int)hd.gop, false))
 					return false;
 			}
 			else
@@ -1039,72 +1098,167 @@ namespace
 			return !z.isError(r) && r == npx * 2;
 		}
 
-		bool decode_chunk(int c)
+		// Chunk c of the file -> ctx.d_frames (decoded, MIN_T added back) on stream st; with to_host the decoded images follow
+		// into ctx.h_frames (one asynchronous copy).  Waits for the stream.  quiet: failures are not logged (the read-ahead
+		// thread: the caller's own attempt will say what is wrong).
+		bool decode_chunk_into(ChunkCodec &ctx, int c, hipStream_t st, bool to_host, bool quiet)
 		{
-			if (c == cached_chunk)
-				return true;
-			if (!device_ready())
+			auto fail = [&](const char *why) {
+				if (!quiet)
+					log_error(why);
 				return false;
+			};
 			const IndexEntry &e = index[c];
 			ChunkHeader ch;
-			if (!read_at(e.file_offset, &ch, sizeof(ch)) || std::memcmp(ch.magic, "CHNK", 4) != 0 || (int)ch.gop != cc.gop ||
-				(int)ch.ntiles != cc.L.ntiles || ch.nframes == 0 || (int)ch.nframes > cc.gop || ch.nframes != e.nframes ||
-				ch.first_frame != e.first_frame || ch.payload_words > (uint64_t)cc.L.stream_max_bytes / 8)
-			{
-				log_error("RIRB file: corrupted chunk header");
+			if (!read_at(e.file_offset, &ch, sizeof(ch)) || std::memcmp(ch.magic, "CHNK", 4) != 0 || (int)ch.gop != ctx.gop ||
+				(int)ch.ntiles != ctx.L.ntiles || ch.nframes == 0 || (int)ch.nframes > ctx.gop || ch.nframes != e.nframes ||
+				ch.first_frame != e.first_frame || ch.payload_words > (uint64_t)ctx.L.stream_max_bytes / 8)
+				return fail("RIRB file: corrupted chunk header");
+			// tables and payload are read straight into page-locked memory (kept for the life of the object): no page faults of a
+			// fresh 7 MB vector per chunk, and the uploads below run at the PCIe rate instead of through the runtime's staging
+			const size_t hdr_n = (size_t)ch.ntiles * ch.gop, toff_n = (size_t)ch.ntiles + 1, pay_n = (size_t)ch.payload_words + 1;
+			const size_t hdr_b = hdr_n * 8, toff_b = (toff_n * 4 + 7) & ~(size_t)7;
+			if (!ctx.h_in.reserve(hdr_b + toff_b + (size_t)ctx.L.stream_max_bytes + 64)) // (+ the guard word, the two chunk offsets and two flag words)
 				return false;
-			}
-			std::vector<uint64_t> hdr((size_t)ch.ntiles * ch.gop), payload((size_t)ch.payload_words + 1);
-			std::vector<uint32_t> toff((size_t)ch.ntiles + 1);
+			uint64_t *hdr = ctx.h_in.as<uint64_t>();
+			uint32_t *toff = reinterpret_cast<uint32_t *>(ctx.h_in.as<char>() + hdr_b);
+			uint64_t *payload = reinterpret_cast<uint64_t *>(ctx.h_in.as<char>() + hdr_b + toff_b);
+			// (the previous uploads from this buffer have completed: this function waits for its stream before it returns)
 			uint64_t off = e.file_offset + sizeof(ch);
-			if (!read_at(off, hdr.data(), hdr.size() * 8))
+			if (!read_at(off, hdr, hdr_b))
 				return false;
-			off += hdr.size() * 8;
-			if (!read_at(off, toff.data(), toff.size() * 4))
+			off += hdr_b;
+			if (!read_at(off, toff, toff_n * 4))
 				return false;
-			off += toff.size() * 4;
-			if (ch.payload_words && !read_at(off, payload.data(), (size_t)ch.payload_words * 8))
+			off += toff_n * 4;
+			if (ch.payload_words && !read_at(off, payload, (size_t)ch.payload_words * 8))
 				return false;
+			payload[ch.payload_words] = 0;
 			// the offsets table comes from the file: monotone and ending exactly at the payload length, or the chunk is
 			// refused before anything reaches the device (the kernel checks again against the stream length it is given)
 			bool toff_ok = toff[0] == 0 && (uint64_t)toff[ch.ntiles] == ch.payload_words;
 			for (size_t t = 0; t < (size_t)ch.ntiles && toff_ok; ++t)
 				toff_ok = toff[t] <= toff[t + 1];
 			if (!toff_ok)
-			{
-				log_error("RIRB file: corrupted tile offsets");
+				return fail("RIRB file: corrupted tile offsets");
+			uint64_t *coff = reinterpret_cast<uint64_t *>(payload + pay_n); // (page-locked too: the copy below is asynchronous)
+			coff[0] = 0, coff[1] = ch.payload_words;
+			int *flags = reinterpret_cast<int *>(coff + 2); // [0] zero for the device's error word, [1] the word read back
+			flags[0] = 0, flags[1] = 0;
+			if (!hip_ok(hipMemcpyAsync(ctx.d_hdr.ptr, hdr, hdr_b, hipMemcpyHostToDevice, st), "H2D") ||
+				!hip_ok(hipMemcpyAsync(ctx.d_tile_off.ptr, toff, toff_n * 4, hipMemcpyHostToDevice, st), "H2D") ||
+				!hip_ok(hipMemcpyAsync(ctx.d_chunk_off.ptr, coff, 16, hipMemcpyHostToDevice, st), "H2D") ||
+				!hip_ok(hipMemcpyAsync(ctx.d_stream.ptr, payload, pay_n * 8, hipMemcpyHostToDevice, st), "H2D") ||
+				!hip_ok(hipMemcpyAsync(ctx.d_err.ptr, flags, sizeof(int), hipMemcpyHostToDevice, st), "H2D"))
 				return false;
-			}
-			hipStream_t st = default_stream();
-			const uint64_t coff[2] = {0, ch.payload_words};
-			const int zero = 0;
-			if (!hip_ok(hipMemcpyAsync(cc.d_hdr.ptr, hdr.data(), hdr.size() * 8, hipMemcpyHostToDevice, st), "H2D") ||
-				!hip_ok(hipMemcpyAsync(cc.d_tile_off.ptr, toff.data(), toff.size() * 4, hipMemcpyHostToDevice, st), "H2D") ||
-				!hip_ok(hipMemcpyAsync(cc.d_chunk_off.ptr, coff, sizeof(coff), hipMemcpyHostToDevice, st), "H2D") ||
-				!hip_ok(hipMemcpyAsync(cc.d_stream.ptr, payload.data(), payload.size() * 8, hipMemcpyHostToDevice, st), "H2D") ||
-				!hip_ok(hipMemcpyAsync(cc.d_err.ptr, &zero, sizeof(int), hipMemcpyHostToDevice, st), "H2D"))
-				return false;
-			if (rir_codec_decode_device(cc.d_hdr.as<unsigned long long>(), cc.d_tile_off.as<unsigned int>(), cc.d_chunk_off.as<unsigned long long>(),
-										cc.d_stream.as<unsigned long long>(), (long long)ch.payload_words, width, height, (int)ch.nframes, cc.gop, cc.d_frames.as<unsigned short>(),
-										cc.d_err.as<int>(), st) != 0)
+			if (rir_codec_decode_device(ctx.d_hdr.as<unsigned long long>(), ctx.d_tile_off.as<unsigned int>(), ctx.d_chunk_off.as<unsigned long long>(),
+										ctx.d_stream.as<unsigned long long>(), (long long)ch.payload_words, width, height, (int)ch.nframes, ctx.gop,
+										ctx.d_frames.as<unsigned short>(), ctx.d_err.as<int>(), st) != 0)
 				return false;
 			// frames recorded with subtractMin: add the stored minimum back (IRFileLoader.cpp:1173-1179)
 			if (min_T && min_T_rows > 0 &&
-				!hip_ok(launch_lossy_add_min(cc.d_frames.as<uint16_t>(), (int64_t)width * height, width * std::min(min_T_rows, height), (int)ch.nframes,
+				!hip_ok(launch_lossy_add_min(ctx.d_frames.as<uint16_t>(), (int64_t)width * height, width * std::min(min_T_rows, height), (int)ch.nframes,
 											 (uint32_t)min_T, st),
 						"add min"))
 				return false;
-			// the decoded chunk stays in HBM (cc.d_frames): frames are filtered there and only the requested
-			// frame crosses PCIe (IRFileLoader::readImage hands out one frame per call)
-			int err = 0;
-			if (!hip_ok(hipMemcpyAsync(&err, cc.d_err.ptr, sizeof(int), hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
+			// the decoded chunk stays in HBM (ctx.d_frames): frames are filtered there and only the requested
+			// frame crosses PCIe (IRFileLoader::readImage hands out one frame per call) - or, for a sequential reader, the whole chunk at once
+			if (!hip_ok(hipMemcpyAsync(flags + 1, ctx.d_err.ptr, sizeof(int), hipMemcpyDeviceToHost, st), "D2H"))
 				return false;
-			if (err)
+			if (to_host && ctx.h_frames.ptr &&
+				!hip_ok(hipMemcpyAsync(ctx.h_frames.ptr, ctx.d_frames.ptr, (size_t)ch.nframes * width * height * 2, hipMemcpyDeviceToHost, st), "D2H"))
+				return false;
+			if (!hip_ok(wait_stream(st), "sync"))
+				return false;
+			if (flags[1])
+				return fail("RIRB file: malformed chunk payload");
+			return true;
+		}
+
+		// ---- read-ahead of the next chunk (sequential readers) ----
+		void prefetch_loop()
+		{
+			(void)hipSetDevice(pf.device);
+			std::unique_lock<std::mutex> lk(pf.mu);
+			for (;;)
 			{
-				cached_chunk = -1;
-				log_error("RIRB file: malformed chunk payload");
-				return false;
+				pf.cv.wait(lk, [&] { return pf.quit || pf.want >= 0; });
+				if (pf.quit)
+					return;
+				const int c = pf.want;
+				pf.want = -1, pf.busy = true, pf.ok = false, pf.have = c;
+				lk.unlock();
+				const bool ok = nx.prepare(width, height, (int)hd.gop, false) && decode_chunk_into(nx, c, pf.stream, true, true);
+				lk.lock();
+				pf.ok = ok, pf.busy = false;
+				pf.cv.notify_all();
 			}
+		}
+		void start_prefetch(int c)
+		{
+			if (c < 0 || c >= (int)index.size() || kind != RIRB)
+				return;
+			std::unique_lock<std::mutex> lk(pf.mu);
+			if (pf.busy || pf.want >= 0 || (pf.have == c && pf.ok))
+				return;
+			if (!pf.stream)
+			{
+				if (hipGetDevice(&pf.device) != hipSuccess || hipStreamCreateWithFlags(&pf.stream, hipStreamNonBlocking) != hipSuccess)
+				{
+					pf.stream = nullptr;
+					return;
+				}
+			}
+			if (!pf.th.joinable())
+				pf.th = std::thread([this] { prefetch_loop(); });
+			pf.want = c, pf.have = -1, pf.ok = false;
+			pf.cv.notify_all();
+		}
+		// true when chunk c was fetched ahead: its buffers become the current ones
+		bool take_prefetched(int c)
+		{
+			std::unique_lock<std::mutex> lk(pf.mu);
+			if (pf.want != c && pf.have != c)
+				return false;
+			pf.cv.wait(lk, [&] { return pf.want < 0 && !pf.busy; });
+			if (pf.have != c || !pf.ok)
+				return false;
+			cc.swap_with(nx);
+			pf.have = -1, pf.ok = false;
+			return true;
+		}
+		void stop_prefetch()
+		{
+			{
+				std::unique_lock<std::mutex> lk(pf.mu);
+				pf.cv.wait(lk, [&] { return pf.want < 0 && !pf.busy; });
+				pf.quit = true;
+			}
+			pf.cv.notify_all();
+			if (pf.th.joinable())
+				pf.th.join();
+			if (pf.stream)
+				(void)hipStreamDestroy(pf.stream);
+			pf.stream = nullptr;
+		}
+
+		bool decode_chunk(int c)
+		{
+			if (c == cached_chunk)
+				return true;
+			if (!device_ready())
+				return false;
+			if (take_prefetched(c))
+			{ // decoded ahead, images already in page-locked memory
+				const IndexEntry &e = index[c];
+				cached_chunk = c;
+				host_chunk = c, host_base = (int)e.first_frame, host_first = (int)e.first_frame, host_end = (int)(e.first_frame + e.nframes);
+				host_pending = false;
+				return true;
+			}
+			cached_chunk = -1, host_chunk = -1;
+			if (!decode_chunk_into(cc, c, default_stream(), false, false))
+				return false;
 			cached_chunk = c;
 			return true;
 		}
@@ -1142,16 +1296,26 @@ namespace
 			// a host copy - 12 us of PCIe time per image instead of a 44 us blocking copy into pageable memory each.
 			if (track)
 				seq_run = (pos == last_pos + 1) ? seq_run + 1 : 0;
-			if (host_chunk >= 0 && host_chunk == cached_chunk && pos >= host_first && pos < host_end)
+			auto on_host = [&] { return host_chunk >= 0 && host_chunk == cached_chunk && pos >= host_first && pos < host_end; };
+			const unsigned short *d = nullptr;
+			if (!on_host())
+			{ // the chunk of `pos` becomes the current one - decoded now, or taken over from the read-ahead thread with its images
+			  // already in page-locked memory
+				d = device_frame(pos);
+				if (!d)
+					return false;
+			}
+			if (on_host())
 			{
 				if (host_pending && !hip_ok(wait_stream(st), "sync"))
 					return false;
 				host_pending = false;
 				std::memcpy(out, cc.h_frames.as<char>() + (size_t)(pos - host_base) * fbytes, fbytes);
+				if (track && seq_run >= 2)
+					start_prefetch(cached_chunk + 1); // (no-op when it is under way, done, or there is no next chunk)
 				return true;
 			}
-			const unsigned short *d = device_frame(pos);
-			if (!d || !hip_ok(hipMemcpyAsync(out, d, fbytes, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
+			if (!hip_ok(hipMemcpyAsync(out, d, fbytes, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
 				return false;
 			if (host_chunk != cached_chunk)
 				host_chunk = -1;

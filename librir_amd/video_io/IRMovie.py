@@ -69,6 +69,7 @@ class IRMovie(object):
         self._reg_file = None
         self._per_frame = {}  # position -> attributes of that image, as read
         self._current = -1
+        self._shape = None  # (height, width), fetched once
         self._owned_file = None  # temporary file this object must delete on close
 
     @classmethod
@@ -150,6 +151,8 @@ class IRMovie(object):
         return _abi.supported_calibrations(self.handle)
 
     def _calibration_number(self, which):
+        if which == 0:  # digital levels: always there, always first (the per-image path asks for nothing else)
+            return 0
         names = self.calibrations
         if isinstance(which, str):
             if which in ("DL", "Digital Level"):
@@ -208,7 +211,9 @@ class IRMovie(object):
     def load_pos(self, pos, calibration=None):
         """Image number ``pos`` (bad-pixel repair and motion correction applied when enabled)."""
         pos = int(pos)
-        image = _abi.load_image(self.handle, pos, self._calibration_number(0 if calibration is None else calibration))
+        if self._shape is None:
+            self._shape = _abi.get_image_size(self.handle)
+        image = _abi.load_image(self.handle, pos, self._calibration_number(0 if calibration is None else calibration), self._shape)
         self._per_frame[pos] = _abi.get_attributes(self.handle)
         self._current = pos
         return image

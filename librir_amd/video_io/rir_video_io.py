@@ -126,9 +126,11 @@ def supported_calibrations(camera):
     return out
 
 
-def load_image(camera, pos, calibration=0):
-    h, w = get_image_size(camera)
-    img = np.zeros((h, w), dtype=np.uint16)
+def load_image(camera, pos, calibration=0, shape=None):
+    """``shape``: (height, width) when the caller already knows it (IRMovie does: one library call less per image).  The
+    buffer is not zero-filled first (the library writes every pixel or fails)."""
+    h, w = get_image_size(camera) if shape is None else shape
+    img = np.empty((h, w), dtype=np.uint16)
     if _v.load_image(camera, int(pos), int(calibration), img.ctypes.data) < 0:
         _fail("load_image")
     return img
@@ -241,9 +243,14 @@ def h264_set_global_attributes(saver, attributes):
 
 
 def _add(fn, name, saver, image, timestamp, attributes):
-    img = np.array(image, dtype=np.uint16, order="C")
-    k, kl, v, vl, n = pack_attributes(attributes)
-    if fn(saver, img.ctypes.data, np.int64(timestamp), n, k, kl.ctypes.data, v, vl.ctypes.data) < 0:
+    # (no copy when the caller's array is already C-contiguous uint16: the library copies the frame out before it returns)
+    img = np.ascontiguousarray(image, dtype=np.uint16)
+    if attributes:
+        k, kl, v, vl, n = pack_attributes(attributes)
+        r = fn(saver, img.ctypes.data, int(timestamp), n, k, kl.ctypes.data, v, vl.ctypes.data)
+    else:
+        r = fn(saver, img.ctypes.data, int(timestamp), 0, None, None, None, None)
+    if r < 0:
         _fail(name)
 
 
