@@ -147,6 +147,12 @@ extern "C"
 						 int running_average, int subtract_min, int remove_bad_pixels);
 	int rir_lossy_step_device(int handle, const unsigned short *d_in, unsigned short *d_out, int nframes, int add_loss, int *low_errors,
 							  int *high_errors, void *stream);
+	/* The same step for nstreams INDEPENDENT streams (handles from rir_lossy_create with equal geometry, stepped the same number of
+	 * frames so far, no bad-pixel repair) in shared launches: the state is sequential in time, so streams - not frames - are what
+	 * runs side by side (SURVEY §8e "replicas").  d_in / d_out: HOST arrays of nstreams device pointers to uint16 [nframes][h][w];
+	 * low_errors / high_errors: HOST int[nstreams][nframes] or NULL. */
+	int rir_lossy_step_multi_device(const int *handles, int nstreams, const unsigned short *const *d_in, unsigned short *const *d_out, int nframes,
+									int add_loss, int *low_errors, int *high_errors, void *stream);
 	void rir_lossy_destroy(int handle);
 
 	/* ---- byte planes ------------------------------------------------------------------------------

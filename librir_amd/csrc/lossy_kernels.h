@@ -34,12 +34,32 @@ namespace rir
 		int reserved;
 	};
 
-	hipError_t launch_lossy_stats(const uint16_t *d_prevT, const uint16_t *d_tmp, const uint16_t *d_img, int s, uint32_t mn, int subtract_min,
-								  uint32_t *d_hist, long long *d_stats, hipStream_t st);
-	hipError_t launch_lossy_budget(long long *d_stats, LossyBudget *d_budget, int s, int add_loss, double std_factor, int low_value_error,
-								   int high_value_error, LossyDecision *d_decision, int *d_errors_out, hipStream_t st);
-	hipError_t launch_lossy_update(const uint16_t *d_tmp, uint16_t *d_out, const LossyDeviceState &state, int s, int full,
-								   const LossyDecision *d_decision, int add_loss, hipStream_t st);
+	// Everything the three kernels of one frame of one stream need (device pointers; plain data, passed by value or in a table).
+	struct LossyStep
+	{
+		const uint16_t *tmp, *img; // the frame after / before bad-pixel repair (the same without it)
+		uint16_t *out;
+		LossyDeviceState st; // ring indices as they are for THIS frame
+		uint32_t *hist;		 // 16 384 bins
+		long long *stats;	 // [8]: background, then the six sums
+		LossyBudget *budget;
+		LossyDecision *decision;
+		int *errors_out;	   // [2] low, high of this frame, or NULL
+		unsigned int *tickets; // [2] arrival counters of the two reduction passes
+		int s, full;		   // pixels below lossy_height, pixels of the frame
+		int hist_px, reserved; // pixels per workgroup of the histogram pass (lossy_hist_px)
+		int add_loss, low_value_error, high_value_error;
+		double std_factor;
+	};
+	// Pixels per workgroup of the histogram pass: each workgroup clears and merges a private 16 384-bin histogram, so a launch wants
+	// about as many workgroups as the chip holds at once (two per CU) - 4 096 pixels for one 640x512 stream, more with many streams.
+	inline int lossy_hist_px(int s, int nstreams)
+	{
+		long long px = ((long long)s * nstreams + 511) / 512;
+		px = (px + 1023) / 1024 * 1024;
+		return (int)(px < 4096 ? 4096 : px);
+	}
+	hipError_t launch_lossy_step(const LossyStep *h_steps, const LossyStep *d_table, int nstreams, hipStream_t st);
 	hipError_t launch_lossy_first(const uint16_t *d_tmp, uint16_t *d_out, const LossyDeviceState &state, int s, int full, hipStream_t st);
 	hipError_t launch_lossy_min(const uint16_t *d_tmp, int s, unsigned int *d_result, hipStream_t st);
 	hipError_t launch_lossy_add_min(uint16_t *d_frames, int64_t npx, int s, int nframes, uint32_t mn, hipStream_t st);

@@ -1,7 +1,8 @@
 // Bounded-loss recording on the GPU: the per-frame loss-injection step of the reference's lossy saver
 // (reference src/cpp/video_io/h264.cpp: get_background :1955-1991, stdDev :1993-2036,
 // RunningAverage2 :1526-1615, decision loop :2397-2413 / :2574-2590).  The state is sequential in
-// time and parallel in space: four elementwise / reduction kernels per frame, all integer, exact.
+// time and parallel in space: three kernels per frame (two reductions with a sequential tail each, one elementwise update),
+// all integer, exact.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -11,45 +12,114 @@ namespace rir
 {
 	__device__ __forceinline__ uint32_t sub_min(uint32_t v, uint32_t mn) { return v < mn ? 0u : v - mn; }
 
-	// L1: histogram of (v >> 2) over 16 384 bins, privatised in LDS (64 KiB), 1024-thread workgroups,
-	// RIR_LOSSY_HIST_PX pixels per workgroup (one frame is a small job: 32 768 pixels per workgroup left it on ten CUs
-	// and took 17 us; the merge only touches the bins a workgroup has filled, a few hundred for thermal images).
-#ifndef RIR_LOSSY_HIST_PX
-#define RIR_LOSSY_HIST_PX 4096
-#endif
-	__global__ __launch_bounds__(1024) void lossy_hist_kernel(const uint16_t *__restrict__ tmp, int s, uint32_t *__restrict__ hist)
+	// One frame of one stream = three launches (histogram + mode, sums + budget, update); blockIdx.y selects the stream when
+	// several independent streams are stepped by the same launches (rir_lossy_step_multi_device: SURVEY §8e "replicas").  The
+	// mode of the histogram and the error budget are sequential tails of a parallel pass: they are run by the LAST workgroup of
+	// that pass to arrive (an agent-scope ticket per stream), not by launches of their own - at one frame per call the step is
+	// bound by launch boundaries, not by HBM.
+	// Hand-off to the last arriver: every word it reads was written by agent-scope atomic adds (executed at the memory side),
+	// each adding wave drains them (s_waitcnt vmcnt(0)) before the workgroup's barrier and the ticket, and the last arriver reads
+	// them with agent-scope (sc1) loads.
+	// The step of this workgroup's stream: the kernel argument (one stream) or entry blockIdx.y of the table (TABLE).  Two
+	// instantiations, not a run-time choice: a select between the kernel-argument segment and global memory turns the struct -
+	// and every pointer in it - generic, and the whole kernel into flat_ loads, stores and atomics (3x slower, measured).
+	// Pointers read from the table are used through global-address-space copies (the compiler cannot know what they point to).
+#define RIR_GLOBAL(T) __attribute__((address_space(1))) T
+	typedef unsigned int lossy_v4u __attribute__((ext_vector_type(4)));
+	template <class T>
+	__device__ __forceinline__ RIR_GLOBAL(T) * as_global(T *p)
 	{
+		return (RIR_GLOBAL(T) *)p;
+	}
+	template <bool TABLE>
+	__device__ __forceinline__ LossyStep lossy_step_of(const LossyStep &one, const LossyStep *__restrict__ table)
+	{
+		if (!TABLE)
+			return one;
+		static_assert(sizeof(LossyStep) % 8 == 0, "LossyStep is copied in 8-byte words");
+		LossyStep p;
+		RIR_GLOBAL(const unsigned long long) *src = (RIR_GLOBAL(const unsigned long long) *)(table + blockIdx.y); // (wave-uniform: scalar loads)
+		unsigned long long *dst = reinterpret_cast<unsigned long long *>(&p);
+#pragma unroll
+		for (size_t k = 0; k < sizeof(LossyStep) / 8; ++k)
+			dst[k] = src[k];
+		return p;
+	}
+	// true in every thread of the workgroup whose ticket is the last of `expected`; last_flag: one LDS word the caller can spare
+	__device__ __forceinline__ bool lossy_last_arriver(unsigned int *ticket_, unsigned int expected, unsigned int *last_flag)
+	{
+		RIR_GLOBAL(unsigned int) *ticket = as_global(ticket_);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's atomic adds have been performed
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			*last_flag = (t == expected - 1) ? 1u : 0u;
+			if (t == expected - 1)
+				__hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next frame
+		}
+		__syncthreads();
+		return *last_flag != 0;
+	}
+
+	// L1: histogram of (v >> 2) over 16 384 bins, privatised in LDS (64 KiB), 1024-thread workgroups,
+	// hist_px pixels per workgroup (lossy_kernels.h: one frame is a small job - 32 768 pixels per workgroup left it on ten CUs and
+	// took 17 us - while 32 streams at 4 096 pixels are five rounds of workgroups that each clear and scan 64 KiB; the merge only
+	// touches the bins a workgroup has filled, a few hundred for thermal images).
+	// The last workgroup to arrive takes the mode of the merged histogram, lowest bin wins ties:
+	// stats[0] = background = (bin << 2) + 1 (get_background, h264.cpp:1955-1991), and clears the histogram.
+	template <bool TABLE>
+	__global__ __launch_bounds__(1024) void lossy_hist_mode_kernel(LossyStep one, const LossyStep *__restrict__ table)
+	{
+		const LossyStep sp = lossy_step_of<TABLE>(one, table);
 		__shared__ uint32_t lh[16384];
 		const int tid = threadIdx.x;
+		RIR_GLOBAL(const uint16_t) *tmp = as_global(sp.tmp);
+		RIR_GLOBAL(uint32_t) *hist = as_global(sp.hist);
+		const int s = sp.s;
 		for (int i = tid; i < 16384; i += 1024)
 			lh[i] = 0;
 		__syncthreads();
-		const int i0 = blockIdx.x * RIR_LOSSY_HIST_PX, i1 = min(i0 + RIR_LOSSY_HIST_PX, s);
-		for (int i = i0 + tid; i < i1; i += 1024)
-			atomicAdd(&lh[tmp[i] >> 2], 1u);
+		const int i0 = blockIdx.x * sp.hist_px, i1 = min(i0 + sp.hist_px, s);
+		if (((i0 | i1) & 7) == 0)
+		{ // 8 pixels per 16-byte load
+			for (int i = i0 / 8 + tid; i < i1 / 8; i += 1024)
+			{
+				const lossy_v4u v = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(tmp + (size_t)i * 8);
+				atomicAdd(&lh[(v.x & 0xffffu) >> 2], 1u), atomicAdd(&lh[v.x >> 18], 1u);
+				atomicAdd(&lh[(v.y & 0xffffu) >> 2], 1u), atomicAdd(&lh[v.y >> 18], 1u);
+				atomicAdd(&lh[(v.z & 0xffffu) >> 2], 1u), atomicAdd(&lh[v.z >> 18], 1u);
+				atomicAdd(&lh[(v.w & 0xffffu) >> 2], 1u), atomicAdd(&lh[v.w >> 18], 1u);
+			}
+		}
+		else
+			for (int i = i0 + tid; i < i1; i += 1024)
+				atomicAdd(&lh[tmp[i] >> 2], 1u);
 		__syncthreads();
 		for (int i = tid; i < 16384; i += 1024)
 			if (lh[i])
-				atomicAdd(&hist[i], lh[i]);
-	}
-
-	// mode of the histogram, lowest bin wins ties; stats[0] = background = (bin << 2) + 1
-	__global__ __launch_bounds__(1024) void lossy_mode_kernel(uint32_t *__restrict__ hist, long long *__restrict__ stats)
-	{
-		__shared__ uint32_t best_v[1024];
-		__shared__ uint32_t best_i[1024];
-		const int tid = threadIdx.x;
+				__hip_atomic_fetch_add(&hist[i], lh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (!lossy_last_arriver(sp.tickets, gridDim.x, &lh[0])) // (the private histogram has been merged: its first word is free)
+			return;
+		// mode: thread t looks at bins t, t + 1024, ... (coalesced: these are agent-scope loads, each one goes to L2 - 16 strided
+		// loads per thread cost 10 us), ascending, strict > keeps the lowest bin; then a tree over the threads on (count, bin)
+		uint32_t *best_v = lh, *best_i = lh + 1024;
 		uint32_t bv = 0, bi = 0;
+		uint32_t v16[16];
+#pragma unroll
 		for (int k = 0; k < 16; ++k)
-		{ // contiguous range of 16 bins per thread, ascending: strict > keeps the lowest bin
-			const uint32_t b = tid * 16 + k, v = hist[b];
-			hist[b] = 0; // ready for the next frame (the histogram is cleared once, when the state is created)
-			if (k == 0 || v > bv)
+			v16[k] = __hip_atomic_load(&hist[k * 1024 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+		for (int k = 0; k < 16; ++k)
+		{
+			hist[k * 1024 + tid] = 0; // ready for the next frame (the histogram is cleared once, when the state is created)
+			if (k == 0 || v16[k] > bv)
 			{
-				bv = v;
-				bi = b;
+				bv = v16[k];
+				bi = (uint32_t)(k * 1024 + tid);
 			}
 		}
+		__syncthreads(); // (lh is being reused)
 		best_v[tid] = bv;
 		best_i[tid] = bi;
 		__syncthreads();
@@ -67,55 +137,9 @@ namespace rir
 			__syncthreads();
 		}
 		if (tid == 0)
-			stats[0] = (long long)((best_i[0] << 2) + 1);
+			as_global(sp.stats)[0] = (long long)((best_i[0] << 2) + 1);
 	}
 
-	// L2: sums of |t - prev| and of its (32-bit wrapped) square, split by img > background.
-	// stats[1..6] = {fg sum d, fg sum d2, fg count, bg sum d, bg sum d2, bg count}
-	__global__ __launch_bounds__(256) void lossy_sums_kernel(const uint16_t *__restrict__ prevT, const uint16_t *__restrict__ tmp,
-															  const uint16_t *__restrict__ img, int s, uint32_t mn, int subtract_min,
-															  long long *__restrict__ stats)
-	{
-		const uint32_t background = (uint32_t)stats[0];
-		long long a[6] = {0, 0, 0, 0, 0, 0};
-		for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < s; i += gridDim.x * blockDim.x)
-		{
-			const uint32_t t = subtract_min ? sub_min(tmp[i], mn) : tmp[i];
-			const int32_t d = abs((int32_t)t - (int32_t)prevT[i]);
-			const int32_t d2 = (int32_t)((uint32_t)d * (uint32_t)d);
-			const int o = img[i] > background ? 0 : 3;
-			a[o] += d;
-			a[o + 1] += d2;
-			a[o + 2] += 1;
-		}
-		// wave reduction, then the four waves of the block through LDS: one atomic per block and sum (a few hundred
-		// in total - one per wave made 24 000 contended 64-bit atomics and cost 0.29 ms per frame)
-		__shared__ long long red[4][6];
-#pragma unroll
-		for (int k = 0; k < 6; ++k)
-		{
-			long long v = a[k];
-#pragma unroll
-			for (int d = 32; d >= 1; d >>= 1)
-				v += __shfl_xor(v, d, 64);
-			if ((threadIdx.x & 63) == 0)
-				red[threadIdx.x >> 6][k] = v;
-		}
-		__syncthreads();
-		if (threadIdx.x < 6)
-		{
-			const long long v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-			if (v)
-				atomicAdd((unsigned long long *)&stats[1 + threadIdx.x], (unsigned long long)v);
-		}
-	}
-
-	// The error budget of the frame (h264.cpp:2335-2385, :2544-2548 for addLoss): the reference's statistic
-	// sqrt((sum d)^2 - sum d^2) / n of this frame against its mean over a 40-frame window, scaled by stdFactor, is
-	// taken off lowValueError / highValueError.  Sequential scalar double arithmetic on exact integer sums - one
-	// thread, same operations in the same order as the host code it replaces (sqrt, division and round of doubles
-	// are IEEE-exact on the device: scripts/ubench/sqrt_f64_check.hip, 1.3e8 samples; this file is compiled with
-	// -ffp-contract=off).  Keeping it here means no statistics travel to the host between the kernels of a frame.
 	// (int) of a double as the reference's x86-64 build converts it (cvttsd2si): NaN and values outside int32 give
 	// INT_MIN.  It matters: with an empty foreground or background the statistic is 0/0, the NaN stays in the 40-frame
 	// window, and the budgets of those frames are whatever this conversion and the wrapping subtraction below make of it
@@ -123,24 +147,30 @@ namespace rir
 	__device__ __forceinline__ int int_of_double_x86(double v) { return (v >= -2147483648.0 && v < 2147483648.0) ? (int)v : (int)0x80000000; }
 	__device__ __forceinline__ int sub_wrap(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
 
-	__global__ void lossy_budget_kernel(long long *__restrict__ stats, LossyBudget *__restrict__ bs, int s, int add_loss, double std_factor,
-										int low_value_error, int high_value_error, LossyDecision *__restrict__ decision, int *__restrict__ errors_out)
+	// The error budget of the frame (h264.cpp:2335-2385, :2544-2548 for addLoss): the reference's statistic
+	// sqrt((sum d)^2 - sum d^2) / n of this frame against its mean over a 40-frame window, scaled by stdFactor, is
+	// taken off lowValueError / highValueError.  Sequential scalar double arithmetic on exact integer sums - one
+	// thread, same operations in the same order as the host code it replaces (sqrt, division and round of doubles
+	// are IEEE-exact on the device: scripts/ubench/sqrt_f64_check.hip, 1.3e8 samples; this file is compiled with
+	// -ffp-contract=off).  Keeping it here means no statistics travel to the host between the kernels of a frame.
+	// st[1..6]: the frame's sums as read by the caller.
+	// b: the stream's budget state, staged in LDS by the caller (the 40-entry window is shifted and summed element by element:
+	// from global memory that was 160 dependent round trips, 8 us).
+	__device__ __forceinline__ void lossy_budget(const LossyStep &sp, const long long *st, LossyBudget &b)
 	{
-		if (threadIdx.x != 0 || blockIdx.x != 0)
-			return;
-		LossyBudget &b = *bs;
+		const int s = sp.s;
 		// stdDev (h264.cpp:1993-2036): unsplit for the first 40 frames
 		double sd[2];
 		if (b.n_win < 40)
 		{
-			const double sum_diff = (double)(stats[1] + stats[4]), sum_diff2 = (double)(stats[2] + stats[5]);
+			const double sum_diff = (double)(st[1] + st[4]), sum_diff2 = (double)(st[2] + st[5]);
 			sd[0] = sd[1] = sqrt(sum_diff * sum_diff - sum_diff2) / s;
 		}
 		else
 		{
-			const double fd = (double)stats[1], fd2 = (double)stats[2], bd = (double)stats[4], bd2 = (double)stats[5];
-			sd[0] = sqrt(bd * bd - bd2) / (int)stats[6];
-			sd[1] = sqrt(fd * fd - fd2) / (int)stats[3];
+			const double fd = (double)st[1], fd2 = (double)st[2], bd = (double)st[4], bd2 = (double)st[5];
+			sd[0] = sqrt(bd * bd - bd2) / (int)st[6];
+			sd[1] = sqrt(fd * fd - fd2) / (int)st[3];
 		}
 		if (b.n_first < 1)
 		{
@@ -166,38 +196,141 @@ namespace rir
 		}
 		mean[0] /= (double)(b.n_win + b.n_first);
 		mean[1] /= (double)(b.n_win + b.n_first);
-		int low_error = low_value_error, high_error = high_value_error;
-		if (add_loss)
+		int low_error = sp.low_value_error, high_error = sp.high_value_error;
+		if (sp.add_loss)
 		{ // one-sided
 			const double dh = sd[1] < mean[1] ? 0 : sd[1] - mean[1], dl = sd[0] < mean[0] ? 0 : sd[0] - mean[0];
-			high_error = sub_wrap(high_error, int_of_double_x86(round(dh * std_factor)));
-			low_error = sub_wrap(low_error, int_of_double_x86(round(dl * std_factor)));
+			high_error = sub_wrap(high_error, int_of_double_x86(round(dh * sp.std_factor)));
+			low_error = sub_wrap(low_error, int_of_double_x86(round(dl * sp.std_factor)));
 		}
 		else
 		{ // two-sided
-			high_error = sub_wrap(high_error, int_of_double_x86(round(fabs(sd[1] - mean[1]) * std_factor)));
-			low_error = sub_wrap(low_error, int_of_double_x86(round(fabs(sd[0] - mean[0]) * std_factor)));
+			high_error = sub_wrap(high_error, int_of_double_x86(round(fabs(sd[1] - mean[1]) * sp.std_factor)));
+			low_error = sub_wrap(low_error, int_of_double_x86(round(fabs(sd[0] - mean[0]) * sp.std_factor)));
 		}
 		if (high_error < 0)
 			high_error = 0;
 		if (low_error < high_error)
 			low_error = high_error;
-		decision->background = (uint32_t)stats[0];
+		RIR_GLOBAL(LossyDecision) *decision = as_global(sp.decision);
+		decision->background = (uint32_t)st[0];
 		decision->low_error = low_error;
 		decision->high_error = high_error;
-		if (errors_out)
+		if (sp.errors_out)
 		{
-			errors_out[0] = low_error;
-			errors_out[1] = high_error;
+			as_global(sp.errors_out)[0] = low_error;
+			as_global(sp.errors_out)[1] = high_error;
 		}
-		for (int i = 1; i < 8; ++i) // the sums are accumulated with atomics: cleared for the next frame
-			stats[i] = 0;
+	}
+
+	// L2: sums of |t - prev| and of its (32-bit wrapped) square, split by img > background.
+	// stats[1..6] = {fg sum d, fg sum d2, fg count, bg sum d, bg sum d2, bg count}; the last workgroup to arrive turns
+	// them into the frame's error budget (lossy_budget) and clears them for the next frame.
+	template <bool TABLE>
+	__global__ __launch_bounds__(256) void lossy_sums_budget_kernel(LossyStep one, const LossyStep *__restrict__ table)
+	{
+		const LossyStep sp = lossy_step_of<TABLE>(one, table);
+		RIR_GLOBAL(const uint16_t) *prevT = as_global((const uint16_t *)sp.st.prevT), *tmp = as_global(sp.tmp), *img = as_global(sp.img);
+		RIR_GLOBAL(long long) *stats = as_global(sp.stats);
+		const int s = sp.s, subtract_min = sp.st.subtract_min;
+		const uint32_t mn = sp.st.min;
+		const uint32_t background = (uint32_t)stats[0];
+		long long a[6] = {0, 0, 0, 0, 0, 0};
+		auto pixel = [&](uint32_t tv, uint32_t pv, uint32_t iv) {
+			const uint32_t t = subtract_min ? sub_min(tv, mn) : tv;
+			const int32_t d = abs((int32_t)t - (int32_t)pv);
+			const int32_t d2 = (int32_t)((uint32_t)d * (uint32_t)d);
+			const int o = iv > background ? 0 : 3;
+			a[o] += d;
+			a[o + 1] += d2;
+			a[o + 2] += 1;
+		};
+		if ((s & 7) == 0)
+		{ // 8 pixels per 16-byte load
+			for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < s / 8; i += gridDim.x * blockDim.x)
+			{
+				const lossy_v4u tv = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(tmp + (size_t)i * 8);
+				const lossy_v4u pv = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(prevT + (size_t)i * 8);
+				const lossy_v4u iv = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(img + (size_t)i * 8);
+#pragma unroll
+				for (int k = 0; k < 4; ++k)
+				{
+					pixel(tv[k] & 0xffffu, pv[k] & 0xffffu, iv[k] & 0xffffu);
+					pixel(tv[k] >> 16, pv[k] >> 16, iv[k] >> 16);
+				}
+			}
+		}
+		else
+			for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < s; i += gridDim.x * blockDim.x)
+				pixel(tmp[i], prevT[i], img[i]);
+		// wave reduction, then the four waves of the block through LDS: one atomic per block and sum (a few hundred
+		// in total - one per wave made 24 000 contended 64-bit atomics and cost 0.29 ms per frame)
+		__shared__ long long red[4][6];
+#pragma unroll
+		for (int k = 0; k < 6; ++k)
+		{
+			long long v = a[k];
+#pragma unroll
+			for (int d = 32; d >= 1; d >>= 1)
+				v += __shfl_xor(v, d, 64);
+			if ((threadIdx.x & 63) == 0)
+				red[threadIdx.x >> 6][k] = v;
+		}
+		__syncthreads();
+		if (threadIdx.x < 6)
+		{
+			const long long v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+			if (v)
+				__hip_atomic_fetch_add((RIR_GLOBAL(unsigned long long) *)&stats[1 + threadIdx.x], (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		if (!lossy_last_arriver(sp.tickets + 1, gridDim.x, reinterpret_cast<unsigned int *>(&red[0][0])))
+			return;
+		// the six sums: one lane each (one round trip, not six), handed to thread 0 through LDS
+		if (threadIdx.x < 6)
+		{
+			red[1][threadIdx.x] = (long long)__hip_atomic_load((RIR_GLOBAL(unsigned long long) *)&stats[1 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			stats[1 + threadIdx.x] = 0; // the sums are accumulated with atomics: cleared for the next frame
+		}
+		// the budget state comes to LDS in one coalesced load, is worked on there by one thread, and goes back the same way
+		__shared__ LossyBudget bl;
+		static_assert(sizeof(LossyBudget) % 8 == 0 && sizeof(LossyBudget) / 8 <= 256, "LossyBudget is moved by one 8-byte word per thread");
+		RIR_GLOBAL(unsigned long long) *gb = (RIR_GLOBAL(unsigned long long) *)as_global(sp.budget);
+		unsigned long long *lb = reinterpret_cast<unsigned long long *>(&bl);
+		if (threadIdx.x < sizeof(LossyBudget) / 8)
+			lb[threadIdx.x] = gb[threadIdx.x];
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			long long st[7];
+			st[0] = stats[0];
+			for (int i = 1; i < 7; ++i)
+				st[i] = red[1][i - 1];
+			lossy_budget(sp, st, bl);
+		}
+		__syncthreads();
+		if (threadIdx.x < sizeof(LossyBudget) / 8)
+			gb[threadIdx.x] = lb[threadIdx.x];
 	}
 
 	// L3 + L4: running average update and decision loop, one thread per pixel of the whole frame.
-	__global__ __launch_bounds__(256) void lossy_update_kernel(const uint16_t *__restrict__ tmp, uint16_t *__restrict__ out, LossyDeviceState st,
-																int s, int full, const LossyDecision *__restrict__ decision, int add_loss)
+	template <bool TABLE>
+	__global__ __launch_bounds__(256) void lossy_update_kernel(LossyStep one, const LossyStep *__restrict__ table)
 	{
+		const LossyStep sp = lossy_step_of<TABLE>(one, table);
+		RIR_GLOBAL(const uint16_t) *tmp = as_global(sp.tmp);
+		RIR_GLOBAL(uint16_t) *out = as_global(sp.out);
+		const LossyDeviceState st_ = sp.st;
+		struct
+		{ // the state's arrays through global pointers; the scalars as they are
+			RIR_GLOBAL(uint16_t) * refT, *prevT, *lastDL, *ra_const_value, *ra_images;
+			RIR_GLOBAL(uint32_t) * ra_sums;
+			RIR_GLOBAL(int16_t) * ra_const_count;
+			int ra_count, ra_head, running_average, subtract_min;
+			uint32_t min;
+		} st = {as_global(st_.refT), as_global(st_.prevT), as_global(st_.lastDL), as_global(st_.ra_const_value), as_global(st_.ra_images),
+				as_global(st_.ra_sums), as_global(st_.ra_const_count), st_.ra_count, st_.ra_head, st_.running_average, st_.subtract_min, st_.min};
+		RIR_GLOBAL(const LossyDecision) *decision = as_global((const LossyDecision *)sp.decision);
+		const int s = sp.s, full = sp.full, add_loss = sp.add_loss;
 		const int i = blockIdx.x * blockDim.x + threadIdx.x;
 		if (i >= full)
 			return;
@@ -257,6 +390,140 @@ namespace rir
 		st.lastDL[i] = (uint16_t)v;
 	}
 
+	// The same update, 8 consecutive pixels per thread through 16-byte loads and stores (used when the lossy region and the frame
+	// are whole multiples of 8 pixels: every group is wholly inside or wholly past lossy_height).  One pixel per thread moves 2
+	// bytes per lane and instruction: with 32 streams per launch that kernel ran at a third of the bandwidth this one reaches.
+	struct U16x8
+	{
+		uint32_t d[4];
+		__device__ __forceinline__ uint32_t get(int k) const { return (k & 1) ? d[k >> 1] >> 16 : d[k >> 1] & 0xffffu; }
+		__device__ __forceinline__ void set(int k, uint32_t v) { d[k >> 1] = (k & 1) ? (d[k >> 1] & 0x0000ffffu) | (v << 16) : (d[k >> 1] & 0xffff0000u) | (v & 0xffffu); }
+	};
+	template <class P>
+	__device__ __forceinline__ U16x8 ld8(P p, int i8)
+	{
+		const lossy_v4u v = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(p + (size_t)i8 * 8);
+		U16x8 r;
+		r.d[0] = v.x, r.d[1] = v.y, r.d[2] = v.z, r.d[3] = v.w;
+		return r;
+	}
+	template <class P>
+	__device__ __forceinline__ void st8(P p, int i8, const U16x8 &r)
+	{
+		lossy_v4u v;
+		v.x = r.d[0], v.y = r.d[1], v.z = r.d[2], v.w = r.d[3];
+		*reinterpret_cast<RIR_GLOBAL(lossy_v4u) *>(p + (size_t)i8 * 8) = v;
+	}
+	template <bool TABLE>
+	__global__ __launch_bounds__(256) void lossy_update_vec_kernel(LossyStep one, const LossyStep *__restrict__ table)
+	{
+		const LossyStep sp = lossy_step_of<TABLE>(one, table);
+		RIR_GLOBAL(const uint16_t) *tmp = as_global(sp.tmp);
+		RIR_GLOBAL(uint16_t) *out = as_global(sp.out);
+		const LossyDeviceState st = sp.st;
+		RIR_GLOBAL(uint16_t) *refT = as_global(st.refT), *prevT = as_global(st.prevT), *lastDL = as_global(st.lastDL);
+		RIR_GLOBAL(uint16_t) *cval = as_global(st.ra_const_value), *ring = as_global(st.ra_images);
+		RIR_GLOBAL(uint16_t) *ccnt = (RIR_GLOBAL(uint16_t) *)as_global(st.ra_const_count);
+		RIR_GLOBAL(uint32_t) *sums = as_global(st.ra_sums);
+		RIR_GLOBAL(const LossyDecision) *decision = as_global((const LossyDecision *)sp.decision);
+		const int s = sp.s, full = sp.full, add_loss = sp.add_loss;
+		const int i8 = blockIdx.x * blockDim.x + threadIdx.x; // group of 8 pixels
+		if (i8 * 8 >= full)
+			return;
+		const U16x8 v8 = ld8(tmp, i8);
+		if (i8 * 8 >= s)
+		{ // rows past lossy_height: stored as they are
+			st8(out, i8, v8);
+			st8(lastDL, i8, v8);
+			return;
+		}
+		const uint32_t background = decision->background;
+		const int low_error = decision->low_error, high_error = decision->high_error;
+		const int ra = st.running_average;
+		const bool full_ring = ra > 0 && st.ra_count == ra;
+		const int n_after = ra > 0 ? (full_ring ? ra : st.ra_count + 1) : 0; // images.size() after addImage
+		U16x8 ref8 = ld8(refT, i8), last8, cc8, cv8, old8, t8, o8;
+		uint32_t sum[8];
+		if (!add_loss)
+			last8 = ld8(lastDL, i8);
+		if (ra > 0)
+		{
+			const lossy_v4u s0 = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(sums + (size_t)i8 * 8), s1 = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(sums + (size_t)i8 * 8 + 4);
+			sum[0] = s0.x, sum[1] = s0.y, sum[2] = s0.z, sum[3] = s0.w, sum[4] = s1.x, sum[5] = s1.y, sum[6] = s1.z, sum[7] = s1.w;
+			cc8 = ld8(ccnt, i8);
+			cv8 = ld8(cval, i8);
+			if (full_ring)
+				old8 = ld8(ring + (size_t)st.ra_head * s, i8);
+		}
+		bool ref_changed = false, cc_changed = false; // (per group of 8: the arrays are written back only where a pixel changed them)
+#pragma unroll
+		for (int k = 0; k < 8; ++k)
+		{
+			const uint32_t v = v8.get(k);
+			uint32_t t = st.subtract_min ? sub_min(v, st.min) : v;
+			t8.set(k, t);
+			uint32_t sm = 0;
+			if (ra > 0)
+			{ // RunningAverage2::addImage
+				sm = sum[k] + t;
+				if (full_ring)
+				{
+					const uint32_t cc = cc8.get(k);
+					if (cc)
+					{
+						cc8.set(k, cc - 1u);
+						cc_changed = true;
+						sm -= cv8.get(k);
+					}
+					else
+						sm -= old8.get(k);
+				}
+			}
+			const uint32_t ref = ref8.get(k);
+			const int diff = abs((int)t - (int)ref);
+			const int max_error = v > background ? high_error : low_error;
+			bool keep = diff <= max_error;
+			if (!add_loss)
+				keep = keep && ((last8.get(k) >> 13) == (v >> 13));
+			if (keep)
+				t = ra > 0 ? sm / (uint32_t)n_after : ref;
+			else
+			{
+				ref8.set(k, t);
+				ref_changed = true;
+				if (ra > 0)
+				{
+					cv8.set(k, t);
+					cc8.set(k, (uint32_t)n_after);
+					cc_changed = true;
+					sm = t * (uint32_t)n_after;
+				}
+			}
+			sum[k] = sm;
+			o8.set(k, t);
+		}
+		if (ra > 0)
+		{
+			// the new image takes the free slot (ring not full) or replaces the oldest one
+			const int slot = full_ring ? st.ra_head : (st.ra_head + st.ra_count) % ra;
+			st8(ring + (size_t)slot * s, i8, t8);
+			lossy_v4u s0, s1;
+			s0.x = sum[0], s0.y = sum[1], s0.z = sum[2], s0.w = sum[3], s1.x = sum[4], s1.y = sum[5], s1.z = sum[6], s1.w = sum[7];
+			*reinterpret_cast<RIR_GLOBAL(lossy_v4u) *>(sums + (size_t)i8 * 8) = s0;
+			*reinterpret_cast<RIR_GLOBAL(lossy_v4u) *>(sums + (size_t)i8 * 8 + 4) = s1;
+			if (cc_changed)
+			{
+				st8(ccnt, i8, cc8);
+				st8(cval, i8, cv8);
+			}
+		}
+		if (ref_changed)
+			st8(refT, i8, ref8);
+		st8(out, i8, o8);
+		st8(prevT, i8, o8);
+		st8(lastDL, i8, v8);
+	}
+
 	// first frame: out = tmp minus the optional minimum on rows < lossy_height; seeds refT / prevT / lastDL
 	__global__ __launch_bounds__(256) void lossy_first_kernel(const uint16_t *__restrict__ tmp, uint16_t *__restrict__ out, LossyDeviceState st, int s,
 															   int full)
@@ -302,32 +569,45 @@ namespace rir
 		}
 	}
 
-	// d_hist (16 384 bins) and d_stats[1..7] must be zero on entry: they are when the state is created, and every frame
-	// leaves them so (lossy_mode_kernel / lossy_budget_kernel clear what they have read).
-	hipError_t launch_lossy_stats(const uint16_t *d_prevT, const uint16_t *d_tmp, const uint16_t *d_img, int s, uint32_t mn, int subtract_min,
-								  uint32_t *d_hist, long long *d_stats, hipStream_t st)
+	// One frame of `nstreams` streams: h_steps[i] describes stream i (device pointers; the ring indices as they are for this
+	// frame).  One stream: the description travels as a kernel argument; several: d_table (device, nstreams entries, already
+	// filled with h_steps by the caller) is indexed by blockIdx.y.  hist (16 384 bins), stats[1..7] and the two tickets of every
+	// stream must be zero on entry: they are when the state is created, and every frame leaves them so.
+	hipError_t launch_lossy_step(const LossyStep *h_steps, const LossyStep *d_table, int nstreams, hipStream_t st)
 	{
-		hipLaunchKernelGGL(lossy_hist_kernel, dim3((s + RIR_LOSSY_HIST_PX - 1) / RIR_LOSSY_HIST_PX), dim3(1024), 0, st, d_tmp, s, d_hist);
-		hipLaunchKernelGGL(lossy_mode_kernel, dim3(1), dim3(1024), 0, st, d_hist, d_stats);
-		int blocks = (s + 2047) / 2048; // 8 pixels per thread
+		const LossyStep &one = h_steps[0];
+		const int s = one.s, full = one.full; // (equal for all streams of a launch)
+		int blocks = (s + 2047) / 2048; // sums: 8 pixels per thread
 		if (blocks > 256)
 			blocks = 256;
-		hipLaunchKernelGGL(lossy_sums_kernel, dim3(blocks), dim3(256), 0, st, d_prevT, d_tmp, d_img, s, mn, subtract_min, d_stats);
-		return hipGetLastError();
-	}
-
-	hipError_t launch_lossy_budget(long long *d_stats, LossyBudget *d_budget, int s, int add_loss, double std_factor, int low_value_error,
-								   int high_value_error, LossyDecision *d_decision, int *d_errors_out, hipStream_t st)
-	{
-		hipLaunchKernelGGL(lossy_budget_kernel, dim3(1), dim3(1), 0, st, d_stats, d_budget, s, add_loss, std_factor, low_value_error, high_value_error,
-						   d_decision, d_errors_out);
-		return hipGetLastError();
-	}
-
-	hipError_t launch_lossy_update(const uint16_t *d_tmp, uint16_t *d_out, const LossyDeviceState &state, int s, int full,
-								   const LossyDecision *d_decision, int add_loss, hipStream_t st)
-	{
-		hipLaunchKernelGGL(lossy_update_kernel, dim3((full + 255) / 256), dim3(256), 0, st, d_tmp, d_out, state, s, full, d_decision, add_loss);
+		const int hist_px = h_steps[0].hist_px;
+		const dim3 gh((s + hist_px - 1) / hist_px, nstreams), gs(blocks, nstreams), gu((full + 255) / 256, nstreams);
+		const dim3 gv((full / 8 + 255) / 256, nstreams);
+		const bool vec = (s % 8 == 0) && (full % 8 == 0); // every group of 8 pixels wholly inside or wholly past the lossy rows
+		if (nstreams > 1)
+		{
+			if (s > 0)
+			{
+				hipLaunchKernelGGL(lossy_hist_mode_kernel<true>, gh, dim3(1024), 0, st, one, d_table);
+				hipLaunchKernelGGL(lossy_sums_budget_kernel<true>, gs, dim3(256), 0, st, one, d_table);
+			}
+			if (vec)
+				hipLaunchKernelGGL(lossy_update_vec_kernel<true>, gv, dim3(256), 0, st, one, d_table);
+			else
+				hipLaunchKernelGGL(lossy_update_kernel<true>, gu, dim3(256), 0, st, one, d_table);
+		}
+		else
+		{
+			if (s > 0)
+			{
+				hipLaunchKernelGGL(lossy_hist_mode_kernel<false>, gh, dim3(1024), 0, st, one, nullptr);
+				hipLaunchKernelGGL(lossy_sums_budget_kernel<false>, gs, dim3(256), 0, st, one, nullptr);
+			}
+			if (vec)
+				hipLaunchKernelGGL(lossy_update_vec_kernel<false>, gv, dim3(256), 0, st, one, nullptr);
+			else
+				hipLaunchKernelGGL(lossy_update_kernel<false>, gu, dim3(256), 0, st, one, nullptr);
+		}
 		return hipGetLastError();
 	}
 

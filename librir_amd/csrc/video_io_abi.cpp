@@ -166,7 +166,7 @@ namespace
 	{
 		int w = 0, h = 0, hl = 0;
 		int frames = 0;
-		DeviceBuffer d_img, d_tmp, d_out, d_ref, d_prev, d_last, d_sums, d_cval, d_ccnt, d_ring, d_hist, d_stats, d_min, d_budget, d_decision, d_errs;
+		DeviceBuffer d_img, d_tmp, d_out, d_ref, d_prev, d_last, d_sums, d_cval, d_ccnt, d_ring, d_hist, d_stats, d_min, d_budget, d_decision, d_errs, d_tickets;
 		LossyDeviceState dev{};
 		int bp_handle = 0;
 
@@ -185,14 +185,15 @@ namespace
 				!d_prev.reserve(full * 2) || !d_last.reserve(full * 2) || !d_sums.reserve(s * 4 + 4) || !d_cval.reserve(s * 2 + 4) ||
 				!d_ccnt.reserve(s * 2 + 4) || !d_ring.reserve((size_t)std::max(ra, 1) * s * 2 + 4) || !d_hist.reserve(16384 * 4) ||
 				!d_stats.reserve(8 * sizeof(long long)) || !d_min.reserve(4) || !d_budget.reserve(sizeof(LossyBudget)) ||
-				!d_decision.reserve(sizeof(LossyDecision)) || !d_errs.reserve(2 * sizeof(int)))
+				!d_decision.reserve(sizeof(LossyDecision)) || !d_errs.reserve(2 * sizeof(int)) || !d_tickets.reserve(2 * sizeof(unsigned int)))
 				return false;
 			hipStream_t st = default_stream();
 			// histogram, sums and budget start at zero; afterwards every frame leaves the first two cleared (lossy_kernels.hip)
 			if (!hip_ok(hipMemsetAsync(d_sums.ptr, 0, s * 4 + 4, st), "memset") || !hip_ok(hipMemsetAsync(d_cval.ptr, 0, s * 2 + 4, st), "memset") ||
 				!hip_ok(hipMemsetAsync(d_ccnt.ptr, 0, s * 2 + 4, st), "memset") || !hip_ok(hipMemsetAsync(d_hist.ptr, 0, 16384 * 4, st), "memset") ||
 				!hip_ok(hipMemsetAsync(d_stats.ptr, 0, 8 * sizeof(long long), st), "memset") ||
-				!hip_ok(hipMemsetAsync(d_budget.ptr, 0, sizeof(LossyBudget), st), "memset"))
+				!hip_ok(hipMemsetAsync(d_budget.ptr, 0, sizeof(LossyBudget), st), "memset") ||
+				!hip_ok(hipMemsetAsync(d_tickets.ptr, 0, 2 * sizeof(unsigned int), st), "memset"))
 				return false;
 			dev.refT = d_ref.as<uint16_t>(), dev.prevT = d_prev.as<uint16_t>(), dev.lastDL = d_last.as<uint16_t>();
 			dev.ra_sums = d_sums.as<uint32_t>(), dev.ra_const_value = d_cval.as<uint16_t>(), dev.ra_const_count = d_ccnt.as<int16_t>();
@@ -287,23 +288,41 @@ namespace
 			}
 			else
 			{
-				if (!hip_ok(launch_lossy_stats(dev.prevT, tmp, d_src, s, dev.min, dev.subtract_min, d_hist.as<uint32_t>(), d_stats.as<long long>(), st),
-							"lossy stats") ||
-					!hip_ok(launch_lossy_budget(d_stats.as<long long>(), d_budget.as<LossyBudget>(), s, add_loss ? 1 : 0, std_factor, low_value_error,
-												high_value_error, d_decision.as<LossyDecision>(), d_errors, st),
-							"lossy budget") ||
-					!hip_ok(launch_lossy_update(tmp, d_dst, dev, s, full, d_decision.as<LossyDecision>(), add_loss ? 1 : 0, st), "lossy update"))
+				const LossyStep step = make_step(tmp, d_src, d_dst, add_loss, low_value_error, high_value_error, std_factor, d_errors);
+				if (!hip_ok(launch_lossy_step(&step, nullptr, 1, st), "lossy step"))
 					return false;
-				if (dev.running_average > 0)
-				{
-					if (dev.ra_count == dev.running_average)
-						dev.ra_head = (dev.ra_head + 1) % dev.running_average;
-					else
-						++dev.ra_count;
-				}
+				advance_ring();
 			}
 			++frames;
 			return true;
+		}
+
+		// what the kernels of the next frame need (the ring indices as they are now)
+		LossyStep make_step(const uint16_t *tmp, const uint16_t *img, uint16_t *dst, bool add_loss, int low_value_error, int high_value_error,
+							double std_factor, int *d_errors, int nstreams = 1)
+		{
+			LossyStep p;
+			p.hist_px = lossy_hist_px(w * hl, nstreams), p.reserved = 0;
+			p.tmp = tmp, p.img = img, p.out = dst;
+			p.st = dev;
+			p.hist = d_hist.as<uint32_t>(), p.stats = d_stats.as<long long>();
+			p.budget = d_budget.as<LossyBudget>(), p.decision = d_decision.as<LossyDecision>();
+			p.errors_out = d_errors;
+			p.tickets = d_tickets.as<unsigned int>();
+			p.s = w * hl, p.full = w * h;
+			p.add_loss = add_loss ? 1 : 0, p.low_value_error = low_value_error, p.high_value_error = high_value_error;
+			p.std_factor = std_factor;
+			return p;
+		}
+		void advance_ring()
+		{
+			if (dev.running_average > 0)
+			{
+				if (dev.ra_count == dev.running_average)
+					dev.ra_head = (dev.ra_head + 1) % dev.running_average;
+				else
+					++dev.ra_count;
+			}
 		}
 	};
 
@@ -316,6 +335,8 @@ namespace
 		double std_factor = 5;
 		bool remove_bad_pixels = false;
 		DeviceBuffer batch_errs; // int[nframes][2] of the last rir_lossy_step_device call
+		DeviceBuffer multi_table; // rir_lossy_step_multi_device: the steps of the call (this object leads it)
+		PinnedBuffer multi_stage;
 	};
 
 	// ---- saver -------------------------------------------------------------------------------
@@ -2174,6 +2195,102 @@ RIR_EXPORT int rir_lossy_step_device(int handle, const unsigned short *d_in, uns
 			!hip_ok(wait_stream(st), "sync"))
 			return -1;
 		for (int i = 0; i < nframes; ++i)
+		{
+			if (low_errors)
+				low_errors[i] = e[2 * i];
+			if (high_errors)
+				high_errors[i] = e[2 * i + 1];
+		}
+	}
+	return 0;
+}
+
+// The same step for `nstreams` INDEPENDENT streams (one state object each, equal geometry and history length) with the streams
+// sharing every launch: frame f of all streams = three launches whose grids carry the stream in their second dimension
+// (the loss state is sequential in time, so streams - not frames - are what runs side by side).
+// d_in[i] / d_out[i]: uint16 [nframes][h][w] of stream i (HOST arrays of nstreams device pointers); low_errors / high_errors:
+// HOST int[nstreams][nframes] or NULL (then nothing waits).
+RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, const unsigned short *const *d_in, unsigned short *const *d_out,
+										   int nframes, int add_loss, int *low_errors, int *high_errors, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (!handles || nstreams <= 0 || nstreams > 65535 || !d_in || !d_out || nframes <= 0)
+	{
+		log_error("rir_lossy_step_multi_device: invalid argument");
+		return -1;
+	}
+	std::vector<std::shared_ptr<LossyObject>> os((size_t)nstreams);
+	for (int i = 0; i < nstreams; ++i)
+	{
+		os[i] = lookup_as<LossyObject>(handles[i]);
+		if (!os[i] || !d_in[i] || !d_out[i] || d_in[i] == d_out[i])
+		{
+			log_error("rir_lossy_step_multi_device: invalid handle or buffer");
+			return -1;
+		}
+		for (int k = 0; k < i; ++k)
+			if (os[k] == os[i])
+			{
+				log_error("rir_lossy_step_multi_device: a stream appears twice");
+				return -1;
+			}
+		const LossyState &a = os[0]->st, &b = os[i]->st;
+		if (a.w != b.w || a.h != b.h || a.hl != b.hl || a.frames != b.frames || os[i]->remove_bad_pixels)
+		{
+			log_error("rir_lossy_step_multi_device: the streams must share geometry and history length (and not repair bad pixels)");
+			return -1;
+		}
+	}
+	hipStream_t st = (hipStream_t)stream;
+	const size_t npx = (size_t)os[0]->st.w * os[0]->st.h;
+	const bool want = low_errors || high_errors;
+	LossyObject &lead = *os[0]; // owns the scratch of the call: the table of steps and the budgets
+	if (want && !lead.batch_errs.reserve((size_t)nstreams * nframes * 2 * sizeof(int)))
+		return -1;
+	int f0 = 0;
+	if (os[0]->st.frames == 0)
+	{ // first frame of every stream: stored as it is, seeds the state - one small launch per stream, once in a stream's life
+		for (int i = 0; i < nstreams; ++i)
+			if (!os[i]->st.queue_frame(d_in[i], d_out[i], add_loss != 0, false, os[i]->low, os[i]->high, os[i]->std_factor,
+									   want ? lead.batch_errs.as<int>() + ((size_t)i * nframes) * 2 : nullptr, st))
+				return -1;
+		f0 = 1;
+	}
+	const int nsteps = nframes - f0;
+	if (nsteps > 0)
+	{
+		// the descriptions of all steps of the call go to the device in one copy (page-locked staging: the copy is asynchronous
+		// and the host buffer must outlive it - it is kept by the leading stream's object)
+		const size_t nb = (size_t)nsteps * nstreams * sizeof(LossyStep);
+		if (!lead.multi_table.reserve(nb) || !lead.multi_stage.reserve(nb))
+			return -1;
+		if (!hip_ok(wait_stream(st), "sync")) // (an earlier call's copy out of the staging buffer may still be in flight)
+			return -1;
+		LossyStep *hs = lead.multi_stage.as<LossyStep>();
+		for (int f = f0; f < nframes; ++f)
+			for (int i = 0; i < nstreams; ++i)
+			{
+				LossyState &ls = os[i]->st;
+				int *errs = want ? lead.batch_errs.as<int>() + ((size_t)i * nframes + f) * 2 : nullptr;
+				hs[(size_t)(f - f0) * nstreams + i] = ls.make_step(d_in[i] + (size_t)f * npx, d_in[i] + (size_t)f * npx, d_out[i] + (size_t)f * npx, add_loss != 0,
+																	 os[i]->low, os[i]->high, os[i]->std_factor, errs, nstreams);
+				ls.advance_ring();
+				++ls.frames;
+			}
+		if (!hip_ok(hipMemcpyAsync(lead.multi_table.ptr, hs, nb, hipMemcpyHostToDevice, st), "H2D"))
+			return -1;
+		for (int f = 0; f < nsteps; ++f)
+			if (!hip_ok(launch_lossy_step(hs + (size_t)f * nstreams, lead.multi_table.as<LossyStep>() + (size_t)f * nstreams, nstreams, st), "lossy step"))
+				return -1;
+	}
+	if (want)
+	{
+		std::vector<int> e((size_t)nstreams * nframes * 2);
+		if (!hip_ok(hipMemcpyAsync(e.data(), lead.batch_errs.ptr, e.size() * sizeof(int), hipMemcpyDeviceToHost, st), "D2H") ||
+			!hip_ok(wait_stream(st), "sync"))
+			return -1;
+		for (size_t i = 0; i < (size_t)nstreams * nframes; ++i)
 		{
 			if (low_errors)
 				low_errors[i] = e[2 * i];

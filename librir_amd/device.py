@@ -84,6 +84,7 @@ _lib.rir_median_filter_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int
 _lib.bad_pixels_destroy.argtypes = [ct.c_int]
 _lib.rir_lossy_create.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_double, ct.c_int, ct.c_int, ct.c_int]
 _lib.rir_lossy_step_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, _vp, _vp, _vp]
+_lib.rir_lossy_step_multi_device.argtypes = [_vp, ct.c_int, _vp, _vp, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.rir_lossy_destroy.argtypes = [ct.c_int]
 _lib.rir_split_planes_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp]
 _lib.rir_merge_planes_device.argtypes = [_vp, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
@@ -436,6 +437,27 @@ class LossyStream:
                                           lo.ctypes.data if errors else None, hi.ctypes.data if errors else None, _stream()),
                "rir_lossy_step_device")
         return out, lo, hi
+
+    @staticmethod
+    def step_many(streams, frames, add_loss=False, errors=True):
+        """The step for several independent streams in shared launches (rir_lossy_step_multi_device): ``streams`` are
+        LossyStream objects of one geometry that have seen the same number of frames, ``frames`` one (n,h,w) uint16 device
+        tensor per stream.  -> (list of processed tensors, low_errors[stream][frame], high_errors[stream][frame])."""
+        S = len(streams)
+        frs = [_frames3(f, torch.uint16) for f in frames]
+        if S == 0 or len(frs) != S or any(tuple(f.shape) != tuple(frs[0].shape) for f in frs) or tuple(frs[0].shape[1:]) != streams[0].shape:
+            raise RuntimeError("LossyStream.step_many: one tensor of the streams' frame size per stream expected")
+        n = frs[0].shape[0]
+        outs = [torch.empty_like(f) for f in frs]
+        handles = (ct.c_int * S)(*[s.handle for s in streams])
+        pin = (ct.c_void_p * S)(*[f.data_ptr() for f in frs])
+        pout = (ct.c_void_p * S)(*[o.data_ptr() for o in outs])
+        lo = np.zeros((S, n), np.int32) if errors else None
+        hi = np.zeros((S, n), np.int32) if errors else None
+        _check(_lib.rir_lossy_step_multi_device(ct.cast(handles, _vp), S, ct.cast(pin, _vp), ct.cast(pout, _vp), n, int(bool(add_loss)),
+                                                lo.ctypes.data if errors else None, hi.ctypes.data if errors else None, _stream()),
+               "rir_lossy_step_multi_device")
+        return outs, lo, hi
 
     def close(self):
         if getattr(self, "handle", 0) > 0:

@@ -149,3 +149,42 @@ def test_device_resident_stream_matches_oracle(oracle, add_loss):
     assert lo_a is None
     assert np.array_equal(torch.cat([a, b]).cpu().numpy(), np.stack(exp))
     ls.close()
+
+
+def test_many_streams_in_shared_launches_equal_their_own_oracles(oracle):
+    """rir_lossy_step_multi_device: S independent streams (different data, different parameters) stepped by the same launches,
+    in two calls (the first seeds the states, the second continues them): every stream's frames and per-frame budgets are
+    those of its own oracle, bit for bit; a stream stepped alone gives the same result."""
+    import torch
+
+    from librir_amd import device as D
+
+    S, n, h, w, hl = 5, 47, 96, 128, 93
+    params = [dict(low=6, high=2, sf=5.0, ra=32), dict(low=3, high=3, sf=0.0, ra=4), dict(low=5, high=1, sf=2.5, ra=0),
+              dict(low=9, high=4, sf=5.0, ra=7), dict(low=6, high=2, sf=5.0, ra=32)]
+    data = [s1_noisy_background(n, h, w, seed=20 + i) for i in range(S)]
+    streams = [D.LossyStream(w, h, hl, p["low"], p["high"], p["sf"], p["ra"]) for p in params]
+    tens = [torch.from_numpy(d).cuda() for d in data]
+    cut = 13
+    o1, lo1, hi1 = D.LossyStream.step_many(streams, [t[:cut] for t in tens])
+    o2, lo2, hi2 = D.LossyStream.step_many(streams, [t[cut:] for t in tens])
+    for i, p in enumerate(params):
+        L = OracleLossy(oracle, w, h, hl, low_err=p["low"], high_err=p["high"], std_factor=p["sf"], running_average=p["ra"])
+        exp, elo, ehi = [], [], []
+        for f in range(n):
+            exp.append(L.step(data[i][f]))
+            lo, hi, _ = L.last_errors()
+            elo.append(lo)
+            ehi.append(hi)
+        got = np.concatenate([o1[i].cpu().numpy(), o2[i].cpu().numpy()])
+        assert np.array_equal(got, np.stack(exp)), i
+        assert np.concatenate([lo1[i], lo2[i]]).tolist() == elo and np.concatenate([hi1[i], hi2[i]]).tolist() == ehi, i
+    alone = D.LossyStream(w, h, hl, params[3]["low"], params[3]["high"], params[3]["sf"], params[3]["ra"])
+    oa, loa, hia = alone.step(tens[3])
+    assert np.array_equal(oa.cpu().numpy(), np.concatenate([o1[3].cpu().numpy(), o2[3].cpu().numpy()]))
+    # streams that are out of step with each other are refused
+    fresh = D.LossyStream(w, h, hl)
+    with pytest.raises(RuntimeError):
+        D.LossyStream.step_many([streams[0], fresh], [tens[0][:2], tens[1][:2]])
+    for s in streams + [alone, fresh]:
+        s.close()
