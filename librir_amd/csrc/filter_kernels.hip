@@ -877,8 +877,13 @@ namespace rir
 	// to the three-kernel chain.  Strategies whose border pixels are not local to the tile (wrap, noborder) are not
 	// offered; a tap outside the wave's block (possible only through float rounding of px + 1) is recomputed from
 	// global memory by chain_gauss_point.
+// Store policy of the output tiles.  Their rows are 60 (median: 63) pixels long, so neighbouring tiles - other waves, other
+// CUs - share 128-byte lines.  With the streaming policy (aux = 2) every partial line went to memory on its own: WRITE_SIZE
+// 244 MB for 168 MB of output (1.45x), and the encoder that reads the frames next found nothing cached.  With the default
+// policy the lines are completed in L2: 172 MB (1.02x); the kernel alone is 3 % slower (0.149 vs 0.145 ms per 256 frames),
+// chain + encode 3 % faster (0.198 vs 0.204 ms) - scripts/chain_variants.sh, profiles/r02_pmc_filters.json.
 #ifndef RIR_CHAIN_STORE_AUX
-#define RIR_CHAIN_STORE_AUX 2
+#define RIR_CHAIN_STORE_AUX 0
 #endif
 #ifndef RIR_CHAIN_TY
 #define RIR_CHAIN_TY 16 /* rows of the gaussian block per wave; OH = TY - 2 output rows */
@@ -1898,7 +1903,7 @@ namespace rir
 				const int ox = x0 + 4 * k, oy = y0 + row;
 				const v2u32 px4 = *reinterpret_cast<const v2u32 *>(&strip[wv][row < TY ? row : 0][4 * k]);
 				const bool st = c < PPR * TY && ox < w && oy < h;
-				__builtin_amdgcn_raw_buffer_store_b64(px4, rd, (int)(st ? (uint32_t)((oy * w + ox) * 2) : 0x80000000u), 0, 2);
+				__builtin_amdgcn_raw_buffer_store_b64(px4, rd, (int)(st ? (uint32_t)((oy * w + ox) * 2) : 0x80000000u), 0, RIR_CHAIN_STORE_AUX);
 			}
 		}
 	}

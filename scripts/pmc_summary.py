@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc counter_collection.csv files: per kernel, mean counter value per dispatch."""
-import csv, glob, sys, collections, json, os
+import csv, glob, sys, collections, json, os, re
 root = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
     for row in csv.DictReader(open(f)):
-        k = row["Kernel_Name"].split("(")[0].replace("rir::", "")
+        k = re.sub(r"<.*", "", row["Kernel_Name"].split("(")[0].replace("void ", "").replace("rir::", ""))  # (template arguments dropped)
         if not k.startswith("rirb1"):
             continue
         agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
