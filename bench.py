@@ -50,6 +50,7 @@ def parse():
     p.add_argument("--gop", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-abi", action="store_true", help="skip the per-frame / batched host-pointer numbers")
+    p.add_argument("--abi-child", action="store_true", help=argparse.SUPPRESS)  # internal: the process that measures those numbers
     p.add_argument("--cpu-frames", type=int, default=1000, help="frames of the same stream the CPU oracle works through per pass")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="the CPU oracle repeats passes until this much time is spent")
     p.add_argument("--exchange-piece", type=int, default=100, help="frames per sub-batch of the decoded all-gather (whole chunks)")
@@ -221,6 +222,12 @@ def abi_numbers(frames_np, D, ctx, frames, out, n, h, w):
     assert np.array_equal(pin_out.numpy(), frames_np)
     with tempfile.TemporaryDirectory() as d:
         dst = os.path.join(d, "abi.h264")
+        with IRSaver(os.path.join(d, "warm.h264"), w, h, h) as s:  # the first saver / loader of a process pay one-off set-up costs
+            for i in range(min(n, 60)):                                # (page-locked staging, the writer and read-ahead threads)
+                s.add_image(frames_np[i], i)
+        with IRMovie.from_filename(os.path.join(d, "warm.h264")) as mov:
+            for i in range(min(n, 60)):
+                mov[i]
         t0 = time.perf_counter()
         with IRSaver(dst, w, h, h) as s:
             for i in range(n):
@@ -253,10 +260,33 @@ def main():
     n, h, w, gop = args.frames, args.height, args.width, args.gop
     # every rank holds its own shard of the stream (different seed = different frames)
     frames_np = s1_noisy_background(n, h, w, seed=1234 + rank)
+    if args.abi_child:
+        import torch
+
+        from librir_amd import device as D
+
+        torch.cuda.set_device(0)
+        frames = torch.from_numpy(frames_np).cuda()
+        ctx = D.CodecContext(w, h, n, gop)
+        print(json.dumps(abi_numbers(frames_np, D, ctx, frames, torch.empty_like(frames), n, h, w)))
+        return
     # the CPU path is timed beside the N=1 run only, before this process touches the GPU (forked workers)
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         cpu = cpu_baseline(frames_np, gop, args.cpu_frames, args.cpu_seconds)
+    # The per-frame / batched host-pointer numbers come from a process of their own, run to completion before this one touches
+    # the GPU: the per-frame path encodes and decodes chunk by chunk (50-frame launches of the same kernels), which would mix
+    # into the per-kernel averages of a rocprofv3 --stats run of this command (profiles/: one stats file per process).
+    extra_abi = {}
+    if world == 1 and not args.no_abi:
+        import subprocess
+
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--abi-child", "--frames", str(n), "--width", str(w), "--height", str(h),
+                            "--gop", str(gop)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        try:
+            extra_abi = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception:
+            extra_abi = {"per_frame_abi_fps": None, "abi_error": (r.stderr or r.stdout)[-300:]}
 
     import torch
     import torch.distributed as dist
@@ -437,8 +467,7 @@ def main():
         ok_sp = ctx.encode_status() == 0 and bool(torch.equal(out.view(torch.int16), frames.view(torch.int16)))
         extra["single_pass_encoder"] = {"ms_per_launch": e0.elapsed_time(e1) / K, "bit_exact_roundtrip": ok_sp,
                                         "kernel": "rirb1_encode_dense (memset + 1 launch)", "two_pass_ms": ms_tiles + ms_compact}
-    if world == 1 and not args.no_abi:
-        extra.update(abi_numbers(frames_np, D, ctx, frames, out, n, h, w))
+    extra.update(extra_abi)
 
     if rank == 0:
         raw = 2.0 * h * w * n  # bytes of raw uint16 per batch

@@ -7,7 +7,18 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python $GRAFT_REPO_ROOT/bench.py > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+# one stats file per process: bench.py measures its per-frame ABI numbers in a child process (50-frame launches of the same kernels);
+# the file of the bench process itself is the one with the most rirb1_decode_tiles time
+python - <<PY
+import csv, glob, shutil
+best, bestt = None, -1
+for f in glob.glob("$OUT/stats/**/*kernel_stats.csv", recursive=True):
+    t = sum(float(r["TotalDurationNs"]) for r in csv.DictReader(open(f)) if "rirb1_decode_tiles" in r["Name"])
+    if t > bestt:
+        best, bestt = f, t
+shutil.copy(best, "$OUT/kernel_stats.csv")
+print("kernel stats of the bench process:", best)
+PY
 cd $GRAFT_REPO_ROOT && bash scripts/pmc.sh $TAG > /dev/null 2>&1
 python scripts/pmc_summary.py gpurun_out/pmc_$TAG > $OUT/pmc_summary.json
 python scripts/pmc_traffic.py $OUT/pmc_summary.json > $OUT/pmc_traffic.json
