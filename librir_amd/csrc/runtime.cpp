@@ -191,10 +191,75 @@ namespace rir
 		cap = want;
 		return ptr;
 	}
+	// Page-locking is slow (a saver's and a loader's staging buffers are 100 - 140 MB: tens of milliseconds, as much as recording
+	// or reading a few hundred frames), so large page-locked buffers of objects that die are kept for the next object instead of
+	// being returned to the system.  A buffer only enters the pool after the device has gone idle (work of the dead object may
+	// still be in flight on some stream; hipHostFree would have waited for it too), and is only handed out for requests it fits
+	// without much waste.  The pool is bounded and is never freed at exit (the runtime may already be gone by then).
+	namespace
+	{
+		struct PinnedPool
+		{
+			std::mutex mu;
+			struct Item
+			{
+				void *ptr;
+				size_t cap;
+				int device;
+			};
+			std::vector<Item> items;
+			size_t total = 0;
+			static constexpr size_t kMin = 1u << 20, kMaxTotal = 768u << 20;
+		};
+		PinnedPool &pinned_pool()
+		{
+			static PinnedPool *p = new PinnedPool; // (leaked on purpose)
+			return *p;
+		}
+		void pinned_release(void *ptr, size_t cap)
+		{
+			int dev = 0;
+			if (cap >= PinnedPool::kMin && hipGetDevice(&dev) == hipSuccess)
+			{
+				PinnedPool &pool = pinned_pool();
+				std::unique_lock<std::mutex> lk(pool.mu);
+				if (pool.total + cap <= PinnedPool::kMaxTotal)
+				{
+					lk.unlock();
+					(void)hipDeviceSynchronize();
+					lk.lock();
+					pool.items.push_back({ptr, cap, dev});
+					pool.total += cap;
+					return;
+				}
+			}
+			(void)hipHostFree(ptr);
+		}
+		void *pinned_acquire(size_t want, size_t &cap_out)
+		{
+			int dev = 0;
+			if (want < PinnedPool::kMin || hipGetDevice(&dev) != hipSuccess)
+				return nullptr;
+			PinnedPool &pool = pinned_pool();
+			std::lock_guard<std::mutex> g(pool.mu);
+			size_t best = pool.items.size();
+			for (size_t i = 0; i < pool.items.size(); ++i)
+				if (pool.items[i].device == dev && pool.items[i].cap >= want && pool.items[i].cap <= want + want / 2 + PinnedPool::kMin &&
+					(best == pool.items.size() || pool.items[i].cap < pool.items[best].cap))
+					best = i;
+			if (best == pool.items.size())
+				return nullptr;
+			void *p = pool.items[best].ptr;
+			cap_out = pool.items[best].cap;
+			pool.total -= cap_out;
+			pool.items.erase(pool.items.begin() + (long)best);
+			return p;
+		}
+	} // namespace
 	PinnedBuffer::~PinnedBuffer()
 	{
 		if (ptr)
-			(void)hipHostFree(ptr);
+			pinned_release(ptr, cap);
 	}
 	void *PinnedBuffer::reserve(size_t bytes)
 	{
@@ -202,11 +267,17 @@ namespace rir
 			return ptr;
 		if (ptr)
 		{
-			(void)hipHostFree(ptr);
+			pinned_release(ptr, cap);
 			ptr = nullptr;
 			cap = 0;
 		}
 		size_t want = bytes < 256 ? 256 : bytes;
+		size_t got = 0;
+		if (void *p = pinned_acquire(want, got))
+		{
+			ptr = p, cap = got;
+			return ptr;
+		}
 		if (!hip_ok(hipHostMalloc(&ptr, want, hipHostMallocDefault), "hipHostMalloc"))
 		{
 			ptr = nullptr;

@@ -72,6 +72,9 @@ def dev_roundtrip():
 ms = gpu_ms(dev_roundtrip, 10)
 assert torch.equal(dec.view(torch.int16), t.view(torch.int16))
 c1 = {"workload": "%d x %dx%d u16, S1, GOP %d, encode+decode" % (n, w, h, gop), "device_resident_fps": n / ms * 1e3}
+ms = gpu_ms(lambda: ctx.decode(ctx.encode(t, single_pass=True), out=dec, check=False), 10)
+assert torch.equal(dec.view(torch.int16), t.view(torch.int16)) and ctx.encode_status() == 0
+c1["device_resident_fps_single_pass_encoder"] = n / ms * 1e3
 pin_in = torch.from_numpy(fr).pin_memory()
 pin_out = torch.empty_like(pin_in)
 enc0 = ctx.encode(t)
@@ -278,6 +281,31 @@ def lossy_dev():
 
 ms = gpu_ms(lossy_dev, 3)
 c4["lossy_then_encode_device_resident_fps"] = n4 / ms * 1e3
+
+
+def lossy_only():
+    ls = D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32)
+    ls.step(treg, errors=False)
+    ls.close()
+
+
+ms = gpu_ms(lossy_only, 3)
+c4["lossy_step_device_resident_fps_one_stream"] = n4 / ms * 1e3
+# independent streams in shared launches (rir_lossy_step_multi_device): the loss state is sequential in time, streams run side by side
+for S in (8, 32):
+    m = 20 if args.quick else 60
+    streams = [D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32) for _ in range(S)]
+    ins = [treg[:m].clone() for _ in range(S)]
+    D.LossyStream.step_many(streams, ins, errors=False)  # first frames + ring fill started
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        D.LossyStream.step_many(streams, ins, errors=False)
+    torch.cuda.synchronize()
+    c4["lossy_step_device_resident_fps_%d_streams" % S] = 3 * m * S / (time.perf_counter() - t0)
+    for st_ in streams:
+        st_.close()
+    del ins
 with tempfile.TemporaryDirectory() as d:
     dst = os.path.join(d, "lossy.h264")
     t0 = time.perf_counter()
