@@ -222,7 +222,7 @@ ms = gpu_ms(lambda: ctx3.decode(ctx3.encode(t3), out=dec3, check=False), 5)
 assert torch.equal(dec3.view(torch.int16), t3.view(torch.int16))
 out["configs[3]"] = {"workload": "per-GPU shard of the 10 000-frame job: %d x %dx%d u16 (250 distinct S1 frames tiled), encode+decode" % (n3, w3, h3),
                      "device_resident_fps": n3 / ms * 1e3, "raw_GBs": n3 * 4.0 * h3 * w3 / ms / 1e6,
-                     "note": "all-gather of the decoded stream is timed by bench.py --gpus N (allgather_decoded_stream)"}
+                     "note": "the exchange of the decoded / compressed stream is timed by bench.py --gpus N (value_with_exchange, value_with_compressed_exchange)"}
 del t3, dec3, ctx3
 torch.cuda.empty_cache()
 
