@@ -337,6 +337,12 @@ namespace
 		DeviceBuffer batch_errs; // int[nframes][2] of the last rir_lossy_step_device call
 		DeviceBuffer multi_table; // rir_lossy_step_multi_device: the steps of the call (this object leads it)
 		PinnedBuffer multi_stage;
+		hipEvent_t multi_copied = nullptr; // the copy out of multi_stage of the last call (whatever its stream) has completed
+		~LossyObject() override
+		{
+			if (multi_copied)
+				(void)hipEventDestroy(multi_copied);
+		}
 	};
 
 	// ---- saver -------------------------------------------------------------------------------
@@ -2265,7 +2271,10 @@ RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, con
 		const size_t nb = (size_t)nsteps * nstreams * sizeof(LossyStep);
 		if (!lead.multi_table.reserve(nb) || !lead.multi_stage.reserve(nb))
 			return -1;
-		if (!hip_ok(wait_stream(st), "sync")) // (an earlier call's copy out of the staging buffer may still be in flight)
+		// an earlier call's copy out of the staging buffer may still be in flight - on whatever stream that call was given
+		if (lead.multi_copied && !hip_ok(hipEventSynchronize(lead.multi_copied), "event"))
+			return -1;
+		if (!lead.multi_copied && !hip_ok(hipEventCreateWithFlags(&lead.multi_copied, hipEventDisableTiming), "event"))
 			return -1;
 		LossyStep *hs = lead.multi_stage.as<LossyStep>();
 		for (int f = f0; f < nframes; ++f)
@@ -2278,7 +2287,7 @@ RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, con
 				ls.advance_ring();
 				++ls.frames;
 			}
-		if (!hip_ok(hipMemcpyAsync(lead.multi_table.ptr, hs, nb, hipMemcpyHostToDevice, st), "H2D"))
+		if (!hip_ok(hipMemcpyAsync(lead.multi_table.ptr, hs, nb, hipMemcpyHostToDevice, st), "H2D") || !hip_ok(hipEventRecord(lead.multi_copied, st), "event"))
 			return -1;
 		for (int f = 0; f < nsteps; ++f)
 			if (!hip_ok(launch_lossy_step(hs + (size_t)f * nstreams, lead.multi_table.as<LossyStep>() + (size_t)f * nstreams, nstreams, st), "lossy step"))
