@@ -26,10 +26,18 @@ namespace rir
 	size_t ecc_workspace_bytes(int w, int h) { return (size_t)ecc_blocks(w, h) * ECC_NSUMS * sizeof(double); }
 
 	// central difference with reflect-101 borders: g(0) = g(n-1) = 0
+	// (thread 0 also resets the alignment's state: one launch less per frame)
 	__global__ __launch_bounds__(256) void ecc_gradient_kernel(const float *__restrict__ img, int w, int h, float *__restrict__ gx,
-															  float *__restrict__ gy)
+															  float *__restrict__ gy, EccState *s, float tx, float ty, int max_iter, double eps)
 	{
 		const int i = blockIdx.x * 256 + threadIdx.x;
+		if (i == 0)
+		{
+			s->tx = tx, s->ty = ty;
+			s->rho = -1.0, s->last_rho = -eps;
+			s->iter = 0, s->done = 0, s->ticket = 0;
+			s->max_iter = max_iter, s->eps = eps;
+		}
 		if (i >= w * h)
 			return;
 		const int y = i / w, x = i - y * w;
@@ -37,14 +45,6 @@ namespace rir
 		const int yu = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yd = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
 		gx[i] = 0.5f * img[y * w + xr] - 0.5f * img[y * w + xl];
 		gy[i] = 0.5f * img[yd * w + x] - 0.5f * img[yu * w + x];
-	}
-
-	__global__ void ecc_init_kernel(EccState *s, float tx, float ty, int max_iter, double eps)
-	{
-		s->tx = tx, s->ty = ty;
-		s->rho = -1.0, s->last_rho = -eps;
-		s->iter = 0, s->done = 0, s->ticket = 0;
-		s->max_iter = max_iter, s->eps = eps;
 	}
 
 	__device__ __forceinline__ float bilinear0(const float *__restrict__ p, int w, int h, int x0, int y0, float fx, float fy)
@@ -65,7 +65,9 @@ namespace rir
 	// leaves one row of 15 partial sums (fixed butterfly inside the wave, waves in order).  ecc_solve_kernel: one
 	// workgroup adds the rows in a fixed tree (deterministic), solves the 2x2 system and updates the state in device memory.
 	// (As ONE kernel whose last workgroup - found through a ticket atomic - did the second half, the iteration was a chain of
-	// short latency-bound phases on few workgroups: 32 us at 512x640 whatever the grid; split, 11 us.)
+	// short latency-bound phases on few workgroups: 32 us at 512x640 whatever the grid; split, 11 us.  Round 2 tried again with
+	// write-through rows, a drained ticket and coalesced agent-scope loads in the last workgroup: 152 us per tracked frame against
+	// 140 us for the two launches - the ticket and the last workgroup's round trips cost more than the launch boundary they save.)
 	__global__ __launch_bounds__(ECC_BLOCK) void ecc_sums_kernel(const float *__restrict__ templ, const float *__restrict__ image,
 																 const float *__restrict__ gximg, const float *__restrict__ gyimg,
 																 const uint8_t *__restrict__ mask, int w, int h, double *__restrict__ partials,
@@ -222,8 +224,7 @@ namespace rir
 	hipError_t launch_ecc_prepare(const float *d_image, int w, int h, float *d_gx, float *d_gy, EccState *d_state, float tx, float ty, int max_iter,
 								  double eps, hipStream_t st)
 	{
-		hipLaunchKernelGGL(ecc_gradient_kernel, dim3((w * h + 255) / 256), dim3(256), 0, st, d_image, w, h, d_gx, d_gy);
-		hipLaunchKernelGGL(ecc_init_kernel, dim3(1), dim3(1), 0, st, d_state, tx, ty, max_iter, eps);
+		hipLaunchKernelGGL(ecc_gradient_kernel, dim3((w * h + 255) / 256), dim3(256), 0, st, d_image, w, h, d_gx, d_gy, d_state, tx, ty, max_iter, eps);
 		return hipGetLastError();
 	}
 
