@@ -206,20 +206,26 @@ def abi_numbers(frames_np, D, ctx, frames, out, n, h, w):
         with IRMovie.from_filename(os.path.join(d, "warm.h264")) as mov:
             for i in range(min(n, 60)):
                 mov[i]
-        t0 = time.perf_counter()
-        with IRSaver(dst, w, h, h) as s:
-            for i in range(n):
-                s.add_image(frames_np[i], i * 1000)
-        te = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        with IRMovie.from_filename(dst) as mov:
-            for i in range(n):
-                img = mov[i]
-        td = time.perf_counter() - t0
-        assert np.array_equal(img, frames_np[n - 1])
-        res["per_frame_abi_fps"] = n / (te + td)
-        res["per_frame_abi_detail"] = {"frames": n, "record_fps": n / te, "read_fps": n / td,
-                                       "path": "IRSaver.add_image + IRMovie[i], file on the box's tmp filesystem"}
+        runs = []
+        for rep in range(3):  # three recordings of the n frames, each read back: the median round trip is reported, the spread beside it
+            dst = os.path.join(d, "abi%d.h264" % rep)
+            t0 = time.perf_counter()
+            with IRSaver(dst, w, h, h) as s:
+                for i in range(n):
+                    s.add_image(frames_np[i], i * 1000)
+            te = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            with IRMovie.from_filename(dst) as mov:
+                for i in range(n):
+                    img = mov[i]
+            td = time.perf_counter() - t0
+            assert np.array_equal(img, frames_np[n - 1])
+            os.remove(dst)
+            runs.append((n / (te + td), n / te, n / td))
+        runs.sort()
+        res["per_frame_abi_fps"] = runs[1][0]
+        res["per_frame_abi_detail"] = {"frames": n, "record_fps": runs[1][1], "read_fps": runs[1][2], "round_trip_fps_of_the_3_runs": [r[0] for r in runs],
+                                       "path": "IRSaver.add_image + IRMovie[i], file on the box's tmp filesystem; median of 3 recordings"}
     pin_in = torch.from_numpy(frames_np).pin_memory()
     pin_out = torch.empty_like(pin_in)
     enc0 = ctx.encode(frames)

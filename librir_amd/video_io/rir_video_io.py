@@ -5,6 +5,7 @@ Function names, argument meaning and error behaviour follow the reference wrappe
 in and out, ``RuntimeError`` when the library reports a failure.
 """
 import ctypes as ct
+import sys
 
 import numpy as np
 
@@ -126,11 +127,29 @@ def supported_calibrations(camera):
     return out
 
 
+_recycled = {}  # (h, w) -> a few arrays handed out earlier
+
+
+def _image_buffer(h, w):
+    """A (h, w) uint16 array for the next image.  A reader that iterates over a movie drops each image before it asks for the next
+    one; a fresh 640x512 array then costs its 160 page faults (30-40 us, as much as the read itself).  Arrays handed out earlier
+    are therefore remembered, and one is handed out again once NOTHING else refers to it any more (its reference count says so:
+    a caller that keeps the image, or a view of it, keeps it for good)."""
+    pool = _recycled.setdefault((h, w), [])
+    for a in pool:
+        if sys.getrefcount(a) == 3:  # the list, the loop variable, getrefcount's argument
+            return a
+    a = np.empty((h, w), dtype=np.uint16)
+    if len(pool) < 4:
+        pool.append(a)
+    return a
+
+
 def load_image(camera, pos, calibration=0, shape=None):
     """``shape``: (height, width) when the caller already knows it (IRMovie does: one library call less per image).  The
     buffer is not zero-filled first (the library writes every pixel or fails)."""
     h, w = get_image_size(camera) if shape is None else shape
-    img = np.empty((h, w), dtype=np.uint16)
+    img = _image_buffer(h, w)
     if _v.load_image(camera, int(pos), int(calibration), img.ctypes.data) < 0:
         _fail("load_image")
     return img
