@@ -95,5 +95,7 @@ if os.environ.get("RIR_DIAG_STATS"):
         started = ((t0 >= lo) & (t0 < hi)).sum()
         dur = (t1 - t0)[(t0 >= lo) & (t0 < hi)]
         print("  t=%5.0f us: walking %4d  waiting %4d  copying %4d  started %4d  walk dur of those %.1f" % (mid, walking, waiting, copying, started, dur.mean() if dur.size else 0))
+if not SP:
+    print("alone: packing %.1f us  scan + gather %.1f us" % (alone(lambda: ctx.encode_tiles(t)), alone(lambda: ctx.encode_compact())))
 print("alone: encode %.1f us  decode %.1f us" % (alone(lambda: ctx.encode(t, single_pass=SP)), alone(lambda: ctx.decode(enc, out=out, check=False))))
 sys.exit(0 if rt else 1)
