@@ -50,6 +50,13 @@ namespace rir
 		int hist_px, reserved; // pixels per workgroup of the histogram pass (lossy_hist_px)
 		int add_loss, low_value_error, high_value_error;
 		double std_factor;
+		// Runs of frames (lossy_frame_kernel: one launch per frame): the launch that updates THIS frame also takes the sums of the
+		// NEXT one - its pixels against this frame's output, which the thread holds in registers - and its last workgroup decides
+		// the next frame's budget.
+		const uint16_t *next_tmp, *next_img; // frame f + 1 after / before repair; NULL: this is the last frame of the call
+		const long long *next_background;	 // its background, from the histogram pass of the run
+		int *next_errors_out;				 // [2] low, high of frame f + 1, or NULL
+		int do_update, reserved2;			 // 0: opening launch of a run (sums of its first frame against the stored prevT only)
 	};
 	// Pixels per workgroup of the histogram pass: each workgroup clears and merges a private 16 384-bin histogram, so a launch wants
 	// about as many workgroups as the chip holds at once (two per CU) - 4 096 pixels for one 640x512 stream, more with many streams.
@@ -60,6 +67,11 @@ namespace rir
 		return (int)(px < 4096 ? 4096 : px);
 	}
 	hipError_t launch_lossy_step(const LossyStep *h_steps, const LossyStep *d_table, int nstreams, hipStream_t st);
+	// Runs of frames.  Backgrounds of `entries` frames (any streams) in one launch: d_table[e] describes frame e (tmp, hist = a
+	// zeroed 16 384-bin slice of its own, stats -> where its background goes, tickets -> a zeroed word of its own, s, hist_px).
+	hipError_t launch_lossy_backgrounds(const LossyStep *d_table, int entries, int s, int hist_px, hipStream_t st);
+	// One launch of a run for `nstreams` streams: d_table[i] is stream i's step (next_* filled in).
+	hipError_t launch_lossy_frame(const LossyStep *d_table, int nstreams, int full, hipStream_t st);
 	hipError_t launch_lossy_first(const uint16_t *d_tmp, uint16_t *d_out, const LossyDeviceState &state, int s, int full, hipStream_t st);
 	hipError_t launch_lossy_min(const uint16_t *d_tmp, int s, unsigned int *d_result, hipStream_t st);
 	hipError_t launch_lossy_add_min(uint16_t *d_frames, int64_t npx, int s, int nframes, uint32_t mn, hipStream_t st);

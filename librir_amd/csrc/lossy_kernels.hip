@@ -156,7 +156,7 @@ namespace rir
 	// st[1..6]: the frame's sums as read by the caller.
 	// b: the stream's budget state, staged in LDS by the caller (the 40-entry window is shifted and summed element by element:
 	// from global memory that was 160 dependent round trips, 8 us).
-	__device__ __forceinline__ void lossy_budget(const LossyStep &sp, const long long *st, LossyBudget &b)
+	__device__ __forceinline__ void lossy_budget(const LossyStep &sp, const long long *st, LossyBudget &b, int *errors_out)
 	{
 		const int s = sp.s;
 		// stdDev (h264.cpp:1993-2036): unsplit for the first 40 frames
@@ -216,10 +216,10 @@ namespace rir
 		decision->background = (uint32_t)st[0];
 		decision->low_error = low_error;
 		decision->high_error = high_error;
-		if (sp.errors_out)
+		if (errors_out)
 		{
-			as_global(sp.errors_out)[0] = low_error;
-			as_global(sp.errors_out)[1] = high_error;
+			as_global(errors_out)[0] = low_error;
+			as_global(errors_out)[1] = high_error;
 		}
 	}
 
@@ -305,7 +305,7 @@ namespace rir
 			st[0] = stats[0];
 			for (int i = 1; i < 7; ++i)
 				st[i] = red[1][i - 1];
-			lossy_budget(sp, st, bl);
+			lossy_budget(sp, st, bl, sp.errors_out);
 		}
 		__syncthreads();
 		if (threadIdx.x < sizeof(LossyBudget) / 8)
@@ -414,11 +414,10 @@ namespace rir
 		v.x = r.d[0], v.y = r.d[1], v.z = r.d[2], v.w = r.d[3];
 		*reinterpret_cast<RIR_GLOBAL(lossy_v4u) *>(p + (size_t)i8 * 8) = v;
 	}
-	template <bool TABLE>
-	__global__ __launch_bounds__(256) void lossy_update_vec_kernel(LossyStep one, const LossyStep *__restrict__ table)
+	// L3 + L4 for the 8 pixels of group i8 (inside the lossy rows), v8 = the frame's pixels: state arrays updated, the lossy pixels
+	// stored to `out` (and to prevT when store_prev) and returned.
+	__device__ __forceinline__ U16x8 lossy_update8(const LossyStep &sp, int i8, const U16x8 &v8, bool store_prev)
 	{
-		const LossyStep sp = lossy_step_of<TABLE>(one, table);
-		RIR_GLOBAL(const uint16_t) *tmp = as_global(sp.tmp);
 		RIR_GLOBAL(uint16_t) *out = as_global(sp.out);
 		const LossyDeviceState st = sp.st;
 		RIR_GLOBAL(uint16_t) *refT = as_global(st.refT), *prevT = as_global(st.prevT), *lastDL = as_global(st.lastDL);
@@ -426,17 +425,7 @@ namespace rir
 		RIR_GLOBAL(uint16_t) *ccnt = (RIR_GLOBAL(uint16_t) *)as_global(st.ra_const_count);
 		RIR_GLOBAL(uint32_t) *sums = as_global(st.ra_sums);
 		RIR_GLOBAL(const LossyDecision) *decision = as_global((const LossyDecision *)sp.decision);
-		const int s = sp.s, full = sp.full, add_loss = sp.add_loss;
-		const int i8 = blockIdx.x * blockDim.x + threadIdx.x; // group of 8 pixels
-		if (i8 * 8 >= full)
-			return;
-		const U16x8 v8 = ld8(tmp, i8);
-		if (i8 * 8 >= s)
-		{ // rows past lossy_height: stored as they are
-			st8(out, i8, v8);
-			st8(lastDL, i8, v8);
-			return;
-		}
+		const int s = sp.s, add_loss = sp.add_loss;
 		const uint32_t background = decision->background;
 		const int low_error = decision->low_error, high_error = decision->high_error;
 		const int ra = st.running_average;
@@ -520,8 +509,133 @@ namespace rir
 		if (ref_changed)
 			st8(refT, i8, ref8);
 		st8(out, i8, o8);
-		st8(prevT, i8, o8);
+		if (store_prev)
+			st8(prevT, i8, o8);
 		st8(lastDL, i8, v8);
+		return o8;
+	}
+
+	template <bool TABLE>
+	__global__ __launch_bounds__(256) void lossy_update_vec_kernel(LossyStep one, const LossyStep *__restrict__ table)
+	{
+		const LossyStep sp = lossy_step_of<TABLE>(one, table);
+		const int i8 = blockIdx.x * blockDim.x + threadIdx.x; // group of 8 pixels
+		if (i8 * 8 >= sp.full)
+			return;
+		const U16x8 v8 = ld8(as_global(sp.tmp), i8);
+		if (i8 * 8 >= sp.s)
+		{ // rows past lossy_height: stored as they are
+			st8(as_global(sp.out), i8, v8);
+			st8(as_global(sp.st.lastDL), i8, v8);
+			return;
+		}
+		(void)lossy_update8(sp, i8, v8, true);
+	}
+
+	// The sums of a frame and, in the last workgroup to arrive, its budget: tail shared by lossy_sums_budget_kernel's form for
+	// runs.  a[6]: this thread's share; every thread of the workgroup calls.
+	__device__ __forceinline__ void lossy_sums_tail(const LossyStep &sp, const long long *a, long long background, int *errors_out)
+	{
+		RIR_GLOBAL(long long) *stats = as_global(sp.stats);
+		__shared__ long long red[4][6];
+		__shared__ LossyBudget bl;
+#pragma unroll
+		for (int k = 0; k < 6; ++k)
+		{
+			long long v = a[k];
+#pragma unroll
+			for (int d = 32; d >= 1; d >>= 1)
+				v += __shfl_xor(v, d, 64);
+			if ((threadIdx.x & 63) == 0)
+				red[threadIdx.x >> 6][k] = v;
+		}
+		__syncthreads();
+		if (threadIdx.x < 6)
+		{
+			const long long v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+			if (v)
+				__hip_atomic_fetch_add((RIR_GLOBAL(unsigned long long) *)&stats[1 + threadIdx.x], (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		if (!lossy_last_arriver(sp.tickets + 1, gridDim.x, reinterpret_cast<unsigned int *>(&red[0][0])))
+			return;
+		if (threadIdx.x < 6)
+		{
+			red[1][threadIdx.x] = (long long)__hip_atomic_load((RIR_GLOBAL(unsigned long long) *)&stats[1 + threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			stats[1 + threadIdx.x] = 0; // the sums are accumulated with atomics: cleared for the next frame
+		}
+		RIR_GLOBAL(unsigned long long) *gb = (RIR_GLOBAL(unsigned long long) *)as_global(sp.budget);
+		unsigned long long *lb = reinterpret_cast<unsigned long long *>(&bl);
+		if (threadIdx.x < sizeof(LossyBudget) / 8)
+			lb[threadIdx.x] = gb[threadIdx.x];
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			long long st[7];
+			st[0] = background;
+			for (int i = 1; i < 7; ++i)
+				st[i] = red[1][i - 1];
+			lossy_budget(sp, st, bl, errors_out);
+		}
+		__syncthreads();
+		if (threadIdx.x < sizeof(LossyBudget) / 8)
+			gb[threadIdx.x] = lb[threadIdx.x];
+	}
+
+	// One launch per frame of a run (lossy_kernels.h, LossyStep::next_*): L3 + L4 of frame f, and L2 of frame f + 1 taken while
+	// frame f's output is still in registers - |t(f+1) - out(f)| is all L2 needs of the state, so the sums never read prevT and
+	// prevT is only stored by the last frame of a call.  The decision of frame f is read by every thread before its workgroup
+	// takes its ticket; the last workgroup to arrive overwrites it with the decision of frame f + 1, which the next launch reads.
+	// Needs s and full to be multiples of 8 (callers fall back to the three-launch step otherwise).  grid.x covers full / 8 threads.
+	template <bool TABLE>
+	__global__ __launch_bounds__(256) void lossy_frame_kernel(LossyStep one, const LossyStep *__restrict__ table)
+	{
+		const LossyStep sp = lossy_step_of<TABLE>(one, table);
+		const int i8 = blockIdx.x * blockDim.x + threadIdx.x; // group of 8 pixels
+		const bool inside = i8 * 8 < sp.full, lossy = i8 * 8 < sp.s;
+		const bool next = sp.next_tmp != nullptr;
+		U16x8 o8;
+		if (sp.do_update)
+		{
+			if (inside)
+			{
+				const U16x8 v8 = ld8(as_global(sp.tmp), i8);
+				if (lossy)
+					o8 = lossy_update8(sp, i8, v8, !next);
+				else
+				{ // rows past lossy_height: stored as they are
+					st8(as_global(sp.out), i8, v8);
+					st8(as_global(sp.st.lastDL), i8, v8);
+				}
+			}
+		}
+		else if (lossy)
+			o8 = ld8(as_global((const uint16_t *)sp.st.prevT), i8);
+		if (!next)
+			return; // (the whole grid)
+		long long a[6] = {0, 0, 0, 0, 0, 0};
+		const long long background = *as_global(sp.next_background);
+		if (lossy)
+		{
+			const int subtract_min = sp.st.subtract_min;
+			const uint32_t mn = sp.st.min, bg = (uint32_t)background;
+			const U16x8 tv = ld8(as_global(sp.next_tmp), i8);
+			const U16x8 iv = sp.next_img == sp.next_tmp ? tv : ld8(as_global(sp.next_img), i8);
+			int32_t fd = 0, fn = 0, bd = 0; // (8 pixels: |d| < 65 536; the wrapped squares are summed in 64 bits)
+			long long f2 = 0, b2 = 0;
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+			{
+				const uint32_t t = subtract_min ? sub_min(tv.get(k), mn) : tv.get(k);
+				const int32_t d = abs((int32_t)t - (int32_t)o8.get(k));
+				const int32_t d2 = (int32_t)((uint32_t)d * (uint32_t)d);
+				if (iv.get(k) > bg)
+					fd += d, f2 += d2, fn += 1;
+				else
+					bd += d, b2 += d2;
+			}
+			a[0] = fd, a[1] = f2, a[2] = fn, a[3] = bd, a[4] = b2, a[5] = 8 - fn;
+		}
+		lossy_sums_tail(sp, a, background, sp.next_errors_out);
 	}
 
 	// first frame: out = tmp minus the optional minimum on rows < lossy_height; seeds refT / prevT / lastDL
@@ -608,6 +722,21 @@ namespace rir
 			else
 				hipLaunchKernelGGL(lossy_update_kernel<false>, gu, dim3(256), 0, st, one, nullptr);
 		}
+		return hipGetLastError();
+	}
+
+	hipError_t launch_lossy_backgrounds(const LossyStep *d_table, int entries, int s, int hist_px, hipStream_t st)
+	{
+		if (entries <= 0 || s <= 0)
+			return hipSuccess;
+		LossyStep none{};
+		hipLaunchKernelGGL(lossy_hist_mode_kernel<true>, dim3((s + hist_px - 1) / hist_px, entries), dim3(1024), 0, st, none, d_table);
+		return hipGetLastError();
+	}
+	hipError_t launch_lossy_frame(const LossyStep *d_table, int nstreams, int full, hipStream_t st)
+	{
+		LossyStep none{};
+		hipLaunchKernelGGL(lossy_frame_kernel<true>, dim3((full / 8 + 255) / 256, nstreams), dim3(256), 0, st, none, d_table);
 		return hipGetLastError();
 	}
 

@@ -312,6 +312,8 @@ namespace
 			p.s = w * hl, p.full = w * h;
 			p.add_loss = add_loss ? 1 : 0, p.low_value_error = low_value_error, p.high_value_error = high_value_error;
 			p.std_factor = std_factor;
+			p.next_tmp = p.next_img = nullptr, p.next_background = nullptr, p.next_errors_out = nullptr;
+			p.do_update = 1, p.reserved2 = 0;
 			return p;
 		}
 		void advance_ring()
@@ -336,6 +338,7 @@ namespace
 		bool remove_bad_pixels = false;
 		DeviceBuffer batch_errs; // int[nframes][2] of the last rir_lossy_step_device call
 		DeviceBuffer multi_table; // rir_lossy_step_multi_device: the steps of the call (this object leads it)
+		DeviceBuffer run_hist, run_tickets, run_bg; // runs of frames: histogram slices and tickets of a group of frames, backgrounds of the call
 		PinnedBuffer multi_stage;
 		hipEvent_t multi_copied = nullptr; // the copy out of multi_stage of the last call (whatever its stream) has completed
 		~LossyObject() override
@@ -2183,6 +2186,13 @@ RIR_EXPORT int rir_lossy_step_device(int handle, const unsigned short *d_in, uns
 		log_error("rir_lossy_step_device: invalid argument");
 		return -1;
 	}
+	// a batch without bad-pixel repair is a run of frames: one launch per frame instead of three (rir_lossy_step_multi_device)
+	if (!o->remove_bad_pixels && nframes >= 3)
+	{
+		const unsigned short *in1[1] = {d_in};
+		unsigned short *out1[1] = {d_out};
+		return rir_lossy_step_multi_device(&handle, 1, in1, out1, nframes, add_loss, low_errors, high_errors, stream);
+	}
 	// every frame is queued without waiting (statistics, budget and update all run on the device); the budgets of the batch
 	// come back in one copy at the end - or not at all when the caller does not ask for them: then nothing here waits
 	const size_t npx = (size_t)o->st.w * o->st.h;
@@ -2264,11 +2274,15 @@ RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, con
 		f0 = 1;
 	}
 	const int nsteps = nframes - f0;
+	const int s_px = os[0]->st.w * os[0]->st.hl, full_px = os[0]->st.w * os[0]->st.h;
+	// runs: one launch per frame (lossy_frame_kernel) + one histogram launch per group of frames; needs whole groups of 8 pixels
+	const bool runs = nsteps >= 2 && s_px > 0 && s_px % 8 == 0 && full_px % 8 == 0;
 	if (nsteps > 0)
 	{
-		// the descriptions of all steps of the call go to the device in one copy (page-locked staging: the copy is asynchronous
+		// the descriptions of all launches of the call go to the device in one copy (page-locked staging: the copy is asynchronous
 		// and the host buffer must outlive it - it is kept by the leading stream's object)
-		const size_t nb = (size_t)nsteps * nstreams * sizeof(LossyStep);
+		const size_t nfused = runs ? (size_t)(nsteps + 1) * nstreams : (size_t)nsteps * nstreams, nhist = runs ? (size_t)nsteps * nstreams : 0;
+		const size_t nb = (nfused + nhist) * sizeof(LossyStep);
 		if (!lead.multi_table.reserve(nb) || !lead.multi_stage.reserve(nb))
 			return -1;
 		// an earlier call's copy out of the staging buffer may still be in flight - on whatever stream that call was given
@@ -2277,21 +2291,91 @@ RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, con
 		if (!lead.multi_copied && !hip_ok(hipEventCreateWithFlags(&lead.multi_copied, hipEventDisableTiming), "event"))
 			return -1;
 		LossyStep *hs = lead.multi_stage.as<LossyStep>();
-		for (int f = f0; f < nframes; ++f)
-			for (int i = 0; i < nstreams; ++i)
-			{
-				LossyState &ls = os[i]->st;
-				int *errs = want ? lead.batch_errs.as<int>() + ((size_t)i * nframes + f) * 2 : nullptr;
-				hs[(size_t)(f - f0) * nstreams + i] = ls.make_step(d_in[i] + (size_t)f * npx, d_in[i] + (size_t)f * npx, d_out[i] + (size_t)f * npx, add_loss != 0,
-																	 os[i]->low, os[i]->high, os[i]->std_factor, errs, nstreams);
-				ls.advance_ring();
-				++ls.frames;
-			}
-		if (!hip_ok(hipMemcpyAsync(lead.multi_table.ptr, hs, nb, hipMemcpyHostToDevice, st), "H2D") || !hip_ok(hipEventRecord(lead.multi_copied, st), "event"))
-			return -1;
-		for (int f = 0; f < nsteps; ++f)
-			if (!hip_ok(launch_lossy_step(hs + (size_t)f * nstreams, lead.multi_table.as<LossyStep>() + (size_t)f * nstreams, nstreams, st), "lossy step"))
+		const LossyStep *dt = lead.multi_table.as<LossyStep>();
+		auto errs_of = [&](int i, int f) { return want ? lead.batch_errs.as<int>() + ((size_t)i * nframes + f) * 2 : (int *)nullptr; };
+		if (!runs)
+		{
+			for (int f = f0; f < nframes; ++f)
+				for (int i = 0; i < nstreams; ++i)
+				{
+					LossyState &ls = os[i]->st;
+					hs[(size_t)(f - f0) * nstreams + i] = ls.make_step(d_in[i] + (size_t)f * npx, d_in[i] + (size_t)f * npx, d_out[i] + (size_t)f * npx, add_loss != 0,
+																		 os[i]->low, os[i]->high, os[i]->std_factor, errs_of(i, f), nstreams);
+					ls.advance_ring();
+					++ls.frames;
+				}
+			if (!hip_ok(hipMemcpyAsync(lead.multi_table.ptr, hs, nb, hipMemcpyHostToDevice, st), "H2D") || !hip_ok(hipEventRecord(lead.multi_copied, st), "event"))
 				return -1;
+			for (int f = 0; f < nsteps; ++f)
+				if (!hip_ok(launch_lossy_step(hs + (size_t)f * nstreams, dt + (size_t)f * nstreams, nstreams, st), "lossy step"))
+					return -1;
+		}
+		else
+		{
+			// histogram scratch: one zeroed 16 384-bin slice and one ticket per frame of a group (the kernels leave them zeroed)
+			const int group = std::max(1, 512 / nstreams); // frames per histogram launch
+			const size_t slices = (size_t)std::min(nsteps, group) * nstreams;
+			const size_t hist_cap = lead.run_hist.cap, tick_cap = lead.run_tickets.cap;
+			if (!lead.run_hist.reserve(slices * 16384 * 4) || !lead.run_tickets.reserve(slices * 4) || !lead.run_bg.reserve(nhist * sizeof(long long)))
+				return -1;
+			if (lead.run_hist.cap != hist_cap && !hip_ok(hipMemsetAsync(lead.run_hist.ptr, 0, lead.run_hist.cap, st), "memset"))
+				return -1;
+			if (lead.run_tickets.cap != tick_cap && !hip_ok(hipMemsetAsync(lead.run_tickets.ptr, 0, lead.run_tickets.cap, st), "memset"))
+				return -1;
+			long long *bg = lead.run_bg.as<long long>();
+			LossyStep *hh = hs + nfused;
+			for (int k = 0; k <= nsteps; ++k) // launch k updates frame f0 + k - 1 (k > 0) and takes the sums of frame f0 + k (k < nsteps)
+				for (int i = 0; i < nstreams; ++i)
+				{
+					LossyState &ls = os[i]->st;
+					LossyStep p;
+					if (k == 0)
+					{
+						p = ls.make_step(nullptr, nullptr, nullptr, add_loss != 0, os[i]->low, os[i]->high, os[i]->std_factor, nullptr, nstreams);
+						p.do_update = 0;
+					}
+					else
+					{
+						const size_t f = (size_t)(f0 + k - 1);
+						p = ls.make_step(d_in[i] + f * npx, d_in[i] + f * npx, d_out[i] + f * npx, add_loss != 0, os[i]->low, os[i]->high, os[i]->std_factor, nullptr,
+										 nstreams);
+						ls.advance_ring();
+						++ls.frames;
+					}
+					if (k < nsteps)
+					{
+						const size_t fn = (size_t)(f0 + k);
+						p.next_tmp = p.next_img = d_in[i] + fn * npx;
+						p.next_background = bg + (size_t)k * nstreams + i;
+						p.next_errors_out = errs_of(i, (int)fn);
+						LossyStep h{};
+						const int in_group = std::min(group, nsteps - k / group * group);
+						const size_t slice = (size_t)(k % group) * nstreams + i;
+						h.tmp = h.img = d_in[i] + fn * npx;
+						h.hist = lead.run_hist.as<uint32_t>() + slice * 16384;
+						h.stats = bg + (size_t)k * nstreams + i;
+						h.tickets = lead.run_tickets.as<unsigned int>() + slice;
+						h.s = s_px, h.full = full_px;
+						h.hist_px = lossy_hist_px(s_px, in_group * nstreams);
+						hh[(size_t)k * nstreams + i] = h;
+					}
+					hs[(size_t)k * nstreams + i] = p;
+				}
+			if (!hip_ok(hipMemcpyAsync(lead.multi_table.ptr, hs, nb, hipMemcpyHostToDevice, st), "H2D") || !hip_ok(hipEventRecord(lead.multi_copied, st), "event"))
+				return -1;
+			for (int k = 0; k <= nsteps; ++k)
+			{
+				if (k < nsteps && k % group == 0)
+				{
+					const int in_group = std::min(group, nsteps - k);
+					if (!hip_ok(launch_lossy_backgrounds(dt + nfused + (size_t)k * nstreams, in_group * nstreams, s_px, lossy_hist_px(s_px, in_group * nstreams), st),
+								"lossy backgrounds"))
+						return -1;
+				}
+				if (!hip_ok(launch_lossy_frame(dt + (size_t)k * nstreams, nstreams, full_px, st), "lossy frame"))
+					return -1;
+			}
+		}
 	}
 	if (want)
 	{
