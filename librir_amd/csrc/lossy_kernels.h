@@ -23,8 +23,9 @@ namespace rir
 	struct LossyBudget
 	{
 		double first_std[2];
-		double win[40][2];
+		double win[40][2]; // a ring once it is full: the oldest entry is win[head]
 		int n_first, n_win;
+		int head, reserved;
 	};
 	// What lossy_budget_kernel decides for the current frame and lossy_update_kernel applies.
 	struct LossyDecision
@@ -58,6 +59,37 @@ namespace rir
 		int *next_errors_out;				 // [2] low, high of frame f + 1, or NULL
 		int do_update, reserved2;			 // 0: opening launch of a run (sums of its first frame against the stored prevT only)
 	};
+	// A run of frames of one stream in ONE launch (lossy_run_kernel): the workgroups of the stream stay resident, every thread keeps
+	// the state of its 8 pixels in registers from frame to frame, and the frame's sums are exchanged between the workgroups through
+	// self-validating words in HBM instead of a kernel boundary.
+	struct LossyRun
+	{
+		const uint16_t *in; // first frame of the run; frames are frame_px pixels apart
+		uint16_t *out;
+		LossyDeviceState st;	  // ring indices before the first frame of the run
+		const long long *bg;	  // background of frame k of the run at bg[k * bg_stride] (histogram pass)
+		LossyBudget *budget;
+		LossyDecision *decision;
+		int *errors_out;			  // [nsteps][2] low, high - or NULL
+		unsigned long long *exchange; // [2][workgroups of the stream][slot_words] + 16 words (decisions), zeroed before the launch
+		unsigned int *error_word;	  // raised when a wait gives up
+		long long frame_px;
+		int bg_stride, nsteps;
+		int s, full;
+		int add_loss, low_value_error, high_value_error;
+		int slot_words; // distance of two workgroups' exchange words, in 8-byte words
+		int leader, reserved; // 1: workgroup 0 collects the sums and publishes the decision (many streams per launch)
+		double std_factor;
+	};
+	constexpr int kLossyRunThreads = 256; // 8 pixels each
+	inline int lossy_run_workgroups(int full) { return (full / 8 + kLossyRunThreads - 1) / kLossyRunThreads; }
+	// The run kernel needs ALL its workgroups resident at once: workgroup i runs on XCD i % 8, each XCD starts its own share of the
+	// grid as its 32 CUs (four 256-thread workgroups of <= 128 VGPRs each) come free, and a stream whose last workgroups can only
+	// start on an XCD that is full of its own waiting workgroups would wait for ever (seen with an oversubscribed grid: one call in
+	// a few hundred).  So: at most 960 workgroups per launch (120 of an XCD's 128 places); more streams or larger frames take the
+	// launch-per-frame path.
+	constexpr int kLossyRunMaxWorkgroups = 960;
+
 	// Pixels per workgroup of the histogram pass: each workgroup clears and merges a private 16 384-bin histogram, so a launch wants
 	// about as many workgroups as the chip holds at once (two per CU) - 4 096 pixels for one 640x512 stream, more with many streams.
 	inline int lossy_hist_px(int s, int nstreams)
@@ -72,6 +104,8 @@ namespace rir
 	hipError_t launch_lossy_backgrounds(const LossyStep *d_table, int entries, int s, int hist_px, hipStream_t st);
 	// One launch of a run for `nstreams` streams: d_table[i] is stream i's step (next_* filled in).
 	hipError_t launch_lossy_frame(const LossyStep *d_table, int nstreams, int full, hipStream_t st);
+	// d_table[i]: the run of stream i; d_ticket: one zeroed word (left zeroed)
+	hipError_t launch_lossy_run(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ticket, hipStream_t st);
 	hipError_t launch_lossy_first(const uint16_t *d_tmp, uint16_t *d_out, const LossyDeviceState &state, int s, int full, hipStream_t st);
 	hipError_t launch_lossy_min(const uint16_t *d_tmp, int s, unsigned int *d_result, hipStream_t st);
 	hipError_t launch_lossy_add_min(uint16_t *d_frames, int64_t npx, int s, int nframes, uint32_t mn, hipStream_t st);

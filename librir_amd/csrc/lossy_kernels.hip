@@ -1,8 +1,13 @@
 // Bounded-loss recording on the GPU: the per-frame loss-injection step of the reference's lossy saver
 // (reference src/cpp/video_io/h264.cpp: get_background :1955-1991, stdDev :1993-2036,
 // RunningAverage2 :1526-1615, decision loop :2397-2413 / :2574-2590).  The state is sequential in
-// time and parallel in space: three kernels per frame (two reductions with a sequential tail each, one elementwise update),
-// all integer, exact.
+// time and parallel in space; all integer, exact.  Three forms of the same arithmetic:
+//   one frame            three kernels (two reductions with a sequential tail each, one elementwise update)
+//   a run of frames      lossy_run_kernel: the stream's workgroups stay resident, pixel state in registers, the frames' sums
+//                        exchanged between workgroups through tagged words (launches of <= 960 workgroups)
+//   a run, large frames  lossy_frame_kernel, one launch per frame: update of frame f fused with the sums of frame f + 1
+//                        or many streams
+// (a run's backgrounds come from one histogram launch per group of frames: they depend on the input only).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -156,7 +161,12 @@ namespace rir
 	// st[1..6]: the frame's sums as read by the caller.
 	// b: the stream's budget state, staged in LDS by the caller (the 40-entry window is shifted and summed element by element:
 	// from global memory that was 160 dependent round trips, 8 us).
-	__device__ __forceinline__ void lossy_budget(const LossyStep &sp, const long long *st, LossyBudget &b, int *errors_out)
+	struct LossyBudgetParams
+	{
+		int s, add_loss, low_value_error, high_value_error;
+		double std_factor;
+	};
+	__device__ __forceinline__ LossyDecision lossy_budget(const LossyBudgetParams &sp, const long long *st, LossyBudget &b)
 	{
 		const int s = sp.s;
 		// stdDev (h264.cpp:1993-2036): unsplit for the first 40 frames
@@ -183,16 +193,28 @@ namespace rir
 			++b.n_win;
 		}
 		else
-		{
-			for (int i = 0; i < 39; ++i)
-				b.win[i][0] = b.win[i + 1][0], b.win[i][1] = b.win[i + 1][1];
-			b.win[39][0] = sd[0], b.win[39][1] = sd[1];
+		{ // the oldest entry makes room (the reference shifts the window; 78 dependent LDS round trips here - a ring instead)
+			b.win[b.head][0] = sd[0], b.win[b.head][1] = sd[1];
+			b.head = b.head == 39 ? 0 : b.head + 1;
 		}
+		// summed oldest to newest, as the reference does
 		double mean[2] = {b.first_std[0], b.first_std[1]};
-		for (int i = 0; i < b.n_win; ++i)
+		if (b.n_win < 40)
+			for (int i = 0; i < b.n_win; ++i)
+			{
+				mean[0] += b.win[i][0];
+				mean[1] += b.win[i][1];
+			}
+		else
 		{
-			mean[0] += b.win[i][0];
-			mean[1] += b.win[i][1];
+			const int h0 = b.head;
+#pragma unroll 4
+			for (int i = 0; i < 40; ++i)
+			{
+				const int j = h0 + i < 40 ? h0 + i : h0 + i - 40;
+				mean[0] += b.win[j][0];
+				mean[1] += b.win[j][1];
+			}
 		}
 		mean[0] /= (double)(b.n_win + b.n_first);
 		mean[1] /= (double)(b.n_win + b.n_first);
@@ -212,15 +234,102 @@ namespace rir
 			high_error = 0;
 		if (low_error < high_error)
 			low_error = high_error;
+		LossyDecision d;
+		d.background = (uint32_t)st[0];
+		d.low_error = low_error;
+		d.high_error = high_error;
+		d.reserved = 0;
+		return d;
+	}
+	__device__ __forceinline__ void lossy_budget(const LossyStep &sp, const long long *st, LossyBudget &b, int *errors_out)
+	{
+		const LossyBudgetParams bp = {sp.s, sp.add_loss, sp.low_value_error, sp.high_value_error, sp.std_factor};
+		const LossyDecision d = lossy_budget(bp, st, b);
 		RIR_GLOBAL(LossyDecision) *decision = as_global(sp.decision);
-		decision->background = (uint32_t)st[0];
-		decision->low_error = low_error;
-		decision->high_error = high_error;
+		decision->background = d.background;
+		decision->low_error = d.low_error;
+		decision->high_error = d.high_error;
 		if (errors_out)
 		{
-			as_global(errors_out)[0] = low_error;
-			as_global(errors_out)[1] = high_error;
+			as_global(errors_out)[0] = d.low_error;
+			as_global(errors_out)[1] = d.high_error;
 		}
+	}
+
+	// The same budget by TWO lanes of a wave, lane c = component c (0: background / low error, 1: foreground / high error), each
+	// doing exactly the operations lossy_budget does for its component, in the same order.  Split in two so that the sum over the
+	// window - 40 dependent additions that do not involve the new frame - is out of the way before the frame's sums arrive:
+	// lossy_budget2_prepare (any time after the previous frame's finish), then lossy_budget2_finish.  Both lanes call; b in LDS.
+	__device__ __forceinline__ double lossy_budget2_prepare(const LossyBudget &b, int c)
+	{
+		double part = b.first_std[c]; // first + the window entries that stay, oldest to newest (the new entry is added last)
+		if (b.n_win < 40)
+			for (int i = 0; i < b.n_win; ++i)
+				part += b.win[i][c];
+		else
+		{
+			const int h0 = b.head;
+#pragma unroll 4
+			for (int i = 1; i < 40; ++i)
+			{
+				const int j = h0 + i < 40 ? h0 + i : h0 + i - 40;
+				part += b.win[j][c];
+			}
+		}
+		return part;
+	}
+	__device__ __forceinline__ LossyDecision lossy_budget2_finish(const LossyBudgetParams &sp, const long long *st, LossyBudget &b, int c, double part)
+	{
+		double sd;
+		if (b.n_win < 40)
+		{
+			const double sum_diff = (double)(st[1] + st[4]), sum_diff2 = (double)(st[2] + st[5]);
+			sd = sqrt(sum_diff * sum_diff - sum_diff2) / sp.s;
+		}
+		else
+		{
+			const double d = (double)(c ? st[1] : st[4]), d2 = (double)(c ? st[2] : st[5]);
+			sd = sqrt(d * d - d2) / (int)(c ? st[3] : st[6]);
+		}
+		const bool first = b.n_first < 1; // (the very first budget of a stream: `part` was taken before first_std existed)
+		if (first)
+			b.first_std[c] = sd;
+		const int n_win = b.n_win, head = b.head;
+		double mean;
+		if (n_win < 40)
+		{
+			b.win[n_win][c] = sd;
+			mean = (first ? sd : part) + sd;
+		}
+		else
+		{
+			b.win[head][c] = sd;
+			mean = part + sd;
+		}
+		const int n_win_after = n_win < 40 ? n_win + 1 : 40;
+		mean /= (double)(n_win_after + 1);
+		const int base = c ? sp.high_value_error : sp.low_value_error;
+		const double dd = sp.add_loss ? (sd < mean ? 0 : sd - mean) : fabs(sd - mean);
+		const int e = sub_wrap(base, int_of_double_x86(round(dd * sp.std_factor)));
+		int high_error = __shfl(e, 1, 64), low_error = __shfl(e, 0, 64);
+		if (c == 0)
+		{ // (one lane moves the counters; the other has read them)
+			b.n_first = 1;
+			if (n_win < 40)
+				b.n_win = n_win + 1;
+			else
+				b.head = head == 39 ? 0 : head + 1;
+		}
+		if (high_error < 0)
+			high_error = 0;
+		if (low_error < high_error)
+			low_error = high_error;
+		LossyDecision d;
+		d.background = (uint32_t)st[0];
+		d.low_error = low_error;
+		d.high_error = high_error;
+		d.reserved = 0;
+		return d;
 	}
 
 	// L2: sums of |t - prev| and of its (32-bit wrapped) square, split by img > background.
@@ -414,6 +523,63 @@ namespace rir
 		v.x = r.d[0], v.y = r.d[1], v.z = r.d[2], v.w = r.d[3];
 		*reinterpret_cast<RIR_GLOBAL(lossy_v4u) *>(p + (size_t)i8 * 8) = v;
 	}
+	// L3 + L4 of ONE pixel (RunningAverage2::addImage h264.cpp:1526-1615, decision loop :2397-2413 / :2574-2590), on values in
+	// registers: v = the frame's pixel, old = the ring's oldest image at this pixel (read only when the ring is full and the pixel
+	// is not in a constant stretch).  Updates ref / sum / cc / cv, returns the stored pixel; *t_in = what enters the ring.
+	struct LossyFrameConsts
+	{
+		uint32_t min, background;
+		int subtract_min, ra, full_ring, n_after, add_loss, low_error, high_error;
+		uint32_t div_magic; // lossy_div_magic(n_after)
+	};
+	// sum / n for sum < 2^22 (at most 64 images of 16 bits) and 1 <= n <= 64 without a division: floor(sum * M / 2^32), M =
+	// floor(2^32 / n) + 1, is exact as long as sum * (M - 2^32 / n) / 2^32 < 1 / n, and sum / 2^32 < 2^-10 < 1 / 64.
+	__device__ __forceinline__ uint32_t lossy_div_magic(int n) { return n > 1 ? (uint32_t)(0x100000000ull / (uint32_t)n) + 1u : 0u; }
+	__device__ __forceinline__ uint32_t lossy_div(uint32_t sum, uint32_t magic) { return magic ? __umulhi(sum, magic) : sum; }
+	__device__ __forceinline__ uint32_t lossy_pixel(const LossyFrameConsts &c, uint32_t v, uint32_t old, uint32_t last, uint32_t &ref, uint32_t &sum, uint32_t &cc,
+												   uint32_t &cv, uint32_t *t_in, bool &ref_changed, bool &cc_changed)
+	{
+		uint32_t t = c.subtract_min ? sub_min(v, c.min) : v;
+		*t_in = t;
+		uint32_t sm = 0;
+		if (c.ra > 0)
+		{
+			sm = sum + t;
+			if (c.full_ring)
+			{
+				if (cc)
+				{
+					cc = cc - 1u;
+					cc_changed = true;
+					sm -= cv;
+				}
+				else
+					sm -= old;
+			}
+		}
+		const int diff = abs((int)t - (int)ref);
+		const int max_error = v > c.background ? c.high_error : c.low_error;
+		bool keep = diff <= max_error;
+		if (!c.add_loss)
+			keep = keep && ((last >> 13) == (v >> 13));
+		if (keep)
+			t = c.ra > 0 ? lossy_div(sm, c.div_magic) : ref;
+		else
+		{
+			ref = t;
+			ref_changed = true;
+			if (c.ra > 0)
+			{
+				cv = t;
+				cc = (uint32_t)c.n_after;
+				cc_changed = true;
+				sm = t * (uint32_t)c.n_after;
+			}
+		}
+		sum = sm;
+		return t;
+	}
+
 	// L3 + L4 for the 8 pixels of group i8 (inside the lossy rows), v8 = the frame's pixels: state arrays updated, the lossy pixels
 	// stored to `out` (and to prevT when store_prev) and returned.
 	__device__ __forceinline__ U16x8 lossy_update8(const LossyStep &sp, int i8, const U16x8 &v8, bool store_prev)
@@ -445,50 +611,17 @@ namespace rir
 				old8 = ld8(ring + (size_t)st.ra_head * s, i8);
 		}
 		bool ref_changed = false, cc_changed = false; // (per group of 8: the arrays are written back only where a pixel changed them)
+		const LossyFrameConsts fc = {st.min, background, st.subtract_min, ra, full_ring ? 1 : 0, n_after, add_loss, low_error, high_error, lossy_div_magic(n_after)};
 #pragma unroll
 		for (int k = 0; k < 8; ++k)
 		{
-			const uint32_t v = v8.get(k);
-			uint32_t t = st.subtract_min ? sub_min(v, st.min) : v;
-			t8.set(k, t);
-			uint32_t sm = 0;
+			uint32_t ref = ref8.get(k), cc = ra > 0 ? cc8.get(k) : 0u, cv = ra > 0 ? cv8.get(k) : 0u, t_in;
+			const uint32_t t = lossy_pixel(fc, v8.get(k), full_ring ? old8.get(k) : 0u, add_loss ? 0u : last8.get(k), ref, sum[k], cc, cv, &t_in, ref_changed,
+										   cc_changed);
+			ref8.set(k, ref);
 			if (ra > 0)
-			{ // RunningAverage2::addImage
-				sm = sum[k] + t;
-				if (full_ring)
-				{
-					const uint32_t cc = cc8.get(k);
-					if (cc)
-					{
-						cc8.set(k, cc - 1u);
-						cc_changed = true;
-						sm -= cv8.get(k);
-					}
-					else
-						sm -= old8.get(k);
-				}
-			}
-			const uint32_t ref = ref8.get(k);
-			const int diff = abs((int)t - (int)ref);
-			const int max_error = v > background ? high_error : low_error;
-			bool keep = diff <= max_error;
-			if (!add_loss)
-				keep = keep && ((last8.get(k) >> 13) == (v >> 13));
-			if (keep)
-				t = ra > 0 ? sm / (uint32_t)n_after : ref;
-			else
-			{
-				ref8.set(k, t);
-				ref_changed = true;
-				if (ra > 0)
-				{
-					cv8.set(k, t);
-					cc8.set(k, (uint32_t)n_after);
-					cc_changed = true;
-					sm = t * (uint32_t)n_after;
-				}
-			}
-			sum[k] = sm;
+				cc8.set(k, cc), cv8.set(k, cv);
+			t8.set(k, t_in);
 			o8.set(k, t);
 		}
 		if (ra > 0)
@@ -638,6 +771,351 @@ namespace rir
 		lossy_sums_tail(sp, a, background, sp.next_errors_out);
 	}
 
+	// ---- a run of frames in one launch ---------------------------------------------------------------------------
+	//
+	// grid = workgroups of a stream (nb = lossy_run_workgroups(full)) x streams, 1-D, all resident at once (kLossyRunMaxWorkgroups,
+	// lossy_kernels.h); a ticket deals (stream, workgroup) in the order workgroups start.  A workgroup only ever waits for
+	// workgroups of ITS stream.
+	// Thread (b, tid) owns pixels [8 i8, 8 i8 + 8), i8 = 1024 b + tid, for every frame of the run: refT, lastDL, the running sums and
+	// the constant-stretch counters of its pixels live in registers from the first frame to the last; per frame it reads the
+	// pixels and the ring's oldest image and writes the output and the ring's newest image (8 bytes per pixel and frame instead of 30).
+	// Frame k of the run, per workgroup:
+	//   1. sums of frame k against the previous output (in registers), reduced over the workgroup; wave 0 publishes them as four
+	//      words TAG(k) << 48 | value(s) to exchange[k & 1][b] (agent-scope stores; a word is its own flag)
+	//   2. wave 0 of every workgroup polls the words of all nb workgroups of its stream (agent-scope loads, lane l takes workgroups
+	//      l, l + 64, ...), adds them up and lane 0 computes the budget - every workgroup the same one, from the same integers
+	//   3. update of frame k with that decision.
+	// A workgroup publishes frame k + 1 only after it has read all of frame k, and nobody gets to publish frame k + 2 before everybody
+	// has published k + 1: two buffers are enough.  Waits are bounded by a clock (2 s): a wait that gives up raises error_word and
+	// the run goes on with whatever it has - wrong, flagged, but never hung.
+	constexpr int kRunWaves = kLossyRunThreads / 64;
+	__global__ __launch_bounds__(kLossyRunThreads) void lossy_run_kernel(const LossyRun *__restrict__ table, unsigned int *__restrict__ ticket_, int nb, int nstreams)
+	{
+		__shared__ unsigned int sh_ticket;
+		__shared__ long long red[kRunWaves][6], red2[kRunWaves][6];
+		__shared__ LossyBudget bl;
+		__shared__ LossyDecision dec;
+		const int tid = threadIdx.x;
+		if (tid == 0)
+		{
+			RIR_GLOBAL(unsigned int) *ticket = as_global(ticket_);
+			const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (t == (unsigned int)(nb * nstreams) - 1u)
+				__hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+			sh_ticket = t;
+		}
+		__syncthreads();
+		const int tk = __builtin_amdgcn_readfirstlane((int)sh_ticket);
+		const int stream = tk / nb, b = tk - stream * nb;
+		LossyRun rp;
+		{
+			static_assert(sizeof(LossyRun) % 8 == 0, "LossyRun is copied in 8-byte words");
+			RIR_GLOBAL(const unsigned long long) *src = (RIR_GLOBAL(const unsigned long long) *)(table + stream);
+			unsigned long long *dst = reinterpret_cast<unsigned long long *>(&rp);
+#pragma unroll
+			for (size_t k = 0; k < sizeof(LossyRun) / 8; ++k)
+				dst[k] = src[k];
+		}
+		const LossyDeviceState st = rp.st;
+		RIR_GLOBAL(uint16_t) *refT = as_global(st.refT), *prevT = as_global(st.prevT), *lastDL = as_global(st.lastDL);
+		RIR_GLOBAL(uint16_t) *cval = as_global(st.ra_const_value), *ring = as_global(st.ra_images);
+		RIR_GLOBAL(uint16_t) *ccnt = (RIR_GLOBAL(uint16_t) *)as_global(st.ra_const_count);
+		RIR_GLOBAL(uint32_t) *sums = as_global(st.ra_sums);
+		RIR_GLOBAL(const uint16_t) *in = as_global(rp.in);
+		RIR_GLOBAL(uint16_t) *out = as_global(rp.out);
+		RIR_GLOBAL(unsigned long long) *exch = as_global(rp.exchange);
+		const int s = rp.s, full = rp.full, ra = st.running_average, add_loss = rp.add_loss;
+		const int i8 = b * kLossyRunThreads + tid;
+		const bool inside = i8 * 8 < full, lossy = i8 * 8 < s;
+		const LossyBudgetParams bp = {s, add_loss, rp.low_value_error, rp.high_value_error, rp.std_factor};
+
+		// the budget state of the stream: every workgroup keeps its own copy in LDS and advances it identically
+		{
+			RIR_GLOBAL(const unsigned long long) *gb = (RIR_GLOBAL(const unsigned long long) *)as_global(rp.budget);
+			unsigned long long *lb = reinterpret_cast<unsigned long long *>(&bl);
+			if (tid < (int)(sizeof(LossyBudget) / 8))
+				lb[tid] = gb[tid];
+		}
+		// state of this thread's pixels -> registers
+		U16x8 ref8{}, last8{}, cc8{}, cv8{}, o8{}, old8{}, t8{};
+		uint32_t sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		int count = st.ra_count, head = st.ra_head;
+		if (lossy)
+		{
+			ref8 = ld8(refT, i8);
+			last8 = ld8(lastDL, i8);
+			o8 = ld8(prevT, i8);
+			if (ra > 0)
+			{
+				const lossy_v4u s0 = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(sums + (size_t)i8 * 8), s1 = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(sums + (size_t)i8 * 8 + 4);
+				sum[0] = s0.x, sum[1] = s0.y, sum[2] = s0.z, sum[3] = s0.w, sum[4] = s1.x, sum[5] = s1.y, sum[6] = s1.z, sum[7] = s1.w;
+				cc8 = ld8(ccnt, i8);
+				cv8 = ld8(cval, i8);
+				if (count == ra)
+					old8 = ld8(ring + (size_t)head * s, i8);
+			}
+		}
+		U16x8 v8{};
+		if (inside)
+			v8 = ld8(in, i8);
+		const unsigned long long t_limit = 200000000ull; // 2 s of the 100 MHz clock
+		bool gave_up = false;
+		for (int k = 0; k < rp.nsteps; ++k)
+		{
+			// the next frame's pixels are requested now: they arrive while this frame's sums go round
+			U16x8 vn{};
+			if (inside && k + 1 < rp.nsteps)
+				vn = ld8(in + (size_t)(k + 1) * rp.frame_px, i8);
+			const long long background = as_global(rp.bg)[(size_t)k * rp.bg_stride];
+			// 1. this workgroup's share of the frame's sums
+			int32_t fd = 0, fn = 0, bd = 0, bn = 0;
+			long long f2 = 0, b2 = 0;
+			if (lossy)
+			{
+				const uint32_t bg = (uint32_t)background;
+#pragma unroll
+				for (int q = 0; q < 8; ++q)
+				{
+					const uint32_t t = st.subtract_min ? sub_min(v8.get(q), st.min) : v8.get(q);
+					const int32_t d = abs((int32_t)t - (int32_t)o8.get(q));
+					const int32_t d2 = (int32_t)((uint32_t)d * (uint32_t)d);
+					if (v8.get(q) > bg)
+						fd += d, f2 += d2, fn += 1;
+					else
+						bd += d, b2 += d2, bn += 1;
+				}
+			}
+#ifdef RIR_LOSSY_DIAG
+			const unsigned long long dg0 = __builtin_amdgcn_s_memrealtime();
+			unsigned long long dg1 = 0, dg2 = 0, dg3 = 0;
+#endif
+			// wave sums -> LDS; wave 0 adds the waves up, publishes, collects everybody's words and decides
+			long long ws[6] = {fd, f2, fn, bd, b2, bn};
+#pragma unroll
+			for (int j = 0; j < 6; ++j)
+#pragma unroll
+				for (int d = 32; d >= 1; d >>= 1)
+					ws[j] += __shfl_xor(ws[j], d, 64);
+			const int lane = tid & 63, wave = tid >> 6;
+			if (lane < 6)
+				red[wave][lane] = lane == 0 ? ws[0] : lane == 1 ? ws[1] : lane == 2 ? ws[2] : lane == 3 ? ws[3] : lane == 4 ? ws[4] : ws[5];
+			__syncthreads();
+			const unsigned long long tag = (unsigned long long)(((unsigned)k & 0x7fffu) | 0x8000u) << 48;
+			const unsigned long long vmask = 0x0000ffffffffffffull;
+			RIR_GLOBAL(unsigned long long) *bank = exch + (size_t)(k & 1) * nb * rp.slot_words;
+			double part = 0;
+			if (wave == 0)
+			{
+				long long val = 0;
+				if (lane < 6)
+#pragma unroll
+					for (int w = 0; w < kRunWaves; ++w)
+						val += red[w][lane];
+#pragma unroll
+				for (int j = 0; j < 6; ++j)
+					ws[j] = __shfl(val, j, 64);
+				// four words: TAG | fg count | fg sum d,  TAG | fg sum d2,  TAG | bg count | bg sum d,  TAG | bg sum d2
+				// (a workgroup has 2 048 pixels: counts < 2^12, sums of d < 2^28, |sums of d2| < 2^42)
+				if (lane < 4)
+				{
+					const unsigned long long w = lane == 0	 ? ((unsigned long long)ws[2] << 30) | (unsigned long long)ws[0]
+												 : lane == 1 ? (unsigned long long)ws[1] & vmask
+												 : lane == 2 ? ((unsigned long long)ws[5] << 30) | (unsigned long long)ws[3]
+															 : (unsigned long long)ws[4] & vmask;
+					__hip_atomic_store(bank + (size_t)b * rp.slot_words + lane, tag | w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				// while the words travel: the part of the budget that does not need them
+				if (lane < 2 && (!rp.leader || b == 0))
+					part = lossy_budget2_prepare(bl, lane);
+			}
+#ifdef RIR_LOSSY_DIAG
+			dg1 = __builtin_amdgcn_s_memrealtime();
+#endif
+			// 2. everybody's shares: thread p takes workgroup p (p + 256, ...).  With many streams in the launch only workgroup 0 of a
+			// stream does that (every workgroup reading every slot is nb^2 polled lines per stream and frame: with 6 streams the polls
+			// took 5.8 us instead of 2) and hands the decision on in one word; the others poll that word - one more hop, 1/nb of the traffic.
+			const bool collect = !rp.leader || b == 0;
+			long long acc[6] = {0, 0, 0, 0, 0, 0};
+			if (collect)
+				for (int p = tid; p < nb; p += kLossyRunThreads)
+				{
+					unsigned long long w[4];
+					const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+					for (;;)
+					{
+						bool ok = true;
+#pragma unroll
+						for (int j = 0; j < 4; ++j)
+						{
+							w[j] = __hip_atomic_load(bank + (size_t)p * rp.slot_words + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							ok = ok && ((w[j] & ~vmask) == tag);
+						}
+						if (ok || gave_up)
+							break;
+						__builtin_amdgcn_s_sleep(1);
+						if (__builtin_amdgcn_s_memrealtime() - t_start > t_limit)
+						{
+							gave_up = true;
+							__hip_atomic_store(as_global(rp.error_word), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						}
+					}
+					acc[0] += (long long)(w[0] & 0x3fffffffull), acc[2] += (long long)((w[0] & vmask) >> 30);
+					acc[1] += (long long)(w[1] << 16) >> 16; // 48-bit two's complement
+					acc[3] += (long long)(w[2] & 0x3fffffffull), acc[5] += (long long)((w[2] & vmask) >> 30);
+					acc[4] += (long long)(w[3] << 16) >> 16;
+				}
+			// the decision word of the frame: TAG | low error (24 bits) | high error (24 bits), after the 2 x nb slots of the stream
+			RIR_GLOBAL(unsigned long long) *dword = exch + (size_t)2 * nb * rp.slot_words + (size_t)(k & 1) * 8;
+			if (collect)
+			{
+#pragma unroll
+				for (int j = 0; j < 6; ++j)
+#pragma unroll
+					for (int d = 32; d >= 1; d >>= 1)
+						acc[j] += __shfl_xor(acc[j], d, 64);
+				if (lane < 6)
+					red2[wave][lane] = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : lane == 3 ? acc[3] : lane == 4 ? acc[4] : acc[5];
+				__syncthreads();
+#ifdef RIR_LOSSY_DIAG
+				dg2 = __builtin_amdgcn_s_memrealtime();
+#endif
+				if (wave == 0)
+				{
+					long long val = 0;
+					if (lane < 6)
+#pragma unroll
+						for (int w = 0; w < kRunWaves; ++w)
+							val += red2[w][lane];
+					long long stt[7];
+					stt[0] = background;
+#pragma unroll
+					for (int j = 0; j < 6; ++j)
+						stt[1 + j] = __shfl(val, j, 64);
+					if (lane < 2)
+					{
+						const LossyDecision d = lossy_budget2_finish(bp, stt, bl, lane, part);
+						if (lane == 0)
+						{
+							dec = d;
+							if (rp.leader)
+								__hip_atomic_store(dword, tag | ((unsigned long long)((unsigned)d.low_error & 0xffffffu) << 24) | ((unsigned)d.high_error & 0xffffffu),
+												   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							if (b == 0 && rp.errors_out)
+							{
+								as_global(rp.errors_out)[2 * k] = d.low_error;
+								as_global(rp.errors_out)[2 * k + 1] = d.high_error;
+							}
+						}
+					}
+				}
+			}
+			else if (tid == 0)
+			{
+				unsigned long long w;
+				const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+				for (;;)
+				{
+					w = __hip_atomic_load(dword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if ((w & ~vmask) == tag || gave_up)
+						break;
+					__builtin_amdgcn_s_sleep(1);
+					if (__builtin_amdgcn_s_memrealtime() - t_start > t_limit)
+					{
+						gave_up = true;
+						__hip_atomic_store(as_global(rp.error_word), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
+				}
+				LossyDecision d;
+				d.background = (uint32_t)background;
+				d.low_error = (int)((w >> 24) & 0xffffffu), d.high_error = (int)(w & 0xffffffu);
+				d.reserved = 0;
+				dec = d;
+			}
+#ifdef RIR_LOSSY_DIAG
+			dg3 = __builtin_amdgcn_s_memrealtime();
+#endif
+			__syncthreads(); // (also keeps the other waves off red / red2 until wave 0 has read them)
+			// 3. update
+			const bool full_ring = ra > 0 && count == ra;
+			const int n_after = ra > 0 ? (full_ring ? ra : count + 1) : 0;
+			if (lossy)
+			{
+				const LossyFrameConsts fc = {st.min, dec.background, st.subtract_min, ra, full_ring ? 1 : 0, n_after, add_loss, dec.low_error, dec.high_error,
+											 lossy_div_magic(n_after)};
+				bool rc = false, ccg = false;
+#pragma unroll
+				for (int q = 0; q < 8; ++q)
+				{
+					uint32_t ref = ref8.get(q), cc = cc8.get(q), cv = cv8.get(q), t_in;
+					const uint32_t t = lossy_pixel(fc, v8.get(q), old8.get(q), last8.get(q), ref, sum[q], cc, cv, &t_in, rc, ccg);
+					ref8.set(q, ref), cc8.set(q, cc), cv8.set(q, cv);
+					t8.set(q, t_in);
+					o8.set(q, t);
+				}
+				last8 = v8;
+				st8(out + (size_t)k * rp.frame_px, i8, o8);
+				if (ra > 0)
+				{
+					const int slot = full_ring ? head : (head + count) % ra;
+					st8(ring + (size_t)slot * s, i8, t8);
+				}
+			}
+			else if (inside)
+				st8(out + (size_t)k * rp.frame_px, i8, v8); // rows past lossy_height: stored as they are
+			if (ra > 0)
+			{
+				if (count == ra)
+					head = (head + 1) % ra;
+				else
+					++count;
+				// the oldest image for the next frame: written at least one frame ago (by this thread) unless the ring holds one image
+				if (lossy && count == ra && k + 1 < rp.nsteps)
+					old8 = ra == 1 ? t8 : ld8(ring + (size_t)head * s, i8);
+			}
+			if (k + 1 < rp.nsteps)
+				v8 = vn;
+#ifdef RIR_LOSSY_DIAG
+			if (b == 0 && tid == 0)
+			{ // ticks (10 ns) of: sums + reduce + publish | poll | reduce | budget | barrier + update, summed over the frames
+				RIR_GLOBAL(unsigned long long) *dg = (RIR_GLOBAL(unsigned long long) *)as_global(rp.error_word) + 8;
+				const unsigned long long dg4 = __builtin_amdgcn_s_memrealtime();
+				dg[0] += dg1 - dg0, dg[1] += dg2 - dg1, dg[2] += dg3 - dg2, dg[3] += dg4 - dg3, dg[4] += 1;
+			}
+#endif
+		}
+		// registers -> state
+		if (lossy)
+		{
+			st8(refT, i8, ref8);
+			st8(lastDL, i8, last8);
+			st8(prevT, i8, o8);
+			if (ra > 0)
+			{
+				lossy_v4u s0, s1;
+				s0.x = sum[0], s0.y = sum[1], s0.z = sum[2], s0.w = sum[3], s1.x = sum[4], s1.y = sum[5], s1.z = sum[6], s1.w = sum[7];
+				*reinterpret_cast<RIR_GLOBAL(lossy_v4u) *>(sums + (size_t)i8 * 8) = s0;
+				*reinterpret_cast<RIR_GLOBAL(lossy_v4u) *>(sums + (size_t)i8 * 8 + 4) = s1;
+				st8(ccnt, i8, cc8);
+				st8(cval, i8, cv8);
+			}
+		}
+		else if (inside)
+			st8(lastDL, i8, v8);
+		if (b == 0)
+		{
+			__syncthreads();
+			RIR_GLOBAL(unsigned long long) *gb = (RIR_GLOBAL(unsigned long long) *)as_global(rp.budget);
+			const unsigned long long *lb = reinterpret_cast<const unsigned long long *>(&bl);
+			if (tid < (int)(sizeof(LossyBudget) / 8))
+				gb[tid] = lb[tid];
+			if (tid == 0)
+			{
+				RIR_GLOBAL(LossyDecision) *gd = as_global(rp.decision);
+				gd->background = dec.background, gd->low_error = dec.low_error, gd->high_error = dec.high_error;
+			}
+		}
+	}
+
 	// first frame: out = tmp minus the optional minimum on rows < lossy_height; seeds refT / prevT / lastDL
 	__global__ __launch_bounds__(256) void lossy_first_kernel(const uint16_t *__restrict__ tmp, uint16_t *__restrict__ out, LossyDeviceState st, int s,
 															   int full)
@@ -737,6 +1215,13 @@ namespace rir
 	{
 		LossyStep none{};
 		hipLaunchKernelGGL(lossy_frame_kernel<true>, dim3((full / 8 + 255) / 256, nstreams), dim3(256), 0, st, none, d_table);
+		return hipGetLastError();
+	}
+
+	hipError_t launch_lossy_run(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ticket, hipStream_t st)
+	{
+		const int nb = lossy_run_workgroups(full);
+		hipLaunchKernelGGL(lossy_run_kernel, dim3((unsigned)(nb * nstreams)), dim3(kLossyRunThreads), 0, st, d_table, d_ticket, nb, nstreams);
 		return hipGetLastError();
 	}
 

@@ -338,6 +338,7 @@ namespace
 		bool remove_bad_pixels = false;
 		DeviceBuffer batch_errs; // int[nframes][2] of the last rir_lossy_step_device call
 		DeviceBuffer multi_table; // rir_lossy_step_multi_device: the steps of the call (this object leads it)
+		DeviceBuffer run_exchange; // the run kernel's ticket, error word and exchange words
 		DeviceBuffer run_hist, run_tickets, run_bg; // runs of frames: histogram slices and tickets of a group of frames, backgrounds of the call
 		PinnedBuffer multi_stage;
 		hipEvent_t multi_copied = nullptr; // the copy out of multi_stage of the last call (whatever its stream) has completed
@@ -2221,6 +2222,20 @@ RIR_EXPORT int rir_lossy_step_device(int handle, const unsigned short *d_in, uns
 	return 0;
 }
 
+// The run kernel's workgroups wait for each other, so all of them must be resident at once (lossy_kernels.h): two such launches
+// on different HIP streams could each hold a part of the chip and wait for the rest for ever.  Every launch therefore waits for
+// the previous one - whatever stream that was on - to have finished.
+static bool launch_run_alone(const LossyRun *d_table, int nstreams, int full_px, unsigned int *d_ticket, hipStream_t st)
+{
+	static std::mutex m;
+	static hipEvent_t last = nullptr;
+	std::lock_guard<std::mutex> lock(m);
+	if (!last && !hip_ok(hipEventCreateWithFlags(&last, hipEventDisableTiming), "event"))
+		return false;
+	return hip_ok(hipStreamWaitEvent(st, last, 0), "wait event") && hip_ok(launch_lossy_run(d_table, nstreams, full_px, d_ticket, st), "lossy run") &&
+		   hip_ok(hipEventRecord(last, st), "event");
+}
+
 // The same step for `nstreams` INDEPENDENT streams (one state object each, equal geometry and history length) with the streams
 // sharing every launch: frame f of all streams = three launches whose grids carry the stream in their second dimension
 // (the loss state is sequential in time, so streams - not frames - are what runs side by side).
@@ -2281,8 +2296,17 @@ RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, con
 	{
 		// the descriptions of all launches of the call go to the device in one copy (page-locked staging: the copy is asynchronous
 		// and the host buffer must outlive it - it is kept by the leading stream's object)
-		const size_t nfused = runs ? (size_t)(nsteps + 1) * nstreams : (size_t)nsteps * nstreams, nhist = runs ? (size_t)nsteps * nstreams : 0;
-		const size_t nb = (nfused + nhist) * sizeof(LossyStep);
+		// persistent: the whole group of frames in one launch (lossy_run_kernel) when the chip holds a stream's workgroups at once
+		const int run_wgs = lossy_run_workgroups(full_px);
+		bool errors_fit = true; // (the run kernel hands a decision on as two 24-bit fields)
+		for (int i = 0; i < nstreams; ++i)
+			errors_fit = errors_fit && os[i]->low < (1 << 24) && os[i]->high < (1 << 24);
+		const bool persistent = runs && errors_fit && (long long)run_wgs * nstreams <= kLossyRunMaxWorkgroups && !getenv("RIR_LOSSY_LAUNCH_PER_FRAME");
+		const int group = std::max(1, 512 / nstreams); // frames per histogram launch
+		const int ngroups = runs ? (nsteps + group - 1) / group : 0;
+		const size_t nfused = persistent ? 0 : runs ? (size_t)(nsteps + 1) * nstreams : (size_t)nsteps * nstreams, nhist = runs ? (size_t)nsteps * nstreams : 0;
+		const size_t run_off = (nfused + nhist) * sizeof(LossyStep); // (a multiple of 8)
+		const size_t nb = run_off + (persistent ? (size_t)ngroups * nstreams * sizeof(LossyRun) : 0);
 		if (!lead.multi_table.reserve(nb) || !lead.multi_stage.reserve(nb))
 			return -1;
 		// an earlier call's copy out of the staging buffer may still be in flight - on whatever stream that call was given
@@ -2313,7 +2337,6 @@ RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, con
 		else
 		{
 			// histogram scratch: one zeroed 16 384-bin slice and one ticket per frame of a group (the kernels leave them zeroed)
-			const int group = std::max(1, 512 / nstreams); // frames per histogram launch
 			const size_t slices = (size_t)std::min(nsteps, group) * nstreams;
 			const size_t hist_cap = lead.run_hist.cap, tick_cap = lead.run_tickets.cap;
 			if (!lead.run_hist.reserve(slices * 16384 * 4) || !lead.run_tickets.reserve(slices * 4) || !lead.run_bg.reserve(nhist * sizeof(long long)))
@@ -2324,6 +2347,70 @@ RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, con
 				return -1;
 			long long *bg = lead.run_bg.as<long long>();
 			LossyStep *hh = hs + nfused;
+			if (persistent)
+			{
+				// scratch of the run kernel: [ticket, error word | 256 B][streams][2][run_wgs][slot_words] exchange words (zeroed before every launch)
+				const char *stride_env = getenv("RIR_LOSSY_SLOT_WORDS");
+				const int slot_words = stride_env && atoi(stride_env) >= 4 ? atoi(stride_env) : 8;
+				const size_t exch_words = (size_t)2 * run_wgs * slot_words + 16, exch_bytes = (size_t)nstreams * exch_words * 8;
+				// workgroup 0 of a stream collects and decides (0: every workgroup does - measured slower at every stream count, kept for measurements)
+				const char *leader_env = getenv("RIR_LOSSY_LEADER");
+				const int leader = leader_env ? atoi(leader_env) : 1;
+				const size_t exch_cap = lead.run_exchange.cap;
+				if (!lead.run_exchange.reserve(256 + exch_bytes))
+					return -1;
+				if (lead.run_exchange.cap != exch_cap && !hip_ok(hipMemsetAsync(lead.run_exchange.ptr, 0, 256, st), "memset"))
+					return -1;
+				unsigned int *d_ticket = lead.run_exchange.as<unsigned int>(), *d_error = d_ticket + 16;
+				unsigned long long *d_exch = reinterpret_cast<unsigned long long *>(lead.run_exchange.as<char>() + 256);
+				LossyRun *hr = reinterpret_cast<LossyRun *>(reinterpret_cast<char *>(hs) + run_off);
+				const LossyRun *dr = reinterpret_cast<const LossyRun *>(lead.multi_table.as<char>() + run_off);
+				for (int g = 0; g < ngroups; ++g)
+				{
+					const int k0 = g * group, in_group = std::min(group, nsteps - k0);
+					for (int i = 0; i < nstreams; ++i)
+					{
+						LossyState &ls = os[i]->st;
+						LossyRun r{};
+						r.in = d_in[i] + (size_t)(f0 + k0) * npx, r.out = d_out[i] + (size_t)(f0 + k0) * npx;
+						r.st = ls.dev;
+						r.bg = bg + (size_t)k0 * nstreams + i, r.bg_stride = nstreams;
+						r.budget = ls.d_budget.as<LossyBudget>(), r.decision = ls.d_decision.as<LossyDecision>();
+						r.errors_out = errs_of(i, f0 + k0);
+						r.exchange = d_exch + (size_t)i * exch_words, r.error_word = d_error, r.slot_words = slot_words, r.leader = leader;
+						r.frame_px = (long long)npx, r.nsteps = in_group;
+						r.s = s_px, r.full = full_px;
+						r.add_loss = add_loss ? 1 : 0, r.low_value_error = os[i]->low, r.high_value_error = os[i]->high, r.std_factor = os[i]->std_factor;
+						hr[(size_t)g * nstreams + i] = r;
+						for (int k = k0; k < k0 + in_group; ++k)
+						{
+							LossyStep h{};
+							const size_t slice = (size_t)(k - k0) * nstreams + i;
+							h.tmp = h.img = d_in[i] + (size_t)(f0 + k) * npx;
+							h.hist = lead.run_hist.as<uint32_t>() + slice * 16384;
+							h.stats = bg + (size_t)k * nstreams + i;
+							h.tickets = lead.run_tickets.as<unsigned int>() + slice;
+							h.s = s_px, h.full = full_px;
+							h.hist_px = lossy_hist_px(s_px, in_group * nstreams);
+							hh[(size_t)k * nstreams + i] = h;
+							ls.advance_ring();
+							++ls.frames;
+						}
+					}
+				}
+				if (!hip_ok(hipMemcpyAsync(lead.multi_table.ptr, hs, nb, hipMemcpyHostToDevice, st), "H2D") || !hip_ok(hipEventRecord(lead.multi_copied, st), "event"))
+					return -1;
+				for (int g = 0; g < ngroups; ++g)
+				{
+					const int k0 = g * group, in_group = std::min(group, nsteps - k0);
+					if (!hip_ok(launch_lossy_backgrounds(dt + nfused + (size_t)k0 * nstreams, in_group * nstreams, s_px, lossy_hist_px(s_px, in_group * nstreams), st),
+								"lossy backgrounds") ||
+						!hip_ok(hipMemsetAsync(d_exch, 0, exch_bytes, st), "memset") || !launch_run_alone(dr + (size_t)g * nstreams, nstreams, full_px, d_ticket, st))
+						return -1;
+				}
+			}
+			else
+			{
 			for (int k = 0; k <= nsteps; ++k) // launch k updates frame f0 + k - 1 (k > 0) and takes the sums of frame f0 + k (k < nsteps)
 				for (int i = 0; i < nstreams; ++i)
 				{
@@ -2375,14 +2462,29 @@ RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, con
 				if (!hip_ok(launch_lossy_frame(dt + (size_t)k * nstreams, nstreams, full_px, st), "lossy frame"))
 					return -1;
 			}
+			}
 		}
 	}
 	if (want)
 	{
 		std::vector<int> e((size_t)nstreams * nframes * 2);
+		unsigned int gave_up = 0; // the run kernel's error word (a wait between workgroups that hit its clock)
 		if (!hip_ok(hipMemcpyAsync(e.data(), lead.batch_errs.ptr, e.size() * sizeof(int), hipMemcpyDeviceToHost, st), "D2H") ||
+			(lead.run_exchange.ptr && !hip_ok(hipMemcpyAsync(&gave_up, lead.run_exchange.as<unsigned int>() + 16, 4, hipMemcpyDeviceToHost, st), "D2H")) ||
 			!hip_ok(wait_stream(st), "sync"))
 			return -1;
+		if (getenv("RIR_LOSSY_DIAG") && lead.run_exchange.ptr)
+		{ // (-DRIR_LOSSY_DIAG builds) where the time of a frame goes, workgroup 0 of stream 0
+			unsigned long long dg[5] = {0, 0, 0, 0, 0};
+			if (hip_ok(hipMemcpy(dg, lead.run_exchange.as<char>() + 128, sizeof(dg), hipMemcpyDeviceToHost), "D2H") && dg[4])
+				std::fprintf(stderr, "lossy run, per frame (us): sums+publish %.2f  poll %.2f  budget %.2f  barrier+update %.2f  (%llu frames)\n",
+							 dg[0] * 0.01 / dg[4], dg[1] * 0.01 / dg[4], dg[2] * 0.01 / dg[4], dg[3] * 0.01 / dg[4], dg[4]);
+		}
+		if (gave_up)
+		{
+			log_error("rir_lossy_step_multi_device: a run of frames gave up waiting (results invalid)");
+			return -1;
+		}
 		for (size_t i = 0; i < (size_t)nstreams * nframes; ++i)
 		{
 			if (low_errors)

@@ -117,8 +117,19 @@ def test_per_frame_error_attributes(tmp_path):
         assert int(mov.attributes["GlobalForegroundError"]) == 2
 
 
+@pytest.fixture(params=["one launch per run", "one launch per frame"])
+def run_path(request, monkeypatch):
+    """Batches of frames are stepped by the resident run kernel or - frames too large for it - by one fused launch per frame
+    (RIR_LOSSY_LAUNCH_PER_FRAME forces that path at any size)."""
+    if request.param == "one launch per frame":
+        monkeypatch.setenv("RIR_LOSSY_LAUNCH_PER_FRAME", "1")
+    else:
+        monkeypatch.delenv("RIR_LOSSY_LAUNCH_PER_FRAME", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("add_loss", [False, True])
-def test_device_resident_stream_matches_oracle(oracle, add_loss):
+def test_device_resident_stream_matches_oracle(oracle, add_loss, run_path):
     """rir_lossy_step_device: the same arithmetic on frames that never leave HBM, in two batches (state carries over)."""
     import torch
 
@@ -149,9 +160,16 @@ def test_device_resident_stream_matches_oracle(oracle, add_loss):
     assert lo_a is None
     assert np.array_equal(torch.cat([a, b]).cpu().numpy(), np.stack(exp))
     ls.close()
+    # runs, single frames (three launches each) and pairs interleaved: the state goes through registers and back unchanged
+    ls = D.LossyStream(w, h, hl, 5, 2, 2.5, 8)
+    cuts = [0, 1, 5, 6, 7, 30, 32, 33, n]
+    parts = [ls.step(t[c0:c1], add_loss=add_loss and c0 > 0) for c0, c1 in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(torch.cat([p[0] for p in parts]).cpu().numpy(), np.stack(exp))
+    assert np.concatenate([p[1] for p in parts]).tolist() == elo and np.concatenate([p[2] for p in parts]).tolist() == ehi
+    ls.close()
 
 
-def test_many_streams_in_shared_launches_equal_their_own_oracles(oracle):
+def test_many_streams_in_shared_launches_equal_their_own_oracles(oracle, run_path):
     """rir_lossy_step_multi_device: S independent streams (different data, different parameters) stepped by the same launches,
     in two calls (the first seeds the states, the second continues them): every stream's frames and per-frame budgets are
     those of its own oracle, bit for bit; a stream stepped alone gives the same result."""
