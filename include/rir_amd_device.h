@@ -176,6 +176,16 @@ extern "C"
 	/* (im - min) / (max - min) in float32 on a w x h window of a device image with row stride src_stride (the
 	 * normalisation of masked_registration_ecc.py:162-166, crop folded in); d_dst dense [h][w]. */
 	int rir_minmax_normalize_device(const float *d_src, int w, int h, int src_stride, float *d_dst, void *stream);
+	/* Pre-processing of `nframes` frames of a tracked sequence in shared launches, ahead of their (sequential) alignments: image
+	 * by image the gaussian pre-filter, window crop, min-max normalisation (masked_registration_ecc.py:88-166) and the gradients
+	 * the alignment samples.  d_imgs: uint16 ('H') or float32 ('f') [nframes][h][w]; d_norm, d_gx, d_gy: float
+	 * [nframes][win_h][win_w] in device memory. */
+	int rir_ecc_prepare_frames_device(const void *d_imgs, int dtype, int w, int h, int nframes, float sigma, int win_x, int win_y, int win_w, int win_h,
+									  float *d_norm, float *d_gx, float *d_gy, void *stream);
+	/* The alignment (cv2.findTransformECC, MOTION_TRANSLATION; masked_registration_ecc.py:166-168) of one prepared image against the
+	 * reference window.  warp: HOST float[2] (tx, ty) in/out. */
+	int rir_ecc_align_prepared_device(const float *d_ref_norm, const float *d_norm, const float *d_gx, const float *d_gy, int w, int h, float *warp,
+									  int max_iterations, double eps, double *cc, int *iterations, void *stream);
 	/* One frame of a tracked sequence in one call - the steps of MaskedRegistratorECC.compute (masked_registration_ecc.py:88-168):
 	 * gaussian pre-filter (sigma > 0), min-max normalisation of the registration window and the alignment against the
 	 * already normalised reference window d_ref_norm [win_h][win_w], queued back to back with one read-back at the end.

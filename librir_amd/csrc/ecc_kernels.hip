@@ -14,6 +14,8 @@
 // Two launches per iteration: workgroups write their partial sums, one workgroup adds them in a fixed order
 // (deterministic), solves the 2x2 system and updates the state in device memory, so iterations queue back to back
 // without a host round trip; the host follows the state through a few words of coherent host memory.
+#include <cstddef>
+
 #include "ecc_kernels.h"
 
 namespace rir
@@ -47,6 +49,21 @@ namespace rir
 		gy[i] = 0.5f * img[yd * w + x] - 0.5f * img[yu * w + x];
 	}
 
+	// the same gradients for a batch of images (blockIdx.y = image): the pre-processing of a sequence runs ahead of its alignments
+	__global__ __launch_bounds__(256) void ecc_gradient_frames_kernel(const float *__restrict__ imgs, int w, int h, float *__restrict__ gxs, float *__restrict__ gys)
+	{
+		const int i = blockIdx.x * 256 + threadIdx.x;
+		if (i >= w * h)
+			return;
+		const size_t base = (size_t)blockIdx.y * w * h;
+		const float *img = imgs + base;
+		const int y = i / w, x = i - y * w;
+		const int xl = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xr = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
+		const int yu = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yd = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
+		gxs[base + i] = 0.5f * img[y * w + xr] - 0.5f * img[y * w + xl];
+		gys[base + i] = 0.5f * img[yd * w + x] - 0.5f * img[yu * w + x];
+	}
+
 	__device__ __forceinline__ float bilinear0(const float *__restrict__ p, int w, int h, int x0, int y0, float fx, float fy)
 	{
 		// zero outside the image (constant border)
@@ -68,21 +85,17 @@ namespace rir
 	// short latency-bound phases on few workgroups: 32 us at 512x640 whatever the grid; split, 11 us.  Round 2 tried again with
 	// write-through rows, a drained ticket and coalesced agent-scope loads in the last workgroup: 152 us per tracked frame against
 	// 140 us for the two launches - the ticket and the last workgroup's round trips cost more than the launch boundary they save.)
-	__global__ __launch_bounds__(ECC_BLOCK) void ecc_sums_kernel(const float *__restrict__ templ, const float *__restrict__ image,
-																 const float *__restrict__ gximg, const float *__restrict__ gyimg,
-																 const uint8_t *__restrict__ mask, int w, int h, double *__restrict__ partials,
-																 const EccState *__restrict__ state)
+	// the 15 sums of workgroup `blk` of `nblk` at translation (tx, ty), reduced over the workgroup (fixed order); valid in threads < ECC_NSUMS
+	__device__ __forceinline__ double ecc_block_sums(const float *__restrict__ templ, const float *__restrict__ image, const float *__restrict__ gximg,
+													 const float *__restrict__ gyimg, const uint8_t *__restrict__ mask, int w, int h, float tx, float ty, int blk,
+													 int nblk, double (*red)[ECC_NSUMS])
 	{
-		if (state->done)
-			return;
-		__shared__ double red[ECC_BLOCK / 64][ECC_NSUMS];
-		const float tx = state->tx, ty = state->ty;
 		double s[ECC_NSUMS];
 #pragma unroll
 		for (int k = 0; k < ECC_NSUMS; ++k)
 			s[k] = 0.0;
 		// grid-stride over the pixels (at most RIR_ECC_MAX_BLOCKS workgroups: one row of partials each)
-		for (int i = blockIdx.x * ECC_BLOCK + threadIdx.x; i < w * h; i += gridDim.x * ECC_BLOCK)
+		for (int i = blk * ECC_BLOCK + threadIdx.x; i < w * h; i += nblk * ECC_BLOCK)
 		{
 			const int y = i / w, x = i - y * w;
 			const float sx = (float)x + tx, sy = (float)y + ty;
@@ -118,13 +131,86 @@ namespace rir
 				red[threadIdx.x >> 6][k] = v;
 		}
 		__syncthreads();
+		double v = 0.0;
 		if (threadIdx.x < ECC_NSUMS)
 		{
-			double v = red[0][threadIdx.x];
+			v = red[0][threadIdx.x];
 			for (int wv = 1; wv < ECC_BLOCK / 64; ++wv)
 				v += red[wv][threadIdx.x];
-			partials[(size_t)blockIdx.x * ECC_NSUMS + threadIdx.x] = v;
 		}
+		return v;
+	}
+
+	__global__ __launch_bounds__(ECC_BLOCK) void ecc_sums_kernel(const float *__restrict__ templ, const float *__restrict__ image,
+																 const float *__restrict__ gximg, const float *__restrict__ gyimg,
+																 const uint8_t *__restrict__ mask, int w, int h, double *__restrict__ partials,
+																 const EccState *__restrict__ state)
+	{
+		if (state->done)
+			return;
+		__shared__ double red[ECC_BLOCK / 64][ECC_NSUMS];
+		const double v = ecc_block_sums(templ, image, gximg, gyimg, mask, w, h, state->tx, state->ty, blockIdx.x, gridDim.x, red);
+		if (threadIdx.x < ECC_NSUMS)
+			partials[(size_t)blockIdx.x * ECC_NSUMS + threadIdx.x] = v;
+	}
+
+	// One update of the alignment from the 15 sums (2x2 normal equations of the forward additive ECC scheme); st: tx, ty, rho,
+	// last_rho and iter are advanced.  Returns done: 0 = go on, 1 = converged or iteration limit, 2 = failed.
+	__device__ __forceinline__ int ecc_solve_step(const double *tot, EccState &st)
+	{
+		const double n = tot[0];
+		int done = 0;
+		double rho = -1.0;
+		if (n < 1.0)
+			done = 2;
+		else
+		{
+			const double mI = tot[1] / n, mT = tot[3] / n;
+			const double imgNorm2 = tot[2] - n * mI * mI, tmpNorm2 = tot[4] - n * mT * mT;
+			const double corr = tot[5] - n * mT * mI;
+			const double h00 = tot[8], h01 = tot[9], h11 = tot[10];
+			const double ip0 = tot[11] - mI * tot[6], ip1 = tot[12] - mI * tot[7];
+			const double tp0 = tot[13] - mT * tot[6], tp1 = tot[14] - mT * tot[7];
+			const double det = h00 * h11 - h01 * h01;
+			rho = corr / (sqrt(imgNorm2) * sqrt(tmpNorm2));
+			if (!(det != 0.0) || isnan(rho))
+				done = 2;
+			else
+			{
+				const double i00 = h11 / det, i01 = -h01 / det, i11 = h00 / det;
+				const double iph0 = i00 * ip0 + i01 * ip1, iph1 = i01 * ip0 + i11 * ip1;
+				const double lambda_n = imgNorm2 - (ip0 * iph0 + ip1 * iph1);
+				const double lambda_d = corr - (tp0 * iph0 + tp1 * iph1);
+				if (lambda_d <= 0.0)
+					done = 2;
+				else
+				{
+					const double lambda = lambda_n / lambda_d;
+					const double e0 = lambda * tp0 - ip0, e1 = lambda * tp1 - ip1;
+					st.tx = (float)((double)st.tx + (i00 * e0 + i01 * e1));
+					st.ty = (float)((double)st.ty + (i01 * e0 + i11 * e1));
+				}
+			}
+		}
+		const double prev = st.rho;
+		st.last_rho = prev;
+		st.rho = rho;
+		st.iter = st.iter + 1;
+		if (!done && (st.iter >= st.max_iter || fabs(rho - prev) < st.eps))
+			done = 1;
+		return done;
+	}
+	// results first, then (release, system scope) the two words the host polls
+	__device__ __forceinline__ void ecc_report(EccHostView *host_view, const EccState &st, int done)
+	{
+		host_view->tx = st.tx;
+		host_view->ty = st.ty;
+		host_view->rho = st.rho;
+		__threadfence_system();
+		// iter and done are one 8-byte word: the host sees both or neither
+		static_assert(offsetof(EccHostView, done) == offsetof(EccHostView, iter) + 4 && offsetof(EccHostView, iter) % 8 == 0, "iter | done << 32");
+		__hip_atomic_store(reinterpret_cast<unsigned long long *>(const_cast<int *>(&host_view->iter)),
+						   (unsigned long long)(unsigned int)st.iter | ((unsigned long long)(unsigned int)done << 32), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 
 	__global__ __launch_bounds__(ECC_SOLVE_BLOCK) void ecc_solve_kernel(const double *__restrict__ partials, int nrows, EccState *__restrict__ state,
@@ -167,57 +253,165 @@ namespace rir
 		__syncthreads();
 		if (threadIdx.x != 0)
 			return;
-		const double n = tot[0];
-		int done = 0;
-		double rho = -1.0;
-		if (n < 1.0)
-			done = 2;
-		else
-		{
-			const double mI = tot[1] / n, mT = tot[3] / n;
-			const double imgNorm2 = tot[2] - n * mI * mI, tmpNorm2 = tot[4] - n * mT * mT;
-			const double corr = tot[5] - n * mT * mI;
-			const double h00 = tot[8], h01 = tot[9], h11 = tot[10];
-			const double ip0 = tot[11] - mI * tot[6], ip1 = tot[12] - mI * tot[7];
-			const double tp0 = tot[13] - mT * tot[6], tp1 = tot[14] - mT * tot[7];
-			const double det = h00 * h11 - h01 * h01;
-			rho = corr / (sqrt(imgNorm2) * sqrt(tmpNorm2));
-			if (!(det != 0.0) || isnan(rho))
-				done = 2;
-			else
-			{
-				const double i00 = h11 / det, i01 = -h01 / det, i11 = h00 / det;
-				const double iph0 = i00 * ip0 + i01 * ip1, iph1 = i01 * ip0 + i11 * ip1;
-				const double lambda_n = imgNorm2 - (ip0 * iph0 + ip1 * iph1);
-				const double lambda_d = corr - (tp0 * iph0 + tp1 * iph1);
-				if (lambda_d <= 0.0)
-					done = 2;
-				else
-				{
-					const double lambda = lambda_n / lambda_d;
-					const double e0 = lambda * tp0 - ip0, e1 = lambda * tp1 - ip1;
-					state->tx = (float)((double)state->tx + (i00 * e0 + i01 * e1));
-					state->ty = (float)((double)state->ty + (i01 * e0 + i11 * e1));
-				}
-			}
-		}
-		const double prev = state->rho;
-		state->last_rho = prev;
-		state->rho = rho;
-		const int it = state->iter + 1;
-		state->iter = it;
-		if (!done && (it >= state->max_iter || fabs(rho - prev) < state->eps))
-			done = 1;
+		EccState stt = *state;
+		const int done = ecc_solve_step(tot, stt);
+		state->tx = stt.tx, state->ty = stt.ty;
+		state->last_rho = stt.last_rho, state->rho = stt.rho;
+		state->iter = stt.iter;
 		__threadfence();
 		state->done = done;
 		if (host_view)
-		{ // results first, then (release, system scope) the two words the host polls
-			host_view->tx = state->tx;
-			host_view->ty = state->ty;
-			host_view->rho = rho;
-			__threadfence_system();
-			__hip_atomic_store(const_cast<int *>(&host_view->done), done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-			__hip_atomic_store(const_cast<int *>(&host_view->iter), it, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			ecc_report(host_view, stt, done);
+	}
+
+	// ---- all iterations of an alignment in ONE launch -----------------------------------------------------------------
+	//
+	// grid = nblk (<= RIR_ECC_MAX_BLOCKS = 256: one workgroup per CU, all resident), block = 256.  Per iteration every workgroup
+	// leaves its row of 15 sums and raises the row's flag; workgroup 0 waits for all flags, adds
+	// the rows in the order ecc_solve_kernel does - the results are the same bits as with two launches per iteration - solves,
+	// and publishes the new translation with a flag the other workgroups wait for.  Two hops across the chip per iteration
+	// instead of two launch boundaries (15 us -> see DESIGN.md).  Flags carry (epoch << 32 | iteration): the host passes a new
+	// epoch with every launch, nothing has to be cleared.  Waits are bounded by a clock; a wait that gives up ends the
+	// alignment as failed (done = 2).
+	// rows:  [nblk][16] doubles, word 15 of a row = its flag;   pub: [0] = tx | ty << 32, [1] = flag, [2] = done
+	__device__ __forceinline__ bool ecc_wait_flag(const unsigned long long *word, unsigned long long want)
+	{
+		const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+		for (;;)
+		{
+			if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want)
+				return true;
+			__builtin_amdgcn_s_sleep(1);
+			if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) // 2 s of the 100 MHz clock
+				return false;
+		}
+	}
+	__global__ __launch_bounds__(ECC_BLOCK) void ecc_run_kernel(const float *__restrict__ templ, const float *__restrict__ image,
+																const float *__restrict__ gximg, const float *__restrict__ gyimg, const uint8_t *__restrict__ mask,
+																int w, int h, double *rows, unsigned long long *pub, EccState *state, EccHostView *host_view, float tx0,
+																float ty0, int max_iter, double eps, unsigned int epoch)
+	{
+		static_assert(ECC_BLOCK >= ECC_SOLVE_BLOCK, "workgroup 0 adds the rows the way ecc_solve_kernel does (waves past its 4 add zeros)");
+		__shared__ double red[ECC_BLOCK / 64][ECC_NSUMS], red_rows[ECC_BLOCK / 64][ECC_NSUMS];
+		__shared__ double tot[ECC_NSUMS];
+		__shared__ float sh_t[2];
+		__shared__ int sh_done;
+		const int b = blockIdx.x, nblk = gridDim.x, tid = threadIdx.x;
+		EccState st; // (workgroup 0, thread 0 keeps the real one)
+		st.tx = tx0, st.ty = ty0;
+		st.rho = -1.0, st.last_rho = -eps;
+		st.iter = 0, st.done = 0, st.ticket = 0;
+		st.max_iter = max_iter, st.eps = eps;
+		float tx = tx0, ty = ty0;
+		int done = 0;
+		for (int it = 1; !done; ++it)
+		{
+			const unsigned long long flag = ((unsigned long long)epoch << 32) | (unsigned long long)(unsigned int)it;
+#ifdef RIR_ECC_DIAG
+			const unsigned long long dg0 = __builtin_amdgcn_s_memrealtime();
+			unsigned long long dg1 = 0, dg2 = 0, dg3 = 0;
+#endif
+			const double v = ecc_block_sums(templ, image, gximg, gyimg, mask, w, h, tx, ty, b, nblk, red);
+			double *row = rows + (size_t)b * 16;
+			// hand-off without fences (a release / acquire pair at agent scope writes back and invalidates whole caches: 227 us per
+			// frame against 139 with two launches per iteration): every byte handed over is stored write-through (sc1), the storing
+			// wave drains its stores, then one lane raises the flag (sc1); the reader polls the flag with sc1 loads and loads the
+			// bytes with sc1 loads after its poll has matched (MI355X_MICROARCH.md, hand-off with a separate flag)
+			if (tid < ECC_NSUMS)
+				__hip_atomic_store(reinterpret_cast<unsigned long long *>(row) + tid, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+								   __HIP_MEMORY_SCOPE_AGENT);
+			if (tid < 64)
+			{ // (the row was written by lanes of this wave)
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				if (tid == 0)
+					__hip_atomic_store(reinterpret_cast<unsigned long long *>(row) + 15, flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+#ifdef RIR_ECC_DIAG
+			dg1 = __builtin_amdgcn_s_memrealtime();
+#endif
+			if (b == 0)
+			{
+				// thread t takes rows t, t + 256, ...; then the butterfly and the waves in order (ecc_solve_kernel)
+				double acc[ECC_NSUMS];
+#pragma unroll
+				for (int k = 0; k < ECC_NSUMS; ++k)
+					acc[k] = 0.0;
+				bool ok = true;
+				for (int r = tid; r < nblk && tid < ECC_SOLVE_BLOCK; r += ECC_SOLVE_BLOCK)
+				{
+					ok = ecc_wait_flag(reinterpret_cast<const unsigned long long *>(rows + (size_t)r * 16) + 15, flag) && ok;
+#pragma unroll
+					for (int k = 0; k < ECC_NSUMS; ++k)
+						acc[k] += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(rows + (size_t)r * 16) + k,
+																					 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+				}
+#ifdef RIR_ECC_DIAG
+				dg2 = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll
+				for (int k = 0; k < ECC_NSUMS; ++k)
+				{
+					double a = acc[k];
+#pragma unroll
+					for (int d = 32; d >= 1; d >>= 1)
+						a += __shfl_xor(a, d, 64);
+					if ((tid & 63) == 0)
+						red_rows[tid >> 6][k] = a;
+				}
+				const int all_ok = __syncthreads_and(ok ? 1 : 0);
+				if (tid < ECC_NSUMS)
+				{
+					double a = red_rows[0][tid];
+					for (int wv = 1; wv < ECC_BLOCK / 64; ++wv)
+						a += red_rows[wv][tid];
+					tot[tid] = a;
+				}
+				__syncthreads();
+				if (tid == 0)
+				{
+					done = all_ok ? ecc_solve_step(tot, st) : 2;
+					sh_t[0] = st.tx, sh_t[1] = st.ty;
+					sh_done = done;
+					__hip_atomic_store(pub, (unsigned long long)__float_as_uint(st.tx) | ((unsigned long long)__float_as_uint(st.ty) << 32), __ATOMIC_RELAXED,
+									   __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store(pub + 2, (unsigned long long)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+					__hip_atomic_store(pub + 1, flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
+			else if (tid == 0)
+			{
+				if (ecc_wait_flag(pub + 1, flag))
+				{
+					const unsigned long long t = __hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					sh_t[0] = __uint_as_float((unsigned int)t), sh_t[1] = __uint_as_float((unsigned int)(t >> 32));
+					sh_done = (int)__hip_atomic_load(pub + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				else
+					sh_done = 2;
+			}
+			__syncthreads();
+			tx = sh_t[0], ty = sh_t[1];
+			done = sh_done;
+#ifdef RIR_ECC_DIAG
+			if (tid == 0 && (b == 0 || b == nblk - 1))
+			{ // ticks (10 ns): sums + publish | wait for the rows | add + solve + publish (workgroup 0) or the whole wait (last workgroup)
+				dg3 = __builtin_amdgcn_s_memrealtime();
+				unsigned long long *dg = pub + 8 + (b == 0 ? 0 : 8);
+				dg[0] += dg1 - dg0, dg[1] += (b == 0 ? dg2 : dg3) - dg1, dg[2] += b == 0 ? dg3 - dg2 : 0, dg[3] += 1;
+			}
+#endif
+			__syncthreads(); // (red / tot / sh_* are reused by the next iteration)
+		}
+		if (b == 0 && tid == 0)
+		{
+			state->tx = st.tx, state->ty = st.ty;
+			state->last_rho = st.last_rho, state->rho = st.rho;
+			state->iter = st.iter;
+			state->max_iter = max_iter, state->eps = eps;
+			state->done = done;
+			if (host_view)
+				ecc_report(host_view, st, done);
 		}
 	}
 
@@ -234,6 +428,22 @@ namespace rir
 		const int nblk = ecc_blocks(w, h);
 		hipLaunchKernelGGL(ecc_sums_kernel, dim3(nblk), dim3(ECC_BLOCK), 0, st, d_templ, d_image, d_gx, d_gy, d_mask, w, h, d_partials, d_state);
 		hipLaunchKernelGGL(ecc_solve_kernel, dim3(1), dim3(ECC_SOLVE_BLOCK), 0, st, d_partials, nblk, d_state, host_view);
+		return hipGetLastError();
+	}
+	size_t ecc_run_workspace_bytes(int w, int h) { return (size_t)ecc_blocks(w, h) * 16 * sizeof(double) + 256; }
+	hipError_t launch_ecc_run(const float *d_templ, const float *d_image, const float *d_gx, const float *d_gy, const uint8_t *d_mask, int w, int h,
+							  double *d_rows, EccState *d_state, EccHostView *host_view, float tx, float ty, int max_iter, double eps, unsigned int epoch,
+							  hipStream_t st)
+	{
+		const int nblk = ecc_blocks(w, h);
+		unsigned long long *pub = reinterpret_cast<unsigned long long *>(d_rows + (size_t)nblk * 16);
+		hipLaunchKernelGGL(ecc_run_kernel, dim3(nblk), dim3(ECC_BLOCK), 0, st, d_templ, d_image, d_gx, d_gy, d_mask, w, h, d_rows, pub, d_state, host_view, tx,
+						   ty, max_iter, eps, epoch);
+		return hipGetLastError();
+	}
+	hipError_t launch_ecc_gradients(const float *d_image, int w, int h, int nframes, float *d_gx, float *d_gy, hipStream_t st)
+	{
+		hipLaunchKernelGGL(ecc_gradient_frames_kernel, dim3((w * h + 255) / 256, nframes), dim3(256), 0, st, d_image, w, h, d_gx, d_gy);
 		return hipGetLastError();
 	}
 } // namespace rir
@@ -289,12 +499,74 @@ namespace rir
 		}
 	}
 
+	// the same two steps for `nframes` images (blockIdx.y = image; images `src_frame` elements apart, outputs dense): exactly the
+	// operations of the single-image kernels, image by image
+	__global__ __launch_bounds__(256) void minmax_partial_frames_kernel(const float *__restrict__ src, int w, int h, int src_stride, int64_t src_frame,
+																		float *__restrict__ part)
+	{
+		src += (size_t)blockIdx.y * src_frame;
+		part += (size_t)blockIdx.y * 2 * gridDim.x;
+		float mn = 3.402823466e38f, mx = -3.402823466e38f;
+		const int n = w * h;
+		for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+		{
+			const int y = i / w, x = i - y * w;
+			const float v = src[(int64_t)y * src_stride + x];
+			mn = fminf(mn, v);
+			mx = fmaxf(mx, v);
+		}
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1)
+		{
+			mn = fminf(mn, __shfl_xor(mn, d, 64));
+			mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+		}
+		__shared__ float smn[4], smx[4];
+		if ((threadIdx.x & 63) == 0)
+			smn[threadIdx.x >> 6] = mn, smx[threadIdx.x >> 6] = mx;
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			part[2 * blockIdx.x] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+			part[2 * blockIdx.x + 1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+		}
+	}
+	__global__ __launch_bounds__(256) void minmax_apply_frames_kernel(const float *__restrict__ src, int w, int h, int src_stride, int64_t src_frame,
+																	  const float *__restrict__ part, int nparts, float *__restrict__ dst)
+	{
+		src += (size_t)blockIdx.y * src_frame;
+		part += (size_t)blockIdx.y * 2 * nparts;
+		dst += (size_t)blockIdx.y * w * h;
+		float mn = part[0], mx = part[1];
+		for (int k = 1; k < nparts; ++k)
+		{
+			mn = fminf(mn, part[2 * k]);
+			mx = fmaxf(mx, part[2 * k + 1]);
+		}
+		const float range = mx - mn;
+		const int n = w * h;
+		for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+		{
+			const int y = i / w, x = i - y * w;
+			dst[i] = (src[(int64_t)y * src_stride + x] - mn) / range;
+		}
+	}
+
 	hipError_t launch_minmax_normalize(const float *d_src, int w, int h, int src_stride, float *d_dst, float *d_part /* >= 2*64 floats */, hipStream_t st)
 	{
 		const int nparts = 64;
 		hipLaunchKernelGGL(minmax_partial_kernel, dim3(nparts), dim3(256), 0, st, d_src, w, h, src_stride, d_part);
 		hipLaunchKernelGGL(minmax_apply_kernel, dim3((w * h + 255) / 256 < 1024 ? (w * h + 255) / 256 : 1024), dim3(256), 0, st, d_src, w, h, src_stride,
 						   d_part, nparts, d_dst);
+		return hipGetLastError();
+	}
+	hipError_t launch_minmax_normalize_frames(const float *d_src, int w, int h, int src_stride, int64_t src_frame, int nframes, float *d_dst,
+											  float *d_part /* >= nframes*2*64 floats */, hipStream_t st)
+	{
+		const int nparts = 64;
+		hipLaunchKernelGGL(minmax_partial_frames_kernel, dim3(nparts, nframes), dim3(256), 0, st, d_src, w, h, src_stride, src_frame, d_part);
+		hipLaunchKernelGGL(minmax_apply_frames_kernel, dim3((w * h + 255) / 256 < 1024 ? (w * h + 255) / 256 : 1024, nframes), dim3(256), 0, st, d_src, w, h,
+						   src_stride, src_frame, d_part, nparts, d_dst);
 		return hipGetLastError();
 	}
 } // namespace rir

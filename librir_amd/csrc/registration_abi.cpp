@@ -6,6 +6,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 
 #include "ecc_kernels.h"
@@ -20,7 +21,7 @@ namespace
 	struct EccScratch
 	{
 		std::mutex mu;
-		DeviceBuffer gx, gy, partials, state, templ, image, mask, mm, full;
+		DeviceBuffer gx, gy, partials, state, templ, image, mask, mm, full, mm_frames, full_frames;
 		EccHostView *view = nullptr; // coherent page-locked host memory (64 bytes, kept for the life of the process), written by
 									  // ecc_solve_kernel, polled by run_ecc
 		// run_ecc returns as soon as the host view says "done", with the rest of its batch (no-op launches that still READ the
@@ -28,6 +29,7 @@ namespace
 		// before it resets the state
 		hipEvent_t tail = nullptr;
 		bool tail_recorded = false;
+		unsigned int epoch = 0; // launches of ecc_run_kernel on this workspace
 	};
 	EccScratch &scratch()
 	{
@@ -60,18 +62,34 @@ namespace
 #ifndef RIR_ECC_FIRST_BATCH
 #define RIR_ECC_FIRST_BATCH 6 /* alignments of a tracked sequence settle within 4-6 iterations: one read-back of the state instead of two */
 #endif
-	// runs the iterations; the caller holds the scratch mutex
-	int run_ecc(EccScratch &sc, const float *d_templ, const float *d_image, const uint8_t *d_mask, int w, int h, float *warp, int max_iter,
-				double eps, double *cc, int *iterations, hipStream_t st)
+	// waits (polling the coherent view) until the alignment in flight reports done or `launched` iterations
+	bool wait_view(EccHostView *view, int launched, hipStream_t st)
 	{
-		const size_t npx = (size_t)w * h;
-		if (!sc.gx.reserve(npx * 4) || !sc.gy.reserve(npx * 4) || !sc.partials.reserve(ecc_workspace_bytes(w, h)) ||
-			!sc.state.reserve(sizeof(EccState)))
+		const auto t0 = std::chrono::steady_clock::now();
+		long spins = 0;
+		while (view->done == 0 && view->iter < launched)
+		{
+			if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
+			{ // (a device fault would leave the words unwritten)
+				log_error("ECC: the device did not report back");
+				(void)hipStreamSynchronize(st);
+				return false;
+			}
+			__builtin_ia32_pause();
+		}
+		std::atomic_thread_fence(std::memory_order_acquire);
+		return true;
+	}
+
+	// The iterations of one alignment of d_image (its gradients d_gx, d_gy already computed) against d_templ; the caller holds the
+	// scratch mutex.  One launch does them all (ecc_run_kernel); RIR_ECC_LAUNCH_PER_ITERATION=1 queues two launches per iteration
+	// in batches instead (the round-1 form, kept for comparison: same sums in the same order, same results).
+	int run_iterations(EccScratch &sc, const float *d_templ, const float *d_image, const float *d_gx, const float *d_gy, const uint8_t *d_mask, int w, int h,
+					   float *warp, int max_iter, double eps, double *cc, int *iterations, bool state_is_reset, hipStream_t st)
+	{
+		if (!sc.partials.reserve(std::max(ecc_workspace_bytes(w, h), ecc_run_workspace_bytes(w, h))) || !sc.state.reserve(sizeof(EccState)))
 			return -1;
 		EccState *d_state = sc.state.as<EccState>();
-		if (!hip_ok(launch_ecc_prepare(d_image, w, h, sc.gx.as<float>(), sc.gy.as<float>(), d_state, warp[0], warp[1], max_iter, eps, st),
-					"ecc prepare"))
-			return -1;
 		if (!sc.view && !hip_ok(hipHostMalloc(reinterpret_cast<void **>(&sc.view), sizeof(EccHostView), hipHostMallocCoherent | hipHostMallocMapped),
 								"hipHostMalloc"))
 			return -1;
@@ -80,36 +98,53 @@ namespace
 		EccHostView *d_view = nullptr;
 		if (!hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&d_view), view, 0), "hipHostGetDevicePointer"))
 			return -1;
-		// iterations are queued in batches (a finished alignment turns the remaining launches into no-ops); the host
-		// polls the view until the alignment is done or the batch is through
 		EccState hs;
 		std::memset(&hs, 0, sizeof(hs));
-		int launched = 0;
-		while (true)
+		static const bool per_iteration = getenv("RIR_ECC_LAUNCH_PER_ITERATION") != nullptr;
+		if (!per_iteration)
 		{
-			const int batch = std::min(launched == 0 ? RIR_ECC_FIRST_BATCH : 8, max_iter - launched);
-			for (int i = 0; i < batch; ++i)
-				if (!hip_ok(launch_ecc_iterate(d_templ, d_image, sc.gx.as<float>(), sc.gy.as<float>(), d_mask, w, h, sc.partials.as<double>(),
-											   d_state, d_view, st),
-							"ecc iterate"))
-					return -1;
-			launched += batch;
-			const auto t0 = std::chrono::steady_clock::now();
-			long spins = 0;
-			while (view->done == 0 && view->iter < launched)
-			{
-				if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
-				{ // (a device fault would leave the words unwritten)
-					log_error("ECC: the device did not report back");
-					(void)hipStreamSynchronize(st);
-					return -1;
-				}
-				__builtin_ia32_pause();
-			}
-			std::atomic_thread_fence(std::memory_order_acquire);
+			if (!hip_ok(launch_ecc_run(d_templ, d_image, d_gx, d_gy, d_mask, w, h, sc.partials.as<double>(), d_state, d_view, warp[0], warp[1], max_iter, eps,
+									   ++sc.epoch, st),
+						"ecc run") ||
+				!wait_view(view, max_iter + 1, st))
+				return -1;
 			hs.done = view->done, hs.iter = view->iter, hs.tx = view->tx, hs.ty = view->ty, hs.rho = view->rho;
-			if (hs.done || launched >= max_iter)
-				break;
+			static const bool diag = getenv("RIR_ECC_DIAG") != nullptr; // (-DRIR_ECC_DIAG builds: where an iteration's time goes)
+			if (diag && (sc.epoch % 64) == 0)
+			{
+				unsigned long long dg[16];
+				const size_t off = ecc_run_workspace_bytes(w, h) - 256 + 64;
+				if (hipMemcpy(dg, sc.partials.as<char>() + off, sizeof(dg), hipMemcpyDeviceToHost) == hipSuccess && dg[3])
+					std::fprintf(stderr, "ecc run, per iteration (us): workgroup 0: sums+publish %.2f  wait rows %.2f  add+solve+publish %.2f | last workgroup: sums+publish %.2f  wait %.2f  (%.1f iterations per frame)\n",
+								 dg[0] * 0.01 / dg[3], dg[1] * 0.01 / dg[3], dg[2] * 0.01 / dg[3], dg[8] * 0.01 / dg[11], dg[9] * 0.01 / dg[11], (double)dg[3] / sc.epoch);
+			}
+		}
+		else
+		{
+			if (!state_is_reset)
+			{
+				EccState init;
+				std::memset(&init, 0, sizeof(init));
+				init.tx = warp[0], init.ty = warp[1], init.rho = -1.0, init.last_rho = -eps, init.max_iter = max_iter, init.eps = eps;
+				if (!hip_ok(hipMemcpyAsync(d_state, &init, sizeof(init), hipMemcpyHostToDevice, st), "H2D") || !hip_ok(hipStreamSynchronize(st), "sync"))
+					return -1;
+			}
+			// iterations are queued in batches (a finished alignment turns the remaining launches into no-ops); the host
+			// polls the view until the alignment is done or the batch is through
+			int launched = 0;
+			while (true)
+			{
+				const int batch = std::min(launched == 0 ? RIR_ECC_FIRST_BATCH : 8, max_iter - launched);
+				for (int i = 0; i < batch; ++i)
+					if (!hip_ok(launch_ecc_iterate(d_templ, d_image, d_gx, d_gy, d_mask, w, h, sc.partials.as<double>(), d_state, d_view, st), "ecc iterate"))
+						return -1;
+				launched += batch;
+				if (!wait_view(view, launched, st))
+					return -1;
+				hs.done = view->done, hs.iter = view->iter, hs.tx = view->tx, hs.ty = view->ty, hs.rho = view->rho;
+				if (hs.done || launched >= max_iter)
+					break;
+			}
 		}
 		if (iterations)
 			*iterations = hs.iter;
@@ -122,6 +157,19 @@ namespace
 		if (cc)
 			*cc = hs.rho;
 		return 0;
+	}
+
+	// gradients of the image, then the iterations; the caller holds the scratch mutex
+	int run_ecc(EccScratch &sc, const float *d_templ, const float *d_image, const uint8_t *d_mask, int w, int h, float *warp, int max_iter,
+				double eps, double *cc, int *iterations, hipStream_t st)
+	{
+		const size_t npx = (size_t)w * h;
+		if (!sc.gx.reserve(npx * 4) || !sc.gy.reserve(npx * 4) || !sc.state.reserve(sizeof(EccState)))
+			return -1;
+		if (!hip_ok(launch_ecc_prepare(d_image, w, h, sc.gx.as<float>(), sc.gy.as<float>(), sc.state.as<EccState>(), warp[0], warp[1], max_iter, eps, st),
+					"ecc prepare"))
+			return -1;
+		return run_iterations(sc, d_templ, d_image, sc.gx.as<float>(), sc.gy.as<float>(), d_mask, w, h, warp, max_iter, eps, cc, iterations, true, st);
 	}
 } // namespace
 
@@ -190,6 +238,76 @@ RIR_EXPORT int rir_ecc_register_frame_device(const void *d_img, int dtype, int w
 	if (!hip_ok(launch_minmax_normalize(g + (size_t)win_y * w + win_x, win_w, win_h, w, sc.image.as<float>(), sc.mm.as<float>(), st), "minmax_normalize"))
 		return -1;
 	return run_ecc(sc, d_ref_norm, sc.image.as<float>(), nullptr, win_w, win_h, warp, max_iterations, eps, cc, iterations, st);
+}
+
+// The pre-processing of `nframes` frames of a tracked sequence in shared launches, ahead of their alignments (which are
+// sequential: each starts from the previous result): gaussian pre-filter (sigma > 0), crop to the registration window, min-max
+// normalisation, gradients - image by image the operations of rir_ecc_register_frame_device.  d_imgs: uint16 ('H') or float32
+// ('f') [nframes][h][w]; d_norm, d_gx, d_gy: float [nframes][win_h][win_w] (device).
+RIR_EXPORT int rir_ecc_prepare_frames_device(const void *d_imgs, int dtype, int w, int h, int nframes, float sigma, int win_x, int win_y, int win_w,
+											 int win_h, float *d_norm, float *d_gx, float *d_gy, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (!d_imgs || (dtype != 'H' && dtype != 'f') || !d_norm || !d_gx || !d_gy || w < 2 || h < 2 || nframes <= 0 || win_x < 0 || win_y < 0 || win_w < 2 ||
+		win_h < 2 || win_x + win_w > w || win_y + win_h > h)
+	{
+		log_error("rir_ecc_prepare_frames_device: invalid argument");
+		return -1;
+	}
+	hipStream_t st = (hipStream_t)stream;
+	EccScratch &sc = scratch();
+	std::lock_guard<std::mutex> lock(sc.mu);
+	ScratchOrder order(sc, st);
+	if (!order.ok)
+		return -1;
+	const size_t npx = (size_t)w * h;
+	if (!sc.mm_frames.reserve((size_t)nframes * 2 * 64 * sizeof(float)))
+		return -1;
+	const float *g = nullptr;
+	if (sigma > 0 || dtype == 'H')
+	{
+		if (!sc.full_frames.reserve(npx * nframes * 4))
+			return -1;
+		float *full = sc.full_frames.as<float>();
+		if (sigma > 0)
+		{
+			const int r = dtype == 'H' ? rir_gaussian_filter_u16_device(static_cast<const unsigned short *>(d_imgs), full, w, h, nframes, sigma, stream)
+									   : rir_gaussian_filter_device(static_cast<const float *>(d_imgs), full, w, h, nframes, sigma, stream);
+			if (r != 0)
+				return -1;
+		}
+		else if (!hip_ok(launch_u16_to_f32(static_cast<const uint16_t *>(d_imgs), full, (int64_t)npx * nframes, st), "u16_to_f32"))
+			return -1;
+		g = full;
+	}
+	else
+		g = static_cast<const float *>(d_imgs);
+	if (!hip_ok(launch_minmax_normalize_frames(g + (size_t)win_y * w + win_x, win_w, win_h, w, (int64_t)npx, nframes, d_norm, sc.mm_frames.as<float>(), st),
+				"minmax_normalize") ||
+		!hip_ok(launch_ecc_gradients(d_norm, win_w, win_h, nframes, d_gx, d_gy, st), "ecc gradients"))
+		return -1;
+	return 0;
+}
+
+// The alignment of ONE prepared image (d_norm and its gradients, [h][w] each: one frame of rir_ecc_prepare_frames_device's output)
+// against the reference window d_ref_norm.  warp: HOST float[2] (tx, ty), start value in, result out.
+RIR_EXPORT int rir_ecc_align_prepared_device(const float *d_ref_norm, const float *d_norm, const float *d_gx, const float *d_gy, int w, int h, float *warp,
+											 int max_iterations, double eps, double *cc, int *iterations, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (!d_ref_norm || !d_norm || !d_gx || !d_gy || !warp || w < 2 || h < 2 || max_iterations <= 0 || !(eps >= 0))
+	{
+		log_error("rir_ecc_align_prepared_device: invalid argument");
+		return -1;
+	}
+	EccScratch &sc = scratch();
+	std::lock_guard<std::mutex> lock(sc.mu);
+	ScratchOrder order(sc, (hipStream_t)stream);
+	if (!order.ok)
+		return -1;
+	return run_iterations(sc, d_ref_norm, d_norm, d_gx, d_gy, nullptr, w, h, warp, max_iterations, eps, cc, iterations, false, (hipStream_t)stream);
 }
 
 // Host-pointer form, the drop-in for cv2.findTransformECC(templ, image, warp, MOTION_TRANSLATION, criteria, mask, 1):

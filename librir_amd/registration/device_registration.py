@@ -24,6 +24,12 @@ _lib.rir_ecc_register_frame_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int
                                                ct.c_int, ct.c_double, ct.POINTER(ct.c_double), ct.POINTER(ct.c_int), _vp]
 
 
+_lib.rir_ecc_prepare_frames_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_float, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp,
+                                               _vp]
+_lib.rir_ecc_align_prepared_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_int, ct.c_int, _vp, ct.c_int, ct.c_double, ct.POINTER(ct.c_double),
+                                               ct.POINTER(ct.c_int), _vp]
+
+
 def _stream():
     return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -77,14 +83,18 @@ class DeviceRegistratorECC:
                                               self.warp.ctypes.data, self.number_of_iterations, self.termination_eps, ct.byref(cc), None,
                                               _stream()) != 0:
             raise RuntimeError("ECC: %s" % last_error())
+        return self._after_alignment(img, cc.value)
+
+    def _after_alignment(self, img, cc):
+        """book-keeping of compute(): records the shift; changes the reference image on a confidence drop"""
         shift = [float(self.warp[1]), float(self.warp[0])]
-        self.confidences.append(cc.value)
+        self.confidences.append(cc)
         self.x.append(shift[1])
         self.y.append(shift[0])
         if len(self.confidences) > 20:
             if self.conf_thresh is None:
                 self.conf_thresh = np.min(self.confidences) - 2 * np.std(self.confidences)
-            if cc.value < self.conf_thresh:  # change of reference image: the current window, shifted back
+            if cc < self.conf_thresh:  # change of reference image: the current window, shifted back
                 g = self._filtered(img)
                 win = g[self.startY:self.startY + self.subH, self.startX:self.startX + self.subW].contiguous()
                 moved = D.translate(win, (-shift[1], -shift[0]), "")[0]
@@ -94,6 +104,34 @@ class DeviceRegistratorECC:
                 self._ref_n = out
                 self.warp[:] = 0
         return shift
+
+    def compute_many(self, frames, chunk=64):
+        """``compute`` for every frame of a (n, h, w) device tensor, in order, with the same results: the pre-processing of a
+        chunk of frames (pre-filter, window normalisation, gradients) runs in shared launches ahead of the alignments, which
+        stay sequential - each starts from the previous shift.  Returns the list of shifts."""
+        if frames.dim() == 2:
+            frames = frames[None]
+        if frames.dtype != torch.float32 and frames.dtype != torch.uint16:
+            frames = frames.to(torch.float32)
+        frames = frames.contiguous()
+        n, h, w = frames.shape
+        dt = ord("H") if frames.dtype == torch.uint16 else ord("f")
+        shifts = []
+        m = min(chunk, n)
+        norm = torch.empty((3, m, self.subH, self.subW), dtype=torch.float32, device=frames.device)
+        for c0 in range(0, n, chunk):
+            k = min(chunk, n - c0)
+            if _lib.rir_ecc_prepare_frames_device(frames[c0].data_ptr(), dt, w, h, k, float(self.sigma), self.startX, self.startY, self.subW, self.subH,
+                                                  norm[0].data_ptr(), norm[1].data_ptr(), norm[2].data_ptr(), _stream()) != 0:
+                raise RuntimeError("rir_ecc_prepare_frames_device: %s" % last_error())
+            cc = ct.c_double(0)
+            for i in range(k):
+                if _lib.rir_ecc_align_prepared_device(self._ref_n.data_ptr(), norm[0, i].data_ptr(), norm[1, i].data_ptr(), norm[2, i].data_ptr(), self.subW,
+                                                      self.subH, self.warp.ctypes.data, self.number_of_iterations, self.termination_eps, ct.byref(cc), None,
+                                                      _stream()) != 0:
+                    raise RuntimeError("ECC: %s" % last_error())
+                shifts.append(self._after_alignment(frames[c0 + i], cc.value))
+        return shifts
 
     def return_coordinates_and_confidence_values(self):
         return np.array([self.x, self.y, self.confidences]).T

@@ -126,3 +126,68 @@ def test_change_of_reference_image_on_a_confidence_drop():
     assert np.allclose(dev.x, host.x, rtol=0, atol=1e-4) and np.allclose(dev.y, host.y, rtol=0, atol=1e-4)
     # (upstream restarts from the identity after the change: with ~30 px of accumulated motion the track does not
     #  recover on this recipe - behaviour mirrored, not judged)
+
+
+@pytest.mark.parametrize("dtype", ["float32", "uint16"])
+def test_compute_many_equals_compute_frame_by_frame(dtype):
+    """DeviceRegistratorECC.compute_many: the pre-processing of a chunk of frames runs ahead in shared launches
+    (rir_ecc_prepare_frames_device), the alignments stay sequential (rir_ecc_align_prepared_device) - the same operations image
+    by image, so the same track to the last bit, through a change of the reference image and across chunk boundaries."""
+    import torch
+
+    from librir_amd.registration import DeviceRegistratorECC
+
+    n = 45
+    f, s = s3_registration(n, 256, 320)
+    f = f.copy()
+    f[30] += np.random.default_rng(8).normal(0, 4, f[30].shape).astype(np.float32)  # a confidence drop: the reference changes
+    t = torch.from_numpy(f if dtype == "float32" else np.clip(f, 0, 65535).astype(np.uint16)).cuda()
+    one = DeviceRegistratorECC(0.8, 0.8, shape=(256, 320))
+    one.start(t[0])
+    for i in range(1, n):
+        one.compute(t[i])
+    many = DeviceRegistratorECC(0.8, 0.8, shape=(256, 320))
+    many.start(t[0])
+    shifts = many.compute_many(t[1:], chunk=16)
+    assert len(shifts) == n - 1
+    assert many.x == one.x and many.y == one.y and many.confidences == one.confidences
+    if dtype == "float32":
+        assert one.conf_thresh is not None and min(one.confidences[21:]) < one.conf_thresh  # the reference did change
+
+
+def test_one_launch_per_alignment_equals_two_launches_per_iteration():
+    """ecc_run_kernel (all iterations of an alignment in one launch, the rows of sums handed between workgroups inside it) adds
+    the same rows in the same order as ecc_sums_kernel + ecc_solve_kernel: same translation, correlation and iteration count."""
+    import ctypes as ct
+    import subprocess
+    import sys
+
+    code = r'''
+import ctypes as ct, json, sys
+import numpy as np, torch
+from librir_amd.registration.device_registration import _lib, _stream
+from librir_amd.synthetic import s3_registration
+f, s = s3_registration(6, 256, 320)
+norm = lambda a: ((a - a.min()) / (a.max() - a.min())).astype(np.float32)
+ref = torch.from_numpy(norm(f[0])).cuda()
+out = []
+for i in range(1, 6):
+    im = torch.from_numpy(norm(f[i])).cuda()
+    warp = np.zeros(2, np.float32); cc = ct.c_double(0); it = ct.c_int(0)
+    assert _lib.rir_ecc_translation_device(ref.data_ptr(), im.data_ptr(), None, 320, 256, warp.ctypes.data, 200, 1e-6, ct.byref(cc), ct.byref(it), _stream()) == 0
+    out.append([float(warp[0]).hex(), float(warp[1]).hex(), cc.value.hex(), it.value])
+print(json.dumps(out))
+'''
+    import json
+    import os
+
+    res = []
+    for env in ({}, {"RIR_ECC_LAUNCH_PER_ITERATION": "1"}):
+        e = dict(os.environ, **env)
+        e.pop("RIR_ECC_LAUNCH_PER_ITERATION", None) if not env else None
+        p = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        assert p.returncode == 0, p.stderr[-2000:]
+        res.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert res[0] == res[1]
+    assert all(r[3] > 2 for r in res[0])
