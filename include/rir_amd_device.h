@@ -186,6 +186,12 @@ extern "C"
 	 * reference window.  warp: HOST float[2] (tx, ty) in/out. */
 	int rir_ecc_align_prepared_device(const float *d_ref_norm, const float *d_norm, const float *d_gx, const float *d_gy, int w, int h, float *warp,
 									  int max_iterations, double eps, double *cc, int *iterations, void *stream);
+	/* The alignments of `nframes` consecutive prepared images in one launch, image i starting from the result of image i - 1 (the
+	 * loop of MaskedRegistratorECC.compute calls, masked_registration_ecc.py:102-123).  results: HOST [nframes][4] doubles = (tx, ty,
+	 * correlation coefficient, iterations).  Returns how many images were aligned before the first failure (nframes: all), -1 on
+	 * an invalid call.  warp: HOST float[2], start value in, last good result out. */
+	int rir_ecc_align_prepared_frames_device(const float *d_ref_norm, const float *d_norm, const float *d_gx, const float *d_gy, int w, int h, int nframes,
+											 float *warp, int max_iterations, double eps, double *results, void *stream);
 	/* One frame of a tracked sequence in one call - the steps of MaskedRegistratorECC.compute (masked_registration_ecc.py:88-168):
 	 * gaussian pre-filter (sigma > 0), min-max normalisation of the registration window and the alignment against the
 	 * already normalised reference window d_ref_norm [win_h][win_w], queued back to back with one read-back at the end.

@@ -45,11 +45,20 @@ namespace rir
 	// host_view: device-visible address of an EccHostView, or NULL
 	hipError_t launch_ecc_iterate(const float *d_templ, const float *d_image, const float *d_gx, const float *d_gy, const uint8_t *d_mask, int w,
 								  int h, double *d_partials, EccState *d_state, EccHostView *host_view, hipStream_t st);
-	// all iterations in one launch (ecc_run_kernel); d_rows: ecc_run_workspace_bytes(); epoch: a number no earlier launch on this workspace used
+	// all iterations of the alignments of `nframes` consecutive images [nframes][h][w] (gradients likewise) in one launch
+	// (ecc_run_kernel), each starting from the previous result; d_results: NULL or [nframes]; d_rows: ecc_run_workspace_bytes(); epoch: a number no earlier launch on this workspace used
+	// what a sequence launch leaves per image
+	struct EccFrameResult
+	{
+		float tx, ty;
+		double rho;
+		int iter, done;
+	};
 	size_t ecc_run_workspace_bytes(int w, int h);
 	hipError_t launch_ecc_run(const float *d_templ, const float *d_image, const float *d_gx, const float *d_gy, const uint8_t *d_mask, int w, int h,
 							  double *d_rows, EccState *d_state, EccHostView *host_view, float tx, float ty, int max_iter, double eps, unsigned int epoch,
-							  hipStream_t st);
+							  int nframes, EccFrameResult *d_results, hipStream_t st);
+	constexpr int kEccMaxSequence = 4096, kEccMaxIterations = (1 << 20) - 1; // (the flag's fields)
 	// gradients of `nframes` dense images [nframes][h][w]
 	hipError_t launch_ecc_gradients(const float *d_image, int w, int h, int nframes, float *d_gx, float *d_gy, hipStream_t st);
 	hipError_t launch_minmax_normalize(const float *d_src, int w, int h, int src_stride, float *d_dst, float *d_part, hipStream_t st);

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "ecc_kernels.h"
 #include "filter_kernels.h"
@@ -30,6 +31,7 @@ namespace
 		hipEvent_t tail = nullptr;
 		bool tail_recorded = false;
 		unsigned int epoch = 0; // launches of ecc_run_kernel on this workspace
+		EccFrameResult *results_host = nullptr; // coherent page-locked host memory, kEccMaxSequence entries, kept for the life of the process
 	};
 	EccScratch &scratch()
 	{
@@ -104,7 +106,7 @@ namespace
 		if (!per_iteration)
 		{
 			if (!hip_ok(launch_ecc_run(d_templ, d_image, d_gx, d_gy, d_mask, w, h, sc.partials.as<double>(), d_state, d_view, warp[0], warp[1], max_iter, eps,
-									   ++sc.epoch, st),
+									   ++sc.epoch, 1, nullptr, st),
 						"ecc run") ||
 				!wait_view(view, max_iter + 1, st))
 				return -1;
@@ -115,8 +117,9 @@ namespace
 				unsigned long long dg[16];
 				const size_t off = ecc_run_workspace_bytes(w, h) - 256 + 64;
 				if (hipMemcpy(dg, sc.partials.as<char>() + off, sizeof(dg), hipMemcpyDeviceToHost) == hipSuccess && dg[3])
-					std::fprintf(stderr, "ecc run, per iteration (us): workgroup 0: sums+publish %.2f  wait rows %.2f  add+solve+publish %.2f | last workgroup: sums+publish %.2f  wait %.2f  (%.1f iterations per frame)\n",
-								 dg[0] * 0.01 / dg[3], dg[1] * 0.01 / dg[3], dg[2] * 0.01 / dg[3], dg[8] * 0.01 / dg[11], dg[9] * 0.01 / dg[11], (double)dg[3] / sc.epoch);
+					std::fprintf(stderr, "ecc run, per iteration (us): workgroup 0: sums+publish %.2f  wait rows %.2f  add+solve+publish %.2f | last workgroup: sums+publish %.2f  wait %.2f  (%.1f iterations per frame) | workgroup 0: pixel loop %.2f  block reduce %.2f\n",
+								 dg[0] * 0.01 / dg[3], dg[1] * 0.01 / dg[3], dg[2] * 0.01 / dg[3], dg[8] * 0.01 / dg[11], dg[9] * 0.01 / dg[11], (double)dg[3] / sc.epoch,
+								 dg[4] * 0.01 / dg[3], dg[5] * 0.01 / dg[3]);
 			}
 		}
 		else
@@ -308,6 +311,65 @@ RIR_EXPORT int rir_ecc_align_prepared_device(const float *d_ref_norm, const floa
 	if (!order.ok)
 		return -1;
 	return run_iterations(sc, d_ref_norm, d_norm, d_gx, d_gy, nullptr, w, h, warp, max_iterations, eps, cc, iterations, false, (hipStream_t)stream);
+}
+
+// The alignments of `nframes` consecutive prepared images (rir_ecc_prepare_frames_device's output) in ONE launch, image i starting
+// from the result of image i - 1 (image 0 from warp), as MaskedRegistratorECC.compute does frame after frame.  results: HOST
+// [nframes][4] doubles = (tx, ty, correlation coefficient, iterations) per image.  Returns the number of images aligned: nframes,
+// or the index of the first one whose alignment failed (where the per-image entry point returns -1; its row and the later ones
+// are not filled), or -1 on an error of the call itself.  warp: HOST float[2], start value in, last good result out.
+RIR_EXPORT int rir_ecc_align_prepared_frames_device(const float *d_ref_norm, const float *d_norm, const float *d_gx, const float *d_gy, int w, int h,
+													int nframes, float *warp, int max_iterations, double eps, double *results, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (!d_ref_norm || !d_norm || !d_gx || !d_gy || !warp || !results || w < 2 || h < 2 || nframes <= 0 || nframes > kEccMaxSequence || max_iterations <= 0 ||
+		max_iterations > kEccMaxIterations || !(eps >= 0))
+	{
+		log_error("rir_ecc_align_prepared_frames_device: invalid argument");
+		return -1;
+	}
+	hipStream_t st = (hipStream_t)stream;
+	EccScratch &sc = scratch();
+	std::lock_guard<std::mutex> lock(sc.mu);
+	ScratchOrder order(sc, st);
+	if (!order.ok)
+		return -1;
+	if (!sc.partials.reserve(std::max(ecc_workspace_bytes(w, h), ecc_run_workspace_bytes(w, h))) || !sc.state.reserve(sizeof(EccState)))
+		return -1;
+	// the host view and the per-image results live in one block of coherent page-locked host memory the kernel writes directly (a
+	// copy of the results and the stream synchronisation behind it cost more than a chunk's book-keeping)
+	if (!sc.view && !hip_ok(hipHostMalloc(reinterpret_cast<void **>(&sc.view), sizeof(EccHostView), hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc"))
+		return -1;
+	if (!sc.results_host &&
+		!hip_ok(hipHostMalloc(reinterpret_cast<void **>(&sc.results_host), (size_t)kEccMaxSequence * sizeof(EccFrameResult), hipHostMallocCoherent | hipHostMallocMapped),
+				"hipHostMalloc"))
+		return -1;
+	EccHostView *view = sc.view;
+	view->iter = 0, view->done = 0;
+	EccHostView *d_view = nullptr;
+	EccFrameResult *d_results = nullptr;
+	if (!hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&d_view), view, 0), "hipHostGetDevicePointer") ||
+		!hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&d_results), sc.results_host, 0), "hipHostGetDevicePointer"))
+		return -1;
+	if (!hip_ok(launch_ecc_run(d_ref_norm, d_norm, d_gx, d_gy, nullptr, w, h, sc.partials.as<double>(), sc.state.as<EccState>(), d_view, warp[0], warp[1],
+							   max_iterations, eps, ++sc.epoch, nframes, d_results, st),
+				"ecc run") ||
+		!wait_view(view, nframes + 1, st))
+		return -1;
+	const int frames_done = view->iter; // images gone through (the last of them may have failed)
+	const EccFrameResult *r = sc.results_host; // (written before the view's release store, read after its acquire)
+	int good = 0;
+	for (; good < frames_done; ++good)
+	{
+		if (r[good].done == 2 || std::isnan(r[good].rho))
+			break;
+		results[4 * good] = r[good].tx, results[4 * good + 1] = r[good].ty, results[4 * good + 2] = r[good].rho, results[4 * good + 3] = r[good].iter;
+		warp[0] = r[good].tx, warp[1] = r[good].ty;
+	}
+	if (good < nframes)
+		log_error("ECC: the alignment did not converge (empty overlap, singular system or non-positive lambda)");
+	return good;
 }
 
 // Host-pointer form, the drop-in for cv2.findTransformECC(templ, image, warp, MOTION_TRANSLATION, criteria, mask, 1):

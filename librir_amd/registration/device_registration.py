@@ -30,6 +30,9 @@ _lib.rir_ecc_align_prepared_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_int, ct.
                                                ct.POINTER(ct.c_int), _vp]
 
 
+_lib.rir_ecc_align_prepared_frames_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp, ct.c_int, ct.c_double, _vp, _vp]
+
+
 def _stream():
     return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -85,8 +88,8 @@ class DeviceRegistratorECC:
             raise RuntimeError("ECC: %s" % last_error())
         return self._after_alignment(img, cc.value)
 
-    def _after_alignment(self, img, cc):
-        """book-keeping of compute(): records the shift; changes the reference image on a confidence drop"""
+    def _after_alignment(self, img, cc, frames=None, index=0):
+        """book-keeping of compute(): records the shift; changes the reference image on a confidence drop (img, or frames[index])"""
         shift = [float(self.warp[1]), float(self.warp[0])]
         self.confidences.append(cc)
         self.x.append(shift[1])
@@ -95,7 +98,7 @@ class DeviceRegistratorECC:
             if self.conf_thresh is None:
                 self.conf_thresh = np.min(self.confidences) - 2 * np.std(self.confidences)
             if cc < self.conf_thresh:  # change of reference image: the current window, shifted back
-                g = self._filtered(img)
+                g = self._filtered(img if img is not None else frames[index])
                 win = g[self.startY:self.startY + self.subH, self.startX:self.startX + self.subW].contiguous()
                 moved = D.translate(win, (-shift[1], -shift[0]), "")[0]
                 out = torch.empty_like(moved)
@@ -105,10 +108,11 @@ class DeviceRegistratorECC:
                 self.warp[:] = 0
         return shift
 
-    def compute_many(self, frames, chunk=64):
-        """``compute`` for every frame of a (n, h, w) device tensor, in order, with the same results: the pre-processing of a
-        chunk of frames (pre-filter, window normalisation, gradients) runs in shared launches ahead of the alignments, which
-        stay sequential - each starts from the previous shift.  Returns the list of shifts."""
+    def compute_many(self, frames, chunk=32):
+        """``compute`` for every frame of a (n, h, w) device tensor, in order, with the same results.  The pre-processing of a
+        chunk of frames (pre-filter, window normalisation, gradients) runs in shared launches, the alignments of the chunk in one
+        launch, each from the previous shift; while the host does the book-keeping of a chunk the device prepares the next one.
+        Returns the list of shifts."""
         if frames.dim() == 2:
             frames = frames[None]
         if frames.dtype != torch.float32 and frames.dtype != torch.uint16:
@@ -118,19 +122,48 @@ class DeviceRegistratorECC:
         dt = ord("H") if frames.dtype == torch.uint16 else ord("f")
         shifts = []
         m = min(chunk, n)
-        norm = torch.empty((3, m, self.subH, self.subW), dtype=torch.float32, device=frames.device)
-        for c0 in range(0, n, chunk):
+        bufs = [torch.empty((3, m, self.subH, self.subW), dtype=torch.float32, device=frames.device) for _ in range(2 if n > chunk else 1)]
+        st = _stream()
+
+        def prepare(c0, norm):
             k = min(chunk, n - c0)
             if _lib.rir_ecc_prepare_frames_device(frames[c0].data_ptr(), dt, w, h, k, float(self.sigma), self.startX, self.startY, self.subW, self.subH,
-                                                  norm[0].data_ptr(), norm[1].data_ptr(), norm[2].data_ptr(), _stream()) != 0:
+                                                  norm[0].data_ptr(), norm[1].data_ptr(), norm[2].data_ptr(), st) != 0:
                 raise RuntimeError("rir_ecc_prepare_frames_device: %s" % last_error())
-            cc = ct.c_double(0)
-            for i in range(k):
-                if _lib.rir_ecc_align_prepared_device(self._ref_n.data_ptr(), norm[0, i].data_ptr(), norm[1, i].data_ptr(), norm[2, i].data_ptr(), self.subW,
-                                                      self.subH, self.warp.ctypes.data, self.number_of_iterations, self.termination_eps, ct.byref(cc), None,
-                                                      _stream()) != 0:
-                    raise RuntimeError("ECC: %s" % last_error())
-                shifts.append(self._after_alignment(frames[c0 + i], cc.value))
+
+        def align(norm, i, cnt, res):
+            good = _lib.rir_ecc_align_prepared_frames_device(self._ref_n.data_ptr(), norm[0, i].data_ptr(), norm[1, i].data_ptr(), norm[2, i].data_ptr(),
+                                                             self.subW, self.subH, cnt, self.warp.ctypes.data, self.number_of_iterations, self.termination_eps,
+                                                             res[i:].ctypes.data, st)
+            if good < 0:
+                raise RuntimeError("ECC: %s" % last_error())
+            return good
+
+        if n:
+            prepare(0, bufs[0])
+        for ci, c0 in enumerate(range(0, n, chunk)):
+            k = min(chunk, n - c0)
+            norm = bufs[ci % len(bufs)]
+            res = np.empty((k, 4), np.float64)
+            # the alignments of the chunk in one launch; the next chunk's pre-processing is queued before the book-keeping of this one.
+            # Where the book-keeping changes the reference image the rest of the chunk is aligned again (new reference, from the identity).
+            i = 0
+            while i < k:
+                cnt = k - i
+                good = align(norm, i, cnt, res)
+                if i == 0 and c0 + chunk < n:
+                    prepare(c0 + chunk, bufs[(ci + 1) % len(bufs)])
+                ref = self._ref_n
+                for j in range(i, i + good):
+                    self.warp[0], self.warp[1] = res[j, 0], res[j, 1]
+                    shifts.append(self._after_alignment(None, float(res[j, 2]), frames, c0 + j))
+                    if self._ref_n is not ref:  # reference changed at frame j: what was aligned after it does not count
+                        good = j + 1 - i
+                        break
+                else:
+                    if good < cnt:
+                        raise RuntimeError("ECC: %s" % last_error())
+                i += good
         return shifts
 
     def return_coordinates_and_confidence_values(self):

@@ -252,9 +252,16 @@ dreg = DeviceRegistratorECC(1, 1)
 dreg.start(tf32[0])
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for i in range(1, nreg):
-    dreg.compute(tf32[i])
+dreg.compute_many(tf32[1:])  # (chunks of frames: pre-processing in shared launches, the chunk's alignments in one launch)
 c4["registration_ecc_device_resident_fps"] = (nreg - 1) / (time.perf_counter() - t0)
+dreg1 = DeviceRegistratorECC(1, 1)
+dreg1.start(tf32[0])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(1, nreg):
+    dreg1.compute(tf32[i])
+c4["registration_ecc_device_resident_frame_by_frame_fps"] = (nreg - 1) / (time.perf_counter() - t0)
+assert dreg1.x == dreg.x and dreg1.y == dreg.y
 c4["registration_max_error_px"] = float(max(np.abs(np.array(regr.x) - shifts[:nreg, 0]).max(), np.abs(np.array(regr.y) - shifts[:nreg, 1]).max()))
 
 
