@@ -191,3 +191,31 @@ print(json.dumps(out))
         res.append(json.loads(p.stdout.strip().splitlines()[-1]))
     assert res[0] == res[1]
     assert all(r[3] > 2 for r in res[0])
+
+
+def test_a_failing_frame_stops_compute_many_where_compute_stops():
+    """A frame whose alignment fails (an image of NaNs: the correlation is NaN) raises from compute_many as it
+    does from compute, with the frames before it recorded and nothing after it - the chunk's launch stops at the first failure."""
+    import torch
+
+    from librir_amd.registration import DeviceRegistratorECC
+
+    n, bad = 30, 17
+    f, s = s3_registration(n, 128, 160)
+    f = f.copy()
+    f[bad] = np.nan
+    t = torch.from_numpy(f).cuda()
+    one = DeviceRegistratorECC(1, 1, shape=(128, 160))
+    one.start(t[0])
+    with pytest.raises(RuntimeError):
+        for i in range(1, n):
+            one.compute(t[i])
+    many = DeviceRegistratorECC(1, 1, shape=(128, 160))
+    many.start(t[0])
+    with pytest.raises(RuntimeError):
+        many.compute_many(t[1:], chunk=12)
+    assert len(one.x) == bad and many.x == one.x and many.y == one.y and many.confidences == one.confidences
+    # both go on from there with the next frames
+    one.compute(t[bad + 1])
+    many.compute_many(t[bad + 1:bad + 2])
+    assert many.x == one.x and many.confidences == one.confidences
