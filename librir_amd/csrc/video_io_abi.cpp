@@ -351,6 +351,10 @@ namespace
 
 	// ---- saver -------------------------------------------------------------------------------
 	// reference: struct H264 (video_io.cpp:651-657) + H264_Saver (h264.cpp:1662-1939)
+	// (defined with the rir_lossy_* entry points)
+	int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned short *const *d_in, unsigned short *const *d_out, int nframes, int add_loss,
+						   int *const *d_errs, int *low_errors, int *high_errors, hipStream_t st);
+
 	struct SaverObject : public Object
 	{
 		const char *type_name() const override { return "H264Saver"; }
@@ -428,8 +432,31 @@ namespace
 		std::vector<int64_t> times;
 		std::vector<AttrMap> frame_attrs;
 		std::vector<unsigned short> low_errors, high_errors;
-		std::unique_ptr<LossyState> lossy;
+		std::unique_ptr<LossyObject> lossy_obj; // (not in the handle table: only this saver uses it)
+		LossyState *lossy = nullptr;			// &lossy_obj->st
 		std::vector<unsigned short> lossy_out;
+		// Bounded-loss frames whose step has not run yet: frames [raw_from, pending) of the chunk being assembled sit RAW in their
+		// page-locked slots; run_deferred_loss() uploads them in one copy and steps them as a run of frames (lossy_kernels.hip:
+		// one resident launch instead of three launches and an upload per frame), straight into the chunk's device frames.  Every
+		// path that reads or advances the loss state, the chunk's device frames or the error lists calls it first.
+		int raw_from = -1;
+		int raw_uploaded = 0;	  // raw frames [raw_from, raw_from + raw_uploaded) are in d_raw already (they go up in groups, as they come)
+		size_t raw_first_err = 0; // position in `deferred` of frame raw_from
+		DeviceBuffer d_raw;
+		bool upload_raw(int upto) // raw frames of the chunk up to slot `upto` -> d_raw
+		{
+			const int have = raw_from + raw_uploaded;
+			if (raw_from < 0 || upto <= have)
+				return true;
+			const size_t fbytes = (size_t)width * height * 2;
+			if (!d_raw.reserve((size_t)chunk_gop * fbytes) ||
+				!hip_ok(hipMemcpyAsync(d_raw.as<char>() + (size_t)raw_uploaded * fbytes, cc.h_frames.as<char>() + (size_t)have * fbytes, (size_t)(upto - have) * fbytes,
+									   hipMemcpyHostToDevice, default_stream()),
+						"H2D frames"))
+				return false;
+			raw_uploaded = upto - raw_from;
+			return true;
+		}
 
 		~SaverObject() override
 		{
@@ -442,11 +469,13 @@ namespace
 		{
 			if (lossy)
 				return true;
-			lossy.reset(new LossyState());
+			lossy_obj.reset(new LossyObject());
+			lossy = &lossy_obj->st;
 			lossy_out.resize((size_t)width * height);
 			if (!lossy->prepare(width, height, lossy_height, runningAverage, subtractMin))
 			{
-				lossy.reset();
+				lossy = nullptr;
+				lossy_obj.reset();
 				return false;
 			}
 			return true;
@@ -470,7 +499,27 @@ namespace
 			const size_t fbytes = (size_t)width * height * 2;
 			unsigned short *slot = reinterpret_cast<unsigned short *>(cc.h_frames.as<char>() + (size_t)pending * fbytes);
 			std::memcpy(slot, img, fbytes);
-			if (!d_err_slots.reserve((size_t)ERR_SLOTS * 2 * sizeof(int)) ||
+			if (!d_err_slots.reserve((size_t)ERR_SLOTS * 2 * sizeof(int)))
+				return false;
+			// every frame but the stream's first is left in its slot and stepped later, with the other frames of the chunk, as a run
+			// (frames with bad-pixel repair or of a size the run kernels do not take go one by one)
+			const int s_px = width * std::max(0, std::min(lossy_height, height)), full_px = width * height;
+			if (!first && !removeBadPixels && s_px > 0 && s_px % 8 == 0 && full_px % 8 == 0)
+			{
+				if (raw_from < 0)
+				{
+					if (!upload_staged(pending)) // (frames staged before this one are not raw: they go up as they are)
+						return false;
+					raw_from = pending, raw_uploaded = 0, raw_first_err = deferred.size();
+				}
+				if (pending + 1 - (raw_from + raw_uploaded) >= kUploadGroup && !upload_raw(pending + 1))
+					return false;
+				deferred.push_back(Deferred{(size_t)nframes, low_errors.size(), true});
+				low_errors.push_back(0);
+				high_errors.push_back(0);
+				return frame_added(ts, attrs);
+			}
+			if (!run_deferred_loss() ||
 				!lossy->queue_host_frame(slot, false, removeBadPixels, lowValueError, highValueError, stdFactor, d_err_slots.as<int>() + 2 * deferred.size()))
 				return false;
 			if (first)
@@ -489,6 +538,30 @@ namespace
 			return add_image_device(lossy->d_out.as<unsigned short>(), ts, attrs); // stays in HBM: no trip through the host
 		}
 
+		bool run_deferred_loss()
+		{
+			if (raw_from < 0)
+				return true;
+			const int a = raw_from, n = pending - a;
+			const bool up = upload_raw(pending);
+			raw_from = -1, raw_uploaded = 0;
+			if (n <= 0)
+				return true;
+			if (!up)
+				return false;
+			const size_t npx = (size_t)width * height;
+			hipStream_t st = default_stream();
+			lossy_obj->low = lowValueError, lossy_obj->high = highValueError, lossy_obj->std_factor = stdFactor, lossy_obj->remove_bad_pixels = false;
+			LossyObject *o = lossy_obj.get();
+			const unsigned short *in = d_raw.as<unsigned short>();
+			unsigned short *out = cc.d_frames.as<unsigned short>() + (size_t)a * npx;
+			int *errs = d_err_slots.as<int>() + 2 * raw_first_err;
+			if (lossy_step_streams(&o, 1, &in, &out, n, 0, &errs, nullptr, nullptr, st) != 0)
+				return false;
+			uploaded = pending; // (the chunk's device frames are complete up to here)
+			return true;
+		}
+
 		// errors of the frames recorded since the last call: into the error lists and the per-frame attributes
 		struct Deferred
 		{
@@ -503,6 +576,8 @@ namespace
 		DeviceBuffer d_err_slots;
 		bool resolve_errors()
 		{
+			if (!run_deferred_loss())
+				return false;
 			if (deferred.empty())
 				return true;
 			std::vector<int> e(deferred.size() * 2);
@@ -542,6 +617,8 @@ namespace
 		{
 			const std::string k = key ? key : "", v = value ? value : "";
 			auto as_int = [&]() { return std::atoi(v.c_str()); };
+			if (!run_deferred_loss()) // (frames already handed in were recorded under the parameters of their time)
+				return false;
 			if (k == "lowValueError")
 				lowValueError = as_int();
 			else if (k == "highValueError")
@@ -702,7 +779,7 @@ namespace
 
 		bool add_image(const unsigned short *img, int64_t ts, const AttrMap &attrs)
 		{
-			if (!img || !open())
+			if (!img || !open() || !run_deferred_loss())
 				return false;
 			if (pending >= chunk_gop && !flush_chunk())
 				return false; // an earlier chunk could not be written: no slot is free, never write past the staging buffers
@@ -723,7 +800,7 @@ namespace
 		// a frame that is already in device memory (bounded-loss path): device-to-device into the chunk
 		bool add_image_device(const unsigned short *d_img, int64_t ts, const AttrMap &attrs)
 		{
-			if (!d_img || !open())
+			if (!d_img || !open() || !run_deferred_loss())
 				return false;
 			if (pending >= chunk_gop && !flush_chunk())
 				return false;
@@ -2241,50 +2318,29 @@ static bool launch_run_alone(const LossyRun *d_table, int nstreams, int full_px,
 // (the loss state is sequential in time, so streams - not frames - are what runs side by side).
 // d_in[i] / d_out[i]: uint16 [nframes][h][w] of stream i (HOST arrays of nstreams device pointers); low_errors / high_errors:
 // HOST int[nstreams][nframes] or NULL (then nothing waits).
-RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, const unsigned short *const *d_in, unsigned short *const *d_out,
-										   int nframes, int add_loss, int *low_errors, int *high_errors, void *stream)
+// The step of `nframes` frames for the streams os[0..nstreams) (checked by the callers: equal geometry and history length, no
+// bad-pixel repair).  d_errs: NULL, or per stream a DEVICE int[nframes][2] that receives the budgets (nothing is read back
+// then); otherwise low_errors / high_errors: HOST int[nstreams][nframes] or NULL.
+namespace
 {
-	if (!device_ready())
-		return -1;
-	if (!handles || nstreams <= 0 || nstreams > 65535 || !d_in || !d_out || nframes <= 0)
-	{
-		log_error("rir_lossy_step_multi_device: invalid argument");
-		return -1;
-	}
-	std::vector<std::shared_ptr<LossyObject>> os((size_t)nstreams);
-	for (int i = 0; i < nstreams; ++i)
-	{
-		os[i] = lookup_as<LossyObject>(handles[i]);
-		if (!os[i] || !d_in[i] || !d_out[i] || d_in[i] == d_out[i])
-		{
-			log_error("rir_lossy_step_multi_device: invalid handle or buffer");
-			return -1;
-		}
-		for (int k = 0; k < i; ++k)
-			if (os[k] == os[i])
-			{
-				log_error("rir_lossy_step_multi_device: a stream appears twice");
-				return -1;
-			}
-		const LossyState &a = os[0]->st, &b = os[i]->st;
-		if (a.w != b.w || a.h != b.h || a.hl != b.hl || a.frames != b.frames || os[i]->remove_bad_pixels)
-		{
-			log_error("rir_lossy_step_multi_device: the streams must share geometry and history length (and not repair bad pixels)");
-			return -1;
-		}
-	}
-	hipStream_t st = (hipStream_t)stream;
+int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned short *const *d_in, unsigned short *const *d_out, int nframes, int add_loss,
+					   int *const *d_errs, int *low_errors, int *high_errors, hipStream_t st)
+{
 	const size_t npx = (size_t)os[0]->st.w * os[0]->st.h;
 	const bool want = low_errors || high_errors;
 	LossyObject &lead = *os[0]; // owns the scratch of the call: the table of steps and the budgets
-	if (want && !lead.batch_errs.reserve((size_t)nstreams * nframes * 2 * sizeof(int)))
+	if (want && !d_errs && !lead.batch_errs.reserve((size_t)nstreams * nframes * 2 * sizeof(int)))
 		return -1;
+	// where the budget of frame f of stream i goes on the device: the caller's array, the call's own (read back below), or nowhere
+	auto errs_of = [&](int i, int f) {
+		return d_errs ? d_errs[i] + (size_t)f * 2 : want ? lead.batch_errs.as<int>() + ((size_t)i * nframes + f) * 2 : (int *)nullptr;
+	};
 	int f0 = 0;
 	if (os[0]->st.frames == 0)
 	{ // first frame of every stream: stored as it is, seeds the state - one small launch per stream, once in a stream's life
 		for (int i = 0; i < nstreams; ++i)
 			if (!os[i]->st.queue_frame(d_in[i], d_out[i], add_loss != 0, false, os[i]->low, os[i]->high, os[i]->std_factor,
-									   want ? lead.batch_errs.as<int>() + ((size_t)i * nframes) * 2 : nullptr, st))
+									   errs_of(i, 0), st))
 				return -1;
 		f0 = 1;
 	}
@@ -2316,7 +2372,6 @@ RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, con
 			return -1;
 		LossyStep *hs = lead.multi_stage.as<LossyStep>();
 		const LossyStep *dt = lead.multi_table.as<LossyStep>();
-		auto errs_of = [&](int i, int f) { return want ? lead.batch_errs.as<int>() + ((size_t)i * nframes + f) * 2 : (int *)nullptr; };
 		if (!runs)
 		{
 			for (int f = f0; f < nframes; ++f)
@@ -2465,7 +2520,7 @@ RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, con
 			}
 		}
 	}
-	if (want)
+	if (want && !d_errs)
 	{
 		std::vector<int> e((size_t)nstreams * nframes * 2);
 		unsigned int gave_up = 0; // the run kernel's error word (a wait between workgroups that hit its clock)
@@ -2494,6 +2549,46 @@ RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, con
 		}
 	}
 	return 0;
+}
+
+
+} // namespace
+
+RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, const unsigned short *const *d_in, unsigned short *const *d_out,
+										   int nframes, int add_loss, int *low_errors, int *high_errors, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (!handles || nstreams <= 0 || nstreams > 65535 || !d_in || !d_out || nframes <= 0)
+	{
+		log_error("rir_lossy_step_multi_device: invalid argument");
+		return -1;
+	}
+	std::vector<std::shared_ptr<LossyObject>> os((size_t)nstreams);
+	std::vector<LossyObject *> ptrs((size_t)nstreams);
+	for (int i = 0; i < nstreams; ++i)
+	{
+		os[i] = lookup_as<LossyObject>(handles[i]);
+		if (!os[i] || !d_in[i] || !d_out[i] || d_in[i] == d_out[i])
+		{
+			log_error("rir_lossy_step_multi_device: invalid handle or buffer");
+			return -1;
+		}
+		for (int k = 0; k < i; ++k)
+			if (os[k] == os[i])
+			{
+				log_error("rir_lossy_step_multi_device: a stream appears twice");
+				return -1;
+			}
+		ptrs[i] = os[i].get();
+		const LossyState &a = os[0]->st, &b = os[i]->st;
+		if (a.w != b.w || a.h != b.h || a.hl != b.hl || a.frames != b.frames || os[i]->remove_bad_pixels)
+		{
+			log_error("rir_lossy_step_multi_device: the streams must share geometry and history length (and not repair bad pixels)");
+			return -1;
+		}
+	}
+	return lossy_step_streams(ptrs.data(), nstreams, d_in, d_out, nframes, add_loss, nullptr, low_errors, high_errors, (hipStream_t)stream);
 }
 
 RIR_EXPORT void rir_lossy_destroy(int handle)

@@ -337,6 +337,8 @@ class OracleLossy:
         self.lib.orc_lossy_step.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_void_p, ct.c_int]
         self.lib.orc_lossy_free.argtypes = [ct.c_void_p]
         self.lib.orc_lossy_last_errors.argtypes = [ct.c_void_p, ct.POINTER(ct.c_int), ct.POINTER(ct.c_int), ct.POINTER(ct.c_uint)]
+        self.lib.orc_lossy_set_errors.argtypes = [ct.c_void_p, ct.c_int, ct.c_int, ct.c_double]
+        self.std_factor = float(std_factor)
         self.p = self.lib.orc_lossy_create(w, h, h if lossy_height is None else lossy_height, low_err, high_err, float(std_factor),
                                            running_average, int(subtract_min))
 
@@ -345,6 +347,12 @@ class OracleLossy:
         out = np.zeros_like(img)
         self.lib.orc_lossy_step(self.p, _p(img), _p(out), int(add_loss))
         return out
+
+    def set_errors(self, low_err, high_err, std_factor=None):
+        """a parameter change on a stream in use (setParameter): applies from the next frame on"""
+        if std_factor is not None:
+            self.std_factor = float(std_factor)
+        self.lib.orc_lossy_set_errors(self.p, int(low_err), int(high_err), float(self.std_factor))
 
     def last_errors(self):
         lo, hi, bg = ct.c_int(0), ct.c_int(0), ct.c_uint(0)

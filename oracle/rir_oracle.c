@@ -854,6 +854,12 @@ EXPORT orc_lossy *orc_lossy_create(int w, int h, int lossy_height, int low_err, 
 	L->ra_const_count = (int16_t *)calloc(s, 2);
 	return L;
 }
+/* H264_Saver::setParameter (h264.cpp:1709-1781) on a stream in use: the budgets apply from the next frame on */
+EXPORT void orc_lossy_set_errors(orc_lossy *L, int low_err, int high_err, double std_factor)
+{
+	L->low_value_error = low_err, L->high_value_error = high_err, L->std_factor = std_factor;
+}
+
 EXPORT void orc_lossy_free(orc_lossy *L)
 {
 	if (!L)

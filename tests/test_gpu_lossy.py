@@ -206,3 +206,46 @@ def test_many_streams_in_shared_launches_equal_their_own_oracles(oracle, run_pat
         D.LossyStream.step_many([streams[0], fresh], [tens[0][:2], tens[1][:2]])
     for s in streams + [alone, fresh]:
         s.close()
+
+
+def test_recording_interleaved_with_queries_parameter_changes_and_add_loss(tmp_path, oracle):
+    """Bounded-loss frames are stepped chunk by chunk as runs of frames; whatever needs the loss state or the budgets in between -
+    the error getters, a parameter change, add_loss on an image that is not recorded, a lossless add_image - comes after the
+    frames already handed in and before the ones that follow, exactly as if every frame had been stepped in its own call."""
+    n, h, w, hl = 130, 48, 96, 45
+    arr = s1_noisy_background(n + 1, h, w, seed=29)
+    L = OracleLossy(oracle, w, h, hl, low_err=6, high_err=2, std_factor=5.0, running_average=8)
+    exp, elow, ehigh = {}, [], []
+    dst = tmp_path / "mixed.h264"
+    recorded = []
+    with IRSaver(dst, w, h, hl) as s:
+        s.set_parameter("runningAverage", 8)
+        s.set_parameter("GOP", 40)
+        for i in range(n):
+            if i == 61:  # a parameter change applies from this frame on
+                s.set_parameter("lowValueError", 9)
+                L.set_errors(9, 2)
+            if i == 77:  # an image that only goes through the loss, not into the file
+                got_loss = s.add_loss(arr[n])
+                exp_loss = L.step(arr[n], add_loss=True)
+                lo, hi, _ = L.last_errors()
+                elow.append(lo), ehigh.append(hi)
+                assert np.array_equal(got_loss, exp_loss)
+            if i == 100:  # a lossless frame in the middle of a chunk
+                s.add_image(arr[i], i * 1000)
+                exp[i] = arr[i]
+                recorded.append(i)
+                continue
+            s.add_image_lossy(arr[i], i * 1000)
+            exp[i] = L.step(arr[i])
+            lo, hi, _ = L.last_errors()
+            elow.append(lo), ehigh.append(hi)
+            recorded.append(i)
+            if i in (7, 8, 53):  # budgets asked for in the middle of a chunk
+                assert list(s.get_low_errors()) == elow and list(s.get_high_errors()) == ehigh
+        assert list(s.get_low_errors()) == elow and list(s.get_high_errors()) == ehigh
+    with IRMovie.from_filename(dst) as mov:
+        assert mov.images == len(recorded)
+        got = mov.data
+    for k, i in enumerate(recorded):
+        assert np.array_equal(got[k], exp[i]), i
