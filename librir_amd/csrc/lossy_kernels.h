@@ -86,8 +86,8 @@ namespace rir
 	// The run kernel needs ALL its workgroups resident at once: workgroup i runs on XCD i % 8, each XCD starts its own share of the
 	// grid as its 32 CUs (four 256-thread workgroups of <= 128 VGPRs each) come free, and a stream whose last workgroups can only
 	// start on an XCD that is full of its own waiting workgroups would wait for ever (seen with an oversubscribed grid: one call in
-	// a few hundred).  So: at most 960 workgroups per launch (120 of an XCD's 128 places); more streams or larger frames take the
-	// launch-per-frame path.
+	// a few hundred).  So: at most 960 workgroups per launch (120 of an XCD's 128 places): more streams go a batch after the other,
+	// larger frames (> 1.9 M pixels) take the launch-per-frame path.
 	constexpr int kLossyRunMaxWorkgroups = 960;
 
 	// Pixels per workgroup of the histogram pass: each workgroup clears and merges a private 16 384-bin histogram, so a launch wants

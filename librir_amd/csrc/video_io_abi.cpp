@@ -2357,8 +2357,13 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 		bool errors_fit = true; // (the run kernel hands a decision on as two 24-bit fields)
 		for (int i = 0; i < nstreams; ++i)
 			errors_fit = errors_fit && os[i]->low < (1 << 24) && os[i]->high < (1 << 24);
-		const bool persistent = runs && errors_fit && (long long)run_wgs * nstreams <= kLossyRunMaxWorkgroups && !getenv("RIR_LOSSY_LAUNCH_PER_FRAME");
-		const int group = std::max(1, 512 / nstreams); // frames per histogram launch
+		// (more streams than the chip holds at once go through the resident kernel a batch of streams after the other: 6 streams of
+		// 640x512 per launch keep 0.49 M frames/s whatever the number of streams; a launch per frame for all of them does 0.30-0.43 M)
+		const char *max_env = getenv("RIR_LOSSY_RUN_MAX_WORKGROUPS"); // (tests: a smaller limit, to go through the batches with small frames)
+		const int max_wgs = max_env && atoi(max_env) > 0 ? std::min(atoi(max_env), kLossyRunMaxWorkgroups) : kLossyRunMaxWorkgroups;
+		const bool persistent = runs && errors_fit && run_wgs <= max_wgs && !getenv("RIR_LOSSY_LAUNCH_PER_FRAME");
+		const int batch = persistent ? std::min(nstreams, max_wgs / run_wgs) : nstreams; // streams per launch of the resident kernel
+		const int group = std::max(1, (persistent ? 2048 : 512) / nstreams); // frames per histogram launch (one 64 KB histogram slice per frame and stream)
 		const int ngroups = runs ? (nsteps + group - 1) / group : 0;
 		const size_t nfused = persistent ? 0 : runs ? (size_t)(nsteps + 1) * nstreams : (size_t)nsteps * nstreams, nhist = runs ? (size_t)nsteps * nstreams : 0;
 		const size_t run_off = (nfused + nhist) * sizeof(LossyStep); // (a multiple of 8)
@@ -2460,8 +2465,11 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 					const int k0 = g * group, in_group = std::min(group, nsteps - k0);
 					if (!hip_ok(launch_lossy_backgrounds(dt + nfused + (size_t)k0 * nstreams, in_group * nstreams, s_px, lossy_hist_px(s_px, in_group * nstreams), st),
 								"lossy backgrounds") ||
-						!hip_ok(hipMemsetAsync(d_exch, 0, exch_bytes, st), "memset") || !launch_run_alone(dr + (size_t)g * nstreams, nstreams, full_px, d_ticket, st))
+						!hip_ok(hipMemsetAsync(d_exch, 0, exch_bytes, st), "memset"))
 						return -1;
+					for (int s0 = 0; s0 < nstreams; s0 += batch)
+						if (!launch_run_alone(dr + (size_t)g * nstreams + s0, std::min(batch, nstreams - s0), full_px, d_ticket, st))
+							return -1;
 				}
 			}
 			else

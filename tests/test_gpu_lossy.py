@@ -117,14 +117,17 @@ def test_per_frame_error_attributes(tmp_path):
         assert int(mov.attributes["GlobalForegroundError"]) == 2
 
 
-@pytest.fixture(params=["one launch per run", "one launch per frame"])
+@pytest.fixture(params=["one launch per run", "one launch per frame", "batches of streams"])
 def run_path(request, monkeypatch):
-    """Batches of frames are stepped by the resident run kernel or - frames too large for it - by one fused launch per frame
-    (RIR_LOSSY_LAUNCH_PER_FRAME forces that path at any size)."""
+    """Batches of frames are stepped by the resident run kernel - all streams in one launch, or, where the chip does not hold them
+    at once, a batch of streams after the other (RIR_LOSSY_RUN_MAX_WORKGROUPS lowers the limit so that small frames get there) -
+    or, frames too large for it, by one fused launch per frame (RIR_LOSSY_LAUNCH_PER_FRAME forces that path at any size)."""
+    monkeypatch.delenv("RIR_LOSSY_LAUNCH_PER_FRAME", raising=False)
+    monkeypatch.delenv("RIR_LOSSY_RUN_MAX_WORKGROUPS", raising=False)
     if request.param == "one launch per frame":
         monkeypatch.setenv("RIR_LOSSY_LAUNCH_PER_FRAME", "1")
-    else:
-        monkeypatch.delenv("RIR_LOSSY_LAUNCH_PER_FRAME", raising=False)
+    elif request.param == "batches of streams":
+        monkeypatch.setenv("RIR_LOSSY_RUN_MAX_WORKGROUPS", "13")  # 128x96 frames take 6 workgroups: two streams per launch
     return request.param
 
 
