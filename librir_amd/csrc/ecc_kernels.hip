@@ -259,32 +259,57 @@ namespace rir
 	// The 15 totals over `nrows` rows of partial sums ([row][16] doubles, word 15 = the row's flag), by the first 256 threads of a
 	// workgroup, in a fixed order: thread t adds, for sum k = t % 16, rows c, c + 16, c + 32, ... (c = t / 16) in order, then thread
 	// k < 15 adds the 16 chunks in order -> tot[k].  POLL: every row is waited for first (its flag == want; false when a wait gave up).
-	template <bool POLL>
+	// 16-byte hand-off granules {value, flag} of the one-launch alignment: written by ONE write-through (sc1) store each, read by sc1
+	// loads - a granule is its own flag, nothing has to be drained or ordered (MI355X_MICROARCH.md: 16-byte sc1 granules observed
+	// untorn on gfx950).  The flag's top two bits are free for a payload of their own (ecc_run_kernel: `done`).
+	typedef unsigned int ecc_v4u __attribute__((ext_vector_type(4)));
+	constexpr unsigned long long kEccFlagMask = 0x3fffffffffffffffull;
+	__device__ __forceinline__ __amdgpu_buffer_rsrc_t ecc_rsrc(const void *base, uint32_t bytes)
+	{
+		const uint64_t b = (uint64_t)base;
+		const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+		const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+		return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+	}
+	__device__ __forceinline__ void ecc_granule_store(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, unsigned long long value, unsigned long long flag)
+	{
+		ecc_v4u g;
+		g.x = (unsigned int)value, g.y = (unsigned int)(value >> 32), g.z = (unsigned int)flag, g.w = (unsigned int)(flag >> 32);
+		__builtin_amdgcn_raw_buffer_store_b128(g, rs, byte_off, 0, 16 /* sc1 */);
+	}
+
+	// The 15 totals over `nrows` rows of partial sums, by the first 256 threads of a workgroup, in a fixed order: thread t adds, for sum
+	// k = t % 16, rows c, c + 16, c + 32, ... (c = t / 16) in order, then thread k < 15 adds the 16 chunks in order -> tot[k].
+	// GRANULES false: rows of 16 doubles left by an earlier launch (ecc_sums_kernel).  GRANULES true: rows of 16 granules written
+	// inside this launch; each is waited for (its flag == want under kEccFlagMask; false when a wait gave up).
+	template <bool GRANULES>
 	__device__ __forceinline__ bool ecc_rows_total(const double *rows, int nrows, unsigned long long want, double (*part)[17], double *tot)
 	{
 		const int t = threadIdx.x, k = t & 15, c = t >> 4;
 		bool ok = true;
 		double a = 0.0;
-		if (t < 256)
+		if (t < 256 && k < ECC_NSUMS)
+		{
+			const __amdgpu_buffer_rsrc_t rs = ecc_rsrc(rows, (uint32_t)nrows * (GRANULES ? 256u : 128u));
 			for (int r0 = c; r0 < nrows; r0 += 16 * 16)
-			{ // 16 rows of this chunk at a time: all flags, then all values
-				if (POLL)
+			{ // 16 rows of this chunk at a time, all loads in flight together (a load behind a test of the previous one is 16 round trips)
+				double v[16];
+				if (GRANULES)
 				{
 					const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 					for (;;)
 					{
-						// (all 16 loads first, from clamped rows, then the tests: a load behind a test of the previous one is 16 round trips)
-						unsigned long long f[16];
+						ecc_v4u g[16];
 #pragma unroll
 						for (int j = 0; j < 16; ++j)
-						{
-							const int r = min(r0 + 16 * j, nrows - 1);
-							f[j] = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(rows + (size_t)r * 16) + 15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						}
+							g[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)min(r0 + 16 * j, nrows - 1) * 256u + (uint32_t)k * 16u, 0, 16 /* sc1 */);
 						unsigned long long bad = 0;
 #pragma unroll
 						for (int j = 0; j < 16; ++j)
-							bad |= f[j] ^ want;
+						{
+							bad |= ((((unsigned long long)g[j].w << 32) | g[j].z) ^ want) & kEccFlagMask;
+							v[j] = __longlong_as_double((long long)(((unsigned long long)g[j].y << 32) | g[j].x));
+						}
 						if (bad == 0)
 							break;
 						__builtin_amdgcn_s_sleep(1);
@@ -295,24 +320,18 @@ namespace rir
 						}
 					}
 				}
-				if (k < ECC_NSUMS)
+				else
 				{
-					double v[16];
 #pragma unroll
 					for (int j = 0; j < 16; ++j)
-					{
-						const int r = r0 + 16 * j;
-						const double x = __longlong_as_double((long long)__hip_atomic_load(
-							reinterpret_cast<const unsigned long long *>(rows + (size_t)min(r, nrows - 1) * 16) + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-						v[j] = r < nrows ? x : 0.0;
-					}
-#pragma unroll
-					for (int j = 0; j < 16; ++j)
-						a += v[j];
+						v[j] = rows[(size_t)min(r0 + 16 * j, nrows - 1) * 16 + k];
 				}
+#pragma unroll
+				for (int j = 0; j < 16; ++j)
+					a += r0 + 16 * j < nrows ? v[j] : 0.0;
 			}
-		if (t < 256 && k < ECC_NSUMS)
 			part[k][c] = a;
+		}
 		const int all_ok = __syncthreads_and(ok ? 1 : 0);
 		if (t < ECC_NSUMS)
 		{
@@ -350,25 +369,13 @@ namespace rir
 	// ---- all iterations of an alignment in ONE launch -----------------------------------------------------------------
 	//
 	// grid = nblk (<= RIR_ECC_MAX_BLOCKS = 256: one workgroup per CU, all resident), block = 256.  Per iteration every workgroup
-	// leaves its row of 15 sums and raises the row's flag; workgroup 0 waits for all flags, adds
+	// leaves its row of 15 sums as granules {value, flag}; workgroup 0 waits for all of them, adds
 	// the rows in the order ecc_solve_kernel does - the results are the same bits as with two launches per iteration - solves,
 	// and publishes the new translation with a flag the other workgroups wait for.  Two hops across the chip per iteration
 	// instead of two launch boundaries (15 us -> see DESIGN.md).  Flags carry (epoch << 32 | frame << 20 | iteration): the host passes a new
 	// epoch with every launch, nothing has to be cleared.  Waits are bounded by a clock; a wait that gives up ends the
 	// alignment as failed (done = 2).
-	// rows:  [nblk][16] doubles, word 15 of a row = its flag;   pub: [0] = tx | ty << 32, [1] = flag, [2] = done
-	__device__ __forceinline__ bool ecc_wait_flag(const unsigned long long *word, unsigned long long want)
-	{
-		const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-		for (;;)
-		{
-			if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want)
-				return true;
-			__builtin_amdgcn_s_sleep(1);
-			if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) // 2 s of the 100 MHz clock
-				return false;
-		}
-	}
+	// rows:  [nblk][16] granules {sum, flag};   pub: one granule {tx | ty << 32, flag | done << 62}
 	__global__ __launch_bounds__(ECC_BLOCK) void ecc_run_kernel(const float *__restrict__ templ, const float *__restrict__ image,
 																const float *__restrict__ gximg, const float *__restrict__ gyimg, const uint8_t *__restrict__ mask,
 																int w, int h, double *rows, unsigned long long *pub, EccState *state, EccHostView *host_view, float tx0,
@@ -381,6 +388,7 @@ namespace rir
 		__shared__ float sh_t[2];
 		__shared__ int sh_done;
 		const int b = blockIdx.x, nblk = gridDim.x, tid = threadIdx.x;
+		const __amdgpu_buffer_rsrc_t rows_rs = ecc_rsrc(rows, (uint32_t)nblk * 256u), pub_rs = ecc_rsrc(pub, 16u);
 		EccState st; // (workgroup 0, thread 0 keeps the real one)
 		st.tx = tx0, st.ty = ty0;
 		float tx = tx0, ty = ty0;
@@ -395,26 +403,16 @@ namespace rir
 		done = 0;
 		for (int it = 1; !done; ++it)
 		{
-			const unsigned long long flag = ((unsigned long long)epoch << 32) | ((unsigned long long)(unsigned int)f << 20) | (unsigned long long)((unsigned int)it & 0xfffffu);
+			const unsigned long long flag = ((unsigned long long)(epoch & 0x3fffffffu) << 32) | ((unsigned long long)(unsigned int)f << 20) | (unsigned long long)((unsigned int)it & 0xfffffu);
 #ifdef RIR_ECC_DIAG
 			const unsigned long long dg0 = __builtin_amdgcn_s_memrealtime();
 			unsigned long long dg1 = 0, dg2 = 0, dg3 = 0;
 #endif
 			const double v = ecc_block_sums(templ, image, gximg, gyimg, mask, w, h, tx, ty, b, nblk, red);
-			double *row = rows + (size_t)b * 16;
 			// hand-off without fences (a release / acquire pair at agent scope writes back and invalidates whole caches: 227 us per
-			// frame against 139 with two launches per iteration): every byte handed over is stored write-through (sc1), the storing
-			// wave drains its stores, then one lane raises the flag (sc1); the reader polls the flag with sc1 loads and loads the
-			// bytes with sc1 loads after its poll has matched (MI355X_MICROARCH.md, hand-off with a separate flag)
+			// frame against 139 with two launches per iteration) and without a drain: every sum travels as a granule {value, flag}
 			if (tid < ECC_NSUMS)
-				__hip_atomic_store(reinterpret_cast<unsigned long long *>(row) + tid, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-								   __HIP_MEMORY_SCOPE_AGENT);
-			if (tid < 64)
-			{ // (the row was written by lanes of this wave)
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-				if (tid == 0)
-					__hip_atomic_store(reinterpret_cast<unsigned long long *>(row) + 15, flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
+				ecc_granule_store(rows_rs, (uint32_t)b * 256u + (uint32_t)tid * 16u, (unsigned long long)__double_as_longlong(v), flag);
 #ifdef RIR_ECC_DIAG
 			dg1 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -429,23 +427,29 @@ namespace rir
 					done = all_ok ? ecc_solve_step(tot, st) : 2;
 					sh_t[0] = st.tx, sh_t[1] = st.ty;
 					sh_done = done;
-					__hip_atomic_store(pub, (unsigned long long)__float_as_uint(st.tx) | ((unsigned long long)__float_as_uint(st.ty) << 32), __ATOMIC_RELAXED,
-									   __HIP_MEMORY_SCOPE_AGENT);
-					__hip_atomic_store(pub + 2, (unsigned long long)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-					__hip_atomic_store(pub + 1, flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					// one granule: {tx | ty << 32, flag | done << 62}
+					ecc_granule_store(pub_rs, 0, (unsigned long long)__float_as_uint(st.tx) | ((unsigned long long)__float_as_uint(st.ty) << 32),
+									  flag | ((unsigned long long)done << 62));
 				}
 			}
 			else if (tid == 0)
 			{
-				if (ecc_wait_flag(pub + 1, flag))
+				const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+				sh_done = 2;
+				for (;;)
 				{
-					const unsigned long long t = __hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					sh_t[0] = __uint_as_float((unsigned int)t), sh_t[1] = __uint_as_float((unsigned int)(t >> 32));
-					sh_done = (int)__hip_atomic_load(pub + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					const ecc_v4u g = __builtin_amdgcn_raw_buffer_load_b128(pub_rs, 0, 0, 16 /* sc1 */);
+					const unsigned long long fl = ((unsigned long long)g.w << 32) | g.z;
+					if (((fl ^ flag) & kEccFlagMask) == 0)
+					{
+						sh_t[0] = __uint_as_float(g.x), sh_t[1] = __uint_as_float(g.y);
+						sh_done = (int)(fl >> 62);
+						break;
+					}
+					__builtin_amdgcn_s_sleep(1);
+					if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) // 2 s of the 100 MHz clock
+						break;
 				}
-				else
-					sh_done = 2;
 			}
 			__syncthreads();
 			tx = sh_t[0], ty = sh_t[1];
@@ -498,13 +502,13 @@ namespace rir
 		hipLaunchKernelGGL(ecc_solve_kernel, dim3(1), dim3(ECC_SOLVE_BLOCK), 0, st, d_partials, nblk, d_state, host_view);
 		return hipGetLastError();
 	}
-	size_t ecc_run_workspace_bytes(int w, int h) { return (size_t)ecc_blocks(w, h) * 16 * sizeof(double) + 256; }
+	size_t ecc_run_workspace_bytes(int w, int h) { return (size_t)ecc_blocks(w, h) * 256 + 256; } // rows of 16 granules, then pub (+ diagnostics)
 	hipError_t launch_ecc_run(const float *d_templ, const float *d_image, const float *d_gx, const float *d_gy, const uint8_t *d_mask, int w, int h,
 							  double *d_rows, EccState *d_state, EccHostView *host_view, float tx, float ty, int max_iter, double eps, unsigned int epoch,
 							  int nframes, EccFrameResult *d_results, hipStream_t st)
 	{
 		const int nblk = ecc_blocks(w, h);
-		unsigned long long *pub = reinterpret_cast<unsigned long long *>(d_rows + (size_t)nblk * 16);
+		unsigned long long *pub = reinterpret_cast<unsigned long long *>(d_rows + (size_t)nblk * 32);
 		hipLaunchKernelGGL(ecc_run_kernel, dim3(nblk), dim3(ECC_BLOCK), 0, st, d_templ, d_image, d_gx, d_gy, d_mask, w, h, d_rows, pub, d_state, host_view, tx,
 						   ty, max_iter, eps, epoch, nframes, d_results);
 		return hipGetLastError();
