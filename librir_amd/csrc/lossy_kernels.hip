@@ -50,6 +50,33 @@ namespace rir
 			dst[k] = src[k];
 		return p;
 	}
+	// Sum of a 64-bit integer over the wave, the same value in every lane: four DPP steps inside each row of 16 lanes (xor 1, xor 2,
+	// mirror of 8, mirror of 16 - integer sums do not care about the pairing), then the four rows through readlane.  A butterfly
+	// of __shfl_xor is six ds_bpermute round trips per half: six of those per frame were 1.3 us of the resident kernel's frame.
+	__device__ __forceinline__ long long lossy_wave_sum(long long v)
+	{
+#define RIR_DPP_ADD(CTRL)                                                                                     \
+	{                                                                                                         \
+		const int lo_ = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(unsigned long long)v, CTRL, 0xf, 0xf, false); \
+		const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)((unsigned long long)v >> 32), CTRL, 0xf, 0xf, false); \
+		v += (long long)(((unsigned long long)(unsigned int)hi_ << 32) | (unsigned int)lo_);                  \
+	}
+		RIR_DPP_ADD(0xB1)  // quad_perm [1,0,3,2]
+		RIR_DPP_ADD(0x4E)  // quad_perm [2,3,0,1]
+		RIR_DPP_ADD(0x141) // row_half_mirror
+		RIR_DPP_ADD(0x140) // row_mirror
+#undef RIR_DPP_ADD
+		long long r = 0;
+#pragma unroll
+		for (int row = 0; row < 4; ++row)
+		{
+			const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(unsigned long long)v, row * 16);
+			const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)v >> 32), row * 16);
+			r += (long long)(((unsigned long long)hi << 32) | lo);
+		}
+		return r;
+	}
+
 	// true in every thread of the workgroup whose ticket is the last of `expected`; last_flag: one LDS word the caller can spare
 	__device__ __forceinline__ bool lossy_last_arriver(unsigned int *ticket_, unsigned int expected, unsigned int *last_flag)
 	{
@@ -378,10 +405,7 @@ namespace rir
 #pragma unroll
 		for (int k = 0; k < 6; ++k)
 		{
-			long long v = a[k];
-#pragma unroll
-			for (int d = 32; d >= 1; d >>= 1)
-				v += __shfl_xor(v, d, 64);
+			const long long v = lossy_wave_sum(a[k]);
 			if ((threadIdx.x & 63) == 0)
 				red[threadIdx.x >> 6][k] = v;
 		}
@@ -675,10 +699,7 @@ namespace rir
 #pragma unroll
 		for (int k = 0; k < 6; ++k)
 		{
-			long long v = a[k];
-#pragma unroll
-			for (int d = 32; d >= 1; d >>= 1)
-				v += __shfl_xor(v, d, 64);
+			const long long v = lossy_wave_sum(a[k]);
 			if ((threadIdx.x & 63) == 0)
 				red[threadIdx.x >> 6][k] = v;
 		}
@@ -788,33 +809,6 @@ namespace rir
 	// A workgroup publishes frame k + 1 only after it has read all of frame k, and nobody gets to publish frame k + 2 before everybody
 	// has published k + 1: two buffers are enough.  Waits are bounded by a clock (2 s): a wait that gives up raises error_word and
 	// the run goes on with whatever it has - wrong, flagged, but never hung.
-	// Sum of a 64-bit integer over the wave, the same value in every lane: four DPP steps inside each row of 16 lanes (xor 1, xor 2,
-	// mirror of 8, mirror of 16 - integer sums do not care about the pairing), then the four rows through readlane.  A butterfly
-	// of __shfl_xor is six ds_bpermute round trips per half: six of those per frame were 1.3 us of the resident kernel's frame.
-	__device__ __forceinline__ long long lossy_wave_sum(long long v)
-	{
-#define RIR_DPP_ADD(CTRL)                                                                                     \
-	{                                                                                                         \
-		const int lo_ = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(unsigned long long)v, CTRL, 0xf, 0xf, false); \
-		const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)((unsigned long long)v >> 32), CTRL, 0xf, 0xf, false); \
-		v += (long long)(((unsigned long long)(unsigned int)hi_ << 32) | (unsigned int)lo_);                  \
-	}
-		RIR_DPP_ADD(0xB1)  // quad_perm [1,0,3,2]
-		RIR_DPP_ADD(0x4E)  // quad_perm [2,3,0,1]
-		RIR_DPP_ADD(0x141) // row_half_mirror
-		RIR_DPP_ADD(0x140) // row_mirror
-#undef RIR_DPP_ADD
-		long long r = 0;
-#pragma unroll
-		for (int row = 0; row < 4; ++row)
-		{
-			const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(unsigned long long)v, row * 16);
-			const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)v >> 32), row * 16);
-			r += (long long)(((unsigned long long)hi << 32) | lo);
-		}
-		return r;
-	}
-
 	constexpr int kRunWaves = kLossyRunThreads / 64;
 	__attribute__((amdgpu_waves_per_eu(kLossyRunWavesPerSimd, kLossyRunWavesPerSimd))) __global__ __launch_bounds__(kLossyRunThreads) void lossy_run_kernel(const LossyRun *__restrict__ table, unsigned int *__restrict__ ticket_, int nb, int nstreams)
 	{
