@@ -305,7 +305,7 @@ def lossy_only():
 ms = gpu_ms(lossy_only, 3)
 c4["lossy_step_device_resident_fps_one_stream"] = n4 / ms * 1e3
 # independent streams in shared launches (rir_lossy_step_multi_device): the loss state is sequential in time, streams run side by side
-for S in (6, 32):  # 6 streams of this size share one resident launch; more take a launch per frame
+for S in (7, 32):  # 7 streams of this size share one resident launch; more go a batch after the other
     m = 20 if args.quick else 60
     streams = [D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32) for _ in range(S)]
     ins = [treg[:m].clone() for _ in range(S)]
