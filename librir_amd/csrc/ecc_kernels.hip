@@ -64,19 +64,6 @@ namespace rir
 		gys[base + i] = 0.5f * img[yd * w + x] - 0.5f * img[yu * w + x];
 	}
 
-	__device__ __forceinline__ float bilinear0(const float *__restrict__ p, int w, int h, int x0, int y0, float fx, float fy)
-	{
-		// zero outside the image (constant border)
-		const bool xa = x0 >= 0 && x0 < w, xb = x0 + 1 >= 0 && x0 + 1 < w, ya = y0 >= 0 && y0 < h, yb = y0 + 1 >= 0 && y0 + 1 < h;
-		// (every tap is loaded, from an address clamped into the image, and dropped afterwards when it lies outside: a load
-		// under a condition is a branch with its own wait - twelve serial latencies per pixel for the three images)
-		const int xc0 = min(max(x0, 0), w - 1), xc1 = min(max(x0 + 1, 0), w - 1), yc0 = min(max(y0, 0), h - 1), yc1 = min(max(y0 + 1, 0), h - 1);
-		const float l00 = p[yc0 * w + xc0], l01 = p[yc0 * w + xc1], l10 = p[yc1 * w + xc0], l11 = p[yc1 * w + xc1];
-		const float v00 = (xa && ya) ? l00 : 0.f, v01 = (xb && ya) ? l01 : 0.f;
-		const float v10 = (xa && yb) ? l10 : 0.f, v11 = (xb && yb) ? l11 : 0.f;
-		const float top = v00 + fx * (v01 - v00), bot = v10 + fx * (v11 - v10);
-		return top + fy * (bot - top);
-	}
 
 	// One iteration = two launches.  ecc_sums_kernel: up to 1 024 workgroups, every thread a pixel or two, each workgroup
 	// leaves one row of 15 partial sums (fixed butterfly inside the wave, waves in order).  ecc_solve_kernel: one
@@ -85,6 +72,25 @@ namespace rir
 	// short latency-bound phases on few workgroups: 32 us at 512x640 whatever the grid; split, 11 us.  Round 2 tried again with
 	// write-through rows, a drained ticket and coalesced agent-scope loads in the last workgroup: 152 us per tracked frame against
 	// 140 us for the two launches - the ticket and the last workgroup's round trips cost more than the launch boundary they save.)
+	// 16-byte hand-off granules {value, flag} of the one-launch alignment: written by ONE write-through (sc1) store each, read by sc1
+	// loads - a granule is its own flag, nothing has to be drained or ordered (MI355X_MICROARCH.md: 16-byte sc1 granules observed
+	// untorn on gfx950).  The flag's top two bits are free for a payload of their own (ecc_run_kernel: `done`).
+	typedef unsigned int ecc_v4u __attribute__((ext_vector_type(4)));
+	constexpr unsigned long long kEccFlagMask = 0x3fffffffffffffffull;
+	__device__ __forceinline__ __amdgpu_buffer_rsrc_t ecc_rsrc(const void *base, uint32_t bytes)
+	{
+		const uint64_t b = (uint64_t)base;
+		const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+		const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+		return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+	}
+	__device__ __forceinline__ void ecc_granule_store(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, unsigned long long value, unsigned long long flag)
+	{
+		ecc_v4u g;
+		g.x = (unsigned int)value, g.y = (unsigned int)(value >> 32), g.z = (unsigned int)flag, g.w = (unsigned int)(flag >> 32);
+		__builtin_amdgcn_raw_buffer_store_b128(g, rs, byte_off, 0, 16 /* sc1 */);
+	}
+
 	// LDS of the reductions: val[k][thread] (padded: the 16 lanes that read 16 different k of one chunk hit different banks),
 	// part[k][chunk]
 	struct EccReduceLds
@@ -112,25 +118,42 @@ namespace rir
 			float I, gx, gy, T;
 			bool valid;
 		};
+		// Pixel coordinates advance by the (wave-uniform) stride instead of a division per pixel, and the 13 taps of a pixel are
+		// buffer loads with 32-bit offsets (four offsets shared by the three images) instead of 64-bit address arithmetic per tap:
+		// the pixel loop is VALU-bound at one wave per SIMD (2.7 of an iteration's 6.6 us).
 		const int npx = w * h, stride = nblk * ECC_BLOCK;
-		auto sample = [&](int i, bool inside) {
-			const int ic = min(i, npx - 1);
-			const int y = ic / w, x = ic - y * w;
+		const int dy = stride / w, dx = stride - dy * w;
+		const uint32_t bytes = (uint32_t)npx * 4u;
+		const __amdgpu_buffer_rsrc_t r_img = ecc_rsrc(image, bytes), r_gx = ecc_rsrc(gximg, bytes), r_gy = ecc_rsrc(gyimg, bytes), r_t = ecc_rsrc(templ, bytes);
+		auto ld = [](__amdgpu_buffer_rsrc_t r, uint32_t off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); };
+		auto sample = [&](int i, int x, int y, bool inside) {
 			const float sx = (float)x + tx, sy = (float)y + ty;
 			// validity: the nearest source pixel lies inside the image and inside the caller's mask
 			const int nx = (int)rintf(sx), ny = (int)rintf(sy);
 			bool valid = inside && nx >= 0 && nx < w && ny >= 0 && ny < h;
 			const uint8_t mv = mask ? mask[min(max(ny, 0), h - 1) * w + min(max(nx, 0), w - 1)] : (uint8_t)1;
 			valid = valid && mv != 0;
-			// (all loads before the test, see bilinear0)
 			const float flx = floorf(sx), fly = floorf(sy);
 			const int x0 = (int)flx, y0 = (int)fly;
 			const float fx = sx - flx, fy = sy - fly;
+			// zero outside the image (constant border); every tap is loaded, from an address clamped into the image, and dropped
+			// afterwards when it lies outside: a load under a condition is a branch with its own wait
+			const bool xa = x0 >= 0 && x0 < w, xb = x0 + 1 >= 0 && x0 + 1 < w, ya = y0 >= 0 && y0 < h, yb = y0 + 1 >= 0 && y0 + 1 < h;
+			const int xc0 = min(max(x0, 0), w - 1), xc1 = min(max(x0 + 1, 0), w - 1), yc0 = min(max(y0, 0), h - 1), yc1 = min(max(y0 + 1, 0), h - 1);
+			const uint32_t o00 = (uint32_t)(yc0 * w + xc0) * 4u, o01 = (uint32_t)(yc0 * w + xc1) * 4u, o10 = (uint32_t)(yc1 * w + xc0) * 4u,
+						   o11 = (uint32_t)(yc1 * w + xc1) * 4u;
+			const bool m00 = xa && ya, m01 = xb && ya, m10 = xa && yb, m11 = xb && yb;
+			auto blend = [&](__amdgpu_buffer_rsrc_t r) {
+				const float l00 = ld(r, o00), l01 = ld(r, o01), l10 = ld(r, o10), l11 = ld(r, o11);
+				const float v00 = m00 ? l00 : 0.f, v01 = m01 ? l01 : 0.f, v10 = m10 ? l10 : 0.f, v11 = m11 ? l11 : 0.f;
+				const float top = v00 + fx * (v01 - v00), bot = v10 + fx * (v11 - v10);
+				return top + fy * (bot - top);
+			};
 			Px p;
-			p.I = bilinear0(image, w, h, x0, y0, fx, fy);
-			p.gx = bilinear0(gximg, w, h, x0, y0, fx, fy);
-			p.gy = bilinear0(gyimg, w, h, x0, y0, fx, fy);
-			p.T = templ[ic];
+			p.I = blend(r_img);
+			p.gx = blend(r_gx);
+			p.gy = blend(r_gy);
+			p.T = ld(r_t, (uint32_t)i * 4u);
 			p.valid = valid;
 			return p;
 		};
@@ -143,11 +166,22 @@ namespace rir
 				s[11] += gx * I, s[12] += gy * I, s[13] += gx * T, s[14] += gy * T;
 			}
 		};
-		for (int i = blk * ECC_BLOCK + threadIdx.x; i < npx; i += 2 * stride)
 		{
-			const Px p0 = sample(i, true), p1 = sample(i + stride, i + stride < npx);
-			add(p0);
-			add(p1);
+			const int i0 = blk * ECC_BLOCK + (int)threadIdx.x;
+			int y = i0 / w, x = i0 - y * w; // (the thread's first pixel; meaningless, and unused, when i0 >= npx)
+			for (int i = i0; i < npx; i += 2 * stride)
+			{ // two pixels per round: their 26 loads are in flight together; sums are taken in pixel order
+				int x1 = x + dx, y1 = y + dy;
+				if (x1 >= w)
+					x1 -= w, ++y1;
+				const bool second = i + stride < npx;
+				const Px p0 = sample(i, x, y, true), p1 = sample(second ? i + stride : i, second ? x1 : x, second ? y1 : y, second);
+				add(p0);
+				add(p1);
+				x = x1 + dx, y = y1 + dy;
+				if (x >= w)
+					x -= w, ++y;
+			}
 		}
 #ifdef RIR_ECC_DIAG
 		ecc_diag_loop_end = __builtin_amdgcn_s_memrealtime();
@@ -259,25 +293,6 @@ namespace rir
 	// The 15 totals over `nrows` rows of partial sums ([row][16] doubles, word 15 = the row's flag), by the first 256 threads of a
 	// workgroup, in a fixed order: thread t adds, for sum k = t % 16, rows c, c + 16, c + 32, ... (c = t / 16) in order, then thread
 	// k < 15 adds the 16 chunks in order -> tot[k].  POLL: every row is waited for first (its flag == want; false when a wait gave up).
-	// 16-byte hand-off granules {value, flag} of the one-launch alignment: written by ONE write-through (sc1) store each, read by sc1
-	// loads - a granule is its own flag, nothing has to be drained or ordered (MI355X_MICROARCH.md: 16-byte sc1 granules observed
-	// untorn on gfx950).  The flag's top two bits are free for a payload of their own (ecc_run_kernel: `done`).
-	typedef unsigned int ecc_v4u __attribute__((ext_vector_type(4)));
-	constexpr unsigned long long kEccFlagMask = 0x3fffffffffffffffull;
-	__device__ __forceinline__ __amdgpu_buffer_rsrc_t ecc_rsrc(const void *base, uint32_t bytes)
-	{
-		const uint64_t b = (uint64_t)base;
-		const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
-		const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
-		return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)bytes, 0x00020000);
-	}
-	__device__ __forceinline__ void ecc_granule_store(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off, unsigned long long value, unsigned long long flag)
-	{
-		ecc_v4u g;
-		g.x = (unsigned int)value, g.y = (unsigned int)(value >> 32), g.z = (unsigned int)flag, g.w = (unsigned int)(flag >> 32);
-		__builtin_amdgcn_raw_buffer_store_b128(g, rs, byte_off, 0, 16 /* sc1 */);
-	}
-
 	// The 15 totals over `nrows` rows of partial sums, by the first 256 threads of a workgroup, in a fixed order: thread t adds, for sum
 	// k = t % 16, rows c, c + 16, c + 32, ... (c = t / 16) in order, then thread k < 15 adds the 16 chunks in order -> tot[k].
 	// GRANULES false: rows of 16 doubles left by an earlier launch (ecc_sums_kernel).  GRANULES true: rows of 16 granules written
