@@ -169,18 +169,27 @@ namespace rir
 		{
 			const int i0 = blk * ECC_BLOCK + (int)threadIdx.x;
 			int y = i0 / w, x = i0 - y * w; // (the thread's first pixel; meaningless, and unused, when i0 >= npx)
-			for (int i = i0; i < npx; i += 2 * stride)
-			{ // two pixels per round: their 26 loads are in flight together; sums are taken in pixel order
-				int x1 = x + dx, y1 = y + dy;
-				if (x1 >= w)
-					x1 -= w, ++y1;
-				const bool second = i + stride < npx;
-				const Px p0 = sample(i, x, y, true), p1 = sample(second ? i + stride : i, second ? x1 : x, second ? y1 : y, second);
-				add(p0);
-				add(p1);
-				x = x1 + dx, y = y1 + dy;
-				if (x >= w)
-					x -= w, ++y;
+#ifndef RIR_ECC_PIXELS_PER_ROUND
+#define RIR_ECC_PIXELS_PER_ROUND 3 /* 19.3 k frames/s; 2: 18.8 k, 6: 19.3 k at 226 VGPRs */
+#endif
+			constexpr int R = RIR_ECC_PIXELS_PER_ROUND;
+			for (int i = i0; i < npx; i += R * stride)
+			{ // R pixels per round: their 13 R loads are in flight together (a thread has 5 pixels at 640x512); sums are taken in pixel order
+				Px px[R];
+				int xx = x, yy = y;
+#pragma unroll
+				for (int q = 0; q < R; ++q)
+				{
+					const bool in = i + q * stride < npx; // (a pixel past the end is sampled at the round's first pixel and not counted)
+					px[q] = sample(in ? i + q * stride : i, in ? xx : x, in ? yy : y, in);
+					xx += dx, yy += dy;
+					if (xx >= w)
+						xx -= w, ++yy;
+				}
+#pragma unroll
+				for (int q = 0; q < R; ++q)
+					add(px[q]);
+				x = xx, y = yy;
 			}
 		}
 #ifdef RIR_ECC_DIAG
