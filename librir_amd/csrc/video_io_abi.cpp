@@ -2545,6 +2545,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 		}
 		if (gave_up)
 		{
+			(void)hipMemsetAsync(lead.run_exchange.as<unsigned int>() + 16, 0, 4, st); // (reported once: later calls start clean)
 			log_error("rir_lossy_step_multi_device: a run of frames gave up waiting (results invalid)");
 			return -1;
 		}
