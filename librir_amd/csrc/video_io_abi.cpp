@@ -582,8 +582,18 @@ namespace
 				return true;
 			std::vector<int> e(deferred.size() * 2);
 			hipStream_t st = default_stream();
-			if (!hip_ok(hipMemcpyAsync(e.data(), d_err_slots.ptr, e.size() * sizeof(int), hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
+			unsigned int gave_up = 0; // the run kernel's error word (lossy_step_streams): a wait between workgroups that hit its clock
+			const bool have_run = lossy_obj && lossy_obj->run_exchange.ptr;
+			if (!hip_ok(hipMemcpyAsync(e.data(), d_err_slots.ptr, e.size() * sizeof(int), hipMemcpyDeviceToHost, st), "D2H") ||
+				(have_run && !hip_ok(hipMemcpyAsync(&gave_up, lossy_obj->run_exchange.as<unsigned int>() + 16, 4, hipMemcpyDeviceToHost, st), "D2H")) ||
+				!hip_ok(wait_stream(st), "sync"))
 				return false;
+			if (gave_up)
+			{
+				(void)hipMemsetAsync(lossy_obj->run_exchange.as<unsigned int>() + 16, 0, 4, st);
+				log_error("h264 saver: the bounded-loss step of a run of frames gave up waiting (frames invalid)");
+				return false;
+			}
 			for (size_t i = 0; i < deferred.size(); ++i)
 			{
 				const Deferred &d = deferred[i];
