@@ -153,6 +153,10 @@ extern "C"
 	 * low_errors / high_errors: HOST int[nstreams][nframes] or NULL. */
 	int rir_lossy_step_multi_device(const int *handles, int nstreams, const unsigned short *const *d_in, unsigned short *const *d_out, int nframes,
 									int add_loss, int *low_errors, int *high_errors, void *stream);
+	/* 0, or -1 when a run of frames led by this stream's object gave up a wait between workgroups since the last query (a resident
+	 * kernel that could not get all its workgroups on the chip: the frames of that call are invalid).  Waits for `stream`.  Calls that
+	 * return budgets report this themselves; queue-only calls (no error arrays) leave it to this query. */
+	int rir_lossy_status(int handle, void *stream);
 	void rir_lossy_destroy(int handle);
 
 	/* ---- byte planes ------------------------------------------------------------------------------

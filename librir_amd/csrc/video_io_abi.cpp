@@ -2610,6 +2610,32 @@ RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, con
 	return lossy_step_streams(ptrs.data(), nstreams, d_in, d_out, nframes, add_loss, nullptr, low_errors, high_errors, (hipStream_t)stream);
 }
 
+// 0 when no run of frames stepped through this stream's object (as the leading stream of its call) has given up a wait between
+// workgroups since the last query, -1 otherwise (the frames of that call are invalid) or on an invalid handle.  Waits for the
+// work queued on `stream`.  Calls that return budgets check this themselves; queue-only calls (no error arrays) do not.
+RIR_EXPORT int rir_lossy_status(int handle, void *stream)
+{
+	auto o = lookup_as<LossyObject>(handle);
+	if (!o)
+	{
+		log_error("rir_lossy_status: invalid handle");
+		return -1;
+	}
+	if (!o->run_exchange.ptr)
+		return hip_ok(wait_stream((hipStream_t)stream), "sync") ? 0 : -1;
+	unsigned int gave_up = 0;
+	if (!hip_ok(hipMemcpyAsync(&gave_up, o->run_exchange.as<unsigned int>() + 16, 4, hipMemcpyDeviceToHost, (hipStream_t)stream), "D2H") ||
+		!hip_ok(wait_stream((hipStream_t)stream), "sync"))
+		return -1;
+	if (gave_up)
+	{
+		(void)hipMemsetAsync(o->run_exchange.as<unsigned int>() + 16, 0, 4, (hipStream_t)stream);
+		log_error("rir_lossy_status: a run of frames gave up waiting (results invalid)");
+		return -1;
+	}
+	return 0;
+}
+
 RIR_EXPORT void rir_lossy_destroy(int handle)
 {
 	if (lookup_as<LossyObject>(handle))

@@ -86,6 +86,7 @@ _lib.rir_lossy_create.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_i
 _lib.rir_lossy_step_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.rir_lossy_step_multi_device.argtypes = [_vp, ct.c_int, _vp, _vp, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.rir_lossy_destroy.argtypes = [ct.c_int]
+_lib.rir_lossy_status.argtypes = [ct.c_int, _vp]
 _lib.rir_split_planes_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp]
 _lib.rir_merge_planes_device.argtypes = [_vp, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.bad_pixels_destroy.restype = None
@@ -458,6 +459,10 @@ class LossyStream:
                                                 lo.ctypes.data if errors else None, hi.ctypes.data if errors else None, _stream()),
                "rir_lossy_step_multi_device")
         return outs, lo, hi
+
+    def status(self):
+        """raises when a queue-only ``step`` / ``step_many`` led by this stream went wrong on the device (waits for the stream)"""
+        _check(_lib.rir_lossy_status(self.handle, _stream()), "rir_lossy_status")
 
     def close(self):
         if getattr(self, "handle", 0) > 0:

@@ -161,6 +161,7 @@ def test_device_resident_stream_matches_oracle(oracle, add_loss, run_path):
     a, lo_a, _ = ls.step(t[:1], add_loss=False, errors=False)
     b, _, _ = ls.step(t[1:], add_loss=add_loss, errors=False)
     assert lo_a is None
+    ls.status()  # (queue-only calls leave the device-side verdict to this query)
     assert np.array_equal(torch.cat([a, b]).cpu().numpy(), np.stack(exp))
     ls.close()
     # runs, single frames (three launches each) and pairs interleaved: the state goes through registers and back unchanged
