@@ -248,6 +248,60 @@ def abi_numbers(frames_np, D, ctx, frames, out, n, h, w):
     torch.cuda.synchronize()
     res["batched_h2d_d2h_fps"] = 3 * n / (time.perf_counter() - t0)
     assert np.array_equal(pin_out.numpy(), frames_np)
+    try:
+        res["other_paths"] = other_paths(D, frames, h, w)
+    except Exception as e:  # (never at the cost of the numbers above)
+        res["other_paths"] = {"error": repr(e)[:300]}
+    return res
+
+
+def other_paths(D, frames, h, w):
+    """The two other device-resident paths of SURVEY §8 that have a rate of their own (BASELINE configs[4]), on 640x512 frames in
+    HBM: the bounded-loss step (one stream, and seven streams - what one resident launch holds) and the ECC registration of a
+    tracked sequence.  Reported beside the headline, not part of it."""
+    import torch
+
+    from librir_amd.registration import DeviceRegistratorECC
+    from librir_amd.synthetic import s3_registration
+
+    res = {}
+    m = min(200, frames.shape[0])
+    fr = frames[:m]
+
+    def rate(fn, count, reps=3):
+        best = 0.0
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            best = max(best, count / (time.perf_counter() - t0))
+        return best
+
+    st = D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32)
+    st.step(fr[:60], errors=False)
+    res["bounded_loss_step_fps_one_stream"] = rate(lambda: st.step(fr, errors=False), m)
+    st.status()
+    st.close()
+    S = 7
+    streams = [D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32) for _ in range(S)]
+    ins = [fr.clone() for _ in range(S)]
+    D.LossyStream.step_many(streams, ins, errors=False)
+    res["bounded_loss_step_fps_7_streams"] = rate(lambda: D.LossyStream.step_many(streams, ins, errors=False), m * S)
+    streams[0].status()
+    for x in streams:
+        x.close()
+    nreg = 100
+    f32, _ = s3_registration(nreg, h, w)
+    tf = torch.from_numpy(f32).to(frames.device)
+
+    def track():
+        reg = DeviceRegistratorECC(1, 1, shape=(h, w))
+        reg.start(tf[0])
+        reg.compute_many(tf[1:])
+
+    res["ecc_tracked_sequence_fps"] = rate(track, nreg - 1)
+    res["note"] = "best of 3; %d-frame calls of the bounded-loss step (low = high = 3, stdFactor 0, 509 lossy rows), %d float32 S3 frames for the registration" % (m, nreg)
     return res
 
 
