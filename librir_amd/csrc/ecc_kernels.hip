@@ -580,11 +580,18 @@ namespace rir
 	__global__ __launch_bounds__(256) void minmax_apply_kernel(const float *__restrict__ src, int w, int h, int src_stride, const float *__restrict__ part,
 															   int nparts, float *__restrict__ dst)
 	{
-		float mn = part[0], mx = part[1];
-		for (int k = 1; k < nparts; ++k)
+		// min / max of the parts: lane k of every wave takes part k (k + 64, ...), then a butterfly (min and max do not depend on the order)
+		float mn = 3.402823466e38f, mx = -3.402823466e38f;
+		for (int k = threadIdx.x & 63; k < nparts; k += 64)
 		{
 			mn = fminf(mn, part[2 * k]);
 			mx = fmaxf(mx, part[2 * k + 1]);
+		}
+#pragma unroll
+		for (int d = 32; d >= 1; d >>= 1)
+		{
+			mn = fminf(mn, __shfl_xor(mn, d, 64));
+			mx = fmaxf(mx, __shfl_xor(mx, d, 64));
 		}
 		const float range = mx - mn;
 		const int n = w * h;
@@ -656,18 +663,18 @@ namespace rir
 		}
 	}
 
-	hipError_t launch_minmax_normalize(const float *d_src, int w, int h, int src_stride, float *d_dst, float *d_part /* >= 2*64 floats */, hipStream_t st)
+	hipError_t launch_minmax_normalize(const float *d_src, int w, int h, int src_stride, float *d_dst, float *d_part, hipStream_t st)
 	{
-		const int nparts = 64;
+		const int nparts = kMinMaxParts; // (one image is a small job: 64 workgroups left it on a quarter of the chip, 9 us)
 		hipLaunchKernelGGL(minmax_partial_kernel, dim3(nparts), dim3(256), 0, st, d_src, w, h, src_stride, d_part);
 		hipLaunchKernelGGL(minmax_apply_kernel, dim3((w * h + 255) / 256 < 1024 ? (w * h + 255) / 256 : 1024), dim3(256), 0, st, d_src, w, h, src_stride,
 						   d_part, nparts, d_dst);
 		return hipGetLastError();
 	}
 	hipError_t launch_minmax_normalize_frames(const float *d_src, int w, int h, int src_stride, int64_t src_frame, int nframes, float *d_dst,
-											  float *d_part /* >= nframes*2*64 floats */, hipStream_t st)
+											  float *d_part, hipStream_t st)
 	{
-		const int nparts = 64;
+		const int nparts = kMinMaxPartsFrames;
 		hipLaunchKernelGGL(minmax_partial_frames_kernel, dim3(nparts, nframes), dim3(256), 0, st, d_src, w, h, src_stride, src_frame, d_part);
 		hipLaunchKernelGGL(minmax_apply_frames_kernel, dim3((w * h + 255) / 256 < 1024 ? (w * h + 255) / 256 : 1024, nframes), dim3(256), 0, st, d_src, w, h,
 						   src_stride, src_frame, d_part, nparts, d_dst);

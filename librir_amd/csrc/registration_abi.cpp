@@ -219,7 +219,7 @@ RIR_EXPORT int rir_ecc_register_frame_device(const void *d_img, int dtype, int w
 	ScratchOrder order(sc, st);
 	if (!order.ok)
 		return -1;
-	if (!sc.full.reserve((size_t)w * h * 4) || !sc.image.reserve((size_t)win_w * win_h * 4) || !sc.mm.reserve(2 * 64 * sizeof(float)))
+	if (!sc.full.reserve((size_t)w * h * 4) || !sc.image.reserve((size_t)win_w * win_h * 4) || !sc.mm.reserve(2 * kMinMaxParts * sizeof(float)))
 		return -1;
 	const float *g = nullptr;
 	if (sigma > 0)
@@ -265,7 +265,7 @@ RIR_EXPORT int rir_ecc_prepare_frames_device(const void *d_imgs, int dtype, int 
 	if (!order.ok)
 		return -1;
 	const size_t npx = (size_t)w * h;
-	if (!sc.mm_frames.reserve((size_t)nframes * 2 * 64 * sizeof(float)))
+	if (!sc.mm_frames.reserve((size_t)nframes * 2 * kMinMaxPartsFrames * sizeof(float)))
 		return -1;
 	const float *g = nullptr;
 	if (sigma > 0 || dtype == 'H')
@@ -416,7 +416,7 @@ RIR_EXPORT int rir_minmax_normalize_device(const float *d_src, int w, int h, int
 	EccScratch &sc = scratch();
 	std::lock_guard<std::mutex> lock(sc.mu);
 	ScratchOrder order(sc, (hipStream_t)stream);
-	if (!order.ok || !sc.mm.reserve(2 * 64 * sizeof(float)))
+	if (!order.ok || !sc.mm.reserve(2 * kMinMaxParts * sizeof(float)))
 		return -1;
 	return hip_ok(launch_minmax_normalize(d_src, w, h, src_stride, d_dst, sc.mm.as<float>(), (hipStream_t)stream), "minmax_normalize") ? 0 : -1;
 }
