@@ -281,3 +281,29 @@ def test_device_resident_step_rate():
     st.close()
     print("bounded-loss step, one stream: %.0f frames/s" % best)
     assert best >= 80000, best
+
+
+@pytest.mark.parametrize("ra", [1, 2, 64])
+def test_ring_lengths_at_the_edges(oracle, ra, run_path):
+    """Running averages over 1 image (the ring's oldest image is the one written a frame ago: the resident kernel keeps it in
+    registers), 2 and the maximum of 64, through every run path."""
+    import torch
+
+    from librir_amd import device as D
+
+    n, h, w, hl = 90, 40, 64, 38
+    arr = s1_noisy_background(n, h, w, seed=31)
+    L = OracleLossy(oracle, w, h, hl, low_err=4, high_err=2, std_factor=1.5, running_average=ra)
+    exp, elo, ehi = [], [], []
+    for i in range(n):
+        exp.append(L.step(arr[i]))
+        lo, hi, _ = L.last_errors()
+        elo.append(lo)
+        ehi.append(hi)
+    ls = D.LossyStream(w, h, hl, 4, 2, 1.5, ra)
+    t = torch.from_numpy(arr).cuda()
+    cuts = [0, 1, 30, 31, n]
+    parts = [ls.step(t[c0:c1]) for c0, c1 in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(torch.cat([p[0] for p in parts]).cpu().numpy(), np.stack(exp))
+    assert np.concatenate([p[1] for p in parts]).tolist() == elo and np.concatenate([p[2] for p in parts]).tolist() == ehi
+    ls.close()
