@@ -59,11 +59,11 @@ namespace rir
 							  double *d_rows, EccState *d_state, EccHostView *host_view, float tx, float ty, int max_iter, double eps, unsigned int epoch,
 							  int nframes, EccFrameResult *d_results, hipStream_t st);
 	constexpr int kEccMaxSequence = 4096, kEccMaxIterations = (1 << 20) - 1; // (the flag's fields)
-	// gradients of `nframes` dense images [nframes][h][w]
-	hipError_t launch_ecc_gradients(const float *d_image, int w, int h, int nframes, float *d_gx, float *d_gy, hipStream_t st);
 	constexpr int kMinMaxParts = 256, kMinMaxPartsFrames = 64; // partial (min, max) pairs per image: one image / a batch of images
 	// d_part: 2 * kMinMaxParts floats (one image), nframes * 2 * kMinMaxPartsFrames floats (a batch)
 	hipError_t launch_minmax_normalize(const float *d_src, int w, int h, int src_stride, float *d_dst, float *d_part, hipStream_t st);
-	hipError_t launch_minmax_normalize_frames(const float *d_src, int w, int h, int src_stride, int64_t src_frame, int nframes, float *d_dst, float *d_part,
-											  hipStream_t st);
+	// the same, and the gradients of the normalised images (central differences, reflected borders), in one pass over the source;
+	// d_part: nframes * 2 * (nframes == 1 ? kMinMaxParts : kMinMaxPartsFrames) floats
+	hipError_t launch_minmax_normalize_grad_frames(const float *d_src, int w, int h, int src_stride, int64_t src_frame, int nframes, float *d_dst, float *d_gx,
+												   float *d_gy, float *d_part, hipStream_t st);
 } // namespace rir

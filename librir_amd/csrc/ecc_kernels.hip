@@ -49,29 +49,6 @@ namespace rir
 		gy[i] = 0.5f * img[yd * w + x] - 0.5f * img[yu * w + x];
 	}
 
-	// the same gradients for a batch of images (blockIdx.y = image): the pre-processing of a sequence runs ahead of its alignments
-	__global__ __launch_bounds__(256) void ecc_gradient_frames_kernel(const float *__restrict__ imgs, int w, int h, float *__restrict__ gxs, float *__restrict__ gys)
-	{
-		const int i = blockIdx.x * 256 + threadIdx.x;
-		if (i >= w * h)
-			return;
-		const size_t base = (size_t)blockIdx.y * w * h;
-		const float *img = imgs + base;
-		const int y = i / w, x = i - y * w;
-		const int xl = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xr = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
-		const int yu = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yd = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
-		gxs[base + i] = 0.5f * img[y * w + xr] - 0.5f * img[y * w + xl];
-		gys[base + i] = 0.5f * img[yd * w + x] - 0.5f * img[yu * w + x];
-	}
-
-
-	// One iteration = two launches.  ecc_sums_kernel: up to 1 024 workgroups, every thread a pixel or two, each workgroup
-	// leaves one row of 15 partial sums (fixed butterfly inside the wave, waves in order).  ecc_solve_kernel: one
-	// workgroup adds the rows in a fixed tree (deterministic), solves the 2x2 system and updates the state in device memory.
-	// (As ONE kernel whose last workgroup - found through a ticket atomic - did the second half, the iteration was a chain of
-	// short latency-bound phases on few workgroups: 32 us at 512x640 whatever the grid; split, 11 us.  Round 2 tried again with
-	// write-through rows, a drained ticket and coalesced agent-scope loads in the last workgroup: 152 us per tracked frame against
-	// 140 us for the two launches - the ticket and the last workgroup's round trips cost more than the launch boundary they save.)
 	// 16-byte hand-off granules {value, flag} of the one-launch alignment: written by ONE write-through (sc1) store each, read by sc1
 	// loads - a granule is its own flag, nothing has to be drained or ordered (MI355X_MICROARCH.md: 16-byte sc1 granules observed
 	// untorn on gfx950).  The flag's top two bits are free for a payload of their own (ecc_run_kernel: `done`).
@@ -537,11 +514,6 @@ namespace rir
 						   ty, max_iter, eps, epoch, nframes, d_results);
 		return hipGetLastError();
 	}
-	hipError_t launch_ecc_gradients(const float *d_image, int w, int h, int nframes, float *d_gx, float *d_gy, hipStream_t st)
-	{
-		hipLaunchKernelGGL(ecc_gradient_frames_kernel, dim3((w * h + 255) / 256, nframes), dim3(256), 0, st, d_image, w, h, d_gx, d_gy);
-		return hipGetLastError();
-	}
 } // namespace rir
 
 // ---- min-max normalisation (MaskedRegistratorECC.compute, masked_registration_ecc.py:162-166) ----------------
@@ -602,8 +574,7 @@ namespace rir
 		}
 	}
 
-	// the same two steps for `nframes` images (blockIdx.y = image; images `src_frame` elements apart, outputs dense): exactly the
-	// operations of the single-image kernels, image by image
+	// the first step for `nframes` images (blockIdx.y = image; images `src_frame` elements apart): min / max are the same whatever the order
 	__global__ __launch_bounds__(256) void minmax_partial_frames_kernel(const float *__restrict__ src, int w, int h, int src_stride, int64_t src_frame,
 																		float *__restrict__ part)
 	{
@@ -634,14 +605,15 @@ namespace rir
 			part[2 * blockIdx.x + 1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
 		}
 	}
-	__global__ __launch_bounds__(256) void minmax_apply_frames_kernel(const float *__restrict__ src, int w, int h, int src_stride, int64_t src_frame,
-																	  const float *__restrict__ part, int nparts, float *__restrict__ dst)
+	// Normalisation AND gradients of the normalised image in one pass (blockIdx.y = image): a pixel's neighbours are normalised again
+	// from the source - the same two float operations, the same values ecc_gradient_kernel would read back.
+	__global__ __launch_bounds__(256) void minmax_apply_grad_frames_kernel(const float *__restrict__ src, int w, int h, int src_stride, int64_t src_frame,
+																		   const float *__restrict__ part, int nparts, float *__restrict__ dst, float *__restrict__ gxs,
+																		   float *__restrict__ gys)
 	{
 		src += (size_t)blockIdx.y * src_frame;
 		part += (size_t)blockIdx.y * 2 * nparts;
-		dst += (size_t)blockIdx.y * w * h;
-		// min / max of the parts: lane k of every wave takes part k (k + 64, ...), then a butterfly (min and max do not depend on the
-		// order; every thread walking the 64 parts itself made this kernel 3.3 us per image)
+		const size_t base = (size_t)blockIdx.y * w * h;
 		float mn = 3.402823466e38f, mx = -3.402823466e38f;
 		for (int k = threadIdx.x & 63; k < nparts; k += 64)
 		{
@@ -656,11 +628,25 @@ namespace rir
 		}
 		const float range = mx - mn;
 		const int n = w * h;
+		auto norm = [&](int x, int y) { return (src[(int64_t)y * src_stride + x] - mn) / range; };
 		for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
 		{
 			const int y = i / w, x = i - y * w;
-			dst[i] = (src[(int64_t)y * src_stride + x] - mn) / range;
+			const int xl = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xr = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
+			const int yu = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yd = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
+			dst[base + i] = norm(x, y);
+			gxs[base + i] = 0.5f * norm(xr, y) - 0.5f * norm(xl, y);
+			gys[base + i] = 0.5f * norm(x, yd) - 0.5f * norm(x, yu);
 		}
+	}
+	hipError_t launch_minmax_normalize_grad_frames(const float *d_src, int w, int h, int src_stride, int64_t src_frame, int nframes, float *d_dst, float *d_gx,
+												   float *d_gy, float *d_part, hipStream_t st)
+	{
+		const int nparts = nframes == 1 ? kMinMaxParts : kMinMaxPartsFrames;
+		hipLaunchKernelGGL(minmax_partial_frames_kernel, dim3(nparts, nframes), dim3(256), 0, st, d_src, w, h, src_stride, src_frame, d_part);
+		hipLaunchKernelGGL(minmax_apply_grad_frames_kernel, dim3((w * h + 255) / 256 < 1024 ? (w * h + 255) / 256 : 1024, nframes), dim3(256), 0, st, d_src, w, h,
+						   src_stride, src_frame, d_part, nparts, d_dst, d_gx, d_gy);
+		return hipGetLastError();
 	}
 
 	hipError_t launch_minmax_normalize(const float *d_src, int w, int h, int src_stride, float *d_dst, float *d_part, hipStream_t st)
@@ -669,15 +655,6 @@ namespace rir
 		hipLaunchKernelGGL(minmax_partial_kernel, dim3(nparts), dim3(256), 0, st, d_src, w, h, src_stride, d_part);
 		hipLaunchKernelGGL(minmax_apply_kernel, dim3((w * h + 255) / 256 < 1024 ? (w * h + 255) / 256 : 1024), dim3(256), 0, st, d_src, w, h, src_stride,
 						   d_part, nparts, d_dst);
-		return hipGetLastError();
-	}
-	hipError_t launch_minmax_normalize_frames(const float *d_src, int w, int h, int src_stride, int64_t src_frame, int nframes, float *d_dst,
-											  float *d_part, hipStream_t st)
-	{
-		const int nparts = kMinMaxPartsFrames;
-		hipLaunchKernelGGL(minmax_partial_frames_kernel, dim3(nparts, nframes), dim3(256), 0, st, d_src, w, h, src_stride, src_frame, d_part);
-		hipLaunchKernelGGL(minmax_apply_frames_kernel, dim3((w * h + 255) / 256 < 1024 ? (w * h + 255) / 256 : 1024, nframes), dim3(256), 0, st, d_src, w, h,
-						   src_stride, src_frame, d_part, nparts, d_dst);
 		return hipGetLastError();
 	}
 } // namespace rir

@@ -238,9 +238,15 @@ RIR_EXPORT int rir_ecc_register_frame_device(const void *d_img, int dtype, int w
 			return -1;
 		g = sc.full.as<float>();
 	}
-	if (!hip_ok(launch_minmax_normalize(g + (size_t)win_y * w + win_x, win_w, win_h, w, sc.image.as<float>(), sc.mm.as<float>(), st), "minmax_normalize"))
+	// normalisation and gradients in one pass, then all iterations in one launch
+	const size_t wpx = (size_t)win_w * win_h;
+	if (!sc.gx.reserve(wpx * 4) || !sc.gy.reserve(wpx * 4) ||
+		!hip_ok(launch_minmax_normalize_grad_frames(g + (size_t)win_y * w + win_x, win_w, win_h, w, 0, 1, sc.image.as<float>(), sc.gx.as<float>(), sc.gy.as<float>(),
+													sc.mm.as<float>(), st),
+				"minmax_normalize"))
 		return -1;
-	return run_ecc(sc, d_ref_norm, sc.image.as<float>(), nullptr, win_w, win_h, warp, max_iterations, eps, cc, iterations, st);
+	return run_iterations(sc, d_ref_norm, sc.image.as<float>(), sc.gx.as<float>(), sc.gy.as<float>(), nullptr, win_w, win_h, warp, max_iterations, eps, cc,
+						  iterations, false, st);
 }
 
 // The pre-processing of `nframes` frames of a tracked sequence in shared launches, ahead of their alignments (which are
@@ -265,7 +271,7 @@ RIR_EXPORT int rir_ecc_prepare_frames_device(const void *d_imgs, int dtype, int 
 	if (!order.ok)
 		return -1;
 	const size_t npx = (size_t)w * h;
-	if (!sc.mm_frames.reserve((size_t)nframes * 2 * kMinMaxPartsFrames * sizeof(float)))
+	if (!sc.mm_frames.reserve((size_t)nframes * 2 * std::max(kMinMaxParts, kMinMaxPartsFrames) * sizeof(float)))
 		return -1;
 	const float *g = nullptr;
 	if (sigma > 0 || dtype == 'H')
@@ -286,9 +292,9 @@ RIR_EXPORT int rir_ecc_prepare_frames_device(const void *d_imgs, int dtype, int 
 	}
 	else
 		g = static_cast<const float *>(d_imgs);
-	if (!hip_ok(launch_minmax_normalize_frames(g + (size_t)win_y * w + win_x, win_w, win_h, w, (int64_t)npx, nframes, d_norm, sc.mm_frames.as<float>(), st),
-				"minmax_normalize") ||
-		!hip_ok(launch_ecc_gradients(d_norm, win_w, win_h, nframes, d_gx, d_gy, st), "ecc gradients"))
+	if (!hip_ok(launch_minmax_normalize_grad_frames(g + (size_t)win_y * w + win_x, win_w, win_h, w, (int64_t)npx, nframes, d_norm, d_gx, d_gy,
+													sc.mm_frames.as<float>(), st),
+				"minmax_normalize"))
 		return -1;
 	return 0;
 }
