@@ -268,3 +268,26 @@ def test_identity_with_offsets_beyond_4_gib(dev):
 
     dec = sub.decode(EncodedBatch(sub.layout, sub.hdr, sub.tile_off, sub.chunk_off, sub.stream))
     assert torch.equal(dec.view(torch.int16), t[-50:].view(torch.int16))
+
+
+def test_workspace_placement_keeps_the_results(oracle):
+    """CodecContext.place_workspace moves the encode workspace to where the packing kernel measures fastest: the encoded batch is
+    the same bit for bit afterwards (it reports the candidates' times, the kept one first)."""
+    import torch
+
+    from librir_amd import device as D
+    from librir_amd.synthetic import s1_noisy_background
+
+    n, h, w = 100, 128, 160
+    fr = torch.from_numpy(s1_noisy_background(n, h, w, seed=5)).cuda()
+    ctx = D.CodecContext(w, h, n, 25)
+    e0 = ctx.encode(fr)
+    words = int(e0.total_words())
+    ref = (e0.hdr.clone(), e0.tile_off.clone(), e0.chunk_off.clone(), e0.stream[:words].clone())
+    times = ctx.place_workspace(fr, tries=3, spacing_bytes=64 << 20)
+    assert len(times) >= 1 and times == sorted(times)
+    e1 = ctx.encode(fr)
+    assert int(e1.total_words()) == words
+    assert torch.equal(e1.hdr, ref[0]) and torch.equal(e1.tile_off, ref[1]) and torch.equal(e1.chunk_off, ref[2]) and torch.equal(e1.stream[:words], ref[3])
+    out = ctx.decode(e1)
+    assert torch.equal(out.view(torch.int16), fr.view(torch.int16))
