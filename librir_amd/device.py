@@ -200,7 +200,7 @@ class CodecContext:
                 self.workspace = old
 
         cands = [(t_pack(self.workspace), self.workspace)]
-        spacers = []
+        spacers, ws = [], None
         for _ in range(max(0, int(tries))):
             try:
                 if spacing_bytes > 0:
@@ -214,7 +214,10 @@ class CodecContext:
         del spacers
         cands.sort(key=lambda c: c[0])
         self.workspace = cands[0][1]
-        return [c[0] for c in cands]
+        times = [c[0] for c in cands]
+        del cands, ws
+        torch.cuda.empty_cache()  # (the spacers and the candidates that lost go back to the device, not into torch's cache)
+        return times
 
     def encode_status(self):
         """0 when the last single-pass encode completed, 1 when one of its look-backs gave up (waits for the stream)"""
