@@ -4,10 +4,13 @@
     python bench.py --gpus N --steps K --warmup W          (N = 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one device-resident batch: rir_codec_encode_device then
-rir_codec_decode_device on BASELINE.json configs[1] (1 000-frame 640x512 uint16 stream, recipe S1,
-SURVEY.md §8d) - per rank.  Ranks hold independent shards (weak scaling, no collective in that data path):
-`value` = frames all ranks processed / the slowest rank's time.
+A "step" is one pass of the hot path over one device-resident batch: lossless encode (rir_codec_encode_tiles_device: record
+headers + one length and one slot per (chunk, tile) segment - the SLOTTED form of the encoded batch, complete as it stands)
+then decode (rir_codec_decode_slots_device) on BASELINE.json configs[1] (1 000-frame 640x512 uint16 stream, recipe S1,
+SURVEY.md §8d) - per rank: two launches that move 4WH + 2C bytes, the algorithmic minimum.  The DENSE (file) form of the same
+batch costs one more pass (rir_codec_encode_compact_device); it is timed beside the step and reported as `dense_file_form`,
+with the rate of encode + compact + decode from the dense stream (round 2's step).  Ranks hold independent shards (weak
+scaling, no collective in that data path): `value` = frames all ranks processed / the slowest rank's time.
 
 N > 1 additionally times, in the same run and with the same bracket, the step WITH the exchange north_star names
 (every GPU ends up holding the whole decoded stream), in both forms of librir_amd/distributed.py:
@@ -207,7 +210,7 @@ def abi_numbers(frames_np, D, ctx, frames, out, n, h, w):
             for i in range(min(n, 60)):
                 mov[i]
         runs = []
-        for rep in range(3):  # three recordings of the n frames, each read back: the median round trip is reported, the spread beside it
+        for rep in range(4):  # four recordings of the n frames, each read back: the first one (cold: page cache, pools) is reported on its own, the median of the other three as the rate
             dst = os.path.join(d, "abi%d.h264" % rep)
             t0 = time.perf_counter()
             with IRSaver(dst, w, h, h) as s:
@@ -222,10 +225,11 @@ def abi_numbers(frames_np, D, ctx, frames, out, n, h, w):
             assert np.array_equal(img, frames_np[n - 1])
             os.remove(dst)
             runs.append((n / (te + td), n / te, n / td))
-        runs.sort()
-        res["per_frame_abi_fps"] = runs[1][0]
-        res["per_frame_abi_detail"] = {"frames": n, "record_fps": runs[1][1], "read_fps": runs[1][2], "round_trip_fps_of_the_3_runs": [r[0] for r in runs],
-                                       "path": "IRSaver.add_image + IRMovie[i], file on the box's tmp filesystem; median of 3 recordings"}
+        cold, warm = runs[0], sorted(runs[1:])
+        res["per_frame_abi_fps"] = warm[1][0]
+        res["per_frame_abi_detail"] = {"frames": n, "record_fps": warm[1][1], "read_fps": warm[1][2], "round_trip_fps_warm_runs": [r[0] for r in warm],
+                                       "round_trip_fps_first_recording_of_the_process": cold[0],
+                                       "path": "IRSaver.add_image + IRMovie[i], file on the box's tmp filesystem; median of the 3 recordings after the first"}
     pin_in = torch.from_numpy(frames_np).pin_memory()
     pin_out = torch.empty_like(pin_in)
     enc0 = ctx.encode(frames)
@@ -371,14 +375,20 @@ def main():
     frames = torch.from_numpy(frames_np).to(dev)
     ctx = D.CodecContext(w, h, n, gop, device=dev)
     out = torch.empty_like(frames)
-    # one-off set-up, before any timed or warm-up step: the encode workspace goes where the packing kernel runs fastest for this
-    # frames buffer (a few alternative allocations, each timed with HIP events; CodecContext.place_workspace)
-    placement_us = ctx.place_workspace(frames)
-
+    # one-off set-up, before any timed or warm-up step: the encode workspace goes into a placement class other than the frames'
+    # (reads and writes of the packing kernel in one class cost it 10 %; CodecContext.place_workspace times a few
+    # alternative allocations with HIP events).  The step with the allocations as a fresh process gets them is timed first.
     def step():
-        enc = ctx.encode(frames)
-        ctx.decode(enc, out=out, check=False)
-        return enc
+        ctx.encode_tiles(frames)
+        ctx.decode_slots(out=out, check=False)
+
+    def k_steps(k):
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k):
+            step()
+        barrier()
+        return time.perf_counter() - t1
 
     def barrier():
         torch.cuda.synchronize()
@@ -393,37 +403,63 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    K = args.steps
     for _ in range(args.warmup):
-        enc = step()
+        step()
+    dt_unplaced = max_over_ranks(k_steps(K))  # (untimed as far as `value` goes: the same K steps before the placement)
+    placement_us = ctx.place_workspace(frames)
+    for _ in range(args.warmup):
+        step()
     barrier()
 
     # ---- timed region: exactly K steps; per-kernel HIP events on the stream the kernels run on ----
-    K = args.steps
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
     barrier()
     t0 = time.perf_counter()
     for k in range(K):
         ev[k][0].record()
         ctx.encode_tiles(frames)
         ev[k][1].record()
-        enc = ctx.encode_compact()
+        ctx.decode_slots(out=out, check=False)
         ev[k][2].record()
-        ctx.decode(enc, out=out, check=False)
-        ev[k][3].record()
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
 
     ms_tiles = sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(K)) / K
-    ms_compact = sum(ev[k][1].elapsed_time(ev[k][2]) for k in range(K)) / K
-    ms_decode = sum(ev[k][2].elapsed_time(ev[k][3]) for k in range(K)) / K
+    ms_decode = sum(ev[k][1].elapsed_time(ev[k][2]) for k in range(K)) / K
 
     # ---- parity gate before any number is reported: decoded stream == input, bit-exact ----
     assert int(ctx.error.item()) == 0
     ok = torch.equal(out.view(torch.int16), frames.view(torch.int16))
-    cbytes = enc.compressed_bytes()
-    payload_bytes = enc.total_words() * 8
+    payload_bytes = ctx.slots_payload_bytes()
     if not ok:
         raise SystemExit("bench.py: decode(encode(x)) != x - refusing to report a number")
+
+    # ---- spread: the same K-step region five more times (extra key; `value` is the region above) ----
+    reps = sorted(max_over_ranks(k_steps(K)) / K * 1e3 for _ in range(5))
+    spread = {"ms_per_step_min": reps[0], "ms_per_step_median": reps[2], "ms_per_step_max": reps[-1], "repeats": 5,
+              "note": "five further K-step regions after the one `value` is computed from"}
+
+    # ---- the dense (file) form of the same batch: one more pass over the payload, then the decode from the dense stream ----
+    evd = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
+    out.zero_()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(K):
+        evd[k][0].record()
+        ctx.encode_tiles(frames)
+        evd[k][1].record()
+        enc = ctx.encode_compact()
+        evd[k][2].record()
+        ctx.decode(enc, out=out, check=False)
+        evd[k][3].record()
+    barrier()
+    dt_dense = max_over_ranks(time.perf_counter() - t0)
+    ms_compact = sum(evd[k][1].elapsed_time(evd[k][2]) for k in range(K)) / K
+    ms_decode_dense = sum(evd[k][2].elapsed_time(evd[k][3]) for k in range(K)) / K
+    cbytes = enc.compressed_bytes()
+    if int(ctx.error.item()) != 0 or not torch.equal(out.view(torch.int16), frames.view(torch.int16)) or enc.total_words() * 8 != payload_bytes:
+        raise SystemExit("bench.py: the dense form does not decode to the input - refusing to report a number")
 
     # ---- N > 1: the same step WITH the exchange, inside its own timed bracket (same K, same barriers) ----
     exchange = None
@@ -514,7 +550,14 @@ def main():
         }
 
     extra = {"workspace_placement": {"packing_us_of_the_candidates": [round(x, 1) for x in placement_us],
-                                     "note": "set-up, untimed: the encode workspace is placed, by measurement, where the packing kernel runs fastest for this frames buffer (first value: kept)"}}
+                                     "value_unplaced": n * K * world / dt_unplaced, "ms_per_step_unplaced": dt_unplaced / K * 1e3,
+                                     "note": "set-up, untimed: the encode workspace is moved to an allocation of another placement class than the frames "
+                                             "(first value: kept; DESIGN.md §5, profiles/r03_placement_classes.md); `value_unplaced` = the same K steps "
+                                             "with the allocations as the fresh process got them"},
+             "spread": spread,
+             "dense_file_form": {"value": n * K * world / dt_dense, "ms_per_step": dt_dense / K * 1e3, "ms_compact": ms_compact,
+                                 "ms_decode_from_dense": ms_decode_dense,
+                                 "note": "encode_tiles + scan/compact (the dense stream a file or an exchange needs) + decode from the dense stream: round 2's step"}}
     if world == 1:
         # the single-pass (look-back) encoder beside the two-pass one that `value` is measured with: same outputs, fewer bytes
         # through HBM, no faster
@@ -530,14 +573,13 @@ def main():
         ctx.decode(sp, out=out, check=False)
         ok_sp = ctx.encode_status() == 0 and bool(torch.equal(out.view(torch.int16), frames.view(torch.int16)))
         extra["single_pass_encoder"] = {"ms_per_launch": e0.elapsed_time(e1) / K, "bit_exact_roundtrip": ok_sp,
-                                        "kernel": "rirb1_encode_dense (memset + 1 launch)", "two_pass_ms": ms_tiles + ms_compact}
+                                        "kernel": "rirb1_encode_dense (memset + 1 launch): the dense stream in one pass", "two_pass_ms": ms_tiles + ms_compact}
     extra.update(extra_abi)
 
     if rank == 0:
         raw = 2.0 * h * w * n  # bytes of raw uint16 per batch
         kernels = {
             "rirb1_encode_tiles": {"ms": ms_tiles, "alg_bytes": raw + payload_bytes + ctx.layout.hdr_bytes},
-            "rirb1_scan_tiles+rirb1_compact": {"ms": ms_compact, "alg_bytes": 2.0 * payload_bytes},
             "rirb1_decode_tiles": {"ms": ms_decode, "alg_bytes": raw + payload_bytes + ctx.layout.hdr_bytes},
         }
         for kv in kernels.values():
@@ -568,11 +610,15 @@ def main():
             "dtype": "u16",
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d-frame %dx%d uint16 stream (S1 noisy background, seed 1234+rank), lossless RIRB1 "
-                                   "encode+decode, device-resident, GOP %d, per GPU; the compressed stream (17 %% of a pass's bytes) is "
-                                   "written by the encoder and read back by the decoder through the 256 MiB Infinity Cache, the raw "
-                                   "frames (655 MB each way) stream from / to HBM" % (n, w, h, gop),
+                                   "encode+decode, device-resident, GOP %d, per GPU; two launches per step: the encoder leaves the slotted "
+                                   "form (headers + one length and one fixed-place slot per segment), the decoder reads it as it is; the "
+                                   "compressed payload (17 %% of a pass's bytes) is written and read back through the 256 MiB Infinity "
+                                   "Cache, the raw frames (655 MB each way) stream from / to HBM" % (n, w, h, gop),
                        "frames_per_gpu": n, "width": w, "height": h, "gop": gop, "sharding": "independent shard per rank"},
             "bit_exact_roundtrip": True,
+            "value_excludes_exchange": True if world > 1 else None,
+            "step_alg_bytes": 2.0 * raw + 2.0 * (payload_bytes + ctx.layout.hdr_bytes),
+            "step_alg_frac_of_hbm_peak": (2.0 * raw + 2.0 * (payload_bytes + ctx.layout.hdr_bytes)) / (dt / K) / 1e9 / HBM_PEAK_GBS,
             "compression_ratio": raw / cbytes,
             "roundtrip_raw_GBs": fps * 4.0 * h * w / 1e9 / world,
             "roundtrip_raw_frac_of_hbm_peak": fps * 4.0 * h * w / 1e9 / world / HBM_PEAK_GBS,

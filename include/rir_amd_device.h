@@ -56,6 +56,34 @@ extern "C"
 	int rir_codec_encode_compact_device(int width, int height, int nframes, int gop, unsigned int *d_tile_off, unsigned long long *d_chunk_off,
 										unsigned long long *d_stream, void *d_workspace, long long workspace_bytes, void *stream);
 
+	/* The SLOTTED form of an encoded batch: what stage 1 (rir_codec_encode_tiles_device) leaves - record headers in d_hdr, and in
+	 * the workspace one length per (chunk, tile) segment plus every segment's payload at the start of a slot of slot_words
+	 * 64-bit words whose place, slot index = chunk * ntiles + tile, depends on no length.  It is a complete encoded batch: the
+	 * same records as the dense form, located by position instead of by the offsets of stage 2 (which exists to make the
+	 * dense FILE form: chunk independence h264.cpp:1052-1064; offset-table precedent ZFile.cpp:434-447).  A consumer on the
+	 * same device decodes it as it is - encode + decode then move 4WH + 2C bytes, the algorithmic minimum, in two launches. */
+	typedef struct rir_codec_slots
+	{
+		int64_t slots_offset_bytes;		/* first slot, from d_workspace */
+		int64_t slot_words;				/* distance of two slots, 64-bit words */
+		int64_t seg_words_offset_bytes; /* uint32 [nchunks][ntiles] segment lengths in words, from d_workspace */
+		int64_t nslots;					/* nchunks * ntiles */
+	} rir_codec_slots;
+	int rir_codec_slots_query(int width, int height, int nframes, int gop, rir_codec_slots *out);
+	int rir_codec_decode_slots_device(const unsigned long long *d_hdr, const void *d_workspace, long long workspace_bytes, int width, int height,
+									  int nframes, int gop, unsigned short *d_frames, int *d_error, void *stream);
+
+	/* An encoder workspace (workspace_bytes of rir_codec_layout) allocated BY THE LIBRARY where the packing kernel runs fast for
+	 * THIS frames buffer.  On MI355X device allocations fall into a few placement classes and the kernel, which reads the frames
+	 * and writes the slots at the same pace, takes 10 % longer when both live in allocations of one class (DESIGN.md §5,
+	 * profiles/r03_placement_classes.md); nothing but a timing tells the class, so this call allocates up to max_tries further
+	 * candidates, spacing_bytes apart (0: back to back), times stage 1 on each with HIP events and keeps the first one that is
+	 * 7 % faster than the first, else the fastest; everything else it allocated is freed before it returns.  times_us: HOST
+	 * float[max_tries + 1] or NULL (the kept candidate's time first), *ntimes = entries filled.  One-off set-up, a few ms. */
+	int rir_codec_workspace_create_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, int max_tries,
+										  long long spacing_bytes, void **d_workspace, float *times_us, int *ntimes, void *stream);
+	void rir_codec_workspace_destroy_device(void *d_workspace);
+
 	/* The encode as one kernel that writes the dense stream directly (segments staged in LDS, decoupled look-back): same
 	 * outputs bit for bit, fewer bytes through HBM, not faster on MI355X.  rir_codec_encode_status (waits for the
 	 * stream): 0 = the last single-pass encode on this workspace completed, 1 = a look-back gave up, the stream is incomplete. */
@@ -153,9 +181,11 @@ extern "C"
 	 * low_errors / high_errors: HOST int[nstreams][nframes] or NULL. */
 	int rir_lossy_step_multi_device(const int *handles, int nstreams, const unsigned short *const *d_in, unsigned short *const *d_out, int nframes,
 									int add_loss, int *low_errors, int *high_errors, void *stream);
-	/* 0, or -1 when a run of frames led by this stream's object gave up a wait between workgroups since the last query (a resident
-	 * kernel that could not get all its workgroups on the chip: the frames of that call are invalid).  Waits for `stream`.  Calls that
-	 * return budgets report this themselves; queue-only calls (no error arrays) leave it to this query. */
+	/* 0, or -1 when a run of frames this stream took part in gave up a wait between workgroups (a resident kernel that could not
+	 * get all its workgroups on the chip).  Waits for `stream`.  The failure is STICKY: the stream's state has been advanced by
+	 * invalid frames, so every later status and step of the stream - and of the streams that shared the failed call - returns -1
+	 * until it is destroyed.  Calls that return budgets report this themselves; queue-only calls (no error arrays) leave it to
+	 * this query. */
 	int rir_lossy_status(int handle, void *stream);
 	void rir_lossy_destroy(int handle);
 

@@ -1,8 +1,10 @@
 // C ABI of the block codec on device-resident batches (format RIRB1).
 // Host-pointer / file-level entry points (h264_add_image_lossless, load_image, ...) are in
 // video_io_abi.cpp and call these.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "codec_format.h"
 #include "filter_kernels.h"
@@ -122,6 +124,172 @@ RIR_EXPORT int rir_codec_encode_compact_device(int width, int height, int nframe
 				  "codec encode (compact)")
 			   ? 0
 			   : -1;
+}
+
+// Where the slotted form lives inside the encoder workspace (byte offsets from d_workspace): what rir_codec_encode_tiles_device
+// leaves there IS a complete encoded batch - record headers in d_hdr, one length per (chunk, tile) segment, every segment's
+// payload at the start of a slot whose place does not depend on any length - that rir_codec_decode_slots_device decodes as it
+// is and rir_codec_encode_compact_device turns into the dense (file) form.
+RIR_EXPORT int rir_codec_slots_query(int width, int height, int nframes, int gop, rir_codec_slots *out)
+{
+	rir_codec_layout L;
+	if (!out || rir_codec_layout_query(width, height, nframes, gop, &L) != 0)
+		return -1;
+	Workspace w;
+	char *base = reinterpret_cast<char *>((uintptr_t)4096);
+	carve(L, base, L.workspace_bytes, w);
+	out->slots_offset_bytes = reinterpret_cast<char *>(w.sparse) - base;
+	out->slot_words = RIRB1_SLOT_WORDS(gop);
+	out->seg_words_offset_bytes = reinterpret_cast<char *>(w.seg_words) - base;
+	out->nslots = (int64_t)L.nchunks * L.ntiles;
+	return 0;
+}
+
+// Decode of the slotted form straight out of the encoder workspace: no offsets, no second encoder pass in front of it.
+RIR_EXPORT int rir_codec_decode_slots_device(const unsigned long long *d_hdr, const void *d_workspace, long long workspace_bytes, int width, int height,
+											 int nframes, int gop, unsigned short *d_frames, int *d_error, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	rir_codec_layout L;
+	Workspace w;
+	if (rir_codec_layout_query(width, height, nframes, gop, &L) != 0 || !check_geometry(L))
+		return -1;
+	if (!d_hdr || !d_frames || !d_error || !carve(L, const_cast<void *>(d_workspace), workspace_bytes, w))
+	{
+		log_error("rir_codec_decode_slots_device: null buffer or workspace too small");
+		return -1;
+	}
+	return hip_ok(launch_decode_slots(reinterpret_cast<const uint64_t *>(d_hdr), w.seg_words, w.sparse, (int64_t)width * height, L.ntiles, nframes, gop,
+									  d_frames, d_error, as_stream(stream)),
+				  "codec decode (slots)")
+			   ? 0
+			   : -1;
+}
+
+// ---- workspace placement -------------------------------------------------------------------------------------------------
+// The packing kernel reads the raw frames and writes the slots at the same pace; on MI355X its time has two values, ~135 and
+// ~150 us for 1 000 x 640x512, and which one it is depends on nothing but the PAIR of device allocations the two regions live
+// in: allocations fall into a few "placement classes" (stretches of the address space handed out by the driver; one
+// allocation, however large, is of one class), the kernel is slow exactly when frames and workspace are of the same class,
+// whatever the offsets inside the allocations and whatever the cache policy of its loads and stores
+// (profiles/r03_placement_classes.md: the class matrix over ten allocations, the offset sweeps, the policy variants, the
+// counters of the two cases) - the signature of read / write turn-arounds inside one rank of the HBM stacks.  A virtual
+// address does not tell the class, so the library finds a workspace of another class than the caller's frames the only way
+// there is: it allocates candidates itself (each `spacing_bytes` further along, the spacers freed before it returns), times
+// the packing kernel on each with HIP events and keeps the first that is 7 % faster than the first one, else the fastest.
+// One-off set-up cost of a few milliseconds; nothing of the caller's is touched, no allocator cache is flushed.
+// times_us: HOST float[max_tries + 1] or NULL, *ntimes entries filled (the kept candidate first).  The workspace is released
+// with rir_codec_workspace_destroy_device.  Returns 0, or -1 (nothing allocated).
+RIR_EXPORT int rir_codec_workspace_create_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, int max_tries,
+												 long long spacing_bytes, void **d_workspace, float *times_us, int *ntimes, void *stream)
+{
+	if (ntimes)
+		*ntimes = 0;
+	if (!device_ready())
+		return -1;
+	rir_codec_layout L;
+	if (rir_codec_layout_query(width, height, nframes, gop, &L) != 0 || !check_geometry(L))
+		return -1;
+	if (!d_frames || !d_workspace || max_tries < 0 || max_tries > 64 || spacing_bytes < 0)
+	{
+		log_error("rir_codec_workspace_create_device: invalid argument");
+		return -1;
+	}
+	*d_workspace = nullptr;
+	hipStream_t st = as_stream(stream);
+	DeviceBuffer hdr;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (!hdr.reserve((size_t)L.hdr_bytes) || !hip_ok(hipEventCreate(&e0), "hipEventCreate") || !hip_ok(hipEventCreate(&e1), "hipEventCreate"))
+	{
+		if (e0)
+			(void)hipEventDestroy(e0);
+		return -1;
+	}
+	constexpr int kReps = 5;
+	auto time_on = [&](void *ws, float &us) {
+		float best[kReps];
+		if (rir_codec_encode_tiles_device(d_frames, width, height, nframes, gop, hdr.as<unsigned long long>(), ws, L.workspace_bytes, stream) != 0)
+			return false;
+		for (int r = 0; r < kReps; ++r)
+		{
+			if (!hip_ok(hipEventRecord(e0, st), "event") ||
+				rir_codec_encode_tiles_device(d_frames, width, height, nframes, gop, hdr.as<unsigned long long>(), ws, L.workspace_bytes, stream) != 0 ||
+				!hip_ok(hipEventRecord(e1, st), "event") || !hip_ok(hipEventSynchronize(e1), "sync") || !hip_ok(hipEventElapsedTime(&best[r], e0, e1), "elapsed"))
+				return false;
+		}
+		std::sort(best, best + kReps);
+		us = best[kReps / 2] * 1e3f;
+		return true;
+	};
+	std::vector<void *> spacers, cands;
+	std::vector<float> times;
+	bool ok = true;
+	for (int t = 0; t <= max_tries && ok; ++t)
+	{
+		void *sp = nullptr, *ws = nullptr;
+		if (t > 0 && spacing_bytes > 0)
+		{
+			if (hipMalloc(&sp, (size_t)spacing_bytes) != hipSuccess)
+			{ // (no room for another candidate: the best so far is kept)
+				(void)hipGetLastError();
+				break;
+			}
+			spacers.push_back(sp);
+		}
+		if (hipMalloc(&ws, (size_t)L.workspace_bytes) != hipSuccess)
+		{
+			(void)hipGetLastError();
+			if (t == 0)
+			{
+				log_error("rir_codec_workspace_create_device: out of device memory");
+				ok = false;
+			}
+			break;
+		}
+		float us = 0;
+		if (!time_on(ws, us))
+		{
+			(void)hipFree(ws);
+			ok = false;
+			break;
+		}
+		cands.push_back(ws);
+		times.push_back(us);
+		if (t > 0 && us < 0.93f * times[0])
+			break;
+	}
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	for (void *sp : spacers)
+		(void)hipFree(sp);
+	size_t keep = 0;
+	for (size_t i = 1; i < cands.size(); ++i)
+		if (times[i] < times[keep])
+			keep = i;
+	for (size_t i = 0; i < cands.size(); ++i)
+		if (!ok || i != keep)
+			(void)hipFree(cands[i]);
+	if (!ok || cands.empty())
+		return -1;
+	*d_workspace = cands[keep];
+	if (times_us)
+	{
+		times_us[0] = times[keep];
+		int k = 1;
+		for (size_t i = 0; i < times.size(); ++i)
+			if (i != keep)
+				times_us[k++] = times[i];
+	}
+	if (ntimes)
+		*ntimes = (int)times.size();
+	return 0;
+}
+
+RIR_EXPORT void rir_codec_workspace_destroy_device(void *d_workspace)
+{
+	if (d_workspace)
+		(void)hipFree(d_workspace);
 }
 
 RIR_EXPORT int rir_codec_encode_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned long long *d_hdr,

@@ -25,6 +25,7 @@
 
 #include "codec_format.h"
 #include "filter_kernels.h"
+#include "runtime.h"
 
 // Cache policy of each traffic class (aux operand of the buffer instructions: 2 = nt, "streaming").
 // Raw frames are read once by the encoder and written once by the decoder, the sparse slots are read once by
@@ -1447,11 +1448,16 @@ namespace rir
 	}
 
 	// grid = (ceil(ntiles/4), nchunks), block = 256 (4 independent waves)
+	// Two layouts of the payload, one record format:
+	//   dense   (seg_words == NULL)  segment (c, t) = stream[chunk_off[c] + tile_off[c][t] ...) - the file form, tables untrusted
+	//   slotted (seg_words != NULL)  segment (c, t) = stream[(c * ntiles + t) * RIRB1_SLOT_WORDS(gop) ...), seg_words[c][t] words
+	//            long - what rirb1_encode_tiles leaves in its workspace: every segment's place is known before anything is
+	//            packed, so the encoder needs no second pass and the decoder no offsets (tile_off / chunk_off unused).
 	__global__ __launch_bounds__(256) void rirb1_decode_tiles(const uint64_t *__restrict__ hdr_table, const uint32_t *__restrict__ tile_off,
 															 const uint64_t *__restrict__ chunk_off, const uint64_t *__restrict__ stream,
 															 uint64_t stream_words, int64_t npx, int ntiles, int nframes, int gop,
-															 const int64_t *__restrict__ chunk_frames, uint16_t *__restrict__ frames,
-															 int *__restrict__ error_flag)
+															 const int64_t *__restrict__ chunk_frames, const uint32_t *__restrict__ seg_words,
+															 uint16_t *__restrict__ frames, int *__restrict__ error_flag)
 	{
 		const int lane = threadIdx.x & 63;
 		const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1478,20 +1484,37 @@ namespace rir
 		}
 		const int64_t slot = (int64_t)chunk * ntiles + tile;
 		const uint64_t *my_hdr = hdr_table + slot * gop;
-		const uint32_t t0 = tile_off[(int64_t)chunk * (ntiles + 1) + tile];
-		const uint32_t t1 = tile_off[(int64_t)chunk * (ntiles + 1) + tile + 1];
-		const uint64_t c0 = chunk_off[chunk], c1 = chunk_off[chunk + 1];
-		// The tables are untrusted (they come from a file): the segment [c0 + t0, c0 + t1) must lie inside the chunk
-		// [c0, c1) and the chunk inside the stream allocation BEFORE a descriptor is built on it - the descriptor's
-		// num_records only bounds accesses relative to its base.
-		if (c0 > c1 || c1 > stream_words || t1 < t0 || (uint64_t)t1 > c1 - c0)
-		{ // malformed offsets tables
-			if (lane == 0)
-				atomicExch(error_flag, 1);
-			return;
+		uint32_t seg_len;
+		const uint64_t *in;
+		if (seg_words)
+		{ // slotted: the slot's place is fixed, its length comes from the encoder's table (clamped to the slot all the same)
+			const uint64_t base = (uint64_t)slot * (uint64_t)RIRB1_SLOT_WORDS(gop);
+			seg_len = min(seg_words[slot], (uint32_t)gop * RIRB1_REC_MAX_WORDS);
+			if (base + seg_len > stream_words)
+			{
+				if (lane == 0)
+					atomicExch(error_flag, 1);
+				return;
+			}
+			in = stream + base;
 		}
-		const uint32_t seg_len = min(t1 - t0, (uint32_t)gop * RIRB1_REC_MAX_WORDS);
-		const uint64_t *in = stream + c0 + t0;
+		else
+		{
+			const uint32_t t0 = tile_off[(int64_t)chunk * (ntiles + 1) + tile];
+			const uint32_t t1 = tile_off[(int64_t)chunk * (ntiles + 1) + tile + 1];
+			const uint64_t c0 = chunk_off[chunk], c1 = chunk_off[chunk + 1];
+			// The tables are untrusted (they come from a file): the segment [c0 + t0, c0 + t1) must lie inside the chunk
+			// [c0, c1) and the chunk inside the stream allocation BEFORE a descriptor is built on it - the descriptor's
+			// num_records only bounds accesses relative to its base.
+			if (c0 > c1 || c1 > stream_words || t1 < t0 || (uint64_t)t1 > c1 - c0)
+			{ // malformed offsets tables
+				if (lane == 0)
+					atomicExch(error_flag, 1);
+				return;
+			}
+			seg_len = min(t1 - t0, (uint32_t)gop * RIRB1_REC_MAX_WORDS);
+			in = stream + c0 + t0;
+		}
 		const bool fast = ((npx & 7) == 0) && ((int64_t)(tile + 1) * RIRB1_TILE_PX <= npx) && ((((uintptr_t)frames) & 15) == 0);
 		if (fast)
 			decode_tile<true>(my_hdr, in, seg_len, npx, nf, f_begin, tile, lane, frames, error_flag);
@@ -1558,6 +1581,11 @@ namespace rir
 			cap = cap_env;
 		const size_t lds = (size_t)WAVES * cap * 8 + 8 + (2 * WAVES + 2) * 4;
 		const int64_t total = (int64_t)nchunks * ntiles;
+		// its workgroups wait for the segments in front of them (dealt by tickets, so any grid size makes progress on its own - but
+		// not beside a launch that holds the chip waiting for ITS missing workgroups): through the process-wide gate (runtime.h)
+		ResidentGate gate(st);
+		if (!gate.ok())
+			return hipErrorUnknown;
 		hipLaunchKernelGGL(rirb1_encode_dense<WAVES>, dim3((unsigned)total), dim3(WAVES * 64), lds, st, d_frames, npx, ntiles, nframes, gop, nchunks, d_hdr,
 						   d_tile_off, d_chunk_off, d_stream, d_ctrl, d_spill, cap);
 		return hipGetLastError();
@@ -1570,7 +1598,18 @@ namespace rir
 		const int nchunks = d_chunk_frames ? nchunks_tab : (nframes + gop - 1) / gop;
 		dim3 grid((ntiles + 3) / 4, nchunks), block(256);
 		hipLaunchKernelGGL(rirb1_decode_tiles, grid, block, 0, st, d_hdr, d_tile_off, d_chunk_off, d_stream, stream_words, npx, ntiles, nframes, gop,
-						   d_chunk_frames, d_frames, d_error);
+						   d_chunk_frames, (const uint32_t *)nullptr, d_frames, d_error);
+		return hipGetLastError();
+	}
+	// the slotted form: d_slots = the encoder's slot array ([nchunks][ntiles] slots of RIRB1_SLOT_WORDS(gop) words), d_seg_words its lengths
+	hipError_t launch_decode_slots(const uint64_t *d_hdr, const uint32_t *d_seg_words, const uint64_t *d_slots, int64_t npx, int ntiles, int nframes,
+								   int gop, uint16_t *d_frames, int *d_error, hipStream_t st)
+	{
+		const int nchunks = (nframes + gop - 1) / gop;
+		dim3 grid((ntiles + 3) / 4, nchunks), block(256);
+		hipLaunchKernelGGL(rirb1_decode_tiles, grid, block, 0, st, d_hdr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, d_slots,
+						   (uint64_t)nchunks * ntiles * (uint64_t)RIRB1_SLOT_WORDS(gop), npx, ntiles, nframes, gop, (const int64_t *)nullptr,
+						   d_seg_words, d_frames, d_error);
 		return hipGetLastError();
 	}
 } // namespace rir

@@ -55,6 +55,8 @@ namespace rir
 		int iter, done;
 	};
 	size_t ecc_run_workspace_bytes(int w, int h);
+	int ecc_run_capacity();			  // resident workgroups of ecc_run_kernel on the current device (runtime.h), 0 = unknown
+	bool ecc_run_fits(int w, int h);  // the grid of an alignment of a w x h window fits: the one-launch forms may be used
 	hipError_t launch_ecc_run(const float *d_templ, const float *d_image, const float *d_gx, const float *d_gy, const uint8_t *d_mask, int w, int h,
 							  double *d_rows, EccState *d_state, EccHostView *host_view, float tx, float ty, int max_iter, double eps, unsigned int epoch,
 							  int nframes, EccFrameResult *d_results, hipStream_t st);

@@ -17,6 +17,7 @@
 #include <cstddef>
 
 #include "ecc_kernels.h"
+#include "runtime.h"
 
 namespace rir
 {
@@ -503,12 +504,21 @@ namespace rir
 		hipLaunchKernelGGL(ecc_solve_kernel, dim3(1), dim3(ECC_SOLVE_BLOCK), 0, st, d_partials, nblk, d_state, host_view);
 		return hipGetLastError();
 	}
+	// workgroups of ecc_run_kernel the current device holds at once (runtime.h; 0 = unknown): the one-launch form is only taken when
+	// the alignment's grid fits - otherwise two launches per iteration (same sums in the same order, same results)
+	int ecc_run_capacity() { return resident_capacity(reinterpret_cast<const void *>(ecc_run_kernel), ECC_BLOCK, 0); }
+	bool ecc_run_fits(int w, int h) { return ecc_blocks(w, h) <= ecc_run_capacity(); }
 	size_t ecc_run_workspace_bytes(int w, int h) { return (size_t)ecc_blocks(w, h) * 256 + 256; } // rows of 16 granules, then pub (+ diagnostics)
 	hipError_t launch_ecc_run(const float *d_templ, const float *d_image, const float *d_gx, const float *d_gy, const uint8_t *d_mask, int w, int h,
 							  double *d_rows, EccState *d_state, EccHostView *host_view, float tx, float ty, int max_iter, double eps, unsigned int epoch,
 							  int nframes, EccFrameResult *d_results, hipStream_t st)
 	{
 		const int nblk = ecc_blocks(w, h);
+		if (nblk > ecc_run_capacity())
+			return hipErrorInvalidConfiguration; // (the callers ask ecc_run_fits() first: never reached)
+		ResidentGate gate(st); // its workgroups wait for each other: not beside any other resident launch of the process
+		if (!gate.ok())
+			return hipErrorUnknown;
 		unsigned long long *pub = reinterpret_cast<unsigned long long *>(d_rows + (size_t)nblk * 32);
 		hipLaunchKernelGGL(ecc_run_kernel, dim3(nblk), dim3(ECC_BLOCK), 0, st, d_templ, d_image, d_gx, d_gy, d_mask, w, h, d_rows, pub, d_state, host_view, tx,
 						   ty, max_iter, eps, epoch, nframes, d_results);

@@ -51,4 +51,6 @@ namespace rir
 	hipError_t launch_decode(const uint64_t *d_hdr, const uint32_t *d_tile_off, const uint64_t *d_chunk_off, const uint64_t *d_stream,
 							 uint64_t stream_words, int64_t npx, int ntiles, int nframes, int gop, const int64_t *d_chunk_frames, int nchunks_tab,
 							 uint16_t *d_frames, int *d_error, hipStream_t st);
+	hipError_t launch_decode_slots(const uint64_t *d_hdr, const uint32_t *d_seg_words, const uint64_t *d_slots, int64_t npx, int ntiles, int nframes,
+								   int gop, uint16_t *d_frames, int *d_error, hipStream_t st);
 } // namespace rir

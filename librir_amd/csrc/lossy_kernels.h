@@ -84,12 +84,13 @@ namespace rir
 	constexpr int kLossyRunThreads = 256; // 8 pixels each
 	inline int lossy_run_workgroups(int full) { return (full / 8 + kLossyRunThreads - 1) / kLossyRunThreads; }
 	// The run kernel needs ALL its workgroups resident at once: workgroup i runs on XCD i % 8, each XCD starts its own share of the
-	// grid as its 32 CUs (five 256-thread workgroups of <= 102 VGPRs each: the kernel is compiled for 5 waves per SIMD, 96 VGPRs)
-	// come free, and a stream whose last workgroups can only start on an XCD that is full of its own waiting workgroups would
-	// wait for ever (seen with an oversubscribed grid: one call in a few hundred).  So: at most 1 200 workgroups per launch (150 of
-	// an XCD's 160 places): more streams go a batch after the other, larger frames (> 2.4 M pixels) take the launch-per-frame path.
+	// grid as its CUs come free, and a stream whose last workgroups can only start on an XCD that is full of its own waiting
+	// workgroups would wait for ever (seen with an oversubscribed grid: one call in a few hundred).  How many the device holds is
+	// asked of the runtime (lossy_run_capacity: occupancy of THIS kernel x the device's CUs, less a margin - on an MI355X, 5
+	// workgroups per CU: 1 200), and the launch goes through the process-wide gate of runtime.h; more streams than fit go a batch
+	// after the other, a frame whose workgroups do not fit (or a device the runtime cannot size) takes the launch-per-frame path.
 	constexpr int kLossyRunWavesPerSimd = 5;
-	constexpr int kLossyRunMaxWorkgroups = 1200;
+	int lossy_run_capacity();
 
 	// Pixels per workgroup of the histogram pass: each workgroup clears and merges a private 16 384-bin histogram, so a launch wants
 	// about as many workgroups as the chip holds at once (two per CU) - 4 096 pixels for one 640x512 stream, more with many streams.

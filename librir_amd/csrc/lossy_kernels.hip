@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "lossy_kernels.h"
+#include "runtime.h"
 
 namespace rir
 {
@@ -1235,9 +1236,16 @@ namespace rir
 		return hipGetLastError();
 	}
 
+	// workgroups of lossy_run_kernel the current device holds at once (runtime.h: occupancy x CUs, less the margin; 0 = unknown)
+	int lossy_run_capacity() { return resident_capacity(reinterpret_cast<const void *>(lossy_run_kernel), kLossyRunThreads, 0); }
 	hipError_t launch_lossy_run(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ticket, hipStream_t st)
 	{
 		const int nb = lossy_run_workgroups(full);
+		if ((long long)nb * nstreams > lossy_run_capacity())
+			return hipErrorInvalidConfiguration; // (the callers plan their launches with lossy_run_capacity(): never reached)
+		ResidentGate gate(st); // its workgroups wait for each other: not beside any other resident launch of the process
+		if (!gate.ok())
+			return hipErrorUnknown;
 		hipLaunchKernelGGL(lossy_run_kernel, dim3((unsigned)(nb * nstreams)), dim3(kLossyRunThreads), 0, st, d_table, d_ticket, nb, nstreams);
 		return hipGetLastError();
 	}

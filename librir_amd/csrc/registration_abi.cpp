@@ -102,7 +102,15 @@ namespace
 			return -1;
 		EccState hs;
 		std::memset(&hs, 0, sizeof(hs));
-		static const bool per_iteration = getenv("RIR_ECC_LAUNCH_PER_ITERATION") != nullptr;
+		// one launch for all iterations when the device holds the alignment's workgroups at once (runtime.h: resident launches),
+		// two launches per iteration otherwise - same sums in the same order, same results
+		static const bool env_per_iteration = getenv("RIR_ECC_LAUNCH_PER_ITERATION") != nullptr;
+		const bool per_iteration = env_per_iteration || !ecc_run_fits(w, h);
+		if (max_iter > kEccMaxIterations)
+		{
+			log_error("ECC: max_iterations exceeds 1 048 575");
+			return -1;
+		}
 		if (!per_iteration)
 		{
 			if (!hip_ok(launch_ecc_run(d_templ, d_image, d_gx, d_gy, d_mask, w, h, sc.partials.as<double>(), d_state, d_view, warp[0], warp[1], max_iter, eps,
@@ -343,6 +351,24 @@ RIR_EXPORT int rir_ecc_align_prepared_frames_device(const float *d_ref_norm, con
 		return -1;
 	if (!sc.partials.reserve(std::max(ecc_workspace_bytes(w, h), ecc_run_workspace_bytes(w, h))) || !sc.state.reserve(sizeof(EccState)))
 		return -1;
+	static const bool env_per_iteration = getenv("RIR_ECC_LAUNCH_PER_ITERATION") != nullptr;
+	if (env_per_iteration || !ecc_run_fits(w, h))
+	{ // the device does not hold the run kernel's workgroups at once: image by image, two launches per iteration (same results)
+		const size_t wpx = (size_t)w * h;
+		int good = 0;
+		for (; good < nframes; ++good)
+		{
+			double cc = 0;
+			int iters = 0;
+			float t[2] = {warp[0], warp[1]};
+			if (run_iterations(sc, d_ref_norm, d_norm + good * wpx, d_gx + good * wpx, d_gy + good * wpx, nullptr, w, h, t, max_iterations, eps, &cc, &iters, false,
+							   st) != 0)
+				break;
+			warp[0] = t[0], warp[1] = t[1];
+			results[4 * good] = t[0], results[4 * good + 1] = t[1], results[4 * good + 2] = cc, results[4 * good + 3] = iters;
+		}
+		return good;
+	}
 	// the host view and the per-image results live in one block of coherent page-locked host memory the kernel writes directly (a
 	// copy of the results and the stream synchronisation behind it cost more than a chunk's book-keeping)
 	if (!sc.view && !hip_ok(hipHostMalloc(reinterpret_cast<void **>(&sc.view), sizeof(EccHostView), hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc"))

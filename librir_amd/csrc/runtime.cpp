@@ -3,9 +3,12 @@
 // get_last_log_error (tools.h:39-55) and set_void_ptr / get_void_ptr / rm_void_ptr (tools.h:67-78).
 #include "runtime.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <tuple>
 
 #ifndef RIR_SPIN_WAIT
 #define RIR_SPIN_WAIT 1
@@ -166,6 +169,105 @@ namespace rir
 		return d.ok;
 	}
 	hipStream_t default_stream() { return device().stream; }
+
+	// ---- resident launches (runtime.h) ---------------------------------------------------------------
+	int resident_capacity_rule(int blocks_per_cu, int cus, int xcds)
+	{
+		if (blocks_per_cu <= 0 || cus <= 0)
+			return 0;
+		if (xcds <= 0 || cus % xcds != 0)
+			xcds = 1;
+		const long long per_xcd = (long long)blocks_per_cu * (cus / xcds);
+		const long long margin = std::max(1ll, per_xcd / 16);
+		const long long cap = (long long)xcds * (per_xcd - margin);
+		return cap <= 0 ? 0 : cap > 0x3fffffff ? 0x3fffffff : (int)cap;
+	}
+	ResidentPlan resident_plan(int capacity, int wgs_per_unit, int units)
+	{
+		ResidentPlan p{0, 0};
+		if (capacity <= 0 || wgs_per_unit <= 0 || units <= 0 || wgs_per_unit > capacity)
+			return p;
+		p.units_per_launch = std::min(units, capacity / wgs_per_unit);
+		p.launches = (units + p.units_per_launch - 1) / p.units_per_launch;
+		return p;
+	}
+	namespace
+	{
+		constexpr int kMaxDevices = 64;
+		struct Gate
+		{
+			std::mutex mu;
+			hipEvent_t last = nullptr;
+			bool recorded = false;
+		};
+		Gate &gate_of(int dev)
+		{
+			static Gate *gates = new Gate[kMaxDevices]; // (leaked on purpose: the runtime may be gone before static destructors run)
+			return gates[dev < 0 || dev >= kMaxDevices ? 0 : dev];
+		}
+		struct CapKey
+		{
+			int dev;
+			const void *kernel;
+			int threads;
+			size_t lds;
+			bool operator<(const CapKey &o) const
+			{
+				return std::tie(dev, kernel, threads, lds) < std::tie(o.dev, o.kernel, o.threads, o.lds);
+			}
+		};
+	} // namespace
+	int resident_capacity(const void *kernel, int block_threads, size_t dynamic_lds)
+	{
+		static std::mutex mu;
+		static std::map<CapKey, int> *cache = new std::map<CapKey, int>;
+		int dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess)
+			return 0;
+		std::lock_guard<std::mutex> g(mu);
+		const CapKey key{dev, kernel, block_threads, dynamic_lds};
+		auto it = cache->find(key);
+		if (it != cache->end())
+			return it->second;
+		int per_cu = 0, cus = 0, xcds = 0, cap = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, dynamic_lds) == hipSuccess &&
+			hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+		{
+			if (hipDeviceGetAttribute(&xcds, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess)
+				xcds = 1;
+			cap = resident_capacity_rule(per_cu, cus, xcds);
+		}
+		else
+			(void)hipGetLastError();
+		if (const char *ev = getenv("RIR_RESIDENT_CAPACITY")) // (tests, partitions the runtime misreports: an upper bound for every kernel)
+			if (atoi(ev) >= 0)
+				cap = std::min(cap, atoi(ev));
+		(*cache)[key] = cap;
+		return cap;
+	}
+	ResidentGate::ResidentGate(hipStream_t st) : st_(st)
+	{
+		int dev = 0;
+		if (!hip_ok(hipGetDevice(&dev), "hipGetDevice"))
+			return;
+		Gate &g = gate_of(dev);
+		g.mu.lock();
+		gate_ = &g;
+		if (!g.last && !hip_ok(hipEventCreateWithFlags(&g.last, hipEventDisableTiming), "hipEventCreate"))
+			return;
+		if (g.recorded && !hip_ok(hipStreamWaitEvent(st_, g.last, 0), "hipStreamWaitEvent"))
+			return;
+		ok_ = true;
+	}
+	ResidentGate::~ResidentGate()
+	{
+		if (!gate_)
+			return;
+		Gate &g = *static_cast<Gate *>(gate_);
+		if (ok_ && g.last)
+			g.recorded = hipEventRecord(g.last, st_) == hipSuccess || g.recorded;
+		g.mu.unlock();
+	}
 
 	DeviceBuffer::~DeviceBuffer()
 	{
@@ -335,3 +437,17 @@ RIR_EXPORT int set_void_ptr(void *obj)
 }
 RIR_EXPORT void *get_void_ptr(int index) { return rir::lookup_object(index).get(); }
 RIR_EXPORT void rm_void_ptr(int index) { rir::remove_object(index); }
+
+// The residency rules of runtime.h as plain functions (no device needed): what tests/test_abi.py checks.
+// rir_resident_capacity_rule: workgroups of a kernel with blocks_per_cu resident workgroups per CU that may wait for each other
+// in one launch on a device of `cus` CUs in `xcds` XCDs.  rir_resident_plan: out[0] = units per launch (0 = a unit does not fit:
+// the caller's launch-per-frame / launch-per-iteration path), out[1] = launches; returns 0, -1 on a NULL pointer.
+RIR_EXPORT int rir_resident_capacity_rule(int blocks_per_cu, int cus, int xcds) { return rir::resident_capacity_rule(blocks_per_cu, cus, xcds); }
+RIR_EXPORT int rir_resident_plan(int capacity, int wgs_per_unit, int units, int *out2)
+{
+	if (!out2)
+		return -1;
+	const rir::ResidentPlan p = rir::resident_plan(capacity, wgs_per_unit, units);
+	out2[0] = p.units_per_launch, out2[1] = p.launches;
+	return 0;
+}

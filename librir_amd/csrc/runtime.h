@@ -76,6 +76,47 @@ namespace rir
 		T *as() { return static_cast<T *>(ptr); }
 	};
 
+	// ---- resident launches ------------------------------------------------------------------------
+	// Three kernel families make workgroups of ONE launch wait for each other (lossy_run_kernel, ecc_run_kernel and, through its
+	// tickets, rirb1_encode_dense): every workgroup such a launch waits for must be on the chip, so (1) a launch may not be
+	// larger than what the device holds at once and (2) two such launches - whatever their kernels, streams or calling threads -
+	// may not run side by side, each holding a part of the chip and waiting for the rest.  The handle-based ABI lets different
+	// objects be driven from different threads (reference registry mutex, tools.cpp:46-50), so both are enforced here, for the
+	// process, per device - not by each kernel family for itself.
+	//
+	// (1) resident_capacity: workgroups of `kernel` (block of `block_threads` threads, `dynamic_lds` bytes) the current device holds
+	// at once, from hipOccupancyMaxActiveBlocksPerMultiprocessor x multiProcessorCount, less a margin (resident_capacity_rule).
+	// 0 when the runtime cannot tell: the caller then takes its launch-per-frame / launch-per-iteration path.  Cached.
+	int resident_capacity(const void *kernel, int block_threads, size_t dynamic_lds);
+	// The rule alone (no device needed; unit-tested on the CPU): workgroup i of a launch starts on XCD i % xcds and every XCD fills
+	// its own CUs, so what counts is an XCD's places, blocks_per_cu x (cus / xcds); one sixteenth of them (at least one) stays
+	// free for whatever else is running.  MI355X, a kernel with 5 workgroups per CU: 8 x (160 - 10) = 1 200.
+	int resident_capacity_rule(int blocks_per_cu, int cus, int xcds);
+	// How `units` independent units (streams, sequences) of `wgs_per_unit` workgroups each go through a resident kernel of the
+	// given capacity: units per launch (0: a unit does not fit at all - take the non-resident path) and the number of launches.
+	struct ResidentPlan
+	{
+		int units_per_launch, launches;
+	};
+	ResidentPlan resident_plan(int capacity, int wgs_per_unit, int units);
+	// (2) the gate: construct it right before the launch, on the launching thread, with the launch's stream; it makes that stream
+	// wait for the previous resident launch of the device (whatever stream that went to) and, when it goes out of scope, leaves
+	// its event behind the launch.  Host side it holds the device's mutex for the duration of the launch call only.
+	class ResidentGate
+	{
+	public:
+		explicit ResidentGate(hipStream_t st);
+		~ResidentGate();
+		bool ok() const { return ok_; }
+		ResidentGate(const ResidentGate &) = delete;
+		ResidentGate &operator=(const ResidentGate &) = delete;
+
+	private:
+		hipStream_t st_;
+		void *gate_ = nullptr;
+		bool ok_ = false;
+	};
+
 	bool hip_ok(hipError_t e, const char *what); // logs "what: hipGetErrorString" on failure
 	hipError_t wait_stream(hipStream_t st);		  // polls the stream (short waits without the wake-up latency of a blocking one)
 

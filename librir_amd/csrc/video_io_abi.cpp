@@ -342,6 +342,42 @@ namespace
 		DeviceBuffer run_hist, run_tickets, run_bg; // runs of frames: histogram slices and tickets of a group of frames, backgrounds of the call
 		PinnedBuffer multi_stage;
 		hipEvent_t multi_copied = nullptr; // the copy out of multi_stage of the last call (whatever its stream) has completed
+		// A resident run that gave up a wait has advanced the stream's state with invalid frames: the failure is STICKY - every
+		// later step / status of a stream that took part in such a call fails until the stream is destroyed.  The error word lives
+		// with the call's leading stream and says "some call since the last check"; so the leader numbers the calls it led and
+		// keeps the ranges found invalid, and every member remembers who led its last run call and that call's number.
+		bool failed = false;
+		uint64_t led_calls = 0, led_clean = 0;					   // as a leader: run calls led / of those, known good at the last check
+		std::vector<std::pair<uint64_t, uint64_t>> led_bad;		   // calls in (first, second] are invalid
+		std::weak_ptr<Object> lead;								   // leader of the last run call this stream took part in (empty: itself)
+		uint64_t lead_call = 0;									   // that call's number with the leader (0: no run call yet)
+		LossyObject *leader()
+		{
+			if (lead_call == 0)
+				return nullptr;
+			auto l = lead.lock();
+			return l ? dynamic_cast<LossyObject *>(l.get()) : this;
+		}
+		bool is_failed()
+		{
+			if (failed)
+				return true;
+			if (LossyObject *l = leader())
+				for (const auto &r : l->led_bad)
+					if (lead_call > r.first && lead_call <= r.second)
+						failed = true;
+			return failed;
+		}
+		// files what a read of the error word (after a wait on the stream the calls were queued on) has shown
+		void checked(unsigned int gave_up, hipStream_t st)
+		{
+			if (gave_up)
+			{
+				led_bad.emplace_back(led_clean, led_calls);
+				(void)hipMemsetAsync(run_exchange.as<unsigned int>() + 16, 0, 4, st);
+			}
+			led_clean = led_calls;
+		}
 		~LossyObject() override
 		{
 			if (multi_copied)
@@ -484,7 +520,7 @@ namespace
 		// H264_Saver::addImageLossyNoCamera (h264.cpp:2253-2424)
 		bool add_image_lossy(const unsigned short *img, int64_t ts, AttrMap attrs)
 		{
-			if (!img || !open() || !lossy_ready())
+			if (!img || !usable() || !open() || !lossy_ready())
 				return false;
 			// The frame is uploaded and its kernels queued; nothing waits here.  Its error budget is decided on the device and
 			// collected later, for all the frames since the last collection at once (resolve_errors: when a chunk is written,
@@ -574,9 +610,20 @@ namespace
 		};
 		std::vector<Deferred> deferred;
 		DeviceBuffer d_err_slots;
+		// Sticky failure: once a bounded-loss run has given up (resolve_errors), the frames of the chunk being assembled and the
+		// loss state are invalid.  The saver takes no more frames, writes nothing more, and close() finishes the file with the
+		// chunks that were complete before.
+		bool failed = false;
+		bool usable()
+		{
+			if (!failed)
+				return true;
+			log_error("h264 saver: a bounded-loss step failed earlier; this saver takes no more frames (close it: the chunks written before the failure are kept)");
+			return false;
+		}
 		bool resolve_errors()
 		{
-			if (!run_deferred_loss())
+			if (!usable() || !run_deferred_loss())
 				return false;
 			if (deferred.empty())
 				return true;
@@ -588,9 +635,11 @@ namespace
 				(have_run && !hip_ok(hipMemcpyAsync(&gave_up, lossy_obj->run_exchange.as<unsigned int>() + 16, 4, hipMemcpyDeviceToHost, st), "D2H")) ||
 				!hip_ok(wait_stream(st), "sync"))
 				return false;
-			if (gave_up)
-			{
-				(void)hipMemsetAsync(lossy_obj->run_exchange.as<unsigned int>() + 16, 0, 4, st);
+			if (have_run)
+				lossy_obj->checked(gave_up, st);
+			if (gave_up || lossy_obj->is_failed())
+			{ // the loss state has been advanced by invalid frames: nothing recorded from here on can be right (usable())
+				failed = true;
 				log_error("h264 saver: the bounded-loss step of a run of frames gave up waiting (frames invalid)");
 				return false;
 			}
@@ -612,7 +661,7 @@ namespace
 		// H264_Saver::addLoss (h264.cpp:2426-2607): the loss is applied to the caller's image, nothing is written
 		bool add_loss(unsigned short *img)
 		{
-			if (!img || !open() || !lossy_ready())
+			if (!img || !usable() || !open() || !lossy_ready())
 				return false;
 			int lo = 0, hi = 0;
 			if (!resolve_errors() || !lossy->step(img, lossy_out.data(), true, removeBadPixels, lowValueError, highValueError, stdFactor, lo, hi))
@@ -789,7 +838,7 @@ namespace
 
 		bool add_image(const unsigned short *img, int64_t ts, const AttrMap &attrs)
 		{
-			if (!img || !open() || !run_deferred_loss())
+			if (!img || !usable() || !open() || !run_deferred_loss())
 				return false;
 			if (pending >= chunk_gop && !flush_chunk())
 				return false; // an earlier chunk could not be written: no slot is free, never write past the staging buffers
@@ -810,7 +859,7 @@ namespace
 		// a frame that is already in device memory (bounded-loss path): device-to-device into the chunk
 		bool add_image_device(const unsigned short *d_img, int64_t ts, const AttrMap &attrs)
 		{
-			if (!d_img || !open() || !run_deferred_loss())
+			if (!d_img || !usable() || !open() || !run_deferred_loss())
 				return false;
 			if (pending >= chunk_gop && !flush_chunk())
 				return false;
@@ -840,7 +889,17 @@ namespace
 			if (!opened)
 				return 0;
 			opened = false;
-			bool ok = flush_chunk();
+			bool ok = failed || flush_chunk();
+			if (failed)
+			{ // (flush_chunk may just have found it out) the frames since the last complete chunk are dropped, the file ends before them:
+			  // a valid file of the chunks written before the failure, which the calls that failed have reported
+				ok = true;
+				nframes -= (uint64_t)pending;
+				times.resize((size_t)nframes);
+				frame_attrs.resize((size_t)nframes);
+				pending = 0, uploaded = 0, raw_from = -1, raw_uploaded = 0;
+				deferred.clear();
+			}
 			stop_writer(); // every chunk is in the file from here on
 			ok = ok && !write_failed;
 			FileHeader hd;
@@ -2309,20 +2368,6 @@ RIR_EXPORT int rir_lossy_step_device(int handle, const unsigned short *d_in, uns
 	return 0;
 }
 
-// The run kernel's workgroups wait for each other, so all of them must be resident at once (lossy_kernels.h): two such launches
-// on different HIP streams could each hold a part of the chip and wait for the rest for ever.  Every launch therefore waits for
-// the previous one - whatever stream that was on - to have finished.
-static bool launch_run_alone(const LossyRun *d_table, int nstreams, int full_px, unsigned int *d_ticket, hipStream_t st)
-{
-	static std::mutex m;
-	static hipEvent_t last = nullptr;
-	std::lock_guard<std::mutex> lock(m);
-	if (!last && !hip_ok(hipEventCreateWithFlags(&last, hipEventDisableTiming), "event"))
-		return false;
-	return hip_ok(hipStreamWaitEvent(st, last, 0), "wait event") && hip_ok(launch_lossy_run(d_table, nstreams, full_px, d_ticket, st), "lossy run") &&
-		   hip_ok(hipEventRecord(last, st), "event");
-}
-
 // The same step for `nstreams` INDEPENDENT streams (one state object each, equal geometry and history length) with the streams
 // sharing every launch: frame f of all streams = three launches whose grids carry the stream in their second dimension
 // (the loss state is sequential in time, so streams - not frames - are what runs side by side).
@@ -2339,6 +2384,12 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 	const size_t npx = (size_t)os[0]->st.w * os[0]->st.h;
 	const bool want = low_errors || high_errors;
 	LossyObject &lead = *os[0]; // owns the scratch of the call: the table of steps and the budgets
+	for (int i = 0; i < nstreams; ++i)
+		if (os[i]->is_failed())
+		{
+			log_error("bounded-loss step: a run of frames of this stream gave up earlier - its state is invalid, destroy the stream");
+			return -1;
+		}
 	if (want && !d_errs && !lead.batch_errs.reserve((size_t)nstreams * nframes * 2 * sizeof(int)))
 		return -1;
 	// where the budget of frame f of stream i goes on the device: the caller's array, the call's own (read back below), or nowhere
@@ -2370,9 +2421,11 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 		// (more streams than the chip holds at once go through the resident kernel a batch of streams after the other: 6 streams of
 		// 640x512 per launch keep 0.49 M frames/s whatever the number of streams; a launch per frame for all of them does 0.30-0.43 M)
 		const char *max_env = getenv("RIR_LOSSY_RUN_MAX_WORKGROUPS"); // (tests: a smaller limit, to go through the batches with small frames)
-		const int max_wgs = max_env && atoi(max_env) > 0 ? std::min(atoi(max_env), kLossyRunMaxWorkgroups) : kLossyRunMaxWorkgroups;
-		const bool persistent = runs && errors_fit && run_wgs <= max_wgs && !getenv("RIR_LOSSY_LAUNCH_PER_FRAME");
-		const int batch = persistent ? std::min(nstreams, max_wgs / run_wgs) : nstreams; // streams per launch of the resident kernel
+		const int capacity = lossy_run_capacity();						 // what THIS device holds of the run kernel at once (0: unknown)
+		const int max_wgs = max_env && atoi(max_env) > 0 ? std::min(atoi(max_env), capacity) : capacity;
+		const ResidentPlan plan = resident_plan(max_wgs, run_wgs, nstreams); // (units_per_launch 0: a stream does not fit - launch per frame)
+		const bool persistent = runs && errors_fit && plan.units_per_launch > 0 && !getenv("RIR_LOSSY_LAUNCH_PER_FRAME");
+		const int batch = persistent ? plan.units_per_launch : nstreams; // streams per launch of the resident kernel
 		const int group = std::max(1, (persistent ? 2048 : 512) / nstreams); // frames per histogram launch (one 64 KB histogram slice per frame and stream)
 		const int ngroups = runs ? (nsteps + group - 1) / group : 0;
 		const size_t nfused = persistent ? 0 : runs ? (size_t)(nsteps + 1) * nstreams : (size_t)nsteps * nstreams, nhist = runs ? (size_t)nsteps * nstreams : 0;
@@ -2470,6 +2523,19 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 				}
 				if (!hip_ok(hipMemcpyAsync(lead.multi_table.ptr, hs, nb, hipMemcpyHostToDevice, st), "H2D") || !hip_ok(hipEventRecord(lead.multi_copied, st), "event"))
 					return -1;
+				// the call is on the leader's books before anything is queued: whatever happens from here on, a raised error word
+				// is charged to it
+				++lead.led_calls;
+				for (int i = 0; i < nstreams; ++i)
+				{
+					os[i]->lead_call = lead.led_calls;
+					if (i == 0)
+						os[i]->lead.reset();
+					else
+						os[i]->lead = lead.weak_from_this();
+				}
+				if (getenv("RIR_DEBUG_LOSSY_GIVE_UP") && !hip_ok(hipMemsetAsync(d_error, 1, 4, st), "memset")) // (tests: as if a wait had hit its clock)
+					return -1;
 				for (int g = 0; g < ngroups; ++g)
 				{
 					const int k0 = g * group, in_group = std::min(group, nsteps - k0);
@@ -2478,7 +2544,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 						!hip_ok(hipMemsetAsync(d_exch, 0, exch_bytes, st), "memset"))
 						return -1;
 					for (int s0 = 0; s0 < nstreams; s0 += batch)
-						if (!launch_run_alone(dr + (size_t)g * nstreams + s0, std::min(batch, nstreams - s0), full_px, d_ticket, st))
+						if (!hip_ok(launch_lossy_run(dr + (size_t)g * nstreams + s0, std::min(batch, nstreams - s0), full_px, d_ticket, st), "lossy run"))
 							return -1;
 				}
 			}
@@ -2553,10 +2619,14 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 				std::fprintf(stderr, "lossy run, per frame (us): sums+publish %.2f  poll %.2f  budget %.2f  barrier+update %.2f  (%llu frames)\n",
 							 dg[0] * 0.01 / dg[4], dg[1] * 0.01 / dg[4], dg[2] * 0.01 / dg[4], dg[3] * 0.01 / dg[4], dg[4]);
 		}
-		if (gave_up)
+		if (lead.run_exchange.ptr)
+			lead.checked(gave_up, st);
+		bool any_failed = false;
+		for (int i = 0; i < nstreams; ++i)
+			any_failed = os[i]->is_failed() || any_failed; // (every stream of the call is marked)
+		if (any_failed)
 		{
-			(void)hipMemsetAsync(lead.run_exchange.as<unsigned int>() + 16, 0, 4, st); // (reported once: later calls start clean)
-			log_error("rir_lossy_step_multi_device: a run of frames gave up waiting (results invalid)");
+			log_error("rir_lossy_step_multi_device: a run of frames gave up waiting (results invalid; the streams of the call take no more frames)");
 			return -1;
 		}
 		for (size_t i = 0; i < (size_t)nstreams * nframes; ++i)
@@ -2610,9 +2680,10 @@ RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, con
 	return lossy_step_streams(ptrs.data(), nstreams, d_in, d_out, nframes, add_loss, nullptr, low_errors, high_errors, (hipStream_t)stream);
 }
 
-// 0 when no run of frames stepped through this stream's object (as the leading stream of its call) has given up a wait between
-// workgroups since the last query, -1 otherwise (the frames of that call are invalid) or on an invalid handle.  Waits for the
-// work queued on `stream`.  Calls that return budgets check this themselves; queue-only calls (no error arrays) do not.
+// 0 when no run of frames this stream took part in has given up a wait between workgroups, -1 otherwise or on an invalid handle.
+// Waits for the work queued on `stream` (calls queued on other streams are not covered).  The failure is sticky: the stream's state
+// has been advanced by invalid frames, so from then on every status and every step of the stream - and of the streams that shared
+// the failed call - returns -1 until it is destroyed.  Calls that return budgets check this themselves; queue-only calls do not.
 RIR_EXPORT int rir_lossy_status(int handle, void *stream)
 {
 	auto o = lookup_as<LossyObject>(handle);
@@ -2621,16 +2692,19 @@ RIR_EXPORT int rir_lossy_status(int handle, void *stream)
 		log_error("rir_lossy_status: invalid handle");
 		return -1;
 	}
-	if (!o->run_exchange.ptr)
-		return hip_ok(wait_stream((hipStream_t)stream), "sync") ? 0 : -1;
+	hipStream_t st = (hipStream_t)stream;
+	// the error word is with the leader of the last run call this stream took part in (itself, for a call of its own)
+	LossyObject *l = o->leader();
+	std::shared_ptr<Object> keep = o->lead.lock(); // (keeps a foreign leader alive while it is read)
+	if (!l || !l->run_exchange.ptr)
+		return hip_ok(wait_stream(st), "sync") && !o->is_failed() ? 0 : -1;
 	unsigned int gave_up = 0;
-	if (!hip_ok(hipMemcpyAsync(&gave_up, o->run_exchange.as<unsigned int>() + 16, 4, hipMemcpyDeviceToHost, (hipStream_t)stream), "D2H") ||
-		!hip_ok(wait_stream((hipStream_t)stream), "sync"))
+	if (!hip_ok(hipMemcpyAsync(&gave_up, l->run_exchange.as<unsigned int>() + 16, 4, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
 		return -1;
-	if (gave_up)
+	l->checked(gave_up, st);
+	if (o->is_failed())
 	{
-		(void)hipMemsetAsync(o->run_exchange.as<unsigned int>() + 16, 0, 4, (hipStream_t)stream);
-		log_error("rir_lossy_status: a run of frames gave up waiting (results invalid)");
+		log_error("rir_lossy_status: a run of frames gave up waiting (results invalid; the stream takes no more frames)");
 		return -1;
 	}
 	return 0;

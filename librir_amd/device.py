@@ -56,7 +56,12 @@ class CodecLayout(ct.Structure):
     ]
 
 
+class CodecSlots(ct.Structure):
+    _fields_ = [("slots_offset_bytes", ct.c_int64), ("slot_words", ct.c_int64), ("seg_words_offset_bytes", ct.c_int64), ("nslots", ct.c_int64)]
+
+
 _vp = ct.c_void_p
+_lib.rir_codec_slots_query.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(CodecSlots)]
 _lib.rir_device_available.restype = ct.c_int
 _lib.rir_stream_synchronize.argtypes = [_vp]
 _lib.rir_codec_layout_query.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(CodecLayout)]
@@ -65,6 +70,11 @@ _lib.rir_codec_encode_single_pass_device.argtypes = [_vp, ct.c_int, ct.c_int, ct
 _lib.rir_codec_encode_status.argtypes = [_vp, _vp]
 _lib.rir_codec_encode_tiles_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, ct.c_longlong, _vp]
 _lib.rir_codec_encode_compact_device.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, ct.c_longlong, _vp]
+_lib.rir_codec_workspace_create_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_longlong, ct.POINTER(ct.c_void_p),
+                                                   ct.POINTER(ct.c_float), ct.POINTER(ct.c_int), _vp]
+_lib.rir_codec_workspace_destroy_device.argtypes = [_vp]
+_lib.rir_codec_workspace_destroy_device.restype = None
+_lib.rir_codec_decode_slots_device.argtypes = [_vp, _vp, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.rir_codec_decode_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.rir_codec_decode_chunks_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, ct.c_longlong, _vp,
                                                 _vp, _vp]
@@ -140,6 +150,26 @@ class EncodedBatch:
         return self.total_words() * 8 + L.hdr_bytes + L.tile_off_bytes + L.chunk_off_bytes
 
 
+class _LibraryBuffer:
+    """Device memory allocated by the library (rir_codec_workspace_create_device), seen from torch as a uint8 tensor that keeps
+    this object - and so the allocation - alive."""
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = int(ptr), int(nbytes)
+        self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2}
+
+    def tensor(self, device):
+        return torch.as_tensor(self, device=device)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.rir_codec_workspace_destroy_device(ct.c_void_p(self.ptr))
+                self.ptr = 0
+        except Exception:
+            pass
+
+
 class CodecContext:
     """Pre-allocated buffers for repeated encode/decode of one batch geometry (no allocation in
     the timed path)."""
@@ -169,55 +199,23 @@ class CodecContext:
         )
         return EncodedBatch(L, self.hdr, self.tile_off, self.chunk_off, self.stream)
 
-    def place_workspace(self, frames, tries=10, reps=5, spacing_bytes=3 << 29):
-        """Moves the encode workspace to where the packing kernel runs fastest for THIS frames buffer, by measurement.
-
-        The packing kernel streams the raw frames in and the sparse slots out, two regions of about the same size walked at the
-        same relative pace; its time depends on where the two allocations sit relative to each other (640x512x1000: 132-140 us,
-        or 147-154 us - the "slow mode" that had looked like a property of the box; along the address space stretches of some
-        10 GB of either kind alternate, tests/perf/enc_placement*.py, and a workspace allocated right after the frames is in
-        a slow one).  ``tries`` further workspaces are allocated, each
-        one ``spacing_bytes`` further along (the earlier candidates and the spacers between them stay alive meanwhile), the
-        packing pass is timed on each with HIP events and the fastest is kept.  One-off set-up cost of a few milliseconds and,
-        for its duration, ``tries`` x (workspace + spacing) of device memory; it stops early at the first candidate that is
-        7 % faster than the current placement.  Returns the list of measured times in microseconds, the kept one first."""
+    def place_workspace(self, frames, tries=10, spacing_bytes=3 << 29):
+        """Replaces the encode workspace by one the LIBRARY allocates where the packing kernel runs fast for THIS frames buffer
+        (rir_codec_workspace_create_device; DESIGN.md §5: device allocations fall into a few placement classes, and the kernel -
+        frames in, slots out at the same pace - is 10 % slower when both are of one class).  One-off set-up of a few
+        milliseconds; the candidates that lose and the spacers between them are freed by the library before it returns, torch's
+        allocator is not touched.  Returns the measured packing times in microseconds, the kept candidate's first."""
         L = self.layout
         fr = _frames3(frames, torch.uint16)
-
-        def t_pack(ws):
-            old, self.workspace = self.workspace, ws
-            try:
-                self.encode_tiles(fr)
-                torch.cuda.synchronize()
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-                ev[0].record()
-                for i in range(reps):
-                    self.encode_tiles(fr)
-                    ev[i + 1].record()
-                torch.cuda.synchronize()
-                return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))[reps // 2] * 1e3
-            finally:
-                self.workspace = old
-
-        cands = [(t_pack(self.workspace), self.workspace)]
-        spacers, ws = [], None
-        for _ in range(max(0, int(tries))):
-            try:
-                if spacing_bytes > 0:
-                    spacers.append(torch.empty((int(spacing_bytes),), dtype=torch.uint8, device=self.workspace.device))
-                ws = torch.empty((L.workspace_bytes,), dtype=torch.uint8, device=self.workspace.device)
-            except RuntimeError:  # (not enough memory for another candidate: keep the best so far)
-                break
-            cands.append((t_pack(ws), ws))
-            if cands[-1][0] < 0.93 * cands[0][0]:
-                break
-        del spacers
-        cands.sort(key=lambda c: c[0])
-        self.workspace = cands[0][1]
-        times = [c[0] for c in cands]
-        del cands, ws
-        torch.cuda.empty_cache()  # (the spacers and the candidates that lost go back to the device, not into torch's cache)
-        return times
+        if tuple(fr.shape) != (L.nframes, L.height, L.width):
+            raise RuntimeError("place_workspace: frames do not match the context geometry")
+        ptr = ct.c_void_p()
+        times = (ct.c_float * (int(tries) + 1))()
+        nt = ct.c_int(0)
+        _check(_lib.rir_codec_workspace_create_device(fr.data_ptr(), L.width, L.height, L.nframes, L.gop, int(tries), int(spacing_bytes), ct.byref(ptr),
+                                                      times, ct.byref(nt), _stream()), "rir_codec_workspace_create_device")
+        self.workspace = _LibraryBuffer(ptr.value, L.workspace_bytes).tensor(self.hdr.device)
+        return [float(times[i]) for i in range(nt.value)]
 
     def encode_status(self):
         """0 when the last single-pass encode completed, 1 when one of its look-backs gave up (waits for the stream)"""
@@ -231,6 +229,34 @@ class CodecContext:
             raise RuntimeError("encode: frames do not match the context geometry")
         _check(_lib.rir_codec_encode_tiles_device(fr.data_ptr(), L.width, L.height, L.nframes, L.gop, self.hdr.data_ptr(),
                                                   self.workspace.data_ptr(), L.workspace_bytes, _stream()), "rir_codec_encode_tiles_device")
+
+    def slots(self):
+        """Views of the slotted form inside the workspace (valid after encode_tiles): (seg_words int32[nchunks, ntiles] - bit
+        pattern uint32 -, slots int64[nchunks, ntiles, slot_words] - bit pattern uint64)."""
+        L = self.layout
+        S = CodecSlots()
+        _check(_lib.rir_codec_slots_query(L.width, L.height, L.nframes, L.gop, ct.byref(S)), "rir_codec_slots_query")
+        n = L.nchunks * L.ntiles
+        seg = self.workspace[S.seg_words_offset_bytes:S.seg_words_offset_bytes + n * 4].view(torch.int32).view(L.nchunks, L.ntiles)
+        sl = self.workspace[S.slots_offset_bytes:S.slots_offset_bytes + n * S.slot_words * 8].view(torch.int64).view(L.nchunks, L.ntiles, S.slot_words)
+        return seg, sl
+
+    def slots_payload_bytes(self):
+        """payload bytes of the slotted batch in the workspace (sum of the segment lengths)"""
+        return int(self.slots()[0].to(torch.int64).sum().item()) * 8
+
+    def decode_slots(self, out=None, check=True):
+        """decode of the slotted form left by encode_tiles (rir_codec_decode_slots_device): no second encoder pass"""
+        L = self.layout
+        if out is None:
+            out = torch.empty((L.nframes, L.height, L.width), dtype=torch.uint16, device=self.hdr.device)
+        if check:
+            self.error.zero_()
+        _check(_lib.rir_codec_decode_slots_device(self.hdr.data_ptr(), self.workspace.data_ptr(), L.workspace_bytes, L.width, L.height, L.nframes,
+                                                  L.gop, out.data_ptr(), self.error.data_ptr(), _stream()), "rir_codec_decode_slots_device")
+        if check and int(self.error.item()) != 0:
+            raise RuntimeError("rir_codec_decode_slots_device: malformed stream")
+        return out
 
     def encode_compact(self):
         L = self.layout

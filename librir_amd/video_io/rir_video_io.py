@@ -6,6 +6,7 @@ in and out, ``RuntimeError`` when the library reports a failure.
 """
 import ctypes as ct
 import sys
+import weakref
 
 import numpy as np
 
@@ -127,22 +128,31 @@ def supported_calibrations(camera):
     return out
 
 
-_recycled = {}  # (h, w) -> a few arrays handed out earlier
+_free_blocks = {}  # (h, w) -> a few memory blocks whose image arrays have died
 
 
 def _image_buffer(h, w):
-    """A (h, w) uint16 array for the next image.  A reader that iterates over a movie drops each image before it asks for the next
-    one; a fresh 640x512 array then costs its 160 page faults (30-40 us, as much as the read itself).  Arrays handed out earlier
-    are therefore remembered, and one is handed out again once NOTHING else refers to it any more (its reference count says so:
-    a caller that keeps the image, or a view of it, keeps it for good)."""
-    pool = _recycled.setdefault((h, w), [])
-    for a in pool:
-        if sys.getrefcount(a) == 3:  # the list, the loop variable, getrefcount's argument
-            return a
-    a = np.empty((h, w), dtype=np.uint16)
-    if len(pool) < 4:
-        pool.append(a)
+    """A fresh (h, w) uint16 array for the next image, as the reference returns (rir_video_io.py load_image: a new array per
+    call) - over RECYCLED memory where that is safe.  A reader that iterates over a movie drops each image before it asks for
+    the next one; a fresh 640x512 allocation then costs its 160 page faults (30-40 us, as much as the read itself).  The memory
+    of an image is a block of its own; the array handed out is built directly on that block (views of it therefore keep IT alive:
+    numpy stops collapsing ``base`` chains at the first non-array), and a weak-reference finaliser returns the block to the pool
+    when the array object is collected - i.e. when neither the caller nor any view of the image refers to it any more.  No
+    reference counts are inspected: an image the caller keeps is never written to again."""
+    pool = _free_blocks.setdefault((h, w), [])
+    try:
+        block = pool.pop()
+    except IndexError:
+        block = bytearray(h * w * 2)
+    a = np.ndarray((h, w), dtype=np.uint16, buffer=block)
+    f = weakref.finalize(a, _recycle_block, pool, block)
+    f.atexit = False
     return a
+
+
+def _recycle_block(pool, block):
+    if len(pool) < 4:
+        pool.append(block)
 
 
 def load_image(camera, pos, calibration=0, shape=None):

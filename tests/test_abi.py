@@ -111,3 +111,56 @@ def test_hash_bytes_matches_reference(lib):
     for n in [0, 1, 7, 8, 9, 15, 16, 31, 1000]:
         buf = rng.integers(0, 256, max(n, 1)).astype(np.uint8)
         assert lib.hash_bytes(buf.ctypes.data, n) == r.lib.hash_bytes(buf.ctypes.data, n)
+
+
+def test_resident_capacity_rule_and_plan(lib):
+    """The selection logic behind every kernel whose workgroups wait for each other (runtime.h: resident launches): how many
+    workgroups a device holds at once - with a margin per XCD - and how units (streams, sequences) are dealt to launches,
+    including "a unit does not fit: take the launch-per-frame / launch-per-iteration path" (units per launch 0)."""
+    lib.rir_resident_capacity_rule.argtypes = [ct.c_int] * 3
+    lib.rir_resident_plan.argtypes = [ct.c_int] * 3 + [ct.POINTER(ct.c_int)]
+    rule = lib.rir_resident_capacity_rule
+    assert rule(5, 256, 8) == 1200  # MI355X, 5 workgroups of the loss kernel per CU: 8 x (160 - 10)
+    assert rule(1, 256, 8) == 8 * (32 - 2)
+    assert rule(8, 256, 8) == 8 * (256 - 16)
+    assert rule(5, 32, 1) == 160 - 10  # one XCD (a CPX partition)
+    assert rule(5, 250, 8) == 1250 - 78  # CUs not a multiple of the XCD count: treated as one pool
+    assert rule(1, 8, 8) == 0 and rule(0, 256, 8) == 0 and rule(5, 0, 8) == 0 and rule(-1, 256, 8) == 0
+    assert rule(2, 8, 8) == 8  # at least one place per XCD stays free
+
+    def plan(capacity, wgs, units):
+        out = (ct.c_int * 2)()
+        assert lib.rir_resident_plan(capacity, wgs, units, out) == 0
+        return out[0], out[1]
+
+    assert plan(1200, 160, 7) == (7, 1)  # seven 640x512 streams in one launch
+    assert plan(1200, 160, 32) == (7, 5)
+    assert plan(1200, 160, 1) == (1, 1)
+    assert plan(1200, 1201, 3) == (0, 0)  # a stream does not fit: not resident
+    assert plan(0, 160, 3) == (0, 0)  # the runtime could not size the device: not resident
+    assert plan(240, 256, 1) == (0, 0) and plan(240, 240, 2) == (1, 2)
+    assert lib.rir_resident_plan(1, 1, 1, None) == -1
+
+
+def test_image_arrays_are_fresh_and_recycled_only_when_dead():
+    """load_image returns a new array per call (reference rir_video_io.py); the memory of an image is handed out again only once
+    neither the caller nor any view refers to the array any more - no reference counts are inspected."""
+    from librir_amd.video_io import rir_video_io as R
+
+    shape = (6, 10)
+    a = R._image_buffer(*shape)
+    a[:] = 7
+    addr = a.ctypes.data
+    view = a[2:4]
+    del a
+    b = R._image_buffer(*shape)
+    b[:] = 9
+    assert b.ctypes.data != addr and (view == 7).all()  # the view keeps the first image
+    del view
+    c = R._image_buffer(*shape)
+    assert c.ctypes.data == addr and c.flags.writeable and c.shape == shape and c.dtype == np.uint16
+    kept = [R._image_buffer(*shape) for _ in range(12)]
+    for i, k in enumerate(kept):
+        k[:] = i
+    assert len({k.ctypes.data for k in kept}) == 12 and all((k == i).all() for i, k in enumerate(kept))
+    assert (b == 9).all()

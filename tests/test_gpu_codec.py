@@ -271,8 +271,8 @@ def test_identity_with_offsets_beyond_4_gib(dev):
 
 
 def test_workspace_placement_keeps_the_results(oracle):
-    """CodecContext.place_workspace moves the encode workspace to where the packing kernel measures fastest: the encoded batch is
-    the same bit for bit afterwards (it reports the candidates' times, the kept one first)."""
+    """CodecContext.place_workspace (rir_codec_workspace_create_device: the library allocates candidates, times the packing
+    kernel on each, keeps one, frees the rest): the encoded batch is the same bit for bit afterwards, in both forms."""
     import torch
 
     from librir_amd import device as D
@@ -285,9 +285,108 @@ def test_workspace_placement_keeps_the_results(oracle):
     words = int(e0.total_words())
     ref = (e0.hdr.clone(), e0.tile_off.clone(), e0.chunk_off.clone(), e0.stream[:words].clone())
     times = ctx.place_workspace(fr, tries=3, spacing_bytes=64 << 20)
-    assert len(times) >= 1 and times == sorted(times)
+    assert 1 <= len(times) <= 4 and times[0] == min(times)
     e1 = ctx.encode(fr)
     assert int(e1.total_words()) == words
     assert torch.equal(e1.hdr, ref[0]) and torch.equal(e1.tile_off, ref[1]) and torch.equal(e1.chunk_off, ref[2]) and torch.equal(e1.stream[:words], ref[3])
     out = ctx.decode(e1)
     assert torch.equal(out.view(torch.int16), fr.view(torch.int16))
+    ctx.encode_tiles(fr)
+    assert torch.equal(ctx.decode_slots().view(torch.int16), fr.view(torch.int16))
+    del ctx  # (the library's allocation goes with the context)
+    torch.cuda.synchronize()
+
+
+def _case_frames(name, shape):
+    n, h, w = shape
+    rng = np.random.default_rng(abs(hash(name)) % 1000)
+    if name == "noisy_small":
+        return s1_noisy_background(n, h, w)
+    if name == "uniform":
+        return s2_uniform_dl_ti(n, h, w)
+    if name == "long_chunk":
+        return (np.cumsum(np.ones((n, h, w), np.uint32), axis=2) * 5 + np.arange(n)[:, None, None] * 300).astype(np.uint16)
+    if name.startswith("ref_shape"):
+        return s1_noisy_background(n, h, w, seed=9)
+    return rng.integers(0, 65536, shape).astype(np.uint16)
+
+
+@pytest.mark.parametrize("name,shape,gop", CASES)
+def test_slotted_form_equals_oracle_and_decodes_without_the_second_pass(dev, oracle, name, shape, gop):
+    """What stage 1 of the encoder leaves (rir_codec_encode_tiles_device: headers + one length and one slot per segment) is a
+    complete encoded batch: segment by segment it is the oracle's stream (same words, located by position instead of by
+    offsets), the oracle decodes it, and rir_codec_decode_slots_device decodes it as it is."""
+    import torch
+
+    n, h, w = shape
+    fr = _case_frames(name, shape)
+    ctx = dev.CodecContext(w, h, n, gop)
+    t = torch.from_numpy(fr).cuda()
+    ctx.encode_tiles(t)
+    dec = ctx.decode_slots()
+    assert np.array_equal(dec.cpu().numpy(), fr)
+    seg, slots = ctx.slots()
+    seg = seg.cpu().numpy().view(np.uint32)
+    slots = slots.cpu().numpy().view(np.uint64)
+    hdr = ctx.hdr.cpu().numpy().view(np.uint64)
+    L = ctx.layout
+    for c in range(L.nchunks):
+        f0 = c * gop
+        nf = min(gop, n - f0)
+        h_o, o_o, st_o = oracle.codec_encode_chunk(fr[f0:f0 + nf])
+        assert np.array_equal(hdr[c][:, :nf], h_o), (name, c)
+        assert np.array_equal(seg[c], np.diff(o_o)), (name, c)
+        dense = np.concatenate([slots[c, t_, :seg[c, t_]] for t_ in range(L.ntiles)])
+        assert np.array_equal(dense, st_o), (name, c)
+        assert np.array_equal(oracle.codec_decode_chunk(hdr[c][:, :nf], o_o, dense, w, h), fr[f0:f0 + nf])
+    # and stage 2 makes the dense form out of exactly these slots
+    enc = ctx.encode_compact()
+    assert np.array_equal(ctx.decode(enc).cpu().numpy(), fr)
+    assert ctx.slots_payload_bytes() == enc.total_words() * 8
+
+
+def test_gpu_decodes_oracle_stream_scattered_into_slots(dev, oracle):
+    """cross-read the other way: segments written by the CPU restatement, put into slots on the host, decode on the GPU"""
+    import torch
+
+    n, h, w, gop = 9, 40, 52, 4
+    fr = s1_noisy_background(n, h, w, seed=3)
+    ctx = dev.CodecContext(w, h, n, gop)
+    L = ctx.layout
+    seg_t, slots_t = ctx.slots()
+    seg = np.zeros(tuple(seg_t.shape), np.uint32)
+    slots = np.full(tuple(slots_t.shape), 0xDEADBEEFDEADBEEF, np.uint64)
+    hdr = np.zeros((L.nchunks, L.ntiles, gop), np.uint64)
+    for c in range(L.nchunks):
+        nf = min(gop, n - c * gop)
+        h_o, o_o, s_o = oracle.codec_encode_chunk(fr[c * gop:c * gop + nf])
+        hdr[c][:, :nf] = h_o
+        seg[c] = np.diff(o_o)
+        for t_ in range(L.ntiles):
+            slots[c, t_, :seg[c, t_]] = s_o[o_o[t_]:o_o[t_ + 1]]
+    ctx.hdr.copy_(torch.from_numpy(hdr.view(np.int64)))
+    seg_t.copy_(torch.from_numpy(seg.view(np.int32)))
+    slots_t.copy_(torch.from_numpy(slots.view(np.int64)))
+    assert np.array_equal(ctx.decode_slots().cpu().numpy(), fr)
+    # a length that does not match the headers is refused
+    seg_t[1, 0] += 1
+    with pytest.raises(RuntimeError):
+        ctx.decode_slots()
+
+
+def test_slotted_identity_at_baseline_size(dev):
+    """configs[1] at full size through the two-launch path (encode_tiles + decode_slots), and the dense form made from the
+    same slots decodes to the same frames"""
+    import torch
+
+    n, h, w = 1000, 512, 640
+    fr = torch.from_numpy(s1_noisy_background(n, h, w)).cuda()
+    ctx = dev.CodecContext(w, h, n, 50)
+    ctx.encode_tiles(fr)
+    out = ctx.decode_slots()
+    assert torch.equal(out.view(torch.int16), fr.view(torch.int16))
+    enc = ctx.encode_compact()
+    assert ctx.slots_payload_bytes() == enc.total_words() * 8
+    assert fr.numel() * 2 / enc.compressed_bytes() > 4.85
+    out.zero_()
+    assert torch.equal(ctx.decode(enc, out=out).view(torch.int16), fr.view(torch.int16))

@@ -1,0 +1,185 @@
+"""GPU: the process-wide gate for kernels whose workgroups wait for each other inside a launch (runtime.h: resident launches;
+reference threading model: handles of different objects may be driven from different threads, tools.cpp:46-50), and the
+sticky failure of a bounded-loss run that gave up."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from librir_amd.synthetic import s1_noisy_background, s3_registration
+
+pytestmark = pytest.mark.gpu
+
+
+def test_three_resident_kernel_families_from_three_threads(dev):
+    """7-stream bounded-loss runs (lossy_run_kernel, 1 120 of the chip's ~1 200 places), tracked-sequence alignments
+    (ecc_run_kernel: 256 workgroups that poll each other) and single-pass encodes (rirb1_encode_dense: look-back between
+    workgroups), each driven from a thread of its own on a stream of its own, at the same time: every result equals the one
+    the same call gives alone, no status is raised, and no call comes near the 2 s clock of a wait between workgroups."""
+    import torch
+
+    from librir_amd import device as D
+    from librir_amd.registration import DeviceRegistratorECC
+
+    S, nl, h, w = 7, 40, 512, 640
+    rounds = 6
+    lossy_in = [torch.from_numpy(s1_noisy_background(nl, h, w, seed=50 + i)).cuda() for i in range(S)]
+    f, _ = s3_registration(61, h, w)
+    ecc_in = torch.from_numpy(f).cuda()
+    enc_in = torch.from_numpy(s1_noisy_background(300, h, w, seed=77)).cuda()
+
+    def lossy_call():
+        streams = [D.LossyStream(w, h, h - 3, 6, 2, 5.0, 8) for _ in range(S)]
+        outs, lo, hi = D.LossyStream.step_many(streams, lossy_in)
+        for s in streams:
+            s.status()
+            s.close()
+        return [o.cpu().numpy() for o in outs], lo.copy(), hi.copy()
+
+    def ecc_call():
+        r = DeviceRegistratorECC(0.7, 0.7, shape=(h, w))
+        r.start(ecc_in[0])
+        r.compute_many(ecc_in[1:], chunk=20)
+        return list(r.x), list(r.y), list(r.confidences)
+
+    ctx = D.CodecContext(w, h, 300, 50)
+
+    def enc_call():
+        e = ctx.encode(enc_in, single_pass=True)
+        st = ctx.encode_status()
+        return st, e.hdr.cpu().numpy().copy(), e.tile_off.cpu().numpy().copy(), e.chunk_off.cpu().numpy().copy(), \
+            e.stream[:e.total_words()].cpu().numpy().copy()
+
+    # the single-threaded answers
+    ref_lossy, ref_ecc, ref_enc = lossy_call(), ecc_call(), enc_call()
+    assert ref_enc[0] == 0
+    torch.cuda.synchronize()
+
+    results, errors, longest = {}, [], {}
+    start = threading.Barrier(3)
+
+    def worker(name, fn):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                start.wait()
+                got, worst = [], 0.0
+                for _ in range(rounds):
+                    t0 = time.perf_counter()
+                    got.append(fn())
+                    worst = max(worst, time.perf_counter() - t0)
+                results[name], longest[name] = got, worst
+        except Exception as e:  # noqa: BLE001
+            errors.append((name, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=a) for a in (("lossy", lossy_call), ("ecc", ecc_call), ("enc", enc_call))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    assert set(results) == {"lossy", "ecc", "enc"}
+    for outs, lo, hi in results["lossy"]:
+        assert all(np.array_equal(a, b) for a, b in zip(outs, ref_lossy[0])) and np.array_equal(lo, ref_lossy[1]) and np.array_equal(hi, ref_lossy[2])
+    for r in results["ecc"]:
+        assert r == ref_ecc
+    for r in results["enc"]:
+        assert r[0] == 0 and all(np.array_equal(a, b) for a, b in zip(r[1:], ref_enc[1:]))
+    # a wait between workgroups that gives up costs 2 s: nothing came near (the calls include their Python glue and D2H copies)
+    assert max(longest.values()) < 1.0, longest
+
+
+def test_a_run_that_gave_up_is_sticky(dev, monkeypatch, tmp_path):
+    """A resident run that gives up a wait (forced through RIR_DEBUG_LOSSY_GIVE_UP) has advanced the stream's state with invalid
+    frames: the call fails, every later step and status of EVERY stream of that call fails, a stream that was not part of it
+    goes on; a saver in that state takes no more frames, writes nothing of the chunk that was being assembled and closes into a
+    readable file that ends with the last complete chunk."""
+    import torch
+
+    from librir_amd import device as D
+    from librir_amd.video_io import IRMovie, IRSaver
+
+    n, h, w = 12, 64, 96
+    fr = [torch.from_numpy(s1_noisy_background(n, h, w, seed=3 + i)).cuda() for i in range(3)]
+    a, b, c = (D.LossyStream(w, h, h - 3) for _ in range(3))
+    D.LossyStream.step_many([a, b], [fr[0][:4], fr[1][:4]])
+    c.step(fr[2][:4])
+    monkeypatch.setenv("RIR_DEBUG_LOSSY_GIVE_UP", "1")
+    with pytest.raises(RuntimeError):
+        D.LossyStream.step_many([a, b], [fr[0][4:8], fr[1][4:8]])
+    monkeypatch.delenv("RIR_DEBUG_LOSSY_GIVE_UP")
+    for s in (a, b):
+        with pytest.raises(RuntimeError):
+            s.step(fr[0][8:])
+        with pytest.raises(RuntimeError):
+            s.status()
+    c.step(fr[2][4:])
+    c.status()
+    # queue-only calls find it out at the status query, for the member as well as for the leader
+    d, e = D.LossyStream(w, h, h - 3), D.LossyStream(w, h, h - 3)
+    D.LossyStream.step_many([d, e], [fr[0][:4], fr[1][:4]], errors=False)
+    monkeypatch.setenv("RIR_DEBUG_LOSSY_GIVE_UP", "1")
+    D.LossyStream.step_many([d, e], [fr[0][4:8], fr[1][4:8]], errors=False)
+    monkeypatch.delenv("RIR_DEBUG_LOSSY_GIVE_UP")
+    with pytest.raises(RuntimeError):
+        e.status()
+    with pytest.raises(RuntimeError):
+        d.status()
+    with pytest.raises(RuntimeError):
+        e.step(fr[1][8:])
+    for s in (a, b, c, d, e):
+        s.close()
+
+    # the saver: GOP 5, 12 good frames (two chunks written, two frames pending), then a run that gives up
+    p = str(tmp_path / "sticky.h264")
+    data = s1_noisy_background(30, h, w, seed=9)
+    s = IRSaver(p, w, h, h - 3)
+    s.set_parameter("GOP", 5)
+    for i in range(12):
+        s.add_image_lossy(data[i], i)
+    monkeypatch.setenv("RIR_DEBUG_LOSSY_GIVE_UP", "1")
+    failed_at = None
+    for i in range(12, 20):
+        try:
+            s.add_image_lossy(data[i], i)
+        except RuntimeError:
+            failed_at = i
+            break
+    monkeypatch.delenv("RIR_DEBUG_LOSSY_GIVE_UP")
+    assert failed_at is not None and failed_at <= 15  # the chunk that completes at frame 14 runs its deferred loss step
+    for i in range(failed_at, failed_at + 3):
+        with pytest.raises(RuntimeError):
+            s.add_image_lossy(data[i], i)
+        with pytest.raises(RuntimeError):
+            s.add_image(data[i], i)
+    s.close()
+    with IRMovie.from_filename(p) as mov:
+        assert mov.images == 10  # the two complete chunks; nothing of the failed one
+        ok = IRSaver(str(tmp_path / "ok.h264"), w, h, h - 3)
+        ok.set_parameter("GOP", 5)
+        for i in range(10):
+            ok.add_image_lossy(data[i], i)
+        ok.close()
+        with IRMovie.from_filename(str(tmp_path / "ok.h264")) as good:
+            assert np.array_equal(mov.data, good.data)
+
+
+def test_images_kept_by_the_caller_survive_later_reads(tmp_path):
+    """an image the caller still holds (or a view of it) is never written to by a later load_image"""
+    from librir_amd.video_io import IRMovie, IRSaver
+
+    n, h, w = 30, 64, 96
+    data = s1_noisy_background(n, h, w, seed=4)
+    p = str(tmp_path / "keep.h264")
+    with IRSaver(p, w, h, h) as s:
+        for i in range(n):
+            s.add_image(data[i], i)
+    with IRMovie.from_filename(p) as mov:
+        kept = [mov[i] for i in range(8)]
+        views = [mov[8 + i][3:9] for i in range(4)]
+        for i in range(12, n):
+            assert np.array_equal(mov[i], data[i])  # dropped at once: their memory goes round
+        for i in range(8):
+            assert np.array_equal(kept[i], data[i])
+        for i in range(4):
+            assert np.array_equal(views[i], data[8 + i][3:9])
