@@ -305,6 +305,17 @@ def other_paths(D, frames, h, w):
         reg.compute_many(tf[1:])
 
     res["ecc_tracked_sequence_fps"] = rate(track, nreg - 1)
+    # eight independent sequences side by side (rir_ecc_align_multi_device): each one's track is bit-identical to its solo run
+    S8 = 8
+    seqs = [tf] + [torch.from_numpy(s3_registration(nreg, h, w, seed=99 + q)[0]).to(frames.device) for q in range(1, S8)]
+
+    def track8():
+        regs = [DeviceRegistratorECC(1, 1, shape=(h, w)) for _ in range(S8)]
+        for q in range(S8):
+            regs[q].start(seqs[q][0])
+        DeviceRegistratorECC.compute_many_multi(regs, [s_[1:] for s_ in seqs])
+
+    res["ecc_tracked_8_sequences_fps"] = rate(track8, S8 * (nreg - 1))
     res["note"] = "best of 3; %d-frame calls of the bounded-loss step (low = high = 3, stdFactor 0, 509 lossy rows), %d float32 S3 frames for the registration" % (m, nreg)
     return res
 

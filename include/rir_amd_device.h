@@ -226,6 +226,15 @@ extern "C"
 	 * an invalid call.  warp: HOST float[2], start value in, last good result out. */
 	int rir_ecc_align_prepared_frames_device(const float *d_ref_norm, const float *d_norm, const float *d_gx, const float *d_gy, int w, int h, int nframes,
 											 float *warp, int max_iterations, double eps, double *results, void *stream);
+	/* The alignments of nseq INDEPENDENT tracked sequences side by side in shared resident launches: for every sequence the
+	 * operations of rir_ecc_align_prepared_frames_device in the same order (same bits), but S dependent chains at once instead of
+	 * one - an alignment is a chain of iterations and cannot fill the chip on its own (masked_registration_ecc.py:105-191 is
+	 * one such chain per camera).  All sequences share the window size w x h; d_ref_norm, d_norm, d_gx, d_gy: HOST arrays of nseq
+	 * device pointers ([h][w] / [nframes[q]][h][w]); warps: HOST [nseq][2] in/out; results: HOST [nseq][results_stride][4]
+	 * doubles (tx, ty, cc, iterations); good: HOST [nseq] = images of that sequence aligned before its first failure. */
+	int rir_ecc_align_multi_device(const float *const *d_ref_norm, const float *const *d_norm, const float *const *d_gx, const float *const *d_gy, int w,
+								   int h, int nseq, const int *nframes, float *warps, int max_iterations, double eps, double *results, int results_stride,
+								   int *good, void *stream);
 	/* One frame of a tracked sequence in one call - the steps of MaskedRegistratorECC.compute (masked_registration_ecc.py:88-168):
 	 * gaussian pre-filter (sigma > 0), min-max normalisation of the registration window and the alignment against the
 	 * already normalised reference window d_ref_norm [win_h][win_w], queued back to back with one read-back at the end.

@@ -54,6 +54,19 @@ namespace rir
 		double rho;
 		int iter, done;
 	};
+	// one tracked sequence of a multi-sequence launch (ecc_run_multi_kernel): device pointers, plain data
+	struct EccSeq
+	{
+		const float *templ;			  // [h][w] the sequence's normalised reference window
+		const float *image, *gx, *gy; // [nframes][h][w] prepared images and their gradients
+		double *rows;				  // ecc_run_workspace_bytes(w, h) of the sequence's own: rows of granules, then its pub granule
+		EccFrameResult *results;	  // [nframes]
+		float tx0, ty0;				  // start value of the first alignment
+		int nframes, frames_done;	  // frames_done: left by the kernel (images gone through; the last of them may have failed)
+	};
+	int ecc_run_multi_capacity(); // resident workgroups of ecc_run_multi_kernel on the current device (runtime.h), 0 = unknown
+	int ecc_rows(int w, int h);	  // rows of partial sums of an alignment of a w x h window (= workgroups of a solo run)
+	hipError_t launch_ecc_run_multi(EccSeq *d_table, int nseq, int nslices, int w, int h, int max_iter, double eps, unsigned int epoch, hipStream_t st);
 	size_t ecc_run_workspace_bytes(int w, int h);
 	int ecc_run_capacity();			  // resident workgroups of ecc_run_kernel on the current device (runtime.h), 0 = unknown
 	bool ecc_run_fits(int w, int h);  // the grid of an alignment of a w x h window fits: the one-launch forms may be used

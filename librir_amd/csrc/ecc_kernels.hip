@@ -79,7 +79,19 @@ namespace rir
 #ifdef RIR_ECC_DIAG
 	static __shared__ unsigned long long ecc_diag_loop_end, ecc_diag_reduced; // (written by every thread with about the same value)
 #endif
+#ifndef RIR_ECC_PIXELS_PER_ROUND
+#define RIR_ECC_PIXELS_PER_ROUND 3 /* one sequence, one wave per SIMD: 19.3 k frames/s; 2: 18.8 k, 6: 19.3 k at 226 VGPRs */
+#endif
+#ifndef RIR_ECC_MULTI_PIXELS_PER_ROUND
+#define RIR_ECC_MULTI_PIXELS_PER_ROUND 5 /* several sequences: a row's 5 pixels per thread (640x512) in one round */
+#endif
+#ifndef RIR_ECC_MULTI_WAVES
+#define RIR_ECC_MULTI_WAVES 3 /* 168 VGPRs, no scratch.  8 sequences of 640x512, k frames/s aggregate (scripts/ecc_multi_variants.sh): (5, 3) 67-71,
+                                 (1, 4) 65-68, (2, 4) 62-65, (3, 4) 54-57, (5, 2) 57-59: the pixel loops are VALU-bound (102 vector instructions
+                                 per pixel, 25 of them double-precision), what differs is how evenly the rows land on the CUs */
+#endif
 	// the 15 sums of workgroup `blk` of `nblk` at translation (tx, ty), reduced over the workgroup (fixed order); valid in threads < ECC_NSUMS
+	template <int R> // pixels per round: their 13 R loads are in flight together; the sums are taken in pixel order whatever R is
 	__device__ __forceinline__ double ecc_block_sums(const float *__restrict__ templ, const float *__restrict__ image, const float *__restrict__ gximg,
 													 const float *__restrict__ gyimg, const uint8_t *__restrict__ mask, int w, int h, float tx, float ty, int blk,
 													 int nblk, EccReduceLds &red)
@@ -147,10 +159,6 @@ namespace rir
 		{
 			const int i0 = blk * ECC_BLOCK + (int)threadIdx.x;
 			int y = i0 / w, x = i0 - y * w; // (the thread's first pixel; meaningless, and unused, when i0 >= npx)
-#ifndef RIR_ECC_PIXELS_PER_ROUND
-#define RIR_ECC_PIXELS_PER_ROUND 3 /* 19.3 k frames/s; 2: 18.8 k, 6: 19.3 k at 226 VGPRs */
-#endif
-			constexpr int R = RIR_ECC_PIXELS_PER_ROUND;
 			for (int i = i0; i < npx; i += R * stride)
 			{ // R pixels per round: their 13 R loads are in flight together (a thread has 5 pixels at 640x512); sums are taken in pixel order
 				Px px[R];
@@ -213,7 +221,7 @@ namespace rir
 		if (state->done)
 			return;
 		__shared__ EccReduceLds red;
-		const double v = ecc_block_sums(templ, image, gximg, gyimg, mask, w, h, state->tx, state->ty, blockIdx.x, gridDim.x, red);
+		const double v = ecc_block_sums<RIR_ECC_PIXELS_PER_ROUND>(templ, image, gximg, gyimg, mask, w, h, state->tx, state->ty, blockIdx.x, gridDim.x, red);
 		if (threadIdx.x < ECC_NSUMS)
 			partials[(size_t)blockIdx.x * 16 + threadIdx.x] = v; // rows of 16 doubles (ecc_rows_total)
 	}
@@ -410,7 +418,7 @@ namespace rir
 			const unsigned long long dg0 = __builtin_amdgcn_s_memrealtime();
 			unsigned long long dg1 = 0, dg2 = 0, dg3 = 0;
 #endif
-			const double v = ecc_block_sums(templ, image, gximg, gyimg, mask, w, h, tx, ty, b, nblk, red);
+			const double v = ecc_block_sums<RIR_ECC_PIXELS_PER_ROUND>(templ, image, gximg, gyimg, mask, w, h, tx, ty, b, nblk, red);
 			// hand-off without fences (a release / acquire pair at agent scope writes back and invalidates whole caches: 227 us per
 			// frame against 139 with two launches per iteration) and without a drain: every sum travels as a granule {value, flag}
 			if (tid < ECC_NSUMS)
@@ -487,6 +495,144 @@ namespace rir
 			if (host_view)
 				ecc_report(host_view, st, done);
 		}
+	}
+
+	// ---- S independent tracked sequences in ONE launch --------------------------------------------------------------------
+	//
+	// An alignment is a dependent chain (iteration after iteration, image after image): one sequence cannot use more of the chip
+	// than one iteration's pixels, and most of an iteration is latency - of the taps at one wave per SIMD and of two hand-offs
+	// between workgroups.  Independent sequences ("R1 ... replicas") are what can run side by side: sequence q =
+	// blockIdx % S owns the workgroups q, q + S, q + 2S, ... (S = 8: one XCD each - workgroup i starts on XCD i % 8 - so a
+	// sequence's four arrays stay in one L2), slice j = blockIdx / S of `nslices`.
+	//
+	// The arithmetic is that of ecc_run_kernel with V = ecc_blocks(w, h) workgroups, bit for bit, whatever S and nslices are: the
+	// pixels are cut into the same V "rows" (row b = what workgroup b of a solo run sums: pixels b * 256 + t + k * V * 256 of
+	// thread t, added in that order, reduced over the 256 threads in the same fixed order), a slice computes rows j, j + nslices,
+	// ... one after the other and leaves each as its row of granules, and the sequence's slice 0 adds the V rows in the order
+	// ecc_solve_kernel does.  Nothing crosses sequences; a sequence whose alignment fails stops, the others go on.
+	// rows: per sequence [V][16] granules, then its pub granule (ecc_run_workspace_bytes).
+	__attribute__((amdgpu_waves_per_eu(RIR_ECC_MULTI_WAVES, RIR_ECC_MULTI_WAVES))) __global__ __launch_bounds__(ECC_BLOCK) void ecc_run_multi_kernel(EccSeq *__restrict__ table, int S, int w, int h, int V, int max_iter, double eps,
+																	  unsigned int epoch)
+	{
+		__shared__ EccReduceLds red;
+		__shared__ double part[ECC_NSUMS][17];
+		__shared__ double tot[ECC_NSUMS];
+		__shared__ float sh_t[2];
+		__shared__ int sh_done;
+		const int q = blockIdx.x % S, slice = blockIdx.x / S, nslices = gridDim.x / S, tid = threadIdx.x;
+		const EccSeq sq = table[q];
+		const float *image = sq.image, *gximg = sq.gx, *gyimg = sq.gy;
+		unsigned long long *pub = reinterpret_cast<unsigned long long *>(sq.rows + (size_t)V * 32);
+		const __amdgpu_buffer_rsrc_t rows_rs = ecc_rsrc(sq.rows, (uint32_t)V * 256u), pub_rs = ecc_rsrc(pub, 16u);
+		EccState st; // (slice 0, thread 0 keeps the real one)
+		st.tx = sq.tx0, st.ty = sq.ty0;
+		float tx = sq.tx0, ty = sq.ty0;
+		int done = 0, frames_done = 0;
+		for (int f = 0; f < sq.nframes && done != 2; ++f, image += (size_t)w * h, gximg += (size_t)w * h, gyimg += (size_t)w * h)
+		{
+			st.rho = -1.0, st.last_rho = -eps;
+			st.iter = 0, st.done = 0, st.ticket = 0;
+			st.max_iter = max_iter, st.eps = eps;
+			done = 0;
+			for (int it = 1; !done; ++it)
+			{
+				const unsigned long long flag =
+					((unsigned long long)(epoch & 0x3fffffffu) << 32) | ((unsigned long long)(unsigned int)f << 20) | (unsigned long long)((unsigned int)it & 0xfffffu);
+#ifdef RIR_ECC_DIAG
+				const unsigned long long dg0 = __builtin_amdgcn_s_memrealtime();
+				unsigned long long dg1 = 0, dg2 = 0;
+#endif
+#ifdef RIR_ECC_DIAG
+				unsigned long long dgl = 0, dgr = 0;
+#endif
+				for (int b = slice; b < V; b += nslices)
+				{
+#ifdef RIR_ECC_DIAG
+					const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+					const double v = ecc_block_sums<RIR_ECC_MULTI_PIXELS_PER_ROUND>(sq.templ, image, gximg, gyimg, nullptr, w, h, tx, ty, b, V, red);
+					if (tid < ECC_NSUMS)
+						ecc_granule_store(rows_rs, (uint32_t)b * 256u + (uint32_t)tid * 16u, (unsigned long long)__double_as_longlong(v), flag);
+#ifdef RIR_ECC_DIAG
+					dgl += ecc_diag_loop_end - r0, dgr += ecc_diag_reduced - ecc_diag_loop_end;
+#endif
+				}
+#ifdef RIR_ECC_DIAG
+				dg1 = __builtin_amdgcn_s_memrealtime();
+#endif
+				if (slice == 0)
+				{
+					const bool all_ok = ecc_rows_total<true>(sq.rows, V, flag, part, tot);
+#ifdef RIR_ECC_DIAG
+					dg2 = __builtin_amdgcn_s_memrealtime();
+#endif
+					if (tid == 0)
+					{
+						done = all_ok ? ecc_solve_step(tot, st) : 2;
+						sh_t[0] = st.tx, sh_t[1] = st.ty;
+						sh_done = done;
+						ecc_granule_store(pub_rs, 0, (unsigned long long)__float_as_uint(st.tx) | ((unsigned long long)__float_as_uint(st.ty) << 32),
+										  flag | ((unsigned long long)done << 62));
+					}
+				}
+				else if (tid == 0)
+				{
+					const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+					sh_done = 2;
+					for (;;)
+					{
+						const ecc_v4u g = __builtin_amdgcn_raw_buffer_load_b128(pub_rs, 0, 0, 16 /* sc1 */);
+						const unsigned long long fl = ((unsigned long long)g.w << 32) | g.z;
+						if (((fl ^ flag) & kEccFlagMask) == 0)
+						{
+							sh_t[0] = __uint_as_float(g.x), sh_t[1] = __uint_as_float(g.y);
+							sh_done = (int)(fl >> 62);
+							break;
+						}
+						__builtin_amdgcn_s_sleep(1);
+						if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) // 2 s of the 100 MHz clock
+							break;
+					}
+				}
+				__syncthreads();
+				tx = sh_t[0], ty = sh_t[1];
+				done = sh_done;
+#ifdef RIR_ECC_DIAG
+				if (q == 0 && tid == 0 && (slice == 0 || slice == nslices - 1))
+				{ // ticks (10 ns): rows | wait for the rows (slice 0) or for the decision (last slice) | add + solve + publish (slice 0)
+					const unsigned long long dg3 = __builtin_amdgcn_s_memrealtime();
+					unsigned long long *dg = pub + 8 + (slice == 0 ? 0 : 8);
+					dg[0] += dg1 - dg0, dg[1] += (slice == 0 ? dg2 : dg3) - dg1, dg[2] += slice == 0 ? dg3 - dg2 : 0, dg[3] += 1;
+					dg[4] += dgl, dg[5] += dgr;
+				}
+#endif
+				__syncthreads(); // (red / tot / sh_* are reused by the next iteration)
+			}
+			if (slice == 0 && tid == 0)
+			{
+				EccFrameResult r;
+				r.tx = st.tx, r.ty = st.ty, r.rho = st.rho, r.iter = st.iter, r.done = done;
+				sq.results[f] = r;
+			}
+			frames_done = f + 1;
+		}
+		if (slice == 0 && tid == 0)
+			table[q].frames_done = frames_done;
+	}
+
+	int ecc_run_multi_capacity() { return resident_capacity(reinterpret_cast<const void *>(ecc_run_multi_kernel), ECC_BLOCK, 0); }
+	int ecc_rows(int w, int h) { return ecc_blocks(w, h); }
+	// d_table: nseq entries (device); nslices workgroups per sequence (1 .. ecc_rows(w, h)); nseq * nslices <= ecc_run_multi_capacity()
+	hipError_t launch_ecc_run_multi(EccSeq *d_table, int nseq, int nslices, int w, int h, int max_iter, double eps, unsigned int epoch, hipStream_t st)
+	{
+		const int V = ecc_blocks(w, h);
+		if (nseq <= 0 || nslices <= 0 || nslices > V || (long long)nseq * nslices > ecc_run_multi_capacity())
+			return hipErrorInvalidConfiguration;
+		ResidentGate gate(st); // its workgroups wait for each other: not beside any other resident launch of the process
+		if (!gate.ok())
+			return hipErrorUnknown;
+		hipLaunchKernelGGL(ecc_run_multi_kernel, dim3((unsigned)(nseq * nslices)), dim3(ECC_BLOCK), 0, st, d_table, nseq, w, h, V, max_iter, eps, epoch);
+		return hipGetLastError();
 	}
 
 	hipError_t launch_ecc_prepare(const float *d_image, int w, int h, float *d_gx, float *d_gy, EccState *d_state, float tx, float ty, int max_iter,

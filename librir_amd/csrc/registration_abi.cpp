@@ -32,6 +32,9 @@ namespace
 		bool tail_recorded = false;
 		unsigned int epoch = 0; // launches of ecc_run_kernel on this workspace
 		EccFrameResult *results_host = nullptr; // coherent page-locked host memory, kEccMaxSequence entries, kept for the life of the process
+		// multi-sequence launches: per sequence its rows of granules, its results; the table of sequences and its page-locked copy
+		DeviceBuffer multi_rows, multi_results, multi_table;
+		PinnedBuffer multi_stage, multi_back;
 	};
 	EccScratch &scratch()
 	{
@@ -332,6 +335,11 @@ RIR_EXPORT int rir_ecc_align_prepared_device(const float *d_ref_norm, const floa
 // [nframes][4] doubles = (tx, ty, correlation coefficient, iterations) per image.  Returns the number of images aligned: nframes,
 // or the index of the first one whose alignment failed (where the per-image entry point returns -1; its row and the later ones
 // are not filled), or -1 on an error of the call itself.  warp: HOST float[2], start value in, last good result out.
+namespace
+{
+	int align_frames_locked(EccScratch &sc, const float *d_ref_norm, const float *d_norm, const float *d_gx, const float *d_gy, int w, int h, int nframes,
+							float *warp, int max_iterations, double eps, double *results, hipStream_t st);
+}
 RIR_EXPORT int rir_ecc_align_prepared_frames_device(const float *d_ref_norm, const float *d_norm, const float *d_gx, const float *d_gy, int w, int h,
 													int nframes, float *warp, int max_iterations, double eps, double *results, void *stream)
 {
@@ -349,6 +357,13 @@ RIR_EXPORT int rir_ecc_align_prepared_frames_device(const float *d_ref_norm, con
 	ScratchOrder order(sc, st);
 	if (!order.ok)
 		return -1;
+	return align_frames_locked(sc, d_ref_norm, d_norm, d_gx, d_gy, w, h, nframes, warp, max_iterations, eps, results, st);
+}
+namespace
+{
+int align_frames_locked(EccScratch &sc, const float *d_ref_norm, const float *d_norm, const float *d_gx, const float *d_gy, int w, int h, int nframes,
+						float *warp, int max_iterations, double eps, double *results, hipStream_t st)
+{
 	if (!sc.partials.reserve(std::max(ecc_workspace_bytes(w, h), ecc_run_workspace_bytes(w, h))) || !sc.state.reserve(sizeof(EccState)))
 		return -1;
 	static const bool env_per_iteration = getenv("RIR_ECC_LAUNCH_PER_ITERATION") != nullptr;
@@ -402,6 +417,126 @@ RIR_EXPORT int rir_ecc_align_prepared_frames_device(const float *d_ref_norm, con
 	if (good < nframes)
 		log_error("ECC: the alignment did not converge (empty overlap, singular system or non-positive lambda)");
 	return good;
+}
+} // namespace
+
+// The alignments of `nseq` INDEPENDENT tracked sequences in shared resident launches (ecc_run_multi_kernel): sequence q aligns its
+// nframes[q] prepared images (d_norm[q], d_gx[q], d_gy[q]: [nframes[q]][h][w], rir_ecc_prepare_frames_device's output) against its
+// reference window d_ref_norm[q], image i from the result of image i - 1, image 0 from warps[2q], warps[2q + 1] - for every
+// sequence the same operations in the same order as rir_ecc_align_prepared_frames_device, so the same bits, but S chains
+// side by side instead of one (an alignment is a dependent chain of iterations: one sequence cannot fill the chip; SURVEY §8e
+// "replicas": masked_registration_ecc.py:105-191 is one such chain per camera).  d_*: HOST arrays of nseq device pointers;
+// results: HOST [nseq][results_stride][4] doubles = (tx, ty, correlation coefficient, iterations) per image; good: HOST [nseq],
+// images aligned before the first failure of that sequence (nframes[q]: all); warps: HOST [nseq][2] in/out (last good result).
+// Returns 0, or -1 on an error of the call itself.
+RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const float *const *d_norm, const float *const *d_gx, const float *const *d_gy, int w,
+										  int h, int nseq, const int *nframes, float *warps, int max_iterations, double eps, double *results, int results_stride,
+										  int *good, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	bool bad = !d_ref_norm || !d_norm || !d_gx || !d_gy || !nframes || !warps || !results || !good || w < 2 || h < 2 || nseq <= 0 || nseq > 4096 ||
+			   max_iterations <= 0 || max_iterations > kEccMaxIterations || !(eps >= 0) || results_stride <= 0;
+	size_t total_frames = 0;
+	for (int q = 0; !bad && q < nseq; ++q)
+	{
+		bad = !d_ref_norm[q] || !d_norm[q] || !d_gx[q] || !d_gy[q] || nframes[q] < 0 || nframes[q] > kEccMaxSequence || nframes[q] > results_stride;
+		total_frames += bad ? 0 : (size_t)nframes[q];
+	}
+	if (bad)
+	{
+		log_error("rir_ecc_align_multi_device: invalid argument");
+		return -1;
+	}
+	hipStream_t st = (hipStream_t)stream;
+	EccScratch &sc = scratch();
+	std::lock_guard<std::mutex> lock(sc.mu);
+	ScratchOrder order(sc, st);
+	if (!order.ok)
+		return -1;
+	const int V = ecc_rows(w, h);
+	static const bool env_per_iteration = getenv("RIR_ECC_LAUNCH_PER_ITERATION") != nullptr;
+	const int cap = env_per_iteration ? 0 : ecc_run_multi_capacity();
+	if (cap < 1)
+	{ // the device cannot hold a resident launch (or the runtime cannot tell): sequence after sequence on the single-sequence path
+		for (int q = 0; q < nseq; ++q)
+		{
+			good[q] = nframes[q] == 0 ? 0
+									  : align_frames_locked(sc, d_ref_norm[q], d_norm[q], d_gx[q], d_gy[q], w, h, nframes[q], warps + 2 * q, max_iterations, eps,
+															results + (size_t)q * results_stride * 4, st);
+			if (good[q] < 0)
+				return -1;
+		}
+		return 0;
+	}
+	const size_t rows_b = (ecc_run_workspace_bytes(w, h) + 255) & ~(size_t)255;
+	if (!sc.multi_rows.reserve((size_t)nseq * rows_b) || !sc.multi_results.reserve(std::max<size_t>(total_frames, 1) * sizeof(EccFrameResult)) ||
+		!sc.multi_table.reserve((size_t)nseq * sizeof(EccSeq)) || !sc.multi_stage.reserve((size_t)nseq * sizeof(EccSeq)) ||
+		!sc.multi_back.reserve((size_t)nseq * sizeof(EccSeq) + std::max<size_t>(total_frames, 1) * sizeof(EccFrameResult)))
+		return -1;
+	EccSeq *hs = sc.multi_stage.as<EccSeq>();
+	size_t r0 = 0;
+	for (int q = 0; q < nseq; ++q)
+	{
+		EccSeq e{};
+		e.templ = d_ref_norm[q], e.image = d_norm[q], e.gx = d_gx[q], e.gy = d_gy[q];
+		e.rows = reinterpret_cast<double *>(sc.multi_rows.as<char>() + (size_t)q * rows_b);
+		e.results = sc.multi_results.as<EccFrameResult>() + r0;
+		e.tx0 = warps[2 * q], e.ty0 = warps[2 * q + 1];
+		e.nframes = nframes[q], e.frames_done = 0;
+		hs[q] = e;
+		r0 += (size_t)nframes[q];
+	}
+	if (!hip_ok(hipMemcpyAsync(sc.multi_table.ptr, hs, (size_t)nseq * sizeof(EccSeq), hipMemcpyHostToDevice, st), "H2D"))
+		return -1;
+	// sequences per launch and workgroups per sequence: as many slices as the device holds for the sequences of the launch
+	// (RIR_ECC_MULTI_SLICES: a fixed number, for measurements)
+	static const int env_slices = getenv("RIR_ECC_MULTI_SLICES") ? atoi(getenv("RIR_ECC_MULTI_SLICES")) : 0;
+	const ResidentPlan plan = resident_plan(cap, 1, nseq);
+	for (int q0 = 0; q0 < nseq; q0 += plan.units_per_launch)
+	{
+		const int nl = std::min(plan.units_per_launch, nseq - q0);
+		int nslices = std::max(1, std::min(V, cap / nl));
+		if (env_slices > 0)
+			nslices = std::max(1, std::min(nslices, env_slices));
+		// (a slice's time is that of its rows, one after the other: no more slices than give every slice the same largest number of rows)
+		const int rows_per_slice = (V + nslices - 1) / nslices;
+		nslices = (V + rows_per_slice - 1) / rows_per_slice;
+		if (!hip_ok(launch_ecc_run_multi(sc.multi_table.as<EccSeq>() + q0, nl, nslices, w, h, max_iterations, eps, ++sc.epoch, st), "ecc run (multi)"))
+			return -1;
+	}
+	char *hb = sc.multi_back.as<char>();
+	if (!hip_ok(hipMemcpyAsync(hb, sc.multi_table.ptr, (size_t)nseq * sizeof(EccSeq), hipMemcpyDeviceToHost, st), "D2H") ||
+		(total_frames && !hip_ok(hipMemcpyAsync(hb + (size_t)nseq * sizeof(EccSeq), sc.multi_results.ptr, total_frames * sizeof(EccFrameResult),
+												hipMemcpyDeviceToHost, st),
+								 "D2H")) ||
+		!hip_ok(wait_stream(st), "sync"))
+		return -1;
+	static const bool diag = getenv("RIR_ECC_DIAG") != nullptr; // (-DRIR_ECC_DIAG builds: where an iteration's time goes, sequence 0)
+	if (diag)
+	{
+		unsigned long long dg[16];
+		if (hipMemcpy(dg, sc.multi_rows.as<char>() + (size_t)V * 256 + 64, sizeof(dg), hipMemcpyDeviceToHost) == hipSuccess && dg[3])
+			std::fprintf(stderr, "ecc multi, per iteration (us), sequence 0: slice 0: rows %.2f (pixel loops %.2f, reductions %.2f)  wait rows %.2f  add+solve+publish %.2f | last slice: rows %.2f  wait %.2f  (%llu iterations so far, %d sequences)\n",
+						 dg[0] * 0.01 / dg[3], dg[4] * 0.01 / dg[3], dg[5] * 0.01 / dg[3], dg[1] * 0.01 / dg[3], dg[2] * 0.01 / dg[3], dg[8] * 0.01 / dg[11], dg[9] * 0.01 / dg[11], dg[3], nseq);
+	}
+	const EccSeq *back = reinterpret_cast<const EccSeq *>(hb);
+	const EccFrameResult *r = reinterpret_cast<const EccFrameResult *>(hb + (size_t)nseq * sizeof(EccSeq));
+	for (int q = 0; q < nseq; ++q)
+	{
+		double *res = results + (size_t)q * results_stride * 4;
+		int g = 0;
+		for (; g < back[q].frames_done && g < nframes[q]; ++g)
+		{
+			if (r[g].done == 2 || std::isnan(r[g].rho))
+				break;
+			res[4 * g] = r[g].tx, res[4 * g + 1] = r[g].ty, res[4 * g + 2] = r[g].rho, res[4 * g + 3] = r[g].iter;
+			warps[2 * q] = r[g].tx, warps[2 * q + 1] = r[g].ty;
+		}
+		good[q] = g;
+		r += nframes[q];
+	}
+	return 0;
 }
 
 // Host-pointer form, the drop-in for cv2.findTransformECC(templ, image, warp, MOTION_TRANSLATION, criteria, mask, 1):

@@ -31,6 +31,7 @@ _lib.rir_ecc_align_prepared_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_int, ct.
 
 
 _lib.rir_ecc_align_prepared_frames_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp, ct.c_int, ct.c_double, _vp, _vp]
+_lib.rir_ecc_align_multi_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, ct.c_int, ct.c_double, _vp, ct.c_int, _vp, _vp]
 
 
 def _stream():
@@ -97,73 +98,150 @@ class DeviceRegistratorECC:
         if len(self.confidences) > 20:
             if self.conf_thresh is None:
                 self.conf_thresh = np.min(self.confidences) - 2 * np.std(self.confidences)
-            if cc < self.conf_thresh:  # change of reference image: the current window, shifted back
-                g = self._filtered(img if img is not None else frames[index])
-                win = g[self.startY:self.startY + self.subH, self.startX:self.startX + self.subW].contiguous()
-                moved = D.translate(win, (-shift[1], -shift[0]), "")[0]
-                out = torch.empty_like(moved)
-                if _lib.rir_minmax_normalize_device(moved.data_ptr(), self.subW, self.subH, self.subW, out.data_ptr(), _stream()) != 0:
-                    raise RuntimeError("rir_minmax_normalize_device: %s" % last_error())
-                self._ref_n = out
-                self.warp[:] = 0
+            if cc < self.conf_thresh:
+                self._change_reference(img, shift, frames, index)
         return shift
+
+    def _change_reference(self, img, shift, frames=None, index=0):
+        """change of reference image: the current window, shifted back (masked_registration_ecc.py:170-189)"""
+        g = self._filtered(img if img is not None else frames[index])
+        win = g[self.startY:self.startY + self.subH, self.startX:self.startX + self.subW].contiguous()
+        moved = D.translate(win, (-shift[1], -shift[0]), "")[0]
+        out = torch.empty_like(moved)
+        if _lib.rir_minmax_normalize_device(moved.data_ptr(), self.subW, self.subH, self.subW, out.data_ptr(), _stream()) != 0:
+            raise RuntimeError("rir_minmax_normalize_device: %s" % last_error())
+        self._ref_n = out
+        self.warp[:] = 0
+
+    def _as_frames(self, frames):
+        if frames.dim() == 2:
+            frames = frames[None]
+        if frames.dtype != torch.float32 and frames.dtype != torch.uint16:
+            frames = frames.to(torch.float32)
+        return frames.contiguous()
+
+    def _prepare(self, frames, c0, k, norm, st):
+        n, h, w = frames.shape
+        dt = ord("H") if frames.dtype == torch.uint16 else ord("f")
+        if _lib.rir_ecc_prepare_frames_device(frames[c0].data_ptr(), dt, w, h, k, float(self.sigma), self.startX, self.startY, self.subW, self.subH,
+                                              norm[0].data_ptr(), norm[1].data_ptr(), norm[2].data_ptr(), st) != 0:
+            raise RuntimeError("rir_ecc_prepare_frames_device: %s" % last_error())
+
+    def _align(self, norm, i, cnt, res, st):
+        good = _lib.rir_ecc_align_prepared_frames_device(self._ref_n.data_ptr(), norm[0, i].data_ptr(), norm[1, i].data_ptr(), norm[2, i].data_ptr(),
+                                                         self.subW, self.subH, cnt, self.warp.ctypes.data, self.number_of_iterations, self.termination_eps,
+                                                         res[i:].ctypes.data, st)
+        if good < 0:
+            raise RuntimeError("ECC: %s" % last_error())
+        return good
+
+    def _consume_chunk(self, frames, c0, k, norm, res, st, shifts, first_good=None, after_first=None):
+        """The book-keeping of a chunk of k prepared frames: the alignments of the chunk in one launch (``first_good``: already
+        done, by a multi-sequence launch, with ``res`` filled), then frame by frame what ``compute`` does; where that changes the
+        reference image the rest of the chunk is aligned again (new reference, from the identity)."""
+        i = 0
+        while i < k:
+            cnt = k - i
+            if i == 0 and first_good is not None:
+                good = first_good
+            else:
+                good = self._align(norm, i, cnt, res, st)
+            if i == 0 and after_first is not None:
+                after_first()
+            # the frames up to the first one whose confidence falls below the threshold (it changes the reference image: what was
+            # aligned after it does not count) are booked in one go - same values as frame-by-frame _after_alignment calls
+            base = len(self.confidences)
+            cc = res[i:i + good, 2]
+            stop = good  # frames of this round that count
+            change = False
+            if good:
+                if self.conf_thresh is None and base + good > 20:
+                    first = max(0, 20 - base)  # the frame that makes it 21 confidences defines the threshold
+                    head = np.array(self.confidences + cc[:first + 1].tolist())
+                    self.conf_thresh = np.min(head) - 2 * np.std(head)
+                    below = np.nonzero(cc[first:] < self.conf_thresh)[0]
+                    if below.size:
+                        stop, change = first + int(below[0]) + 1, True
+                elif self.conf_thresh is not None:
+                    below = np.nonzero(cc < self.conf_thresh)[0]
+                    if below.size:
+                        stop, change = int(below[0]) + 1, True
+            xs, ys = res[i:i + stop, 0].tolist(), res[i:i + stop, 1].tolist()
+            self.x.extend(xs)
+            self.y.extend(ys)
+            self.confidences.extend(cc[:stop].tolist())
+            shifts.extend([y, x] for x, y in zip(xs, ys))
+            if stop:
+                self.warp[0], self.warp[1] = res[i + stop - 1, 0], res[i + stop - 1, 1]
+            if change:
+                self._change_reference(None, [ys[-1], xs[-1]], frames, c0 + i + stop - 1)
+            elif good < cnt:
+                raise RuntimeError("ECC: the alignment did not converge (empty overlap, singular system or non-positive lambda)")
+            i += stop
 
     def compute_many(self, frames, chunk=32):
         """``compute`` for every frame of a (n, h, w) device tensor, in order, with the same results.  The pre-processing of a
         chunk of frames (pre-filter, window normalisation, gradients) runs in shared launches, the alignments of the chunk in one
         launch, each from the previous shift; while the host does the book-keeping of a chunk the device prepares the next one.
         Returns the list of shifts."""
-        if frames.dim() == 2:
-            frames = frames[None]
-        if frames.dtype != torch.float32 and frames.dtype != torch.uint16:
-            frames = frames.to(torch.float32)
-        frames = frames.contiguous()
-        n, h, w = frames.shape
-        dt = ord("H") if frames.dtype == torch.uint16 else ord("f")
+        frames = self._as_frames(frames)
+        n = frames.shape[0]
         shifts = []
         m = min(chunk, n)
         bufs = [torch.empty((3, m, self.subH, self.subW), dtype=torch.float32, device=frames.device) for _ in range(2 if n > chunk else 1)]
         st = _stream()
-
-        def prepare(c0, norm):
-            k = min(chunk, n - c0)
-            if _lib.rir_ecc_prepare_frames_device(frames[c0].data_ptr(), dt, w, h, k, float(self.sigma), self.startX, self.startY, self.subW, self.subH,
-                                                  norm[0].data_ptr(), norm[1].data_ptr(), norm[2].data_ptr(), st) != 0:
-                raise RuntimeError("rir_ecc_prepare_frames_device: %s" % last_error())
-
-        def align(norm, i, cnt, res):
-            good = _lib.rir_ecc_align_prepared_frames_device(self._ref_n.data_ptr(), norm[0, i].data_ptr(), norm[1, i].data_ptr(), norm[2, i].data_ptr(),
-                                                             self.subW, self.subH, cnt, self.warp.ctypes.data, self.number_of_iterations, self.termination_eps,
-                                                             res[i:].ctypes.data, st)
-            if good < 0:
-                raise RuntimeError("ECC: %s" % last_error())
-            return good
-
         if n:
-            prepare(0, bufs[0])
+            self._prepare(frames, 0, min(chunk, n), bufs[0], st)
         for ci, c0 in enumerate(range(0, n, chunk)):
             k = min(chunk, n - c0)
             norm = bufs[ci % len(bufs)]
             res = np.empty((k, 4), np.float64)
-            # the alignments of the chunk in one launch; the next chunk's pre-processing is queued before the book-keeping of this one.
-            # Where the book-keeping changes the reference image the rest of the chunk is aligned again (new reference, from the identity).
-            i = 0
-            while i < k:
-                cnt = k - i
-                good = align(norm, i, cnt, res)
-                if i == 0 and c0 + chunk < n:
-                    prepare(c0 + chunk, bufs[(ci + 1) % len(bufs)])
-                ref = self._ref_n
-                for j in range(i, i + good):
-                    self.warp[0], self.warp[1] = res[j, 0], res[j, 1]
-                    shifts.append(self._after_alignment(None, float(res[j, 2]), frames, c0 + j))
-                    if self._ref_n is not ref:  # reference changed at frame j: what was aligned after it does not count
-                        good = j + 1 - i
-                        break
-                else:
-                    if good < cnt:
-                        raise RuntimeError("ECC: %s" % last_error())
-                i += good
+            nxt = None
+            if c0 + chunk < n:  # the next chunk's pre-processing is queued before the book-keeping of this one
+                nxt = lambda c0=c0, ci=ci: self._prepare(frames, c0 + chunk, min(chunk, n - c0 - chunk), bufs[(ci + 1) % len(bufs)], st)  # noqa: E731
+            self._consume_chunk(frames, c0, k, norm, res, st, shifts, after_first=nxt)
+        return shifts
+
+    @staticmethod
+    def compute_many_multi(registrators, frames, chunk=32):
+        """``compute_many`` for S independent sequences at once - ``registrators[q]`` (each started on its own reference image, all
+        with one window size) tracks ``frames[q]`` (n, h, w) - with the alignments of a chunk of ALL sequences in one resident
+        launch (rir_ecc_align_multi_device): an alignment is a chain of dependent iterations that cannot fill the chip, S chains
+        side by side can.  Every sequence gets exactly the track its own ``compute_many`` gives.  Returns the lists of shifts."""
+        S = len(registrators)
+        if S == 0 or len(frames) != S:
+            raise RuntimeError("compute_many_multi: one frames tensor per registrator expected")
+        frs = [r._as_frames(f) for r, f in zip(registrators, frames)]
+        n = frs[0].shape[0]
+        r0 = registrators[0]
+        if any(f.shape[0] != n for f in frs) or any((r.subW, r.subH, r.number_of_iterations, r.termination_eps) !=
+                                                    (r0.subW, r0.subH, r0.number_of_iterations, r0.termination_eps) for r in registrators):
+            raise RuntimeError("compute_many_multi: the sequences must share length, window size and termination criteria")
+        st = _stream()
+        m = min(chunk, n)
+        dev = frs[0].device
+        bufs = [[torch.empty((3, m, r0.subH, r0.subW), dtype=torch.float32, device=dev) for _ in range(S)] for _ in range(2 if n > chunk else 1)]
+        shifts = [[] for _ in range(S)]
+        ptr = lambda ts: (ct.c_void_p * S)(*[t.data_ptr() for t in ts])  # noqa: E731
+        for q in range(S):
+            if n:
+                registrators[q]._prepare(frs[q], 0, m, bufs[0][q], st)
+        for ci, c0 in enumerate(range(0, n, chunk)):
+            k = min(chunk, n - c0)
+            norm = bufs[ci % len(bufs)]
+            res = np.empty((S, k, 4), np.float64)
+            warps = np.stack([r.warp for r in registrators]).astype(np.float32)
+            counts = (ct.c_int * S)(*([k] * S))
+            good = (ct.c_int * S)()
+            if _lib.rir_ecc_align_multi_device(ptr([r._ref_n for r in registrators]), ptr([b[0] for b in norm]), ptr([b[1] for b in norm]),
+                                               ptr([b[2] for b in norm]), r0.subW, r0.subH, S, counts, warps.ctypes.data, r0.number_of_iterations,
+                                               r0.termination_eps, res.ctypes.data, k, good, st) != 0:
+                raise RuntimeError("ECC: %s" % last_error())
+            if c0 + chunk < n:  # the next chunk's pre-processing is queued before the book-keeping of this one
+                for q in range(S):
+                    registrators[q]._prepare(frs[q], c0 + chunk, min(chunk, n - c0 - chunk), bufs[(ci + 1) % len(bufs)][q], st)
+            for q in range(S):
+                registrators[q]._consume_chunk(frs[q], c0, k, norm[q], res[q], st, shifts[q], first_good=int(good[q]))
         return shifts
 
     def return_coordinates_and_confidence_values(self):

@@ -244,3 +244,39 @@ def test_tracked_sequence_rate():
     print("ECC registration, tracked sequence: %.0f frames/s" % best)
     assert len(reg.x) == n
     assert best >= 12000, best
+
+
+@pytest.mark.parametrize("S,chunk", [(8, 16), (3, 32), (1, 7)])
+def test_sequences_side_by_side_equal_their_own_tracks(S, chunk):
+    """DeviceRegistratorECC.compute_many_multi (rir_ecc_align_multi_device, ecc_run_multi_kernel): S independent sequences aligned
+    in shared resident launches - each one's track is, to the last bit, the track its own compute_many gives (same rows of
+    partial sums added in the same order, whatever the number of sequences and of workgroups per sequence), through a change of
+    the reference image in one of them and across chunk boundaries."""
+    import torch
+
+    from librir_amd.registration import DeviceRegistratorECC
+
+    n, h, w = 45, 256, 320
+    seqs = []
+    for q in range(S):
+        f, _ = s3_registration(n, h, w, seed=100 + q)
+        f = f.copy()
+        if q == 1 or S == 1:
+            f[30] += np.random.default_rng(8 + q).normal(0, 4, f[30].shape).astype(np.float32)  # a confidence drop: this sequence changes its reference
+        seqs.append(torch.from_numpy(f if q % 2 == 0 else np.clip(f, 0, 65535).astype(np.uint16)).cuda())
+    solo = []
+    for q in range(S):
+        r = DeviceRegistratorECC(0.8, 0.8, shape=(h, w))
+        r.start(seqs[q][0])
+        r.compute_many(seqs[q][1:], chunk=chunk)
+        solo.append(r)
+    multi = [DeviceRegistratorECC(0.8, 0.8, shape=(h, w)) for _ in range(S)]
+    for q in range(S):
+        multi[q].start(seqs[q][0])
+    shifts = DeviceRegistratorECC.compute_many_multi(multi, [s[1:] for s in seqs], chunk=chunk)
+    assert [len(s) for s in shifts] == [n - 1] * S
+    for q in range(S):
+        assert multi[q].x == solo[q].x and multi[q].y == solo[q].y and multi[q].confidences == solo[q].confidences, q
+    if S > 1:
+        assert solo[1].conf_thresh is not None and min(solo[1].confidences[21:]) < solo[1].conf_thresh  # the reference of sequence 1 did change
+        assert solo[0].x != solo[2].x  # (the sequences are different data)
