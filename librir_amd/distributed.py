@@ -83,32 +83,56 @@ def all_gather_frames(local_frames, plan, group=None):
 class FrameGather:
     """Sub-batched all-gather of decoded frames that overlaps the decode of the next sub-batch.
 
-    Every rank holds ``n`` frames (equal shards), cut in pieces of ``piece`` frames.  ``run(produce)`` calls
-    ``produce(j, f0, f1)`` - which must leave frames [f0, f1) of the local shard in ``local`` on the current stream -
-    and issues the all-gather of piece j behind it on the communicator's stream while piece j + 1 is produced.
+    Every rank holds up to ``n`` frames in ``local`` (n = the largest shard, a whole number of pieces of ``piece`` frames;
+    ``counts[r]`` = frames rank r really has - all n when ``counts`` is None: equal shards).  ``run(produce)`` calls
+    ``produce(j, f0, f1)`` - which must leave frames [f0, f1) of the local shard in ``local`` on the current stream; f1 is
+    clipped to this rank's count and ranks that have nothing in a piece are not called for it - and issues the all-gather of
+    piece j behind it on the communicator's stream while piece j + 1 is produced.
     The gathered stream is PIECE-MAJOR: an ``all_gather_into_tensor`` output is the concatenation of its inputs over
     the ranks, so frame f of rank r lives at ``full[piece_index(f), r, f % piece]`` (``locate``); a rank-major copy
-    would cost another pass over the whole stream in HBM."""
+    would cost another pass over the whole stream in HBM (``assemble`` makes one, for callers that want stream order)."""
 
-    def __init__(self, local, piece, group=None):
+    def __init__(self, local, piece, group=None, counts=None):
         self.group = group
         self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
         self.local = local
         n = local.shape[0]
-        self.piece = max(1, min(piece, n))
+        self.counts = [n] * self.world if counts is None else [int(c) for c in counts]
+        if len(self.counts) != self.world or any(c < 0 or c > n for c in self.counts):
+            raise RuntimeError("FrameGather: one frame count per rank, none larger than the local buffer")
+        self.piece = max(1, min(piece, n)) if n else 1
         self.bounds = [(f0, min(f0 + self.piece, n)) for f0 in range(0, n, self.piece)]
         if any(f1 - f0 != self.piece for f0, f1 in self.bounds):
-            raise RuntimeError("FrameGather: the shard must be a whole number of pieces")
+            raise RuntimeError("FrameGather: the shard buffer must be a whole number of pieces")
         self.full = torch.empty((len(self.bounds), self.world, self.piece) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        per_frame = (local.numel() // n if n else 0) * local.element_size()
+        # what the collective moves to this rank (padding of shorter shards included: the pieces are of one size)
         self.bytes_received = (self.world - 1) * local.numel() * local.element_size()
+        self.valid_bytes_received = sum(c for r, c in enumerate(self.counts) if r != self.rank) * per_frame
 
     def locate(self, rank, f):
         return f // self.piece, rank, f % self.piece
 
+    def assemble(self, out=None):
+        """the gathered frames in stream order (rank after rank, each rank's frames in order): a copy, (sum(counts), ...)"""
+        total = sum(self.counts)
+        if out is None:
+            out = torch.empty((total,) + tuple(self.local.shape[1:]), dtype=self.local.dtype, device=self.local.device)
+        pos = 0
+        for r, c in enumerate(self.counts):
+            for f0 in range(0, c, self.piece):
+                k = min(self.piece, c - f0)
+                out[pos:pos + k] = self.full[f0 // self.piece, r, :k]
+                pos += k
+        return out
+
     def run(self, produce):
         works = []
+        mine = self.counts[self.rank]
         for j, (f0, f1) in enumerate(self.bounds):
-            produce(j, f0, f1)
+            if f0 < mine:
+                produce(j, f0, min(f1, mine))
             works.append(_gather_bytes(self.full[j], self.local[f0:f1], self.group, async_op=True))
         for w in works:
             if w is not None:

@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the sharding plan and the two exchange steps that reassemble the stream on every rank
+"""CPU, world_size 2 and 4, gloo: the sharding plan and the two exchange steps that reassemble the stream on every rank
 (the N>1 path of bench.py / DESIGN.md §6): the all-gather of decoded frames, whole and in overlapped sub-batches,
 and the all-gather of COMPRESSED chunks decoded on arrival.  The HIP codec is not run here (GPU only): frames are
 fabricated from the global frame index, and the compressed exchange is checked with the oracle as encoder/decoder."""
@@ -151,6 +151,77 @@ def test_compressed_chunks_gathered_and_decoded_on_arrival_world2(nframes, gop, 
     (35, 10): a short last chunk; (10, 10): one rank has no frames at all."""
     world = 2
     port = 29500 + (os.getpid() + nframes * 7 + per_piece) % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_compressed_worker, args=(world, port, nframes, gop, shape[0], shape[1], per_piece, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+# ---- world 4: uneven shards, a rank without frames ---------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("nframes,gop", [(230, 50), (120, 50)])
+def test_all_gather_reassembles_the_stream_world4(nframes, gop):
+    """(230, 50): 5 chunks over 4 ranks = 2 + 1 + 1 + 1, the last one short; (120, 50): 3 chunks, rank 3 has no frames"""
+    world = 4
+    port = 29500 + (os.getpid() + nframes + 11) % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, nframes, gop, 6, 9, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def _uneven_piece_worker(rank, world, port, nframes, gop, piece, ret):
+    """FrameGather with the shards of shard_plan: pieces gathered while the next one is produced, ranks that have run out of
+    frames contribute padding and are not asked to produce; every real frame is found where locate() says, assemble() gives
+    the stream in order."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        h, w = 5, 7
+        plan = shard_plan(nframes, gop, world)
+        counts = [c for _, c in plan]
+        nmax = -(-max(counts) // piece) * piece
+        local = torch.zeros((nmax, h, w), dtype=torch.uint16)
+        fg = FrameGather(local, piece, counts=counts)
+        calls = []
+
+        def produce(j, f0, f1):
+            calls.append((j, f0, f1))
+            for f in range(f0, f1):
+                local[f] = (plan[rank][0] + f) * 3 % 65536  # a function of the GLOBAL frame index
+
+        full = fg.run(produce)
+        mine = counts[rank]
+        exp_calls = [(f0 // piece, f0, min(f0 + piece, mine)) for f0 in range(0, mine, piece)]
+        ok = calls == exp_calls and tuple(full.shape) == (nmax // piece, world, piece, h, w)
+        for r in range(world):
+            for f in range(counts[r]):
+                ok = ok and int(full[fg.locate(r, f)][0, 0]) == (plan[r][0] + f) * 3 % 65536
+        stream = fg.assemble()
+        ok = ok and stream.shape[0] == nframes and all(int(stream[g][h - 1, w - 1]) == g * 3 % 65536 for g in range(nframes))
+        ok = ok and fg.valid_bytes_received == (nframes - mine) * h * w * 2 and fg.bytes_received == (world - 1) * nmax * h * w * 2
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nframes,gop,piece", [(230, 50, 50), (120, 50, 25), (30, 10, 10)])
+def test_sub_batched_frame_gather_world4_uneven(nframes, gop, piece):
+    """(230, 50): shards of 100 / 50 / 50 / 30 frames; (120, 50): 50 / 50 / 20 / 0 - a rank without frames, pieces smaller than a
+    chunk; (30, 10): 3 chunks over 4 ranks"""
+    world = 4
+    port = 29500 + (os.getpid() + nframes * 3 + piece) % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_uneven_piece_worker, args=(world, port, nframes, gop, piece, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+@pytest.mark.parametrize("nframes,gop,per_piece,shape", [(70, 10, 2, (67, 83)), (25, 10, 1, (32, 64)), (64, 8, 4, (40, 52))])
+def test_compressed_chunks_gathered_and_decoded_on_arrival_world4(nframes, gop, per_piece, shape):
+    """(70, 10): 7 chunks over 4 ranks = 2 + 2 + 2 + 1 (padding entries in rank 3's pieces); (25, 10): 3 chunks - rank 3 has no
+    frames - and a short last chunk; (64, 8): even shards, one piece"""
+    world = 4
+    port = 29500 + (os.getpid() + nframes * 5 + per_piece + 3) % 2000
     ret = mp.Manager().dict()
     mp.spawn(_compressed_worker, args=(world, port, nframes, gop, shape[0], shape[1], per_piece, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)

@@ -255,6 +255,7 @@ def test_recording_interleaved_with_queries_parameter_changes_and_add_loss(tmp_p
         assert np.array_equal(got[k], exp[i]), i
 
 
+@pytest.mark.perf
 def test_device_resident_step_rate():
     """The review's mark for the bounded-loss step on frames that stay in HBM: >= 80 000 frames/s for one 640x512 stream (a run of
     frames is one resident launch; measured 120-130 k, `tests/perf/lossy_time.py`).  The floor asserted here leaves a third of
@@ -309,6 +310,7 @@ def test_ring_lengths_at_the_edges(oracle, ra, run_path):
     ls.close()
 
 
+@pytest.mark.perf
 def test_recording_rate(tmp_path):
     """Bounded-loss recording through the per-frame ABI (IRSaver.add_image_lossy, 640x512): the frames of a chunk are stepped as one
     run, measured 24 k frames/s (8.8 k with an upload and three launches per frame).  Floor with a factor two of margin; best of two."""

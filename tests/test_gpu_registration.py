@@ -221,6 +221,7 @@ def test_a_failing_frame_stops_compute_many_where_compute_stops():
     assert many.x == one.x and many.confidences == one.confidences
 
 
+@pytest.mark.perf
 def test_tracked_sequence_rate():
     """The review's mark for the registration of a tracked sequence on frames in HBM: >= 12 000 frames/s at 640x512 (a chunk of
     frames is pre-processed in shared launches and aligned in one launch; measured 18-24 k, `tests/perf/ecc_time.py`).  Best of three."""

@@ -365,6 +365,7 @@ def test_sequential_read_ahead_is_transparent(tmp_path):
     rv.close_camera(cam)
 
 
+@pytest.mark.perf
 def test_per_frame_abi_round_trip_rate(tmp_path):
     """north_star's literal target on the drop-in path: >= 10 000 frames/s through IRSaver.add_image + IRMovie[i] for 640x512
     frames (one frame per call, host pointers, as the reference wrapper drives the library).  The floor asserted here is
