@@ -21,6 +21,11 @@
 
 #include <type_traits>
 
+#include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+
 #include "filter_kernels.h"
 
 namespace rir
@@ -973,33 +978,25 @@ namespace rir
 		return p < 0 ? 0 : (p >= (float)size ? size - 1 : (int)p);
 	}
 
-	// register budget for 7 waves per SIMD (73 VGPRs; the compiler's own choice, 76, leaves 6: 0.156 -> 0.145 ms)
-#ifndef RIR_CHAIN_WAVES
-#define RIR_CHAIN_WAVES 7
-#endif
-#define RIR_CHAIN_OCC __attribute__((amdgpu_waves_per_eu(R <= 2 ? RIR_CHAIN_WAVES : 1, R <= 2 ? RIR_CHAIN_WAVES : 8))) /* wider kernels: the compiler's choice */
-	template <int R>
-	RIR_CHAIN_OCC __global__ __launch_bounds__(256) void filter_chain_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w, int h,
-															   ChainBadPixels bp, const float *__restrict__ kern, const float *__restrict__ offsets,
-															   int per_frame_offsets, int strategy, uint32_t background)
+	// One wave's tile of the chain: output pixels [x0, x0 + OW) x [y0, y0 + OH) of frame n, x0 = bx * OW, y0 = byw * OH.
+	// MODE 0: both paths below in one kernel (radius 2..4).  Radius 1 - the configuration the chain is used with, sigma 0.75 -
+	// is two kernels: MODE 1, the REGULAR tiles only, entirely in registers (39 VGPRs: 8 waves per SIMD, no scratch); a tile that
+	// is not regular (first / last row bands of the image, float rounding of px + 1, ...) is put on a list instead (one 64-bit
+	// entry, n << 32 | byw << 16 | bx) and MODE 2, the general path, works the list off.  As one kernel the general path's
+	// registers (10 spilled at the regular path's occupancy) cost every wave its scratch set-up and the regular path a wave
+	// per SIMD.  `tile`: the wave's LDS strip [TY][64].  MODE 2 never takes the regular path (the list holds what it refused).
+	template <int R, int MODE>
+	__device__ __forceinline__ void chain_tile(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w, int h, const ChainBadPixels &bp,
+												const float *__restrict__ kern, const float *__restrict__ offsets, int per_frame_offsets, int strategy,
+												uint32_t background, int bx, int byw, int n, int lane, float (*tile_w)[64], unsigned long long *__restrict__ worklist,
+												unsigned int *__restrict__ work_count)
 	{
 		constexpr int TY = RIR_CHAIN_TY, KW = 2 * R + 1, OUTW = 64 - 2 * R, OW = OUTW - 2, OH = TY - 2, NR = TY + 2 * R;
 		static_assert(TY % 2 == 0 && (R != 1 || OW % 4 == 0), "rows in pairs (packed FMAs); 4-pixel output pieces in the register path");
-		__shared__ float tile[4][TY][64];
-		const int lane = threadIdx.x & 63;
-		const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-		int bx, by, bz;
-		{ // XCD-major tile order, row bands fastest (see gaussian_sep_kernel)
-			const unsigned gx = gridDim.x, gy = gridDim.y;
-			const unsigned id2 = xcd_major(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
-			by = (int)(id2 % gy);
-			bx = (int)((id2 / gy) % gx);
-			bz = (int)(id2 / (gy * gx));
-		}
-		const int x0 = bx * OW, y0 = (by * 4 + wv) * OH;
+		static_assert(MODE == 0 || R == 1, "the regular / listed split exists for radius 1");
+		const int x0 = bx * OW, y0 = byw * OH;
 		if (y0 >= h)
 			return;
-		const int n = bz;
 		const int64_t fbase = (int64_t)n * w * h;
 		const uint16_t *s = src + fbase;
 		const float dx = offsets[per_frame_offsets ? 2 * n : 0];
@@ -1119,18 +1116,17 @@ namespace rir
 		}
 		// gaussian, column pass: in registers, rows j and j + TY/2 side by side in packed FMAs (two IEEE fmas per
 		// instruction: the same values as the scalar form, half the instructions)
+		// (two rows per packed FMA; which two rows share an instruction does not matter for the values: the regular tiles below take
+		// NEIGHBOURING rows, 2p and 2p + 1, and consume them at once - column pass, row pass and blend of a pair of rows before the next
+		// pair is touched, so that no array of column sums or filtered pixels is ever held: 8 waves per SIMD without scratch)
 		constexpr int HY = TY / 2;
-		float cs[TY];
-#pragma unroll
-		for (int j = 0; j < HY; ++j)
-		{
+		auto column_pair = [&](int r0, int r1) -> v2f {
 			v2f acc = {0.f, 0.f};
 #pragma unroll
 			for (int d = 0; d < KW; ++d)
-				acc = __builtin_elementwise_fma((v2f){a[d], a[d]}, (v2f){v[j + d], v[j + HY + d]}, acc);
-			cs[j] = acc.x;
-			cs[j + HY] = acc.y;
-		}
+				acc = __builtin_elementwise_fma((v2f){a[d], a[d]}, (v2f){v[r0 + d], v[r1 + d]}, acc);
+			return acc;
+		};
 		// this lane's output column and its taps (expressions of translate_px / Filters.h:249-326)
 		const int x = x0 + lane;
 		const bool act_x = lane < OW && x < w;
@@ -1143,7 +1139,7 @@ namespace rir
 			r = l;
 		const double u = (double)(px - (float)l);
 
-		if constexpr (R == 1)
+		if constexpr (R == 1 && MODE != 2)
 		{
 			// ---- regular tiles (all but the first / last row bands of the image): no LDS at all -------------------------
 			// When the block does not touch the first / last R rows, lane i's taps are the
@@ -1194,24 +1190,9 @@ namespace rir
 							sx += a[d + R];
 					norm_den = sx * full;
 				}
-				double dl[TY]; // filtered pixel (gx0 + lane, gy0 + j) = this lane's left tap column
-#pragma unroll
-				for (int j = 0; j < HY; ++j)
-				{
-					v2f acc = __builtin_elementwise_fma((v2f){a[0], a[0]}, (v2f){shr1(cs[j]), shr1(cs[j + HY])}, (v2f){0.f, 0.f});
-					acc = __builtin_elementwise_fma((v2f){a[1], a[1]}, (v2f){cs[j], cs[j + HY]}, acc);
-					acc = __builtin_elementwise_fma((v2f){a[2], a[2]}, (v2f){shl1(cs[j]), shl1(cs[j + HY])}, acc);
-					if (needs_norm)
-					{ // (wave-uniform) first / last R columns of the image: renormalised by the weight of the taps inside it
-						acc.x = xb ? acc.x / norm_den : acc.x;
-						acc.y = xb ? acc.y / norm_den : acc.y;
-					}
-					dl[j] = (double)shl1(acc.x); // lane i owns column gx0 - 1 + i: column gx0 + i is one lane up
-					dl[j + HY] = (double)shl1(acc.y);
-				}
 				const double u1 = 1 - u;
 				const double vv = (double)vv0, v1 = 1 - vv;
-				// Results leave through raw-buffer stores with the streaming policy (written once, not read again here).
+				// Results leave through raw-buffer stores (written once, not read again here).
 				// The vector-memory path handles one wave instruction per few cycles whatever the bytes per lane, and 14
 				// two-byte stores per tile were a quarter of the kernel's time: when rows are 8-byte aligned (w % 4 == 0)
 				// the tile is turned through the wave's LDS strip so that a lane writes 4 neighbouring pixels at once -
@@ -1222,26 +1203,48 @@ namespace rir
 				const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)dhi << 32) | dlo), 0, w * h * 2, 0x00020000);
 				const uint32_t dstep = (uint32_t)w * 2u;
 				const bool wide = (w & 3) == 0;
-				uint16_t *ot = reinterpret_cast<uint16_t *>(&tile[wv][0][0]); // [OH][64] uint16
+				uint16_t *ot = reinterpret_cast<uint16_t *>(&tile_w[0][0]); // [OH][64] uint16
 				uint16_t res[OH];
-#pragma unroll
-				for (int j = 0; j < OH; ++j)
-				{ // (rows past the end of the image are computed and not stored: no early exit, the loop unrolls)
-					const double cl = dl[j + 1] * v1 + dl[j] * vv;
+				// output row j from the filtered pixels of rows j (top tap) and j + 1 (bottom tap) of this lane's left tap column;
+				// (rows past the end of the image are computed and not stored: no early exit, the loop unrolls)
+				auto blend_row = [&](double top, double bottom) -> uint16_t {
+					const double cl = bottom * v1 + top * vv;
 					const uint64_t clb = __builtin_bit_cast(uint64_t, cl);
 					const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)clb, 0x130, 0xf, 0xf, true);
 					const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(clb >> 32), 0x130, 0xf, 0xf, true);
 					const double cs1 = __builtin_bit_cast(double, (uint64_t)lo | ((uint64_t)hi << 32));
 					const double cr = r_is_l ? cl : cs1;
-					res[j] = CastTo<u16_via_f32>::from(cl * u1 + cr * u).v;
+					uint16_t out = CastTo<u16_via_f32>::from(cl * u1 + cr * u).v;
 					if (outs != 0)
 					{ // (wave-uniform) columns outside the source: the constant, or the first / last source column of row t_j
-						const uint64_t eb = __builtin_bit_cast(uint64_t, dl[j]);
+						const uint64_t eb = __builtin_bit_cast(uint64_t, top);
 						const uint32_t elo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)eb, edge_lane & 63);
 						const uint32_t ehi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(eb >> 32), edge_lane & 63);
 						const uint16_t near = CastTo<u16_via_f32>::from(__builtin_bit_cast(double, (uint64_t)elo | ((uint64_t)ehi << 32))).v;
-						res[j] = out_x ? (strategy == TRANSLATE_CONSTANT ? (uint16_t)background : near) : res[j];
+						out = out_x ? (strategy == TRANSLATE_CONSTANT ? (uint16_t)background : near) : out;
 					}
+					return out;
+				};
+				double carry = 0.0; // filtered pixel (gx0 + lane, gy0 + 2p - 1): the bottom row of the previous pair
+#pragma unroll
+				for (int p = 0; p < HY; ++p)
+				{
+					const v2f cs = column_pair(2 * p, 2 * p + 1); // column sums of rows 2p, 2p + 1
+					v2f acc = __builtin_elementwise_fma((v2f){a[0], a[0]}, (v2f){shr1(cs.x), shr1(cs.y)}, (v2f){0.f, 0.f});
+					acc = __builtin_elementwise_fma((v2f){a[1], a[1]}, cs, acc);
+					acc = __builtin_elementwise_fma((v2f){a[2], a[2]}, (v2f){shl1(cs.x), shl1(cs.y)}, acc);
+					if (needs_norm)
+					{ // (wave-uniform) first / last R columns of the image: renormalised by the weight of the taps inside it
+						acc.x = xb ? acc.x / norm_den : acc.x;
+						acc.y = xb ? acc.y / norm_den : acc.y;
+					}
+					// lane i owns column gx0 - 1 + i: column gx0 + i, this lane's left tap column, is one lane up
+					const double d0 = (double)shl1(acc.x), d1 = (double)shl1(acc.y);
+					if (p > 0)
+						res[2 * p - 1] = blend_row(carry, d0);
+					if (2 * p < OH)
+						res[2 * p] = blend_row(d0, d1);
+					carry = d1;
 				}
 				if (!wide)
 				{
@@ -1273,11 +1276,25 @@ namespace rir
 				return;
 			}
 		}
-
+		if constexpr (MODE == 1)
+		{ // not a regular tile: on the list, for the general path (filter_chain_listed_kernel)
+			if (lane == 0)
+			{
+				const unsigned int slot = atomicAdd(work_count, 1u);
+				worklist[slot] = ((unsigned long long)(unsigned int)n << 32) | ((unsigned long long)(unsigned int)byw << 16) | (unsigned long long)(unsigned int)bx;
+			}
+			return;
+		}
+		else
+		{
 		// ---- general path: row pass through the wave's LDS strip (in place), taps read from it ----------------------
 #pragma unroll
-		for (int j = 0; j < TY; ++j)
-			tile[wv][j][lane] = cs[j];
+		for (int j = 0; j < HY; ++j)
+		{
+			const v2f cs = column_pair(j, j + HY);
+			tile_w[j][lane] = cs.x;
+			tile_w[j + HY][lane] = cs.y;
+		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1306,7 +1323,7 @@ namespace rir
 				float acc = 0.f;
 #pragma unroll
 				for (int d = 0; d < KW; ++d)
-					acc = fmaf(a[d], tile[wv][j][(lane - R + d) & 63], acc);
+					acc = fmaf(a[d], tile_w[j][(lane - R + d) & 63], acc);
 				const bool yb = gy < R || gy >= h - R;
 				if (xb || yb)
 				{
@@ -1322,7 +1339,7 @@ namespace rir
 					acc = acc / (sx * sy);
 				}
 				if (owner)
-					tile[wv][j][lane] = acc; // every lane has read row j before any lane writes it (one wave, in order)
+					tile_w[j][lane] = acc; // every lane has read row j before any lane writes it (one wave, in order)
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1335,7 +1352,7 @@ namespace rir
 		// a filtered pixel of the block: LDS address clamped into the strip (always readable); `ok` says whether it is the
 		// pixel asked for - when not (float rounding of px + 1 only), the pixel is recomputed from global memory
 		auto in_block = [&](int c, int rr) -> bool { return c >= gx0 && c < gx0 + OUTW && rr >= gy0 && rr < gy0 + TY; };
-		auto block_px = [&](int c, int rr) -> float { return tile[wv][min(max(rr - gy0, 0), TY - 1)][min(max(c - gx0 + R, 0), 63)]; };
+		auto block_px = [&](int c, int rr) -> float { return tile_w[min(max(rr - gy0, 0), TY - 1)][min(max(c - gx0 + R, 0), 63)]; };
 		uint16_t *d = dst + fbase + x;
 		for (int j = 0; j < OH; ++j)
 		{
@@ -1365,6 +1382,99 @@ namespace rir
 			const uint16_t near = CastTo<u16_via_f32>::from((double)p2).v;
 			d[(int64_t)y * w] = outside ? (strategy == TRANSLATE_CONSTANT ? (uint16_t)background : near) : blend;
 		}
+		}
+	}
+
+	// register budget of the one-kernel form (radius 2: 6 waves per SIMD - at 7 it spilled 2 VGPRs; wider: the compiler's choice)
+#define RIR_CHAIN_OCC __attribute__((amdgpu_waves_per_eu(R == 1 ? 7 : R == 2 ? 5 : 1, R == 1 ? 7 : R == 2 ? 5 : 8)))
+	// grid = (tiles along x, groups of 4 tile rows, frames), block = 256 (4 independent waves, one tile each)
+	template <int R>
+	RIR_CHAIN_OCC __global__ __launch_bounds__(256) void filter_chain_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w, int h,
+															   ChainBadPixels bp, const float *__restrict__ kern, const float *__restrict__ offsets,
+															   int per_frame_offsets, int strategy, uint32_t background)
+	{
+		__shared__ float tile[4][RIR_CHAIN_TY][64];
+		const int lane = threadIdx.x & 63;
+		const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+		// XCD-major tile order, row bands fastest (see gaussian_sep_kernel)
+		const unsigned gx = gridDim.x, gy = gridDim.y;
+		const unsigned id2 = xcd_major(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+		const int by = (int)(id2 % gy), bx = (int)((id2 / gy) % gx), bz = (int)(id2 / (gy * gx));
+		chain_tile<R, 0>(src, dst, w, h, bp, kern, offsets, per_frame_offsets, strategy, background, bx, by * 4 + wv, bz, lane, tile[wv], nullptr, nullptr);
+	}
+	// radius 1, the regular tiles (same grid): 8 waves per SIMD, no scratch; what it cannot take goes on the list
+	__attribute__((amdgpu_waves_per_eu(8, 8))) __global__ __launch_bounds__(256) void filter_chain_regular_kernel(
+		const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w, int h, ChainBadPixels bp, const float *__restrict__ kern,
+		const float *__restrict__ offsets, int per_frame_offsets, int strategy, uint32_t background, unsigned long long *__restrict__ worklist,
+		unsigned int *__restrict__ work_count)
+	{
+		__shared__ float tile[4][RIR_CHAIN_TY][64];
+		const int lane = threadIdx.x & 63;
+		const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+		const unsigned gx = gridDim.x, gy = gridDim.y;
+		const unsigned id2 = xcd_major(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+		const int by = (int)(id2 % gy), bx = (int)((id2 / gy) % gx), bz = (int)(id2 / (gy * gx));
+		chain_tile<1, 1>(src, dst, w, h, bp, kern, offsets, per_frame_offsets, strategy, background, bx, by * 4 + wv, bz, lane, tile[wv], worklist, work_count);
+	}
+	// radius 1, the listed tiles through the general path: grid = any, block = 256; wave (block, wv) takes entries block * 4 + wv,
+	// + 4 * gridDim.x, ... of the list
+	__global__ __launch_bounds__(256) void filter_chain_listed_kernel(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int w, int h,
+																	  ChainBadPixels bp, const float *__restrict__ kern, const float *__restrict__ offsets,
+																	  int per_frame_offsets, int strategy, uint32_t background,
+																	  const unsigned long long *__restrict__ worklist, const unsigned int *__restrict__ work_count,
+																	  unsigned int *__restrict__ other_count)
+	{
+		__shared__ float tile[4][RIR_CHAIN_TY][64];
+		const int lane = threadIdx.x & 63;
+		const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+		const unsigned int count = __hip_atomic_load(work_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		for (unsigned int e = blockIdx.x * 4u + (unsigned int)wv; e < count; e += gridDim.x * 4u)
+		{
+			const unsigned long long id = worklist[e];
+			chain_tile<1, 2>(src, dst, w, h, bp, kern, offsets, per_frame_offsets, strategy, background, (int)(id & 0xffffu), (int)((id >> 16) & 0xffffu),
+							 (int)(id >> 32), lane, tile[wv], nullptr, nullptr);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the strip is reused by the wave's next tile)
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		}
+		// the OTHER counter of the list - the one the previous call on this stream used, long read by then - is emptied for the next
+		// call (a ticket that finds the last workgroup to leave costs more than the kernel: 2 048 atomic adds on one address)
+		if (blockIdx.x == 0 && threadIdx.x == 0)
+			__hip_atomic_store(other_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+
+	// the list of a stream's calls: [two counters, used in turn | one 64-bit entry per tile], zeroed once when it is allocated; a call
+	// appends under one counter and empties the other one (filter_chain_listed_kernel).  Calls on one stream are ordered, calls on
+	// different streams have lists of their own.  Grow-only, kept for the life of the process.  *parity: which counter this call uses.
+	static unsigned int *chain_list_of(hipStream_t st, size_t ntile, int *parity)
+	{
+		struct List
+		{
+			void *first = nullptr;
+			size_t second = 0;
+			int calls = 0;
+		};
+		static std::mutex mu;
+		static std::map<hipStream_t, List> *lists = new std::map<hipStream_t, List>;
+		std::lock_guard<std::mutex> g(mu);
+		auto &e = (*lists)[st];
+		*parity = e.calls++ & 1;
+		if (e.second < ntile)
+		{
+			void *p = nullptr;
+			const size_t want = std::max<size_t>(ntile, 4096);
+			if (hipMalloc(&p, 8 + want * 8) != hipSuccess)
+				return nullptr;
+			if (hipMemsetAsync(p, 0, 8, st) != hipSuccess)
+			{
+				(void)hipFree(p);
+				return nullptr;
+			}
+			if (e.first)
+				(void)hipFree(e.first); // (waits for the device: the previous calls that used it are through)
+			e.first = p, e.second = want;
+		}
+		return static_cast<unsigned int *>(e.first);
 	}
 
 	// d_fix: [nframes][nbad] uint32 scratch (unused when nbad == 0).  radius 1..4, strategy CONSTANT or NEAREST.
@@ -1384,8 +1494,29 @@ namespace rir
 		switch (radius)
 		{
 		case 1:
+#ifdef RIR_CHAIN_ONE_KERNEL /* (measurements: round 2's form, both paths in one kernel at 7 waves per SIMD) */
 			hipLaunchKernelGGL((filter_chain_kernel<1>), grid, block, 0, st, src, dst, w, h, bp, d_kernel, d_offsets, per_frame, strategy, (uint32_t)background);
 			break;
+#endif
+		{
+			// regular tiles in registers; the rest through a list (stream-ordered scratch: [count | pad to 8 bytes][one entry per tile])
+			const size_t ntile = (size_t)grid.x * grid.y * 4 * grid.z;
+			int par = 0;
+			unsigned int *counters = chain_list_of(st, ntile, &par);
+			if (!counters)
+				return hipErrorOutOfMemory;
+			unsigned long long *entries = reinterpret_cast<unsigned long long *>(counters + 2);
+			unsigned int *count = counters + par;
+			// (8 waves per SIMD; with its workgroups per CU capped by unused LDS - 7, 6, 5, 4 waves per SIMD - the kernel is no faster: 0.152-0.159,
+			// 0.154-0.156, 0.152-0.157, 0.164, 0.163 ms per 256 frames against 0.153-0.159)
+			hipLaunchKernelGGL(filter_chain_regular_kernel, grid, block, 0, st, src, dst, w, h, bp, d_kernel, d_offsets, per_frame, strategy,
+							   (uint32_t)background, entries, count);
+			// (the list is short - the first / last row bands of every frame: enough workgroups for it, not for every tile)
+			const unsigned int lb = (unsigned int)std::min<size_t>((ntile / 8 + 3) / 4 + 1, 2048);
+			hipLaunchKernelGGL(filter_chain_listed_kernel, dim3(lb), block, 0, st, src, dst, w, h, bp, d_kernel, d_offsets, per_frame, strategy,
+							   (uint32_t)background, entries, count, counters + (par ^ 1));
+			break;
+		}
 		case 2:
 			hipLaunchKernelGGL((filter_chain_kernel<2>), grid, block, 0, st, src, dst, w, h, bp, d_kernel, d_offsets, per_frame, strategy, (uint32_t)background);
 			break;
