@@ -793,6 +793,105 @@ namespace rir
 		lossy_sums_tail(sp, a, background, sp.next_errors_out);
 	}
 
+	// ---- the pixel arithmetic of a run on PAIRS of pixels (packed 16-bit instructions) -----------------------------------
+	// The resident kernel is bound by its vector instructions once several streams share the chip (PMC, profiles/r03_pmc_lossy.json:
+	// 838 per wave and frame, SIMD utilisation 0.60 with seven streams); most of them unpacked 16-bit lanes, worked on them as
+	// 32-bit values and packed them again.  Everything that is 16 bits wide in the reference (pixels, reference and constant
+	// values, counters, the per-pixel error bound - errors above 65 535 bound nothing, |t - ref| <= 65 535) is done here two
+	// pixels per instruction: saturating subtract for sub_min and for "a > b" (a -sat b != 0), max - min for |a - b|, bit-field
+	// inserts under 0 / 0xffff half masks for every select; only the running sums and the squares are 32 bits per pixel.
+	// Same values as lossy_pixel / the scalar sums, bit for bit (tests/test_gpu_lossy.py against the oracle).
+	typedef unsigned short lossy_u16x2 __attribute__((ext_vector_type(2)));
+	__device__ __forceinline__ lossy_u16x2 lp2(uint32_t v) { return __builtin_bit_cast(lossy_u16x2, v); }
+	__device__ __forceinline__ uint32_t lu1(lossy_u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+	__device__ __forceinline__ uint32_t lossy_both(uint32_t v) { return (v > 65535u ? 65535u : v) * 0x10001u; } // a 16-bit bound in both halves
+	// per half: 0xffff where the half of x is not 0, else 0
+	__device__ __forceinline__ uint32_t lossy_nz_mask(lossy_u16x2 x)
+	{
+		const lossy_u16x2 one = {1, 1}, ffff = {0xffff, 0xffff};
+		return lu1(__builtin_elementwise_min(x, one) * ffff);
+	}
+	__device__ __forceinline__ uint32_t lossy_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); } // mask ? a : b, bit by bit
+	struct LossyPairConsts
+	{
+		uint32_t min2, bg2, low2, high2, n2; // both halves: subtract_min bound (0 when off), background, error bounds, n_after
+	};
+	__device__ __forceinline__ LossyPairConsts lossy_pair_consts(const LossyFrameConsts &c)
+	{
+		LossyPairConsts p;
+		p.min2 = c.subtract_min ? lossy_both(c.min) : 0u;
+		p.bg2 = lossy_both(c.background);
+		p.low2 = lossy_both((uint32_t)c.low_error), p.high2 = lossy_both((uint32_t)c.high_error); // (both >= 0: lossy_budget*)
+		p.n2 = (uint32_t)c.n_after * 0x10001u;
+		return p;
+	}
+	// lossy_pixel for the pixels 2p, 2p + 1 of a group of 8 (word p of the U16x8 values)
+	__device__ __forceinline__ void lossy_pixel_pair(const LossyFrameConsts &c, const LossyPairConsts &pc, uint32_t v2, uint32_t old2, uint32_t last2, uint32_t &ref2,
+													 uint32_t &sum_lo, uint32_t &sum_hi, uint32_t &cc2, uint32_t &cv2, uint32_t &t_in2, uint32_t &out2)
+	{
+		const lossy_u16x2 one = {1, 1};
+		const lossy_u16x2 v = lp2(v2), ref = lp2(ref2);
+		const lossy_u16x2 t = __builtin_elementwise_sub_sat(v, lp2(pc.min2)); // sub_min (min2 = 0 when off)
+		t_in2 = lu1(t);
+		const uint32_t fgm = lossy_nz_mask(__builtin_elementwise_sub_sat(v, lp2(pc.bg2))); // v > background
+		const lossy_u16x2 max_error = lp2(lossy_bfi(fgm, pc.high2, pc.low2));
+		const lossy_u16x2 diff = __builtin_elementwise_max(t, ref) - __builtin_elementwise_min(t, ref);
+		lossy_u16x2 nk = __builtin_elementwise_sub_sat(diff, max_error); // != 0: the pixel is not kept
+		if (!c.add_loss)
+			nk = nk | ((lp2(last2) ^ v) >> (lossy_u16x2){13, 13});
+		const uint32_t NM = lossy_nz_mask(nk);
+		if (c.ra > 0)
+		{
+			uint32_t sel = 0;
+			lossy_u16x2 cc = lp2(cc2);
+			if (c.full_ring)
+			{ // what leaves the sum: the constant value while its stretch lasts, else the ring's oldest image
+				sel = lossy_bfi(lossy_nz_mask(cc), cv2, old2);
+				cc = __builtin_elementwise_sub_sat(cc, one);
+			}
+			const uint32_t t_lo = lu1(t) & 0xffffu, t_hi = lu1(t) >> 16;
+			const uint32_t sm_lo = sum_lo + t_lo - (sel & 0xffffu), sm_hi = sum_hi + t_hi - (sel >> 16);
+			const uint32_t q = lossy_div(sm_lo, c.div_magic) | (lossy_div(sm_hi, c.div_magic) << 16);
+			sum_lo = (NM & 0xffffu) ? __umul24(t_lo, (uint32_t)c.n_after) : sm_lo;
+			sum_hi = (NM >> 16) ? __umul24(t_hi, (uint32_t)c.n_after) : sm_hi;
+			out2 = lossy_bfi(NM, lu1(t), q);
+			cv2 = lossy_bfi(NM, lu1(t), cv2);
+			cc2 = lossy_bfi(NM, pc.n2, lu1(cc));
+		}
+		else
+			out2 = lossy_bfi(NM, lu1(t), ref2);
+		ref2 = lossy_bfi(NM, lu1(t), ref2);
+	}
+	// the sums of a frame over the 8 pixels of a thread against the previous output: totals and foreground parts
+	//   a[0] = sum d (fg) + (fg pixels << 32), a[1] = sum d2 (fg), a[2] = sum d (all) + (8 << 32), a[3] = sum d2 (all)
+	// (the background parts are the differences; d2 = the wrapped 32-bit square, sign-extended, as the reference's int arithmetic has it)
+	__device__ __forceinline__ void lossy_sums8_packed(const U16x8 &v8, const U16x8 &o8, uint32_t min2, uint32_t bg2, long long *a)
+	{
+		const lossy_u16x2 one = {1, 1};
+		uint32_t fd = 0, fn = 0, dall = 0;
+		long long f2 = 0, t2 = 0;
+#pragma unroll
+		for (int p = 0; p < 4; ++p)
+		{
+			const lossy_u16x2 v = lp2(v8.d[p]), o = lp2(o8.d[p]);
+			const lossy_u16x2 t = __builtin_elementwise_sub_sat(v, lp2(min2));
+			const lossy_u16x2 d = __builtin_elementwise_max(t, o) - __builtin_elementwise_min(t, o);
+			const lossy_u16x2 fg = __builtin_elementwise_min(__builtin_elementwise_sub_sat(v, lp2(bg2)), one); // 1 where v > background
+			fd = __builtin_amdgcn_udot2(d, fg, fd, false);
+			dall = __builtin_amdgcn_udot2(d, one, dall, false);
+			fn = __builtin_amdgcn_udot2(fg, one, fn, false);
+			const uint32_t d_lo = lu1(d) & 0xffffu, d_hi = lu1(d) >> 16;
+			const int32_t q_lo = (int32_t)__umul24(d_lo, d_lo), q_hi = (int32_t)__umul24(d_hi, d_hi); // (d < 2^16: the 24-bit multiplier gives the low 32 bits of d * d)
+			const uint32_t m = lu1(fg);
+			t2 += (long long)q_lo + (long long)q_hi;
+			f2 += (long long)((m & 1u) ? q_lo : 0) + (long long)((m >> 16) ? q_hi : 0);
+		}
+		a[0] = (long long)(((unsigned long long)fn << 32) | fd);
+		a[1] = f2;
+		a[2] = (long long)((8ull << 32) | dall);
+		a[3] = t2;
+	}
+
 	// ---- a run of frames in one launch ---------------------------------------------------------------------------
 	//
 	// grid = workgroups of a stream (nb = lossy_run_workgroups(full)) x streams, 1-D, all resident at once (kLossyRunMaxWorkgroups,
@@ -889,7 +988,10 @@ namespace rir
 			if (inside && k + 1 < rp.nsteps)
 				vn = ld8(in + (size_t)(k + 1) * rp.frame_px, i8);
 			const long long background = as_global(rp.bg)[(size_t)k * rp.bg_stride];
-			// 1. this workgroup's share of the frame's sums
+			// 1. this workgroup's share of the frame's sums (the packed form of the sums - lossy_sums8_packed, four reductions instead of
+			// six - is kept behind RIR_LOSSY_PACKED_SUMS: same values, but its extra live registers cost more than its instructions save:
+			// 7 streams 509 k frames/s against 593 k; scripts/lossy_ab.sh)
+#ifndef RIR_LOSSY_PACKED_SUMS
 			int32_t fd = 0, fn = 0, bd = 0, bn = 0;
 			long long f2 = 0, b2 = 0;
 			if (lossy)
@@ -907,15 +1009,33 @@ namespace rir
 						bd += d, b2 += d2, bn += 1;
 				}
 			}
+#else
+			long long ps[4] = {0, 0, 0, 0};
+			if (lossy)
+				lossy_sums8_packed(v8, o8, st.subtract_min ? lossy_both(st.min) : 0u, lossy_both((uint32_t)background), ps);
+#endif
 #ifdef RIR_LOSSY_DIAG
 			const unsigned long long dg0 = __builtin_amdgcn_s_memrealtime();
 			unsigned long long dg1 = 0, dg2 = 0, dg3 = 0;
 #endif
 			// wave sums -> LDS; wave 0 adds the waves up, publishes, collects everybody's words and decides
+#ifndef RIR_LOSSY_PACKED_SUMS
 			long long ws[6] = {fd, f2, fn, bd, b2, bn};
 #pragma unroll
 			for (int j = 0; j < 6; ++j)
 				ws[j] = lossy_wave_sum(ws[j]);
+#else
+			// four reductions instead of six: counts ride in the high halves of the sums of d (a wave's sum of d stays below 2^26),
+			// the background parts are totals minus foreground
+			long long ws[6];
+			{
+#pragma unroll
+				for (int j = 0; j < 4; ++j)
+					ps[j] = lossy_wave_sum(ps[j]);
+				const long long wfd = ps[0] & 0xffffffffll, wfn = ps[0] >> 32, wd = ps[2] & 0xffffffffll, wn = ps[2] >> 32;
+				ws[0] = wfd, ws[1] = ps[1], ws[2] = wfn, ws[3] = wd - wfd, ws[4] = ps[3] - ps[1], ws[5] = wn - wfn;
+			}
+#endif
 			const int lane = tid & 63, wave = tid >> 6;
 			if (lane < 6)
 				red[wave][lane] = lane == 0 ? ws[0] : lane == 1 ? ws[1] : lane == 2 ? ws[2] : lane == 3 ? ws[3] : lane == 4 ? ws[4] : ws[5];
@@ -1060,6 +1180,7 @@ namespace rir
 			{
 				const LossyFrameConsts fc = {st.min, dec.background, st.subtract_min, ra, full_ring ? 1 : 0, n_after, add_loss, dec.low_error, dec.high_error,
 											 lossy_div_magic(n_after)};
+#ifdef RIR_LOSSY_SCALAR_UPDATE /* (round 2's form, one pixel at a time: 7 streams 570 k frames/s against 593 k with pairs) */
 				bool rc = false, ccg = false;
 #pragma unroll
 				for (int q = 0; q < 8; ++q)
@@ -1070,6 +1191,12 @@ namespace rir
 					t8.set(q, t_in);
 					o8.set(q, t);
 				}
+#else
+				const LossyPairConsts pc = lossy_pair_consts(fc);
+#pragma unroll
+				for (int p = 0; p < 4; ++p)
+					lossy_pixel_pair(fc, pc, v8.d[p], old8.d[p], last8.d[p], ref8.d[p], sum[2 * p], sum[2 * p + 1], cc8.d[p], cv8.d[p], t8.d[p], o8.d[p]);
+#endif
 				last8 = v8;
 				st8(out + (size_t)k * rp.frame_px, i8, o8);
 				if (ra > 0)
