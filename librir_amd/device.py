@@ -199,12 +199,14 @@ class CodecContext:
         )
         return EncodedBatch(L, self.hdr, self.tile_off, self.chunk_off, self.stream)
 
-    def place_workspace(self, frames, tries=10, spacing_bytes=3 << 29):
+    def place_workspace(self, frames, tries=6, spacing_bytes=6 << 30):
         """Replaces the encode workspace by one the LIBRARY allocates where the packing kernel runs fast for THIS frames buffer
         (rir_codec_workspace_create_device; DESIGN.md §5: device allocations fall into a few placement classes, and the kernel -
         frames in, slots out at the same pace - is 10 % slower when both are of one class).  One-off set-up of a few
         milliseconds; the candidates that lose and the spacers between them are freed by the library before it returns, torch's
-        allocator is not touched.  Returns the measured packing times in microseconds, the kept candidate's first."""
+        allocator is not touched.  There are three classes and they come in runs of 8-24 GiB of the address space
+        (profiles/r03_placement/): candidates ``spacing_bytes`` apart, at most ``tries`` of them.  Returns the measured packing
+        times in microseconds, the kept candidate's first."""
         L = self.layout
         fr = _frames3(frames, torch.uint16)
         if tuple(fr.shape) != (L.nframes, L.height, L.width):
