@@ -66,13 +66,17 @@ dec = torch.empty_like(t)
 ctx.place_workspace(t)  # (set-up: the workspace goes where the packing kernel measures fastest for this frames buffer, as in bench.py)
 
 
-def dev_roundtrip():
-    ctx.decode(ctx.encode(t), out=dec, check=False)
+def dev_roundtrip():  # the two-launch step of bench.py: the slotted form straight into the decoder
+    ctx.encode_tiles(t)
+    ctx.decode_slots(out=dec, check=False)
 
 
 ms = gpu_ms(dev_roundtrip, 10)
 assert torch.equal(dec.view(torch.int16), t.view(torch.int16))
 c1 = {"workload": "%d x %dx%d u16, S1, GOP %d, encode+decode" % (n, w, h, gop), "device_resident_fps": n / ms * 1e3}
+ms_dense = gpu_ms(lambda: ctx.decode(ctx.encode(t), out=dec, check=False), 10)
+assert torch.equal(dec.view(torch.int16), t.view(torch.int16))
+c1["device_resident_fps_through_the_dense_form"] = n / ms_dense * 1e3
 ms = gpu_ms(lambda: ctx.decode(ctx.encode(t, single_pass=True), out=dec, check=False), 10)
 assert torch.equal(dec.view(torch.int16), t.view(torch.int16)) and ctx.encode_status() == 0
 c1["device_resident_fps_single_pass_encoder"] = n / ms * 1e3
@@ -226,7 +230,7 @@ if n3 > base.shape[0]:
 ctx3 = D.CodecContext(w3, h3, n3, gop, device=dev)
 dec3 = torch.empty_like(t3)
 ctx3.place_workspace(t3)
-ms = gpu_ms(lambda: ctx3.decode(ctx3.encode(t3), out=dec3, check=False), 5)
+ms = gpu_ms(lambda: (ctx3.encode_tiles(t3), ctx3.decode_slots(out=dec3, check=False)), 5)
 assert torch.equal(dec3.view(torch.int16), t3.view(torch.int16))
 out["configs[3]"] = {"workload": "per-GPU shard of the 10 000-frame job: %d x %dx%d u16 (250 distinct S1 frames tiled), encode+decode" % (n3, w3, h3),
                      "device_resident_fps": n3 / ms * 1e3, "raw_GBs": n3 * 4.0 * h3 * w3 / ms / 1e6,
@@ -270,6 +274,21 @@ for i in range(1, nreg):
     dreg1.compute(tf32[i])
 c4["registration_ecc_device_resident_frame_by_frame_fps"] = (nreg - 1) / (time.perf_counter() - t0)
 assert dreg1.x == dreg.x and dreg1.y == dreg.y
+# eight independent sequences side by side (rir_ecc_align_multi_device): each one's track is bit-identical to its solo run
+S8 = 8
+seqs8 = [tf32] + [torch.from_numpy(s3_registration(nreg, h, w, seed=99 + q)[0]).to(dev) for q in range(1, S8)]
+best8 = 0.0
+for _ in range(3):
+    rs = [DeviceRegistratorECC(1, 1) for _ in range(S8)]
+    for q in range(S8):
+        rs[q].start(seqs8[q][0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    DeviceRegistratorECC.compute_many_multi(rs, [s_[1:] for s_ in seqs8])
+    best8 = max(best8, S8 * (nreg - 1) / (time.perf_counter() - t0))
+assert rs[0].x == dreg.x and rs[0].y == dreg.y
+c4["registration_ecc_8_sequences_device_resident_fps"] = best8
+del seqs8, rs
 c4["registration_max_error_px"] = float(max(np.abs(np.array(regr.x) - shifts[:nreg, 0]).max(), np.abs(np.array(regr.y) - shifts[:nreg, 1]).max()))
 
 
@@ -298,26 +317,36 @@ ms = gpu_ms(lossy_dev, 3)
 c4["lossy_then_encode_device_resident_fps"] = n4 / ms * 1e3
 
 
-def lossy_only():
-    ls = D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32)
-    ls.step(treg, errors=False)
-    ls.close()
+# the step alone, as bench.py's other_paths times it: the stream exists already (created and seeded outside the clock), calls of 200 frames
+# (on bench.py's data, the S1 recipe, so that the two tools agree: best of 3, as there)
+m1 = 200
+s1_200 = torch.from_numpy(s1_noisy_background(m1, h, w)).to(dev)
 
 
-ms = gpu_ms(lossy_only, 3)
-c4["lossy_step_device_resident_fps_one_stream"] = n4 / ms * 1e3
+def best_rate(fn, count, reps=3):
+    b = 0.0
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        b = max(b, count / (time.perf_counter() - t0_))
+    return b
+
+
+ls1 = D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32)
+ls1.step(s1_200[:60], errors=False)
+c4["lossy_step_device_resident_fps_one_stream"] = best_rate(lambda: ls1.step(s1_200, errors=False), m1)
+ls1.status()
+ls1.close()
 # independent streams in shared launches (rir_lossy_step_multi_device): the loss state is sequential in time, streams run side by side
 for S in (7, 32):  # 7 streams of this size share one resident launch; more go a batch after the other
-    m = 20 if args.quick else 60
+    m = 20 if args.quick else m1
     streams = [D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32) for _ in range(S)]
-    ins = [treg[:m].clone() for _ in range(S)]
+    ins = [s1_200[:m].clone() for _ in range(S)]
     D.LossyStream.step_many(streams, ins, errors=False)  # first frames + ring fill started
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        D.LossyStream.step_many(streams, ins, errors=False)
-    torch.cuda.synchronize()
-    c4["lossy_step_device_resident_fps_%d_streams" % S] = 3 * m * S / (time.perf_counter() - t0)
+    c4["lossy_step_device_resident_fps_%d_streams" % S] = best_rate(lambda: D.LossyStream.step_many(streams, ins, errors=False), m * S)
+    streams[0].status()
     for st_ in streams:
         st_.close()
     del ins
