@@ -101,6 +101,50 @@ namespace rir
 	// touches the bins a workgroup has filled, a few hundred for thermal images).
 	// The last workgroup to arrive takes the mode of the merged histogram, lowest bin wins ties:
 	// stats[0] = background = (bin << 2) + 1 (get_background, h264.cpp:1955-1991), and clears the histogram.
+	// The 8 pixels of every lane into the workgroup's LDS histogram.  Thermal scenes are flat: on the motion-corrected registration
+	// stream of BASELINE configs[4] a frame has ~20 distinct levels, the 512 pixels of a wave instruction fall into two or three
+	// bins, and 64 LDS atomics on one address are 64 passes (the histogram pass of 7 x 199 such frames took 1.34 ms against 0.25 ms
+	// on the S1 recipe's ~1 000 levels - 38 % of the whole step).  So a wave first looks at the four bins around its first pixel's:
+	// when at least half of the lanes start there, every lane counts its pixels in those four bins into four 16-bit fields, ONE
+	// reduction over the wave adds the fields up and four lanes add the totals - 4 atomics instead of ~500; pixels outside the four
+	// bins, and waves on spread data (one ballot to find out), use plain atomics.  Same counts either way.
+	__device__ __forceinline__ void lossy_hist_add8(uint32_t *lh, const uint32_t *bins, bool in)
+	{
+		const unsigned long long votes = __ballot(in);
+		if (!votes)
+			return;
+		const int lane = (int)(threadIdx.x & 63);
+		const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)bins[0], __builtin_ctzll(votes)) & ~3u;
+		if (__builtin_popcountll(__ballot(in && bins[0] - base < 4u)) * 2 >= __builtin_popcountll(votes))
+		{
+			unsigned long long packed = 0;
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+			{
+				const uint32_t rel = bins[k] - base; // (below the base: wraps to a large number)
+				packed += (in && rel < 4u) ? 1ull << (16 * (rel & 3u)) : 0ull;
+			}
+			const unsigned long long tot = (unsigned long long)lossy_wave_sum((long long)packed); // (a wave holds 512 pixels: no field overflows)
+			if (lane < 4)
+			{
+				const uint32_t c = (uint32_t)(tot >> (16 * lane)) & 0xffffu;
+				if (c)
+					atomicAdd(&lh[base + lane], c);
+			}
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+				if (in && bins[k] - base >= 4u)
+					atomicAdd(&lh[bins[k]], 1u);
+		}
+		else
+		{
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+				if (in)
+					atomicAdd(&lh[bins[k]], 1u);
+		}
+	}
+
 	template <bool TABLE>
 	__global__ __launch_bounds__(1024) void lossy_hist_mode_kernel(LossyStep one, const LossyStep *__restrict__ table)
 	{
@@ -116,17 +160,20 @@ namespace rir
 		const int i0 = blockIdx.x * sp.hist_px, i1 = min(i0 + sp.hist_px, s);
 		if (((i0 | i1) & 7) == 0)
 		{ // 8 pixels per 16-byte load
-			for (int i = i0 / 8 + tid; i < i1 / 8; i += 1024)
-			{
-				const lossy_v4u v = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(tmp + (size_t)i * 8);
-				atomicAdd(&lh[(v.x & 0xffffu) >> 2], 1u), atomicAdd(&lh[v.x >> 18], 1u);
-				atomicAdd(&lh[(v.y & 0xffffu) >> 2], 1u), atomicAdd(&lh[v.y >> 18], 1u);
-				atomicAdd(&lh[(v.z & 0xffffu) >> 2], 1u), atomicAdd(&lh[v.z >> 18], 1u);
-				atomicAdd(&lh[(v.w & 0xffffu) >> 2], 1u), atomicAdd(&lh[v.w >> 18], 1u);
+			const int n8 = i1 / 8;
+			for (int ib = i0 / 8; ib < n8; ib += 1024)
+			{ // (wave-uniform trip count: lossy_hist_add votes across the wave)
+				const int i = ib + tid;
+				const bool in = i < n8;
+				lossy_v4u v = {0, 0, 0, 0};
+				if (in)
+					v = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(tmp + (size_t)i * 8);
+				const uint32_t bins[8] = {(v.x & 0xffffu) >> 2, v.x >> 18, (v.y & 0xffffu) >> 2, v.y >> 18, (v.z & 0xffffu) >> 2, v.z >> 18, (v.w & 0xffffu) >> 2, v.w >> 18};
+				lossy_hist_add8(lh, bins, in);
 			}
 		}
 		else
-			for (int i = i0 + tid; i < i1; i += 1024)
+			for (int i = i0 + tid; i < i1; i += 1024) // (frames whose lossy part is not a multiple of 8 pixels: one pixel per lane)
 				atomicAdd(&lh[tmp[i] >> 2], 1u);
 		__syncthreads();
 		for (int i = tid; i < 16384; i += 1024)

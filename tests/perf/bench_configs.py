@@ -350,6 +350,16 @@ for S in (7, 32):  # 7 streams of this size share one resident launch; more go a
     for st_ in streams:
         st_.close()
     del ins
+# the same seven streams on THIS configuration's data, the motion-corrected registration stream: a flat scene, ~20 distinct levels per frame -
+# the histogram pass of the step depends on how the levels are spread (lossy_hist_add8, lossy_kernels.hip)
+streams = [D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32) for _ in range(7)]
+ins = [treg[:m1].clone() for _ in range(7)]
+D.LossyStream.step_many(streams, ins, errors=False)
+c4["lossy_step_device_resident_fps_7_streams_on_the_motion_corrected_stream"] = best_rate(lambda: D.LossyStream.step_many(streams, ins, errors=False), ins[0].shape[0] * 7)
+streams[0].status()
+for st_ in streams:
+    st_.close()
+del ins
 with tempfile.TemporaryDirectory() as d:
     dst = os.path.join(d, "lossy.h264")
     t0 = time.perf_counter()
