@@ -17,6 +17,7 @@
 #include <cstddef>
 
 #include "ecc_kernels.h"
+#include "resident_device.h"
 #include "runtime.h"
 
 namespace rir
@@ -512,13 +513,18 @@ namespace rir
 	// ecc_solve_kernel does.  Nothing crosses sequences; a sequence whose alignment fails stops, the others go on.
 	// rows: per sequence [V][16] granules, then its pub granule (ecc_run_workspace_bytes).
 	__attribute__((amdgpu_waves_per_eu(RIR_ECC_MULTI_WAVES, RIR_ECC_MULTI_WAVES))) __global__ __launch_bounds__(ECC_BLOCK) void ecc_run_multi_kernel(EccSeq *__restrict__ table, int S, int w, int h, int V, int max_iter, double eps,
-																	  unsigned int epoch)
+																	  unsigned int epoch, unsigned int *__restrict__ ctl, unsigned int arrivals_before)
 	{
 		__shared__ EccReduceLds red;
 		__shared__ double part[ECC_NSUMS][17];
 		__shared__ double tot[ECC_NSUMS];
 		__shared__ float sh_t[2];
 		__shared__ int sh_done;
+		__shared__ unsigned int sh_flag;
+		// is the whole launch on the chip?  (resident_device.h: if not - ordinary kernels of other streams can keep the last workgroups
+		// from fitting - everybody leaves before anything is written and the host runs the chunk again with fewer slices)
+		if (resident_rendezvous(ctl, arrivals_before, gridDim.x, epoch, &sh_flag) != RESIDENT_GO)
+			return;
 		const int q = blockIdx.x % S, slice = blockIdx.x / S, nslices = gridDim.x / S, tid = threadIdx.x;
 		const EccSeq sq = table[q];
 		const float *image = sq.image, *gximg = sq.gx, *gyimg = sq.gy;
@@ -623,7 +629,8 @@ namespace rir
 	int ecc_run_multi_capacity() { return resident_capacity(reinterpret_cast<const void *>(ecc_run_multi_kernel), ECC_BLOCK, 0); }
 	int ecc_rows(int w, int h) { return ecc_blocks(w, h); }
 	// d_table: nseq entries (device); nslices workgroups per sequence (1 .. ecc_rows(w, h)); nseq * nslices <= ecc_run_multi_capacity()
-	hipError_t launch_ecc_run_multi(EccSeq *d_table, int nseq, int nslices, int w, int h, int max_iter, double eps, unsigned int epoch, hipStream_t st)
+	hipError_t launch_ecc_run_multi(EccSeq *d_table, int nseq, int nslices, int w, int h, int max_iter, double eps, unsigned int epoch, unsigned int *d_ctl,
+									unsigned int arrivals_before, hipStream_t st)
 	{
 		const int V = ecc_blocks(w, h);
 		if (nseq <= 0 || nslices <= 0 || nslices > V || (long long)nseq * nslices > ecc_run_multi_capacity())
@@ -631,7 +638,8 @@ namespace rir
 		ResidentGate gate(st); // its workgroups wait for each other: not beside any other resident launch of the process
 		if (!gate.ok())
 			return hipErrorUnknown;
-		hipLaunchKernelGGL(ecc_run_multi_kernel, dim3((unsigned)(nseq * nslices)), dim3(ECC_BLOCK), 0, st, d_table, nseq, w, h, V, max_iter, eps, epoch);
+		hipLaunchKernelGGL(ecc_run_multi_kernel, dim3((unsigned)(nseq * nslices)), dim3(ECC_BLOCK), 0, st, d_table, nseq, w, h, V, max_iter, eps, epoch, d_ctl,
+						   arrivals_before);
 		return hipGetLastError();
 	}
 

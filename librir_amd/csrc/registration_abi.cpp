@@ -3,6 +3,7 @@
 // The reference computes sub-pixel translations in Python by calling OpenCV
 // (src/python/librir/registration/masked_registration_ecc.py:166-168, cv2.findTransformECC with
 // MOTION_TRANSLATION); these two entry points are what that call binds to here.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -33,12 +34,28 @@ namespace
 		unsigned int epoch = 0; // launches of ecc_run_kernel on this workspace
 		EccFrameResult *results_host = nullptr; // coherent page-locked host memory, kEccMaxSequence entries, kept for the life of the process
 		// multi-sequence launches: per sequence its rows of granules, its results; the table of sequences and its page-locked copy
-		DeviceBuffer multi_rows, multi_results, multi_table;
+		DeviceBuffer multi_rows, multi_results, multi_table, multi_ctl;
 		PinnedBuffer multi_stage, multi_back;
+		unsigned int multi_arrivals = 0; // workgroups launched on multi_ctl so far (resident_device.h)
 	};
 	EccScratch &scratch()
 	{
 		static EccScratch s;
+		return s;
+	}
+	// The pre-processing of a chunk of frames (rir_ecc_prepare_frames_device) has a scratch and a stream order of its own: it shares
+	// nothing with the alignments, so a caller may run the pre-processing of chunk k + 1 on a second stream under the alignments
+	// of chunk k (DeviceRegistratorECC.compute_many_multi).  Only its own calls are ordered among themselves.
+	struct PrepScratch
+	{
+		std::mutex mu;
+		DeviceBuffer mm_frames, full_frames;
+		hipEvent_t tail = nullptr;
+		bool tail_recorded = false;
+	};
+	PrepScratch &prep_scratch()
+	{
+		static PrepScratch s;
 		return s;
 	}
 
@@ -276,11 +293,19 @@ RIR_EXPORT int rir_ecc_prepare_frames_device(const void *d_imgs, int dtype, int 
 		return -1;
 	}
 	hipStream_t st = (hipStream_t)stream;
-	EccScratch &sc = scratch();
+	PrepScratch &sc = prep_scratch();
 	std::lock_guard<std::mutex> lock(sc.mu);
-	ScratchOrder order(sc, st);
-	if (!order.ok)
+	// (stream order among the calls that share this scratch: wait for the previous call's last launch, leave an event behind this one's)
+	if (!sc.tail && !hip_ok(hipEventCreateWithFlags(&sc.tail, hipEventDisableTiming), "hipEventCreate"))
 		return -1;
+	if (sc.tail_recorded && !hip_ok(hipStreamWaitEvent(st, sc.tail, 0), "hipStreamWaitEvent"))
+		return -1;
+	struct Leave
+	{
+		PrepScratch &p;
+		hipStream_t s;
+		~Leave() { p.tail_recorded = hipEventRecord(p.tail, s) == hipSuccess; }
+	} leave{sc, st};
 	const size_t npx = (size_t)w * h;
 	if (!sc.mm_frames.reserve((size_t)nframes * 2 * std::max(kMinMaxParts, kMinMaxPartsFrames) * sizeof(float)))
 		return -1;
@@ -490,8 +515,18 @@ RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const 
 	if (!hip_ok(hipMemcpyAsync(sc.multi_table.ptr, hs, (size_t)nseq * sizeof(EccSeq), hipMemcpyHostToDevice, st), "H2D"))
 		return -1;
 	// sequences per launch and workgroups per sequence: as many slices as the device holds for the sequences of the launch
-	// (RIR_ECC_MULTI_SLICES: a fixed number, for measurements)
+	// (RIR_ECC_MULTI_SLICES: a fixed number, for measurements).  Every launch first finds out whether it is fully resident
+	// (resident_device.h); one that is not has written nothing and is repeated with half the slices - any number of slices gives the
+	// same bits - and, from one slice per sequence, handed to the single-sequence path.
 	static const int env_slices = getenv("RIR_ECC_MULTI_SLICES") ? atoi(getenv("RIR_ECC_MULTI_SLICES")) : 0;
+	const bool debug_bail = getenv("RIR_DEBUG_ECC_BAIL") != nullptr; // (tests: as if the first attempt of every launch had not become resident)
+	const bool fresh_ctl = sc.multi_ctl.cap == 0;
+	if (!sc.multi_ctl.reserve(256))
+		return -1;
+	if (fresh_ctl && (!hip_ok(hipMemsetAsync(sc.multi_ctl.ptr, 0, 256, st), "memset") || (sc.multi_arrivals = 0, false)))
+		return -1;
+	unsigned int *d_ctl = sc.multi_ctl.as<unsigned int>();
+	std::vector<int> solo; // sequences that go through the single-sequence path in the end
 	const ResidentPlan plan = resident_plan(cap, 1, nseq);
 	for (int q0 = 0; q0 < nseq; q0 += plan.units_per_launch)
 	{
@@ -499,11 +534,35 @@ RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const 
 		int nslices = std::max(1, std::min(V, cap / nl));
 		if (env_slices > 0)
 			nslices = std::max(1, std::min(nslices, env_slices));
-		// (a slice's time is that of its rows, one after the other: no more slices than give every slice the same largest number of rows)
-		const int rows_per_slice = (V + nslices - 1) / nslices;
-		nslices = (V + rows_per_slice - 1) / rows_per_slice;
-		if (!hip_ok(launch_ecc_run_multi(sc.multi_table.as<EccSeq>() + q0, nl, nslices, w, h, max_iterations, eps, ++sc.epoch, st), "ecc run (multi)"))
-			return -1;
+		for (int attempt = 0;; ++attempt)
+		{
+			// (a slice's time is that of its rows, one after the other: no more slices than give every slice the same largest number of rows)
+			const int rows_per_slice = (V + nslices - 1) / nslices;
+			nslices = (V + rows_per_slice - 1) / rows_per_slice;
+			const unsigned int epoch = ++sc.epoch, total = (unsigned int)(nl * nslices);
+			if (debug_bail && attempt == 0)
+			{ // the launch is called off by hand: the decision word says BAIL before anybody arrives
+				const unsigned int w_ = ((epoch & 0x3fffffffu) << 2) | 2u;
+				if (!hip_ok(hipMemcpyAsync(d_ctl + 1, &w_, 4, hipMemcpyHostToDevice, st), "H2D") || !hip_ok(hipStreamSynchronize(st), "sync"))
+					return -1;
+			}
+			if (!hip_ok(launch_ecc_run_multi(sc.multi_table.as<EccSeq>() + q0, nl, nslices, w, h, max_iterations, eps, epoch, d_ctl, sc.multi_arrivals, st),
+						"ecc run (multi)"))
+				return -1;
+			sc.multi_arrivals += total;
+			unsigned int decision = 0;
+			if (!hip_ok(hipMemcpyAsync(&decision, d_ctl + 1, 4, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
+				return -1;
+			if (decision == (((epoch & 0x3fffffffu) << 2) | 1u))
+				break; // resident: the chunk is aligned
+			if (nslices == 1)
+			{ // not even one workgroup per sequence fits beside what else is running: sequence by sequence
+				for (int q = q0; q < q0 + nl; ++q)
+					solo.push_back(q);
+				break;
+			}
+			nslices = std::max(1, nslices / 2);
+		}
 	}
 	char *hb = sc.multi_back.as<char>();
 	if (!hip_ok(hipMemcpyAsync(hb, sc.multi_table.ptr, (size_t)nseq * sizeof(EccSeq), hipMemcpyDeviceToHost, st), "D2H") ||
@@ -522,10 +581,23 @@ RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const 
 	}
 	const EccSeq *back = reinterpret_cast<const EccSeq *>(hb);
 	const EccFrameResult *r = reinterpret_cast<const EccFrameResult *>(hb + (size_t)nseq * sizeof(EccSeq));
+	for (int q : solo)
+	{
+		good[q] = nframes[q] == 0 ? 0
+								  : align_frames_locked(sc, d_ref_norm[q], d_norm[q], d_gx[q], d_gy[q], w, h, nframes[q], warps + 2 * q, max_iterations, eps,
+														results + (size_t)q * results_stride * 4, st);
+		if (good[q] < 0)
+			return -1;
+	}
 	for (int q = 0; q < nseq; ++q)
 	{
 		double *res = results + (size_t)q * results_stride * 4;
 		int g = 0;
+		if (std::find(solo.begin(), solo.end(), q) != solo.end())
+		{
+			r += nframes[q];
+			continue;
+		}
 		for (; g < back[q].frames_done && g < nframes[q]; ++g)
 		{
 			if (r[g].done == 2 || std::isnan(r[g].rho))
@@ -534,6 +606,13 @@ RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const 
 			warps[2 * q] = r[g].tx, warps[2 * q + 1] = r[g].ty;
 		}
 		good[q] = g;
+		if (g < nframes[q])
+		{ // (what stopped the sequence: its own failure - done 2 -, or images it never reached)
+			char msg[200];
+			std::snprintf(msg, sizeof(msg), "ECC: sequence %d of %d stopped at image %d of %d (images gone through %d, done %d, iterations %d)", q, nseq, g,
+						  nframes[q], back[q].frames_done, g < back[q].frames_done ? r[g].done : -1, g < back[q].frames_done ? r[g].iter : -1);
+			log_error(msg);
+		}
 		r += nframes[q];
 	}
 	return 0;

@@ -176,7 +176,7 @@ class DeviceRegistratorECC:
             if change:
                 self._change_reference(None, [ys[-1], xs[-1]], frames, c0 + i + stop - 1)
             elif good < cnt:
-                raise RuntimeError("ECC: the alignment did not converge (empty overlap, singular system or non-positive lambda)")
+                raise RuntimeError("ECC: the alignment did not converge (empty overlap, singular system or non-positive lambda) - %s" % last_error())
             i += stop
 
     def compute_many(self, frames, chunk=32):
@@ -226,6 +226,10 @@ class DeviceRegistratorECC:
         for q in range(S):
             if n:
                 registrators[q]._prepare(frs[q], 0, m, bufs[0][q], st)
+        # (The pre-processing of chunk k + 1 is NOT run on a second stream under the alignments of chunk k.  It was tried: +8 % when
+        # it worked, and most of the time it did not - the alignment kernel needs ALL its workgroups on the chip (3 per CU, 504 of a
+        # SIMD's 512 VGPRs), ordinary kernels that come and go beside it leave the register files and the LDS fragmented, the last
+        # workgroups then never fit although enough is free, and the launch runs into its clock: DESIGN.md §4, "Resident launches".)
         for ci, c0 in enumerate(range(0, n, chunk)):
             k = min(chunk, n - c0)
             norm = bufs[ci % len(bufs)]
@@ -237,7 +241,7 @@ class DeviceRegistratorECC:
                                                ptr([b[2] for b in norm]), r0.subW, r0.subH, S, counts, warps.ctypes.data, r0.number_of_iterations,
                                                r0.termination_eps, res.ctypes.data, k, good, st) != 0:
                 raise RuntimeError("ECC: %s" % last_error())
-            if c0 + chunk < n:  # the next chunk's pre-processing is queued before the book-keeping of this one
+            if c0 + chunk < n:  # the next chunk's pre-processing is queued (same stream) before the book-keeping of this one
                 for q in range(S):
                     registrators[q]._prepare(frs[q], c0 + chunk, min(chunk, n - c0 - chunk), bufs[(ci + 1) % len(bufs)][q], st)
             for q in range(S):

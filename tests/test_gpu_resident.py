@@ -183,3 +183,77 @@ def test_images_kept_by_the_caller_survive_later_reads(tmp_path):
             assert np.array_equal(kept[i], data[i])
         for i in range(4):
             assert np.array_equal(views[i], data[8 + i][3:9])
+
+
+def test_a_launch_that_is_not_resident_is_repeated_smaller_with_the_same_results(monkeypatch):
+    """ecc_run_multi_kernel finds out at its start whether all its workgroups are on the chip (resident_device.h); a launch that is
+    not - forced here through RIR_DEBUG_ECC_BAIL: the first attempt of every launch is called off - has written nothing and is
+    repeated with half the workgroups per sequence: the tracks are the ones of the undisturbed run, bit for bit."""
+    import torch
+
+    from librir_amd.registration import DeviceRegistratorECC
+
+    S, n, h, w = 5, 40, 256, 320
+    seqs = [torch.from_numpy(s3_registration(n, h, w, seed=70 + q)[0]).cuda() for q in range(S)]
+
+    def run():
+        rs = [DeviceRegistratorECC(0.8, 0.8, shape=(h, w)) for _ in range(S)]
+        for q in range(S):
+            rs[q].start(seqs[q][0])
+        DeviceRegistratorECC.compute_many_multi(rs, [s[1:] for s in seqs], chunk=16)
+        return [(r.x, r.y, r.confidences) for r in rs]
+
+    ref = run()
+    monkeypatch.setenv("RIR_DEBUG_ECC_BAIL", "1")
+    got = run()
+    monkeypatch.delenv("RIR_DEBUG_ECC_BAIL")
+    assert got == ref
+    assert run() == ref
+
+
+def test_alignments_beside_a_flood_of_ordinary_kernels(dev):
+    """Ordinary kernels of another thread and stream beside resident launches: they fragment the register files and the LDS, and a
+    launch that needs nearly the whole chip may not become resident (resident_device.h).  It must still give its results - through
+    the rendezvous and the smaller repeat - and never the error of a 2 s clock."""
+    import torch
+
+    from librir_amd import device as D
+    from librir_amd.registration import DeviceRegistratorECC
+
+    S, n, h, w = 8, 48, 512, 640
+    seqs = [torch.from_numpy(s3_registration(n, h, w, seed=99 + q)[0]).cuda() for q in range(S)]
+
+    def run():
+        rs = [DeviceRegistratorECC(1, 1, shape=(h, w)) for _ in range(S)]
+        for q in range(S):
+            rs[q].start(seqs[q][0])
+        DeviceRegistratorECC.compute_many_multi(rs, [s[1:] for s in seqs])
+        return [(r.x, r.y) for r in rs]
+
+    ref = run()
+    stop = []
+
+    def flood():
+        with torch.cuda.stream(torch.cuda.Stream()):
+            x = torch.from_numpy(s1_noisy_background(64, h, w)).cuda()
+            k = 0
+            while not stop:
+                D.gaussian_filter(x, 0.75)
+                k += 1
+                if k % 8 == 0:
+                    torch.cuda.current_stream().synchronize()
+
+    th = threading.Thread(target=flood)
+    th.start()
+    try:
+        time.sleep(0.2)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            worst = 0.0
+            for _ in range(6):
+                t0 = time.perf_counter()
+                assert run() == ref
+                worst = max(worst, time.perf_counter() - t0)
+    finally:
+        stop.append(1)
+        th.join()
+    assert worst < 1.5, worst  # (a 2 s clock was never the way out)
