@@ -106,8 +106,11 @@ namespace rir
 	hipError_t launch_lossy_backgrounds(const LossyStep *d_table, int entries, int s, int hist_px, hipStream_t st);
 	// One launch of a run for `nstreams` streams: d_table[i] is stream i's step (next_* filled in).
 	hipError_t launch_lossy_frame(const LossyStep *d_table, int nstreams, int full, hipStream_t st);
-	// d_table[i]: the run of stream i; d_ticket: one zeroed word (left zeroed)
-	hipError_t launch_lossy_run(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ticket, hipStream_t st);
+	// d_table[i]: the run of stream i; d_ticket: the 256-byte header of the exchange buffer, zeroed once: word 0 the ticket (left zeroed), word 16
+	// the error word, words kLossyRunCtlWord .. + 3 the residency control block (resident_device.h: arrivals, decision, poison, epoch of the
+	// first launch that bailed out); epoch: a number no earlier launch on this header used; arrivals_before: workgroups of those launches
+	constexpr int kLossyRunCtlWord = 48;
+	hipError_t launch_lossy_run(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ticket, unsigned int epoch, unsigned int arrivals_before, hipStream_t st);
 	hipError_t launch_lossy_first(const uint16_t *d_tmp, uint16_t *d_out, const LossyDeviceState &state, int s, int full, hipStream_t st);
 	hipError_t launch_lossy_min(const uint16_t *d_tmp, int s, unsigned int *d_result, hipStream_t st);
 	hipError_t launch_lossy_add_min(uint16_t *d_frames, int64_t npx, int s, int nframes, uint32_t mn, hipStream_t st);

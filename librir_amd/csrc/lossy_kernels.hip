@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "lossy_kernels.h"
+#include "resident_device.h"
 #include "runtime.h"
 
 namespace rir
@@ -957,9 +958,10 @@ namespace rir
 	// has published k + 1: two buffers are enough.  Waits are bounded by a clock (2 s): a wait that gives up raises error_word and
 	// the run goes on with whatever it has - wrong, flagged, but never hung.
 	constexpr int kRunWaves = kLossyRunThreads / 64;
-	__attribute__((amdgpu_waves_per_eu(kLossyRunWavesPerSimd, kLossyRunWavesPerSimd))) __global__ __launch_bounds__(kLossyRunThreads) void lossy_run_kernel(const LossyRun *__restrict__ table, unsigned int *__restrict__ ticket_, int nb, int nstreams)
+	__attribute__((amdgpu_waves_per_eu(kLossyRunWavesPerSimd, kLossyRunWavesPerSimd))) __global__ __launch_bounds__(kLossyRunThreads) void lossy_run_kernel(const LossyRun *__restrict__ table, unsigned int *__restrict__ ticket_, int nb, int nstreams, unsigned int epoch, unsigned int arrivals_before)
 	{
 		__shared__ unsigned int sh_ticket;
+		__shared__ unsigned int sh_flag;
 		__shared__ long long red[kRunWaves][6], red2[kRunWaves][6];
 		__shared__ LossyBudget bl;
 		__shared__ LossyDecision dec;
@@ -974,6 +976,10 @@ namespace rir
 		}
 		__syncthreads();
 		const int tk = __builtin_amdgcn_readfirstlane((int)sh_ticket);
+		// is the whole launch on the chip (resident_device.h)?  If not - or if an earlier group of the same call was not done - everybody
+		// leaves before the state is touched; the control words live in the header of the exchange buffer, behind the ticket and the error word
+		if (resident_rendezvous(ticket_ + kLossyRunCtlWord, arrivals_before, gridDim.x, epoch, &sh_flag, true) != RESIDENT_GO)
+			return;
 		const int stream = tk / nb, b = tk - stream * nb;
 		LossyRun rp;
 		{
@@ -1412,7 +1418,7 @@ namespace rir
 
 	// workgroups of lossy_run_kernel the current device holds at once (runtime.h: occupancy x CUs, less the margin; 0 = unknown)
 	int lossy_run_capacity() { return resident_capacity(reinterpret_cast<const void *>(lossy_run_kernel), kLossyRunThreads, 0); }
-	hipError_t launch_lossy_run(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ticket, hipStream_t st)
+	hipError_t launch_lossy_run(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ticket, unsigned int epoch, unsigned int arrivals_before, hipStream_t st)
 	{
 		const int nb = lossy_run_workgroups(full);
 		if ((long long)nb * nstreams > lossy_run_capacity())
@@ -1420,7 +1426,7 @@ namespace rir
 		ResidentGate gate(st); // its workgroups wait for each other: not beside any other resident launch of the process
 		if (!gate.ok())
 			return hipErrorUnknown;
-		hipLaunchKernelGGL(lossy_run_kernel, dim3((unsigned)(nb * nstreams)), dim3(kLossyRunThreads), 0, st, d_table, d_ticket, nb, nstreams);
+		hipLaunchKernelGGL(lossy_run_kernel, dim3((unsigned)(nb * nstreams)), dim3(kLossyRunThreads), 0, st, d_table, d_ticket, nb, nstreams, epoch, arrivals_before);
 		return hipGetLastError();
 	}
 

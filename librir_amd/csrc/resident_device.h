@@ -18,6 +18,10 @@
 //
 // ctl[0]: arrivals, monotone over the launches that use this control block (the host passes the count expected before
 // this launch); ctl[1]: decision word, (epoch << 2) | code.  Zeroed once, when the block is allocated.
+// Launches that build on each other's results (the groups of frames of a bounded-loss run, queued back to back without a
+// host round trip) pass `chained`: then ctl[2] is a POISON word - raised by the launch that bails out, it makes every later
+// launch on the block bail out at once, so that nothing is computed on top of work that was not done - and ctl[3] keeps
+// the epoch of the first launch that bailed out; the host clears both when it has dealt with it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,7 +37,8 @@ namespace rir
 
 	// Called by every thread of every workgroup, first thing.  `flag`: one LDS word.  Returns RESIDENT_GO or RESIDENT_BAIL, the
 	// same value in every thread of every workgroup of the launch.
-	__device__ __forceinline__ int resident_rendezvous(unsigned int *ctl, unsigned int arrivals_before, unsigned int total, unsigned int epoch, unsigned int *flag)
+	__device__ __forceinline__ int resident_rendezvous(unsigned int *ctl, unsigned int arrivals_before, unsigned int total, unsigned int epoch, unsigned int *flag,
+													   bool chained = false)
 	{
 		if (threadIdx.x == 0)
 		{
@@ -50,7 +55,9 @@ namespace rir
 					break;
 				}
 				unsigned int want = 0;
-				if (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - arrivals_before >= total)
+				if (chained && __hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+					want = RESIDENT_BAIL; // an earlier launch of the chain was not done
+				else if (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - arrivals_before >= total)
 					want = RESIDENT_GO;
 				else if (__builtin_amdgcn_s_memrealtime() - t0 > kResidentRendezvousTicks)
 					want = RESIDENT_BAIL;
@@ -61,6 +68,12 @@ namespace rir
 					continue;
 				}
 				__builtin_amdgcn_s_sleep(2);
+			}
+			if (chained && code == RESIDENT_BAIL)
+			{ // (idempotent: every workgroup of a launch that bails out writes the same things)
+				unsigned int zero = 0;
+				__hip_atomic_compare_exchange_strong(ctl + 3, &zero, epoch, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(ctl + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 			*flag = code;
 		}

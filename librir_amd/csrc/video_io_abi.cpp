@@ -346,6 +346,7 @@ namespace
 		// later step / status of a stream that took part in such a call fails until the stream is destroyed.  The error word lives
 		// with the call's leading stream and says "some call since the last check"; so the leader numbers the calls it led and
 		// keeps the ranges found invalid, and every member remembers who led its last run call and that call's number.
+		unsigned int run_epoch = 0, run_arrivals = 0; // residency control block in run_exchange's header (resident_device.h): launches / workgroups so far
 		bool failed = false;
 		uint64_t led_calls = 0, led_clean = 0;					   // as a leader: run calls led / of those, known good at the last check
 		std::vector<std::pair<uint64_t, uint64_t>> led_bad;		   // calls in (first, second] are invalid
@@ -389,7 +390,7 @@ namespace
 	// reference: struct H264 (video_io.cpp:651-657) + H264_Saver (h264.cpp:1662-1939)
 	// (defined with the rir_lossy_* entry points)
 	int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned short *const *d_in, unsigned short *const *d_out, int nframes, int add_loss,
-						   int *const *d_errs, int *low_errors, int *high_errors, hipStream_t st);
+						   int *const *d_errs, int *low_errors, int *high_errors, hipStream_t st, bool force_per_frame = false);
 
 	struct SaverObject : public Object
 	{
@@ -630,11 +631,14 @@ namespace
 			std::vector<int> e(deferred.size() * 2);
 			hipStream_t st = default_stream();
 			unsigned int gave_up = 0; // the run kernel's error word (lossy_step_streams): a wait between workgroups that hit its clock
+			unsigned int poison = 0;  // ... or a launch that did not become resident and was called off (resident_device.h): its frames were not stepped
 			const bool have_run = lossy_obj && lossy_obj->run_exchange.ptr;
 			if (!hip_ok(hipMemcpyAsync(e.data(), d_err_slots.ptr, e.size() * sizeof(int), hipMemcpyDeviceToHost, st), "D2H") ||
-				(have_run && !hip_ok(hipMemcpyAsync(&gave_up, lossy_obj->run_exchange.as<unsigned int>() + 16, 4, hipMemcpyDeviceToHost, st), "D2H")) ||
+				(have_run && (!hip_ok(hipMemcpyAsync(&gave_up, lossy_obj->run_exchange.as<unsigned int>() + 16, 4, hipMemcpyDeviceToHost, st), "D2H") ||
+							  !hip_ok(hipMemcpyAsync(&poison, lossy_obj->run_exchange.as<unsigned int>() + kLossyRunCtlWord + 2, 4, hipMemcpyDeviceToHost, st), "D2H"))) ||
 				!hip_ok(wait_stream(st), "sync"))
 				return false;
+			gave_up |= poison;
 			if (have_run)
 				lossy_obj->checked(gave_up, st);
 			if (gave_up || lossy_obj->is_failed())
@@ -2379,7 +2383,7 @@ RIR_EXPORT int rir_lossy_step_device(int handle, const unsigned short *d_in, uns
 namespace
 {
 int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned short *const *d_in, unsigned short *const *d_out, int nframes, int add_loss,
-					   int *const *d_errs, int *low_errors, int *high_errors, hipStream_t st)
+					   int *const *d_errs, int *low_errors, int *high_errors, hipStream_t st, bool force_per_frame)
 {
 	const size_t npx = (size_t)os[0]->st.w * os[0]->st.h;
 	const bool want = low_errors || high_errors;
@@ -2406,6 +2410,16 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 		f0 = 1;
 	}
 	const int nsteps = nframes - f0;
+	// resident launches of this call (resident_device.h): their epochs group by group, and the host side of every stream's state as it
+	// was before each group - what a launch that did not become resident (it has written nothing) is repeated from
+	struct Snap
+	{
+		int ra_count, ra_head;
+		int64_t frames;
+	};
+	std::vector<unsigned int> run_epochs;	// [ngroups]: epoch of the group's first launch
+	std::vector<Snap> snaps;				// [ngroups][nstreams]
+	int run_group = 0, run_launches_per_group = 0;
 	const int s_px = os[0]->st.w * os[0]->st.hl, full_px = os[0]->st.w * os[0]->st.h;
 	// runs: one launch per frame (lossy_frame_kernel) + one histogram launch per group of frames; needs whole groups of 8 pixels
 	const bool runs = nsteps >= 2 && s_px > 0 && s_px % 8 == 0 && full_px % 8 == 0;
@@ -2424,7 +2438,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 		const int capacity = lossy_run_capacity();						 // what THIS device holds of the run kernel at once (0: unknown)
 		const int max_wgs = max_env && atoi(max_env) > 0 ? std::min(atoi(max_env), capacity) : capacity;
 		const ResidentPlan plan = resident_plan(max_wgs, run_wgs, nstreams); // (units_per_launch 0: a stream does not fit - launch per frame)
-		const bool persistent = runs && errors_fit && plan.units_per_launch > 0 && !getenv("RIR_LOSSY_LAUNCH_PER_FRAME");
+		const bool persistent = runs && errors_fit && plan.units_per_launch > 0 && !force_per_frame && !getenv("RIR_LOSSY_LAUNCH_PER_FRAME");
 		const int batch = persistent ? plan.units_per_launch : nstreams; // streams per launch of the resident kernel
 		const int group = std::max(1, (persistent ? 2048 : 512) / nstreams); // frames per histogram launch (one 64 KB histogram slice per frame and stream)
 		const int ngroups = runs ? (nsteps + group - 1) / group : 0;
@@ -2482,8 +2496,12 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 				const size_t exch_cap = lead.run_exchange.cap;
 				if (!lead.run_exchange.reserve(256 + exch_bytes))
 					return -1;
-				if (lead.run_exchange.cap != exch_cap && !hip_ok(hipMemsetAsync(lead.run_exchange.ptr, 0, 256, st), "memset"))
-					return -1;
+				if (lead.run_exchange.cap != exch_cap)
+				{
+					if (!hip_ok(hipMemsetAsync(lead.run_exchange.ptr, 0, 256, st), "memset"))
+						return -1;
+					lead.run_arrivals = 0; // (a fresh control block)
+				}
 				unsigned int *d_ticket = lead.run_exchange.as<unsigned int>(), *d_error = d_ticket + 16;
 				unsigned long long *d_exch = reinterpret_cast<unsigned long long *>(lead.run_exchange.as<char>() + 256);
 				LossyRun *hr = reinterpret_cast<LossyRun *>(reinterpret_cast<char *>(hs) + run_off);
@@ -2494,6 +2512,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 					for (int i = 0; i < nstreams; ++i)
 					{
 						LossyState &ls = os[i]->st;
+						snaps.push_back(Snap{ls.dev.ra_count, ls.dev.ra_head, (int64_t)ls.frames});
 						LossyRun r{};
 						r.in = d_in[i] + (size_t)(f0 + k0) * npx, r.out = d_out[i] + (size_t)(f0 + k0) * npx;
 						r.st = ls.dev;
@@ -2544,9 +2563,23 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 						!hip_ok(hipMemsetAsync(d_exch, 0, exch_bytes, st), "memset"))
 						return -1;
 					for (int s0 = 0; s0 < nstreams; s0 += batch)
-						if (!hip_ok(launch_lossy_run(dr + (size_t)g * nstreams + s0, std::min(batch, nstreams - s0), full_px, d_ticket, st), "lossy run"))
+					{
+						const int nl = std::min(batch, nstreams - s0);
+						const unsigned int epoch = ++lead.run_epoch;
+						if (s0 == 0)
+							run_epochs.push_back(epoch);
+						if (getenv("RIR_DEBUG_LOSSY_BAIL") && atoi(getenv("RIR_DEBUG_LOSSY_BAIL")) == g)
+						{ // (tests: as if group g's launch had not become resident: its decision is BAIL before anybody arrives)
+							const unsigned int w_ = ((epoch & 0x3fffffffu) << 2) | 2u;
+							if (!hip_ok(hipMemcpyAsync(d_ticket + kLossyRunCtlWord + 1, &w_, 4, hipMemcpyHostToDevice, st), "H2D") || !hip_ok(hipStreamSynchronize(st), "sync"))
+								return -1;
+						}
+						if (!hip_ok(launch_lossy_run(dr + (size_t)g * nstreams + s0, nl, full_px, d_ticket, epoch, lead.run_arrivals, st), "lossy run"))
 							return -1;
+						lead.run_arrivals += (unsigned int)(nl * run_wgs);
+					}
 				}
+				run_group = group, run_launches_per_group = (nstreams + batch - 1) / batch;
 			}
 			else
 			{
@@ -2608,9 +2641,50 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 	{
 		std::vector<int> e((size_t)nstreams * nframes * 2);
 		unsigned int gave_up = 0; // the run kernel's error word (a wait between workgroups that hit its clock)
-		if (!hip_ok(hipMemcpyAsync(e.data(), lead.batch_errs.ptr, e.size() * sizeof(int), hipMemcpyDeviceToHost, st), "D2H") ||
-			(lead.run_exchange.ptr && !hip_ok(hipMemcpyAsync(&gave_up, lead.run_exchange.as<unsigned int>() + 16, 4, hipMemcpyDeviceToHost, st), "D2H")) ||
+		unsigned int ctl[4] = {0, 0, 0, 0}; // the residency control block: arrivals, decision, poison, epoch of the first launch that bailed out
+		if ((lead.run_exchange.ptr && (!hip_ok(hipMemcpyAsync(&gave_up, lead.run_exchange.as<unsigned int>() + 16, 4, hipMemcpyDeviceToHost, st), "D2H") ||
+									   !hip_ok(hipMemcpyAsync(ctl, lead.run_exchange.as<unsigned int>() + kLossyRunCtlWord, sizeof(ctl), hipMemcpyDeviceToHost, st), "D2H"))) ||
 			!hip_ok(wait_stream(st), "sync"))
+			return -1;
+		if (ctl[2] != 0 && !run_epochs.empty())
+		{
+			// A group's launch did not become resident (ordinary kernels of other streams can keep the last workgroups from fitting:
+			// resident_device.h).  It and every launch behind it have written nothing.  The call waits here anyway, so the frames
+			// from that group on are stepped again on the launch-per-frame path - same results - from the host state of that moment.
+			int g_bad = -1;
+			for (size_t g = 0; g < run_epochs.size(); ++g)
+				if (g_bad < 0 && (int)(ctl[3] - run_epochs[g]) >= 0 && (int)(ctl[3] - run_epochs[g]) < run_launches_per_group)
+					g_bad = (int)g;
+			const unsigned int zero2[2] = {0, 0};
+			if (!hip_ok(hipMemcpyAsync(lead.run_exchange.as<unsigned int>() + kLossyRunCtlWord + 2, zero2, sizeof(zero2), hipMemcpyHostToDevice, st), "H2D") ||
+				!hip_ok(hipStreamSynchronize(st), "sync"))
+				return -1;
+			if (g_bad < 0 || run_launches_per_group != 1)
+			{ // (a poison left by an earlier, queue-only call - or streams that went in several batches and stand at different frames)
+				gave_up = 1;
+			}
+			else
+			{
+				const int fr0 = f0 + g_bad * run_group; // first frame that was not stepped
+				for (int i = 0; i < nstreams; ++i)
+				{
+					const Snap &sn = snaps[(size_t)g_bad * nstreams + i];
+					os[i]->st.dev.ra_count = sn.ra_count, os[i]->st.dev.ra_head = sn.ra_head, os[i]->st.frames = (decltype(os[i]->st.frames))sn.frames;
+				}
+				std::vector<const unsigned short *> in2((size_t)nstreams);
+				std::vector<unsigned short *> out2((size_t)nstreams);
+				std::vector<int *> errs2((size_t)nstreams);
+				for (int i = 0; i < nstreams; ++i)
+				{
+					in2[i] = d_in[i] + (size_t)fr0 * npx, out2[i] = d_out[i] + (size_t)fr0 * npx;
+					errs2[i] = lead.batch_errs.as<int>() + ((size_t)i * nframes + fr0) * 2;
+				}
+				if (lossy_step_streams(os, nstreams, in2.data(), out2.data(), nframes - fr0, add_loss, errs2.data(), nullptr, nullptr, st, true) != 0 ||
+					!hip_ok(wait_stream(st), "sync"))
+					return -1;
+			}
+		}
+		if (!hip_ok(hipMemcpyAsync(e.data(), lead.batch_errs.ptr, e.size() * sizeof(int), hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
 			return -1;
 		if (getenv("RIR_LOSSY_DIAG") && lead.run_exchange.ptr)
 		{ // (-DRIR_LOSSY_DIAG builds) where the time of a frame goes, workgroup 0 of stream 0
@@ -2698,10 +2772,11 @@ RIR_EXPORT int rir_lossy_status(int handle, void *stream)
 	std::shared_ptr<Object> keep = o->lead.lock(); // (keeps a foreign leader alive while it is read)
 	if (!l || !l->run_exchange.ptr)
 		return hip_ok(wait_stream(st), "sync") && !o->is_failed() ? 0 : -1;
-	unsigned int gave_up = 0;
-	if (!hip_ok(hipMemcpyAsync(&gave_up, l->run_exchange.as<unsigned int>() + 16, 4, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
+	unsigned int gave_up = 0, poison = 0; // a wait that hit its clock / a launch that was called off because it did not become resident
+	if (!hip_ok(hipMemcpyAsync(&gave_up, l->run_exchange.as<unsigned int>() + 16, 4, hipMemcpyDeviceToHost, st), "D2H") ||
+		!hip_ok(hipMemcpyAsync(&poison, l->run_exchange.as<unsigned int>() + kLossyRunCtlWord + 2, 4, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
 		return -1;
-	l->checked(gave_up, st);
+	l->checked(gave_up | poison, st);
 	if (o->is_failed())
 	{
 		log_error("rir_lossy_status: a run of frames gave up waiting (results invalid; the stream takes no more frames)");

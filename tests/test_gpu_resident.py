@@ -257,3 +257,42 @@ def test_alignments_beside_a_flood_of_ordinary_kernels(dev):
         stop.append(1)
         th.join()
     assert worst < 1.5, worst  # (a 2 s clock was never the way out)
+
+
+@pytest.mark.parametrize("bail_group", [0, 1])
+def test_a_loss_run_that_is_not_resident_is_stepped_again_frame_by_frame(oracle, monkeypatch, bail_group):
+    """lossy_run_kernel finds out at its start whether all its workgroups are on the chip (resident_device.h); a group of frames whose
+    launch was called off - forced through RIR_DEBUG_LOSSY_BAIL=<group> - has written nothing, poisons the groups queued behind it,
+    and a call that waits for the budgets steps the frames from that group on again on the launch-per-frame path: frames and budgets
+    are those of the undisturbed run (and of the oracle), the streams stay usable."""
+    import torch
+
+    from librir_amd import device as D
+    from oracle.pyoracle import OracleLossy
+
+    S, n, h, w, hl = 64, 47, 96, 128, 93  # 64 streams: groups of 32 frames, so the 46 steps after the first frame are two groups
+    data = [s1_noisy_background(n, h, w, seed=300 + i) for i in range(S)]
+    tens = [torch.from_numpy(d).cuda() for d in data]
+
+    def run(more):
+        streams = [D.LossyStream(w, h, hl, 6, 2, 5.0, 8) for _ in range(S)]
+        o, lo, hi = D.LossyStream.step_many(streams, tens)
+        o2, lo2, hi2 = D.LossyStream.step_many(streams, [t[:more] for t in tens])  # the streams go on afterwards
+        for s in streams:
+            s.status()
+            s.close()
+        return [x.cpu().numpy() for x in o], lo.copy(), hi.copy(), [x.cpu().numpy() for x in o2], lo2.copy(), hi2.copy()
+
+    ref = run(9)
+    monkeypatch.setenv("RIR_DEBUG_LOSSY_BAIL", str(bail_group))
+    got = run(9)
+    monkeypatch.delenv("RIR_DEBUG_LOSSY_BAIL")
+    for a, b in zip(got, ref):
+        if isinstance(a, list):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
+        else:
+            assert np.array_equal(a, b)
+    for i in (0, 17, 63):
+        L = OracleLossy(oracle, w, h, hl, low_err=6, high_err=2, std_factor=5.0, running_average=8)
+        exp = np.stack([L.step(data[i][f]) for f in range(n)])
+        assert np.array_equal(got[0][i], exp), i
