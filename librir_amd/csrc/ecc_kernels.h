@@ -75,7 +75,9 @@ namespace rir
 	bool ecc_run_fits(int w, int h);  // the grid of an alignment of a w x h window fits: the one-launch forms may be used
 	hipError_t launch_ecc_run(const float *d_templ, const float *d_image, const float *d_gx, const float *d_gy, const uint8_t *d_mask, int w, int h,
 							  double *d_rows, EccState *d_state, EccHostView *host_view, float tx, float ty, int max_iter, double eps, unsigned int epoch,
-							  int nframes, EccFrameResult *d_results, hipStream_t st);
+							  int nframes, EccFrameResult *d_results, unsigned int *d_ctl, unsigned int arrivals_before, hipStream_t st);
+	int ecc_run_grid(int w, int h); // workgroups of such a launch
+	// (d_ctl, arrivals_before: the residency control block, resident_device.h; a launch that was called off reports done = 3 through the host view)
 	constexpr int kEccMaxSequence = 4096, kEccMaxIterations = (1 << 20) - 1; // (the flag's fields)
 	constexpr int kMinMaxParts = 256, kMinMaxPartsFrames = 64; // partial (min, max) pairs per image: one image / a batch of images
 	// d_part: 2 * kMinMaxParts floats (one image), nframes * 2 * kMinMaxPartsFrames floats (a batch)

@@ -390,10 +390,24 @@ namespace rir
 	__global__ __launch_bounds__(ECC_BLOCK) void ecc_run_kernel(const float *__restrict__ templ, const float *__restrict__ image,
 																const float *__restrict__ gximg, const float *__restrict__ gyimg, const uint8_t *__restrict__ mask,
 																int w, int h, double *rows, unsigned long long *pub, EccState *state, EccHostView *host_view, float tx0,
-																float ty0, int max_iter, double eps, unsigned int epoch, int nframes, EccFrameResult *results)
+																float ty0, int max_iter, double eps, unsigned int epoch, int nframes, EccFrameResult *results,
+																unsigned int *__restrict__ ctl, unsigned int arrivals_before)
 	{
 		static_assert(ECC_BLOCK >= ECC_SOLVE_BLOCK, "workgroup 0 adds the rows the way ecc_solve_kernel does: by its first 256 threads");
 		__shared__ EccReduceLds red;
+		__shared__ unsigned int sh_flag;
+		// is the whole launch on the chip (resident_device.h)?  If not, nothing is written but the host's view: done = 3, "not run" -
+		// the host then takes the launch-per-iteration kernels, which need no residency
+		if (resident_rendezvous(ctl, arrivals_before, gridDim.x, epoch, &sh_flag) != RESIDENT_GO)
+		{
+			if (blockIdx.x == 0 && threadIdx.x == 0 && host_view)
+			{
+				EccState none;
+				none.tx = tx0, none.ty = ty0, none.rho = 0.0, none.iter = 0;
+				ecc_report(host_view, none, 3);
+			}
+			return;
+		}
 		__shared__ double part[ECC_NSUMS][17];
 		__shared__ double tot[ECC_NSUMS];
 		__shared__ float sh_t[2];
@@ -626,6 +640,7 @@ namespace rir
 			table[q].frames_done = frames_done;
 	}
 
+	int ecc_run_grid(int w, int h) { return ecc_blocks(w, h); }
 	int ecc_run_multi_capacity() { return resident_capacity(reinterpret_cast<const void *>(ecc_run_multi_kernel), ECC_BLOCK, 0); }
 	int ecc_rows(int w, int h) { return ecc_blocks(w, h); }
 	// d_table: nseq entries (device); nslices workgroups per sequence (1 .. ecc_rows(w, h)); nseq * nslices <= ecc_run_multi_capacity()
@@ -665,7 +680,7 @@ namespace rir
 	size_t ecc_run_workspace_bytes(int w, int h) { return (size_t)ecc_blocks(w, h) * 256 + 256; } // rows of 16 granules, then pub (+ diagnostics)
 	hipError_t launch_ecc_run(const float *d_templ, const float *d_image, const float *d_gx, const float *d_gy, const uint8_t *d_mask, int w, int h,
 							  double *d_rows, EccState *d_state, EccHostView *host_view, float tx, float ty, int max_iter, double eps, unsigned int epoch,
-							  int nframes, EccFrameResult *d_results, hipStream_t st)
+							  int nframes, EccFrameResult *d_results, unsigned int *d_ctl, unsigned int arrivals_before, hipStream_t st)
 	{
 		const int nblk = ecc_blocks(w, h);
 		if (nblk > ecc_run_capacity())
@@ -675,7 +690,7 @@ namespace rir
 			return hipErrorUnknown;
 		unsigned long long *pub = reinterpret_cast<unsigned long long *>(d_rows + (size_t)nblk * 32);
 		hipLaunchKernelGGL(ecc_run_kernel, dim3(nblk), dim3(ECC_BLOCK), 0, st, d_templ, d_image, d_gx, d_gy, d_mask, w, h, d_rows, pub, d_state, host_view, tx,
-						   ty, max_iter, eps, epoch, nframes, d_results);
+						   ty, max_iter, eps, epoch, nframes, d_results, d_ctl, arrivals_before);
 		return hipGetLastError();
 	}
 } // namespace rir

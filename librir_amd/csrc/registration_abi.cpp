@@ -37,11 +37,30 @@ namespace
 		DeviceBuffer multi_rows, multi_results, multi_table, multi_ctl;
 		PinnedBuffer multi_stage, multi_back;
 		unsigned int multi_arrivals = 0; // workgroups launched on multi_ctl so far (resident_device.h)
+		DeviceBuffer run_ctl;			 // the same for the single-sequence launches
+		unsigned int run_arrivals = 0;
+		unsigned int *ctl_of_runs(hipStream_t st)
+		{ // two zeroed words, allocated once
+			if (run_ctl.cap)
+				return run_ctl.as<unsigned int>();
+			if (!run_ctl.reserve(256) || hipMemsetAsync(run_ctl.ptr, 0, 256, st) != hipSuccess)
+				return nullptr;
+			run_arrivals = 0;
+			return run_ctl.as<unsigned int>();
+		}
 	};
 	EccScratch &scratch()
 	{
 		static EccScratch s;
 		return s;
+	}
+	// (tests, RIR_DEBUG_ECC_BAIL: as if the next launch on this control block had not become resident - its decision says BAIL before anybody arrives)
+	bool debug_call_off(unsigned int *d_ctl, unsigned int epoch, hipStream_t st)
+	{
+		if (!getenv("RIR_DEBUG_ECC_BAIL"))
+			return true;
+		const unsigned int w_ = ((epoch & 0x3fffffffu) << 2) | 2u;
+		return hip_ok(hipMemcpyAsync(d_ctl + 1, &w_, 4, hipMemcpyHostToDevice, st), "H2D") && hip_ok(hipStreamSynchronize(st), "sync");
 	}
 	// The pre-processing of a chunk of frames (rir_ecc_prepare_frames_device) has a scratch and a stream order of its own: it shares
 	// nothing with the alignments, so a caller may run the pre-processing of chunk k + 1 on a second stream under the alignments
@@ -131,14 +150,30 @@ namespace
 			log_error("ECC: max_iterations exceeds 1 048 575");
 			return -1;
 		}
+		bool called_off = false;
 		if (!per_iteration)
 		{
+			unsigned int *d_ctl = sc.ctl_of_runs(st);
+			if (!d_ctl)
+				return -1;
+			const unsigned int before = sc.run_arrivals;
+			sc.run_arrivals += (unsigned int)ecc_run_grid(w, h);
+			if (!debug_call_off(d_ctl, sc.epoch + 1, st))
+				return -1;
 			if (!hip_ok(launch_ecc_run(d_templ, d_image, d_gx, d_gy, d_mask, w, h, sc.partials.as<double>(), d_state, d_view, warp[0], warp[1], max_iter, eps,
-									   ++sc.epoch, 1, nullptr, st),
+									   ++sc.epoch, 1, nullptr, d_ctl, before, st),
 						"ecc run") ||
 				!wait_view(view, max_iter + 1, st))
 				return -1;
 			hs.done = view->done, hs.iter = view->iter, hs.tx = view->tx, hs.ty = view->ty, hs.rho = view->rho;
+			called_off = hs.done == 3; // the launch did not become resident (resident_device.h) and has computed nothing: two launches per iteration instead
+			if (called_off)
+			{
+				if (!hip_ok(hipStreamSynchronize(st), "sync"))
+					return -1;
+				view->iter = 0, view->done = 0;
+				state_is_reset = false;
+			}
 			static const bool diag = getenv("RIR_ECC_DIAG") != nullptr; // (-DRIR_ECC_DIAG builds: where an iteration's time goes)
 			if (diag && (sc.epoch % 64) == 0)
 			{
@@ -150,7 +185,7 @@ namespace
 								 dg[4] * 0.01 / dg[3], dg[5] * 0.01 / dg[3]);
 			}
 		}
-		else
+		if (per_iteration || called_off)
 		{
 			if (!state_is_reset)
 			{
@@ -392,8 +427,8 @@ int align_frames_locked(EccScratch &sc, const float *d_ref_norm, const float *d_
 	if (!sc.partials.reserve(std::max(ecc_workspace_bytes(w, h), ecc_run_workspace_bytes(w, h))) || !sc.state.reserve(sizeof(EccState)))
 		return -1;
 	static const bool env_per_iteration = getenv("RIR_ECC_LAUNCH_PER_ITERATION") != nullptr;
-	if (env_per_iteration || !ecc_run_fits(w, h))
-	{ // the device does not hold the run kernel's workgroups at once: image by image, two launches per iteration (same results)
+	// image by image through run_iterations (one launch per alignment where it becomes resident, else two launches per iteration): same results
+	auto image_by_image = [&]() {
 		const size_t wpx = (size_t)w * h;
 		int good = 0;
 		for (; good < nframes; ++good)
@@ -408,7 +443,9 @@ int align_frames_locked(EccScratch &sc, const float *d_ref_norm, const float *d_
 			results[4 * good] = t[0], results[4 * good + 1] = t[1], results[4 * good + 2] = cc, results[4 * good + 3] = iters;
 		}
 		return good;
-	}
+	};
+	if (env_per_iteration || !ecc_run_fits(w, h))
+		return image_by_image(); // the device does not hold the run kernel's workgroups at once
 	// the host view and the per-image results live in one block of coherent page-locked host memory the kernel writes directly (a
 	// copy of the results and the stream synchronisation behind it cost more than a chunk's book-keeping)
 	if (!sc.view && !hip_ok(hipHostMalloc(reinterpret_cast<void **>(&sc.view), sizeof(EccHostView), hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc"))
@@ -424,11 +461,24 @@ int align_frames_locked(EccScratch &sc, const float *d_ref_norm, const float *d_
 	if (!hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&d_view), view, 0), "hipHostGetDevicePointer") ||
 		!hip_ok(hipHostGetDevicePointer(reinterpret_cast<void **>(&d_results), sc.results_host, 0), "hipHostGetDevicePointer"))
 		return -1;
+	unsigned int *d_ctl = sc.ctl_of_runs(st);
+	if (!d_ctl)
+		return -1;
+	const unsigned int before = sc.run_arrivals;
+	sc.run_arrivals += (unsigned int)ecc_run_grid(w, h);
+	if (!debug_call_off(d_ctl, sc.epoch + 1, st))
+		return -1;
 	if (!hip_ok(launch_ecc_run(d_ref_norm, d_norm, d_gx, d_gy, nullptr, w, h, sc.partials.as<double>(), sc.state.as<EccState>(), d_view, warp[0], warp[1],
-							   max_iterations, eps, ++sc.epoch, nframes, d_results, st),
+							   max_iterations, eps, ++sc.epoch, nframes, d_results, d_ctl, before, st),
 				"ecc run") ||
 		!wait_view(view, nframes + 1, st))
 		return -1;
+	if (view->done == 3)
+	{ // the launch did not become resident (resident_device.h) and has aligned nothing
+		if (!hip_ok(hipStreamSynchronize(st), "sync"))
+			return -1;
+		return image_by_image();
+	}
 	const int frames_done = view->iter; // images gone through (the last of them may have failed)
 	const EccFrameResult *r = sc.results_host; // (written before the view's release store, read after its acquire)
 	int good = 0;

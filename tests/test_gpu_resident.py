@@ -296,3 +296,33 @@ def test_a_loss_run_that_is_not_resident_is_stepped_again_frame_by_frame(oracle,
         L = OracleLossy(oracle, w, h, hl, low_err=6, high_err=2, std_factor=5.0, running_average=8)
         exp = np.stack([L.step(data[i][f]) for f in range(n)])
         assert np.array_equal(got[0][i], exp), i
+
+
+def test_a_single_sequence_launch_that_is_not_resident_falls_back_to_two_launches_per_iteration(monkeypatch):
+    """ecc_run_kernel with the same rendezvous: a launch that was called off (RIR_DEBUG_ECC_BAIL: every launch) reports "not run"
+    through the host view and the alignment - one frame, or a chunk of frames - is done by the launch-per-iteration kernels, which
+    add the same rows in the same order: same track, same iteration counts."""
+    import torch
+
+    from librir_amd.registration import DeviceRegistratorECC, find_transform_ecc_translation
+
+    n, h, w = 30, 256, 320
+    f, _ = s3_registration(n, h, w, seed=31)
+    t = torch.from_numpy(f).cuda()
+
+    def run():
+        a = DeviceRegistratorECC(0.8, 0.8, shape=(h, w))
+        a.start(t[0])
+        a.compute_many(t[1:], chunk=8)
+        b = DeviceRegistratorECC(0.8, 0.8, shape=(h, w))
+        b.start(t[0])
+        for i in range(1, 6):
+            b.compute(t[i])
+        cc, wm = find_transform_ecc_translation(f[0] / f[0].max(), f[3] / f[3].max())
+        return a.x, a.y, a.confidences, b.x, b.y, b.confidences, cc, wm.tolist()
+
+    ref = run()
+    monkeypatch.setenv("RIR_DEBUG_ECC_BAIL", "1")
+    got = run()
+    monkeypatch.delenv("RIR_DEBUG_ECC_BAIL")
+    assert got == ref
