@@ -36,7 +36,10 @@ namespace rir
 		float tx, ty;
 		double rho;
 		volatile int iter; // iterations finished (written after the fields above)
-		volatile int done; // as EccState::done
+		volatile int done; // as EccState::done; 3: the resident launch was called off before it did anything (resident_device.h)
+		volatile unsigned int progress; // moves while a resident launch is alive (every image of a sequence, every 64 iterations of an alignment):
+										// the host gives up on lack of progress, not on total time - a launch may legitimately run for minutes
+		unsigned int pad;
 	};
 	size_t ecc_workspace_bytes(int w, int h);
 	hipError_t launch_ecc_prepare(const float *d_image, int w, int h, float *d_gx, float *d_gy, EccState *d_state, float tx, float ty, int max_iter,

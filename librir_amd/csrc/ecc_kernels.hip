@@ -455,6 +455,8 @@ namespace rir
 					// one granule: {tx | ty << 32, flag | done << 62}
 					ecc_granule_store(pub_rs, 0, (unsigned long long)__float_as_uint(st.tx) | ((unsigned long long)__float_as_uint(st.ty) << 32),
 									  flag | ((unsigned long long)done << 62));
+					if (host_view && (done || (it & 63) == 0)) // a sign of life for the host (posted write to coherent host memory, nothing waits for it)
+						__hip_atomic_store(const_cast<unsigned int *>(&host_view->progress), (unsigned int)((f << 20) + it), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 				}
 			}
 			else if (tid == 0)

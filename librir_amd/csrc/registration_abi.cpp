@@ -106,15 +106,24 @@ namespace
 	// waits (polling the coherent view) until the alignment in flight reports done or `launched` iterations
 	bool wait_view(EccHostView *view, int launched, hipStream_t st)
 	{
-		const auto t0 = std::chrono::steady_clock::now();
+		auto t0 = std::chrono::steady_clock::now();
 		long spins = 0;
+		unsigned int seen = view->progress;
 		while (view->done == 0 && view->iter < launched)
 		{
-			if ((++spins & 0x3ff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
-			{ // (a device fault would leave the words unwritten)
-				log_error("ECC: the device did not report back");
-				(void)hipStreamSynchronize(st);
-				return false;
+			if ((++spins & 0x3ff) == 0)
+			{
+				// the clock is one of NO PROGRESS, not of total time: a resident launch may hold thousands of images with up to a million
+				// iterations each and moves `progress` at least every 64 iterations; the launch-per-iteration batches move `iter`
+				const unsigned int p = view->progress;
+				if (p != seen)
+					seen = p, t0 = std::chrono::steady_clock::now();
+				else if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
+				{ // (a device fault would leave the words unwritten)
+					log_error("ECC: the device did not report back");
+					(void)hipStreamSynchronize(st);
+					return false;
+				}
 			}
 			__builtin_ia32_pause();
 		}
