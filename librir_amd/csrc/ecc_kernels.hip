@@ -84,12 +84,18 @@ namespace rir
 #define RIR_ECC_PIXELS_PER_ROUND 3 /* one sequence, one wave per SIMD: 19.3 k frames/s; 2: 18.8 k, 6: 19.3 k at 226 VGPRs */
 #endif
 #ifndef RIR_ECC_MULTI_PIXELS_PER_ROUND
-#define RIR_ECC_MULTI_PIXELS_PER_ROUND 5 /* several sequences: a row's 5 pixels per thread (640x512) in one round */
+#define RIR_ECC_MULTI_PIXELS_PER_ROUND 1 /* several sequences: latency is hidden by waves (RIR_ECC_MULTI_WAVES per SIMD), not by pixels in flight */
 #endif
 #ifndef RIR_ECC_MULTI_WAVES
-#define RIR_ECC_MULTI_WAVES 3 /* 168 VGPRs, no scratch.  8 sequences of 640x512, k frames/s aggregate (scripts/ecc_multi_variants.sh): (5, 3) 67-71,
-                                 (1, 4) 65-68, (2, 4) 62-65, (3, 4) 54-57, (5, 2) 57-59: the pixel loops are VALU-bound (102 vector instructions
-                                 per pixel, 25 of them double-precision), what differs is how evenly the rows land on the CUs */
+#define RIR_ECC_MULTI_WAVES 4 /* 128 VGPRs, no scratch: 4 workgroups per CU = 1 024 places, i.e. 8 sequences x 128 slices of exactly 2 rows: every
+                                 CU gets the same 8 rows.  8 sequences of 640x512, k frames/s aggregate (scripts/ecc_multi_variants.sh), with every place
+                                 of the device used (RIR_ECC_MULTI_MARGIN 0: this kernel checks its own residency and is repeated smaller when it
+                                 is not, resident_device.h): (1, 4) 70-75, (2, 4) 65-69, (3, 4) 62-66, (5, 3) 62-65; with the margin of the
+                                 residency rule (86 slices of 3 rows: CUs with 6 and CUs with 9 rows) (5, 3) 67-71, (1, 4) 65-68, (5, 2) 57-59.
+                                 The pixel loops are bound by the CU's memory pipeline (13 taps per pixel), the rest is how evenly the rows land */
+#endif
+#ifndef RIR_ECC_MULTI_MARGIN
+#define RIR_ECC_MULTI_MARGIN 0
 #endif
 	// the 15 sums of workgroup `blk` of `nblk` at translation (tx, ty), reduced over the workgroup (fixed order); valid in threads < ECC_NSUMS
 	template <int R> // pixels per round: their 13 R loads are in flight together; the sums are taken in pixel order whatever R is
@@ -643,7 +649,7 @@ namespace rir
 	}
 
 	int ecc_run_grid(int w, int h) { return ecc_blocks(w, h); }
-	int ecc_run_multi_capacity() { return resident_capacity(reinterpret_cast<const void *>(ecc_run_multi_kernel), ECC_BLOCK, 0); }
+	int ecc_run_multi_capacity() { return resident_capacity(reinterpret_cast<const void *>(ecc_run_multi_kernel), ECC_BLOCK, 0, RIR_ECC_MULTI_MARGIN != 0); }
 	int ecc_rows(int w, int h) { return ecc_blocks(w, h); }
 	// d_table: nseq entries (device); nslices workgroups per sequence (1 .. ecc_rows(w, h)); nseq * nslices <= ecc_run_multi_capacity()
 	hipError_t launch_ecc_run_multi(EccSeq *d_table, int nseq, int nslices, int w, int h, int max_iter, double eps, unsigned int epoch, unsigned int *d_ctl,

@@ -217,7 +217,7 @@ namespace rir
 			}
 		};
 	} // namespace
-	int resident_capacity(const void *kernel, int block_threads, size_t dynamic_lds)
+	int resident_capacity(const void *kernel, int block_threads, size_t dynamic_lds, bool with_margin)
 	{
 		static std::mutex mu;
 		static std::map<CapKey, int> *cache = new std::map<CapKey, int>;
@@ -225,7 +225,7 @@ namespace rir
 		if (hipGetDevice(&dev) != hipSuccess)
 			return 0;
 		std::lock_guard<std::mutex> g(mu);
-		const CapKey key{dev, kernel, block_threads, dynamic_lds};
+		const CapKey key{dev, kernel, with_margin ? block_threads : -block_threads, dynamic_lds};
 		auto it = cache->find(key);
 		if (it != cache->end())
 			return it->second;
@@ -235,7 +235,7 @@ namespace rir
 		{
 			if (hipDeviceGetAttribute(&xcds, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess)
 				xcds = 1;
-			cap = resident_capacity_rule(per_cu, cus, xcds);
+			cap = with_margin ? resident_capacity_rule(per_cu, cus, xcds) : (int)std::min<long long>((long long)per_cu * cus, 0x3fffffff);
 		}
 		else
 			(void)hipGetLastError();

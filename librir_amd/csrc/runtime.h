@@ -87,7 +87,9 @@ namespace rir
 	// (1) resident_capacity: workgroups of `kernel` (block of `block_threads` threads, `dynamic_lds` bytes) the current device holds
 	// at once, from hipOccupancyMaxActiveBlocksPerMultiprocessor x multiProcessorCount, less a margin (resident_capacity_rule).
 	// 0 when the runtime cannot tell: the caller then takes its launch-per-frame / launch-per-iteration path.  Cached.
-	int resident_capacity(const void *kernel, int block_threads, size_t dynamic_lds);
+	// with_margin false: every place of the device - only for kernels that find out at their start whether they are resident and
+	// whose host side repeats a launch that was not (resident_device.h): there a launch that does not fit costs a detour, not an error.
+	int resident_capacity(const void *kernel, int block_threads, size_t dynamic_lds, bool with_margin = true);
 	// The rule alone (no device needed; unit-tested on the CPU): workgroup i of a launch starts on XCD i % xcds and every XCD fills
 	// its own CUs, so what counts is an XCD's places, blocks_per_cu x (cus / xcds); one sixteenth of them (at least one) stays
 	// free for whatever else is running.  MI355X, a kernel with 5 workgroups per CU: 8 x (160 - 10) = 1 200.
