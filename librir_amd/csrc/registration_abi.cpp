@@ -165,14 +165,14 @@ namespace
 			unsigned int *d_ctl = sc.ctl_of_runs(st);
 			if (!d_ctl)
 				return -1;
-			const unsigned int before = sc.run_arrivals;
-			sc.run_arrivals += (unsigned int)ecc_run_grid(w, h);
 			if (!debug_call_off(d_ctl, sc.epoch + 1, st))
 				return -1;
 			if (!hip_ok(launch_ecc_run(d_templ, d_image, d_gx, d_gy, d_mask, w, h, sc.partials.as<double>(), d_state, d_view, warp[0], warp[1], max_iter, eps,
-									   ++sc.epoch, 1, nullptr, d_ctl, before, st),
-						"ecc run") ||
-				!wait_view(view, max_iter + 1, st))
+									   ++sc.epoch, 1, nullptr, d_ctl, sc.run_arrivals, st),
+						"ecc run"))
+				return -1;
+			sc.run_arrivals += (unsigned int)ecc_run_grid(w, h); // (counted once the launch is queued: its workgroups will arrive)
+			if (!wait_view(view, max_iter + 1, st))
 				return -1;
 			hs.done = view->done, hs.iter = view->iter, hs.tx = view->tx, hs.ty = view->ty, hs.rho = view->rho;
 			called_off = hs.done == 3; // the launch did not become resident (resident_device.h) and has computed nothing: two launches per iteration instead
@@ -473,14 +473,14 @@ int align_frames_locked(EccScratch &sc, const float *d_ref_norm, const float *d_
 	unsigned int *d_ctl = sc.ctl_of_runs(st);
 	if (!d_ctl)
 		return -1;
-	const unsigned int before = sc.run_arrivals;
-	sc.run_arrivals += (unsigned int)ecc_run_grid(w, h);
 	if (!debug_call_off(d_ctl, sc.epoch + 1, st))
 		return -1;
 	if (!hip_ok(launch_ecc_run(d_ref_norm, d_norm, d_gx, d_gy, nullptr, w, h, sc.partials.as<double>(), sc.state.as<EccState>(), d_view, warp[0], warp[1],
-							   max_iterations, eps, ++sc.epoch, nframes, d_results, d_ctl, before, st),
-				"ecc run") ||
-		!wait_view(view, nframes + 1, st))
+							   max_iterations, eps, ++sc.epoch, nframes, d_results, d_ctl, sc.run_arrivals, st),
+				"ecc run"))
+		return -1;
+	sc.run_arrivals += (unsigned int)ecc_run_grid(w, h);
+	if (!wait_view(view, nframes + 1, st))
 		return -1;
 	if (view->done == 3)
 	{ // the launch did not become resident (resident_device.h) and has aligned nothing

@@ -216,7 +216,9 @@ class CodecContext:
         nt = ct.c_int(0)
         _check(_lib.rir_codec_workspace_create_device(fr.data_ptr(), L.width, L.height, L.nframes, L.gop, int(tries), int(spacing_bytes), ct.byref(ptr),
                                                       times, ct.byref(nt), _stream()), "rir_codec_workspace_create_device")
-        self.workspace = _LibraryBuffer(ptr.value, L.workspace_bytes).tensor(self.hdr.device)
+        owner = _LibraryBuffer(ptr.value, L.workspace_bytes)
+        self.workspace = owner.tensor(self.hdr.device)
+        self._workspace_owner = owner  # (the allocation lives as long as this context uses it, whatever torch keeps alive)
         return [float(times[i]) for i in range(nt.value)]
 
     def encode_status(self):
