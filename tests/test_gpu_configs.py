@@ -176,3 +176,40 @@ def test_config4_full_size_chain_registration_correction_bounded_loss(tmp_path, 
         got = mov.data
     assert np.array_equal(got, exp)
     assert np.abs(got.astype(np.int32) - reg_ref).max() <= 6
+
+
+def test_config4_thousand_frames_correction_and_bounded_loss(tmp_path, dev, oracle):
+    """BASELINE configs[4] at its stated LENGTH, 1 000 frames 640x512: the registration recipe's shifts (i % 100 pixels: the track itself is
+    checked on 100 frames above - across the jump back to 0 it is lost, upstream's too) -> motion correction on the device -> bounded-loss
+    recording through the saver (20 chunks, the loss state carried across them, the deferred runs of 49-50 frames) -> read back: every frame
+    bit-exact against the oracle's chain, and the same 1 000 frames through the device-resident stream operator in two calls."""
+    n, h, w = 1000, 512, 640
+    f32, shifts = s3_registration(n, h, w)
+    u16 = np.clip(f32, 0, 65535).astype(np.uint16)
+    del f32
+    sh = shifts.astype(np.float32)
+    t16 = torch.from_numpy(u16).to("cuda")
+    reg_gpu_t = D.remove_motion(t16, torch.from_numpy(sh).to("cuda"), rows=h - 3)
+    reg_gpu = reg_gpu_t.cpu().numpy()
+    L = OracleLossy(oracle, w, h, h - 3, low_err=3, high_err=3, std_factor=0.0, running_average=32)
+    exp = np.empty_like(u16)
+    for i in range(n):
+        ref_i = oracle.remove_motion(u16[i], float(sh[i, 0]), float(sh[i, 1]), rows=h - 3)
+        assert np.array_equal(reg_gpu[i], ref_i), i
+        exp[i] = L.step(ref_i)
+    dst = tmp_path / "cfg4_1000.h264"
+    with IRSaver(dst, w, h, h - 3) as s:
+        s.set_parameter("lowValueError", 3)
+        s.set_parameter("highValueError", 3)
+        s.set_parameter("stdFactor", 0)
+        for i in range(n):
+            s.add_image_lossy(reg_gpu[i], i * 1000)
+    with IRMovie.from_filename(dst) as mov:
+        assert mov.images == n
+        for i in range(n):
+            assert np.array_equal(mov[i], exp[i]), i
+    ls = D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32)
+    a, _, _ = ls.step(reg_gpu_t[:400])
+    b, _, _ = ls.step(reg_gpu_t[400:])
+    ls.close()
+    assert np.array_equal(a.cpu().numpy(), exp[:400]) and np.array_equal(b.cpu().numpy(), exp[400:])
