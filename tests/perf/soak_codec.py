@@ -32,6 +32,11 @@ for k in range(cases):
     t = torch.from_numpy(fr).cuda()
     enc = ctx.encode(t); dec = ctx.decode(enc); torch.cuda.synchronize()
     ok = np.array_equal(dec.cpu().numpy(), fr)
+    # the slotted form (stage 1 alone) straight into the decoder, and its lengths against the dense offsets
+    ctx.encode_tiles(t)
+    ok = ok and np.array_equal(ctx.decode_slots().cpu().numpy(), fr)
+    seg = ctx.slots()[0].cpu().numpy().view(np.uint32)
+    ok = ok and np.array_equal(seg, np.diff(enc.tile_off.cpu().numpy().view(np.uint32).astype(np.int64), axis=1).astype(np.uint32))
     hdr = enc.hdr.cpu().numpy().view(np.uint64); toff = enc.tile_off.cpu().numpy().view(np.uint32); coff = enc.chunk_off.cpu().numpy(); st = enc.stream.cpu().numpy().view(np.uint64)
     same = True
     for c in range(ctx.layout.nchunks):
