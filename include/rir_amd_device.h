@@ -24,6 +24,14 @@ extern "C"
 	int rir_device_available(void);
 	int rir_stream_synchronize(void *stream);
 
+	/* The sizing rules of kernels whose workgroups wait for each other inside a launch ("resident launches", librir_amd/csrc/runtime.h),
+	 * as plain host functions (no device needed; what the CPU tests check): workgroups of a kernel with blocks_per_cu resident
+	 * workgroups per CU that one launch may hold on a device of `cus` CUs in `xcds` XCDs; and how `units` independent units (streams,
+	 * sequences) of wgs_per_unit workgroups go through a kernel of that capacity: out2[0] = units per launch (0: a unit does not fit - the
+	 * launch-per-frame / launch-per-iteration kernels are used), out2[1] = launches. */
+	int rir_resident_capacity_rule(int blocks_per_cu, int cus, int xcds);
+	int rir_resident_plan(int capacity, int wgs_per_unit, int units, int *out2);
+
 	/* ---- block codec (format RIRB1) ----------------------------------------------------------
 	 * Replaces, for device-resident batches, the encode/decode the reference delegates to
 	 * libx264 (reference src/cpp/video_io/h264.cpp:1022-1131 AddFrame, :3096-3229 GetFrame).
