@@ -942,7 +942,7 @@ namespace rir
 
 	// ---- a run of frames in one launch ---------------------------------------------------------------------------
 	//
-	// grid = workgroups of a stream (nb = lossy_run_workgroups(full)) x streams, 1-D, all resident at once (kLossyRunMaxWorkgroups,
+	// grid = workgroups of a stream (nb = lossy_run_workgroups(full)) x streams, 1-D, all resident at once (lossy_run_capacity(),
 	// lossy_kernels.h); a ticket deals (stream, workgroup) in the order workgroups start.  A workgroup only ever waits for
 	// workgroups of ITS stream.
 	// Thread (b, tid) owns pixels [8 i8, 8 i8 + 8), i8 = 1024 b + tid, for every frame of the run: refT, lastDL, the running sums and
