@@ -92,6 +92,14 @@ extern "C"
 										  long long spacing_bytes, void **d_workspace, float *times_us, int *ntimes, void *stream);
 	void rir_codec_workspace_destroy_device(void *d_workspace);
 
+	/* The same placement for ANY pair of buffers that a kernel walks at the same pace - the input and the output of the frame-buffer
+	 * kernels (translate, gaussian_filter, the fused chain, the 3x3 median: 5-10 % between the classes): `bytes` of device memory in another
+	 * placement class than d_other, found by timing a plain streaming copy from d_other into each candidate.  Arguments as for
+	 * rir_codec_workspace_create_device; release with rir_buffer_destroy_device. */
+	int rir_buffer_create_beside_device(const void *d_other, long long other_bytes, long long bytes, int max_tries, long long spacing_bytes,
+										void **d_buffer, float *times_us, int *ntimes, void *stream);
+	void rir_buffer_destroy_device(void *d_buffer);
+
 	/* The encode as one kernel that writes the dense stream directly (segments staged in LDS, decoupled look-back): same
 	 * outputs bit for bit, fewer bytes through HBM, not faster on MI355X.  rir_codec_encode_status (waits for the
 	 * stream): 0 = the last single-pass encode on this workspace completed, 1 = a look-back gave up, the stream is incomplete. */

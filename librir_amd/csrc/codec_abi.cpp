@@ -286,6 +286,115 @@ RIR_EXPORT int rir_codec_workspace_create_device(const unsigned short *d_frames,
 	return 0;
 }
 
+// The same for ANY pair of buffers a kernel walks at the same pace (the frame-buffer kernels: translate 92-99 us against 86-88, gaussian 119
+// against 107, the fused chain 119-129 against 116-117 per 256 frames 640x512, tests/perf/filter_class_probe.py): `bytes` of device memory in
+// another placement class than the buffer d_other (other_bytes long), found by timing a plain streaming copy from d_other into each candidate
+// (up to 256 MiB of it).  Candidates `spacing_bytes` apart, at most max_tries further ones; the first that copies 5 % faster than the first
+// one is kept, else the fastest; spacers and losers are freed before the call returns.  Release with rir_buffer_destroy_device.
+RIR_EXPORT int rir_buffer_create_beside_device(const void *d_other, long long other_bytes, long long bytes, int max_tries, long long spacing_bytes,
+											   void **d_buffer, float *times_us, int *ntimes, void *stream)
+{
+	if (ntimes)
+		*ntimes = 0;
+	if (!device_ready())
+		return -1;
+	if (!d_other || !d_buffer || other_bytes < 16 || bytes < 16 || max_tries < 0 || max_tries > 64 || spacing_bytes < 0 || ((uintptr_t)d_other & 15))
+	{
+		log_error("rir_buffer_create_beside_device: invalid argument");
+		return -1;
+	}
+	*d_buffer = nullptr;
+	hipStream_t st = as_stream(stream);
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (!hip_ok(hipEventCreate(&e0), "hipEventCreate") || !hip_ok(hipEventCreate(&e1), "hipEventCreate"))
+	{
+		if (e0)
+			(void)hipEventDestroy(e0);
+		return -1;
+	}
+	const int64_t probe = (std::min<long long>(std::min<long long>(other_bytes, bytes), 256ll << 20)) & ~15ll;
+	constexpr int kReps = 5;
+	auto time_on = [&](void *cand, float &us) {
+		float t[kReps];
+		if (!hip_ok(launch_stream_copy_probe(d_other, cand, probe, st), "copy probe"))
+			return false;
+		for (int r = 0; r < kReps; ++r)
+			if (!hip_ok(hipEventRecord(e0, st), "event") || !hip_ok(launch_stream_copy_probe(d_other, cand, probe, st), "copy probe") ||
+				!hip_ok(hipEventRecord(e1, st), "event") || !hip_ok(hipEventSynchronize(e1), "sync") || !hip_ok(hipEventElapsedTime(&t[r], e0, e1), "elapsed"))
+				return false;
+		std::sort(t, t + kReps);
+		us = t[kReps / 2] * 1e3f;
+		return true;
+	};
+	std::vector<void *> spacers, cands;
+	std::vector<float> times;
+	bool ok = true;
+	for (int k = 0; k <= max_tries && ok; ++k)
+	{
+		void *sp = nullptr, *b = nullptr;
+		if (k > 0 && spacing_bytes > 0)
+		{
+			if (hipMalloc(&sp, (size_t)spacing_bytes) != hipSuccess)
+			{
+				(void)hipGetLastError();
+				break;
+			}
+			spacers.push_back(sp);
+		}
+		if (hipMalloc(&b, (size_t)bytes) != hipSuccess)
+		{
+			(void)hipGetLastError();
+			if (k == 0)
+			{
+				log_error("rir_buffer_create_beside_device: out of device memory");
+				ok = false;
+			}
+			break;
+		}
+		float us = 0;
+		if (!time_on(b, us))
+		{
+			(void)hipFree(b);
+			ok = false;
+			break;
+		}
+		cands.push_back(b);
+		times.push_back(us);
+		if (k > 0 && us < 0.95f * times[0])
+			break;
+	}
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
+	for (void *sp : spacers)
+		(void)hipFree(sp);
+	size_t keep = 0;
+	for (size_t i = 1; i < cands.size(); ++i)
+		if (times[i] < times[keep])
+			keep = i;
+	for (size_t i = 0; i < cands.size(); ++i)
+		if (!ok || i != keep)
+			(void)hipFree(cands[i]);
+	if (!ok || cands.empty())
+		return -1;
+	*d_buffer = cands[keep];
+	if (times_us)
+	{
+		times_us[0] = times[keep];
+		int k = 1;
+		for (size_t i = 0; i < times.size(); ++i)
+			if (i != keep)
+				times_us[k++] = times[i];
+	}
+	if (ntimes)
+		*ntimes = (int)times.size();
+	return 0;
+}
+RIR_EXPORT void rir_buffer_destroy_device(void *d_buffer)
+{
+	if (d_buffer)
+		(void)hipFree(d_buffer);
+}
+
 RIR_EXPORT void rir_codec_workspace_destroy_device(void *d_workspace)
 {
 	if (d_workspace)

@@ -39,6 +39,7 @@ namespace rir
 	hipError_t launch_merge_planes(const uint8_t *Y, const uint8_t *U, const uint8_t *V, int linesize, int w, int h, int nframes, uint16_t *img,
 								   uint8_t *it, hipStream_t st);
 	hipError_t launch_u16_to_f32(const uint16_t *src, float *dst, int64_t total, hipStream_t st);
+	hipError_t launch_stream_copy_probe(const void *src, void *dst, int64_t bytes, hipStream_t st); // 16-byte aligned buffers, bytes a multiple of 16
 
 	// codec_kernels.hip
 	hipError_t launch_encode_tiles(const uint16_t *d_frames, int64_t npx, int ntiles, int nframes, int gop, uint64_t *d_hdr,

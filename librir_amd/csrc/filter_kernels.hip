@@ -2128,6 +2128,21 @@ namespace rir
 		for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
 			dst[i] = (float)src[i];
 	}
+	// A plain streaming copy, 16 bytes per lane: the probe of rir_buffer_create_beside_device (which placement class is an allocation of?
+	// - a kernel that reads one buffer and writes another at the same pace is 7-10 % slower when both are of one class)
+	typedef unsigned int probe_v4u __attribute__((ext_vector_type(4)));
+	__global__ __launch_bounds__(256) void stream_copy_probe_kernel(const probe_v4u *__restrict__ src, probe_v4u *__restrict__ dst, int64_t n16)
+	{
+		for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
+			dst[i] = __builtin_nontemporal_load(src + i);
+	}
+	hipError_t launch_stream_copy_probe(const void *src, void *dst, int64_t bytes, hipStream_t st)
+	{
+		const int64_t n16 = bytes / 16;
+		hipLaunchKernelGGL(stream_copy_probe_kernel, dim3(8192), dim3(256), 0, st, static_cast<const probe_v4u *>(src), static_cast<probe_v4u *>(dst), n16);
+		return hipGetLastError();
+	}
+
 	hipError_t launch_u16_to_f32(const uint16_t *src, float *dst, int64_t total, hipStream_t st)
 	{
 		int blocks = (int)(((total + 255) / 256) < 4096 ? ((total + 255) / 256) : 4096);

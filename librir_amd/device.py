@@ -72,6 +72,10 @@ _lib.rir_codec_encode_tiles_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int
 _lib.rir_codec_encode_compact_device.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, ct.c_longlong, _vp]
 _lib.rir_codec_workspace_create_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_longlong, ct.POINTER(ct.c_void_p),
                                                    ct.POINTER(ct.c_float), ct.POINTER(ct.c_int), _vp]
+_lib.rir_buffer_create_beside_device.argtypes = [_vp, ct.c_longlong, ct.c_longlong, ct.c_int, ct.c_longlong, ct.POINTER(ct.c_void_p), ct.POINTER(ct.c_float),
+                                                 ct.POINTER(ct.c_int), _vp]
+_lib.rir_buffer_destroy_device.argtypes = [_vp]
+_lib.rir_buffer_destroy_device.restype = None
 _lib.rir_codec_workspace_destroy_device.argtypes = [_vp]
 _lib.rir_codec_workspace_destroy_device.restype = None
 _lib.rir_codec_decode_slots_device.argtypes = [_vp, _vp, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
@@ -154,8 +158,9 @@ class _LibraryBuffer:
     """Device memory allocated by the library (rir_codec_workspace_create_device), seen from torch as a uint8 tensor that keeps
     this object - and so the allocation - alive."""
 
-    def __init__(self, ptr, nbytes):
+    def __init__(self, ptr, nbytes, destroy=None):
         self.ptr, self.nbytes = int(ptr), int(nbytes)
+        self._destroy = destroy if destroy is not None else _lib.rir_codec_workspace_destroy_device
         self.__cuda_array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2}
 
     def tensor(self, device):
@@ -164,10 +169,29 @@ class _LibraryBuffer:
     def __del__(self):
         try:
             if self.ptr:
-                _lib.rir_codec_workspace_destroy_device(ct.c_void_p(self.ptr))
+                self._destroy(ct.c_void_p(self.ptr))
                 self.ptr = 0
         except Exception:
             pass
+
+
+def empty_beside(other, shape, dtype, tries=6, spacing_bytes=6 << 30):
+    """A device tensor of ``shape`` / ``dtype`` in another placement class than the tensor ``other`` (rir_buffer_create_beside_device): the
+    output buffer for a kernel that reads ``other`` and writes an output of similar size at the same pace - translate, gaussian_filter,
+    filter_chain, median_filter are 5-10 % faster then (tests/perf/filter_class_probe.py).  One-off set-up: candidates are
+    allocated by the library, a streaming copy is timed on each, the rest is freed.  Returns (tensor, measured times in us, kept first)."""
+    nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+    nbytes = (nbytes + 15) // 16 * 16
+    ptr = ct.c_void_p()
+    times = (ct.c_float * (int(tries) + 1))()
+    nt = ct.c_int(0)
+    o = other.contiguous()
+    _check(_lib.rir_buffer_create_beside_device(o.data_ptr(), o.numel() * o.element_size(), nbytes, int(tries), int(spacing_bytes), ct.byref(ptr), times,
+                                                ct.byref(nt), _stream()), "rir_buffer_create_beside_device")
+    owner = _LibraryBuffer(ptr.value, nbytes, _lib.rir_buffer_destroy_device)
+    t = owner.tensor(other.device)[:int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()].view(dtype).view(*shape)
+    t._rir_owner = owner  # (belt and braces: the allocation lives as long as the tensor object the caller holds)
+    return t, [float(times[i]) for i in range(nt.value)]
 
 
 class CodecContext:
@@ -365,7 +389,7 @@ def translate_to_u16(frames, offsets, strategy="nearest", background=0):
     return dst
 
 
-def filter_chain(frames, bad_pixels, sigma, offsets, strategy="nearest", background=0):
+def filter_chain(frames, bad_pixels, sigma, offsets, strategy="nearest", background=0, out=None):
     """``bad_pixels.correct`` -> ``gaussian_filter(sigma)`` -> ``translate(offsets, strategy)`` -> uint16, in ONE pass over the
     uint16 frames (4 bytes of HBM traffic per pixel instead of 14); bit-identical to the three calls.  ``bad_pixels``: a
     ``BadPixels`` object or None.  Strategies "nearest" and "background"; for the others run the three calls."""
@@ -379,7 +403,9 @@ def filter_chain(frames, bad_pixels, sigma, offsets, strategy="nearest", backgro
     per_frame = 1 if off.dim() == 2 else 0
     if per_frame and off.shape[0] != n:
         raise RuntimeError("filter_chain: one (dx,dy) pair per frame expected")
-    dst = torch.empty((n, h, w), dtype=torch.uint16, device=fr.device)
+    if out is not None and (tuple(out.shape) != (n, h, w) or out.dtype != torch.uint16 or not out.is_contiguous() or out.data_ptr() == fr.data_ptr()):
+        raise RuntimeError("filter_chain: out must be a contiguous uint16 tensor of the frames' shape, not the input")
+    dst = out if out is not None else torch.empty((n, h, w), dtype=torch.uint16, device=fr.device)  # (out: e.g. from empty_beside(frames, ...))
     back = np.array([background], dtype=np.uint16)
     handle = bad_pixels.handle if bad_pixels is not None else 0
     _check(_lib.rir_filter_chain_device(handle, fr.data_ptr(), dst.data_ptr(), w, h, n, float(sigma), off.data_ptr(), per_frame, back.ctypes.data,

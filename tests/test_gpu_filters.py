@@ -265,3 +265,23 @@ def test_translate_where_the_reference_reads_out_of_bounds(dev, oracle, dtype):
         g = dev.translate(torch.from_numpy(img).cuda(), (dx, dy), strat, background=7).cpu().numpy()
         r = np.stack([oracle.translate(img[i], dx, dy, strat, background=7) for i in range(2)])
         assert np.array_equal(g, r), (dtype, dx, dy, strat)
+
+
+def test_output_buffer_in_another_placement_class(dev):
+    """rir_buffer_create_beside_device / empty_beside: an output buffer allocated by the library in another placement class than the
+    input (found by timing a streaming copy); the fused chain writes into it and gives what it gives into any other buffer."""
+    import torch
+
+    from librir_amd.synthetic import s1_noisy_background
+
+    n, h, w = 32, 256, 320
+    fr = torch.from_numpy(s1_noisy_background(n, h, w, seed=12)).cuda()
+    out, times = dev.empty_beside(fr, (n, h, w), torch.uint16, tries=2, spacing_bytes=64 << 20)
+    assert tuple(out.shape) == (n, h, w) and out.dtype == torch.uint16 and 1 <= len(times) <= 3 and times[0] == min(times)
+    ref = dev.filter_chain(fr, None, 0.75, (1.25, -2.5), "nearest")
+    got = dev.filter_chain(fr, None, 0.75, (1.25, -2.5), "nearest", out=out)
+    assert got.data_ptr() == out.data_ptr() and torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    with pytest.raises(RuntimeError):
+        dev.filter_chain(fr, None, 0.75, (1.25, -2.5), "nearest", out=fr)
+    del got, out
+    torch.cuda.synchronize()
