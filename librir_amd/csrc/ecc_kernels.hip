@@ -127,22 +127,24 @@ namespace rir
 			const float sx = (float)x + tx, sy = (float)y + ty;
 			// validity: the nearest source pixel lies inside the image and inside the caller's mask
 			const int nx = (int)rintf(sx), ny = (int)rintf(sy);
-			bool valid = inside && nx >= 0 && nx < w && ny >= 0 && ny < h;
+			bool valid = inside && (unsigned)nx < (unsigned)w && (unsigned)ny < (unsigned)h;
 			const uint8_t mv = mask ? mask[min(max(ny, 0), h - 1) * w + min(max(nx, 0), w - 1)] : (uint8_t)1;
 			valid = valid && mv != 0;
 			const float flx = floorf(sx), fly = floorf(sy);
 			const int x0 = (int)flx, y0 = (int)fly;
 			const float fx = sx - flx, fy = sy - fly;
-			// zero outside the image (constant border); every tap is loaded, from an address clamped into the image, and dropped
-			// afterwards when it lies outside: a load under a condition is a branch with its own wait
-			const bool xa = x0 >= 0 && x0 < w, xb = x0 + 1 >= 0 && x0 + 1 < w, ya = y0 >= 0 && y0 < h, yb = y0 + 1 >= 0 && y0 + 1 < h;
-			const int xc0 = min(max(x0, 0), w - 1), xc1 = min(max(x0 + 1, 0), w - 1), yc0 = min(max(y0, 0), h - 1), yc1 = min(max(y0 + 1, 0), h - 1);
-			const uint32_t o00 = (uint32_t)(yc0 * w + xc0) * 4u, o01 = (uint32_t)(yc0 * w + xc1) * 4u, o10 = (uint32_t)(yc1 * w + xc0) * 4u,
-						   o11 = (uint32_t)(yc1 * w + xc1) * 4u;
-			const bool m00 = xa && ya, m01 = xb && ya, m10 = xa && yb, m11 = xb && yb;
+			// zero outside the image (constant border); every tap is loaded - a load under a condition is a branch with its own wait - and a
+			// tap outside the image is loaded from an offset outside the BUFFER: the hardware's range check returns +0.0 for it.  Four
+			// selects on the offsets (shared by the three images) instead of eight clamps and twelve selects on the values; the taps
+			// inside need no clamp, and their row offset is one 24-bit multiply-add (v_mul_lo_u32 is a quarter-rate instruction).
+			const bool xa = (unsigned)x0 < (unsigned)w, xb = (unsigned)(x0 + 1) < (unsigned)w, ya = (unsigned)y0 < (unsigned)h,
+					   yb = (unsigned)(y0 + 1) < (unsigned)h;
+			constexpr uint32_t kOutside = 0xfffffff0u; // (beyond any image: bytes < 2^32 - 16)
+			const uint32_t lin = (uint32_t)(__mul24(y0, w) + x0) * 4u, w4 = (uint32_t)w * 4u; // (meaningful when the tap is inside: y0 < h < 2^23)
+			const uint32_t o00 = xa && ya ? lin : kOutside, o01 = xb && ya ? lin + 4u : kOutside, o10 = xa && yb ? lin + w4 : kOutside,
+						   o11 = xb && yb ? lin + w4 + 4u : kOutside;
 			auto blend = [&](__amdgpu_buffer_rsrc_t r) {
-				const float l00 = ld(r, o00), l01 = ld(r, o01), l10 = ld(r, o10), l11 = ld(r, o11);
-				const float v00 = m00 ? l00 : 0.f, v01 = m01 ? l01 : 0.f, v10 = m10 ? l10 : 0.f, v11 = m11 ? l11 : 0.f;
+				const float v00 = ld(r, o00), v01 = ld(r, o01), v10 = ld(r, o10), v11 = ld(r, o11);
 				const float top = v00 + fx * (v01 - v00), bot = v10 + fx * (v11 - v10);
 				return top + fy * (bot - top);
 			};
@@ -547,6 +549,8 @@ namespace rir
 		// from fitting - everybody leaves before anything is written and the host runs the chunk again with fewer slices)
 		if (resident_rendezvous(ctl, arrivals_before, gridDim.x, epoch, &sh_flag) != RESIDENT_GO)
 			return;
+		// (sequences dealt ACROSS the XCDs instead - q = (blockIdx.x % S + slice) % S, so that a CU holds workgroups of four sequences in
+		// different phases - measured no faster, with 1, 2 or 3 pixels per round: a waiting sequence's share of the CU is not picked up)
 		const int q = blockIdx.x % S, slice = blockIdx.x / S, nslices = gridDim.x / S, tid = threadIdx.x;
 		const EccSeq sq = table[q];
 		const float *image = sq.image, *gximg = sq.gx, *gyimg = sq.gy;

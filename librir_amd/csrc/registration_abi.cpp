@@ -16,6 +16,9 @@
 #include "rir_amd_device.h"
 #include "runtime.h"
 
+// the alignment kernels address an image through 32-bit byte offsets of one buffer descriptor and 24-bit row numbers (ecc_kernels.hip)
+static inline bool ecc_size_ok(int w, int h) { return w < (1 << 23) && h < (1 << 23) && (long long)w * h <= (1ll << 29); }
+
 using namespace rir;
 
 namespace
@@ -255,7 +258,7 @@ RIR_EXPORT int rir_ecc_translation_device(const float *d_templ, const float *d_i
 {
 	if (!device_ready())
 		return -1;
-	if (!d_templ || !d_image || !warp || w < 2 || h < 2 || max_iterations <= 0 || !(eps >= 0))
+	if (!d_templ || !d_image || !warp || w < 2 || h < 2 || !ecc_size_ok(w, h) || max_iterations <= 0 || !(eps >= 0))
 	{
 		log_error("rir_ecc_translation_device: invalid argument");
 		return -1;
@@ -386,7 +389,7 @@ RIR_EXPORT int rir_ecc_align_prepared_device(const float *d_ref_norm, const floa
 {
 	if (!device_ready())
 		return -1;
-	if (!d_ref_norm || !d_norm || !d_gx || !d_gy || !warp || w < 2 || h < 2 || max_iterations <= 0 || !(eps >= 0))
+	if (!d_ref_norm || !d_norm || !d_gx || !d_gy || !warp || w < 2 || h < 2 || !ecc_size_ok(w, h) || max_iterations <= 0 || !(eps >= 0))
 	{
 		log_error("rir_ecc_align_prepared_device: invalid argument");
 		return -1;
@@ -414,7 +417,7 @@ RIR_EXPORT int rir_ecc_align_prepared_frames_device(const float *d_ref_norm, con
 {
 	if (!device_ready())
 		return -1;
-	if (!d_ref_norm || !d_norm || !d_gx || !d_gy || !warp || !results || w < 2 || h < 2 || nframes <= 0 || nframes > kEccMaxSequence || max_iterations <= 0 ||
+	if (!d_ref_norm || !d_norm || !d_gx || !d_gy || !warp || !results || w < 2 || h < 2 || !ecc_size_ok(w, h) || nframes <= 0 || nframes > kEccMaxSequence || max_iterations <= 0 ||
 		max_iterations > kEccMaxIterations || !(eps >= 0))
 	{
 		log_error("rir_ecc_align_prepared_frames_device: invalid argument");
@@ -519,7 +522,7 @@ RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const 
 {
 	if (!device_ready())
 		return -1;
-	bool bad = !d_ref_norm || !d_norm || !d_gx || !d_gy || !nframes || !warps || !results || !good || w < 2 || h < 2 || nseq <= 0 || nseq > 4096 ||
+	bool bad = !d_ref_norm || !d_norm || !d_gx || !d_gy || !nframes || !warps || !results || !good || w < 2 || h < 2 || !ecc_size_ok(w, h) || nseq <= 0 || nseq > 4096 ||
 			   max_iterations <= 0 || max_iterations > kEccMaxIterations || !(eps >= 0) || results_stride <= 0;
 	size_t total_frames = 0;
 	for (int q = 0; !bad && q < nseq; ++q)
@@ -684,7 +687,7 @@ RIR_EXPORT int find_transform_ecc_translation(const float *templ, const float *i
 {
 	if (!device_ready())
 		return -1;
-	if (!templ || !image || !warp || w < 2 || h < 2 || max_iterations <= 0 || !(eps >= 0))
+	if (!templ || !image || !warp || w < 2 || h < 2 || !ecc_size_ok(w, h) || max_iterations <= 0 || !(eps >= 0))
 	{
 		log_error("find_transform_ecc_translation: invalid argument");
 		return -1;
