@@ -145,8 +145,13 @@ namespace rir
 						   o11 = xb && yb ? lin + w4 + 4u : kOutside;
 			auto blend = [&](__amdgpu_buffer_rsrc_t r) {
 				const float v00 = ld(r, o00), v01 = ld(r, o01), v10 = ld(r, o10), v11 = ld(r, o11);
+#ifndef RIR_ECC_NO_FMA /* fused: one rounding less per term (the file is built with -ffp-contract=off, so fusing is spelled out); RIR_ECC_NO_FMA for an A/B */
+				const float top = __builtin_fmaf(fx, v01 - v00, v00), bot = __builtin_fmaf(fx, v11 - v10, v10);
+				return __builtin_fmaf(fy, bot - top, top);
+#else
 				const float top = v00 + fx * (v01 - v00), bot = v10 + fx * (v11 - v10);
 				return top + fy * (bot - top);
+#endif
 			};
 			Px p;
 			p.I = blend(r_img);
@@ -160,9 +165,15 @@ namespace rir
 			const double I = p.I, gx = p.gx, gy = p.gy, T = p.T;
 			if (p.valid)
 			{
+#ifndef RIR_ECC_NO_FMA /* fused: one rounding less per term (the file is built with -ffp-contract=off, so fusing is spelled out); RIR_ECC_NO_FMA for an A/B */
+				s[0] += 1.0, s[1] += I, s[2] = __builtin_fma(I, I, s[2]), s[3] += T, s[4] = __builtin_fma(T, T, s[4]), s[5] = __builtin_fma(T, I, s[5]);
+				s[6] += gx, s[7] += gy, s[8] = __builtin_fma(gx, gx, s[8]), s[9] = __builtin_fma(gx, gy, s[9]), s[10] = __builtin_fma(gy, gy, s[10]);
+				s[11] = __builtin_fma(gx, I, s[11]), s[12] = __builtin_fma(gy, I, s[12]), s[13] = __builtin_fma(gx, T, s[13]), s[14] = __builtin_fma(gy, T, s[14]);
+#else
 				s[0] += 1.0, s[1] += I, s[2] += I * I, s[3] += T, s[4] += T * T, s[5] += T * I;
 				s[6] += gx, s[7] += gy, s[8] += gx * gx, s[9] += gx * gy, s[10] += gy * gy;
 				s[11] += gx * I, s[12] += gy * I, s[13] += gx * T, s[14] += gy * T;
+#endif
 			}
 		};
 		{
