@@ -70,13 +70,22 @@ namespace rir
 		__builtin_amdgcn_raw_buffer_store_b128(g, rs, byte_off, 0, 16 /* sc1 */);
 	}
 
-	// LDS of the reductions: val[k][thread] (padded: the 16 lanes that read 16 different k of one chunk hit different banks),
-	// part[k][chunk]
+	// LDS of the reductions (18.5 KB: five workgroups to a CU).  Stage 1 goes through val[k - 8 half][thread], a half of the sums at a
+	// time (padded: the 16 lanes that read 16 different k of one chunk hit different banks); a chunk of 16 threads lies inside one
+	// wave, so only the wave that wrote an entry reads it - no workgroup barrier, LDS serves a wave's accesses in order.  Stage 2
+	// goes through part[call parity][k][chunk]: one barrier per call (the call after the next, which writes this parity again, is
+	// behind the next call's barrier).
 	struct EccReduceLds
 	{
-		double val[ECC_NSUMS][ECC_BLOCK + 1];
-		double part[ECC_NSUMS][ECC_BLOCK / 16 + 1];
+		double val[8][ECC_BLOCK + 1];
+		double part[2][ECC_NSUMS][ECC_BLOCK / 16 + 1];
 	};
+	__device__ __forceinline__ void ecc_wave_sync()
+	{ // orders the wave's own LDS writes and reads for the compiler (the hardware keeps a wave's LDS accesses in order)
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
 #ifdef RIR_ECC_DIAG
 	static __shared__ unsigned long long ecc_diag_loop_end, ecc_diag_reduced; // (written by every thread with about the same value)
 #endif
@@ -101,7 +110,7 @@ namespace rir
 	template <int R> // pixels per round: their 13 R loads are in flight together; the sums are taken in pixel order whatever R is
 	__device__ __forceinline__ double ecc_block_sums(const float *__restrict__ templ, const float *__restrict__ image, const float *__restrict__ gximg,
 													 const float *__restrict__ gyimg, const uint8_t *__restrict__ mask, int w, int h, float tx, float ty, int blk,
-													 int nblk, EccReduceLds &red)
+													 int nblk, EccReduceLds &red, int parity)
 	{
 		double s[ECC_NSUMS];
 #pragma unroll
@@ -202,23 +211,29 @@ namespace rir
 		ecc_diag_loop_end = __builtin_amdgcn_s_memrealtime();
 #endif
 		// Reduction over the workgroup through LDS, in a fixed order and without cross-lane operations (fifteen 64-bit butterflies of
-		// six ds_bpermute steps each took 3.3 us of a 14 us iteration): every thread leaves its 15 sums in lds[k][thread]; thread t
-		// then adds, for sum k = t % 16, the 16 threads of chunk c = t / 16 in order; thread k < 15 finally adds the chunks in order.
-		static_assert(ECC_BLOCK % 16 == 0 && ECC_NSUMS <= 16, "16 lanes per chunk, one per sum");
+		// six ds_bpermute steps each took 3.3 us of a 14 us iteration): every thread leaves its 15 sums in LDS; thread t then adds, for
+		// sum k = t % 16, the 16 threads of chunk c = t / 16 in order; thread k < 15 finally adds the chunks in order.
+		static_assert(ECC_BLOCK % 64 == 0 && ECC_NSUMS <= 16, "16 lanes per chunk, one per sum; a chunk inside one wave");
 		constexpr int NCH = ECC_BLOCK / 16;
-#pragma unroll
-		for (int k = 0; k < ECC_NSUMS; ++k)
-			red.val[k][threadIdx.x] = s[k];
-		__syncthreads();
 		{
 			const int k = threadIdx.x & 15, c = threadIdx.x >> 4;
-			if (k < ECC_NSUMS)
-			{
-				double a = 0.0;
 #pragma unroll
-				for (int j = 0; j < 16; ++j)
-					a += red.val[k][c * 16 + j];
-				red.part[k][c] = a;
+			for (int half = 0; half < 2; ++half)
+			{
+#pragma unroll
+				for (int kk = 0; kk < 8; ++kk)
+					if (half * 8 + kk < ECC_NSUMS)
+						red.val[kk][threadIdx.x] = s[half * 8 + kk];
+				ecc_wave_sync();
+				if ((k >> 3) == half && k < ECC_NSUMS)
+				{
+					double a = 0.0;
+#pragma unroll
+					for (int j = 0; j < 16; ++j)
+						a += red.val[k & 7][c * 16 + j];
+					red.part[parity][k][c] = a;
+				}
+				ecc_wave_sync();
 			}
 		}
 		__syncthreads();
@@ -229,7 +244,7 @@ namespace rir
 		if (threadIdx.x < ECC_NSUMS)
 #pragma unroll 4
 			for (int c = 0; c < NCH; ++c)
-				v += red.part[threadIdx.x][c];
+				v += red.part[parity][threadIdx.x][c];
 		return v;
 	}
 
@@ -241,7 +256,7 @@ namespace rir
 		if (state->done)
 			return;
 		__shared__ EccReduceLds red;
-		const double v = ecc_block_sums<RIR_ECC_PIXELS_PER_ROUND>(templ, image, gximg, gyimg, mask, w, h, state->tx, state->ty, blockIdx.x, gridDim.x, red);
+		const double v = ecc_block_sums<RIR_ECC_PIXELS_PER_ROUND>(templ, image, gximg, gyimg, mask, w, h, state->tx, state->ty, blockIdx.x, gridDim.x, red, 0);
 		if (threadIdx.x < ECC_NSUMS)
 			partials[(size_t)blockIdx.x * 16 + threadIdx.x] = v; // rows of 16 doubles (ecc_rows_total)
 	}
@@ -452,7 +467,7 @@ namespace rir
 			const unsigned long long dg0 = __builtin_amdgcn_s_memrealtime();
 			unsigned long long dg1 = 0, dg2 = 0, dg3 = 0;
 #endif
-			const double v = ecc_block_sums<RIR_ECC_PIXELS_PER_ROUND>(templ, image, gximg, gyimg, mask, w, h, tx, ty, b, nblk, red);
+			const double v = ecc_block_sums<RIR_ECC_PIXELS_PER_ROUND>(templ, image, gximg, gyimg, mask, w, h, tx, ty, b, nblk, red, it & 1);
 			// hand-off without fences (a release / acquire pair at agent scope writes back and invalidates whole caches: 227 us per
 			// frame against 139 with two launches per iteration) and without a drain: every sum travels as a granule {value, flag}
 			if (tid < ECC_NSUMS)
@@ -570,7 +585,7 @@ namespace rir
 		EccState st; // (slice 0, thread 0 keeps the real one)
 		st.tx = sq.tx0, st.ty = sq.ty0;
 		float tx = sq.tx0, ty = sq.ty0;
-		int done = 0, frames_done = 0;
+		int done = 0, frames_done = 0, red_calls = 0;
 		for (int f = 0; f < sq.nframes && done != 2; ++f, image += (size_t)w * h, gximg += (size_t)w * h, gyimg += (size_t)w * h)
 		{
 			st.rho = -1.0, st.last_rho = -eps;
@@ -593,7 +608,7 @@ namespace rir
 #ifdef RIR_ECC_DIAG
 					const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-					const double v = ecc_block_sums<RIR_ECC_MULTI_PIXELS_PER_ROUND>(sq.templ, image, gximg, gyimg, nullptr, w, h, tx, ty, b, V, red);
+					const double v = ecc_block_sums<RIR_ECC_MULTI_PIXELS_PER_ROUND>(sq.templ, image, gximg, gyimg, nullptr, w, h, tx, ty, b, V, red, (red_calls++) & 1);
 					if (tid < ECC_NSUMS)
 						ecc_granule_store(rows_rs, (uint32_t)b * 256u + (uint32_t)tid * 16u, (unsigned long long)__double_as_longlong(v), flag);
 #ifdef RIR_ECC_DIAG
