@@ -71,6 +71,7 @@ namespace rir
 	int ecc_rows(int w, int h);	  // rows of partial sums of an alignment of a w x h window (= workgroups of a solo run)
 	// d_ctl: two zero-initialised words (resident_device.h: arrivals, decision); arrivals_before: workgroups of the earlier launches on d_ctl.
 	// After the launch d_ctl[1] == (epoch & 0x3fffffff) << 2 | RESIDENT_GO, or | RESIDENT_BAIL: the launch did not become resident and has written nothing.
+	int ecc_run_multi_grid(int nseq, int nslices); // workgroups of such a launch: a service workgroup per sequence + nslices compute workgroups per pair
 	hipError_t launch_ecc_run_multi(EccSeq *d_table, int nseq, int nslices, int w, int h, int max_iter, double eps, unsigned int epoch, unsigned int *d_ctl,
 									unsigned int arrivals_before, hipStream_t st);
 	size_t ecc_run_workspace_bytes(int w, int h);

@@ -55,6 +55,7 @@ namespace rir
 	// loads - a granule is its own flag, nothing has to be drained or ordered (MI355X_MICROARCH.md: 16-byte sc1 granules observed
 	// untorn on gfx950).  The flag's top two bits are free for a payload of their own (ecc_run_kernel: `done`).
 	typedef unsigned int ecc_v4u __attribute__((ext_vector_type(4)));
+	typedef unsigned int ecc_v2u __attribute__((ext_vector_type(2)));
 	constexpr unsigned long long kEccFlagMask = 0x3fffffffffffffffull;
 	__device__ __forceinline__ __amdgpu_buffer_rsrc_t ecc_rsrc(const void *base, uint32_t bytes)
 	{
@@ -80,6 +81,12 @@ namespace rir
 		double val[8][ECC_BLOCK + 1];
 		double part[2][ECC_NSUMS][ECC_BLOCK / 16 + 1];
 	};
+	__device__ __forceinline__ void ecc_lds_barrier()
+	{ // a workgroup barrier that orders LDS only: loads from memory that are in flight stay in flight across it (__syncthreads() drains them)
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+		__builtin_amdgcn_s_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+	}
 	__device__ __forceinline__ void ecc_wave_sync()
 	{ // orders the wave's own LDS writes and reads for the compiler (the hardware keeps a wave's LDS accesses in order)
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -96,12 +103,12 @@ namespace rir
 #define RIR_ECC_MULTI_PIXELS_PER_ROUND 1 /* several sequences: latency is hidden by waves (RIR_ECC_MULTI_WAVES per SIMD), not by pixels in flight */
 #endif
 #ifndef RIR_ECC_MULTI_WAVES
-#define RIR_ECC_MULTI_WAVES 4 /* 128 VGPRs, no scratch: 4 workgroups per CU = 1 024 places, i.e. 8 sequences x 128 slices of exactly 2 rows: every
-                                 CU gets the same 8 rows.  8 sequences of 640x512, k frames/s aggregate (scripts/ecc_multi_variants.sh), with every place
-                                 of the device used (RIR_ECC_MULTI_MARGIN 0: this kernel checks its own residency and is repeated smaller when it
-                                 is not, resident_device.h): (1, 4) 70-75, (2, 4) 65-69, (3, 4) 62-66, (5, 3) 62-65; with the margin of the
-                                 residency rule (86 slices of 3 rows: CUs with 6 and CUs with 9 rows) (5, 3) 67-71, (1, 4) 65-68, (5, 2) 57-59.
-                                 The pixel loops are bound by the CU's memory pipeline (13 taps per pixel), the rest is how evenly the rows land */
+#define RIR_ECC_MULTI_WAVES 5 /* 96 VGPRs, 23 KB of LDS: five workgroups to a CU, 1 280 places - the 1 024 compute workgroups of 8 sequences (4 pairs x
+                                 256 slices of one row each: four to every CU, the dispatcher deals them evenly - scripts/ubench/wg_placement.hip) and
+                                 their 8 service workgroups.  (The first form of the kernel - no service workgroups, the adding done by each sequence's
+                                 slice 0 - at 128 VGPRs, 4 workgroups per CU, (pixels per round, waves per SIMD): (1, 4) 70-75 k frames/s over 8
+                                 sequences, (2, 4) 65-69, (3, 4) 62-66, (5, 3) 62-65.)  The pixel loop is bound by latency - 44 % of its L2 accesses miss:
+                                 a sequence's four arrays are 5.2 MB, an XCD's L2 4 MB (scripts/ecc_pmc.sh) - which more pixels per round did not hide */
 #endif
 #ifndef RIR_ECC_MULTI_MARGIN
 #define RIR_ECC_MULTI_MARGIN 0
@@ -150,22 +157,23 @@ namespace rir
 					   yb = (unsigned)(y0 + 1) < (unsigned)h;
 			constexpr uint32_t kOutside = 0xfffffff0u; // (beyond any image: bytes < 2^32 - 16)
 			const uint32_t lin = (uint32_t)(__mul24(y0, w) + x0) * 4u, w4 = (uint32_t)w * 4u; // (meaningful when the tap is inside: y0 < h < 2^23)
-			const uint32_t o00 = xa && ya ? lin : kOutside, o01 = xb && ya ? lin + 4u : kOutside, o10 = xa && yb ? lin + w4 : kOutside,
-						   o11 = xb && yb ? lin + w4 + 4u : kOutside;
-			auto blend = [&](__amdgpu_buffer_rsrc_t r) {
-				const float v00 = ld(r, o00), v01 = ld(r, o01), v10 = ld(r, o10), v11 = ld(r, o11);
-#ifndef RIR_ECC_NO_FMA /* fused: one rounding less per term (the file is built with -ffp-contract=off, so fusing is spelled out); RIR_ECC_NO_FMA for an A/B */
+			auto lerp2 = [&](float v00, float v01, float v10, float v11) {
+				// fused: one rounding less per term (the file is built with -ffp-contract=off, so fusing is spelled out)
 				const float top = __builtin_fmaf(fx, v01 - v00, v00), bot = __builtin_fmaf(fx, v11 - v10, v10);
 				return __builtin_fmaf(fy, bot - top, top);
-#else
-				const float top = v00 + fx * (v01 - v00), bot = v10 + fx * (v11 - v10);
-				return top + fy * (bot - top);
-#endif
 			};
 			Px p;
-			p.I = blend(r_img);
-			p.gx = blend(r_gx);
-			p.gy = blend(r_gy);
+			// (The two taps of an image row as ONE 8-byte load - 7 loads per pixel instead of 13, the lanes at the image's left and right edge
+			// fixed up afterwards - was measured: the loop took 5.4 us a row instead of 3.6.  8-byte loads at addresses that are only
+			// 4-byte aligned are not what the memory pipeline likes.)
+			{
+				const uint32_t o00 = xa && ya ? lin : kOutside, o01 = xb && ya ? lin + 4u : kOutside, o10 = xa && yb ? lin + w4 : kOutside,
+							   o11 = xb && yb ? lin + w4 + 4u : kOutside;
+				auto blend = [&](__amdgpu_buffer_rsrc_t r) { return lerp2(ld(r, o00), ld(r, o01), ld(r, o10), ld(r, o11)); };
+				p.I = blend(r_img);
+				p.gx = blend(r_gx);
+				p.gy = blend(r_gy);
+			}
 			p.T = ld(r_t, (uint32_t)i * 4u);
 			p.valid = valid;
 			return p;
@@ -174,15 +182,9 @@ namespace rir
 			const double I = p.I, gx = p.gx, gy = p.gy, T = p.T;
 			if (p.valid)
 			{
-#ifndef RIR_ECC_NO_FMA /* fused: one rounding less per term (the file is built with -ffp-contract=off, so fusing is spelled out); RIR_ECC_NO_FMA for an A/B */
 				s[0] += 1.0, s[1] += I, s[2] = __builtin_fma(I, I, s[2]), s[3] += T, s[4] = __builtin_fma(T, T, s[4]), s[5] = __builtin_fma(T, I, s[5]);
 				s[6] += gx, s[7] += gy, s[8] = __builtin_fma(gx, gx, s[8]), s[9] = __builtin_fma(gx, gy, s[9]), s[10] = __builtin_fma(gy, gy, s[10]);
 				s[11] = __builtin_fma(gx, I, s[11]), s[12] = __builtin_fma(gy, I, s[12]), s[13] = __builtin_fma(gx, T, s[13]), s[14] = __builtin_fma(gy, T, s[14]);
-#else
-				s[0] += 1.0, s[1] += I, s[2] += I * I, s[3] += T, s[4] += T * T, s[5] += T * I;
-				s[6] += gx, s[7] += gy, s[8] += gx * gx, s[9] += gx * gy, s[10] += gy * gy;
-				s[11] += gx * I, s[12] += gy * I, s[13] += gx * T, s[14] += gy * T;
-#endif
 			}
 		};
 		{
@@ -236,7 +238,7 @@ namespace rir
 				ecc_wave_sync();
 			}
 		}
-		__syncthreads();
+		ecc_lds_barrier();
 #ifdef RIR_ECC_DIAG
 		ecc_diag_reduced = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -551,17 +553,39 @@ namespace rir
 	// ---- S independent tracked sequences in ONE launch --------------------------------------------------------------------
 	//
 	// An alignment is a dependent chain (iteration after iteration, image after image): one sequence cannot use more of the chip
-	// than one iteration's pixels, and most of an iteration is latency - of the taps at one wave per SIMD and of two hand-offs
-	// between workgroups.  Independent sequences ("R1 ... replicas") are what can run side by side: sequence q =
-	// blockIdx % S owns the workgroups q, q + S, q + 2S, ... (S = 8: one XCD each - workgroup i starts on XCD i % 8 - so a
-	// sequence's four arrays stay in one L2), slice j = blockIdx / S of `nslices`.
+	// than one iteration's pixels, and between two iterations lie two hand-offs across the chip - the rows of partial sums to
+	// whoever adds them, the new translation back: 4-5 us in which the sequence's workgroups have nothing to do.  Independent
+	// sequences ("R1 ... replicas") are what can run side by side, and what can fill those gaps:
+	//   * sequences are taken in PAIRS (group g = sequences 2g, 2g + 1; the last group may hold one).  A group owns `nslices`
+	//     COMPUTE workgroups; each computes its rows of the first sequence, leaves them, computes its rows of the second one, and
+	//     only then needs the first one's new translation - which has travelled while it worked;
+	//   * every sequence has a SERVICE workgroup of its own (the last S workgroups of the launch) that computes no rows: it waits
+	//     for the sequence's rows, adds them, solves and publishes the translation - while the compute workgroups are busy with
+	//     the other sequence of the pair.  (With the adding done by a compute workgroup, as in the first form of this kernel, the
+	//     hand-off starts only when that workgroup's own rows are done: the interleaving then hides nothing.)
+	// With 8 sequences a pair's compute workgroups live on two XCDs (workgroup i starts on XCD i % 8), half of its rows in each.
 	//
 	// The arithmetic is that of ecc_run_kernel with V = ecc_blocks(w, h) workgroups, bit for bit, whatever S and nslices are: the
 	// pixels are cut into the same V "rows" (row b = what workgroup b of a solo run sums: pixels b * 256 + t + k * V * 256 of
 	// thread t, added in that order, reduced over the 256 threads in the same fixed order), a slice computes rows j, j + nslices,
-	// ... one after the other and leaves each as its row of granules, and the sequence's slice 0 adds the V rows in the order
+	// ... one after the other and leaves each as its row of granules, and the service workgroup adds the V rows in the order
 	// ecc_solve_kernel does.  Nothing crosses sequences; a sequence whose alignment fails stops, the others go on.
 	// rows: per sequence [V][16] granules, then its pub granule (ecc_run_workspace_bytes).
+	// wave-uniform values the compiler cannot see are uniform (read from LDS or through a table pointer): into scalar registers, so
+	// that the pixel loop keeps the vector registers
+	__device__ __forceinline__ int ecc_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+	__device__ __forceinline__ float ecc_uni(float v) { return __uint_as_float((unsigned int)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); }
+	template <class T>
+	__device__ __forceinline__ T *ecc_uni(T *p)
+	{
+		const uint64_t b = (uint64_t)p;
+		const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+		return (T *)(((uint64_t)hi << 32) | lo);
+	}
+	__device__ __forceinline__ unsigned long long ecc_flag(unsigned int epoch, int f, int it)
+	{
+		return ((unsigned long long)(epoch & 0x3fffffffu) << 32) | ((unsigned long long)(unsigned int)f << 20) | (unsigned long long)((unsigned int)it & 0xfffffu);
+	}
 	__attribute__((amdgpu_waves_per_eu(RIR_ECC_MULTI_WAVES, RIR_ECC_MULTI_WAVES))) __global__ __launch_bounds__(ECC_BLOCK) void ecc_run_multi_kernel(EccSeq *__restrict__ table, int S, int w, int h, int V, int max_iter, double eps,
 																	  unsigned int epoch, unsigned int *__restrict__ ctl, unsigned int arrivals_before)
 	{
@@ -575,124 +599,226 @@ namespace rir
 		// from fitting - everybody leaves before anything is written and the host runs the chunk again with fewer slices)
 		if (resident_rendezvous(ctl, arrivals_before, gridDim.x, epoch, &sh_flag) != RESIDENT_GO)
 			return;
-		// (sequences dealt ACROSS the XCDs instead - q = (blockIdx.x % S + slice) % S, so that a CU holds workgroups of four sequences in
-		// different phases - measured no faster, with 1, 2 or 3 pixels per round: a waiting sequence's share of the CU is not picked up)
-		const int q = blockIdx.x % S, slice = blockIdx.x / S, nslices = gridDim.x / S, tid = threadIdx.x;
-		const EccSeq sq = table[q];
-		const float *image = sq.image, *gximg = sq.gx, *gyimg = sq.gy;
-		unsigned long long *pub = reinterpret_cast<unsigned long long *>(sq.rows + (size_t)V * 32);
-		const __amdgpu_buffer_rsrc_t rows_rs = ecc_rsrc(sq.rows, (uint32_t)V * 256u), pub_rs = ecc_rsrc(pub, 16u);
-		EccState st; // (slice 0, thread 0 keeps the real one)
-		st.tx = sq.tx0, st.ty = sq.ty0;
-		float tx = sq.tx0, ty = sq.ty0;
-		int done = 0, frames_done = 0, red_calls = 0;
-		for (int f = 0; f < sq.nframes && done != 2; ++f, image += (size_t)w * h, gximg += (size_t)w * h, gyimg += (size_t)w * h)
-		{
-			st.rho = -1.0, st.last_rho = -eps;
-			st.iter = 0, st.done = 0, st.ticket = 0;
-			st.max_iter = max_iter, st.eps = eps;
-			done = 0;
-			for (int it = 1; !done; ++it)
+		const int tid = threadIdx.x;
+		const size_t npx = (size_t)w * h;
+		const int ncompute = (int)gridDim.x - S;
+		if ((int)blockIdx.x >= ncompute)
+		{ // ---- the service workgroup of sequence q: rows in, translation out, image after image ----
+			const int q = (int)blockIdx.x - ncompute;
+			__builtin_amdgcn_s_setprio(3); // (it shares its CU with four compute workgroups, and everybody waits for what it does)
+			const EccSeq sq = table[q];
+			unsigned long long *pub = reinterpret_cast<unsigned long long *>(sq.rows + (size_t)V * 32);
+			const __amdgpu_buffer_rsrc_t pub_rs = ecc_rsrc(pub, 16u);
+			EccState st; // (thread 0 keeps the real one)
+			st.tx = sq.tx0, st.ty = sq.ty0;
+			int done = 0, frames_done = 0;
+			for (int f = 0; f < sq.nframes && done != 2; ++f)
 			{
-				const unsigned long long flag =
-					((unsigned long long)(epoch & 0x3fffffffu) << 32) | ((unsigned long long)(unsigned int)f << 20) | (unsigned long long)((unsigned int)it & 0xfffffu);
-#ifdef RIR_ECC_DIAG
-				const unsigned long long dg0 = __builtin_amdgcn_s_memrealtime();
-				unsigned long long dg1 = 0, dg2 = 0;
-#endif
-#ifdef RIR_ECC_DIAG
-				unsigned long long dgl = 0, dgr = 0;
-#endif
-				for (int b = slice; b < V; b += nslices)
+				st.rho = -1.0, st.last_rho = -eps;
+				st.iter = 0, st.done = 0, st.ticket = 0;
+				st.max_iter = max_iter, st.eps = eps;
+				done = 0;
+				for (int it = 1; !done; ++it)
 				{
+					const unsigned long long flag = ecc_flag(epoch, f, it);
 #ifdef RIR_ECC_DIAG
-					const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+					const unsigned long long dg0 = __builtin_amdgcn_s_memrealtime();
 #endif
-					const double v = ecc_block_sums<RIR_ECC_MULTI_PIXELS_PER_ROUND>(sq.templ, image, gximg, gyimg, nullptr, w, h, tx, ty, b, V, red, (red_calls++) & 1);
-					if (tid < ECC_NSUMS)
-						ecc_granule_store(rows_rs, (uint32_t)b * 256u + (uint32_t)tid * 16u, (unsigned long long)__double_as_longlong(v), flag);
-#ifdef RIR_ECC_DIAG
-					dgl += ecc_diag_loop_end - r0, dgr += ecc_diag_reduced - ecc_diag_loop_end;
-#endif
-				}
-#ifdef RIR_ECC_DIAG
-				dg1 = __builtin_amdgcn_s_memrealtime();
-#endif
-				if (slice == 0)
-				{
+					// While the rows are being computed only a few of them are watched - every 16th, one granule each, by 16 lanes - and
+					// the whole set (61 KB of write-through granules per look) is asked for when those have come: the rows of a turn are
+					// finished within a microsecond of each other, and eight service workgroups that look at everything all the time
+					// are 0.3 TB/s of traffic past the L2s that the pixel loops feel.
+					if (tid < 16)
+					{
+						const __amdgpu_buffer_rsrc_t rs = ecc_rsrc(sq.rows, (uint32_t)V * 256u);
+						const uint32_t off = (uint32_t)min(tid * 16 + 15, V - 1) * 256u;
+						const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+						for (;;)
+						{
+							const ecc_v4u gr = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16 /* sc1 */);
+							const bool here = (((((unsigned long long)gr.w << 32) | gr.z) ^ flag) & kEccFlagMask) == 0;
+							if (__builtin_amdgcn_ballot_w64(!here) == 0 || __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull)
+								break; // (all 16 have come - or 2 s have passed: the full look below has a clock of its own)
+							__builtin_amdgcn_s_sleep(2);
+						}
+					}
+					__syncthreads();
 					const bool all_ok = ecc_rows_total<true>(sq.rows, V, flag, part, tot);
 #ifdef RIR_ECC_DIAG
-					dg2 = __builtin_amdgcn_s_memrealtime();
+					const unsigned long long dg1 = __builtin_amdgcn_s_memrealtime();
 #endif
 					if (tid == 0)
 					{
 						done = all_ok ? ecc_solve_step(tot, st) : 2;
-						sh_t[0] = st.tx, sh_t[1] = st.ty;
 						sh_done = done;
 						ecc_granule_store(pub_rs, 0, (unsigned long long)__float_as_uint(st.tx) | ((unsigned long long)__float_as_uint(st.ty) << 32),
 										  flag | ((unsigned long long)done << 62));
-					}
-				}
-				else if (tid == 0)
-				{
-					const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-					sh_done = 2;
-					for (;;)
-					{
-						const ecc_v4u g = __builtin_amdgcn_raw_buffer_load_b128(pub_rs, 0, 0, 16 /* sc1 */);
-						const unsigned long long fl = ((unsigned long long)g.w << 32) | g.z;
-						if (((fl ^ flag) & kEccFlagMask) == 0)
-						{
-							sh_t[0] = __uint_as_float(g.x), sh_t[1] = __uint_as_float(g.y);
-							sh_done = (int)(fl >> 62);
-							break;
-						}
-						__builtin_amdgcn_s_sleep(1);
-						if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) // 2 s of the 100 MHz clock
-							break;
-					}
-				}
-				__syncthreads();
-				tx = sh_t[0], ty = sh_t[1];
-				done = sh_done;
 #ifdef RIR_ECC_DIAG
-				if (q == 0 && tid == 0 && (slice == 0 || slice == nslices - 1))
-				{ // ticks (10 ns): rows | wait for the rows (slice 0) or for the decision (last slice) | add + solve + publish (slice 0)
-					const unsigned long long dg3 = __builtin_amdgcn_s_memrealtime();
-					unsigned long long *dg = pub + 8 + (slice == 0 ? 0 : 8);
-					dg[0] += dg1 - dg0, dg[1] += (slice == 0 ? dg2 : dg3) - dg1, dg[2] += slice == 0 ? dg3 - dg2 : 0, dg[3] += 1;
-					dg[4] += dgl, dg[5] += dgr;
-				}
+						if (q == 0)
+						{ // ticks (10 ns): waiting for + adding the rows | solve + publish
+							unsigned long long *dg = pub + 8;
+							dg[0] += dg1 - dg0, dg[1] += __builtin_amdgcn_s_memrealtime() - dg1, dg[2] += 1;
+						}
 #endif
-				__syncthreads(); // (red / tot / sh_* are reused by the next iteration)
+					}
+					__syncthreads();
+					done = sh_done;
+					__syncthreads(); // (part / tot / sh_done are reused by the next iteration)
+				}
+				if (tid == 0)
+				{
+					EccFrameResult r;
+					r.tx = st.tx, r.ty = st.ty, r.rho = st.rho, r.iter = st.iter, r.done = done;
+					sq.results[f] = r;
+				}
+				frames_done = f + 1;
 			}
-			if (slice == 0 && tid == 0)
-			{
-				EccFrameResult r;
-				r.tx = st.tx, r.ty = st.ty, r.rho = st.rho, r.iter = st.iter, r.done = done;
-				sq.results[f] = r;
-			}
-			frames_done = f + 1;
+			if (tid == 0)
+				table[q].frames_done = frames_done;
+			return;
 		}
-		if (slice == 0 && tid == 0)
-			table[q].frames_done = frames_done;
+		// ---- a compute workgroup of group g: its rows of the group's sequences in turn ----
+		constexpr int G = 2;
+		// group and slice of compute workgroup c (it starts on XCD c % 8).  A slice's rows are strips of 256 consecutive pixels, slices
+		// next to each other read image lines next to each other: where a group spreads over several XCDs (fewer than 8 groups) each
+		// XCD gets a run of consecutive slices, so that an L2 holds a band of the group's images instead of most of every image
+		const int NG = (S + G - 1) / G, c = (int)blockIdx.x, nslices = ncompute / NG;
+		int g = c % NG, slice = c / NG;
+		if (8 % NG == 0 && nslices % (8 / NG) == 0)
+		{
+			const int x = c & 7, m = c >> 3;
+			g = x % NG, slice = (x / NG) * (nslices / (8 / NG)) + m;
+		}
+		struct Turn
+		{
+			const float *templ, *image, *gx, *gy;
+			__amdgpu_buffer_rsrc_t rows_rs, pub_rs;
+			float tx, ty;
+			int f, it, nframes;
+			bool live, asked; // asked: rows of (f, it) are out, the decision on them has not been read yet
+		} tn[G];
+#pragma unroll
+		for (int j = 0; j < G; ++j)
+		{
+			const int q = g * G + j;
+			tn[j].live = q < S;
+			const EccSeq sq = table[tn[j].live ? q : g * G];
+			tn[j].templ = ecc_uni(sq.templ), tn[j].image = ecc_uni(sq.image), tn[j].gx = ecc_uni(sq.gx), tn[j].gy = ecc_uni(sq.gy);
+			tn[j].rows_rs = ecc_rsrc(sq.rows, (uint32_t)V * 256u);
+			tn[j].pub_rs = ecc_rsrc(reinterpret_cast<const unsigned long long *>(sq.rows + (size_t)V * 32), 16u);
+			tn[j].tx = ecc_uni(sq.tx0), tn[j].ty = ecc_uni(sq.ty0);
+			tn[j].f = 0, tn[j].it = 1, tn[j].nframes = ecc_uni(sq.nframes);
+			tn[j].live = tn[j].live && tn[j].nframes > 0;
+			tn[j].asked = false;
+		}
+		int red_calls = 0;
+		// (Asking for the decision a turn starts with already between the pixel loop and the reduction of the turn before - its answer
+		// kept in flight across the reduction's barrier - was tried: no faster; the decision is rarely there that early.)
+#ifdef RIR_ECC_DIAG
+		unsigned long long dg_rows = 0, dg_wait = 0, dg_n = 0, dg_loop = 0;
+#endif
+		for (bool any = true; any;)
+		{
+			any = false;
+#pragma unroll
+			for (int j = 0; j < G; ++j)
+			{
+				Turn &t = tn[j];
+				if (!t.live)
+					continue;
+				if (t.asked)
+				{ // the decision on the rows this workgroup left a turn ago
+#ifdef RIR_ECC_DIAG
+					const unsigned long long w0 = __builtin_amdgcn_s_memrealtime();
+#endif
+					const unsigned long long flag = ecc_flag(epoch, t.f, t.it);
+					if (tid == 0)
+					{
+						const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+						sh_done = 2;
+						for (;;)
+						{
+							const ecc_v4u gr = __builtin_amdgcn_raw_buffer_load_b128(t.pub_rs, 0, 0, 16 /* sc1 */);
+							const unsigned long long fl = ((unsigned long long)gr.w << 32) | gr.z;
+							if (((fl ^ flag) & kEccFlagMask) == 0)
+							{
+								sh_t[0] = __uint_as_float(gr.x), sh_t[1] = __uint_as_float(gr.y);
+								sh_done = (int)(fl >> 62);
+								break;
+							}
+							__builtin_amdgcn_s_sleep(1);
+							if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) // 2 s of the 100 MHz clock
+								break;
+						}
+					}
+					__syncthreads();
+					const int done = ecc_uni(sh_done);
+					if (done != 2)
+						t.tx = ecc_uni(sh_t[0]), t.ty = ecc_uni(sh_t[1]);
+					__syncthreads(); // (sh_* are reused by the next turn)
+#ifdef RIR_ECC_DIAG
+					dg_wait += __builtin_amdgcn_s_memrealtime() - w0;
+#endif
+					t.asked = false;
+					if (done == 0)
+						++t.it;
+					else if (done == 1)
+					{ // the image is aligned: the next one starts from its translation
+						++t.f, t.it = 1;
+						t.image += npx, t.gx += npx, t.gy += npx;
+					}
+					if (done == 2 || t.f >= t.nframes)
+					{
+						t.live = false;
+						continue;
+					}
+				}
+				any = true;
+#ifdef RIR_ECC_DIAG
+				const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+				const unsigned long long flag = ecc_flag(epoch, t.f, t.it);
+				for (int b = slice; b < V; b += nslices)
+				{
+					const double v = ecc_block_sums<RIR_ECC_MULTI_PIXELS_PER_ROUND>(t.templ, t.image, t.gx, t.gy, nullptr, w, h, t.tx, t.ty, b, V, red, (red_calls++) & 1);
+					if (tid < ECC_NSUMS)
+						ecc_granule_store(t.rows_rs, (uint32_t)b * 256u + (uint32_t)tid * 16u, (unsigned long long)__double_as_longlong(v), flag);
+#ifdef RIR_ECC_DIAG
+					dg_loop += ecc_diag_loop_end - r0; // (one row per turn: r0 is the row's start)
+#endif
+				}
+				t.asked = true;
+#ifdef RIR_ECC_DIAG
+				dg_rows += __builtin_amdgcn_s_memrealtime() - r0, dg_n += 1;
+#endif
+			}
+		}
+#ifdef RIR_ECC_DIAG
+		if (g == 0 && tid == 0 && (slice == 0 || slice == nslices - 1))
+		{ // ticks (10 ns), per turn: rows | waiting for a decision
+			unsigned long long *dg = reinterpret_cast<unsigned long long *>(table[0].rows + (size_t)V * 32) + 8 + (slice == 0 ? 4 : 8);
+			dg[0] += dg_rows, dg[1] += dg_wait, dg[2] += dg_n, dg[3] += dg_loop;
+		}
+#endif
 	}
 
 	int ecc_run_grid(int w, int h) { return ecc_blocks(w, h); }
 	int ecc_run_multi_capacity() { return resident_capacity(reinterpret_cast<const void *>(ecc_run_multi_kernel), ECC_BLOCK, 0, RIR_ECC_MULTI_MARGIN != 0); }
 	int ecc_rows(int w, int h) { return ecc_blocks(w, h); }
-	// d_table: nseq entries (device); nslices workgroups per sequence (1 .. ecc_rows(w, h)); nseq * nslices <= ecc_run_multi_capacity()
+	// d_table: nseq entries (device); nslices compute workgroups per PAIR of sequences (1 .. ecc_rows(w, h)), one service workgroup per
+	// sequence: ecc_run_multi_grid(nseq, nslices) <= ecc_run_multi_capacity()
+	int ecc_run_multi_grid(int nseq, int nslices) { return nseq + (nseq + 1) / 2 * nslices; }
 	hipError_t launch_ecc_run_multi(EccSeq *d_table, int nseq, int nslices, int w, int h, int max_iter, double eps, unsigned int epoch, unsigned int *d_ctl,
 									unsigned int arrivals_before, hipStream_t st)
 	{
 		const int V = ecc_blocks(w, h);
-		if (nseq <= 0 || nslices <= 0 || nslices > V || (long long)nseq * nslices > ecc_run_multi_capacity())
+		if (nseq <= 0 || nslices <= 0 || nslices > V || ecc_run_multi_grid(nseq, nslices) > ecc_run_multi_capacity())
 			return hipErrorInvalidConfiguration;
 		ResidentGate gate(st); // its workgroups wait for each other: not beside any other resident launch of the process
 		if (!gate.ok())
 			return hipErrorUnknown;
-		hipLaunchKernelGGL(ecc_run_multi_kernel, dim3((unsigned)(nseq * nslices)), dim3(ECC_BLOCK), 0, st, d_table, nseq, w, h, V, max_iter, eps, epoch, d_ctl,
-						   arrivals_before);
+		hipLaunchKernelGGL(ecc_run_multi_kernel, dim3((unsigned)ecc_run_multi_grid(nseq, nslices)), dim3(ECC_BLOCK), 0, st, d_table, nseq, w, h, V, max_iter, eps,
+						   epoch, d_ctl, arrivals_before);
 		return hipGetLastError();
 	}
 
@@ -822,8 +948,12 @@ namespace rir
 			part[2 * blockIdx.x + 1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
 		}
 	}
-	// Normalisation AND gradients of the normalised image in one pass (blockIdx.y = image): a pixel's neighbours are normalised again
-	// from the source - the same two float operations, the same values ecc_gradient_kernel would read back.
+	// Normalisation AND gradients of the normalised image in one pass (blockIdx.y = image): neighbours are normalised again from the
+	// source - the same two float operations, the same values ecc_gradient_kernel would read back.  A wave owns a tile of 64 columns x
+	// kGradRows rows, a lane one column of it: it normalises its kGradRows + 2 pixels once (1.25 divisions per pixel instead of 5 - the
+	// kernel was bound by them: 53 us for 32 images of 640x512), takes the vertical neighbours from its own registers and the
+	// horizontal ones from the lanes beside it; lanes at a tile's or the image's edge load theirs.
+	constexpr int kGradRows = 8;
 	__global__ __launch_bounds__(256) void minmax_apply_grad_frames_kernel(const float *__restrict__ src, int w, int h, int src_stride, int64_t src_frame,
 																		   const float *__restrict__ part, int nparts, float *__restrict__ dst, float *__restrict__ gxs,
 																		   float *__restrict__ gys)
@@ -831,8 +961,12 @@ namespace rir
 		src += (size_t)blockIdx.y * src_frame;
 		part += (size_t)blockIdx.y * 2 * nparts;
 		const size_t base = (size_t)blockIdx.y * w * h;
+		const int lane = threadIdx.x & 63, tiles_x = (w + 63) / 64, tiles_y = (h + kGradRows - 1) / kGradRows;
+		const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+		if (tile >= tiles_x * tiles_y)
+			return; // (whole waves)
 		float mn = 3.402823466e38f, mx = -3.402823466e38f;
-		for (int k = threadIdx.x & 63; k < nparts; k += 64)
+		for (int k = lane; k < nparts; k += 64)
 		{
 			mn = fminf(mn, part[2 * k]);
 			mx = fmaxf(mx, part[2 * k + 1]);
@@ -844,16 +978,37 @@ namespace rir
 			mx = fmaxf(mx, __shfl_xor(mx, d, 64));
 		}
 		const float range = mx - mn;
-		const int n = w * h;
 		auto norm = [&](int x, int y) { return (src[(int64_t)y * src_stride + x] - mn) / range; };
-		for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+		const int by = tile / tiles_x, bx = tile - by * tiles_x, x = bx * 64 + lane, y0 = by * kGradRows;
+		const int xc = min(x, w - 1);
+		// reflect-101 neighbours (w, h >= 2)
+		const int xl = xc > 0 ? xc - 1 : 1, xr = xc < w - 1 ? xc + 1 : w - 2;
+		const bool own_l = lane == 0 || xc == 0, own_r = lane == 63 || xc >= w - 1;
+		float c[kGradRows + 2]; // rows y0 - 1 .. y0 + kGradRows of this column
+#pragma unroll
+		for (int r = 0; r < kGradRows + 2; ++r)
 		{
-			const int y = i / w, x = i - y * w;
-			const int xl = x > 0 ? x - 1 : (w > 1 ? 1 : 0), xr = x < w - 1 ? x + 1 : (w > 1 ? w - 2 : 0);
-			const int yu = y > 0 ? y - 1 : (h > 1 ? 1 : 0), yd = y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0);
-			dst[base + i] = norm(x, y);
-			gxs[base + i] = 0.5f * norm(xr, y) - 0.5f * norm(xl, y);
-			gys[base + i] = 0.5f * norm(x, yd) - 0.5f * norm(x, yu);
+			const int yy = y0 - 1 + r;
+			c[r] = norm(xc, yy < 0 ? 1 : (yy < h ? yy : (yy == h ? h - 2 : h - 1)));
+		}
+#pragma unroll
+		for (int r = 1; r <= kGradRows; ++r)
+		{
+			const int y = y0 + r - 1;
+			if (y >= h)
+				break; // (uniform)
+			float l = __shfl_up(c[r], 1, 64), rr = __shfl_down(c[r], 1, 64);
+			if (own_l)
+				l = norm(xl, y);
+			if (own_r)
+				rr = norm(xr, y);
+			if (x < w)
+			{
+				const size_t o = base + (size_t)y * w + x;
+				dst[o] = c[r];
+				gxs[o] = 0.5f * rr - 0.5f * l;
+				gys[o] = 0.5f * c[r + 1] - 0.5f * c[r - 1];
+			}
 		}
 	}
 	hipError_t launch_minmax_normalize_grad_frames(const float *d_src, int w, int h, int src_stride, int64_t src_frame, int nframes, float *d_dst, float *d_gx,
@@ -861,8 +1016,9 @@ namespace rir
 	{
 		const int nparts = nframes == 1 ? kMinMaxParts : kMinMaxPartsFrames;
 		hipLaunchKernelGGL(minmax_partial_frames_kernel, dim3(nparts, nframes), dim3(256), 0, st, d_src, w, h, src_stride, src_frame, d_part);
-		hipLaunchKernelGGL(minmax_apply_grad_frames_kernel, dim3((w * h + 255) / 256 < 1024 ? (w * h + 255) / 256 : 1024, nframes), dim3(256), 0, st, d_src, w, h,
-						   src_stride, src_frame, d_part, nparts, d_dst, d_gx, d_gy);
+		const int tiles = ((w + 63) / 64) * ((h + kGradRows - 1) / kGradRows);
+		hipLaunchKernelGGL(minmax_apply_grad_frames_kernel, dim3((tiles + 3) / 4, nframes), dim3(256), 0, st, d_src, w, h, src_stride, src_frame, d_part, nparts,
+						   d_dst, d_gx, d_gy);
 		return hipGetLastError();
 	}
 

@@ -589,11 +589,25 @@ RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const 
 		return -1;
 	unsigned int *d_ctl = sc.multi_ctl.as<unsigned int>();
 	std::vector<int> solo; // sequences that go through the single-sequence path in the end
-	const ResidentPlan plan = resident_plan(cap, 1, nseq);
-	for (int q0 = 0; q0 < nseq; q0 += plan.units_per_launch)
+	char *hb = sc.multi_back.as<char>();
+	auto read_back = [&]() { // the table (images gone through) and the per-image results, queued behind what has been launched
+		return hip_ok(hipMemcpyAsync(hb, sc.multi_table.ptr, (size_t)nseq * sizeof(EccSeq), hipMemcpyDeviceToHost, st), "D2H") &&
+			   (!total_frames || hip_ok(hipMemcpyAsync(hb + (size_t)nseq * sizeof(EccSeq), sc.multi_results.ptr, total_frames * sizeof(EccFrameResult),
+													   hipMemcpyDeviceToHost, st),
+										"D2H"));
+	};
+	bool back_fresh = false;
+	// (a launch holds sequences in pairs: two service workgroups and at least one compute workgroup per pair)
+	const ResidentPlan plan = resident_plan(cap, 3, (nseq + 1) / 2);
+	if (plan.units_per_launch < 1)
+	{ // (a device that holds fewer than three such workgroups)
+		for (int q = 0; q < nseq; ++q)
+			solo.push_back(q);
+	}
+	for (int q0 = 0; plan.units_per_launch >= 1 && q0 < nseq; q0 += 2 * plan.units_per_launch)
 	{
-		const int nl = std::min(plan.units_per_launch, nseq - q0);
-		int nslices = std::max(1, std::min(V, cap / nl));
+		const int nl = std::min(2 * plan.units_per_launch, nseq - q0), groups = (nl + 1) / 2;
+		int nslices = std::max(1, std::min(V, (cap - nl) / groups));
 		if (env_slices > 0)
 			nslices = std::max(1, std::min(nslices, env_slices));
 		for (int attempt = 0;; ++attempt)
@@ -601,7 +615,7 @@ RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const 
 			// (a slice's time is that of its rows, one after the other: no more slices than give every slice the same largest number of rows)
 			const int rows_per_slice = (V + nslices - 1) / nslices;
 			nslices = (V + rows_per_slice - 1) / rows_per_slice;
-			const unsigned int epoch = ++sc.epoch, total = (unsigned int)(nl * nslices);
+			const unsigned int epoch = ++sc.epoch, total = (unsigned int)ecc_run_multi_grid(nl, nslices);
 			if (debug_bail && attempt == 0)
 			{ // the launch is called off by hand: the decision word says BAIL before anybody arrives
 				const unsigned int w_ = ((epoch & 0x3fffffffu) << 2) | 2u;
@@ -613,12 +627,17 @@ RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const 
 				return -1;
 			sc.multi_arrivals += total;
 			unsigned int decision = 0;
-			if (!hip_ok(hipMemcpyAsync(&decision, d_ctl + 1, 4, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
+			// (behind the last launch the results come back with the decision: one wait instead of two)
+			const bool last = q0 + 2 * plan.units_per_launch >= nseq;
+			if (!hip_ok(hipMemcpyAsync(&decision, d_ctl + 1, 4, hipMemcpyDeviceToHost, st), "D2H") || (last && !read_back()) || !hip_ok(wait_stream(st), "sync"))
 				return -1;
 			if (decision == (((epoch & 0x3fffffffu) << 2) | 1u))
-				break; // resident: the chunk is aligned
+			{ // resident: the chunk is aligned
+				back_fresh = last;
+				break;
+			}
 			if (nslices == 1)
-			{ // not even one workgroup per sequence fits beside what else is running: sequence by sequence
+			{ // not even one compute workgroup per pair fits beside what else is running: sequence by sequence
 				for (int q = q0; q < q0 + nl; ++q)
 					solo.push_back(q);
 				break;
@@ -626,20 +645,15 @@ RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const 
 			nslices = std::max(1, nslices / 2);
 		}
 	}
-	char *hb = sc.multi_back.as<char>();
-	if (!hip_ok(hipMemcpyAsync(hb, sc.multi_table.ptr, (size_t)nseq * sizeof(EccSeq), hipMemcpyDeviceToHost, st), "D2H") ||
-		(total_frames && !hip_ok(hipMemcpyAsync(hb + (size_t)nseq * sizeof(EccSeq), sc.multi_results.ptr, total_frames * sizeof(EccFrameResult),
-												hipMemcpyDeviceToHost, st),
-								 "D2H")) ||
-		!hip_ok(wait_stream(st), "sync"))
+	if (!back_fresh && (!read_back() || !hip_ok(wait_stream(st), "sync")))
 		return -1;
 	static const bool diag = getenv("RIR_ECC_DIAG") != nullptr; // (-DRIR_ECC_DIAG builds: where an iteration's time goes, sequence 0)
 	if (diag)
 	{
 		unsigned long long dg[16];
-		if (hipMemcpy(dg, sc.multi_rows.as<char>() + (size_t)V * 256 + 64, sizeof(dg), hipMemcpyDeviceToHost) == hipSuccess && dg[3])
-			std::fprintf(stderr, "ecc multi, per iteration (us), sequence 0: slice 0: rows %.2f (pixel loops %.2f, reductions %.2f)  wait rows %.2f  add+solve+publish %.2f | last slice: rows %.2f  wait %.2f  (%llu iterations so far, %d sequences)\n",
-						 dg[0] * 0.01 / dg[3], dg[4] * 0.01 / dg[3], dg[5] * 0.01 / dg[3], dg[1] * 0.01 / dg[3], dg[2] * 0.01 / dg[3], dg[8] * 0.01 / dg[11], dg[9] * 0.01 / dg[11], dg[3], nseq);
+		if (hipMemcpy(dg, sc.multi_rows.as<char>() + (size_t)V * 256 + 64, sizeof(dg), hipMemcpyDeviceToHost) == hipSuccess && dg[2] && dg[6] && dg[10])
+			std::fprintf(stderr, "ecc multi (us), sequence 0's service workgroup, per iteration: waiting for + adding the rows %.2f  solve + publish %.2f | group 0, per turn: slice 0: rows %.2f (pixel loop of the first row %.2f)  waiting for the decision %.2f | last slice: rows %.2f (%.2f)  waiting %.2f  (%llu iterations so far, %d sequences)\n",
+						 dg[0] * 0.01 / dg[2], dg[1] * 0.01 / dg[2], dg[4] * 0.01 / dg[6], dg[7] * 0.01 / dg[6], dg[5] * 0.01 / dg[6], dg[8] * 0.01 / dg[10], dg[11] * 0.01 / dg[10], dg[9] * 0.01 / dg[10], dg[2], nseq);
 	}
 	const EccSeq *back = reinterpret_cast<const EccSeq *>(hb);
 	const EccFrameResult *r = reinterpret_cast<const EccFrameResult *>(hb + (size_t)nseq * sizeof(EccSeq));

@@ -203,7 +203,7 @@ class DeviceRegistratorECC:
         return shifts
 
     @staticmethod
-    def compute_many_multi(registrators, frames, chunk=32):
+    def compute_many_multi(registrators, frames, chunk=64):
         """``compute_many`` for S independent sequences at once - ``registrators[q]`` (each started on its own reference image, all
         with one window size) tracks ``frames[q]`` (n, h, w) - with the alignments of a chunk of ALL sequences in one resident
         launch (rir_ecc_align_multi_device): an alignment is a chain of dependent iterations that cannot fill the chip, S chains
