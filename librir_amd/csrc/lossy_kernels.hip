@@ -1129,6 +1129,8 @@ namespace rir
 			// took 5.8 us instead of 2) and hands the decision on in one word; the others poll that word - one more hop, 1/nb of the traffic.
 			const bool collect = !rp.leader || b == 0;
 			long long acc[6] = {0, 0, 0, 0, 0, 0};
+			if (rp.leader && b == 0)
+				__builtin_amdgcn_s_setprio(3); // (the whole stream waits for what this workgroup does next, and it shares its CU with four others: 7 streams 561 -> 579 k frames/s)
 			if (collect)
 				for (int p = tid; p < nb; p += kLossyRunThreads)
 				{
@@ -1225,6 +1227,8 @@ namespace rir
 #ifdef RIR_LOSSY_DIAG
 			dg3 = __builtin_amdgcn_s_memrealtime();
 #endif
+			if (rp.leader && b == 0)
+				__builtin_amdgcn_s_setprio(0);
 			__syncthreads(); // (also keeps the other waves off red / red2 until wave 0 has read them)
 			// 3. update
 			const bool full_ring = ra > 0 && count == ra;
@@ -1417,7 +1421,12 @@ namespace rir
 	}
 
 	// workgroups of lossy_run_kernel the current device holds at once (runtime.h: occupancy x CUs, less the margin; 0 = unknown)
-	int lossy_run_capacity() { return resident_capacity(reinterpret_cast<const void *>(lossy_run_kernel), kLossyRunThreads, 0); }
+#ifndef RIR_LOSSY_RUN_MARGIN
+#define RIR_LOSSY_RUN_MARGIN 1 /* 0: every place of the device - 8 streams of 640x512 per launch instead of 7, 617 k frames/s instead of 577 k; not shipped: a launch
+                                  that fills the chip to the last place is called off whenever anything else is resident, and a loss run that is called off
+                                  goes on frame by frame - or, for queue-only calls, fails the stream */
+#endif
+	int lossy_run_capacity() { return resident_capacity(reinterpret_cast<const void *>(lossy_run_kernel), kLossyRunThreads, 0, RIR_LOSSY_RUN_MARGIN != 0); }
 	hipError_t launch_lossy_run(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ticket, unsigned int epoch, unsigned int arrivals_before, hipStream_t st)
 	{
 		const int nb = lossy_run_workgroups(full);
