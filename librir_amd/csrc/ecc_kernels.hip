@@ -924,13 +924,16 @@ namespace rir
 		src += (size_t)blockIdx.y * src_frame;
 		part += (size_t)blockIdx.y * 2 * gridDim.x;
 		float mn = 3.402823466e38f, mx = -3.402823466e38f;
-		const int n = w * h;
-		for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+		// part p takes the rows p, p + parts, ...: no division per pixel (min and max do not care how the pixels are dealt)
+		for (int y = blockIdx.x; y < h; y += gridDim.x)
 		{
-			const int y = i / w, x = i - y * w;
-			const float v = src[(int64_t)y * src_stride + x];
-			mn = fminf(mn, v);
-			mx = fmaxf(mx, v);
+			const float *row = src + (int64_t)y * src_stride;
+			for (int x = threadIdx.x; x < w; x += 256)
+			{
+				const float v = row[x];
+				mn = fminf(mn, v);
+				mx = fmaxf(mx, v);
+			}
 		}
 #pragma unroll
 		for (int d = 32; d >= 1; d >>= 1)
