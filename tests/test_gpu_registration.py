@@ -281,3 +281,59 @@ def test_sequences_side_by_side_equal_their_own_tracks(S, chunk):
     if S > 1:
         assert solo[1].conf_thresh is not None and min(solo[1].confidences[21:]) < solo[1].conf_thresh  # the reference of sequence 1 did change
         assert solo[0].x != solo[2].x  # (the sequences are different data)
+
+
+def test_side_by_side_with_ragged_lengths_an_empty_and_a_failing_sequence():
+    """rir_ecc_align_multi_device through the C ABI with what compute_many_multi never gives it: sequences of different lengths, one
+    without images, an odd number of sequences (the last pair holds one), and one whose third image is NaN - it stops there (good = 2),
+    its pair partner and everybody else go on; every sequence's results equal those of rir_ecc_align_prepared_frames_device on its own."""
+    import ctypes as ct
+
+    import torch
+
+    from librir_amd.registration import DeviceRegistratorECC
+    from librir_amd.registration import device_registration as DR
+
+    h, w = 192, 256
+    lengths = [9, 4, 0, 7, 1]
+    S = len(lengths)
+    st = DR._stream()
+    regs, norms = [], []
+    for q in range(S):
+        f, _ = s3_registration(max(lengths[q], 1) + 1, h, w, seed=300 + q)
+        f = f.copy()
+        if q == 3:
+            f[3][:] = np.nan  # (image 2 of the frames handed to the alignment)
+        t = torch.from_numpy(f).cuda()
+        r = DeviceRegistratorECC(1, 1, shape=(h, w))
+        r.start(t[0])
+        buf = torch.zeros((3, max(lengths[q], 1), r.subH, r.subW), dtype=torch.float32, device="cuda")
+        if lengths[q]:
+            r._prepare(t, 1, lengths[q], buf, st)
+        regs.append(r)
+        norms.append(buf)
+    torch.cuda.synchronize()
+    stride = max(lengths)
+    ptr = lambda ts: (ct.c_void_p * S)(*[x.data_ptr() for x in ts])  # noqa: E731
+    res = np.full((S, stride, 4), -7.0, np.float64)
+    warps = np.zeros((S, 2), np.float32)
+    counts = (ct.c_int * S)(*lengths)
+    good = (ct.c_int * S)()
+    r0 = regs[0]
+    assert DR._lib.rir_ecc_align_multi_device(ptr([r._ref_n for r in regs]), ptr([b[0] for b in norms]), ptr([b[1] for b in norms]),
+                                             ptr([b[2] for b in norms]), r0.subW, r0.subH, S, counts, warps.ctypes.data, r0.number_of_iterations,
+                                             r0.termination_eps, res.ctypes.data, stride, good, st) == 0
+    assert list(good) == [9, 4, 0, 2, 1]
+    for q in range(S):
+        if not lengths[q]:
+            continue
+        own = np.full((lengths[q], 4), -7.0, np.float64)
+        regs[q].warp[:] = 0
+        g = DR._lib.rir_ecc_align_prepared_frames_device(regs[q]._ref_n.data_ptr(), norms[q][0].data_ptr(), norms[q][1].data_ptr(), norms[q][2].data_ptr(),
+                                                         r0.subW, r0.subH, lengths[q], regs[q].warp.ctypes.data, r0.number_of_iterations, r0.termination_eps,
+                                                         own.ctypes.data, st)
+        assert g == good[q], q
+        assert np.array_equal(own[:g], res[q, :g]), q
+        assert np.all(res[q, g:] == -7.0)  # (nothing is written behind the last good image)
+        if g:
+            assert warps[q, 0] == np.float32(own[g - 1, 0]) and warps[q, 1] == np.float32(own[g - 1, 1])
