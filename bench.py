@@ -45,8 +45,8 @@ XGMI_IN_GBS = 7 * 76.8  # 7 links x 153.6 GB/s bidirectional = 76.8 GB/s inbound
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=200)  # (0.27 ms each: a timed region of ~55 ms; 20 steps were 6 ms - shorter than a utilisation sampler's period)
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--frames", type=int, default=1000)
     p.add_argument("--width", type=int, default=640)
     p.add_argument("--height", type=int, default=512)

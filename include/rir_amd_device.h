@@ -251,6 +251,22 @@ extern "C"
 	int rir_ecc_align_multi_device(const float *const *d_ref_norm, const float *const *d_norm, const float *const *d_gx, const float *const *d_gy, int w,
 								   int h, int nseq, const int *nframes, float *warps, int max_iterations, double eps, double *results, int results_stride,
 								   int *good, void *stream);
+	/* The same with the pre-processing of what comes next UNDER the alignments: `next` = nnext jobs, each the arguments of one
+	 * rir_ecc_prepare_frames_device call (normally the next chunk of every sequence).  The alignment launch needs the whole device to
+	 * start, but once it is resident a fifth of every CU's places and most of the memory system are free: the library waits for the
+	 * launch to report that and then runs the jobs on a stream of its own beside it; the caller's stream is ordered behind them when
+	 * the call returns.  The jobs' outputs must not be buffers this call's alignments read. */
+	typedef struct rir_ecc_prepare_job
+	{
+		const void *d_imgs;
+		int dtype, w, h, nframes;
+		float sigma;
+		int win_x, win_y, win_w, win_h;
+		float *d_norm, *d_gx, *d_gy;
+	} rir_ecc_prepare_job;
+	int rir_ecc_align_multi_overlapped_device(const float *const *d_ref_norm, const float *const *d_norm, const float *const *d_gx, const float *const *d_gy,
+											  int w, int h, int nseq, const int *nframes, float *warps, int max_iterations, double eps, double *results,
+											  int results_stride, int *good, const rir_ecc_prepare_job *next, int nnext, void *stream);
 	/* One frame of a tracked sequence in one call - the steps of MaskedRegistratorECC.compute (masked_registration_ecc.py:88-168):
 	 * gaussian pre-filter (sigma > 0), min-max normalisation of the registration window and the alignment against the
 	 * already normalised reference window d_ref_norm [win_h][win_w], queued back to back with one read-back at the end.

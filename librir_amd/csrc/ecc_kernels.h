@@ -72,8 +72,10 @@ namespace rir
 	// d_ctl: two zero-initialised words (resident_device.h: arrivals, decision); arrivals_before: workgroups of the earlier launches on d_ctl.
 	// After the launch d_ctl[1] == (epoch & 0x3fffffff) << 2 | RESIDENT_GO, or | RESIDENT_BAIL: the launch did not become resident and has written nothing.
 	int ecc_run_multi_grid(int nseq, int nslices); // workgroups of such a launch: a service workgroup per sequence + nslices compute workgroups per pair
+	// host_go: NULL, or a word of coherent page-locked host memory that receives `epoch` once the launch is resident (from then on
+	// other kernels may be started beside it)
 	hipError_t launch_ecc_run_multi(EccSeq *d_table, int nseq, int nslices, int w, int h, int max_iter, double eps, unsigned int epoch, unsigned int *d_ctl,
-									unsigned int arrivals_before, hipStream_t st);
+									unsigned int arrivals_before, unsigned int *host_go, hipStream_t st);
 	size_t ecc_run_workspace_bytes(int w, int h);
 	int ecc_run_capacity();			  // resident workgroups of ecc_run_kernel on the current device (runtime.h), 0 = unknown
 	bool ecc_run_fits(int w, int h);  // the grid of an alignment of a w x h window fits: the one-launch forms may be used

@@ -587,7 +587,8 @@ namespace rir
 		return ((unsigned long long)(epoch & 0x3fffffffu) << 32) | ((unsigned long long)(unsigned int)f << 20) | (unsigned long long)((unsigned int)it & 0xfffffu);
 	}
 	__attribute__((amdgpu_waves_per_eu(RIR_ECC_MULTI_WAVES, RIR_ECC_MULTI_WAVES))) __global__ __launch_bounds__(ECC_BLOCK) void ecc_run_multi_kernel(EccSeq *__restrict__ table, int S, int w, int h, int V, int max_iter, double eps,
-																	  unsigned int epoch, unsigned int *__restrict__ ctl, unsigned int arrivals_before)
+																	  unsigned int epoch, unsigned int *__restrict__ ctl, unsigned int arrivals_before,
+																	  unsigned int *host_go)
 	{
 		__shared__ EccReduceLds red;
 		__shared__ double part[ECC_NSUMS][17];
@@ -600,6 +601,10 @@ namespace rir
 		if (resident_rendezvous(ctl, arrivals_before, gridDim.x, epoch, &sh_flag) != RESIDENT_GO)
 			return;
 		const int tid = threadIdx.x;
+		// "the launch is resident", for the host (a word of coherent page-locked memory): from here on other kernels may be started
+		// beside it - they can no longer keep it from fitting - and the host uses the time for the pre-processing of the next chunk
+		if (host_go && blockIdx.x == 0 && tid == 0)
+			__hip_atomic_store(host_go, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		const size_t npx = (size_t)w * h;
 		const int ncompute = (int)gridDim.x - S;
 		if ((int)blockIdx.x >= ncompute)
@@ -809,7 +814,7 @@ namespace rir
 	// sequence: ecc_run_multi_grid(nseq, nslices) <= ecc_run_multi_capacity()
 	int ecc_run_multi_grid(int nseq, int nslices) { return nseq + (nseq + 1) / 2 * nslices; }
 	hipError_t launch_ecc_run_multi(EccSeq *d_table, int nseq, int nslices, int w, int h, int max_iter, double eps, unsigned int epoch, unsigned int *d_ctl,
-									unsigned int arrivals_before, hipStream_t st)
+									unsigned int arrivals_before, unsigned int *host_go, hipStream_t st)
 	{
 		const int V = ecc_blocks(w, h);
 		if (nseq <= 0 || nslices <= 0 || nslices > V || ecc_run_multi_grid(nseq, nslices) > ecc_run_multi_capacity())
@@ -818,7 +823,7 @@ namespace rir
 		if (!gate.ok())
 			return hipErrorUnknown;
 		hipLaunchKernelGGL(ecc_run_multi_kernel, dim3((unsigned)ecc_run_multi_grid(nseq, nslices)), dim3(ECC_BLOCK), 0, st, d_table, nseq, w, h, V, max_iter, eps,
-						   epoch, d_ctl, arrivals_before);
+						   epoch, d_ctl, arrivals_before, host_go);
 		return hipGetLastError();
 	}
 

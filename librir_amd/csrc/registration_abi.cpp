@@ -40,6 +40,9 @@ namespace
 		DeviceBuffer multi_rows, multi_results, multi_table, multi_ctl;
 		PinnedBuffer multi_stage, multi_back;
 		unsigned int multi_arrivals = 0; // workgroups launched on multi_ctl so far (resident_device.h)
+		unsigned int *multi_go = nullptr; // coherent page-locked host word: "the multi-sequence launch is resident" (its epoch)
+		hipStream_t side = nullptr;		  // the stream of the pre-processing that runs beside a resident launch
+		hipEvent_t side_in = nullptr, side_out = nullptr;
 		DeviceBuffer run_ctl;			 // the same for the single-sequence launches
 		unsigned int run_arrivals = 0;
 		unsigned int *ctl_of_runs(hipStream_t st)
@@ -328,18 +331,30 @@ RIR_EXPORT int rir_ecc_register_frame_device(const void *d_img, int dtype, int w
 // sequential: each starts from the previous result): gaussian pre-filter (sigma > 0), crop to the registration window, min-max
 // normalisation, gradients - image by image the operations of rir_ecc_register_frame_device.  d_imgs: uint16 ('H') or float32
 // ('f') [nframes][h][w]; d_norm, d_gx, d_gy: float [nframes][win_h][win_w] (device).
+static bool prepare_args_ok(const void *d_imgs, int dtype, int w, int h, int nframes, int win_x, int win_y, int win_w, int win_h, const float *d_norm,
+							const float *d_gx, const float *d_gy)
+{
+	return d_imgs && (dtype == 'H' || dtype == 'f') && d_norm && d_gx && d_gy && w >= 2 && h >= 2 && nframes > 0 && win_x >= 0 && win_y >= 0 && win_w >= 2 &&
+		   win_h >= 2 && win_x + win_w <= w && win_y + win_h <= h;
+}
+static int prepare_frames_on(const void *d_imgs, int dtype, int w, int h, int nframes, float sigma, int win_x, int win_y, int win_w, int win_h, float *d_norm,
+							 float *d_gx, float *d_gy, hipStream_t st);
 RIR_EXPORT int rir_ecc_prepare_frames_device(const void *d_imgs, int dtype, int w, int h, int nframes, float sigma, int win_x, int win_y, int win_w,
 											 int win_h, float *d_norm, float *d_gx, float *d_gy, void *stream)
 {
 	if (!device_ready())
 		return -1;
-	if (!d_imgs || (dtype != 'H' && dtype != 'f') || !d_norm || !d_gx || !d_gy || w < 2 || h < 2 || nframes <= 0 || win_x < 0 || win_y < 0 || win_w < 2 ||
-		win_h < 2 || win_x + win_w > w || win_y + win_h > h)
+	if (!prepare_args_ok(d_imgs, dtype, w, h, nframes, win_x, win_y, win_w, win_h, d_norm, d_gx, d_gy))
 	{
 		log_error("rir_ecc_prepare_frames_device: invalid argument");
 		return -1;
 	}
-	hipStream_t st = (hipStream_t)stream;
+	return prepare_frames_on(d_imgs, dtype, w, h, nframes, sigma, win_x, win_y, win_w, win_h, d_norm, d_gx, d_gy, (hipStream_t)stream);
+}
+static int prepare_frames_on(const void *d_imgs, int dtype, int w, int h, int nframes, float sigma, int win_x, int win_y, int win_w, int win_h, float *d_norm,
+							 float *d_gx, float *d_gy, hipStream_t st)
+{
+	void *stream = (void *)st;
 	PrepScratch &sc = prep_scratch();
 	std::lock_guard<std::mutex> lock(sc.mu);
 	// (stream order among the calls that share this scratch: wait for the previous call's last launch, leave an event behind this one's)
@@ -520,8 +535,36 @@ RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const 
 										  int h, int nseq, const int *nframes, float *warps, int max_iterations, double eps, double *results, int results_stride,
 										  int *good, void *stream)
 {
+	return rir_ecc_align_multi_overlapped_device(d_ref_norm, d_norm, d_gx, d_gy, w, h, nseq, nframes, warps, max_iterations, eps, results, results_stride, good,
+												 nullptr, 0, stream);
+}
+
+// The same, and UNDER the alignments the pre-processing of what comes next (`next`: nnext jobs, each the arguments of one
+// rir_ecc_prepare_frames_device call - normally the next chunk of every sequence): the alignment launch needs the whole chip to
+// START (every workgroup resident: other kernels beside it then can keep the last ones from fitting), but once it
+// reports that it is resident it leaves a fifth of every CU's places and most of the memory system unused - so the library waits
+// for that report (a word of host memory the kernel writes) and then runs the jobs on a stream of its own beside it.  The
+// caller's stream is ordered behind them when the call returns.  Results and errors as rir_ecc_align_multi_device; the jobs'
+// outputs must not be what this call's alignments read.
+RIR_EXPORT int rir_ecc_align_multi_overlapped_device(const float *const *d_ref_norm, const float *const *d_norm, const float *const *d_gx,
+													 const float *const *d_gy, int w, int h, int nseq, const int *nframes, float *warps, int max_iterations,
+													 double eps, double *results, int results_stride, int *good, const rir_ecc_prepare_job *next, int nnext,
+													 void *stream)
+{
 	if (!device_ready())
 		return -1;
+	if (nnext < 0 || (nnext > 0 && !next))
+	{
+		log_error("rir_ecc_align_multi_overlapped_device: invalid argument");
+		return -1;
+	}
+	for (int j = 0; j < nnext; ++j)
+		if (!prepare_args_ok(next[j].d_imgs, next[j].dtype, next[j].w, next[j].h, next[j].nframes, next[j].win_x, next[j].win_y, next[j].win_w, next[j].win_h,
+							 next[j].d_norm, next[j].d_gx, next[j].d_gy))
+		{
+			log_error("rir_ecc_align_multi_overlapped_device: invalid pre-processing job");
+			return -1;
+		}
 	bool bad = !d_ref_norm || !d_norm || !d_gx || !d_gy || !nframes || !warps || !results || !good || w < 2 || h < 2 || !ecc_size_ok(w, h) || nseq <= 0 || nseq > 4096 ||
 			   max_iterations <= 0 || max_iterations > kEccMaxIterations || !(eps >= 0) || results_stride <= 0;
 	size_t total_frames = 0;
@@ -543,7 +586,57 @@ RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const 
 		return -1;
 	const int V = ecc_rows(w, h);
 	static const bool env_per_iteration = getenv("RIR_ECC_LAUNCH_PER_ITERATION") != nullptr;
+	static const bool env_no_overlap = getenv("RIR_ECC_NO_OVERLAP") != nullptr; // (measurements: the jobs after the alignments, on the caller's stream)
 	const int cap = env_per_iteration ? 0 : ecc_run_multi_capacity();
+	// the jobs of `next`: once, on `on` (the side stream behind what the caller's stream held when the call came - its inputs are ready and
+	// the previous readers of its outputs are through - or the caller's stream itself)
+	bool next_done = nnext == 0, next_on_side = false;
+	auto run_next = [&](hipStream_t on) {
+		if (next_done)
+			return true;
+		next_done = true;
+		for (int j = 0; j < nnext; ++j)
+			if (prepare_frames_on(next[j].d_imgs, next[j].dtype, next[j].w, next[j].h, next[j].nframes, next[j].sigma, next[j].win_x, next[j].win_y,
+								  next[j].win_w, next[j].win_h, next[j].d_norm, next[j].d_gx, next[j].d_gy, on) != 0)
+				return false;
+		return true;
+	};
+	const bool overlap = nnext > 0 && !env_no_overlap && cap >= 1;
+	if (overlap)
+	{
+		if (!sc.multi_go && !hip_ok(hipHostMalloc(reinterpret_cast<void **>(&sc.multi_go), 64, hipHostMallocCoherent | hipHostMallocMapped), "hipHostMalloc"))
+			return -1;
+		if (!sc.side && (!hip_ok(hipStreamCreateWithFlags(&sc.side, hipStreamNonBlocking), "hipStreamCreate") ||
+						 !hip_ok(hipEventCreateWithFlags(&sc.side_in, hipEventDisableTiming), "hipEventCreate") ||
+						 !hip_ok(hipEventCreateWithFlags(&sc.side_out, hipEventDisableTiming), "hipEventCreate")))
+			return -1;
+		if (!hip_ok(hipEventRecord(sc.side_in, st), "hipEventRecord") || !hip_ok(hipStreamWaitEvent(sc.side, sc.side_in, 0), "hipStreamWaitEvent"))
+			return -1;
+	}
+	// beside a launch that has reported itself resident (or has ended without): the jobs on the side stream
+	auto overlap_next = [&](unsigned int epoch) {
+		if (!overlap || next_done)
+			return true;
+		const auto t0 = std::chrono::steady_clock::now();
+		volatile unsigned int *go = sc.multi_go;
+		while (*go != epoch)
+		{
+			if (hipStreamQuery(st) != hipErrorNotReady || std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+				break; // (the launch has ended - it was called off, or the chunk is tiny - or never said so: the jobs are queued all the same)
+			__builtin_ia32_pause();
+		}
+		(void)hipGetLastError();
+		next_on_side = true;
+		return run_next(sc.side) && hip_ok(hipEventRecord(sc.side_out, sc.side), "hipEventRecord");
+	};
+	// (before every return from here on: the caller's stream behind the jobs)
+	auto finish = [&](int rc) {
+		if (rc == 0 && !next_done && !run_next(st))
+			return -1;
+		if (next_on_side && !hip_ok(hipStreamWaitEvent(st, sc.side_out, 0), "hipStreamWaitEvent"))
+			return -1;
+		return rc;
+	};
 	if (cap < 1)
 	{ // the device cannot hold a resident launch (or the runtime cannot tell): sequence after sequence on the single-sequence path
 		for (int q = 0; q < nseq; ++q)
@@ -554,12 +647,14 @@ RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const 
 			if (good[q] < 0)
 				return -1;
 		}
-		return 0;
+		return finish(0);
 	}
 	const size_t rows_b = (ecc_run_workspace_bytes(w, h) + 255) & ~(size_t)255;
+	// the page-locked block the results come back to: the table, the per-image results, the launch's decision word
+	const size_t back_bytes = ((size_t)nseq * sizeof(EccSeq) + std::max<size_t>(total_frames, 1) * sizeof(EccFrameResult) + 15) & ~(size_t)15;
 	if (!sc.multi_rows.reserve((size_t)nseq * rows_b) || !sc.multi_results.reserve(std::max<size_t>(total_frames, 1) * sizeof(EccFrameResult)) ||
 		!sc.multi_table.reserve((size_t)nseq * sizeof(EccSeq)) || !sc.multi_stage.reserve((size_t)nseq * sizeof(EccSeq)) ||
-		!sc.multi_back.reserve((size_t)nseq * sizeof(EccSeq) + std::max<size_t>(total_frames, 1) * sizeof(EccFrameResult)))
+		!sc.multi_back.reserve(back_bytes + 16))
 		return -1;
 	EccSeq *hs = sc.multi_stage.as<EccSeq>();
 	size_t r0 = 0;
@@ -622,14 +717,23 @@ RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const 
 				if (!hip_ok(hipMemcpyAsync(d_ctl + 1, &w_, 4, hipMemcpyHostToDevice, st), "H2D") || !hip_ok(hipStreamSynchronize(st), "sync"))
 					return -1;
 			}
-			if (!hip_ok(launch_ecc_run_multi(sc.multi_table.as<EccSeq>() + q0, nl, nslices, w, h, max_iterations, eps, epoch, d_ctl, sc.multi_arrivals, st),
+			if (overlap)
+				*static_cast<volatile unsigned int *>(sc.multi_go) = 0u;
+			if (!hip_ok(launch_ecc_run_multi(sc.multi_table.as<EccSeq>() + q0, nl, nslices, w, h, max_iterations, eps, epoch, d_ctl, sc.multi_arrivals,
+											 overlap ? sc.multi_go : nullptr, st),
 						"ecc run (multi)"))
 				return -1;
 			sc.multi_arrivals += total;
-			unsigned int decision = 0;
+			// while the launch runs: the next chunk's pre-processing beside it.  (Before anything else is queued behind the launch - a
+			// copy to host memory that is not page-locked holds the calling thread until the stream has got there.)
+			if (!overlap_next(epoch))
+				return -1;
 			// (behind the last launch the results come back with the decision: one wait instead of two)
+			volatile unsigned int &decision = *reinterpret_cast<volatile unsigned int *>(hb + back_bytes);
+			decision = 0;
 			const bool last = q0 + 2 * plan.units_per_launch >= nseq;
-			if (!hip_ok(hipMemcpyAsync(&decision, d_ctl + 1, 4, hipMemcpyDeviceToHost, st), "D2H") || (last && !read_back()) || !hip_ok(wait_stream(st), "sync"))
+			if (!hip_ok(hipMemcpyAsync(hb + back_bytes, d_ctl + 1, 4, hipMemcpyDeviceToHost, st), "D2H") || (last && !read_back()) ||
+				!hip_ok(wait_stream(st), "sync"))
 				return -1;
 			if (decision == (((epoch & 0x3fffffffu) << 2) | 1u))
 			{ // resident: the chunk is aligned
@@ -691,7 +795,7 @@ RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const 
 		}
 		r += nframes[q];
 	}
-	return 0;
+	return finish(0);
 }
 
 // Host-pointer form, the drop-in for cv2.findTransformECC(templ, image, warp, MOTION_TRANSLATION, criteria, mask, 1):

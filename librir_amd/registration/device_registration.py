@@ -34,6 +34,16 @@ _lib.rir_ecc_align_prepared_frames_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_i
 _lib.rir_ecc_align_multi_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, ct.c_int, ct.c_double, _vp, ct.c_int, _vp, _vp]
 
 
+class PrepareJob(ct.Structure):
+    """rir_ecc_prepare_job (include/rir_amd_device.h): the arguments of one rir_ecc_prepare_frames_device call"""
+    _fields_ = [("d_imgs", _vp), ("dtype", ct.c_int), ("w", ct.c_int), ("h", ct.c_int), ("nframes", ct.c_int), ("sigma", ct.c_float),
+                ("win_x", ct.c_int), ("win_y", ct.c_int), ("win_w", ct.c_int), ("win_h", ct.c_int), ("d_norm", _vp), ("d_gx", _vp), ("d_gy", _vp)]
+
+
+_lib.rir_ecc_align_multi_overlapped_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, ct.c_int, ct.c_double, _vp, ct.c_int, _vp,
+                                                       ct.POINTER(PrepareJob), ct.c_int, _vp]
+
+
 def _stream():
     return ct.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -126,6 +136,12 @@ class DeviceRegistratorECC:
         if _lib.rir_ecc_prepare_frames_device(frames[c0].data_ptr(), dt, w, h, k, float(self.sigma), self.startX, self.startY, self.subW, self.subH,
                                               norm[0].data_ptr(), norm[1].data_ptr(), norm[2].data_ptr(), st) != 0:
             raise RuntimeError("rir_ecc_prepare_frames_device: %s" % last_error())
+
+    def _prepare_job(self, frames, c0, k, norm):
+        """what _prepare(frames, c0, k, norm, st) would do, as a job for rir_ecc_align_multi_overlapped_device"""
+        n, h, w = frames.shape
+        return PrepareJob(frames[c0].data_ptr(), ord("H") if frames.dtype == torch.uint16 else ord("f"), w, h, k, float(self.sigma), self.startX, self.startY,
+                          self.subW, self.subH, norm[0].data_ptr(), norm[1].data_ptr(), norm[2].data_ptr())
 
     def _align(self, norm, i, cnt, res, st):
         good = _lib.rir_ecc_align_prepared_frames_device(self._ref_n.data_ptr(), norm[0, i].data_ptr(), norm[1, i].data_ptr(), norm[2, i].data_ptr(),
@@ -226,10 +242,11 @@ class DeviceRegistratorECC:
         for q in range(S):
             if n:
                 registrators[q]._prepare(frs[q], 0, m, bufs[0][q], st)
-        # (The pre-processing of chunk k + 1 is NOT run on a second stream under the alignments of chunk k.  It was tried: +8 % when
-        # it worked, and most of the time it did not - the alignment kernel needs ALL its workgroups on the chip (3 per CU, 504 of a
-        # SIMD's 512 VGPRs), ordinary kernels that come and go beside it leave the register files and the LDS fragmented, the last
-        # workgroups then never fit although enough is free, and the launch runs into its clock: DESIGN.md §4, "Resident launches".)
+        # The pre-processing of chunk k + 1 runs UNDER the alignments of chunk k - but it is the library that starts it
+        # (rir_ecc_align_multi_overlapped_device), and only once the alignment launch has reported itself resident: that launch
+        # needs every one of its workgroups on the chip to start, and ordinary kernels that come and go beside it before that
+        # leave the register files fragmented and keep the last ones out ("Resident launches": queued from here on
+        # a second stream it failed 10 launches of 12).
         for ci, c0 in enumerate(range(0, n, chunk)):
             k = min(chunk, n - c0)
             norm = bufs[ci % len(bufs)]
@@ -237,13 +254,16 @@ class DeviceRegistratorECC:
             warps = np.stack([r.warp for r in registrators]).astype(np.float32)
             counts = (ct.c_int * S)(*([k] * S))
             good = (ct.c_int * S)()
-            if _lib.rir_ecc_align_multi_device(ptr([r._ref_n for r in registrators]), ptr([b[0] for b in norm]), ptr([b[1] for b in norm]),
-                                               ptr([b[2] for b in norm]), r0.subW, r0.subH, S, counts, warps.ctypes.data, r0.number_of_iterations,
-                                               r0.termination_eps, res.ctypes.data, k, good, st) != 0:
-                raise RuntimeError("ECC: %s" % last_error())
-            if c0 + chunk < n:  # the next chunk's pre-processing is queued (same stream) before the book-keeping of this one
+            jobs = (PrepareJob * S)()
+            njobs = 0
+            if c0 + chunk < n:  # the next chunk's pre-processing: beside the alignments of this one
+                njobs = S
                 for q in range(S):
-                    registrators[q]._prepare(frs[q], c0 + chunk, min(chunk, n - c0 - chunk), bufs[(ci + 1) % len(bufs)][q], st)
+                    jobs[q] = registrators[q]._prepare_job(frs[q], c0 + chunk, min(chunk, n - c0 - chunk), bufs[(ci + 1) % len(bufs)][q])
+            if _lib.rir_ecc_align_multi_overlapped_device(ptr([r._ref_n for r in registrators]), ptr([b[0] for b in norm]), ptr([b[1] for b in norm]),
+                                                          ptr([b[2] for b in norm]), r0.subW, r0.subH, S, counts, warps.ctypes.data,
+                                                          r0.number_of_iterations, r0.termination_eps, res.ctypes.data, k, good, jobs, njobs, st) != 0:
+                raise RuntimeError("ECC: %s" % last_error())
             for q in range(S):
                 registrators[q]._consume_chunk(frs[q], c0, k, norm[q], res[q], st, shifts[q], first_good=int(good[q]))
         return shifts

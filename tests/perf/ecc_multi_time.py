@@ -74,7 +74,7 @@ def wrap(name):
 class Shim:
     def __init__(self, lib):
         self._lib = lib
-        self.rir_ecc_align_multi_device = wrap("rir_ecc_align_multi_device")
+        self.rir_ecc_align_multi_overlapped_device = wrap("rir_ecc_align_multi_overlapped_device")
         self.rir_ecc_prepare_frames_device = wrap("rir_ecc_prepare_frames_device")
 
     def __getattr__(self, k):
@@ -91,5 +91,5 @@ tot = time.perf_counter() - t0
 DR._lib = real
 fr = S * (n - 1)
 print("breakdown per frame (us): align %.2f  prepare %.2f  rest (python book-keeping, start) %.2f  | total %.2f" %
-      (acc["rir_ecc_align_multi_device"] / fr * 1e6, acc["rir_ecc_prepare_frames_device"] / fr * 1e6,
+      (acc["rir_ecc_align_multi_overlapped_device"] / fr * 1e6, acc.get("rir_ecc_prepare_frames_device", 0.0) / fr * 1e6,
        (tot - sum(acc.values())) / fr * 1e6, tot / fr * 1e6))

@@ -337,3 +337,52 @@ def test_side_by_side_with_ragged_lengths_an_empty_and_a_failing_sequence():
         assert np.all(res[q, g:] == -7.0)  # (nothing is written behind the last good image)
         if g:
             assert warps[q, 0] == np.float32(own[g - 1, 0]) and warps[q, 1] == np.float32(own[g - 1, 1])
+
+
+def test_pre_processing_under_the_alignments_gives_the_same_arrays_and_results():
+    """rir_ecc_align_multi_overlapped_device: the jobs it runs beside the resident launch leave the arrays rir_ecc_prepare_frames_device
+    leaves, the alignments' results are those of rir_ecc_align_multi_device, and work queued on the caller's stream after the call sees
+    the jobs' outputs (the stream is ordered behind them)."""
+    import ctypes as ct
+
+    import torch
+
+    from librir_amd.registration import DeviceRegistratorECC
+    from librir_amd.registration import device_registration as DR
+
+    h, w, S, k = 200, 264, 4, 6
+    st = DR._stream()
+    regs, now, nxt, want, frames = [], [], [], [], []
+    for q in range(S):
+        f, _ = s3_registration(2 * k + 1, h, w, seed=400 + q)
+        t = torch.from_numpy(f if q % 2 else np.clip(f, 0, 65535).astype(np.uint16)).cuda()
+        r = DeviceRegistratorECC(0.75, 0.75, shape=(h, w))
+        r.start(t[0])
+        a = torch.zeros((3, k, r.subH, r.subW), dtype=torch.float32, device="cuda")
+        b = torch.full((3, k, r.subH, r.subW), -1.0, dtype=torch.float32, device="cuda")
+        c = torch.zeros_like(a)
+        r._prepare(t, 1, k, a, st)
+        r._prepare(t, 1 + k, k, c, st)  # what the jobs must produce
+        regs.append(r), now.append(a), nxt.append(b), want.append(c), frames.append(t)
+    ptr = lambda ts: (ct.c_void_p * S)(*[x.data_ptr() for x in ts])  # noqa: E731
+    r0 = regs[0]
+    counts = (ct.c_int * S)(*([k] * S))
+
+    def call(jobs, njobs):
+        res = np.zeros((S, k, 4), np.float64)
+        warps = np.zeros((S, 2), np.float32)
+        good = (ct.c_int * S)()
+        assert DR._lib.rir_ecc_align_multi_overlapped_device(ptr([r._ref_n for r in regs]), ptr([x[0] for x in now]), ptr([x[1] for x in now]),
+                                                            ptr([x[2] for x in now]), r0.subW, r0.subH, S, counts, warps.ctypes.data,
+                                                            r0.number_of_iterations, r0.termination_eps, res.ctypes.data, k, good, jobs, njobs, st) == 0
+        return res, warps, list(good)
+
+    plain = call((DR.PrepareJob * S)(), 0)
+    jobs = (DR.PrepareJob * S)(*[regs[q]._prepare_job(frames[q], 1 + k, k, nxt[q]) for q in range(S)])
+    over = call(jobs, S)
+    sums = [x.sum().item() for x in nxt]  # (queued on the caller's stream, not synchronised by hand: must already see the jobs' outputs)
+    assert plain[2] == over[2] == [k] * S
+    assert np.array_equal(plain[0], over[0]) and np.array_equal(plain[1], over[1])
+    for q in range(S):
+        assert torch.equal(nxt[q], want[q]), q
+        assert sums[q] == want[q].sum().item()
