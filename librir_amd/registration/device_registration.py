@@ -219,7 +219,7 @@ class DeviceRegistratorECC:
         return shifts
 
     @staticmethod
-    def compute_many_multi(registrators, frames, chunk=64):
+    def compute_many_multi(registrators, frames, chunk=32):
         """``compute_many`` for S independent sequences at once - ``registrators[q]`` (each started on its own reference image, all
         with one window size) tracks ``frames[q]`` (n, h, w) - with the alignments of a chunk of ALL sequences in one resident
         launch (rir_ecc_align_multi_device): an alignment is a chain of dependent iterations that cannot fill the chip, S chains
@@ -234,6 +234,8 @@ class DeviceRegistratorECC:
                                                     (r0.subW, r0.subH, r0.number_of_iterations, r0.termination_eps) for r in registrators):
             raise RuntimeError("compute_many_multi: the sequences must share length, window size and termination criteria")
         st = _stream()
+        if n > chunk:  # chunks of equal size, none larger than asked for (a last chunk of three images costs a launch like any other)
+            chunk = -(-n // -(-n // chunk))
         m = min(chunk, n)
         dev = frs[0].device
         bufs = [[torch.empty((3, m, r0.subH, r0.subW), dtype=torch.float32, device=dev) for _ in range(S)] for _ in range(2 if n > chunk else 1)]
