@@ -80,10 +80,17 @@ class DeviceRegistratorECC:
     def start(self, img):
         g = self._filtered(img)
         self._ref_full = g
+        self._ref_win = None  # (the window of the current reference before normalisation: a view of _ref_full until the reference changes)
         self._ref_n = self._normalised_window(g)
         self.x.append(0)
         self.y.append(0)
         self.confidences.append(1)
+
+    def reference_window(self):
+        """the registration window of the current reference image, filtered, not normalised (what the host class calls ``ref_img``): device tensor"""
+        if self._ref_win is not None:
+            return self._ref_win
+        return self._ref_full[self.startY:self.startY + self.subH, self.startX:self.startX + self.subW]
 
     def compute(self, img):
         img = img if img.dim() == 2 else img[0]
@@ -121,6 +128,7 @@ class DeviceRegistratorECC:
         if _lib.rir_minmax_normalize_device(moved.data_ptr(), self.subW, self.subH, self.subW, out.data_ptr(), _stream()) != 0:
             raise RuntimeError("rir_minmax_normalize_device: %s" % last_error())
         self._ref_n = out
+        self._ref_win = moved
         self.warp[:] = 0
 
     def _as_frames(self, frames):

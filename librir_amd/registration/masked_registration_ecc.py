@@ -8,6 +8,7 @@ low-percentile mask, min-max normalisation, the confidence-driven change of refe
 TSV that ``load_motion_correction_file`` reads - follows the reference class step by step.
 """
 import ctypes as ct
+import os
 
 import numpy as np
 
@@ -62,7 +63,8 @@ class MaskedRegistratorECC:
         self.subW, self.subH = int(columns * window_factorh), int(rows * window_factorv)
         self.startX, self.startY = int((columns - self.subW) / 2), int((rows - self.subH) / 2)
         self.x, self.y, self.confidences = [], [], []
-        self.ref_img = None       # registration window of the current reference image
+        self._dev = None          # the one-call-per-image path (start()): every step on the device, one upload per image
+        self._ref_img = None      # registration window of the current reference image (``ref_img``)
         self.mask_ref_img = None
         self.conf_thresh = None   # fixed the first time HISTORY_BEFORE_RESET is exceeded: min - 2 std of the history
         self.start_mat = np.eye(2, 3, dtype=np.float32)
@@ -92,14 +94,82 @@ class MaskedRegistratorECC:
         self.y.append(ty)
         self.confidences.append(confidence)
 
+    # ---- the plain configuration in one library call per image ------------------------------------------------------------------
+    # Without masks, percentile clipping, a fixed reference or user pre-processing - what upstream's own tests use - an image goes up
+    # once and gaussian pre-filter, window normalisation and alignment are ONE call into the library (rir_ecc_register_frame_device,
+    # through DeviceRegistratorECC: the same kernels in the same order as the calls below, the same track -
+    # tests/test_gpu_registration.py), instead of five host round trips.  RIR_REGISTRATION_STEP_BY_STEP=1 keeps the calls below.
+    def _one_call_path(self, img):
+        if os.environ.get("RIR_REGISTRATION_STEP_BY_STEP") or self.pre_process is not None or self.mask is not None or self.median < 1 or self.ref is not None:
+            return False
+        if not isinstance(img, np.ndarray) or img.ndim != 2 or img.dtype not in (np.uint16, np.float32):
+            return False
+        if self.subW < 2 or self.subH < 2 or self.startX + self.subW > img.shape[1] or self.startY + self.subH > img.shape[0]:
+            return False  # (numpy truncates such a window; the device entry point refuses it)
+        try:
+            import torch
+
+            return bool(torch.cuda.is_available())
+        except Exception:
+            return False
+
+    @staticmethod
+    def _up(img):
+        import torch
+
+        return torch.from_numpy(np.ascontiguousarray(img)).cuda()
+
+    @property
+    def ref_img(self):
+        if self._dev is not None and self._ref_img is None:
+            self._ref_img = self._dev.reference_window().cpu().numpy()
+        return self._ref_img
+
+    @ref_img.setter
+    def ref_img(self, value):
+        self._ref_img = value
+
+    def _leave_one_call_path(self):
+        """the state of the device-side registrator back into this object (an image the one-call path does not take came along)"""
+        dev, self._ref_img = self._dev, None
+        ref = self.ref_img
+        self._dev = None
+        self.ref_img = ref
+        self.start_mat = np.eye(2, 3, dtype=np.float32)
+        self.start_mat[0, 2], self.start_mat[1, 2] = dev.warp[0], dev.warp[1]
+        self.conf_thresh = dev.conf_thresh
+
     # ---- the two calls ---------------------------------------------------------------------------------------------------
     def start(self, img):
+        if self._one_call_path(img):
+            from .device_registration import DeviceRegistratorECC
+
+            dev = DeviceRegistratorECC(self.window_factorH, self.window_factorV, self.sigma, shape=self.CAMERA_SHAPE)
+            dev.subW, dev.subH, dev.startX, dev.startY = self.subW, self.subH, self.startX, self.startY  # (as they are NOW: callers do adjust them)
+            dev.x, dev.y, dev.confidences = self.x, self.y, self.confidences  # (one set of lists)
+            dev.start(self._up(img))
+            self._dev, self._ref_img, self._shape = dev, None, (img.shape, img.dtype)
+            return
         self.ref_img = self._window(self._prepared(img))
         if self.mask is not None:
             self.mask = self._window(self.mask)
         self._record(0, 0, 1)
 
     def compute(self, img):
+        if self._dev is not None:
+            if isinstance(img, np.ndarray) and (img.shape, img.dtype) == self._shape and self._one_call_path(img):
+                dev = self._dev
+                dev.number_of_iterations, dev.termination_eps, dev.conf_thresh = self.number_of_iterations, self.termination_eps, self.conf_thresh
+                reference = dev._ref_n
+                dy, dx = dev.compute(self._up(img))
+                self.x[-1], self.y[-1] = np.float32(dx), np.float32(dy)  # (the types the calls below leave)
+                self.start_mat = np.eye(2, 3, dtype=np.float32)
+                self.start_mat[0, 2], self.start_mat[1, 2] = dev.warp[0], dev.warp[1]
+                self.conf_thresh = dev.conf_thresh
+                if dev._ref_n is not reference:
+                    self._ref_img = None  # (the reference changed: fetched when somebody asks for it)
+                return [np.float32(dy), np.float32(dx)]
+            self._leave_one_call_path()
         current = self._window(self._prepared(img)).copy()
         template = np.array(self.ref_img if self.ref is None else self.ref, dtype=np.float32)
         moving = np.array(current, dtype=np.float32)

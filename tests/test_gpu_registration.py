@@ -79,9 +79,12 @@ def test_registrator_on_the_reference_recipe(tmp_path, oracle):
     mov.close()
 
 
-def test_device_resident_registrator_equals_the_host_class():
-    """DeviceRegistratorECC keeps the frames in HBM; same kernels, same float32 normalisation: same track."""
+def test_device_resident_registrator_equals_the_host_class(monkeypatch):
+    """DeviceRegistratorECC keeps the frames in HBM; same kernels, same float32 normalisation: same track.  (The host class
+    step by step, as upstream's compute() goes: without the switch it would itself call the device class once per image.)"""
     import torch
+
+    monkeypatch.setenv("RIR_REGISTRATION_STEP_BY_STEP", "1")
 
     from librir_amd.registration import DeviceRegistratorECC
 
@@ -99,11 +102,13 @@ def test_device_resident_registrator_equals_the_host_class():
     assert np.allclose(dev.confidences, host.confidences, rtol=0, atol=1e-7)
 
 
-def test_change_of_reference_image_on_a_confidence_drop():
+def test_change_of_reference_image_on_a_confidence_drop(monkeypatch):
     """masked_registration_ecc.py:177-189: after 20 frames a frame whose correlation falls below min - 2 std becomes
-    the new reference (shifted back by its own translation) and the start value returns to the identity.  Host and
-    device classes take the same decision and report the same track afterwards."""
+    the new reference (shifted back by its own translation) and the start value returns to the identity.  Host (step by
+    step) and device classes take the same decision and report the same track afterwards."""
     import torch
+
+    monkeypatch.setenv("RIR_REGISTRATION_STEP_BY_STEP", "1")
 
     from librir_amd.registration import DeviceRegistratorECC
 
@@ -386,3 +391,40 @@ def test_pre_processing_under_the_alignments_gives_the_same_arrays_and_results()
     for q in range(S):
         assert torch.equal(nxt[q], want[q]), q
         assert sums[q] == want[q].sum().item()
+
+
+@pytest.mark.parametrize("dtype", ["float32", "uint16"])
+def test_host_class_one_call_per_image_equals_its_step_by_step_path(monkeypatch, dtype):
+    """MaskedRegistratorECC in the plain configuration sends an image up once and does pre-filter, window normalisation and alignment
+    in one library call; with RIR_REGISTRATION_STEP_BY_STEP it goes through the five host round trips upstream's compute() makes.
+    Same track, confidences, threshold, start matrix and reference window - through a change of the reference image - and an image
+    the one-call path does not take (another dtype) carries on step by step from the same state."""
+    n = 34
+    f, _ = s3_registration(n, 256, 320)
+    f = f.copy()
+    f[27] += np.random.default_rng(3).normal(0, 4, f[27].shape).astype(np.float32)
+    if dtype == "uint16":
+        f = np.clip(f, 0, 65535).astype(np.uint16)
+
+    def run(step_by_step):
+        if step_by_step:
+            monkeypatch.setenv("RIR_REGISTRATION_STEP_BY_STEP", "1")
+        else:
+            monkeypatch.delenv("RIR_REGISTRATION_STEP_BY_STEP", raising=False)
+        r = MaskedRegistratorECC(1, 1)
+        r.subW, r.subH, r.startX, r.startY = 320, 256, 0, 0
+        r.start(f[0])
+        assert (r._dev is None) == step_by_step
+        shifts = [r.compute(f[i]) for i in range(1, n - 2)]
+        shifts += [r.compute(f[i].astype(np.float64)) for i in range(n - 2, n)]  # (float64: the step-by-step calls from here on)
+        assert r._dev is None
+        return r, shifts
+
+    a, sa = run(True)
+    b, sb = run(False)
+    assert a.conf_thresh is not None and min(a.confidences[21:]) < a.conf_thresh  # the reference did change
+    assert np.allclose(a.x, b.x, rtol=0, atol=1e-5) and np.allclose(a.y, b.y, rtol=0, atol=1e-5)
+    assert np.allclose(a.confidences, b.confidences, rtol=0, atol=1e-7) and np.allclose(sa, sb, rtol=0, atol=1e-5)
+    assert np.isclose(a.conf_thresh, b.conf_thresh, rtol=0, atol=1e-7) and np.allclose(a.start_mat, b.start_mat, rtol=0, atol=1e-5)
+    assert a.ref_img.shape == b.ref_img.shape and np.allclose(a.ref_img, b.ref_img, rtol=0, atol=1e-3)
+    assert all(type(v) is type(w_) for v, w_ in zip(a.x[1:], b.x[1:]))
