@@ -428,3 +428,31 @@ def test_host_class_one_call_per_image_equals_its_step_by_step_path(monkeypatch,
     assert np.isclose(a.conf_thresh, b.conf_thresh, rtol=0, atol=1e-7) and np.allclose(a.start_mat, b.start_mat, rtol=0, atol=1e-5)
     assert a.ref_img.shape == b.ref_img.shape and np.allclose(a.ref_img, b.ref_img, rtol=0, atol=1e-3)
     assert all(type(v) is type(w_) for v, w_ in zip(a.x[1:], b.x[1:]))
+
+
+def test_eight_sequences_at_the_headline_size_equal_their_own_tracks():
+    """BASELINE configs[4]'s registration at its full frame size: 8 sequences of 640x512 (full-frame window: 256 rows of partial sums, one
+    per compute workgroup and pair of sequences, a service workgroup per sequence, the next chunk's pre-processing under the alignments)
+    against each sequence's own compute_many - identical lists - and the known shifts of the recipe within the 2 px upstream's loose
+    criterion allows."""
+    import torch
+
+    from librir_amd.registration import DeviceRegistratorECC
+
+    S, n, h, w = 8, 41, 512, 640
+    seqs, truth = [], []
+    for q in range(S):
+        f, s = s3_registration(n, h, w, seed=500 + q)
+        seqs.append(torch.from_numpy(f).cuda())
+        truth.append(s)
+    multi = [DeviceRegistratorECC(1, 1, shape=(h, w)) for _ in range(S)]
+    for q in range(S):
+        multi[q].start(seqs[q][0])
+    DeviceRegistratorECC.compute_many_multi(multi, [s[1:] for s in seqs], chunk=16)
+    for q in range(S):
+        solo = DeviceRegistratorECC(1, 1, shape=(h, w))
+        solo.start(seqs[q][0])
+        solo.compute_many(seqs[q][1:])
+        assert multi[q].x == solo.x and multi[q].y == solo.y and multi[q].confidences == solo.confidences, q
+        got = np.stack([multi[q].x, multi[q].y], 1)
+        assert np.abs(np.abs(got) - np.abs(np.asarray(truth[q])[:, :2])).max() < 2.0, q
