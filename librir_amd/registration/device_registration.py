@@ -227,7 +227,7 @@ class DeviceRegistratorECC:
         return shifts
 
     @staticmethod
-    def compute_many_multi(registrators, frames, chunk=32):
+    def compute_many_multi(registrators, frames, chunk=64):
         """``compute_many`` for S independent sequences at once - ``registrators[q]`` (each started on its own reference image, all
         with one window size) tracks ``frames[q]`` (n, h, w) - with the alignments of a chunk of ALL sequences in one resident
         launch (rir_ecc_align_multi_device): an alignment is a chain of dependent iterations that cannot fill the chip, S chains
@@ -242,23 +242,31 @@ class DeviceRegistratorECC:
                                                     (r0.subW, r0.subH, r0.number_of_iterations, r0.termination_eps) for r in registrators):
             raise RuntimeError("compute_many_multi: the sequences must share length, window size and termination criteria")
         st = _stream()
-        if n > chunk:  # chunks of equal size, none larger than asked for (a last chunk of three images costs a launch like any other)
-            chunk = -(-n // -(-n // chunk))
-        m = min(chunk, n)
+        # The chunks: a SHORT first one - its pre-processing is the only one that nothing hides (every later chunk's runs under the
+        # alignments of the chunk before) - then chunks of equal size, none larger than asked for (a last chunk of three images
+        # costs a launch like any other).
+        first = min(n, max(4, chunk // 4)) if n > chunk else n
+        rest = n - first
+        if rest > chunk:
+            chunk = -(-rest // -(-rest // chunk))
+        starts = [0] + list(range(first, n, chunk))
+        sizes = [first] + [min(chunk, n - c) for c in starts[1:]]
+        m = max(sizes)
         dev = frs[0].device
-        bufs = [[torch.empty((3, m, r0.subH, r0.subW), dtype=torch.float32, device=dev) for _ in range(S)] for _ in range(2 if n > chunk else 1)]
+        bufs = [[torch.empty((3, m, r0.subH, r0.subW), dtype=torch.float32, device=dev) for _ in range(S)] for _ in range(2 if len(starts) > 1 else 1)]
         shifts = [[] for _ in range(S)]
         ptr = lambda ts: (ct.c_void_p * S)(*[t.data_ptr() for t in ts])  # noqa: E731
         for q in range(S):
             if n:
-                registrators[q]._prepare(frs[q], 0, m, bufs[0][q], st)
+                registrators[q]._prepare(frs[q], 0, first, bufs[0][q], st)
         # The pre-processing of chunk k + 1 runs UNDER the alignments of chunk k - but it is the library that starts it
         # (rir_ecc_align_multi_overlapped_device), and only once the alignment launch has reported itself resident: that launch
         # needs every one of its workgroups on the chip to start, and ordinary kernels that come and go beside it before that
         # leave the register files fragmented and keep the last ones out ("Resident launches": queued from here on
         # a second stream it failed 10 launches of 12).
-        for ci, c0 in enumerate(range(0, n, chunk)):
-            k = min(chunk, n - c0)
+        for ci, (c0, k) in enumerate(zip(starts, sizes)):
+            if k == 0:
+                break
             norm = bufs[ci % len(bufs)]
             res = np.empty((S, k, 4), np.float64)
             warps = np.stack([r.warp for r in registrators]).astype(np.float32)
@@ -266,10 +274,10 @@ class DeviceRegistratorECC:
             good = (ct.c_int * S)()
             jobs = (PrepareJob * S)()
             njobs = 0
-            if c0 + chunk < n:  # the next chunk's pre-processing: beside the alignments of this one
+            if ci + 1 < len(starts):  # the next chunk's pre-processing: beside the alignments of this one
                 njobs = S
                 for q in range(S):
-                    jobs[q] = registrators[q]._prepare_job(frs[q], c0 + chunk, min(chunk, n - c0 - chunk), bufs[(ci + 1) % len(bufs)][q])
+                    jobs[q] = registrators[q]._prepare_job(frs[q], starts[ci + 1], sizes[ci + 1], bufs[(ci + 1) % len(bufs)][q])
             if _lib.rir_ecc_align_multi_overlapped_device(ptr([r._ref_n for r in registrators]), ptr([b[0] for b in norm]), ptr([b[1] for b in norm]),
                                                           ptr([b[2] for b in norm]), r0.subW, r0.subH, S, counts, warps.ctypes.data,
                                                           r0.number_of_iterations, r0.termination_eps, res.ctypes.data, k, good, jobs, njobs, st) != 0:
