@@ -590,7 +590,17 @@ RIR_EXPORT int rir_ecc_align_multi_overlapped_device(const float *const *d_ref_n
 	const int cap = env_per_iteration ? 0 : ecc_run_multi_capacity();
 	// the jobs of `next`: once, on `on` (the side stream behind what the caller's stream held when the call came - its inputs are ready and
 	// the previous readers of its outputs are through - or the caller's stream itself)
-	bool next_done = nnext == 0, next_on_side = false;
+	bool next_done = nnext == 0, next_on_side = false, next_ordered = false;
+	struct SideGuard
+	{ // a return on an error path: the jobs already queued on the side stream write the caller's buffers - not behind the caller's back
+		EccScratch &sc;
+		const bool &on_side, &ordered;
+		~SideGuard()
+		{
+			if (on_side && !ordered)
+				(void)hipStreamSynchronize(sc.side);
+		}
+	} side_guard{sc, next_on_side, next_ordered};
 	auto run_next = [&](hipStream_t on) {
 		if (next_done)
 			return true;
@@ -633,8 +643,12 @@ RIR_EXPORT int rir_ecc_align_multi_overlapped_device(const float *const *d_ref_n
 	auto finish = [&](int rc) {
 		if (rc == 0 && !next_done && !run_next(st))
 			return -1;
-		if (next_on_side && !hip_ok(hipStreamWaitEvent(st, sc.side_out, 0), "hipStreamWaitEvent"))
-			return -1;
+		if (next_on_side && !next_ordered)
+		{
+			if (!hip_ok(hipStreamWaitEvent(st, sc.side_out, 0), "hipStreamWaitEvent"))
+				return -1;
+			next_ordered = true;
+		}
 		return rc;
 	};
 	if (cap < 1)
@@ -717,6 +731,8 @@ RIR_EXPORT int rir_ecc_align_multi_overlapped_device(const float *const *d_ref_n
 				if (!hip_ok(hipMemcpyAsync(d_ctl + 1, &w_, 4, hipMemcpyHostToDevice, st), "H2D") || !hip_ok(hipStreamSynchronize(st), "sync"))
 					return -1;
 			}
+			if (attempt > 0 && next_on_side)
+				(void)hipStreamSynchronize(sc.side); // (a launch that was called off is repeated smaller: not beside this call's own jobs)
 			if (overlap)
 				*static_cast<volatile unsigned int *>(sc.multi_go) = 0u;
 			if (!hip_ok(launch_ecc_run_multi(sc.multi_table.as<EccSeq>() + q0, nl, nslices, w, h, max_iterations, eps, epoch, d_ctl, sc.multi_arrivals,
