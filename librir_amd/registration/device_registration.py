@@ -174,6 +174,17 @@ class DeviceRegistratorECC:
                 after_first()
             # the frames up to the first one whose confidence falls below the threshold (it changes the reference image: what was
             # aligned after it does not count) are booked in one go - same values as frame-by-frame _after_alignment calls
+            if good == cnt and self.conf_thresh is not None and (good == 0 or float(res[i:i + good, 2].min()) >= self.conf_thresh):
+                # the ordinary round - every image aligned, no confidence below the (established) threshold - in four list operations
+                blk = res[i:i + good]
+                cols = blk.T.tolist()
+                self.x.extend(cols[0])
+                self.y.extend(cols[1])
+                self.confidences.extend(cols[2])
+                shifts.extend(blk[:, 1::-1].tolist())  # [y, x] pairs
+                if good:
+                    self.warp[0], self.warp[1] = blk[-1, 0], blk[-1, 1]
+                return
             base = len(self.confidences)
             cc = res[i:i + good, 2]
             stop = good  # frames of this round that count
@@ -194,7 +205,7 @@ class DeviceRegistratorECC:
             self.x.extend(xs)
             self.y.extend(ys)
             self.confidences.extend(cc[:stop].tolist())
-            shifts.extend([y, x] for x, y in zip(xs, ys))
+            shifts.extend(res[i:i + stop, 1::-1].tolist())  # [y, x] pairs
             if stop:
                 self.warp[0], self.warp[1] = res[i + stop - 1, 0], res[i + stop - 1, 1]
             if change:
