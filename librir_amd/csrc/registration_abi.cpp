@@ -55,10 +55,20 @@ namespace
 			return run_ctl.as<unsigned int>();
 		}
 	};
+	// one scratch per DEVICE (its buffers, events, page-locked words and side stream belong to the device that was current when they were
+	// made: a process that drives two GPUs must not use one device's on the other's stream); the current device's is returned
+	constexpr int kScratchDevices = 64;
+	int scratch_slot()
+	{
+		int dev = 0;
+		if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kScratchDevices)
+			dev = 0;
+		return dev;
+	}
 	EccScratch &scratch()
 	{
-		static EccScratch s;
-		return s;
+		static EccScratch *s = new EccScratch[kScratchDevices]; // (never destroyed: the runtime may be gone before static destructors run)
+		return s[scratch_slot()];
 	}
 	// (tests, RIR_DEBUG_ECC_BAIL: as if the next launch on this control block had not become resident - its decision says BAIL before anybody arrives)
 	bool debug_call_off(unsigned int *d_ctl, unsigned int epoch, hipStream_t st)
@@ -80,8 +90,8 @@ namespace
 	};
 	PrepScratch &prep_scratch()
 	{
-		static PrepScratch s;
-		return s;
+		static PrepScratch *s = new PrepScratch[kScratchDevices]; // (per device, as above)
+		return s[scratch_slot()];
 	}
 
 	// Stream ordering of the shared scratch (the host mutex only orders the CALLS): constructed, under the mutex, before an
