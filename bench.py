@@ -287,14 +287,15 @@ def other_paths(D, frames, h, w):
     res["bounded_loss_step_fps_one_stream"] = rate(lambda: st.step(fr, errors=False), m)
     st.status()
     st.close()
-    S = 7
-    streams = [D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32) for _ in range(S)]
-    ins = [fr.clone() for _ in range(S)]
-    D.LossyStream.step_many(streams, ins, errors=False)
-    res["bounded_loss_step_fps_7_streams"] = rate(lambda: D.LossyStream.step_many(streams, ins, errors=False), m * S)
-    streams[0].status()
-    for x in streams:
-        x.close()
+    for S in (7, 9):  # (7: what one launch of the run kernel's first form holds; 9: its second form - state parked in LDS, 6 waves per SIMD)
+        streams = [D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32) for _ in range(S)]
+        ins = [fr.clone() for _ in range(S)]
+        D.LossyStream.step_many(streams, ins, errors=False)
+        res["bounded_loss_step_fps_%d_streams" % S] = rate(lambda: D.LossyStream.step_many(streams, ins, errors=False), m * S)
+        streams[0].status()
+        for x in streams:
+            x.close()
+        del streams, ins
     nreg = 100
     f32, _ = s3_registration(nreg, h, w)
     tf = torch.from_numpy(f32).to(frames.device)

@@ -90,7 +90,10 @@ namespace rir
 	// workgroups per CU: 1 200), and the launch goes through the process-wide gate of runtime.h; more streams than fit go a batch
 	// after the other, a frame whose workgroups do not fit (or a device the runtime cannot size) takes the launch-per-frame path.
 	constexpr int kLossyRunWavesPerSimd = 5;
-	int lossy_run_capacity();
+	// the second form of the run kernel (lossy_run_parked_kernel): part of the pixel state parked in LDS between the frames, 6 waves per
+	// SIMD - more streams per launch (9 of 640x512 instead of 7), each a little slower: taken when it saves a launch
+	constexpr int kLossyRunParkedWavesPerSimd = 6;
+	int lossy_run_capacity(bool parked = false);
 
 	// Pixels per workgroup of the histogram pass: each workgroup clears and merges a private 16 384-bin histogram, so a launch wants
 	// about as many workgroups as the chip holds at once (two per CU) - 4 096 pixels for one 640x512 stream, more with many streams.
@@ -110,7 +113,8 @@ namespace rir
 	// the error word, words kLossyRunCtlWord .. + 3 the residency control block (resident_device.h: arrivals, decision, poison, epoch of the
 	// first launch that bailed out); epoch: a number no earlier launch on this header used; arrivals_before: workgroups of those launches
 	constexpr int kLossyRunCtlWord = 48;
-	hipError_t launch_lossy_run(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ticket, unsigned int epoch, unsigned int arrivals_before, hipStream_t st);
+	hipError_t launch_lossy_run(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ticket, unsigned int epoch, unsigned int arrivals_before, bool parked,
+								hipStream_t st);
 	hipError_t launch_lossy_first(const uint16_t *d_tmp, uint16_t *d_out, const LossyDeviceState &state, int s, int full, hipStream_t st);
 	hipError_t launch_lossy_min(const uint16_t *d_tmp, int s, unsigned int *d_result, hipStream_t st);
 	hipError_t launch_lossy_add_min(uint16_t *d_frames, int64_t npx, int s, int nframes, uint32_t mn, hipStream_t st);

@@ -958,13 +958,23 @@ namespace rir
 	// has published k + 1: two buffers are enough.  Waits are bounded by a clock (2 s): a wait that gives up raises error_word and
 	// the run goes on with whatever it has - wrong, flagged, but never hung.
 	constexpr int kRunWaves = kLossyRunThreads / 64;
-	__attribute__((amdgpu_waves_per_eu(kLossyRunWavesPerSimd, kLossyRunWavesPerSimd))) __global__ __launch_bounds__(kLossyRunThreads) void lossy_run_kernel(const LossyRun *__restrict__ table, unsigned int *__restrict__ ticket_, int nb, int nstreams, unsigned int epoch, unsigned int arrivals_before)
+	// PARKED: the running sums and the constant-stretch counters / values of a thread's pixels live in LDS between the frames (64 B per
+	// thread; a thread only ever touches its own slots: no barrier; [pair][thread]: 8- and 4-byte accesses at that lane stride) and come
+	// into registers a pixel pair at a time - 16 VGPRs less at the peak, which is what lets the kernel be built for 6 waves per SIMD
+	// (80 VGPRs, a handful spilled outside the pixel arithmetic) instead of 5: NINE streams of 640x512 per launch instead of seven.
+	// A stream is a little slower that way (7 streams: 564 k frames/s against 581 k), nine at once are faster than seven (625 k), so
+	// the host takes this form when it saves a launch (lossy_run_parked_kernel; same arithmetic, same results).
+	template <bool PARKED>
+	__device__ __forceinline__ void lossy_run_body(const LossyRun *__restrict__ table, unsigned int *__restrict__ ticket_, int nb, int nstreams, unsigned int epoch, unsigned int arrivals_before)
 	{
 		__shared__ unsigned int sh_ticket;
 		__shared__ unsigned int sh_flag;
 		__shared__ long long red[kRunWaves][6], red2[kRunWaves][6];
 		__shared__ LossyBudget bl;
 		__shared__ LossyDecision dec;
+		constexpr int kParkedThreads = PARKED ? kLossyRunThreads : 1;
+		__shared__ uint2 st_sum[4][kParkedThreads];
+		__shared__ uint32_t st_cc[4][kParkedThreads], st_cv[4][kParkedThreads];
 		const int tid = threadIdx.x;
 		if (tid == 0)
 		{
@@ -1028,6 +1038,12 @@ namespace rir
 				if (count == ra)
 					old8 = ld8(ring + (size_t)head * s, i8);
 			}
+		}
+		if constexpr (PARKED)
+		{
+#pragma unroll
+			for (int p = 0; p < 4; ++p)
+				st_sum[p][tid] = make_uint2(sum[2 * p], sum[2 * p + 1]), st_cc[p][tid] = cc8.d[p], st_cv[p][tid] = cv8.d[p];
 		}
 		U16x8 v8{};
 		if (inside)
@@ -1250,9 +1266,23 @@ namespace rir
 				}
 #else
 				const LossyPairConsts pc = lossy_pair_consts(fc);
+				if constexpr (PARKED)
+				{
 #pragma unroll
-				for (int p = 0; p < 4; ++p)
-					lossy_pixel_pair(fc, pc, v8.d[p], old8.d[p], last8.d[p], ref8.d[p], sum[2 * p], sum[2 * p + 1], cc8.d[p], cv8.d[p], t8.d[p], o8.d[p]);
+					for (int p = 0; p < 4; ++p)
+					{ // (a pair's sums and counters come from LDS right before its update and go back right after: four registers live, not sixteen)
+						uint2 s2 = st_sum[p][tid];
+						uint32_t c2 = st_cc[p][tid], v2 = st_cv[p][tid];
+						lossy_pixel_pair(fc, pc, v8.d[p], old8.d[p], last8.d[p], ref8.d[p], s2.x, s2.y, c2, v2, t8.d[p], o8.d[p]);
+						st_sum[p][tid] = s2, st_cc[p][tid] = c2, st_cv[p][tid] = v2;
+					}
+				}
+				else
+				{
+#pragma unroll
+					for (int p = 0; p < 4; ++p)
+						lossy_pixel_pair(fc, pc, v8.d[p], old8.d[p], last8.d[p], ref8.d[p], sum[2 * p], sum[2 * p + 1], cc8.d[p], cv8.d[p], t8.d[p], o8.d[p]);
+				}
 #endif
 				last8 = v8;
 				st8(out + (size_t)k * rp.frame_px, i8, o8);
@@ -1286,6 +1316,15 @@ namespace rir
 #endif
 		}
 		// registers -> state
+		if constexpr (PARKED)
+		{
+#pragma unroll
+			for (int p = 0; p < 4; ++p)
+			{
+				const uint2 s2 = st_sum[p][tid];
+				sum[2 * p] = s2.x, sum[2 * p + 1] = s2.y, cc8.d[p] = st_cc[p][tid], cv8.d[p] = st_cv[p][tid];
+			}
+		}
 		if (lossy)
 		{
 			st8(refT, i8, ref8);
@@ -1316,6 +1355,17 @@ namespace rir
 				gd->background = dec.background, gd->low_error = dec.low_error, gd->high_error = dec.high_error;
 			}
 		}
+	}
+
+	__attribute__((amdgpu_waves_per_eu(kLossyRunWavesPerSimd, kLossyRunWavesPerSimd))) __global__ __launch_bounds__(kLossyRunThreads) void lossy_run_kernel(
+		const LossyRun *__restrict__ table, unsigned int *__restrict__ ticket_, int nb, int nstreams, unsigned int epoch, unsigned int arrivals_before)
+	{
+		lossy_run_body<false>(table, ticket_, nb, nstreams, epoch, arrivals_before);
+	}
+	__attribute__((amdgpu_waves_per_eu(kLossyRunParkedWavesPerSimd, kLossyRunParkedWavesPerSimd))) __global__ __launch_bounds__(kLossyRunThreads) void lossy_run_parked_kernel(
+		const LossyRun *__restrict__ table, unsigned int *__restrict__ ticket_, int nb, int nstreams, unsigned int epoch, unsigned int arrivals_before)
+	{
+		lossy_run_body<true>(table, ticket_, nb, nstreams, epoch, arrivals_before);
 	}
 
 	// first frame: out = tmp minus the optional minimum on rows < lossy_height; seeds refT / prevT / lastDL
@@ -1426,16 +1476,25 @@ namespace rir
                                   that fills the chip to the last place is called off whenever anything else is resident, and a loss run that is called off
                                   goes on frame by frame - or, for queue-only calls, fails the stream */
 #endif
-	int lossy_run_capacity() { return resident_capacity(reinterpret_cast<const void *>(lossy_run_kernel), kLossyRunThreads, 0, RIR_LOSSY_RUN_MARGIN != 0); }
-	hipError_t launch_lossy_run(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ticket, unsigned int epoch, unsigned int arrivals_before, hipStream_t st)
+	int lossy_run_capacity(bool parked)
+	{
+		return resident_capacity(parked ? reinterpret_cast<const void *>(lossy_run_parked_kernel) : reinterpret_cast<const void *>(lossy_run_kernel), kLossyRunThreads,
+								 0, RIR_LOSSY_RUN_MARGIN != 0);
+	}
+	hipError_t launch_lossy_run(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ticket, unsigned int epoch, unsigned int arrivals_before, bool parked,
+								hipStream_t st)
 	{
 		const int nb = lossy_run_workgroups(full);
-		if ((long long)nb * nstreams > lossy_run_capacity())
+		if ((long long)nb * nstreams > lossy_run_capacity(parked))
 			return hipErrorInvalidConfiguration; // (the callers plan their launches with lossy_run_capacity(): never reached)
 		ResidentGate gate(st); // its workgroups wait for each other: not beside any other resident launch of the process
 		if (!gate.ok())
 			return hipErrorUnknown;
-		hipLaunchKernelGGL(lossy_run_kernel, dim3((unsigned)(nb * nstreams)), dim3(kLossyRunThreads), 0, st, d_table, d_ticket, nb, nstreams, epoch, arrivals_before);
+		if (parked)
+			hipLaunchKernelGGL(lossy_run_parked_kernel, dim3((unsigned)(nb * nstreams)), dim3(kLossyRunThreads), 0, st, d_table, d_ticket, nb, nstreams, epoch,
+							   arrivals_before);
+		else
+			hipLaunchKernelGGL(lossy_run_kernel, dim3((unsigned)(nb * nstreams)), dim3(kLossyRunThreads), 0, st, d_table, d_ticket, nb, nstreams, epoch, arrivals_before);
 		return hipGetLastError();
 	}
 

@@ -2437,9 +2437,21 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 		const char *max_env = getenv("RIR_LOSSY_RUN_MAX_WORKGROUPS"); // (tests: a smaller limit, to go through the batches with small frames)
 		const int capacity = lossy_run_capacity();						 // what THIS device holds of the run kernel at once (0: unknown)
 		const int max_wgs = max_env && atoi(max_env) > 0 ? std::min(atoi(max_env), capacity) : capacity;
-		const ResidentPlan plan = resident_plan(max_wgs, run_wgs, nstreams); // (units_per_launch 0: a stream does not fit - launch per frame)
+		ResidentPlan plan = resident_plan(max_wgs, run_wgs, nstreams); // (units_per_launch 0: a stream does not fit - launch per frame)
+		// the second form of the kernel (part of the pixel state parked in LDS, one more wave per SIMD): more streams per launch, each a
+		// little slower - taken when it saves a launch (RIR_LOSSY_RUN_FORM=5 / 6: one form only, for tests and measurements)
+		bool parked = false;
+		{
+			const int cap6 = lossy_run_capacity(true), max6 = max_env && atoi(max_env) > 0 ? std::min(atoi(max_env), cap6) : cap6;
+			const ResidentPlan plan6 = resident_plan(max6, run_wgs, nstreams);
+			const char *form = getenv("RIR_LOSSY_RUN_FORM");
+			const bool want6 = form ? atoi(form) == 6 : (plan6.units_per_launch > 0 && (plan.units_per_launch == 0 || plan6.launches < plan.launches));
+			if (want6 && plan6.units_per_launch > 0)
+				parked = true, plan = plan6;
+		}
 		const bool persistent = runs && errors_fit && plan.units_per_launch > 0 && !force_per_frame && !getenv("RIR_LOSSY_LAUNCH_PER_FRAME");
-		const int batch = persistent ? plan.units_per_launch : nstreams; // streams per launch of the resident kernel
+		// streams per launch of the resident kernel: the launches the plan needs, filled evenly (32 streams at 9 per launch: 8, 8, 8, 8 - not 9, 9, 9, 5)
+		const int batch = persistent ? (nstreams + plan.launches - 1) / plan.launches : nstreams;
 		const int group = std::max(1, (persistent ? 2048 : 512) / nstreams); // frames per histogram launch (one 64 KB histogram slice per frame and stream)
 		const int ngroups = runs ? (nsteps + group - 1) / group : 0;
 		const size_t nfused = persistent ? 0 : runs ? (size_t)(nsteps + 1) * nstreams : (size_t)nsteps * nstreams, nhist = runs ? (size_t)nsteps * nstreams : 0;
@@ -2574,7 +2586,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 							if (!hip_ok(hipMemcpyAsync(d_ticket + kLossyRunCtlWord + 1, &w_, 4, hipMemcpyHostToDevice, st), "H2D") || !hip_ok(hipStreamSynchronize(st), "sync"))
 								return -1;
 						}
-						if (!hip_ok(launch_lossy_run(dr + (size_t)g * nstreams + s0, nl, full_px, d_ticket, epoch, lead.run_arrivals, st), "lossy run"))
+						if (!hip_ok(launch_lossy_run(dr + (size_t)g * nstreams + s0, nl, full_px, d_ticket, epoch, lead.run_arrivals, parked, st), "lossy run"))
 							return -1;
 						lead.run_arrivals += (unsigned int)(nl * run_wgs);
 					}

@@ -12,7 +12,7 @@ from librir_amd import device as D
 from librir_amd.synthetic import s1_noisy_background
 h, w, m = 512, 640, 200
 fr = torch.from_numpy(s1_noisy_background(m, h, w)).cuda()
-for S in (7, 8, 14, 16):
+for S in [int(x) for x in __import__("os").environ.get("STREAMS", "7,8,14,16").split(",")]:
     streams = [D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32) for _ in range(S)]
     ins = [fr.clone() for _ in range(S)]
     D.LossyStream.step_many(streams, ins, errors=False)

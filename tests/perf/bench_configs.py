@@ -346,7 +346,7 @@ c4["lossy_step_device_resident_fps_one_stream"] = best_rate(lambda: ls1.step(s1_
 ls1.status()
 ls1.close()
 # independent streams in shared launches (rir_lossy_step_multi_device): the loss state is sequential in time, streams run side by side
-for S in (7, 32):  # 7 streams of this size share one resident launch; more go a batch after the other
+for S in (7, 9, 32):  # 7 streams of this size share one resident launch of the first form of the run kernel, 9 one of the second; more go a batch after the other
     m = 20 if args.quick else m1
     streams = [D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32) for _ in range(S)]
     ins = [s1_200[:m].clone() for _ in range(S)]

@@ -117,16 +117,19 @@ def test_per_frame_error_attributes(tmp_path):
         assert int(mov.attributes["GlobalForegroundError"]) == 2
 
 
-@pytest.fixture(params=["one launch per run", "one launch per frame", "batches of streams"])
+@pytest.fixture(params=["one launch per run", "one launch per frame", "batches of streams", "state parked in LDS", "parked, batches of streams"])
 def run_path(request, monkeypatch):
     """Batches of frames are stepped by the resident run kernel - all streams in one launch, or, where the chip does not hold them
     at once, a batch of streams after the other (RIR_LOSSY_RUN_MAX_WORKGROUPS lowers the limit so that small frames get there) -
-    or, frames too large for it, by one fused launch per frame (RIR_LOSSY_LAUNCH_PER_FRAME forces that path at any size)."""
+    or, frames too large for it, by one fused launch per frame (RIR_LOSSY_LAUNCH_PER_FRAME forces that path at any size).  The run
+    kernel has a second form, taken when it saves a launch (part of the pixel state parked in LDS, 6 waves per SIMD:
+    RIR_LOSSY_RUN_FORM=6 forces it, 5 forbids it)."""
     monkeypatch.delenv("RIR_LOSSY_LAUNCH_PER_FRAME", raising=False)
     monkeypatch.delenv("RIR_LOSSY_RUN_MAX_WORKGROUPS", raising=False)
+    monkeypatch.setenv("RIR_LOSSY_RUN_FORM", "6" if "parked" in request.param else "5")
     if request.param == "one launch per frame":
         monkeypatch.setenv("RIR_LOSSY_LAUNCH_PER_FRAME", "1")
-    elif request.param == "batches of streams":
+    elif "batches of streams" in request.param:
         monkeypatch.setenv("RIR_LOSSY_RUN_MAX_WORKGROUPS", "13")  # 128x96 frames take 6 workgroups: two streams per launch
     return request.param
 
