@@ -958,12 +958,13 @@ namespace rir
 	// has published k + 1: two buffers are enough.  Waits are bounded by a clock (2 s): a wait that gives up raises error_word and
 	// the run goes on with whatever it has - wrong, flagged, but never hung.
 	constexpr int kRunWaves = kLossyRunThreads / 64;
-	// PARKED: the running sums and the constant-stretch counters / values of a thread's pixels live in LDS between the frames (64 B per
-	// thread; a thread only ever touches its own slots: no barrier; [pair][thread]: 8- and 4-byte accesses at that lane stride) and come
-	// into registers a pixel pair at a time - 16 VGPRs less at the peak, which is what lets the kernel be built for 6 waves per SIMD
-	// (80 VGPRs, a handful spilled outside the pixel arithmetic) instead of 5: NINE streams of 640x512 per launch instead of seven.
-	// A stream is a little slower that way (7 streams: 564 k frames/s against 581 k), nine at once are faster than seven (625 k), so
-	// the host takes this form when it saves a launch (lossy_run_parked_kernel; same arithmetic, same results).
+	// PARKED: the running sums, the constant-stretch counters / values, the reference levels and the previous frame's pixels of a thread's
+	// pixels live in LDS between the frames (96 B per thread; a thread only ever touches its own slots: no barrier; [pair][thread]: 8- and
+	// 4-byte accesses at that lane stride) and come into registers a pixel pair at a time - 24 VGPRs less at the peak, which is what lets
+	// the kernel be built for 6 waves per SIMD (80 VGPRs, nothing spilled; 25.6 KB of LDS: six workgroups to a CU) instead of 5: NINE
+	// streams of 640x512 per launch instead of seven.  Seven streams run about as fast either way (568 against 580 k frames/s), nine at
+	// once are faster than seven (636 k): the host takes this form when it saves a launch (lossy_run_parked_kernel; same arithmetic,
+	// same results; scripts/lossy_forms.sh).
 	template <bool PARKED>
 	__device__ __forceinline__ void lossy_run_body(const LossyRun *__restrict__ table, unsigned int *__restrict__ ticket_, int nb, int nstreams, unsigned int epoch, unsigned int arrivals_before)
 	{
@@ -975,6 +976,7 @@ namespace rir
 		constexpr int kParkedThreads = PARKED ? kLossyRunThreads : 1;
 		__shared__ uint2 st_sum[4][kParkedThreads];
 		__shared__ uint32_t st_cc[4][kParkedThreads], st_cv[4][kParkedThreads];
+		__shared__ uint32_t st_ref[4][kParkedThreads], st_last[4][kParkedThreads];
 		const int tid = threadIdx.x;
 		if (tid == 0)
 		{
@@ -1043,7 +1045,10 @@ namespace rir
 		{
 #pragma unroll
 			for (int p = 0; p < 4; ++p)
+			{
 				st_sum[p][tid] = make_uint2(sum[2 * p], sum[2 * p + 1]), st_cc[p][tid] = cc8.d[p], st_cv[p][tid] = cv8.d[p];
+				st_ref[p][tid] = ref8.d[p], st_last[p][tid] = last8.d[p];
+			}
 		}
 		U16x8 v8{};
 		if (inside)
@@ -1273,7 +1278,10 @@ namespace rir
 					{ // (a pair's sums and counters come from LDS right before its update and go back right after: four registers live, not sixteen)
 						uint2 s2 = st_sum[p][tid];
 						uint32_t c2 = st_cc[p][tid], v2 = st_cv[p][tid];
-						lossy_pixel_pair(fc, pc, v8.d[p], old8.d[p], last8.d[p], ref8.d[p], s2.x, s2.y, c2, v2, t8.d[p], o8.d[p]);
+						uint32_t r2 = st_ref[p][tid];
+						const uint32_t l2 = st_last[p][tid];
+						lossy_pixel_pair(fc, pc, v8.d[p], old8.d[p], l2, r2, s2.x, s2.y, c2, v2, t8.d[p], o8.d[p]);
+						st_ref[p][tid] = r2, st_last[p][tid] = v8.d[p]; // (this frame's pixels are the next frame's "last")
 						st_sum[p][tid] = s2, st_cc[p][tid] = c2, st_cv[p][tid] = v2;
 					}
 				}
@@ -1284,7 +1292,8 @@ namespace rir
 						lossy_pixel_pair(fc, pc, v8.d[p], old8.d[p], last8.d[p], ref8.d[p], sum[2 * p], sum[2 * p + 1], cc8.d[p], cv8.d[p], t8.d[p], o8.d[p]);
 				}
 #endif
-				last8 = v8;
+				if constexpr (!PARKED)
+					last8 = v8;
 				st8(out + (size_t)k * rp.frame_px, i8, o8);
 				if (ra > 0)
 				{
@@ -1323,6 +1332,7 @@ namespace rir
 			{
 				const uint2 s2 = st_sum[p][tid];
 				sum[2 * p] = s2.x, sum[2 * p + 1] = s2.y, cc8.d[p] = st_cc[p][tid], cv8.d[p] = st_cv[p][tid];
+				ref8.d[p] = st_ref[p][tid], last8.d[p] = st_last[p][tid];
 			}
 		}
 		if (lossy)
