@@ -79,6 +79,17 @@ namespace rir
 		return r;
 	}
 
+	// the same for a 32-bit integer (wrapping): four DPP adds, four readlanes - a third of the 64-bit form's instructions
+	__device__ __forceinline__ uint32_t lossy_wave_sum32(uint32_t v)
+	{
+		v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+		v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+		v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, false); // row_half_mirror
+		v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, false); // row_mirror
+		return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) + (uint32_t)__builtin_amdgcn_readlane((int)v, 32) +
+			   (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+	}
+
 	// true in every thread of the workgroup whose ticket is the last of `expected`; last_flag: one LDS word the caller can spare
 	__device__ __forceinline__ bool lossy_last_arriver(unsigned int *ticket_, unsigned int expected, unsigned int *last_flag)
 	{
@@ -1094,10 +1105,14 @@ namespace rir
 #endif
 			// wave sums -> LDS; wave 0 adds the waves up, publishes, collects everybody's words and decides
 #ifndef RIR_LOSSY_PACKED_SUMS
-			long long ws[6] = {fd, f2, fn, bd, b2, bn};
-#pragma unroll
-			for (int j = 0; j < 6; ++j)
-				ws[j] = lossy_wave_sum(ws[j]);
+			// (a wave holds 512 pixels: its sums of d stay below 2^25 and its counts below 2^10 - three 32-bit reductions, the two counts in
+			// one word, and two 64-bit ones for the squares, instead of six 64-bit ones: 72 vector instructions less per frame)
+			long long ws[6];
+			{
+				const uint32_t wfd = lossy_wave_sum32((uint32_t)fd), wbd = lossy_wave_sum32((uint32_t)bd), wn = lossy_wave_sum32((uint32_t)fn | ((uint32_t)bn << 16));
+				ws[0] = (long long)wfd, ws[1] = lossy_wave_sum(f2), ws[2] = (long long)(wn & 0xffffu), ws[3] = (long long)wbd, ws[4] = lossy_wave_sum(b2),
+				ws[5] = (long long)(wn >> 16);
+			}
 #else
 			// four reductions instead of six: counts ride in the high halves of the sums of d (a wave's sum of d stays below 2^26),
 			// the background parts are totals minus foreground
@@ -1184,9 +1199,9 @@ namespace rir
 			RIR_GLOBAL(unsigned long long) *dword = exch + (size_t)2 * nb * rp.slot_words + (size_t)(k & 1) * 8;
 			if (collect)
 			{
-#pragma unroll
-				for (int j = 0; j < 6; ++j)
-					acc[j] = lossy_wave_sum(acc[j]);
+				// (the counts of a stream stay below 2^32: 32-bit reductions for them)
+				acc[0] = lossy_wave_sum(acc[0]), acc[1] = lossy_wave_sum(acc[1]), acc[3] = lossy_wave_sum(acc[3]), acc[4] = lossy_wave_sum(acc[4]);
+				acc[2] = (long long)lossy_wave_sum32((uint32_t)acc[2]), acc[5] = (long long)lossy_wave_sum32((uint32_t)acc[5]);
 				if (lane < 6)
 					red2[wave][lane] = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : lane == 3 ? acc[3] : lane == 4 ? acc[4] : acc[5];
 				__syncthreads();
