@@ -1105,6 +1105,9 @@ namespace rir
 #endif
 			// wave sums -> LDS; wave 0 adds the waves up, publishes, collects everybody's words and decides
 #ifndef RIR_LOSSY_PACKED_SUMS
+			// (The per-pixel sums above as totals + foreground parts without the branch - |t - o| as one v_sad_u16, selects instead of the two
+			// sides under exec masks - were measured: 7 streams 589 k frames/s against 635 k; two 64-bit adds per pixel cost more than the exec
+			// switches.)
 			// (a wave holds 512 pixels: its sums of d stay below 2^25 and its counts below 2^10 - three 32-bit reductions, the two counts in
 			// one word, and two 64-bit ones for the squares, instead of six 64-bit ones: 72 vector instructions less per frame)
 			long long ws[6];
