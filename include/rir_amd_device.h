@@ -31,6 +31,7 @@ extern "C"
 	 * launch-per-frame / launch-per-iteration kernels are used), out2[1] = launches. */
 	int rir_resident_capacity_rule(int blocks_per_cu, int cus, int xcds);
 	int rir_resident_plan(int capacity, int wgs_per_unit, int units, int *out2);
+	int rir_resident_plan_two_forms(int capacity_a, int capacity_b, int wgs_per_unit, int units, int *out3); /* a kernel in two forms: [2] = 1 when the larger, slower one saves a launch */
 
 	/* ---- block codec (format RIRB1) ----------------------------------------------------------
 	 * Replaces, for device-resident batches, the encode/decode the reference delegates to

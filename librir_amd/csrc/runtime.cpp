@@ -191,6 +191,14 @@ namespace rir
 		p.launches = (units + p.units_per_launch - 1) / p.units_per_launch;
 		return p;
 	}
+	ResidentPlan resident_plan_two_forms(int capacity_a, int capacity_b, int wgs_per_unit, int units, bool *second)
+	{
+		const ResidentPlan a = resident_plan(capacity_a, wgs_per_unit, units), b = resident_plan(capacity_b, wgs_per_unit, units);
+		const bool take_b = b.units_per_launch > 0 && (a.units_per_launch == 0 || b.launches < a.launches);
+		if (second)
+			*second = take_b;
+		return take_b ? b : a;
+	}
 	namespace
 	{
 		constexpr int kMaxDevices = 64;
@@ -443,6 +451,16 @@ RIR_EXPORT void rm_void_ptr(int index) { rir::remove_object(index); }
 // in one launch on a device of `cus` CUs in `xcds` XCDs.  rir_resident_plan: out[0] = units per launch (0 = a unit does not fit:
 // the caller's launch-per-frame / launch-per-iteration path), out[1] = launches; returns 0, -1 on a NULL pointer.
 RIR_EXPORT int rir_resident_capacity_rule(int blocks_per_cu, int cus, int xcds) { return rir::resident_capacity_rule(blocks_per_cu, cus, xcds); }
+// rir_resident_plan_two_forms: out[0] = units per launch when filled evenly, out[1] = launches, out[2] = 1 when the second form is taken.
+RIR_EXPORT int rir_resident_plan_two_forms(int capacity_a, int capacity_b, int wgs_per_unit, int units, int *out3)
+{
+	if (!out3)
+		return -1;
+	bool second = false;
+	const rir::ResidentPlan p = rir::resident_plan_two_forms(capacity_a, capacity_b, wgs_per_unit, units, &second);
+	out3[0] = p.units_per_launch > 0 ? rir::resident_batch(p, units) : 0, out3[1] = p.launches, out3[2] = second ? 1 : 0;
+	return 0;
+}
 RIR_EXPORT int rir_resident_plan(int capacity, int wgs_per_unit, int units, int *out2)
 {
 	if (!out2)

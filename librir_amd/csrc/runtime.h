@@ -101,6 +101,11 @@ namespace rir
 		int units_per_launch, launches;
 	};
 	ResidentPlan resident_plan(int capacity, int wgs_per_unit, int units);
+	// A kernel built in two forms - the second holds more workgroups at once (capacity_b > capacity_a) but runs a unit a little slower:
+	// the second form is taken when it saves a launch (or when only it fits); *second says which.  The plan's launches are then
+	// filled evenly (resident_batch): 32 units at 9 per launch go as 8, 8, 8, 8.
+	ResidentPlan resident_plan_two_forms(int capacity_a, int capacity_b, int wgs_per_unit, int units, bool *second);
+	inline int resident_batch(const ResidentPlan &p, int units) { return p.launches > 0 ? (units + p.launches - 1) / p.launches : 0; }
 	// (2) the gate: construct it right before the launch, on the launching thread, with the launch's stream; it makes that stream
 	// wait for the previous resident launch of the device (whatever stream that went to) and, when it goes out of scope, leaves
 	// its event behind the launch.  Host side it holds the device's mutex for the duration of the launch call only.

@@ -2437,21 +2437,17 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 		const char *max_env = getenv("RIR_LOSSY_RUN_MAX_WORKGROUPS"); // (tests: a smaller limit, to go through the batches with small frames)
 		const int capacity = lossy_run_capacity();						 // what THIS device holds of the run kernel at once (0: unknown)
 		const int max_wgs = max_env && atoi(max_env) > 0 ? std::min(atoi(max_env), capacity) : capacity;
-		ResidentPlan plan = resident_plan(max_wgs, run_wgs, nstreams); // (units_per_launch 0: a stream does not fit - launch per frame)
-		// the second form of the kernel (part of the pixel state parked in LDS, one more wave per SIMD): more streams per launch, each a
-		// little slower - taken when it saves a launch (RIR_LOSSY_RUN_FORM=5 / 6: one form only, for tests and measurements)
+		// the run kernel has a second form (part of the pixel state parked in LDS, one more wave per SIMD): more streams per launch, each
+		// a little slower - taken when it saves a launch (runtime.h; RIR_LOSSY_RUN_FORM=5 / 6: one form only, for tests and measurements)
+		const int cap6 = lossy_run_capacity(true), max6 = max_env && atoi(max_env) > 0 ? std::min(atoi(max_env), cap6) : cap6;
+		const char *form = getenv("RIR_LOSSY_RUN_FORM");
 		bool parked = false;
-		{
-			const int cap6 = lossy_run_capacity(true), max6 = max_env && atoi(max_env) > 0 ? std::min(atoi(max_env), cap6) : cap6;
-			const ResidentPlan plan6 = resident_plan(max6, run_wgs, nstreams);
-			const char *form = getenv("RIR_LOSSY_RUN_FORM");
-			const bool want6 = form ? atoi(form) == 6 : (plan6.units_per_launch > 0 && (plan.units_per_launch == 0 || plan6.launches < plan.launches));
-			if (want6 && plan6.units_per_launch > 0)
-				parked = true, plan = plan6;
-		}
+		ResidentPlan plan = form ? resident_plan(atoi(form) == 6 ? max6 : max_wgs, run_wgs, nstreams) : resident_plan_two_forms(max_wgs, max6, run_wgs, nstreams, &parked);
+		if (form)
+			parked = atoi(form) == 6; // (units_per_launch 0: a stream does not fit - launch per frame)
 		const bool persistent = runs && errors_fit && plan.units_per_launch > 0 && !force_per_frame && !getenv("RIR_LOSSY_LAUNCH_PER_FRAME");
 		// streams per launch of the resident kernel: the launches the plan needs, filled evenly (32 streams at 9 per launch: 8, 8, 8, 8 - not 9, 9, 9, 5)
-		const int batch = persistent ? (nstreams + plan.launches - 1) / plan.launches : nstreams;
+		const int batch = persistent ? resident_batch(plan, nstreams) : nstreams;
 		const int group = std::max(1, (persistent ? 2048 : 512) / nstreams); // frames per histogram launch (one 64 KB histogram slice per frame and stream)
 		const int ngroups = runs ? (nsteps + group - 1) / group : 0;
 		const size_t nfused = persistent ? 0 : runs ? (size_t)(nsteps + 1) * nstreams : (size_t)nsteps * nstreams, nhist = runs ? (size_t)nsteps * nstreams : 0;

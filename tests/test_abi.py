@@ -140,6 +140,17 @@ def test_resident_capacity_rule_and_plan(lib):
     assert plan(0, 160, 3) == (0, 0)  # the runtime could not size the device: not resident
     assert plan(240, 256, 1) == (0, 0) and plan(240, 240, 2) == (1, 2)
     assert lib.rir_resident_plan(1, 1, 1, None) == -1
+    # a kernel in two forms (the resident loss kernel: 1 200 places at 5 waves per SIMD, 1 440 with part of its state parked in LDS):
+    # the larger, slower form only when it saves a launch - or when only it fits; launches filled evenly
+    lib.rir_resident_plan_two_forms.argtypes = [ct.c_int] * 4 + [ct.POINTER(ct.c_int)]
+    out3 = (ct.c_int * 3)()
+    for units, want in ((1, (1, 1, 0)), (7, (7, 1, 0)), (8, (8, 1, 1)), (9, (9, 1, 1)), (10, (5, 2, 0)), (14, (7, 2, 0)), (16, (8, 2, 1)),
+                        (18, (9, 2, 1)), (21, (7, 3, 0)), (32, (8, 4, 1)), (0, (0, 0, 0))):
+        assert lib.rir_resident_plan_two_forms(1200, 1440, 160, units, out3) == 0
+        assert tuple(out3) == want, (units, tuple(out3))
+    assert lib.rir_resident_plan_two_forms(100, 1440, 160, 3, out3) == 0 and tuple(out3) == (3, 1, 1)  # (only the second form holds a unit)
+    assert lib.rir_resident_plan_two_forms(100, 120, 160, 3, out3) == 0 and tuple(out3) == (0, 0, 0)  # (neither does: the caller's other path)
+    assert lib.rir_resident_plan_two_forms(1, 1, 1, 1, None) == -1
 
 
 def test_image_arrays_are_fresh_and_recycled_only_when_dead():
