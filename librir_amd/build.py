@@ -14,7 +14,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIBS = os.path.join(HERE, "libs")
 ROOT = os.path.dirname(HERE)
 LIB_NAME = "librir_amd.so"
-ALIASES = ["libtools.so", "libsignal_processing.so", "libvideo_io.so"]
+# the names the wrapper globs for, and the SONAMEs the reference's own libraries record for each other (SOVERSION = major
+# version, src/cpp/tools/CMakeLists.txt:83-84): the reference's libgeometry.so, which a drop-in keeps, NEEDs libtools.so.6
+ALIASES = ["libtools.so", "libsignal_processing.so", "libvideo_io.so", "libtools.so.6", "libsignal_processing.so.6", "libvideo_io.so.6"]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = [

@@ -435,6 +435,44 @@ RIR_EXPORT int get_last_log_error(char *text, int *len)
 	return 0;
 }
 
+// ---- the C++ names of the reference's tools/Log.h ------------------------------------------------------
+// The reference's libgeometry.so - which a drop-in keeps - is linked against libtools.so and binds
+// rir::logError (src/cpp/geometry/geometry.cpp:147,214; declared TOOLS_EXPORT in src/cpp/tools/Log.h:31-35).  ctypes loads
+// with RTLD_NOW, so the wrapper's loadDlls() (src/python/librir/low_level/misc.py:129-134) fails on the geometry line unless
+// the library that stands in for libtools.so exports the mangled names too.  All of Log.h:20-40 is here, forwarding to the
+// one log state above, so that a geometry built at another version still binds.
+#define RIR_CXX_EXPORT __attribute__((visibility("default")))
+namespace rir
+{
+	typedef print_function log_print_function; // Log.h:20
+	RIR_CXX_EXPORT void logInfo(const char *text) { log_message(LOG_INFO, text); }
+	RIR_CXX_EXPORT void logWarning(const char *text) { log_message(LOG_WARNING, text); }
+	RIR_CXX_EXPORT void logError(const char *text) { log_message(LOG_ERROR, text); }
+	RIR_CXX_EXPORT void set_log_function(log_print_function function)
+	{
+		std::lock_guard<std::mutex> g(log_mutex());
+		log_state().fn = function;
+		log_state().enabled = true;
+	}
+	RIR_CXX_EXPORT void disable_log()
+	{
+		std::lock_guard<std::mutex> g(log_mutex());
+		log_state().enabled = false;
+	}
+	RIR_CXX_EXPORT log_print_function log_function()
+	{
+		std::lock_guard<std::mutex> g(log_mutex());
+		return log_state().fn;
+	}
+	RIR_CXX_EXPORT void reset_log_function()
+	{
+		std::lock_guard<std::mutex> g(log_mutex());
+		log_state().fn = nullptr;
+		log_state().enabled = true;
+	}
+	RIR_CXX_EXPORT int getLastErrorLog(char *text, int *len) { return ::get_last_log_error(text, len); }
+} // namespace rir
+
 // The reference stores any BaseShared-derived object; here only objects created by this library
 // (rir::Object) can be registered.
 RIR_EXPORT int set_void_ptr(void *obj)

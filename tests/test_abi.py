@@ -39,8 +39,33 @@ def test_every_declared_symbol_is_exported(lib):
 
 def test_aliases_resolve_to_one_object():
     libs = os.path.join(ROOT, "librir_amd", "libs")
-    for alias in ["libtools.so", "libsignal_processing.so", "libvideo_io.so"]:
+    for alias in ["libtools.so", "libsignal_processing.so", "libvideo_io.so", "libtools.so.6", "libsignal_processing.so.6", "libvideo_io.so.6"]:
         assert os.path.realpath(os.path.join(libs, alias)) == os.path.realpath(os.path.join(libs, "librir_amd.so"))
+
+
+def test_cxx_log_names_of_the_reference_tools_library_are_exported():
+    # the reference's libgeometry.so binds rir::logError from libtools.so (geometry.cpp:147,214; Log.h:31-35): mangled names
+    out = os.popen("nm -D --defined-only %s" % os.path.join(ROOT, "librir_amd", "libs", "librir_amd.so")).read()
+    for sym in ["_ZN3rir8logErrorEPKc", "_ZN3rir7logInfoEPKc", "_ZN3rir10logWarningEPKc", "_ZN3rir15getLastErrorLogEPcPi",
+                "_ZN3rir16set_log_functionEPFviPKcE", "_ZN3rir11disable_logEv", "_ZN3rir12log_functionEv", "_ZN3rir18reset_log_functionEv"]:
+        assert " T %s\n" % sym in out, sym
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/python/librir"), reason="build container only: needs the reference's Python wrapper")
+def test_reference_wrapper_imports_and_runs_on_this_library():
+    """INTEGRATION.md section 1, executed: the reference's own `librir` package over librir_amd.so + its own libgeometry.so
+    (scripts/wrapper_drop_in_check.py; what it found is held in tests/golden/wrapper_drop_in.json)."""
+    import importlib.util
+    import json
+
+    spec = importlib.util.spec_from_file_location("wrapper_drop_in_check", os.path.join(ROOT, "scripts", "wrapper_drop_in_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    got = mod.run()
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "wrapper_drop_in.json")))
+    assert got == want
+    assert got["import"] == "ok" and got["last_log_error_after_geometry"] == "Wrong data type"
+    assert got["translate_without_device"] == "RuntimeError" and got["h264_add_image_lossless_without_device"] == "RuntimeError"
 
 
 def test_layout_query_is_pure_host(lib):
