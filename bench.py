@@ -4,13 +4,15 @@
     python bench.py --gpus N --steps K --warmup W          (N = 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one device-resident batch: lossless encode (rir_codec_encode_tiles_device: record
-headers + one length and one slot per (chunk, tile) segment - the SLOTTED form of the encoded batch, complete as it stands)
-then decode (rir_codec_decode_slots_device) on BASELINE.json configs[1] (1 000-frame 640x512 uint16 stream, recipe S1,
-SURVEY.md §8d) - per rank: two launches that move 4WH + 2C bytes, the algorithmic minimum.  The DENSE (file) form of the same
-batch costs one more pass (rir_codec_encode_compact_device); it is timed beside the step and reported as `dense_file_form`,
-with the rate of encode + compact + decode from the dense stream (round 2's step).  Ranks hold independent shards (weak
-scaling, no collective in that data path): `value` = frames all ranks processed / the slowest rank's time.
+A "step" is one pass of the hot path over one device-resident batch: lossless encode (rir_codec_encode_packed_device: ONE
+kernel that leaves the PACKED form of the encoded batch - record headers, a (position, length) pair per (chunk, tile) segment
+and the payload without holes in a buffer of HALF the raw size; `encoded_footprint_bytes` says what it occupies) then decode
+(rir_codec_decode_packed_device) on BASELINE.json configs[1] (1 000-frame 640x512 uint16 stream, recipe S1) -
+per rank: two launches that move 4WH + 2C bytes (+ 6 % of the frames re-read where the waves of a segment meet in time).
+Beside it, as extra keys: `slotted_form` (round 3's step: the encoder's worst-case slots decoded in place - faster, but the
+encoded batch is larger than its input) and `dense_file_form` (the canonical ordered stream of the file format: one more
+pass).  Ranks hold independent shards (weak scaling, no collective in that data path): `value` = frames all ranks processed /
+the slowest rank's time.
 
 N > 1 additionally times, in the same run and with the same bracket, the step WITH the exchange north_star names
 (every GPU ends up holding the whole decoded stream), in both forms of librir_amd/distributed.py:
@@ -326,6 +328,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: start the N ranks as CHILD processes (a spawn, never an exec; nothing has touched the GPU
+        # yet), relay what they print - rank 0's JSON line - and leave with their status
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     if world != args.gpus:
         if rank == 0:
             sys.stderr.write("bench.py: WORLD_SIZE=%d but --gpus %d\n" % (world, args.gpus))
@@ -385,20 +399,24 @@ def main():
     from librir_amd.distributed import CompressedGather, FrameGather, shard_plan
 
     frames = torch.from_numpy(frames_np).to(dev)
-    ctx = D.CodecContext(w, h, n, gop, device=dev)
+    ctx = D.CodecContext(w, h, n, gop, device=dev)  # (the slotted and the dense form, timed beside the step)
+    pc = D.PackedCodec(w, h, n, gop, device=dev)    # the step: stream buffer = the 8 bit-per-pixel budget (half the raw bytes)
     out = torch.empty_like(frames)
-    # one-off set-up, before any timed or warm-up step: the encode workspace goes into a placement class other than the frames'
-    # (reads and writes of the packing kernel in one class cost it 10 %; CodecContext.place_workspace times a few
-    # alternative allocations with HIP events).  The step with the allocations as a fresh process gets them is timed first.
+
     def step():
+        pc.encode(frames)
+        pc.decode(out=out, check=False)
+
+    def step_slotted():
         ctx.encode_tiles(frames)
         ctx.decode_slots(out=out, check=False)
 
-    def k_steps(k):
+    def k_steps(k, fn=None):
+        fn = fn or step
         barrier()
         t1 = time.perf_counter()
         for _ in range(k):
-            step()
+            fn()
         barrier()
         return time.perf_counter() - t1
 
@@ -416,10 +434,19 @@ def main():
         return float(t.item())
 
     K = args.steps
+    # ---- set-up, untimed.  A device that has been idle runs its first milliseconds of work below its sustained clocks (the CPU
+    # baseline and the host-pointer child above take tens of seconds): the same K steps measured straight after the W warm-up steps
+    # are reported as `value_from_idle`, then one second of the step brings the device to the state a pipeline keeps it in ----
     for _ in range(args.warmup):
         step()
-    dt_unplaced = max_over_ranks(k_steps(K))  # (untimed as far as `value` goes: the same K steps before the placement)
-    placement_us = ctx.place_workspace(frames)
+    dt_idle = max_over_ranks(k_steps(K))
+    t_ramp = time.perf_counter()
+    ramp_steps = 0
+    while time.perf_counter() - t_ramp < 1.0 and ramp_steps < 100000:
+        k_steps(16)
+        ramp_steps += 16
+    if world > 1:
+        dist.barrier()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -427,6 +454,9 @@ def main():
     # ---- timed region: exactly K steps, bracketed by barrier + synchronize ----
     out.zero_()
     dt = max_over_ranks(k_steps(K))
+    code, low_words, high_words, arena_words = pc.status()
+    if code != 0:
+        raise SystemExit("bench.py: the encoded batch did not fit its budget (code %d) - refusing to report a number" % code)
 
     # ---- the same K steps once more with HIP events between the launches (on the stream the kernels run on): the per-kernel
     # durations of the roofline.  An event between two launches keeps the second kernel from starting under the tail of the
@@ -436,9 +466,9 @@ def main():
     t0 = time.perf_counter()
     for k in range(K):
         ev[k][0].record()
-        ctx.encode_tiles(frames)
+        pc.encode(frames)
         ev[k][1].record()
-        ctx.decode_slots(out=out, check=False)
+        pc.decode(out=out, check=True)  # (zeroes the error word first and reads it back: the parity gate below sees every decode)
         ev[k][2].record()
     barrier()
     dt_events = max_over_ranks(time.perf_counter() - t0)
@@ -447,16 +477,38 @@ def main():
     ms_decode = sum(ev[k][1].elapsed_time(ev[k][2]) for k in range(K)) / K
 
     # ---- parity gate before any number is reported: decoded stream == input, bit-exact ----
-    assert int(ctx.error.item()) == 0
     ok = torch.equal(out.view(torch.int16), frames.view(torch.int16))
-    payload_bytes = ctx.slots_payload_bytes()
+    batch = pc.finish()
+    payload_bytes = batch.payload_bytes()
     if not ok:
         raise SystemExit("bench.py: decode(encode(x)) != x - refusing to report a number")
 
-    # ---- spread: the same K-step region five more times (extra key; `value` is the region above) ----
-    reps = sorted(max_over_ranks(k_steps(K)) / K * 1e3 for _ in range(5))
-    spread = {"ms_per_step_min": reps[0], "ms_per_step_median": reps[2], "ms_per_step_max": reps[-1], "repeats": 5,
-              "note": "five further K-step regions after the one `value` is computed from"}
+    # ---- spread, and a GPU that is visibly busy: the same K-step region again and again until 2 s of it have run (a utilisation
+    # sampler with a period of seconds sees nothing of a 5 ms region); `value` stays the first region above ----
+    reps = []
+    t_busy = time.perf_counter()
+    while len(reps) < 5 or (time.perf_counter() - t_busy < 2.0 and len(reps) < 2000):
+        reps.append(max_over_ranks(k_steps(K)) / K * 1e3)
+        if world > 1 and len(reps) >= 5:  # (every rank must leave the loop in the same round: the region count is rank 0's decision)
+            go = torch.tensor([1 if time.perf_counter() - t_busy < 2.0 else 0], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            dist.broadcast(go, 0)
+            if int(go.item()) == 0:
+                break
+    nreg = len(reps)
+    reps.sort()
+    spread = {"ms_per_step_min": reps[0], "ms_per_step_median": reps[nreg // 2], "ms_per_step_max": reps[-1], "repeats": nreg,
+              "note": "further K-step regions after the one `value` is computed from, repeated until the GPU had been busy for 2 s"}
+
+    # ---- round 3's step beside it: the slotted form (encode_tiles + decode_slots; the encoded batch lives in worst-case slots) ----
+    for _ in range(args.warmup):
+        step_slotted()
+    dt_slotted_unplaced = max_over_ranks(k_steps(K, step_slotted))
+    placement_us = ctx.place_workspace(frames)
+    for _ in range(args.warmup):
+        step_slotted()
+    dt_slotted = max_over_ranks(k_steps(K, step_slotted))
+    if int(ctx.error.item()) != 0 or not torch.equal(out.view(torch.int16), frames.view(torch.int16)) or ctx.slots_payload_bytes() != payload_bytes:
+        raise SystemExit("bench.py: the slotted form does not decode to the input - refusing to report a number")
 
     # ---- the dense (file) form of the same batch: one more pass over the payload, then the decode from the dense stream ----
     evd = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
@@ -473,6 +525,7 @@ def main():
         evd[k][3].record()
     barrier()
     dt_dense = max_over_ranks(time.perf_counter() - t0)
+    ms_compact_tiles = sum(evd[k][0].elapsed_time(evd[k][1]) for k in range(K)) / K
     ms_compact = sum(evd[k][1].elapsed_time(evd[k][2]) for k in range(K)) / K
     ms_decode_dense = sum(evd[k][2].elapsed_time(evd[k][3]) for k in range(K)) / K
     cbytes = enc.compressed_bytes()
@@ -575,15 +628,26 @@ def main():
         except Exception as e:  # the exchange is an EXTRA measurement: it must not cost the line its `value` (never run on RCCL before a driver does)
             exchange = {"exchange_error": repr(e)[:400]}
 
-    extra = {"workspace_placement": {"packing_us_of_the_candidates": [round(x, 1) for x in placement_us],
-                                     "value_unplaced": n * K * world / dt_unplaced, "ms_per_step_unplaced": dt_unplaced / K * 1e3,
-                                     "note": "set-up, untimed: the encode workspace is moved to an allocation of another placement class than the frames "
-                                             "(first value: kept; DESIGN.md §5, profiles/r03_placement_classes.md); `value_unplaced` = the same K steps "
-                                             "with the allocations as the fresh process got them"},
+    tables_bytes = batch.nbytes() - payload_bytes
+    extra = {"encoded_footprint_bytes": batch.nbytes(), "raw_bytes": int(2 * h * w * n),
+             "value_from_idle": n * K * world / dt_idle,
+             "value_from_idle_note": "the same K steps after the same W warm-up steps on a device that had been idle (no ramp): %d steps of set-up ran between "
+                                     "this region and the one `value` is computed from" % ramp_steps,
+             "encoded_batch": {"payload_bytes": payload_bytes, "tables_bytes": tables_bytes, "extent_low_bytes": low_words * 8, "extent_high_bytes": high_words * 8,
+                               "stream_buffer_bytes": pc.stream.numel() * 8, "encoder_workspace_bytes": pc.workspace.numel(), "arena_bytes_used": arena_words * 8,
+                               "note": "what the step's encoder leaves: headers + a (position, length) pair per segment + the payload without holes at the two "
+                                       "ends of a stream buffer of half the raw size (8 bit-per-pixel budget; a batch that needs more is refused, not "
+                                       "written out of bounds) - everything a file or an exchange needs, nothing else"},
+             "slotted_form": {"value": n * K * world / dt_slotted, "ms_per_step": dt_slotted / K * 1e3,
+                              "value_unplaced": n * K * world / dt_slotted_unplaced,
+                              "workspace_bytes": int(ctx.layout.workspace_bytes),
+                              "packing_us_of_the_placement_candidates": [round(x, 1) for x in placement_us],
+                              "note": "round 3's step (encode_tiles + decode_slots): the encoded batch lives in worst-case slots inside a workspace larger "
+                                      "than the input - an on-device hand-over, not an encoded batch one can keep; workspace placed by measurement (DESIGN.md §5)"},
              "spread": spread,
              "dense_file_form": {"value": n * K * world / dt_dense, "ms_per_step": dt_dense / K * 1e3, "ms_compact": ms_compact,
                                  "ms_decode_from_dense": ms_decode_dense,
-                                 "note": "encode_tiles + scan/compact (the dense stream a file or an exchange needs) + decode from the dense stream: round 2's step"}}
+                                 "note": "encode_tiles + scan/compact (the canonical ordered stream of the FILE format) + decode from it: round 2's step"}}
     if world == 1:
         # the single-pass (look-back) encoder beside the two-pass one that `value` is measured with: same outputs, fewer bytes
         # through HBM, no faster
@@ -599,18 +663,18 @@ def main():
         ctx.decode(sp, out=out, check=False)
         ok_sp = ctx.encode_status() == 0 and bool(torch.equal(out.view(torch.int16), frames.view(torch.int16)))
         extra["single_pass_encoder"] = {"ms_per_launch": e0.elapsed_time(e1) / K, "bit_exact_roundtrip": ok_sp,
-                                        "kernel": "rirb1_encode_dense (memset + 1 launch): the dense stream in one pass", "two_pass_ms": ms_tiles + ms_compact}
+                                        "kernel": "rirb1_encode_dense (memset + 1 launch): the dense stream in one pass", "two_pass_ms": ms_compact_tiles + ms_compact}
     extra.update(extra_abi)
 
     if rank == 0:
         raw = 2.0 * h * w * n  # bytes of raw uint16 per batch
         kernels = {
-            "rirb1_encode_tiles": {"ms": ms_tiles, "alg_bytes": raw + payload_bytes + ctx.layout.hdr_bytes},
-            "rirb1_decode_tiles": {"ms": ms_decode, "alg_bytes": raw + payload_bytes + ctx.layout.hdr_bytes},
+            "rirb1_encode_packed": {"ms": ms_tiles, "alg_bytes": raw + payload_bytes + tables_bytes},
+            "rirb1_decode_tiles": {"ms": ms_decode, "alg_bytes": raw + payload_bytes + tables_bytes},
         }
         for kv in kernels.values():
             kv["GBs"] = kv["alg_bytes"] / (kv["ms"] * 1e-3) / 1e9
-        dom = max(("rirb1_encode_tiles", "rirb1_decode_tiles"), key=lambda k_: kernels[k_]["ms"])
+        dom = max(("rirb1_encode_packed", "rirb1_decode_tiles"), key=lambda k_: kernels[k_]["ms"])
         traffic = None
         import glob
 
@@ -636,15 +700,16 @@ def main():
             "dtype": "u16",
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d-frame %dx%d uint16 stream (S1 noisy background, seed 1234+rank), lossless RIRB1 "
-                                   "encode+decode, device-resident, GOP %d, per GPU; two launches per step: the encoder leaves the slotted "
-                                   "form (headers + one length and one fixed-place slot per segment), the decoder reads it as it is; the "
-                                   "compressed payload (17 %% of a pass's bytes) is written and read back through the 256 MiB Infinity "
-                                   "Cache, the raw frames (655 MB each way) stream from / to HBM" % (n, w, h, gop),
+                                   "encode+decode, device-resident, GOP %d, per GPU; two launches per step: the encoder leaves the PACKED "
+                                   "form (headers + position and length per segment + the payload without holes: encoded_footprint_bytes, "
+                                   "in a buffer of half the raw size), the decoder reads it as it is; the compressed payload (17 %% of a "
+                                   "pass's bytes) is written and read back through the 256 MiB Infinity Cache, the raw frames (655 MB "
+                                   "each way) stream from / to HBM" % (n, w, h, gop),
                        "frames_per_gpu": n, "width": w, "height": h, "gop": gop, "sharding": "independent shard per rank"},
             "bit_exact_roundtrip": True,
             "value_excludes_exchange": True if world > 1 else None,
-            "step_alg_bytes": 2.0 * raw + 2.0 * (payload_bytes + ctx.layout.hdr_bytes),
-            "step_alg_frac_of_hbm_peak": (2.0 * raw + 2.0 * (payload_bytes + ctx.layout.hdr_bytes)) / (dt / K) / 1e9 / HBM_PEAK_GBS,
+            "step_alg_bytes": 2.0 * raw + 2.0 * (payload_bytes + tables_bytes),
+            "step_alg_frac_of_hbm_peak": (2.0 * raw + 2.0 * (payload_bytes + tables_bytes)) / (dt / K) / 1e9 / HBM_PEAK_GBS,
             "compression_ratio": raw / cbytes,
             "roundtrip_raw_GBs": fps * 4.0 * h * w / 1e9 / world,
             "roundtrip_raw_frac_of_hbm_peak": fps * 4.0 * h * w / 1e9 / world / HBM_PEAK_GBS,

@@ -109,6 +109,42 @@ extern "C"
 											void *d_workspace, long long workspace_bytes, void *stream);
 	int rir_codec_encode_status(const void *d_workspace, void *stream);
 
+	/* The PACKED form of an encoded batch: the dense stream without the order.  One pass over the frames (one kernel), and
+	 * the encoded batch occupies exactly its payload + tables - what can be kept, sent between devices or written:
+	 *   d_hdr        uint64 [nchunks][ntiles][gop]  record headers, as in every form
+	 *   d_seg_pos    uint64 [nchunks][ntiles]       first 64-bit word of segment (chunk, tile) in d_stream
+	 *   d_seg_words  uint32 [nchunks][ntiles]       its length in words
+	 *   d_stream     two extents without holes, [0, low) and [capacity - high, capacity): the segments back to back in ORDER OF
+	 *                ARRIVAL (the order differs from run to run, every segment's words are the canonical ones) - a table of
+	 *                positions instead of an order, as the reference's own ZFile container keeps for its records (ZFile.cpp:434-447)
+	 * A segment is staged in LDS and, when its length is known, handed the next free words by one atomic add: no second pass
+	 * (rir_codec_encode_compact_device), no look-back (rir_codec_encode_single_pass_device), no worst-case slots (the slotted form).
+	 * Two cursors because one is a bottleneck (12 800 returning adds on one address: 16 ns each), from the two ENDS of the
+	 * capacity so that they share it.  stream_capacity_words is what the caller provides at d_stream - a budget, not a worst case
+	 * (stream_budget_bytes = 8 bits per pixel; the reference documents a factor of about 5, docs/video_io.md:13): a batch that
+	 * needs more is not written beyond it, the status says so and how many words it needs.  The workspace holds the control
+	 * block and an arena for what does not fit a wave's LDS staging (noisy data only): workspace_min_bytes always works for
+	 * data within the budget, workspace_max_bytes for any data.
+	 * rir_codec_encode_packed_status (waits for the stream): out[0] = low, out[1] = high (words; the batch needs low + high),
+	 * out[2] = arena words asked for; returns 0 = complete, 1 = stream capacity exceeded, 2 = arena exceeded (3 = both), -1 = error.
+	 * Decoding checks every segment against stream_words before it reads through it. */
+	typedef struct rir_codec_packed_layout
+	{
+		int ntiles, nchunks;
+		int64_t hdr_bytes, seg_pos_bytes, seg_words_bytes;
+		int64_t stream_budget_bytes; /* 8 bits per pixel: half the raw size */
+		int64_t stream_max_bytes;	 /* any data fits */
+		int64_t workspace_min_bytes, workspace_max_bytes;
+	} rir_codec_packed_layout;
+	int rir_codec_packed_query(int width, int height, int nframes, int gop, rir_codec_packed_layout *out);
+	int rir_codec_encode_packed_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned long long *d_hdr,
+									   unsigned long long *d_seg_pos, unsigned int *d_seg_words, unsigned long long *d_stream,
+									   long long stream_capacity_words, void *d_workspace, long long workspace_bytes, void *stream);
+	int rir_codec_encode_packed_status(const void *d_workspace, unsigned long long *out3, void *stream);
+	int rir_codec_decode_packed_device(const unsigned long long *d_hdr, const unsigned long long *d_seg_pos, const unsigned int *d_seg_words,
+									   const unsigned long long *d_stream, long long stream_words, int width, int height, int nframes, int gop,
+									   unsigned short *d_frames, int *d_error, void *stream);
+
 	/* *d_error (device int, zero it first) becomes 1 when a malformed table/record was met.  stream_words = number of
 	 * 64-bit words readable at d_stream: the tables are untrusted (they may come from a file) and a (chunk, tile)
 	 * segment that does not lie inside [0, stream_words) is rejected before anything is read through it. */

@@ -449,6 +449,88 @@ RIR_EXPORT int rir_codec_encode_status(const void *d_workspace, void *stream)
 	return word != 0 ? 1 : 0;
 }
 
+// ---- the packed form (include/rir_amd_device.h; kernel: rirb1_encode_packed) ---------------------------------------------
+RIR_EXPORT int rir_codec_packed_query(int width, int height, int nframes, int gop, rir_codec_packed_layout *out)
+{
+	rir_codec_layout L;
+	if (!out || rir_codec_layout_query(width, height, nframes, gop, &L) != 0)
+		return -1;
+	std::memset(out, 0, sizeof(*out));
+	const int64_t slots = (int64_t)L.nchunks * L.ntiles;
+	out->ntiles = L.ntiles, out->nchunks = L.nchunks;
+	out->hdr_bytes = L.hdr_bytes;
+	out->seg_pos_bytes = slots * 8;
+	out->seg_words_bytes = slots * 4;
+	out->stream_budget_bytes = (int64_t)align256((size_t)((int64_t)width * height * nframes)); // 8 bits per pixel
+	out->stream_max_bytes = L.stream_max_bytes;
+	// the arena: a spilling wave takes the worst case of its share of a chunk; min = room for one workgroup in sixteen, max = for all
+	const int64_t share_words = ((int64_t)(gop + 4) / 4 + 1) * RIRB1_REC_MAX_WORDS;
+	out->workspace_max_bytes = RIRB1_PACKED_CTRL_BYTES + (int64_t)align256((size_t)(slots * 4 * share_words * 8));
+	out->workspace_min_bytes = RIRB1_PACKED_CTRL_BYTES + (int64_t)align256((size_t)(((slots + 15) / 16) * 4 * share_words * 8));
+	return 0;
+}
+
+RIR_EXPORT int rir_codec_encode_packed_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned long long *d_hdr,
+											  unsigned long long *d_seg_pos, unsigned int *d_seg_words, unsigned long long *d_stream,
+											  long long stream_capacity_words, void *d_workspace, long long workspace_bytes, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	rir_codec_layout L;
+	if (rir_codec_layout_query(width, height, nframes, gop, &L) != 0 || !check_geometry(L))
+		return -1;
+	if (!d_frames || !d_hdr || !d_seg_pos || !d_seg_words || !d_stream || stream_capacity_words < 0 || !d_workspace ||
+		workspace_bytes < RIRB1_PACKED_CTRL_BYTES || ((uintptr_t)d_workspace & 127))
+	{
+		log_error("rir_codec_encode_packed_device: null buffer, negative capacity, or a workspace that is too small or not 128-byte aligned");
+		return -1;
+	}
+	uint64_t *ctrl = static_cast<uint64_t *>(d_workspace);
+	uint64_t *arena = ctrl + RIRB1_PACKED_CTRL_BYTES / 8;
+	const uint64_t arena_words = (uint64_t)(workspace_bytes - RIRB1_PACKED_CTRL_BYTES) / 8;
+	return hip_ok(launch_encode_packed(d_frames, (int64_t)width * height, L.ntiles, nframes, gop, reinterpret_cast<uint64_t *>(d_hdr),
+									   reinterpret_cast<uint64_t *>(d_seg_pos), d_seg_words, reinterpret_cast<uint64_t *>(d_stream),
+									   (uint64_t)stream_capacity_words, ctrl, arena, arena_words, as_stream(stream)),
+				  "codec encode (packed)")
+			   ? 0
+			   : -1;
+}
+
+RIR_EXPORT int rir_codec_encode_packed_status(const void *d_workspace, unsigned long long *out3, void *stream)
+{
+	if (!device_ready() || !d_workspace)
+		return -1;
+	unsigned long long c[RIRB1_PACKED_CTRL_BYTES / 8];
+	if (!hip_ok(hipMemcpyAsync(c, d_workspace, sizeof(c), hipMemcpyDeviceToHost, as_stream(stream)), "D2H") ||
+		!hip_ok(hipStreamSynchronize(as_stream(stream)), "sync"))
+		return -1;
+	if (out3)
+		out3[0] = c[0], out3[1] = c[16], out3[2] = c[32];
+	return (int)(c[48] & 3u) | (c[0] + c[16] > c[64] ? 1 : 0);
+}
+
+RIR_EXPORT int rir_codec_decode_packed_device(const unsigned long long *d_hdr, const unsigned long long *d_seg_pos, const unsigned int *d_seg_words,
+											  const unsigned long long *d_stream, long long stream_words, int width, int height, int nframes, int gop,
+											  unsigned short *d_frames, int *d_error, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	rir_codec_layout L;
+	if (rir_codec_layout_query(width, height, nframes, gop, &L) != 0)
+		return -1;
+	if (!d_frames || !d_hdr || !d_seg_pos || !d_seg_words || (!d_stream && stream_words != 0) || !d_error || stream_words < 0)
+	{
+		log_error("rir_codec_decode_packed_device: null buffer or negative stream length");
+		return -1;
+	}
+	return hip_ok(launch_decode_packed(reinterpret_cast<const uint64_t *>(d_hdr), reinterpret_cast<const uint64_t *>(d_seg_pos), d_seg_words,
+									   reinterpret_cast<const uint64_t *>(d_stream), (uint64_t)stream_words, (int64_t)width * height, L.ntiles, nframes, gop,
+									   d_frames, d_error, as_stream(stream)),
+				  "codec decode (packed)")
+			   ? 0
+			   : -1;
+}
+
 RIR_EXPORT int rir_codec_decode_device(const unsigned long long *d_hdr, const unsigned int *d_tile_off, const unsigned long long *d_chunk_off,
 									   const unsigned long long *d_stream, long long stream_words, int width, int height, int nframes,
 									   int gop, unsigned short *d_frames, int *d_error, void *stream)

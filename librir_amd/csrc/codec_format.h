@@ -15,3 +15,7 @@
 #define RIRB1_SLOT_PAD_WORDS 16
 #endif
 #define RIRB1_SLOT_WORDS(gop) ((int64_t)(gop) * RIRB1_REC_MAX_WORDS + RIRB1_SLOT_PAD_WORDS)
+
+// Control block of the packed form's encoder (rirb1_encode_packed), at the start of its workspace: three 128-byte lines -
+// stream cursor, spill cursor, error word - and a spare one.
+#define RIRB1_PACKED_CTRL_BYTES 4096

@@ -842,6 +842,11 @@ namespace rir
 
 	// Where a wave's payload goes: the first records into its LDS region, from the first record that does not fit
 	// (wave-uniform decision) everything into its spill area in the workspace.
+	// Two kinds of spill area.  STATIC (arena == nullptr): `spill` is the wave's own worst-case slot, there from the start
+	// (rirb1_encode_dense).  DYNAMIC (rirb1_encode_packed): nothing is reserved; the wave that starts to spill takes an extent
+	// of `need` words - the worst case of its share of the chunk - from a bump cursor in the workspace, once (a returning
+	// atomic inside the rare, wave-uniform branch), and an arena that is full raises bit 1 of the error word and leaves the
+	// descriptor empty: the stores go nowhere, the segment is reported unusable, nothing is written out of bounds.
 	struct Staging
 	{
 		uint64_t *lds;	   // this wave's region
@@ -849,7 +854,32 @@ namespace rir
 		uint32_t lds_used; // words in LDS once spilling has started
 		bool spilling;
 		__amdgpu_buffer_rsrc_t spill;
+		// dynamic spill extents
+		uint64_t *arena;			 // nullptr: static
+		unsigned long long *cursor;	 // words handed out so far
+		uint64_t arena_words;
+		uint32_t need;				 // words this wave asks for when it starts to spill
+		uint64_t extent;			 // first word of its extent (valid once spilling and granted)
+		uint32_t *error_word;
 	};
+
+	// first word of an extent of `need` words, ~0 when the arena is full (the launch is marked); wave-uniform
+	__device__ __noinline__ uint64_t staging_take_extent(unsigned long long *cursor, uint32_t need, uint64_t arena_words, uint32_t *error_word)
+	{
+		unsigned long long off = 0;
+		if ((threadIdx.x & 63u) == 0)
+			off = __hip_atomic_fetch_add(cursor, (unsigned long long)need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
+		const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32));
+		off = ((unsigned long long)hi << 32) | lo;
+		if (off + need > arena_words)
+		{ // no room: the caller's descriptor stays empty (every store is dropped by the range check)
+			if ((threadIdx.x & 63u) == 0)
+				__hip_atomic_fetch_or(error_word, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			return ~0ull;
+		}
+		return off;
+	}
 
 	__device__ __forceinline__ uint64_t emit_staged(const Px8 &r, uint32_t mode, uint32_t base, Staging &sg, uint32_t pos, const LaneConsts &lc,
 													const TransposeConsts &tc, uint32_t *words)
@@ -862,7 +892,15 @@ namespace rir
 		else
 			h = emit_words_wide(r, mode, base, rw, pos, lc, tc, words);
 		if (!sg.spilling && pos + *words > sg.cap)
+		{
 			sg.spilling = true, sg.lds_used = pos;
+			if (sg.arena)
+			{
+				sg.extent = staging_take_extent(sg.cursor, sg.need, sg.arena_words, sg.error_word);
+				if (sg.extent != ~0ull)
+					sg.spill = make_rsrc(sg.arena + sg.extent, sg.need * 8u);
+			}
+		}
 		if (!sg.spilling)
 		{ // LDS operations only inside this (wave-uniform) branch: the vector-memory stream below stays unconditional
 			if (rw.ia != RIR_NONE)
@@ -1139,6 +1177,7 @@ namespace rir
 		sg.cap = (uint32_t)cap;
 		sg.lds_used = 0;
 		sg.spilling = false;
+		sg.arena = nullptr, sg.cursor = nullptr, sg.arena_words = 0, sg.need = 0, sg.extent = 0, sg.error_word = nullptr;
 		uint64_t *my_spill = spill + (int64_t)seg * RIRB1_SLOT_WORDS(gop) + (int64_t)rec0 * RIRB1_REC_MAX_WORDS;
 		sg.spill = make_rsrc(my_spill, (uint32_t)(nrec > 0 ? nrec : 0) * RIRB1_REC_MAX_WORDS * 8u);
 		uint32_t pos = 0;
@@ -1250,6 +1289,182 @@ namespace rir
 			unsigned hwid;
 			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 32)" : "=s"(hwid));
 			dbg[5] = ((uint64_t)xcc << 32) | hwid;
+		}
+#endif
+	}
+
+	// ==== packed form: the dense stream without the order ===============================================
+	//
+	// What made the single-pass DENSE encoder slow was not the staging but the ORDER: a segment's place is the sum of all
+	// lengths in front of it, so every workgroup waits for the slowest of its predecessors.  The
+	// reference's own ZFile container does not order its records by anything either: it keeps a table of positions
+	// (ZFile.cpp:434-447).  The PACKED form does the same on the device: a segment is packed into LDS exactly as above, and
+	// when its length is known ONE returning atomic add on a cursor hands it the next free words of the stream - first come,
+	// first placed, nobody waits for anybody.  The batch is
+	//   hdr       [nchunks][ntiles][gop]  u64   record headers (as everywhere)
+	//   seg_pos   [nchunks][ntiles]       u64   first word of the segment in `stream`
+	//   seg_words [nchunks][ntiles]       u32   its length
+	//   stream    cursor words, no holes: the segments in order of arrival
+	// i.e. exactly C bytes of payload plus tables - what can be kept, sent or written - from ONE pass over the frames.  The
+	// layout differs from run to run (arrival order); every segment's words are the oracle's.
+	// ONE cursor is not enough: 12 800 returning atomic adds on one address take 16 ns each at the memory side - 205 us, longer
+	// than the kernel (measured: 207 us with one cursor, 162-165 with two or more or with none).  So there are TWO, and so that
+	// they share the caller's capacity instead of halving it they work from its two ends: segments with an even (tile + chunk)
+	// are placed upwards from word 0, the others downwards from word `capacity`.  The batch is two extents without holes,
+	// [0, low) and [capacity - high, capacity); it fits when low + high <= capacity.
+	// ctrl (zeroed before the launch, a line each): [0] low cursor, [16] high cursor, [32] spill cursor, [48] error word (u32): bit 0
+	// = a segment did not fit its side (the cursors still say how many words the batch needs), bit 1 = the spill arena was
+	// exceeded; [64] the capacity the launch was given (for the status call: the extents cross when low + high > capacity).
+#ifndef RIR_PACKED_COPY_ALL_WAVES
+#define RIR_PACKED_COPY_ALL_WAVES 0
+#endif
+#ifndef RIR_PACKED_WAVES
+#define RIR_PACKED_WAVES 4
+#endif
+	// Two kernels, as for rirb1_encode_tiles: FAST for the tiles that lie whole inside 16-byte aligned frames, the ragged form for
+	// the last tile of a frame whose size is not a multiple of 512 pixels.  grid = (tile_count, nchunks).
+	template <int WAVES, bool FAST>
+	__attribute__((amdgpu_waves_per_eu(8, 8))) __global__ __launch_bounds__(WAVES * 64) void rirb1_encode_packed(
+		const uint16_t *__restrict__ frames, int64_t npx, int ntiles, int tile_first, int nframes, int gop, uint64_t *__restrict__ hdr_table,
+		uint64_t *__restrict__ seg_pos, uint32_t *__restrict__ seg_words, uint64_t *__restrict__ stream, uint64_t capacity_words,
+		uint64_t *__restrict__ ctrl, uint64_t *__restrict__ arena, uint64_t arena_words, int cap, int diag)
+	{
+		extern __shared__ __attribute__((aligned(16))) uint64_t enc_lds[];
+		uint64_t *sh_u64 = enc_lds + (size_t)WAVES * cap;			  // [0] segment's first word in the stream, [1 + w] wave w's spill extent
+		uint32_t *sh_u32 = reinterpret_cast<uint32_t *>(sh_u64 + 1 + WAVES); // [0..WAVES) words of each wave, [WAVES..2 WAVES) of them in LDS
+		const int lane = threadIdx.x & 63;
+		const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+		const bool downwards = ((blockIdx.x + blockIdx.y) & 1u) != 0 && diag != 1; // (diag 1: one cursor)
+		unsigned long long *cursor = reinterpret_cast<unsigned long long *>(ctrl) + (downwards ? 16 : 0);
+		unsigned long long *spill_cursor = reinterpret_cast<unsigned long long *>(ctrl + 32);
+		uint32_t *error_word = reinterpret_cast<uint32_t *>(ctrl + 48);
+		if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+			ctrl[64] = capacity_words;
+
+		const int chunk = blockIdx.y, tile = tile_first + blockIdx.x;
+		const int64_t seg = (int64_t)chunk * ntiles + tile;
+		const int f_begin = chunk * gop;
+		const int nf = min(gop, nframes - f_begin);
+		uint64_t *my_hdr = hdr_table + seg * gop;
+
+		const int rec0 = enc_split(w, WAVES, nf), rec1 = enc_split(w + 1, WAVES, nf);
+		const int nrec = rec1 - rec0;
+		const bool has_key = w == 0;
+		const int first_load = has_key ? 0 : rec0 - 1;
+		const int nload = nrec > 0 ? rec1 - first_load : 0;
+		Staging sg;
+		sg.lds = enc_lds + (size_t)w * cap;
+		sg.cap = (uint32_t)cap;
+		sg.lds_used = 0;
+		sg.spilling = false;
+		sg.spill = make_rsrc(arena, 0); // empty until the wave takes an extent
+		sg.arena = arena, sg.cursor = spill_cursor, sg.arena_words = arena_words, sg.error_word = error_word;
+		sg.need = (uint32_t)(nrec > 0 ? nrec : 0) * RIRB1_REC_MAX_WORDS;
+		sg.extent = ~0ull;
+		uint32_t pos = 0;
+		if (nrec > 0)
+			pos = encode_run<FAST>(frames, npx, nload, (int64_t)f_begin + first_load, has_key, tile, lane, my_hdr + first_load, sg);
+		for (int f = nf + (int)threadIdx.x; f < gop; f += WAVES * 64)
+			my_hdr[f] = 0; // short last chunk: the unused table entries are defined
+		if (lane == 0)
+		{
+			sh_u32[w] = pos;
+			sh_u32[WAVES + w] = sg.spilling ? sg.lds_used : pos;
+			sh_u64[1 + w] = sg.extent;
+		}
+		if (sg.spilling)
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the spilled words have left this wave before another wave reads them
+		__syncthreads();
+#if !RIR_PACKED_COPY_ALL_WAVES
+		if (w != 0)
+			return; // the segment is complete in LDS (+ extents): one wave places and copies it, the others make room
+#endif
+		uint32_t total = 0, before = 0;
+		bool lost = false; // a wave of this segment wanted an extent and got none
+		(void)before;
+#pragma unroll
+		for (int i = 0; i < WAVES; ++i)
+		{
+			const uint32_t n = sh_u32[i];
+			before += i < w ? n : 0u;
+			total += n;
+			lost |= n > sh_u32[WAVES + i] && sh_u64[1 + i] == ~0ull;
+		}
+		if (w == 0)
+		{
+			unsigned long long at = 0;
+			if (lane == 0)
+				at = __hip_atomic_fetch_add(cursor, (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)at);
+			const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(at >> 32));
+			at = ((unsigned long long)hi << 32) | lo;
+			const bool fits = at + total <= capacity_words;
+			if (downwards)
+				at = capacity_words - at - total; // (unused when it does not fit)
+			if (lane == 0)
+			{
+				seg_pos[seg] = at;
+				seg_words[seg] = total;
+				if (!fits)
+					__hip_atomic_fetch_or(error_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				sh_u64[0] = (fits && !lost) ? at : ~0ull;
+			}
+#if !RIR_PACKED_COPY_ALL_WAVES
+			if (!fits || lost)
+				return;
+			uint64_t *dst = stream + at;
+			for (int i = 0; i < WAVES; ++i)
+			{
+				const uint64_t *src = enc_lds + (size_t)i * cap;
+				const uint32_t n_all = sh_u32[i], n_lds = sh_u32[WAVES + i];
+				uint32_t j = (uint32_t)lane;
+				for (; j + 192 < n_lds; j += 256)
+				{
+					const uint64_t v0 = src[j], v1 = src[j + 64], v2 = src[j + 128], v3 = src[j + 192];
+					dst[j] = v0, dst[j + 64] = v1, dst[j + 128] = v2, dst[j + 192] = v3;
+				}
+				for (; j < n_lds; j += 64)
+					dst[j] = src[j];
+				if (n_all > n_lds)
+				{ // what wave i spilled comes back from its extent (sc1 loads: from L2, where its stores went)
+					const int r0 = enc_split(i, WAVES, nf), r1 = enc_split(i + 1, WAVES, nf);
+					const __amdgpu_buffer_rsrc_t sp = make_rsrc(arena + sh_u64[1 + i], (uint32_t)(r1 - r0) * RIRB1_REC_MAX_WORDS * 8u);
+					for (uint32_t q = (uint32_t)lane; q < n_all - n_lds; q += 64)
+					{
+						const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(sp, q * 8u, 0, 16 /* sc1 */);
+						dst[n_lds + q] = ((uint64_t)v.y << 32) | v.x;
+					}
+				}
+				dst += n_all;
+			}
+#endif
+		}
+#if RIR_PACKED_COPY_ALL_WAVES
+		__syncthreads();
+		const uint64_t at = sh_u64[0];
+		if (at == ~0ull)
+			return;
+		{ // every wave moves its own words
+			uint64_t *dst = stream + at + before;
+			const uint64_t *src = enc_lds + (size_t)w * cap;
+			const uint32_t n_all = sh_u32[w], n_lds = sh_u32[WAVES + w];
+			uint32_t j = (uint32_t)lane;
+			for (; j + 192 < n_lds; j += 256)
+			{
+				const uint64_t v0 = src[j], v1 = src[j + 64], v2 = src[j + 128], v3 = src[j + 192];
+				dst[j] = v0, dst[j + 64] = v1, dst[j + 128] = v2, dst[j + 192] = v3;
+			}
+			for (; j < n_lds; j += 64)
+				dst[j] = src[j];
+			if (n_all > n_lds)
+			{
+				const __amdgpu_buffer_rsrc_t sp = make_rsrc(arena + sh_u64[1 + w], (uint32_t)nrec * RIRB1_REC_MAX_WORDS * 8u);
+				for (uint32_t q = (uint32_t)lane; q < n_all - n_lds; q += 64)
+				{
+					const v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(sp, q * 8u, 0, 16 /* sc1 */);
+					dst[n_lds + q] = ((uint64_t)v.y << 32) | v.x;
+				}
+			}
 		}
 #endif
 	}
@@ -1453,11 +1668,14 @@ namespace rir
 	//   slotted (seg_words != NULL)  segment (c, t) = stream[(c * ntiles + t) * RIRB1_SLOT_WORDS(gop) ...), seg_words[c][t] words
 	//            long - what rirb1_encode_tiles leaves in its workspace: every segment's place is known before anything is
 	//            packed, so the encoder needs no second pass and the decoder no offsets (tile_off / chunk_off unused).
+	//   packed  (seg_pos != NULL too) segment (c, t) = stream[seg_pos[c][t] ...), seg_words[c][t] words long - what rirb1_encode_packed
+	//            leaves: a stream without holes whose segments lie in order of arrival.
 	__global__ __launch_bounds__(256) void rirb1_decode_tiles(const uint64_t *__restrict__ hdr_table, const uint32_t *__restrict__ tile_off,
 															 const uint64_t *__restrict__ chunk_off, const uint64_t *__restrict__ stream,
 															 uint64_t stream_words, int64_t npx, int ntiles, int nframes, int gop,
 															 const int64_t *__restrict__ chunk_frames, const uint32_t *__restrict__ seg_words,
-															 uint16_t *__restrict__ frames, int *__restrict__ error_flag)
+															 const uint64_t *__restrict__ seg_pos, uint16_t *__restrict__ frames,
+															 int *__restrict__ error_flag)
 	{
 		const int lane = threadIdx.x & 63;
 		const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1487,10 +1705,12 @@ namespace rir
 		uint32_t seg_len;
 		const uint64_t *in;
 		if (seg_words)
-		{ // slotted: the slot's place is fixed, its length comes from the encoder's table (clamped to the slot all the same)
-			const uint64_t base = (uint64_t)slot * (uint64_t)RIRB1_SLOT_WORDS(gop);
+		{ // slotted: the slot's place is fixed, its length comes from the encoder's table (clamped to the slot all the same);
+		  // packed (seg_pos != NULL): the place comes from a table too - untrusted like the length (a batch received from another
+		  // device), so the segment must lie inside the stream before a descriptor is built on it
+			const uint64_t base = seg_pos ? seg_pos[slot] : (uint64_t)slot * (uint64_t)RIRB1_SLOT_WORDS(gop);
 			seg_len = min(seg_words[slot], (uint32_t)gop * RIRB1_REC_MAX_WORDS);
-			if (base + seg_len > stream_words)
+			if (base > stream_words || (uint64_t)seg_len > stream_words - base)
 			{
 				if (lane == 0)
 					atomicExch(error_flag, 1);
@@ -1598,7 +1818,7 @@ namespace rir
 		const int nchunks = d_chunk_frames ? nchunks_tab : (nframes + gop - 1) / gop;
 		dim3 grid((ntiles + 3) / 4, nchunks), block(256);
 		hipLaunchKernelGGL(rirb1_decode_tiles, grid, block, 0, st, d_hdr, d_tile_off, d_chunk_off, d_stream, stream_words, npx, ntiles, nframes, gop,
-						   d_chunk_frames, (const uint32_t *)nullptr, d_frames, d_error);
+						   d_chunk_frames, (const uint32_t *)nullptr, (const uint64_t *)nullptr, d_frames, d_error);
 		return hipGetLastError();
 	}
 	// the slotted form: d_slots = the encoder's slot array ([nchunks][ntiles] slots of RIRB1_SLOT_WORDS(gop) words), d_seg_words its lengths
@@ -1609,7 +1829,60 @@ namespace rir
 		dim3 grid((ntiles + 3) / 4, nchunks), block(256);
 		hipLaunchKernelGGL(rirb1_decode_tiles, grid, block, 0, st, d_hdr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, d_slots,
 						   (uint64_t)nchunks * ntiles * (uint64_t)RIRB1_SLOT_WORDS(gop), npx, ntiles, nframes, gop, (const int64_t *)nullptr,
-						   d_seg_words, d_frames, d_error);
+						   d_seg_words, (const uint64_t *)nullptr, d_frames, d_error);
+		return hipGetLastError();
+	}
+
+	// the packed form.  d_ctrl: RIRB1_PACKED_CTRL_BYTES at the start of the workspace (zeroed here), d_arena: the rest of it.
+	int packed_lds_words(int gop)
+	{
+		constexpr int WAVES = RIR_PACKED_WAVES;
+		const int share = (gop + 1 + WAVES - 1) / WAVES + 1;
+		int cap = 448 * 4 / WAVES; // 14.4 KB per workgroup, as the dense kernel: the reference's recipe needs 290-355 words per wave of four
+		if (cap > share * RIRB1_REC_MAX_WORDS)
+			cap = share * RIRB1_REC_MAX_WORDS;
+		static int cap_env = -1;
+		if (cap_env < 0)
+		{
+			const char *ev = getenv("RIR_ENC_LDS_WORDS"); // tuning aid
+			cap_env = ev ? atoi(ev) : 0;
+		}
+		return cap_env > 0 ? cap_env : cap;
+	}
+	hipError_t launch_encode_packed(const uint16_t *d_frames, int64_t npx, int ntiles, int nframes, int gop, uint64_t *d_hdr, uint64_t *d_seg_pos,
+									uint32_t *d_seg_words, uint64_t *d_stream, uint64_t capacity_words, uint64_t *d_ctrl, uint64_t *d_arena,
+									uint64_t arena_words, hipStream_t st)
+	{
+		const int nchunks = (nframes + gop - 1) / gop;
+		hipError_t e = hipMemsetAsync(d_ctrl, 0, RIRB1_PACKED_CTRL_BYTES, st);
+		if (e != hipSuccess)
+			return e;
+		constexpr int WAVES = RIR_PACKED_WAVES;
+		const int cap = packed_lds_words(gop);
+		static int diag = -1;
+		if (diag < 0)
+		{
+			const char *ev = getenv("RIR_PACKED_ONE_CURSOR"); // measurement aid (tests/perf/packed_time.py): 1 = every segment through the low cursor
+			diag = ev ? (atoi(ev) != 0) : 0;
+		}
+		const size_t lds = (size_t)WAVES * cap * 8 + (1 + WAVES) * 8 + 2 * WAVES * 4;
+		const bool aligned = ((npx & 7) == 0) && ((((uintptr_t)d_frames) & 15) == 0);
+		const int nfast = aligned ? (int)(npx / RIRB1_TILE_PX) : 0; // tiles that lie whole inside the frame
+		if (nfast > 0)
+			hipLaunchKernelGGL((rirb1_encode_packed<WAVES, true>), dim3(nfast, nchunks), dim3(WAVES * 64), lds, st, d_frames, npx, ntiles, 0, nframes, gop, d_hdr,
+							   d_seg_pos, d_seg_words, d_stream, capacity_words, d_ctrl, d_arena, arena_words, cap, diag);
+		if (ntiles > nfast)
+			hipLaunchKernelGGL((rirb1_encode_packed<WAVES, false>), dim3(ntiles - nfast, nchunks), dim3(WAVES * 64), lds, st, d_frames, npx, ntiles, nfast,
+							   nframes, gop, d_hdr, d_seg_pos, d_seg_words, d_stream, capacity_words, d_ctrl, d_arena, arena_words, cap, diag);
+		return hipGetLastError();
+	}
+	hipError_t launch_decode_packed(const uint64_t *d_hdr, const uint64_t *d_seg_pos, const uint32_t *d_seg_words, const uint64_t *d_stream,
+									uint64_t stream_words, int64_t npx, int ntiles, int nframes, int gop, uint16_t *d_frames, int *d_error, hipStream_t st)
+	{
+		const int nchunks = (nframes + gop - 1) / gop;
+		dim3 grid((ntiles + 3) / 4, nchunks), block(256);
+		hipLaunchKernelGGL(rirb1_decode_tiles, grid, block, 0, st, d_hdr, (const uint32_t *)nullptr, (const uint64_t *)nullptr, d_stream, stream_words, npx,
+						   ntiles, nframes, gop, (const int64_t *)nullptr, d_seg_words, d_seg_pos, d_frames, d_error);
 		return hipGetLastError();
 	}
 } // namespace rir

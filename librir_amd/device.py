@@ -60,6 +60,12 @@ class CodecSlots(ct.Structure):
     _fields_ = [("slots_offset_bytes", ct.c_int64), ("slot_words", ct.c_int64), ("seg_words_offset_bytes", ct.c_int64), ("nslots", ct.c_int64)]
 
 
+class CodecPackedLayout(ct.Structure):
+    _fields_ = [("ntiles", ct.c_int), ("nchunks", ct.c_int), ("hdr_bytes", ct.c_int64), ("seg_pos_bytes", ct.c_int64), ("seg_words_bytes", ct.c_int64),
+                ("stream_budget_bytes", ct.c_int64), ("stream_max_bytes", ct.c_int64), ("workspace_min_bytes", ct.c_int64),
+                ("workspace_max_bytes", ct.c_int64)]
+
+
 _vp = ct.c_void_p
 _lib.rir_codec_slots_query.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(CodecSlots)]
 _lib.rir_device_available.restype = ct.c_int
@@ -79,6 +85,10 @@ _lib.rir_buffer_destroy_device.restype = None
 _lib.rir_codec_workspace_destroy_device.argtypes = [_vp]
 _lib.rir_codec_workspace_destroy_device.restype = None
 _lib.rir_codec_decode_slots_device.argtypes = [_vp, _vp, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
+_lib.rir_codec_packed_query.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(CodecPackedLayout)]
+_lib.rir_codec_encode_packed_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, ct.c_longlong, _vp, ct.c_longlong, _vp]
+_lib.rir_codec_encode_packed_status.argtypes = [_vp, ct.POINTER(ct.c_ulonglong), _vp]
+_lib.rir_codec_decode_packed_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.rir_codec_decode_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.rir_codec_decode_chunks_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, ct.c_longlong, _vp,
                                                 _vp, _vp]
@@ -308,6 +318,91 @@ class CodecContext:
         )
         if check and int(self.error.item()) != 0:
             raise RuntimeError("rir_codec_decode_device: malformed stream")
+        return out
+
+
+class PackedBatch:
+    """An encoded batch in the packed form: record headers, one (position, length) pair per (chunk, tile) segment and a stream
+    buffer whose two ends hold the payload without holes - ``[0, low)`` and ``[capacity - high, capacity)`` words.  ``nbytes()``
+    is what it occupies and what has to be kept, sent or written."""
+
+    def __init__(self, codec, hdr, seg_pos, seg_words, stream, low, high):
+        self.codec, self.hdr, self.seg_pos, self.seg_words, self.stream, self.low, self.high = codec, hdr, seg_pos, seg_words, stream, int(low), int(high)
+        self.words = self.low + self.high
+
+    def extents(self):
+        """the two pieces of the payload as views of the stream buffer"""
+        return self.stream[:self.low], self.stream[self.stream.numel() - self.high:]
+
+    def payload_bytes(self):
+        return self.words * 8
+
+    def nbytes(self):
+        return self.words * 8 + self.hdr.numel() * 8 + self.seg_pos.numel() * 8 + self.seg_words.numel() * 4
+
+
+class PackedCodec:
+    """Encode / decode of one batch geometry through the PACKED form (rir_codec_encode_packed_device): one pass over the
+    frames, the encoded batch = exactly its payload + tables.  ``stream_bytes``: capacity of the stream buffer - default the
+    8 bit-per-pixel budget (half the raw size; the reference documents a factor of about 5, docs/video_io.md:13), "max" = room
+    for any data.  ``workspace_bytes``: default the minimum (control block + a small arena), "max" = room for any data.  A batch
+    that does not fit raises in ``finish()`` / ``encode(..., check=True)`` with the sizes it needs; ``grow()`` provides them."""
+
+    def __init__(self, width, height, nframes, gop=DEFAULT_GOP, device="cuda", stream_bytes=None, workspace_bytes=None):
+        self.width, self.height, self.nframes, self.gop = int(width), int(height), int(nframes), int(gop)
+        self.P = P = CodecPackedLayout()
+        _check(_lib.rir_codec_packed_query(width, height, nframes, gop, ct.byref(P)), "rir_codec_packed_query")
+        self.device = dev = torch.device(device)
+        self.hdr = torch.zeros((P.nchunks, P.ntiles, self.gop), dtype=torch.int64, device=dev)
+        self.seg_pos = torch.zeros((P.nchunks, P.ntiles), dtype=torch.int64, device=dev)
+        self.seg_words = torch.zeros((P.nchunks, P.ntiles), dtype=torch.int32, device=dev)
+        sb = P.stream_budget_bytes if stream_bytes is None else (P.stream_max_bytes if stream_bytes == "max" else int(stream_bytes))
+        wb = P.workspace_min_bytes if workspace_bytes is None else (P.workspace_max_bytes if workspace_bytes == "max" else int(workspace_bytes))
+        self.stream = torch.empty((max(sb // 8, 1),), dtype=torch.int64, device=dev)
+        self.workspace = torch.empty((max(wb, 4096),), dtype=torch.uint8, device=dev)
+        self.error = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.raw_bytes = self.width * self.height * self.nframes * 2
+
+    def encode(self, frames, check=False):
+        """Asynchronous; ``check=True`` (or a later ``finish()``) waits and returns the PackedBatch."""
+        fr = _frames3(frames, torch.uint16)
+        if tuple(fr.shape) != (self.nframes, self.height, self.width):
+            raise RuntimeError("encode: frames do not match the codec geometry")
+        _check(_lib.rir_codec_encode_packed_device(fr.data_ptr(), self.width, self.height, self.nframes, self.gop, self.hdr.data_ptr(), self.seg_pos.data_ptr(),
+                                                   self.seg_words.data_ptr(), self.stream.data_ptr(), self.stream.numel(), self.workspace.data_ptr(),
+                                                   self.workspace.numel(), _stream()), "rir_codec_encode_packed_device")
+        return self.finish() if check else None
+
+    def status(self):
+        """(code, low words, high words, arena words asked for): code 0 complete, bit 0 stream capacity, bit 1 arena exceeded; waits."""
+        out = (ct.c_ulonglong * 3)()
+        r = int(_lib.rir_codec_encode_packed_status(self.workspace.data_ptr(), out, _stream()))
+        if r < 0:
+            raise RuntimeError("rir_codec_encode_packed_status failed: %s" % last_error())
+        return r, int(out[0]), int(out[1]), int(out[2])
+
+    def finish(self):
+        r, low, high, arena = self.status()
+        if r != 0:
+            raise RuntimeError("packed encode: the batch does not fit (code %d): it needs %d stream bytes (capacity %d) and asked for %d arena bytes "
+                               "(capacity %d)" % (r, (low + high) * 8, self.stream.numel() * 8, arena * 8, self.workspace.numel() - 4096))
+        return PackedBatch(self, self.hdr, self.seg_pos, self.seg_words, self.stream, low, high)
+
+    def grow(self):
+        """room for any data (after a batch did not fit)"""
+        self.stream = torch.empty((self.P.stream_max_bytes // 8,), dtype=torch.int64, device=self.device)
+        self.workspace = torch.empty((self.P.workspace_max_bytes,), dtype=torch.uint8, device=self.device)
+
+    def decode(self, batch=None, out=None, check=True):
+        hdr, pos, seg, st = (batch.hdr, batch.seg_pos, batch.seg_words, batch.stream) if batch is not None else (self.hdr, self.seg_pos, self.seg_words, self.stream)
+        if out is None:
+            out = torch.empty((self.nframes, self.height, self.width), dtype=torch.uint16, device=self.device)
+        if check:
+            self.error.zero_()
+        _check(_lib.rir_codec_decode_packed_device(hdr.data_ptr(), pos.data_ptr(), seg.data_ptr(), st.data_ptr(), st.numel(), self.width, self.height,
+                                                   self.nframes, self.gop, out.data_ptr(), self.error.data_ptr(), _stream()), "rir_codec_decode_packed_device")
+        if check and int(self.error.item()) != 0:
+            raise RuntimeError("rir_codec_decode_packed_device: malformed batch")
         return out
 
 

@@ -390,3 +390,133 @@ def test_slotted_identity_at_baseline_size(dev):
     assert fr.numel() * 2 / enc.compressed_bytes() > 4.85
     out.zero_()
     assert torch.equal(ctx.decode(enc, out=out).view(torch.int16), fr.view(torch.int16))
+
+
+# ---- the packed form: the dense stream without the order (rir_codec_encode_packed_device) ---------------------------------
+def _packed_segments(batch):
+    pos = batch.seg_pos.cpu().numpy().view(np.uint64)
+    seg = batch.seg_words.cpu().numpy().view(np.uint32)
+    st = batch.stream.cpu().numpy().view(np.uint64)
+    return pos, seg, st
+
+
+@pytest.mark.parametrize("name,shape,gop", CASES)
+def test_packed_form_equals_oracle_segment_by_segment_and_has_no_holes(dev, oracle, name, shape, gop):
+    """One kernel, and the encoded batch is exactly its payload: every (chunk, tile) segment holds the oracle's words, the
+    segments tile [0, words) without gap or overlap (in whatever order they arrived), the oracle decodes them, the GPU
+    decodes the batch as it is."""
+    import torch
+
+    n, h, w = shape
+    fr = _case_frames(name, shape)
+    pc = dev.PackedCodec(w, h, n, gop, stream_bytes="max", workspace_bytes="max")
+    t = torch.from_numpy(fr).cuda()
+    batch = pc.encode(t, check=True)
+    assert np.array_equal(pc.decode(batch).cpu().numpy(), fr)
+    pos, seg, st = _packed_segments(batch)
+    hdr = batch.hdr.cpu().numpy().view(np.uint64)
+    assert int(seg.astype(np.int64).sum()) == batch.words == batch.low + batch.high <= st.size
+    order = np.argsort(pos.ravel(), kind="stable")
+    p, s = pos.ravel()[order].astype(np.int64), seg.ravel()[order].astype(np.int64)
+    keep = s > 0  # (empty segments may share a position)
+    p, s = p[keep], s[keep]
+    nlow = int(np.searchsorted(p, batch.low))  # segments of the low extent [0, low), the rest fill [capacity - high, capacity)
+    assert np.array_equal(p[:nlow], np.concatenate([[0], np.cumsum(s[:nlow])])[:nlow]) and int(s[:nlow].sum()) == batch.low, "holes in the low extent"
+    assert np.array_equal(p[nlow:], st.size - batch.high + np.concatenate([[0], np.cumsum(s[nlow:])])[:p.size - nlow]), "holes in the high extent"
+    for c in range(pc.P.nchunks):
+        f0 = c * gop
+        nf = min(gop, n - f0)
+        h_o, o_o, st_o = oracle.codec_encode_chunk(fr[f0:f0 + nf])
+        assert np.array_equal(hdr[c][:, :nf], h_o), (name, c)
+        assert np.array_equal(seg[c], np.diff(o_o)), (name, c)
+        dense = np.concatenate([st[int(pos[c, t_]):int(pos[c, t_]) + int(seg[c, t_])] for t_ in range(pc.P.ntiles)])
+        assert np.array_equal(dense, st_o), (name, c)
+        assert np.array_equal(oracle.codec_decode_chunk(hdr[c][:, :nf], o_o, dense, w, h), fr[f0:f0 + nf])
+
+
+def test_gpu_decodes_an_oracle_stream_laid_out_as_a_packed_batch(dev, oracle):
+    """cross-read the other way: the CPU restatement's segments, shuffled into a packed batch on the host, decode on the GPU;
+    a position or a length that points outside the stream is refused before anything is read through it"""
+    import torch
+
+    n, h, w, gop = 9, 40, 52, 4
+    fr = s1_noisy_background(n, h, w, seed=3)
+    pc = dev.PackedCodec(w, h, n, gop, stream_bytes="max")
+    P = pc.P
+    hdr = np.zeros((P.nchunks, P.ntiles, gop), np.uint64)
+    segs = {}
+    for c in range(P.nchunks):
+        nf = min(gop, n - c * gop)
+        h_o, o_o, s_o = oracle.codec_encode_chunk(fr[c * gop:c * gop + nf])
+        hdr[c][:, :nf] = h_o
+        for t_ in range(P.ntiles):
+            segs[(c, t_)] = s_o[o_o[t_]:o_o[t_ + 1]]
+    keys = list(segs)
+    np.random.default_rng(5).shuffle(keys)
+    pos = np.zeros((P.nchunks, P.ntiles), np.uint64)
+    seg = np.zeros((P.nchunks, P.ntiles), np.uint32)
+    parts, at = [], 0
+    for k in keys:
+        pos[k], seg[k] = at, segs[k].size
+        parts.append(segs[k])
+        at += segs[k].size
+    st = np.concatenate(parts)
+    batch = dev.PackedBatch(pc, torch.from_numpy(hdr.view(np.int64)).cuda(), torch.from_numpy(pos.view(np.int64)).cuda(),
+                            torch.from_numpy(seg.view(np.int32)).cuda(), torch.from_numpy(st.view(np.int64)).cuda(), st.size, 0)
+    assert np.array_equal(pc.decode(batch).cpu().numpy(), fr)
+    for bad_pos, bad_len in ((st.size - 1, None), (2 ** 63, None), (None, 1)):
+        b2 = dev.PackedBatch(pc, batch.hdr, batch.seg_pos.clone(), batch.seg_words.clone(), batch.stream, st.size, 0)
+        if bad_pos is not None:
+            b2.seg_pos.view(-1)[3] = np.array(bad_pos, np.uint64).view(np.int64).item()
+        else:
+            b2.seg_words.view(-1)[3] += bad_len
+        with pytest.raises(RuntimeError):
+            pc.decode(b2)
+
+
+def test_packed_batch_that_exceeds_its_budget_says_so_and_fits_after_grow(dev):
+    """incompressible frames against the 8 bit-per-pixel budget and the minimal arena: nothing is written out of bounds (canaries), the
+    status names what the batch needs, and with room for any data the same call succeeds"""
+    import torch
+
+    n, h, w, gop = 12, 67, 83, 5
+    rng = np.random.default_rng(11)
+    fr = rng.integers(0, 65536, (n, h, w)).astype(np.uint16)
+    t = torch.from_numpy(fr).cuda()
+    pc = dev.PackedCodec(w, h, n, gop)
+    cap = pc.stream.numel()
+    big = torch.full((cap + 4096,), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64, device="cuda")
+    pc.stream = big[:cap]
+    wcap = pc.workspace.numel()
+    wbig = torch.full((wcap + 32768,), 0xA5, dtype=torch.uint8, device="cuda")
+    pc.workspace = wbig[:wcap]
+    pc.encode(t)
+    code, low, high, arena = pc.status()
+    words = low + high
+    assert code != 0 and words * 8 > cap * 8 and words * 8 >= fr.nbytes * 0.95
+    with pytest.raises(RuntimeError, match="does not fit"):
+        pc.finish()
+    assert bool((big[cap:] == 0x5A5A5A5A5A5A5A5A).all()) and bool((wbig[wcap:] == 0xA5).all()), "wrote past the capacity it was given"
+    pc.grow()
+    batch = pc.encode(t, check=True)
+    assert batch.words == words
+    assert np.array_equal(pc.decode(batch).cpu().numpy(), fr)
+
+
+def test_packed_identity_and_footprint_at_baseline_size(dev):
+    """configs[1] at full size: two launches, the encoded batch fits the 8 bpp budget (it is less than a quarter of the raw bytes), it
+    decodes to the input, and it has as many payload words as the dense (file) form"""
+    import torch
+
+    n, h, w = 1000, 512, 640
+    fr = torch.from_numpy(s1_noisy_background(n, h, w)).cuda()
+    pc = dev.PackedCodec(w, h, n, 50)
+    batch = pc.encode(fr, check=True)
+    assert pc.stream.numel() * 8 <= fr.numel() * 2 // 2 + 256
+    assert batch.nbytes() < fr.numel() * 2 / 4.7
+    out = pc.decode(batch)
+    assert torch.equal(out.view(torch.int16), fr.view(torch.int16))
+    ctx = dev.CodecContext(w, h, n, 50)
+    enc = ctx.encode(fr)
+    assert enc.total_words() == batch.words
+    assert torch.equal(ctx.hdr, batch.hdr)
