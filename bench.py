@@ -440,13 +440,10 @@ def main():
     for _ in range(args.warmup):
         step()
     dt_idle = max_over_ranks(k_steps(K))
-    t_ramp = time.perf_counter()
-    ramp_steps = 0
-    while time.perf_counter() - t_ramp < 1.0 and ramp_steps < 100000:
-        k_steps(16)
-        ramp_steps += 16
-    if world > 1:
-        dist.barrier()
+    ramp_steps = min(100000, max(16, int(1.0 / (dt_idle / K))))  # (from the max over ranks: the same count on every rank)
+    for _ in range(ramp_steps):
+        step()
+    barrier()
     for _ in range(args.warmup):
         step()
     barrier()

@@ -240,6 +240,14 @@ extern "C"
 	 * until it is destroyed.  Calls that return budgets report this themselves; queue-only calls (no error arrays) leave it to
 	 * this query. */
 	int rir_lossy_status(int handle, void *stream);
+	/* lowValueError / highValueError / stdFactor of a stream in use (H264_Saver::setParameter, h264.cpp:1709-1781): from the next frame on */
+	int rir_lossy_set_errors(int handle, int low_value_error, int high_value_error, double std_factor);
+	/* Which form stepped the last batch this stream led: out[0] = groups of frames offered to the constant-budget form (stdFactor == 0:
+	 * the budget arithmetic of h264.cpp:2370-2376 multiplies the statistic by zero, so nothing a frame needs comes from another
+	 * workgroup - an ordinary streaming launch instead of the resident one; 0 = the batch was not eligible), out[1] = of those, groups it
+	 * took (it declines, on the device, when a frame's foreground or background may be empty or a NaN sits in the 40-frame window: then
+	 * the general form steps the group, same results).  Waits for the stream. */
+	int rir_lossy_path_stats(int handle, int *out2, void *stream);
 	void rir_lossy_destroy(int handle);
 
 	/* ---- byte planes ------------------------------------------------------------------------------

@@ -80,7 +80,12 @@ namespace rir
 		int slot_words; // distance of two workgroups' exchange words, in 8-byte words
 		int leader, reserved; // 1: workgroup 0 collects the sums and publishes the decision (many streams per launch)
 		double std_factor;
+		unsigned long long *partials; // constant-budget form: [kLossyConstSlots][workgroups of the stream][4] words, this stream's
 	};
+	// The constant-budget form of a run (lossy_const_run_kernel + lossy_const_finish_kernel): with stdFactor == 0 and no NaN in play the
+	// budgets are the configured errors, frame after frame, and nothing a frame needs comes from another workgroup.  Only the last 40
+	// frames of a group (and the stream's very first budget frame) leave sums behind: what the 40-frame window holds afterwards.
+	constexpr int kLossyConstTail = 40, kLossyConstSlots = kLossyConstTail + 1;
 	constexpr int kLossyRunThreads = 256; // 8 pixels each
 	inline int lossy_run_workgroups(int full) { return (full / 8 + kLossyRunThreads - 1) / kLossyRunThreads; }
 	// The run kernel needs ALL its workgroups resident at once: workgroup i runs on XCD i % 8, each XCD starts its own share of the
@@ -114,7 +119,12 @@ namespace rir
 	// first launch that bailed out); epoch: a number no earlier launch on this header used; arrivals_before: workgroups of those launches
 	constexpr int kLossyRunCtlWord = 48;
 	hipError_t launch_lossy_run(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ticket, unsigned int epoch, unsigned int arrivals_before, bool parked,
-								hipStream_t st);
+								hipStream_t st, const unsigned int *d_ok = nullptr);
+	// The constant-budget form for the group of frames d_table describes (nstreams entries, partials filled in): both launches look at
+	// the group's background words (bit 40: a class may be empty), the streams' budget windows (NaN) and *d_poison (an earlier group of
+	// the call was not stepped) and do nothing unless everything is clear; *d_ok (zeroed by the caller) says which it was - the resident
+	// launch that follows reads it and leaves the group alone when it is 1 (launch_lossy_run's d_ok).
+	hipError_t launch_lossy_const(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ok, const unsigned int *d_poison, hipStream_t st);
 	hipError_t launch_lossy_first(const uint16_t *d_tmp, uint16_t *d_out, const LossyDeviceState &state, int s, int full, hipStream_t st);
 	hipError_t launch_lossy_min(const uint16_t *d_tmp, int s, unsigned int *d_result, hipStream_t st);
 	hipError_t launch_lossy_add_min(uint16_t *d_frames, int64_t npx, int s, int nframes, uint32_t mn, hipStream_t st);

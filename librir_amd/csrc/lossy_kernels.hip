@@ -228,8 +228,29 @@ namespace rir
 			}
 			__syncthreads();
 		}
+		// Does the frame surely have pixels on BOTH sides of its background ((bin << 2) + 1: every pixel of a higher bin is above it,
+		// every pixel of a lower bin below; the mode bin itself holds both kinds)?  The constant-budget form of a run
+		// (lossy_const_run_kernel) only takes frames whose two classes cannot be empty - an empty class makes the reference's statistic
+		// 0 / 0, and that NaN decides the budgets of the next 40 frames (int_of_double_x86 below).  Bit 40 of the word = "not sure";
+		// every reader of the background takes the low 32 bits.
+		const uint32_t mode_bin = best_i[0], mode_count = best_v[0];
 		if (tid == 0)
-			as_global(sp.stats)[0] = (long long)((best_i[0] << 2) + 1);
+			lh[2048] = 0;
+		__syncthreads();
+		uint32_t below = 0;
+#pragma unroll
+		for (int k = 0; k < 16; ++k)
+			below += (uint32_t)(k * 1024 + tid) < mode_bin ? v16[k] : 0u;
+		below = lossy_wave_sum32(below);
+		if ((tid & 63) == 0 && below)
+			atomicAdd(&lh[2048], below);
+		__syncthreads();
+		if (tid == 0)
+		{
+			const uint32_t nb_ = lh[2048], na_ = (uint32_t)s - nb_ - mode_count;
+			const long long unsure = (nb_ == 0 || na_ == 0) ? (1ll << 40) : 0ll;
+			as_global(sp.stats)[0] = (long long)((mode_bin << 2) + 1) | unsure;
+		}
 	}
 
 	// (int) of a double as the reference's x86-64 build converts it (cvttsd2si): NaN and values outside int32 give
@@ -977,7 +998,8 @@ namespace rir
 	// once are faster than seven (636 k): the host takes this form when it saves a launch (lossy_run_parked_kernel; same arithmetic,
 	// same results; scripts/lossy_forms.sh).
 	template <bool PARKED>
-	__device__ __forceinline__ void lossy_run_body(const LossyRun *__restrict__ table, unsigned int *__restrict__ ticket_, int nb, int nstreams, unsigned int epoch, unsigned int arrivals_before)
+	__device__ __forceinline__ void lossy_run_body(const LossyRun *__restrict__ table, unsigned int *__restrict__ ticket_, int nb, int nstreams, unsigned int epoch, unsigned int arrivals_before,
+												   const unsigned int *__restrict__ ok_word)
 	{
 		__shared__ unsigned int sh_ticket;
 		__shared__ unsigned int sh_flag;
@@ -999,6 +1021,15 @@ namespace rir
 		}
 		__syncthreads();
 		const int tk = __builtin_amdgcn_readfirstlane((int)sh_ticket);
+		// The group has been stepped by the constant-budget form (lossy_const_run_kernel; the word was written by an earlier launch of the
+		// same stream): every workgroup ARRIVES - the control block's count stays what the host expects - and leaves without waiting for
+		// anybody: a launch that has nothing to do cannot fail to be resident.
+		if (ok_word && *as_global(ok_word) != 0u)
+		{
+			if (tid == 0)
+				__hip_atomic_fetch_add(as_global(ticket_ + kLossyRunCtlWord), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			return;
+		}
 		// is the whole launch on the chip (resident_device.h)?  If not - or if an earlier group of the same call was not done - everybody
 		// leaves before the state is touched; the control words live in the header of the exchange buffer, behind the ticket and the error word
 		if (resident_rendezvous(ticket_ + kLossyRunCtlWord, arrivals_before, gridDim.x, epoch, &sh_flag, true) != RESIDENT_GO)
@@ -1386,14 +1417,348 @@ namespace rir
 	}
 
 	__attribute__((amdgpu_waves_per_eu(kLossyRunWavesPerSimd, kLossyRunWavesPerSimd))) __global__ __launch_bounds__(kLossyRunThreads) void lossy_run_kernel(
-		const LossyRun *__restrict__ table, unsigned int *__restrict__ ticket_, int nb, int nstreams, unsigned int epoch, unsigned int arrivals_before)
+		const LossyRun *__restrict__ table, unsigned int *__restrict__ ticket_, int nb, int nstreams, unsigned int epoch, unsigned int arrivals_before,
+		const unsigned int *__restrict__ ok_word)
 	{
-		lossy_run_body<false>(table, ticket_, nb, nstreams, epoch, arrivals_before);
+		lossy_run_body<false>(table, ticket_, nb, nstreams, epoch, arrivals_before, ok_word);
 	}
 	__attribute__((amdgpu_waves_per_eu(kLossyRunParkedWavesPerSimd, kLossyRunParkedWavesPerSimd))) __global__ __launch_bounds__(kLossyRunThreads) void lossy_run_parked_kernel(
-		const LossyRun *__restrict__ table, unsigned int *__restrict__ ticket_, int nb, int nstreams, unsigned int epoch, unsigned int arrivals_before)
+		const LossyRun *__restrict__ table, unsigned int *__restrict__ ticket_, int nb, int nstreams, unsigned int epoch, unsigned int arrivals_before,
+		const unsigned int *__restrict__ ok_word)
 	{
-		lossy_run_body<true>(table, ticket_, nb, nstreams, epoch, arrivals_before);
+		lossy_run_body<true>(table, ticket_, nb, nstreams, epoch, arrivals_before, ok_word);
+	}
+
+	// ---- the constant-budget form of a run ---------------------------------------------------------------------------------
+	//
+	// With stdFactor == 0 - the configuration BASELINE names for configs[4] (reference tests/python/test_video_io.py:112-116) - the
+	// budget arithmetic (h264.cpp:2370-2376) multiplies the frame's statistic by zero: lowError / highError are the configured values for
+	// every frame, UNLESS a NaN is in play (an empty foreground or background makes the statistic 0 / 0, and NaN x 0 is NaN: the frame
+	// and the 39 after it become lossless - lossy_budget above).  What is left of the frame loop (h264.cpp:2387-2413: running mean,
+	// decision, refT, lastDL) is per pixel in time: nothing a frame needs comes from another workgroup, so the two cross-workgroup
+	// hand-offs per frame that the resident kernel spends most of its time on (profiles/r03_pmc_lossy.json: 69 % of the wave cycles
+	// waiting, 0.05 of the HBM peak for one stream) buy nothing here.
+	//
+	// lossy_const_run_kernel: grid = (workgroups of a stream, streams), an ordinary launch - nobody waits for anybody, any grid fits.
+	// A thread owns 8 pixels for every frame of the group and keeps their state in registers, as in lossy_run_kernel; frames come in
+	// through a ring of 4 slots (three frames requested ahead).  Per pixel and frame: the pixel in, the pixel out, and the frame that
+	// leaves the running average - which, from the ring's length on, is an INPUT frame of this very group (the ring holds the last `ra`
+	// inputs less the minimum), re-read where it lies, mostly from the Infinity Cache; the ring itself is only written by the last `ra`
+	// frames of the group (what it must hold afterwards) and only read by the first `ra`.  The statistic of a frame is still history
+	// (a later set_parameter("stdFactor", 5) must find the window as the reference would have it), but only the last 40 frames of a group
+	// are in the window afterwards: they - and the stream's very first budget frame, which seeds firstStdDevs - leave their sums, per
+	// workgroup, in `partials`; lossy_const_finish_kernel turns those into the window entries in exact double arithmetic, as
+	// lossy_budget does, and writes the budgets of the group's frames.
+	// Both kernels first make sure the precondition holds for EVERY stream of the launch - backgrounds without the "not sure" bit, no NaN
+	// in any window, no poison from an earlier group - and otherwise return before touching anything; the resident kernel that the host
+	// queues behind them then does the group (lossy_run_body's ok_word).  Same inputs, same decision in every workgroup.
+	__device__ __forceinline__ bool lossy_const_precondition(const LossyRun *__restrict__ table, int nstreams, const unsigned int *__restrict__ poison, unsigned int *sh)
+	{
+		const int tid = threadIdx.x, nt = blockDim.x;
+		if (tid == 0)
+			*sh = 0;
+		__syncthreads();
+		bool bad = poison && __hip_atomic_load(as_global(poison), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+		for (int q = 0; q < nstreams && !bad; ++q)
+		{
+			RIR_GLOBAL(const LossyRun) *r = as_global(table + q);
+			RIR_GLOBAL(const long long) *bg = as_global(r->bg);
+			const int n = r->nsteps, stride = r->bg_stride;
+			for (int k = tid; k < n; k += nt)
+				bad = bad || ((bg[(size_t)k * stride] >> 40) & 1) != 0;
+			RIR_GLOBAL(const LossyBudget) *b = as_global(r->budget);
+			const int n_first = b->n_first, n_win = b->n_win;
+			if (tid < 2 && n_first > 0)
+				bad = bad || b->first_std[tid] != b->first_std[tid];
+			for (int j = tid; j < 2 * n_win && j < 80; j += nt)
+				bad = bad || b->win[j >> 1][j & 1] != b->win[j >> 1][j & 1];
+		}
+		if (bad)
+			atomicOr(sh, 1u);
+		__syncthreads();
+		const bool ok = *sh == 0;
+		__syncthreads();
+		return ok;
+	}
+	// slot of frame k of a group of n frames in `partials`, -1: the frame leaves no sums
+	__device__ __forceinline__ int lossy_const_slot(int k, int n)
+	{
+		const int tail0 = n > kLossyConstTail ? n - kLossyConstTail : 0;
+		return k >= tail0 ? 1 + (k - tail0) : (k == 0 ? 0 : -1);
+	}
+
+	constexpr int kConstDepth = 4; // frames in flight per thread
+	__global__ __launch_bounds__(256) void lossy_const_run_kernel(const LossyRun *__restrict__ table, int nstreams, unsigned int *__restrict__ ok_word,
+																  const unsigned int *__restrict__ poison)
+	{
+		__shared__ unsigned int sh_flag;
+		__shared__ long long red[4][6];
+		const int tid = threadIdx.x, b = blockIdx.x, stream = blockIdx.y, nb = gridDim.x;
+		const bool ok = lossy_const_precondition(table, nstreams, poison, &sh_flag);
+		if (b == 0 && stream == 0 && tid == 0)
+			__hip_atomic_store(as_global(ok_word), ok ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (!ok)
+			return;
+		LossyRun rp;
+		{
+			RIR_GLOBAL(const unsigned long long) *src = (RIR_GLOBAL(const unsigned long long) *)(table + stream);
+			unsigned long long *dst = reinterpret_cast<unsigned long long *>(&rp);
+#pragma unroll
+			for (size_t k = 0; k < sizeof(LossyRun) / 8; ++k)
+				dst[k] = src[k];
+		}
+		const LossyDeviceState st = rp.st;
+		RIR_GLOBAL(uint16_t) *refT = as_global(st.refT), *prevT = as_global(st.prevT), *lastDL = as_global(st.lastDL);
+		RIR_GLOBAL(uint16_t) *cval = as_global(st.ra_const_value), *ring = as_global(st.ra_images);
+		RIR_GLOBAL(uint16_t) *ccnt = (RIR_GLOBAL(uint16_t) *)as_global(st.ra_const_count);
+		RIR_GLOBAL(uint32_t) *sums = as_global(st.ra_sums);
+		RIR_GLOBAL(const uint16_t) *in = as_global(rp.in);
+		RIR_GLOBAL(uint16_t) *out = as_global(rp.out);
+		RIR_GLOBAL(const long long) *bgw = as_global(rp.bg);
+		RIR_GLOBAL(unsigned long long) *partials = as_global(rp.partials);
+		const int s = rp.s, full = rp.full, ra = st.running_average, add_loss = rp.add_loss, n = rp.nsteps;
+		const int i8 = b * 256 + tid;
+		const bool inside = i8 * 8 < full, lossy = i8 * 8 < s;
+		// the budget of every frame (lossy_budget with a statistic that is multiplied by zero)
+		int high_error = rp.high_value_error < 0 ? 0 : rp.high_value_error;
+		int low_error = rp.low_value_error < high_error ? high_error : rp.low_value_error;
+		const uint32_t min2 = st.subtract_min ? lossy_both(st.min) : 0u;
+
+		U16x8 ref8{}, last8{}, cc8{}, cv8{}, o8{}, t8{};
+		uint32_t sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		int count = st.ra_count, head = st.ra_head;
+		const int count0 = count, head0 = head;
+		if (lossy)
+		{
+			ref8 = ld8(refT, i8);
+			last8 = ld8(lastDL, i8);
+			o8 = ld8(prevT, i8);
+			if (ra > 0)
+			{
+				const lossy_v4u s0 = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(sums + (size_t)i8 * 8), s1 = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(sums + (size_t)i8 * 8 + 4);
+				sum[0] = s0.x, sum[1] = s0.y, sum[2] = s0.z, sum[3] = s0.w, sum[4] = s1.x, sum[5] = s1.y, sum[6] = s1.z, sum[7] = s1.w;
+				cc8 = ld8(ccnt, i8);
+				cv8 = ld8(cval, i8);
+			}
+		}
+		// what leaves the running average at frame k, when the ring is full then: the input of frame k - ra (less the minimum) once that is a
+		// frame of this group, else the ring's image at the head as it is at frame k - an image from before the group, which the group
+		// has not overwritten (it only writes the ring in its last `ra` frames, each slot after it has been read)
+		auto request_old = [&](int k, U16x8 &dst) {
+			if (!(lossy && ra > 0 && count0 + k >= ra && k < n))
+				return;
+			if (k >= ra)
+			{
+				dst = ld8(in + (size_t)(k - ra) * rp.frame_px, i8);
+#pragma unroll
+				for (int p = 0; p < 4; ++p)
+					dst.d[p] = lu1(__builtin_elementwise_sub_sat(lp2(dst.d[p]), lp2(min2)));
+			}
+			else
+			{
+				const int adv = count0 + k - ra; // steps the head has made by frame k (it moves once the ring is full)
+				dst = ld8(ring + (size_t)((head0 + (count0 == ra ? k : adv)) % ra) * s, i8);
+			}
+		};
+		U16x8 V[kConstDepth], O[kConstDepth];
+#pragma unroll
+		for (int j = 0; j < kConstDepth; ++j)
+		{
+			V[j] = U16x8{}, O[j] = U16x8{};
+			if (inside && j < n)
+				V[j] = ld8(in + (size_t)j * rp.frame_px, i8);
+			request_old(j, O[j]);
+		}
+		for (int k0 = 0; k0 < n; k0 += kConstDepth)
+		{
+#pragma unroll
+			for (int j = 0; j < kConstDepth; ++j)
+			{
+				const int k = k0 + j;
+				if (k >= n)
+					break;
+				const U16x8 v8 = V[j], old8 = O[j];
+				if (inside && k + kConstDepth < n)
+					V[j] = ld8(in + (size_t)(k + kConstDepth) * rp.frame_px, i8);
+				request_old(k + kConstDepth, O[j]);
+				const uint32_t background = (uint32_t)bgw[(size_t)k * rp.bg_stride];
+				const int slot = lossy_const_slot(k, n);
+				if (slot >= 0)
+				{ // this frame's statistic will be in the window (or seeds it): its sums against the previous output, per workgroup
+					int32_t fd = 0, fn = 0, bd = 0, bn = 0;
+					long long f2 = 0, b2 = 0;
+					if (lossy)
+					{
+#pragma unroll
+						for (int q = 0; q < 8; ++q)
+						{
+							const uint32_t t = st.subtract_min ? sub_min(v8.get(q), st.min) : v8.get(q);
+							const int32_t d = abs((int32_t)t - (int32_t)o8.get(q));
+							const int32_t d2 = (int32_t)((uint32_t)d * (uint32_t)d);
+							if (v8.get(q) > background)
+								fd += d, f2 += d2, fn += 1;
+							else
+								bd += d, b2 += d2, bn += 1;
+						}
+					}
+					const uint32_t wfd = lossy_wave_sum32((uint32_t)fd), wbd = lossy_wave_sum32((uint32_t)bd), wn = lossy_wave_sum32((uint32_t)fn | ((uint32_t)bn << 16));
+					const long long wf2 = lossy_wave_sum(f2), wb2 = lossy_wave_sum(b2);
+					const int lane = tid & 63, wave = tid >> 6;
+					if (lane == 0)
+						red[wave][0] = (long long)wfd, red[wave][1] = wf2, red[wave][2] = (long long)(wn & 0xffffu), red[wave][3] = (long long)wbd, red[wave][4] = wb2,
+						red[wave][5] = (long long)(wn >> 16);
+					__syncthreads();
+					if (tid < 4)
+					{ // four words per workgroup: fg count << 32 | fg sum d,  fg sum d2,  bg count << 32 | bg sum d,  bg sum d2
+						const int a = tid == 0 ? 0 : tid == 1 ? 1 : tid == 2 ? 3 : 4;
+						long long v = red[0][a] + red[1][a] + red[2][a] + red[3][a];
+						if (tid == 0 || tid == 2)
+							v |= (red[0][a + 2] + red[1][a + 2] + red[2][a + 2] + red[3][a + 2]) << 32;
+						partials[((size_t)slot * nb + b) * 4 + tid] = (unsigned long long)v;
+					}
+					__syncthreads();
+				}
+				const bool full_ring = ra > 0 && count == ra;
+				const int n_after = ra > 0 ? (full_ring ? ra : count + 1) : 0;
+				if (lossy)
+				{
+					const LossyFrameConsts fc = {st.min, background, st.subtract_min, ra, full_ring ? 1 : 0, n_after, add_loss, low_error, high_error, lossy_div_magic(n_after)};
+					const LossyPairConsts pc = lossy_pair_consts(fc);
+#pragma unroll
+					for (int p = 0; p < 4; ++p)
+						lossy_pixel_pair(fc, pc, v8.d[p], old8.d[p], last8.d[p], ref8.d[p], sum[2 * p], sum[2 * p + 1], cc8.d[p], cv8.d[p], t8.d[p], o8.d[p]);
+					last8 = v8;
+					st8(out + (size_t)k * rp.frame_px, i8, o8);
+					if (ra > 0 && k >= n - ra)
+					{ // the ring as it must be after the group: the last `ra` inputs
+						const int rs = full_ring ? head : (head + count) % ra;
+						st8(ring + (size_t)rs * s, i8, t8);
+					}
+				}
+				else if (inside)
+				{
+					st8(out + (size_t)k * rp.frame_px, i8, v8); // rows past lossy_height: stored as they are
+					last8 = v8;
+				}
+				if (ra > 0)
+				{
+					if (count == ra)
+						head = (head + 1) % ra;
+					else
+						++count;
+				}
+			}
+		}
+		if (lossy)
+		{
+			st8(refT, i8, ref8);
+			st8(lastDL, i8, last8);
+			st8(prevT, i8, o8);
+			if (ra > 0)
+			{
+				lossy_v4u s0, s1;
+				s0.x = sum[0], s0.y = sum[1], s0.z = sum[2], s0.w = sum[3], s1.x = sum[4], s1.y = sum[5], s1.z = sum[6], s1.w = sum[7];
+				*reinterpret_cast<RIR_GLOBAL(lossy_v4u) *>(sums + (size_t)i8 * 8) = s0;
+				*reinterpret_cast<RIR_GLOBAL(lossy_v4u) *>(sums + (size_t)i8 * 8 + 4) = s1;
+				st8(ccnt, i8, cc8);
+				st8(cval, i8, cv8);
+			}
+		}
+		else if (inside)
+			st8(lastDL, i8, last8);
+	}
+
+	// grid = streams, 256 threads.  The window entries of the frames that left sums (exact integers -> the reference's double
+	// arithmetic, lossy_budget's), the window's counters as they are after the group's n frames, the budgets of the frames.
+	__global__ __launch_bounds__(256) void lossy_const_finish_kernel(const LossyRun *__restrict__ table, int nb, const unsigned int *__restrict__ ok_word)
+	{
+		__shared__ double sd[kLossyConstSlots][2];
+		if (*as_global(ok_word) == 0u)
+			return;
+		const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+		RIR_GLOBAL(const LossyRun) *r = as_global(table + blockIdx.x);
+		RIR_GLOBAL(const unsigned long long) *partials = as_global(r->partials);
+		RIR_GLOBAL(LossyBudget) *bud = as_global(r->budget);
+		const int n = r->nsteps, s = r->s;
+		const int n_first0 = bud->n_first, n_win0 = bud->n_win, head0 = bud->head;
+		const int tail0 = n > kLossyConstTail ? n - kLossyConstTail : 0;
+		for (int slot = wave; slot < kLossyConstSlots; slot += 4)
+		{
+			const int k = slot == 0 ? 0 : tail0 + slot - 1; // the frame of this slot
+			if (k >= n || (slot == 0 && tail0 == 0))
+				continue; // (slot 0 is only filled when frame 0 is not in the tail)
+			long long a[4] = {0, 0, 0, 0}; // fg d | n << 32 summed field-wise below
+			long long fd = 0, fn = 0, bd = 0, bn = 0;
+			for (int w = lane; w < nb; w += 64)
+			{
+				const unsigned long long w0 = partials[((size_t)slot * nb + w) * 4 + 0], w2 = partials[((size_t)slot * nb + w) * 4 + 2];
+				fd += (long long)(w0 & 0xffffffffull), fn += (long long)(w0 >> 32);
+				bd += (long long)(w2 & 0xffffffffull), bn += (long long)(w2 >> 32);
+				a[1] += (long long)partials[((size_t)slot * nb + w) * 4 + 1];
+				a[3] += (long long)partials[((size_t)slot * nb + w) * 4 + 3];
+			}
+			fd = lossy_wave_sum(fd), fn = lossy_wave_sum(fn), bd = lossy_wave_sum(bd), bn = lossy_wave_sum(bn);
+			const long long f2 = lossy_wave_sum(a[1]), b2 = lossy_wave_sum(a[3]);
+			if (lane == 0)
+			{ // stdDev (h264.cpp:1993-2036), as lossy_budget: unsplit while the window is not full
+				const int n_win_k = n_win0 + k < 40 ? n_win0 + k : 40;
+				if (n_win_k < 40)
+				{
+					const double sum_diff = (double)(fd + bd), sum_diff2 = (double)(f2 + b2);
+					sd[slot][0] = sd[slot][1] = sqrt(sum_diff * sum_diff - sum_diff2) / s;
+				}
+				else
+				{
+					const double dfd = (double)fd, dfd2 = (double)f2, dbd = (double)bd, dbd2 = (double)b2;
+					sd[slot][0] = sqrt(dbd * dbd - dbd2) / (int)bn;
+					sd[slot][1] = sqrt(dfd * dfd - dfd2) / (int)fn;
+				}
+			}
+		}
+		__syncthreads();
+		if (tid == 0)
+		{
+			const int first_slot = tail0 == 0 ? 1 : 0;
+			if (n_first0 < 1)
+			{
+				bud->first_std[0] = sd[first_slot][0], bud->first_std[1] = sd[first_slot][1];
+				bud->n_first = 1;
+			}
+			// the frames before the tail go through the window and are gone by the end of the group: only the counters move
+			int n_win = n_win0, head = head0;
+			{
+				const int fill = tail0 < 40 - n_win ? tail0 : 40 - n_win;
+				n_win += fill;
+				head = (head + (tail0 - fill)) % 40;
+			}
+			for (int k = tail0; k < n; ++k)
+			{
+				const int slot = 1 + (k - tail0);
+				if (n_win < 40)
+				{
+					bud->win[n_win][0] = sd[slot][0], bud->win[n_win][1] = sd[slot][1];
+					++n_win;
+				}
+				else
+				{
+					bud->win[head][0] = sd[slot][0], bud->win[head][1] = sd[slot][1];
+					head = head == 39 ? 0 : head + 1;
+				}
+			}
+			bud->n_win = n_win, bud->head = head;
+			RIR_GLOBAL(LossyDecision) *gd = as_global(r->decision);
+			const int high_error = r->high_value_error < 0 ? 0 : r->high_value_error;
+			gd->background = (uint32_t)as_global(r->bg)[(size_t)(n - 1) * r->bg_stride];
+			gd->high_error = high_error, gd->low_error = r->low_value_error < high_error ? high_error : r->low_value_error;
+		}
+		if (r->errors_out)
+		{
+			const int high_error = r->high_value_error < 0 ? 0 : r->high_value_error;
+			const int low_error = r->low_value_error < high_error ? high_error : r->low_value_error;
+			RIR_GLOBAL(int) *e = as_global(r->errors_out);
+			for (int k = tid; k < n; k += 256)
+				e[2 * k] = low_error, e[2 * k + 1] = high_error;
+		}
 	}
 
 	// first frame: out = tmp minus the optional minimum on rows < lossy_height; seeds refT / prevT / lastDL
@@ -1510,7 +1875,7 @@ namespace rir
 								 0, RIR_LOSSY_RUN_MARGIN != 0);
 	}
 	hipError_t launch_lossy_run(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ticket, unsigned int epoch, unsigned int arrivals_before, bool parked,
-								hipStream_t st)
+								hipStream_t st, const unsigned int *d_ok)
 	{
 		const int nb = lossy_run_workgroups(full);
 		if ((long long)nb * nstreams > lossy_run_capacity(parked))
@@ -1520,9 +1885,16 @@ namespace rir
 			return hipErrorUnknown;
 		if (parked)
 			hipLaunchKernelGGL(lossy_run_parked_kernel, dim3((unsigned)(nb * nstreams)), dim3(kLossyRunThreads), 0, st, d_table, d_ticket, nb, nstreams, epoch,
-							   arrivals_before);
+							   arrivals_before, d_ok);
 		else
-			hipLaunchKernelGGL(lossy_run_kernel, dim3((unsigned)(nb * nstreams)), dim3(kLossyRunThreads), 0, st, d_table, d_ticket, nb, nstreams, epoch, arrivals_before);
+			hipLaunchKernelGGL(lossy_run_kernel, dim3((unsigned)(nb * nstreams)), dim3(kLossyRunThreads), 0, st, d_table, d_ticket, nb, nstreams, epoch, arrivals_before, d_ok);
+		return hipGetLastError();
+	}
+	hipError_t launch_lossy_const(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ok, const unsigned int *d_poison, hipStream_t st)
+	{
+		const int nb = lossy_run_workgroups(full);
+		hipLaunchKernelGGL(lossy_const_run_kernel, dim3((unsigned)nb, (unsigned)nstreams), dim3(256), 0, st, d_table, nstreams, d_ok, d_poison);
+		hipLaunchKernelGGL(lossy_const_finish_kernel, dim3((unsigned)nstreams), dim3(256), 0, st, d_table, nb, (const unsigned int *)d_ok);
 		return hipGetLastError();
 	}
 

@@ -340,6 +340,8 @@ namespace
 		DeviceBuffer multi_table; // rir_lossy_step_multi_device: the steps of the call (this object leads it)
 		DeviceBuffer run_exchange; // the run kernel's ticket, error word and exchange words
 		DeviceBuffer run_hist, run_tickets, run_bg; // runs of frames: histogram slices and tickets of a group of frames, backgrounds of the call
+	DeviceBuffer const_ok, const_partials;		// constant-budget form: one word per group of the last call (1 = stepped by it), the tail frames' sums
+	int const_groups = 0;						// groups of the last run call that were OFFERED to the constant-budget form (0: it was not eligible)
 		PinnedBuffer multi_stage;
 		hipEvent_t multi_copied = nullptr; // the copy out of multi_stage of the last call (whatever its stream) has completed
 		// A resident run that gave up a wait has advanced the stream's state with invalid frames: the failure is STICKY - every
@@ -2326,6 +2328,20 @@ RIR_EXPORT int rir_lossy_create(int width, int height, int lossy_height, int low
 	return register_object(o);
 }
 
+// A parameter change on a stream in use (H264_Saver::setParameter lowValueError / highValueError / stdFactor, h264.cpp:1709-1781): applies
+// from the next frame on; the history the budget is computed from (firstStdDevs, the 40-frame window) stays.
+RIR_EXPORT int rir_lossy_set_errors(int handle, int low_value_error, int high_value_error, double std_factor)
+{
+	auto o = lookup_as<LossyObject>(handle);
+	if (!o)
+	{
+		log_error("rir_lossy_set_errors: invalid handle");
+		return -1;
+	}
+	o->low = low_value_error, o->high = high_value_error, o->std_factor = std_factor;
+	return 0;
+}
+
 // d_in, d_out: uint16 [nframes][height][width], distinct buffers; low_errors / high_errors: HOST int[nframes] (may be NULL).
 // Frames are processed in order (the state is sequential); add_loss != 0 selects the addLoss variant.
 RIR_EXPORT int rir_lossy_step_device(int handle, const unsigned short *d_in, unsigned short *d_out, int nframes, int add_loss, int *low_errors,
@@ -2510,6 +2526,22 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 						return -1;
 					lead.run_arrivals = 0; // (a fresh control block)
 				}
+				// The constant-budget form (lossy_kernels.hip: lossy_const_run_kernel): with stdFactor == 0 for every stream of the call each
+				// group is first offered to an ordinary launch that needs no hand-offs between workgroups; it declines - on the device, nothing
+				// waits for the host - when a frame's class may be empty or a NaN sits in a window, and the resident launch behind it, which
+				// otherwise finds the group done and leaves, steps it.
+				bool const_form = !getenv("RIR_LOSSY_NO_CONST");
+				for (int i = 0; i < nstreams; ++i)
+					const_form = const_form && os[i]->std_factor == 0.0;
+				const size_t part_words = (size_t)kLossyConstSlots * run_wgs * 4;
+				lead.const_groups = 0;
+				if (const_form)
+				{
+					if (!lead.const_ok.reserve((size_t)ngroups * 4) || !lead.const_partials.reserve((size_t)nstreams * part_words * 8) ||
+						!hip_ok(hipMemsetAsync(lead.const_ok.ptr, 0, (size_t)ngroups * 4, st), "memset"))
+						return -1;
+					lead.const_groups = ngroups;
+				}
 				unsigned int *d_ticket = lead.run_exchange.as<unsigned int>(), *d_error = d_ticket + 16;
 				unsigned long long *d_exch = reinterpret_cast<unsigned long long *>(lead.run_exchange.as<char>() + 256);
 				LossyRun *hr = reinterpret_cast<LossyRun *>(reinterpret_cast<char *>(hs) + run_off);
@@ -2531,6 +2563,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 						r.frame_px = (long long)npx, r.nsteps = in_group;
 						r.s = s_px, r.full = full_px;
 						r.add_loss = add_loss ? 1 : 0, r.low_value_error = os[i]->low, r.high_value_error = os[i]->high, r.std_factor = os[i]->std_factor;
+						r.partials = const_form ? lead.const_partials.as<unsigned long long>() + (size_t)i * part_words : nullptr;
 						hr[(size_t)g * nstreams + i] = r;
 						for (int k = k0; k < k0 + in_group; ++k)
 						{
@@ -2570,6 +2603,11 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 								"lossy backgrounds") ||
 						!hip_ok(hipMemsetAsync(d_exch, 0, exch_bytes, st), "memset"))
 						return -1;
+					const unsigned int *d_ok = const_form ? lead.const_ok.as<unsigned int>() + g : nullptr;
+					if (const_form && !hip_ok(launch_lossy_const(dr + (size_t)g * nstreams, nstreams, full_px, lead.const_ok.as<unsigned int>() + g,
+																  d_ticket + kLossyRunCtlWord + 2, st),
+											  "lossy constant-budget run"))
+						return -1;
 					for (int s0 = 0; s0 < nstreams; s0 += batch)
 					{
 						const int nl = std::min(batch, nstreams - s0);
@@ -2582,7 +2620,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 							if (!hip_ok(hipMemcpyAsync(d_ticket + kLossyRunCtlWord + 1, &w_, 4, hipMemcpyHostToDevice, st), "H2D") || !hip_ok(hipStreamSynchronize(st), "sync"))
 								return -1;
 						}
-						if (!hip_ok(launch_lossy_run(dr + (size_t)g * nstreams + s0, nl, full_px, d_ticket, epoch, lead.run_arrivals, parked, st), "lossy run"))
+						if (!hip_ok(launch_lossy_run(dr + (size_t)g * nstreams + s0, nl, full_px, d_ticket, epoch, lead.run_arrivals, parked, st, d_ok), "lossy run"))
 							return -1;
 						lead.run_arrivals += (unsigned int)(nl * run_wgs);
 					}
@@ -2760,6 +2798,30 @@ RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, con
 		}
 	}
 	return lossy_step_streams(ptrs.data(), nstreams, d_in, d_out, nframes, add_loss, nullptr, low_errors, high_errors, (hipStream_t)stream);
+}
+
+// Which form stepped the groups of frames of the last run call this stream LED (a call of its own, or a multi-stream call it was first in):
+// out[0] = groups offered to the constant-budget form (0: the call was not eligible - stdFactor != 0, frames stepped one by one, ...),
+// out[1] = of those, groups it stepped (the others were declined on the device and stepped by the resident kernel).  Waits for `stream`.
+RIR_EXPORT int rir_lossy_path_stats(int handle, int *out2, void *stream)
+{
+	auto o = lookup_as<LossyObject>(handle);
+	if (!o || !out2)
+	{
+		log_error("rir_lossy_path_stats: invalid argument");
+		return -1;
+	}
+	out2[0] = o->const_groups, out2[1] = 0;
+	if (o->const_groups > 0)
+	{
+		std::vector<unsigned int> w((size_t)o->const_groups);
+		if (!hip_ok(hipMemcpyAsync(w.data(), o->const_ok.ptr, w.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)stream), "D2H") ||
+			!hip_ok(wait_stream((hipStream_t)stream), "sync"))
+			return -1;
+		for (unsigned int v : w)
+			out2[1] += v != 0 ? 1 : 0;
+	}
+	return 0;
 }
 
 // 0 when no run of frames this stream took part in has given up a wait between workgroups, -1 otherwise or on an invalid handle.

@@ -111,6 +111,8 @@ _lib.rir_lossy_step_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, _
 _lib.rir_lossy_step_multi_device.argtypes = [_vp, ct.c_int, _vp, _vp, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.rir_lossy_destroy.argtypes = [ct.c_int]
 _lib.rir_lossy_status.argtypes = [ct.c_int, _vp]
+_lib.rir_lossy_path_stats.argtypes = [ct.c_int, ct.POINTER(ct.c_int), _vp]
+_lib.rir_lossy_set_errors.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_double]
 _lib.rir_split_planes_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp]
 _lib.rir_merge_planes_device.argtypes = [_vp, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.bad_pixels_destroy.restype = None
@@ -660,6 +662,16 @@ class LossyStream:
                                                 lo.ctypes.data if errors else None, hi.ctypes.data if errors else None, _stream()),
                "rir_lossy_step_multi_device")
         return outs, lo, hi
+
+    def set_errors(self, low_value_error, high_value_error, std_factor):
+        """lowValueError / highValueError / stdFactor from the next frame on (the budget's history stays)"""
+        _check(_lib.rir_lossy_set_errors(self.handle, int(low_value_error), int(high_value_error), float(std_factor)), "rir_lossy_set_errors")
+
+    def path_stats(self):
+        """(groups of frames of the last batch this stream led that were offered to the constant-budget form, groups it took); waits"""
+        out = (ct.c_int * 2)()
+        _check(_lib.rir_lossy_path_stats(self.handle, out, _stream()), "rir_lossy_path_stats")
+        return int(out[0]), int(out[1])
 
     def status(self):
         """raises when a queue-only ``step`` / ``step_many`` led by this stream went wrong on the device (waits for the stream)"""

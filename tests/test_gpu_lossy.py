@@ -337,3 +337,166 @@ def test_recording_rate(tmp_path):
         assert mov.images == n and np.abs(mov[n - 1].astype(np.int32) - fr[n - 1]).max() <= 6
     print("bounded-loss recording: %.0f frames/s" % best)
     assert best >= 12000, best
+
+
+# ---- the constant-budget form of a run (stdFactor == 0: lossy_const_run_kernel) ------------------------------------------------
+def _oracle_track(oracle, arr, w, h, hl, low, high, sf, ra, subtract_min=False, add_loss=False, changes=None):
+    """frames, low and high errors of the oracle; changes: {frame: (low, high, std_factor)} applied before that frame"""
+    L = OracleLossy(oracle, w, h, hl, low_err=low, high_err=high, std_factor=sf, running_average=ra, subtract_min=subtract_min)
+    exp, elo, ehi = [], [], []
+    for i in range(arr.shape[0]):
+        if changes and i in changes:
+            L.set_errors(*changes[i])
+        exp.append(L.step(arr[i], add_loss=add_loss and i > 0))
+        lo, hi, _ = L.last_errors()
+        elo.append(lo)
+        ehi.append(hi)
+    return np.stack(exp), elo, ehi
+
+
+CONST_CASES = {
+    "ra8": dict(n=130, h=64, w=96, hl=61, low=3, high=3, ra=8, cuts=[0, 1, 50, 130]),
+    "ra0": dict(n=60, h=40, w=64, hl=40, low=5, high=1, ra=0, cuts=[0, 1, 60]),
+    "ra1": dict(n=70, h=40, w=64, hl=38, low=4, high=2, ra=1, cuts=[0, 1, 30, 31, 70]),
+    "ra2": dict(n=70, h=40, w=64, hl=38, low=4, high=2, ra=2, cuts=[0, 1, 3, 70]),
+    "ra64_longer_than_the_calls": dict(n=150, h=40, w=64, hl=38, low=4, high=2, ra=64, cuts=[0, 1, 20, 45, 150]),
+    "ra32_ring_fills_inside_a_call": dict(n=90, h=48, w=64, hl=48, low=6, high=2, ra=32, cuts=[0, 10, 90]),
+    "high_above_low": dict(n=50, h=40, w=64, hl=38, low=1, high=4, ra=4, cuts=[0, 1, 50]),
+    "subtract_min": dict(n=60, h=40, w=64, hl=37, low=4, high=2, ra=8, cuts=[0, 1, 60], subtract_min=True),
+    "short_calls": dict(n=40, h=40, w=64, hl=38, low=3, high=3, ra=4, cuts=[0, 1, 4, 7, 11, 40]),
+}
+
+
+@pytest.mark.parametrize("add_loss", [False, True], ids=["add_image_lossy", "add_loss"])
+@pytest.mark.parametrize("name", list(CONST_CASES))
+def test_constant_budget_form_matches_oracle(oracle, name, add_loss, monkeypatch):
+    """stdFactor == 0 (BASELINE configs[4], reference test_video_io.py:112-116): batches of frames go through the streaming kernel
+    that needs no hand-off between workgroups - every group of frames taken by it (path_stats), frames and budgets the oracle's,
+    the state handed between the calls, the rings of every length, both variants of the decision."""
+    import torch
+
+    from librir_amd import device as D
+
+    monkeypatch.delenv("RIR_LOSSY_LAUNCH_PER_FRAME", raising=False)
+    monkeypatch.delenv("RIR_LOSSY_RUN_MAX_WORKGROUPS", raising=False)
+    c = CONST_CASES[name]
+    arr = s1_noisy_background(c["n"], c["h"], c["w"], seed=41)
+    exp, elo, ehi = _oracle_track(oracle, arr, c["w"], c["h"], c["hl"], c["low"], c["high"], 0.0, c["ra"], c.get("subtract_min", False), add_loss)
+    ls = D.LossyStream(c["w"], c["h"], c["hl"], c["low"], c["high"], 0.0, c["ra"], subtract_min=c.get("subtract_min", False))
+    t = torch.from_numpy(arr).cuda()
+    got, lo, hi = [], [], []
+    for c0, c1 in zip(c["cuts"][:-1], c["cuts"][1:]):
+        o, l_, h_ = ls.step(t[c0:c1], add_loss=add_loss and c0 > 0)
+        got.append(o), lo.append(l_), hi.append(h_)
+        steps = (c1 - c0) - (1 if c0 == 0 else 0)
+        if c1 - c0 >= 3 and steps >= 2:
+            offered, taken = ls.path_stats()
+            assert offered >= 1 and taken == offered, (name, c0, c1, offered, taken)
+    assert np.array_equal(torch.cat(got).cpu().numpy(), exp)
+    assert np.concatenate(lo).tolist() == elo and np.concatenate(hi).tolist() == ehi
+    ls.close()
+
+
+def test_constant_budget_form_keeps_the_history_a_later_std_factor_needs(oracle):
+    """The window of statistics is history even while it is multiplied by zero: stdFactor raised on a stream that has gone through
+    the constant-budget form - before its window is full, and long after - finds every entry where the reference would have it."""
+    import torch
+
+    from librir_amd import device as D
+
+    n, h, w, hl = 200, 48, 96, 45
+    arr = s1_noisy_background(n, h, w, seed=43)
+    for switch, back in ((20, 60), (131, 170)):
+        changes = {switch: (6, 2, 5.0), back: (4, 4, 0.0)}
+        exp, elo, ehi = _oracle_track(oracle, arr, w, h, hl, 3, 3, 0.0, 8, changes=changes)
+        ls = D.LossyStream(w, h, hl, 3, 3, 0.0, 8)
+        t = torch.from_numpy(arr).cuda()
+        a = ls.step(t[:switch])
+        assert ls.path_stats()[1] >= 1
+        ls.set_errors(6, 2, 5.0)
+        b = ls.step(t[switch:back])
+        assert ls.path_stats() == (0, 0)
+        ls.set_errors(4, 4, 0.0)
+        c = ls.step(t[back:])
+        assert ls.path_stats()[1] >= 1
+        assert np.array_equal(torch.cat([a[0], b[0], c[0]]).cpu().numpy(), exp), switch
+        assert np.concatenate([a[1], b[1], c[1]]).tolist() == elo and np.concatenate([a[2], b[2], c[2]]).tolist() == ehi, switch
+        assert any(e != 6 for e in elo[switch:back]), "the test stream never moved the budget"
+        ls.close()
+
+
+def test_constant_budget_form_declines_what_it_must_not_take(oracle):
+    """An empty foreground or background makes the reference's statistic 0 / 0, and the NaN decides the budgets of that frame and of the
+    39 after it (lossless frames): groups with a frame whose classes are not surely both there, and groups stepped while a NaN sits in
+    the window, are declined on the device and stepped by the general form; afterwards the streaming form takes over again.  Same
+    frames and budgets as the oracle throughout."""
+    import torch
+
+    from librir_amd import device as D
+
+    n, h, w, hl = 260, 40, 64, 40
+    arr = s1_noisy_background(n, h, w, seed=47)
+    arr[60:64] = 1000  # uniform frames: everything in the mode bin, no foreground (from frame 41 on the statistic is split)
+    arr[64] = np.where(np.arange(h * w).reshape(h, w) % 2 == 0, 1000, 1001)  # two levels inside one bin: nothing above, nothing below
+    exp, elo, ehi = _oracle_track(oracle, arr, w, h, hl, 3, 3, 0.0, 4)
+    assert ehi[59] == 3 and ehi[60] == 0 and ehi[103] == 0 and ehi[104] == 3 and set(elo) == {3}, "the crafted stream does not do what the test is about"
+    ls = D.LossyStream(w, h, hl, 3, 3, 0.0, 4)
+    t = torch.from_numpy(arr).cuda()
+    cuts = [0, 1, 50, 70, 90, 140, 200, n]
+    want_taken = {(1, 50): True, (50, 70): False, (70, 90): False, (90, 140): False, (140, 200): True, (200, n): True}
+    got, lo, hi = [], [], []
+    for c0, c1 in zip(cuts[:-1], cuts[1:]):
+        o, l_, h_ = ls.step(t[c0:c1])
+        got.append(o), lo.append(l_), hi.append(h_)
+        if (c0, c1) in want_taken:
+            offered, taken = ls.path_stats()
+            assert offered == 1 and (taken == 1) == want_taken[(c0, c1)], (c0, c1, offered, taken)
+    assert np.array_equal(torch.cat(got).cpu().numpy(), exp)
+    assert np.concatenate(lo).tolist() == elo and np.concatenate(hi).tolist() == ehi
+    ls.close()
+
+
+def test_constant_budget_form_with_many_streams_and_mixed_parameters(oracle):
+    """several streams in the same launches: all with stdFactor 0 -> the streaming form (each with its own errors and ring), one with another
+    factor -> the whole call through the general form; every stream equals its own oracle either way"""
+    import torch
+
+    from librir_amd import device as D
+
+    S, n, h, w, hl = 4, 75, 48, 64, 45
+    for params in ([dict(low=3, high=3, sf=0.0, ra=4), dict(low=6, high=2, sf=0.0, ra=32), dict(low=5, high=1, sf=0.0, ra=0), dict(low=2, high=2, sf=0.0, ra=7)],
+                   [dict(low=3, high=3, sf=0.0, ra=4), dict(low=6, high=2, sf=2.5, ra=32), dict(low=5, high=1, sf=0.0, ra=0), dict(low=2, high=2, sf=0.0, ra=7)]):
+        data = [s1_noisy_background(n, h, w, seed=60 + i) for i in range(S)]
+        streams = [D.LossyStream(w, h, hl, p["low"], p["high"], p["sf"], p["ra"]) for p in params]
+        tens = [torch.from_numpy(d).cuda() for d in data]
+        o1, lo1, hi1 = D.LossyStream.step_many(streams, [t[:30] for t in tens])
+        o2, lo2, hi2 = D.LossyStream.step_many(streams, [t[30:] for t in tens])
+        offered, taken = streams[0].path_stats()
+        if all(p["sf"] == 0.0 for p in params):
+            assert offered >= 1 and taken == offered
+        else:
+            assert offered == 0
+        for i, p in enumerate(params):
+            exp, elo, ehi = _oracle_track(oracle, data[i], w, h, hl, p["low"], p["high"], p["sf"], p["ra"])
+            assert np.array_equal(np.concatenate([o1[i].cpu().numpy(), o2[i].cpu().numpy()]), exp), i
+            assert np.concatenate([lo1[i], lo2[i]]).tolist() == elo and np.concatenate([hi1[i], hi2[i]]).tolist() == ehi, i
+        for s_ in streams:
+            s_.close()
+
+
+def test_constant_budget_form_through_the_saver_with_a_parameter_change(tmp_path, oracle):
+    """h264_add_image_lossy with stdFactor 0 (the saver steps its chunks as runs of frames), stdFactor raised in mid-recording"""
+    n, h, w, hl = 150, 48, 96, 45
+    arr = s1_noisy_background(n, h, w, seed=53)
+    exp, elo, ehi = _oracle_track(oracle, arr, w, h, hl, 3, 3, 0.0, 8, changes={95: (3, 3, 5.0)})
+    dst = tmp_path / "const.h264"
+    with IRSaver(dst, w, h, hl) as s:
+        for k, v in (("lowValueError", 3), ("highValueError", 3), ("stdFactor", 0), ("runningAverage", 8), ("GOP", 40)):
+            s.set_parameter(k, v)
+        for i in range(n):
+            if i == 95:
+                s.set_parameter("stdFactor", 5)
+            s.add_image_lossy(arr[i], i * 1000)
+        assert list(s.get_low_errors()) == elo and list(s.get_high_errors()) == ehi
+    with IRMovie.from_filename(dst) as mov:
+        assert np.array_equal(mov.data, exp)
