@@ -86,6 +86,7 @@ namespace rir
 	// budgets are the configured errors, frame after frame, and nothing a frame needs comes from another workgroup.  Only the last 40
 	// frames of a group (and the stream's very first budget frame) leave sums behind: what the 40-frame window holds afterwards.
 	constexpr int kLossyConstTail = 40, kLossyConstSlots = kLossyConstTail + 1;
+	constexpr int kLossyConstMaxFrames = 2048; // frames of a group it takes (the callers' groups are at most that long)
 	constexpr int kLossyRunThreads = 256; // 8 pixels each
 	inline int lossy_run_workgroups(int full) { return (full / 8 + kLossyRunThreads - 1) / kLossyRunThreads; }
 	// The run kernel needs ALL its workgroups resident at once: workgroup i runs on XCD i % 8, each XCD starts its own share of the
@@ -124,7 +125,9 @@ namespace rir
 	// the group's background words (bit 40: a class may be empty), the streams' budget windows (NaN) and *d_poison (an earlier group of
 	// the call was not stepped) and do nothing unless everything is clear; *d_ok (zeroed by the caller) says which it was - the resident
 	// launch that follows reads it and leaves the group alone when it is 1 (launch_lossy_run's d_ok).
-	hipError_t launch_lossy_const(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ok, const unsigned int *d_poison, hipStream_t st);
+	int lossy_const_workgroups(int full, int nstreams); // workgroups of a stream in that launch: partials holds kLossyConstSlots x this many x 4 words per stream
+	// any_ra: some stream of the launch keeps a running average; add_loss: the addLoss variant of the decision (the same for all streams)
+	hipError_t launch_lossy_const(const LossyRun *d_table, int nstreams, int full, bool any_ra, bool add_loss, unsigned int *d_ok, const unsigned int *d_poison, hipStream_t st);
 	hipError_t launch_lossy_first(const uint16_t *d_tmp, uint16_t *d_out, const LossyDeviceState &state, int s, int full, hipStream_t st);
 	hipError_t launch_lossy_min(const uint16_t *d_tmp, int s, unsigned int *d_result, hipStream_t st);
 	hipError_t launch_lossy_add_min(uint16_t *d_frames, int64_t npx, int s, int nframes, uint32_t mn, hipStream_t st);

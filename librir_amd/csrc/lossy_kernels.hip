@@ -1487,14 +1487,201 @@ namespace rir
 		return k >= tail0 ? 1 + (k - tail0) : (k == 0 ? 0 : -1);
 	}
 
-	constexpr int kConstDepth = 4; // frames in flight per thread
+#ifndef RIR_LOSSY_CONST_DEPTH
+#define RIR_LOSSY_CONST_DEPTH 4
+#endif
+	constexpr int kConstDepth = RIR_LOSSY_CONST_DEPTH; // frames in flight per thread (4, 8 and 12 measure the same: instruction issue, not what is in flight, bounds the kernel)
+	// NP pairs of pixels per thread (4: one 16-byte access per thread, frame and array, as the resident kernel; 2; 1).  Nobody waits for anybody
+	// here, so a stream may be cut as finely as pays: with 8 pixels per thread a 640x512 stream is 640 waves on the chip's 1 024 SIMDs - each
+	// working through its ~300 vector instructions per frame alone - with 2 pixels it is 2 560 waves that hide each other's latencies.
+	typedef unsigned int lossy_v2u __attribute__((ext_vector_type(2)));
+	template <int NP>
+	struct PxN
+	{
+		uint32_t d[NP];
+		__device__ __forceinline__ uint32_t get(int k) const { return (k & 1) ? d[k >> 1] >> 16 : d[k >> 1] & 0xffffu; }
+	};
+	template <int NP, class P>
+	__device__ __forceinline__ PxN<NP> ldn(P p, size_t i)
+	{
+		PxN<NP> r;
+		if constexpr (NP == 4)
+		{
+			const lossy_v4u v = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(p + i * 8);
+			r.d[0] = v.x, r.d[1] = v.y, r.d[2] = v.z, r.d[3] = v.w;
+		}
+		else if constexpr (NP == 2)
+		{
+			const lossy_v2u v = *reinterpret_cast<RIR_GLOBAL(const lossy_v2u) *>(p + i * 4);
+			r.d[0] = v.x, r.d[1] = v.y;
+		}
+		else
+			r.d[0] = *reinterpret_cast<RIR_GLOBAL(const uint32_t) *>(p + i * 2);
+		return r;
+	}
+	template <int NP, class P>
+	__device__ __forceinline__ void stn(P p, size_t i, const PxN<NP> &r)
+	{
+		if constexpr (NP == 4)
+		{
+			lossy_v4u v;
+			v.x = r.d[0], v.y = r.d[1], v.z = r.d[2], v.w = r.d[3];
+			*reinterpret_cast<RIR_GLOBAL(lossy_v4u) *>(p + i * 8) = v;
+		}
+		else if constexpr (NP == 2)
+		{
+			lossy_v2u v;
+			v.x = r.d[0], v.y = r.d[1];
+			*reinterpret_cast<RIR_GLOBAL(lossy_v2u) *>(p + i * 4) = v;
+		}
+		else
+			*reinterpret_cast<RIR_GLOBAL(uint32_t) *>(p + i * 2) = r.d[0];
+	}
+
+	// Every vector-memory operation of the frame loop is an UNCONDITIONAL raw-buffer access - a lane without a pixel, a frame past the end
+	// of the group, a ring that is not read or written this frame: an out-of-range offset or an empty descriptor, which the hardware turns
+	// into "no access" - in straight-line code: only then does the compiler keep counted waits (s_waitcnt vmcnt(N)) and the loads of the
+	// next three frames stay in flight while this one is worked on.  (The first version of this kernel had its loads and stores under
+	// `if (inside)` / `if (lossy)`: every frame began with s_waitcnt vmcnt(0) - a full memory latency per frame and wave, 1.4 us.)
+	typedef unsigned int lossy_v2u_b __attribute__((ext_vector_type(2)));
+#define RIR_LOSSY_BUF_FLAGS 0x00020000 /* raw buffer, 32-bit data format (gfx942 / gfx950 descriptor word 3) */
+#define RIR_LOSSY_OOB 0x80000000u		/* beyond any num_records used here (a frame is < 2 GiB) */
+	__device__ __forceinline__ __amdgpu_buffer_rsrc_t lossy_rsrc(const void *base, uint32_t bytes)
+	{ // (base and bytes are wave-uniform by construction: scalar loads of the launch's table and scalar arithmetic on them)
+		return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, RIR_LOSSY_BUF_FLAGS);
+	}
+	template <int NP>
+	__device__ __forceinline__ PxN<NP> buf_ldn(__amdgpu_buffer_rsrc_t r, uint32_t off)
+	{
+		PxN<NP> x;
+		if constexpr (NP == 4)
+		{
+			const lossy_v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+			x.d[0] = v.x, x.d[1] = v.y, x.d[2] = v.z, x.d[3] = v.w;
+		}
+		else if constexpr (NP == 2)
+		{
+			const lossy_v2u_b v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+			x.d[0] = v.x, x.d[1] = v.y;
+		}
+		else
+			x.d[0] = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+		return x;
+	}
+	template <int NP>
+	__device__ __forceinline__ void buf_stn(const PxN<NP> &x, __amdgpu_buffer_rsrc_t r, uint32_t off)
+	{
+		if constexpr (NP == 4)
+		{
+			lossy_v4u v;
+			v.x = x.d[0], v.y = x.d[1], v.z = x.d[2], v.w = x.d[3];
+			__builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+		}
+		else if constexpr (NP == 2)
+		{
+			lossy_v2u_b v;
+			v.x = x.d[0], v.y = x.d[1];
+			__builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, 0);
+		}
+		else
+			__builtin_amdgcn_raw_buffer_store_b32(x.d[0], r, off, 0, 0);
+	}
+
+	// lossy_pixel_pair without its wave-uniform branches (compile-time: a running average or none, the addLoss variant or not; run time, as
+	// masks: whether the ring is full).  Same values, bit for bit.
+	struct ConstPairConsts
+	{
+		uint32_t min2, bg2, low2, high2, n2; // both halves: subtract_min bound (0 when off), background, error bounds, n_after
+		uint32_t n_after, magic;			 // images in the running average after this frame, lossy_div_magic of it
+		uint32_t full_mask, full_one2;		 // ring full: 0xffffffff / 0x00010001, else 0 / 0
+		uint32_t ra_mask;					 // this stream keeps a running average (a launch built for one may hold streams without)
+	};
+	template <bool RA_ON, bool ADD_LOSS>
+	__device__ __forceinline__ void const_pixel_pair(const ConstPairConsts &c, uint32_t v2, uint32_t old2, uint32_t last2, uint32_t &ref2, uint32_t &sum_lo, uint32_t &sum_hi,
+													 uint32_t &cc2, uint32_t &cv2, uint32_t &t_in2, uint32_t &out2)
+	{
+		const lossy_u16x2 v = lp2(v2), ref = lp2(ref2);
+		const lossy_u16x2 t = __builtin_elementwise_sub_sat(v, lp2(c.min2));
+		t_in2 = lu1(t);
+		const uint32_t fgm = lossy_nz_mask(__builtin_elementwise_sub_sat(v, lp2(c.bg2))); // v > background
+		const lossy_u16x2 max_error = lp2(lossy_bfi(fgm, c.high2, c.low2));
+		const lossy_u16x2 diff = __builtin_elementwise_max(t, ref) - __builtin_elementwise_min(t, ref);
+		lossy_u16x2 nk = __builtin_elementwise_sub_sat(diff, max_error); // != 0: the pixel is not kept
+		if (!ADD_LOSS)
+			nk = nk | ((lp2(last2) ^ v) >> (lossy_u16x2){13, 13});
+		const uint32_t NM = lossy_nz_mask(nk);
+		if (RA_ON)
+		{
+			lossy_u16x2 cc = lp2(cc2);
+			// what leaves the sum when the ring is full: the constant value while its stretch lasts, else the ring's oldest image
+			const uint32_t sel = lossy_bfi(lossy_nz_mask(cc), cv2, old2) & c.full_mask;
+			cc = __builtin_elementwise_sub_sat(cc, lp2(c.full_one2));
+			const uint32_t t_lo = lu1(t) & 0xffffu, t_hi = lu1(t) >> 16;
+			const uint32_t sm_lo = sum_lo + t_lo - (sel & 0xffffu), sm_hi = sum_hi + t_hi - (sel >> 16);
+			const uint32_t q = lossy_div(sm_lo, c.magic) | (lossy_div(sm_hi, c.magic) << 16);
+			sum_lo = (NM & 0xffffu) ? __umul24(t_lo, c.n_after) : sm_lo;
+			sum_hi = (NM >> 16) ? __umul24(t_hi, c.n_after) : sm_hi;
+			out2 = lossy_bfi(NM, lu1(t), lossy_bfi(c.ra_mask, q, ref2));
+			cv2 = lossy_bfi(NM, lu1(t), cv2);
+			cc2 = lossy_bfi(NM, c.n2, lu1(cc));
+		}
+		else
+			out2 = lossy_bfi(NM, lu1(t), ref2);
+		ref2 = lossy_bfi(NM, lu1(t), ref2);
+	}
+
+	// The sums of a frame over the workgroup (h264.cpp:1993-2036): threads 0..3 return the four words of the workgroup's share - fg count << 32
+	// | fg sum d,  fg sum d2,  bg count << 32 | bg sum d,  bg sum d2.  red: 4 x 6 words of LDS.  Every thread of the workgroup calls.
+	template <int NP>
+	__device__ __noinline__ unsigned long long const_frame_sums(PxN<NP> v, PxN<NP> o, uint32_t background, bool lossy, int subtract_min, uint32_t mn, long long *red)
+	{
+		constexpr int PX = 2 * NP;
+		const int tid = threadIdx.x;
+		int32_t fd = 0, fn = 0, bd = 0, bn = 0;
+		long long f2 = 0, b2 = 0;
+#pragma unroll
+		for (int q = 0; q < PX; ++q)
+		{
+			const uint32_t tq = subtract_min ? sub_min(v.get(q), mn) : v.get(q);
+			const int32_t d = lossy ? abs((int32_t)tq - (int32_t)o.get(q)) : 0;
+			const int32_t d2 = (int32_t)((uint32_t)d * (uint32_t)d);
+			const int one = lossy ? 1 : 0;
+			if (v.get(q) > background)
+				fd += d, f2 += d2, fn += one;
+			else
+				bd += d, b2 += d2, bn += one;
+		}
+		const uint32_t wfd = lossy_wave_sum32((uint32_t)fd), wbd = lossy_wave_sum32((uint32_t)bd), wn = lossy_wave_sum32((uint32_t)fn | ((uint32_t)bn << 16));
+		const long long wf2 = lossy_wave_sum(f2), wb2 = lossy_wave_sum(b2);
+		const int lane = tid & 63, wave = tid >> 6;
+		if (lane == 0)
+			red[wave * 6 + 0] = (long long)wfd, red[wave * 6 + 1] = wf2, red[wave * 6 + 2] = (long long)(wn & 0xffffu), red[wave * 6 + 3] = (long long)wbd,
+						 red[wave * 6 + 4] = wb2, red[wave * 6 + 5] = (long long)(wn >> 16);
+		__syncthreads();
+		long long val = 0;
+		if (tid < 4)
+		{
+			const int a = tid == 0 ? 0 : tid == 1 ? 1 : tid == 2 ? 3 : 4;
+			val = red[a] + red[6 + a] + red[12 + a] + red[18 + a];
+			if (tid == 0 || tid == 2)
+				val |= (red[a + 2] + red[6 + a + 2] + red[12 + a + 2] + red[18 + a + 2]) << 32;
+		}
+		__syncthreads();
+		return (unsigned long long)val;
+	}
+
+	template <int NP, bool RA_ON, bool ADD_LOSS>
 	__global__ __launch_bounds__(256) void lossy_const_run_kernel(const LossyRun *__restrict__ table, int nstreams, unsigned int *__restrict__ ok_word,
 																  const unsigned int *__restrict__ poison)
 	{
+		constexpr int PX = 2 * NP;
+		constexpr int D = kConstDepth;
+		typedef PxN<NP> Px;
 		__shared__ unsigned int sh_flag;
 		__shared__ long long red[4][6];
+		__shared__ uint32_t sh_bg[kLossyConstMaxFrames];
 		const int tid = threadIdx.x, b = blockIdx.x, stream = blockIdx.y, nb = gridDim.x;
-		const bool ok = lossy_const_precondition(table, nstreams, poison, &sh_flag);
+		const bool ok = lossy_const_precondition(table, nstreams, poison, &sh_flag) && as_global(table + stream)->nsteps <= kLossyConstMaxFrames;
 		if (b == 0 && stream == 0 && tid == 0)
 			__hip_atomic_store(as_global(ok_word), ok ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		if (!ok)
@@ -1509,168 +1696,184 @@ namespace rir
 		}
 		const LossyDeviceState st = rp.st;
 		RIR_GLOBAL(uint16_t) *refT = as_global(st.refT), *prevT = as_global(st.prevT), *lastDL = as_global(st.lastDL);
-		RIR_GLOBAL(uint16_t) *cval = as_global(st.ra_const_value), *ring = as_global(st.ra_images);
+		RIR_GLOBAL(uint16_t) *cval = as_global(st.ra_const_value);
 		RIR_GLOBAL(uint16_t) *ccnt = (RIR_GLOBAL(uint16_t) *)as_global(st.ra_const_count);
 		RIR_GLOBAL(uint32_t) *sums = as_global(st.ra_sums);
-		RIR_GLOBAL(const uint16_t) *in = as_global(rp.in);
-		RIR_GLOBAL(uint16_t) *out = as_global(rp.out);
 		RIR_GLOBAL(const long long) *bgw = as_global(rp.bg);
-		RIR_GLOBAL(unsigned long long) *partials = as_global(rp.partials);
-		const int s = rp.s, full = rp.full, ra = st.running_average, add_loss = rp.add_loss, n = rp.nsteps;
-		const int i8 = b * 256 + tid;
-		const bool inside = i8 * 8 < full, lossy = i8 * 8 < s;
+		const int s = rp.s, full = rp.full, n = rp.nsteps;
+		const int ra = RA_ON ? st.running_average : 0;
+		const size_t ig = (size_t)b * 256 + tid; // this thread's group of PX pixels
+		const bool inside = ig * PX < (size_t)full, lossy = ig * PX < (size_t)s;
+		const uint32_t off_in = inside ? (uint32_t)(ig * PX * 2) : RIR_LOSSY_OOB, off_lossy = lossy ? (uint32_t)(ig * PX * 2) : RIR_LOSSY_OOB;
+		const uint32_t lossy_mask = lossy ? 0xffffffffu : 0u;
+		const uint32_t full_bytes = (uint32_t)full * 2u, s_bytes = (uint32_t)s * 2u;
+		const uint64_t frame_bytes = (uint64_t)rp.frame_px * 2u, ring_bytes = (uint64_t)s * 2u;
+		const uint64_t in0 = (uint64_t)rp.in, ring0 = (uint64_t)st.ra_images;
 		// the budget of every frame (lossy_budget with a statistic that is multiplied by zero)
-		int high_error = rp.high_value_error < 0 ? 0 : rp.high_value_error;
-		int low_error = rp.low_value_error < high_error ? high_error : rp.low_value_error;
-		const uint32_t min2 = st.subtract_min ? lossy_both(st.min) : 0u;
+		const int high_error = rp.high_value_error < 0 ? 0 : rp.high_value_error;
+		const int low_error = rp.low_value_error < high_error ? high_error : rp.low_value_error;
+		ConstPairConsts pc;
+		pc.min2 = st.subtract_min ? lossy_both(st.min) : 0u;
+		pc.low2 = lossy_both((uint32_t)low_error), pc.high2 = lossy_both((uint32_t)high_error);
+		pc.ra_mask = ra > 0 ? 0xffffffffu : 0u;
+		const __amdgpu_buffer_rsrc_t part_rsrc = lossy_rsrc(rp.partials, (uint32_t)((size_t)kLossyConstSlots * nb * 32));
+		// the group's backgrounds, once, into LDS: a frame's background read from global memory inside the loop is a wave-uniform value the
+		// compiler wants in a scalar register at once - a memory latency per frame and wave
+		for (int k = tid; k < n; k += 256)
+			sh_bg[k] = (uint32_t)bgw[(size_t)k * rp.bg_stride];
+		__syncthreads();
 
-		U16x8 ref8{}, last8{}, cc8{}, cv8{}, o8{}, t8{};
-		uint32_t sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		Px ref{}, last{}, cc{}, cv{}, o{}, t{};
+		uint32_t sum[PX];
+#pragma unroll
+		for (int q = 0; q < PX; ++q)
+			sum[q] = 0;
 		int count = st.ra_count, head = st.ra_head;
-		const int count0 = count, head0 = head;
 		if (lossy)
 		{
-			ref8 = ld8(refT, i8);
-			last8 = ld8(lastDL, i8);
-			o8 = ld8(prevT, i8);
+			ref = ldn<NP>(refT, ig);
+			last = ldn<NP>(lastDL, ig);
+			o = ldn<NP>(prevT, ig);
 			if (ra > 0)
 			{
-				const lossy_v4u s0 = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(sums + (size_t)i8 * 8), s1 = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(sums + (size_t)i8 * 8 + 4);
-				sum[0] = s0.x, sum[1] = s0.y, sum[2] = s0.z, sum[3] = s0.w, sum[4] = s1.x, sum[5] = s1.y, sum[6] = s1.z, sum[7] = s1.w;
-				cc8 = ld8(ccnt, i8);
-				cv8 = ld8(cval, i8);
-			}
-		}
-		// what leaves the running average at frame k, when the ring is full then: the input of frame k - ra (less the minimum) once that is a
-		// frame of this group, else the ring's image at the head as it is at frame k - an image from before the group, which the group
-		// has not overwritten (it only writes the ring in its last `ra` frames, each slot after it has been read)
-		auto request_old = [&](int k, U16x8 &dst) {
-			if (!(lossy && ra > 0 && count0 + k >= ra && k < n))
-				return;
-			if (k >= ra)
-			{
-				dst = ld8(in + (size_t)(k - ra) * rp.frame_px, i8);
 #pragma unroll
-				for (int p = 0; p < 4; ++p)
-					dst.d[p] = lu1(__builtin_elementwise_sub_sat(lp2(dst.d[p]), lp2(min2)));
-			}
-			else
-			{
-				const int adv = count0 + k - ra; // steps the head has made by frame k (it moves once the ring is full)
-				dst = ld8(ring + (size_t)((head0 + (count0 == ra ? k : adv)) % ra) * s, i8);
-			}
-		};
-		U16x8 V[kConstDepth], O[kConstDepth];
-#pragma unroll
-		for (int j = 0; j < kConstDepth; ++j)
-		{
-			V[j] = U16x8{}, O[j] = U16x8{};
-			if (inside && j < n)
-				V[j] = ld8(in + (size_t)j * rp.frame_px, i8);
-			request_old(j, O[j]);
-		}
-		for (int k0 = 0; k0 < n; k0 += kConstDepth)
-		{
-#pragma unroll
-			for (int j = 0; j < kConstDepth; ++j)
-			{
-				const int k = k0 + j;
-				if (k >= n)
-					break;
-				const U16x8 v8 = V[j], old8 = O[j];
-				if (inside && k + kConstDepth < n)
-					V[j] = ld8(in + (size_t)(k + kConstDepth) * rp.frame_px, i8);
-				request_old(k + kConstDepth, O[j]);
-				const uint32_t background = (uint32_t)bgw[(size_t)k * rp.bg_stride];
-				const int slot = lossy_const_slot(k, n);
-				if (slot >= 0)
-				{ // this frame's statistic will be in the window (or seeds it): its sums against the previous output, per workgroup
-					int32_t fd = 0, fn = 0, bd = 0, bn = 0;
-					long long f2 = 0, b2 = 0;
-					if (lossy)
-					{
-#pragma unroll
-						for (int q = 0; q < 8; ++q)
-						{
-							const uint32_t t = st.subtract_min ? sub_min(v8.get(q), st.min) : v8.get(q);
-							const int32_t d = abs((int32_t)t - (int32_t)o8.get(q));
-							const int32_t d2 = (int32_t)((uint32_t)d * (uint32_t)d);
-							if (v8.get(q) > background)
-								fd += d, f2 += d2, fn += 1;
-							else
-								bd += d, b2 += d2, bn += 1;
-						}
-					}
-					const uint32_t wfd = lossy_wave_sum32((uint32_t)fd), wbd = lossy_wave_sum32((uint32_t)bd), wn = lossy_wave_sum32((uint32_t)fn | ((uint32_t)bn << 16));
-					const long long wf2 = lossy_wave_sum(f2), wb2 = lossy_wave_sum(b2);
-					const int lane = tid & 63, wave = tid >> 6;
-					if (lane == 0)
-						red[wave][0] = (long long)wfd, red[wave][1] = wf2, red[wave][2] = (long long)(wn & 0xffffu), red[wave][3] = (long long)wbd, red[wave][4] = wb2,
-						red[wave][5] = (long long)(wn >> 16);
-					__syncthreads();
-					if (tid < 4)
-					{ // four words per workgroup: fg count << 32 | fg sum d,  fg sum d2,  bg count << 32 | bg sum d,  bg sum d2
-						const int a = tid == 0 ? 0 : tid == 1 ? 1 : tid == 2 ? 3 : 4;
-						long long v = red[0][a] + red[1][a] + red[2][a] + red[3][a];
-						if (tid == 0 || tid == 2)
-							v |= (red[0][a + 2] + red[1][a + 2] + red[2][a + 2] + red[3][a + 2]) << 32;
-						partials[((size_t)slot * nb + b) * 4 + tid] = (unsigned long long)v;
-					}
-					__syncthreads();
-				}
-				const bool full_ring = ra > 0 && count == ra;
-				const int n_after = ra > 0 ? (full_ring ? ra : count + 1) : 0;
-				if (lossy)
-				{
-					const LossyFrameConsts fc = {st.min, background, st.subtract_min, ra, full_ring ? 1 : 0, n_after, add_loss, low_error, high_error, lossy_div_magic(n_after)};
-					const LossyPairConsts pc = lossy_pair_consts(fc);
-#pragma unroll
-					for (int p = 0; p < 4; ++p)
-						lossy_pixel_pair(fc, pc, v8.d[p], old8.d[p], last8.d[p], ref8.d[p], sum[2 * p], sum[2 * p + 1], cc8.d[p], cv8.d[p], t8.d[p], o8.d[p]);
-					last8 = v8;
-					st8(out + (size_t)k * rp.frame_px, i8, o8);
-					if (ra > 0 && k >= n - ra)
-					{ // the ring as it must be after the group: the last `ra` inputs
-						const int rs = full_ring ? head : (head + count) % ra;
-						st8(ring + (size_t)rs * s, i8, t8);
-					}
-				}
-				else if (inside)
-				{
-					st8(out + (size_t)k * rp.frame_px, i8, v8); // rows past lossy_height: stored as they are
-					last8 = v8;
-				}
-				if (ra > 0)
-				{
-					if (count == ra)
-						head = (head + 1) % ra;
-					else
-						++count;
-				}
-			}
-		}
-		if (lossy)
-		{
-			st8(refT, i8, ref8);
-			st8(lastDL, i8, last8);
-			st8(prevT, i8, o8);
-			if (ra > 0)
-			{
-				lossy_v4u s0, s1;
-				s0.x = sum[0], s0.y = sum[1], s0.z = sum[2], s0.w = sum[3], s1.x = sum[4], s1.y = sum[5], s1.z = sum[6], s1.w = sum[7];
-				*reinterpret_cast<RIR_GLOBAL(lossy_v4u) *>(sums + (size_t)i8 * 8) = s0;
-				*reinterpret_cast<RIR_GLOBAL(lossy_v4u) *>(sums + (size_t)i8 * 8 + 4) = s1;
-				st8(ccnt, i8, cc8);
-				st8(cval, i8, cv8);
+				for (int q = 0; q < PX; ++q)
+					sum[q] = sums[ig * PX + q];
+				cc = ldn<NP>(ccnt, ig);
+				cv = ldn<NP>(cval, ig);
 			}
 		}
 		else if (inside)
-			st8(lastDL, i8, last8);
+			last = ldn<NP>(lastDL, ig);
+		// Frame kf is REQUESTED: its pixels, its background, and what leaves the running average at it when the ring is full then - the
+		// input of frame kf - ra (less the minimum) once that is a frame of this group, else the ring's image at the head as it is at frame
+		// kf: an image from before the group, which the group has not overwritten (it only writes the ring in its last `ra` frames, each
+		// slot after it has been read).  All wave-uniform choices, all addresses running sums: one load each, whatever the case.
+		Px V[D], O[D];
+		uint32_t B[D], M[D];
+		int kf = 0;					 // the next frame to request
+		uint64_t req_in = in0;		 // its pixels
+		int req_count = count;		 // images in the ring when it is stepped
+		int req_slot = head;		 // the ring's head then (valid once the ring is full)
+		const uint64_t ra_back = (uint64_t)ra * frame_bytes;
+		auto request = [&](Px &v, Px &old, uint32_t &bgv, uint32_t &mv) {
+			const bool more = kf < n;
+			bgv = sh_bg[more ? kf : 0];
+			v = buf_ldn<NP>(lossy_rsrc((const void *)req_in, more ? full_bytes : 0u), off_in);
+			if (RA_ON)
+			{
+				const bool need_old = more && ra > 0 && req_count == ra;
+				const bool from_in = kf >= ra;
+				const uint64_t ob = from_in ? req_in - ra_back : ring0 + (uint64_t)req_slot * ring_bytes;
+				old = buf_ldn<NP>(lossy_rsrc((const void *)ob, need_old ? s_bytes : 0u), off_lossy);
+				mv = from_in ? pc.min2 : 0u;
+				if (req_count == ra)
+					req_slot = req_slot + 1 == ra ? 0 : req_slot + 1;
+				else
+					++req_count;
+			}
+			req_in += frame_bytes;
+			++kf;
+		};
+#pragma unroll
+		for (int j = 0; j < D; ++j)
+			request(V[j], O[j], B[j], M[j]);
+		// per-frame constants that only move while the ring fills
+		auto ring_consts = [&]() {
+			const int n_after = ra > 0 ? (count == ra ? ra : count + 1) : 0;
+			pc.n_after = (uint32_t)n_after, pc.magic = lossy_div_magic(n_after), pc.n2 = (uint32_t)n_after * 0x10001u;
+			pc.full_mask = (ra > 0 && count == ra) ? 0xffffffffu : 0u, pc.full_one2 = pc.full_mask & 0x00010001u;
+		};
+		ring_consts();
+		const int tail0 = n > kLossyConstTail ? n - kLossyConstTail : 0;
+		const int ring_from = n - ra; // frames from here on are in the ring after the group
+		uint64_t out_p = (uint64_t)rp.out;
+		auto step = [&](int k, Px &Vj, Px &Oj, uint32_t &Bj, uint32_t &Mj) {
+			const Px v = Vj;
+			Px old = Oj;
+			if (RA_ON)
+			{
+#pragma unroll
+				for (int p = 0; p < NP; ++p)
+					old.d[p] = lu1(__builtin_elementwise_sub_sat(lp2(old.d[p]), lp2(Mj)));
+			}
+			const uint32_t background = Bj;
+			request(Vj, Oj, Bj, Mj);
+			// the frame's sums, if its statistic will be in the window (or seeds it): against the previous output, per workgroup (out of
+			// line: 41 frames of a group come here, and the loop body is unrolled kConstDepth times)
+			lossy_v2u_b pval = {0u, 0u};
+			uint32_t poff = RIR_LOSSY_OOB;
+			if (k >= tail0 || k == 0)
+			{
+				const int slot = k >= tail0 ? 1 + (k - tail0) : 0;
+				const unsigned long long val = const_frame_sums<NP>(v, o, background, lossy, st.subtract_min, st.min, &red[0][0]);
+				if (tid < 4)
+				{
+					pval.x = (uint32_t)val, pval.y = (uint32_t)(val >> 32);
+					poff = (uint32_t)((((size_t)slot * nb + b) * 4 + tid) * 8);
+				}
+			}
+			__builtin_amdgcn_raw_buffer_store_b64(pval, part_rsrc, poff, 0, 0); // (every frame: out of range unless the frame leaves sums)
+			pc.bg2 = lossy_both(background);
+			Px ov;
+#pragma unroll
+			for (int p = 0; p < NP; ++p)
+			{
+				const_pixel_pair<RA_ON, ADD_LOSS>(pc, v.d[p], old.d[p], last.d[p], ref.d[p], sum[2 * p], sum[2 * p + 1], cc.d[p], cv.d[p], t.d[p], o.d[p]);
+				ov.d[p] = lossy_bfi(lossy_mask, o.d[p], v.d[p]); // rows past lossy_height: stored as they are
+			}
+			last = v;
+			buf_stn<NP>(ov, lossy_rsrc((const void *)out_p, full_bytes), off_in);
+			out_p += frame_bytes;
+			if (RA_ON)
+			{
+				// the ring as it must be after the group: the last `ra` inputs
+				const bool full_ring = count == ra;
+				int rs = full_ring ? head : head + count;
+				rs = rs >= ra ? rs - ra : rs;
+				buf_stn<NP>(t, lossy_rsrc((const void *)(ring0 + (uint64_t)rs * ring_bytes), (ra > 0 && k >= ring_from) ? s_bytes : 0u), off_lossy);
+				if (full_ring)
+					head = head + 1 == ra ? 0 : head + 1;
+				else
+				{
+					++count;
+					ring_consts();
+				}
+			}
+		};
+		int k0 = 0;
+		for (; k0 + D <= n; k0 += D)
+		{ // whole iterations of D unconditional steps
+#pragma unroll
+			for (int j = 0; j < D; ++j)
+				step(k0 + j, V[j], O[j], B[j], M[j]);
+		}
+		// up to D - 1 left-over frames (the slot rotation stays aligned)
+#pragma unroll
+		for (int j = 0; j < D - 1; ++j)
+			if (k0 + j < n)
+				step(k0 + j, V[j], O[j], B[j], M[j]);
+		if (lossy)
+		{
+			stn<NP>(refT, ig, ref);
+			stn<NP>(lastDL, ig, last);
+			stn<NP>(prevT, ig, o);
+			if (ra > 0)
+			{
+#pragma unroll
+				for (int q = 0; q < PX; ++q)
+					sums[ig * PX + q] = sum[q];
+				stn<NP>(ccnt, ig, cc);
+				stn<NP>(cval, ig, cv);
+			}
+		}
+		else if (inside)
+			stn<NP>(lastDL, ig, last);
 	}
 
-	// grid = streams, 256 threads.  The window entries of the frames that left sums (exact integers -> the reference's double
+	// grid = streams, 1 024 threads.  The window entries of the frames that left sums (exact integers -> the reference's double
 	// arithmetic, lossy_budget's), the window's counters as they are after the group's n frames, the budgets of the frames.
-	__global__ __launch_bounds__(256) void lossy_const_finish_kernel(const LossyRun *__restrict__ table, int nb, const unsigned int *__restrict__ ok_word)
+	__global__ __launch_bounds__(1024) void lossy_const_finish_kernel(const LossyRun *__restrict__ table, int nb, const unsigned int *__restrict__ ok_word)
 	{
 		__shared__ double sd[kLossyConstSlots][2];
 		if (*as_global(ok_word) == 0u)
@@ -1682,7 +1885,7 @@ namespace rir
 		const int n = r->nsteps, s = r->s;
 		const int n_first0 = bud->n_first, n_win0 = bud->n_win, head0 = bud->head;
 		const int tail0 = n > kLossyConstTail ? n - kLossyConstTail : 0;
-		for (int slot = wave; slot < kLossyConstSlots; slot += 4)
+		for (int slot = wave; slot < kLossyConstSlots; slot += 16)
 		{
 			const int k = slot == 0 ? 0 : tail0 + slot - 1; // the frame of this slot
 			if (k >= n || (slot == 0 && tail0 == 0))
@@ -1756,7 +1959,7 @@ namespace rir
 			const int high_error = r->high_value_error < 0 ? 0 : r->high_value_error;
 			const int low_error = r->low_value_error < high_error ? high_error : r->low_value_error;
 			RIR_GLOBAL(int) *e = as_global(r->errors_out);
-			for (int k = tid; k < n; k += 256)
+			for (int k = tid; k < n; k += 1024)
 				e[2 * k] = low_error, e[2 * k + 1] = high_error;
 		}
 	}
@@ -1890,11 +2093,53 @@ namespace rir
 			hipLaunchKernelGGL(lossy_run_kernel, dim3((unsigned)(nb * nstreams)), dim3(kLossyRunThreads), 0, st, d_table, d_ticket, nb, nstreams, epoch, arrivals_before, d_ok);
 		return hipGetLastError();
 	}
-	hipError_t launch_lossy_const(const LossyRun *d_table, int nstreams, int full, unsigned int *d_ok, const unsigned int *d_poison, hipStream_t st)
+	// Pairs of pixels per thread: the kernel is bound by instruction issue - ~100 vector + ~100 scalar instructions per frame and wave whatever
+	// the wave holds, ~80 vector instructions per pair - so a launch wants its pixels spread over 2-3 waves per SIMD and, beyond that, as many
+	// pixels per wave as possible: the largest of 4, 2, 1 pairs that still gives 2 500 waves (one 640x512 stream: 1 pair, 2 560 waves -
+	// 0.95 M frames/s against 0.85 M with 4 pairs; nine streams: 4 pairs, 1.28 M against 1.08 M with 1).
+	int lossy_const_pairs(int full, int nstreams)
 	{
-		const int nb = lossy_run_workgroups(full);
-		hipLaunchKernelGGL(lossy_const_run_kernel, dim3((unsigned)nb, (unsigned)nstreams), dim3(256), 0, st, d_table, nstreams, d_ok, d_poison);
-		hipLaunchKernelGGL(lossy_const_finish_kernel, dim3((unsigned)nstreams), dim3(256), 0, st, d_table, nb, (const unsigned int *)d_ok);
+		static int forced = -1;
+		if (forced < 0)
+		{
+			const char *ev = getenv("RIR_LOSSY_CONST_PAIRS"); // measurement aid
+			forced = ev ? atoi(ev) : 0;
+			if (forced != 4 && forced != 2 && forced != 1)
+				forced = 0;
+		}
+		if (forced)
+			return forced;
+		for (int np = 4; np > 1; np >>= 1)
+			if ((long long)full / (2 * np) / 64 * nstreams >= 2500)
+				return np;
+		return 1;
+	}
+	int lossy_const_workgroups(int full, int nstreams) { return (full / (2 * lossy_const_pairs(full, nstreams)) + 255) / 256; }
+	hipError_t launch_lossy_const(const LossyRun *d_table, int nstreams, int full, bool any_ra, bool add_loss, unsigned int *d_ok, const unsigned int *d_poison, hipStream_t st)
+	{
+		const int np = lossy_const_pairs(full, nstreams), nb = lossy_const_workgroups(full, nstreams);
+		const dim3 grid((unsigned)nb, (unsigned)nstreams);
+		// (the variant - a running average or none, addLoss or not - is the launch's: streams of a call share add_loss, and a call whose streams
+		// differ in having a running average goes through the instantiation with one, which reads each stream's own length)
+#define RIR_CONST_LAUNCH(NPV)                                                                                                                  \
+	{                                                                                                                                          \
+		if (any_ra && add_loss)                                                                                                                \
+			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, true, true>), grid, dim3(256), 0, st, d_table, nstreams, d_ok, d_poison);          \
+		else if (any_ra)                                                                                                                       \
+			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, true, false>), grid, dim3(256), 0, st, d_table, nstreams, d_ok, d_poison);         \
+		else if (add_loss)                                                                                                                     \
+			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, false, true>), grid, dim3(256), 0, st, d_table, nstreams, d_ok, d_poison);         \
+		else                                                                                                                                   \
+			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, false, false>), grid, dim3(256), 0, st, d_table, nstreams, d_ok, d_poison);        \
+	}
+		if (np == 4)
+			RIR_CONST_LAUNCH(4)
+		else if (np == 2)
+			RIR_CONST_LAUNCH(2)
+		else
+			RIR_CONST_LAUNCH(1)
+#undef RIR_CONST_LAUNCH
+		hipLaunchKernelGGL(lossy_const_finish_kernel, dim3((unsigned)nstreams), dim3(1024), 0, st, d_table, nb, (const unsigned int *)d_ok);
 		return hipGetLastError();
 	}
 

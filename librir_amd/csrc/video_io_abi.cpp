@@ -2533,7 +2533,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 				bool const_form = !getenv("RIR_LOSSY_NO_CONST");
 				for (int i = 0; i < nstreams; ++i)
 					const_form = const_form && os[i]->std_factor == 0.0;
-				const size_t part_words = (size_t)kLossyConstSlots * run_wgs * 4;
+				const size_t part_words = (size_t)kLossyConstSlots * lossy_const_workgroups(full_px, nstreams) * 4;
 				lead.const_groups = 0;
 				if (const_form)
 				{
@@ -2604,7 +2604,10 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 						!hip_ok(hipMemsetAsync(d_exch, 0, exch_bytes, st), "memset"))
 						return -1;
 					const unsigned int *d_ok = const_form ? lead.const_ok.as<unsigned int>() + g : nullptr;
-					if (const_form && !hip_ok(launch_lossy_const(dr + (size_t)g * nstreams, nstreams, full_px, lead.const_ok.as<unsigned int>() + g,
+					bool any_ra = false;
+					for (int i = 0; i < nstreams; ++i)
+						any_ra = any_ra || os[i]->st.dev.running_average > 0;
+					if (const_form && !hip_ok(launch_lossy_const(dr + (size_t)g * nstreams, nstreams, full_px, any_ra, add_loss != 0, lead.const_ok.as<unsigned int>() + g,
 																  d_ticket + kLossyRunCtlWord + 2, st),
 											  "lossy constant-budget run"))
 						return -1;
