@@ -96,6 +96,9 @@ namespace rir
 #ifdef RIR_ECC_DIAG
 	static __shared__ unsigned long long ecc_diag_loop_end, ecc_diag_reduced; // (written by every thread with about the same value)
 #endif
+#ifndef RIR_ECC_GRAD_ON_THE_FLY
+#define RIR_ECC_GRAD_ON_THE_FLY 0 /* measured: slower (81 k against 90 k frames/s over 8 sequences) although the L2 then holds a sequence - DESIGN.md */
+#endif
 #ifndef RIR_ECC_PIXELS_PER_ROUND
 #define RIR_ECC_PIXELS_PER_ROUND 3 /* one sequence, one wave per SIMD: 19.3 k frames/s; 2: 18.8 k, 6: 19.3 k at 226 VGPRs */
 #endif
@@ -138,6 +141,7 @@ namespace rir
 		const int dy = stride / w, dx = stride - dy * w;
 		const uint32_t bytes = (uint32_t)npx * 4u;
 		const __amdgpu_buffer_rsrc_t r_img = ecc_rsrc(image, bytes), r_gx = ecc_rsrc(gximg, bytes), r_gy = ecc_rsrc(gyimg, bytes), r_t = ecc_rsrc(templ, bytes);
+		(void)r_gx, (void)r_gy;
 		auto ld = [](__amdgpu_buffer_rsrc_t r, uint32_t off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); };
 		auto sample = [&](int i, int x, int y, bool inside) {
 			const float sx = (float)x + tx, sy = (float)y + ty;
@@ -166,6 +170,33 @@ namespace rir
 			// (The two taps of an image row as ONE 8-byte load - 7 loads per pixel instead of 13, the lanes at the image's left and right edge
 			// fixed up afterwards - was measured: the loop took 5.4 us a row instead of 3.6.  8-byte loads at addresses that are only
 			// 4-byte aligned are not what the memory pipeline likes.)
+#if RIR_ECC_GRAD_ON_THE_FLY
+			// The gradient taps are COMPUTED from the image instead of loaded from the gradient arrays: the same twelve loads per pixel, but
+			// all of them from ONE array - a sequence's working set is its image and its template, 2.6 MB instead of 5.2, under an XCD's 4 MB
+			// L2 (with four arrays 44 % of the L2 accesses of the sequence kernels missed: profiles/r03_pmc_ecc_caches.json).  Same values,
+			// bit for bit: a stored gradient is 0.5f * right - 0.5f * left of the stored image (ecc_gradient_kernel,
+			// minmax_apply_grad_frames_kernel), two exact products and one rounding, and at the image's edge, where reflection makes both
+			// neighbours the same pixel, it is 0.5f a - 0.5f a = +0.
+			{
+				const bool xm = (unsigned)(x0 - 1) < (unsigned)w, xp = (unsigned)(x0 + 2) < (unsigned)w, ym = (unsigned)(y0 - 1) < (unsigned)h,
+						   yp = (unsigned)(y0 + 2) < (unsigned)h;
+				const float i00 = ld(r_img, xa && ya ? lin : kOutside), i01 = ld(r_img, xb && ya ? lin + 4u : kOutside);
+				const float i10 = ld(r_img, xa && yb ? lin + w4 : kOutside), i11 = ld(r_img, xb && yb ? lin + w4 + 4u : kOutside);
+				const float im0 = ld(r_img, xm && ya ? lin - 4u : kOutside), ip0 = ld(r_img, xp && ya ? lin + 8u : kOutside);
+				const float im1 = ld(r_img, xm && yb ? lin + w4 - 4u : kOutside), ip1 = ld(r_img, xp && yb ? lin + w4 + 8u : kOutside);
+				const float iu0 = ld(r_img, xa && ym ? lin - w4 : kOutside), iu1 = ld(r_img, xb && ym ? lin - w4 + 4u : kOutside);
+				const float id0 = ld(r_img, xa && yp ? lin + 2u * w4 : kOutside), id1 = ld(r_img, xb && yp ? lin + 2u * w4 + 4u : kOutside);
+				// a tap (c, r) has a horizontal gradient when it is inside the image and not in its first or last column (there: + 0)
+				const bool cx0 = x0 > 0 && x0 < w - 1, cx1 = x0 + 1 > 0 && x0 + 1 < w - 1, cy0 = y0 > 0 && y0 < h - 1, cy1 = y0 + 1 > 0 && y0 + 1 < h - 1;
+				const float gx00 = cx0 && ya ? 0.5f * i01 - 0.5f * im0 : 0.0f, gx01 = cx1 && ya ? 0.5f * ip0 - 0.5f * i00 : 0.0f;
+				const float gx10 = cx0 && yb ? 0.5f * i11 - 0.5f * im1 : 0.0f, gx11 = cx1 && yb ? 0.5f * ip1 - 0.5f * i10 : 0.0f;
+				const float gy00 = cy0 && xa ? 0.5f * i10 - 0.5f * iu0 : 0.0f, gy01 = cy0 && xb ? 0.5f * i11 - 0.5f * iu1 : 0.0f;
+				const float gy10 = cy1 && xa ? 0.5f * id0 - 0.5f * i00 : 0.0f, gy11 = cy1 && xb ? 0.5f * id1 - 0.5f * i01 : 0.0f;
+				p.I = lerp2(i00, i01, i10, i11);
+				p.gx = lerp2(gx00, gx01, gx10, gx11);
+				p.gy = lerp2(gy00, gy01, gy10, gy11);
+			}
+#else
 			{
 				const uint32_t o00 = xa && ya ? lin : kOutside, o01 = xb && ya ? lin + 4u : kOutside, o10 = xa && yb ? lin + w4 : kOutside,
 							   o11 = xb && yb ? lin + w4 + 4u : kOutside;
@@ -174,6 +205,7 @@ namespace rir
 				p.gx = blend(r_gx);
 				p.gy = blend(r_gy);
 			}
+#endif
 			p.T = ld(r_t, (uint32_t)i * 4u);
 			p.valid = valid;
 			return p;
@@ -586,6 +618,85 @@ namespace rir
 	{
 		return ((unsigned long long)(epoch & 0x3fffffffu) << 32) | ((unsigned long long)(unsigned int)f << 20) | (unsigned long long)((unsigned int)it & 0xfffffu);
 	}
+	// The service workgroup of sequence q of a multi-sequence launch: rows in, translation out, image after image.  Out of line: its
+	// registers (the 2x2 solve in double precision) are then not the pixel loop's, which is pinned at 96 by five waves per SIMD.
+	__device__ __noinline__ void ecc_multi_service(EccSeq *__restrict__ table, int q, int V, int max_iter, double eps, unsigned int epoch, double (*part)[17],
+												   double *tot, int *sh_done_p)
+	{
+		const int tid = threadIdx.x;
+		int &sh_done = *sh_done_p;
+		__builtin_amdgcn_s_setprio(3); // (it shares its CU with four compute workgroups, and everybody waits for what it does)
+		const EccSeq sq = table[q];
+		unsigned long long *pub = reinterpret_cast<unsigned long long *>(sq.rows + (size_t)V * 32);
+		const __amdgpu_buffer_rsrc_t pub_rs = ecc_rsrc(pub, 16u);
+		EccState st; // (thread 0 keeps the real one)
+		st.tx = sq.tx0, st.ty = sq.ty0;
+		int done = 0, frames_done = 0;
+		for (int f = 0; f < sq.nframes && done != 2; ++f)
+		{
+			st.rho = -1.0, st.last_rho = -eps;
+			st.iter = 0, st.done = 0, st.ticket = 0;
+			st.max_iter = max_iter, st.eps = eps;
+			done = 0;
+			for (int it = 1; !done; ++it)
+			{
+				const unsigned long long flag = ecc_flag(epoch, f, it);
+#ifdef RIR_ECC_DIAG
+				const unsigned long long dg0 = __builtin_amdgcn_s_memrealtime();
+#endif
+				// While the rows are being computed only a few of them are watched - every 16th, one granule each, by 16 lanes - and
+				// the whole set (61 KB of write-through granules per look) is asked for when those have come: the rows of a turn are
+				// finished within a microsecond of each other, and eight service workgroups that look at everything all the time
+				// are 0.3 TB/s of traffic past the L2s that the pixel loops feel.
+				if (tid < 16)
+				{
+					const __amdgpu_buffer_rsrc_t rs = ecc_rsrc(sq.rows, (uint32_t)V * 256u);
+					const uint32_t off = (uint32_t)min(tid * 16 + 15, V - 1) * 256u;
+					const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+					for (;;)
+					{
+						const ecc_v4u gr = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16 /* sc1 */);
+						const bool here = (((((unsigned long long)gr.w << 32) | gr.z) ^ flag) & kEccFlagMask) == 0;
+						if (__builtin_amdgcn_ballot_w64(!here) == 0 || __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull)
+							break; // (all 16 have come - or 2 s have passed: the full look below has a clock of its own)
+						__builtin_amdgcn_s_sleep(2);
+					}
+				}
+				__syncthreads();
+				const bool all_ok = ecc_rows_total<true>(sq.rows, V, flag, part, tot);
+#ifdef RIR_ECC_DIAG
+				const unsigned long long dg1 = __builtin_amdgcn_s_memrealtime();
+#endif
+				if (tid == 0)
+				{
+					done = all_ok ? ecc_solve_step(tot, st) : 2;
+					sh_done = done;
+					ecc_granule_store(pub_rs, 0, (unsigned long long)__float_as_uint(st.tx) | ((unsigned long long)__float_as_uint(st.ty) << 32),
+									  flag | ((unsigned long long)done << 62));
+#ifdef RIR_ECC_DIAG
+					if (q == 0)
+					{ // ticks (10 ns): waiting for + adding the rows | solve + publish
+						unsigned long long *dg = pub + 8;
+						dg[0] += dg1 - dg0, dg[1] += __builtin_amdgcn_s_memrealtime() - dg1, dg[2] += 1;
+					}
+#endif
+				}
+				__syncthreads();
+				done = sh_done;
+				__syncthreads(); // (part / tot / sh_done are reused by the next iteration)
+			}
+			if (tid == 0)
+			{
+				EccFrameResult r;
+				r.tx = st.tx, r.ty = st.ty, r.rho = st.rho, r.iter = st.iter, r.done = done;
+				sq.results[f] = r;
+			}
+			frames_done = f + 1;
+		}
+		if (tid == 0)
+			table[q].frames_done = frames_done;
+	}
+
 	__attribute__((amdgpu_waves_per_eu(RIR_ECC_MULTI_WAVES, RIR_ECC_MULTI_WAVES))) __global__ __launch_bounds__(ECC_BLOCK) void ecc_run_multi_kernel(EccSeq *__restrict__ table, int S, int w, int h, int V, int max_iter, double eps,
 																	  unsigned int epoch, unsigned int *__restrict__ ctl, unsigned int arrivals_before,
 																	  unsigned int *host_go)
@@ -608,78 +719,8 @@ namespace rir
 		const size_t npx = (size_t)w * h;
 		const int ncompute = (int)gridDim.x - S;
 		if ((int)blockIdx.x >= ncompute)
-		{ // ---- the service workgroup of sequence q: rows in, translation out, image after image ----
-			const int q = (int)blockIdx.x - ncompute;
-			__builtin_amdgcn_s_setprio(3); // (it shares its CU with four compute workgroups, and everybody waits for what it does)
-			const EccSeq sq = table[q];
-			unsigned long long *pub = reinterpret_cast<unsigned long long *>(sq.rows + (size_t)V * 32);
-			const __amdgpu_buffer_rsrc_t pub_rs = ecc_rsrc(pub, 16u);
-			EccState st; // (thread 0 keeps the real one)
-			st.tx = sq.tx0, st.ty = sq.ty0;
-			int done = 0, frames_done = 0;
-			for (int f = 0; f < sq.nframes && done != 2; ++f)
-			{
-				st.rho = -1.0, st.last_rho = -eps;
-				st.iter = 0, st.done = 0, st.ticket = 0;
-				st.max_iter = max_iter, st.eps = eps;
-				done = 0;
-				for (int it = 1; !done; ++it)
-				{
-					const unsigned long long flag = ecc_flag(epoch, f, it);
-#ifdef RIR_ECC_DIAG
-					const unsigned long long dg0 = __builtin_amdgcn_s_memrealtime();
-#endif
-					// While the rows are being computed only a few of them are watched - every 16th, one granule each, by 16 lanes - and
-					// the whole set (61 KB of write-through granules per look) is asked for when those have come: the rows of a turn are
-					// finished within a microsecond of each other, and eight service workgroups that look at everything all the time
-					// are 0.3 TB/s of traffic past the L2s that the pixel loops feel.
-					if (tid < 16)
-					{
-						const __amdgpu_buffer_rsrc_t rs = ecc_rsrc(sq.rows, (uint32_t)V * 256u);
-						const uint32_t off = (uint32_t)min(tid * 16 + 15, V - 1) * 256u;
-						const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-						for (;;)
-						{
-							const ecc_v4u gr = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16 /* sc1 */);
-							const bool here = (((((unsigned long long)gr.w << 32) | gr.z) ^ flag) & kEccFlagMask) == 0;
-							if (__builtin_amdgcn_ballot_w64(!here) == 0 || __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull)
-								break; // (all 16 have come - or 2 s have passed: the full look below has a clock of its own)
-							__builtin_amdgcn_s_sleep(2);
-						}
-					}
-					__syncthreads();
-					const bool all_ok = ecc_rows_total<true>(sq.rows, V, flag, part, tot);
-#ifdef RIR_ECC_DIAG
-					const unsigned long long dg1 = __builtin_amdgcn_s_memrealtime();
-#endif
-					if (tid == 0)
-					{
-						done = all_ok ? ecc_solve_step(tot, st) : 2;
-						sh_done = done;
-						ecc_granule_store(pub_rs, 0, (unsigned long long)__float_as_uint(st.tx) | ((unsigned long long)__float_as_uint(st.ty) << 32),
-										  flag | ((unsigned long long)done << 62));
-#ifdef RIR_ECC_DIAG
-						if (q == 0)
-						{ // ticks (10 ns): waiting for + adding the rows | solve + publish
-							unsigned long long *dg = pub + 8;
-							dg[0] += dg1 - dg0, dg[1] += __builtin_amdgcn_s_memrealtime() - dg1, dg[2] += 1;
-						}
-#endif
-					}
-					__syncthreads();
-					done = sh_done;
-					__syncthreads(); // (part / tot / sh_done are reused by the next iteration)
-				}
-				if (tid == 0)
-				{
-					EccFrameResult r;
-					r.tx = st.tx, r.ty = st.ty, r.rho = st.rho, r.iter = st.iter, r.done = done;
-					sq.results[f] = r;
-				}
-				frames_done = f + 1;
-			}
-			if (tid == 0)
-				table[q].frames_done = frames_done;
+		{ // ---- the service workgroup of sequence q ----
+			ecc_multi_service(table, (int)blockIdx.x - ncompute, V, max_iter, eps, epoch, part, tot, &sh_done);
 			return;
 		}
 		// ---- a compute workgroup of group g: its rows of the group's sequences in turn ----
