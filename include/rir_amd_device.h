@@ -161,6 +161,13 @@ extern "C"
 									   const long long *d_chunk_frames, long long frames_capacity, unsigned short *d_frames, int *d_error,
 									   void *stream);
 
+	/* gaussian_filter as the 2-D sum in the reference's own order (signal_processing.cpp:101-148: dx outer, dy inner, a rounding per product
+	 * and per sum) instead of the separable form: results bit-identical to the reference's instead of within 2e-6 of them, in gaussian_filter,
+	 * rir_gaussian_filter*_device and rir_filter_chain_device (which then runs its three steps one after the other on the device), at about
+	 * three times the time.  Process-wide, default off; also RIR_GAUSSIAN_REFERENCE_ORDER=1 in the environment. */
+	void rir_set_gaussian_reference_order(int on);
+	int rir_gaussian_reference_order(void);
+
 	/* ---- frame-buffer kernels -------------------------------------------------------------------
 	 * translate: reference signal_processing.h:29 / Filters.h:249-326.  `type` is the numpy
 	 * dtype char ('?','b','B','h','H','i','I','l','L','f','d'); d_offsets holds float (dx,dy)

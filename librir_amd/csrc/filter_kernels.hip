@@ -27,6 +27,7 @@
 #include <mutex>
 
 #include "filter_kernels.h"
+#include "runtime.h"
 
 namespace rir
 {
@@ -499,7 +500,11 @@ namespace rir
 	// ---- gaussian ------------------------------------------------------------------------------
 	// The (2r+1)^2 table is built on the host with the reference's own float sequence and uploaded.
 	// Accumulation order = dx outer, dy inner, res = res + k*src (two roundings), exactly as the host.
-	__global__ __launch_bounds__(256) void gaussian_kernel(const float *__restrict__ src, float *__restrict__ dst, int w, int h,
+	// TIN = float, or uint16_t (the conversion of a u16 pixel to float is exact).  Any radius: the form radius > 4 always takes, and - with
+	// the reference-order switch on (runtime.h: gaussian_reference_order) - every radius: bit-identical to the reference's loop, at the
+	// price of (2r + 1)^2 taps per pixel instead of 2 (2r + 1).
+	template <class TIN>
+	__global__ __launch_bounds__(256) void gaussian_kernel(const TIN *__restrict__ src, float *__restrict__ dst, int w, int h,
 														   const float *__restrict__ kern, int radius)
 	{
 		const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -508,7 +513,7 @@ namespace rir
 		if (x >= w)
 			return;
 		const int64_t fbase = (int64_t)n * w * h;
-		const float *s = src + fbase;
+		const TIN *s = src + fbase;
 		const int kw = 2 * radius + 1;
 		if (x >= radius && x < w - radius && y >= radius && y < h - radius)
 		{
@@ -516,7 +521,7 @@ namespace rir
 			for (int dx = -radius; dx <= radius; ++dx)
 				for (int dy = -radius; dy <= radius; ++dy)
 				{
-					const float p = __fmul_rn(kern[dx + radius + (dy + radius) * kw], s[x + dx + (int64_t)(y + dy) * w]);
+					const float p = __fmul_rn(kern[dx + radius + (dy + radius) * kw], (float)s[x + dx + (int64_t)(y + dy) * w]);
 					res = __fadd_rn(res, p);
 				}
 			dst[fbase + x + (int64_t)y * w] = res;
@@ -532,7 +537,7 @@ namespace rir
 					{
 						const float k = kern[dx + radius + (dy + radius) * kw];
 						sum = __fadd_rn(sum, k);
-						res = __fadd_rn(res, __fmul_rn(k, s[_x + (int64_t)_y * w]));
+						res = __fadd_rn(res, __fmul_rn(k, (float)s[_x + (int64_t)_y * w]));
 					}
 				}
 			dst[fbase + x + (int64_t)y * w] = __fdiv_rn(res, sum);
@@ -721,6 +726,146 @@ namespace rir
 		}
 	}
 
+	// The reference's own 2-D sum (signal_processing.cpp:101-148) with the tiling of the separable kernel above: a wave owns 64 columns
+	// (R of halo on each side) x TY rows, a lane one column - its TY + 2R pixels in registers, loaded once; the columns x + dx come from the
+	// neighbouring lanes through DPP wave shifts.  For every output pixel the products are added in the reference's order - dx outer, dy
+	// inner, one rounding per product and one per sum (no fused multiply-add: the reference's x86-64 build has none) - so the result is the
+	// reference's bit for bit.  Pixels closer than R to the image's edge divide by the sum of the weights that fall inside the image,
+	// accumulated in the same order (a tap outside the image adds k x 0 to the one and + 0 to the other: what skipping it adds).
+	template <int R, class TIN>
+	__global__ __launch_bounds__(256) void gaussian_exact_kernel(const TIN *__restrict__ src, float *__restrict__ dst, int w, int h, const float *__restrict__ kern)
+	{
+		constexpr int TY = RIR_GAUSS_TY, KW = 2 * R + 1, OUTW = 64 - 2 * R, NR = TY + 2 * R;
+		const int lane = threadIdx.x & 63;
+		const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+		int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+		{
+			const unsigned gx = gridDim.x, gy = gridDim.y;
+			const unsigned id2 = xcd_major(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+			by = (int)(id2 % gy);
+			bx = (int)((id2 / gy) % gx);
+			bz = (int)(id2 / (gy * gx));
+		}
+		const int x0 = bx * OUTW - R;
+		const int x = x0 + lane;
+		const int y0 = (by * 4 + wv) * TY;
+		if (y0 >= h)
+			return;
+		const int64_t fbase = (int64_t)bz * w * h;
+		const TIN *s = src + fbase;
+		const bool xin = x >= 0 && x < w;
+		float v[NR];
+		if ((int64_t)w * h * (int64_t)sizeof(TIN) < (int64_t)1 << 31)
+		{ // raw-buffer loads: a pixel outside the image has an offset outside the buffer and reads as 0 (gaussian_sep_kernel)
+			const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)s);
+			const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)s >> 32));
+			const __amdgpu_buffer_rsrc_t rs =
+				__builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, w * h * (int)sizeof(TIN), 0x00020000);
+			const uint32_t step = (uint32_t)w * (uint32_t)sizeof(TIN);
+			uint32_t off = xin ? (uint32_t)(((y0 - R) * w + x) * (int)sizeof(TIN)) : 0x80000000u;
+#pragma unroll
+			for (int i = 0; i < NR; ++i)
+			{
+				if constexpr (sizeof(TIN) == 2)
+					v[i] = (float)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, 0, 0);
+				else
+					v[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+				off += step;
+			}
+		}
+		else
+		{
+			const TIN *col = s + min(max(x, 0), w - 1);
+#pragma unroll
+			for (int i = 0; i < NR; ++i)
+			{
+				const int gy = y0 - R + i;
+				const float val = (float)col[(int64_t)min(max(gy, 0), h - 1) * w];
+				v[i] = (xin && gy >= 0 && gy < h) ? val : 0.f;
+			}
+		}
+		// every output pixel of the tile an interior pixel of the image?  (wave-uniform: then no weight sums are needed)
+		const bool interior = x0 >= 0 && x0 + 63 - R < w - R && y0 >= R && y0 + TY - 1 < h - R;
+		float res[TY], sum[TY];
+#pragma unroll
+		for (int j = 0; j < TY; ++j)
+			res[j] = 0.f, sum[j] = 0.f;
+		float c[NR];
+		float cin = xin ? 1.f : 0.f; // is the column a tap comes from inside the image (travels with the shifts)
+		auto taps = [&](int dx) {
+#pragma unroll
+			for (int dy = -R; dy <= R; ++dy)
+			{
+				const float k = kern[dx + R + (dy + R) * KW];
+#pragma unroll
+				for (int j = 0; j < TY; ++j)
+					res[j] = __fadd_rn(res[j], __fmul_rn(k, c[j + dy + R]));
+				if (!interior)
+				{
+#pragma unroll
+					for (int j = 0; j < TY; ++j)
+					{
+						const int yy = y0 + j + dy;
+						sum[j] = __fadd_rn(sum[j], (cin != 0.f && yy >= 0 && yy < h) ? k : 0.f);
+					}
+				}
+			}
+		};
+		// dx = -R .. 0: the column R lanes to the left, then one lane closer per step (lane i holds column x + dx of ITS x; the values
+		// shifted in at the wave's ends only ever reach halo lanes)
+#pragma unroll
+		for (int i = 0; i < NR; ++i)
+		{
+			c[i] = v[i];
+#pragma unroll
+			for (int d = 0; d < R; ++d)
+				c[i] = wave_shr1(c[i]);
+		}
+		const float cin0 = cin;
+#pragma unroll
+		for (int d = 0; d < R; ++d)
+			cin = wave_shr1(cin);
+#pragma unroll
+		for (int dx = -R; dx <= 0; ++dx)
+		{
+			taps(dx);
+			if (dx < 0)
+			{
+#pragma unroll
+				for (int i = 0; i < NR; ++i)
+					c[i] = wave_shl1(c[i]);
+				cin = wave_shl1(cin);
+			}
+		}
+		// dx = 1 .. R: from the lane's own column to the right
+#pragma unroll
+		for (int i = 0; i < NR; ++i)
+			c[i] = v[i];
+		cin = cin0;
+#pragma unroll
+		for (int dx = 1; dx <= R; ++dx)
+		{
+#pragma unroll
+			for (int i = 0; i < NR; ++i)
+				c[i] = wave_shl1(c[i]);
+			cin = wave_shl1(cin);
+			taps(dx);
+		}
+		if (lane < R || lane >= 64 - R || x >= w)
+			return; // halo lanes, and columns past the right edge, have no output
+		const bool xb = x < R || x >= w - R;
+		float *o = dst + fbase + x + (int64_t)y0 * w;
+#pragma unroll
+		for (int j = 0; j < TY; ++j)
+		{
+			const int y = y0 + j;
+			if (y >= h)
+				break;
+			const bool border = xb || y < R || y >= h - R;
+			o[(int64_t)j * w] = border ? __fdiv_rn(res[j], sum[j]) : res[j];
+		}
+	}
+
 	template <class TIN>
 	static bool launch_gaussian_sep(const TIN *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st)
 	{
@@ -745,12 +890,37 @@ namespace rir
 		}
 	}
 
+	template <class TIN>
+	static bool launch_gaussian_exact(const TIN *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st)
+	{
+		if (radius < 1 || radius > 4)
+			return false;
+		const int outw = 64 - 2 * radius;
+		dim3 block(256), tgrid((w + outw - 1) / outw, (h + 4 * RIR_GAUSS_TY - 1) / (4 * RIR_GAUSS_TY), nframes);
+		switch (radius)
+		{
+		case 1:
+			hipLaunchKernelGGL((gaussian_exact_kernel<1, TIN>), tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			return true;
+		case 2:
+			hipLaunchKernelGGL((gaussian_exact_kernel<2, TIN>), tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			return true;
+		case 3:
+			hipLaunchKernelGGL((gaussian_exact_kernel<3, TIN>), tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			return true;
+		default:
+			hipLaunchKernelGGL((gaussian_exact_kernel<4, TIN>), tgrid, block, 0, st, src, dst, w, h, d_kernel);
+			return true;
+		}
+	}
+
 	hipError_t launch_gaussian(const float *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st)
 	{
-		if (!launch_gaussian_sep<float>(src, dst, w, h, nframes, d_kernel, radius, st))
-		{ // radius > 4: the direct 2-D form
+		if (gaussian_reference_order() ? !launch_gaussian_exact<float>(src, dst, w, h, nframes, d_kernel, radius, st)
+									   : !launch_gaussian_sep<float>(src, dst, w, h, nframes, d_kernel, radius, st))
+		{ // radius > 4: the direct 2-D form, one thread per pixel (the reference's order too)
 			dim3 block(256), grid((w + 255) / 256, h, nframes);
-			hipLaunchKernelGGL(gaussian_kernel, grid, block, 0, st, src, dst, w, h, d_kernel, radius);
+			hipLaunchKernelGGL(gaussian_kernel<float>, grid, block, 0, st, src, dst, w, h, d_kernel, radius);
 		}
 		return hipGetLastError();
 	}
@@ -758,8 +928,12 @@ namespace rir
 	// uint16 frames in, float out (radius <= 4 only: hipErrorInvalidValue otherwise)
 	hipError_t launch_gaussian_u16(const uint16_t *src, float *dst, int w, int h, int nframes, const float *d_kernel, int radius, hipStream_t st)
 	{
-		if (!launch_gaussian_sep<uint16_t>(src, dst, w, h, nframes, d_kernel, radius, st))
+		if (radius < 1 || radius > 4)
 			return hipErrorInvalidValue;
+		if (gaussian_reference_order())
+			launch_gaussian_exact<uint16_t>(src, dst, w, h, nframes, d_kernel, radius, st);
+		else
+			launch_gaussian_sep<uint16_t>(src, dst, w, h, nframes, d_kernel, radius, st);
 		return hipGetLastError();
 	}
 

@@ -3,6 +3,8 @@
 // get_last_log_error (tools.h:39-55) and set_void_ptr / get_void_ptr / rm_void_ptr (tools.h:67-78).
 #include "runtime.h"
 
+#include <atomic>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -398,6 +400,32 @@ namespace rir
 	}
 
 } // namespace rir
+
+namespace rir
+{
+	namespace
+	{
+		std::atomic<int> &gauss_order_flag()
+		{
+			static std::atomic<int> f{-1}; // -1: not decided yet (environment), 0 / 1
+			return f;
+		}
+	} // namespace
+	bool gaussian_reference_order()
+	{
+		int v = gauss_order_flag().load(std::memory_order_relaxed);
+		if (v < 0)
+		{
+			const char *e = std::getenv("RIR_GAUSSIAN_REFERENCE_ORDER");
+			v = (e && e[0] && e[0] != '0') ? 1 : 0;
+			gauss_order_flag().store(v, std::memory_order_relaxed);
+		}
+		return v != 0;
+	}
+	void set_gaussian_reference_order(bool on) { gauss_order_flag().store(on ? 1 : 0, std::memory_order_relaxed); }
+} // namespace rir
+RIR_EXPORT void rir_set_gaussian_reference_order(int on) { rir::set_gaussian_reference_order(on != 0); }
+RIR_EXPORT int rir_gaussian_reference_order() { return rir::gaussian_reference_order() ? 1 : 0; }
 
 // ---- exported `tools` symbols ---------------------------------------------------------------------
 

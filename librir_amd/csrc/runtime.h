@@ -55,6 +55,11 @@ namespace rir
 	// which logs and returns false when no HIP device is usable, and the entry point returns its
 	// error code.
 	bool device_ready();
+	// gaussian_filter as the 2-D sum in the reference's own order (signal_processing.cpp:101-148: dx outer, dy inner, one rounding per product
+	// and per sum) instead of the separable form: bit-identical results instead of results within 2e-6, three times the time.  Process-wide,
+	// default off; RIR_GAUSSIAN_REFERENCE_ORDER=1 in the environment or rir_set_gaussian_reference_order(1) turn it on.
+	bool gaussian_reference_order();
+	void set_gaussian_reference_order(bool on);
 	hipStream_t default_stream(); // one non-blocking stream owned by the library
 
 	struct DeviceBuffer

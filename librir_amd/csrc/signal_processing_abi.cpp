@@ -430,6 +430,32 @@ RIR_EXPORT int rir_filter_chain_device(int bad_pixels_handle, const unsigned sho
 			return -1;
 		}
 	}
+	if (gaussian_reference_order())
+	{
+		// the reference's own summation order was asked for (runtime.h): the chain as its three steps, still without leaving the device -
+		// repair, gaussian_filter as the 2-D sum, translate + truncation - through stream-ordered scratch; the chain's output is then the
+		// reference chain's, bit for bit (the fused kernel's separable gaussian differs by +-1 level on < 0.2 % of the pixels)
+		hipStream_t st = as_stream(stream);
+		const size_t npx = (size_t)w * h * nframes;
+		void *d_fixed = nullptr, *d_f32 = nullptr;
+		if ((bp && !hip_ok(hipMallocAsync(&d_fixed, npx * 2, st), "hipMallocAsync")) || !hip_ok(hipMallocAsync(&d_f32, npx * 4, st), "hipMallocAsync"))
+		{
+			if (d_fixed)
+				(void)hipFreeAsync(d_fixed, st);
+			return -1;
+		}
+		int r = 0;
+		if (bp)
+			r = rir_bad_pixels_correct_device(bad_pixels_handle, d_src, static_cast<unsigned short *>(d_fixed), nframes, stream);
+		if (r == 0)
+			r = rir_gaussian_filter_u16_device(bp ? static_cast<const unsigned short *>(d_fixed) : d_src, static_cast<float *>(d_f32), w, h, nframes, sigma, stream);
+		if (r == 0)
+			r = rir_translate_f32_u16_device(static_cast<const float *>(d_f32), d_dst, w, h, nframes, d_offsets, per_frame_offsets, background, strategy, stream);
+		if (d_fixed)
+			(void)hipFreeAsync(d_fixed, st);
+		(void)hipFreeAsync(d_f32, st);
+		return r;
+	}
 	const int nbad = bp ? bp->count() : 0;
 	if (nbad > 0 && !bp->d_fix.reserve((size_t)nbad * nframes * sizeof(uint32_t)))
 		return -1;

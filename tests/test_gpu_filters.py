@@ -285,3 +285,72 @@ def test_output_buffer_in_another_placement_class(dev):
         dev.filter_chain(fr, None, 0.75, (1.25, -2.5), "nearest", out=fr)
     del got, out
     torch.cuda.synchronize()
+
+
+# ---- gaussian_filter in the reference's own summation order (rir_set_gaussian_reference_order) -----------------------------------
+@pytest.fixture
+def reference_order(lib):
+    lib.rir_set_gaussian_reference_order(1)
+    yield
+    lib.rir_set_gaussian_reference_order(0)
+
+
+@pytest.mark.parametrize("shape", GAUSS_SHAPES)
+def test_gaussian_in_reference_order_is_bit_identical_to_the_compiled_reference(lib, golden, oracle, shape, reference_order):
+    """with the switch on, gaussian_filter is the reference's 2-D sum, dx outer / dy inner, a rounding per product and per sum: the goldens
+    produced by the compiled reference (arrays, and hashes at full size) are reproduced bit for bit, not within a tolerance"""
+    from librir_amd.signal_processing import gaussian_filter
+
+    assert lib.rir_gaussian_reference_order() == 1
+    h, w = shape
+    img = gauss_input(h, w)
+    arrays, hashes = golden
+    for s in GAUSS_SIGMAS:
+        out = gaussian_filter(img, s)
+        key = "ga_%dx%d_%g" % (h, w, s)
+        if key in arrays.files:
+            assert np.array_equal(out.view(np.uint32), arrays[key].view(np.uint32)), key
+        else:
+            assert hashes[key] == sha(out), key
+
+
+def test_device_gaussian_in_reference_order_equals_the_oracle(dev, oracle, reference_order):
+    import torch
+
+    rng = np.random.default_rng(3)
+    for (n, h, w) in ((2, 67, 83), (1, 512, 640), (2, 3, 5)):
+        f32 = (rng.random((n, h, w)) * 16000).astype(np.float32)
+        u16 = f32.astype(np.uint16)
+        for s in (0.3, 0.75, 1.0, 1.6, 2.0, 2.6):
+            g = dev.gaussian_filter(torch.from_numpy(f32).cuda(), s).cpu().numpy()
+            r = np.stack([oracle.gaussian_filter(f32[i], s) for i in range(n)])
+            assert np.array_equal(g.view(np.uint32), r.view(np.uint32)), (h, w, s)
+            if s < 2.5:  # (the uint16 entry point: the conversion folded into the load)
+                g = dev.gaussian_filter(torch.from_numpy(u16).cuda(), s).cpu().numpy()
+                r = np.stack([oracle.gaussian_filter(u16[i].astype(np.float32), s) for i in range(n)])
+                assert np.array_equal(g.view(np.uint32), r.view(np.uint32)), (h, w, s)
+
+
+@pytest.mark.parametrize("shape,sigma,off,strategy", CHAIN_CASES[:5] + CHAIN_CASES[6:7])
+def test_filter_chain_in_reference_order_equals_the_oracle_chain(dev, oracle, shape, sigma, off, strategy, reference_order):
+    """configs[2]'s pipeline with the switch on: the chain's uint16 output IS the reference chain's - every frame, every pixel, difference 0"""
+    import torch
+
+    n, h, w = shape
+    arr = inject_bad_pixels(s1_noisy_background(n, h, w, seed=11), min(200, h * w // 20))
+    x = torch.from_numpy(arr).cuda()
+    bp = dev.BadPixels(x[0])
+    out = dev.filter_chain(x, bp, sigma, off, strategy, background=7).cpu().numpy()
+    xy = oracle.bad_pixels_detect(arr[0])
+    _, fc = oracle.bad_pixels_stats(arr[0])
+    for i in range(n):
+        c = oracle.bad_pixels_correct(arr[i], xy, fc)
+        t = oracle.translate(oracle.gaussian_filter(c.astype(np.float32), sigma), float(off[0]), float(off[1]), "background" if strategy == "background" else strategy,
+                             background=7.0)
+        d = np.abs(t.astype(np.int64).clip(0, 65535) - out[i].astype(np.int64))
+        assert d.max() == 0, (shape, i, d.max(), (d != 0).mean())
+    # without the repair stage too
+    out = dev.filter_chain(x, None, sigma, off, strategy, background=7).cpu().numpy()
+    t = oracle.translate(oracle.gaussian_filter(arr[0].astype(np.float32), sigma), float(off[0]), float(off[1]), "background" if strategy == "background" else strategy,
+                         background=7.0)
+    assert np.array_equal(t.astype(np.int64).clip(0, 65535), out[0].astype(np.int64))
