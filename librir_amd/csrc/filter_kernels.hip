@@ -1631,14 +1631,21 @@ namespace rir
 		static std::mutex mu;
 		static std::map<hipStream_t, List> *lists = new std::map<hipStream_t, List>;
 		std::lock_guard<std::mutex> g(mu);
+		if (lists->size() >= 64 && lists->find(st) == lists->end())
+		{ // streams come and go (the map is keyed by their handles): the lists of the others are released once in a while
+			(void)hipDeviceSynchronize();
+			for (auto &kv : *lists)
+				if (kv.second.first)
+					(void)hipFree(kv.second.first);
+			lists->clear();
+		}
 		auto &e = (*lists)[st];
-		*parity = e.calls++ & 1;
 		if (e.second < ntile)
 		{
 			void *p = nullptr;
 			const size_t want = std::max<size_t>(ntile, 4096);
 			if (hipMalloc(&p, 8 + want * 8) != hipSuccess)
-				return nullptr;
+				return nullptr; // (the call fails and the counter parity stays where the last successful call left it)
 			if (hipMemsetAsync(p, 0, 8, st) != hipSuccess)
 			{
 				(void)hipFree(p);
@@ -1648,6 +1655,8 @@ namespace rir
 				(void)hipFree(e.first); // (waits for the device: the previous calls that used it are through)
 			e.first = p, e.second = want;
 		}
+		// the parity only moves with a call that goes on to launch: the counter this call uses is the one the previous launch reset
+		*parity = e.calls++ & 1;
 		return static_cast<unsigned int *>(e.first);
 	}
 

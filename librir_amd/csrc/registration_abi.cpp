@@ -123,6 +123,7 @@ namespace
 	bool wait_view(EccHostView *view, int launched, hipStream_t st)
 	{
 		auto t0 = std::chrono::steady_clock::now();
+		const auto t_begin = t0;
 		long spins = 0;
 		unsigned int seen = view->progress;
 		while (view->done == 0 && view->iter < launched)
@@ -135,7 +136,17 @@ namespace
 				if (p != seen)
 					seen = p, t0 = std::chrono::steady_clock::now();
 				else if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10))
-				{ // (a device fault would leave the words unwritten)
+				{
+					// No word for 10 s.  The launch may not have STARTED: it queues behind the previous resident launch of the device
+					// (ResidentGate), and another thread's may legitimately run for minutes.  The stream tells the two cases apart: while
+					// it still has work the wait goes on (every wait inside the kernels is bounded, so a launch that started ends); a
+					// stream that has drained without the words having been written is a device that did not report back.
+					if (hipStreamQuery(st) == hipErrorNotReady && std::chrono::steady_clock::now() - t_begin < std::chrono::minutes(30))
+					{
+						t0 = std::chrono::steady_clock::now();
+						continue;
+					}
+					(void)hipGetLastError();
 					log_error("ECC: the device did not report back");
 					(void)hipStreamSynchronize(st);
 					return false;
@@ -296,7 +307,7 @@ RIR_EXPORT int rir_ecc_register_frame_device(const void *d_img, int dtype, int w
 	if (!device_ready())
 		return -1;
 	if (!d_img || (dtype != 'H' && dtype != 'f') || !d_ref_norm || !warp || w < 2 || h < 2 || win_x < 0 || win_y < 0 || win_w < 2 || win_h < 2 ||
-		win_x + win_w > w || win_y + win_h > h || max_iterations <= 0 || !(eps >= 0))
+		win_x + win_w > w || win_y + win_h > h || !ecc_size_ok(w, h) || !ecc_size_ok(win_w, win_h) || max_iterations <= 0 || !(eps >= 0))
 	{
 		log_error("rir_ecc_register_frame_device: invalid argument");
 		return -1;

@@ -22,6 +22,7 @@
 
 #include "codec_format.h"
 #include "file_attributes.h"
+#include "filter_kernels.h"
 #include "lossy_kernels.h"
 #include "rir_amd_device.h"
 #include "runtime.h"
@@ -352,14 +353,19 @@ namespace
 		bool failed = false;
 		uint64_t led_calls = 0, led_clean = 0;					   // as a leader: run calls led / of those, known good at the last check
 		std::vector<std::pair<uint64_t, uint64_t>> led_bad;		   // calls in (first, second] are invalid
-		std::weak_ptr<Object> lead;								   // leader of the last run call this stream took part in (empty: itself)
+		std::weak_ptr<Object> lead;								   // leader of the last run call this stream took part in, when that was another stream
+		bool led_by_other = false;								   // ... which `lead` then names (a leader that has been destroyed leaves no record)
 		uint64_t lead_call = 0;									   // that call's number with the leader (0: no run call yet)
 		LossyObject *leader()
 		{
 			if (lead_call == 0)
 				return nullptr;
+			if (!led_by_other)
+				return this;
+			// a foreign leader that is gone took its books with it: lead_call is a number of ITS numbering and must not be read against this
+			// object's own ranges - "no record" (a call that was checked while its leader lived has filed its verdict with every member: is_failed())
 			auto l = lead.lock();
-			return l ? dynamic_cast<LossyObject *>(l.get()) : this;
+			return l ? dynamic_cast<LossyObject *>(l.get()) : nullptr;
 		}
 		bool is_failed()
 		{
@@ -497,8 +503,43 @@ namespace
 			return true;
 		}
 
+		// The first recording of a process pays for the device runtime's start and for page-locking ~110 MB of staging (160 ms: as much as
+		// recording 4 000 frames).  The reference opens its encoder lazily, on the first frame (video_io.cpp:746-752), and so does this saver -
+		// but nothing keeps the preparation from starting when the FILE is opened: h264_open_file starts this thread, which brings the device
+		// up and page-locks buffers of the sizes the saver will ask for (default GOP; they go to the pool of runtime.cpp, where open() finds
+		// them).  Whatever the caller does between opening the file and its first frame - setting parameters, waiting for a camera - then
+		// overlaps with it; open() joins the thread first, so a frame that comes at once waits for the same work as before, never for more.
+		std::thread warmup;
+		void start_warmup()
+		{
+			const int w = width, h = height, gop = GOP < 1 ? 1 : GOP;
+			if (w <= 0 || h <= 0 || w > 65535 || h > 65535 || (int64_t)gop * w * h * 2 >= (1ll << 32))
+				return;
+			warmup = std::thread([w, h, gop] {
+				rir_codec_layout L;
+				if (!device_ready() || rir_codec_layout_query(w, h, gop, gop, &L) != 0)
+					return;
+				{ // the library's stream, and the code object on the device (the first launch of a process loads it: 80 ms)
+					DeviceBuffer probe;
+					if (probe.reserve(512) && launch_stream_copy_probe(probe.ptr, probe.as<char>() + 256, 256, default_stream()) == hipSuccess)
+						(void)hipStreamSynchronize(default_stream());
+				}
+				PinnedBuffer frames, out0, out1;
+				const size_t ob = (size_t)L.ntiles * gop * 8 + (((size_t)L.ntiles + 1) * 4 + 7) / 8 * 8 + (size_t)L.stream_max_bytes;
+				(void)frames.reserve((size_t)w * h * 2 * gop);
+				(void)out0.reserve(ob);
+				(void)out1.reserve(ob);
+			}); // (the buffers' destructors hand them to the pool)
+		}
+		void join_warmup()
+		{
+			if (warmup.joinable())
+				warmup.join();
+		}
+
 		~SaverObject() override
 		{
+			join_warmup();
 			close();
 			stop_writer();
 		}
@@ -719,6 +760,7 @@ namespace
 		{ // lazy, on the first frame (video_io.cpp:746-752)
 			if (opened)
 				return true;
+			join_warmup();
 			if (!device_ready())
 				return false;
 			if (width <= 0 || height <= 0 || width > 65535 || height > 65535)
@@ -2227,6 +2269,7 @@ RIR_EXPORT int h264_open_file(const char *filename, int width, int height, int l
 		log_error("h264_open_file: cannot remove output file");
 		return 0;
 	}
+	s->start_warmup();
 	return register_object(s);
 }
 
@@ -2589,6 +2632,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 				for (int i = 0; i < nstreams; ++i)
 				{
 					os[i]->lead_call = lead.led_calls;
+					os[i]->led_by_other = i != 0;
 					if (i == 0)
 						os[i]->lead.reset();
 					else
