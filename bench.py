@@ -20,7 +20,7 @@ N > 1 additionally times, in the same run and with the same bracket, the step WI
                                   communicator's stream while the next sub-batch decodes
   value_with_compressed_exchange  encode, all-gather of the COMPRESSED chunks in pieces, every rank decodes every
                                   rank's chunks on arrival into the reassembled stream
-each with the bytes a rank receives, its GB/s and the fraction of the per-GPU xGMI budget (DESIGN.md §6).
+each with the bytes a rank receives, its GB/s and the fraction of the per-GPU xGMI budget (DESIGN.md §8).
 
 One JSON line is printed by rank 0: whole-job frames/s, plus
   roofline      - the dominant kernel's algorithmic bytes / its HIP-event duration vs 8 TB/s
@@ -55,6 +55,7 @@ def parse():
     p.add_argument("--gop", type=int, default=50)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-abi", action="store_true", help="skip the per-frame / batched host-pointer numbers")
+    p.add_argument("--profile", action="store_true", help="for rocprofv3 --pmc passes: only the step itself (no ramp, no 2 s of repeats, no other forms)")
     p.add_argument("--abi-child", action="store_true", help=argparse.SUPPRESS)  # internal: the process that measures those numbers
     p.add_argument("--cpu-frames", type=int, default=1000, help="frames of the same stream the CPU oracle works through per pass")
     p.add_argument("--cpu-seconds", type=float, default=10.0, help="the CPU oracle repeats passes until this much time is spent")
@@ -440,7 +441,7 @@ def main():
     for _ in range(args.warmup):
         step()
     dt_idle = max_over_ranks(k_steps(K))
-    ramp_steps = min(100000, max(16, int(1.0 / (dt_idle / K))))  # (from the max over ranks: the same count on every rank)
+    ramp_steps = 0 if args.profile else min(100000, max(16, int(1.0 / (dt_idle / K))))  # (from the max over ranks: the same count on every rank)
     for _ in range(ramp_steps):
         step()
     barrier()
@@ -462,8 +463,9 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for k in range(K):
+        pc.reset()  # (the fill launch that zeroes the encoder's control block: outside the packing kernel's events)
         ev[k][0].record()
-        pc.encode(frames)
+        pc.encode(frames, reset=False)
         ev[k][1].record()
         pc.decode(out=out, check=True)  # (zeroes the error word first and reads it back: the parity gate below sees every decode)
         ev[k][2].record()
@@ -484,9 +486,9 @@ def main():
     # sampler with a period of seconds sees nothing of a 5 ms region); `value` stays the first region above ----
     reps = []
     t_busy = time.perf_counter()
-    while len(reps) < 5 or (time.perf_counter() - t_busy < 2.0 and len(reps) < 2000):
+    while len(reps) < (1 if args.profile else 5) or (not args.profile and time.perf_counter() - t_busy < 2.0 and len(reps) < 2000):
         reps.append(max_over_ranks(k_steps(K)) / K * 1e3)
-        if world > 1 and len(reps) >= 5:  # (every rank must leave the loop in the same round: the region count is rank 0's decision)
+        if world > 1 and len(reps) >= 5 and not args.profile:  # (every rank must leave the loop in the same round: the region count is rank 0's decision)
             go = torch.tensor([1 if time.perf_counter() - t_busy < 2.0 else 0], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
             dist.broadcast(go, 0)
             if int(go.item()) == 0:
@@ -496,6 +498,14 @@ def main():
     spread = {"ms_per_step_min": reps[0], "ms_per_step_median": reps[nreg // 2], "ms_per_step_max": reps[-1], "repeats": nreg,
               "note": "further K-step regions after the one `value` is computed from, repeated until the GPU had been busy for 2 s"}
 
+    if args.profile:
+        if rank == 0:
+            print(json.dumps({"profile_run": True, "ms_per_step": dt / K * 1e3, "kernels_ms": {"rirb1_encode_packed": ms_tiles, "rirb1_decode_tiles": ms_decode},
+                              "payload_bytes": payload_bytes, "encoded_footprint_bytes": batch.nbytes()}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # ---- round 3's step beside it: the slotted form (encode_tiles + decode_slots; the encoded batch lives in worst-case slots) ----
     for _ in range(args.warmup):
         step_slotted()
@@ -618,7 +628,7 @@ def main():
                 "note": "`value` is the sharded path (no collective: each rank encodes+decodes its own chunks). With the whole decoded stream "
                         "reassembled on EVERY GPU each rank must receive (N-1)/N of it: the job's rate is bounded by "
                         "xGMI inbound bandwidth / ((N-1)/N x 655 360 B) for decoded frames, and by N decodes per rank for compressed chunks "
-                        "(DESIGN.md §6)",
+                        "(DESIGN.md §8)",
             }
         except SystemExit:
             raise  # (a stream that arrived damaged: no number at all)
@@ -640,7 +650,7 @@ def main():
                               "workspace_bytes": int(ctx.layout.workspace_bytes),
                               "packing_us_of_the_placement_candidates": [round(x, 1) for x in placement_us],
                               "note": "round 3's step (encode_tiles + decode_slots): the encoded batch lives in worst-case slots inside a workspace larger "
-                                      "than the input - an on-device hand-over, not an encoded batch one can keep; workspace placed by measurement (DESIGN.md §5)"},
+                                      "than the input - an on-device hand-over, not an encoded batch one can keep; workspace placed by measurement (DESIGN.md §7)"},
              "spread": spread,
              "dense_file_form": {"value": n * K * world / dt_dense, "ms_per_step": dt_dense / K * 1e3, "ms_compact": ms_compact,
                                  "ms_decode_from_dense": ms_decode_dense,

@@ -84,8 +84,8 @@ extern "C"
 
 	/* An encoder workspace (workspace_bytes of rir_codec_layout) allocated BY THE LIBRARY where the packing kernel runs fast for
 	 * THIS frames buffer.  On MI355X device allocations fall into a few placement classes and the kernel, which reads the frames
-	 * and writes the slots at the same pace, takes 10 % longer when both live in allocations of one class (DESIGN.md §5,
-	 * profiles/r03_placement_classes.md); nothing but a timing tells the class, so this call allocates up to max_tries further
+	 * and writes the slots at the same pace, takes 10 % longer when both live in allocations of one class (DESIGN.md §7,
+	 * profiles/r03_placement/README.md); nothing but a timing tells the class, so this call allocates up to max_tries further
 	 * candidates, spacing_bytes apart (0: back to back), times stage 1 on each with HIP events and keeps the first one that is
 	 * 7 % faster than the first, else the fastest; everything else it allocated is freed before it returns.  times_us: HOST
 	 * float[max_tries + 1] or NULL (the kept candidate's time first), *ntimes = entries filled.  One-off set-up, a few ms. */
@@ -141,6 +141,12 @@ extern "C"
 									   unsigned long long *d_seg_pos, unsigned int *d_seg_words, unsigned long long *d_stream,
 									   long long stream_capacity_words, void *d_workspace, long long workspace_bytes, void *stream);
 	int rir_codec_encode_packed_status(const void *d_workspace, unsigned long long *out3, void *stream);
+	/* rir_codec_encode_packed_device in its two halves (the reset of the workspace's control block is a fill launch of its own): for callers
+	 * that time the packing kernel alone.  _launch_ packs into a workspace that has just been reset on the same stream. */
+	int rir_codec_packed_reset_device(void *d_workspace, long long workspace_bytes, void *stream);
+	int rir_codec_encode_packed_launch_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned long long *d_hdr,
+											  unsigned long long *d_seg_pos, unsigned int *d_seg_words, unsigned long long *d_stream,
+											  long long stream_capacity_words, void *d_workspace, long long workspace_bytes, void *stream);
 	int rir_codec_decode_packed_device(const unsigned long long *d_hdr, const unsigned long long *d_seg_pos, const unsigned int *d_seg_words,
 									   const unsigned long long *d_stream, long long stream_words, int width, int height, int nframes, int gop,
 									   unsigned short *d_frames, int *d_error, void *stream);

@@ -173,7 +173,7 @@ RIR_EXPORT int rir_codec_decode_slots_device(const unsigned long long *d_hdr, co
 // in: allocations fall into a few "placement classes" (stretches of the address space handed out by the driver; one
 // allocation, however large, is of one class), the kernel is slow exactly when frames and workspace are of the same class,
 // whatever the offsets inside the allocations and whatever the cache policy of its loads and stores
-// (profiles/r03_placement_classes.md: the class matrix over ten allocations, the offset sweeps, the policy variants, the
+// (profiles/r03_placement/README.md: the class matrix over ten allocations, the offset sweeps, the policy variants, the
 // counters of the two cases) - the signature of read / write turn-arounds inside one rank of the HBM stacks.  A virtual
 // address does not tell the class, so the library finds a workspace of another class than the caller's frames the only way
 // there is: it allocates candidates itself (each `spacing_bytes` further along, the spacers freed before it returns), times
@@ -470,9 +470,43 @@ RIR_EXPORT int rir_codec_packed_query(int width, int height, int nframes, int go
 	return 0;
 }
 
+namespace
+{
+	int encode_packed(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned long long *d_hdr, unsigned long long *d_seg_pos,
+					  unsigned int *d_seg_words, unsigned long long *d_stream, long long stream_capacity_words, void *d_workspace, long long workspace_bytes,
+					  bool reset, void *stream);
+}
 RIR_EXPORT int rir_codec_encode_packed_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned long long *d_hdr,
 											  unsigned long long *d_seg_pos, unsigned int *d_seg_words, unsigned long long *d_stream,
 											  long long stream_capacity_words, void *d_workspace, long long workspace_bytes, void *stream)
+{
+	return encode_packed(d_frames, width, height, nframes, gop, d_hdr, d_seg_pos, d_seg_words, d_stream, stream_capacity_words, d_workspace, workspace_bytes, true, stream);
+}
+// The two halves of the call above, for a caller that wants them apart (bench.py's per-kernel HIP events: the reset is a fill launch of its own):
+// rir_codec_packed_reset_device zeroes the control block of a workspace, rir_codec_encode_packed_launch_device packs into a workspace that has
+// just been reset on the same stream.
+RIR_EXPORT int rir_codec_packed_reset_device(void *d_workspace, long long workspace_bytes, void *stream)
+{
+	if (!device_ready())
+		return -1;
+	if (!d_workspace || workspace_bytes < RIRB1_PACKED_CTRL_BYTES)
+	{
+		log_error("rir_codec_packed_reset_device: workspace too small");
+		return -1;
+	}
+	return hip_ok(hipMemsetAsync(d_workspace, 0, RIRB1_PACKED_CTRL_BYTES, as_stream(stream)), "memset") ? 0 : -1;
+}
+RIR_EXPORT int rir_codec_encode_packed_launch_device(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned long long *d_hdr,
+													 unsigned long long *d_seg_pos, unsigned int *d_seg_words, unsigned long long *d_stream,
+													 long long stream_capacity_words, void *d_workspace, long long workspace_bytes, void *stream)
+{
+	return encode_packed(d_frames, width, height, nframes, gop, d_hdr, d_seg_pos, d_seg_words, d_stream, stream_capacity_words, d_workspace, workspace_bytes, false, stream);
+}
+namespace
+{
+int encode_packed(const unsigned short *d_frames, int width, int height, int nframes, int gop, unsigned long long *d_hdr, unsigned long long *d_seg_pos,
+				  unsigned int *d_seg_words, unsigned long long *d_stream, long long stream_capacity_words, void *d_workspace, long long workspace_bytes,
+				  bool reset, void *stream)
 {
 	if (!device_ready())
 		return -1;
@@ -490,11 +524,12 @@ RIR_EXPORT int rir_codec_encode_packed_device(const unsigned short *d_frames, in
 	const uint64_t arena_words = (uint64_t)(workspace_bytes - RIRB1_PACKED_CTRL_BYTES) / 8;
 	return hip_ok(launch_encode_packed(d_frames, (int64_t)width * height, L.ntiles, nframes, gop, reinterpret_cast<uint64_t *>(d_hdr),
 									   reinterpret_cast<uint64_t *>(d_seg_pos), d_seg_words, reinterpret_cast<uint64_t *>(d_stream),
-									   (uint64_t)stream_capacity_words, ctrl, arena, arena_words, as_stream(stream)),
+									   (uint64_t)stream_capacity_words, ctrl, arena, arena_words, reset, as_stream(stream)),
 				  "codec encode (packed)")
 			   ? 0
 			   : -1;
 }
+} // namespace
 
 RIR_EXPORT int rir_codec_encode_packed_status(const void *d_workspace, unsigned long long *out3, void *stream)
 {

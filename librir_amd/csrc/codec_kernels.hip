@@ -1794,7 +1794,7 @@ namespace rir
 		static int cap_env = -1;
 		if (cap_env < 0)
 		{
-			const char *ev = getenv("RIR_ENC_LDS_WORDS"); // tuning aid (tests/perf/enc_ab.py)
+			const char *ev = getenv("RIR_ENC_LDS_WORDS"); // tuning aid
 			cap_env = ev ? atoi(ev) : 0;
 		}
 		if (cap_env > 0)
@@ -1851,12 +1851,15 @@ namespace rir
 	}
 	hipError_t launch_encode_packed(const uint16_t *d_frames, int64_t npx, int ntiles, int nframes, int gop, uint64_t *d_hdr, uint64_t *d_seg_pos,
 									uint32_t *d_seg_words, uint64_t *d_stream, uint64_t capacity_words, uint64_t *d_ctrl, uint64_t *d_arena,
-									uint64_t arena_words, hipStream_t st)
+									uint64_t arena_words, bool reset, hipStream_t st)
 	{
 		const int nchunks = (nframes + gop - 1) / gop;
-		hipError_t e = hipMemsetAsync(d_ctrl, 0, RIRB1_PACKED_CTRL_BYTES, st);
-		if (e != hipSuccess)
-			return e;
+		if (reset)
+		{
+			hipError_t e = hipMemsetAsync(d_ctrl, 0, RIRB1_PACKED_CTRL_BYTES, st);
+			if (e != hipSuccess)
+				return e;
+		}
 		constexpr int WAVES = RIR_PACKED_WAVES;
 		const int cap = packed_lds_words(gop);
 		static int diag = -1;

@@ -57,7 +57,7 @@ namespace rir
 	// the packed form (codec_kernels.hip: rirb1_encode_packed)
 	hipError_t launch_encode_packed(const uint16_t *d_frames, int64_t npx, int ntiles, int nframes, int gop, uint64_t *d_hdr, uint64_t *d_seg_pos,
 									uint32_t *d_seg_words, uint64_t *d_stream, uint64_t capacity_words, uint64_t *d_ctrl, uint64_t *d_arena,
-									uint64_t arena_words, hipStream_t st);
+									uint64_t arena_words, bool reset, hipStream_t st); // reset: zero the control block first (else the caller has)
 	hipError_t launch_decode_packed(const uint64_t *d_hdr, const uint64_t *d_seg_pos, const uint32_t *d_seg_words, const uint64_t *d_stream,
 									uint64_t stream_words, int64_t npx, int ntiles, int nframes, int gop, uint16_t *d_frames, int *d_error, hipStream_t st);
 } // namespace rir

@@ -562,7 +562,7 @@ RIR_EXPORT int rir_ecc_align_multi_device(const float *const *d_ref_norm, const 
 
 // The same, and UNDER the alignments the pre-processing of what comes next (`next`: nnext jobs, each the arguments of one
 // rir_ecc_prepare_frames_device call - normally the next chunk of every sequence): the alignment launch needs the whole chip to
-// START (every workgroup resident: other kernels beside it then can keep the last ones from fitting, DESIGN.md §4), but once it
+// START (every workgroup resident: other kernels beside it then can keep the last ones from fitting, DESIGN.md §5), but once it
 // reports that it is resident it leaves a fifth of every CU's places and most of the memory system unused - so the library waits
 // for that report (a word of host memory the kernel writes) and then runs the jobs on a stream of its own beside it.  The
 // caller's stream is ordered behind them when the call returns.  Results and errors as rir_ecc_align_multi_device; the jobs'

@@ -87,6 +87,8 @@ _lib.rir_codec_workspace_destroy_device.restype = None
 _lib.rir_codec_decode_slots_device.argtypes = [_vp, _vp, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.rir_codec_packed_query.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(CodecPackedLayout)]
 _lib.rir_codec_encode_packed_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, ct.c_longlong, _vp, ct.c_longlong, _vp]
+_lib.rir_codec_encode_packed_launch_device.argtypes = [_vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, ct.c_longlong, _vp, ct.c_longlong, _vp]
+_lib.rir_codec_packed_reset_device.argtypes = [_vp, ct.c_longlong, _vp]
 _lib.rir_codec_encode_packed_status.argtypes = [_vp, ct.POINTER(ct.c_ulonglong), _vp]
 _lib.rir_codec_decode_packed_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.rir_codec_decode_device.argtypes = [_vp, _vp, _vp, _vp, ct.c_longlong, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
@@ -190,7 +192,7 @@ class _LibraryBuffer:
 def empty_beside(other, shape, dtype, tries=6, spacing_bytes=6 << 30):
     """A device tensor of ``shape`` / ``dtype`` in another placement class than the tensor ``other`` (rir_buffer_create_beside_device): the
     output buffer for a kernel that reads ``other`` and writes an output of similar size at the same pace - translate, gaussian_filter,
-    filter_chain, median_filter are 5-10 % faster then (tests/perf/filter_class_probe.py).  One-off set-up: candidates are
+    filter_chain, median_filter are 5-10 % faster then (placement classes).  One-off set-up: candidates are
     allocated by the library, a streaming copy is timed on each, the rest is freed.  Returns (tensor, measured times in us, kept first)."""
     nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
     nbytes = (nbytes + 15) // 16 * 16
@@ -237,7 +239,7 @@ class CodecContext:
 
     def place_workspace(self, frames, tries=6, spacing_bytes=6 << 30):
         """Replaces the encode workspace by one the LIBRARY allocates where the packing kernel runs fast for THIS frames buffer
-        (rir_codec_workspace_create_device; DESIGN.md §5: device allocations fall into a few placement classes, and the kernel -
+        (rir_codec_workspace_create_device; DESIGN.md §7: device allocations fall into a few placement classes, and the kernel -
         frames in, slots out at the same pace - is 10 % slower when both are of one class).  One-off set-up of a few
         milliseconds; the candidates that lose and the spacers between them are freed by the library before it returns, torch's
         allocator is not touched.  There are three classes and they come in runs of 8-24 GiB of the address space
@@ -365,12 +367,17 @@ class PackedCodec:
         self.error = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.raw_bytes = self.width * self.height * self.nframes * 2
 
-    def encode(self, frames, check=False):
-        """Asynchronous; ``check=True`` (or a later ``finish()``) waits and returns the PackedBatch."""
+    def reset(self):
+        """the first half of encode(): zero the workspace's control block (a fill launch of its own)"""
+        _check(_lib.rir_codec_packed_reset_device(self.workspace.data_ptr(), self.workspace.numel(), _stream()), "rir_codec_packed_reset_device")
+
+    def encode(self, frames, check=False, reset=True):
+        """Asynchronous; ``check=True`` (or a later ``finish()``) waits and returns the PackedBatch.  ``reset=False``: the caller has just
+        called reset() on the same stream (the packing kernel alone, for timings)."""
         fr = _frames3(frames, torch.uint16)
         if tuple(fr.shape) != (self.nframes, self.height, self.width):
             raise RuntimeError("encode: frames do not match the codec geometry")
-        _check(_lib.rir_codec_encode_packed_device(fr.data_ptr(), self.width, self.height, self.nframes, self.gop, self.hdr.data_ptr(), self.seg_pos.data_ptr(),
+        _check((_lib.rir_codec_encode_packed_device if reset else _lib.rir_codec_encode_packed_launch_device)(fr.data_ptr(), self.width, self.height, self.nframes, self.gop, self.hdr.data_ptr(), self.seg_pos.data_ptr(),
                                                    self.seg_words.data_ptr(), self.stream.data_ptr(), self.stream.numel(), self.workspace.data_ptr(),
                                                    self.workspace.numel(), _stream()), "rir_codec_encode_packed_device")
         return self.finish() if check else None

@@ -273,7 +273,7 @@ class DeviceRegistratorECC:
         # The pre-processing of chunk k + 1 runs UNDER the alignments of chunk k - but it is the library that starts it
         # (rir_ecc_align_multi_overlapped_device), and only once the alignment launch has reported itself resident: that launch
         # needs every one of its workgroups on the chip to start, and ordinary kernels that come and go beside it before that
-        # leave the register files fragmented and keep the last ones out ("Resident launches": queued from here on
+        # leave the register files fragmented and keep the last ones out (the residency gate: queued from here on
         # a second stream it failed 10 launches of 12).
         for ci, (c0, k) in enumerate(zip(starts, sizes)):
             if k == 0:

@@ -1,5 +1,5 @@
 """CPU, world_size 2 and 4, gloo: the sharding plan and the two exchange steps that reassemble the stream on every rank
-(the N>1 path of bench.py / DESIGN.md §6): the all-gather of decoded frames, whole and in overlapped sub-batches,
+(the N>1 path of bench.py / DESIGN.md §8): the all-gather of decoded frames, whole and in overlapped sub-batches,
 and the all-gather of COMPRESSED chunks decoded on arrival.  The HIP codec is not run here (GPU only): frames are
 fabricated from the global frame index, and the compressed exchange is checked with the oracle as encoder/decoder."""
 import os
