@@ -460,6 +460,7 @@ def main():
     # durations of the roofline.  An event between two launches keeps the second kernel from starting under the tail of the
     # first one; that costs this region some 5 % (`ms_per_step_with_events`), which is why `value` is not taken from it ----
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(K)]
+    pc.error.zero_()  # (raised by any decode from here on that meets a malformed table or record; read once, after the region)
     barrier()
     t0 = time.perf_counter()
     for k in range(K):
@@ -467,7 +468,7 @@ def main():
         ev[k][0].record()
         pc.encode(frames, reset=False)
         ev[k][1].record()
-        pc.decode(out=out, check=True)  # (zeroes the error word first and reads it back: the parity gate below sees every decode)
+        pc.decode(out=out, check=False)
         ev[k][2].record()
     barrier()
     dt_events = max_over_ranks(time.perf_counter() - t0)
@@ -476,7 +477,7 @@ def main():
     ms_decode = sum(ev[k][1].elapsed_time(ev[k][2]) for k in range(K)) / K
 
     # ---- parity gate before any number is reported: decoded stream == input, bit-exact ----
-    ok = torch.equal(out.view(torch.int16), frames.view(torch.int16))
+    ok = torch.equal(out.view(torch.int16), frames.view(torch.int16)) and int(pc.error.item()) == 0
     batch = pc.finish()
     payload_bytes = batch.payload_bytes()
     if not ok:
