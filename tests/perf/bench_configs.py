@@ -66,14 +66,26 @@ dec = torch.empty_like(t)
 ctx.place_workspace(t)  # (set-up: the workspace goes where the packing kernel measures fastest for this frames buffer, as in bench.py)
 
 
-def dev_roundtrip():  # the two-launch step of bench.py: the slotted form straight into the decoder
+pc = D.PackedCodec(w, h, n, gop, device=dev)
+
+
+def dev_roundtrip():  # the two-launch step of bench.py: the packed form (the encoded batch = its payload + tables) straight into the decoder
+    pc.encode(t)
+    pc.decode(out=dec, check=False)
+
+
+def dev_roundtrip_slotted():  # round 3's step: the encoder's worst-case slots decoded in place
     ctx.encode_tiles(t)
     ctx.decode_slots(out=dec, check=False)
 
 
 ms = gpu_ms(dev_roundtrip, 10)
 assert torch.equal(dec.view(torch.int16), t.view(torch.int16))
-c1 = {"workload": "%d x %dx%d u16, S1, GOP %d, encode+decode" % (n, w, h, gop), "device_resident_fps": n / ms * 1e3}
+c1 = {"workload": "%d x %dx%d u16, S1, GOP %d, encode+decode" % (n, w, h, gop), "device_resident_fps": n / ms * 1e3,
+      "encoded_batch_bytes": pc.finish().nbytes(), "raw_bytes": int(t.numel() * 2)}
+ms = gpu_ms(dev_roundtrip_slotted, 10)
+assert torch.equal(dec.view(torch.int16), t.view(torch.int16))
+c1["device_resident_fps_slotted_form"] = n / ms * 1e3
 ms_dense = gpu_ms(lambda: ctx.decode(ctx.encode(t), out=dec, check=False), 10)
 assert torch.equal(dec.view(torch.int16), t.view(torch.int16))
 c1["device_resident_fps_through_the_dense_form"] = n / ms_dense * 1e3
@@ -177,12 +189,15 @@ def chain(x):
 ms_unfused = gpu_ms(lambda: chain_unfused(t2), 5)
 ms = gpu_ms(lambda: chain(t2), 5)
 ms_slots = gpu_ms(lambda: ctx2.encode_tiles(D.filter_chain(t2, bp, 0.75, offs, "nearest")), 5)  # the encoded batch stays on the device: no gather
+pc2 = D.PackedCodec(w, h, n2, gop, device=dev)
+ms_packed = gpu_ms(lambda: pc2.encode(D.filter_chain(t2, bp, 0.75, offs, "nearest")), 5)  # the packed form: one kernel, payload + tables
+assert pc2.status()[0] == 0
 # ... with the chain's output and the encoder's workspace each in another placement class than what is read beside them (set-up, untimed)
 out2, _ = D.empty_beside(t2, tuple(t2.shape), torch.uint16)
 ctx2.place_workspace(out2)
 ms_placed = gpu_ms(lambda: ctx2.encode_tiles(D.filter_chain(t2, bp, 0.75, offs, "nearest", out=out2)), 5)
 c2 = {"workload": "%d x %dx%d u16, S1 + 200 bad pixels: bad_pixels_correct -> gaussian(0.75) -> translate(1.25,-2.5,nearest) -> encode; filters fused in one kernel (rir_filter_chain_device)" % (n2, w, h),
-      "device_resident_fps": n2 / ms * 1e3, "device_resident_fps_slotted_encode": n2 / ms_slots * 1e3, "device_resident_fps_slotted_encode_buffers_placed": n2 / ms_placed * 1e3,
+      "device_resident_fps": n2 / ms_packed * 1e3, "device_resident_fps_dense_file_form": n2 / ms * 1e3, "device_resident_fps_slotted_encode": n2 / ms_slots * 1e3, "device_resident_fps_slotted_encode_buffers_placed": n2 / ms_placed * 1e3,
       "device_resident_fps_unfused_3_filter_kernels": n2 / ms_unfused * 1e3}
 pin2 = torch.from_numpy(fr2).pin_memory()
 
@@ -236,12 +251,17 @@ if n3 > base.shape[0]:
 ctx3 = D.CodecContext(w3, h3, n3, gop, device=dev)
 dec3 = torch.empty_like(t3)
 ctx3.place_workspace(t3)
-ms = gpu_ms(lambda: (ctx3.encode_tiles(t3), ctx3.decode_slots(out=dec3, check=False)), 5)
+ms_sl = gpu_ms(lambda: (ctx3.encode_tiles(t3), ctx3.decode_slots(out=dec3, check=False)), 5)
 assert torch.equal(dec3.view(torch.int16), t3.view(torch.int16))
+dec3.zero_()
+pc3 = D.PackedCodec(w3, h3, n3, gop, device=dev)
+ms = gpu_ms(lambda: (pc3.encode(t3), pc3.decode(out=dec3, check=False)), 5)
+assert torch.equal(dec3.view(torch.int16), t3.view(torch.int16)) and pc3.status()[0] == 0
 out["configs[3]"] = {"workload": "per-GPU shard of the 10 000-frame job: %d x %dx%d u16 (250 distinct S1 frames tiled), encode+decode" % (n3, w3, h3),
-                     "device_resident_fps": n3 / ms * 1e3, "raw_GBs": n3 * 4.0 * h3 * w3 / ms / 1e6,
+                     "device_resident_fps": n3 / ms * 1e3, "raw_GBs": n3 * 4.0 * h3 * w3 / ms / 1e6, "device_resident_fps_slotted_form": n3 / ms_sl * 1e3,
+                     "encoded_batch_bytes": pc3.finish().nbytes(), "raw_bytes": int(t3.numel() * 2),
                      "note": "the exchange of the decoded / compressed stream is timed by bench.py --gpus N (value_with_exchange, value_with_compressed_exchange)"}
-del t3, dec3, ctx3
+del t3, dec3, ctx3, pc3
 torch.cuda.empty_cache()
 
 # ------------------------------------------------------------------ configs[4]: float32 stream, motion correction + bounded loss
@@ -311,12 +331,14 @@ treg = torch.from_numpy(reg).to(dev)
 ctx4 = D.CodecContext(w, h, n4, gop, device=dev)
 
 
+pc4 = D.PackedCodec(w, h, n4, gop, device=dev)
+
+
 def lossy_dev():
     ls = D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32)
-    out4, _, _ = ls.step(treg)
-    enc4 = ctx4.encode(out4)
+    out4, _, _ = ls.step(treg, errors=False)
+    pc4.encode(out4)
     ls.close()
-    return enc4
 
 
 ms = gpu_ms(lossy_dev, 3)
@@ -344,7 +366,23 @@ ls1 = D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32)
 ls1.step(s1_200[:60], errors=False)
 c4["lossy_step_device_resident_fps_one_stream"] = best_rate(lambda: ls1.step(s1_200, errors=False), m1)
 ls1.status()
+c4["lossy_step_groups_offered_to_and_taken_by_the_constant_budget_form"] = list(ls1.path_stats())
 ls1.close()
+if not args.quick:  # the same in calls of 1 000 frames (the call's fixed cost - ~130 us of tables, small launches and their gaps - spread over more frames)
+    s1_1000 = torch.from_numpy(s1_noisy_background(1000, h, w)).to(dev)
+    ls1 = D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32)
+    ls1.step(s1_1000[:60], errors=False)
+    c4["lossy_step_device_resident_fps_one_stream_1000_frame_calls"] = best_rate(lambda: ls1.step(s1_1000, errors=False), 1000)
+    ls1.status()
+    ls1.close()
+    os.environ["RIR_LOSSY_NO_CONST"] = "1"  # the general (resident) form on the same call, for comparison
+    ls1 = D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32)
+    ls1.step(s1_1000[:60], errors=False)
+    c4["lossy_step_device_resident_fps_one_stream_1000_frame_calls_general_form"] = best_rate(lambda: ls1.step(s1_1000, errors=False), 1000)
+    ls1.status()
+    ls1.close()
+    del os.environ["RIR_LOSSY_NO_CONST"]
+    del s1_1000
 # independent streams in shared launches (rir_lossy_step_multi_device): the loss state is sequential in time, streams run side by side
 for S in (7, 9, 32):  # 7 streams of this size share one resident launch of the first form of the run kernel, 9 one of the second; more go a batch after the other
     m = 20 if args.quick else m1
