@@ -9,6 +9,7 @@ O = Oracle()
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 bad = 0
+refused = 0
 for k in range(cases):
     h, w = int(rng.integers(1, 97)), int(rng.integers(1, 161))
     if rng.random() < 0.3:
@@ -43,8 +44,26 @@ for k in range(cases):
         f0 = c * gop; nf = min(gop, n - f0)
         h_o, o_o, st_o = O.codec_encode_chunk(fr[f0:f0 + nf])
         same &= bool(np.array_equal(hdr[c][:, :nf], h_o) and np.array_equal(toff[c], o_o) and np.array_equal(st[coff[c]:coff[c + 1]], st_o))
+    # the packed form: with room for any data - every segment the dense stream's words, the extents without holes - and, for a budget-sized
+    # buffer with the minimal arena, either a complete batch that decodes or a refusal (never a wrong frame)
+    pc = D.PackedCodec(w, h, n, gop, stream_bytes="max", workspace_bytes="max")
+    pb = pc.encode(t, check=True)
+    ok = ok and np.array_equal(pc.decode(pb).cpu().numpy(), fr)
+    pos = pb.seg_pos.cpu().numpy().view(np.uint64); sw = pb.seg_words.cpu().numpy().view(np.uint32); pst = pb.stream.cpu().numpy().view(np.uint64)
+    same = same and np.array_equal(sw, seg) and int(sw.astype(np.int64).sum()) == pb.low + pb.high
+    for c in range(ctx.layout.nchunks):
+        for tl in range(ctx.layout.ntiles):
+            a0 = int(coff[c]) + int(toff[c][tl])
+            same = same and bool(np.array_equal(pst[int(pos[c, tl]):int(pos[c, tl]) + int(sw[c, tl])], st[a0:a0 + int(sw[c, tl])]))
+    pc2 = D.PackedCodec(w, h, n, gop)
+    pc2.encode(t)
+    code = pc2.status()[0]
+    if code == 0:
+        ok = ok and np.array_equal(pc2.decode().cpu().numpy(), fr)
+    else:
+        refused += 1
     if not (ok and same):
         bad += 1
         print("FAIL case", k, (n, h, w, gop, kind), "roundtrip", ok, "stream==oracle", same)
-print("soak: %d cases, %d failures" % (cases, bad))
+print("soak: %d cases, %d failures (packed form within the 8 bpp budget and the minimal arena: %d batches refused, the rest decoded)" % (cases, bad, refused))
 sys.exit(1 if bad else 0)
