@@ -1750,34 +1750,35 @@ namespace rir
 		// kf: an image from before the group, which the group has not overwritten (it only writes the ring in its last `ra` frames, each
 		// slot after it has been read).  All wave-uniform choices, all addresses running sums: one load each, whatever the case.
 		Px V[D], O[D];
-		uint32_t B[D], M[D];
 		int kf = 0;					 // the next frame to request
 		uint64_t req_in = in0;		 // its pixels
 		int req_count = count;		 // images in the ring when it is stepped
-		int req_slot = head;		 // the ring's head then (valid once the ring is full)
+		// the ring slot the head is at when that frame is stepped (valid once the ring is full), as a running address
+		const uint64_t ring_end = ring0 + (uint64_t)(ra > 0 ? ra : 1) * ring_bytes;
+		uint64_t req_old = ring0 + (uint64_t)head * ring_bytes;
 		const uint64_t ra_back = (uint64_t)ra * frame_bytes;
-		auto request = [&](Px &v, Px &old, uint32_t &bgv, uint32_t &mv) {
+		auto request = [&](Px &v, Px &old) {
 			const bool more = kf < n;
-			bgv = sh_bg[more ? kf : 0];
 			v = buf_ldn<NP>(lossy_rsrc((const void *)req_in, more ? full_bytes : 0u), off_in);
 			if (RA_ON)
 			{
-				const bool need_old = more && ra > 0 && req_count == ra;
+				const bool full_then = req_count == ra;
+				const bool need_old = more && ra > 0 && full_then;
 				const bool from_in = kf >= ra;
-				const uint64_t ob = from_in ? req_in - ra_back : ring0 + (uint64_t)req_slot * ring_bytes;
+				const uint64_t ob = from_in ? req_in - ra_back : req_old;
 				old = buf_ldn<NP>(lossy_rsrc((const void *)ob, need_old ? s_bytes : 0u), off_lossy);
-				mv = from_in ? pc.min2 : 0u;
-				if (req_count == ra)
-					req_slot = req_slot + 1 == ra ? 0 : req_slot + 1;
-				else
-					++req_count;
+				// (the head moves once per frame from the moment the ring is full; until then the ring grows)
+				const uint64_t nxt = req_old + ring_bytes;
+				req_old = full_then ? (nxt == ring_end ? ring0 : nxt) : req_old;
+				req_count += full_then ? 0 : 1;
 			}
 			req_in += frame_bytes;
 			++kf;
 		};
 #pragma unroll
 		for (int j = 0; j < D; ++j)
-			request(V[j], O[j], B[j], M[j]);
+			request(V[j], O[j]);
+		uint32_t bg_next = sh_bg[0]; // (a frame's background is read from LDS a frame ahead)
 		// per-frame constants that only move while the ring fills
 		auto ring_consts = [&]() {
 			const int n_after = ra > 0 ? (count == ra ? ra : count + 1) : 0;
@@ -1788,17 +1789,21 @@ namespace rir
 		const int tail0 = n > kLossyConstTail ? n - kLossyConstTail : 0;
 		const int ring_from = n - ra; // frames from here on are in the ring after the group
 		uint64_t out_p = (uint64_t)rp.out;
-		auto step = [&](int k, Px &Vj, Px &Oj, uint32_t &Bj, uint32_t &Mj) {
+		// where a frame's input goes in the ring: the slot after the newest image - one further per frame, full ring or not
+		uint64_t wr_p = ring0 + (uint64_t)((head + (count == ra ? 0 : count)) % (ra > 0 ? ra : 1)) * ring_bytes;
+		auto step = [&](int k, Px &Vj, Px &Oj) {
 			const Px v = Vj;
 			Px old = Oj;
 			if (RA_ON)
-			{
+			{ // (what leaves the average came from the input - frame k - ra, still with its minimum - or from the ring, where it is stored without)
+				const uint32_t mj = k >= ra ? pc.min2 : 0u;
 #pragma unroll
 				for (int p = 0; p < NP; ++p)
-					old.d[p] = lu1(__builtin_elementwise_sub_sat(lp2(old.d[p]), lp2(Mj)));
+					old.d[p] = lu1(__builtin_elementwise_sub_sat(lp2(old.d[p]), lp2(mj)));
 			}
-			const uint32_t background = Bj;
-			request(Vj, Oj, Bj, Mj);
+			const uint32_t background = bg_next;
+			bg_next = sh_bg[k + 1 < n ? k + 1 : k];
+			request(Vj, Oj);
 			// the frame's sums, if its statistic will be in the window (or seeds it): against the previous output, per workgroup (out of
 			// line: 41 frames of a group come here, and the loop body is unrolled kConstDepth times)
 			lossy_v2u_b pval = {0u, 0u};
@@ -1828,14 +1833,11 @@ namespace rir
 			if (RA_ON)
 			{
 				// the ring as it must be after the group: the last `ra` inputs
-				const bool full_ring = count == ra;
-				int rs = full_ring ? head : head + count;
-				rs = rs >= ra ? rs - ra : rs;
-				buf_stn<NP>(t, lossy_rsrc((const void *)(ring0 + (uint64_t)rs * ring_bytes), (ra > 0 && k >= ring_from) ? s_bytes : 0u), off_lossy);
-				if (full_ring)
-					head = head + 1 == ra ? 0 : head + 1;
-				else
-				{
+				buf_stn<NP>(t, lossy_rsrc((const void *)wr_p, (ra > 0 && k >= ring_from) ? s_bytes : 0u), off_lossy);
+				const uint64_t nxt = wr_p + ring_bytes;
+				wr_p = nxt == ring_end ? ring0 : nxt;
+				if (count != ra)
+				{ // (only while the ring fills: the constants of the running average move)
 					++count;
 					ring_consts();
 				}
@@ -1846,13 +1848,13 @@ namespace rir
 		{ // whole iterations of D unconditional steps
 #pragma unroll
 			for (int j = 0; j < D; ++j)
-				step(k0 + j, V[j], O[j], B[j], M[j]);
+				step(k0 + j, V[j], O[j]);
 		}
 		// up to D - 1 left-over frames (the slot rotation stays aligned)
 #pragma unroll
 		for (int j = 0; j < D - 1; ++j)
 			if (k0 + j < n)
-				step(k0 + j, V[j], O[j], B[j], M[j]);
+				step(k0 + j, V[j], O[j]);
 		if (lossy)
 		{
 			stn<NP>(refT, ig, ref);
