@@ -113,6 +113,9 @@ namespace rir
 	// Runs of frames.  Backgrounds of `entries` frames (any streams) in one launch: d_table[e] describes frame e (tmp, hist = a
 	// zeroed 16 384-bin slice of its own, stats -> where its background goes, tickets -> a zeroed word of its own, s, hist_px).
 	hipError_t launch_lossy_backgrounds(const LossyStep *d_table, int entries, int s, int hist_px, hipStream_t st);
+	// the same for `frames` frames of the nstreams runs d_runs describes (in, frame_px, bg, bg_stride): no per-frame table; d_hist: frames x nstreams
+	// zeroed slices of 16 384 bins, d_tickets: as many zeroed words (entry = frame * nstreams + stream)
+	hipError_t launch_lossy_backgrounds_of_runs(const LossyRun *d_runs, int nstreams, int frames, uint32_t *d_hist, unsigned int *d_tickets, int s, int hist_px, hipStream_t st);
 	// One launch of a run for `nstreams` streams: d_table[i] is stream i's step (next_* filled in).
 	hipError_t launch_lossy_frame(const LossyStep *d_table, int nstreams, int full, hipStream_t st);
 	// d_table[i]: the run of stream i; d_ticket: the 256-byte header of the exchange buffer, zeroed once: word 0 the ticket (left zeroed), word 16

@@ -157,11 +157,17 @@ namespace rir
 		}
 	}
 
-	template <bool TABLE>
-	__global__ __launch_bounds__(1024) void lossy_hist_mode_kernel(LossyStep one, const LossyStep *__restrict__ table)
+	// what the histogram pass needs of a frame: its pixels, a zeroed 16 384-bin slice, where its background goes, a zeroed ticket
+	struct LossyHistJob
 	{
-		const LossyStep sp = lossy_step_of<TABLE>(one, table);
-		__shared__ uint32_t lh[16384];
+		const uint16_t *tmp;
+		uint32_t *hist;
+		long long *stats;
+		unsigned int *tickets;
+		int s, hist_px;
+	};
+	__device__ __forceinline__ void lossy_hist_mode_body(const LossyHistJob &sp, uint32_t *lh)
+	{
 		const int tid = threadIdx.x;
 		RIR_GLOBAL(const uint16_t) *tmp = as_global(sp.tmp);
 		RIR_GLOBAL(uint32_t) *hist = as_global(sp.hist);
@@ -251,6 +257,25 @@ namespace rir
 			const long long unsure = (nb_ == 0 || na_ == 0) ? (1ll << 40) : 0ll;
 			as_global(sp.stats)[0] = (long long)((mode_bin << 2) + 1) | unsure;
 		}
+	}
+	template <bool TABLE>
+	__global__ __launch_bounds__(1024) void lossy_hist_mode_kernel(LossyStep one, const LossyStep *__restrict__ table)
+	{
+		__shared__ uint32_t lh[16384];
+		const LossyStep sp = lossy_step_of<TABLE>(one, table);
+		const LossyHistJob job = {sp.tmp, sp.hist, sp.stats, sp.tickets, sp.s, sp.hist_px};
+		lossy_hist_mode_body(job, lh);
+	}
+	// The backgrounds of a group of frames of a run, straight from the runs' descriptions (no per-frame table to build and copy): entry
+	// blockIdx.y = frame k of stream i of the group (k major), its histogram slice and ticket the entry's own.
+	__global__ __launch_bounds__(1024) void lossy_hist_mode_runs_kernel(const LossyRun *__restrict__ runs, int nstreams, uint32_t *__restrict__ hist_base,
+																		unsigned int *__restrict__ tick_base, int s, int hist_px)
+	{
+		__shared__ uint32_t lh[16384];
+		const int e = blockIdx.y, k = e / nstreams, i = e - k * nstreams;
+		RIR_GLOBAL(const LossyRun) *r = as_global(runs + i);
+		const LossyHistJob job = {r->in + (size_t)k * r->frame_px, hist_base + (size_t)e * 16384, const_cast<long long *>(r->bg) + (size_t)k * r->bg_stride, tick_base + e, s, hist_px};
+		lossy_hist_mode_body(job, lh);
 	}
 
 	// (int) of a double as the reference's x86-64 build converts it (cvttsd2si): NaN and values outside int32 give
@@ -1801,7 +1826,7 @@ namespace rir
 				for (int p = 0; p < NP; ++p)
 					old.d[p] = lu1(__builtin_elementwise_sub_sat(lp2(old.d[p]), lp2(mj)));
 			}
-			const uint32_t background = bg_next;
+			const uint32_t background = (uint32_t)__builtin_amdgcn_readfirstlane((int)bg_next); // (wave-uniform: what is derived from it stays on the scalar unit)
 			bg_next = sh_bg[k + 1 < n ? k + 1 : k];
 			request(Vj, Oj);
 			// the frame's sums, if its statistic will be in the window (or seeds it): against the previous output, per workgroup (out of
@@ -2059,6 +2084,14 @@ namespace rir
 			return hipSuccess;
 		LossyStep none{};
 		hipLaunchKernelGGL(lossy_hist_mode_kernel<true>, dim3((s + hist_px - 1) / hist_px, entries), dim3(1024), 0, st, none, d_table);
+		return hipGetLastError();
+	}
+	hipError_t launch_lossy_backgrounds_of_runs(const LossyRun *d_runs, int nstreams, int frames, uint32_t *d_hist, unsigned int *d_tickets, int s, int hist_px, hipStream_t st)
+	{
+		if (frames <= 0 || nstreams <= 0 || s <= 0)
+			return hipSuccess;
+		hipLaunchKernelGGL(lossy_hist_mode_runs_kernel, dim3((s + hist_px - 1) / hist_px, (unsigned)(frames * nstreams)), dim3(1024), 0, st, d_runs, nstreams, d_hist, d_tickets,
+						   s, hist_px);
 		return hipGetLastError();
 	}
 	hipError_t launch_lossy_frame(const LossyStep *d_table, int nstreams, int full, hipStream_t st)

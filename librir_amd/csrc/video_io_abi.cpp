@@ -2509,7 +2509,8 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 		const int batch = persistent ? resident_batch(plan, nstreams) : nstreams;
 		const int group = std::max(1, (persistent ? 2048 : 512) / nstreams); // frames per histogram launch (one 64 KB histogram slice per frame and stream)
 		const int ngroups = runs ? (nsteps + group - 1) / group : 0;
-		const size_t nfused = persistent ? 0 : runs ? (size_t)(nsteps + 1) * nstreams : (size_t)nsteps * nstreams, nhist = runs ? (size_t)nsteps * nstreams : 0;
+		const size_t nfused = persistent ? 0 : runs ? (size_t)(nsteps + 1) * nstreams : (size_t)nsteps * nstreams, nbg = runs ? (size_t)nsteps * nstreams : 0,
+					 nhist = persistent ? 0 : nbg; // (the resident / constant-budget path takes its backgrounds straight from the runs' descriptions: no per-frame table)
 		const size_t run_off = (nfused + nhist) * sizeof(LossyStep); // (a multiple of 8)
 		const size_t nb = run_off + (persistent ? (size_t)ngroups * nstreams * sizeof(LossyRun) : 0);
 		if (!lead.multi_table.reserve(nb) || !lead.multi_stage.reserve(nb))
@@ -2543,7 +2544,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 			// histogram scratch: one zeroed 16 384-bin slice and one ticket per frame of a group (the kernels leave them zeroed)
 			const size_t slices = (size_t)std::min(nsteps, group) * nstreams;
 			const size_t hist_cap = lead.run_hist.cap, tick_cap = lead.run_tickets.cap;
-			if (!lead.run_hist.reserve(slices * 16384 * 4) || !lead.run_tickets.reserve(slices * 4) || !lead.run_bg.reserve(nhist * sizeof(long long)))
+			if (!lead.run_hist.reserve(slices * 16384 * 4) || !lead.run_tickets.reserve(slices * 4) || !lead.run_bg.reserve(nbg * sizeof(long long)))
 				return -1;
 			if (lead.run_hist.cap != hist_cap && !hip_ok(hipMemsetAsync(lead.run_hist.ptr, 0, lead.run_hist.cap, st), "memset"))
 				return -1;
@@ -2609,16 +2610,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 						r.partials = const_form ? lead.const_partials.as<unsigned long long>() + (size_t)i * part_words : nullptr;
 						hr[(size_t)g * nstreams + i] = r;
 						for (int k = k0; k < k0 + in_group; ++k)
-						{
-							LossyStep h{};
-							const size_t slice = (size_t)(k - k0) * nstreams + i;
-							h.tmp = h.img = d_in[i] + (size_t)(f0 + k) * npx;
-							h.hist = lead.run_hist.as<uint32_t>() + slice * 16384;
-							h.stats = bg + (size_t)k * nstreams + i;
-							h.tickets = lead.run_tickets.as<unsigned int>() + slice;
-							h.s = s_px, h.full = full_px;
-							h.hist_px = lossy_hist_px(s_px, in_group * nstreams);
-							hh[(size_t)k * nstreams + i] = h;
+						{ // (the host side of the stream's state as it will be after the group)
 							ls.advance_ring();
 							++ls.frames;
 						}
@@ -2643,7 +2635,8 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 				for (int g = 0; g < ngroups; ++g)
 				{
 					const int k0 = g * group, in_group = std::min(group, nsteps - k0);
-					if (!hip_ok(launch_lossy_backgrounds(dt + nfused + (size_t)k0 * nstreams, in_group * nstreams, s_px, lossy_hist_px(s_px, in_group * nstreams), st),
+					if (!hip_ok(launch_lossy_backgrounds_of_runs(dr + (size_t)g * nstreams, nstreams, in_group, lead.run_hist.as<uint32_t>(), lead.run_tickets.as<unsigned int>(), s_px,
+																 lossy_hist_px(s_px, in_group * nstreams), st),
 								"lossy backgrounds") ||
 						!hip_ok(hipMemsetAsync(d_exch, 0, exch_bytes, st), "memset"))
 						return -1;
