@@ -14,6 +14,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBS = os.path.join(HERE, "libs")
 ROOT = os.path.dirname(HERE)
 LIB_NAME = "librir_amd.so"
+# The same library with the TEST HOOKS compiled in (-DRIR_TEST_HOOKS: fault injection through RIR_DEBUG_* variables, runtime.h).  Only the
+# tests that force a bail-out path load it (tests/hook_cases.py, RIR_LIBRARY_VARIANT=testhooks); the product library contains no hook.
+HOOKS_LIB_NAME = "librir_amd_testhooks.so"
+HOOKS_UNITS = ["video_io_abi.cpp", "registration_abi.cpp"]  # the translation units that read a hook
 # the names the wrapper globs for, and the SONAMEs the reference's own libraries record for each other (SOVERSION = major
 # version, src/cpp/tools/CMakeLists.txt:83-84): the reference's libgeometry.so, which a drop-in keeps, NEEDs libtools.so.6
 ALIASES = ["libtools.so", "libsignal_processing.so", "libvideo_io.so", "libtools.so.6", "libsignal_processing.so.6", "libvideo_io.so.6"]
@@ -85,6 +89,23 @@ def build(force=False, verbose=True):
     if force or procs or not os.path.exists(target):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs + ["-ldl", "-lpthread"]
         subprocess.check_call(cmd)
+    # the build with the test hooks: the units that read one compiled again with -DRIR_TEST_HOOKS, everything else shared
+    hooks_target = os.path.join(LIBS, HOOKS_LIB_NAME)
+    hprocs, hobjs = [], list(objs)
+    for unit in HOOKS_UNITS:
+        src = os.path.join(CSRC, unit)
+        obj = os.path.join(objdir, unit + ".hooks.o")
+        hobjs[hobjs.index(os.path.join(objdir, unit + ".o"))] = obj
+        if force or _newer(src, obj):
+            cmd = [HIPCC, "-x", "hip"] + COMMON + ["-DRIR_TEST_HOOKS", "-c", src, "-o", obj]
+            hprocs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in hprocs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode(errors="replace"))
+            raise RuntimeError("librir_amd: hipcc compilation failed (test-hooks build)")
+    if force or procs or hprocs or not os.path.exists(hooks_target):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", hooks_target] + hobjs + ["-ldl", "-lpthread"])
     for a in ALIASES:
         link = os.path.join(LIBS, a)
         if os.path.islink(link) or os.path.exists(link):

@@ -73,7 +73,7 @@ namespace
 	// (tests, RIR_DEBUG_ECC_BAIL: as if the next launch on this control block had not become resident - its decision says BAIL before anybody arrives)
 	bool debug_call_off(unsigned int *d_ctl, unsigned int epoch, hipStream_t st)
 	{
-		if (!getenv("RIR_DEBUG_ECC_BAIL"))
+		if (!test_hook("RIR_DEBUG_ECC_BAIL"))
 			return true;
 		const unsigned int w_ = ((epoch & 0x3fffffffu) << 2) | 2u;
 		return hip_ok(hipMemcpyAsync(d_ctl + 1, &w_, 4, hipMemcpyHostToDevice, st), "H2D") && hip_ok(hipStreamSynchronize(st), "sync");
@@ -711,7 +711,7 @@ RIR_EXPORT int rir_ecc_align_multi_overlapped_device(const float *const *d_ref_n
 	// (resident_device.h); one that is not has written nothing and is repeated with half the slices - any number of slices gives the
 	// same bits - and, from one slice per sequence, handed to the single-sequence path.
 	static const int env_slices = getenv("RIR_ECC_MULTI_SLICES") ? atoi(getenv("RIR_ECC_MULTI_SLICES")) : 0;
-	const bool debug_bail = getenv("RIR_DEBUG_ECC_BAIL") != nullptr; // (tests: as if the first attempt of every launch had not become resident)
+	const bool debug_bail = test_hook("RIR_DEBUG_ECC_BAIL") != nullptr; // (tests: as if the first attempt of every launch had not become resident)
 	const bool fresh_ctl = sc.multi_ctl.cap == 0;
 	if (!sc.multi_ctl.reserve(256))
 		return -1;

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <map>
 #include <memory>
@@ -54,6 +55,13 @@ namespace rir
 	// The product path has NO CPU fallback: every compute entry point first calls device_ready(),
 	// which logs and returns false when no HIP device is usable, and the entry point returns its
 	// error code.
+	// Test hooks (fault injection: RIR_DEBUG_LOSSY_GIVE_UP, RIR_DEBUG_LOSSY_BAIL, RIR_DEBUG_ECC_BAIL) exist only in the build made with
+	// -DRIR_TEST_HOOKS (librir_amd/build.py: libs/librir_amd_testhooks.so, loaded by the tests that need it); the product library reads none of them.
+#ifdef RIR_TEST_HOOKS
+	inline const char *test_hook(const char *name) { return getenv(name); }
+#else
+	inline const char *test_hook(const char *) { return nullptr; }
+#endif
 	bool device_ready();
 	// gaussian_filter as the 2-D sum in the reference's own order (signal_processing.cpp:101-148: dx outer, dy inner, one rounding per product
 	// and per sum) instead of the separable form: bit-identical results instead of results within 2e-6, three times the time.  Process-wide,

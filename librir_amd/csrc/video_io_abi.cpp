@@ -2630,7 +2630,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 					else
 						os[i]->lead = lead.weak_from_this();
 				}
-				if (getenv("RIR_DEBUG_LOSSY_GIVE_UP") && !hip_ok(hipMemsetAsync(d_error, 1, 4, st), "memset")) // (tests: as if a wait had hit its clock)
+				if (test_hook("RIR_DEBUG_LOSSY_GIVE_UP") && !hip_ok(hipMemsetAsync(d_error, 1, 4, st), "memset")) // (tests: as if a wait had hit its clock)
 					return -1;
 				for (int g = 0; g < ngroups; ++g)
 				{
@@ -2654,7 +2654,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 						const unsigned int epoch = ++lead.run_epoch;
 						if (s0 == 0)
 							run_epochs.push_back(epoch);
-						if (getenv("RIR_DEBUG_LOSSY_BAIL") && atoi(getenv("RIR_DEBUG_LOSSY_BAIL")) == g)
+						if (test_hook("RIR_DEBUG_LOSSY_BAIL") && atoi(test_hook("RIR_DEBUG_LOSSY_BAIL")) == g)
 						{ // (tests: as if group g's launch had not become resident: its decision is BAIL before anybody arrives)
 							const unsigned int w_ = ((epoch & 0x3fffffffu) << 2) | 2u;
 							if (!hip_ok(hipMemcpyAsync(d_ticket + kLossyRunCtlWord + 1, &w_, 4, hipMemcpyHostToDevice, st), "H2D") || !hip_ok(hipStreamSynchronize(st), "sync"))

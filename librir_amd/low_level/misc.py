@@ -11,7 +11,9 @@ import ctypes as ct
 import os
 
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-_LIB_PATH = os.path.join(_HERE, "libs", "librir_amd.so")
+# RIR_LIBRARY_VARIANT=testhooks: the build with the fault-injection hooks compiled in (librir_amd/build.py) - for the tests that force a
+# bail-out path (tests/hook_cases.py); anything else: the product library
+_LIB_PATH = os.path.join(_HERE, "libs", "librir_amd_testhooks.so" if os.environ.get("RIR_LIBRARY_VARIANT") == "testhooks" else "librir_amd.so")
 
 
 def _load():

@@ -125,8 +125,8 @@ def stage(tmp):
     ours = os.path.join(ROOT, "librir_amd", "libs")
     for e in os.listdir(ours):  # cp -P: the aliases stay symlinks to librir_amd.so
         s = os.path.join(ours, e)
-        if os.path.isdir(s) and not os.path.islink(s):
-            continue  # (scripts/variants.py keeps its experimental builds in a sub-directory)
+        if (os.path.isdir(s) and not os.path.islink(s)) or "testhooks" in e:
+            continue  # (scripts/variants.py keeps its experimental builds in a sub-directory; the build with the test hooks is not part of a drop-in)
         if os.path.islink(s):
             os.symlink(os.readlink(s), os.path.join(libs, e))
         else:

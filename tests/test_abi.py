@@ -68,6 +68,16 @@ def test_reference_wrapper_imports_and_runs_on_this_library():
     assert got["translate_without_device"] == "RuntimeError" and got["h264_add_image_lossless_without_device"] == "RuntimeError"
 
 
+def test_the_product_library_has_no_test_hooks():
+    """the fault-injection hooks (RIR_DEBUG_*) exist only in libs/librir_amd_testhooks.so"""
+    libs = os.path.join(ROOT, "librir_amd", "libs")
+    product = open(os.path.join(libs, "librir_amd.so"), "rb").read()
+    hooks = open(os.path.join(libs, "librir_amd_testhooks.so"), "rb").read()
+    for name in (b"RIR_DEBUG_LOSSY_GIVE_UP", b"RIR_DEBUG_LOSSY_BAIL", b"RIR_DEBUG_ECC_BAIL"):
+        assert name not in product, name
+        assert name in hooks, name
+
+
 def test_layout_query_is_pure_host(lib):
     from librir_amd.device import codec_layout
 

@@ -89,79 +89,27 @@ def test_three_resident_kernel_families_from_three_threads(dev):
     assert max(longest.values()) < 1.0, longest
 
 
-def test_a_run_that_gave_up_is_sticky(dev, monkeypatch, tmp_path):
-    """A resident run that gives up a wait (forced through RIR_DEBUG_LOSSY_GIVE_UP) has advanced the stream's state with invalid
+def _hook_case(*args):
+    """runs tests/hook_cases.py <case> in a process that loads the build WITH the test hooks (the product library has none)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RIR_LIBRARY_VARIANT="testhooks")
+    for k in ("RIR_DEBUG_LOSSY_GIVE_UP", "RIR_DEBUG_LOSSY_BAIL", "RIR_DEBUG_ECC_BAIL"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "hook_cases.py")] + [str(a) for a in args], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "case ok" in r.stdout, r.stdout[-3000:]
+
+
+def test_a_run_that_gave_up_is_sticky():
+    """A resident run that gives up a wait (forced through the test hook RIR_DEBUG_LOSSY_GIVE_UP) has advanced the stream's state with invalid
     frames: the call fails, every later step and status of EVERY stream of that call fails, a stream that was not part of it
     goes on; a saver in that state takes no more frames, writes nothing of the chunk that was being assembled and closes into a
-    readable file that ends with the last complete chunk."""
-    import torch
-
-    from librir_amd import device as D
-    from librir_amd.video_io import IRMovie, IRSaver
-
-    n, h, w = 12, 64, 96
-    fr = [torch.from_numpy(s1_noisy_background(n, h, w, seed=3 + i)).cuda() for i in range(3)]
-    a, b, c = (D.LossyStream(w, h, h - 3) for _ in range(3))
-    D.LossyStream.step_many([a, b], [fr[0][:4], fr[1][:4]])
-    c.step(fr[2][:4])
-    monkeypatch.setenv("RIR_DEBUG_LOSSY_GIVE_UP", "1")
-    with pytest.raises(RuntimeError):
-        D.LossyStream.step_many([a, b], [fr[0][4:8], fr[1][4:8]])
-    monkeypatch.delenv("RIR_DEBUG_LOSSY_GIVE_UP")
-    for s in (a, b):
-        with pytest.raises(RuntimeError):
-            s.step(fr[0][8:])
-        with pytest.raises(RuntimeError):
-            s.status()
-    c.step(fr[2][4:])
-    c.status()
-    # queue-only calls find it out at the status query, for the member as well as for the leader
-    d, e = D.LossyStream(w, h, h - 3), D.LossyStream(w, h, h - 3)
-    D.LossyStream.step_many([d, e], [fr[0][:4], fr[1][:4]], errors=False)
-    monkeypatch.setenv("RIR_DEBUG_LOSSY_GIVE_UP", "1")
-    D.LossyStream.step_many([d, e], [fr[0][4:8], fr[1][4:8]], errors=False)
-    monkeypatch.delenv("RIR_DEBUG_LOSSY_GIVE_UP")
-    with pytest.raises(RuntimeError):
-        e.status()
-    with pytest.raises(RuntimeError):
-        d.status()
-    with pytest.raises(RuntimeError):
-        e.step(fr[1][8:])
-    for s in (a, b, c, d, e):
-        s.close()
-
-    # the saver: GOP 5, 12 good frames (two chunks written, two frames pending), then a run that gives up
-    p = str(tmp_path / "sticky.h264")
-    data = s1_noisy_background(30, h, w, seed=9)
-    s = IRSaver(p, w, h, h - 3)
-    s.set_parameter("GOP", 5)
-    for i in range(12):
-        s.add_image_lossy(data[i], i)
-    monkeypatch.setenv("RIR_DEBUG_LOSSY_GIVE_UP", "1")
-    failed_at = None
-    for i in range(12, 20):
-        try:
-            s.add_image_lossy(data[i], i)
-        except RuntimeError:
-            failed_at = i
-            break
-    monkeypatch.delenv("RIR_DEBUG_LOSSY_GIVE_UP")
-    assert failed_at is not None and failed_at <= 15  # the chunk that completes at frame 14 runs its deferred loss step
-    for i in range(failed_at, failed_at + 3):
-        with pytest.raises(RuntimeError):
-            s.add_image_lossy(data[i], i)
-        with pytest.raises(RuntimeError):
-            s.add_image(data[i], i)
-    s.close()
-    with IRMovie.from_filename(p) as mov:
-        assert mov.images == 10  # the two complete chunks; nothing of the failed one
-        ok = IRSaver(str(tmp_path / "ok.h264"), w, h, h - 3)
-        ok.set_parameter("GOP", 5)
-        for i in range(10):
-            ok.add_image_lossy(data[i], i)
-        ok.close()
-        with IRMovie.from_filename(str(tmp_path / "ok.h264")) as good:
-            assert np.array_equal(mov.data, good.data)
+    readable file that ends with the last complete chunk.  (tests/hook_cases.py: sticky)"""
+    _hook_case("sticky")
 
 
 def test_images_kept_by_the_caller_survive_later_reads(tmp_path):
@@ -185,30 +133,12 @@ def test_images_kept_by_the_caller_survive_later_reads(tmp_path):
             assert np.array_equal(views[i], data[8 + i][3:9])
 
 
-def test_a_launch_that_is_not_resident_is_repeated_smaller_with_the_same_results(monkeypatch):
+def test_a_launch_that_is_not_resident_is_repeated_smaller_with_the_same_results():
     """ecc_run_multi_kernel finds out at its start whether all its workgroups are on the chip (resident_device.h); a launch that is
-    not - forced here through RIR_DEBUG_ECC_BAIL: the first attempt of every launch is called off - has written nothing and is
-    repeated with half the workgroups per sequence: the tracks are the ones of the undisturbed run, bit for bit."""
-    import torch
-
-    from librir_amd.registration import DeviceRegistratorECC
-
-    S, n, h, w = 5, 40, 256, 320
-    seqs = [torch.from_numpy(s3_registration(n, h, w, seed=70 + q)[0]).cuda() for q in range(S)]
-
-    def run():
-        rs = [DeviceRegistratorECC(0.8, 0.8, shape=(h, w)) for _ in range(S)]
-        for q in range(S):
-            rs[q].start(seqs[q][0])
-        DeviceRegistratorECC.compute_many_multi(rs, [s[1:] for s in seqs], chunk=16)
-        return [(r.x, r.y, r.confidences) for r in rs]
-
-    ref = run()
-    monkeypatch.setenv("RIR_DEBUG_ECC_BAIL", "1")
-    got = run()
-    monkeypatch.delenv("RIR_DEBUG_ECC_BAIL")
-    assert got == ref
-    assert run() == ref
+    not - forced through the test hook RIR_DEBUG_ECC_BAIL: the first attempt of every launch is called off - has written nothing and is
+    repeated with half the workgroups per sequence: the tracks are the ones of the undisturbed run, bit for bit.
+    (tests/hook_cases.py: multi_repeated_smaller)"""
+    _hook_case("multi_repeated_smaller")
 
 
 def test_alignments_beside_a_flood_of_ordinary_kernels(dev):
@@ -260,69 +190,16 @@ def test_alignments_beside_a_flood_of_ordinary_kernels(dev):
 
 
 @pytest.mark.parametrize("bail_group", [0, 1])
-def test_a_loss_run_that_is_not_resident_is_stepped_again_frame_by_frame(oracle, monkeypatch, bail_group):
+def test_a_loss_run_that_is_not_resident_is_stepped_again_frame_by_frame(bail_group):
     """lossy_run_kernel finds out at its start whether all its workgroups are on the chip (resident_device.h); a group of frames whose
-    launch was called off - forced through RIR_DEBUG_LOSSY_BAIL=<group> - has written nothing, poisons the groups queued behind it,
+    launch was called off - forced through the test hook RIR_DEBUG_LOSSY_BAIL=<group> - has written nothing, poisons the groups queued behind it,
     and a call that waits for the budgets steps the frames from that group on again on the launch-per-frame path: frames and budgets
-    are those of the undisturbed run (and of the oracle), the streams stay usable."""
-    import torch
-
-    from librir_amd import device as D
-    from oracle.pyoracle import OracleLossy
-
-    S, n, h, w, hl = 64, 47, 96, 128, 93  # 64 streams: groups of 32 frames, so the 46 steps after the first frame are two groups
-    data = [s1_noisy_background(n, h, w, seed=300 + i) for i in range(S)]
-    tens = [torch.from_numpy(d).cuda() for d in data]
-
-    def run(more):
-        streams = [D.LossyStream(w, h, hl, 6, 2, 5.0, 8) for _ in range(S)]
-        o, lo, hi = D.LossyStream.step_many(streams, tens)
-        o2, lo2, hi2 = D.LossyStream.step_many(streams, [t[:more] for t in tens])  # the streams go on afterwards
-        for s in streams:
-            s.status()
-            s.close()
-        return [x.cpu().numpy() for x in o], lo.copy(), hi.copy(), [x.cpu().numpy() for x in o2], lo2.copy(), hi2.copy()
-
-    ref = run(9)
-    monkeypatch.setenv("RIR_DEBUG_LOSSY_BAIL", str(bail_group))
-    got = run(9)
-    monkeypatch.delenv("RIR_DEBUG_LOSSY_BAIL")
-    for a, b in zip(got, ref):
-        if isinstance(a, list):
-            assert all(np.array_equal(x, y) for x, y in zip(a, b))
-        else:
-            assert np.array_equal(a, b)
-    for i in (0, 17, 63):
-        L = OracleLossy(oracle, w, h, hl, low_err=6, high_err=2, std_factor=5.0, running_average=8)
-        exp = np.stack([L.step(data[i][f]) for f in range(n)])
-        assert np.array_equal(got[0][i], exp), i
+    are those of the undisturbed run (and of the oracle), the streams stay usable.  (tests/hook_cases.py: loss_run_stepped_again)"""
+    _hook_case("loss_run_stepped_again", bail_group)
 
 
-def test_a_single_sequence_launch_that_is_not_resident_falls_back_to_two_launches_per_iteration(monkeypatch):
-    """ecc_run_kernel with the same rendezvous: a launch that was called off (RIR_DEBUG_ECC_BAIL: every launch) reports "not run"
+def test_a_single_sequence_launch_that_is_not_resident_falls_back_to_two_launches_per_iteration():
+    """ecc_run_kernel with the same rendezvous: a launch that was called off (test hook RIR_DEBUG_ECC_BAIL: every launch) reports "not run"
     through the host view and the alignment - one frame, or a chunk of frames - is done by the launch-per-iteration kernels, which
-    add the same rows in the same order: same track, same iteration counts."""
-    import torch
-
-    from librir_amd.registration import DeviceRegistratorECC, find_transform_ecc_translation
-
-    n, h, w = 30, 256, 320
-    f, _ = s3_registration(n, h, w, seed=31)
-    t = torch.from_numpy(f).cuda()
-
-    def run():
-        a = DeviceRegistratorECC(0.8, 0.8, shape=(h, w))
-        a.start(t[0])
-        a.compute_many(t[1:], chunk=8)
-        b = DeviceRegistratorECC(0.8, 0.8, shape=(h, w))
-        b.start(t[0])
-        for i in range(1, 6):
-            b.compute(t[i])
-        cc, wm = find_transform_ecc_translation(f[0] / f[0].max(), f[3] / f[3].max())
-        return a.x, a.y, a.confidences, b.x, b.y, b.confidences, cc, wm.tolist()
-
-    ref = run()
-    monkeypatch.setenv("RIR_DEBUG_ECC_BAIL", "1")
-    got = run()
-    monkeypatch.delenv("RIR_DEBUG_ECC_BAIL")
-    assert got == ref
+    add the same rows in the same order: same track, same iteration counts.  (tests/hook_cases.py: single_sequence_falls_back)"""
+    _hook_case("single_sequence_falls_back")
