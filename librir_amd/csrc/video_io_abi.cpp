@@ -2507,7 +2507,15 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 		const bool persistent = runs && errors_fit && plan.units_per_launch > 0 && !force_per_frame && !getenv("RIR_LOSSY_LAUNCH_PER_FRAME");
 		// streams per launch of the resident kernel: the launches the plan needs, filled evenly (32 streams at 9 per launch: 8, 8, 8, 8 - not 9, 9, 9, 5)
 		const int batch = persistent ? resident_batch(plan, nstreams) : nstreams;
-		const int group = std::max(1, (persistent ? 2048 : 512) / nstreams); // frames per histogram launch (one 64 KB histogram slice per frame and stream)
+		// The constant-budget form (lossy_kernels.hip: lossy_const_run_kernel): with stdFactor == 0 for every stream of the call each group is
+		// first offered to an ordinary launch that needs no hand-offs between workgroups (decided below, on the device, group by group).
+		bool const_form = persistent && !getenv("RIR_LOSSY_NO_CONST");
+		for (int i = 0; i < nstreams; ++i)
+			const_form = const_form && os[i]->std_factor == 0.0;
+		// frames per histogram launch (one 64 KB histogram slice per frame and stream).  A group costs four small launches beside its
+		// frames, so streams that may take the constant-budget form - 0.1 us per stream-frame - get groups four times as long (up to
+		// 512 MB of slices, allocated as needed; 32 streams x 200 frames: 64-frame groups 0.83 M frames/s, one group 1.2 M)
+		const int group = std::min(kLossyConstMaxFrames, std::max(1, (persistent ? (const_form ? 8192 : 2048) : 512) / nstreams));
 		const int ngroups = runs ? (nsteps + group - 1) / group : 0;
 		const size_t nfused = persistent ? 0 : runs ? (size_t)(nsteps + 1) * nstreams : (size_t)nsteps * nstreams, nbg = runs ? (size_t)nsteps * nstreams : 0,
 					 nhist = persistent ? 0 : nbg; // (the resident / constant-budget path takes its backgrounds straight from the runs' descriptions: no per-frame table)
@@ -2574,9 +2582,6 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 				// group is first offered to an ordinary launch that needs no hand-offs between workgroups; it declines - on the device, nothing
 				// waits for the host - when a frame's class may be empty or a NaN sits in a window, and the resident launch behind it, which
 				// otherwise finds the group done and leaves, steps it.
-				bool const_form = !getenv("RIR_LOSSY_NO_CONST");
-				for (int i = 0; i < nstreams; ++i)
-					const_form = const_form && os[i]->std_factor == 0.0;
 				const size_t part_words = (size_t)kLossyConstSlots * lossy_const_workgroups(full_px, nstreams) * 4;
 				lead.const_groups = 0;
 				if (const_form)
