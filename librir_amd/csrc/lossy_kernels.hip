@@ -913,8 +913,17 @@ namespace rir
 	// per half: 0xffff where the half of x is not 0, else 0
 	__device__ __forceinline__ uint32_t lossy_nz_mask(lossy_u16x2 x)
 	{
+#ifndef RIR_LOSSY_NZ_MASK_PLAIN
+		// min(x, 1) and 0 - that, two packed instructions.  Spelled as such: written in C (min(x, 1) * 0xffff) the compiler sees through
+		// the mask and turns every select under it into two 16-bit compares, two conditional moves and a byte permute.
+		uint32_t t, r;
+		asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(lu1(x)), "s"(0x00010001u));
+		asm("v_pk_sub_u16 %0, 0, %1" : "=v"(r) : "v"(t));
+		return r;
+#else
 		const lossy_u16x2 one = {1, 1}, ffff = {0xffff, 0xffff};
 		return lu1(__builtin_elementwise_min(x, one) * ffff);
+#endif
 	}
 	__device__ __forceinline__ uint32_t lossy_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); } // mask ? a : b, bit by bit
 	struct LossyPairConsts
