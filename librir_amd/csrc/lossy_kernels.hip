@@ -177,40 +177,75 @@ namespace rir
 		__syncthreads();
 		const int i0 = blockIdx.x * sp.hist_px, i1 = min(i0 + sp.hist_px, s);
 		if (((i0 | i1) & 7) == 0)
-		{ // 8 pixels per 16-byte load
+		{ // 8 pixels per 16-byte load, kHistAhead loads of a thread in flight: with one (load, count, load, ...) a workgroup that takes a
+		  // whole frame - a run of 1 000 frames is 1 000 such workgroups, two to a CU - waited a memory latency per 16 KB: 32 KB in flight
+		  // per CU, 3.9 TB/s over the chip.  Unconditional buffer loads (a lane past the end: an offset out of range, zeros it does not
+		  // count), so that the waits stay counted (s_waitcnt vmcnt(N)).
+			constexpr int kHistAhead = 4;
 			const int n8 = i1 / 8;
-			for (int ib = i0 / 8; ib < n8; ib += 1024)
-			{ // (wave-uniform trip count: lossy_hist_add votes across the wave)
-				const int i = ib + tid;
-				const bool in = i < n8;
-				lossy_v4u v = {0, 0, 0, 0};
-				if (in)
-					v = *reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(tmp + (size_t)i * 8);
-				const uint32_t bins[8] = {(v.x & 0xffffu) >> 2, v.x >> 18, (v.y & 0xffffu) >> 2, v.y >> 18, (v.z & 0xffffu) >> 2, v.z >> 18, (v.w & 0xffffu) >> 2, v.w >> 18};
-				lossy_hist_add8(lh, bins, in);
+			const uint32_t bytes = (uint32_t)n8 * 16u; // (s < 2^27 pixels: lossy_state_create)
+			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(sp.tmp), 0, (int)bytes, 0x00020000);
+			lossy_v4u q[kHistAhead];
+			int ib = i0 / 8;
+#pragma unroll
+			for (int a = 0; a < kHistAhead; ++a)
+			{ // (in this order, as the loop asks again: the wait at its top is one instruction for both ways in)
+				q[a] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(ib + a * 1024 + tid) * 16u, 0, 0);
+				__builtin_amdgcn_sched_barrier(0);
+			}
+			for (; ib < n8; ib += 1024 * kHistAhead)
+			{ // (wave-uniform trip counts: lossy_hist_add8 votes across the wave)
+#pragma unroll
+				for (int a = 0; a < kHistAhead; ++a)
+				{ // (a round past the end: no lane is `in`, nothing is counted)
+					const lossy_v4u v = q[a];
+					const bool in = ib + a * 1024 + tid < n8;
+					uint32_t bins[8] = {(v.x & 0xffffu) >> 2, v.x >> 18, (v.y & 0xffffu) >> 2, v.y >> 18, (v.z & 0xffffu) >> 2, v.z >> 18, (v.w & 0xffffu) >> 2, v.w >> 18};
+					// the slot is asked for again when the pixels in it have become bins (here, not where a bin is first used - the empty asm pins
+					// that): asked for earlier, old and new are alive together and the compiler rotates the slots through a fifth, with copies at
+					// the top of the loop - after waiting for every load
+#pragma unroll
+					for (int k = 0; k < 8; ++k)
+						asm volatile("" : "+v"(bins[k]));
+					__builtin_amdgcn_sched_barrier(0);
+					q[a] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(ib + (a + kHistAhead) * 1024 + tid) * 16u, 0, 0);
+					__builtin_amdgcn_sched_barrier(0);
+					lossy_hist_add8(lh, bins, in);
+				}
 			}
 		}
 		else
 			for (int i = i0 + tid; i < i1; i += 1024) // (frames whose lossy part is not a multiple of 8 pixels: one pixel per lane)
 				atomicAdd(&lh[tmp[i] >> 2], 1u);
 		__syncthreads();
-		for (int i = tid; i < 16384; i += 1024)
-			if (lh[i])
-				__hip_atomic_fetch_add(&hist[i], lh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (!lossy_last_arriver(sp.tickets, gridDim.x, &lh[0])) // (the private histogram has been merged: its first word is free)
-			return;
-		// mode: thread t looks at bins t, t + 1024, ... (coalesced: these are agent-scope loads, each one goes to L2 - 16 strided
-		// loads per thread cost 10 us), ascending, strict > keeps the lowest bin; then a tree over the threads on (count, bin)
+		uint32_t v16[16];
+		const bool alone = gridDim.x == 1; // the workgroup has the whole frame: its private histogram IS the frame's (nothing to merge, nothing to clear)
+		if (alone)
+		{
+#pragma unroll
+			for (int k = 0; k < 16; ++k)
+				v16[k] = lh[k * 1024 + tid];
+		}
+		else
+		{
+			for (int i = tid; i < 16384; i += 1024)
+				if (lh[i])
+					__hip_atomic_fetch_add(&hist[i], lh[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (!lossy_last_arriver(sp.tickets, gridDim.x, &lh[0])) // (the private histogram has been merged: its first word is free)
+				return;
+			// thread t looks at bins t, t + 1024, ... (coalesced: these are agent-scope loads, each one goes to L2 - 16 strided loads per thread cost 10 us)
+#pragma unroll
+			for (int k = 0; k < 16; ++k)
+				v16[k] = __hip_atomic_load(&hist[k * 1024 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		// mode: ascending, strict > keeps the lowest bin; then a tree over the threads on (count, bin)
 		uint32_t *best_v = lh, *best_i = lh + 1024;
 		uint32_t bv = 0, bi = 0;
-		uint32_t v16[16];
-#pragma unroll
-		for (int k = 0; k < 16; ++k)
-			v16[k] = __hip_atomic_load(&hist[k * 1024 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
 		for (int k = 0; k < 16; ++k)
 		{
-			hist[k * 1024 + tid] = 0; // ready for the next frame (the histogram is cleared once, when the state is created)
+			if (!alone)
+				hist[k * 1024 + tid] = 0; // ready for the next frame (the histogram is cleared once, when the state is created)
 			if (k == 0 || v16[k] > bv)
 			{
 				bv = v16[k];
@@ -1524,6 +1559,9 @@ namespace rir
 #ifndef RIR_LOSSY_CONST_DEPTH
 #define RIR_LOSSY_CONST_DEPTH 4
 #endif
+#ifndef RIR_LOSSY_CONST_PIN_STEPS
+#define RIR_LOSSY_CONST_PIN_STEPS 1
+#endif
 	constexpr int kConstDepth = RIR_LOSSY_CONST_DEPTH; // frames in flight per thread (4, 8 and 12 measure the same: instruction issue, not what is in flight, bounds the kernel)
 	// NP pairs of pixels per thread (4: one 16-byte access per thread, frame and array, as the resident kernel; 2; 1).  Nobody waits for anybody
 	// here, so a stream may be cut as finely as pays: with 8 pixels per thread a 640x512 stream is 640 waves on the chip's 1 024 SIMDs - each
@@ -1585,40 +1623,40 @@ namespace rir
 		return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, RIR_LOSSY_BUF_FLAGS);
 	}
 	template <int NP>
-	__device__ __forceinline__ PxN<NP> buf_ldn(__amdgpu_buffer_rsrc_t r, uint32_t off)
-	{
+	__device__ __forceinline__ PxN<NP> buf_ldn(__amdgpu_buffer_rsrc_t r, uint32_t off, uint32_t soff = 0u)
+	{ // soff: a wave-uniform offset (a scalar register of the instruction)
 		PxN<NP> x;
 		if constexpr (NP == 4)
 		{
-			const lossy_v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+			const lossy_v4u v = __builtin_amdgcn_raw_buffer_load_b128(r, off, soff, 0);
 			x.d[0] = v.x, x.d[1] = v.y, x.d[2] = v.z, x.d[3] = v.w;
 		}
 		else if constexpr (NP == 2)
 		{
-			const lossy_v2u_b v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+			const lossy_v2u_b v = __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0);
 			x.d[0] = v.x, x.d[1] = v.y;
 		}
 		else
-			x.d[0] = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+			x.d[0] = __builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0);
 		return x;
 	}
 	template <int NP>
-	__device__ __forceinline__ void buf_stn(const PxN<NP> &x, __amdgpu_buffer_rsrc_t r, uint32_t off)
+	__device__ __forceinline__ void buf_stn(const PxN<NP> &x, __amdgpu_buffer_rsrc_t r, uint32_t off, uint32_t soff = 0u)
 	{
 		if constexpr (NP == 4)
 		{
 			lossy_v4u v;
 			v.x = x.d[0], v.y = x.d[1], v.z = x.d[2], v.w = x.d[3];
-			__builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b128(v, r, off, soff, 0);
 		}
 		else if constexpr (NP == 2)
 		{
 			lossy_v2u_b v;
 			v.x = x.d[0], v.y = x.d[1];
-			__builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b64(v, r, off, soff, 0);
 		}
 		else
-			__builtin_amdgcn_raw_buffer_store_b32(x.d[0], r, off, 0, 0);
+			__builtin_amdgcn_raw_buffer_store_b32(x.d[0], r, off, soff, 0);
 	}
 
 	// lossy_pixel_pair without its wave-uniform branches (compile-time: a running average or none, the addLoss variant or not; run time, as
@@ -1629,8 +1667,10 @@ namespace rir
 		uint32_t n_after, magic;			 // images in the running average after this frame, lossy_div_magic of it
 		uint32_t full_mask, full_one2;		 // ring full: 0xffffffff / 0x00010001, else 0 / 0
 		uint32_t ra_mask;					 // this stream keeps a running average (a launch built for one may hold streams without)
+		uint32_t mid_magic, mid_shift;		 // MID: sum / n_after as umulhi(sum << mid_shift, mid_magic) - n_after == 1 included, no branch
 	};
-	template <bool RA_ON, bool ADD_LOSS>
+	// MID: a frame in the middle of a group - the ring is full (and stays so), see lossy_const_run_kernel
+	template <bool RA_ON, bool ADD_LOSS, bool MID = false>
 	__device__ __forceinline__ void const_pixel_pair(const ConstPairConsts &c, uint32_t v2, uint32_t old2, uint32_t last2, uint32_t &ref2, uint32_t &sum_lo, uint32_t &sum_hi,
 													 uint32_t &cc2, uint32_t &cv2, uint32_t &t_in2, uint32_t &out2)
 	{
@@ -1648,11 +1688,14 @@ namespace rir
 		{
 			lossy_u16x2 cc = lp2(cc2);
 			// what leaves the sum when the ring is full: the constant value while its stretch lasts, else the ring's oldest image
-			const uint32_t sel = lossy_bfi(lossy_nz_mask(cc), cv2, old2) & c.full_mask;
-			cc = __builtin_elementwise_sub_sat(cc, lp2(c.full_one2));
+			uint32_t sel = lossy_bfi(lossy_nz_mask(cc), cv2, old2);
+			if (!MID)
+				sel &= c.full_mask;
+			cc = __builtin_elementwise_sub_sat(cc, lp2(MID ? 0x00010001u : c.full_one2));
 			const uint32_t t_lo = lu1(t) & 0xffffu, t_hi = lu1(t) >> 16;
 			const uint32_t sm_lo = sum_lo + t_lo - (sel & 0xffffu), sm_hi = sum_hi + t_hi - (sel >> 16);
-			const uint32_t q = lossy_div(sm_lo, c.magic) | (lossy_div(sm_hi, c.magic) << 16);
+			const uint32_t q = MID ? (__umulhi(sm_lo << c.mid_shift, c.mid_magic) | (__umulhi(sm_hi << c.mid_shift, c.mid_magic) << 16))
+								   : (lossy_div(sm_lo, c.magic) | (lossy_div(sm_hi, c.magic) << 16));
 			sum_lo = (NM & 0xffffu) ? __umul24(t_lo, c.n_after) : sm_lo;
 			sum_hi = (NM >> 16) ? __umul24(t_hi, c.n_after) : sm_hi;
 			out2 = lossy_bfi(NM, lu1(t), lossy_bfi(c.ra_mask, q, ref2));
@@ -1713,7 +1756,7 @@ namespace rir
 		typedef PxN<NP> Px;
 		__shared__ unsigned int sh_flag;
 		__shared__ long long red[4][6];
-		__shared__ uint32_t sh_bg[kLossyConstMaxFrames];
+		__shared__ __attribute__((aligned(16))) uint32_t sh_bg[kLossyConstMaxFrames + 8];
 		const int tid = threadIdx.x, b = blockIdx.x, stream = blockIdx.y, nb = gridDim.x;
 		const bool ok = lossy_const_precondition(table, nstreams, poison, &sh_flag) && as_global(table + stream)->nsteps <= kLossyConstMaxFrames;
 		if (b == 0 && stream == 0 && tid == 0)
@@ -1818,13 +1861,15 @@ namespace rir
 			const int n_after = ra > 0 ? (count == ra ? ra : count + 1) : 0;
 			pc.n_after = (uint32_t)n_after, pc.magic = lossy_div_magic(n_after), pc.n2 = (uint32_t)n_after * 0x10001u;
 			pc.full_mask = (ra > 0 && count == ra) ? 0xffffffffu : 0u, pc.full_one2 = pc.full_mask & 0x00010001u;
+			pc.mid_magic = n_after > 1 ? pc.magic : 0x80000000u, pc.mid_shift = n_after > 1 ? 0u : 1u; // (n_after == 1: sum * 2 * 2^31 >> 32)
 		};
 		ring_consts();
 		const int tail0 = n > kLossyConstTail ? n - kLossyConstTail : 0;
 		const int ring_from = n - ra; // frames from here on are in the ring after the group
 		uint64_t out_p = (uint64_t)rp.out;
 		// where a frame's input goes in the ring: the slot after the newest image - one further per frame, full ring or not
-		uint64_t wr_p = ring0 + (uint64_t)((head + (count == ra ? 0 : count)) % (ra > 0 ? ra : 1)) * ring_bytes;
+		int wr_slot = (head + (count == ra ? 0 : count)) % (ra > 0 ? ra : 1);
+		uint64_t wr_p = ring0 + (uint64_t)wr_slot * ring_bytes;
 		auto step = [&](int k, Px &Vj, Px &Oj) {
 			const Px v = Vj;
 			Px old = Oj;
@@ -1870,6 +1915,7 @@ namespace rir
 				buf_stn<NP>(t, lossy_rsrc((const void *)wr_p, (ra > 0 && k >= ring_from) ? s_bytes : 0u), off_lossy);
 				const uint64_t nxt = wr_p + ring_bytes;
 				wr_p = nxt == ring_end ? ring0 : nxt;
+				wr_slot = nxt == ring_end ? 0 : wr_slot + 1;
 				if (count != ra)
 				{ // (only while the ring fills: the constants of the running average move)
 					++count;
@@ -1877,9 +1923,111 @@ namespace rir
 				}
 			}
 		};
+		// ---- the frames in the MIDDLE of a group: [mid0, mid1), both multiples of D ----
+		// From frame max(ra, 1) on the ring is full and what leaves the average is an input frame of the group; before frame n - 40 no frame
+		// leaves sums, before frame n - ra none is written to the ring; four frames ahead there still is a frame.  For those frames - all but
+		// ~50 of a group of 1 000 - every wave-uniform choice of step() is known, and what is left of the scalar side of a frame is ONE
+		// addition: the three arrays of the frame (input four frames ahead, the input `ra` frames before that one, output) are one
+		// descriptor each for the whole phase - bases shifted so that the same scalar offset k * frame_bytes serves all three - and the
+		// frame's background comes four to a 16-byte LDS read.  (step() above is ~60 scalar and ~60 vector instructions per frame and pair,
+		// and a wave issues one instruction at a time: the scalar half of that was half of the kernel's time.)  Same values, bit for bit.
+		int mid0 = ((ra > 1 ? ra : 1) + D - 1) / D * D, mid1 = mid0;
+		{
+			const int end = (tail0 < n - ra ? tail0 : n - ra);
+			// every offset of the phase below 2^31, the mark of a lane without a pixel (RIR_LOSSY_OOB)
+			const bool small = (uint64_t)(n + ra + D) * frame_bytes < 0x80000000ull;
+			if (small && end > mid0)
+				mid1 = mid0 + (end - mid0) / D * D;
+		}
+		auto middle = [&]() {
+			const uint32_t fb = (uint32_t)frame_bytes;
+			const uint64_t group_bytes = (uint64_t)n * frame_bytes;
+			const __amdgpu_buffer_rsrc_t rs_in = lossy_rsrc((const void *)(in0 + (uint64_t)D * frame_bytes), (uint32_t)(group_bytes - (uint64_t)D * frame_bytes));
+			const __amdgpu_buffer_rsrc_t rs_old = lossy_rsrc((const void *)(in0 + (uint64_t)D * frame_bytes - ra_back),
+															 ra > 0 ? (uint32_t)(group_bytes - (uint64_t)D * frame_bytes + ra_back) : 0u);
+			const __amdgpu_buffer_rsrc_t rs_out = lossy_rsrc((const void *)(uint64_t)rp.out, (uint32_t)group_bytes);
+			uint32_t so = (uint32_t)mid0 * fb;
+			uint32_t bgq[D], bgn[D];
+			auto backgrounds = [&](int k) { // of frames k .. k + D - 1 (k a multiple of D; the array is padded)
+				if constexpr (D == 4)
+				{
+					const lossy_v4u q = *reinterpret_cast<const lossy_v4u *>(&sh_bg[k]);
+					bgn[0] = q.x, bgn[1] = q.y, bgn[2] = q.z, bgn[3] = q.w;
+				}
+				else
+				{
+#pragma unroll
+					for (int j = 0; j < D; ++j)
+						bgn[j] = sh_bg[k + j];
+				}
+			};
+			backgrounds(mid0);
+			V[D - 1] = last; // (frame mid0 + D - 1, which step() has asked for, is asked for again by the first step below)
+			for (int k0 = mid0; k0 < mid1; k0 += D)
+			{
+#pragma unroll
+				for (int j = 0; j < D; ++j)
+					bgq[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)bgn[j]);
+				backgrounds(k0 + D); // (k0 + D <= mid1 < n)
+#pragma unroll
+				for (int j = 0; j < D; ++j)
+				{
+					const Px v = V[j];
+					Px old = O[j];
+					if (RA_ON)
+					{
+#pragma unroll
+						for (int p = 0; p < NP; ++p)
+							old.d[p] = lu1(__builtin_elementwise_sub_sat(lp2(old.d[p]), lp2(pc.min2)));
+					}
+					pc.bg2 = lossy_both(bgq[j]);
+					const Px before = V[(j + D - 1) % D]; // the frame before this one: still in its slot
+					Px ov;
+#pragma unroll
+					for (int p = 0; p < NP; ++p)
+					{
+						const_pixel_pair<RA_ON, ADD_LOSS, true>(pc, v.d[p], old.d[p], before.d[p], ref.d[p], sum[2 * p], sum[2 * p + 1], cc.d[p], cv.d[p], t.d[p], o.d[p]);
+						ov.d[p] = lossy_bfi(lossy_mask, o.d[p], v.d[p]);
+					}
+					buf_stn<NP>(ov, rs_out, off_in, so);
+					// A slot's next frame is asked for when nothing needs the frame in it any more - in the step AFTER its own, which compares with
+					// it (lastDL): asked for earlier the two are alive together, and the compiler copies all D slots out of the way at the top of
+					// the iteration, after waiting for every one of them.  D - 1 frames are in flight.
+					if (RA_ON)
+						O[j] = buf_ldn<NP>(rs_old, off_lossy, so);
+					V[(j + D - 1) % D] = buf_ldn<NP>(rs_in, off_in, so - fb);
+					so += fb;
+#if RIR_LOSSY_CONST_PIN_STEPS
+					// a frame's instructions stay together: left alone, the scheduler gathers the loads of two or three frames at the end of the
+					// iteration, and its top then waits for loads issued 40 instructions ago
+					__builtin_amdgcn_sched_barrier(0);
+#endif
+				}
+			}
+			// step()'s running state as mid1 - mid0 steps would have left it
+			last = V[D - 1];
+			V[D - 1] = buf_ldn<NP>(rs_in, off_in, so - fb);
+			const int nmid = mid1 - mid0;
+			kf = mid1 + D;
+			req_in = in0 + (uint64_t)kf * frame_bytes;
+			out_p = (uint64_t)rp.out + (uint64_t)mid1 * frame_bytes;
+			if (RA_ON && ra > 0)
+			{
+				wr_slot = (wr_slot + nmid) % ra;
+				wr_p = ring0 + (uint64_t)wr_slot * ring_bytes;
+			}
+			bg_next = sh_bg[mid1];
+		};
 		int k0 = 0;
 		for (; k0 + D <= n; k0 += D)
 		{ // whole iterations of D unconditional steps
+			if (k0 == mid0 && mid1 > mid0)
+			{
+				middle();
+				k0 = mid1;
+				if (k0 + D > n)
+					break;
+			}
 #pragma unroll
 			for (int j = 0; j < D; ++j)
 				step(k0 + j, V[j], O[j]);

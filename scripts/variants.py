@@ -44,7 +44,7 @@ def build(specs):
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise SystemExit("variant %s failed" % name)
-        objs = [obj if f == unit + ".o" else os.path.join(objdir, f) for f in sorted(os.listdir(objdir)) if f.endswith(".o")]
+        objs = [obj if f == unit + ".o" else os.path.join(objdir, f) for f in sorted(os.listdir(objdir)) if f.endswith(".o") and not f.endswith(".hooks.o")]
         subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.join(VDIR, name + ".so")] + objs + ["-ldl", "-lpthread"])
         os.remove(obj)
         print("built", name)
