@@ -10,6 +10,7 @@
 // (a run's backgrounds come from one histogram launch per group of frames: they depend on the input only).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "lossy_kernels.h"
 #include "resident_device.h"
@@ -120,40 +121,42 @@ namespace rir
 	// when at least half of the lanes start there, every lane counts its pixels in those four bins into four 16-bit fields, ONE
 	// reduction over the wave adds the fields up and four lanes add the totals - 4 atomics instead of ~500; pixels outside the four
 	// bins, and waves on spread data (one ballot to find out), use plain atomics.  Same counts either way.
-	__device__ __forceinline__ void lossy_hist_add8(uint32_t *lh, const uint32_t *bins, bool in)
+	// offs: the pixels' bins as BYTE offsets into the histogram (bin * 4: one mask per pixel, v & 0xfffc, and no shift at the atomic)
+	__device__ __forceinline__ void lossy_hist_add8(uint32_t *lh, const uint32_t *offs, bool in)
 	{
 		const unsigned long long votes = __ballot(in);
 		if (!votes)
 			return;
 		const int lane = (int)(threadIdx.x & 63);
-		const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)bins[0], __builtin_ctzll(votes)) & ~3u;
-		if (__builtin_popcountll(__ballot(in && bins[0] - base < 4u)) * 2 >= __builtin_popcountll(votes))
+		const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)offs[0], __builtin_ctzll(votes)) & ~15u; // (four bins: 16 bytes)
+		auto word = [&](uint32_t off) { return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lh) + off); };
+		if (__builtin_popcountll(__ballot(in && offs[0] - base < 16u)) * 2 >= __builtin_popcountll(votes))
 		{
 			unsigned long long packed = 0;
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
 			{
-				const uint32_t rel = bins[k] - base; // (below the base: wraps to a large number)
-				packed += (in && rel < 4u) ? 1ull << (16 * (rel & 3u)) : 0ull;
+				const uint32_t rel = offs[k] - base; // (below the base: wraps to a large number)
+				packed += (in && rel < 16u) ? 1ull << (4 * (rel & 12u)) : 0ull;
 			}
 			const unsigned long long tot = (unsigned long long)lossy_wave_sum((long long)packed); // (a wave holds 512 pixels: no field overflows)
 			if (lane < 4)
 			{
 				const uint32_t c = (uint32_t)(tot >> (16 * lane)) & 0xffffu;
 				if (c)
-					atomicAdd(&lh[base + lane], c);
+					atomicAdd(word(base + 4u * (uint32_t)lane), c);
 			}
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
-				if (in && bins[k] - base >= 4u)
-					atomicAdd(&lh[bins[k]], 1u);
+				if (in && offs[k] - base >= 16u)
+					atomicAdd(word(offs[k]), 1u);
 		}
 		else
-		{
+		{ // spread data: eight atomics, none under a branch (a lane past the end adds 0 - to bin 0, where its zero pixels point)
+			const uint32_t one = in ? 1u : 0u;
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
-				if (in)
-					atomicAdd(&lh[bins[k]], 1u);
+				atomicAdd(word(offs[k]), one);
 		}
 	}
 
@@ -200,7 +203,7 @@ namespace rir
 				{ // (a round past the end: no lane is `in`, nothing is counted)
 					const lossy_v4u v = q[a];
 					const bool in = ib + a * 1024 + tid < n8;
-					uint32_t bins[8] = {(v.x & 0xffffu) >> 2, v.x >> 18, (v.y & 0xffffu) >> 2, v.y >> 18, (v.z & 0xffffu) >> 2, v.z >> 18, (v.w & 0xffffu) >> 2, v.w >> 18};
+					uint32_t bins[8] = {v.x & 0xfffcu, (v.x >> 16) & 0xfffcu, v.y & 0xfffcu, (v.y >> 16) & 0xfffcu, v.z & 0xfffcu, (v.z >> 16) & 0xfffcu, v.w & 0xfffcu, (v.w >> 16) & 0xfffcu}; // (as byte offsets)
 					// the slot is asked for again when the pixels in it have become bins (here, not where a bin is first used - the empty asm pins
 					// that): asked for earlier, old and new are alive together and the compiler rotates the slots through a fifth, with copies at
 					// the top of the loop - after waiting for every load
@@ -1747,6 +1750,33 @@ namespace rir
 		return (unsigned long long)val;
 	}
 
+	// The same sums over ONE WAVE, left in LDS (dst: the six words of this wave and frame: fg sum d, fg sum d2, fg count, bg sum d, bg sum d2,
+	// bg count) - no barrier: the frames at the end of a group each have their own words, and the workgroup adds its waves up once, after
+	// the last frame.
+	template <int NP>
+	__device__ __noinline__ void const_frame_sums_wave(PxN<NP> v, PxN<NP> o, uint32_t background, bool lossy, int subtract_min, uint32_t mn, long long *dst)
+	{
+		constexpr int PX = 2 * NP;
+		int32_t fd = 0, fn = 0, bd = 0, bn = 0;
+		long long f2 = 0, b2 = 0;
+#pragma unroll
+		for (int q = 0; q < PX; ++q)
+		{
+			const uint32_t tq = subtract_min ? sub_min(v.get(q), mn) : v.get(q);
+			const int32_t d = lossy ? abs((int32_t)tq - (int32_t)o.get(q)) : 0;
+			const int32_t d2 = (int32_t)((uint32_t)d * (uint32_t)d);
+			const int one = lossy ? 1 : 0;
+			if (v.get(q) > background)
+				fd += d, f2 += d2, fn += one;
+			else
+				bd += d, b2 += d2, bn += one;
+		}
+		const uint32_t wfd = lossy_wave_sum32((uint32_t)fd), wbd = lossy_wave_sum32((uint32_t)bd), wn = lossy_wave_sum32((uint32_t)fn | ((uint32_t)bn << 16));
+		const long long wf2 = lossy_wave_sum(f2), wb2 = lossy_wave_sum(b2);
+		if ((threadIdx.x & 63) == 0)
+			dst[0] = (long long)wfd, dst[1] = wf2, dst[2] = (long long)(wn & 0xffffu), dst[3] = (long long)wbd, dst[4] = wb2, dst[5] = (long long)(wn >> 16);
+	}
+
 	template <int NP, bool RA_ON, bool ADD_LOSS>
 	__global__ __launch_bounds__(256) void lossy_const_run_kernel(const LossyRun *__restrict__ table, int nstreams, unsigned int *__restrict__ ok_word,
 																  const unsigned int *__restrict__ poison)
@@ -1757,6 +1787,7 @@ namespace rir
 		__shared__ unsigned int sh_flag;
 		__shared__ long long red[4][6];
 		__shared__ __attribute__((aligned(16))) uint32_t sh_bg[kLossyConstMaxFrames + 8];
+		__shared__ long long red_tail[kLossyConstTail][4][6]; // the sums of the last frames of a group, per wave (const_frame_sums_wave)
 		const int tid = threadIdx.x, b = blockIdx.x, stream = blockIdx.y, nb = gridDim.x;
 		const bool ok = lossy_const_precondition(table, nstreams, poison, &sh_flag) && as_global(table + stream)->nsteps <= kLossyConstMaxFrames;
 		if (b == 0 && stream == 0 && tid == 0)
@@ -1963,6 +1994,55 @@ namespace rir
 			};
 			backgrounds(mid0);
 			V[D - 1] = last; // (frame mid0 + D - 1, which step() has asked for, is asked for again by the first step below)
+			const __amdgpu_buffer_rsrc_t rs_ring_on = lossy_rsrc((const void *)ring0, (uint32_t)((uint64_t)(ra > 0 ? ra : 0) * ring_bytes));
+			const __amdgpu_buffer_rsrc_t rs_ring_off = lossy_rsrc((const void *)ring0, 0u);
+			uint32_t so_ring = 0; // (set where the tail begins)
+			// One frame, slot j of the ring of registers.  TAIL: a frame of the group's end - it may leave sums (per wave, in LDS), it may go into
+			// the ring of images, and the frame D ahead of it may not exist.
+			auto frame = [&](auto tail_tag, int j, int k) {
+				constexpr bool TAIL = decltype(tail_tag)::value;
+				const Px v = V[j];
+				Px old = O[j];
+				if (RA_ON)
+				{
+#pragma unroll
+					for (int p = 0; p < NP; ++p)
+						old.d[p] = lu1(__builtin_elementwise_sub_sat(lp2(old.d[p]), lp2(pc.min2)));
+				}
+				if (TAIL && k >= tail0)
+					const_frame_sums_wave<NP>(v, o, bgq[j], lossy, st.subtract_min, st.min, &red_tail[k - tail0][tid >> 6][0]);
+				pc.bg2 = lossy_both(bgq[j]);
+				const Px before = V[(j + D - 1) % D]; // the frame before this one: still in its slot
+				Px ov;
+#pragma unroll
+				for (int p = 0; p < NP; ++p)
+				{
+					const_pixel_pair<RA_ON, ADD_LOSS, true>(pc, v.d[p], old.d[p], before.d[p], ref.d[p], sum[2 * p], sum[2 * p + 1], cc.d[p], cv.d[p], t.d[p], o.d[p]);
+					ov.d[p] = lossy_bfi(lossy_mask, o.d[p], v.d[p]);
+				}
+				buf_stn<NP>(ov, rs_out, off_in, so);
+				if (TAIL && RA_ON)
+				{ // the ring as it must be after the group: the last `ra` inputs (less the minimum), each in the slot after the one before
+					buf_stn<NP>(t, k >= ring_from ? rs_ring_on : rs_ring_off, off_lossy, so_ring);
+					so_ring += (uint32_t)ring_bytes;
+					so_ring = so_ring >= (uint32_t)((uint64_t)(ra > 0 ? ra : 1) * ring_bytes) ? 0u : so_ring;
+				}
+				if (TAIL && k == n - 1)
+					last = v;
+				// A slot's next frame is asked for when nothing needs the frame in it any more - in the step AFTER its own, which compares with
+				// it (lastDL): asked for earlier the two are alive together, and the compiler copies all D slots out of the way at the top of
+				// the iteration, after waiting for every one of them.  D - 1 frames are in flight.
+				const uint32_t off_o = !TAIL || k + D < n ? off_lossy : RIR_LOSSY_OOB, off_v = !TAIL || k - 1 + D < n ? off_in : RIR_LOSSY_OOB;
+				if (RA_ON)
+					O[j] = buf_ldn<NP>(rs_old, off_o, so);
+				V[(j + D - 1) % D] = buf_ldn<NP>(rs_in, off_v, so - fb);
+				so += fb;
+#if RIR_LOSSY_CONST_PIN_STEPS
+				// a frame's instructions stay together: left alone, the scheduler gathers the loads of two or three frames at the end of the
+				// iteration, and its top then waits for loads issued 40 instructions ago
+				__builtin_amdgcn_sched_barrier(0);
+#endif
+			};
 			for (int k0 = mid0; k0 < mid1; k0 += D)
 			{
 #pragma unroll
@@ -1971,72 +2051,55 @@ namespace rir
 				backgrounds(k0 + D); // (k0 + D <= mid1 < n)
 #pragma unroll
 				for (int j = 0; j < D; ++j)
-				{
-					const Px v = V[j];
-					Px old = O[j];
-					if (RA_ON)
-					{
-#pragma unroll
-						for (int p = 0; p < NP; ++p)
-							old.d[p] = lu1(__builtin_elementwise_sub_sat(lp2(old.d[p]), lp2(pc.min2)));
-					}
-					pc.bg2 = lossy_both(bgq[j]);
-					const Px before = V[(j + D - 1) % D]; // the frame before this one: still in its slot
-					Px ov;
-#pragma unroll
-					for (int p = 0; p < NP; ++p)
-					{
-						const_pixel_pair<RA_ON, ADD_LOSS, true>(pc, v.d[p], old.d[p], before.d[p], ref.d[p], sum[2 * p], sum[2 * p + 1], cc.d[p], cv.d[p], t.d[p], o.d[p]);
-						ov.d[p] = lossy_bfi(lossy_mask, o.d[p], v.d[p]);
-					}
-					buf_stn<NP>(ov, rs_out, off_in, so);
-					// A slot's next frame is asked for when nothing needs the frame in it any more - in the step AFTER its own, which compares with
-					// it (lastDL): asked for earlier the two are alive together, and the compiler copies all D slots out of the way at the top of
-					// the iteration, after waiting for every one of them.  D - 1 frames are in flight.
-					if (RA_ON)
-						O[j] = buf_ldn<NP>(rs_old, off_lossy, so);
-					V[(j + D - 1) % D] = buf_ldn<NP>(rs_in, off_in, so - fb);
-					so += fb;
-#if RIR_LOSSY_CONST_PIN_STEPS
-					// a frame's instructions stay together: left alone, the scheduler gathers the loads of two or three frames at the end of the
-					// iteration, and its top then waits for loads issued 40 instructions ago
-					__builtin_amdgcn_sched_barrier(0);
-#endif
-				}
+					frame(std::false_type{}, j, k0 + j);
 			}
-			// step()'s running state as mid1 - mid0 steps would have left it
-			last = V[D - 1];
-			V[D - 1] = buf_ldn<NP>(rs_in, off_in, so - fb);
-			const int nmid = mid1 - mid0;
-			kf = mid1 + D;
-			req_in = in0 + (uint64_t)kf * frame_bytes;
-			out_p = (uint64_t)rp.out + (uint64_t)mid1 * frame_bytes;
-			if (RA_ON && ra > 0)
+			// ---- the frames from mid1 to the end of the group: the same body with the three things a frame of the end may have to do ----
+			so_ring = (uint32_t)((uint64_t)((wr_slot + (mid1 - mid0)) % (ra > 0 ? ra : 1)) * ring_bytes); // (the slot frame mid1 goes to: one further per frame)
+			for (int k0 = mid1; k0 < n; k0 += D)
 			{
-				wr_slot = (wr_slot + nmid) % ra;
-				wr_p = ring0 + (uint64_t)wr_slot * ring_bytes;
+#pragma unroll
+				for (int j = 0; j < D; ++j)
+					bgq[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)bgn[j]);
+				backgrounds(k0 + D); // (the array is padded by D)
+#pragma unroll
+				for (int j = 0; j < D; ++j)
+					if (k0 + j < n)
+						frame(std::true_type{}, j, k0 + j);
 			}
-			bg_next = sh_bg[mid1];
+			// the workgroup's sums of the frames of the end: its four waves added up, where step() leaves them
+			__syncthreads();
+			if (tid < kLossyConstTail * 4 && tail0 + tid / 4 < n)
+			{
+				const int f = tid / 4, wd = tid & 3; // words: fg count << 32 | fg sum d,  fg sum d2,  bg count << 32 | bg sum d,  bg sum d2
+				const int a = wd == 0 ? 0 : wd == 1 ? 1 : wd == 2 ? 3 : 4;
+				long long val = red_tail[f][0][a] + red_tail[f][1][a] + red_tail[f][2][a] + red_tail[f][3][a];
+				if (wd == 0 || wd == 2)
+					val |= (red_tail[f][0][a + 2] + red_tail[f][1][a + 2] + red_tail[f][2][a + 2] + red_tail[f][3][a + 2]) << 32;
+				as_global(rp.partials)[((size_t)(1 + f) * nb + b) * 4 + wd] = (unsigned long long)val;
+			}
 		};
 		int k0 = 0;
+		bool done = false;
 		for (; k0 + D <= n; k0 += D)
 		{ // whole iterations of D unconditional steps
 			if (k0 == mid0 && mid1 > mid0)
 			{
-				middle();
-				k0 = mid1;
-				if (k0 + D > n)
-					break;
+				middle(); // (all the frames from mid0 on)
+				done = true;
+				break;
 			}
 #pragma unroll
 			for (int j = 0; j < D; ++j)
 				step(k0 + j, V[j], O[j]);
 		}
 		// up to D - 1 left-over frames (the slot rotation stays aligned)
+		if (!done)
+		{
 #pragma unroll
-		for (int j = 0; j < D - 1; ++j)
-			if (k0 + j < n)
-				step(k0 + j, V[j], O[j]);
+			for (int j = 0; j < D - 1; ++j)
+				if (k0 + j < n)
+					step(k0 + j, V[j], O[j]);
+		}
 		if (lossy)
 		{
 			stn<NP>(refT, ig, ref);
