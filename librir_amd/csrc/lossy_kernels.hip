@@ -1670,7 +1670,6 @@ namespace rir
 		uint32_t n_after, magic;			 // images in the running average after this frame, lossy_div_magic of it
 		uint32_t full_mask, full_one2;		 // ring full: 0xffffffff / 0x00010001, else 0 / 0
 		uint32_t ra_mask;					 // this stream keeps a running average (a launch built for one may hold streams without)
-		uint32_t mid_magic, mid_shift;		 // MID: sum / n_after as umulhi(sum << mid_shift, mid_magic) - n_after == 1 included, no branch
 	};
 	// MID: a frame in the middle of a group - the ring is full (and stays so), see lossy_const_run_kernel
 	template <bool RA_ON, bool ADD_LOSS, bool MID = false>
@@ -1697,8 +1696,8 @@ namespace rir
 			cc = __builtin_elementwise_sub_sat(cc, lp2(MID ? 0x00010001u : c.full_one2));
 			const uint32_t t_lo = lu1(t) & 0xffffu, t_hi = lu1(t) >> 16;
 			const uint32_t sm_lo = sum_lo + t_lo - (sel & 0xffffu), sm_hi = sum_hi + t_hi - (sel >> 16);
-			const uint32_t q = MID ? (__umulhi(sm_lo << c.mid_shift, c.mid_magic) | (__umulhi(sm_hi << c.mid_shift, c.mid_magic) << 16))
-								   : (lossy_div(sm_lo, c.magic) | (lossy_div(sm_hi, c.magic) << 16));
+			// (MID: n_after > 1 - lossy_const_run_kernel - the division is the multiplication, without lossy_div's branch)
+			const uint32_t q = MID ? (__umulhi(sm_lo, c.magic) | (__umulhi(sm_hi, c.magic) << 16)) : (lossy_div(sm_lo, c.magic) | (lossy_div(sm_hi, c.magic) << 16));
 			sum_lo = (NM & 0xffffu) ? __umul24(t_lo, c.n_after) : sm_lo;
 			sum_hi = (NM >> 16) ? __umul24(t_hi, c.n_after) : sm_hi;
 			out2 = lossy_bfi(NM, lu1(t), lossy_bfi(c.ra_mask, q, ref2));
@@ -1892,7 +1891,6 @@ namespace rir
 			const int n_after = ra > 0 ? (count == ra ? ra : count + 1) : 0;
 			pc.n_after = (uint32_t)n_after, pc.magic = lossy_div_magic(n_after), pc.n2 = (uint32_t)n_after * 0x10001u;
 			pc.full_mask = (ra > 0 && count == ra) ? 0xffffffffu : 0u, pc.full_one2 = pc.full_mask & 0x00010001u;
-			pc.mid_magic = n_after > 1 ? pc.magic : 0x80000000u, pc.mid_shift = n_after > 1 ? 0u : 1u; // (n_after == 1: sum * 2 * 2^31 >> 32)
 		};
 		ring_consts();
 		const int tail0 = n > kLossyConstTail ? n - kLossyConstTail : 0;
@@ -1967,7 +1965,7 @@ namespace rir
 			const int end = (tail0 < n - ra ? tail0 : n - ra);
 			// every offset of the phase below 2^31, the mark of a lane without a pixel (RIR_LOSSY_OOB)
 			const bool small = (uint64_t)(n + ra + D) * frame_bytes < 0x80000000ull;
-			if (small && end > mid0)
+			if (small && end > mid0 && ra != 1) // (ra == 1: an "average" of one image, no division - lossy_div's other branch: step() has it)
 				mid1 = mid0 + (end - mid0) / D * D;
 		}
 		auto middle = [&]() {
@@ -2125,31 +2123,38 @@ namespace rir
 		__shared__ double sd[kLossyConstSlots][2];
 		if (*as_global(ok_word) == 0u)
 			return;
-		const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+		const int tid = threadIdx.x;
 		RIR_GLOBAL(const LossyRun) *r = as_global(table + blockIdx.x);
 		RIR_GLOBAL(const unsigned long long) *partials = as_global(r->partials);
 		RIR_GLOBAL(LossyBudget) *bud = as_global(r->budget);
 		const int n = r->nsteps, s = r->s;
 		const int n_first0 = bud->n_first, n_win0 = bud->n_win, head0 = bud->head;
 		const int tail0 = n > kLossyConstTail ? n - kLossyConstTail : 0;
-		for (int slot = wave; slot < kLossyConstSlots; slot += 16)
+		// 16 lanes to a slot (a frame that left sums), each adds up a sixteenth of the workgroups' rows - independent loads, many in flight -
+		// and the sixteen are added within their row of the wave
 		{
+			const int slot = tid >> 4, part = tid & 15;
 			const int k = slot == 0 ? 0 : tail0 + slot - 1; // the frame of this slot
-			if (k >= n || (slot == 0 && tail0 == 0))
-				continue; // (slot 0 is only filled when frame 0 is not in the tail)
-			long long a[4] = {0, 0, 0, 0}; // fg d | n << 32 summed field-wise below
-			long long fd = 0, fn = 0, bd = 0, bn = 0;
-			for (int w = lane; w < nb; w += 64)
+			const bool live = slot < kLossyConstSlots && k < n && !(slot == 0 && tail0 == 0); // (slot 0 is only filled when frame 0 is not in the tail)
+			long long fd = 0, fn = 0, bd = 0, bn = 0, f2 = 0, b2 = 0;
+			if (live)
 			{
-				const unsigned long long w0 = partials[((size_t)slot * nb + w) * 4 + 0], w2 = partials[((size_t)slot * nb + w) * 4 + 2];
-				fd += (long long)(w0 & 0xffffffffull), fn += (long long)(w0 >> 32);
-				bd += (long long)(w2 & 0xffffffffull), bn += (long long)(w2 >> 32);
-				a[1] += (long long)partials[((size_t)slot * nb + w) * 4 + 1];
-				a[3] += (long long)partials[((size_t)slot * nb + w) * 4 + 3];
+				RIR_GLOBAL(const lossy_v4u) *rows = reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(partials + (size_t)slot * nb * 4);
+#pragma unroll 4
+				for (int w = part; w < nb; w += 16)
+				{
+					const lossy_v4u lo = rows[2 * w], hi = rows[2 * w + 1]; // words 0, 1 | 2, 3
+					fd += (long long)lo.x, fn += (long long)lo.y, f2 += (long long)(((unsigned long long)lo.w << 32) | lo.z);
+					bd += (long long)hi.x, bn += (long long)hi.y, b2 += (long long)(((unsigned long long)hi.w << 32) | hi.z);
+				}
 			}
-			fd = lossy_wave_sum(fd), fn = lossy_wave_sum(fn), bd = lossy_wave_sum(bd), bn = lossy_wave_sum(bn);
-			const long long f2 = lossy_wave_sum(a[1]), b2 = lossy_wave_sum(a[3]);
-			if (lane == 0)
+#pragma unroll
+			for (int d = 8; d >= 1; d >>= 1)
+			{ // (every lane takes part: __shfl_xor within 16 lanes)
+				fd += __shfl_xor(fd, d, 16), fn += __shfl_xor(fn, d, 16), bd += __shfl_xor(bd, d, 16), bn += __shfl_xor(bn, d, 16);
+				f2 += __shfl_xor(f2, d, 16), b2 += __shfl_xor(b2, d, 16);
+			}
+			if (live && part == 0)
 			{ // stdDev (h264.cpp:1993-2036), as lossy_budget: unsplit while the window is not full
 				const int n_win_k = n_win0 + k < 40 ? n_win0 + k : 40;
 				if (n_win_k < 40)

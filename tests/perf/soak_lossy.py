@@ -1,5 +1,5 @@
 """One-off soak: random parameters of the bounded-loss step, device stream operator against the oracle.
-    python tests/perf/soak_lossy.py [cases] [seed]"""
+    python tests/perf/soak_lossy.py [cases] [seed] [longest run, default 70 frames]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -8,6 +8,7 @@ from oracle.pyoracle import Oracle, OracleLossy
 O = Oracle()
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+nmax = int(sys.argv[3]) if len(sys.argv) > 3 else 70  # (the constant-budget kernel has three phases: a run of 45 + ring length frames or more goes through all of them)
 bad = 0
 const_offered = const_taken = 0
 for k in range(cases):
@@ -15,7 +16,7 @@ for k in range(cases):
     if rng.integers(0, 2):
         w = (w + 7) // 8 * 8  # (runs of frames - the resident and the constant-budget kernels - need whole groups of 8 pixels)
     hl = int(rng.integers(1, h + 1))
-    n = int(rng.integers(2, 70))
+    n = int(rng.integers(2, nmax))
     low, high = int(rng.integers(0, 12)), int(rng.integers(0, 8))
     sf = float(rng.choice([0, 0, 0, 0.5, 5, 20]))
     ra = int(rng.choice([0, 1, 2, 5, 32, 64, 100]))
