@@ -2515,7 +2515,11 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 		// frames per histogram launch (one 64 KB histogram slice per frame and stream).  A group costs four small launches beside its
 		// frames, so streams that may take the constant-budget form - 0.1 us per stream-frame - get groups four times as long (up to
 		// 512 MB of slices, allocated as needed; 32 streams x 200 frames: 64-frame groups 0.83 M frames/s, one group 1.2 M)
-		const int group = std::min(kLossyConstMaxFrames, std::max(1, (persistent ? (const_form ? 8192 : 2048) : 512) / nstreams));
+		int group = std::min(kLossyConstMaxFrames, std::max(1, (persistent ? (const_form ? 8192 : 2048) : 512) / nstreams));
+		// (the constant-budget kernel addresses a group's frames with 32-bit offsets below 2^31: groups of large frames are cut to fit -
+		// 64 = the longest ring, 8 = the most frames it keeps in flight; lossy_const_run_kernel decides for itself, this only keeps it fast)
+		if (const_form)
+			group = (int)std::max<long long>(1, std::min<long long>(group, 0x7fffffffll / ((long long)npx * 2) - 64 - 8));
 		const int ngroups = runs ? (nsteps + group - 1) / group : 0;
 		const size_t nfused = persistent ? 0 : runs ? (size_t)(nsteps + 1) * nstreams : (size_t)nsteps * nstreams, nbg = runs ? (size_t)nsteps * nstreams : 0,
 					 nhist = persistent ? 0 : nbg; // (the resident / constant-budget path takes its backgrounds straight from the runs' descriptions: no per-frame table)

@@ -374,6 +374,17 @@ if not args.quick:  # the same in calls of 1 000 frames (the call's fixed cost -
     ls1.step(s1_1000[:60], errors=False)
     c4["lossy_step_device_resident_fps_one_stream_1000_frame_calls"] = best_rate(lambda: ls1.step(s1_1000, errors=False), 1000)
     ls1.status()
+    # ... and the recording chain in its steady state - the stream stays open, as a recording keeps it (the key above creates and closes a
+    # stream inside the clock): loss step, then the packed encoder on what it leaves
+    pc1000 = D.PackedCodec(w, h, 1000, gop, device=dev)
+
+    def chain_1000():
+        o_, _, _ = ls1.step(s1_1000, errors=False)
+        pc1000.encode(o_)
+
+    chain_1000()
+    c4["lossy_then_encode_device_resident_fps_open_stream_1000_frame_calls"] = best_rate(chain_1000, 1000)
+    del pc1000
     ls1.close()
     os.environ["RIR_LOSSY_NO_CONST"] = "1"  # the general (resident) form on the same call, for comparison
     ls1 = D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32)
