@@ -128,6 +128,7 @@ namespace rir
 	// the group's background words (bit 40: a class may be empty), the streams' budget windows (NaN) and *d_poison (an earlier group of
 	// the call was not stepped) and do nothing unless everything is clear; *d_ok (zeroed by the caller) says which it was - the resident
 	// launch that follows reads it and leaves the group alone when it is 1 (launch_lossy_run's d_ok).
+	void lossy_const_force_pairs(int np); // 4, 2, 1: that many pairs of pixels per thread whatever the launch; anything else: chosen by lossy_const_pairs (test hook RIR_LOSSY_CONST_PAIRS)
 	int lossy_const_workgroups(int full, int nstreams); // workgroups of a stream in that launch: partials holds kLossyConstSlots x this many x 4 words per stream
 	// any_ra: some stream of the launch keeps a running average; add_loss: the addLoss variant of the decision (the same for all streams)
 	hipError_t launch_lossy_const(const LossyRun *d_table, int nstreams, int full, bool any_ra, bool add_loss, unsigned int *d_ok, const unsigned int *d_poison, hipStream_t st);

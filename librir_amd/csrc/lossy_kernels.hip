@@ -2357,18 +2357,12 @@ namespace rir
 	// the wave holds, ~80 vector instructions per pair - so a launch wants its pixels spread over 2-3 waves per SIMD and, beyond that, as many
 	// pixels per wave as possible: the largest of 4, 2, 1 pairs that still gives 2 500 waves (one 640x512 stream: 1 pair, 2 560 waves -
 	// 0.95 M frames/s against 0.85 M with 4 pairs; nine streams: 4 pairs, 1.28 M against 1.08 M with 1).
+	static int g_const_pairs_forced = 0; // (tests and measurements, through the build with the test hooks: lossy_const_force_pairs)
+	void lossy_const_force_pairs(int np) { g_const_pairs_forced = (np == 4 || np == 2 || np == 1) ? np : 0; }
 	int lossy_const_pairs(int full, int nstreams)
 	{
-		static int forced = -1;
-		if (forced < 0)
-		{
-			const char *ev = getenv("RIR_LOSSY_CONST_PAIRS"); // measurement aid
-			forced = ev ? atoi(ev) : 0;
-			if (forced != 4 && forced != 2 && forced != 1)
-				forced = 0;
-		}
-		if (forced)
-			return forced;
+		if (g_const_pairs_forced)
+			return g_const_pairs_forced;
 		for (int np = 4; np > 1; np >>= 1)
 			if ((long long)full / (2 * np) / 64 * nstreams >= 2500)
 				return np;

@@ -2510,6 +2510,10 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 		// The constant-budget form (lossy_kernels.hip: lossy_const_run_kernel): with stdFactor == 0 for every stream of the call each group is
 		// first offered to an ordinary launch that needs no hand-offs between workgroups (decided below, on the device, group by group).
 		bool const_form = persistent && !getenv("RIR_LOSSY_NO_CONST");
+		{ // (only in the build with the test hooks: the forms of the kernel that small test frames would never take)
+			const char *pairs = test_hook("RIR_LOSSY_CONST_PAIRS");
+			lossy_const_force_pairs(pairs ? atoi(pairs) : 0);
+		}
 		for (int i = 0; i < nstreams; ++i)
 			const_form = const_form && os[i]->std_factor == 0.0;
 		// frames per histogram launch (one 64 KB histogram slice per frame and stream).  A group costs four small launches beside its

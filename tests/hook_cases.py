@@ -200,6 +200,40 @@ def single_sequence_falls_back():
     assert got == ref
 
 
+def const_pairs(pairs):
+    """The streaming kernel of the bounded-loss step exists for 2, 4 and 8 pixels per thread (lossy_const_pairs picks by the number of waves:
+    many streams of 640x512 take 8); small test frames only ever see 2.  The hook RIR_LOSSY_CONST_PAIRS forces the others: same frames, same
+    budgets as the oracle's."""
+    import torch
+
+    from librir_amd import device as D
+    from oracle.pyoracle import Oracle
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_lossy import CONST_CASES, _oracle_track
+
+    oracle = Oracle()
+    os.environ["RIR_LOSSY_CONST_PAIRS"] = str(pairs)
+    for name in ("ra8", "subtract_min", "ra64_longer_than_the_calls", "high_above_low", "ra0"):
+        c = CONST_CASES[name]
+        arr = s1_noisy_background(c["n"], c["h"], c["w"], seed=47)
+        for add_loss in (False, True):
+            exp, elo, ehi = _oracle_track(oracle, arr, c["w"], c["h"], c["hl"], c["low"], c["high"], 0.0, c["ra"], c.get("subtract_min", False), add_loss)
+            ls = D.LossyStream(c["w"], c["h"], c["hl"], c["low"], c["high"], 0.0, c["ra"], subtract_min=c.get("subtract_min", False))
+            t = torch.from_numpy(arr).cuda()
+            got, lo, hi = [], [], []
+            for c0, c1 in zip(c["cuts"][:-1], c["cuts"][1:]):
+                o, l_, h_ = ls.step(t[c0:c1], add_loss=add_loss and c0 > 0)
+                got.append(o), lo.append(l_), hi.append(h_)
+                if c1 - c0 >= 3:
+                    offered, taken = ls.path_stats()
+                    assert offered >= 1 and taken == offered, (name, c0, c1, offered, taken)
+            assert np.array_equal(torch.cat(got).cpu().numpy(), exp), (name, pairs, add_loss)
+            assert np.concatenate(lo).tolist() == elo and np.concatenate(hi).tolist() == ehi, (name, pairs, add_loss)
+            ls.close()
+    del os.environ["RIR_LOSSY_CONST_PAIRS"]
+
+
 if __name__ == "__main__":
     from librir_amd.low_level.misc import _LIB_PATH
 
@@ -210,6 +244,8 @@ if __name__ == "__main__":
             sticky(_Path(d))
     elif case == "multi_repeated_smaller":
         multi_repeated_smaller()
+    elif case == "const_pairs":
+        const_pairs(int(sys.argv[2]))
     elif case == "loss_run_stepped_again":
         from oracle.pyoracle import Oracle
 

@@ -397,6 +397,16 @@ def test_constant_budget_form_matches_oracle(oracle, name, add_loss, monkeypatch
     ls.close()
 
 
+@pytest.mark.parametrize("pairs", [2, 4])
+def test_constant_budget_form_with_more_pixels_per_thread(pairs):
+    """The streaming kernel exists for 2, 4 and 8 pixels per thread (lossy_const_pairs picks by the number of waves: many streams of
+    640x512 take 8); small test frames would only ever see 2.  The test hook RIR_LOSSY_CONST_PAIRS forces the other two - in a process
+    that loads the build with the hooks (tests/hook_cases.py: const_pairs): same frames, same budgets as the oracle's."""
+    from test_gpu_resident import _hook_case
+
+    _hook_case("const_pairs", pairs)
+
+
 def test_constant_budget_form_keeps_the_history_a_later_std_factor_needs(oracle):
     """The window of statistics is history even while it is multiplied by zero: stdFactor raised on a stream that has gone through
     the constant-budget form - before its window is full, and long after - finds every entry where the reference would have it."""
