@@ -114,50 +114,123 @@ namespace rir
 	// touches the bins a workgroup has filled, a few hundred for thermal images).
 	// The last workgroup to arrive takes the mode of the merged histogram, lowest bin wins ties:
 	// stats[0] = background = (bin << 2) + 1 (get_background, h264.cpp:1955-1991), and clears the histogram.
-	// The 8 pixels of every lane into the workgroup's LDS histogram.  Thermal scenes are flat: on the motion-corrected registration
-	// stream of BASELINE configs[4] a frame has ~20 distinct levels, the 512 pixels of a wave instruction fall into two or three
-	// bins, and 64 LDS atomics on one address are 64 passes (the histogram pass of 7 x 199 such frames took 1.34 ms against 0.25 ms
-	// on the S1 recipe's ~1 000 levels - 38 % of the whole step).  So a wave first looks at the four bins around its first pixel's:
-	// when at least half of the lanes start there, every lane counts its pixels in those four bins into four 16-bit fields, ONE
-	// reduction over the wave adds the fields up and four lanes add the totals - 4 atomics instead of ~500; pixels outside the four
-	// bins, and waves on spread data (one ballot to find out), use plain atomics.  Same counts either way.
-	// offs: the pixels' bins as BYTE offsets into the histogram (bin * 4: one mask per pixel, v & 0xfffc, and no shift at the atomic)
-	__device__ __forceinline__ void lossy_hist_add8(uint32_t *lh, const uint32_t *offs, bool in)
+	// smallest value over the wave, the same in every lane (as lossy_wave_sum32: four DPP steps in the rows, the rows through readlane)
+	__device__ __forceinline__ uint32_t lossy_wave_min32(uint32_t v)
+	{
+		v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false));
+		v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false));
+		v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xf, 0xf, false));
+		v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xf, 0xf, false));
+		return min(min((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+				   min((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+	}
+	// The 8 pixels of every lane into the workgroup's LDS histogram.  offs: the pixels' bins as BYTE offsets into it (bin * 4: one mask per
+	// pixel, v & 0xfffc, and no shift at the atomic).
+	// Thermal scenes are flat - the motion-corrected registration stream of configs[4] has ~20 levels, five or six bins, per frame - and
+	// LDS atomics on a handful of addresses serialise lane by lane (scripts/ubench/lds_atomic_rate.hip: 54 ns a wave instruction on one
+	// address, 9 on sixteen, 4.7 on 250).  So every wave keeps a WINDOW of sixteen bins (64 levels), anchored a little below the smallest of
+	// its pixels since it last emptied it, in registers: a round's eight pixels are counted in the 4-bit fields of two words (the bin's byte
+	// offset in a word IS the shift: four instructions a pixel and word), the nibbles are spread into words of four 8-bit counts (five
+	// instructions a round and word), and those are added up over the wave and put into the histogram every 31 rounds (8 pixels a round: 248) and at the end
+	// of the frame.  No atomic, nothing across lanes, and no 64-bit integer instruction in the round (the first form of this - four 16-bit
+	// fields in a 64-bit word - spent its time in v_lshlrev_b64: 2 x slower on flat frames than the plain atomics on spread ones).
+	// A round in which more than a quarter of the lanes see pixels outside the window is spread data (one ballot to find out) and goes
+	// through plain atomics, none of them under a branch - and so do the seven rounds after it, without a look at the window; the few
+	// pixels outside the window in other rounds do too.  Same counts either way.
+	constexpr int kHistWindowWords = 2; // the window: 8 bins (32 levels) to a word
+	struct LossyHistWindow
+	{
+		uint32_t even[kHistWindowWords], odd[kHistWindowWords]; // this lane's counts of the bins 0, 2, 4, 6 / 1, 3, 5, 7 of each word of the window: 8 bits each
+		uint32_t base;											 // byte offset of the window's first bin (wave-uniform); set whenever the counts are empty
+		int rounds;												 // rounds in the counts (wave-uniform)
+		int skip;												 // rounds still to go straight to the atomics after a round of spread data (wave-uniform)
+	};
+	__device__ __forceinline__ uint32_t *lossy_hist_word(uint32_t *lh, uint32_t off) { return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lh) + off); }
+	__device__ __forceinline__ void lossy_hist_window_flush(uint32_t *lh, LossyHistWindow &hw)
+	{ // (wave-uniform call) 8-bit counts -> 16-bit fields, two to a word; over the wave: <= 64 lanes x 248
+		const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+		for (int wd = 0; wd < kHistWindowWords; ++wd)
+		{
+			const uint32_t b04 = lossy_wave_sum32(hw.even[wd] & 0x00ff00ffu), b26 = lossy_wave_sum32((hw.even[wd] >> 8) & 0x00ff00ffu);
+			const uint32_t b15 = lossy_wave_sum32(hw.odd[wd] & 0x00ff00ffu), b37 = lossy_wave_sum32((hw.odd[wd] >> 8) & 0x00ff00ffu);
+			if (lane < 8)
+			{ // lane = bin of this word of the window
+				const uint32_t v = (lane & 1) ? ((lane & 2) ? b37 : b15) : ((lane & 2) ? b26 : b04);
+				const uint32_t c = (lane & 4) ? v >> 16 : v & 0xffffu;
+				if (c)
+					atomicAdd(lossy_hist_word(lh, hw.base + 32u * (uint32_t)wd + 4u * (uint32_t)lane), c);
+			}
+			hw.even[wd] = hw.odd[wd] = 0u;
+		}
+		hw.rounds = 0;
+	}
+	__device__ __forceinline__ void lossy_hist_add8(uint32_t *lh, const uint32_t *offs, bool in, LossyHistWindow &hw)
 	{
 		const unsigned long long votes = __ballot(in);
 		if (!votes)
 			return;
-		const int lane = (int)(threadIdx.x & 63);
-		const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)offs[0], __builtin_ctzll(votes)) & ~15u; // (four bins: 16 bytes)
-		auto word = [&](uint32_t off) { return reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(lh) + off); };
-		if (__builtin_popcountll(__ballot(in && offs[0] - base < 16u)) * 2 >= __builtin_popcountll(votes))
+		const uint32_t one = in ? 1u : 0u;
+		if (__builtin_amdgcn_readfirstlane(hw.skip) > 0)
+		{ // spread data a moment ago: the next look at the window is a few rounds away (it costs ~100 instructions that such a frame gets nothing for)
+			hw.skip = __builtin_amdgcn_readfirstlane(hw.skip) - 1;
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+				atomicAdd(lossy_hist_word(lh, offs[k]), one);
+			return;
+		}
+		if (__builtin_amdgcn_readfirstlane(hw.rounds) == 0)
+		{ // nothing in the registers: the window is anchored anew, four bins below the (four-bin group of the) smallest pixel of this round
+			uint32_t mn = 0xffffffffu;
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+				mn = min(mn, offs[k]);
+			mn = lossy_wave_min32(in ? mn : 0xffffffffu) & ~15u;
+			hw.base = mn >= 16u ? mn - 16u : 0u;
+		}
+		uint32_t nib[kHistWindowWords], inside_all = 1u;
+#pragma unroll
+		for (int wd = 0; wd < kHistWindowWords; ++wd)
+			nib[wd] = 0u;
+#pragma unroll
+		for (int k = 0; k < 8; ++k)
 		{
-			unsigned long long packed = 0;
+			const uint32_t rel = offs[k] - hw.base; // (below the window: wraps to a large number)
+			uint32_t inw = 0u;
 #pragma unroll
-			for (int k = 0; k < 8; ++k)
+			for (int wd = 0; wd < kHistWindowWords; ++wd)
 			{
-				const uint32_t rel = offs[k] - base; // (below the base: wraps to a large number)
-				packed += (in && rel < 16u) ? 1ull << (4 * (rel & 12u)) : 0ull;
+				const uint32_t r = rel - 32u * (uint32_t)wd, here = r < 32u ? 1u : 0u;
+				nib[wd] += here << (r & 31u); // bin r / 4 of this word: four bits each, at most 8 in a field
+				inw |= here;
 			}
-			const unsigned long long tot = (unsigned long long)lossy_wave_sum((long long)packed); // (a wave holds 512 pixels: no field overflows)
-			if (lane < 4)
-			{
-				const uint32_t c = (uint32_t)(tot >> (16 * lane)) & 0xffffu;
-				if (c)
-					atomicAdd(word(base + 4u * (uint32_t)lane), c);
-			}
-#pragma unroll
-			for (int k = 0; k < 8; ++k)
-				if (in && offs[k] - base >= 16u)
-					atomicAdd(word(offs[k]), 1u);
+			inside_all &= inw;
 		}
-		else
+		const unsigned long long strays = __ballot(in && !inside_all);
+		if (__builtin_popcountll(strays) * 4 > __builtin_popcountll(votes))
 		{ // spread data: eight atomics, none under a branch (a lane past the end adds 0 - to bin 0, where its zero pixels point)
-			const uint32_t one = in ? 1u : 0u;
 #pragma unroll
 			for (int k = 0; k < 8; ++k)
-				atomicAdd(word(offs[k]), one);
+				atomicAdd(lossy_hist_word(lh, offs[k]), one);
+			hw.skip = 7;
+			return;
 		}
+#pragma unroll
+		for (int wd = 0; wd < kHistWindowWords; ++wd)
+		{
+			const uint32_t nb = in ? nib[wd] : 0u;
+			hw.even[wd] += nb & 0x0f0f0f0fu, hw.odd[wd] += (nb >> 4) & 0x0f0f0f0fu;
+		}
+		if (strays)
+		{
+#pragma unroll
+			for (int k = 0; k < 8; ++k)
+				if (in && offs[k] - hw.base >= 32u * kHistWindowWords)
+					atomicAdd(lossy_hist_word(lh, offs[k]), 1u);
+		}
+		hw.rounds = __builtin_amdgcn_readfirstlane(hw.rounds) + 1;
+		if (hw.rounds == 31)
+			lossy_hist_window_flush(lh, hw);
 	}
 
 	// what the histogram pass needs of a frame: its pixels, a zeroed 16 384-bin slice, where its background goes, a zeroed ticket
@@ -189,6 +262,7 @@ namespace rir
 			const uint32_t bytes = (uint32_t)n8 * 16u; // (s < 2^27 pixels: lossy_state_create)
 			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(sp.tmp), 0, (int)bytes, 0x00020000);
 			lossy_v4u q[kHistAhead];
+			LossyHistWindow hw = {};
 			int ib = i0 / 8;
 #pragma unroll
 			for (int a = 0; a < kHistAhead; ++a)
@@ -213,9 +287,11 @@ namespace rir
 					__builtin_amdgcn_sched_barrier(0);
 					q[a] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(ib + (a + kHistAhead) * 1024 + tid) * 16u, 0, 0);
 					__builtin_amdgcn_sched_barrier(0);
-					lossy_hist_add8(lh, bins, in);
+					lossy_hist_add8(lh, bins, in, hw);
 				}
 			}
+			if (hw.rounds)
+				lossy_hist_window_flush(lh, hw);
 		}
 		else
 			for (int i = i0 + tid; i < i1; i += 1024) // (frames whose lossy part is not a multiple of 8 pixels: one pixel per lane)
