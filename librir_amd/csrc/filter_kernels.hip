@@ -1875,19 +1875,47 @@ namespace rir
 			if (tid == 0)
 				found = 0x7fffffff;
 			__syncthreads();
-			const uint4 *f4 = reinterpret_cast<const uint4 *>(f);
-			for (int64_t i = tid; i < nvec; i += 1024)
-			{
-				const uint4 v = f4[i];
-				const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+			if (nvec > 0)
+			{ // Four 16-byte loads of a thread in flight (with one - load, count, load - a workgroup waited a memory latency per 16 KB), every
+			  // one an unconditional buffer load (a lane past the end: an offset out of range, zeros it does not count) so that the waits stay
+			  // counted; the eight atomics of a round are not under branches either: a pixel of another quarter adds 0.  A slot is asked for
+			  // again when its pixels have become counter offsets (the empty asm pins that point: see lossy_hist_mode_body).
+				constexpr int kAhead = 4;
+				typedef unsigned int q_v4u __attribute__((ext_vector_type(4)));
+				const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(f), 0, (int)(uint32_t)(nvec * 16), 0x00020000); // (a frame is < 2^31 bytes: rir_* checks)
+				q_v4u qv[kAhead];
 #pragma unroll
-				for (int k = 0; k < 4; ++k)
+				for (int a = 0; a < kAhead; ++a)
 				{
-					const uint32_t lo = d[k] & 0xffffu, hi = d[k] >> 16;
-					if ((lo >> 14) == q)
-						atomicAdd(&cnt[lo & 16383u], 1u);
-					if ((hi >> 14) == q)
-						atomicAdd(&cnt[hi & 16383u], 1u);
+					qv[a] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(a * 1024 + tid) * 16u, 0, 0);
+					__builtin_amdgcn_sched_barrier(0);
+				}
+				for (int64_t i0 = 0; i0 < nvec; i0 += 1024 * kAhead)
+				{
+#pragma unroll
+					for (int a = 0; a < kAhead; ++a)
+					{
+						const q_v4u v = qv[a];
+						const bool in = i0 + a * 1024 + tid < nvec;
+						const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+						uint32_t off[8], one[8];
+#pragma unroll
+						for (int k = 0; k < 4; ++k)
+						{
+							const uint32_t lo = d[k] & 0xffffu, hi = d[k] >> 16;
+							off[2 * k] = (lo & 16383u) * 4u, off[2 * k + 1] = (hi & 16383u) * 4u;
+							one[2 * k] = (in && (lo >> 14) == q) ? 1u : 0u, one[2 * k + 1] = (in && (hi >> 14) == q) ? 1u : 0u;
+						}
+#pragma unroll
+						for (int k = 0; k < 8; ++k)
+							asm volatile("" : "+v"(off[k]), "+v"(one[k]));
+						__builtin_amdgcn_sched_barrier(0);
+						qv[a] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(i0 + (a + kAhead) * 1024 + tid) * 16u, 0, 0);
+						__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+						for (int k = 0; k < 8; ++k)
+							atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(cnt) + off[k]), one[k]);
+					}
 				}
 			}
 			for (int64_t i = nvec * 8 + tid; i < npx; i += 1024)
