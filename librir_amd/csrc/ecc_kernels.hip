@@ -145,14 +145,26 @@ namespace rir
 		auto ld = [](__amdgpu_buffer_rsrc_t r, uint32_t off) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0)); };
 		auto sample = [&](int i, int x, int y, bool inside) {
 			const float sx = (float)x + tx, sy = (float)y + ty;
-			// validity: the nearest source pixel lies inside the image and inside the caller's mask
-			const int nx = (int)rintf(sx), ny = (int)rintf(sy);
-			bool valid = inside && (unsigned)nx < (unsigned)w && (unsigned)ny < (unsigned)h;
-			const uint8_t mv = mask ? mask[min(max(ny, 0), h - 1) * w + min(max(nx, 0), w - 1)] : (uint8_t)1;
-			valid = valid && mv != 0;
 			const float flx = floorf(sx), fly = floorf(sy);
 			const int x0 = (int)flx, y0 = (int)fly;
 			const float fx = sx - flx, fy = sy - fly;
+			// Where nothing can be outside - all four taps of every lane in the image (then the nearest source pixel is too), no mask, no lane
+			// past the end - the validity test, the four range tests of the taps and the four selects on their offsets are left out: same
+			// values, bit for bit, a sixth of the loop's vector instructions fewer, and the loop is bound by those (profiles/r04_pmc_ecc.json).
+			// Decided per WAVE (64 consecutive pixels of a line): with a translation of t pixels every wave but those within t of two borders.
+#if !RIR_ECC_GRAD_ON_THE_FLY && !defined(RIR_ECC_NO_INTERIOR_PATH)
+			const bool interior = mask == nullptr && __builtin_amdgcn_ballot_w64(!(inside && (unsigned)x0 < (unsigned)(w - 1) && (unsigned)y0 < (unsigned)(h - 1))) == 0;
+#else
+			const bool interior = false;
+#endif
+			bool valid = true;
+			if (!interior)
+			{ // validity: the nearest source pixel lies inside the image and inside the caller's mask
+				const int nx = (int)rintf(sx), ny = (int)rintf(sy);
+				valid = inside && (unsigned)nx < (unsigned)w && (unsigned)ny < (unsigned)h;
+				const uint8_t mv = mask ? mask[min(max(ny, 0), h - 1) * w + min(max(nx, 0), w - 1)] : (uint8_t)1;
+				valid = valid && mv != 0;
+			}
 			// zero outside the image (constant border); every tap is loaded - a load under a condition is a branch with its own wait - and a
 			// tap outside the image is loaded from an offset outside the BUFFER: the hardware's range check returns +0.0 for it.  Four
 			// selects on the offsets (shared by the three images) instead of eight clamps and twelve selects on the values; the taps
@@ -198,8 +210,9 @@ namespace rir
 			}
 #else
 			{
-				const uint32_t o00 = xa && ya ? lin : kOutside, o01 = xb && ya ? lin + 4u : kOutside, o10 = xa && yb ? lin + w4 : kOutside,
-							   o11 = xb && yb ? lin + w4 + 4u : kOutside;
+				uint32_t o00 = lin, o01 = lin + 4u, o10 = lin + w4, o11 = lin + w4 + 4u;
+				if (!interior)
+					o00 = xa && ya ? o00 : kOutside, o01 = xb && ya ? o01 : kOutside, o10 = xa && yb ? o10 : kOutside, o11 = xb && yb ? o11 : kOutside;
 				auto blend = [&](__amdgpu_buffer_rsrc_t r) { return lerp2(ld(r, o00), ld(r, o01), ld(r, o10), ld(r, o11)); };
 				p.I = blend(r_img);
 				p.gx = blend(r_gx);
