@@ -1641,7 +1641,7 @@ namespace rir
 #ifndef RIR_LOSSY_CONST_PIN_STEPS
 #define RIR_LOSSY_CONST_PIN_STEPS 1
 #endif
-	constexpr int kConstDepth = RIR_LOSSY_CONST_DEPTH; // frames in flight per thread (4, 8 and 12 measure the same: instruction issue, not what is in flight, bounds the kernel)
+	constexpr int kConstDepth = RIR_LOSSY_CONST_DEPTH; // slots of a thread's ring of frames: 3 in flight in the middle of a group (4: 1.49 M frames/s one stream, 6: 1.53, 8: 1.50 - vector issue, not what is in flight, bounds the kernel)
 	// NP pairs of pixels per thread (4: one 16-byte access per thread, frame and array, as the resident kernel; 2; 1).  Nobody waits for anybody
 	// here, so a stream may be cut as finely as pays: with 8 pixels per thread a 640x512 stream is 640 waves on the chip's 1 024 SIMDs - each
 	// working through its ~300 vector instructions per frame alone - with 2 pixels it is 2 560 waves that hide each other's latencies.
@@ -1989,7 +1989,7 @@ namespace rir
 			bg_next = sh_bg[k + 1 < n ? k + 1 : k];
 			request(Vj, Oj);
 			// the frame's sums, if its statistic will be in the window (or seeds it): against the previous output, per workgroup (out of
-			// line: 41 frames of a group come here, and the loop body is unrolled kConstDepth times)
+			// line: frame 0 and, where a group is too short for the middle loop, its last 40 frames come here; the loop body is unrolled kConstDepth times)
 			lossy_v2u_b pval = {0u, 0u};
 			uint32_t poff = RIR_LOSSY_OOB;
 			if (k >= tail0 || k == 0)
@@ -2429,10 +2429,10 @@ namespace rir
 			hipLaunchKernelGGL(lossy_run_kernel, dim3((unsigned)(nb * nstreams)), dim3(kLossyRunThreads), 0, st, d_table, d_ticket, nb, nstreams, epoch, arrivals_before, d_ok);
 		return hipGetLastError();
 	}
-	// Pairs of pixels per thread: the kernel is bound by instruction issue - ~100 vector + ~100 scalar instructions per frame and wave whatever
-	// the wave holds, ~80 vector instructions per pair - so a launch wants its pixels spread over 2-3 waves per SIMD and, beyond that, as many
-	// pixels per wave as possible: the largest of 4, 2, 1 pairs that still gives 2 500 waves (one 640x512 stream: 1 pair, 2 560 waves -
-	// 0.95 M frames/s against 0.85 M with 4 pairs; nine streams: 4 pairs, 1.28 M against 1.08 M with 1).
+	// Pairs of pixels per thread.  A frame costs a wave ~44 vector instructions per pair and ~10 whatever it holds, so beyond the point where
+	// the SIMDs are busy - about five waves each - fewer, fatter waves win, and below it more waves do: the largest of 4, 2, 1 pairs that
+	// still gives 5 000 waves (640x512, measured through the hook RIR_LOSSY_CONST_PAIRS with 1 / 2 / 4 pairs: two streams 1.98 / 1.89 / 1.77 M
+	// frames/s, nine 1.52 / 1.59 / 1.70, thirty-two 1.43 / 1.61 / 1.81; one stream is 2 560 waves with one pair and has no choice).
 	static int g_const_pairs_forced = 0; // (tests and measurements, through the build with the test hooks: lossy_const_force_pairs)
 	void lossy_const_force_pairs(int np) { g_const_pairs_forced = (np == 4 || np == 2 || np == 1) ? np : 0; }
 	int lossy_const_pairs(int full, int nstreams)
@@ -2440,7 +2440,7 @@ namespace rir
 		if (g_const_pairs_forced)
 			return g_const_pairs_forced;
 		for (int np = 4; np > 1; np >>= 1)
-			if ((long long)full / (2 * np) / 64 * nstreams >= 2500)
+			if ((long long)full / (2 * np) / 64 * nstreams >= 5000)
 				return np;
 		return 1;
 	}
