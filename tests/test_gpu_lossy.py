@@ -260,9 +260,10 @@ def test_recording_interleaved_with_queries_parameter_changes_and_add_loss(tmp_p
 
 @pytest.mark.perf
 def test_device_resident_step_rate():
-    """The review's mark for the bounded-loss step on frames that stay in HBM: >= 80 000 frames/s for one 640x512 stream (a run of
-    frames is one resident launch; measured 120-130 k, `tests/perf/lossy_time.py`).  The floor asserted here leaves a third of
-    margin for a busy box; best of three."""
+    """The bounded-loss step on frames that stay in HBM, one 640x512 stream, BASELINE configs[4]'s parameters (stdFactor 0: the
+    constant-budget form).  Review r3 asked for >= 1 M frames/s in long calls (measured 1.6-1.7 M in 1 000-frame calls, 0.85 M in
+    the 200-frame calls timed here; `tests/perf/lossy_const_time.py`); the general (resident) form, which this floor was written
+    for in round 2, runs at 0.16 M.  The floors leave a third of margin for a busy box; best of three."""
     import time
 
     import torch
@@ -282,9 +283,11 @@ def test_device_resident_step_rate():
         torch.cuda.synchronize()
         best = max(best, 2 * n / (time.perf_counter() - t0))
     st.status()
+    st_path = st.path_stats()
     st.close()
-    print("bounded-loss step, one stream: %.0f frames/s" % best)
-    assert best >= 80000, best
+    print("bounded-loss step, one stream, 200-frame calls: %.0f frames/s" % best)
+    assert st_path[1] >= 1, st_path  # (taken by the constant-budget form)
+    assert best >= 500000, best
 
 
 @pytest.mark.parametrize("ra", [1, 2, 64])
