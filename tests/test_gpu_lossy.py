@@ -513,3 +513,48 @@ def test_constant_budget_form_through_the_saver_with_a_parameter_change(tmp_path
         assert list(s.get_low_errors()) == elo and list(s.get_high_errors()) == ehi
     with IRMovie.from_filename(dst) as mov:
         assert np.array_equal(mov.data, exp)
+
+
+FLAT_SCENES = {
+    # level of the scene, noise (levels), hot blob (offset above the scene, or None), frames
+    "low_levels": dict(level=14, noise=3, blob=40),
+    "mid_levels_wide_noise": dict(level=21000, noise=30, blob=200),
+    "top_of_the_range": dict(level=65470, noise=6, blob=50),
+    "two_plateaus": dict(level=3000, noise=2, blob=None, plateau=90),
+}
+
+
+@pytest.mark.parametrize("name", list(FLAT_SCENES))
+@pytest.mark.parametrize("std_factor", [0.0, 5.0], ids=["constant_budgets", "general_run"])
+def test_histogram_pass_on_flat_full_size_scenes(oracle, name, std_factor):
+    """The histogram pass keeps a 16-bin window of counts in REGISTERS per wave (lossy_hist_add8) and empties it every 31 rounds: small test
+    frames are less than one round per wave, so this is the test that takes a frame through all of it - 640x512 (40 rounds per wave:
+    one flush on the way, one at the end), flat scenes whose pixels sit in a handful of bins, with a hot blob above the window (pixels
+    that go through the atomics beside it), a plateau 22 bins up (a window that has to be left and anchored anew), a constant frame, a
+    frame at the top of the value range (a window that reaches past the last bin).  The background of every frame decides which of the
+    two error bounds a pixel gets (low != high here): frames and budgets must be the oracle's."""
+    import torch
+
+    from librir_amd import device as D
+
+    c = FLAT_SCENES[name]
+    n, h, w, hl = 14, 512, 640, 509
+    rng = np.random.default_rng(97)
+    fr = np.clip(c["level"] + rng.integers(-c["noise"], c["noise"] + 1, (n, h, w)) + np.arange(n)[:, None, None] * 2, 0, 65535).astype(np.uint16)
+    if c.get("blob"):
+        yy, xx = np.mgrid[0:h, 0:w]
+        m = (yy - 170) ** 2 + (xx - 120) ** 2 < 75 ** 2
+        fr[:, m] = np.clip(fr[:, m].astype(np.int64) + c["blob"] + rng.integers(0, 60, (n, int(m.sum()))), 0, 65535).astype(np.uint16)
+    if c.get("plateau"):
+        fr[:, h // 3:, :] += np.uint16(c["plateau"])
+    fr[5] = fr[5, 0, 0]  # a constant frame: one bin, 325 760 times
+    exp, elo, ehi = _oracle_track(oracle, fr, w, h, hl, 6, 2, std_factor, 8)
+    ls = D.LossyStream(w, h, hl, 6, 2, std_factor, 8)
+    t = torch.from_numpy(fr).cuda()
+    a = ls.step(t[:1])
+    b = ls.step(t[1:])
+    got = torch.cat([a[0], b[0]]).cpu().numpy()
+    assert np.concatenate([a[1], b[1]]).tolist() == elo and np.concatenate([a[2], b[2]]).tolist() == ehi
+    bad = [i for i in range(n) if not np.array_equal(got[i], exp[i])]
+    assert not bad, bad
+    ls.close()
