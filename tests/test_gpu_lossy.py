@@ -497,6 +497,39 @@ def test_constant_budget_form_with_many_streams_and_mixed_parameters(oracle):
             s_.close()
 
 
+def test_constant_budget_form_full_size_many_streams(oracle):
+    """Seventeen 640x512 streams in one call: the launch that takes 8 pixels per thread by itself (lossy_const_pairs: 5 000 waves and
+    more with four pairs), every phase of the streaming kernel (first frames, the loop of the middle, the frames of the end) at the
+    size the rates are quoted for - each stream against its own oracle, rings of several lengths side by side."""
+    import torch
+
+    from librir_amd import device as D
+
+    h, w, n, S = 512, 640, 56, 17
+    base = s1_noisy_background(n, h, w, seed=71)
+    streams, ins, exps = [], [], []
+    for i in range(S):
+        ra, smin = (0, 3, 8, 32)[i % 4], i % 3 == 0
+        arr = base if i == 0 else (base + np.uint16(7 * i)).astype(np.uint16)
+        if i % 5 == 2:
+            arr = arr[:, ::-1].copy()
+        exps.append(_oracle_track(oracle, arr, w, h, h - 3, 4 + i % 3, 2, 0.0, ra, smin))
+        streams.append(D.LossyStream(w, h, h - 3, 4 + i % 3, 2, 0.0, ra, subtract_min=smin))
+        ins.append(torch.from_numpy(arr).cuda())
+    o1, lo1, hi1 = D.LossyStream.step_many(streams, [t[:1] for t in ins])
+    o2, lo2, hi2 = D.LossyStream.step_many(streams, [t[1:] for t in ins])
+    offered, taken = streams[0].path_stats()
+    assert offered >= 1 and taken == offered, (offered, taken)
+    for i in range(S):
+        exp, elo, ehi = exps[i]
+        got = torch.cat([o1[i], o2[i]]).cpu().numpy()
+        bad = [k for k in range(n) if not np.array_equal(got[k], exp[k])]
+        assert not bad, (i, bad)
+        assert np.concatenate([lo1[i], lo2[i]]).tolist() == elo and np.concatenate([hi1[i], hi2[i]]).tolist() == ehi, i
+    for s_ in streams:
+        s_.close()
+
+
 def test_constant_budget_form_through_the_saver_with_a_parameter_change(tmp_path, oracle):
     """h264_add_image_lossy with stdFactor 0 (the saver steps its chunks as runs of frames), stdFactor raised in mid-recording"""
     n, h, w, hl = 150, 48, 96, 45
