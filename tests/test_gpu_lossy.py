@@ -530,6 +530,31 @@ def test_constant_budget_form_full_size_many_streams(oracle):
         s_.close()
 
 
+@pytest.mark.parametrize("shape", [(768, 1024, 765), (600, 800, 600), (513, 648, 511)], ids=["1024x768", "800x600", "648x513"])
+def test_constant_budget_form_other_full_sizes(oracle, shape):
+    """configs[3]'s geometry and two others (a lossy height that is the whole frame; a width that is a multiple of 8 but not of 64, the
+    last workgroup of a stream half empty): 70 frames in two calls, ring of 8, subtractMin - frames and budgets the oracle's."""
+    import torch
+
+    from librir_amd import device as D
+
+    h, w, hl = shape
+    n = 70
+    arr = s1_noisy_background(n, h, w, seed=83)
+    exp, elo, ehi = _oracle_track(oracle, arr, w, h, hl, 5, 2, 0.0, 8, True)
+    ls = D.LossyStream(w, h, hl, 5, 2, 0.0, 8, subtract_min=True)
+    t = torch.from_numpy(arr).cuda()
+    a = ls.step(t[:9])
+    assert ls.path_stats()[1] >= 1
+    b = ls.step(t[9:])
+    assert ls.path_stats()[1] >= 1
+    got = torch.cat([a[0], b[0]]).cpu().numpy()
+    bad = [k for k in range(n) if not np.array_equal(got[k], exp[k])]
+    assert not bad, bad
+    assert np.concatenate([a[1], b[1]]).tolist() == elo and np.concatenate([a[2], b[2]]).tolist() == ehi
+    ls.close()
+
+
 def test_constant_budget_form_through_the_saver_with_a_parameter_change(tmp_path, oracle):
     """h264_add_image_lossy with stdFactor 0 (the saver steps its chunks as runs of frames), stdFactor raised in mid-recording"""
     n, h, w, hl = 150, 48, 96, 45
