@@ -288,7 +288,10 @@ def other_paths(D, frames, h, w):
     st = D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32)
     st.step(fr[:60], errors=False)
     res["bounded_loss_step_fps_one_stream"] = rate(lambda: st.step(fr, errors=False), m)
+    if frames.shape[0] > m:  # the whole batch in one call: a call's fixed cost (~0.1 ms: first and last frames of the group, finish kernel, the gap to the next call) over more frames
+        res["bounded_loss_step_fps_one_stream_%d_frame_calls" % frames.shape[0]] = rate(lambda: st.step(frames, errors=False), frames.shape[0])
     st.status()
+    res["bounded_loss_groups_offered_to_and_taken_by_the_constant_budget_form"] = list(st.path_stats())
     st.close()
     for S in (7, 9):  # (7: what one launch of the run kernel's first form holds; 9: its second form - state parked in LDS, 6 waves per SIMD)
         streams = [D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32) for _ in range(S)]
