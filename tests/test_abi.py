@@ -73,7 +73,7 @@ def test_the_product_library_has_no_test_hooks():
     libs = os.path.join(ROOT, "librir_amd", "libs")
     product = open(os.path.join(libs, "librir_amd.so"), "rb").read()
     hooks = open(os.path.join(libs, "librir_amd_testhooks.so"), "rb").read()
-    for name in (b"RIR_DEBUG_LOSSY_GIVE_UP", b"RIR_DEBUG_LOSSY_BAIL", b"RIR_DEBUG_ECC_BAIL"):
+    for name in (b"RIR_DEBUG_LOSSY_GIVE_UP", b"RIR_DEBUG_LOSSY_BAIL", b"RIR_DEBUG_ECC_BAIL", b"RIR_LOSSY_CONST_PAIRS"):
         assert name not in product, name
         assert name in hooks, name
 
