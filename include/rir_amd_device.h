@@ -239,6 +239,8 @@ extern "C"
 	 * back to back; with both arrays NULL the call returns without waiting, else it waits once, at the end. */
 	int rir_lossy_create(int width, int height, int lossy_height, int low_value_error, int high_value_error, double std_factor,
 						 int running_average, int subtract_min, int remove_bad_pixels);
+	/* (the nframes input frames and the nframes output frames must not overlap: a run of frames reads input frames again - the frame
+	 * that leaves the running average - after later outputs have been written; -1 otherwise) */
 	int rir_lossy_step_device(int handle, const unsigned short *d_in, unsigned short *d_out, int nframes, int add_loss, int *low_errors,
 							  int *high_errors, void *stream);
 	/* The same step for nstreams INDEPENDENT streams (handles from rir_lossy_create with equal geometry, stepped the same number of

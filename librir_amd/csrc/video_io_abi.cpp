@@ -2396,6 +2396,14 @@ RIR_EXPORT int rir_lossy_step_device(int handle, const unsigned short *d_in, uns
 		log_error("rir_lossy_step_device: invalid argument");
 		return -1;
 	}
+	{
+		const size_t span = (size_t)nframes * (size_t)o->st.w * (size_t)o->st.h;
+		if (d_in < d_out + span && d_out < d_in + span)
+		{
+			log_error("rir_lossy_step_device: input and output frames overlap");
+			return -1;
+		}
+	}
 	// a batch without bad-pixel repair is a run of frames: one launch per frame instead of three (rir_lossy_step_multi_device)
 	if (!o->remove_bad_pixels && nframes >= 3)
 	{
@@ -2835,6 +2843,14 @@ RIR_EXPORT int rir_lossy_step_multi_device(const int *handles, int nstreams, con
 		{
 			log_error("rir_lossy_step_multi_device: invalid handle or buffer");
 			return -1;
+		}
+		{ // (the runs of frames read input frames again - the frame that leaves the running average - after later outputs have been written)
+			const size_t span = (size_t)nframes * (size_t)os[i]->st.w * (size_t)os[i]->st.h;
+			if (d_in[i] < d_out[i] + span && d_out[i] < d_in[i] + span)
+			{
+				log_error("rir_lossy_step_multi_device: input and output frames overlap");
+				return -1;
+			}
 		}
 		for (int k = 0; k < i; ++k)
 			if (os[k] == os[i])

@@ -616,3 +616,27 @@ def test_histogram_pass_on_flat_full_size_scenes(oracle, name, std_factor):
     bad = [i for i in range(n) if not np.array_equal(got[i], exp[i])]
     assert not bad, bad
     ls.close()
+
+
+def test_overlapping_input_and_output_are_refused():
+    """a run of frames reads input frames again after later outputs have been written (the frame that leaves the running average):
+    output frames that lie inside the input batch - or the other way round - are an error, not a wrong result"""
+    import ctypes as ct
+
+    import torch
+
+    from librir_amd import device as D
+    from librir_amd.low_level.misc import _lib
+
+    n, h, w = 12, 40, 64
+    buf = torch.from_numpy(s1_noisy_background(2 * n, h, w, seed=5)).cuda()
+    ls = D.LossyStream(w, h, h - 3, 3, 3, 0.0, 4)
+    fn = _lib.rir_lossy_step_device
+    fn.restype = ct.c_int
+    fn.argtypes = [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p]
+    frame = h * w * 2
+    for shift in (1, n - 1, -3):
+        assert fn(ls.handle, buf.data_ptr() + 4 * frame, buf.data_ptr() + (4 + shift) * frame, n, 0, None, None, None) == -1, shift
+    assert fn(ls.handle, buf.data_ptr(), buf.data_ptr() + n * frame, n, 0, None, None, None) == 0  # (side by side: fine)
+    ls.status()
+    ls.close()
