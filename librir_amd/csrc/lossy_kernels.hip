@@ -10,6 +10,7 @@
 // (a run's backgrounds come from one histogram launch per group of frames: they depend on the input only).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <type_traits>
 
 #include "lossy_kernels.h"
@@ -2433,12 +2434,12 @@ namespace rir
 	// the SIMDs are busy - about five waves each - fewer, fatter waves win, and below it more waves do: the largest of 4, 2, 1 pairs that
 	// still gives 5 000 waves (640x512, measured through the hook RIR_LOSSY_CONST_PAIRS with 1 / 2 / 4 pairs: two streams 1.98 / 1.89 / 1.77 M
 	// frames/s, nine 1.52 / 1.59 / 1.70, thirty-two 1.43 / 1.61 / 1.81; one stream is 2 560 waves with one pair and has no choice).
-	static int g_const_pairs_forced = 0; // (tests and measurements, through the build with the test hooks: lossy_const_force_pairs)
-	void lossy_const_force_pairs(int np) { g_const_pairs_forced = (np == 4 || np == 2 || np == 1) ? np : 0; }
+	static std::atomic<int> g_const_pairs_forced{0}; // (tests and measurements, through the build with the test hooks: lossy_const_force_pairs; calls of several threads all store 0)
+	void lossy_const_force_pairs(int np) { g_const_pairs_forced.store((np == 4 || np == 2 || np == 1) ? np : 0, std::memory_order_relaxed); }
 	int lossy_const_pairs(int full, int nstreams)
 	{
-		if (g_const_pairs_forced)
-			return g_const_pairs_forced;
+		if (const int forced = g_const_pairs_forced.load(std::memory_order_relaxed))
+			return forced;
 		for (int np = 4; np > 1; np >>= 1)
 			if ((long long)full / (2 * np) / 64 * nstreams >= 5000)
 				return np;
