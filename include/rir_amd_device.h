@@ -337,6 +337,16 @@ extern "C"
 	int find_transform_ecc_translation(const float *templ, const float *image, const unsigned char *mask, int w, int h, float *warp,
 									   int max_iterations, double eps, double *cc);
 
+	/* The host copy the per-frame entry points use between the caller's memory and page-locked staging (librir_amd/csrc/host_copy.cpp:
+	 * a frame cut over a few helper threads; the reference's per-frame calls copy the caller's image the same way before they return,
+	 * video_io.cpp:726-756 -> h264.cpp:1066-1082).  Plain host memory, no device involved: exported for tests and measurements.
+	 * Returns the number of helper threads a copy may use (RIR_HOST_COPY_THREADS, default 3; 0 = memcpy on the calling thread), -1 on bad
+	 * arguments. */
+	int rir_host_copy(void *dst, const void *src, int64_t bytes);
+	/* The same helpers move a chunk between page-locked memory and the container file (the saver's writer, the loader's read-ahead):
+	 * write != 0 writes buf to [file_off, file_off + bytes) of the descriptor, else reads that range - all of it, or -1.  0 on success. */
+	int rir_host_file_rw(int fd, void *buf, int64_t bytes, int64_t file_off, int write);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,272 @@
+// Host-side copy of a frame between the caller's memory and page-locked staging - and a chunk's trip to / from the file - spread over
+// a few helper threads.
+//
+// Why: on the per-frame C ABI (h264_add_image_lossless, load_image, the signal_processing entry points) the caller owns its buffer
+// again when the call returns, so every frame crosses the host once more than the PCIe link asks for - user memory <-> a page-locked
+// slot.  Measured on the GPU box (tests/perf/abi_breakdown.py, 640x512 uint16): that one memcpy is 23 us of a 27 us add_image call and
+// 15-20 us of a 21 us load_image call, while the link needs 13 us per frame: the calls are bound by ONE core's copy rate.  Four cores
+// copy a frame in a quarter of the time; the link then is the limit, as it should be.
+//
+// How: helpers are assigned explicitly.  A helper is IDLE (spinning on its own state word), BUSY (owned by exactly one caller) or
+// PARKED (asleep on its condition variable after kSpinNs without work).  A caller takes the helpers it finds IDLE (one CAS each),
+// cuts the copy into that many parts + its own, and waits for the parts it handed out; a PARKED helper is woken for the NEXT call
+// and this call does without it.  Nothing is shared between two callers, so several savers / loaders driven from different threads
+// simply compete for the idle helpers.  During a burst of per-frame calls (a recording, a sequential read) the helpers stay hot;
+// a few hundred microseconds after the last call they sleep and cost nothing.
+// The same helpers move a chunk between page-locked memory and the FILE (host_pread / host_pwrite: disjoint ranges of one descriptor):
+// a 7 MB chunk through the page cache is 0.8-1.4 ms on one thread - longer than the chunk's 0.65 ms on the PCIe link.
+// RIR_HOST_COPY_THREADS = number of helpers (default 3, 0 = everything on the calling thread, at most 7).
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include <errno.h>
+#include <pthread.h>
+#include <unistd.h>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+#include "runtime.h"
+
+namespace rir
+{
+	namespace
+	{
+		constexpr int kMaxHelpers = 7;
+		constexpr size_t kParallelFrom = 192 * 1024; // below this a single memcpy is faster than a hand-off
+		constexpr int64_t kSpinNs = 300 * 1000;		 // an idle helper spins this long before it parks
+
+		enum : int
+		{
+			IDLE = 0,
+			BUSY = 1,
+			PARKED = 2
+		};
+
+		enum : int
+		{
+			JOB_COPY = 0,
+			JOB_PREAD = 1,
+			JOB_PWRITE = 2
+		};
+		// the whole range or failure (short reads / writes are continued, EINTR repeated)
+		bool pread_all(int fd, void *dst, size_t bytes, int64_t off)
+		{
+			char *p = static_cast<char *>(dst);
+			while (bytes)
+			{
+				const ssize_t r = ::pread(fd, p, bytes, (off_t)off);
+				if (r < 0 && errno == EINTR)
+					continue;
+				if (r <= 0)
+					return false; // error, or the file ends inside the range
+				p += r, off += r, bytes -= (size_t)r;
+			}
+			return true;
+		}
+		bool pwrite_all(int fd, const void *src, size_t bytes, int64_t off)
+		{
+			const char *p = static_cast<const char *>(src);
+			while (bytes)
+			{
+				const ssize_t r = ::pwrite(fd, p, bytes, (off_t)off);
+				if (r < 0 && errno == EINTR)
+					continue;
+				if (r <= 0)
+					return false;
+				p += r, off += r, bytes -= (size_t)r;
+			}
+			return true;
+		}
+		bool do_job(int kind, void *dst, const void *src, size_t bytes, int fd, int64_t off)
+		{
+			if (kind == JOB_PREAD)
+				return pread_all(fd, dst, bytes, off);
+			if (kind == JOB_PWRITE)
+				return pwrite_all(fd, src, bytes, off);
+			std::memcpy(dst, src, bytes);
+			return true;
+		}
+
+		inline void cpu_relax()
+		{
+#if defined(__x86_64__)
+			_mm_pause();
+#else
+			std::this_thread::yield();
+#endif
+		}
+		inline int64_t now_ns()
+		{
+			return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+		}
+
+		struct alignas(128) Helper
+		{
+			std::atomic<int> state{PARKED}; // a helper starts parked: the first call wakes it
+			std::atomic<uint64_t> go{0};	 // written by the owner after the job below
+			std::atomic<uint64_t> done{0};	 // written by the helper: the last job it finished
+			int kind = 0; // JOB_*
+			void *dst = nullptr;
+			const void *src = nullptr;
+			size_t bytes = 0;
+			int fd = -1;
+			int64_t file_off = 0;
+			std::atomic<int> *failed = nullptr; // the owner's flag, raised when a file job fails (written before `done`)
+			std::mutex m;
+			std::condition_variable cv;
+			bool wake = false;
+			std::thread th;
+		};
+
+		std::atomic<bool> g_forked{false}; // set in the child of a fork(): the helper threads do not exist there
+
+		struct Pool
+		{
+			Helper h[kMaxHelpers];
+			int n = 0;
+			Pool()
+			{
+				pthread_atfork(nullptr, nullptr, [] { g_forked.store(true, std::memory_order_relaxed); });
+				int want = 3;
+				if (const char *e = std::getenv("RIR_HOST_COPY_THREADS"))
+					want = std::atoi(e);
+				const unsigned hw = std::thread::hardware_concurrency();
+				if (hw && (unsigned)want > hw - 1)
+					want = (int)hw - 1; // never more threads than other cores
+				n = want < 0 ? 0 : (want > kMaxHelpers ? kMaxHelpers : want);
+				for (int i = 0; i < n; ++i)
+				{
+					h[i].th = std::thread([this, i] { run(h[i]); });
+					h[i].th.detach(); // the pool lives as long as the process (it is leaked on purpose: no destructor order to get wrong)
+				}
+			}
+			static void run(Helper &me)
+			{
+				uint64_t seq = 0;
+				int64_t idle_since = now_ns();
+				for (;;)
+				{
+					int s = me.state.load(std::memory_order_acquire);
+					if (s == BUSY)
+					{ // a caller owns this helper: its job follows at once
+						while (me.go.load(std::memory_order_acquire) == seq)
+							cpu_relax();
+						++seq;
+						if (!do_job(me.kind, me.dst, me.src, me.bytes, me.fd, me.file_off))
+							me.failed->store(1, std::memory_order_relaxed);
+						me.done.store(seq, std::memory_order_release);
+						me.state.store(IDLE, std::memory_order_release);
+						idle_since = now_ns();
+						continue;
+					}
+					if (s == IDLE && now_ns() - idle_since > kSpinNs)
+					{
+						int expect = IDLE;
+						if (me.state.compare_exchange_strong(expect, PARKED, std::memory_order_acq_rel))
+							s = PARKED;
+					}
+					if (s == PARKED)
+					{
+						std::unique_lock<std::mutex> lk(me.m);
+						me.cv.wait(lk, [&] { return me.wake; });
+						me.wake = false;
+						me.state.store(IDLE, std::memory_order_release);
+						idle_since = now_ns();
+						continue;
+					}
+					cpu_relax();
+				}
+			}
+		};
+
+		Pool *pool()
+		{
+			static Pool *p = new Pool(); // (leaked: see Pool())
+			return p;
+		}
+	} // namespace
+
+	int host_copy_threads() { return g_forked.load(std::memory_order_relaxed) ? 0 : pool()->n; }
+
+	namespace
+	{
+		// one job cut into parts over the idle helpers + the calling thread; false when a part failed (file jobs)
+		bool run_parts(int kind, void *dst, const void *src, size_t bytes, int fd, int64_t file_off)
+		{
+			if (bytes < kParallelFrom || g_forked.load(std::memory_order_relaxed))
+				return do_job(kind, dst, src, bytes, fd, file_off);
+			Pool *p = pool();
+			Helper *mine[kMaxHelpers];
+			int k = 0;
+			for (int i = 0; i < p->n; ++i)
+			{
+				Helper &h = p->h[i];
+				int expect = IDLE;
+				if (h.state.compare_exchange_strong(expect, BUSY, std::memory_order_acq_rel))
+					mine[k++] = &h;
+				else if (expect == PARKED)
+				{ // wake it for the next call; this one does without it
+					std::lock_guard<std::mutex> lk(h.m);
+					if (!h.wake)
+					{
+						h.wake = true;
+						h.cv.notify_one();
+					}
+				}
+			}
+			// k + 1 parts, cut at multiples of 4 KiB; the caller takes the last one
+			const size_t part = ((bytes / (size_t)(k + 1)) + 4095) & ~(size_t)4095;
+			uint64_t want[kMaxHelpers];
+			std::atomic<int> failed{0}; // (the helpers write it before they report `done`, and this function waits for every `done`)
+			size_t off = 0;
+			for (int i = 0; i < k; ++i)
+			{
+				Helper &h = *mine[i];
+				const size_t n = off + part <= bytes ? part : bytes - off;
+				h.kind = kind, h.fd = fd, h.file_off = file_off + (int64_t)off, h.failed = &failed;
+				h.dst = dst ? static_cast<char *>(dst) + off : nullptr, h.src = src ? static_cast<const char *>(src) + off : nullptr, h.bytes = n;
+				want[i] = h.go.load(std::memory_order_relaxed) + 1;
+				h.go.store(want[i], std::memory_order_release);
+				off += n;
+			}
+			bool ok = true;
+			if (off < bytes)
+				ok = do_job(kind, dst ? static_cast<char *>(dst) + off : nullptr, src ? static_cast<const char *>(src) + off : nullptr, bytes - off, fd,
+							file_off + (int64_t)off);
+			// (`done` only grows: by the time this caller looks, the helper may have finished a LATER job of another caller already)
+			for (int i = 0; i < k; ++i)
+				while (mine[i]->done.load(std::memory_order_acquire) < want[i])
+					cpu_relax();
+			return ok && failed.load(std::memory_order_relaxed) == 0;
+		}
+	} // namespace
+
+	void host_copy(void *dst, const void *src, size_t bytes) { (void)run_parts(JOB_COPY, dst, src, bytes, -1, 0); }
+	bool host_pread(int fd, void *dst, size_t bytes, int64_t file_off) { return run_parts(JOB_PREAD, dst, nullptr, bytes, fd, file_off); }
+	bool host_pwrite(int fd, const void *src, size_t bytes, int64_t file_off) { return run_parts(JOB_PWRITE, nullptr, src, bytes, fd, file_off); }
+} // namespace rir
+
+// Test / measurement entry (include/rir_amd_device.h): the copy the per-frame entry points use, on plain host memory.  No device involved.
+RIR_EXPORT int rir_host_copy(void *dst, const void *src, int64_t bytes)
+{
+	if (bytes < 0 || (bytes > 0 && (!dst || !src)))
+		return -1;
+	rir::host_copy(dst, src, (size_t)bytes);
+	return rir::host_copy_threads();
+}
+// The chunk I/O of the saver and the loader on a caller's descriptor: `write` != 0 writes buf to [file_off, file_off + bytes), else reads that range
+// (the whole range or -1: a file that ends inside it is a failure).  0 on success.
+RIR_EXPORT int rir_host_file_rw(int fd, void *buf, int64_t bytes, int64_t file_off, int write)
+{
+	if (fd < 0 || bytes < 0 || file_off < 0 || (bytes > 0 && !buf))
+		return -1;
+	const bool ok = write ? rir::host_pwrite(fd, buf, (size_t)bytes, file_off) : rir::host_pread(fd, buf, (size_t)bytes, file_off);
+	return ok ? 0 : -1;
+}

@@ -137,6 +137,14 @@ namespace rir
 		bool ok_ = false;
 	};
 
+	// memcpy of a frame between the caller's memory and page-locked staging, spread over a few helper threads (host_copy.cpp): the
+	// per-frame entry points are bound by this copy, not by the link.  Plain memcpy for small sizes / RIR_HOST_COPY_THREADS=0.
+	void host_copy(void *dst, const void *src, size_t bytes);
+	// a chunk between page-locked memory and the file, the same way (disjoint ranges of one descriptor; the whole range or false)
+	bool host_pread(int fd, void *dst, size_t bytes, int64_t file_off);
+	bool host_pwrite(int fd, const void *src, size_t bytes, int64_t file_off);
+	int host_copy_threads(); // helpers a copy may use
+
 	bool hip_ok(hipError_t e, const char *what); // logs "what: hipGetErrorString" on failure
 	hipError_t wait_stream(hipStream_t st);		  // polls the stream (short waits without the wake-up latency of a blocking one)
 

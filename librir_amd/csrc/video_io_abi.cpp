@@ -578,7 +578,7 @@ namespace
 			// the slot is not reused before the chunk has been flushed, i.e. after a wait on the stream)
 			const size_t fbytes = (size_t)width * height * 2;
 			unsigned short *slot = reinterpret_cast<unsigned short *>(cc.h_frames.as<char>() + (size_t)pending * fbytes);
-			std::memcpy(slot, img, fbytes);
+			host_copy(slot, img, fbytes);
 			if (!d_err_slots.reserve((size_t)ERR_SLOTS * 2 * sizeof(int)))
 				return false;
 			// every frame but the stream's first is left in its slot and stepped later, with the other frames of the chunk, as a run
@@ -896,7 +896,7 @@ namespace
 			// with the caller preparing its next frame.  (Uploading straight from the caller's pointer saves 13 us per
 			// 640x512 frame but leans on how the runtime treats pageable / pinned sources; not worth the risk.)
 			char *slot = cc.h_frames.as<char>() + (size_t)pending * fbytes;
-			std::memcpy(slot, img, fbytes);
+			host_copy(slot, img, fbytes);
 			// uploads go in groups of a few frames (one asynchronous copy each: the call overhead of a copy per frame was a sixth
 			// of the time of this function); what is left of a chunk goes when the chunk is flushed
 			if (pending + 1 - uploaded >= kUploadGroup && !upload_staged(pending + 1))
@@ -1535,7 +1535,7 @@ namespace
 				if (host_pending && !hip_ok(wait_stream(st), "sync"))
 					return false;
 				host_pending = false;
-				std::memcpy(out, cc.h_frames.as<char>() + (size_t)(pos - host_base) * fbytes, fbytes);
+				host_copy(out, cc.h_frames.as<char>() + (size_t)(pos - host_base) * fbytes, fbytes);
 				if (track && seq_run >= 2)
 					start_prefetch(cached_chunk + 1); // (no-op when it is under way, done, or there is no next chunk)
 				return true;

@@ -210,3 +210,81 @@ def test_image_arrays_are_fresh_and_recycled_only_when_dead():
         k[:] = i
     assert len({k.ctypes.data for k in kept}) == 12 and all((k == i).all() for i, k in enumerate(kept))
     assert (b == 9).all()
+
+
+def test_host_copy_over_helper_threads(lib):
+    """rir_host_copy = the copy the per-frame entry points use between the caller's memory and page-locked staging
+    (csrc/host_copy.cpp): sizes around the hand-off threshold, unaligned ends, a burst (helpers hot), a pause (helpers parked
+    and woken again) and several calling threads at once - every byte must arrive, nothing outside the destination may move."""
+    import threading
+    import time
+
+    lib.rir_host_copy.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int64]
+    rng = np.random.default_rng(11)
+    assert lib.rir_host_copy(None, None, -1) == -1
+    assert lib.rir_host_copy(None, None, 0) >= 0
+    src = rng.integers(0, 256, 4 << 20, dtype=np.uint8)
+    helpers = None
+    for rep in range(3):
+        for n in [1, 4095, 192 * 1024 - 1, 192 * 1024, 192 * 1024 + 1, 640 * 512 * 2, 640 * 512 * 2 + 3, 1024 * 768 * 2, (4 << 20) - 129]:
+            for a, b in [(0, 0), (1, 3), (64, 7)]:
+                dst = np.full(n + 256, 0xA5, np.uint8)
+                helpers = lib.rir_host_copy(dst.ctypes.data + 128 + a, src.ctypes.data + b, n - a - b if n > a + b else 0)
+                m = n - a - b if n > a + b else 0
+                assert np.array_equal(dst[128 + a:128 + a + m], src[b:b + m])
+                assert (dst[:128 + a] == 0xA5).all() and (dst[128 + a + m:] == 0xA5).all()
+        time.sleep(0.01 * rep)  # longer than the helpers' spin: the next round finds them parked
+    assert helpers is not None and 0 <= helpers <= 7
+
+    errors = []
+
+    def worker(seed):
+        r = np.random.default_rng(seed)
+        s = r.integers(0, 256, 1 << 20, dtype=np.uint8)
+        d = np.empty_like(s)
+        for i in range(300):
+            n = int(r.integers(1, s.size)) if i % 4 == 0 else int(r.integers(192 * 1024, s.size))  # (mostly sizes that are handed out)
+            lib.rir_host_copy(d.ctypes.data, s.ctypes.data, n)
+            if not np.array_equal(d[:n], s[:n]):
+                errors.append((seed, i, n))
+                return
+            d[:n] = 0
+
+    # more calling threads than cores here: callers are preempted between handing a part out and looking for it (a helper may by then
+    # have finished a later job of another caller)
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(12)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors
+
+
+def test_host_file_io_over_helper_threads(lib, tmp_path):
+    """rir_host_file_rw = how a chunk travels between page-locked memory and the container file (csrc/host_copy.cpp: disjoint ranges
+    of one descriptor written / read by the helper threads): what was written is in the file, at its offset, and comes back; a range
+    that ends past the end of the file is a failure, not a short read."""
+    lib.rir_host_file_rw.argtypes = [ct.c_int, ct.c_void_p, ct.c_int64, ct.c_int64, ct.c_int]
+    rng = np.random.default_rng(12)
+    path = str(tmp_path / "chunks.bin")
+    fd = os.open(path, os.O_RDWR | os.O_CREAT, 0o600)
+    try:
+        pieces, off = [], 77
+        for n in [1, 5000, 192 * 1024 + 5, 7 * 1000 * 1000 + 3, 640 * 512 * 2]:
+            a = rng.integers(0, 256, n, dtype=np.uint8)
+            assert lib.rir_host_file_rw(fd, a.ctypes.data, n, off, 1) == 0
+            pieces.append((off, a))
+            off += n + 13
+        raw = np.fromfile(path, dtype=np.uint8)
+        assert raw.size == off - 13
+        for o, a in pieces:
+            assert np.array_equal(raw[o:o + a.size], a)
+            back = np.zeros_like(a)
+            assert lib.rir_host_file_rw(fd, back.ctypes.data, a.size, o, 0) == 0
+            assert np.array_equal(back, a)
+        big = np.zeros(1 << 20, np.uint8)
+        assert lib.rir_host_file_rw(fd, big.ctypes.data, big.size, raw.size - 1000, 0) == -1  # ends past the end of the file
+        assert lib.rir_host_file_rw(fd, big.ctypes.data, 100, raw.size, 0) == -1
+        assert lib.rir_host_file_rw(-1, big.ctypes.data, 10, 0, 0) == -1 and lib.rir_host_file_rw(fd, None, 10, 0, 1) == -1
+    finally:
+        os.close(fd)
