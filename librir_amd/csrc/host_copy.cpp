@@ -15,7 +15,8 @@
 // a few hundred microseconds after the last call they sleep and cost nothing.
 // The same helpers move a chunk between page-locked memory and the FILE (host_pread / host_pwrite: disjoint ranges of one descriptor):
 // a 7 MB chunk through the page cache is 0.8-1.4 ms on one thread - longer than the chunk's 0.65 ms on the PCIe link.
-// RIR_HOST_COPY_THREADS = number of helpers (default 3, 0 = everything on the calling thread, at most 7).
+// RIR_HOST_COPY_THREADS / RIR_HOST_IO_THREADS = helpers for memory copies / for file jobs (default 3 each, 0 = on the calling thread, at
+// most 7).
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -127,25 +128,34 @@ namespace rir
 
 		std::atomic<bool> g_forked{false}; // set in the child of a fork(): the helper threads do not exist there
 
+		// Two groups of helpers: memory copies (the calling thread of a per-frame entry point waits for them: 10 us jobs, every 10-20 us
+		// during a recording or a read) and file jobs (the saver's writer thread, the loader's read-ahead lanes: a few hundred
+		// microseconds each).  With one group a file job held the helpers while the caller's copies ran alone at a third of the rate.
 		struct Pool
 		{
-			Helper h[kMaxHelpers];
-			int n = 0;
+			Helper h[2][kMaxHelpers];
+			int n[2] = {0, 0};
+			static int wanted(const char *var, int dflt, unsigned hw)
+			{
+				int want = dflt;
+				if (const char *e = std::getenv(var))
+					want = std::atoi(e);
+				if (hw && (unsigned)want > hw - 1)
+					want = (int)hw - 1; // never more threads than other cores
+				return want < 0 ? 0 : (want > kMaxHelpers ? kMaxHelpers : want);
+			}
 			Pool()
 			{
 				pthread_atfork(nullptr, nullptr, [] { g_forked.store(true, std::memory_order_relaxed); });
-				int want = 3;
-				if (const char *e = std::getenv("RIR_HOST_COPY_THREADS"))
-					want = std::atoi(e);
 				const unsigned hw = std::thread::hardware_concurrency();
-				if (hw && (unsigned)want > hw - 1)
-					want = (int)hw - 1; // never more threads than other cores
-				n = want < 0 ? 0 : (want > kMaxHelpers ? kMaxHelpers : want);
-				for (int i = 0; i < n; ++i)
-				{
-					h[i].th = std::thread([this, i] { run(h[i]); });
-					h[i].th.detach(); // the pool lives as long as the process (it is leaked on purpose: no destructor order to get wrong)
-				}
+				n[0] = wanted("RIR_HOST_COPY_THREADS", 3, hw);
+				n[1] = wanted("RIR_HOST_IO_THREADS", 3, hw > 4 ? hw - 3 : 1);
+				for (int g = 0; g < 2; ++g)
+					for (int i = 0; i < n[g]; ++i)
+					{
+						h[g][i].th = std::thread([this, g, i] { run(h[g][i]); });
+						h[g][i].th.detach(); // the pool lives as long as the process (it is leaked on purpose: no destructor order to get wrong)
+					}
 			}
 			static void run(Helper &me)
 			{
@@ -193,7 +203,7 @@ namespace rir
 		}
 	} // namespace
 
-	int host_copy_threads() { return g_forked.load(std::memory_order_relaxed) ? 0 : pool()->n; }
+	int host_copy_threads() { return g_forked.load(std::memory_order_relaxed) ? 0 : pool()->n[0]; }
 
 	namespace
 	{
@@ -205,9 +215,10 @@ namespace rir
 			Pool *p = pool();
 			Helper *mine[kMaxHelpers];
 			int k = 0;
-			for (int i = 0; i < p->n; ++i)
+			const int g = kind == JOB_COPY ? 0 : 1;
+			for (int i = 0; i < p->n[g]; ++i)
 			{
-				Helper &h = p->h[i];
+				Helper &h = p->h[g][i];
 				int expect = IDLE;
 				if (h.state.compare_exchange_strong(expect, BUSY, std::memory_order_acq_rel))
 					mine[k++] = &h;

@@ -130,6 +130,23 @@ namespace rir
 		return hipStreamSynchronize(st);
 	}
 
+	hipError_t wait_event(hipEvent_t ev)
+	{
+#if RIR_SPIN_WAIT
+		const auto t0 = std::chrono::steady_clock::now();
+		for (long spins = 1;; ++spins)
+		{
+			const hipError_t e = hipEventQuery(ev);
+			if (e != hipErrorNotReady)
+				return e;
+			if ((spins & 0x3f) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
+				break;
+			__builtin_ia32_pause();
+		}
+#endif
+		return hipEventSynchronize(ev);
+	}
+
 	namespace
 	{
 		struct Device
@@ -411,6 +428,14 @@ namespace rir
 			return f;
 		}
 	} // namespace
+	bool abi_zero_copy()
+	{
+		static const bool on = [] {
+			const char *e = std::getenv("RIR_ABI_ZERO_COPY");
+			return !(e && e[0] == '0');
+		}();
+		return on;
+	}
 	bool gaussian_reference_order()
 	{
 		int v = gauss_order_flag().load(std::memory_order_relaxed);

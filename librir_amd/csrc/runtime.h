@@ -147,5 +147,10 @@ namespace rir
 
 	bool hip_ok(hipError_t e, const char *what); // logs "what: hipGetErrorString" on failure
 	hipError_t wait_stream(hipStream_t st);		  // polls the stream (short waits without the wake-up latency of a blocking one)
+	hipError_t wait_event(hipEvent_t ev);		  // the same for an event
+	// The per-frame entry points let the codec kernels work straight on page-locked host memory (the saver's staged frames are read, its
+	// tables and payload written, the loader's frames written over the link by the kernels themselves: no copy calls, no device round trip
+	// per chunk).  RIR_ABI_ZERO_COPY=0 turns that off (copies through device buffers, as before round 5).
+	bool abi_zero_copy();
 
 } // namespace rir

@@ -133,6 +133,7 @@ namespace
 		rir_codec_layout L{};
 		DeviceBuffer d_frames, d_hdr, d_tile_off, d_chunk_off, d_stream, d_ws, d_err, d_tmp, d_shift;
 		PinnedBuffer h_frames, h_in; // h_in: a chunk's tables and payload as read from the file (loader)
+		bool on_device = true;		 // loader: the decoded chunk is in d_frames (false: it was decoded straight into h_frames)
 		bool prepare(int w_, int h_, int gop_, bool encoder = true)
 		{ // encoder: the encode workspace is needed too (the loader only decodes)
 			if (w == w_ && h == h_ && gop == gop_ && d_frames.ptr)
@@ -148,7 +149,7 @@ namespace
 		// the buffers change owner (the structs hold raw pointers and free them when they die: member-wise, never by copy)
 		void swap_with(ChunkCodec &o)
 		{
-			std::swap(w, o.w), std::swap(h, o.h), std::swap(gop, o.gop), std::swap(L, o.L);
+			std::swap(w, o.w), std::swap(h, o.h), std::swap(gop, o.gop), std::swap(L, o.L), std::swap(on_device, o.on_device);
 			DeviceBuffer *a[] = {&d_frames, &d_hdr, &d_tile_off, &d_chunk_off, &d_stream, &d_ws, &d_err, &d_tmp, &d_shift};
 			DeviceBuffer *b[] = {&o.d_frames, &o.d_hdr, &o.d_tile_off, &o.d_chunk_off, &o.d_stream, &o.d_ws, &o.d_err, &o.d_tmp, &o.d_shift};
 			for (int i = 0; i < 9; ++i)
@@ -426,6 +427,7 @@ namespace
 			size_t hdr_n = 0, toff_n = 0, hdr_b = 0, toff_b = 0;
 			uint64_t words = 0;
 			int buf = 0;
+			uint64_t file_off = 0; // where the chunk goes: the writer uses pwrite (its helper threads write disjoint ranges)
 		};
 		PinnedBuffer h_out[2];
 		int next_buf = 0;
@@ -447,10 +449,14 @@ namespace
 				const WriteJob j = job;
 				job_ready = false, writer_busy = true;
 				lk.unlock();
+				// chunk header | record headers | tile offsets | payload, the large parts cut over the helper threads (host_copy.cpp: 7 MB into
+				// the page cache on one thread take longer than the chunk's trip over the link)
 				const char *hb = h_out[j.buf].as<char>();
-				const bool ok = std::fwrite(&j.ch, sizeof(j.ch), 1, fp) == 1 && std::fwrite(hb, 8, j.hdr_n, fp) == j.hdr_n &&
-								std::fwrite(hb + j.hdr_b, 4, j.toff_n, fp) == j.toff_n &&
-								(!j.words || std::fwrite(hb + j.hdr_b + j.toff_b, 8, (size_t)j.words, fp) == (size_t)j.words);
+				const int fd = fileno(fp);
+				const uint64_t o_hdr = j.file_off + sizeof(j.ch), o_toff = o_hdr + j.hdr_n * 8, o_pay = o_toff + j.toff_n * 4;
+				const bool ok = host_pwrite(fd, &j.ch, sizeof(j.ch), (int64_t)j.file_off) && host_pwrite(fd, hb, j.hdr_n * 8, (int64_t)o_hdr) &&
+								host_pwrite(fd, hb + j.hdr_b, j.toff_n * 4, (int64_t)o_toff) &&
+								(!j.words || host_pwrite(fd, hb + j.hdr_b + j.toff_b, (size_t)j.words * 8, (int64_t)o_pay));
 				lk.lock();
 				writer_busy = false;
 				if (!ok)
@@ -473,6 +479,22 @@ namespace
 		}
 		int pending = 0;
 		uint64_t nframes = 0;
+		// Lossless chunks straight from page-locked memory.  A chunk whose frames all came through add_image is encoded where it lies: the
+		// kernels read the staged frames over the link themselves and write tables and payload into the writer's page-locked buffer - no
+		// upload calls, no read-back, no wait in the call that completes the chunk (tests/perf/zero_copy_probe.py: 711 us for 50 frames
+		// of 640x512, the link's rate).  The caller fills the OTHER staging buffer meanwhile; one chunk is in flight at most, the call
+		// that completes the next one collects it (and waits for it: the link is then the limit).
+		PinnedBuffer h_stage_b;
+		int cur_stage = 0; // 0: cc.h_frames, 1: h_stage_b
+		char *stage_ptr() { return cur_stage ? h_stage_b.as<char>() : cc.h_frames.as<char>(); }
+		struct InFlight
+		{
+			bool active = false;
+			int buf = 0, nframes = 0, ntiles = 0;
+			uint64_t first_frame = 0;
+		};
+		InFlight flying;
+		hipEvent_t fly_ev = nullptr;
 		std::vector<IndexEntry> index;
 		std::vector<int64_t> times;
 		std::vector<AttrMap> frame_attrs;
@@ -495,7 +517,7 @@ namespace
 				return true;
 			const size_t fbytes = (size_t)width * height * 2;
 			if (!d_raw.reserve((size_t)chunk_gop * fbytes) ||
-				!hip_ok(hipMemcpyAsync(d_raw.as<char>() + (size_t)raw_uploaded * fbytes, cc.h_frames.as<char>() + (size_t)have * fbytes, (size_t)(upto - have) * fbytes,
+				!hip_ok(hipMemcpyAsync(d_raw.as<char>() + (size_t)raw_uploaded * fbytes, stage_ptr() + (size_t)have * fbytes, (size_t)(upto - have) * fbytes,
 									   hipMemcpyHostToDevice, default_stream()),
 						"H2D frames"))
 				return false;
@@ -524,9 +546,11 @@ namespace
 					if (probe.reserve(512) && launch_stream_copy_probe(probe.ptr, probe.as<char>() + 256, 256, default_stream()) == hipSuccess)
 						(void)hipStreamSynchronize(default_stream());
 				}
-				PinnedBuffer frames, out0, out1;
-				const size_t ob = (size_t)L.ntiles * gop * 8 + (((size_t)L.ntiles + 1) * 4 + 7) / 8 * 8 + (size_t)L.stream_max_bytes;
+				PinnedBuffer frames, frames_b, out0, out1;
+				const size_t ob = (size_t)L.ntiles * gop * 8 + (((size_t)L.ntiles + 1) * 4 + 7) / 8 * 8 + (size_t)L.stream_max_bytes + 64;
 				(void)frames.reserve((size_t)w * h * 2 * gop);
+				if (abi_zero_copy())
+					(void)frames_b.reserve((size_t)w * h * 2 * gop);
 				(void)out0.reserve(ob);
 				(void)out1.reserve(ob);
 			}); // (the buffers' destructors hand them to the pool)
@@ -542,6 +566,8 @@ namespace
 			join_warmup();
 			close();
 			stop_writer();
+			if (fly_ev)
+				(void)hipEventDestroy(fly_ev);
 		}
 
 		// the loss-injection state is created on the first lossy call (after the lazy open)
@@ -577,7 +603,7 @@ namespace
 			// the caller owns its buffer again on return: the image goes through this chunk's page-locked slot (see add_image;
 			// the slot is not reused before the chunk has been flushed, i.e. after a wait on the stream)
 			const size_t fbytes = (size_t)width * height * 2;
-			unsigned short *slot = reinterpret_cast<unsigned short *>(cc.h_frames.as<char>() + (size_t)pending * fbytes);
+			unsigned short *slot = reinterpret_cast<unsigned short *>(stage_ptr() + (size_t)pending * fbytes);
 			host_copy(slot, img, fbytes);
 			if (!d_err_slots.reserve((size_t)ERR_SLOTS * 2 * sizeof(int)))
 				return false;
@@ -798,8 +824,11 @@ namespace
 			hd.width = width, hd.height = height, hd.gop = chunk_gop, hd.fps = fps;
 			if (std::fwrite(&box, sizeof(box), 1, fp) != 1 || std::fwrite(&hd, sizeof(hd), 1, fp) != 1)
 				return false;
+			if (std::fflush(fp) != 0) // (the chunks are written with pwrite on the descriptor; the FILE comes back into use at close)
+				return false;
 			file_pos = sizeof(box) + sizeof(hd);
 			write_failed = false;
+			cur_stage = 0, flying.active = false;
 			opened = true;
 			return true;
 		}
@@ -813,6 +842,10 @@ namespace
 			hipStream_t st = default_stream();
 			rir_codec_layout L;
 			if (rir_codec_layout_query(width, height, pending, chunk_gop, &L) != 0)
+				return false;
+			if (abi_zero_copy() && uploaded == 0)
+				return submit_staged_chunk(L, st);
+			if (!collect_flying()) // (this path waits for its own chunk: the one before it goes to the file first)
 				return false;
 			// the frames are in cc.d_frames: uploaded in groups (or produced there) as they were added; the last group goes now
 			if (!upload_staged(pending))
@@ -834,7 +867,7 @@ namespace
 			j.buf = next_buf;
 			const size_t pay_b = (size_t)words * 8;
 			PinnedBuffer &hob = h_out[j.buf]; // (the job in flight, if any, reads the other buffer)
-			if (pay_b > (size_t)cc.L.stream_max_bytes || !hob.reserve(j.hdr_b + j.toff_b + (size_t)cc.L.stream_max_bytes))
+			if (pay_b > (size_t)cc.L.stream_max_bytes || !hob.reserve(out_layout(L.ntiles).total())) // (one size for both ways a chunk is made)
 				return false;
 			char *hb = hob.as<char>();
 			if (!hip_ok(hipMemcpyAsync(hb, cc.d_hdr.ptr, j.hdr_b, hipMemcpyDeviceToHost, st), "D2H") ||
@@ -842,11 +875,23 @@ namespace
 				(words && !hip_ok(hipMemcpyAsync(hb + j.hdr_b + j.toff_b, cc.d_stream.ptr, pay_b, hipMemcpyDeviceToHost, st), "D2H")) ||
 				!hip_ok(wait_stream(st), "sync"))
 				return false;
+			if (!queue_write(j, pending, nframes - pending, L.ntiles))
+				return false;
+			next_buf ^= 1;
+			pending = 0;
+			uploaded = 0;
+			return true;
+		}
+
+		// a finished chunk (tables and payload in h_out[j.buf]) goes to the writer thread; its place in the file and its index entry are fixed here
+		bool queue_write(WriteJob &j, int chunk_frames, uint64_t first_frame, int ntiles)
+		{
 			std::memset(&j.ch, 0, sizeof(j.ch));
 			std::memcpy(j.ch.magic, "CHNK", 4);
-			j.ch.nframes = pending, j.ch.ntiles = L.ntiles, j.ch.gop = chunk_gop, j.ch.payload_words = words, j.ch.first_frame = nframes - pending;
-			IndexEntry e{file_pos, nframes - pending, (uint32_t)pending, 0};
-			file_pos += sizeof(j.ch) + j.hdr_n * 8 + j.toff_n * 4 + pay_b;
+			j.ch.nframes = (uint32_t)chunk_frames, j.ch.ntiles = ntiles, j.ch.gop = chunk_gop, j.ch.payload_words = j.words, j.ch.first_frame = first_frame;
+			j.file_off = file_pos;
+			IndexEntry e{file_pos, first_frame, (uint32_t)chunk_frames, 0};
+			file_pos += sizeof(j.ch) + j.hdr_n * 8 + j.toff_n * 4 + (size_t)j.words * 8;
 			{
 				std::unique_lock<std::mutex> lk(wmu);
 				if (!writer.joinable())
@@ -861,11 +906,73 @@ namespace
 				job_ready = true;
 			}
 			wcv.notify_all();
-			next_buf ^= 1;
 			index.push_back(e);
+			return true;
+		}
+
+		// layout of a chunk in its page-locked output buffer: record headers | tile offsets (padded to 8) | payload (worst case) | the two chunk offsets
+		struct OutLayout
+		{
+			size_t hdr_n, toff_n, hdr_b, toff_b, pay_max;
+			size_t coff_at() const { return hdr_b + toff_b + pay_max; }
+			size_t total() const { return coff_at() + 64; }
+		};
+		OutLayout out_layout(int ntiles) const
+		{
+			OutLayout o;
+			o.hdr_n = (size_t)ntiles * chunk_gop, o.toff_n = (size_t)ntiles + 1;
+			o.hdr_b = o.hdr_n * 8, o.toff_b = (o.toff_n * 4 + 7) & ~(size_t)7, o.pay_max = (size_t)cc.L.stream_max_bytes;
+			return o;
+		}
+
+		// The chunk in the current staging buffer, every frame of it staged by add_image: encoded from there into h_out[next_buf], nothing
+		// waited for.  The chunk before it is collected first (one in flight; its staging buffer is the one filled next).
+		bool submit_staged_chunk(const rir_codec_layout &L, hipStream_t st)
+		{
+			if (!collect_flying())
+				return false;
+			const OutLayout o = out_layout(L.ntiles);
+			PinnedBuffer &hob = h_out[next_buf]; // (free: the writer's job in flight, if any, reads the other buffer - queue_write waits for the job before)
+			const size_t fb = (size_t)width * height * 2 * chunk_gop;
+			if (!hob.reserve(o.total()) || !h_stage_b.reserve(fb))
+				return false;
+			if (!fly_ev && !hip_ok(hipEventCreateWithFlags(&fly_ev, hipEventDisableTiming), "hipEventCreate"))
+				return false;
+			char *hb = hob.as<char>();
+			uint64_t *coff = reinterpret_cast<uint64_t *>(hb + o.coff_at());
+			coff[0] = 0, coff[1] = ~0ull; // (what the kernels leave is checked against the buffer before it is believed)
+			if (rir_codec_encode_device(reinterpret_cast<const unsigned short *>(stage_ptr()), width, height, pending, chunk_gop,
+										reinterpret_cast<unsigned long long *>(hb), reinterpret_cast<unsigned int *>(hb + o.hdr_b),
+										reinterpret_cast<unsigned long long *>(coff), reinterpret_cast<unsigned long long *>(hb + o.hdr_b + o.toff_b), cc.d_ws.ptr,
+										(long long)cc.d_ws.cap, st) != 0 ||
+				!hip_ok(hipEventRecord(fly_ev, st), "hipEventRecord"))
+				return false;
+			flying.active = true, flying.buf = next_buf, flying.nframes = pending, flying.ntiles = L.ntiles, flying.first_frame = nframes - pending;
+			next_buf ^= 1;
+			cur_stage ^= 1;
 			pending = 0;
 			uploaded = 0;
 			return true;
+		}
+		// the chunk in flight, if any: waited for and handed to the writer
+		bool collect_flying()
+		{
+			if (!flying.active)
+				return true;
+			flying.active = false;
+			if (!hip_ok(wait_event(fly_ev), "sync"))
+				return false;
+			const OutLayout o = out_layout(flying.ntiles);
+			const char *hb = h_out[flying.buf].as<char>();
+			const uint64_t *coff = reinterpret_cast<const uint64_t *>(hb + o.coff_at());
+			if (coff[0] != 0 || coff[1] > o.pay_max / 8)
+			{
+				log_error("h264 saver: the encoder left no chunk length");
+				return false;
+			}
+			WriteJob j;
+			j.hdr_n = o.hdr_n, j.toff_n = o.toff_n, j.hdr_b = o.hdr_b, j.toff_b = o.toff_b, j.words = coff[1], j.buf = flying.buf;
+			return queue_write(j, flying.nframes, flying.first_frame, flying.ntiles);
 		}
 
 		// frames [uploaded, upto) of the chunk being assembled: page-locked staging -> device
@@ -876,7 +983,7 @@ namespace
 			if (upto <= uploaded)
 				return true;
 			const size_t fbytes = (size_t)width * height * 2;
-			if (!hip_ok(hipMemcpyAsync(cc.d_frames.as<char>() + (size_t)uploaded * fbytes, cc.h_frames.as<char>() + (size_t)uploaded * fbytes,
+			if (!hip_ok(hipMemcpyAsync(cc.d_frames.as<char>() + (size_t)uploaded * fbytes, stage_ptr() + (size_t)uploaded * fbytes,
 									   (size_t)(upto - uploaded) * fbytes, hipMemcpyHostToDevice, default_stream()),
 						"H2D frames"))
 				return false;
@@ -895,11 +1002,12 @@ namespace
 			// copy it into the chunk's page-locked slot, then upload that slot asynchronously - the transfer overlaps
 			// with the caller preparing its next frame.  (Uploading straight from the caller's pointer saves 13 us per
 			// 640x512 frame but leans on how the runtime treats pageable / pinned sources; not worth the risk.)
-			char *slot = cc.h_frames.as<char>() + (size_t)pending * fbytes;
+			char *slot = stage_ptr() + (size_t)pending * fbytes;
 			host_copy(slot, img, fbytes);
-			// uploads go in groups of a few frames (one asynchronous copy each: the call overhead of a copy per frame was a sixth
-			// of the time of this function); what is left of a chunk goes when the chunk is flushed
-			if (pending + 1 - uploaded >= kUploadGroup && !upload_staged(pending + 1))
+			// A chunk made of such frames only is encoded from where they lie (submit_staged_chunk).  Without that (RIR_ABI_ZERO_COPY=0, or a
+			// chunk that already holds device frames) uploads go in groups of a few frames, one asynchronous copy each; what is left of a
+			// chunk goes when the chunk is flushed
+			if ((!abi_zero_copy() || uploaded > 0) && pending + 1 - uploaded >= kUploadGroup && !upload_staged(pending + 1))
 				return false;
 			return frame_added(ts, attrs);
 		}
@@ -948,6 +1056,9 @@ namespace
 				pending = 0, uploaded = 0, raw_from = -1, raw_uploaded = 0;
 				deferred.clear();
 			}
+			if (!failed)
+				ok = collect_flying() && ok;
+			flying.active = false;
 			stop_writer(); // every chunk is in the file from here on
 			ok = ok && !write_failed;
 			FileHeader hd;
@@ -955,8 +1066,9 @@ namespace
 			std::memcpy(hd.magic, "RIRBLOCK", 8);
 			hd.version = 1;
 			hd.width = width, hd.height = height, hd.gop = chunk_gop, hd.fps = fps;
-			hd.index_offset = (uint64_t)std::ftell(fp);
+			hd.index_offset = file_pos; // (the chunks went through pwrite: the stream's own position has not moved since the header)
 			hd.nframes = nframes, hd.nchunks = index.size();
+			ok = ok && std::fseek(fp, (long)file_pos, SEEK_SET) == 0;
 			if (index.size())
 				ok = ok && std::fwrite(index.data(), sizeof(IndexEntry), index.size(), fp) == index.size();
 			std::fseek(fp, sizeof(FtypBox), SEEK_SET);
@@ -1020,10 +1132,11 @@ namespace
 		std::vector<IndexEntry> index;
 		ChunkCodec cc;
 		int cached_chunk = -1;
-		// Sequential readers: while the images of chunk k are handed out from page-locked memory, a helper thread reads chunk
-		// k + 1 from the file, decodes it on a second stream into the buffers of `nx` and brings its images to the host; when
-		// the reader gets there the two buffer sets are swapped.
-		ChunkCodec nx;
+		// Sequential readers: while the images of chunk k are handed out from page-locked memory, helper threads ("lanes") read chunks
+		// k + 1 and k + 2 from the file and decode them, each on a stream and into a buffer set (`nx`) of its own, so that their images are
+		// in page-locked memory when the reader gets there; the lane's buffer set and the current one are then swapped.
+		static constexpr int kLanes = 2;
+		ChunkCodec nx[kLanes];
 		struct Prefetch
 		{
 			std::thread th;
@@ -1034,7 +1147,7 @@ namespace
 			bool busy = false, ok = false, quit = false;
 			hipStream_t stream = nullptr;
 			int device = 0;
-		} pf;
+		} pf[kLanes];
 		// sequential read-ahead: images [host_first, host_end) of chunk host_chunk are (being) copied to cc.h_frames
 		int seq_run = 0, host_chunk = -1, host_base = 0, host_first = 0, host_end = 0;
 		bool host_pending = false;
@@ -1081,6 +1194,19 @@ namespace
 				d += r, off += (uint64_t)r, n -= (size_t)r;
 			}
 			return true;
+		}
+
+		// a chunk's tables / payload: the same, cut over the helper threads (host_copy.cpp)
+		bool read_at_large(uint64_t off, void *dst, size_t n)
+		{
+			if (!fp)
+			{
+				if (off + n > mem.size())
+					return false;
+				host_copy(dst, mem.data() + off, n);
+				return true;
+			}
+			return host_pread(fileno(fp), dst, n, (int64_t)off);
 		}
 
 		bool open_common()
@@ -1350,13 +1476,13 @@ namespace
 			uint64_t *payload = reinterpret_cast<uint64_t *>(ctx.h_in.as<char>() + hdr_b + toff_b);
 			// (the previous uploads from this buffer have completed: this function waits for its stream before it returns)
 			uint64_t off = e.file_offset + sizeof(ch);
-			if (!read_at(off, hdr, hdr_b))
+			if (!read_at_large(off, hdr, hdr_b))
 				return false;
 			off += hdr_b;
 			if (!read_at(off, toff, toff_n * 4))
 				return false;
 			off += toff_n * 4;
-			if (ch.payload_words && !read_at(off, payload, (size_t)ch.payload_words * 8))
+			if (ch.payload_words && !read_at_large(off, payload, (size_t)ch.payload_words * 8))
 				return false;
 			payload[ch.payload_words] = 0;
 			// the offsets table comes from the file: monotone and ending exactly at the payload length, or the chunk is
@@ -1370,11 +1496,29 @@ namespace
 			coff[0] = 0, coff[1] = ch.payload_words;
 			int *flags = reinterpret_cast<int *>(coff + 2); // [0] zero for the device's error word, [1] the word read back
 			flags[0] = 0, flags[1] = 0;
+			// A chunk that is only wanted on the host (the read-ahead of a sequential reader, no read-back filter in play) is decoded where
+			// it lies: the kernel reads tables and payload from this page-locked buffer and writes the images into ctx.h_frames, both over
+			// the link, at the link's rate (tests/perf/zero_copy_probe.py: 667 us for 50 frames of 640x512 against 590 for the bare copy of
+			// the images) - no upload calls, no device copy of the chunk, no copy back.  ctx.on_device says which it was.
+			const bool host_only = to_host && abi_zero_copy() && ctx.h_frames.ptr && !(min_T && min_T_rows > 0) && !bp_enabled && !motion_enabled;
+			ctx.on_device = !host_only;
+			if (!hip_ok(hipMemcpyAsync(ctx.d_err.ptr, flags, sizeof(int), hipMemcpyHostToDevice, st), "H2D"))
+				return false;
+			if (host_only)
+			{
+				if (rir_codec_decode_device(reinterpret_cast<unsigned long long *>(hdr), toff, reinterpret_cast<unsigned long long *>(coff),
+											reinterpret_cast<unsigned long long *>(payload), (long long)ch.payload_words, width, height, (int)ch.nframes, ctx.gop,
+											ctx.h_frames.as<unsigned short>(), ctx.d_err.as<int>(), st) != 0 ||
+					!hip_ok(hipMemcpyAsync(flags + 1, ctx.d_err.ptr, sizeof(int), hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
+					return false;
+				if (flags[1])
+					return fail("RIRB file: malformed chunk payload");
+				return true;
+			}
 			if (!hip_ok(hipMemcpyAsync(ctx.d_hdr.ptr, hdr, hdr_b, hipMemcpyHostToDevice, st), "H2D") ||
 				!hip_ok(hipMemcpyAsync(ctx.d_tile_off.ptr, toff, toff_n * 4, hipMemcpyHostToDevice, st), "H2D") ||
 				!hip_ok(hipMemcpyAsync(ctx.d_chunk_off.ptr, coff, 16, hipMemcpyHostToDevice, st), "H2D") ||
-				!hip_ok(hipMemcpyAsync(ctx.d_stream.ptr, payload, pay_n * 8, hipMemcpyHostToDevice, st), "H2D") ||
-				!hip_ok(hipMemcpyAsync(ctx.d_err.ptr, flags, sizeof(int), hipMemcpyHostToDevice, st), "H2D"))
+				!hip_ok(hipMemcpyAsync(ctx.d_stream.ptr, payload, pay_n * 8, hipMemcpyHostToDevice, st), "H2D"))
 				return false;
 			if (rir_codec_decode_device(ctx.d_hdr.as<unsigned long long>(), ctx.d_tile_off.as<unsigned int>(), ctx.d_chunk_off.as<unsigned long long>(),
 										ctx.d_stream.as<unsigned long long>(), (long long)ch.payload_words, width, height, (int)ch.nframes, ctx.gop,
@@ -1400,87 +1544,127 @@ namespace
 			return true;
 		}
 
-		// ---- read-ahead of the next chunk (sequential readers) ----
-		void prefetch_loop()
+		// ---- read-ahead of the next chunks (sequential readers) ----
+		// Two lanes, each a thread with its own stream and buffer set: while the images of chunk k are handed out, one lane has chunk k + 1
+		// (read from the file, decoded, its images in page-locked memory) and the other is busy with chunk k + 2 - a lane's file read
+		// overlaps with the other lane's trip over the link, so the link, not a lane's latency (read + decode + copy: longer than the
+		// reader needs for a chunk), sets the pace.
+		void prefetch_loop(int lane)
 		{
-			(void)hipSetDevice(pf.device);
-			std::unique_lock<std::mutex> lk(pf.mu);
+			Prefetch &p = pf[lane];
+			(void)hipSetDevice(p.device);
+			std::unique_lock<std::mutex> lk(p.mu);
 			for (;;)
 			{
-				pf.cv.wait(lk, [&] { return pf.quit || pf.want >= 0; });
-				if (pf.quit)
+				p.cv.wait(lk, [&] { return p.quit || p.want >= 0; });
+				if (p.quit)
 					return;
-				const int c = pf.want;
-				pf.want = -1, pf.busy = true, pf.ok = false, pf.have = c;
+				const int c = p.want;
+				p.want = -1, p.busy = true, p.ok = false, p.have = c;
 				lk.unlock();
-				const bool ok = nx.prepare(width, height, (int)hd.gop, false) && decode_chunk_into(nx, c, pf.stream, true, true);
+				const bool ok = nx[lane].prepare(width, height, (int)hd.gop, false) && decode_chunk_into(nx[lane], c, p.stream, true, true);
 				lk.lock();
-				pf.ok = ok, pf.busy = false;
-				pf.cv.notify_all();
+				p.ok = ok, p.busy = false;
+				p.cv.notify_all();
 			}
+		}
+		// the lane that has, is fetching or is about to fetch chunk c (-1: none)
+		int lane_of(int c)
+		{
+			for (int l = 0; l < kLanes; ++l)
+			{
+				std::unique_lock<std::mutex> lk(pf[l].mu);
+				if (pf[l].want == c || (pf[l].have == c && (pf[l].busy || pf[l].ok)))
+					return l;
+			}
+			return -1;
 		}
 		void start_prefetch(int c)
 		{
-			if (c < 0 || c >= (int)index.size() || kind != RIRB)
+			if (c < 0 || c >= (int)index.size() || kind != RIRB || lane_of(c) >= 0)
 				return;
-			std::unique_lock<std::mutex> lk(pf.mu);
-			if (pf.busy || pf.want >= 0 || (pf.have == c && pf.ok))
-				return;
-			if (!pf.stream)
+			for (int l = 0; l < kLanes; ++l)
 			{
-				if (hipGetDevice(&pf.device) != hipSuccess || hipStreamCreateWithFlags(&pf.stream, hipStreamNonBlocking) != hipSuccess)
+				Prefetch &p = pf[l];
+				std::unique_lock<std::mutex> lk(p.mu);
+				// a lane is free when it is idle and what it holds is not one of the chunks the reader comes to next
+				const bool holds_next = p.ok && p.have > cached_chunk && p.have <= cached_chunk + kLanes;
+				if (p.busy || p.want >= 0 || holds_next)
+					continue;
+				if (!p.stream)
 				{
-					pf.stream = nullptr;
-					return;
+					if (hipGetDevice(&p.device) != hipSuccess || hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) != hipSuccess)
+					{
+						p.stream = nullptr;
+						return;
+					}
 				}
+				if (!p.th.joinable())
+					p.th = std::thread([this, l] { prefetch_loop(l); });
+				p.want = c, p.have = -1, p.ok = false;
+				p.cv.notify_all();
+				return;
 			}
-			if (!pf.th.joinable())
-				pf.th = std::thread([this] { prefetch_loop(); });
-			pf.want = c, pf.have = -1, pf.ok = false;
-			pf.cv.notify_all();
 		}
 		// true when chunk c was fetched ahead: its buffers become the current ones
 		bool take_prefetched(int c)
 		{
-			std::unique_lock<std::mutex> lk(pf.mu);
-			if (pf.want != c && pf.have != c)
+			const int l = lane_of(c);
+			if (l < 0)
 				return false;
-			pf.cv.wait(lk, [&] { return pf.want < 0 && !pf.busy; });
-			if (pf.have != c || !pf.ok)
+			Prefetch &p = pf[l];
+			std::unique_lock<std::mutex> lk(p.mu);
+			if (p.want != c && p.have != c)
 				return false;
-			cc.swap_with(nx);
-			pf.have = -1, pf.ok = false;
+			p.cv.wait(lk, [&] { return p.want < 0 && !p.busy; });
+			if (p.have != c || !p.ok)
+				return false;
+			cc.swap_with(nx[l]);
+			p.have = -1, p.ok = false;
 			return true;
 		}
 		void stop_prefetch()
 		{
+			for (int l = 0; l < kLanes; ++l)
 			{
-				std::unique_lock<std::mutex> lk(pf.mu);
-				pf.cv.wait(lk, [&] { return pf.want < 0 && !pf.busy; });
-				pf.quit = true;
+				Prefetch &p = pf[l];
+				{
+					std::unique_lock<std::mutex> lk(p.mu);
+					p.cv.wait(lk, [&] { return p.want < 0 && !p.busy; });
+					p.quit = true;
+				}
+				p.cv.notify_all();
+				if (p.th.joinable())
+					p.th.join();
+				if (p.stream)
+					(void)hipStreamDestroy(p.stream);
+				p.stream = nullptr;
 			}
-			pf.cv.notify_all();
-			if (pf.th.joinable())
-				pf.th.join();
-			if (pf.stream)
-				(void)hipStreamDestroy(pf.stream);
-			pf.stream = nullptr;
 		}
 
-		bool decode_chunk(int c)
+		bool decode_chunk(int c, bool need_device = true)
 		{
-			if (c == cached_chunk)
+			if (c == cached_chunk && (cc.on_device || !need_device))
 				return true;
 			if (!device_ready())
 				return false;
-			if (take_prefetched(c))
+			if (host_pending)
+			{ // (images of the current chunk are still on their way into cc.h_frames: those buffers are about to change hands)
+				if (!hip_ok(wait_stream(default_stream()), "sync"))
+					return false;
+				host_pending = false;
+			}
+			if (c != cached_chunk && take_prefetched(c))
 			{ // decoded ahead, images already in page-locked memory
 				const IndexEntry &e = index[c];
 				cached_chunk = c;
 				host_chunk = c, host_base = (int)e.first_frame, host_first = (int)e.first_frame, host_end = (int)(e.first_frame + e.nframes);
 				host_pending = false;
-				return true;
+				if (cc.on_device || !need_device)
+					return true;
 			}
+			// (also: the chunk is here, but only on the host, and its device copy is asked for - a read-back filter was switched on
+			// after the read-ahead had fetched it: it is decoded again, into device memory this time)
 			cached_chunk = -1, host_chunk = -1;
 			if (!decode_chunk_into(cc, c, default_stream(), false, false))
 				return false;
@@ -1489,7 +1673,7 @@ namespace
 		}
 
 		// Device address of decoded frame `pos` (RIRB files; decodes its chunk when it is not the cached one).
-		const unsigned short *device_frame(int pos)
+		int chunk_of(int pos) const
 		{
 			int c = (int)(pos / (int)hd.gop); // chunks hold `gop` frames except possibly the last
 			if (c >= (int)index.size() || (uint64_t)pos < index[c].first_frame || (uint64_t)pos >= index[c].first_frame + index[c].nframes)
@@ -1498,10 +1682,13 @@ namespace
 				for (size_t i = 0; i < index.size(); ++i)
 					if ((uint64_t)pos >= index[i].first_frame && (uint64_t)pos < index[i].first_frame + index[i].nframes)
 						c = (int)i;
-				if (c < 0)
-					return nullptr;
 			}
-			if (!decode_chunk(c))
+			return c;
+		}
+		const unsigned short *device_frame(int pos)
+		{
+			const int c = chunk_of(pos);
+			if (c < 0 || !decode_chunk(c, true))
 				return nullptr;
 			return cc.d_frames.as<unsigned short>() + (size_t)(pos - (int)index[c].first_frame) * width * height;
 		}
@@ -1525,10 +1712,16 @@ namespace
 			const unsigned short *d = nullptr;
 			if (!on_host())
 			{ // the chunk of `pos` becomes the current one - decoded now, or taken over from the read-ahead thread with its images
-			  // already in page-locked memory
-				d = device_frame(pos);
-				if (!d)
+			  // already in page-locked memory (and then possibly nowhere else)
+				const int c = chunk_of(pos);
+				if (c < 0 || !decode_chunk(c, false))
 					return false;
+				if (!on_host())
+				{
+					d = device_frame(pos);
+					if (!d)
+						return false;
+				}
 			}
 			if (on_host())
 			{
@@ -1537,7 +1730,10 @@ namespace
 				host_pending = false;
 				host_copy(out, cc.h_frames.as<char>() + (size_t)(pos - host_base) * fbytes, fbytes);
 				if (track && seq_run >= 2)
-					start_prefetch(cached_chunk + 1); // (no-op when it is under way, done, or there is no next chunk)
+				{ // (no-ops when they are under way, done, or there is no such chunk)
+					start_prefetch(cached_chunk + 1);
+					start_prefetch(cached_chunk + 2);
+				}
 				return true;
 			}
 			if (!hip_ok(hipMemcpyAsync(out, d, fbytes, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))

@@ -395,3 +395,112 @@ def test_per_frame_abi_round_trip_rate(tmp_path):
     fps = n / (te + td)
     print("per-frame ABI: record %.0f fps, read %.0f fps, round trip %.0f fps" % (n / te, n / td, fps))
     assert fps >= 8000, (n / te, n / td, fps)
+
+
+_RECORD_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from librir_amd.synthetic import s1_noisy_background
+from librir_amd.video_io import IRSaver
+h, w, n, gop = 67, 83, 53, 8
+arr = s1_noisy_background(n, h, w)
+with IRSaver(sys.argv[2], w, h, h) as s:
+    s.set_parameter("GOP", gop)
+    s.set_global_attributes({"who": "zero-copy test"})
+    for i in range(n):
+        s.add_image(arr[i], i * 1000, attributes={"i": str(i)})
+"""
+
+
+def test_chunks_encoded_from_page_locked_memory_give_the_same_file(tmp_path):
+    """Round 5: a chunk of add_image frames is encoded where it was staged - the kernels read the page-locked frames over the link and
+    write tables and payload into the writer's page-locked buffer.  The FILE must be the one the copying path writes (RIR_ABI_ZERO_COPY=0,
+    the path of rounds 1-4), byte for byte: a ragged frame size (tiles cut by the end of the frame), several chunks, a short last one."""
+    import hashlib
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for mode in ("1", "0"):
+        dst = tmp_path / ("zc%s.h264" % mode)
+        env = dict(os.environ, RIR_ABI_ZERO_COPY=mode)
+        r = subprocess.run([sys.executable, "-c", _RECORD_SCRIPT, root, str(dst)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+        assert r.returncode == 0, r.stdout.decode()[-2000:]
+        digests[mode] = hashlib.sha256(dst.read_bytes()).hexdigest()
+    assert digests["1"] == digests["0"]
+    arr = s1_noisy_background(53, 67, 83)
+    with IRMovie.from_filename(tmp_path / "zc1.h264") as mov:
+        assert np.array_equal(mov.data, arr)
+        mov.load_pos(17)
+        assert mov.frame_attributes == {"i": b"17"}
+
+
+def test_lossless_and_bounded_loss_frames_in_one_chunk(tmp_path):
+    """A chunk that holds both kinds of frames takes the copying path (its bounded-loss frames are produced in device memory); chunks of
+    lossless frames before and after it are encoded from page-locked memory and are collected in file order."""
+    h, w, gop = 48, 64, 6
+    arr = images(40, h, w)
+    dst = tmp_path / "mixed.h264"
+    lossy_at = set(range(14, 21)) | {33}
+    with IRSaver(dst, w, h, h) as s:
+        s.set_parameter("GOP", gop)
+        s.set_parameter("lowValueError", 2)
+        s.set_parameter("highValueError", 2)
+        s.set_parameter("stdFactor", 0)
+        for i in range(40):
+            if i in lossy_at:
+                s.add_image_lossy(arr[i], i * 1000)
+            else:
+                s.add_image(arr[i], i * 1000)
+    with IRMovie.from_filename(dst) as mov:
+        data = mov.data
+    for i in range(40):
+        if i in lossy_at:
+            assert np.abs(data[i].astype(np.int32) - arr[i]).max() <= 4, i
+        else:
+            assert np.array_equal(data[i], arr[i]), i
+
+
+def test_filters_switched_on_under_the_read_ahead(tmp_path, oracle):
+    """The read-ahead decodes chunks straight into page-locked memory when no read-back filter is on; a filter switched on afterwards
+    needs the chunk in device memory and must get it (decoded again), and reads after the filter is switched off again go back to
+    the page-locked images - every image as recorded / as the oracle repairs it."""
+    h, w, n = 40, 96, 64
+    arr = inject_bad_pixels(images(n, h, w), 7)
+    dst = tmp_path / "ahead.h264"
+    with IRSaver(dst, w, h, h) as s:
+        s.set_parameter("GOP", 8)
+        for i in range(n):
+            s.add_image(arr[i], i * 1000)
+    xy = oracle.bad_pixels_detect(arr[0][: h - 3])
+    cam = rv.open_camera_file(dst)
+    for i in range(20):  # sequential: the lanes are ahead by now
+        assert np.array_equal(rv.load_image(cam, i), arr[i]), i
+    rv.enable_bad_pixels(cam, True)
+    for i in (20, 21, 22, 23, 24, 25, 30, 31):  # inside the chunk being handed out, then the ones fetched ahead
+        assert np.array_equal(rv.load_image(cam, i), oracle.remove_bad_pixels(arr[i], xy, rows=h - 3)), i
+    rv.enable_bad_pixels(cam, False)
+    for i in list(range(32, n)) + [3, 4, 5, 6, 7, 8, 9, 10]:
+        assert np.array_equal(rv.load_image(cam, i), arr[i]), i
+    rv.close_camera(cam)
+
+
+def test_many_chunks_sequential_and_strided(tmp_path):
+    """Forty chunks through the two read-ahead lanes: sequential, then every third image (each chunk is still visited in order), then
+    backwards - what is handed out is what was recorded."""
+    h, w, n, gop = 64, 80, 200, 5
+    arr = images(n, h, w)
+    dst = tmp_path / "lanes.h264"
+    with IRSaver(dst, w, h, h) as s:
+        s.set_parameter("GOP", gop)
+        for i in range(n):
+            s.add_image(arr[i], i * 1000)
+    with IRMovie.from_filename(dst) as mov:
+        for i in range(n):
+            assert np.array_equal(mov[i], arr[i]), i
+        for i in range(0, n, 3):
+            assert np.array_equal(mov[i], arr[i]), i
+        for i in range(n - 1, -1, -7):
+            assert np.array_equal(mov[i], arr[i]), i
