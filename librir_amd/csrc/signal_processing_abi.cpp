@@ -157,23 +157,44 @@ namespace
 		return s;
 	}
 	// The caller's images are pageable memory.  Handed to hipMemcpyAsync as they are, the runtime stages them itself, a chunk at a time on
-	// the calling thread (measured, one 640x512 image: 70-130 us each way); staged here - the copy cut over the helper threads
-	// (host_copy.cpp), then ONE transfer from / to page-locked memory - an image crosses in 20-35 us.  `slot`: byte offset in the staging
-	// buffer (a call may upload two images before anything runs).
-	bool upload(HostScratch &s, void *d_dst, const void *h_src, size_t bytes, size_t slot, hipStream_t st)
+	// the calling thread (measured, one 640x512 image: 70-130 us each way).  Here an image is staged in page-locked memory - the copy cut
+	// over the helper threads (host_copy.cpp) - and the KERNEL works on the staging buffers themselves, reading its input and writing its
+	// result over the link (tests/perf/zero_copy_probe.py: translate of a float image 54 us that way, 89 us with a copy in and a copy out,
+	// before the copy calls' own cost): no copy call, one launch, one wait.  RIR_ABI_ZERO_COPY=0: a transfer into / out of device buffers
+	// around the kernel, as before.  `slot`: byte offset in the input staging buffer (a call may stage two images).
+	// -> the address the kernel reads (nullptr on failure)
+	const void *stage_in(HostScratch &s, DeviceBuffer &d, const void *h_src, size_t bytes, size_t slot, hipStream_t st)
 	{
 		if (!s.h_in.ptr || s.h_in.cap < slot + bytes)
-			return false;
+			return nullptr;
 		char *stage = s.h_in.as<char>() + slot;
 		host_copy(stage, h_src, bytes);
-		return hip_ok(hipMemcpyAsync(d_dst, stage, bytes, hipMemcpyHostToDevice, st), "H2D");
+		if (abi_zero_copy())
+			return stage;
+		if (!d.reserve(bytes) || !hip_ok(hipMemcpyAsync(d.ptr, stage, bytes, hipMemcpyHostToDevice, st), "H2D"))
+			return nullptr;
+		return d.ptr;
 	}
-	// the call's result: device -> staging, wait for the stream (the call is synchronous), staging -> caller
-	bool download(HostScratch &s, void *h_dst, const void *d_src, size_t bytes, hipStream_t st)
+	// -> the address the kernel writes its result to (nullptr on failure); keep: the caller's buffer holds values the kernel keeps
+	// (translate "noborder"), it goes in first
+	void *stage_out(HostScratch &s, DeviceBuffer &d, void *h_dst, size_t bytes, bool keep, hipStream_t st)
 	{
 		if (!s.h_out.reserve(bytes))
+			return nullptr;
+		if (keep)
+			host_copy(s.h_out.ptr, h_dst, bytes);
+		if (abi_zero_copy())
+			return s.h_out.ptr;
+		if (!d.reserve(bytes) || (keep && !hip_ok(hipMemcpyAsync(d.ptr, s.h_out.ptr, bytes, hipMemcpyHostToDevice, st), "H2D")))
+			return nullptr;
+		return d.ptr;
+	}
+	// the call's result (at `from`, what stage_out returned) -> the caller: waits for the stream (the call is synchronous)
+	bool hand_out(HostScratch &s, void *h_dst, const void *from, size_t bytes, hipStream_t st)
+	{
+		if (from != s.h_out.ptr && !hip_ok(hipMemcpyAsync(s.h_out.ptr, from, bytes, hipMemcpyDeviceToHost, st), "D2H"))
 			return false;
-		if (!hip_ok(hipMemcpyAsync(s.h_out.ptr, d_src, bytes, hipMemcpyDeviceToHost, st), "D2H") || !hip_ok(wait_stream(st), "sync"))
+		if (!hip_ok(wait_stream(st), "sync"))
 			return false;
 		host_copy(h_dst, s.h_out.ptr, bytes);
 		return true;
@@ -594,18 +615,20 @@ RIR_EXPORT int translate(int type, void *src, void *dst, int w, int h, float dx,
 	const size_t bytes = (size_t)w * h * es;
 	hipStream_t st = default_stream();
 	const bool keeps_dst = strategy_from_string(strategy) == TRANSLATE_UNCHANGED;
-	if (!s.a.reserve(bytes) || !s.b.reserve(bytes) || !s.c.reserve(8) || !s.h_in.reserve(2 * bytes + 64))
+	const size_t off_at = (bytes + 63) & ~(size_t)63;
+	if (!s.h_in.reserve(off_at + 64))
 		return -1;
 	// dst is an in/out buffer: "noborder" keeps whatever the caller put there (Filters.h:261-264), so only that
-	// strategy needs the caller's dst on the device; the others write every pixel
-	float *off = reinterpret_cast<float *>(s.h_in.as<char>() + 2 * bytes);
+	// strategy needs the caller's dst where the kernel works; the others write every pixel
+	float *off = reinterpret_cast<float *>(s.h_in.as<char>() + off_at); // (page-locked: the kernel reads the two floats from there)
 	off[0] = dx, off[1] = dy;
-	if (!upload(s, s.a.ptr, src, bytes, 0, st) || (keeps_dst && !upload(s, s.b.ptr, dst, bytes, bytes, st)) ||
-		!hip_ok(hipMemcpyAsync(s.c.ptr, off, 2 * sizeof(float), hipMemcpyHostToDevice, st), "H2D"))
+	const void *in = stage_in(s, s.a, src, bytes, 0, st);
+	void *out = in ? stage_out(s, s.b, dst, bytes, keeps_dst, st) : nullptr;
+	if (!in || !out)
 		return -1;
-	if (rir_translate_device(type, s.a.ptr, s.b.ptr, w, h, 1, s.c.as<float>(), 0, background, strategy, st) != 0)
+	if (rir_translate_device(type, in, out, w, h, 1, off, 0, background, strategy, st) != 0)
 		return -1;
-	return download(s, dst, s.b.ptr, bytes, st) ? 0 : -1;
+	return hand_out(s, dst, out, bytes, st) ? 0 : -1;
 }
 
 RIR_EXPORT int gaussian_filter(float *src, float *dst, int w, int h, float sigma)
@@ -618,13 +641,15 @@ RIR_EXPORT int gaussian_filter(float *src, float *dst, int w, int h, float sigma
 	std::lock_guard<std::mutex> g(s.mu);
 	const size_t bytes = (size_t)w * h * sizeof(float);
 	hipStream_t st = default_stream();
-	if (!s.a.reserve(bytes) || !s.b.reserve(bytes) || !s.h_in.reserve(bytes))
+	if (!s.h_in.reserve(bytes))
 		return -1;
-	if (!upload(s, s.a.ptr, src, bytes, 0, st))
+	const void *in = stage_in(s, s.a, src, bytes, 0, st);
+	void *out = in ? stage_out(s, s.b, dst, bytes, false, st) : nullptr;
+	if (!in || !out)
 		return -1;
-	if (rir_gaussian_filter_device(s.a.as<float>(), s.b.as<float>(), w, h, 1, sigma, st) != 0)
+	if (rir_gaussian_filter_device(static_cast<const float *>(in), static_cast<float *>(out), w, h, 1, sigma, st) != 0)
 		return -1;
-	return download(s, dst, s.b.ptr, bytes, st) ? 0 : -1;
+	return hand_out(s, dst, out, bytes, st) ? 0 : -1;
 }
 
 static int find_median_host(unsigned short *pixels, unsigned char *mask, int size, float percent)
@@ -637,14 +662,13 @@ static int find_median_host(unsigned short *pixels, unsigned char *mask, int siz
 	std::lock_guard<std::mutex> g(s.mu);
 	hipStream_t st = default_stream();
 	const size_t pbytes = (size_t)size * 2, mslot = (pbytes + 63) & ~(size_t)63;
-	if (!s.a.reserve(pbytes) || !s.b.reserve(65536 * sizeof(uint32_t)) || !s.c.reserve(sizeof(int)) || (mask && !s.d.reserve((size_t)size)) ||
-		!s.h_in.reserve(mslot + (mask ? (size_t)size : 0)))
+	if (!s.b.reserve(65536 * sizeof(uint32_t)) || !s.c.reserve(sizeof(int)) || !s.h_in.reserve(mslot + (mask ? (size_t)size : 0)))
 		return -1;
-	if (!upload(s, s.a.ptr, pixels, pbytes, 0, st))
+	const void *px = stage_in(s, s.a, pixels, pbytes, 0, st);
+	const void *mk = mask ? stage_in(s, s.d, mask, (size_t)size, mslot, st) : nullptr;
+	if (!px || (mask && !mk))
 		return -1;
-	if (mask && !upload(s, s.d.ptr, mask, (size_t)size, mslot, st))
-		return -1;
-	if (rir_find_median_pixel_device(s.a.as<unsigned short>(), mask ? s.d.as<unsigned char>() : nullptr, size, 1, percent, s.c.as<int>(),
+	if (rir_find_median_pixel_device(static_cast<const unsigned short *>(px), static_cast<const unsigned char *>(mk), size, 1, percent, s.c.as<int>(),
 									 s.b.as<unsigned int>(), st) != 0)
 		return -1;
 	int res = 0;
@@ -670,7 +694,11 @@ RIR_EXPORT int bad_pixels_create(unsigned short *first_image, int width, int hei
 	std::lock_guard<std::mutex> g(s.mu);
 	hipStream_t st = default_stream();
 	const size_t bytes = (size_t)width * height * 2;
-	if (!s.a.reserve(bytes) || !s.h_in.reserve(bytes) || !upload(s, s.a.ptr, first_image, bytes, 0, st))
+	// (the detector makes several passes over the image: it goes to device memory, whatever the switch says)
+	if (!s.a.reserve(bytes) || !s.h_in.reserve(bytes))
+		return 0;
+	host_copy(s.h_in.ptr, first_image, bytes);
+	if (!hip_ok(hipMemcpyAsync(s.a.ptr, s.h_in.ptr, bytes, hipMemcpyHostToDevice, st), "H2D"))
 		return 0;
 	return rir_bad_pixels_create_device(s.a.as<unsigned short>(), width, height, st);
 }
@@ -688,13 +716,15 @@ RIR_EXPORT int bad_pixels_correct(int handle, unsigned short *in, unsigned short
 	std::lock_guard<std::mutex> g(s.mu);
 	hipStream_t st = default_stream();
 	const size_t bytes = (size_t)bp->width * bp->height * 2;
-	if (!s.a.reserve(bytes) || !s.b.reserve(bytes) || !s.h_in.reserve(bytes))
+	if (!s.h_in.reserve(bytes))
 		return -1;
-	if (!upload(s, s.a.ptr, in, bytes, 0, st))
+	const void *src = stage_in(s, s.a, in, bytes, 0, st);
+	void *dst = src ? stage_out(s, s.b, out, bytes, false, st) : nullptr;
+	if (!src || !dst)
 		return -1;
-	if (rir_bad_pixels_correct_device(handle, s.a.as<unsigned short>(), s.b.as<unsigned short>(), 1, st) != 0)
+	if (rir_bad_pixels_correct_device(handle, static_cast<const unsigned short *>(src), static_cast<unsigned short *>(dst), 1, st) != 0)
 		return -1;
-	return download(s, out, s.b.ptr, bytes, st) ? 0 : -1;
+	return hand_out(s, out, dst, bytes, st) ? 0 : -1;
 }
 
 RIR_EXPORT void bad_pixels_destroy(int handle)

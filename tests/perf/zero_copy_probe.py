@@ -89,3 +89,51 @@ assert np.array_equal(o_pin.numpy(), fr) and int(err.item()) == 0
 print("decode to host == input")
 timed(lambda: f_dev.copy_(f_pin, non_blocking=True), "hipMemcpyAsync H2D of the chunk (for comparison)", raw)
 timed(lambda: o_pin.copy_(f_dev, non_blocking=True), "hipMemcpyAsync D2H of the chunk (for comparison)", raw)
+
+# ---- the frame-buffer kernels on one image in page-locked host memory (the per-frame signal_processing entry points) ----
+img = torch.from_numpy(fr[0].copy())
+f32 = img.to(torch.float32)
+
+
+def pinned(t):
+    p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    p.copy_(t)
+    assert p.is_pinned()
+    return p
+
+
+shift_dev = torch.tensor([1.25, -2.5], dtype=torch.float32, device=dev)
+bg = np.zeros(1, np.float64)
+for name, src in (("u16", img), ("f32", f32)):
+    s_dev, s_pin = src.to(dev), pinned(src)
+    d_dev, d_pin = torch.empty_like(s_dev), pinned(torch.zeros_like(src))
+    ch = D._DTYPE_CHARS[src.dtype].encode()
+    nbytes = src.numel() * src.element_size()
+
+    def tr(a, b):
+        bgv = np.zeros(1, D._NP_OF[src.dtype])
+        r = L_.rir_translate_device(ord(ch), a.data_ptr(), b.data_ptr(), w, h, 1, shift_dev.data_ptr(), 0, bgv.ctypes.data, b"nearest", st())
+        assert r == 0, D.last_error()
+
+    timed(lambda: tr(s_dev, d_dev), "translate %s: HBM -> HBM" % name, 2 * nbytes)
+    timed(lambda: tr(s_pin, d_dev), "translate %s: HOST -> HBM" % name, nbytes)
+    timed(lambda: tr(s_dev, d_pin), "translate %s: HBM -> HOST" % name, nbytes)
+    timed(lambda: tr(s_pin, d_pin), "translate %s: HOST -> HOST" % name, 2 * nbytes)
+    torch.cuda.synchronize()
+    assert torch.equal(d_pin, d_dev.cpu())
+    timed(lambda: (s_dev.copy_(s_pin, non_blocking=True), tr(s_dev, d_dev), d_pin.copy_(d_dev, non_blocking=True)), "translate %s: copy in, HBM -> HBM, copy out" % name,
+          2 * nbytes)
+s_dev, s_pin = f32.to(dev), pinned(f32)
+d_dev, d_pin = torch.empty_like(s_dev), pinned(torch.zeros_like(f32))
+
+
+def ga(a, b):
+    assert L_.rir_gaussian_filter_device(a.data_ptr(), b.data_ptr(), w, h, 1, ct.c_float(0.75), st()) == 0, D.last_error()
+
+
+nb = f32.numel() * 4
+timed(lambda: ga(s_dev, d_dev), "gaussian f32: HBM -> HBM", 2 * nb)
+timed(lambda: ga(s_pin, d_pin), "gaussian f32: HOST -> HOST", 2 * nb)
+timed(lambda: (s_dev.copy_(s_pin, non_blocking=True), ga(s_dev, d_dev), d_pin.copy_(d_dev, non_blocking=True)), "gaussian f32: copy in, HBM -> HBM, copy out", 2 * nb)
+torch.cuda.synchronize()
+assert torch.equal(d_pin, d_dev.cpu())
