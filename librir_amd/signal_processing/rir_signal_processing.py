@@ -55,8 +55,9 @@ def translate(image, dx, dy, strategy=str(), background=None):
     strat = toCharP(strategy)
     if strat == b"constant":
         strat = b"background"
-    src = np.array(image, order="C", copy=True)
-    dst = np.array(image, order="C", copy=True)  # "noborder" leaves these values in place
+    src = np.ascontiguousarray(image)  # (the library reads it and leaves it alone: no copy of an array that is contiguous already)
+    # "noborder" leaves the values of the pixels it does not reach in place: only then does the result start as a copy of the image
+    dst = np.array(image, order="C", copy=True) if strat in (b"", b"noborder") else np.empty(src.shape, dtype=src.dtype)
     back = np.zeros(1, dtype=image.dtype)
     if background is not None:
         back[0] = background
@@ -72,8 +73,8 @@ def gaussian_filter(image, sigma=1.0):
     image = np.asarray(image)
     if image.ndim != 2:
         raise RuntimeError("gaussian_filter: wrong input image dimension")
-    src = np.array(image, dtype=np.float32, order="C")
-    dst = np.zeros(image.shape, dtype=np.float32)
+    src = np.ascontiguousarray(image, dtype=np.float32)
+    dst = np.empty(image.shape, dtype=np.float32)  # (the library writes every pixel or fails)
     r = _sp.gaussian_filter(src.ctypes.data, dst.ctypes.data, src.shape[1], src.shape[0], np.float32(sigma))
     if r < 0:
         raise RuntimeError("An error occured while calling 'gaussian_filter': " + last_error())
@@ -112,7 +113,7 @@ def bad_pixels_correct(handle, img):
     if img.ndim != 2:
         raise RuntimeError("bad_pixels_correct: wrong input image dimension")
     src = np.ascontiguousarray(img, dtype=np.uint16)
-    out = np.zeros(src.shape, dtype=np.uint16)
+    out = np.empty(src.shape, dtype=np.uint16)  # (the library writes every pixel or fails)
     r = _sp.bad_pixels_correct(handle, src.ctypes.data, out.ctypes.data)
     if r < 0:
         raise RuntimeError("An error occured while calling 'bad_pixels_correct': " + last_error())

@@ -211,10 +211,13 @@ def batched_chain():
 
 ms = gpu_ms(batched_chain, 5)
 c2["batched_h2d_d2h_fps"] = n2 / ms * 1e3
-nabi2 = 20 if args.quick else 60
+nabi2 = 20 if args.quick else min(250, fr2.shape[0])
 with tempfile.TemporaryDirectory() as d:
     dst = os.path.join(d, "abi2.h264")
     hbp = sp.bad_pixels_create(fr2[0])
+    with IRSaver(os.path.join(d, "warm2.h264"), w, h, h) as s:  # (the first calls of a process pay one-off set-up costs)
+        for i in range(5):
+            s.add_image(sp.translate(sp.gaussian_filter(sp.bad_pixels_correct(hbp, fr2[i]).astype(np.float32), 0.75), 1.25, -2.5, "nearest").astype(np.uint16), i)
     t0 = time.perf_counter()
     with IRSaver(dst, w, h, h) as s:
         for i in range(nabi2):
@@ -263,6 +266,34 @@ out["configs[3]"] = {"workload": "per-GPU shard of the 10 000-frame job: %d x %d
                      "note": "the exchange of the decoded / compressed stream is timed by bench.py --gpus N (value_with_exchange, value_with_compressed_exchange)"}
 del t3, dec3, ctx3, pc3
 torch.cuda.empty_cache()
+# the whole 10 000-frame job on ONE device (15.7 GB of raw frames in its 288 GB): the eight shards of the 8-GPU plan back to back, each
+# through the packed form, frames made on the device (tests/test_gpu_configs.py::test_config3_ten_thousand_frames_on_one_device checks them)
+if not args.quick and torch.cuda.mem_get_info()[0] > (40 << 30):
+    nfull, shard = 10000, 1250
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234)
+    bgf = torch.rand((h3, w3), generator=gen, device=dev) * 1000.0
+    whole = torch.empty((nfull, h3, w3), dtype=torch.uint16, device=dev)
+    for f0 in range(0, nfull, 250):
+        ii = torch.arange(f0, f0 + 250, device=dev, dtype=torch.float32).view(-1, 1, 1)
+        whole[f0:f0 + 250] = (bgf + 10.0 + ii + torch.randn((250, h3, w3), generator=gen, device=dev) * (0.5 ** 0.5)).to(torch.int32).to(torch.uint16)
+    pcs = [D.PackedCodec(w3, h3, shard, gop, device=dev) for _ in range(nfull // shard)]  # (every shard keeps its encoded batch, as every rank would)
+    back = torch.empty_like(whole)
+
+    def job():
+        for k, pck in enumerate(pcs):
+            pck.encode(whole[k * shard:(k + 1) * shard])
+        for k, pck in enumerate(pcs):
+            pck.decode(out=back[k * shard:(k + 1) * shard], check=False)
+
+    ms_full = gpu_ms(job, 3)
+    assert torch.equal(back.view(torch.int16), whole.view(torch.int16)) and all(pck.status()[0] == 0 for pck in pcs)
+    out["configs[3]"]["whole_job_on_one_device"] = {
+        "frames": nfull, "raw_bytes": int(whole.numel() * 2), "encoded_bytes": int(sum(pck.finish().nbytes() for pck in pcs)), "ms": ms_full,
+        "fps": nfull / ms_full * 1e3, "raw_GBs": nfull * 4.0 * h3 * w3 / ms_full / 1e6,
+        "note": "10 000 frames 1024x768 resident in one MI355X's HBM: encode of all eight shards, then decode of all eight (16 launches), bit-exact"}
+    del whole, back, pcs
+    torch.cuda.empty_cache()
 
 # ------------------------------------------------------------------ configs[4]: float32 stream, motion correction + bounded loss
 n4 = 60 if args.quick else 300

@@ -102,6 +102,41 @@ def test_config3_shards_are_independent_and_reassemble(dev):
     assert torch.equal(out.view(torch.int16), whole.view(torch.int16))
 
 
+def test_config3_ten_thousand_frames_on_one_device(dev):
+    """BASELINE configs[3] at its stated SIZE - 10 000 frames of 1024x768, 15.7 GB of raw frames - held by ONE MI355X (288 GB): the eight
+    chunk-aligned shards of the 8-GPU plan, one after the other through one packed codec (each shard = what a rank of the real job
+    encodes: 1 250 frames, 1.97 GB), every shard decoded from its own packed batch and compared with its frames on the device.
+    The frames are made on the device from a seed (the S1 recipe's arithmetic: a fixed background + 10 + i + noise of variance 0.5);
+    there is no oracle at this size - the property checked is the one the reference's tests hold: decode(encode(x)) == x, bit for bit,
+    plus the footprint (the recipe's ratio is about 5)."""
+    h, w, gop, n, world = 768, 1024, 50, 10000, 8
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 << 30:
+        pytest.skip("needs 40 GB of free device memory")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    bg = torch.rand((h, w), generator=g, device="cuda") * 1000.0
+    whole = torch.empty((n, h, w), dtype=torch.uint16, device="cuda")
+    for f0 in range(0, n, 250):
+        i = torch.arange(f0, f0 + 250, device="cuda", dtype=torch.float32).view(-1, 1, 1)
+        noise = torch.randn((250, h, w), generator=g, device="cuda") * (0.5 ** 0.5)
+        whole[f0:f0 + 250] = (bg + 10.0 + i + noise).to(torch.int32).to(torch.uint16)
+    plan = shard_plan(n, gop, world)
+    assert [c for _, c in plan] == [1250] * 8 and all(f0 % gop == 0 for f0, _ in plan)
+    pc = D.PackedCodec(w, h, 1250, gop)
+    out = torch.empty((1250, h, w), dtype=torch.uint16, device="cuda")
+    total = 0
+    for f0, cnt in plan:
+        batch = pc.encode(whole[f0:f0 + cnt], check=True)
+        total += batch.nbytes()
+        out.zero_()
+        pc.decode(batch, out=out)
+        assert torch.equal(out.view(torch.int16), whole[f0:f0 + cnt].view(torch.int16)), f0
+    raw = n * h * w * 2
+    assert 3.5 < raw / total < 8.0, raw / total
+    print("configs[3] on one device: %d raw bytes, %d encoded = 1/%.2f" % (raw, total, raw / total))
+
+
 def test_config4_motion_correction_then_bounded_loss(tmp_path, dev, oracle):
     n, h, w = 45, 128, 160
     f32, shifts = s3_registration(n, h, w)
