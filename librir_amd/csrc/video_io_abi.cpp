@@ -487,13 +487,26 @@ namespace
 		PinnedBuffer h_stage_b;
 		int cur_stage = 0; // 0: cc.h_frames, 1: h_stage_b
 		char *stage_ptr() { return cur_stage ? h_stage_b.as<char>() : cc.h_frames.as<char>(); }
+		struct Deferred
+		{ // a bounded-loss frame whose error budget has not been read back yet: its slot of d_err_slots, where the budget goes
+			size_t frame, slot;
+			bool with_attrs;
+		};
 		struct InFlight
 		{
 			bool active = false;
 			int buf = 0, nframes = 0, ntiles = 0;
 			uint64_t first_frame = 0;
+			std::vector<Deferred> defs; // its bounded-loss frames (their budgets are in h_errs when the event has passed)
+			bool have_run = false;
 		};
 		InFlight flying;
+#ifdef RIR_SAVER_DIAG
+		double dg_wait_ev = 0, dg_wait_writer = 0, dg_loss = 0, dg_submit = 0, dg_flush = 0;
+		int dg_n = 0;
+		static double dg_now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#endif
+		PinnedBuffer h_errs; // [ERR_SLOTS][2] budgets of the chunk in flight, then the run kernel's error word and the poison word
 		hipEvent_t fly_ev = nullptr;
 		std::vector<IndexEntry> index;
 		std::vector<int64_t> times;
@@ -653,7 +666,7 @@ namespace
 			raw_from = -1, raw_uploaded = 0;
 			if (n <= 0)
 				return true;
-			if (!up)
+			if (!up || !collect_flying()) // (a run call is made below: the verdict on the calls before it is filed first - LossyObject::checked)
 				return false;
 			const size_t npx = (size_t)width * height;
 			hipStream_t st = default_stream();
@@ -669,11 +682,6 @@ namespace
 		}
 
 		// errors of the frames recorded since the last call: into the error lists and the per-frame attributes
-		struct Deferred
-		{
-			size_t frame, slot;
-			bool with_attrs;
-		};
 		enum
 		{
 			ERR_SLOTS = 256
@@ -691,9 +699,36 @@ namespace
 			log_error("h264 saver: a bounded-loss step failed earlier; this saver takes no more frames (close it: the chunks written before the failure are kept)");
 			return false;
 		}
+		// budgets `e` (pairs, in the order of `defs`) into the error lists and the per-frame attributes; gave_up: the error word of the run
+		// kernel (a wait between workgroups that hit its clock) or the poison word of a launch that was called off, read after the frames
+		bool file_errors(const std::vector<Deferred> &defs, const int *e, unsigned int gave_up, bool have_run)
+		{
+			if (have_run)
+				lossy_obj->checked(gave_up, default_stream());
+			if (gave_up || (lossy_obj && lossy_obj->is_failed()))
+			{ // the loss state has been advanced by invalid frames: nothing recorded from here on can be right (usable())
+				failed = true;
+				log_error("h264 saver: the bounded-loss step of a run of frames gave up waiting (frames invalid)");
+				return false;
+			}
+			for (size_t i = 0; i < defs.size(); ++i)
+			{
+				const Deferred &d = defs[i];
+				low_errors[d.slot] = (unsigned short)e[2 * i];
+				high_errors[d.slot] = (unsigned short)e[2 * i + 1];
+				if (d.with_attrs && d.frame < frame_attrs.size())
+				{
+					frame_attrs[d.frame]["BackgroundError"] = std::to_string(e[2 * i]);
+					frame_attrs[d.frame]["ForegroundError"] = std::to_string(e[2 * i + 1]);
+				}
+			}
+			return true;
+		}
 		bool resolve_errors()
 		{
-			if (!usable() || !run_deferred_loss())
+			// (the chunk in flight first: its budgets are filed in frame order, and the books of the run calls - LossyObject::checked - are
+			// kept in the order the calls were made)
+			if (!usable() || !collect_flying() || !run_deferred_loss())
 				return false;
 			if (deferred.empty())
 				return true;
@@ -707,28 +742,9 @@ namespace
 							  !hip_ok(hipMemcpyAsync(&poison, lossy_obj->run_exchange.as<unsigned int>() + kLossyRunCtlWord + 2, 4, hipMemcpyDeviceToHost, st), "D2H"))) ||
 				!hip_ok(wait_stream(st), "sync"))
 				return false;
-			gave_up |= poison;
-			if (have_run)
-				lossy_obj->checked(gave_up, st);
-			if (gave_up || lossy_obj->is_failed())
-			{ // the loss state has been advanced by invalid frames: nothing recorded from here on can be right (usable())
-				failed = true;
-				log_error("h264 saver: the bounded-loss step of a run of frames gave up waiting (frames invalid)");
-				return false;
-			}
-			for (size_t i = 0; i < deferred.size(); ++i)
-			{
-				const Deferred &d = deferred[i];
-				low_errors[d.slot] = (unsigned short)e[2 * i];
-				high_errors[d.slot] = (unsigned short)e[2 * i + 1];
-				if (d.with_attrs && d.frame < frame_attrs.size())
-				{
-					frame_attrs[d.frame]["BackgroundError"] = std::to_string(e[2 * i]);
-					frame_attrs[d.frame]["ForegroundError"] = std::to_string(e[2 * i + 1]);
-				}
-			}
+			const bool ok = file_errors(deferred, e.data(), gave_up | poison, have_run);
 			deferred.clear();
-			return true;
+			return ok;
 		}
 
 		// H264_Saver::addLoss (h264.cpp:2426-2607): the loss is applied to the caller's image, nothing is written
@@ -835,16 +851,36 @@ namespace
 
 		bool flush_chunk()
 		{
+			hipStream_t st = default_stream();
+			rir_codec_layout L;
+			if (abi_zero_copy() && pending > 0)
+			{ // nothing is waited for but the chunk BEFORE this one: this chunk's loss step, its encode and its error budgets are queued
+#ifdef RIR_SAVER_DIAG
+				const double t0 = dg_now();
+				struct Fin { SaverObject *s; double t0; ~Fin() { s->dg_flush += dg_now() - t0; ++s->dg_n; } } fin{this, t0};
+				if (!usable() || !collect_flying())
+					return false;
+				const double t1 = dg_now();
+				if (!run_deferred_loss())
+					return false;
+				dg_loss += dg_now() - t1;
+#else
+				if (!usable() || !collect_flying() || !run_deferred_loss())
+					return false;
+#endif
+				if (rir_codec_layout_query(width, height, pending, chunk_gop, &L) != 0)
+					return false;
+				const bool staged_only = uploaded == 0; // every frame came through add_image and lies in the staging buffer
+				if (!staged_only && !upload_staged(pending))
+					return false;
+				return submit_chunk(staged_only ? reinterpret_cast<const unsigned short *>(stage_ptr()) : cc.d_frames.as<unsigned short>(), L, st);
+			}
 			if (!resolve_errors())
 				return false;
 			if (pending == 0)
 				return true;
-			hipStream_t st = default_stream();
-			rir_codec_layout L;
 			if (rir_codec_layout_query(width, height, pending, chunk_gop, &L) != 0)
 				return false;
-			if (abi_zero_copy() && uploaded == 0)
-				return submit_staged_chunk(L, st);
 			if (!collect_flying()) // (this path waits for its own chunk: the one before it goes to the file first)
 				return false;
 			// the frames are in cc.d_frames: uploaded in groups (or produced there) as they were added; the last group goes now
@@ -896,7 +932,13 @@ namespace
 				std::unique_lock<std::mutex> lk(wmu);
 				if (!writer.joinable())
 					writer = std::thread([this] { writer_loop(); });
+#ifdef RIR_SAVER_DIAG
+				const double tq = dg_now();
+#endif
 				wcv.wait(lk, [&] { return !job_ready && !writer_busy; }); // one job in flight: the previous chunk is on disk before this one is queued
+#ifdef RIR_SAVER_DIAG
+				dg_wait_writer += dg_now() - tq;
+#endif
 				if (write_failed)
 				{
 					log_error("h264 saver: write error on " + filename);
@@ -925,12 +967,31 @@ namespace
 			return o;
 		}
 
-		// The chunk in the current staging buffer, every frame of it staged by add_image: encoded from there into h_out[next_buf], nothing
-		// waited for.  The chunk before it is collected first (one in flight; its staging buffer is the one filled next).
-		bool submit_staged_chunk(const rir_codec_layout &L, hipStream_t st)
+		// The chunk being assembled - its frames in the current staging buffer (every one of them staged by add_image: the kernels read them
+		// over the link) or in cc.d_frames (uploaded, or produced there by the bounded-loss step, which is queued on the same stream) -
+		// encoded into h_out[next_buf], nothing waited for.  The error budgets of its bounded-loss frames are copied into page-locked
+		// memory behind the loss step and filed when the chunk is collected.  The chunk before it has been collected (one in flight; its
+		// staging buffer is the one filled next).
+		bool submit_chunk(const unsigned short *chunk_frames, const rir_codec_layout &L, hipStream_t st)
 		{
 			if (!collect_flying())
 				return false;
+			flying.defs.clear();
+			if (!deferred.empty())
+			{ // (slots 0 .. deferred.size() of d_err_slots: the frames of this chunk; the copy runs before any kernel of the next chunk)
+				const bool have_run = lossy_obj && lossy_obj->run_exchange.ptr;
+				const size_t eb = deferred.size() * 2 * sizeof(int);
+				if (!h_errs.reserve((size_t)ERR_SLOTS * 2 * sizeof(int) + 16))
+					return false;
+				unsigned int *words = reinterpret_cast<unsigned int *>(h_errs.as<char>() + (size_t)ERR_SLOTS * 2 * sizeof(int));
+				words[0] = words[1] = 0;
+				if (!hip_ok(hipMemcpyAsync(h_errs.ptr, d_err_slots.ptr, eb, hipMemcpyDeviceToHost, st), "D2H") ||
+					(have_run && (!hip_ok(hipMemcpyAsync(words, lossy_obj->run_exchange.as<unsigned int>() + 16, 4, hipMemcpyDeviceToHost, st), "D2H") ||
+								  !hip_ok(hipMemcpyAsync(words + 1, lossy_obj->run_exchange.as<unsigned int>() + kLossyRunCtlWord + 2, 4, hipMemcpyDeviceToHost, st), "D2H"))))
+					return false;
+				flying.defs.swap(deferred);
+				flying.have_run = have_run;
+			}
 			const OutLayout o = out_layout(L.ntiles);
 			PinnedBuffer &hob = h_out[next_buf]; // (free: the writer's job in flight, if any, reads the other buffer - queue_write waits for the job before)
 			const size_t fb = (size_t)width * height * 2 * chunk_gop;
@@ -941,7 +1002,7 @@ namespace
 			char *hb = hob.as<char>();
 			uint64_t *coff = reinterpret_cast<uint64_t *>(hb + o.coff_at());
 			coff[0] = 0, coff[1] = ~0ull; // (what the kernels leave is checked against the buffer before it is believed)
-			if (rir_codec_encode_device(reinterpret_cast<const unsigned short *>(stage_ptr()), width, height, pending, chunk_gop,
+			if (rir_codec_encode_device(chunk_frames, width, height, pending, chunk_gop,
 										reinterpret_cast<unsigned long long *>(hb), reinterpret_cast<unsigned int *>(hb + o.hdr_b),
 										reinterpret_cast<unsigned long long *>(coff), reinterpret_cast<unsigned long long *>(hb + o.hdr_b + o.toff_b), cc.d_ws.ptr,
 										(long long)cc.d_ws.cap, st) != 0 ||
@@ -960,8 +1021,30 @@ namespace
 			if (!flying.active)
 				return true;
 			flying.active = false;
+#ifdef RIR_SAVER_DIAG
+			const double tw = dg_now();
+#endif
 			if (!hip_ok(wait_event(fly_ev), "sync"))
 				return false;
+#ifdef RIR_SAVER_DIAG
+			dg_wait_ev += dg_now() - tw;
+#endif
+			if (!flying.defs.empty())
+			{ // the chunk's bounded-loss frames: their budgets, and whether the run that stepped them gave up (resolve_errors)
+				const int *e = h_errs.as<int>();
+				const unsigned int *words = reinterpret_cast<const unsigned int *>(h_errs.as<char>() + (size_t)ERR_SLOTS * 2 * sizeof(int));
+				const bool ok = file_errors(flying.defs, e, words[0] | words[1], flying.have_run);
+				flying.defs.clear();
+				if (!ok)
+				{ // (`failed` is set) this chunk and whatever has been handed in since are invalid: the recording ends with the chunk before it
+					nframes = flying.first_frame;
+					times.resize((size_t)nframes);
+					frame_attrs.resize((size_t)nframes);
+					pending = 0, uploaded = 0, raw_from = -1, raw_uploaded = 0;
+					deferred.clear();
+					return false;
+				}
+			}
 			const OutLayout o = out_layout(flying.ntiles);
 			const char *hb = h_out[flying.buf].as<char>();
 			const uint64_t *coff = reinterpret_cast<const uint64_t *>(hb + o.coff_at());
@@ -1059,6 +1142,11 @@ namespace
 			if (!failed)
 				ok = collect_flying() && ok;
 			flying.active = false;
+#ifdef RIR_SAVER_DIAG
+			if (dg_n)
+				fprintf(stderr, "saver diag: %d chunk flushes, per flush: total %.0f us = wait for the chunk in flight %.0f + wait for the writer %.0f + loss step queued %.0f + the rest\n", dg_n,
+						dg_flush / dg_n, dg_wait_ev / dg_n, dg_wait_writer / dg_n, dg_loss / dg_n);
+#endif
 			stop_writer(); // every chunk is in the file from here on
 			ok = ok && !write_failed;
 			FileHeader hd;

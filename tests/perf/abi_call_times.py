@@ -58,3 +58,22 @@ with tempfile.TemporaryDirectory() as d:
             ts.append(pc() - t0)
         V.close_camera(cam)
         summary("load_image run %d" % rep, ts, (50,))
+
+# bounded-loss recording (low = high = 3, stdFactor 0: the parameters of the reference's own test), the same frames
+with tempfile.TemporaryDirectory() as d:
+    for rep in range(3):
+        p = os.path.join(d, "l%d.h264" % rep)
+        hd = V.h264_open_file(p.encode(), w, h, h - 3)
+        for k, v in ((b"lowValueError", b"3"), (b"highValueError", b"3"), (b"stdFactor", b"0")):
+            V.h264_set_parameter(hd, k, v)
+        time.sleep(0.3)
+        ts = []
+        fn = V.h264_add_image_lossy
+        for i in range(n):
+            t0 = pc()
+            fn(hd, ptrs[i], i * 1000, 0, None, None, None, None)
+            ts.append(pc() - t0)
+        t0 = pc()
+        V.h264_close_file(hd)
+        print("close %.2f ms" % ((pc() - t0) * 1e3))
+        summary("add_image_lossy run %d" % rep, ts)
