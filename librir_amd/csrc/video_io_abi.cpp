@@ -1223,7 +1223,10 @@ namespace
 		// Sequential readers: while the images of chunk k are handed out from page-locked memory, helper threads ("lanes") read chunks
 		// k + 1 and k + 2 from the file and decode them, each on a stream and into a buffer set (`nx`) of its own, so that their images are
 		// in page-locked memory when the reader gets there; the lane's buffer set and the current one are then swapped.
-		static constexpr int kLanes = 2;
+#ifndef RIR_LOADER_LANES
+#define RIR_LOADER_LANES 2
+#endif
+		static constexpr int kLanes = RIR_LOADER_LANES;
 		ChunkCodec nx[kLanes];
 		struct Prefetch
 		{
@@ -1819,8 +1822,8 @@ namespace
 				host_copy(out, cc.h_frames.as<char>() + (size_t)(pos - host_base) * fbytes, fbytes);
 				if (track && seq_run >= 2)
 				{ // (no-ops when they are under way, done, or there is no such chunk)
-					start_prefetch(cached_chunk + 1);
-					start_prefetch(cached_chunk + 2);
+					for (int a = 1; a <= kLanes; ++a)
+						start_prefetch(cached_chunk + a);
 				}
 				return true;
 			}
