@@ -896,7 +896,12 @@ namespace rir
 			sg.spilling = true, sg.lds_used = pos;
 			if (sg.arena)
 			{
-				sg.extent = staging_take_extent(sg.cursor, sg.need, sg.arena_words, sg.error_word);
+				// (the extent comes back from a call: vector registers, "divergent" for the compiler - and with it the branch below and the
+				// descriptor it sets, which then lived in VGPRs and cost every record two waterfall loops, 12 vector + 12 scalar
+				// instructions, around its two stores.  It is wave-uniform: say so.)
+				const uint64_t ext = staging_take_extent(sg.cursor, sg.need, sg.arena_words, sg.error_word);
+				sg.extent = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ext >> 32)) << 32) |
+							(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ext);
 				if (sg.extent != ~0ull)
 					sg.spill = make_rsrc(sg.arena + sg.extent, sg.need * 8u);
 			}
