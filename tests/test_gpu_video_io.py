@@ -410,6 +410,10 @@ with IRSaver(sys.argv[2], w, h, h) as s:
     s.set_global_attributes({"who": "zero-copy test"})
     for i in range(n):
         s.add_image(arr[i], i * 1000, attributes={"i": str(i)})
+from librir_amd.video_io import IRMovie
+with IRMovie.from_filename(sys.argv[2]) as mov:   # the loader of the same mode: sequential (read-ahead lanes), then a few jumps
+    for i in list(range(n)) + [3, 40, 41, 42, 7]:
+        assert np.array_equal(mov[i], arr[i]), i
 """
 
 
