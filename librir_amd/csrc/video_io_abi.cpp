@@ -522,16 +522,43 @@ namespace
 		int raw_from = -1;
 		int raw_uploaded = 0;	  // raw frames [raw_from, raw_from + raw_uploaded) are in d_raw already (they go up in groups, as they come)
 		size_t raw_first_err = 0; // position in `deferred` of frame raw_from
-		DeviceBuffer d_raw;
-		bool upload_raw(int upto) // raw frames of the chunk up to slot `upto` -> d_raw
+		// The raw frames of a run go up on a COPY STREAM of this saver, into one of two device buffers: the uploads of the next chunk then
+		// cross the link while the loss step and the encode of the chunk before it run (on one stream the 0.6 ms of a chunk's uploads
+		// queued behind them: 20 us per image, with the copy stream 13-15).  The compute stream waits for a run's uploads (up_ev) before
+		// its loss step; the copy stream waits for the loss step that last read a buffer (loss_ev) before it writes that buffer again.
+		DeviceBuffer d_raw[2];
+		int raw_buf = 0; // the buffer the current run's frames go to
+		hipStream_t copy_st = nullptr;
+		hipEvent_t up_ev = nullptr, loss_ev[2] = {nullptr, nullptr};
+		bool loss_ev_set[2] = {false, false}, copy_st_failed = false;
+		hipStream_t upload_stream()
+		{
+			if (!abi_zero_copy() || copy_st_failed)
+				return default_stream();
+			if (!copy_st)
+			{
+				if (hipStreamCreateWithFlags(&copy_st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&up_ev, hipEventDisableTiming) != hipSuccess ||
+					hipEventCreateWithFlags(&loss_ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&loss_ev[1], hipEventDisableTiming) != hipSuccess)
+				{
+					copy_st_failed = true;
+					return default_stream();
+				}
+			}
+			return copy_st;
+		}
+		bool upload_raw(int upto) // raw frames of the chunk up to slot `upto` -> d_raw[raw_buf]
 		{
 			const int have = raw_from + raw_uploaded;
 			if (raw_from < 0 || upto <= have)
 				return true;
 			const size_t fbytes = (size_t)width * height * 2;
-			if (!d_raw.reserve((size_t)chunk_gop * fbytes) ||
-				!hip_ok(hipMemcpyAsync(d_raw.as<char>() + (size_t)raw_uploaded * fbytes, stage_ptr() + (size_t)have * fbytes, (size_t)(upto - have) * fbytes,
-									   hipMemcpyHostToDevice, default_stream()),
+			hipStream_t us = upload_stream();
+			if (!d_raw[raw_buf].reserve((size_t)chunk_gop * fbytes))
+				return false;
+			if (raw_uploaded == 0 && us == copy_st && loss_ev_set[raw_buf] && !hip_ok(hipStreamWaitEvent(us, loss_ev[raw_buf], 0), "hipStreamWaitEvent"))
+				return false; // (the first upload of a run: the loss step that read this buffer last must be through)
+			if (!hip_ok(hipMemcpyAsync(d_raw[raw_buf].as<char>() + (size_t)raw_uploaded * fbytes, stage_ptr() + (size_t)have * fbytes, (size_t)(upto - have) * fbytes,
+									   hipMemcpyHostToDevice, us),
 						"H2D frames"))
 				return false;
 			raw_uploaded = upto - raw_from;
@@ -581,6 +608,14 @@ namespace
 			stop_writer();
 			if (fly_ev)
 				(void)hipEventDestroy(fly_ev);
+			if (copy_st)
+			{
+				(void)hipStreamSynchronize(copy_st);
+				(void)hipStreamDestroy(copy_st);
+			}
+			for (hipEvent_t e : {up_ev, loss_ev[0], loss_ev[1]})
+				if (e)
+					(void)hipEventDestroy(e);
 		}
 
 		// the loss-injection state is created on the first lossy call (after the lazy open)
@@ -631,7 +666,10 @@ namespace
 						return false;
 					raw_from = pending, raw_uploaded = 0, raw_first_err = deferred.size();
 				}
-				if (pending + 1 - (raw_from + raw_uploaded) >= kUploadGroup && !upload_raw(pending + 1))
+				// (a copy call costs the calling thread ~40 us whatever it moves: with the copy stream, whose transfers overlap the chunk
+				// before, the frames go in few large pieces; on the one stream of the copying path small groups keep the link busy early)
+				const int group = upload_stream() == copy_st && copy_st ? kRawUploadGroup : kUploadGroup;
+				if (pending + 1 - (raw_from + raw_uploaded) >= group && !upload_raw(pending + 1))
 					return false;
 				deferred.push_back(Deferred{(size_t)nframes, low_errors.size(), true});
 				low_errors.push_back(0);
@@ -670,13 +708,23 @@ namespace
 				return false;
 			const size_t npx = (size_t)width * height;
 			hipStream_t st = default_stream();
+			const bool side = copy_st && upload_stream() == copy_st; // the run's frames went up on the copy stream
+			if (side && (!hip_ok(hipEventRecord(up_ev, copy_st), "hipEventRecord") || !hip_ok(hipStreamWaitEvent(st, up_ev, 0), "hipStreamWaitEvent")))
+				return false;
 			lossy_obj->low = lowValueError, lossy_obj->high = highValueError, lossy_obj->std_factor = stdFactor, lossy_obj->remove_bad_pixels = false;
 			LossyObject *o = lossy_obj.get();
-			const unsigned short *in = d_raw.as<unsigned short>();
+			const unsigned short *in = d_raw[raw_buf].as<unsigned short>();
 			unsigned short *out = cc.d_frames.as<unsigned short>() + (size_t)a * npx;
 			int *errs = d_err_slots.as<int>() + 2 * raw_first_err;
 			if (lossy_step_streams(&o, 1, &in, &out, n, 0, &errs, nullptr, nullptr, st) != 0)
 				return false;
+			if (side)
+			{ // the next run goes to the other buffer; this one is free again when this run's loss step is through
+				if (!hip_ok(hipEventRecord(loss_ev[raw_buf], st), "hipEventRecord"))
+					return false;
+				loss_ev_set[raw_buf] = true;
+				raw_buf ^= 1;
+			}
 			uploaded = pending; // (the chunk's device frames are complete up to here)
 			return true;
 		}
@@ -1060,6 +1108,10 @@ namespace
 
 		// frames [uploaded, upto) of the chunk being assembled: page-locked staging -> device
 		static constexpr int kUploadGroup = 5;
+#ifndef RIR_RAW_UPLOAD_GROUP
+#define RIR_RAW_UPLOAD_GROUP 25
+#endif
+		static constexpr int kRawUploadGroup = RIR_RAW_UPLOAD_GROUP;
 		int uploaded = 0;
 		bool upload_staged(int upto)
 		{
