@@ -1139,7 +1139,7 @@ namespace
 			// 640x512 frame but leans on how the runtime treats pageable / pinned sources; not worth the risk.)
 			char *slot = stage_ptr() + (size_t)pending * fbytes;
 			host_copy(slot, img, fbytes);
-			// A chunk made of such frames only is encoded from where they lie (submit_staged_chunk).  Without that (RIR_ABI_ZERO_COPY=0, or a
+			// A chunk made of such frames only is encoded from where they lie (submit_chunk).  Without that (RIR_ABI_ZERO_COPY=0, or a
 			// chunk that already holds device frames) uploads go in groups of a few frames, one asynchronous copy each; what is left of a
 			// chunk goes when the chunk is flushed
 			if ((!abi_zero_copy() || uploaded > 0) && pending + 1 - uploaded >= kUploadGroup && !upload_staged(pending + 1))

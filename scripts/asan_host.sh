@@ -12,7 +12,7 @@ OUT=gpurun_out/san_$SAN
 mkdir -p $OUT
 if [ "$SAN" = address ]; then RT=$(find /opt/rocm/lib/llvm -name "libclang_rt.asan-x86_64.so" | head -1); LINK=-shared-libasan;
 else RT=$(find /opt/rocm/lib/llvm -name "libclang_rt.ubsan_standalone-x86_64.so" | head -1); LINK=; fi
-for f in video_io_abi registration_abi signal_processing_abi runtime file_attributes codec_abi; do
+for f in video_io_abi registration_abi signal_processing_abi runtime file_attributes codec_abi host_copy; do
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC -fsanitize=$SAN -fno-omit-frame-pointer -fvisibility=hidden -Ilibrir_amd/csrc -Iinclude \
       -c librir_amd/csrc/$f.cpp -o $OUT/$f.o
 done

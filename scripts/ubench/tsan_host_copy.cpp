@@ -1,0 +1,57 @@
+// ThreadSanitizer harness for librir_amd/csrc/host_copy.cpp (build container, no GPU): callers on many threads, sizes around the
+// hand-off threshold, pauses that let the helpers park, file jobs beside memory jobs.
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include <fcntl.h>
+#include <unistd.h>
+namespace rir
+{
+	void host_copy(void *dst, const void *src, size_t bytes);
+	bool host_pread(int fd, void *dst, size_t bytes, int64_t file_off);
+	bool host_pwrite(int fd, const void *src, size_t bytes, int64_t file_off);
+}
+int main()
+{
+	std::atomic<int> bad{0};
+	char name[] = "/tmp/tsan/io_XXXXXX";
+	int fd = mkstemp(name);
+	std::vector<std::thread> ts;
+	for (int t = 0; t < 10; ++t)
+		ts.emplace_back([&, t] {
+			unsigned s = 1234u + t;
+			auto rnd = [&] { s = s * 1664525u + 1013904223u; return s >> 8; };
+			std::vector<unsigned char> a(1 << 20), b(1 << 20);
+			for (auto &x : a)
+				x = (unsigned char)rnd();
+			for (int i = 0; i < 300; ++i)
+			{
+				const size_t n = (i % 3 == 0) ? rnd() % a.size() : 192 * 1024 + rnd() % (a.size() - 192 * 1024);
+				if (t < 7)
+				{
+					rir::host_copy(b.data(), a.data(), n);
+					if (memcmp(a.data(), b.data(), n) != 0)
+						bad++;
+					memset(b.data(), 0, n);
+				}
+				else
+				{
+					const int64_t off = (int64_t)t * (2 << 20);
+					if (!rir::host_pwrite(fd, a.data(), n, off) || !rir::host_pread(fd, b.data(), n, off) || memcmp(a.data(), b.data(), n) != 0)
+						bad++;
+				}
+				if (i % 50 == 49)
+					std::this_thread::sleep_for(std::chrono::milliseconds(2)); // the helpers park
+			}
+		});
+	for (auto &t : ts)
+		t.join();
+	close(fd);
+	unlink(name);
+	printf("host_copy under ThreadSanitizer: %d mismatches\n", bad.load());
+	return bad.load() ? 1 : 0;
+}
