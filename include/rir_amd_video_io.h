@@ -57,6 +57,9 @@ extern "C"
 	/* calibration / emissivity: the reference ships no calibration plugin; these answer as the
 	 * reference does without one */
 	int calibrate_inplace(int camera, unsigned short *img, int size, int calibration);			/* video_io.h:108 */
+	/* The emissivity map is state of the loader whether or not a calibration uses it (IRVideoLoader.h:29-97, video_io.cpp:282-338): what
+	 * is set is read back - set_global_emissivity fills the map with one value in [0, 1], set_emissivity takes the first `size` pixels
+	 * (1 for the rest), get_emissivity returns how many values it wrote (a single 1 and 0 when nothing was ever set). */
 	int set_global_emissivity(int camera, float emi);											/* video_io.h:114 */
 	int set_emissivity(int camera, float *emi, int size);										/* video_io.h:120 */
 	int get_emissivity(int camera, float *emi, int size);										/* video_io.h:125 */

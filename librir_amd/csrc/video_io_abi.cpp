@@ -1300,6 +1300,8 @@ namespace
 		bool motion_enabled = false;
 		std::vector<float> shifts; // (x,y) per frame
 		int min_T = 0, min_T_rows = 0; // global attributes MIN_T / MIN_T_HEIGHT (IRFileLoader.cpp:905-921)
+		std::vector<float> inv_emi;	   // inverse emissivities as set through set_[global_]emissivity (IRVideoLoader.h:29-30)
+		float global_emi = 1.f;
 
 		~CameraObject() override
 		{
@@ -2506,6 +2508,9 @@ RIR_EXPORT int support_emissivity(int cam)
 	log_error("support_emissivity: NULL camera");
 	return -1;
 }
+// The emissivity map is STATE of the loader whether or not a calibration uses it (IRVideoLoader.h:29-97: a vector of inverse
+// emissivities + the global value; IRFileLoader.cpp:1099-1111 forwards to it and answers true): what is set is what is read back
+// (tests/python/test_video_io.py:195-205 asserts that on a plain recording).  Host-side book-keeping, no pixel is touched.
 RIR_EXPORT int set_global_emissivity(int cam, float emi)
 {
 	if (emi < 0.f || emi > 1.f)
@@ -2513,30 +2518,53 @@ RIR_EXPORT int set_global_emissivity(int cam, float emi)
 		log_error("set_emissivity: wrong emissivity value");
 		return -1;
 	}
-	if (!camera(cam))
+	auto c = camera(cam);
+	if (!c)
 	{
 		log_error("set_global_emissivity: NULL camera");
 		return -1;
 	}
+	if (emi != c->global_emi || c->inv_emi.empty())
+	{ // IRVideoLoader::setEmissivity
+		c->inv_emi.assign((size_t)std::max(c->width, 0) * (size_t)std::max(c->height, 0), 1.f / emi);
+		c->global_emi = emi;
+	}
 	return 0;
 }
-RIR_EXPORT int set_emissivity(int cam, float *, int)
+RIR_EXPORT int set_emissivity(int cam, float *emi, int size)
 {
-	if (!camera(cam))
+	auto c = camera(cam);
+	if (!c)
+	{
 		log_error("set_emissivity: NULL camera");
-	else
-		log_error("set_emissivity: wrong vector size");
-	return -1;
+		return -1;
+	}
+	if (size > 0 && emi)
+	{ // IRVideoLoader::setEmissivities: the first `size` pixels, 1 for the rest
+		const size_t npx = (size_t)std::max(c->width, 0) * (size_t)std::max(c->height, 0), n = std::min((size_t)size, npx);
+		c->inv_emi.resize(npx);
+		for (size_t i = 0; i < n; ++i)
+			c->inv_emi[i] = 1.f / emi[i];
+		for (size_t i = n; i < npx; ++i)
+			c->inv_emi[i] = 1.f;
+		c->global_emi = 0;
+	}
+	return 0; // (the file loader answers true whatever the size, IRFileLoader.cpp:1105-1111)
 }
-RIR_EXPORT int get_emissivity(int cam, float *emi, int)
-{
-	if (!camera(cam) || !emi)
+RIR_EXPORT int get_emissivity(int cam, float *emi, int size)
+{ // video_io.cpp:319-338: as many values as asked for and stored; 1 in the first place when nothing is stored; returns the count
+	auto c = camera(cam);
+	if (!c || !emi)
 	{
 		log_error("get_emissivity: NULL camera");
 		return -1;
 	}
-	*emi = 1;
-	return 0;
+	const int s = std::max(0, std::min(size, (int)std::min<size_t>(c->inv_emi.size(), 0x7fffffff)));
+	for (int i = 0; i < s; ++i)
+		emi[i] = 1.f / c->inv_emi[(size_t)i];
+	if (s == 0)
+		*emi = 1;
+	return s;
 }
 RIR_EXPORT int calibrate_inplace(int cam, unsigned short *, int, int calibration)
 {

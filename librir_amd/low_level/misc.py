@@ -58,6 +58,22 @@ def toBytes(s):
     return str(s).encode("utf-8")
 
 
+def get_memory_folder():
+    """Folder of on-disk caches: ``$LIBRIR_TEMP_FOLDER`` or the system's temporary folder, with a last component ending in "cache";
+    created when missing (reference low_level/misc.py:39-49)."""
+    import os
+    import tempfile
+    from pathlib import Path
+
+    folder = Path(os.getenv("LIBRIR_TEMP_FOLDER") or tempfile.gettempdir())
+    if not folder.name.endswith("cache"):
+        folder = folder / "cache"
+    if not folder.exists():
+        folder.mkdir()
+        folder.chmod(0o775)
+    return folder
+
+
 def toCharP(s):
     return toBytes(s)
 

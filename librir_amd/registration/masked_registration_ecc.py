@@ -231,3 +231,25 @@ class MaskedRegistratorECC:
             out.write("\t".join(["", "x-axis translations", "y-axis translations", "Confidence level"]) + "\n")
             for index, (tx, ty, confidence) in enumerate(rows):
                 out.write("\t".join([str(index), repr(float(tx)), repr(float(ty)), repr(float(confidence))]) + "\n")
+
+
+def manage_computation_and_tries(img, regis_obj):
+    """``regis_obj.compute(img)`` with up to five attempts (reference masked_registration_ecc.py:218-245): an alignment that does not
+    converge is tried again with the percentile of the dynamic mask lowered by 0.01 each time; after five failures the image takes the
+    translation and confidence of its predecessor.  The failure upstream catches is ``cv2.error``; here the alignment raises
+    ``RuntimeError`` where OpenCV raises.  Returns ``regis_obj``."""
+    attempts, limit = 0, 5
+    while attempts < limit:
+        try:
+            regis_obj.compute(img)
+            if regis_obj.median < 1:
+                regis_obj.median = 1
+            break
+        except RuntimeError:
+            regis_obj.median -= 0.01
+            attempts += 1
+            print("try number : {}".format(attempts))
+    if attempts >= limit:
+        regis_obj.append_last_coordinates_and_confidence()
+        print("took previous estimates.")
+    return regis_obj

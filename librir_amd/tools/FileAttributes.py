@@ -38,6 +38,9 @@ class FileAttributes(object):
             rt.attrs_close(self.handle)
             self.handle = 0
 
+    def is_open(self):
+        return self.handle > 0
+
     def discard(self):
         if self.handle > 0:
             rt.attrs_discard(self.handle)

@@ -23,6 +23,8 @@ _tools.attrs_frame_attribute_count.argtypes = [ct.c_int, ct.c_int]
 _tools.attrs_frame_attribute_name.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_char_p, _ip]
 _tools.attrs_frame_attribute_value.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_char_p, _ip]
 _tools.attrs_timestamps.argtypes = [ct.c_int, _vp]
+_tools.attrs_frame_timestamp.argtypes = [ct.c_int, ct.c_int, ct.POINTER(ct.c_int64)]
+_tools.attrs_set_time.argtypes = [ct.c_int, ct.c_int, ct.c_int64]
 _tools.attrs_set_times.argtypes = [ct.c_int, _vp, ct.c_int]
 _tools.attrs_set_frame_attributes.argtypes = [ct.c_int, ct.c_int, ct.c_char_p, _vp, ct.c_char_p, _vp, ct.c_int]
 _tools.attrs_set_global_attributes.argtypes = [ct.c_int, ct.c_char_p, _vp, ct.c_char_p, _vp, ct.c_int]
@@ -109,6 +111,50 @@ def attrs_frame_attributes(h, frame):
         k = _read_sized(_tools.attrs_frame_attribute_name, h, frame, i)
         out[k.decode("utf-8", errors="replace")] = _read_sized(_tools.attrs_frame_attribute_value, h, frame, i)
     return out
+
+
+# ---- one item at a time (the reference exposes these too, src/python/librir/tools/rir_tools.py:134-316) -------------------------
+def _count(fn, name, *args):
+    n = fn(*args)
+    if n < 0:
+        raise RuntimeError("An error occured while calling '%s'" % name)
+    return n
+
+
+def attrs_global_attribute_count(handle):
+    return _count(_tools.attrs_global_attribute_count, "attrs_global_attribute_count", int(handle))
+
+
+def attrs_frame_attribute_count(handle, pos):
+    return _count(_tools.attrs_frame_attribute_count, "attrs_frame_attribute_count", int(handle), int(pos))
+
+
+def attrs_global_attribute_name(handle, index):
+    return _read_sized(_tools.attrs_global_attribute_name, int(handle), int(index)).decode("utf-8", errors="replace")
+
+
+def attrs_global_attribute_value(handle, index):
+    return _read_sized(_tools.attrs_global_attribute_value, int(handle), int(index))
+
+
+def attrs_frame_attribute_name(handle, frame, index):
+    return _read_sized(_tools.attrs_frame_attribute_name, int(handle), int(frame), int(index)).decode("utf-8", errors="replace")
+
+
+def attrs_frame_attribute_value(handle, frame, index):
+    return _read_sized(_tools.attrs_frame_attribute_value, int(handle), int(frame), int(index))
+
+
+def attrs_frame_timestamp(handle, frame):
+    t = ct.c_int64(0)
+    if _tools.attrs_frame_timestamp(int(handle), int(frame), ct.byref(t)) < 0:
+        raise RuntimeError("An error occured while calling 'attrs_frame_timestamp'")
+    return t.value
+
+
+def attrs_set_time(handle, frame, time):
+    if _tools.attrs_set_time(int(handle), int(frame), int(time)) < 0:
+        raise RuntimeError("An error occured while calling 'attrs_set_time'")
 
 
 def attrs_timestamps(h):

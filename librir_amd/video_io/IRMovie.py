@@ -37,6 +37,10 @@ class InvalidMovie(Exception):
     pass
 
 
+class CalibrationNotFound(Exception):
+    """a calibration asked for by name or number that the movie does not offer (reference IRMovie.py:52-53, :172-197)"""
+
+
 def create_pcr_header(rows, columns, frequency=50, bits=16):
     """The 1024-byte header of a raw PCR file as 256 little-endian uint32 (layout: reference IRFileLoader.h:43-61;
     words 2/3 = X/Y, 5 = Bits, 7 = Frequency, 9 = bytes per image, 10/11 = grab size)."""
@@ -158,16 +162,21 @@ class IRMovie(object):
             if which in ("DL", "Digital Level"):
                 return 0
             if which not in names:
-                raise RuntimeError("calibration not found: %s" % which)
+                raise CalibrationNotFound("%s not in available calibrations : %s" % (which, names + ["DL"]))
             return names.index(which)
         number = int(which)
         if not 0 <= number < len(names):
-            raise RuntimeError("calibration index out of range")
+            raise CalibrationNotFound("Available calibrations : %s. Calibration index out of range : %s" % (names, number))
         return number
+
+    # short names of the calibrations, in the library's order (reference IRMovie.py:77, :169-170: "DL" for "Digital Level")
+    _calibration_nickname_mapper = {"DL": "Digital Level"}
 
     @property
     def calibration(self):
-        return self.calibrations[self._calibration_index]
+        """the current calibration by its SHORT name where it has one ("DL"), as upstream answers"""
+        short = list(self._calibration_nickname_mapper)
+        return short[self._calibration_index] if self._calibration_index < len(short) else self.calibrations[self._calibration_index]
 
     @calibration.setter
     def calibration(self, value):
@@ -179,6 +188,38 @@ class IRMovie(object):
     @property
     def support_emissivity(self):
         return _abi.support_emissivity(self.handle)
+
+    # (reference IRMovie.py:401-423: a movie whose calibration takes no emissivity reads as 1 everywhere and refuses to be set)
+    @property
+    def global_emissivity(self):
+        return _abi.get_global_emissivity(self.handle) if self.support_emissivity else 1.0
+
+    @global_emissivity.setter
+    def global_emissivity(self, value):
+        if not self.support_emissivity:
+            raise RuntimeError("Cannot set custom emissivity value for this handle")
+        _abi.set_global_emissivity(self.handle, value)
+
+    @property
+    def emissivity(self):
+        return _abi.get_emissivity(self.handle) if self.support_emissivity else np.ones(self.image_size, dtype=np.float32)
+
+    @emissivity.setter
+    def emissivity(self, emissivity_array):
+        if not self.support_emissivity:
+            raise RuntimeError("Cannot set custom emissivity value for this handle")
+        _abi.set_emissivity(self.handle, emissivity_array)
+
+    def calibrate(self, image, calib):
+        """``calib`` applied to a digital-level image, as a new array (IRMovie.py:510-514); only calibration 0 exists here."""
+        return _abi.calibrate_image(self.handle, image, calib)
+
+    @property
+    def calibration_files(self):
+        try:
+            return _abi.calibration_files(self.handle)
+        except RuntimeError:
+            return []
 
     # ---- geometry ----------------------------------------------------------------------------------------------------------
     @property
@@ -294,6 +335,30 @@ class IRMovie(object):
     def frame_attributes(self):
         """attributes of the image read last"""
         return self._per_frame.get(self._current, {})
+
+    @property
+    def frames_attributes(self):
+        """The attributes of EVERY image as a table, one row per image (IRMovie.py:642-649: images not read yet are read for it).
+        A pandas DataFrame like the reference's; values are the attribute bytes as stored."""
+        import pandas as pd
+
+        for pos in range(self.images):
+            if pos not in self._per_frame:
+                self.load_pos(pos, self._calibration_index)
+        return pd.DataFrame({pos: self._per_frame[pos] for pos in range(self.images)}).T
+
+    def _frame_attribute_getter(self, key):
+        """one attribute of every image as floats (empty when no image carries it)"""
+        try:
+            values = self.frames_attributes[key]
+        except KeyError:
+            values = []
+        return np.array(values, dtype=float)
+
+    def to_thermavip(self, th_instance="Thermavip-1", player_id=0):
+        """The reference hands the file to a running Thermavip viewer through shared memory (IRMovie.py:660-676); that bridge is outside
+        this build: like the reference without a Thermavip instance, nothing is opened and None is returned."""
+        return None
 
     # ---- filters applied while reading -----------------------------------------------------------------------------------------------
     @property

@@ -1,6 +1,8 @@
 """Mirror of librir's ``video_io`` Python package (reference src/python/librir/video_io/)."""
-from .IRMovie import FileFormat, InvalidMovie, IRMovie
+from .IRMovie import CalibrationNotFound, FileFormat, InvalidMovie, IRMovie
 from .IRSaver import IRSaver
 from .rir_video_io import *  # noqa: F401,F403
 
-__all__ = ["IRMovie", "IRSaver", "FileFormat", "InvalidMovie"]
+from .utils import is_ir_file_corrupted, split_rush  # noqa: E402,F401
+
+__all__ = ["IRMovie", "IRSaver", "FileFormat", "InvalidMovie", "CalibrationNotFound", "split_rush", "is_ir_file_corrupted"]

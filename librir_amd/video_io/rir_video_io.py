@@ -227,6 +227,55 @@ def support_emissivity(camera):
     return _v.support_emissivity(camera) > 0
 
 
+# Emissivity and calibration (reference rir_video_io.py:248-361).  This build ships no calibration plugin (digital levels only, SURVEY §2
+# row 6): the library answers what the reference answers for a camera without one - support_emissivity false, emissivity 1, calibration
+# 0 the identity, any other calibration an error - and these wrappers turn its codes into the reference's exceptions.
+def set_global_emissivity(camera, emi_value):
+    if _v.set_global_emissivity(int(camera), float(emi_value)) < 0:
+        raise RuntimeError("An error occured while calling 'set_global_emissivity' with emissivity " + str(emi_value))
+
+
+def get_global_emissivity(camera):
+    one = np.zeros(1, dtype=np.float32)
+    if _v.get_emissivity(int(camera), one.ctypes.data_as(ct.POINTER(ct.c_float)), 1) < 0:
+        raise RuntimeError("An error occured while calling 'get_emissivity'")
+    return one[0]
+
+
+def set_emissivity(camera, emissivity_array):
+    e = np.ascontiguousarray(emissivity_array, dtype=np.float32)
+    if _v.set_emissivity(int(camera), e.ctypes.data_as(ct.POINTER(ct.c_float)), int(e.size)) < 0:
+        raise RuntimeError("An error occured while calling 'set_emissivity'")
+
+
+def get_emissivity(camera):
+    e = np.zeros(get_image_size(camera), dtype=np.float32)
+    if _v.get_emissivity(int(camera), e.ctypes.data_as(ct.POINTER(ct.c_float)), int(e.size)) < 0:
+        raise RuntimeError("An error occured while calling 'get_emissivity'")
+    return e
+
+
+def camera_saturate(movie_handle):
+    """True when the last load_image saturated the temperature calibration (never, without a calibration)."""
+    return _v.camera_saturate(int(movie_handle)) == 1
+
+
+def calibrate_image(camera, image, calib):
+    """The calibration ``calib`` applied to a digital-level image; returns a new uint16 array."""
+    img = np.array(image, dtype=np.uint16, order="C")  # (always a copy: the library works in place)
+    if _v.calibrate_inplace(int(camera), img.ctypes.data_as(ct.POINTER(ct.c_uint16)), int(img.size), int(calib)) < 0:
+        raise RuntimeError("calibrate_image: unable to apply selected calibration")
+    return img
+
+
+def change_hcc_external_blackbody_temperature(filename, temperature):
+    """HCC vendor files are outside this build: the library refuses, this raises like the reference does on failure."""
+    r = _v.change_hcc_external_blackbody_temperature(toBytes(str(filename)), ct.c_float(float(temperature)))
+    if r < 0:
+        raise RuntimeError("An error occured while calling 'change_hcc_external_blackbody_temperature'")
+    return r
+
+
 def calibration_files(camera):
     return []
 

@@ -456,3 +456,24 @@ def test_eight_sequences_at_the_headline_size_equal_their_own_tracks():
         assert multi[q].x == solo.x and multi[q].y == solo.y and multi[q].confidences == solo.confidences, q
         got = np.stack([multi[q].x, multi[q].y], 1)
         assert np.abs(np.abs(got) - np.abs(np.asarray(truth[q])[:, :2])).max() < 2.0, q
+
+
+def test_manage_computation_and_tries(dev):
+    """reference tests/python/test_registration.py:137-147 (and the function, masked_registration_ecc.py:218-245): the recipe's images
+    through the retrying wrapper - every image gets a translation; an image that cannot be aligned (not-a-number everywhere: so is its
+    correlation) is tried five times, the percentile going down by 0.01 each time, and then takes its predecessor's values."""
+    from librir_amd.registration import manage_computation_and_tries
+
+    f32, shifts = s3_registration(12, 512, 640)
+    reg = MaskedRegistratorECC(1, 1)
+    reg.start(f32[0])
+    for img in f32[1:]:
+        assert manage_computation_and_tries(img, reg) is reg
+    assert len(reg.x) == 12 and abs(reg.x[-1] - shifts[11, 0]) < 0.5 and abs(reg.y[-1] - shifts[11, 1]) < 0.5
+    before = (reg.x[-1], reg.y[-1], reg.confidences[-1])
+    reg.median = 0.999  # (the dynamic-mask path: the step-by-step body)
+    hopeless = np.full((512, 640), np.nan, np.float32)
+    with np.errstate(all="ignore"):
+        manage_computation_and_tries(hopeless, reg)
+    assert len(reg.x) == 13 and (reg.x[-1], reg.y[-1], reg.confidences[-1]) == before
+    assert abs(reg.median - (0.999 - 0.05)) < 1e-9

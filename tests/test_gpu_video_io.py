@@ -508,3 +508,41 @@ def test_many_chunks_sequential_and_strided(tmp_path):
             assert np.array_equal(mov[i], arr[i]), i
         for i in range(n - 1, -1, -7):
             assert np.array_equal(mov[i], arr[i]), i
+
+
+def test_split_rush_and_corruption_check(tmp_path):
+    """reference tests/python/test_IRMovie.py:232-245: a movie cut into pieces of two images - as many pieces as images // 2, every
+    piece a sane movie holding its images - and the corruption check on a good and on a missing file."""
+    from librir_amd.video_io.utils import is_ir_file_corrupted, split_rush
+
+    arr = images(7, 32, 48)
+    src = tmp_path / "rush.h264"
+    with IRSaver(src, 48, 32, 32) as s:
+        for i in range(7):
+            s.add_image(arr[i], i * 1000)
+    pieces = split_rush(src, step=2)
+    assert len(pieces) == 7 // 2 and [p.name for p in pieces] == ["0.h264", "1.h264", "2.h264"]
+    for k, p in enumerate(pieces):
+        assert not is_ir_file_corrupted(p)
+        with IRMovie.from_filename(p) as mov:
+            assert np.array_equal(mov.data, arr[2 * k:2 * k + 2])
+            assert np.allclose(mov.timestamps, [0.0, 0.02])
+    named = split_rush(src, index=[1.234, "b"], step=3, dest_folder=tmp_path / "out")
+    assert [p.name for p in named] == ["1.23.h264", "b.h264"]
+    assert not is_ir_file_corrupted(src)
+    assert is_ir_file_corrupted("inexistent_filename")
+
+
+def test_frames_attributes_table(tmp_path):
+    """reference IRMovie.frames_attributes (IRMovie.py:642-658): one row per image, read on demand, and one attribute as floats"""
+    arr = images(6, 24, 32)
+    src = tmp_path / "fa.h264"
+    with IRSaver(src, 32, 24, 24) as s:
+        s.set_parameter("GOP", 4)
+        for i in range(6):
+            s.add_image(arr[i], i * 1000, attributes={"power": str(10 * i), "tag": "t%d" % i})
+    with IRMovie.from_filename(src) as mov:
+        table = mov.frames_attributes
+        assert table.shape == (6, 2) and list(table["tag"]) == [b"t%d" % i for i in range(6)]
+        assert np.array_equal(mov._frame_attribute_getter("power"), 10.0 * np.arange(6))
+        assert mov._frame_attribute_getter("absent").size == 0

@@ -326,3 +326,92 @@ def test_zfile_damaged_files_fail_cleanly(tmp_path):
         rv.load_image(cam, 0)
     assert np.array_equal(rv.load_image(cam, 2), fr[2])
     rv.close_camera(cam)
+
+
+def test_emissivity_and_calibration_surface_without_a_gpu(tmp_path):
+    """The loader's emissivity map is state of the loader whether or not a calibration uses it: what is set is what is read back
+    (reference tests/python/test_video_io.py:187-232 and test_IRMovie.py:159-180,338-360 replayed on a raw PCR movie, which needs no
+    device).  Calibration 0 is the identity, nothing else exists; names and exceptions are the wrapper's."""
+    from librir_amd.video_io import CalibrationNotFound, IRMovie
+
+    fr = np.random.default_rng(3).integers(0, 16000, (3, 12, 16)).astype(np.uint16)
+    p = tmp_path / "e.pcr"
+    write_pcr(p, fr, frequency=50)
+    with IRMovie.from_filename(p) as movie:
+        h = movie.handle
+        assert rv.support_emissivity(h) is False and not movie.support_emissivity
+        # nothing set yet: one value, 1 (video_io.cpp:329-337), and the movie answers ones
+        first = rv.get_emissivity(h)
+        assert first.shape == (12, 16) and first.flat[0] == 1 and not first.flat[1:].any()
+        assert np.array_equal(movie.emissivity, np.ones((12, 16), np.float32)) and movie.global_emissivity == 1.0
+        emi = np.ones((12, 16)) * 0.25
+        rv.set_emissivity(h, emi)
+        assert np.array_equal(rv.get_emissivity(h), emi)  # test_video_io.py:195-202
+        part = np.full(5, 0.5, np.float32)  # fewer values than pixels: 1 for the rest (IRVideoLoader.h:58-73)
+        rv.set_emissivity(h, part)
+        back = rv.get_emissivity(h)
+        assert np.array_equal(back.flat[:5], part) and (back.flat[5:] == 1).all()
+        rv.set_global_emissivity(h, 0.5)
+        assert (rv.get_emissivity(h) == 0.5).all() and rv.get_global_emissivity(h) == 0.5
+        with pytest.raises(RuntimeError):
+            rv.set_global_emissivity(h, 1.5)
+        with pytest.raises(RuntimeError):
+            rv.get_emissivity(-1)  # test_video_io.py:208-212
+        with pytest.raises(RuntimeError):
+            movie.emissivity = emi  # the movie refuses where its calibration takes none (IRMovie.py:419-423)
+        with pytest.raises(RuntimeError):
+            movie.global_emissivity = 0.9
+        assert rv.camera_saturate(h) is False
+        img = movie[0]
+        out = movie.calibrate(img, 0)  # test_IRMovie.py:159-161
+        assert np.array_equal(out, img) and out is not img
+        assert np.array_equal(rv.calibrate_image(h, movie.data, 0), movie.data)  # test_video_io.py:187-191
+        with pytest.raises(RuntimeError):
+            rv.calibrate_image(h, img, 1)
+        assert movie.calibration_files == []  # test_video_io.py:147-148
+        movie.calibration = "DL"  # test_IRMovie.py:165-178
+        assert movie._calibration_index == 0 and movie.calibration == "DL"
+        with pytest.raises(CalibrationNotFound):
+            movie.calibration = "T"
+        with pytest.raises(CalibrationNotFound):
+            movie.calibration = 1
+        assert movie.calibration == "DL" and movie._calibration_index == 0
+        assert movie.to_thermavip() is None
+    with pytest.raises(RuntimeError):
+        rv.change_hcc_external_blackbody_temperature(p, 20.0)
+
+
+def test_attribute_accessors_one_at_a_time(tmp_path):
+    """reference tools/rir_tools.py:134-316: counts, names, values and time stamps of a trailer, item by item"""
+    from librir_amd.low_level.misc import get_memory_folder
+    from librir_amd.tools import rir_tools as rt
+
+    p = tmp_path / "a.bin"
+    p.write_bytes(b"payload")
+    fa = FileAttributes.from_filename(p)
+    assert fa.is_open()
+    fa.attributes = {"cam": "A", "n": "3"}
+    fa.timestamps = [5, 7, 11]
+    fa.set_frame_attributes(1, {"k": b"v\x00w"})
+    fa.flush()
+    h = fa.handle
+    assert rt.attrs_global_attribute_count(h) == 2 and rt.attrs_frame_attribute_count(h, 1) == 1 and rt.attrs_frame_attribute_count(h, 0) == 0
+    got = {rt.attrs_global_attribute_name(h, i): rt.attrs_global_attribute_value(h, i) for i in range(2)}
+    assert got == {"cam": b"A", "n": b"3"}
+    assert rt.attrs_frame_attribute_name(h, 1, 0) == "k" and rt.attrs_frame_attribute_value(h, 1, 0) == b"v\x00w"
+    assert [rt.attrs_frame_timestamp(h, i) for i in range(3)] == [5, 7, 11]
+    rt.attrs_set_time(h, 2, 13)
+    assert rt.attrs_frame_timestamp(h, 2) == 13
+    with pytest.raises(RuntimeError):
+        rt.attrs_frame_timestamp(h, 3)
+    with pytest.raises(RuntimeError):
+        rt.attrs_global_attribute_count(-1)
+    fa.close()
+    assert not fa.is_open()
+    os.environ["LIBRIR_TEMP_FOLDER"] = str(tmp_path / "mem")
+    try:
+        (tmp_path / "mem").mkdir()
+        folder = get_memory_folder()
+        assert folder == tmp_path / "mem" / "cache" and folder.is_dir()
+    finally:
+        del os.environ["LIBRIR_TEMP_FOLDER"]
