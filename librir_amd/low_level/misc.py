@@ -10,6 +10,8 @@ error codes and the Python wrappers raise ``RuntimeError``.
 import ctypes as ct
 import os
 
+import numpy as np
+
 _HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # RIR_LIBRARY_VARIANT=testhooks: the build with the fault-injection hooks compiled in (librir_amd/build.py) - for the tests that force a
 # bail-out path (tests/hook_cases.py); anything else: the product library
@@ -42,14 +44,13 @@ _video_io = _lib
 
 
 def toString(ar):
-    """bytes / char array -> str (stops at the first NUL), like the reference helper."""
-    if isinstance(ar, str):
-        return ar
-    b = bytes(ar)
-    i = b.find(b"\x00")
-    if i >= 0:
-        b = b[:i]
-    return b.decode("utf-8", errors="replace")
+    """A char array / bytes object as str: ASCII, else UTF-8, every NUL dropped (reference low_level/misc.py:55-60; a ``str`` argument
+    is a TypeError there too - ``bytes("a")`` - and its tests hold that, tests/python/test_rir.py:29-33)."""
+    raw = bytes(ar)
+    try:
+        return raw.decode("ascii").replace("\x00", "")
+    except UnicodeDecodeError:
+        return raw.decode("utf8").replace("\x00", "")
 
 
 def toBytes(s):
@@ -74,13 +75,23 @@ def get_memory_folder():
     return folder
 
 
-def toCharP(s):
-    return toBytes(s)
+def toCharP(obj):
+    """str (ASCII) or bytes as the bytes a ``char *`` argument takes; anything else through ``bytes()`` (reference :78-85, so that
+    ``toCharP(1) == b"\\x00"``)."""
+    if isinstance(obj, str):
+        return obj.encode("ascii")
+    if isinstance(obj, bytes):
+        return obj
+    return bytes(obj)
 
 
-def toArray(s):
-    """str -> mutable char buffer"""
-    return ct.create_string_buffer(toBytes(s))
+def toArray(string):
+    """str or bytes as a numpy array of single characters (reference :63-75)"""
+    raw = string if isinstance(string, bytes) else str(string).encode("ascii")
+    out = np.zeros(len(string), dtype="c")
+    for i in range(len(raw)):
+        out[i] = raw[i:i + 1]
+    return out
 
 
 def last_error():

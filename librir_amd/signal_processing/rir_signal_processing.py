@@ -122,3 +122,29 @@ def bad_pixels_correct(handle, img):
 
 def bad_pixels_destroy(handle):
     _sp.bad_pixels_destroy(handle)
+
+
+# ---- outside the accelerated path ---------------------------------------------------------------------
+# The reference's signal_processing library also holds four CPU utilities that never touch the frame pipeline: two on time vectors
+# (extract_times, resample_time_serie) and a connected-component labelling with its "largest component" filter (label_image,
+# keep_largest_area).  The library exports their names and refuses; the wrappers below exist so that code importing them still imports,
+# and they fail the way the wrapper fails when the library answers with an error: RuntimeError, with the library's message.
+def _outside(name):
+    raise RuntimeError("An error occured while calling '%s': not provided by the MI355X hot-path library "
+                       "(a CPU utility of the reference outside the accelerated path; keep the reference's own library for it)" % name)
+
+
+def extract_times(time_series, strategy="union"):
+    _outside("extract_times")
+
+
+def resample_time_serie(x, y, time_vector, padd=None, interp=True):
+    _outside("resample_time_serie")
+
+
+def label_image(image, background_value=0):
+    _outside("label_image")
+
+
+def keep_largest_area(image, background_value=0, foreground_value=1):
+    _outside("keep_largest_area")

@@ -191,8 +191,13 @@ def zstd_decompress_bound(src):
     return int(_tools.zstd_decompress_bound(bytes(src), len(src)))
 
 
+def _as_bytes(src):
+    """str arguments are accepted like upstream (encoded, unencodable characters replaced: rir_tools.py:34-36,60-62)"""
+    return bytes(src.encode(errors="replace") if isinstance(src, str) else src)
+
+
 def zstd_compress(src, level=0):
-    src = bytes(src)
+    src = _as_bytes(src)
     cap = zstd_compress_bound(len(src))
     if cap < 0:
         raise RuntimeError("'zstd_compress': libzstd is not available on this host")
@@ -204,7 +209,7 @@ def zstd_compress(src, level=0):
 
 
 def zstd_decompress(src):
-    src = bytes(src)
+    src = _as_bytes(src)
     cap = zstd_decompress_bound(src)
     if cap < 0:
         raise RuntimeError("An error occured while calling 'zstd_decompress'")

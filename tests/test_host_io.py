@@ -415,3 +415,34 @@ def test_attribute_accessors_one_at_a_time(tmp_path):
         assert folder == tmp_path / "mem" / "cache" and folder.is_dir()
     finally:
         del os.environ["LIBRIR_TEMP_FOLDER"]
+
+
+def test_low_level_helpers_behave_like_the_reference():
+    """reference tests/python/test_rir.py:21-74: the string helpers of low_level.misc and the zstd wrappers on str arguments"""
+    from librir_amd.low_level.misc import toArray, toCharP, toString
+
+    with pytest.raises(TypeError):
+        toString("a")
+    assert toString(b"a") == "a" and toString(b"\xe2\x82\xac") == "€" and toString(b"ab\x00c\x00") == "abc"
+    assert np.array_equal(toArray("a"), np.array(("a",), dtype="c"))
+    assert toCharP("a") == b"a" and toCharP(b"a") == b"a" and toCharP(1) == b"\x00"
+    assert zstd_decompress(zstd_compress("toto")) == b"toto"
+    for garbage in (b"garbage", "garbage"):
+        with pytest.raises(RuntimeError):
+            zstd_decompress(garbage)
+
+
+def test_functions_outside_the_path_import_and_refuse():
+    """the four CPU utilities of the reference's signal_processing that this build leaves out: the names import - from the
+    package, like upstream - and every call is a RuntimeError, which is also what the reference's own error-case tests expect of them
+    (tests/python/test_rir.py:272-296)"""
+    import librir_amd.signal_processing as sp
+
+    with pytest.raises(RuntimeError):
+        sp.label_image(np.ndarray((10, 10, 10)), 0)
+    with pytest.raises(RuntimeError):
+        sp.keep_largest_area(np.ndarray((10, 10), dtype="object"), 0)
+    with pytest.raises(RuntimeError):
+        sp.extract_times((), "inter")
+    with pytest.raises(RuntimeError):
+        sp.resample_time_serie([], range(10), [0, 1])
