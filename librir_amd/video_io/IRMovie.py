@@ -238,7 +238,9 @@ class IRMovie(object):
 
     @property
     def filename(self):
-        return _abi.get_filename(self.handle)
+        """a ``Path`` (None for a movie without a file), like upstream (IRMovie.py:341-344)"""
+        name = _abi.get_filename(self.handle)
+        return Path(name) if name else None
 
     @property
     def video_file_format(self):
@@ -409,9 +411,18 @@ class IRMovie(object):
                 image = self.load_pos(pos, 0)
                 saver.add_image(image, stamps[pos], attributes=self.frame_attributes if frame_attributes is None else frame_attributes[written])
 
+    def _build_outfile(self):
+        """where pcr2h264 writes by default: beside the movie, suffix ``.h264``; a movie that is encoded already names itself
+        (IRMovie.py:533-545)"""
+        if self.video_file_format != FileFormat.H264:
+            source = str(self._owned_file or self.filename)
+            return os.path.abspath(os.path.splitext(source)[0] + ".h264")
+        return self.filename
+
     def pcr2h264(self, outfile=None, overwrite=False, **kwargs):
-        target = str(Path(self.filename).with_suffix(".h264")) if outfile is None else outfile
-        if os.path.exists(target) and not overwrite:
-            raise RuntimeError("file exists: %s" % target)
-        self.to_h264(target, **kwargs)
-        return IRMovie.from_filename(target)
+        """A raw (PCR) movie re-recorded through the codec; ``kwargs`` go to ``to_h264``.  A destination that exists is kept unless
+        ``overwrite``.  Returns the destination file name (IRMovie.py:520-531)."""
+        outfile = outfile or self._build_outfile()
+        if not os.path.exists(outfile) or overwrite:
+            self.to_h264(outfile, **kwargs)
+        return outfile

@@ -546,3 +546,55 @@ def test_frames_attributes_table(tmp_path):
         assert table.shape == (6, 2) and list(table["tag"]) == [b"t%d" % i for i in range(6)]
         assert np.array_equal(mov._frame_attribute_getter("power"), 10.0 * np.arange(6))
         assert mov._frame_attribute_getter("absent").size == 0
+
+
+def test_more_of_the_reference_scenarios(tmp_path):
+    """reference tests/python/test_IRMovie.py:17-37 (what opens and what does not), :72-79 (pcr2h264), :90-100 (to_h264 from an image
+    on), :103-143 (index kinds), :150-152 (iteration), :268-322 (the RuntimeErrors of to_h264 and the attributes of a subset)."""
+    from librir_amd.video_io import InvalidMovie
+
+    arr = images(9, 24, 40)
+    src = tmp_path / "ref.h264"
+    with IRSaver(src, 40, 24) as s:  # (three arguments, like upstream's tests)
+        for i in range(9):
+            s.add_image(arr[i], i * 1e6, attributes={"n": i})
+    with pytest.raises(RuntimeError):
+        IRMovie.from_filename("")
+    with pytest.raises(InvalidMovie):
+        IRMovie(0)
+    with IRMovie.from_filename(src) as movie:
+        assert type(movie) is IRMovie and movie.filename == src
+        again = IRMovie(movie.handle)
+        assert again.handle == movie.handle
+        again.handle = 0  # (two objects, one handle: only one of them may close it)
+        data = movie.data
+        for index in (-1, slice(-1), [0], np.array([0])):
+            assert np.array_equal(movie[index], data[index])
+        assert np.array_equal(movie[0.0], movie.load_secs(0.0))
+        for i, img in enumerate(movie):
+            assert np.array_equal(img, movie.load_pos(i))
+        movie.to_h264(tmp_path / "tail", start_img=4)
+        with IRMovie.from_filename(tmp_path / "tail") as tail:
+            assert np.array_equal(tail.data, data[4:])
+        fattrs = [{"additional_frame_attribute": i} for i in range(9)]
+        for kw in (dict(start_img=0, count=4, frame_attributes=fattrs), dict(start_img=4, count=4, frame_attributes=fattrs),
+                   dict(start_img=9, count=0, frame_attributes=fattrs), dict(start_img=9, count=0, frame_attributes=None)):
+            with pytest.raises(RuntimeError):
+                movie.to_h264(tmp_path / "no.h264", attrs={"additional": 123}, **kw)
+        movie.to_h264(tmp_path / "sub.h264", start_img=0, count=4, attrs={"additional": 123}, frame_attributes=fattrs[:4])
+        with IRMovie.from_filename(tmp_path / "sub.h264") as sub:
+            assert sub.attributes == {"additional": b"123", "GOP": movie.attributes["GOP"]}
+            assert len(sub.frames_attributes) == sub.images == 4
+    raw = IRMovie.from_numpy_array(arr)  # (an encoded temporary; pcr2h264 of a movie that is encoded already names itself)
+    assert raw.pcr2h264() == raw.filename
+    raw.close()
+    from test_host_io import write_pcr
+
+    pcr = tmp_path / "m.pcr"
+    write_pcr(pcr, arr, frequency=50)
+    with IRMovie.from_filename(pcr) as mov:
+        out = mov.pcr2h264(outfile=str(tmp_path / "m_scratch.h264"))
+        assert out == str(tmp_path / "m_scratch.h264")
+        assert mov.pcr2h264() == str(tmp_path / "m.h264") and os.path.exists(tmp_path / "m.h264")
+        with IRMovie.from_filename(out) as enc:
+            assert np.array_equal(enc.data, mov.data)
