@@ -484,6 +484,10 @@ namespace
 		// upload calls, no read-back, no wait in the call that completes the chunk (tests/perf/zero_copy_probe.py: 711 us for 50 frames
 		// of 640x512, the link's rate).  The caller fills the OTHER staging buffer meanwhile; one chunk is in flight at most, the call
 		// that completes the next one collects it (and waits for it: the link is then the limit).
+		// (decided at open(): the switch, and a chunk of at most kInFlightMaxChunkBytes - the second staging buffer and the second raw
+		// buffer are a chunk each, and chunks of gigabytes gain nothing from being in flight)
+		static constexpr size_t kInFlightMaxChunkBytes = (size_t)768 << 20;
+		bool in_flight_mode = false;
 		PinnedBuffer h_stage_b;
 		int cur_stage = 0; // 0: cc.h_frames, 1: h_stage_b
 		char *stage_ptr() { return cur_stage ? h_stage_b.as<char>() : cc.h_frames.as<char>(); }
@@ -533,7 +537,7 @@ namespace
 		bool loss_ev_set[2] = {false, false}, copy_st_failed = false;
 		hipStream_t upload_stream()
 		{
-			if (!abi_zero_copy() || copy_st_failed)
+			if (!in_flight_mode || copy_st_failed)
 				return default_stream();
 			if (!copy_st)
 			{
@@ -589,7 +593,7 @@ namespace
 				PinnedBuffer frames, frames_b, out0, out1;
 				const size_t ob = (size_t)L.ntiles * gop * 8 + (((size_t)L.ntiles + 1) * 4 + 7) / 8 * 8 + (size_t)L.stream_max_bytes + 64;
 				(void)frames.reserve((size_t)w * h * 2 * gop);
-				if (abi_zero_copy())
+				if (abi_zero_copy() && (size_t)w * h * 2 * gop <= kInFlightMaxChunkBytes)
 					(void)frames_b.reserve((size_t)w * h * 2 * gop);
 				(void)out0.reserve(ob);
 				(void)out1.reserve(ob);
@@ -893,6 +897,7 @@ namespace
 			file_pos = sizeof(box) + sizeof(hd);
 			write_failed = false;
 			cur_stage = 0, flying.active = false;
+			in_flight_mode = abi_zero_copy() && (size_t)chunk_gop * width * height * 2 <= kInFlightMaxChunkBytes;
 			opened = true;
 			return true;
 		}
@@ -901,7 +906,7 @@ namespace
 		{
 			hipStream_t st = default_stream();
 			rir_codec_layout L;
-			if (abi_zero_copy() && pending > 0)
+			if (in_flight_mode && pending > 0)
 			{ // nothing is waited for but the chunk BEFORE this one: this chunk's loss step, its encode and its error budgets are queued
 #ifdef RIR_SAVER_DIAG
 				const double t0 = dg_now();
@@ -1142,7 +1147,7 @@ namespace
 			// A chunk made of such frames only is encoded from where they lie (submit_chunk).  Without that (RIR_ABI_ZERO_COPY=0, or a
 			// chunk that already holds device frames) uploads go in groups of a few frames, one asynchronous copy each; what is left of a
 			// chunk goes when the chunk is flushed
-			if ((!abi_zero_copy() || uploaded > 0) && pending + 1 - uploaded >= kUploadGroup && !upload_staged(pending + 1))
+			if ((!in_flight_mode || uploaded > 0) && pending + 1 - uploaded >= kUploadGroup && !upload_staged(pending + 1))
 				return false;
 			return frame_added(ts, attrs);
 		}
@@ -1876,7 +1881,9 @@ namespace
 				host_copy(out, cc.h_frames.as<char>() + (size_t)(pos - host_base) * fbytes, fbytes);
 				if (track && seq_run >= 2)
 				{ // (no-ops when they are under way, done, or there is no such chunk)
-					for (int a = 1; a <= kLanes; ++a)
+					// (chunks of hundreds of megabytes: one lane - a lane holds a chunk twice in page-locked memory)
+					const int lanes = (size_t)hd.gop * width * height * 2 <= ((size_t)256 << 20) ? kLanes : 1;
+					for (int a = 1; a <= lanes; ++a)
 						start_prefetch(cached_chunk + a);
 				}
 				return true;
