@@ -255,6 +255,31 @@ def abi_numbers(frames_np, D, ctx, frames, out, n, h, w):
     torch.cuda.synchronize()
     res["batched_h2d_d2h_fps"] = 3 * n / (time.perf_counter() - t0)
     assert np.array_equal(pin_out.numpy(), frames_np)
+    # the host link itself, for the per-frame numbers above: one chunk of 50 frames each way, page-locked memory, HIP events
+    k = min(n, 50)
+
+    def link_gbs(dst, src):
+        best = 0.0
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dst.copy_(src, non_blocking=True)
+            e1.record()
+            torch.cuda.synchronize()
+            best = max(best, src.numel() * src.element_size() / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        return best
+
+    up, down = link_gbs(frames[:k], pin_in[:k]), link_gbs(pin_out[:k], frames[:k])
+    fb = float(h * w * 2)
+    us_up, us_down = fb / up / 1e3, fb / down / 1e3
+    d = res["per_frame_abi_detail"]
+    res["host_link"] = {
+        "h2d_GBs": up, "d2h_GBs": down, "us_per_image_up": us_up, "us_per_image_down": us_down,
+        "round_trip_bound_fps": 1e6 / (us_up + us_down),
+        "per_frame_abi_frac_of_link_bound": res["per_frame_abi_fps"] / (1e6 / (us_up + us_down)),
+        "record_frac_of_link_bound": d["record_fps"] / (1e6 / us_up), "read_frac_of_link_bound": d["read_fps"] / (1e6 / us_down),
+        "note": "the per-frame C ABI moves every image over this link once in each direction (record: images up, a fifth of their size back as payload; "
+                "read: payload up, images down); the bound counts the images alone"}
     try:
         res["other_paths"] = other_paths(D, frames, h, w)
     except Exception as e:  # (never at the cost of the numbers above)
