@@ -1619,7 +1619,11 @@ namespace
 			// fresh 7 MB vector per chunk, and the uploads below run at the PCIe rate instead of through the runtime's staging
 			const size_t hdr_n = (size_t)ch.ntiles * ch.gop, toff_n = (size_t)ch.ntiles + 1, pay_n = (size_t)ch.payload_words + 1;
 			const size_t hdr_b = hdr_n * 8, toff_b = (toff_n * 4 + 7) & ~(size_t)7;
-			if (!ctx.h_in.reserve(hdr_b + toff_b + (size_t)ctx.L.stream_max_bytes + 64)) // (+ the guard word, the two chunk offsets and two flag words)
+			// (+ the guard word, the two chunk offsets and two flag words).  Sized for THIS chunk with a quarter to spare, not for the worst
+			// case a chunk can be (the raw size): a recording compresses about five times, and page-locking is what the first read of a
+			// process waits for (0.3 ms per megabyte, three buffer sets); a later chunk that needs more makes the buffer grow.
+			const size_t in_need = hdr_b + toff_b + pay_n * 8 + 64;
+			if (ctx.h_in.cap < in_need && !ctx.h_in.reserve(std::min(in_need + in_need / 4, hdr_b + toff_b + (size_t)ctx.L.stream_max_bytes + 64)))
 				return false;
 			uint64_t *hdr = ctx.h_in.as<uint64_t>();
 			uint32_t *toff = reinterpret_cast<uint32_t *>(ctx.h_in.as<char>() + hdr_b);
@@ -1712,7 +1716,11 @@ namespace
 				const int c = p.want;
 				p.want = -1, p.busy = true, p.ok = false, p.have = c;
 				lk.unlock();
-				const bool ok = nx[lane].prepare(width, height, (int)hd.gop, false) && decode_chunk_into(nx[lane], c, p.stream, true, true);
+				// (the lane's stream is made here, on the lane's thread: creating a stream takes milliseconds, which the reader's call
+				// that starts the lane should not wait for)
+				if (!p.stream && hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) != hipSuccess)
+					p.stream = nullptr;
+				const bool ok = p.stream && nx[lane].prepare(width, height, (int)hd.gop, false) && decode_chunk_into(nx[lane], c, p.stream, true, true);
 				lk.lock();
 				p.ok = ok, p.busy = false;
 				p.cv.notify_all();
@@ -1741,16 +1749,12 @@ namespace
 				const bool holds_next = p.ok && p.have > cached_chunk && p.have <= cached_chunk + kLanes;
 				if (p.busy || p.want >= 0 || holds_next)
 					continue;
-				if (!p.stream)
-				{
-					if (hipGetDevice(&p.device) != hipSuccess || hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking) != hipSuccess)
-					{
-						p.stream = nullptr;
-						return;
-					}
-				}
 				if (!p.th.joinable())
+				{
+					if (hipGetDevice(&p.device) != hipSuccess)
+						return;
 					p.th = std::thread([this, l] { prefetch_loop(l); });
+				}
 				p.want = c, p.have = -1, p.ok = false;
 				p.cv.notify_all();
 				return;
