@@ -12,7 +12,8 @@
 // cuts the copy into that many parts + its own, and waits for the parts it handed out; a PARKED helper is woken for the NEXT call
 // and this call does without it.  Nothing is shared between two callers, so several savers / loaders driven from different threads
 // simply compete for the idle helpers.  During a burst of per-frame calls (a recording, a sequential read) the helpers stay hot;
-// a few hundred microseconds after the last call they sleep and cost nothing.
+// a few hundred microseconds after the last call they sleep and cost nothing.  The helpers of the file group sleep between jobs and are
+// woken with their part (a chunk's read or write is long against a wake-up).
 // The same helpers move a chunk between page-locked memory and the FILE (host_pread / host_pwrite: disjoint ranges of one descriptor):
 // a 7 MB chunk through the page cache is 0.8-1.4 ms on one thread - longer than the chunk's 0.65 ms on the PCIe link.
 // RIR_HOST_COPY_THREADS / RIR_HOST_IO_THREADS = helpers for memory copies / for file jobs (default 3 each, 0 = on the calling thread, at
@@ -123,6 +124,7 @@ namespace rir
 			std::mutex m;
 			std::condition_variable cv;
 			bool wake = false;
+			int64_t spin_ns = kSpinNs; // how long it spins idle before it parks (0: at once - the file group)
 			std::thread th;
 		};
 
@@ -153,6 +155,9 @@ namespace rir
 				for (int g = 0; g < 2; ++g)
 					for (int i = 0; i < n[g]; ++i)
 					{
+						// a copy job comes every 10-20 us and takes 8: its helpers spin between jobs.  A file job comes once a chunk and takes
+						// hundreds of microseconds: its helpers sleep in between and are woken WITH their job (50 us of wake-up do not matter)
+						h[g][i].spin_ns = g == 0 ? kSpinNs : 0;
 						h[g][i].th = std::thread([this, g, i] { run(h[g][i]); });
 						h[g][i].th.detach(); // the pool lives as long as the process (it is leaked on purpose: no destructor order to get wrong)
 					}
@@ -176,7 +181,7 @@ namespace rir
 						idle_since = now_ns();
 						continue;
 					}
-					if (s == IDLE && now_ns() - idle_since > kSpinNs)
+					if (s == IDLE && now_ns() - idle_since >= me.spin_ns)
 					{
 						int expect = IDLE;
 						if (me.state.compare_exchange_strong(expect, PARKED, std::memory_order_acq_rel))
@@ -184,10 +189,14 @@ namespace rir
 					}
 					if (s == PARKED)
 					{
-						std::unique_lock<std::mutex> lk(me.m);
-						me.cv.wait(lk, [&] { return me.wake; });
-						me.wake = false;
-						me.state.store(IDLE, std::memory_order_release);
+						{
+							std::unique_lock<std::mutex> lk(me.m);
+							me.cv.wait(lk, [&] { return me.wake; });
+							me.wake = false;
+						}
+						// woken for the next call (still PARKED: spin now), or woken WITH a job (an owner made it BUSY while it slept)
+						int expect = PARKED;
+						(void)me.state.compare_exchange_strong(expect, IDLE, std::memory_order_acq_rel);
 						idle_since = now_ns();
 						continue;
 					}
@@ -216,6 +225,15 @@ namespace rir
 			Helper *mine[kMaxHelpers];
 			int k = 0;
 			const int g = kind == JOB_COPY ? 0 : 1;
+			bool asleep[kMaxHelpers] = {};
+			auto wake = [](Helper &h) {
+				std::lock_guard<std::mutex> lk(h.m);
+				if (!h.wake)
+				{
+					h.wake = true;
+					h.cv.notify_one();
+				}
+			};
 			for (int i = 0; i < p->n[g]; ++i)
 			{
 				Helper &h = p->h[g][i];
@@ -223,13 +241,11 @@ namespace rir
 				if (h.state.compare_exchange_strong(expect, BUSY, std::memory_order_acq_rel))
 					mine[k++] = &h;
 				else if (expect == PARKED)
-				{ // wake it for the next call; this one does without it
-					std::lock_guard<std::mutex> lk(h.m);
-					if (!h.wake)
-					{
-						h.wake = true;
-						h.cv.notify_one();
-					}
+				{
+					if (g == 0)
+						wake(h); // a copy: woken for the next call, this one does without it
+					else if (h.state.compare_exchange_strong(expect, BUSY, std::memory_order_acq_rel))
+						asleep[k] = true, mine[k++] = &h; // a file job: taken asleep, woken below with its part
 				}
 			}
 			// k + 1 parts, cut at multiples of 4 KiB; the caller takes the last one
@@ -245,6 +261,8 @@ namespace rir
 				h.dst = dst ? static_cast<char *>(dst) + off : nullptr, h.src = src ? static_cast<const char *>(src) + off : nullptr, h.bytes = n;
 				want[i] = h.go.load(std::memory_order_relaxed) + 1;
 				h.go.store(want[i], std::memory_order_release);
+				if (asleep[i])
+					wake(h);
 				off += n;
 			}
 			bool ok = true;
@@ -253,8 +271,13 @@ namespace rir
 							file_off + (int64_t)off);
 			// (`done` only grows: by the time this caller looks, the helper may have finished a LATER job of another caller already)
 			for (int i = 0; i < k; ++i)
-				while (mine[i]->done.load(std::memory_order_acquire) < want[i])
-					cpu_relax();
+				for (unsigned spins = 0; mine[i]->done.load(std::memory_order_acquire) < want[i]; ++spins)
+				{
+					if (g == 1 && spins > 2000)
+						std::this_thread::yield(); // (a file job: the writer thread / a read-ahead lane waits, for as long as the file system takes)
+					else
+						cpu_relax();
+				}
 			return ok && failed.load(std::memory_order_relaxed) == 0;
 		}
 	} // namespace
