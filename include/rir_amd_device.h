@@ -230,6 +230,17 @@ extern "C"
 	/* 3x3 median filter: reference Filters.h:71-129 (template without C export upstream). */
 	int rir_median_filter_device(const unsigned short *d_src, unsigned short *d_dst, int w, int h, int nframes, void *stream);
 
+	/* connected components: reference signal_processing.h:90-92 / Filters.h:365-540 (labelImage, keepLargestArea) on one image in
+	 * device memory.  type: the reference's dtype character; background: HOST pointer to one cell of that type.
+	 * d_dst int32 [h][w].  label: d_xy double[2*(labels)], d_area int[labels], d_count int[1] receive the per-component tables and
+	 * labels = components + 1 (room for w*h + 1 entries is always enough); any memory the device can write.
+	 * d_work: device memory, 8-byte aligned, at least rir_label_workspace_bytes(w, h) (0: geometry refused).  0 / -1. */
+	size_t rir_label_workspace_bytes(int w, int h);
+	int rir_label_image_device(int type, const void *d_src, int *d_dst, int w, int h, const void *background, double *d_xy, int *d_area,
+							   int *d_count, void *d_work, size_t work_bytes, void *stream);
+	int rir_keep_largest_area_device(int type, const void *d_src, int *d_dst, int w, int h, const void *background, int foreground, void *d_work,
+									 size_t work_bytes, void *stream);
+
 	/* ---- bounded-loss step on a device-resident stream -------------------------------------------------
 	 * The loss injection of H264_Saver::addImageLossyNoCamera / addLoss (reference src/cpp/video_io/h264.cpp:2253-2607)
 	 * as a stream operator: uint16 frames [n][h][w] in HBM in and out (distinct buffers), one state object per

@@ -35,12 +35,21 @@ extern "C"
 	/* reference signal_processing.h:94 */
 	size_t hash_bytes(void *ptr, size_t len);
 
-	/* reference signal_processing.h:55,71,90,92 — CPU utilities outside the accelerated path
-	 * (SURVEY.md §8): the symbols resolve, the calls log an error and return -1. */
+	/* reference signal_processing.h:55 / signal_processing.cpp:158-181 — one time axis out of several (s: 0 union, 1 intersection).
+	 * time_vector: the vectors one after the other, vector_sizes[vector_count] their lengths.  0; -2 with the needed size in
+	 * *output_size when the output is too small; -1 on input the reference does not return from (csrc/time_series.cpp). */
 	int extract_times(double *time_vector, int vector_count, int *vector_sizes, int s, double *output, int *output_size);
+	/* reference signal_processing.h:71 / signal_processing.cpp:183-195 — (sample_x, sample_y) read at `times` (s: 2 pad with padds
+	 * outside the samples, 4 interpolate).  0; -1 when the output is too small (needed size in *output_size). */
 	int resample_time_serie(double *sample_x, double *sample_y, int size, double *times, int times_size, int s, double padds, double *output,
 							int *output_size);
+	/* reference signal_processing.h:90 / signal_processing.cpp:224-266 — connected components of `src` (cells != *background; joined
+	 * vertically whatever their values, horizontally when equal), numbered from 1 in raster order of their first pixel into dst.
+	 * Returns the number of table entries (components + 1; entry 0 is the background's) written to out_xy (x of the first pixel, twice -
+	 * as upstream) and out_area, -1 on an unknown type. */
 	int label_image(int type, void *src, int *dst, int w, int h, void *background, double *out_xy, int *out_area);
+	/* reference signal_processing.h:92 / signal_processing.cpp:276-318 — dst = foreground on the largest component, (int)*background
+	 * elsewhere (all zero without a component).  0, -1 on an unknown type. */
 	int keep_largest_area(int type, void *src, int *dst, int w, int h, void *background, int foreground);
 
 #ifdef __cplusplus

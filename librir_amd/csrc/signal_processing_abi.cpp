@@ -12,6 +12,7 @@
 #include <map>
 
 #include "filter_kernels.h"
+#include "label_kernels.h"
 #include "runtime.h"
 
 using namespace rir;
@@ -150,6 +151,7 @@ namespace
 		std::mutex mu;
 		DeviceBuffer a, b, c, d;
 		PinnedBuffer h_in, h_out; // page-locked staging of the caller's images
+		PinnedBuffer h_tab;		  // label_image: the per-component tables, written by the kernel
 	};
 	HostScratch &scratch()
 	{
@@ -764,15 +766,161 @@ RIR_EXPORT size_t hash_bytes(void *_ptr, size_t len)
 	return (size_t)h;
 }
 
-// Out of the hot path (SURVEY.md §8, rows marked out of scope): sequential 1-D time-series and
-// connected-component utilities.  The symbols exist so that the drop-in library resolves them;
-// they report an error instead of computing.
-static int out_of_scope(const char *name)
+// ---- connected components (label_kernels.hip) -----------------------------------------------------------------------------------
+namespace
 {
-	log_error(std::string(name) + ": not provided by the MI355X hot-path library (CPU utility outside the accelerated path)");
-	return -1;
+	int cell_bytes_of(int type)
+	{ // what `==` means for the reference's cell types (signal_processing.cpp:228-263): integers by their bits, floating point as IEEE
+		switch (type)
+		{
+		case 'f':
+			return -4;
+		case 'd':
+			return -8;
+		default:
+			return dtype_size(type); // 0: unknown
+		}
+	}
+	// `(U)background` with U = int (Filters.h:535): the host's own conversion of the cell type, at run time like the reference's
+	int background_as_int(int type, const void *bg)
+	{
+		switch (type)
+		{
+		case '?':
+		case 'B':
+			return (int)*static_cast<const unsigned char *>(bg);
+		case 'b':
+			return (int)*static_cast<const signed char *>(bg);
+		case 'h':
+			return (int)*static_cast<const short *>(bg);
+		case 'H':
+			return (int)*static_cast<const unsigned short *>(bg);
+		case 'i':
+			return *static_cast<const int *>(bg);
+		case 'I':
+			return (int)*static_cast<const unsigned int *>(bg);
+		case 'l':
+			return (int)*static_cast<const long long *>(bg);
+		case 'L':
+			return (int)*static_cast<const unsigned long long *>(bg);
+		case 'f':
+		{
+			volatile float f = *static_cast<const float *>(bg);
+			return (int)f;
+		}
+		case 'd':
+		{
+			volatile double d = *static_cast<const double *>(bg);
+			return (int)d;
+		}
+		default:
+			return 0;
+		}
+	}
+} // namespace
+
+RIR_EXPORT size_t rir_label_workspace_bytes(int w, int h) { return label_workspace_bytes(w, h); }
+
+RIR_EXPORT int rir_label_image_device(int type, const void *d_src, int *d_dst, int w, int h, const void *background, double *d_xy, int *d_area,
+									  int *d_count, void *d_work, size_t work_bytes, void *stream)
+{
+	const int cell = cell_bytes_of(type);
+	if (cell == 0)
+		return -1;
+	if (!device_ready())
+		return -1;
+	const size_t need = label_workspace_bytes(w, h);
+	if (need == 0 || work_bytes < need || ((uintptr_t)d_work & 7))
+		return -1;
+	return hip_ok(launch_label_image(cell, d_src, background, w, h, d_dst, d_xy, d_area, d_count, d_work, as_stream(stream)), "label_image") ? 0 : -1;
 }
-RIR_EXPORT int extract_times(double *, int, int *, int, double *, int *) { return out_of_scope("extract_times"); }
-RIR_EXPORT int resample_time_serie(double *, double *, int, double *, int, int, double, double *, int *) { return out_of_scope("resample_time_serie"); }
-RIR_EXPORT int label_image(int, void *, int *, int, int, void *, double *, int *) { return out_of_scope("label_image"); }
-RIR_EXPORT int keep_largest_area(int, void *, int *, int, int, void *, int) { return out_of_scope("keep_largest_area"); }
+
+RIR_EXPORT int rir_keep_largest_area_device(int type, const void *d_src, int *d_dst, int w, int h, const void *background, int foreground,
+											void *d_work, size_t work_bytes, void *stream)
+{
+	const int cell = cell_bytes_of(type);
+	if (cell == 0 || !background)
+		return -1;
+	if (!device_ready())
+		return -1;
+	const size_t need = label_workspace_bytes(w, h);
+	if (need == 0 || work_bytes < need || ((uintptr_t)d_work & 7))
+		return -1;
+	return hip_ok(launch_keep_largest_area(cell, d_src, background, w, h, d_dst, foreground, background_as_int(type, background), d_work,
+										   as_stream(stream)),
+				  "keep_largest_area")
+			   ? 0
+			   : -1;
+}
+
+// The image goes to device memory (the passes read it several times); the labels come back through the page-locked staging buffer
+// like every other image of this file, the small tables (one entry per component) are written over the link by the kernel itself.
+static int label_host(int type, void *src, int *dst, int w, int h, void *background, double *out_xy, int *out_area, bool keep, int foreground)
+{
+	const int es = dtype_size(type);
+	if (es == 0) // signal_processing.cpp:261-262, :313-314
+		return -1;
+	if (!device_ready())
+		return -1;
+	if (!src || !dst || !background || w < 0 || h < 0 || (!keep && (!out_xy || !out_area)))
+		return -1;
+	if (w == 0 || h == 0)
+	{ // no pixel: the table holds the background's entry alone (Filters.h:489, Label() = (-1, -1), area 0)
+		if (keep)
+			return 0;
+		out_xy[0] = out_xy[1] = -1.0;
+		out_area[0] = 0;
+		return 1;
+	}
+	const size_t work = label_workspace_bytes(w, h);
+	if (work == 0)
+	{
+		log_error("label_image: image too large");
+		return -1;
+	}
+	HostScratch &s = scratch();
+	std::lock_guard<std::mutex> g(s.mu);
+	hipStream_t st = default_stream();
+	const size_t n = (size_t)w * h, in_bytes = n * es, out_bytes = n * sizeof(int);
+	const size_t xy_bytes = (n + 1) * 2 * sizeof(double), area_bytes = (n + 1) * sizeof(int);
+	if (!s.h_in.reserve(in_bytes) || !s.a.reserve(in_bytes) || !s.c.reserve(work) || (!keep && !s.h_tab.reserve(xy_bytes + area_bytes + 64)))
+		return -1;
+	host_copy(s.h_in.ptr, src, in_bytes);
+	if (!hip_ok(hipMemcpyAsync(s.a.ptr, s.h_in.ptr, in_bytes, hipMemcpyHostToDevice, st), "H2D"))
+		return -1;
+	void *out = stage_out(s, s.b, dst, out_bytes, false, st);
+	if (!out)
+		return -1;
+	if (keep)
+	{
+		if (rir_keep_largest_area_device(type, s.a.ptr, static_cast<int *>(out), w, h, background, foreground, s.c.ptr, s.c.cap, st) != 0)
+			return -1;
+		return hand_out(s, dst, out, out_bytes, st) ? 0 : -1;
+	}
+	double *xy = s.h_tab.as<double>();
+	int *area = reinterpret_cast<int *>(s.h_tab.as<char>() + xy_bytes);
+	int *count = reinterpret_cast<int *>(s.h_tab.as<char>() + xy_bytes + area_bytes);
+	*count = -1;
+	if (rir_label_image_device(type, s.a.ptr, static_cast<int *>(out), w, h, background, xy, area, count, s.c.ptr, s.c.cap, st) != 0)
+		return -1;
+	if (!hand_out(s, dst, out, out_bytes, st)) // (waits for the stream: the tables are complete)
+		return -1;
+	const int labels = *count;
+	if (labels < 1 || (size_t)labels > n + 1)
+		return -1;
+	std::memcpy(out_xy, xy, (size_t)labels * 2 * sizeof(double));
+	std::memcpy(out_area, area, (size_t)labels * sizeof(int));
+	return labels;
+}
+
+// reference signal_processing.cpp:224-266: the number of table entries (components + 1), -1 on an unknown type.  out_xy / out_area
+// receive that many entries (the caller sizes them; one entry per pixel plus one is always enough).
+RIR_EXPORT int label_image(int type, void *src, int *dst, int w, int h, void *background, double *out_xy, int *out_area)
+{
+	return label_host(type, src, dst, w, h, background, out_xy, out_area, false, 0);
+}
+// reference signal_processing.cpp:276-318: 0, -1 on an unknown type
+RIR_EXPORT int keep_largest_area(int type, void *src, int *dst, int w, int h, void *background, int foreground)
+{
+	return label_host(type, src, dst, w, h, background, nullptr, nullptr, true, foreground);
+}

@@ -108,6 +108,10 @@ _lib.rir_remove_bad_pixels_device.argtypes = [ct.c_int, _vp, ct.c_int, ct.c_int,
 _lib.rir_remove_motion_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp]
 _lib.rir_median_filter_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp]
 _lib.bad_pixels_destroy.argtypes = [ct.c_int]
+_lib.rir_label_workspace_bytes.argtypes = [ct.c_int, ct.c_int]
+_lib.rir_label_workspace_bytes.restype = ct.c_size_t
+_lib.rir_label_image_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, _vp, ct.c_size_t, _vp]
+_lib.rir_keep_largest_area_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, _vp, ct.c_int, _vp, ct.c_size_t, _vp]
 _lib.rir_lossy_create.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_double, ct.c_int, ct.c_int, ct.c_int]
 _lib.rir_lossy_step_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, _vp, _vp, _vp]
 _lib.rir_lossy_step_multi_device.argtypes = [_vp, ct.c_int, _vp, _vp, ct.c_int, ct.c_int, _vp, _vp, _vp]
@@ -593,6 +597,46 @@ def median_filter(frames):
     out = torch.empty_like(fr)
     _check(_lib.rir_median_filter_device(fr.data_ptr(), out.data_ptr(), w, h, n, _stream()), "rir_median_filter_device")
     return out
+
+
+def _label_args(image, background):
+    if image.dim() != 2 or not image.is_cuda:
+        raise RuntimeError("label_image: one (h, w) image on the device expected")
+    img = image.contiguous()
+    ch = _DTYPE_CHARS.get(img.dtype)
+    if ch is None:
+        raise RuntimeError("label_image: unsupported dtype")
+    h, w = img.shape
+    need = _lib.rir_label_workspace_bytes(w, h)
+    if need == 0:
+        raise RuntimeError("label_image: geometry refused")
+    work = torch.empty(need // 8 + 1, dtype=torch.int64, device=img.device)
+    back = np.zeros(1, dtype=_NP_OF[img.dtype])
+    back[0] = background
+    return img, ch, h, w, work, back
+
+
+def label_image(image, background=0):
+    """Connected components of one image in device memory (reference Filters.h:365-509): (labels int32 (h, w), areas, first-pixel table),
+    everything on the device; entry 0 of the tables is the background's."""
+    img, ch, h, w, work, back = _label_args(image, background)
+    dst = torch.empty((h, w), dtype=torch.int32, device=img.device)
+    xy = torch.empty((h * w + 1, 2), dtype=torch.float64, device=img.device)
+    area = torch.empty(h * w + 1, dtype=torch.int32, device=img.device)
+    count = torch.zeros(1, dtype=torch.int32, device=img.device)
+    _check(_lib.rir_label_image_device(ord(ch), img.data_ptr(), dst.data_ptr(), w, h, back.ctypes.data, xy.data_ptr(), area.data_ptr(),
+                                       count.data_ptr(), work.data_ptr(), work.numel() * 8, _stream()), "rir_label_image_device")
+    r = int(count.item())
+    return dst, area[:r], xy[:r]
+
+
+def keep_largest_area(image, background=0, foreground=1):
+    """`foreground` on the largest component, int(background) elsewhere (reference Filters.h:511-540), int32 (h, w) on the device."""
+    img, ch, h, w, work, back = _label_args(image, background)
+    dst = torch.empty((h, w), dtype=torch.int32, device=img.device)
+    _check(_lib.rir_keep_largest_area_device(ord(ch), img.data_ptr(), dst.data_ptr(), w, h, back.ctypes.data, int(foreground), work.data_ptr(),
+                                             work.numel() * 8, _stream()), "rir_keep_largest_area_device")
+    return dst
 
 
 def split_planes(frames, linesize=None, it=None):

@@ -124,27 +124,123 @@ def bad_pixels_destroy(handle):
     _sp.bad_pixels_destroy(handle)
 
 
-# ---- outside the accelerated path ---------------------------------------------------------------------
-# The reference's signal_processing library also holds four CPU utilities that never touch the frame pipeline: two on time vectors
-# (extract_times, resample_time_serie) and a connected-component labelling with its "largest component" filter (label_image,
-# keep_largest_area).  The library exports their names and refuses; the wrappers below exist so that code importing them still imports,
-# and they fail the way the wrapper fails when the library answers with an error: RuntimeError, with the library's message.
-def _outside(name):
-    raise RuntimeError("An error occured while calling '%s': not provided by the MI355X hot-path library "
-                       "(a CPU utility of the reference outside the accelerated path; keep the reference's own library for it)" % name)
+# ---- time axes (host bookkeeping, csrc/time_series.cpp) -------------------------------------------------------------------------
+_sp.extract_times.argtypes = [ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p, ct.POINTER(ct.c_int)]
+_sp.resample_time_serie.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int, ct.c_double, ct.c_void_p, ct.POINTER(ct.c_int)]
+_sp.label_image.argtypes = [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p]
+_sp.keep_largest_area.argtypes = [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int]
 
 
 def extract_times(time_series, strategy="union"):
-    _outside("extract_times")
+    """
+    Create a unique time vector from several ones (reference rir_signal_processing.py:150-207).
+    time_series is a list of input time series
+    strategy is either 'union' (take the union of all time series) or 'inter'
+    Returns a growing time vector containing all different time values given in
+    time_series, without redundant times.
+
+    Where the reference never returns (an empty series, a NaN at either end of one or two NaN in one, a series with no sample inside the
+    common range of 'inter') the library refuses and this raises RuntimeError.
+    """
+    if len(time_series) == 0:
+        raise RuntimeError("extract_times: NULL size")
+    if strategy != "union" and strategy != "inter":
+        raise RuntimeError("extract_times: wrong strategy")
+    series = [np.array(t, dtype=np.float64).ravel() for t in time_series]
+    times = np.ascontiguousarray(np.concatenate(series + [np.zeros(1)]))  # (one spare element: never an empty buffer)
+    sizes = np.array([t.size for t in series], dtype=np.int32)
+    outsize = ct.c_int(int(sizes.sum()))
+    out = np.zeros(max(outsize.value, 1), dtype=np.float64)
+    s = 1 if strategy == "inter" else 0
+    tmp = _sp.extract_times(times.ctypes.data, len(series), sizes.ctypes.data, s, out.ctypes.data, ct.byref(outsize))
+    if tmp == -2:
+        out = np.zeros(outsize.value, dtype=np.float64)
+        tmp = _sp.extract_times(times.ctypes.data, len(series), sizes.ctypes.data, s, out.ctypes.data, ct.byref(outsize))
+    if tmp != 0:
+        raise RuntimeError(last_error() or "extract_times: unknown error")
+    return out[0:outsize.value]
 
 
 def resample_time_serie(x, y, time_vector, padd=None, interp=True):
-    _outside("resample_time_serie")
+    """
+    Resample a time serie based on a new time vector (reference rir_signal_processing.py:210-270)
+    - x: time vector of the time serie
+    - y: values associated to the time serie
+    - time_vector: new time vector
+    - padd: if not None, padd the output serie with this value at boundaries
+    - interp: if True, interpolate values.
+    Returns the new y values corresponding to the new time vector.
+
+    (The reference gives the library room for 2 * len(x) values and raises "unknown error" for a longer time_vector; here the room is
+    the time vector's length.)
+    """
+    if len(x) != len(y) or len(x) == 0:
+        raise RuntimeError("resample_time_serie: wrong input serie size")
+    if len(time_vector) == 0:
+        raise RuntimeError("resample_time_serie: wrong time vector size")
+    x = np.ascontiguousarray(np.array(x, dtype=np.float64).ravel())
+    y = np.ascontiguousarray(np.array(y, dtype=np.float64).ravel())
+    time_vector = np.ascontiguousarray(np.array(time_vector, dtype=np.float64).ravel())
+    s = 0
+    if padd is not None:
+        s |= 2
+    if bool(interp):
+        s |= 4
+    padd = 0.0 if padd is None else float(padd)
+    outsize = ct.c_int(max(2 * x.size, time_vector.size))
+    out = np.zeros(outsize.value, dtype=np.float64)
+    tmp = _sp.resample_time_serie(x.ctypes.data, y.ctypes.data, x.size, time_vector.ctypes.data, time_vector.size, s, padd, out.ctypes.data,
+                                  ct.byref(outsize))
+    if tmp != 0:
+        raise RuntimeError(last_error() or "resample_time_serie: unknown error")
+    return out[0:outsize.value]
 
 
-def label_image(image, background_value=0):
-    _outside("label_image")
+# ---- connected components (csrc/label_kernels.hip) ------------------------------------------------------------------------------
+def _labelling_input(image, background_value, name):
+    if not isinstance(image, np.ndarray) or len(image.shape) != 2:
+        raise RuntimeError("%s: wrong input image dimension" % name)
+    dt = _DTYPES.get(image.dtype, None)
+    if dt is None:
+        raise RuntimeError("An error occured while calling '%s'" % name)
+    img = np.ascontiguousarray(image)
+    background = np.zeros(1, dtype=image.dtype)
+    background[0] = background_value
+    return img, background, dt
+
+
+def label_image(image: np.ndarray, background_value=0):
+    """
+    Closed Component Labelling algorithm (reference rir_signal_processing.py:319-370)
+    Returns a tuple (image,areas, first_points), each index of the list corresponding
+    to the label value.
+    The index 0 corresponds to the background, and does not contain meaningful
+    information.
+
+    Pixels differing from background_value form the components; vertical neighbours are joined whatever their values, horizontal
+    neighbours when their values are equal (as upstream); labels follow the raster order of the components' first pixels.  As upstream,
+    both columns of first_points hold the first pixel's x.
+    """
+    img, background, dt = _labelling_input(image, background_value, "label_image")
+    res = np.empty(img.shape, dtype=np.int32)
+    areas = np.empty(img.size + 1, dtype=np.int32)  # (the reference allocates img.size entries: one short when every pixel of a row
+    xy = np.empty((img.size + 1, 2), dtype=np.float64)  # image is its own component)
+    r = _sp.label_image(ord(dt), img.ctypes.data, res.ctypes.data, img.shape[1], img.shape[0], background.ctypes.data, xy.ctypes.data,
+                        areas.ctypes.data)
+    if r < 0:
+        raise RuntimeError("An error occured while calling 'label_image'")
+    return (res, areas[0:r], xy[0:r])
 
 
 def keep_largest_area(image, background_value=0, foreground_value=1):
-    _outside("keep_largest_area")
+    """
+    Returns an image where the largest closed region of input image is set to
+    foreground_value,
+    the rest to background_value (reference rir_signal_processing.py:373-415)
+    """
+    img, background, dt = _labelling_input(image, background_value, "keep_largest_area")
+    res = np.empty(img.shape, dtype=np.int32)
+    r = _sp.keep_largest_area(ord(dt), img.ctypes.data, res.ctypes.data, img.shape[1], img.shape[0], background.ctypes.data, int(foreground_value))
+    if r < 0:
+        raise RuntimeError("An error occured while calling 'keep_largest_area'")
+    return res

@@ -77,6 +77,64 @@ class _SignalProcessingMixin:
         f.restype = ct.c_int
         return f(_p(img), _p(m), img.size, np.float32(percent))
 
+    def label_image(self, image, background=0):
+        """-> (labels int32 [h][w], areas [components + 1], xy [components + 1][2])"""
+        img = np.ascontiguousarray(image)
+        h, w = img.shape
+        dst = np.full(img.shape, -7, dtype=np.int32)
+        xy = np.zeros((img.size + 1, 2), dtype=np.float64)
+        area = np.zeros(img.size + 1, dtype=np.int32)
+        back = np.zeros(1, dtype=img.dtype)
+        back[0] = background
+        f = self._fn("label_image")
+        f.argtypes = [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p]
+        f.restype = ct.c_int
+        r = f(ord(DTYPE_CHARS[img.dtype]), _p(img), _p(dst), w, h, _p(back), _p(xy), _p(area))
+        if r < 0:
+            raise RuntimeError("label_image failed")
+        return dst, area[:r].copy(), xy[:r].copy()
+
+    def keep_largest_area(self, image, background=0, foreground=1):
+        img = np.ascontiguousarray(image)
+        h, w = img.shape
+        dst = np.full(img.shape, -7, dtype=np.int32)
+        back = np.zeros(1, dtype=img.dtype)
+        back[0] = background
+        f = self._fn("keep_largest_area")
+        f.argtypes = [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int]
+        f.restype = ct.c_int
+        if f(ord(DTYPE_CHARS[img.dtype]), _p(img), _p(dst), w, h, _p(back), int(foreground)) < 0:
+            raise RuntimeError("keep_largest_area failed")
+        return dst
+
+    def extract_times(self, series, strategy=0, room=None):
+        """series: sequences of doubles; strategy 0 union / 1 intersection -> (return code, axis)"""
+        vs = [np.asarray(v, dtype=np.float64).ravel() for v in series]
+        flat = np.concatenate(vs) if vs else np.zeros(0)
+        flat = np.ascontiguousarray(np.append(flat, 0.0))  # (never an empty buffer)
+        sizes = np.array([v.size for v in vs] + [0], dtype=np.int32)
+        cap = int(sum(v.size for v in vs)) if room is None else room
+        out = np.zeros(max(cap, 1), dtype=np.float64)
+        n = ct.c_int(cap)
+        f = self._fn("extract_times")
+        f.argtypes = [ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p, ct.POINTER(ct.c_int)]
+        f.restype = ct.c_int
+        rc = f(_p(flat), len(vs), _p(sizes), int(strategy), _p(out), ct.byref(n))
+        return rc, (out[:n.value].copy() if rc == 0 else n.value)
+
+    def resample_time_serie(self, x, y, times, strategy=4, padd=0.0, room=None):
+        x = np.ascontiguousarray(np.append(np.asarray(x, dtype=np.float64), 0.0))
+        y = np.ascontiguousarray(np.append(np.asarray(y, dtype=np.float64), 0.0))
+        t = np.ascontiguousarray(np.append(np.asarray(times, dtype=np.float64), 0.0))
+        cap = t.size - 1 if room is None else room
+        out = np.zeros(max(cap, 1), dtype=np.float64)
+        n = ct.c_int(cap)
+        f = self._fn("resample_time_serie")
+        f.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int, ct.c_double, ct.c_void_p, ct.POINTER(ct.c_int)]
+        f.restype = ct.c_int
+        rc = f(_p(x), _p(y), x.size - 1, _p(t), t.size - 1, int(strategy), float(padd), _p(out), ct.byref(n))
+        return rc, (out[:n.value].copy() if rc == 0 else n.value)
+
 
 class Oracle(_SignalProcessingMixin):
     _prefix = "orc_"

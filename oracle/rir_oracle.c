@@ -1174,3 +1174,332 @@ EXPORT int orc_ecc_translation(const float *templ, const float *image, const uin
 /* C5  ZFile method 1 equivalent (CPU baseline only): one-shot zstd per raw frame is timed by  */
 /*     bench.py through dlopen("libzstd.so.1"); nothing to restate here (third-party).         */
 /* ------------------------------------------------------------------------------------------ */
+
+/* ------------------------------------------------------------------------------------------ */
+/* F7  labelImage / keepLargestArea   reference: src/cpp/signal_processing/Filters.h:365-540    */
+/*     C entries + dtype dispatch: src/cpp/signal_processing/signal_processing.cpp:224-318      */
+/* The classic two-pass labelling, with the reference's two joining rules: a pixel continues   */
+/* its LEFT neighbour when their values are equal, and the pixel ABOVE whenever that one has a  */
+/* label at all (its value is not looked at).  Final numbers follow the first pixel of each    */
+/* component in raster order.                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+static int set_root(int *parent, int a)
+{
+	while (parent[a] != a)
+	{
+		parent[a] = parent[parent[a]];
+		a = parent[a];
+	}
+	return a;
+}
+
+#define DEFINE_LABEL(NAME, T)                                                                    \
+	static int label_##NAME(const T *src, T bg, int w, int h, int *dst, double *xy, int *area)     \
+	{                                                                                              \
+		const int64_t n = (int64_t)w * h;                                                          \
+		int *parent = (int *)malloc((size_t)(n + 2) * sizeof(int));                                \
+		int next = 1;                                                                              \
+		parent[0] = 0;                                                                             \
+		for (int y = 0; y < h; ++y)                                                                \
+			for (int x = 0; x < w; ++x)                                                            \
+			{                                                                                      \
+				const int64_t i = (int64_t)y * w + x;                                              \
+				const T v = src[i];                                                                \
+				dst[i] = 0;                                                                        \
+				if (v == bg)                                                                       \
+					continue;                                                                      \
+				const int left = (x > 0 && src[i - 1] == v) ? dst[i - 1] : 0;                      \
+				const int up = y > 0 ? dst[i - w] : 0;                                             \
+				if (left && up)                                                                    \
+				{                                                                                  \
+					const int a = set_root(parent, left), b = set_root(parent, up);                \
+					if (a < b)                                                                     \
+						parent[b] = a;                                                             \
+					else                                                                           \
+						parent[a] = b;                                                             \
+					dst[i] = left;                                                                 \
+				}                                                                                  \
+				else if (left || up)                                                               \
+					dst[i] = left ? left : up;                                                     \
+				else                                                                               \
+				{                                                                                  \
+					parent[next] = next;                                                           \
+					dst[i] = next++;                                                               \
+				}                                                                                  \
+			}                                                                                      \
+		/* the lowest provisional label of a set is its root (the lower root always wins) and the  \
+		 * label its first pixel opened: numbering the roots in label order = raster order */      \
+		int *number = (int *)calloc((size_t)next + 1, sizeof(int));                                \
+		int count = 0;                                                                             \
+		for (int l = 1; l < next; ++l)                                                             \
+			if (set_root(parent, l) == l)                                                          \
+				number[l] = ++count;                                                               \
+		xy[0] = xy[1] = -1.0;                                                                      \
+		area[0] = 0;                                                                               \
+		for (int k = 1; k <= count; ++k)                                                           \
+			area[k] = 0;                                                                           \
+		for (int64_t i = 0; i < n; ++i)                                                            \
+			if (dst[i])                                                                            \
+			{                                                                                      \
+				const int k = number[set_root(parent, dst[i])];                                    \
+				dst[i] = k;                                                                        \
+				if (area[k]++ == 0)                                                                \
+					xy[2 * k] = xy[2 * k + 1] = (double)(i % w); /* x twice: signal_processing.cpp:262-263 */ \
+			}                                                                                      \
+		free(number);                                                                              \
+		free(parent);                                                                              \
+		return count + 1;                                                                          \
+	}
+
+DEFINE_LABEL(u8, uint8_t)
+DEFINE_LABEL(u16, uint16_t)
+DEFINE_LABEL(u32, uint32_t)
+DEFINE_LABEL(u64, uint64_t)
+DEFINE_LABEL(f32, float)
+DEFINE_LABEL(f64, double)
+
+/* out_xy / out_area: room for w*h + 1 entries.  Returns components + 1, -1 on an unknown type. */
+EXPORT int orc_label_image(int type, const void *src, int *dst, int w, int h, const void *background, double *out_xy, int *out_area)
+{
+	switch (type)
+	{
+	case '?':
+	case 'b':
+	case 'B':
+		return label_u8((const uint8_t *)src, *(const uint8_t *)background, w, h, dst, out_xy, out_area);
+	case 'h':
+	case 'H':
+		return label_u16((const uint16_t *)src, *(const uint16_t *)background, w, h, dst, out_xy, out_area);
+	case 'i':
+	case 'I':
+		return label_u32((const uint32_t *)src, *(const uint32_t *)background, w, h, dst, out_xy, out_area);
+	case 'l':
+	case 'L':
+		return label_u64((const uint64_t *)src, *(const uint64_t *)background, w, h, dst, out_xy, out_area);
+	case 'f':
+		return label_f32((const float *)src, *(const float *)background, w, h, dst, out_xy, out_area);
+	case 'd':
+		return label_f64((const double *)src, *(const double *)background, w, h, dst, out_xy, out_area);
+	default:
+		return -1;
+	}
+}
+
+/* keepLargestArea: the largest component (the earlier one among equals) takes `foreground`, every other pixel (int)background;
+ * an image without a component stays all zero. */
+EXPORT int orc_keep_largest_area(int type, const void *src, int *dst, int w, int h, const void *background, int foreground)
+{
+	const int64_t n = (int64_t)w * h;
+	double *xy = (double *)malloc((size_t)(n + 1) * 2 * sizeof(double));
+	int *area = (int *)malloc((size_t)(n + 1) * sizeof(int));
+	const int labels = orc_label_image(type, src, dst, w, h, background, xy, area);
+	int rc = labels < 0 ? -1 : 0;
+	if (labels >= 2)
+	{
+		int best = 1;
+		for (int k = 2; k < labels; ++k)
+			if (area[k] > area[best])
+				best = k;
+		int bg;
+		switch (type)
+		{
+		case '?':
+		case 'B':
+			bg = (int)*(const uint8_t *)background;
+			break;
+		case 'b':
+			bg = (int)*(const int8_t *)background;
+			break;
+		case 'h':
+			bg = (int)*(const int16_t *)background;
+			break;
+		case 'H':
+			bg = (int)*(const uint16_t *)background;
+			break;
+		case 'i':
+		case 'I':
+			bg = (int)*(const uint32_t *)background;
+			break;
+		case 'l':
+		case 'L':
+			bg = (int)*(const uint64_t *)background;
+			break;
+		case 'f':
+			bg = (int)*(const volatile float *)background;
+			break;
+		default:
+			bg = (int)*(const volatile double *)background;
+			break;
+		}
+		for (int64_t i = 0; i < n; ++i)
+			dst[i] = dst[i] == best ? foreground : bg;
+	}
+	free(xy);
+	free(area);
+	return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* T1  extractTimes / resampleSignal   reference: src/cpp/signal_processing/Filters.cpp:111-333 */
+/*     C entries: src/cpp/signal_processing/signal_processing.cpp:158-195                      */
+/* Defined inputs only (the reference loops for ever on an empty run - an empty vector, a NaN   */
+/* at either end of one, a second NaN, a run outside the common range): those return -1 here.   */
+/* ------------------------------------------------------------------------------------------ */
+EXPORT int orc_extract_times(const double *vectors, int vector_count, const int *sizes, int s, double *output, int *output_size)
+{
+	if (vector_count <= 0)
+	{
+		*output_size = 0;
+		return 0;
+	}
+	int64_t total = 0;
+	for (int i = 0; i < vector_count; ++i)
+		total += sizes[i];
+	double *res = (double *)malloc((size_t)(total + 1) * sizeof(double));
+	int64_t nres = 0;
+	int rc = 0;
+	if (vector_count == 1)
+	{
+		memcpy(res, vectors, (size_t)sizes[0] * sizeof(double));
+		nres = sizes[0];
+	}
+	else
+	{
+		/* runs as [from, to) index pairs into `vectors`; a NaN cuts its vector in two */
+		int64_t *from = (int64_t *)malloc((size_t)vector_count * 2 * sizeof(int64_t)), *to = (int64_t *)malloc((size_t)vector_count * 2 * sizeof(int64_t));
+		int nruns = 0;
+		int64_t base = 0;
+		double lo = 0, hi = -1;
+		int disjoint = 0;
+		for (int i = 0; i < vector_count && rc == 0; ++i)
+		{
+			const int64_t len = sizes[i];
+			if (len <= 0)
+			{
+				rc = -1;
+				break;
+			}
+			int64_t cut = -1;
+			for (int64_t p = 0; p < len; ++p)
+				if (isnan(vectors[base + p]))
+				{
+					if (cut >= 0)
+						rc = -1;
+					else
+						cut = p;
+				}
+			if (cut == 0 || cut == len - 1)
+				rc = -1;
+			if (cut < 0)
+				from[nruns] = base, to[nruns++] = base + len;
+			else
+			{
+				from[nruns] = base, to[nruns++] = base + cut;
+				from[nruns] = base + cut + 1, to[nruns++] = base + len;
+			}
+			if ((s & 1) && !disjoint)
+			{
+				const double first = vectors[base], last = vectors[base + len - 1];
+				if (hi < lo)
+					lo = first, hi = last;
+				else if (last < lo || first > hi)
+					disjoint = 1;
+				else
+				{
+					lo = first > lo ? first : lo; /* std::max(lo, first) / std::min(hi, last) */
+					hi = last < hi ? last : hi;
+				}
+			}
+			base += len;
+		}
+		if (disjoint)
+			rc = 0, nruns = 0; /* before anything else: the reference answers with an empty axis */
+		else if (rc == 0 && (s & 1))
+			for (int r = 0; r < nruns; ++r)
+			{
+				while (from[r] < to[r] && vectors[from[r]] < lo)
+					++from[r];
+				while (to[r] > from[r] && vectors[to[r] - 1] > hi)
+					--to[r];
+				if (from[r] == to[r])
+					rc = -1;
+			}
+		while (rc == 0 && nruns > 0)
+		{
+			double t = vectors[from[0]];
+			for (int r = 1; r < nruns; ++r)
+				t = vectors[from[r]] < t ? vectors[from[r]] : t; /* std::min(t, head) */
+			int kept = 0;
+			for (int r = 0; r < nruns; ++r)
+			{
+				if (vectors[from[r]] == t)
+					++from[r];
+				if (from[r] != to[r])
+					from[kept] = from[r], to[kept++] = to[r];
+			}
+			nruns = kept;
+			res[nres++] = t;
+		}
+		free(from), free(to);
+	}
+	if (rc == 0)
+	{
+		if (nres > *output_size)
+			rc = -2;
+		else
+			memcpy(output, res, (size_t)nres * sizeof(double));
+		*output_size = (int)nres;
+	}
+	free(res);
+	return rc;
+}
+
+EXPORT int orc_resample_time_serie(const double *sx, const double *sy, int size, const double *times, int times_size, int s, double padds,
+								   double *output, int *output_size)
+{
+	if (times_size > *output_size)
+	{
+		*output_size = times_size;
+		return -1;
+	}
+	*output_size = times_size;
+	const int padded = s & 2, interp = s & 4;
+	int k = 0;
+	for (int t = 0; t < times_size; ++t)
+	{
+		const double time = times[t];
+		double r;
+		if (size == 0)
+			r = padded ? padds : 0.0;
+		else
+		{
+			int consume = 0, sought = 0;
+			if (k < size && !(time == sx[k]) && !(time < sx[k]))
+			{ /* past the cursor's sample: move on to the first sample that is not below `time` */
+				while (k < size && sx[k] < time)
+					++k;
+				sought = 1;
+			}
+			if (k == size)
+				r = padded ? padds : sy[size - 1];
+			else if (time == sx[k])
+				r = sy[k], consume = !sought; /* met without moving: the sample is used up */
+			else if (k == 0)
+			{
+				if (sought)
+					return -1; /* NaN: the reference reads before its input */
+				r = padded ? padds : sy[0];
+			}
+			else if (interp)
+			{
+				const double f = (time - sx[k - 1]) / (sx[k] - sx[k - 1]);
+				r = sy[k] * f + (1 - f) * sy[k - 1];
+			}
+			else
+				r = (time - sx[k - 1] < sx[k] - time) ? sy[k - 1] : sy[k];
+			k += consume;
+		}
+		output[t] = r;
+	}
+	return 0;
+}

@@ -1,0 +1,157 @@
+"""label_image / keep_largest_area on the GPU (csrc/label_kernels.hip) through the C ABI: against the golden vectors made from the
+compiled reference, against the oracle on random images, and - at the BASELINE geometries - through properties that do not need either.
+Reference tests: tests/python/test_rir.py:279-300 (the wrappers' error behaviour)."""
+import numpy as np
+import pytest
+
+from cases import LABEL_DTYPES, label_cases
+from test_labelling_oracle import check_against_golden, label_golden  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+class _Wrapper:
+    """librir_amd.signal_processing with the oracle's method names"""
+
+    def __init__(self):
+        from librir_amd import signal_processing as sp
+
+        self.sp = sp
+
+    def label_image(self, img, bg=0):
+        return self.sp.label_image(img, bg)
+
+    def keep_largest_area(self, img, bg=0, fg=1):
+        return self.sp.keep_largest_area(img, bg, fg)
+
+
+@pytest.fixture(scope="module")
+def wrapper(dev):
+    return _Wrapper()
+
+
+def test_every_golden_case_through_the_c_abi(wrapper, label_golden):  # noqa: F811
+    assert check_against_golden(wrapper, label_golden) > 600
+
+
+def test_random_images_against_the_oracle(wrapper, oracle):
+    rng = np.random.default_rng(11)
+    for it in range(400):
+        h, w = int(rng.integers(1, 70)), int(rng.integers(1, 300))
+        dt = LABEL_DTYPES[it % len(LABEL_DTYPES)]
+        levels = int(rng.integers(1, 6))
+        img = rng.integers(0, levels + 1, (h, w)).astype(dt)
+        if it % 3 == 0:  # larger structures
+            img = np.kron(img[:(h + 3) // 4, :(w + 3) // 4], np.ones((4, 4), dtype=img.dtype))[:h, :w].astype(dt)
+        if np.dtype(dt).kind == "f" and it % 2 == 0:
+            img[rng.random((h, w)) < 0.03] = np.nan
+        bg = int(rng.integers(0, 2))
+        got, exp = wrapper.label_image(img, bg), oracle.label_image(img, bg)
+        for a, b in zip(got, exp):
+            assert np.array_equal(a, b), (it, h, w, dt)
+        fg = int(rng.integers(-5, 6))
+        assert np.array_equal(wrapper.keep_largest_area(img, bg, fg), oracle.keep_largest_area(img, bg, fg)), (it, h, w, dt)
+
+
+def test_device_layer_against_the_oracle(dev, oracle):
+    import torch
+
+    for dt in (np.uint8, np.uint16, np.int32, np.int64, np.float32, np.float64):
+        for name, img, bg in label_cases(67, 83, dt) + label_cases(23, 64, dt):
+            t = torch.from_numpy(img).cuda()
+            lab, area, xy = dev.label_image(t, bg)
+            exp = oracle.label_image(img, bg)
+            assert np.array_equal(lab.cpu().numpy(), exp[0]) and np.array_equal(area.cpu().numpy(), exp[1]), (dt, name)
+            assert np.array_equal(xy.cpu().numpy(), exp[2]), (dt, name)
+            assert np.array_equal(dev.keep_largest_area(t, bg, -2).cpu().numpy(), oracle.keep_largest_area(img, bg, -2)), (dt, name)
+
+
+@pytest.mark.parametrize("shape", [(512, 640), (768, 1024), (1537, 2049)])
+def test_properties_at_full_size(wrapper, shape):
+    """what the labels must satisfy whatever produced them: each table entry counts its label's pixels and holds its first pixel's x,
+    labels rise with the first pixels, labelling the label image changes nothing, vertical neighbours of components share a label,
+    horizontal neighbours share one exactly when their values are equal"""
+    h, w = shape
+    rng = np.random.default_rng(h)
+    small = rng.integers(0, 4, ((h + 7) // 8, (w + 7) // 8))
+    img = np.kron(small, np.ones((8, 8), dtype=np.int64))[:h, :w]
+    img[rng.random((h, w)) < 0.02] = 5
+    img = img.astype(np.uint16)
+    lab, area, xy = wrapper.label_image(img, 0)
+    n = area.size
+    assert n >= 2 and lab.min() == 0 and lab.max() == n - 1
+    assert np.array_equal((lab == 0), (img == 0))
+    counts = np.bincount(lab.ravel(), minlength=n)
+    assert np.array_equal(counts[1:], area[1:]) and area[0] == 0
+    flat = lab.ravel()
+    first = np.full(n, flat.size, dtype=np.int64)
+    np.minimum.at(first, flat, np.arange(flat.size))
+    assert np.all(np.diff(first[1:]) > 0)  # numbered in raster order of the first pixels
+    assert np.array_equal(xy[1:, 0], first[1:] % w) and np.array_equal(xy[1:, 1], xy[1:, 0]) and np.array_equal(xy[0], [-1, -1])
+    both = (img[1:] != 0) & (img[:-1] != 0)
+    assert np.array_equal(lab[1:][both], lab[:-1][both])
+    side = (img[:, 1:] != 0) & (img[:, :-1] != 0)
+    same = img[:, 1:] == img[:, :-1]
+    assert np.all(lab[:, 1:][side & same] == lab[:, :-1][side & same])
+    again, area2, xy2 = wrapper.label_image(lab, 0)
+    assert np.array_equal(again, lab) and np.array_equal(area2, area) and np.array_equal(xy2, xy)
+    keep = wrapper.keep_largest_area(img, 0, 3)
+    best = 1 + int(np.argmax(area[1:]))  # argmax: the first among equals
+    assert np.array_equal(keep, np.where(lab == best, 3, 0))
+
+
+def test_degenerate_images_and_errors(wrapper, lib):
+    import ctypes as ct
+
+    from librir_amd.signal_processing import keep_largest_area, label_image
+
+    lab, area, xy = label_image(np.zeros((0, 5), np.uint16), 0)
+    assert lab.shape == (0, 5) and np.array_equal(area, [0]) and np.array_equal(xy, [[-1, -1]])
+    assert keep_largest_area(np.zeros((3, 0), np.uint8), 0).shape == (3, 0)
+    # every pixel of a one-row image its own component: w + 1 table entries
+    row = (np.arange(70) % 2 + 1).astype(np.uint8).reshape(1, 70)
+    lab, area, xy = label_image(row, 0)
+    assert np.array_equal(lab, np.arange(1, 71).reshape(1, 70)) and area.size == 71 and np.all(area[1:] == 1)
+    # reference tests/python/test_rir.py:279-300
+    with pytest.raises(RuntimeError):
+        label_image(np.ndarray((10, 10, 10)), 0)
+    with pytest.raises(RuntimeError):
+        label_image(np.ndarray((10, 10), dtype="object"), 0)
+    with pytest.raises(RuntimeError):
+        keep_largest_area(np.ndarray((10, 10, 10)), 0)
+    with pytest.raises(RuntimeError):
+        keep_largest_area(np.ndarray((10, 10), dtype="object"), 0)
+    # the C entry points: unknown type character
+    img = np.ones((4, 4), np.uint16)
+    dst = np.zeros((4, 4), np.int32)
+    bg = np.zeros(1, np.uint16)
+    xyb, ab = np.zeros(40), np.zeros(20, np.int32)
+    lib.label_image.argtypes = [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_void_p]
+    lib.keep_largest_area.argtypes = [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int]
+    assert lib.label_image(ord("O"), img.ctypes.data, dst.ctypes.data, 4, 4, bg.ctypes.data, xyb.ctypes.data, ab.ctypes.data) == -1
+    assert lib.keep_largest_area(ord("x"), img.ctypes.data, dst.ctypes.data, 4, 4, bg.ctypes.data, 1) == -1
+    assert lib.label_image(ord("H"), img.ctypes.data, dst.ctypes.data, 4, 4, bg.ctypes.data, xyb.ctypes.data, ab.ctypes.data) == 2
+
+
+def test_labelling_on_the_copy_path(oracle):
+    """RIR_ABI_ZERO_COPY=0: the labels come back through a device buffer and a transfer instead of being written over the link"""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import numpy as np, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "from librir_amd import signal_processing as sp\n"
+            "rng = np.random.default_rng(3)\n"
+            "img = np.kron(rng.integers(0, 3, (40, 50)), np.ones((8, 8), dtype=np.int64)).astype(np.uint16)\n"
+            "lab, area, xy = sp.label_image(img, 0)\n"
+            "np.savez(sys.argv[1], lab=lab, area=area, xy=xy, keep=sp.keep_largest_area(img, 0, 4), img=img)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "o.npz")
+        subprocess.check_call([sys.executable, "-c", code, out], env=dict(os.environ, RIR_ABI_ZERO_COPY="0"))
+        z = np.load(out)
+        exp = oracle.label_image(z["img"], 0)
+        assert np.array_equal(z["lab"], exp[0]) and np.array_equal(z["area"], exp[1]) and np.array_equal(z["xy"], exp[2])
+        assert np.array_equal(z["keep"], oracle.keep_largest_area(z["img"], 0, 4))

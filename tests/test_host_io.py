@@ -432,10 +432,11 @@ def test_low_level_helpers_behave_like_the_reference():
             zstd_decompress(garbage)
 
 
-def test_functions_outside_the_path_import_and_refuse():
-    """the four CPU utilities of the reference's signal_processing that this build leaves out: the names import - from the
-    package, like upstream - and every call is a RuntimeError, which is also what the reference's own error-case tests expect of them
-    (tests/python/test_rir.py:272-296)"""
+def test_labelling_and_time_axis_wrappers_refuse_bad_arguments_without_a_gpu():
+    """the argument checks of the four wrappers that came last (label_image, keep_largest_area, extract_times, resample_time_serie)
+    happen before the library is asked: reference tests/python/test_rir.py:239-243,256-262,279-300.  Without a device the two labelling
+    calls fail like every compute entry point (no CPU fallback); the two time-axis helpers are host bookkeeping and answer
+    (tests/test_time_series.py)."""
     import librir_amd.signal_processing as sp
 
     with pytest.raises(RuntimeError):
@@ -446,3 +447,10 @@ def test_functions_outside_the_path_import_and_refuse():
         sp.extract_times((), "inter")
     with pytest.raises(RuntimeError):
         sp.resample_time_serie([], range(10), [0, 1])
+    import torch
+
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            sp.label_image(np.ones((4, 4), np.uint16), 0)
+        with pytest.raises(RuntimeError):
+            sp.keep_largest_area(np.ones((4, 4), np.uint16), 0)
