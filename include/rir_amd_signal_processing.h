@@ -3,7 +3,8 @@
  * Same symbol names, argument meaning and return codes as the reference header
  * src/cpp/signal_processing/signal_processing.h (cited per function), so that the library can be
  * loaded by librir's Python wrapper in place of libsignal_processing.so.
- * Host pointers in, host pointers out, synchronous.  No CPU fallback.
+ * Host pointers in, host pointers out, synchronous.  No CPU fallback: every entry point that touches pixels runs on the device or
+ * fails; extract_times / resample_time_serie / hash_bytes are host bookkeeping on timestamps and bytes and need none.
  */
 #ifndef RIR_AMD_SIGNAL_PROCESSING_H
 #define RIR_AMD_SIGNAL_PROCESSING_H

