@@ -15,7 +15,8 @@ What is exercised needs no GPU:
     state, where the wrapper's `get_last_log_error` reads it back
   * `zstd_compress` / `zstd_decompress`, garbage -> RuntimeError (tests/python/test_rir.py:47-74)
   * `FileAttributes.from_filename`: write, reopen, read back (tools/FileAttributes.py)
-  * `translate`, `h264_add_image_lossless` without a device: the wrapper's RuntimeError, not a crash
+  * `translate`, `label_image`, `h264_add_image_lossless` without a device: the wrapper's RuntimeError, not a crash
+  * `extract_times` / `resample_time_serie` (host bookkeeping, no device needed): the reference tests' calls and results
 
 Prints one JSON object; `tests/golden/wrapper_drop_in.json` holds it and `tests/test_abi.py` asserts a fresh
 run equals it (skipped where `/root/reference` does not exist).  `--write` refreshes the golden file.
@@ -106,9 +107,21 @@ def record():
     finally:
         V.h264_close_file(h)
 out["h264_add_image_lossless_without_device"] = outcome(record)
+out["label_image_without_device"] = outcome(lambda: S.label_image(fr, 0))
+out["keep_largest_area_without_device"] = outcome(lambda: S.keep_largest_area(fr, 0))
 n = ct.c_int(256)
 misc._tools.get_last_log_error(buf, ct.byref(n))
 out["last_log_error_after_compute"] = buf.raw[:n.value].decode()
+# the time-axis helpers need no device: the reference wrapper's own calls (tests/python/test_rir.py:232-262) on this library
+t1, t2 = [0, 0.2, 1, 1.5, 2.3, 3.3, 4, 5], [-1, 3, 4, 4.3, 4.7]
+out["extract_times_union"] = [float(v) for v in S.extract_times((t1, t2), "union")]
+out["extract_times_inter"] = [float(v) for v in S.extract_times((t1, t2), "inter")]
+out["extract_times_long"] = int(S.extract_times((t1, range(10000)), "union").size)
+times = [0, 0.2, 1, 1.5, 2.3, 3.3, 4, 5, 5.6, 9.9, 10, 12, 13]
+out["resample_default"] = [round(float(v), 9) for v in S.resample_time_serie(range(10), range(10), times)]
+out["resample_padded"] = [round(float(v), 9) for v in S.resample_time_serie(range(10), range(10), times, 0)]
+out["resample_nearest"] = [float(v) for v in S.resample_time_serie(range(10), range(10), times, None, False)]
+out["resample_output_too_small"] = outcome(lambda: S.resample_time_serie([0, 1], [0, 1], np.linspace(0, 1, 9)))  # the wrapper's room: 2 * len(x)
 print("JSON:" + json.dumps(out, sort_keys=True))
 '''
 
