@@ -12,7 +12,7 @@ OUT=gpurun_out/san_$SAN
 mkdir -p $OUT
 if [ "$SAN" = address ]; then RT=$(find /opt/rocm/lib/llvm -name "libclang_rt.asan-x86_64.so" | head -1); LINK=-shared-libasan;
 else RT=$(find /opt/rocm/lib/llvm -name "libclang_rt.ubsan_standalone-x86_64.so" | head -1); LINK=; fi
-for f in video_io_abi registration_abi signal_processing_abi runtime file_attributes codec_abi host_copy; do
+for f in video_io_abi registration_abi signal_processing_abi runtime file_attributes codec_abi host_copy time_series; do
   /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC -fsanitize=$SAN -fno-omit-frame-pointer -fvisibility=hidden -Ilibrir_amd/csrc -Iinclude \
       -c librir_amd/csrc/$f.cpp -o $OUT/$f.o
 done
@@ -20,7 +20,7 @@ done
 cp librir_amd/libs/librir_amd.so $OUT/librir_amd.so.keep
 trap 'cp $OUT/librir_amd.so.keep librir_amd/libs/librir_amd.so' EXIT
 cp $OUT/librir_amd_asan.so librir_amd/libs/librir_amd.so
-ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 LD_PRELOAD=$RT python -m pytest tests/test_host_io.py tests/test_abi.py -x -q -s
+ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 LD_PRELOAD=$RT python -m pytest tests/test_host_io.py tests/test_abi.py tests/test_time_series.py -x -q -s
 # the CPU oracle (plain C) under both sanitizers with its own tests
 cp oracle/librir_oracle.so $OUT/oracle_keep.so
 trap 'cp $OUT/librir_amd.so.keep librir_amd/libs/librir_amd.so; cp $OUT/oracle_keep.so oracle/librir_oracle.so' EXIT
@@ -28,4 +28,5 @@ gcc -O1 -g -std=c11 -ffp-contract=off -fPIC -shared -fsanitize=address,undefined
 cp $OUT/librir_amd.so.keep librir_amd/libs/librir_amd.so
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
   LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) \
-  python -m pytest tests/test_oracle_golden.py tests/test_codec_oracle.py tests/test_lossy_oracle.py tests/test_registration_oracle.py -x -q
+  python -m pytest tests/test_oracle_golden.py tests/test_codec_oracle.py tests/test_lossy_oracle.py tests/test_registration_oracle.py \
+  tests/test_labelling_oracle.py tests/test_time_series.py -x -q

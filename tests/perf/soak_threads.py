@@ -1,5 +1,5 @@
 """One-off soak: the per-frame C ABI driven from several Python threads at once, each with its own handles (ctypes releases
-the GIL during the calls) - savers, cameras, the host-pointer filters and the registration entry (not collected by pytest).
+the GIL during the calls) - savers, cameras, the host-pointer filters, the labelling, the time-axis helper and the registration entry (not collected by pytest).
    python tests/perf/soak_threads.py [threads] [rounds]"""
 import os
 import sys
@@ -42,6 +42,13 @@ def worker(k, tmp):
             g = sp.gaussian_filter(fr[1].astype(np.float32), 0.75)
             if not np.allclose(g, O.gaussian_filter(fr[1].astype(np.float32), 0.75), rtol=1e-5, atol=0):
                 errors.append(("gaussian", k, r))
+            regions = ((fr[3] >> 5) % 3).astype(np.uint16)
+            got, exp = sp.label_image(regions, 0), O.label_image(regions, 0)
+            if not all(np.array_equal(x, y) for x, y in zip(got, exp)) or not np.array_equal(sp.keep_largest_area(regions, 0, 4), O.keep_largest_area(regions, 0, 4)):
+                errors.append(("labelling", k, r))
+            ts_a, ts_b = np.sort(rng.integers(0, 50, 20)) * 0.5, np.sort(rng.integers(0, 50, 30)) * 0.5
+            if not np.array_equal(sp.extract_times((ts_a, ts_b), "union"), O.extract_times((ts_a, ts_b), 0)[1]):
+                errors.append(("extract_times", k, r))
             a = sp.gaussian_filter(fr[2].astype(np.float32), 2.0)  # (white noise has no basin of attraction: smooth it)
             a = (a - a.min()) / (a.max() - a.min())
             b = np.roll(a, (1, 2), axis=(0, 1))
