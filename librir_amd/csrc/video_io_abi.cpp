@@ -1269,6 +1269,7 @@ namespace
 		int last_raw_pos = -1; // frame held by last_raw (fetched on demand after a filtered read)
 		// PCR
 		int64_t pcr_start = 0, pcr_transfer = 0;
+		int raw_format = FILE_FORMAT_PCR; // kind == PCR: which of the raw formats (PCR, PCR in a BIN envelope, BIN / WEST)
 		// ZFile: record offsets, scratch for one compressed frame
 		std::vector<int64_t> z_positions;
 		std::vector<char> z_buf;
@@ -1411,13 +1412,21 @@ namespace
 				// detection rules of IRFileLoader.cpp:130-165 for plain PCR files
 				const bool lab = ph.Bits == 16 && ph.X == 640 && ph.Y == 512 && ph.Frequency == 50;
 				const bool pcr = ph.Bits == 16 && std::abs(ph.TransfertSize - ph.X * ph.Y * 2) < 2000 && ph.X > 0 && ph.Y > 0 && ph.X < 2000 && ph.Y < 2000;
+				// ... a PCR header behind a 133-byte envelope (IRFileLoader.cpp:166-181), tested next like there
+				PcrHeader pe;
+				std::memcpy(&pe, buf + 128 + 5, sizeof(pe));
+				const bool pcr_enc = !lab && !pcr && pe.Bits == 16 && std::abs(pe.TransfertSize - pe.X * pe.Y * 2) < 2000 && pe.X > 0 && pe.Y > 0 &&
+									 pe.X < 1000 && pe.Y < 1000;
 				ZHeader zh;
 				ZTrigger zt;
 				std::memcpy(&zh, buf, sizeof(zh));
 				std::memcpy(&zt, buf + sizeof(zh), sizeof(zt));
-				// IRFileLoader.cpp:213-236, tested after the PCR rules like there
-				const bool zfile = !lab && !pcr && zh.version == 1 && zh.compression >= 1 && zh.compression <= 3 && zh.triggers == 1 && zt.data_size_x > 0 &&
-								   zt.data_size_x < 3000 && zt.data_size_y > 0 && zt.data_size_y < 3000 && zt.rate > 0 && zt.rate < 1000;
+				// ... the BIN (WEST) file: the two 128-byte blocks of a ZFile with compression 0, raw frames behind them (IRFileLoader.cpp:182-209)
+				const bool west = !lab && !pcr && !pcr_enc && zh.version < 10 && zh.compression == 0 && zh.triggers == 1 && zt.data_size_x > 0 &&
+								  zt.data_size_x < 1000 && zt.data_size_y > 0 && zt.data_size_y < 1000 && zt.rate > 0 && zt.rate < 1000;
+				// IRFileLoader.cpp:213-236, tested after those
+				const bool zfile = !lab && !pcr && !pcr_enc && !west && zh.version == 1 && zh.compression >= 1 && zh.compression <= 3 && zh.triggers == 1 &&
+								   zt.data_size_x > 0 && zt.data_size_x < 3000 && zt.data_size_y > 0 && zt.data_size_y < 3000 && zt.rate > 0 && zt.rate < 1000;
 				if (zfile)
 				{
 					if (zh.compression != 1)
@@ -1429,13 +1438,24 @@ namespace
 					width = (int)zt.data_size_x, height = (int)zt.data_size_y;
 					count = (int)std::min<uint64_t>(zt.samples, 0x7fffffffull);
 				}
+				else if (pcr_enc)
+					open_pcr(pe, false, fsize, 128 + 5 + (int64_t)sizeof(PcrHeader), FILE_FORMAT_PCR_ENCAPSULATED);
+				else if (west)
+				{
+					PcrHeader wh;
+					std::memset(&wh, 0, sizeof(wh));
+					wh.X = (int)zt.data_size_x, wh.Y = (int)zt.data_size_y, wh.Bits = 16;
+					wh.TransfertSize = wh.X * wh.Y * 2, wh.Frequency = (int)zt.rate;
+					open_pcr(wh, false, fsize, (int64_t)(sizeof(ZHeader) + sizeof(ZTrigger)), FILE_FORMAT_WEST);
+				}
 				else if (!lab && !pcr)
 				{
-					log_error("unsupported file format (this library reads its own RIRB files, ZFile (zstd) files and raw PCR files)");
+					log_error("unsupported file format (this library reads its own RIRB files, ZFile (zstd) files and the raw formats: PCR, PCR in a BIN "
+							  "envelope, BIN)");
 					return false;
 				}
 				else
-					open_pcr(ph, lab, fsize);
+					open_pcr(ph, lab, fsize, (int64_t)sizeof(PcrHeader), FILE_FORMAT_PCR);
 				if (kind == PCR && count <= 0)
 					return false;
 			}
@@ -1485,16 +1505,18 @@ namespace
 			return true;
 		}
 
-		// raw PCR file (IRFileLoader.cpp:130-165 detection, :255-282 / :421-451 timestamps)
-		void open_pcr(PcrHeader ph, bool lab, size_t fsize)
+		// raw frames behind a header: PCR, PCR in a BIN envelope, BIN / WEST (IRFileLoader.cpp:130-209 detection, :404-451 geometry and
+		// timestamps - the three share that code upstream too)
+		void open_pcr(PcrHeader ph, bool lab, size_t fsize, int64_t start, int format)
 		{
 			if (lab)
 				ph.TransfertSize = ph.X * ph.Y * 2;
 			kind = PCR;
+			raw_format = format;
 			width = ph.X, height = ph.Y;
-			pcr_start = sizeof(PcrHeader);
+			pcr_start = start;
 			pcr_transfer = ph.TransfertSize;
-			count = pcr_transfer ? (int)((fsize - pcr_start) / pcr_transfer) : 0;
+			count = (pcr_transfer > 0 && (int64_t)fsize > pcr_start) ? (int)std::min<int64_t>(((int64_t)fsize - pcr_start) / pcr_transfer, 0x7fffffff) : 0;
 			if (count <= 0)
 				return;
 			// timestamps: last 8 bytes of each frame when strictly increasing (IRFileLoader.cpp:255-282)
@@ -2146,7 +2168,7 @@ namespace
 
 	int format_of(const CameraObject &c)
 	{
-		return c.kind == CameraObject::PCR ? FILE_FORMAT_PCR : c.kind == CameraObject::ZFILE ? FILE_FORMAT_ZSTD_COMPRESSED : FILE_FORMAT_H264;
+		return c.kind == CameraObject::PCR ? c.raw_format : c.kind == CameraObject::ZFILE ? FILE_FORMAT_ZSTD_COMPRESSED : FILE_FORMAT_H264;
 	}
 
 	int kv_out(const AttrMap &m, int index, char *key, int *key_len, char *value, int *value_len, bool global)
