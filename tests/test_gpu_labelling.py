@@ -155,3 +155,19 @@ def test_labelling_on_the_copy_path(oracle):
         exp = oracle.label_image(z["img"], 0)
         assert np.array_equal(z["lab"], exp[0]) and np.array_equal(z["area"], exp[1]) and np.array_equal(z["xy"], exp[2])
         assert np.array_equal(z["keep"], oracle.keep_largest_area(z["img"], 0, 4))
+
+
+def test_the_reference_scenario(wrapper):
+    """reference tests/python/test_rir.py:306-314: two filled shapes of one value on an int32 image (drawn there with the geometry
+    library the drop-in keeps; rasterised by hand here), labelled and reduced to the larger one with the default arguments"""
+    from librir_amd import signal_processing as sp
+
+    img = np.zeros((20, 20), np.int32)
+    for y in range(10):
+        img[y, 0:max(1, 6 - y // 2)] = 5  # a wedge from the corner
+    img[15:18, 14:17] = 5  # a small block
+    lab, area, xy = sp.label_image(img)
+    assert area.size == 3 and lab[0, 0] == 1 and lab[16, 15] == 2 and area[1] == (img[:10] == 5).sum() and area[2] == 9
+    assert np.array_equal(xy, [[-1, -1], [0, 0], [14, 14]])
+    keep = sp.keep_largest_area(img)
+    assert keep.dtype == np.int32 and np.array_equal(keep, (lab == 1).astype(np.int32))
