@@ -114,7 +114,7 @@ namespace rir
 			{
 				const int ly = wv * kRowsPerWave + j, y = y0 + ly, t = ly * kTileW + lane;
 				const bool in = x < w && y < h;
-				const int i = y * w + x;
+				const int i = in ? y * w + x : 0;
 				const C v = in ? src[i] : bg;
 				const bool fg = in && v != bg;
 				const bool joins_left = fg && x > 0 && src[i - 1] == v;
