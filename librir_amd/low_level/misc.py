@@ -75,6 +75,22 @@ def get_memory_folder():
     return folder
 
 
+def createZeroArrayHandle(shape, _dtype):
+    """For a given shape and dtype, create a zero filled array and its ctype handle (reference low_level/misc.py:88-95)"""
+    ar = np.zeros(shape, dtype=_dtype)
+    if str(ar.dtype) == "|S1":
+        handle = ar.ctypes.data_as(ct.POINTER(ct.c_char))
+    else:
+        handle = ar.ctypes.data_as(ct.POINTER(np.ctypeslib.as_ctypes_type(ar.dtype)))
+    return (ar, handle)
+
+
+def loadDlls():
+    """Load the library (reference low_level/misc.py:98-139 loads its four; here they are one file, loaded when this module is
+    imported: calling this again hands the same handles back)"""
+    return _tools, _signal_processing, _video_io
+
+
 def toCharP(obj):
     """str (ASCII) or bytes as the bytes a ``char *`` argument takes; anything else through ``bytes()`` (reference :78-85, so that
     ``toCharP(1) == b"\\x00"``)."""

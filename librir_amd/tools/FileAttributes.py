@@ -16,8 +16,8 @@ class FileAttributes(object):
         return cls(rt.attrs_open_file(filename))
 
     @classmethod
-    def from_buffer(cls, data):
-        return cls(rt.attrs_open_buffer(data))
+    def from_buffer(cls, buffer):
+        return cls(rt.attrs_open_buffer(buffer))
 
     def __enter__(self):
         return self
@@ -81,8 +81,8 @@ class FileAttributes(object):
     def frame_count(self):
         return rt.attrs_image_count(self.handle)
 
-    def frame_attributes(self, frame):
-        return rt.attrs_frame_attributes(self.handle, frame)
+    def frame_attributes(self, frame_index):
+        return rt.attrs_frame_attributes(self.handle, frame_index)
 
-    def set_frame_attributes(self, frame, attributes):
-        rt.attrs_set_frame_attributes(self.handle, frame, attributes)
+    def set_frame_attributes(self, frame_index, attributes):
+        rt.attrs_set_frame_attributes(self.handle, frame_index, attributes)

@@ -72,29 +72,29 @@ def attrs_open_file(filename):
     return h
 
 
-def attrs_open_buffer(data):
-    data = bytes(data)
-    h = _tools.attrs_open_from_memory(ct.cast(ct.c_char_p(data), ct.c_void_p), len(data))
+def attrs_open_buffer(buf):
+    buf = bytes(buf)
+    h = _tools.attrs_open_from_memory(ct.cast(ct.c_char_p(buf), ct.c_void_p), len(buf))
     if h <= 0:
         raise RuntimeError("cannot read file attributes from buffer")
     return h
 
 
-def attrs_close(h):
-    _tools.attrs_close(h)
+def attrs_close(handle):
+    _tools.attrs_close(handle)
 
 
-def attrs_discard(h):
-    _tools.attrs_discard(h)
+def attrs_discard(handle):
+    _tools.attrs_discard(handle)
 
 
-def attrs_flush(h):
-    if _tools.attrs_flush(h) < 0:
+def attrs_flush(handle):
+    if _tools.attrs_flush(handle) < 0:
         raise RuntimeError("An error occured while calling 'attrs_flush'")
 
 
-def attrs_image_count(h):
-    return _tools.attrs_image_count(h)
+def attrs_image_count(handle):
+    return _tools.attrs_image_count(handle)
 
 
 def attrs_global_attributes(h):
@@ -157,29 +157,29 @@ def attrs_set_time(handle, frame, time):
         raise RuntimeError("An error occured while calling 'attrs_set_time'")
 
 
-def attrs_timestamps(h):
-    n = max(_tools.attrs_image_count(h), 0)
+def attrs_timestamps(handle):
+    n = max(_tools.attrs_image_count(handle), 0)
     t = np.zeros(n, dtype=np.int64)
-    if n and _tools.attrs_timestamps(h, t.ctypes.data) < 0:
+    if n and _tools.attrs_timestamps(handle, t.ctypes.data) < 0:
         raise RuntimeError("An error occured while calling 'attrs_timestamps'")
     return t
 
 
-def attrs_set_times(h, times):
+def attrs_set_times(handle, times):
     t = np.ascontiguousarray(times, dtype=np.int64)
-    if _tools.attrs_set_times(h, t.ctypes.data, len(t)) < 0:
+    if _tools.attrs_set_times(handle, t.ctypes.data, len(t)) < 0:
         raise RuntimeError("An error occured while calling 'attrs_set_times'")
 
 
-def attrs_set_frame_attributes(h, pos, attributes):
+def attrs_set_frame_attributes(handle, frame, attributes):
     k, kl, v, vl, n = pack_attributes(attributes)
-    if _tools.attrs_set_frame_attributes(h, pos, k, kl.ctypes.data, v, vl.ctypes.data, n) < 0:
+    if _tools.attrs_set_frame_attributes(handle, frame, k, kl.ctypes.data, v, vl.ctypes.data, n) < 0:
         raise RuntimeError("An error occured while calling 'attrs_set_frame_attributes'")
 
 
-def attrs_set_global_attributes(h, attributes):
+def attrs_set_global_attributes(handle, attributes):
     k, kl, v, vl, n = pack_attributes(attributes)
-    if _tools.attrs_set_global_attributes(h, k, kl.ctypes.data, v, vl.ctypes.data, n) < 0:
+    if _tools.attrs_set_global_attributes(handle, k, kl.ctypes.data, v, vl.ctypes.data, n) < 0:
         raise RuntimeError("An error occured while calling 'attrs_set_global_attributes'")
 
 

@@ -10,27 +10,16 @@ PCIe per ``load_pos``.  Only digital levels are offered (no calibration plugin i
 import math
 import os
 import tempfile
-from enum import Enum
 from pathlib import Path
 
 import numpy as np
 
 from ..tools.FileAttributes import FileAttributes
 from . import rir_video_io as _abi
+from .rir_video_io import FileFormat
 from .IRSaver import IRSaver
 
 _TI_MASK, _TI_SHIFT = 0xE000, 13  # the three top bits of a digital level carry the integration-time index
-
-
-class FileFormat(Enum):
-    """``video_file_format`` codes (reference src/cpp/video_io/video_io.h FILE_FORMAT_*)"""
-    PCR = 1
-    WEST = 2
-    PCR_ENCAPSULATED = 3
-    ZSTD_COMPRESSED = 4
-    H264 = 5
-    HCC = 6
-    OTHER = 7
 
 
 class InvalidMovie(Exception):
@@ -244,7 +233,7 @@ class IRMovie(object):
 
     @property
     def video_file_format(self):
-        return FileFormat(_abi.video_file_format(self.filename))
+        return _abi.video_file_format(self.filename)
 
     @property
     def is_file_uncompressed(self):

@@ -5,6 +5,7 @@ Function names, argument meaning and error behaviour follow the reference wrappe
 in and out, ``RuntimeError`` when the library reports a failure.
 """
 import ctypes as ct
+import enum
 import sys
 import weakref
 
@@ -81,8 +82,27 @@ def open_camera_memory(buffer):
     return h
 
 
+class FileFormat(enum.IntEnum):
+    """``video_file_format`` codes (reference rir_video_io.py:52-57 over video_io.h:17-23; an IntEnum, so that the deprecated
+    ``FILE_FORMAT_*`` integers of the reference module compare equal to the members)"""
+    PCR = 1
+    WEST = 2
+    PCR_ENCAPSULATED = 3
+    ZSTD_COMPRESSED = 4
+    H264 = 5
+    HCC = 6
+    OTHER = 7
+
+
 def video_file_format(filename):
-    return _v.video_file_format(toBytes(str(filename)))
+    """
+    Returns the video file format of given video file (a ``FileFormat``); RuntimeError when the file cannot be opened as a video
+    (reference rir_video_io.py:111-118)
+    """
+    res = _v.video_file_format(toBytes(str(filename)))
+    if res <= 0:
+        raise RuntimeError("cannot open file " + str(filename))
+    return FileFormat(res)
 
 
 def close_camera(camera):
@@ -276,7 +296,7 @@ def change_hcc_external_blackbody_temperature(filename, temperature):
     return r
 
 
-def calibration_files(camera):
+def calibration_files(movie_handle):
     return []
 
 

@@ -133,7 +133,9 @@ def test_pcr_reader_needs_no_gpu(tmp_path):
     junk.write_bytes(b"\x00" * 5000)
     with pytest.raises(RuntimeError):
         rv.open_camera_file(junk)
-    assert rv.video_file_format(junk) == -1
+    with pytest.raises(RuntimeError):  # reference rir_video_io.py:115-117, tests/python/test_rir.py:336-339
+        rv.video_file_format(junk)
+    assert rv.video_file_format(p) is rv.FileFormat.PCR  # (reference tests/python/test_video_io.py:165-166)
 
 
 def test_the_other_raw_formats_need_no_gpu(tmp_path):
@@ -503,3 +505,28 @@ def test_labelling_and_time_axis_wrappers_refuse_bad_arguments_without_a_gpu():
             sp.label_image(np.ones((4, 4), np.uint16), 0)
         with pytest.raises(RuntimeError):
             sp.keep_largest_area(np.ones((4, 4), np.uint16), 0)
+
+
+def test_package_surface_like_the_reference():
+    """names a user of the reference package reaches without thinking about it: the top-level classes and modules
+    (src/python/librir/__init__.py:4-12), ``low_level``'s exports (low_level/__init__.py), ``FileFormat`` and the reference's argument
+    names on the calls that are made with keywords"""
+    import inspect
+
+    import librir_amd as librir
+    from librir_amd.low_level import _geometry, _signal_processing, _tools, _video_io, createZeroArrayHandle, loadDlls, toArray, toCharP, toString  # noqa: F401
+    from librir_amd.tools import rir_tools
+    from librir_amd.video_io import FileFormat, video_file_format  # noqa: F401
+
+    assert librir.IRMovie.__name__ == "IRMovie" and librir.IRSaver.__name__ == "IRSaver" and librir.BadPixels.__name__ == "BadPixels"
+    assert librir.rir_video_io.FileFormat is FileFormat and librir.rir_tools is rir_tools and librir.misc.toString(b"x") == "x"
+    assert librir.rir_signal_processing.translate is librir.signal_processing.translate
+    with pytest.raises(AttributeError):
+        librir.rir_geometry
+    assert [m.name for m in FileFormat][:5] == ["PCR", "WEST", "PCR_ENCAPSULATED", "ZSTD_COMPRESSED", "H264"] and FileFormat.H264 == rv.FILE_FORMAT_H264
+    ar, handle = createZeroArrayHandle((2, 3), np.int32)
+    assert ar.shape == (2, 3) and handle[0] == 0 and loadDlls()[0] is _tools and _geometry is None
+    for fn, names in ((rir_tools.attrs_set_frame_attributes, ["handle", "frame", "attributes"]), (rir_tools.attrs_open_buffer, ["buf"]),
+                      (FileAttributes.frame_attributes, ["self", "frame_index"]), (FileAttributes.set_frame_attributes, ["self", "frame_index", "attributes"]),
+                      (rv.calibration_files, ["movie_handle"]), (rv.load_image, ["camera", "pos", "calibration", "shape"])):
+        assert list(inspect.signature(fn).parameters) == names
