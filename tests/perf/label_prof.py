@@ -1,3 +1,7 @@
+"""Target of the kernel trace of the labelling kernels (GPU box):
+    rocprofv3 --kernel-trace --stats --output-format csv -d OUT -- python tests/perf/label_prof.py
+20 label_image calls each on four 640x512 uint16 images in device memory: empty, regions, vertical stripes of distinct values, one flat
+component (profiles/r05_label_kernel_trace.csv)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
