@@ -15,7 +15,7 @@
 // which a root is always the LOWEST index of its tree (links go from the higher root to the lower one, atomicMin), i.e. the component's
 // first pixel in raster order; numbering the roots by a prefix sum over the raster gives the reference's numbers bit for bit.
 //
-// Integer work on a frame buffer, in five launches: (1) every 64 x 16 tile is labelled on its own in LDS - LDS atomics, no traffic
+// Integer work on a frame buffer, in five launches: (1) every 64 x 32 tile is labelled on its own in LDS - LDS atomics, no traffic
 // but one read of the image - and leaves every pixel linked to its tile-local root with the root's pixel count beside it; (2) the joins
 // across tile borders, the only ones made with global atomics; (3) every pixel learns its final root, tile roots hand their counts to
 // it; (4) one workgroup turns the per-block root counts into offsets; (5) labels and tables out.  Every pass reads or
@@ -31,7 +31,18 @@ namespace rir
 	{
 		constexpr int kBlock = 256;		 // 4 wavefronts
 		constexpr int kScanBlock = 1024; // the one workgroup that turns per-block root counts into offsets
-		constexpr int kTileW = 64, kTileH = 16, kRowsPerWave = kTileH / (kBlock / 64);
+// Tile of the first launch: 64 columns (a wavefront per row piece) x RIR_LABEL_TILE_H rows, RIR_LABEL_TILE_THREADS threads.  Measured on 640x512
+// images (scripts/variants.py, tests/perf/label_time.py): heights 8 / 16 / 32 / 64 with 256 / 512 / 1024 threads are within 8 % of each other on
+// every kind of image; 32 rows with 1024 threads (two rows a wavefront) is the best by a few per cent (regions 25.4 us against 27.3 for 16 rows
+// and 256 threads, vertical stripes 31.6 against 36.0, the spiral 183 against 206).
+#ifndef RIR_LABEL_TILE_H
+#define RIR_LABEL_TILE_H 32
+#endif
+#ifndef RIR_LABEL_TILE_THREADS
+#define RIR_LABEL_TILE_THREADS 1024
+#endif
+		constexpr int kTileW = 64, kTileH = RIR_LABEL_TILE_H, kTileThreads = RIR_LABEL_TILE_THREADS, kRowsPerWave = kTileH / (kTileThreads / 64);
+		static_assert(kRowsPerWave * (kTileThreads / 64) == kTileH && kRowsPerWave >= 1, "tile rows divide over the wavefronts");
 
 		// The forests are read and written by many waves at once: a link is loaded and stored as one 32-bit access at the scope that
 		// shares it (never a stale copy from the CU's vector cache, never torn).
@@ -92,13 +103,13 @@ namespace rir
 		}
 		constexpr int kTile = __HIP_MEMORY_SCOPE_WORKGROUP, kImage = __HIP_MEMORY_SCOPE_AGENT;
 
-		// Launch 1: one workgroup per tile, one wavefront per 4 rows of it, row after row.  A pixel starts linked to the first pixel of its
+		// Launch 1: one workgroup per tile, its rows dealt to the wavefronts (two each), row after row.  A pixel starts linked to the first pixel of its
 		// horizontal run inside the tile (a run = neighbours with equal values), then every pixel is joined with the pixel above it.  A
 		// vertical join is implied (and skipped) when the pixel and the one above both continue their left neighbour's run: that
 		// neighbour pair is joined already - a flat tile makes one join per row instead of one per pixel.  Out: L[i] = the image index of
 		// the pixel's tile-local root (-1 on the background), cnt[i] = the tile-local component's pixel count at that root, 0 elsewhere.
 		template <class C>
-		__global__ __launch_bounds__(kBlock) void ccl_tile_kernel(const C *__restrict__ src, C bg, int w, int h, int tiles_x, int *__restrict__ L,
+		__global__ __launch_bounds__(kTileThreads) void ccl_tile_kernel(const C *__restrict__ src, C bg, int w, int h, int tiles_x, int *__restrict__ L,
 																  int *__restrict__ cnt, unsigned long long *__restrict__ best)
 		{
 			__shared__ int lab[kTileW * kTileH];
@@ -400,7 +411,7 @@ namespace rir
 			C bg;
 			__builtin_memcpy(&bg, background, sizeof(C));
 			const int tiles_x = (w + kTileW - 1) / kTileW, tiles_y = (h + kTileH - 1) / kTileH;
-			hipLaunchKernelGGL(ccl_tile_kernel<C>, dim3((unsigned)(tiles_x * tiles_y)), dim3(kBlock), 0, st, static_cast<const C *>(d_src), bg, w, h,
+			hipLaunchKernelGGL(ccl_tile_kernel<C>, dim3((unsigned)(tiles_x * tiles_y)), dim3(kTileThreads), 0, st, static_cast<const C *>(d_src), bg, w, h,
 							   tiles_x, k.L, k.cnt, k.best);
 			const int64_t joins = (int64_t)(tiles_y - 1) * w + (int64_t)(tiles_x - 1) * h;
 			if (joins > 0)
