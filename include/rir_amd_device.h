@@ -357,6 +357,9 @@ extern "C"
 	/* The same helpers move a chunk between page-locked memory and the container file (the saver's writer, the loader's read-ahead):
 	 * write != 0 writes buf to [file_off, file_off + bytes) of the descriptor, else reads that range - all of it, or -1.  0 on success. */
 	int rir_host_file_rw(int fd, void *buf, int64_t bytes, int64_t file_off, int write);
+	/* first touch of [buf, buf + bytes) - fresh host memory that is being filled, e.g. the stack a slice of a movie is read into - one atomic
+	 * compare-and-swap of a byte with itself per page on the calling thread (meant to run on a thread of its own, ahead of the reads); contents are left as they are. */
+	int rir_host_touch(void *buf, int64_t bytes);
 
 #ifdef __cplusplus
 }

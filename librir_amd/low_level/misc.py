@@ -75,6 +75,41 @@ def get_memory_folder():
     return folder
 
 
+class touch_ahead:
+    """``with touch_ahead(stack): fill stack`` - a FRESH array (``np.empty``) that the library is about to fill image by image gets its pages
+    made by threads of their own, ahead of the copies: a first touch is otherwise a page fault and a zeroed (huge) page under the threads
+    that copy each image in - for the stack of a 1 000-image slice, twice the time of the reads themselves.  One thread makes pages at
+    about 25 GB/s, the reads fill 40 GB/s: three threads take the array's 16 MiB pieces in turn, so that the made part grows from the front.
+    The threads hold the array until they are through; contents are left as they are (``rir_host_touch``: an atomic compare-and-swap of a
+    byte with itself per page)."""
+
+    PIECE = 16 << 20
+    THREADS = 3
+
+    def __init__(self, array):
+        self.threads = []
+        if array.nbytes >= (8 << 20) and array.flags.c_contiguous and array.flags.writeable:
+            import threading
+
+            base, total = array.ctypes.data, array.nbytes
+
+            def run(k, keep=array):  # (`keep`: the array lives as long as this thread)
+                for start in range(k * self.PIECE, total, self.THREADS * self.PIECE):
+                    _lib.rir_host_touch(ct.c_void_p(base + start), ct.c_int64(min(self.PIECE, total - start)))
+
+            for k in range(self.THREADS):
+                self.threads.append(threading.Thread(target=run, args=(k,), daemon=True))
+                self.threads[-1].start()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        for t in self.threads:
+            t.join()
+        return False
+
+
 def createZeroArrayHandle(shape, _dtype):
     """For a given shape and dtype, create a zero filled array and its ctype handle (reference low_level/misc.py:88-95)"""
     ar = np.zeros(shape, dtype=_dtype)

@@ -175,11 +175,17 @@ def _recycle_block(pool, block):
         pool.append(block)
 
 
-def load_image(camera, pos, calibration=0, shape=None):
+def load_image(camera, pos, calibration=0, shape=None, out=None):
     """``shape``: (height, width) when the caller already knows it (IRMovie does: one library call less per image).  The
-    buffer is not zero-filled first (the library writes every pixel or fails)."""
+    buffer is not zero-filled first (the library writes every pixel or fails).  ``out``: a C-contiguous uint16 array of that shape
+    to read into (a row of a stack: reading a slice of a movie then costs no copy of each image) - returned instead of a new array."""
     h, w = get_image_size(camera) if shape is None else shape
-    img = _image_buffer(h, w)
+    if out is None:
+        img = _image_buffer(h, w)
+    else:
+        img = out
+        if img.dtype != np.uint16 or img.shape != (h, w) or not img.flags.c_contiguous or not img.flags.writeable:
+            raise RuntimeError("load_image: 'out' must be a writeable C-contiguous uint16 array of the image's shape")
     if _v.load_image(camera, int(pos), int(calibration), img.ctypes.data) < 0:
         _fail("load_image")
     return img

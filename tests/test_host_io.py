@@ -528,5 +528,38 @@ def test_package_surface_like_the_reference():
     assert ar.shape == (2, 3) and handle[0] == 0 and loadDlls()[0] is _tools and _geometry is None
     for fn, names in ((rir_tools.attrs_set_frame_attributes, ["handle", "frame", "attributes"]), (rir_tools.attrs_open_buffer, ["buf"]),
                       (FileAttributes.frame_attributes, ["self", "frame_index"]), (FileAttributes.set_frame_attributes, ["self", "frame_index", "attributes"]),
-                      (rv.calibration_files, ["movie_handle"]), (rv.load_image, ["camera", "pos", "calibration", "shape"])):
+                      (rv.calibration_files, ["movie_handle"]), (rv.load_image, ["camera", "pos", "calibration", "shape", "out"])):
         assert list(inspect.signature(fn).parameters) == names
+
+
+def test_slices_fill_their_stack_in_place_with_pages_made_ahead(tmp_path):
+    """IRMovie[a:b] / .data read every image straight into its row of the stack while threads of their own make the stack's pages
+    (low_level.misc.touch_ahead over rir_host_touch); the touching must never change what the reads have written, whichever comes
+    first.  A raw movie: no device needed."""
+    from librir_amd.low_level.misc import touch_ahead
+    from librir_amd.video_io import IRMovie
+
+    rng = np.random.default_rng(8)
+    fr = rng.integers(0, 16000, (30, 512, 640)).astype(np.uint16)  # 19.7 MB: above the size from which pages are made ahead
+    p = tmp_path / "big.pcr"
+    write_pcr(p, fr)
+    with IRMovie.from_filename(p) as mov:
+        assert np.array_equal(mov.data, fr)
+        assert np.array_equal(mov[2:29:4], fr[2:29:4]) and np.array_equal(mov[-13:], fr[-13:]) and mov[4:4].shape == (0, 512, 640)
+        row = np.empty((512, 640), np.uint16)
+        assert mov.load_pos(7, out=row) is row and np.array_equal(row, fr[7])
+        for bad in (np.empty((512, 640), np.int16), np.empty((512, 641), np.uint16), np.empty((640, 512), np.uint16).T):
+            with pytest.raises(RuntimeError):
+                mov.load_pos(0, out=bad)
+    # the toucher against a writer, many times over: every byte is the writer's
+    for rep in range(6):
+        a = np.empty(48 << 20, dtype=np.uint8)
+        with touch_ahead(a) as t:
+            assert len(t.threads) == touch_ahead.THREADS
+            for start in range(0, a.size, 1 << 20):
+                a[start:start + (1 << 20)] = (start >> 20) + rep
+        assert np.array_equal(a[::4096], ((np.arange(0, a.size, 4096) >> 20) + rep).astype(np.uint8))
+        assert np.array_equal(a[4095::4096], ((np.arange(4095, a.size, 4096) >> 20) + rep).astype(np.uint8))
+    small = np.zeros(100, np.uint8)
+    with touch_ahead(small) as t:  # too small to bother
+        assert t.threads == []
