@@ -230,14 +230,21 @@ extern "C"
 	/* 3x3 median filter: reference Filters.h:71-129 (template without C export upstream). */
 	int rir_median_filter_device(const unsigned short *d_src, unsigned short *d_dst, int w, int h, int nframes, void *stream);
 
-	/* connected components: reference signal_processing.h:90-92 / Filters.h:365-540 (labelImage, keepLargestArea) on one image in
-	 * device memory.  type: the reference's dtype character; background: HOST pointer to one cell of that type.
-	 * d_dst int32 [h][w].  label: d_xy double[2*(labels)], d_area int[labels], d_count int[1] receive the per-component tables and
-	 * labels = components + 1 (room for w*h + 1 entries is always enough); any memory the device can write.
-	 * d_work: device memory, 8-byte aligned, at least rir_label_workspace_bytes(w, h) (0: geometry refused).  0 / -1. */
+	/* connected components: reference signal_processing.h:90-92 / Filters.h:365-540 (labelImage, keepLargestArea) on images in device memory,
+	 * [nframes][h][w], every image labelled on its own; five launches for the whole batch.  type: the reference's dtype character;
+	 * background: HOST pointer to one cell of that type.  d_dst int32 [nframes][h][w].
+	 * label: per image `table_entries` entries of d_xy (two doubles each: the first cell's x, twice - as upstream) and d_area, of which the
+	 * first min(labels, table_entries) are written; d_count int[nframes] = labels = components + 1 (w*h + 1 entries are always enough);
+	 * any memory the device can write.  d_work: device memory, 8-byte aligned, at least rir_label_workspace_bytes_batch(w, h, nframes)
+	 * (0: geometry refused).  0 / -1.  The *_image_* forms are the batch of one with tables of w*h + 1 entries. */
 	size_t rir_label_workspace_bytes(int w, int h);
+	size_t rir_label_workspace_bytes_batch(int w, int h, int nframes);
+	int rir_label_images_device(int type, const void *d_src, int *d_dst, int w, int h, int nframes, const void *background, double *d_xy, int *d_area,
+								int table_entries, int *d_count, void *d_work, size_t work_bytes, void *stream);
 	int rir_label_image_device(int type, const void *d_src, int *d_dst, int w, int h, const void *background, double *d_xy, int *d_area,
 							   int *d_count, void *d_work, size_t work_bytes, void *stream);
+	int rir_keep_largest_areas_device(int type, const void *d_src, int *d_dst, int w, int h, int nframes, const void *background, int foreground,
+									  void *d_work, size_t work_bytes, void *stream);
 	int rir_keep_largest_area_device(int type, const void *d_src, int *d_dst, int w, int h, const void *background, int foreground, void *d_work,
 									 size_t work_bytes, void *stream);
 

@@ -103,6 +103,16 @@ namespace rir
 		}
 		constexpr int kTile = __HIP_MEMORY_SCOPE_WORKGROUP, kImage = __HIP_MEMORY_SCOPE_AGENT;
 
+		// A launch works on a batch of images [frames][h][w] (blockIdx.y = the image): where the next image's part of every array begins.
+		struct Pitch
+		{
+			int64_t cells;	// image (in cells) and label image (in ints)
+			int64_t plane;	// L, cnt (ints)
+			int64_t waves;	// root_bits, wave_before (entries)
+			int64_t blocks; // block_roots (entries)
+			int64_t table;	// entries of the per-image tables the caller gave room for
+		};
+
 		// Launch 1: one workgroup per tile, its rows dealt to the wavefronts (two each), row after row.  A pixel starts linked to the first pixel of its
 		// horizontal run inside the tile (a run = neighbours with equal values), then every pixel is joined with the pixel above it.  A
 		// vertical join is implied (and skipped) when the pixel and the one above both continue their left neighbour's run: that
@@ -110,13 +120,14 @@ namespace rir
 		// the pixel's tile-local root (-1 on the background), cnt[i] = the tile-local component's pixel count at that root, 0 elsewhere.
 		template <class C>
 		__global__ __launch_bounds__(kTileThreads) void ccl_tile_kernel(const C *__restrict__ src, C bg, int w, int h, int tiles_x, int *__restrict__ L,
-																  int *__restrict__ cnt, unsigned long long *__restrict__ best)
+																  int *__restrict__ cnt, unsigned long long *__restrict__ best, Pitch pitch)
 		{
 			__shared__ int lab[kTileW * kTileH];
 			__shared__ int num[kTileW * kTileH];
 			__shared__ uint8_t flags[kTileW * kTileH]; // 1: belongs to a component, 2: continues its left neighbour's run
+			src += blockIdx.y * pitch.cells, L += blockIdx.y * pitch.plane, cnt += blockIdx.y * pitch.plane;
 			if (blockIdx.x == 0 && threadIdx.x == 0)
-				best[0] = 0ull;
+				best[blockIdx.y] = 0ull;
 			const int ty = (int)blockIdx.x / tiles_x, tx = (int)blockIdx.x - ty * tiles_x;
 			const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
 			const int x = tx * kTileW + lane, y0 = ty * kTileH;
@@ -177,8 +188,9 @@ namespace rir
 		// the pair to the left is on the same border), the first column of every tile but the left ones with the pixel to its left when
 		// the run continues.
 		template <class C>
-		__global__ __launch_bounds__(kBlock) void ccl_border_kernel(const C *__restrict__ src, C bg, int w, int h, int rows, int cols, int *L)
+		__global__ __launch_bounds__(kBlock) void ccl_border_kernel(const C *__restrict__ src, C bg, int w, int h, int rows, int cols, int *L, Pitch pitch)
 		{
+			src += blockIdx.y * pitch.cells, L += blockIdx.y * pitch.plane;
 			const int k = (int)(blockIdx.x * (unsigned)kBlock + threadIdx.x);
 			if (k < rows * w)
 			{
@@ -210,9 +222,11 @@ namespace rir
 		// Every store to a link that other waves climb through (the tile roots: cnt > 0) lowers it - atomicMin - so that a
 		// path-shortening store of another wave that lands late cannot put an ancestor back where the root has been written.
 		__global__ __launch_bounds__(kBlock) void ccl_flatten_kernel(int *L, int n, int *__restrict__ cnt, unsigned long long *__restrict__ root_bits,
-																	 int *__restrict__ wave_before, int *__restrict__ block_roots)
+																	 int *__restrict__ wave_before, int *__restrict__ block_roots, Pitch pitch)
 		{
 			__shared__ int wave_roots[kBlock / 64];
+			L += blockIdx.y * pitch.plane, cnt += blockIdx.y * pitch.plane, root_bits += blockIdx.y * pitch.waves, wave_before += blockIdx.y * pitch.waves,
+				block_roots += blockIdx.y * pitch.blocks;
 			const int i = (int)(blockIdx.x * (unsigned)kBlock + threadIdx.x);
 			const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
 			const int first = i < n ? link_load<kImage>(&L[i]) : -1;
@@ -273,8 +287,9 @@ namespace rir
 		// has an entry 0 for the background, Filters.h:489).  Its own launch: folded into the pass above - the block that finishes last
 		// doing the sums - it needs a device-scope release from every block, which on this part writes the XCD's L2 back each time:
 		// 34 us for the 1280 blocks of a 640 x 512 image, against 4 us for this launch.
-		__global__ __launch_bounds__(kScanBlock) void ccl_scan_kernel(int *__restrict__ block_roots, int nb, int *__restrict__ count)
+		__global__ __launch_bounds__(kScanBlock) void ccl_scan_kernel(int *__restrict__ block_roots, int nb, int *__restrict__ count, Pitch pitch)
 		{
+			block_roots += blockIdx.x * pitch.blocks, count += blockIdx.x; // (one workgroup per image)
 			__shared__ int wave_sum[kScanBlock / 64];
 			__shared__ int carry;
 			const int lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
@@ -314,8 +329,10 @@ namespace rir
 		__global__ __launch_bounds__(kBlock) void ccl_labels_kernel(const int *__restrict__ R, int n, int w, const int *__restrict__ cnt,
 																	const unsigned long long *__restrict__ root_bits, const int *__restrict__ wave_before,
 																	const int *__restrict__ block_before, int *__restrict__ dst, double *__restrict__ xy,
-																	int *__restrict__ area)
+																	int *__restrict__ area, Pitch pitch)
 		{
+			R += blockIdx.y * pitch.plane, cnt += blockIdx.y * pitch.plane, root_bits += blockIdx.y * pitch.waves, wave_before += blockIdx.y * pitch.waves,
+				block_before += blockIdx.y * pitch.blocks, dst += blockIdx.y * pitch.cells, xy += blockIdx.y * pitch.table * 2, area += blockIdx.y * pitch.table;
 			const int i = (int)(blockIdx.x * (unsigned)kBlock + threadIdx.x);
 			if (i >= n)
 				return;
@@ -330,7 +347,7 @@ namespace rir
 			if (r >= 0)
 				k = block_before[r / kBlock] + wave_before[r >> 6] + __popcll(root_bits[r >> 6] & ((1ull << (r & 63)) - 1ull)) + 1;
 			dst[i] = k;
-			if (r == i)
+			if (r == i && k < pitch.table) // (a table with less room than the image has components keeps its first entries; the count says how many there are)
 			{
 				const double x = (double)(i % w);
 				xy[2 * (int64_t)k] = x;
@@ -340,35 +357,49 @@ namespace rir
 		}
 
 		// keepLargestArea: the component with the most pixels, the first in raster order among equals (Filters.h:524-533 keeps the
-		// earlier one unless a later one is strictly larger) = the largest key (area, ~root).  One atomic per block that holds a
-		// candidate above what is published already.
+		// earlier one unless a later one is strictly larger) = the largest key (area, ~root).  Four cells a thread (one 16-byte load);
+		// roots are few: a wavefront that holds one publishes its best when it beats what is published - compared first with a copy from
+		// the CU's cache, which may be old but only ever too low - and the others are through after their load: no barrier, no LDS (a batch
+		// of 256 images: 1.45 us an image against 2.5 with one cell a thread, a reduction over the block and a look at the published value by
+		// every block; an image of noise 38-43 us a call against 40-50).
 		__global__ __launch_bounds__(kBlock) void ccl_largest_kernel(const int *__restrict__ R, int n, const int *__restrict__ cnt,
-																	 unsigned long long *best)
+																	 unsigned long long *best, Pitch pitch)
 		{
-			__shared__ unsigned long long wave_key[kBlock / 64];
-			const int i = (int)(blockIdx.x * (unsigned)kBlock + threadIdx.x);
+			R += blockIdx.y * pitch.plane, cnt += blockIdx.y * pitch.plane, best += blockIdx.y;
+			const int i0 = (int)(blockIdx.x * (unsigned)kBlock + threadIdx.x) * 4;
+			int r[4] = {-1, -1, -1, -1};
+			if (i0 + 3 < n)
+			{
+				const int4 v = *reinterpret_cast<const int4 *>(R + i0); // (a plane starts on a 64-byte boundary)
+				r[0] = v.x, r[1] = v.y, r[2] = v.z, r[3] = v.w;
+			}
+			else
+				for (int q = 0; q < 4; ++q)
+					if (i0 + q < n)
+						r[q] = R[i0 + q];
 			unsigned long long key = 0ull;
-			if (i < n && R[i] == i)
-				key = ((unsigned long long)(unsigned)cnt[i] << 32) | (unsigned)~(unsigned)i;
+#pragma unroll
+			for (int q = 0; q < 4; ++q)
+				if (r[q] == i0 + q)
+				{ // (within a thread a later root is a later cell: it wins only when strictly larger)
+					const unsigned long long k = ((unsigned long long)(unsigned)cnt[i0 + q] << 32) | (unsigned)~(unsigned)(i0 + q);
+					key = k > key ? k : key;
+				}
+			if (__ballot(key != 0ull) == 0ull)
+				return;
 			for (int d = 32; d >= 1; d >>= 1)
 			{
 				const unsigned long long o = __shfl_xor(key, d);
 				key = o > key ? o : key;
 			}
-			if ((threadIdx.x & 63) == 0)
-				wave_key[threadIdx.x >> 6] = key;
-			__syncthreads();
-			if (threadIdx.x == 0)
-			{
-				for (int q = 1; q < kBlock / 64; ++q)
-					key = wave_key[q] > key ? wave_key[q] : key;
-				if (key > __hip_atomic_load(best, __ATOMIC_RELAXED, kImage))
-					atomicMax(best, key);
-			}
+			if ((threadIdx.x & 63) == 0 && key > *static_cast<const volatile unsigned long long *>(best) &&
+				key > __hip_atomic_load(best, __ATOMIC_RELAXED, kImage))
+				atomicMax(best, key);
 		}
 		__global__ __launch_bounds__(kBlock) void ccl_keep_kernel(const int *__restrict__ R, int n, const unsigned long long *__restrict__ best,
-																  int fg_value, int bg_value, int *__restrict__ dst)
+																  int fg_value, int bg_value, int *__restrict__ dst, Pitch pitch)
 		{
+			R += blockIdx.y * pitch.plane, best += blockIdx.y, dst += blockIdx.y * pitch.cells;
 			const int i = (int)(blockIdx.x * (unsigned)kBlock + threadIdx.x);
 			if (i >= n)
 				return;
@@ -387,96 +418,115 @@ namespace rir
 			int *L, *cnt, *block_roots, *wave_before;
 			unsigned long long *root_bits, *best;
 			int n, nb;
+			Pitch pitch;
 		};
 		size_t align64(size_t b) { return (b + 63) & ~(size_t)63; }
-		Work carve(void *d_work, int w, int h)
+		Pitch pitch_of(int w, int h, int64_t table)
+		{
+			const size_t n = (size_t)w * h, nb = (n + kBlock - 1) / kBlock;
+			Pitch p;
+			p.cells = (int64_t)n;
+			p.plane = (int64_t)(align64(n * sizeof(int)) / sizeof(int));
+			p.waves = (int64_t)((nb * (kBlock / 64) + 7) & ~(size_t)7);
+			p.blocks = (int64_t)((nb + 15) & ~(size_t)15);
+			p.table = table;
+			return p;
+		}
+		Work carve(void *d_work, int w, int h, int frames, int64_t table)
 		{
 			Work k;
 			k.n = w * h;
 			k.nb = (k.n + kBlock - 1) / kBlock;
+			k.pitch = pitch_of(w, h, table);
 			char *p = static_cast<char *>(d_work);
-			const size_t plane = align64((size_t)k.n * sizeof(int)), waves = (size_t)k.nb * (kBlock / 64);
+			const size_t f = (size_t)frames;
 			k.L = reinterpret_cast<int *>(p);
-			k.cnt = reinterpret_cast<int *>(p += plane);
-			k.root_bits = reinterpret_cast<unsigned long long *>(p += plane);
-			k.wave_before = reinterpret_cast<int *>(p += align64(waves * sizeof(unsigned long long)));
-			k.block_roots = reinterpret_cast<int *>(p += align64(waves * sizeof(int)));
-			k.best = reinterpret_cast<unsigned long long *>(p += align64((size_t)k.nb * sizeof(int)));
+			k.cnt = reinterpret_cast<int *>(p += f * k.pitch.plane * sizeof(int));
+			k.root_bits = reinterpret_cast<unsigned long long *>(p += f * k.pitch.plane * sizeof(int));
+			k.wave_before = reinterpret_cast<int *>(p += f * k.pitch.waves * sizeof(unsigned long long));
+			k.block_roots = reinterpret_cast<int *>(p += align64(f * k.pitch.waves * sizeof(int)));
+			k.best = reinterpret_cast<unsigned long long *>(p += align64(f * k.pitch.blocks * sizeof(int)));
 			return k;
 		}
 
 		template <class C>
-		hipError_t forest(const void *d_src, const void *background, int w, int h, const Work &k, hipStream_t st)
+		hipError_t forest(const void *d_src, const void *background, int w, int h, int frames, const Work &k, hipStream_t st)
 		{
 			C bg;
 			__builtin_memcpy(&bg, background, sizeof(C));
 			const int tiles_x = (w + kTileW - 1) / kTileW, tiles_y = (h + kTileH - 1) / kTileH;
-			hipLaunchKernelGGL(ccl_tile_kernel<C>, dim3((unsigned)(tiles_x * tiles_y)), dim3(kTileThreads), 0, st, static_cast<const C *>(d_src), bg, w, h,
-							   tiles_x, k.L, k.cnt, k.best);
+			const unsigned fy = (unsigned)frames;
+			hipLaunchKernelGGL(ccl_tile_kernel<C>, dim3((unsigned)(tiles_x * tiles_y), fy), dim3(kTileThreads), 0, st, static_cast<const C *>(d_src), bg, w, h,
+							   tiles_x, k.L, k.cnt, k.best, k.pitch);
 			const int64_t joins = (int64_t)(tiles_y - 1) * w + (int64_t)(tiles_x - 1) * h;
 			if (joins > 0)
-				hipLaunchKernelGGL(ccl_border_kernel<C>, dim3((unsigned)((joins + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-								   static_cast<const C *>(d_src), bg, w, h, tiles_y - 1, tiles_x - 1, k.L);
-			hipLaunchKernelGGL(ccl_flatten_kernel, dim3((unsigned)k.nb), dim3(kBlock), 0, st, k.L, k.n, k.cnt, k.root_bits, k.wave_before, k.block_roots);
+				hipLaunchKernelGGL(ccl_border_kernel<C>, dim3((unsigned)((joins + kBlock - 1) / kBlock), fy), dim3(kBlock), 0, st,
+								   static_cast<const C *>(d_src), bg, w, h, tiles_y - 1, tiles_x - 1, k.L, k.pitch);
+			hipLaunchKernelGGL(ccl_flatten_kernel, dim3((unsigned)k.nb, fy), dim3(kBlock), 0, st, k.L, k.n, k.cnt, k.root_bits, k.wave_before, k.block_roots,
+							   k.pitch);
 			return hipGetLastError();
 		}
-		hipError_t forest_of(int cell_bytes, const void *d_src, const void *background, int w, int h, const Work &k, hipStream_t st)
+		hipError_t forest_of(int cell_bytes, const void *d_src, const void *background, int w, int h, int frames, const Work &k, hipStream_t st)
 		{
 			switch (cell_bytes)
 			{
 			case 1:
-				return forest<uint8_t>(d_src, background, w, h, k, st);
+				return forest<uint8_t>(d_src, background, w, h, frames, k, st);
 			case 2:
-				return forest<uint16_t>(d_src, background, w, h, k, st);
+				return forest<uint16_t>(d_src, background, w, h, frames, k, st);
 			case 4:
-				return forest<uint32_t>(d_src, background, w, h, k, st);
+				return forest<uint32_t>(d_src, background, w, h, frames, k, st);
 			case 8:
-				return forest<uint64_t>(d_src, background, w, h, k, st);
+				return forest<uint64_t>(d_src, background, w, h, frames, k, st);
 			case -4:
-				return forest<float>(d_src, background, w, h, k, st);
+				return forest<float>(d_src, background, w, h, frames, k, st);
 			case -8:
-				return forest<double>(d_src, background, w, h, k, st);
+				return forest<double>(d_src, background, w, h, frames, k, st);
 			default:
 				return hipErrorInvalidValue;
 			}
 		}
-		bool geometry_ok(int w, int h) { return w > 0 && h > 0 && (int64_t)w * h <= 0x7FFF0000LL; }
+		// (a launch's second grid dimension carries the image: 65 535 at most)
+		bool geometry_ok(int w, int h, int frames) { return w > 0 && h > 0 && (int64_t)w * h <= 0x7FFF0000LL && frames > 0 && frames <= 65535; }
 	} // namespace
 
-	size_t label_workspace_bytes(int w, int h)
+	size_t label_workspace_bytes(int w, int h, int frames)
 	{
-		if (!geometry_ok(w, h))
+		if (!geometry_ok(w, h, frames))
 			return 0;
-		const size_t n = (size_t)w * h, nb = (n + kBlock - 1) / kBlock, waves = nb * (kBlock / 64);
-		return 2 * align64(n * sizeof(int)) + align64(waves * sizeof(unsigned long long)) + align64(waves * sizeof(int)) + align64(nb * sizeof(int)) + 64;
+		const Pitch p = pitch_of(w, h, 0);
+		const size_t f = (size_t)frames;
+		return 2 * f * p.plane * sizeof(int) + f * p.waves * sizeof(unsigned long long) + align64(f * p.waves * sizeof(int)) + align64(f * p.blocks * sizeof(int)) +
+			   align64(f * sizeof(unsigned long long)) + 64;
 	}
 
-	hipError_t launch_label_image(int cell_bytes, const void *d_src, const void *background, int w, int h, int *d_dst, double *d_xy, int *d_area,
-								  int *d_count, void *d_work, hipStream_t st)
+	hipError_t launch_label_images(int cell_bytes, const void *d_src, const void *background, int w, int h, int frames, int *d_dst, double *d_xy,
+								   int *d_area, int64_t table_entries, int *d_count, void *d_work, hipStream_t st)
 	{
-		if (!geometry_ok(w, h) || !d_src || !background || !d_dst || !d_xy || !d_area || !d_count || !d_work)
+		if (!geometry_ok(w, h, frames) || table_entries < 1 || !d_src || !background || !d_dst || !d_xy || !d_area || !d_count || !d_work)
 			return hipErrorInvalidValue;
-		const Work k = carve(d_work, w, h);
-		hipError_t e = forest_of(cell_bytes, d_src, background, w, h, k, st);
+		const Work k = carve(d_work, w, h, frames, table_entries);
+		hipError_t e = forest_of(cell_bytes, d_src, background, w, h, frames, k, st);
 		if (e != hipSuccess)
 			return e;
-		hipLaunchKernelGGL(ccl_scan_kernel, dim3(1), dim3(kScanBlock), 0, st, k.block_roots, k.nb, d_count);
-		hipLaunchKernelGGL(ccl_labels_kernel, dim3((unsigned)k.nb), dim3(kBlock), 0, st, k.L, k.n, w, k.cnt, k.root_bits, k.wave_before, k.block_roots,
-						   d_dst, d_xy, d_area);
+		hipLaunchKernelGGL(ccl_scan_kernel, dim3((unsigned)frames), dim3(kScanBlock), 0, st, k.block_roots, k.nb, d_count, k.pitch);
+		hipLaunchKernelGGL(ccl_labels_kernel, dim3((unsigned)k.nb, (unsigned)frames), dim3(kBlock), 0, st, k.L, k.n, w, k.cnt, k.root_bits, k.wave_before,
+						   k.block_roots, d_dst, d_xy, d_area, k.pitch);
 		return hipGetLastError();
 	}
 
-	hipError_t launch_keep_largest_area(int cell_bytes, const void *d_src, const void *background, int w, int h, int *d_dst, int foreground,
-										int background_as_int, void *d_work, hipStream_t st)
+	hipError_t launch_keep_largest_areas(int cell_bytes, const void *d_src, const void *background, int w, int h, int frames, int *d_dst, int foreground,
+										 int background_as_int, void *d_work, hipStream_t st)
 	{
-		if (!geometry_ok(w, h) || !d_src || !background || !d_dst || !d_work)
+		if (!geometry_ok(w, h, frames) || !d_src || !background || !d_dst || !d_work)
 			return hipErrorInvalidValue;
-		const Work k = carve(d_work, w, h);
-		hipError_t e = forest_of(cell_bytes, d_src, background, w, h, k, st);
+		const Work k = carve(d_work, w, h, frames, 0);
+		hipError_t e = forest_of(cell_bytes, d_src, background, w, h, frames, k, st);
 		if (e != hipSuccess)
 			return e;
-		hipLaunchKernelGGL(ccl_largest_kernel, dim3((unsigned)k.nb), dim3(kBlock), 0, st, k.L, k.n, k.cnt, k.best);
-		hipLaunchKernelGGL(ccl_keep_kernel, dim3((unsigned)k.nb), dim3(kBlock), 0, st, k.L, k.n, k.best, foreground, background_as_int, d_dst);
+		hipLaunchKernelGGL(ccl_largest_kernel, dim3((unsigned)((k.nb + 3) / 4), (unsigned)frames), dim3(kBlock), 0, st, k.L, k.n, k.cnt, k.best, k.pitch);
+		hipLaunchKernelGGL(ccl_keep_kernel, dim3((unsigned)k.nb, (unsigned)frames), dim3(kBlock), 0, st, k.L, k.n, k.best, foreground, background_as_int, d_dst,
+						   k.pitch);
 		return hipGetLastError();
 	}
 } // namespace rir

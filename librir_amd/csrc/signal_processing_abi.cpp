@@ -819,38 +819,55 @@ namespace
 	}
 } // namespace
 
-RIR_EXPORT size_t rir_label_workspace_bytes(int w, int h) { return label_workspace_bytes(w, h); }
+RIR_EXPORT size_t rir_label_workspace_bytes(int w, int h) { return label_workspace_bytes(w, h, 1); }
+RIR_EXPORT size_t rir_label_workspace_bytes_batch(int w, int h, int nframes) { return label_workspace_bytes(w, h, nframes); }
 
-RIR_EXPORT int rir_label_image_device(int type, const void *d_src, int *d_dst, int w, int h, const void *background, double *d_xy, int *d_area,
-									  int *d_count, void *d_work, size_t work_bytes, void *stream)
+// A batch of images [nframes][h][w] in device memory, every one labelled on its own (five launches for the whole batch).
+RIR_EXPORT int rir_label_images_device(int type, const void *d_src, int *d_dst, int w, int h, int nframes, const void *background, double *d_xy,
+									   int *d_area, int table_entries, int *d_count, void *d_work, size_t work_bytes, void *stream)
 {
 	const int cell = cell_bytes_of(type);
 	if (cell == 0)
 		return -1;
 	if (!device_ready())
 		return -1;
-	const size_t need = label_workspace_bytes(w, h);
-	if (need == 0 || work_bytes < need || ((uintptr_t)d_work & 7))
+	const size_t need = label_workspace_bytes(w, h, nframes);
+	if (need == 0 || work_bytes < need || ((uintptr_t)d_work & 7) || table_entries < 1)
 		return -1;
-	return hip_ok(launch_label_image(cell, d_src, background, w, h, d_dst, d_xy, d_area, d_count, d_work, as_stream(stream)), "label_image") ? 0 : -1;
+	return hip_ok(launch_label_images(cell, d_src, background, w, h, nframes, d_dst, d_xy, d_area, table_entries, d_count, d_work, as_stream(stream)),
+				  "label_image")
+			   ? 0
+			   : -1;
+}
+RIR_EXPORT int rir_label_image_device(int type, const void *d_src, int *d_dst, int w, int h, const void *background, double *d_xy, int *d_area,
+									  int *d_count, void *d_work, size_t work_bytes, void *stream)
+{
+	if (w <= 0 || h <= 0 || (int64_t)w * h >= 0x7FFFFFFFLL)
+		return -1;
+	return rir_label_images_device(type, d_src, d_dst, w, h, 1, background, d_xy, d_area, w * h + 1, d_count, d_work, work_bytes, stream);
 }
 
-RIR_EXPORT int rir_keep_largest_area_device(int type, const void *d_src, int *d_dst, int w, int h, const void *background, int foreground,
-											void *d_work, size_t work_bytes, void *stream)
+RIR_EXPORT int rir_keep_largest_areas_device(int type, const void *d_src, int *d_dst, int w, int h, int nframes, const void *background, int foreground,
+											 void *d_work, size_t work_bytes, void *stream)
 {
 	const int cell = cell_bytes_of(type);
 	if (cell == 0 || !background)
 		return -1;
 	if (!device_ready())
 		return -1;
-	const size_t need = label_workspace_bytes(w, h);
+	const size_t need = label_workspace_bytes(w, h, nframes);
 	if (need == 0 || work_bytes < need || ((uintptr_t)d_work & 7))
 		return -1;
-	return hip_ok(launch_keep_largest_area(cell, d_src, background, w, h, d_dst, foreground, background_as_int(type, background), d_work,
-										   as_stream(stream)),
+	return hip_ok(launch_keep_largest_areas(cell, d_src, background, w, h, nframes, d_dst, foreground, background_as_int(type, background), d_work,
+											as_stream(stream)),
 				  "keep_largest_area")
 			   ? 0
 			   : -1;
+}
+RIR_EXPORT int rir_keep_largest_area_device(int type, const void *d_src, int *d_dst, int w, int h, const void *background, int foreground,
+											void *d_work, size_t work_bytes, void *stream)
+{
+	return rir_keep_largest_areas_device(type, d_src, d_dst, w, h, 1, background, foreground, d_work, work_bytes, stream);
 }
 
 // The image goes to device memory (the passes read it several times); the labels come back through the page-locked staging buffer
@@ -872,7 +889,7 @@ static int label_host(int type, void *src, int *dst, int w, int h, void *backgro
 		out_area[0] = 0;
 		return 1;
 	}
-	const size_t work = label_workspace_bytes(w, h);
+	const size_t work = label_workspace_bytes(w, h, 1);
 	if (work == 0)
 	{
 		log_error("label_image: image too large");

@@ -110,6 +110,10 @@ _lib.rir_median_filter_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int
 _lib.bad_pixels_destroy.argtypes = [ct.c_int]
 _lib.rir_label_workspace_bytes.argtypes = [ct.c_int, ct.c_int]
 _lib.rir_label_workspace_bytes.restype = ct.c_size_t
+_lib.rir_label_workspace_bytes_batch.argtypes = [ct.c_int, ct.c_int, ct.c_int]
+_lib.rir_label_workspace_bytes_batch.restype = ct.c_size_t
+_lib.rir_label_images_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, ct.c_int, _vp, _vp, ct.c_size_t, _vp]
+_lib.rir_keep_largest_areas_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, _vp, ct.c_int, _vp, ct.c_size_t, _vp]
 _lib.rir_label_image_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp, _vp, ct.c_size_t, _vp]
 _lib.rir_keep_largest_area_device.argtypes = [ct.c_int, _vp, _vp, ct.c_int, ct.c_int, _vp, ct.c_int, _vp, ct.c_size_t, _vp]
 _lib.rir_lossy_create.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_double, ct.c_int, ct.c_int, ct.c_int]
@@ -636,6 +640,47 @@ def keep_largest_area(image, background=0, foreground=1):
     dst = torch.empty((h, w), dtype=torch.int32, device=img.device)
     _check(_lib.rir_keep_largest_area_device(ord(ch), img.data_ptr(), dst.data_ptr(), w, h, back.ctypes.data, int(foreground), work.data_ptr(),
                                              work.numel() * 8, _stream()), "rir_keep_largest_area_device")
+    return dst
+
+
+def _label_batch_args(frames, background):
+    fr = _frames3(frames)
+    if not fr.is_cuda:
+        raise RuntimeError("label_images: frames on the device expected")
+    ch = _DTYPE_CHARS.get(fr.dtype)
+    if ch is None:
+        raise RuntimeError("label_images: unsupported dtype")
+    n, h, w = fr.shape
+    need = _lib.rir_label_workspace_bytes_batch(w, h, n)
+    if need == 0:
+        raise RuntimeError("label_images: geometry refused")
+    work = torch.empty(need // 8 + 1, dtype=torch.int64, device=fr.device)
+    back = np.zeros(1, dtype=_NP_OF[fr.dtype])
+    back[0] = background
+    return fr, ch, n, h, w, work, back
+
+
+def label_images(frames, background=0, table_entries=None):
+    """Connected components of every image of a batch (n, h, w) in device memory, five launches for the whole batch: (labels int32 (n, h, w),
+    areas (n, table_entries), first-pixel table (n, table_entries, 2), counts (n,)), on the device.  counts[i] = components of image i + 1;
+    a table with fewer entries than that holds the first ``table_entries`` of them (default: 1 024 entries, or h*w + 1 if that is less)."""
+    fr, ch, n, h, w, work, back = _label_batch_args(frames, background)
+    cap = min(1024, h * w + 1) if table_entries is None else int(table_entries)
+    dst = torch.empty((n, h, w), dtype=torch.int32, device=fr.device)
+    xy = torch.zeros((n, cap, 2), dtype=torch.float64, device=fr.device)
+    area = torch.zeros((n, cap), dtype=torch.int32, device=fr.device)
+    count = torch.zeros(n, dtype=torch.int32, device=fr.device)
+    _check(_lib.rir_label_images_device(ord(ch), fr.data_ptr(), dst.data_ptr(), w, h, n, back.ctypes.data, xy.data_ptr(), area.data_ptr(), cap,
+                                        count.data_ptr(), work.data_ptr(), work.numel() * 8, _stream()), "rir_label_images_device")
+    return dst, area, xy, count
+
+
+def keep_largest_areas(frames, background=0, foreground=1):
+    """``foreground`` on the largest component of every image of a batch (n, h, w), int(background) elsewhere; int32 (n, h, w) on the device."""
+    fr, ch, n, h, w, work, back = _label_batch_args(frames, background)
+    dst = torch.empty((n, h, w), dtype=torch.int32, device=fr.device)
+    _check(_lib.rir_keep_largest_areas_device(ord(ch), fr.data_ptr(), dst.data_ptr(), w, h, n, back.ctypes.data, int(foreground), work.data_ptr(),
+                                              work.numel() * 8, _stream()), "rir_keep_largest_areas_device")
     return dst
 
 

@@ -1,8 +1,8 @@
 """Soak of label_image / keep_largest_area against the oracle (GPU box):
     python tests/perf/soak_labelling.py [iterations]
 random geometries (1 .. 700 wide, 1 .. 600 high; now and then a 2000 x 1500 one), every cell type, images of every structure - blocks,
-noise, thin mazes with long winding components (the deep forests), stripes, NaN cells - through the C entry points and, every fourth
-time, the device layer."""
+noise, thin mazes with long winding components (the deep forests), stripes, NaN cells - through the C entry points, every fourth
+time the device layer and every eighth a batch of three images in one call."""
 import os
 import sys
 import time
@@ -65,6 +65,18 @@ for it in range(iters):
     fg = int(rng.integers(-4, 9))
     exp = O.label_image(img, bg)
     exp_keep = O.keep_largest_area(img, bg, fg)
+    if it % 8 == 5 and h * w < 200000:  # a batch on the device: this image, its mirror image and its negative mask, each against the oracle
+        batch = np.ascontiguousarray(np.stack([img, img[:, ::-1], (img == bg).astype(dt)]))
+        tb = torch.from_numpy(batch).cuda()
+        labs, areas, xys, counts = D.label_images(tb, bg, table_entries=h * w + 1)
+        keeps = D.keep_largest_areas(tb, bg, fg).cpu().numpy()
+        for k in range(3):
+            e = O.label_image(batch[k], bg)
+            c = int(counts[k])
+            if not (c == e[1].size and np.array_equal(labs[k].cpu().numpy(), e[0]) and np.array_equal(areas[k, :c].cpu().numpy(), e[1])
+                    and np.array_equal(xys[k, :c].cpu().numpy(), e[2]) and np.array_equal(keeps[k], O.keep_largest_area(batch[k], bg, fg))):
+                fails += 1
+                print("DIFFERS (batch, image %d): iteration %d, %d x %d, %s, kind %d" % (k, it, h, w, dt, kind), flush=True)
     if it % 4 == 3:
         t = torch.from_numpy(img).cuda()
         got = tuple(x.cpu().numpy() for x in D.label_image(t, bg))

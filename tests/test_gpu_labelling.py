@@ -202,3 +202,34 @@ def test_rate_floor_of_the_labelling(dev):
     assert out.shape == img.shape
     assert best_dev < 100e-6, "keep_largest_area on the device: %.1f us" % (best_dev * 1e6)
     assert best_abi < 400e-6, "label_image per host image: %.1f us" % (best_abi * 1e6)
+
+
+def test_batches_of_images_on_the_device(dev, oracle):
+    """every image of a batch labelled on its own, five launches for all of them: each against the oracle; tables with less room than an
+    image has components keep their first entries and the count says how many there are"""
+    import torch
+
+    rng = np.random.default_rng(21)
+    for dt, (n, h, w) in ((np.uint16, (9, 67, 131)), (np.float32, (5, 40, 64)), (np.uint8, (33, 20, 70)), (np.int64, (3, 128, 257))):
+        frames = np.stack([np.kron(rng.integers(0, 4, (h // 4 + 1, w // 4 + 1)), np.ones((4, 4), dtype=np.int64))[:h, :w] for _ in range(n)])
+        frames[1] = 0  # an image without a component
+        frames[2] = 3  # one flat component
+        frames = frames.astype(dt)
+        if np.dtype(dt).kind == "f":
+            frames[rng.random(frames.shape) < 0.01] = np.nan
+        t = torch.from_numpy(frames).cuda()
+        lab, area, xy, count = dev.label_images(t, 0, table_entries=h * w + 1)
+        keep = dev.keep_largest_areas(t, 0, 6).cpu().numpy()
+        lab, area, xy, count = lab.cpu().numpy(), area.cpu().numpy(), xy.cpu().numpy(), count.cpu().numpy()
+        for i in range(n):
+            exp = oracle.label_image(frames[i], 0)
+            k = int(count[i])
+            assert k == exp[1].size and np.array_equal(lab[i], exp[0]) and np.array_equal(area[i, :k], exp[1]) and np.array_equal(xy[i, :k], exp[2]), (dt, i)
+            assert np.array_equal(keep[i], oracle.keep_largest_area(frames[i], 0, 6)), (dt, i)
+        small = 4
+        lab2, area2, xy2, count2 = dev.label_images(t, 0, table_entries=small)
+        assert np.array_equal(lab2.cpu().numpy(), lab) and np.array_equal(count2.cpu().numpy(), count)
+        for i in range(n):
+            k = min(int(count[i]), small)
+            assert np.array_equal(area2[i, :k].cpu().numpy(), area[i, :k]) and np.array_equal(xy2[i, :k].cpu().numpy(), xy[i, :k])
+            assert not area2[i, k:].any()  # nothing written past what there is room for
