@@ -104,3 +104,22 @@ for name, ma, mb in (("low half / high half", [0xFFFFFFFF] * 4 + [0] * 4, [0] * 
     c = wall(lambda: (enc(ra, f_pin, b_enc), dec(rb, b_dec, o_pin)))
     print("masked streams, %-26s: encode %.0f us, decode %.0f us, both at once %.0f us" % (name, a, b, c), flush=True)
 assert np.array_equal(o_pin.numpy(), fr) and int(err.item()) == 0
+
+# a kernel's host traffic one way, a copy call the other way
+hip.hipMemcpyAsync.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int, ct.c_void_p]
+
+
+def copy_down(stream):
+    assert hip.hipMemcpyAsync(o_pin.data_ptr(), o_dev.data_ptr(), raw, 2, ct.c_void_p(stream.cuda_stream)) == 0  # hipMemcpyDeviceToHost
+
+
+def copy_up(stream):
+    assert hip.hipMemcpyAsync(f_dev.data_ptr(), f_pin.data_ptr(), raw, 1, ct.c_void_p(stream.cuda_stream)) == 0  # hipMemcpyHostToDevice
+
+
+a, b = wall(lambda: enc(s1, f_pin, b_enc)), wall(lambda: copy_down(s2))
+c = wall(lambda: (enc(s1, f_pin, b_enc), copy_down(s2)))
+print("encode from host %.0f us + hipMemcpyAsync down %.0f us: together %.0f us" % (a, b, c), flush=True)
+a, b = wall(lambda: copy_up(s1)), wall(lambda: dec(s2, b_dec, o_pin))
+c = wall(lambda: (copy_up(s1), dec(s2, b_dec, o_pin)))
+print("hipMemcpyAsync up %.0f us + decode to host %.0f us: together %.0f us" % (a, b, c), flush=True)
