@@ -100,6 +100,13 @@ extern "C"
 	int correct_PCR_file(const char *filename, int width, int height, int freq);				/* video_io.h:319 */
 	int change_hcc_external_blackbody_temperature(const char *filename, float temperature);	/* video_io.h:321 (always -1 here) */
 
+	/* ---- extension over the reference's one-image calls (prefix rir_) ----
+	 * Images first .. first + count - 1 of a recording of this library re-recorded into a saver of the same geometry without leaving the
+	 * device (what IRMovie.to_h264 / split_rush do image by image through load_image, video_io.h:147, and h264_add_image_lossless, :268):
+	 * per-image attributes travel with the images when keep_attributes != 0, timestamps_ns[count] are the new time stamps.  Returns count; -2 when this way is not
+	 * open (another kind of file or geometry, a read-back filter switched on) and the caller goes image by image; -1 on failure. */
+	int rir_transcode_images(int camera, int saver, int first, int count, const int64_t *timestamps_ns, int keep_attributes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <condition_variable>
 #include <mutex>
@@ -1167,6 +1168,35 @@ namespace
 				return false;
 			uploaded = pending + 1;
 			return frame_added(ts, attrs);
+		}
+
+		// a run of frames that lie one behind the other in device memory (a decoded chunk of a loader: rir_transcode_images): as many as the
+		// chunk being assembled still takes, in one device-to-device copy.  -> the number taken (>= 1), 0 on failure
+		int add_images_device(const unsigned short *d_imgs, int n, const int64_t *ts, const AttrMap *attrs)
+		{
+			if (!d_imgs || n <= 0 || !usable() || !open() || !run_deferred_loss())
+				return 0;
+			if (pending >= chunk_gop && !flush_chunk())
+				return 0;
+			const size_t fbytes = (size_t)width * height * 2;
+			const int take = std::min(n, chunk_gop - pending);
+			if (!upload_staged(pending)) // frames staged on the host before these go first: `uploaded` is a prefix of the chunk
+				return 0;
+			if (!hip_ok(hipMemcpyAsync(cc.d_frames.as<char>() + (size_t)pending * fbytes, d_imgs, (size_t)take * fbytes, hipMemcpyDeviceToDevice,
+									   default_stream()),
+						"D2D frames"))
+				return 0;
+			uploaded = pending + take;
+			for (int k = 0; k < take; ++k)
+			{
+				++pending;
+				++nframes;
+				times.push_back(ts[k]);
+				frame_attrs.push_back(attrs[k]);
+			}
+			if (pending == chunk_gop && !flush_chunk())
+				return 0;
+			return take;
 		}
 
 		bool frame_added(int64_t ts, const AttrMap &attrs)
@@ -2403,6 +2433,67 @@ RIR_EXPORT int load_image(int cam, int pos, int calibration, unsigned short *pix
 		return -1;
 	}
 	return guarded("load_image", -1, [&] { return c->read_image(pos, calibration, pixels) ? 0 : -1; });
+}
+
+// Extension: images first .. first + count - 1 of a recording of this library go into a saver of the same geometry WITHOUT leaving the device:
+// a chunk is decoded into device memory, its frames are copied device-to-device into the chunk the saver assembles, with their per-image
+// attributes (keep_attributes != 0; else without any) and the given time stamps (IRMovie.to_h264 / split_rush: 6 us an image instead of the 30 of reading each image into host
+// memory and recording it from there).  Returns `count`; -2 when this way is not open - another kind of file, another geometry, a
+// read-back filter switched on (the images would have to pass through it) - and the caller goes image by image; -1 on failure.
+RIR_EXPORT int rir_transcode_images(int cam, int file, int first, int count, const int64_t *timestamps_ns, int keep_attributes)
+{
+	auto c = camera(cam);
+	auto s = saver(file);
+	if (!c || !s)
+	{
+		log_error("rir_transcode_images: NULL camera or saver");
+		return -1;
+	}
+	if (first < 0 || count < 0 || (count > 0 && !timestamps_ns) || (int64_t)first + count > c->count)
+		return -1;
+	return guarded("rir_transcode_images", -1, [&] {
+		const bool filtered = (c->bp_enabled && c->bp_handle > 0 && c->global_attrs.count("Type") == 0) || (c->motion_enabled && !c->shifts.empty());
+		if (c->kind != CameraObject::RIRB || c->width != s->width || c->height != s->height || filtered)
+			return -2;
+		const size_t npx = (size_t)c->width * c->height;
+		const bool diag = std::getenv("RIR_TRANSCODE_DIAG") != nullptr;
+		const std::vector<AttrMap> none(keep_attributes ? 0 : (size_t)std::max(1, (int)c->hd.gop)); // (a run never exceeds a chunk of the source)
+		double t_dec = 0, t_add = 0;
+		auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+		int done = 0;
+		while (done < count)
+		{
+			const int pos = first + done;
+			const int ch = c->chunk_of(pos);
+			if (ch < 0)
+				return -1;
+			const int run = std::min(count - done, (int)(c->index[ch].first_frame + c->index[ch].nframes) - pos);
+			const double t0 = diag ? now() : 0;
+			const unsigned short *d = c->device_frame(pos);
+			if (!d)
+				return -1;
+			const double t1 = diag ? now() : 0;
+			for (int k = 0; k < run;)
+			{
+				const int took = s->add_images_device(d + (size_t)k * npx, run - k, timestamps_ns + done + k,
+													  keep_attributes ? &c->frame_attrs[(size_t)pos + k] : none.data());
+				if (took <= 0)
+					return -1;
+				k += took;
+			}
+			if (diag)
+				t_dec += t1 - t0, t_add += now() - t1;
+			done += run;
+		}
+		if (diag)
+			fprintf(stderr, "rir_transcode_images: %d images, chunks into device memory %.0f us, into the saver %.0f us\n", count, t_dec, t_add);
+		if (count > 0)
+		{
+			c->last_pos = first + count - 1;
+			c->last_raw_pos = -1;
+		}
+		return count;
+	});
 }
 
 // video_io.cpp:377-391: the uint16 image cast to float (IRVideoLoader.h:109-117)

@@ -416,13 +416,19 @@ class IRMovie(object):
             saver.set_global_attributes(global_attrs)
             saver.set_parameter("threads", cthreads)
             saver.set_parameter("codec", "h264")
-            # (Measured and not kept: a thread reading ahead of the recording one.  Image by image 33-70 us an image, in stacks of sixteen
-            # through bulk library calls 34-37 us - against 30-33 us for one thing after the other as below.  Reading alone is 17 us an
-            # image, recording alone 17-19: the two do not overlap, because the kernels' own traffic over the link does not - a chunk's
-            # encode reading its frames from host memory (705 us) and a chunk's decode writing its frames there (660 us) take 1 210-1 270 us
-            # together on two streams, with or without disjoint compute-unit masks, while the copy engines' transfers up and down do
-            # overlap (587 + 585 -> 686 us), and so do a copy call upwards and the decode's writes (581 + 660 -> 812): it is the kernels'
-            # reads of host memory that do not share the link.  tests/perf/link_duplex_probe.py, profiles/r05_link_duplex.txt.)
+            # A recording of this library goes from its loader to the saver without leaving the device (chunks decoded into device memory,
+            # their images copied device to device into the chunk the saver assembles, attributes with them): 6 us an image.  Anything
+            # else - raw files, read-back filters switched on, attributes given per image - goes image by image through host memory.
+            if frame_attributes is None and _abi.transcode_images(self.handle, saver.handle, start_img, count,
+                                                                  [int(stamps[pos]) for pos in range(start_img, start_img + count)]):
+                return
+            # (Measured and not kept for that path: a thread reading ahead of the recording one.  Image by image 33-70 us an image, in
+            # stacks of sixteen through bulk library calls 34-37 us - against 30-33 us for one thing after the other as below.  Reading alone
+            # is 17 us an image, recording alone 17-19: the two do not overlap, because the kernels' own traffic over the link does not - a
+            # chunk's encode reading its frames from host memory (705 us) and a chunk's decode writing its frames there (660 us) take
+            # 1 210-1 270 us together on two streams, with or without disjoint compute-unit masks, while the copy engines' transfers up and
+            # down do overlap (587 + 585 -> 686 us), and so do a copy call upwards and the decode's writes (581 + 660 -> 812): it is the
+            # kernels' reads of host memory that do not share the link.  tests/perf/link_duplex_probe.py, profiles/r05_link_duplex.txt.)
             for written, pos in enumerate(range(start_img, start_img + count)):
                 image = self.load_pos(pos, 0)
                 saver.add_image(image, stamps[pos], attributes=self.frame_attributes if frame_attributes is None else frame_attributes[written])

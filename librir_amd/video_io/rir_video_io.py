@@ -20,6 +20,7 @@ _ip = ct.POINTER(ct.c_int)
 _v.open_camera_file.argtypes = [ct.c_char_p, _ip]
 _v.open_camera_from_memory.argtypes = [_vp, ct.c_int64, _ip]
 _v.video_file_format.argtypes = [ct.c_char_p]
+_v.rir_transcode_images.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_void_p, ct.c_int]
 _v.get_image_time.argtypes = [ct.c_int, ct.c_int, ct.POINTER(ct.c_int64)]
 _v.get_image_size.argtypes = [ct.c_int, _ip, _ip]
 _v.get_filename.argtypes = [ct.c_int, ct.c_char_p]
@@ -360,6 +361,21 @@ def _add(fn, name, saver, image, timestamp, attributes):
 
 def h264_add_image_lossless(saver, image, timestamp, attributes=None):
     _add(_v.h264_add_image_lossless, "h264_add_image_lossless", saver, image, timestamp, attributes)
+
+
+def transcode_images(camera, saver, first, count, timestamps_ns, keep_attributes=True):
+    """Extension (``rir_transcode_images``): images ``first .. first + count - 1`` of a recording of this library re-recorded into ``saver``
+    (same geometry) without leaving the device, with their per-image attributes unless ``keep_attributes`` is false.  True when done; False when this way is not open (another
+    kind of file or geometry, a read-back filter switched on) - the caller then goes image by image."""
+    stamps = np.ascontiguousarray(timestamps_ns, dtype=np.int64)
+    if stamps.shape != (int(count),):
+        raise RuntimeError("transcode_images: one time stamp per image expected")
+    r = _v.rir_transcode_images(camera, saver, int(first), int(count), stamps.ctypes.data, int(bool(keep_attributes)))
+    if r == -2:
+        return False
+    if r != count:
+        _fail("transcode_images")
+    return True
 
 
 def h264_add_image_lossy(saver, image_DL, timestamp, attributes=None):

@@ -4,6 +4,7 @@
 import logging
 from pathlib import Path
 
+from . import rir_video_io as _abi
 from .IRMovie import IRMovie
 from .IRSaver import IRSaver
 
@@ -28,8 +29,11 @@ def split_rush(filename, index=None, step=30, dest_folder=None):
             target.parent.mkdir(exist_ok=True, parents=True)
             if not target.exists():
                 with IRSaver(target, width=width, height=height) as saver:
-                    for k, image in enumerate(movie[first:first + step]):
-                        saver.add_image(image, k * 20e6)
+                    many = min(step, movie.images - first)
+                    # (a recording of this library is cut on the device; anything else image by image)
+                    if not _abi.transcode_images(movie.handle, saver.handle, first, many, [int(k * 20e6) for k in range(many)], keep_attributes=False):
+                        for k, image in enumerate(movie[first:first + step]):
+                            saver.add_image(image, k * 20e6)
             pieces.append(target)
     return pieces
 

@@ -621,3 +621,99 @@ def test_rate_floor_of_whole_movie_reads(tmp_path):
             assert data.shape == fr.shape
             del data
     assert best < 40e-6, "IRMovie.data: %.1f us an image" % (best * 1e6)
+
+
+def test_to_h264_of_a_recording_stays_on_the_device(tmp_path):
+    """IRMovie.to_h264 of one of this library's recordings hands decoded chunks to the saver device to device (rir_transcode_images): the
+    copy holds the same images, per-image attributes and time stamps as the image-by-image way, across chunk boundaries of both files,
+    for a part of the movie, for a bounded-loss recording whose minimum was subtracted; with a read-back filter switched on the
+    image-by-image way is taken and the images are the filtered ones"""
+    rng = np.random.default_rng(17)
+    n, h, w = 61, 40, 72
+    fr = s1_noisy_background(n, h, w, seed=5)
+    src = tmp_path / "src.h264"
+    with IRSaver(str(src), w, h, h) as s:
+        s.set_parameter("GOP", 7)  # source chunks of 7, destination chunks of 50 (and of 9 below)
+        s.set_global_attributes({"Campaign": "C5", "Blob": bytes(range(50))})
+        for i in range(n):
+            s.add_image(fr[i], 1000 * i + 3, attributes={"idx": str(i), "odd": b"\x00\x01"} if i % 3 else {})
+    with IRMovie.from_filename(src) as mov:
+        mov[5]  # (a read before: the loader holds a chunk, on the host only)
+        with pytest.raises(RuntimeError):  # no such saver
+            rv.transcode_images(mov.handle, 0, 0, 0, np.zeros(0, np.int64))
+        whole, part = tmp_path / "whole.h264", tmp_path / "part.h264"
+        mov.to_h264(whole)
+        mov.to_h264(part, start_img=5, count=40)
+        for dst, first, count in ((whole, 0, n), (part, 5, 40)):
+            with IRMovie.from_filename(dst) as out:
+                assert out.images == count and np.array_equal(out.data, fr[first:first + count])
+                assert np.allclose(out.timestamps, mov.timestamps[first:first + count], rtol=0, atol=1e-12)
+                assert out.attributes["Campaign"] == b"C5" and out.attributes["Blob"] == bytes(range(50))
+                for k in (0, 1, 2, 7, count - 1):
+                    out[k]
+                    i = first + k
+                    exp = {"idx": str(i).encode(), "odd": b"\x00\x01"} if i % 3 else {}
+                    assert out.frame_attributes == exp, (dst.name, k)
+        # given time stamps, a destination with small chunks: still the device's way
+        small = tmp_path / "small.h264"
+        stamps = [7 * i for i in range(n)]
+        rows, cols = mov.image_size
+        with IRSaver(str(small), cols, rows, rows) as s2:
+            s2.set_parameter("GOP", 9)
+            assert rv.transcode_images(mov.handle, s2.handle, 2, 30, stamps[2:32]) is True
+            s2.add_image(fr[0], 999)  # and the saver goes on with images from the host
+        with IRMovie.from_filename(small) as out:
+            assert out.images == 31 and np.array_equal(out.data[:30], fr[2:32]) and np.array_equal(out[30], fr[0])
+            assert [rv.get_image_time(out.handle, k) for k in (0, 1, 29, 30)] == [14, 21, 217, 999]
+        # without the attributes (what split_rush wants)
+        bare = tmp_path / "bare.h264"
+        with IRSaver(str(bare), cols, rows, rows) as s6:
+            assert rv.transcode_images(mov.handle, s6.handle, 0, 12, stamps[:12], keep_attributes=False) is True
+        with IRMovie.from_filename(bare) as out:
+            assert np.array_equal(out.data, fr[:12])
+            for k in (1, 4, 11):
+                out[k]
+                assert out.frame_attributes == {}
+        from librir_amd.video_io import split_rush
+
+        pieces = split_rush(src, step=20, dest_folder=tmp_path / "pieces")
+        assert len(pieces) == 3
+        for j, piece in enumerate(pieces):
+            with IRMovie.from_filename(piece) as out:
+                assert np.array_equal(out.data, fr[20 * j:20 * j + 20]) and np.allclose(out.timestamps, np.arange(20) * 0.02, rtol=0, atol=1e-12)
+                out[1]
+                assert out.frame_attributes == {}
+        # a read-back filter switched on: the images must pass through it, image by image
+        mov.bad_pixels_correction = True
+        filtered = tmp_path / "filtered.h264"
+        with IRSaver(str(filtered), cols, rows, rows) as s3:
+            assert rv.transcode_images(mov.handle, s3.handle, 0, 5, stamps[:5]) is False
+            s3.add_image(fr[0], 0)
+        expect = np.stack([mov[i] for i in range(n)])
+        mov.to_h264(filtered)
+        with IRMovie.from_filename(filtered) as out:
+            assert np.array_equal(out.data, expect)
+        mov.bad_pixels_correction = False
+        # another geometry: not this way
+        with IRSaver(str(tmp_path / "other.h264"), cols + 8, rows, rows) as s4:
+            assert rv.transcode_images(mov.handle, s4.handle, 0, 5, stamps[:5]) is False
+            s4.add_image(np.zeros((rows, cols + 8), np.uint16), 0)
+        with pytest.raises(RuntimeError):
+            with IRSaver(str(tmp_path / "bad.h264"), cols, rows, rows) as s5:
+                try:
+                    rv.transcode_images(mov.handle, s5.handle, n - 2, 5, stamps[:5])  # past the end
+                finally:
+                    s5.add_image(fr[0], 0)
+    # a bounded-loss recording with its minimum subtracted: the copy reads back what the original reads back
+    lossy = tmp_path / "lossy.h264"
+    with IRSaver(str(lossy), w, h, h - 3) as s:
+        for k, v in (("lowValueError", 3), ("highValueError", 3), ("stdFactor", 0), ("runningAverage", 4), ("subtractMin", 1), ("GOP", 6)):
+            s.set_parameter(k, v)
+        for i in range(30):
+            s.add_image_lossy(fr[i], i)
+    with IRMovie.from_filename(lossy) as mov:
+        original = mov.data
+        mov.to_h264(tmp_path / "lossy_copy.h264")
+    with IRMovie.from_filename(tmp_path / "lossy_copy.h264") as out:
+        assert np.array_equal(out.data, original)
+        assert "MIN_T" not in out.attributes
