@@ -717,3 +717,59 @@ def test_to_h264_of_a_recording_stays_on_the_device(tmp_path):
     with IRMovie.from_filename(tmp_path / "lossy_copy.h264") as out:
         assert np.array_equal(out.data, original)
         assert "MIN_T" not in out.attributes
+
+
+def test_sequential_and_scattered_filtered_reads_agree(tmp_path, oracle):
+    """with a read-back filter switched on, a reader that goes image after image gets its images from chunks filtered as a whole, one that
+    jumps about gets each image filtered on its own: the same images (and the oracle's), through changes of the filters' settings under way"""
+    n, h, w, gop = 45, 37, 80, 8
+    fr = inject_bad_pixels(s1_noisy_background(n, h, w, seed=9), 10)
+    p = tmp_path / "m.h264"
+    with IRSaver(str(p), w, h, h) as s:
+        s.set_parameter("GOP", gop)
+        for i in range(n):
+            s.add_image(fr[i], i * 1000)
+
+    def shifts_file(name, fx, fy):
+        path = tmp_path / name
+        with open(path, "w") as f:
+            f.write("\tx-axis translations\ty-axis translations\tConfidence level\n")
+            for i in range(n):
+                f.write("%d\t%r\t%r\t0.9\n" % (i, fx(i), fy(i)))
+        return path
+
+    reg_a = shifts_file("a.tsv", lambda i: 0.25 * (i % 7), lambda i: -0.5 * (i % 3))
+    reg_b = shifts_file("b.tsv", lambda i: -1.5 + 0.1 * i, lambda i: 0.75)
+    order = np.random.default_rng(2).permutation(n)
+    with IRMovie.from_filename(p) as seq, IRMovie.from_filename(p) as jump:
+        for bp, reg in ((True, None), (False, reg_a), (True, reg_a), (True, reg_b), (False, None)):
+            for mov in (seq, jump):
+                mov.bad_pixels_correction = bp
+                if reg is not None:
+                    mov.registration_file = reg
+                mov.registration = reg is not None
+            scattered = {int(i): jump[int(i)].copy() for i in order}
+            for i in range(n):
+                assert np.array_equal(seq[i], scattered[i]), (bp, reg, i)
+            # under way: the other shifts from the middle of a chunk on, then the repair switched off
+            if reg is reg_a and bp:
+                for i in range(12):
+                    seq[i]
+                seq.registration_file = reg_b
+                jump.registration_file = reg_b
+                for i in range(12, 30):
+                    assert np.array_equal(seq[i], jump[i]), i
+                seq.bad_pixels_correction = False
+                jump.bad_pixels_correction = False
+                for i in range(30, n):
+                    assert np.array_equal(seq[i], jump[i]), i
+        assert np.array_equal(seq.data, fr)  # filters off again: the recording itself
+    # against the oracle: repair, then motion removal on rows < h - 3
+    xy = oracle.bad_pixels_detect(fr[0][:h - 3])
+    with IRMovie.from_filename(p) as mov:
+        mov.bad_pixels_correction = True
+        mov.registration_file = reg_a
+        mov.registration = True
+        for i in range(n):
+            exp = oracle.remove_motion(oracle.remove_bad_pixels(fr[i], xy, rows=h - 3), 0.25 * (i % 7), -0.5 * (i % 3), rows=h - 3)
+            assert np.array_equal(mov[i], exp), i
