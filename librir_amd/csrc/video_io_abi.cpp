@@ -121,6 +121,18 @@ namespace
 	static_assert(sizeof(ZHeader) == 128 && sizeof(ZTrigger) == 128, "layout");
 	static_assert(sizeof(FtypBox) == 32 && sizeof(FileHeader) == 64 && sizeof(ChunkHeader) == 32 && sizeof(PcrHeader) == 1024, "layout");
 
+	// ZFile: zstd works on one thread per image (0.25-0.5 ms for a 640x512 image either way).  A loader read image after image and a writer
+	// decompress / compress several images at once on threads of their own; RIR_ZFILE_THREADS: how many (default 8, 0: every image in the
+	// call that brings or asks for it).
+	int zfile_threads()
+	{
+		static const int n = [] {
+			const char *e = std::getenv("RIR_ZFILE_THREADS");
+			return e ? std::max(0, std::min(16, std::atoi(e))) : 8;
+		}();
+		return n;
+	}
+
 	bool file_exists(const char *name)
 	{
 		struct stat st;
@@ -1303,6 +1315,24 @@ namespace
 		// ZFile: record offsets, scratch for one compressed frame
 		std::vector<int64_t> z_positions;
 		std::vector<char> z_buf;
+		// ZFile, a reader that goes image after image: the next images are decompressed ahead by a few threads of this object (zstd is one
+		// thread per image: 0.45-0.8 ms for a 640x512 image, the whole cost of such a read).  A slot = one image being / having been
+		// decompressed ahead; everything under z_mu.
+		struct ZSlot
+		{
+			int pos = -1; // the image this slot is for (-1: free)
+			bool busy = false, ready = false, failed = false;
+			std::vector<unsigned short> img;
+			std::vector<char> comp;
+		};
+		static constexpr int kZSlots = 12;
+		ZSlot z_slots[kZSlots];
+		std::mutex z_mu;
+		std::condition_variable z_work, z_done;
+		std::vector<int> z_todo;
+		std::vector<std::thread> z_threads;
+		bool z_quit = false;
+		int z_last = -2, z_seq = 0;
 		// RIRB
 		FileHeader hd{};
 		std::vector<IndexEntry> index;
@@ -1350,6 +1380,7 @@ namespace
 		~CameraObject() override
 		{
 			stop_prefetch();
+			stop_zfile_ahead();
 			if (fp)
 				std::fclose(fp);
 			if (bp_handle > 0)
@@ -1647,16 +1678,125 @@ namespace
 		}
 
 		// one ZFile record -> one frame (ZFile.cpp:544-629)
-		bool read_zfile(int pos, unsigned short *out)
+		// one image of a ZFile, decompressed into `out` (npx cells) through `comp` (any thread: pread and one-shot zstd keep no state here)
+		bool zfile_image(int pos, unsigned short *out, std::vector<char> &comp)
 		{
 			const size_t npx = (size_t)width * height;
 			const uint64_t off = (uint64_t)z_positions[pos];
 			uint32_t csize = 0;
-			if (!read_at(off + 8, &csize, 4) || csize > z_buf.size() || !read_at(off + 12, z_buf.data(), csize))
+			if (!read_at(off + 8, &csize, 4) || csize > comp.size() || !read_at(off + 12, comp.data(), csize))
 				return false;
 			const ZstdApi &z = ZstdApi::get();
-			const size_t r = z.decompress(out, npx * 2, z_buf.data(), csize);
+			const size_t r = z.decompress(out, npx * 2, comp.data(), csize);
 			return !z.isError(r) && r == npx * 2;
+		}
+		void zfile_ahead_loop()
+		{
+			std::unique_lock<std::mutex> lk(z_mu);
+			for (;;)
+			{
+				z_work.wait(lk, [&] { return z_quit || !z_todo.empty(); });
+				if (z_quit)
+					return;
+				ZSlot &sl = z_slots[z_todo.front()];
+				z_todo.erase(z_todo.begin());
+				const int pos = sl.pos;
+				lk.unlock();
+				if (sl.img.size() != (size_t)width * height)
+					sl.img.resize((size_t)width * height);
+				if (sl.comp.size() != z_buf.size())
+					sl.comp.resize(z_buf.size());
+				const bool ok = zfile_image(pos, sl.img.data(), sl.comp);
+				lk.lock();
+				sl.busy = false, sl.ready = ok, sl.failed = !ok;
+				z_done.notify_all();
+			}
+		}
+		void stop_zfile_ahead()
+		{
+			{
+				std::unique_lock<std::mutex> lk(z_mu);
+				z_quit = true;
+			}
+			z_work.notify_all();
+			for (auto &t : z_threads)
+				if (t.joinable())
+					t.join();
+			z_threads.clear();
+		}
+		bool read_zfile(int pos, unsigned short *out)
+		{
+			const size_t npx = (size_t)width * height;
+			bool served = false, found = false;
+			{
+				std::unique_lock<std::mutex> lk(z_mu);
+				for (ZSlot &sl : z_slots)
+					if (sl.pos == pos)
+					{ // decompressed ahead, or on its way
+						found = true;
+						z_done.wait(lk, [&] { return !sl.busy; });
+						if (sl.ready)
+						{
+							lk.unlock();
+							host_copy(out, sl.img.data(), npx * 2); // (the slot is this image's until it is freed below: nobody else touches it)
+							lk.lock();
+							served = true;
+						}
+						sl.pos = -1, sl.ready = sl.failed = false;
+						break;
+					}
+			}
+			if (!served && !zfile_image(pos, out, z_buf))
+				return false;
+			(void)found;
+			// the images after this one, once the reader has shown that it goes image after image
+			z_seq = (pos == z_last + 1) ? z_seq + 1 : 0;
+			z_last = pos;
+			const int ahead_threads = zfile_threads();
+			if (ahead_threads == 0)
+				return true;
+			std::unique_lock<std::mutex> lk(z_mu);
+			if (z_seq < 2)
+			{ // a reader that jumps about: what was made ahead is dropped (slots still being worked on free themselves when asked for - or never)
+				for (ZSlot &sl : z_slots)
+					if (!sl.busy && sl.pos >= 0)
+						sl.pos = -1, sl.ready = sl.failed = false;
+				for (size_t i = 0; i < z_todo.size();)
+				{
+					z_slots[z_todo[i]].pos = -1, z_slots[z_todo[i]].busy = false;
+					z_todo.erase(z_todo.begin() + (std::ptrdiff_t)i);
+				}
+				return true;
+			}
+			bool queued = false;
+			for (int p = pos + 1; p < count && p <= pos + kZSlots; ++p)
+			{
+				bool there = false;
+				for (const ZSlot &sl : z_slots)
+					there = there || sl.pos == p;
+				if (there)
+					continue;
+				ZSlot *free_slot = nullptr;
+				for (ZSlot &sl : z_slots)
+					if (!sl.busy && (sl.pos < 0 || sl.pos <= pos || sl.pos > pos + kZSlots)) // free, an image the reader has passed, or one far from here
+					{
+						free_slot = &sl;
+						break;
+					}
+				if (!free_slot)
+					break;
+				free_slot->pos = p, free_slot->busy = true, free_slot->ready = free_slot->failed = false;
+				z_todo.push_back((int)(free_slot - z_slots));
+				queued = true;
+			}
+			if (queued)
+			{
+				if (z_threads.empty())
+					for (int t = 0; t < ahead_threads; ++t)
+						z_threads.emplace_back([this] { zfile_ahead_loop(); });
+				z_work.notify_all();
+			}
+			return true;
 		}
 
 		// Chunk c of the file -> ctx.d_frames (decoded, MIN_T added back) on stream st; with to_host the decoded images follow
@@ -2209,35 +2349,153 @@ namespace
 			buf.resize(z.compressBound((size_t)width * height * 2));
 			return std::fwrite(&zh, sizeof(zh), 1, fp) == 1 && std::fwrite(&zt, sizeof(zt), 1, fp) == 1;
 		}
-		bool add(const unsigned short *img, int64_t timestamp)
+		// Images are compressed on threads of this object, several at once, and go to the file in the order they came (a record's place in the
+		// file depends on the sizes before it): image_write copies the image into a slot and returns; the calls that follow, and close, write
+		// what has been compressed in order.  An image that could not be compressed or written fails the call that finds it out, and
+		// every call after it.
+		struct Slot
 		{
-			if (!fp || !img)
-				return false;
+			enum State
+			{
+				FREE,
+				QUEUED,
+				DONE,
+				FAILED
+			} state = FREE;
+			int64_t ts = 0;
+			size_t csize = 0;
+			std::vector<unsigned short> img;
+			std::vector<char> comp;
+		};
+		static constexpr int kSlots = 12;
+		Slot slots[kSlots];
+		uint64_t seq_in = 0, seq_out = 0; // images taken / written
+		bool broken = false;
+		std::mutex mu;
+		std::condition_variable work, done;
+		std::vector<int> todo;
+		std::vector<std::thread> threads;
+		bool quit = false;
+
+		void compress_loop()
+		{
 			const ZstdApi &z = ZstdApi::get();
-			const size_t c = z.compress(buf.data(), buf.size(), img, (size_t)zt.data_size_x * zt.data_size_y * 2, clevel);
-			if (z.isError(c))
-				return false;
+			std::unique_lock<std::mutex> lk(mu);
+			for (;;)
+			{
+				work.wait(lk, [&] { return quit || !todo.empty(); });
+				if (todo.empty())
+					return; // (quit, and nothing left to do)
+				Slot &sl = slots[todo.front()];
+				todo.erase(todo.begin());
+				lk.unlock();
+				const size_t c = z.compress(sl.comp.data(), sl.comp.size(), sl.img.data(), sl.img.size() * 2, clevel);
+				lk.lock();
+				sl.csize = c;
+				sl.state = z.isError(c) ? Slot::FAILED : Slot::DONE;
+				done.notify_all();
+			}
+		}
+		bool write_record(int64_t timestamp, const void *data, size_t c)
+		{
 			const int64_t pos = (int64_t)ftello(fp);
 			const uint32_t csize = (uint32_t)c;
-			if (std::fwrite(&timestamp, 8, 1, fp) != 1 || std::fwrite(&csize, 4, 1, fp) != 1 || std::fwrite(buf.data(), 1, c, fp) != c)
+			if (std::fwrite(&timestamp, 8, 1, fp) != 1 || std::fwrite(&csize, 4, 1, fp) != 1 || std::fwrite(data, 1, c, fp) != c)
 				return false;
 			zt.samples++;
 			times.push_back(timestamp);
 			positions.push_back(pos);
 			return true;
 		}
+		// writes the images that are compressed, in order, as far as they go (all: waits for every image taken so far); mu held
+		bool commit(std::unique_lock<std::mutex> &lk, bool all)
+		{
+			while (seq_out < seq_in)
+			{
+				Slot &sl = slots[seq_out % kSlots];
+				if (all)
+					done.wait(lk, [&] { return sl.state != Slot::QUEUED; });
+				if (sl.state == Slot::QUEUED)
+					break;
+				const bool ok = sl.state == Slot::DONE;
+				lk.unlock();
+				const bool written = ok && !broken && write_record(sl.ts, sl.comp.data(), sl.csize);
+				lk.lock();
+				if (!written)
+					broken = true;
+				sl.state = Slot::FREE;
+				++seq_out;
+			}
+			return !broken;
+		}
+		bool add(const unsigned short *img, int64_t timestamp)
+		{
+			if (!fp || !img || broken)
+				return false;
+			const size_t npx = (size_t)zt.data_size_x * zt.data_size_y;
+			const int nthreads = zfile_threads();
+			if (nthreads == 0)
+			{
+				const ZstdApi &z = ZstdApi::get();
+				const size_t c = z.compress(buf.data(), buf.size(), img, npx * 2, clevel);
+				if (z.isError(c) || !write_record(timestamp, buf.data(), c))
+					return broken = true, false;
+				return true;
+			}
+			std::unique_lock<std::mutex> lk(mu);
+			Slot &sl = slots[seq_in % kSlots];
+			if (sl.state != Slot::FREE && !commit(lk, false))
+				return false;
+			if (sl.state != Slot::FREE)
+			{ // every slot holds an image that is not written yet: the oldest one first
+				Slot &oldest = slots[seq_out % kSlots];
+				done.wait(lk, [&] { return oldest.state != Slot::QUEUED; });
+				if (!commit(lk, false))
+					return false;
+			}
+			if (sl.img.size() != npx)
+				sl.img.resize(npx), sl.comp.resize(buf.size());
+			lk.unlock();
+			host_copy(sl.img.data(), img, npx * 2); // (the slot is free and nobody else looks at a free slot)
+			lk.lock();
+			sl.ts = timestamp, sl.state = Slot::QUEUED;
+			todo.push_back((int)(seq_in % kSlots));
+			++seq_in;
+			if (threads.empty())
+				for (int t = 0; t < nthreads; ++t)
+					threads.emplace_back([this] { compress_loop(); });
+			work.notify_one();
+			return commit(lk, false);
+		}
+		void stop_threads()
+		{
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				quit = true;
+			}
+			work.notify_all();
+			for (auto &t : threads)
+				if (t.joinable())
+					t.join();
+			threads.clear();
+		}
 		// size of the image data (the trailer comes after it), as z_close_file returns
 		int64_t close()
 		{
 			if (!fp)
 				return -1;
+			{
+				std::unique_lock<std::mutex> lk(mu);
+				(void)commit(lk, true); // every image taken is in the file (or the writer is broken)
+			}
+			stop_threads();
 			const int64_t data_end = (int64_t)ftello(fp);
 			bool ok = fseeko(fp, sizeof(ZHeader), SEEK_SET) == 0 && std::fwrite(&zt, sizeof(zt), 1, fp) == 1 && fseeko(fp, 0, SEEK_END) == 0;
 			AttrMap global;
 			global["positions"] = std::string(reinterpret_cast<const char *>(positions.data()), positions.size() * 8);
 			const std::string trailer = FileAttributes::serialize(global, std::vector<AttrMap>(times.size()), times);
 			ok = ok && std::fwrite(trailer.data(), 1, trailer.size(), fp) == trailer.size();
-			ok = (std::fclose(fp) == 0) && ok;
+			ok = (std::fclose(fp) == 0) && ok && !broken;
 			fp = nullptr;
 			return ok ? data_end : -1;
 		}

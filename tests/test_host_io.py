@@ -563,3 +563,59 @@ def test_slices_fill_their_stack_in_place_with_pages_made_ahead(tmp_path):
     small = np.zeros(100, np.uint8)
     with touch_ahead(small) as t:  # too small to bother
         assert t.threads == []
+
+
+def test_zfile_images_decompressed_ahead_of_a_sequential_reader(tmp_path):
+    """a ZFile read image after image has its next images decompressed ahead by threads of the loader; whatever the order of the reads -
+    runs, jumps back and forth, a close with images still on their way - every image is the recorded one.  No device needed."""
+    rng = np.random.default_rng(3)
+    n, h, w = 60, 48, 80
+    fr = rng.integers(0, 16000, (n, h, w)).astype(np.uint16)
+    p = tmp_path / "z.bin"
+    hd = rv.open_video_write(p, w, h, 50, 1, 0)
+    for i in range(n):
+        rv.image_write(hd, fr[i], i * 1000)
+    rv.close_video(hd)
+    for rep in range(12):
+        cam = rv.open_camera_file(p)
+        order = list(range(n)) if rep % 3 == 0 else (list(range(10)) + list(rng.permutation(n)) + list(range(20, 50)) + [5, 6, 7, 8, 9, 10, 3, 4, 5, 6, 7])
+        for i in order:
+            assert np.array_equal(rv.load_image(cam, int(i)), fr[int(i)]), (rep, i)
+        rv.close_camera(cam)
+
+
+def test_zfile_writer_compresses_on_its_threads_and_writes_in_order(tmp_path):
+    """open_video_write / image_write with zstd on several threads: the file is the one the single-threaded writer makes, byte for byte
+    (RIR_ZFILE_THREADS = 0, 1 and the default), and reads back; a writer closed at once leaves a valid empty file"""
+    import hashlib
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "from librir_amd.video_io import rir_video_io as rv\n"
+            "rng = np.random.default_rng(4)\n"
+            "n, h, w = 70, 60, 88\n"
+            "fr = (rng.integers(0, 300, (n, h, w)) + np.arange(n)[:, None, None] * 3).astype(np.uint16)\n"
+            "hd = rv.open_video_write(sys.argv[1], w, h, 50, 1, 3)\n"
+            "for i in range(n): rv.image_write(hd, fr[i], i * 777)\n"
+            "size = rv.close_video(hd)\n"
+            "cam = rv.open_camera_file(sys.argv[1])\n"
+            "assert rv.get_image_count(cam) == n\n"
+            "for i in list(range(12)) + [40, 69]: assert np.array_equal(rv.load_image(cam, i), fr[i])\n"
+            "assert rv.get_image_time(cam, 5) == 5 * 777 * 1000000  # (small stamps are taken as milliseconds: IRFileLoader.cpp:355-376)\n"
+            "rv.close_camera(cam)\n"
+            "print(size)\n") % root
+    seen = set()
+    for threads in ("0", "1", None):
+        p = tmp_path / ("z%s.bin" % threads)
+        env = dict(os.environ)
+        env.pop("RIR_ZFILE_THREADS", None)
+        if threads is not None:
+            env["RIR_ZFILE_THREADS"] = threads
+        r = subprocess.run([sys.executable, "-c", code, str(p)], env=env, stdout=subprocess.PIPE, check=True)
+        seen.add((hashlib.sha256(p.read_bytes()).hexdigest(), r.stdout.decode().strip()))
+    assert len(seen) == 1
+    empty = tmp_path / "empty.bin"
+    assert rv.close_video(rv.open_video_write(empty, 20, 10, 50, 1, 0)) == 256  # the two header blocks, no image
