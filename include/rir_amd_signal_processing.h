@@ -53,6 +53,14 @@ extern "C"
 	 * elsewhere (all zero without a component).  0, -1 on an unknown type. */
 	int keep_largest_area(int type, void *src, int *dst, int w, int h, void *background, int foreground);
 
+	/* ---- extension (prefix rir_) ----
+	 * bad_pixels_correct -> gaussian_filter(sigma) -> translate(dx, dy, strategy) -> uint16 on one host image in ONE call: what a caller of the
+	 * three entry points above does in three (BASELINE configs[2]), without the two float images in between.  bad_pixels_handle 0: no
+	 * repair; strategy "nearest" or "background" (background: one uint16).  The three calls' result within one level, or exactly with
+	 * rir_set_gaussian_reference_order(1) (rir_amd_device.h).  0 / -1. */
+	int rir_filter_chain(int bad_pixels_handle, unsigned short *in, unsigned short *out, int w, int h, float sigma, float dx, float dy,
+						 void *background, const char *strategy);
+
 #ifdef __cplusplus
 }
 #endif

@@ -729,6 +729,36 @@ RIR_EXPORT int bad_pixels_correct(int handle, unsigned short *in, unsigned short
 	return hand_out(s, out, dst, bytes, st) ? 0 : -1;
 }
 
+// Extension: bad_pixels_correct -> gaussian_filter(sigma) -> translate(dx, dy, strategy) -> uint16 on ONE host image in one call (the reference's
+// callers make the three calls, three trips over the link and two float images in between: configs[2] of BASELINE).  bad_pixels_handle 0: no
+// repair.  Strategies "nearest" and "background"; the result is what rir_filter_chain_device gives (the three calls' result within one
+// level, or exactly with rir_set_gaussian_reference_order(1)).  0 / -1.
+RIR_EXPORT int rir_filter_chain(int bad_pixels_handle, unsigned short *in, unsigned short *out, int w, int h, float sigma, float dx, float dy,
+								void *background, const char *strategy)
+{
+	if (!device_ready())
+		return -1;
+	if (!in || !out || w <= 0 || h <= 0)
+		return -1;
+	HostScratch &s = scratch();
+	std::lock_guard<std::mutex> g(s.mu);
+	hipStream_t st = default_stream();
+	const size_t bytes = (size_t)w * h * 2;
+	const size_t off_at = (bytes + 63) & ~(size_t)63;
+	if (!s.h_in.reserve(off_at + 64))
+		return -1;
+	float *off = reinterpret_cast<float *>(s.h_in.as<char>() + off_at); // (page-locked: the kernel reads the two floats from there)
+	off[0] = dx, off[1] = dy;
+	const void *src = stage_in(s, s.a, in, bytes, 0, st);
+	void *dst = src ? stage_out(s, s.b, out, bytes, false, st) : nullptr;
+	if (!src || !dst)
+		return -1;
+	if (rir_filter_chain_device(bad_pixels_handle, static_cast<const unsigned short *>(src), static_cast<unsigned short *>(dst), w, h, 1, sigma, off, 0,
+								background, strategy, st) != 0)
+		return -1;
+	return hand_out(s, out, dst, bytes, st) ? 0 : -1;
+}
+
 RIR_EXPORT void bad_pixels_destroy(int handle)
 {
 	if (lookup_as<BadPixelsObject>(handle))

@@ -124,6 +124,28 @@ def bad_pixels_destroy(handle):
     _sp.bad_pixels_destroy(handle)
 
 
+# ---- extension: the three pre-recording filters in one call ----------------------------------------------------------------------
+_sp.rir_filter_chain.argtypes = [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_float, ct.c_float, ct.c_float, ct.c_void_p, ct.c_char_p]
+
+
+def filter_chain(image, bad_pixels, sigma, dx, dy, strategy="nearest", background=0):
+    """Extension: ``bad_pixels.correct(image)`` -> ``gaussian_filter(sigma)`` -> ``translate(dx, dy, strategy)`` -> uint16 in ONE library call
+    on one uint16 image (the three calls cross the link three times with two float images in between).  ``bad_pixels``: a ``BadPixels``
+    object, a handle, or None.  Strategies "nearest" and "background" / "constant"."""
+    img = np.ascontiguousarray(image)
+    if img.ndim != 2 or img.dtype != np.uint16:
+        raise RuntimeError("filter_chain: a 2-D uint16 image expected")
+    if strategy == "constant":
+        strategy = "background"
+    handle = 0 if bad_pixels is None else int(getattr(bad_pixels, "handle", bad_pixels))
+    out = np.empty(img.shape, dtype=np.uint16)
+    back = np.array([background], dtype=np.uint16)
+    if _sp.rir_filter_chain(handle, img.ctypes.data, out.ctypes.data, img.shape[1], img.shape[0], float(sigma), float(dx), float(dy), back.ctypes.data,
+                            toCharP(strategy)) < 0:
+        raise RuntimeError("An error occured while calling 'filter_chain': " + (last_error() or ""))
+    return out
+
+
 # ---- time axes (host bookkeeping, csrc/time_series.cpp) -------------------------------------------------------------------------
 _sp.extract_times.argtypes = [ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_void_p, ct.POINTER(ct.c_int)]
 _sp.resample_time_serie.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_void_p, ct.c_int, ct.c_int, ct.c_double, ct.c_void_p, ct.POINTER(ct.c_int)]

@@ -84,7 +84,7 @@ with tempfile.TemporaryDirectory() as d:
     assert np.array_equal(buf, fr[n - 1])
 
 # the signal_processing entry points, one image per call (the reference wrapper's calling convention)
-from librir_amd.signal_processing import BadPixels, gaussian_filter, translate  # noqa: E402
+from librir_amd.signal_processing import BadPixels, filter_chain, gaussian_filter, translate  # noqa: E402
 
 img = fr[0]
 f32 = img.astype(np.float32)
@@ -93,7 +93,8 @@ m = 300
 for name, fn in [("translate u16 (1.25, -2.5, nearest)", lambda: translate(img, 1.25, -2.5, "nearest")),
                  ("translate f32", lambda: translate(f32, 1.25, -2.5, "nearest")),
                  ("gaussian_filter f32 sigma 0.75", lambda: gaussian_filter(f32, 0.75)),
-                 ("BadPixels.correct u16", lambda: bp.correct(img))]:
+                 ("BadPixels.correct u16", lambda: bp.correct(img)),
+                 ("filter_chain (the three in one call)", lambda: filter_chain(img, bp, 0.75, 1.25, -2.5, "nearest"))]:
     fn()
     for rep in range(2):
         t0 = time.perf_counter()
@@ -108,3 +109,8 @@ for i in range(m):
     x = translate(x, 1.25, -2.5, "nearest")
 dt = time.perf_counter() - t0
 print("configs[2] chain, three calls per image    : %7.0f frames/s (%5.1f us)" % (m / dt, dt / m * 1e6), flush=True)
+t0 = time.perf_counter()
+for i in range(m):
+    x = filter_chain(fr[i], bp, 0.75, 1.25, -2.5, "nearest")
+dt = time.perf_counter() - t0
+print("configs[2] chain, one call per image       : %7.0f frames/s (%5.1f us)" % (m / dt, dt / m * 1e6), flush=True)

@@ -354,3 +354,34 @@ def test_filter_chain_in_reference_order_equals_the_oracle_chain(dev, oracle, sh
     t = oracle.translate(oracle.gaussian_filter(arr[0].astype(np.float32), sigma), float(off[0]), float(off[1]), "background" if strategy == "background" else strategy,
                          background=7.0)
     assert np.array_equal(t.astype(np.int64).clip(0, 65535), out[0].astype(np.int64))
+
+
+def test_the_three_filters_in_one_call_per_host_image(oracle):
+    """rir_filter_chain (extension): repair -> gaussian -> translate -> uint16 on one host image in one call = the three entry points one after
+    the other within one level; exactly the device layer's fused chain; strategies and the no-repair form; bad arguments refused"""
+    import torch
+
+    from librir_amd import device as D
+    from librir_amd.signal_processing import BadPixels, filter_chain, gaussian_filter, translate
+    from librir_amd.synthetic import inject_bad_pixels, s1_noisy_background
+
+    for (h, w) in ((67, 83), (512, 640)):
+        fr = inject_bad_pixels(s1_noisy_background(3, h, w, seed=h), 12)
+        bp = BadPixels(fr[0])
+        dbp = D.BadPixels(torch.from_numpy(fr[0]).cuda())
+        for img in (fr[1], fr[2]):
+            for strategy, bg in (("nearest", 0), ("background", 77)):
+                got = filter_chain(img, bp, 0.75, 1.25, -2.5, strategy, bg)
+                steps = translate(gaussian_filter(bp.correct(img).astype(np.float32), 0.75), 1.25, -2.5, strategy, bg).astype(np.uint16)
+                assert got.dtype == np.uint16 and np.abs(got.astype(np.int64) - steps.astype(np.int64)).max() <= 1
+                fused = D.filter_chain(torch.from_numpy(img[None]).cuda(), dbp, 0.75, (1.25, -2.5), strategy, bg).cpu().numpy()[0]
+                assert np.array_equal(got, fused)
+            plain = filter_chain(img, None, 1.0, -0.5, 0.25)
+            steps = translate(gaussian_filter(img.astype(np.float32), 1.0), -0.5, 0.25, "nearest").astype(np.uint16)
+            assert np.abs(plain.astype(np.int64) - steps.astype(np.int64)).max() <= 1
+        with pytest.raises(RuntimeError):
+            filter_chain(fr[1], bp, 0.75, 0, 0, "wrap")
+        with pytest.raises(RuntimeError):
+            filter_chain(fr[1].astype(np.float32), bp, 0.75, 0, 0)
+        with pytest.raises(RuntimeError):
+            filter_chain(fr[1][:, :-1], bp, 0.75, 0, 0)  # the repair object was made for another image size
