@@ -38,7 +38,7 @@ def _load():
 _lib = _load()
 # same module-level names as the reference wrapper
 _tools = _lib
-_geometry = _lib
+_geometry = None  # (the polygon library is not part of this build: a drop-in keeps the reference's own)
 _signal_processing = _lib
 _video_io = _lib
 
