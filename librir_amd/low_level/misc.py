@@ -1,7 +1,7 @@
 """Library loading, mirroring librir's ``low_level.misc`` (reference
-src/python/librir/low_level/misc.py:98-139): the four handles ``_tools``, ``_geometry``,
+src/python/librir/low_level/misc.py:98-139): the handles ``_tools``,
 ``_signal_processing`` and ``_video_io`` exist, but here they all resolve to the one HIP shared
-object ``libs/librir_amd.so`` (built in-tree by ``librir_amd.build``).
+object ``libs/librir_amd.so`` (built in-tree by ``librir_amd.build``); ``_geometry`` is None (the polygon library is not part of this build).
 
 There is no CPU implementation behind this package: if the shared object is missing, importing
 fails with an explicit message; if no HIP device is present, the compute entry points return their
