@@ -128,6 +128,33 @@ namespace rir
 	// the group's background words (bit 40: a class may be empty), the streams' budget windows (NaN) and *d_poison (an earlier group of
 	// the call was not stepped) and do nothing unless everything is clear; *d_ok (zeroed by the caller) says which it was - the resident
 	// launch that follows reads it and leaves the group alone when it is 1 (launch_lossy_run's d_ok).
+	// The SPECULATIVE form of a run (round 6): streams whose budgets follow the frames' statistics (stdFactor != 0, the reference's default: 5,
+	// h264.cpp:1662-1665).  The budget of frame k (h264.cpp:2335-2385) depends on the output of frame k - 1, so the chain is strict - unless the
+	// budgets are GUESSED.  On scenes that do not move the rounded correction round(|std - mean| x stdFactor) is 0 frame after frame and the budgets
+	// are the configured constants; so a group is first stepped by the streaming kernel with a per-frame budget table filled with that guess, into
+	// SHADOW state (the stream's state stays what it was), a second kernel takes every frame's six exact sums from the frames where they lie
+	// (input k against output k - 1: fully parallel), and a third runs the reference's double arithmetic for every frame (a thread per frame: the
+	// window mean of frame k is its own chain of 40 additions over statistics that are all known).  The sums are right up to and including the first
+	// frame m whose true budget is not the table's; that entry is corrected and the group is stepped again, up to `passes` times; a group whose table
+	// then verifies is committed (shadow -> state, window, budgets), any other is left to the resident kernel behind, exactly as a declined
+	// constant-budget group is.  A stream whose groups keep failing is not offered for a while (a counter on the device: 1, 3, 7, 15 groups).
+	struct LossySpec
+	{
+		LossyDeviceState shadow;   // where a pass leaves the state after the group (ring: the slots the group writes)
+		uint32_t *budgets;		   // [nsteps] low | high << 16, both clamped to 0 .. 65 535 (a difference never exceeds that)
+		unsigned long long *rows;  // [nsteps][stat workgroups][4] the sums of a frame, per slab of kLossySpecSlab pixels (words as lossy_const_run_kernel's partials)
+		double *sd;				   // [nsteps][2] the statistic of every frame (verify -> commit)
+		unsigned int *ctl;		   // [8] 0: status (0 to be stepped, 1 verified, 2 given up), 1: passes so far, 2: first mismatch of the last pass, 3: passes allowed
+		unsigned int *backoff;	   // [2] of the call's leading stream: groups still to skip, failures in a row
+	};
+	constexpr int kLossySpecSlab = 16384; // pixels of a frame per workgroup of the sums kernel
+	inline int lossy_spec_stat_workgroups(int s) { return (s + kLossySpecSlab - 1) / kLossySpecSlab; }
+	// begin: precondition (as the constant-budget form's) and back-off, the guess into every stream's table; one pass = streaming kernel + sums + verify;
+	// commit: all streams verified -> shadow state, windows, budgets into place, *d_ok = 1.  Every launch looks at the words the one before left and
+	// returns at once when there is nothing for it to do; nothing waits for the host.
+	hipError_t launch_lossy_spec_begin(const LossyRun *d_table, const LossySpec *d_spec, int nstreams, int passes, unsigned int *d_ok, const unsigned int *d_poison, hipStream_t st);
+	hipError_t launch_lossy_spec_pass(const LossyRun *d_table, const LossySpec *d_spec, int nstreams, int s, int full, int max_frames, bool any_ra, bool add_loss, hipStream_t st);
+	hipError_t launch_lossy_spec_commit(const LossyRun *d_table, const LossySpec *d_spec, int nstreams, int s, int full, unsigned int *d_ok, hipStream_t st);
 	void lossy_const_force_pairs(int np); // 4, 2, 1: that many pairs of pixels per thread whatever the launch; anything else: chosen by lossy_const_pairs (test hook RIR_LOSSY_CONST_PAIRS)
 	int lossy_const_workgroups(int full, int nstreams); // workgroups of a stream in that launch: partials holds kLossyConstSlots x this many x 4 words per stream
 	// any_ra: some stream of the launch keeps a running average; add_loss: the addLoss variant of the decision (the same for all streams)

@@ -40,6 +40,19 @@ namespace rir
 	{
 		return (RIR_GLOBAL(T) *)p;
 	}
+	// a plain struct out of a table in global memory, in 8-byte words (wave-uniform addresses: scalar loads)
+	template <class T>
+	__device__ __forceinline__ T lossy_load_struct(const T *p_)
+	{
+		static_assert(sizeof(T) % 8 == 0, "copied in 8-byte words");
+		T v;
+		RIR_GLOBAL(const unsigned long long) *src = (RIR_GLOBAL(const unsigned long long) *)p_;
+		unsigned long long *dst = reinterpret_cast<unsigned long long *>(&v);
+#pragma unroll
+		for (size_t k = 0; k < sizeof(T) / 8; ++k)
+			dst[k] = src[k];
+		return v;
+	}
 	template <bool TABLE>
 	__device__ __forceinline__ LossyStep lossy_step_of(const LossyStep &one, const LossyStep *__restrict__ table)
 	{
@@ -1853,9 +1866,11 @@ namespace rir
 			dst[0] = (long long)wfd, dst[1] = wf2, dst[2] = (long long)(wn & 0xffffu), dst[3] = (long long)wbd, dst[4] = wb2, dst[5] = (long long)(wn >> 16);
 	}
 
-	template <int NP, bool RA_ON, bool ADD_LOSS>
+	// SPEC: the speculative form (lossy_kernels.h: LossySpec) - the budgets come from the stream's table, frame by frame, the state after the
+	// group and the ring's new images go to the SHADOW arrays, and no frame leaves sums (lossy_spec_stats_kernel takes them from the frames).
+	template <int NP, bool RA_ON, bool ADD_LOSS, bool SPEC = false>
 	__global__ __launch_bounds__(256) void lossy_const_run_kernel(const LossyRun *__restrict__ table, int nstreams, unsigned int *__restrict__ ok_word,
-																  const unsigned int *__restrict__ poison)
+																  const unsigned int *__restrict__ poison, const LossySpec *__restrict__ spec)
 	{
 		constexpr int PX = 2 * NP;
 		constexpr int D = kConstDepth;
@@ -1863,13 +1878,25 @@ namespace rir
 		__shared__ unsigned int sh_flag;
 		__shared__ long long red[4][6];
 		__shared__ __attribute__((aligned(16))) uint32_t sh_bg[kLossyConstMaxFrames + 8];
-		__shared__ long long red_tail[kLossyConstTail][4][6]; // the sums of the last frames of a group, per wave (const_frame_sums_wave)
+		__shared__ __attribute__((aligned(16))) uint32_t sh_err[SPEC ? kLossyConstMaxFrames + 8 : 4]; // SPEC: the budgets of the group's frames, low | high << 16
+		__shared__ long long red_tail[SPEC ? 1 : kLossyConstTail][4][6]; // the sums of the last frames of a group, per wave (const_frame_sums_wave)
 		const int tid = threadIdx.x, b = blockIdx.x, stream = blockIdx.y, nb = gridDim.x;
-		const bool ok = lossy_const_precondition(table, nstreams, poison, &sh_flag) && as_global(table + stream)->nsteps <= kLossyConstMaxFrames;
-		if (b == 0 && stream == 0 && tid == 0)
-			__hip_atomic_store(as_global(ok_word), ok ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (!ok)
-			return;
+		LossyDeviceState sto; // where the state goes after the group
+		if constexpr (SPEC)
+		{ // (the launch before this one has decided: lossy_spec_begin_kernel / lossy_spec_verify_kernel)
+			RIR_GLOBAL(const LossySpec) *sp = as_global(spec + stream);
+			if (__hip_atomic_load(as_global(sp->ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+				return;
+			sto = lossy_load_struct(&(spec + stream)->shadow);
+		}
+		else
+		{
+			const bool ok = lossy_const_precondition(table, nstreams, poison, &sh_flag) && as_global(table + stream)->nsteps <= kLossyConstMaxFrames;
+			if (b == 0 && stream == 0 && tid == 0)
+				__hip_atomic_store(as_global(ok_word), ok ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (!ok)
+				return;
+		}
 		LossyRun rp;
 		{
 			RIR_GLOBAL(const unsigned long long) *src = (RIR_GLOBAL(const unsigned long long) *)(table + stream);
@@ -1879,6 +1906,8 @@ namespace rir
 				dst[k] = src[k];
 		}
 		const LossyDeviceState st = rp.st;
+		if constexpr (!SPEC)
+			sto = st;
 		RIR_GLOBAL(uint16_t) *refT = as_global(st.refT), *prevT = as_global(st.prevT), *lastDL = as_global(st.lastDL);
 		RIR_GLOBAL(uint16_t) *cval = as_global(st.ra_const_value);
 		RIR_GLOBAL(uint16_t) *ccnt = (RIR_GLOBAL(uint16_t) *)as_global(st.ra_const_count);
@@ -1893,6 +1922,7 @@ namespace rir
 		const uint32_t full_bytes = (uint32_t)full * 2u, s_bytes = (uint32_t)s * 2u;
 		const uint64_t frame_bytes = (uint64_t)rp.frame_px * 2u, ring_bytes = (uint64_t)s * 2u;
 		const uint64_t in0 = (uint64_t)rp.in, ring0 = (uint64_t)st.ra_images;
+		const uint64_t ring_w0 = (uint64_t)sto.ra_images; // the ring the group's last images are written to (SPEC: the shadow ring, same slots)
 		// the budget of every frame (lossy_budget with a statistic that is multiplied by zero)
 		const int high_error = rp.high_value_error < 0 ? 0 : rp.high_value_error;
 		const int low_error = rp.low_value_error < high_error ? high_error : rp.low_value_error;
@@ -1905,6 +1935,12 @@ namespace rir
 		// compiler wants in a scalar register at once - a memory latency per frame and wave
 		for (int k = tid; k < n; k += 256)
 			sh_bg[k] = (uint32_t)bgw[(size_t)k * rp.bg_stride];
+		if constexpr (SPEC)
+		{
+			RIR_GLOBAL(const uint32_t) *bud = as_global(as_global(spec + stream)->budgets);
+			for (int k = tid; k < n + 8; k += 256)
+				sh_err[k] = k < n ? bud[k] : 0u;
+		}
 		__syncthreads();
 
 		Px ref{}, last{}, cc{}, cv{}, o{}, t{};
@@ -1963,6 +1999,7 @@ namespace rir
 		for (int j = 0; j < D; ++j)
 			request(V[j], O[j]);
 		uint32_t bg_next = sh_bg[0]; // (a frame's background is read from LDS a frame ahead)
+		uint32_t err_next = SPEC ? sh_err[0] : 0u;
 		// per-frame constants that only move while the ring fills
 		auto ring_consts = [&]() {
 			const int n_after = ra > 0 ? (count == ra ? ra : count + 1) : 0;
@@ -1970,12 +2007,14 @@ namespace rir
 			pc.full_mask = (ra > 0 && count == ra) ? 0xffffffffu : 0u, pc.full_one2 = pc.full_mask & 0x00010001u;
 		};
 		ring_consts();
-		const int tail0 = n > kLossyConstTail ? n - kLossyConstTail : 0;
+		// (SPEC: no frame leaves sums; the frames from tail0 on only differ in that the frame D ahead of them may not exist)
+		const int tail0 = SPEC ? (n > D ? n - D : 0) : (n > kLossyConstTail ? n - kLossyConstTail : 0);
 		const int ring_from = n - ra; // frames from here on are in the ring after the group
 		uint64_t out_p = (uint64_t)rp.out;
 		// where a frame's input goes in the ring: the slot after the newest image - one further per frame, full ring or not
 		int wr_slot = (head + (count == ra ? 0 : count)) % (ra > 0 ? ra : 1);
-		uint64_t wr_p = ring0 + (uint64_t)wr_slot * ring_bytes;
+		const uint64_t ring_w_end = ring_w0 + (uint64_t)(ra > 0 ? ra : 1) * ring_bytes;
+		uint64_t wr_p = ring_w0 + (uint64_t)wr_slot * ring_bytes;
 		auto step = [&](int k, Px &Vj, Px &Oj) {
 			const Px v = Vj;
 			Px old = Oj;
@@ -1988,12 +2027,18 @@ namespace rir
 			}
 			const uint32_t background = (uint32_t)__builtin_amdgcn_readfirstlane((int)bg_next); // (wave-uniform: what is derived from it stays on the scalar unit)
 			bg_next = sh_bg[k + 1 < n ? k + 1 : k];
+			if constexpr (SPEC)
+			{
+				const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)err_next);
+				err_next = sh_err[k + 1 < n ? k + 1 : k];
+				pc.low2 = lossy_both(e & 0xffffu), pc.high2 = lossy_both(e >> 16);
+			}
 			request(Vj, Oj);
 			// the frame's sums, if its statistic will be in the window (or seeds it): against the previous output, per workgroup (out of
 			// line: frame 0 and, where a group is too short for the middle loop, its last 40 frames come here; the loop body is unrolled kConstDepth times)
 			lossy_v2u_b pval = {0u, 0u};
 			uint32_t poff = RIR_LOSSY_OOB;
-			if (k >= tail0 || k == 0)
+			if (!SPEC && (k >= tail0 || k == 0))
 			{
 				const int slot = k >= tail0 ? 1 + (k - tail0) : 0;
 				const unsigned long long val = const_frame_sums<NP>(v, o, background, lossy, st.subtract_min, st.min, &red[0][0]);
@@ -2003,7 +2048,8 @@ namespace rir
 					poff = (uint32_t)((((size_t)slot * nb + b) * 4 + tid) * 8);
 				}
 			}
-			__builtin_amdgcn_raw_buffer_store_b64(pval, part_rsrc, poff, 0, 0); // (every frame: out of range unless the frame leaves sums)
+			if constexpr (!SPEC)
+				__builtin_amdgcn_raw_buffer_store_b64(pval, part_rsrc, poff, 0, 0); // (every frame: out of range unless the frame leaves sums)
 			pc.bg2 = lossy_both(background);
 			Px ov;
 #pragma unroll
@@ -2020,8 +2066,8 @@ namespace rir
 				// the ring as it must be after the group: the last `ra` inputs
 				buf_stn<NP>(t, lossy_rsrc((const void *)wr_p, (ra > 0 && k >= ring_from) ? s_bytes : 0u), off_lossy);
 				const uint64_t nxt = wr_p + ring_bytes;
-				wr_p = nxt == ring_end ? ring0 : nxt;
-				wr_slot = nxt == ring_end ? 0 : wr_slot + 1;
+				wr_p = nxt == ring_w_end ? ring_w0 : nxt;
+				wr_slot = nxt == ring_w_end ? 0 : wr_slot + 1;
 				if (count != ra)
 				{ // (only while the ring fills: the constants of the running average move)
 					++count;
@@ -2053,24 +2099,42 @@ namespace rir
 															 ra > 0 ? (uint32_t)(group_bytes - (uint64_t)D * frame_bytes + ra_back) : 0u);
 			const __amdgpu_buffer_rsrc_t rs_out = lossy_rsrc((const void *)(uint64_t)rp.out, (uint32_t)group_bytes);
 			uint32_t so = (uint32_t)mid0 * fb;
-			uint32_t bgq[D], bgn[D];
-			auto backgrounds = [&](int k) { // of frames k .. k + D - 1 (k a multiple of D; the array is padded)
+			uint32_t bgq[D], bgn[D], erq[D], ern[D];
+			auto backgrounds = [&](int k) { // of frames k .. k + D - 1 (k a multiple of D; the array is padded) - SPEC: and their budgets
 				if constexpr (D == 4)
 				{
 					const lossy_v4u q = *reinterpret_cast<const lossy_v4u *>(&sh_bg[k]);
 					bgn[0] = q.x, bgn[1] = q.y, bgn[2] = q.z, bgn[3] = q.w;
+					if constexpr (SPEC)
+					{
+						const lossy_v4u e = *reinterpret_cast<const lossy_v4u *>(&sh_err[k]);
+						ern[0] = e.x, ern[1] = e.y, ern[2] = e.z, ern[3] = e.w;
+					}
 				}
 				else
 				{
 #pragma unroll
 					for (int j = 0; j < D; ++j)
+					{
 						bgn[j] = sh_bg[k + j];
+						if constexpr (SPEC)
+							ern[j] = sh_err[k + j];
+					}
+				}
+			};
+			auto uniform = [&]() { // the next D frames' backgrounds (and budgets) into scalar registers
+#pragma unroll
+				for (int j = 0; j < D; ++j)
+				{
+					bgq[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)bgn[j]);
+					if constexpr (SPEC)
+						erq[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ern[j]);
 				}
 			};
 			backgrounds(mid0);
 			V[D - 1] = last; // (frame mid0 + D - 1, which step() has asked for, is asked for again by the first step below)
-			const __amdgpu_buffer_rsrc_t rs_ring_on = lossy_rsrc((const void *)ring0, (uint32_t)((uint64_t)(ra > 0 ? ra : 0) * ring_bytes));
-			const __amdgpu_buffer_rsrc_t rs_ring_off = lossy_rsrc((const void *)ring0, 0u);
+			const __amdgpu_buffer_rsrc_t rs_ring_on = lossy_rsrc((const void *)ring_w0, (uint32_t)((uint64_t)(ra > 0 ? ra : 0) * ring_bytes));
+			const __amdgpu_buffer_rsrc_t rs_ring_off = lossy_rsrc((const void *)ring_w0, 0u);
 			uint32_t so_ring = 0; // (set where the tail begins)
 			// One frame, slot j of the ring of registers.  TAIL: a frame of the group's end - it may leave sums (per wave, in LDS), it may go into
 			// the ring of images, and the frame D ahead of it may not exist.
@@ -2084,9 +2148,11 @@ namespace rir
 					for (int p = 0; p < NP; ++p)
 						old.d[p] = lu1(__builtin_elementwise_sub_sat(lp2(old.d[p]), lp2(pc.min2)));
 				}
-				if (TAIL && k >= tail0)
+				if (!SPEC && TAIL && k >= tail0)
 					const_frame_sums_wave<NP>(v, o, bgq[j], lossy, st.subtract_min, st.min, &red_tail[k - tail0][tid >> 6][0]);
 				pc.bg2 = lossy_both(bgq[j]);
+				if constexpr (SPEC)
+					pc.low2 = lossy_both(erq[j] & 0xffffu), pc.high2 = lossy_both(erq[j] >> 16);
 				const Px before = V[(j + D - 1) % D]; // the frame before this one: still in its slot
 				Px ov;
 #pragma unroll
@@ -2120,9 +2186,7 @@ namespace rir
 			};
 			for (int k0 = mid0; k0 < mid1; k0 += D)
 			{
-#pragma unroll
-				for (int j = 0; j < D; ++j)
-					bgq[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)bgn[j]);
+				uniform();
 				backgrounds(k0 + D); // (k0 + D <= mid1 < n)
 #pragma unroll
 				for (int j = 0; j < D; ++j)
@@ -2132,9 +2196,7 @@ namespace rir
 			so_ring = (uint32_t)((uint64_t)((wr_slot + (mid1 - mid0)) % (ra > 0 ? ra : 1)) * ring_bytes); // (the slot frame mid1 goes to: one further per frame)
 			for (int k0 = mid1; k0 < n; k0 += D)
 			{
-#pragma unroll
-				for (int j = 0; j < D; ++j)
-					bgq[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)bgn[j]);
+				uniform();
 				backgrounds(k0 + D); // (the array is padded by D)
 #pragma unroll
 				for (int j = 0; j < D; ++j)
@@ -2142,6 +2204,8 @@ namespace rir
 						frame(std::true_type{}, j, k0 + j);
 			}
 			// the workgroup's sums of the frames of the end: its four waves added up, where step() leaves them
+			if constexpr (SPEC)
+				return;
 			__syncthreads();
 			if (tid < kLossyConstTail * 4 && tail0 + tid / 4 < n)
 			{
@@ -2175,22 +2239,24 @@ namespace rir
 				if (k0 + j < n)
 					step(k0 + j, V[j], O[j]);
 		}
+		RIR_GLOBAL(uint16_t) *refT_o = as_global(sto.refT), *prevT_o = as_global(sto.prevT), *lastDL_o = as_global(sto.lastDL);
 		if (lossy)
 		{
-			stn<NP>(refT, ig, ref);
-			stn<NP>(lastDL, ig, last);
-			stn<NP>(prevT, ig, o);
+			stn<NP>(refT_o, ig, ref);
+			stn<NP>(lastDL_o, ig, last);
+			stn<NP>(prevT_o, ig, o);
 			if (ra > 0)
 			{
+				RIR_GLOBAL(uint32_t) *sums_o = as_global(sto.ra_sums);
 #pragma unroll
 				for (int q = 0; q < PX; ++q)
-					sums[ig * PX + q] = sum[q];
-				stn<NP>(ccnt, ig, cc);
-				stn<NP>(cval, ig, cv);
+					sums_o[ig * PX + q] = sum[q];
+				stn<NP>((RIR_GLOBAL(uint16_t) *)as_global(sto.ra_const_count), ig, cc);
+				stn<NP>(as_global(sto.ra_const_value), ig, cv);
 			}
 		}
 		else if (inside)
-			stn<NP>(lastDL, ig, last);
+			stn<NP>(lastDL_o, ig, last);
 	}
 
 	// grid = streams, 1 024 threads.  The window entries of the frames that left sums (exact integers -> the reference's double
@@ -2290,6 +2356,365 @@ namespace rir
 			RIR_GLOBAL(int) *e = as_global(r->errors_out);
 			for (int k = tid; k < n; k += 1024)
 				e[2 * k] = low_error, e[2 * k + 1] = high_error;
+		}
+	}
+
+
+	// ---- the speculative form of a run (lossy_kernels.h: LossySpec) -------------------------------------------------------------------
+	//
+	// lossy_spec_begin_kernel: one workgroup.  The group is offered when the constant-budget form's precondition holds for every stream (no
+	// class that may be empty, no NaN in a window, no poison), every group fits the streaming kernel and the leading stream is not backing
+	// off; then every stream's table gets the guess - the configured errors, clamped as lossy_budget clamps them - and status 0.
+	__device__ __forceinline__ uint32_t lossy_spec_pack(int low_error, int high_error)
+	{ // (a difference of two 16-bit values never exceeds 65 535: larger budgets decide as 65 535 does)
+		const uint32_t lo = (uint32_t)(low_error > 65535 ? 65535 : low_error), hi = (uint32_t)(high_error > 65535 ? 65535 : high_error);
+		return lo | (hi << 16);
+	}
+	__global__ __launch_bounds__(1024) void lossy_spec_begin_kernel(const LossyRun *__restrict__ table, const LossySpec *__restrict__ spec, int nstreams, int passes,
+																	unsigned int *__restrict__ ok_word, const unsigned int *__restrict__ poison)
+	{
+		__shared__ unsigned int sh_flag;
+		const int tid = threadIdx.x;
+		bool ok = lossy_const_precondition(table, nstreams, poison, &sh_flag);
+		for (int q = 0; q < nstreams; ++q)
+			ok = ok && as_global(table + q)->nsteps <= kLossyConstMaxFrames;
+		RIR_GLOBAL(unsigned int) *bk = as_global(as_global(spec)->backoff);
+		const unsigned int skip = bk[0];
+		__syncthreads();
+		if (ok && skip > 0u)
+		{ // a stream whose groups keep failing: this one goes straight to the resident kernel
+			if (tid == 0)
+				bk[0] = skip - 1u;
+			ok = false;
+		}
+		if (tid == 0)
+			__hip_atomic_store(as_global(ok_word), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		for (int q = 0; q < nstreams; ++q)
+		{
+			RIR_GLOBAL(const LossyRun) *r = as_global(table + q);
+			RIR_GLOBAL(const LossySpec) *sp = as_global(spec + q);
+			if (tid == 0)
+			{
+				RIR_GLOBAL(unsigned int) *ctl = as_global(sp->ctl);
+				ctl[0] = ok ? 0u : 2u, ctl[1] = 0u, ctl[2] = 0u, ctl[3] = (unsigned int)passes;
+				ctl[4] = ok ? 1u : 0u; // (the group was offered: rir_lossy_spec_stats)
+			}
+			if (ok)
+			{
+				const int high_error = r->high_value_error < 0 ? 0 : r->high_value_error;
+				const int low_error = r->low_value_error < high_error ? high_error : r->low_value_error;
+				const uint32_t guess = lossy_spec_pack(low_error, high_error);
+				RIR_GLOBAL(uint32_t) *bud = as_global(sp->budgets);
+				for (int k = tid; k < r->nsteps; k += 1024)
+					bud[k] = guess;
+			}
+		}
+	}
+
+	// lossy_spec_stats_kernel: grid = (slabs of a frame, frames, streams).  The six sums of frame k (h264.cpp:1993-2036) from the frames where
+	// they lie: input k (less the minimum) against output k - 1 - the stream's prevT for the group's first frame, which a pass leaves alone -
+	// split by input k > background k.  Per slab of kLossySpecSlab pixels four words, as lossy_const_run_kernel's partials.
+	__global__ __launch_bounds__(256) void lossy_spec_stats_kernel(const LossyRun *__restrict__ table, const LossySpec *__restrict__ spec)
+	{
+		__shared__ long long red[4][6];
+		const int tid = threadIdx.x, slab = blockIdx.x, k = blockIdx.y, stream = blockIdx.z, nslabs = gridDim.x;
+		RIR_GLOBAL(const LossySpec) *sp = as_global(spec + stream);
+		if (__hip_atomic_load(as_global(sp->ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+			return;
+		RIR_GLOBAL(const LossyRun) *r = as_global(table + stream);
+		if (k >= r->nsteps)
+			return;
+		const int s = r->s;
+		const size_t frame_px = (size_t)r->frame_px;
+		const uint16_t *in_k = r->in + (size_t)k * frame_px;
+		const uint16_t *prev = k == 0 ? (const uint16_t *)r->st.prevT : (const uint16_t *)r->out + (size_t)(k - 1) * frame_px;
+		const uint32_t background = (uint32_t)as_global(r->bg)[(size_t)k * r->bg_stride];
+		const int subtract_min = r->st.subtract_min;
+		const uint32_t mn = r->st.min;
+		const int i0 = slab * kLossySpecSlab, i1 = min(i0 + kLossySpecSlab, s); // (s is a multiple of 8: the callers' `runs`)
+		const uint32_t bytes = (uint32_t)i1 * 2u;
+		const __amdgpu_buffer_rsrc_t rs_in = lossy_rsrc(in_k, bytes), rs_pv = lossy_rsrc(prev, bytes);
+		uint32_t fd = 0, bd = 0, fn = 0, bn = 0;
+		long long f2 = 0, b2 = 0;
+		constexpr int kIter = kLossySpecSlab / 8 / 256; // 16-byte loads per thread and array
+		lossy_v4u a[kIter], p[kIter];
+#pragma unroll
+		for (int j = 0; j < kIter; ++j)
+		{ // (a lane past the end of the lossy rows: out of range - zeros, and nothing is counted for it below)
+			const uint32_t off = (uint32_t)(i0 / 8 + j * 256 + tid) * 16u;
+			a[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
+			p[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_pv, off, 0, 0);
+		}
+#pragma unroll
+		for (int j = 0; j < kIter; ++j)
+		{
+			const bool in = (i0 / 8 + j * 256 + tid) * 8 < i1;
+#pragma unroll
+			for (int q = 0; q < 8; ++q)
+			{
+				const uint32_t aw = a[j][q >> 1], pw = p[j][q >> 1];
+				const uint32_t v = (q & 1) ? aw >> 16 : aw & 0xffffu, o = (q & 1) ? pw >> 16 : pw & 0xffffu;
+				const uint32_t t = subtract_min ? sub_min(v, mn) : v;
+				const int32_t d = in ? abs((int32_t)t - (int32_t)o) : 0;
+				const int32_t d2 = (int32_t)((uint32_t)d * (uint32_t)d);
+				const uint32_t one = in ? 1u : 0u;
+				if (v > background)
+					fd += (uint32_t)d, f2 += d2, fn += one;
+				else
+					bd += (uint32_t)d, b2 += d2, bn += one;
+			}
+		}
+		const uint32_t wfd = lossy_wave_sum32(fd), wbd = lossy_wave_sum32(bd), wfn = lossy_wave_sum32(fn), wbn = lossy_wave_sum32(bn);
+		const long long wf2 = lossy_wave_sum(f2), wb2 = lossy_wave_sum(b2);
+		const int lane = tid & 63, wave = tid >> 6;
+		if (lane == 0)
+			red[wave][0] = (long long)wfd, red[wave][1] = wf2, red[wave][2] = (long long)wfn, red[wave][3] = (long long)wbd, red[wave][4] = wb2, red[wave][5] = (long long)wbn;
+		__syncthreads();
+		if (tid < 4)
+		{ // words: fg count << 32 | fg sum d,  fg sum d2,  bg count << 32 | bg sum d,  bg sum d2
+			const int c = tid == 0 ? 0 : tid == 1 ? 1 : tid == 2 ? 3 : 4;
+			long long val = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+			if (tid == 0 || tid == 2)
+				val |= (red[0][c + 2] + red[1][c + 2] + red[2][c + 2] + red[3][c + 2]) << 32;
+			as_global(sp->rows)[((size_t)k * nslabs + slab) * 4 + tid] = (unsigned long long)val;
+		}
+	}
+
+	// lossy_spec_verify_kernel: grid = streams, 1 024 threads, a thread per frame (two for groups of more than 1 024).  With the sums of
+	// every frame known, the statistic of every frame is known, and the budget of frame k is the reference's arithmetic (lossy_budget, operation
+	// for operation) over ITS window: the entries the stream had before the group, then the group's statistics up to k - a chain of at most
+	// 41 additions of its own.  Everything is right up to and including the first frame whose budget differs from the table's.
+	struct LossySpecWindow
+	{
+		double first[2];
+		double old[40][2]; // the window before the group, oldest first
+		int n_old, have_first;
+	};
+	__device__ __forceinline__ uint32_t lossy_spec_budget(const LossySpecWindow &w, const double (*sd)[2], int k, const LossyBudgetParams &bp)
+	{
+		const double first[2] = {w.have_first ? w.first[0] : sd[0][0], w.have_first ? w.first[1] : sd[0][1]};
+		const int total = w.n_old + k + 1;			// statistics so far, this frame's included
+		const int c = total < 40 ? total : 40;		// entries of the window once this frame's is in
+		double mean[2] = {first[0], first[1]};
+		for (int j = total - c; j < total; ++j)
+		{ // oldest to newest, as the reference adds them up
+			const double *e = j < w.n_old ? w.old[j] : sd[j - w.n_old];
+			mean[0] += e[0], mean[1] += e[1];
+		}
+		mean[0] /= (double)(c + 1);
+		mean[1] /= (double)(c + 1);
+		int low_error = bp.low_value_error, high_error = bp.high_value_error;
+		const double s0 = sd[k][0], s1 = sd[k][1];
+		if (bp.add_loss)
+		{
+			const double dh = s1 < mean[1] ? 0 : s1 - mean[1], dl = s0 < mean[0] ? 0 : s0 - mean[0];
+			high_error = sub_wrap(high_error, int_of_double_x86(round(dh * bp.std_factor)));
+			low_error = sub_wrap(low_error, int_of_double_x86(round(dl * bp.std_factor)));
+		}
+		else
+		{
+			high_error = sub_wrap(high_error, int_of_double_x86(round(fabs(s1 - mean[1]) * bp.std_factor)));
+			low_error = sub_wrap(low_error, int_of_double_x86(round(fabs(s0 - mean[0]) * bp.std_factor)));
+		}
+		if (high_error < 0)
+			high_error = 0;
+		if (low_error < high_error)
+			low_error = high_error;
+		return lossy_spec_pack(low_error, high_error);
+	}
+	__global__ __launch_bounds__(1024) void lossy_spec_verify_kernel(const LossyRun *__restrict__ table, const LossySpec *__restrict__ spec, int nslabs)
+	{
+		__shared__ double sd[kLossyConstMaxFrames][2];
+		__shared__ LossySpecWindow w;
+		__shared__ int sh_m;
+		const int tid = threadIdx.x, stream = blockIdx.x;
+		RIR_GLOBAL(const LossySpec) *sp = as_global(spec + stream);
+		RIR_GLOBAL(unsigned int) *ctl = as_global(sp->ctl);
+		if (__hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+			return;
+		RIR_GLOBAL(const LossyRun) *r = as_global(table + stream);
+		RIR_GLOBAL(const LossyBudget) *bud = as_global(r->budget);
+		const int n = r->nsteps, s = r->s;
+		const LossyBudgetParams bp = {s, r->add_loss, r->low_value_error, r->high_value_error, r->std_factor};
+		const int n_win0 = bud->n_win, head0 = bud->head;
+		if (tid < 80)
+		{
+			const int j = tid >> 1, c = tid & 1;
+			if (j < n_win0)
+				w.old[j][c] = bud->win[n_win0 < 40 ? j : (head0 + j) % 40][c];
+		}
+		if (tid == 0)
+		{
+			w.n_old = n_win0, w.have_first = bud->n_first >= 1 ? 1 : 0;
+			w.first[0] = bud->first_std[0], w.first[1] = bud->first_std[1];
+			sh_m = n;
+		}
+		RIR_GLOBAL(const lossy_v4u) *rows = reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(as_global(sp->rows));
+		for (int k = tid; k < n; k += 1024)
+		{
+			long long fd = 0, fn = 0, bd = 0, bn = 0, f2 = 0, b2 = 0;
+			for (int q = 0; q < nslabs; ++q)
+			{
+				const lossy_v4u lo = rows[((size_t)k * nslabs + q) * 2], hi = rows[((size_t)k * nslabs + q) * 2 + 1];
+				fd += (long long)lo.x, fn += (long long)lo.y, f2 += (long long)(((unsigned long long)lo.w << 32) | lo.z);
+				bd += (long long)hi.x, bn += (long long)hi.y, b2 += (long long)(((unsigned long long)hi.w << 32) | hi.z);
+			}
+			// stdDev (h264.cpp:1993-2036), as lossy_budget: unsplit while the window is not full
+			if (n_win0 + k < 40)
+			{
+				const double sum_diff = (double)(fd + bd), sum_diff2 = (double)(f2 + b2);
+				sd[k][0] = sd[k][1] = sqrt(sum_diff * sum_diff - sum_diff2) / s;
+			}
+			else
+			{
+				const double dfd = (double)fd, dfd2 = (double)f2, dbd = (double)bd, dbd2 = (double)b2;
+				sd[k][0] = sqrt(dbd * dbd - dbd2) / (int)bn;
+				sd[k][1] = sqrt(dfd * dfd - dfd2) / (int)fn;
+			}
+		}
+		__syncthreads();
+		RIR_GLOBAL(uint32_t) *tab = as_global(sp->budgets);
+		uint32_t mine[2] = {0u, 0u};
+		for (int k = tid, q = 0; k < n; k += 1024, ++q)
+		{
+			mine[q] = lossy_spec_budget(w, sd, k, bp);
+			if (mine[q] != tab[k])
+				atomicMin(&sh_m, k);
+		}
+		__syncthreads();
+		const int m = sh_m;
+		if (m == n)
+		{ // every budget of the table is the reference's: the statistics go to the commit
+			RIR_GLOBAL(double) *gsd = as_global(sp->sd);
+			for (int k = tid; k < n; k += 1024)
+				gsd[2 * k] = sd[k][0], gsd[2 * k + 1] = sd[k][1];
+			if (tid == 0)
+			{
+				ctl[1] = ctl[1] + 1u, ctl[2] = (unsigned int)n;
+				__hip_atomic_store(ctl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			return;
+		}
+		for (int k = tid, q = 0; k < n; k += 1024, ++q)
+			if (k == m)
+				tab[k] = mine[q]; // (the sums of frame m are right - every frame before it was - and so is this budget)
+		if (tid == 0)
+		{
+			const unsigned int passes = ctl[1] + 1u;
+			ctl[1] = passes, ctl[2] = (unsigned int)m;
+			if (passes >= ctl[3])
+				__hip_atomic_store(ctl, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+
+	// lossy_spec_commit_kernel: grid = (workgroups, streams).  Every stream verified: the shadow state becomes the state (a copy: 14 bytes a
+	// pixel and the ring's new images, against 6 bytes a pixel and FRAME of the passes), workgroup 0 of a stream files its window, its last
+	// decision and its budgets, and the group's word says "done" to the resident launch behind.  Anything else: nothing is touched but the
+	// leading stream's back-off.
+	__global__ __launch_bounds__(256) void lossy_spec_commit_kernel(const LossyRun *__restrict__ table, const LossySpec *__restrict__ spec, int nstreams,
+																	 unsigned int *__restrict__ ok_word)
+	{
+		__shared__ unsigned int sh_all, sh_offered;
+		const int tid = threadIdx.x, b = blockIdx.x, stream = blockIdx.y, nb = gridDim.x;
+		if (tid == 0)
+			sh_all = 1u, sh_offered = 0u;
+		__syncthreads();
+		for (int q = tid; q < nstreams; q += 256)
+		{
+			RIR_GLOBAL(unsigned int) *c = as_global(as_global(spec + q)->ctl);
+			if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
+				atomicAnd(&sh_all, 0u);
+			if (c[4] != 0u)
+				atomicOr(&sh_offered, 1u);
+		}
+		__syncthreads();
+		const bool all = sh_all != 0u, offered = sh_offered != 0u;
+		if (b == 0 && stream == 0 && tid == 0)
+		{
+			RIR_GLOBAL(unsigned int) *bk = as_global(as_global(spec)->backoff);
+			if (all)
+				bk[1] = 0u;
+			else if (offered)
+			{ // (a group that was not offered - precondition, back-off - does not count)
+				const unsigned int streak = bk[1] < 4u ? bk[1] + 1u : 4u;
+				bk[1] = streak, bk[0] = (1u << streak) - 1u;
+			}
+			__hip_atomic_store(as_global(ok_word), all ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		if (!all)
+			return;
+		RIR_GLOBAL(const LossyRun) *r = as_global(table + stream);
+		RIR_GLOBAL(const LossySpec) *sp = as_global(spec + stream);
+		const LossyDeviceState st = lossy_load_struct(&(table + stream)->st), sh = lossy_load_struct(&(spec + stream)->shadow);
+		const int s = r->s, full = r->full, n = r->nsteps, ra = st.running_average;
+		// 16 bytes a thread and round; s and full are multiples of 8 pixels
+		auto copy16 = [&](void *dst_, const void *src_, size_t bytes) {
+			RIR_GLOBAL(lossy_v4u) *dst = reinterpret_cast<RIR_GLOBAL(lossy_v4u) *>(as_global((char *)dst_));
+			RIR_GLOBAL(const lossy_v4u) *src = reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(as_global((const char *)src_));
+			for (size_t i = (size_t)b * 256 + tid; i < bytes / 16; i += (size_t)nb * 256)
+				dst[i] = src[i];
+		};
+		copy16(st.refT, sh.refT, (size_t)s * 2);
+		copy16(st.prevT, sh.prevT, (size_t)s * 2);
+		copy16(st.lastDL, sh.lastDL, (size_t)full * 2);
+		if (ra > 0)
+		{
+			copy16(st.ra_sums, sh.ra_sums, (size_t)s * 4);
+			copy16(st.ra_const_value, sh.ra_const_value, (size_t)s * 2);
+			copy16(st.ra_const_count, sh.ra_const_count, (size_t)s * 2);
+			// the ring's new images: the group's last min(ra, n) inputs, each in the slot after the one before (lossy_const_run_kernel's wr_slot)
+			const int wr0 = (st.ra_head + (st.ra_count == ra ? 0 : st.ra_count)) % ra;
+			const int nw = n < ra ? n : ra;
+			for (int j = 0; j < nw; ++j)
+			{
+				const int slot = (wr0 + (n - nw) + j) % ra;
+				copy16(st.ra_images + (size_t)slot * s, sh.ra_images + (size_t)slot * s, (size_t)s * 2);
+			}
+		}
+		if (b != 0)
+			return;
+		// the budget state after the group's n frames: the window's last 40 statistics, the seed, the last decision; the budgets of the frames
+		RIR_GLOBAL(LossyBudget) *bud = as_global(r->budget);
+		RIR_GLOBAL(const double) *gsd = as_global(sp->sd);
+		RIR_GLOBAL(const uint32_t) *tab = as_global(sp->budgets);
+		if (tid == 0)
+		{
+			if (bud->n_first < 1)
+			{
+				bud->first_std[0] = gsd[0], bud->first_std[1] = gsd[1];
+				bud->n_first = 1;
+			}
+			int n_win = bud->n_win, head = bud->head;
+			// (frames that have left the window by the end of the group only move the counters)
+			const int tail0 = n > 40 ? n - 40 : 0;
+			{
+				const int fill = tail0 < 40 - n_win ? tail0 : 40 - n_win;
+				n_win += fill;
+				head = (head + (tail0 - fill)) % 40;
+			}
+			for (int k = tail0; k < n; ++k)
+			{
+				if (n_win < 40)
+				{
+					bud->win[n_win][0] = gsd[2 * k], bud->win[n_win][1] = gsd[2 * k + 1];
+					++n_win;
+				}
+				else
+				{
+					bud->win[head][0] = gsd[2 * k], bud->win[head][1] = gsd[2 * k + 1];
+					head = head == 39 ? 0 : head + 1;
+				}
+			}
+			bud->n_win = n_win, bud->head = head;
+			RIR_GLOBAL(LossyDecision) *gd = as_global(r->decision);
+			gd->background = (uint32_t)as_global(r->bg)[(size_t)(n - 1) * r->bg_stride];
+			gd->low_error = (int)(tab[n - 1] & 0xffffu), gd->high_error = (int)(tab[n - 1] >> 16);
+		}
+		if (r->errors_out)
+		{ // (the callers only offer streams whose configured errors are below 65 536: the table's fields ARE the budgets)
+			RIR_GLOBAL(int) *e = as_global(r->errors_out);
+			for (int k = tid; k < n; k += 256)
+				e[2 * k] = (int)(tab[k] & 0xffffu), e[2 * k + 1] = (int)(tab[k] >> 16);
 		}
 	}
 
@@ -2455,13 +2880,13 @@ namespace rir
 #define RIR_CONST_LAUNCH(NPV)                                                                                                                  \
 	{                                                                                                                                          \
 		if (any_ra && add_loss)                                                                                                                \
-			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, true, true>), grid, dim3(256), 0, st, d_table, nstreams, d_ok, d_poison);          \
+			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, true, true>), grid, dim3(256), 0, st, d_table, nstreams, d_ok, d_poison, (const LossySpec *)nullptr);          \
 		else if (any_ra)                                                                                                                       \
-			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, true, false>), grid, dim3(256), 0, st, d_table, nstreams, d_ok, d_poison);         \
+			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, true, false>), grid, dim3(256), 0, st, d_table, nstreams, d_ok, d_poison, (const LossySpec *)nullptr);         \
 		else if (add_loss)                                                                                                                     \
-			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, false, true>), grid, dim3(256), 0, st, d_table, nstreams, d_ok, d_poison);         \
+			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, false, true>), grid, dim3(256), 0, st, d_table, nstreams, d_ok, d_poison, (const LossySpec *)nullptr);         \
 		else                                                                                                                                   \
-			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, false, false>), grid, dim3(256), 0, st, d_table, nstreams, d_ok, d_poison);        \
+			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, false, false>), grid, dim3(256), 0, st, d_table, nstreams, d_ok, d_poison, (const LossySpec *)nullptr);        \
 	}
 		if (np == 4)
 			RIR_CONST_LAUNCH(4)
@@ -2471,6 +2896,48 @@ namespace rir
 			RIR_CONST_LAUNCH(1)
 #undef RIR_CONST_LAUNCH
 		hipLaunchKernelGGL(lossy_const_finish_kernel, dim3((unsigned)nstreams), dim3(1024), 0, st, d_table, nb, (const unsigned int *)d_ok);
+		return hipGetLastError();
+	}
+
+	hipError_t launch_lossy_spec_begin(const LossyRun *d_table, const LossySpec *d_spec, int nstreams, int passes, unsigned int *d_ok, const unsigned int *d_poison, hipStream_t st)
+	{
+		hipLaunchKernelGGL(lossy_spec_begin_kernel, dim3(1), dim3(1024), 0, st, d_table, d_spec, nstreams, passes, d_ok, d_poison);
+		return hipGetLastError();
+	}
+	hipError_t launch_lossy_spec_pass(const LossyRun *d_table, const LossySpec *d_spec, int nstreams, int s, int full, int max_frames, bool any_ra, bool add_loss, hipStream_t st)
+	{
+		const int np = lossy_const_pairs(full, nstreams), nb = lossy_const_workgroups(full, nstreams);
+		const dim3 grid((unsigned)nb, (unsigned)nstreams);
+#define RIR_SPEC_LAUNCH(NPV)                                                                                                                                      \
+	{                                                                                                                                                             \
+		if (any_ra && add_loss)                                                                                                                                   \
+			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, true, true, true>), grid, dim3(256), 0, st, d_table, nstreams, (unsigned int *)nullptr, (const unsigned int *)nullptr, d_spec);   \
+		else if (any_ra)                                                                                                                                          \
+			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, true, false, true>), grid, dim3(256), 0, st, d_table, nstreams, (unsigned int *)nullptr, (const unsigned int *)nullptr, d_spec);  \
+		else if (add_loss)                                                                                                                                        \
+			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, false, true, true>), grid, dim3(256), 0, st, d_table, nstreams, (unsigned int *)nullptr, (const unsigned int *)nullptr, d_spec);  \
+		else                                                                                                                                                      \
+			hipLaunchKernelGGL((lossy_const_run_kernel<NPV, false, false, true>), grid, dim3(256), 0, st, d_table, nstreams, (unsigned int *)nullptr, (const unsigned int *)nullptr, d_spec); \
+	}
+		if (np == 4)
+			RIR_SPEC_LAUNCH(4)
+		else if (np == 2)
+			RIR_SPEC_LAUNCH(2)
+		else
+			RIR_SPEC_LAUNCH(1)
+#undef RIR_SPEC_LAUNCH
+		const int nslabs = lossy_spec_stat_workgroups(s);
+		hipLaunchKernelGGL(lossy_spec_stats_kernel, dim3((unsigned)nslabs, (unsigned)max_frames, (unsigned)nstreams), dim3(256), 0, st, d_table, d_spec);
+		hipLaunchKernelGGL(lossy_spec_verify_kernel, dim3((unsigned)nstreams), dim3(1024), 0, st, d_table, d_spec, nslabs);
+		return hipGetLastError();
+	}
+	hipError_t launch_lossy_spec_commit(const LossyRun *d_table, const LossySpec *d_spec, int nstreams, int s, int full, unsigned int *d_ok, hipStream_t st)
+	{
+		(void)s;
+		int nb = (full / 8 + 255) / 256; // 16 bytes a thread
+		if (nb > 256)
+			nb = 256;
+		hipLaunchKernelGGL(lossy_spec_commit_kernel, dim3((unsigned)nb, (unsigned)nstreams), dim3(256), 0, st, d_table, d_spec, nstreams, d_ok);
 		return hipGetLastError();
 	}
 

@@ -183,6 +183,8 @@ namespace
 		int frames = 0;
 		DeviceBuffer d_img, d_tmp, d_out, d_ref, d_prev, d_last, d_sums, d_cval, d_ccnt, d_ring, d_hist, d_stats, d_min, d_budget, d_decision, d_errs, d_tickets;
 		LossyDeviceState dev{};
+		DeviceBuffer d_shadow;		   // the speculative form of a run (lossy_kernels.h: LossySpec): where a pass leaves the state after the group
+		LossyDeviceState shadow{};	   // ... carved out of it (reserve_shadow)
 		int bp_handle = 0;
 
 		~LossyState()
@@ -331,6 +333,28 @@ namespace
 			p.do_update = 1, p.reserved2 = 0;
 			return p;
 		}
+		// the shadow arrays of the speculative form, allocated when a stream is first offered to it: as the state's own, ring included
+		bool reserve_shadow()
+		{
+			if (shadow.refT)
+				return true;
+			const size_t full = (size_t)w * h, s = (size_t)w * hl;
+			auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+			const size_t ring = (size_t)std::max(dev.running_average, 1) * s * 2 + 16;
+			const size_t total = 3 * up(full * 2 + 16) + up(s * 4 + 16) + 2 * up(s * 2 + 16) + up(ring);
+			if (!d_shadow.reserve(total))
+				return false;
+			char *p = d_shadow.as<char>();
+			shadow = dev;
+			shadow.refT = reinterpret_cast<uint16_t *>(p), p += up(full * 2 + 16);
+			shadow.prevT = reinterpret_cast<uint16_t *>(p), p += up(full * 2 + 16);
+			shadow.lastDL = reinterpret_cast<uint16_t *>(p), p += up(full * 2 + 16);
+			shadow.ra_sums = reinterpret_cast<uint32_t *>(p), p += up(s * 4 + 16);
+			shadow.ra_const_value = reinterpret_cast<uint16_t *>(p), p += up(s * 2 + 16);
+			shadow.ra_const_count = reinterpret_cast<int16_t *>(p), p += up(s * 2 + 16);
+			shadow.ra_images = reinterpret_cast<uint16_t *>(p);
+			return true;
+		}
 		void advance_ring()
 		{
 			if (dev.running_average > 0)
@@ -357,6 +381,10 @@ namespace
 		DeviceBuffer run_hist, run_tickets, run_bg; // runs of frames: histogram slices and tickets of a group of frames, backgrounds of the call
 	DeviceBuffer const_ok, const_partials;		// constant-budget form: one word per group of the last call (1 = stepped by it), the tail frames' sums
 	int const_groups = 0;						// groups of the last run call that were OFFERED to the constant-budget form (0: it was not eligible)
+	// speculative form (lossy_kernels.h: LossySpec): the budget tables, sums and statistics of a group (reused group after group), the control
+	// words of every group and stream of the last call, and - for good - the back-off words of the calls this stream leads
+	DeviceBuffer spec_budgets, spec_rows, spec_sd, spec_ctl, spec_backoff;
+	int spec_groups = 0, spec_streams = 0;		// groups (and streams) of the last run call that went through the speculative launches (0: not eligible)
 		PinnedBuffer multi_stage;
 		hipEvent_t multi_copied = nullptr; // the copy out of multi_stage of the last call (whatever its stream) has completed
 		// A resident run that gave up a wait has advanced the stream's state with invalid frames: the failure is STICKY - every
@@ -3324,19 +3352,31 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 		}
 		for (int i = 0; i < nstreams; ++i)
 			const_form = const_form && os[i]->std_factor == 0.0;
+		// The speculative form (lossy_kernels.h: LossySpec): budgets that follow the statistics (stdFactor != 0, the reference's default) are guessed -
+		// the configured errors, what a scene that does not move gets - and verified on the device; a group whose guess does not verify within
+		// `spec_passes` corrections is left to the resident kernel, exactly as a declined constant-budget group is.
+		bool spec_form = persistent && !const_form && !getenv("RIR_LOSSY_NO_SPEC");
+		for (int i = 0; i < nstreams; ++i)
+			spec_form = spec_form && os[i]->low <= 65535 && os[i]->high <= 65535; // (the budget table holds 16-bit fields)
+		int spec_passes = 3;
+		if (const char *pe = getenv("RIR_LOSSY_SPEC_PASSES"))
+			spec_passes = std::max(1, std::min(8, atoi(pe)));
+		const bool stream_form = const_form || spec_form; // a streaming kernel steps whole groups: long ones
 		// frames per histogram launch (one 64 KB histogram slice per frame and stream).  A group costs four small launches beside its
 		// frames, so streams that may take the constant-budget form - 0.1 us per stream-frame - get groups four times as long (up to
 		// 512 MB of slices, allocated as needed; 32 streams x 200 frames: 64-frame groups 0.83 M frames/s, one group 1.2 M)
-		int group = std::min(kLossyConstMaxFrames, std::max(1, (persistent ? (const_form ? 8192 : 2048) : 512) / nstreams));
+		int group = std::min(kLossyConstMaxFrames, std::max(1, (persistent ? (stream_form ? 8192 : 2048) : 512) / nstreams));
 		// (the constant-budget kernel addresses a group's frames with 32-bit offsets below 2^31: groups of large frames are cut to fit -
 		// 64 = the longest ring, 8 = the most frames it keeps in flight; lossy_const_run_kernel decides for itself, this only keeps it fast)
-		if (const_form)
+		if (stream_form)
 			group = (int)std::max<long long>(1, std::min<long long>(group, 0x7fffffffll / ((long long)npx * 2) - 64 - 8));
 		const int ngroups = runs ? (nsteps + group - 1) / group : 0;
 		const size_t nfused = persistent ? 0 : runs ? (size_t)(nsteps + 1) * nstreams : (size_t)nsteps * nstreams, nbg = runs ? (size_t)nsteps * nstreams : 0,
 					 nhist = persistent ? 0 : nbg; // (the resident / constant-budget path takes its backgrounds straight from the runs' descriptions: no per-frame table)
 		const size_t run_off = (nfused + nhist) * sizeof(LossyStep); // (a multiple of 8)
-		const size_t nb = run_off + (persistent ? (size_t)ngroups * nstreams * sizeof(LossyRun) : 0);
+		const size_t spec_off = run_off + (persistent ? (size_t)ngroups * nstreams * sizeof(LossyRun) : 0);
+		static_assert(sizeof(LossyRun) % 8 == 0 && sizeof(LossySpec) % 8 == 0, "the tables of a call lie behind each other in one buffer");
+		const size_t nb = spec_off + (persistent && spec_form ? (size_t)ngroups * nstreams * sizeof(LossySpec) : 0);
 		if (!lead.multi_table.reserve(nb) || !lead.multi_stage.reserve(nb))
 			return -1;
 		// an earlier call's copy out of the staging buffer may still be in flight - on whatever stream that call was given
@@ -3407,10 +3447,30 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 						return -1;
 					lead.const_groups = ngroups;
 				}
+				lead.spec_groups = 0;
+				const int spec_slabs = lossy_spec_stat_workgroups(s_px);
+				const size_t spec_group = (size_t)std::min(nsteps, group);
+				if (spec_form)
+				{
+					const size_t bk_cap = lead.spec_backoff.cap;
+					if (!lead.const_ok.reserve((size_t)ngroups * 4) || !hip_ok(hipMemsetAsync(lead.const_ok.ptr, 0, (size_t)ngroups * 4, st), "memset") ||
+						!lead.spec_budgets.reserve((size_t)nstreams * (spec_group + 8) * 4) || !lead.spec_rows.reserve((size_t)nstreams * spec_group * spec_slabs * 32) ||
+						!lead.spec_sd.reserve((size_t)nstreams * spec_group * 16) || !lead.spec_ctl.reserve((size_t)ngroups * nstreams * 32) ||
+						!hip_ok(hipMemsetAsync(lead.spec_ctl.ptr, 0, (size_t)ngroups * nstreams * 32, st), "memset") || !lead.spec_backoff.reserve(8))
+						return -1;
+					if (lead.spec_backoff.cap != bk_cap && !hip_ok(hipMemsetAsync(lead.spec_backoff.ptr, 0, 8, st), "memset"))
+						return -1;
+					for (int i = 0; i < nstreams; ++i)
+						if (!os[i]->st.reserve_shadow())
+							return -1;
+					lead.spec_groups = ngroups, lead.spec_streams = nstreams;
+				}
 				unsigned int *d_ticket = lead.run_exchange.as<unsigned int>(), *d_error = d_ticket + 16;
 				unsigned long long *d_exch = reinterpret_cast<unsigned long long *>(lead.run_exchange.as<char>() + 256);
 				LossyRun *hr = reinterpret_cast<LossyRun *>(reinterpret_cast<char *>(hs) + run_off);
 				const LossyRun *dr = reinterpret_cast<const LossyRun *>(lead.multi_table.as<char>() + run_off);
+				LossySpec *hsp = reinterpret_cast<LossySpec *>(reinterpret_cast<char *>(hs) + spec_off);
+				const LossySpec *dsp = reinterpret_cast<const LossySpec *>(lead.multi_table.as<char>() + spec_off);
 				for (int g = 0; g < ngroups; ++g)
 				{
 					const int k0 = g * group, in_group = std::min(group, nsteps - k0);
@@ -3430,6 +3490,18 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 						r.add_loss = add_loss ? 1 : 0, r.low_value_error = os[i]->low, r.high_value_error = os[i]->high, r.std_factor = os[i]->std_factor;
 						r.partials = const_form ? lead.const_partials.as<unsigned long long>() + (size_t)i * part_words : nullptr;
 						hr[(size_t)g * nstreams + i] = r;
+						if (spec_form)
+						{
+							LossySpec sp{};
+							sp.shadow = ls.shadow;
+							sp.shadow.ra_count = ls.dev.ra_count, sp.shadow.ra_head = ls.dev.ra_head, sp.shadow.running_average = ls.dev.running_average;
+							sp.budgets = lead.spec_budgets.as<uint32_t>() + (size_t)i * (spec_group + 8);
+							sp.rows = lead.spec_rows.as<unsigned long long>() + (size_t)i * spec_group * spec_slabs * 4;
+							sp.sd = lead.spec_sd.as<double>() + (size_t)i * spec_group * 2;
+							sp.ctl = lead.spec_ctl.as<unsigned int>() + ((size_t)g * nstreams + i) * 8;
+							sp.backoff = lead.spec_backoff.as<unsigned int>();
+							hsp[(size_t)g * nstreams + i] = sp;
+						}
 						for (int k = k0; k < k0 + in_group; ++k)
 						{ // (the host side of the stream's state as it will be after the group)
 							ls.advance_ring();
@@ -3461,7 +3533,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 								"lossy backgrounds") ||
 						!hip_ok(hipMemsetAsync(d_exch, 0, exch_bytes, st), "memset"))
 						return -1;
-					const unsigned int *d_ok = const_form ? lead.const_ok.as<unsigned int>() + g : nullptr;
+					const unsigned int *d_ok = stream_form ? lead.const_ok.as<unsigned int>() + g : nullptr;
 					bool any_ra = false;
 					for (int i = 0; i < nstreams; ++i)
 						any_ra = any_ra || os[i]->st.dev.running_average > 0;
@@ -3469,6 +3541,20 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 																  d_ticket + kLossyRunCtlWord + 2, st),
 											  "lossy constant-budget run"))
 						return -1;
+					if (spec_form)
+					{ // guess, (step, sums, verify) x passes, commit: every launch returns at once when the one before left it nothing to do
+						if (!hip_ok(launch_lossy_spec_begin(dr + (size_t)g * nstreams, dsp + (size_t)g * nstreams, nstreams, spec_passes, lead.const_ok.as<unsigned int>() + g,
+															 d_ticket + kLossyRunCtlWord + 2, st),
+									"lossy speculative run"))
+							return -1;
+						for (int pass = 0; pass < spec_passes; ++pass)
+							if (!hip_ok(launch_lossy_spec_pass(dr + (size_t)g * nstreams, dsp + (size_t)g * nstreams, nstreams, s_px, full_px, in_group, any_ra, add_loss != 0, st),
+										"lossy speculative pass"))
+								return -1;
+						if (!hip_ok(launch_lossy_spec_commit(dr + (size_t)g * nstreams, dsp + (size_t)g * nstreams, nstreams, s_px, full_px, lead.const_ok.as<unsigned int>() + g, st),
+									"lossy speculative commit"))
+							return -1;
+					}
 					for (int s0 = 0; s0 < nstreams; s0 += batch)
 					{
 						const int nl = std::min(batch, nstreams - s0);
@@ -3689,6 +3775,39 @@ RIR_EXPORT int rir_lossy_path_stats(int handle, int *out2, void *stream)
 			return -1;
 		for (unsigned int v : w)
 			out2[1] += v != 0 ? 1 : 0;
+	}
+	return 0;
+}
+
+// The speculative form's books for the last run call this stream LED: out[0] = groups that went through its launches (0: the call was not
+// eligible - stdFactor 0, frames stepped one by one, ...), out[1] = of those, groups that were offered (precondition held, no back-off),
+// out[2] = groups it committed, out[3] = passes over all groups (a group's passes: the most any of its streams took).  Waits for `stream`.
+RIR_EXPORT int rir_lossy_spec_stats(int handle, int *out4, void *stream)
+{
+	auto o = lookup_as<LossyObject>(handle);
+	if (!o || !out4)
+	{
+		log_error("rir_lossy_spec_stats: invalid argument");
+		return -1;
+	}
+	out4[0] = o->spec_groups, out4[1] = out4[2] = out4[3] = 0;
+	if (o->spec_groups > 0)
+	{
+		const size_t ng = (size_t)o->spec_groups, ns = (size_t)o->spec_streams;
+		std::vector<unsigned int> w(ng * ns * 8), okw(ng);
+		if (!hip_ok(hipMemcpyAsync(w.data(), o->spec_ctl.ptr, w.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)stream), "D2H") ||
+			!hip_ok(hipMemcpyAsync(okw.data(), o->const_ok.ptr, okw.size() * 4, hipMemcpyDeviceToHost, (hipStream_t)stream), "D2H") ||
+			!hip_ok(wait_stream((hipStream_t)stream), "sync"))
+			return -1;
+		for (size_t g = 0; g < ng; ++g)
+		{
+			unsigned int passes = 0;
+			for (size_t i = 0; i < ns; ++i)
+				passes = std::max(passes, w[(g * ns + i) * 8 + 1]);
+			out4[1] += w[g * ns * 8 + 4] != 0 ? 1 : 0;
+			out4[2] += okw[g] != 0 ? 1 : 0;
+			out4[3] += (int)passes;
+		}
 	}
 	return 0;
 }

@@ -122,6 +122,7 @@ _lib.rir_lossy_step_multi_device.argtypes = [_vp, ct.c_int, _vp, _vp, ct.c_int, 
 _lib.rir_lossy_destroy.argtypes = [ct.c_int]
 _lib.rir_lossy_status.argtypes = [ct.c_int, _vp]
 _lib.rir_lossy_path_stats.argtypes = [ct.c_int, ct.POINTER(ct.c_int), _vp]
+_lib.rir_lossy_spec_stats.argtypes = [ct.c_int, ct.POINTER(ct.c_int), _vp]
 _lib.rir_lossy_set_errors.argtypes = [ct.c_int, ct.c_int, ct.c_int, ct.c_double]
 _lib.rir_split_planes_device.argtypes = [_vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp, _vp]
 _lib.rir_merge_planes_device.argtypes = [_vp, _vp, _vp, ct.c_int, ct.c_int, ct.c_int, ct.c_int, _vp, _vp, _vp]
@@ -768,6 +769,13 @@ class LossyStream:
         out = (ct.c_int * 2)()
         _check(_lib.rir_lossy_path_stats(self.handle, out, _stream()), "rir_lossy_path_stats")
         return int(out[0]), int(out[1])
+
+    def spec_stats(self):
+        """the speculative form's books for the last batch this stream led: (groups through its launches, groups offered, groups committed,
+        passes over all groups); waits"""
+        out = (ct.c_int * 4)()
+        _check(_lib.rir_lossy_spec_stats(self.handle, out, _stream()), "rir_lossy_spec_stats")
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3])
 
     def status(self):
         """raises when a queue-only ``step`` / ``step_many`` led by this stream went wrong on the device (waits for the stream)"""

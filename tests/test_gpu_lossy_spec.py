@@ -1,0 +1,199 @@
+"""GPU: the SPECULATIVE form of a bounded-loss run - budgets that follow the statistics (stdFactor != 0: the reference's defaults 6 / 2 / 5 / 32,
+h264.cpp:1662-1665; budget :2335-2385) guessed, stepped by the streaming kernel into shadow state, verified frame by frame on the device,
+corrected and stepped again, or left to the general form.  Whatever path a group takes, frames and budgets are the oracle's, bit for bit;
+which path it took is asserted through rir_lossy_spec_stats."""
+import numpy as np
+import pytest
+
+from librir_amd.synthetic import s1_noisy_background
+from test_gpu_lossy import CONST_CASES, _oracle_track
+
+pytestmark = pytest.mark.gpu
+
+
+def static_scene(n, h, w, seed, sigma=0.7, levels=1000.0):
+    """a scene that does not move: a fixed background and sensor noise (the S1 recipe of SURVEY §8d without its +1 level per frame)"""
+    rng = np.random.default_rng(seed)
+    bg = rng.random((h, w)) * levels
+    return np.stack([(bg + 10 + rng.normal(0, sigma, (h, w))).astype(np.uint16) for _ in range(n)])
+
+
+@pytest.fixture(autouse=True)
+def _plain_paths(monkeypatch):
+    for k in ("RIR_LOSSY_LAUNCH_PER_FRAME", "RIR_LOSSY_RUN_MAX_WORKGROUPS", "RIR_LOSSY_NO_SPEC", "RIR_LOSSY_SPEC_PASSES", "RIR_LOSSY_RUN_FORM"):
+        monkeypatch.delenv(k, raising=False)
+
+
+def _run_cuts(ls, t, cuts, add_loss=False):
+    """steps the stream call by call; returns frames, budgets and the speculative form's books of every call"""
+    import torch
+
+    got, lo, hi, books = [], [], [], []
+    for c0, c1 in zip(cuts[:-1], cuts[1:]):
+        o, l_, h_ = ls.step(t[c0:c1], add_loss=add_loss and c0 > 0)
+        got.append(o), lo.append(l_), hi.append(h_)
+        books.append(ls.spec_stats())
+    return torch.cat(got).cpu().numpy(), np.concatenate(lo).tolist(), np.concatenate(hi).tolist(), books
+
+
+@pytest.mark.parametrize("add_loss", [False, True], ids=["add_image_lossy", "add_loss"])
+@pytest.mark.parametrize("name", list(CONST_CASES))
+def test_static_scene_with_default_std_factor_is_committed(oracle, name, add_loss, monkeypatch):
+    """Every case of the constant-budget tests (ring lengths 0 .. 64, short calls, subtractMin, high above low, both decision variants) with
+    stdFactor 5 on a scene that does not move: the guess verifies at the first pass - or, where a small frame's statistic moves a budget by
+    one level now and then, one pass later per such frame - every group is committed, and frames, budgets and the state handed from call to
+    call are the oracle's."""
+    import torch
+
+    from librir_amd import device as D
+
+    monkeypatch.setenv("RIR_LOSSY_SPEC_PASSES", "8")
+    c = CONST_CASES[name]
+    h, w, hl = 64, 96, 64 - (c["h"] - c["hl"])  # (frames large enough for a steady statistic: 40x64 scenes move their own budgets every few frames)
+    arr = static_scene(c["n"], h, w, seed=71)
+    exp, elo, ehi = _oracle_track(oracle, arr, w, h, hl, c["low"], c["high"], 5.0, c["ra"], c.get("subtract_min", False), add_loss)
+    high = max(c["high"], 0)
+    guess = (max(c["low"], high), high)
+    moved = [i for i in range(c["n"]) if (elo[i], ehi[i]) != guess]
+    assert len(moved) <= 3, "the scene moves its budgets: not what this test is about"
+    ls = D.LossyStream(w, h, hl, c["low"], c["high"], 5.0, c["ra"], subtract_min=c.get("subtract_min", False))
+    got, lo, hi, books = _run_cuts(ls, torch.from_numpy(arr).cuda(), c["cuts"], add_loss)
+    assert np.array_equal(got, exp)
+    assert lo == elo and hi == ehi
+    for (c0, c1), (through, offered, committed, passes) in zip(zip(c["cuts"][:-1], c["cuts"][1:]), books):
+        steps = (c1 - c0) - (1 if c0 == 0 else 0)
+        if c1 - c0 >= 3 and steps >= 2:
+            here = sum(1 for i in moved if c0 <= i < c1)
+            assert through == 1 and offered == 1 and committed == 1 and passes == 1 + here, (name, c0, c1, through, offered, committed, passes, moved)
+    assert ls.path_stats() == (0, 0)  # (the constant-budget form's books: not its call)
+    ls.close()
+
+
+def test_events_in_a_static_scene_take_further_passes(oracle, monkeypatch):
+    """A weak flash moves the budget of one frame: the first pass finds it, the second verifies.  A stronger one moves three frames' budgets
+    (the flash, the frame after it, and the frame at which the flash leaves the 40-frame window... whatever the oracle says): with three
+    passes allowed the group is left to the general form, with four it is committed.  Same frames and budgets either way."""
+    import torch
+
+    from librir_amd import device as D
+
+    n, h, w, hl = 150, 64, 96, 61
+    base = static_scene(n, h, w, seed=41)
+    for amp, passes_allowed, want in ((2, 3, "committed"), (5, 3, "fallback"), (5, 8, "committed")):
+        arr = base.copy()
+        arr[80, 20:40, 30:60] += amp
+        exp, elo, ehi = _oracle_track(oracle, arr, w, h, hl, 6, 2, 5.0, 32)
+        moved = [i for i in range(n) if (elo[i], ehi[i]) != (6, 2)]
+        assert 1 <= len(moved) <= 6, moved
+        monkeypatch.setenv("RIR_LOSSY_SPEC_PASSES", str(passes_allowed))
+        ls = D.LossyStream(w, h, hl, 6, 2, 5.0, 32)
+        got, lo, hi, books = _run_cuts(ls, torch.from_numpy(arr).cuda(), [0, n])
+        assert np.array_equal(got, exp), (amp, passes_allowed)
+        assert lo == elo and hi == ehi
+        through, offered, committed, passes = books[0]
+        assert through == 1 and offered == 1, books
+        if want == "committed":
+            assert committed == 1 and passes == len(moved) + 1, (amp, passes_allowed, books, moved)
+        else:
+            assert len(moved) + 1 > passes_allowed and committed == 0 and passes == passes_allowed, (amp, passes_allowed, books, moved)
+        ls.close()
+
+
+def test_budgets_that_move_every_frame_fall_back_and_the_stream_backs_off(oracle):
+    """The S1 recipe (one level up per frame) under the default parameters moves its budget nearly every frame: nothing to guess.  The group
+    is left to the general form after the allowed passes, and the stream is not offered again for 1, 3, 7 ... groups.  Bit-exact throughout."""
+    import torch
+
+    from librir_amd import device as D
+
+    n, h, w, hl = 241, 64, 96, 61
+    arr = s1_noisy_background(n, h, w, seed=11)
+    exp, elo, ehi = _oracle_track(oracle, arr, w, h, hl, 6, 2, 5.0, 32)
+    assert sum(1 for i in range(1, n) if (elo[i], ehi[i]) != (6, 2)) > n // 2, "the stream does not move its budgets"
+    ls = D.LossyStream(w, h, hl, 6, 2, 5.0, 32)
+    cuts = [0] + list(range(1, n + 1, 30))
+    got, lo, hi, books = _run_cuts(ls, torch.from_numpy(arr).cuda(), cuts)
+    assert np.array_equal(got, exp)
+    assert lo == elo and hi == ehi
+    # calls of 30 frames = one group each: failed, skipped, failed, skipped x 3, failed, ...
+    assert [b[:3] for b in books[1:]] == [(1, 1, 0), (1, 0, 0), (1, 1, 0), (1, 0, 0), (1, 0, 0), (1, 0, 0), (1, 1, 0), (1, 0, 0)], books
+    assert all(b[3] == (3 if b[1] else 0) for b in books[1:]), books
+    ls.close()
+
+
+def test_streams_of_one_call_are_committed_together_or_not_at_all(oracle):
+    """Streams that share their launches: every stream's guess must verify for the group to be committed.  Static scenes side by side are
+    committed; with one stream that moves its budgets among them the group goes to the general form for all - every stream its own oracle's."""
+    import torch
+
+    from librir_amd import device as D
+
+    n, h, w, hl = 90, 64, 96, 61
+    params = [(6, 2, 5.0, 32), (4, 2, 2.5, 8), (5, 1, 5.0, 0), (3, 3, 0.0, 4)]  # (the last one: stdFactor 0 among the others - its guess is its budget)
+    for mover in (None, 2):
+        arrs = [static_scene(n, h, w, seed=80 + i) for i in range(len(params))]
+        if mover is not None:
+            arrs[mover] = s1_noisy_background(n, h, w, seed=90)
+        exps = [_oracle_track(oracle, arrs[i], w, h, hl, *params[i]) for i in range(len(params))]
+        streams = [D.LossyStream(w, h, hl, *p) for p in params]
+        ins = [torch.from_numpy(a).cuda() for a in arrs]
+        outs, lo, hi = D.LossyStream.step_many(streams, ins)
+        through, offered, committed, passes = streams[0].spec_stats()
+        assert through == 1 and offered == 1 and committed == (1 if mover is None else 0), (mover, through, offered, committed, passes)
+        for i in range(len(params)):
+            assert np.array_equal(outs[i].cpu().numpy(), exps[i][0]), (mover, i)
+            assert lo[i].tolist() == exps[i][1] and hi[i].tolist() == exps[i][2], (mover, i)
+        for s_ in streams:
+            s_.close()
+
+
+def test_full_size_static_stream_with_defaults(oracle):
+    """640x512, the reference's default parameters, calls of 150 frames (one group each, the ring filling inside the first): committed, bit-exact."""
+    import torch
+
+    from librir_amd import device as D
+
+    n, h, w, hl = 300, 512, 640, 509
+    arr = static_scene(n, h, w, seed=5)
+    exp, elo, ehi = _oracle_track(oracle, arr, w, h, hl, 6, 2, 5.0, 32)
+    ls = D.LossyStream(w, h, hl, 6, 2, 5.0, 32)
+    got, lo, hi, books = _run_cuts(ls, torch.from_numpy(arr).cuda(), [0, 150, 300])
+    assert np.array_equal(got, exp)
+    assert lo == elo and hi == ehi
+    assert [b[:3] for b in books] == [(1, 1, 1), (1, 1, 1)], books
+    ls.close()
+
+
+def test_switching_the_form_off_changes_nothing(oracle, monkeypatch):
+    """RIR_LOSSY_NO_SPEC: the general form alone - the same frames and budgets (what the speculative form is checked against in the field)."""
+    import torch
+
+    from librir_amd import device as D
+
+    n, h, w, hl = 80, 64, 96, 61
+    arr = static_scene(n, h, w, seed=3)
+    exp, elo, ehi = _oracle_track(oracle, arr, w, h, hl, 6, 2, 5.0, 32)
+    monkeypatch.setenv("RIR_LOSSY_NO_SPEC", "1")
+    ls = D.LossyStream(w, h, hl, 6, 2, 5.0, 32)
+    got, lo, hi, books = _run_cuts(ls, torch.from_numpy(arr).cuda(), [0, n])
+    assert np.array_equal(got, exp) and lo == elo and hi == ehi
+    assert books[0] == (0, 0, 0, 0)
+    ls.close()
+
+
+def test_default_parameters_through_the_saver(tmp_path, oracle):
+    """h264_add_image_lossy with the reference's defaults on a static scene: the saver's deferred runs take the same launches; the file holds
+    the oracle's frames and the per-frame budgets it reports are the oracle's."""
+    from librir_amd.video_io import IRMovie, IRSaver
+
+    n, h, w, hl = 130, 64, 96, 61
+    arr = static_scene(n, h, w, seed=23)
+    exp, elo, ehi = _oracle_track(oracle, arr, w, h, hl, 6, 2, 5.0, 32)
+    dst = tmp_path / "static.h264"
+    with IRSaver(dst, w, h, hl) as s:
+        for i in range(n):
+            s.add_image_lossy(arr[i], i * 1000)
+        low, high = list(s.get_low_errors()), list(s.get_high_errors())
+    assert low == elo and high == ehi
+    with IRMovie.from_filename(dst) as mov:
+        assert np.array_equal(mov.data, exp)
