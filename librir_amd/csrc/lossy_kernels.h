@@ -143,7 +143,8 @@ namespace rir
 		LossyDeviceState shadow;   // where a pass leaves the state after the group (ring: the slots the group writes)
 		uint32_t *budgets;		   // [nsteps] low | high << 16, both clamped to 0 .. 65 535 (a difference never exceeds that)
 		unsigned long long *rows;  // [nsteps][stat workgroups][4] the sums of a frame, per slab of kLossySpecSlab pixels (words as lossy_const_run_kernel's partials)
-		double *sd;				   // [nsteps][2] the statistic of every frame (verify -> commit)
+		double *sd;				   // [nsteps][2] the statistic of every frame (sums kernel -> verify, commit)
+		unsigned int *tickets;	   // [nsteps] arrival counters of the frames' slabs: zero between launches (the last arriver clears its own)
 		unsigned int *ctl;		   // [8] 0: status (0 to be stepped, 1 verified, 2 given up), 1: passes so far, 2: first mismatch of the last pass, 3: passes allowed
 		unsigned int *backoff;	   // [2] of the call's leading stream: groups still to skip, failures in a row
 	};

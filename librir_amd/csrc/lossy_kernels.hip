@@ -2413,10 +2413,13 @@ namespace rir
 
 	// lossy_spec_stats_kernel: grid = (slabs of a frame, frames, streams).  The six sums of frame k (h264.cpp:1993-2036) from the frames where
 	// they lie: input k (less the minimum) against output k - 1 - the stream's prevT for the group's first frame, which a pass leaves alone -
-	// split by input k > background k.  Per slab of kLossySpecSlab pixels four words, as lossy_const_run_kernel's partials.
+	// split by input k > background k.  Per slab of kLossySpecSlab pixels four words, as lossy_const_run_kernel's partials; the LAST slab of
+	// a frame to arrive (a ticket per frame; rows written and read with agent-scope accesses, as lossy_last_arriver's callers do) adds them up and
+	// leaves the frame's statistic, stdDev's double arithmetic on the exact sums.
 	__global__ __launch_bounds__(256) void lossy_spec_stats_kernel(const LossyRun *__restrict__ table, const LossySpec *__restrict__ spec)
 	{
 		__shared__ long long red[4][6];
+		__shared__ unsigned int sh_last;
 		const int tid = threadIdx.x, slab = blockIdx.x, k = blockIdx.y, stream = blockIdx.z, nslabs = gridDim.x;
 		RIR_GLOBAL(const LossySpec) *sp = as_global(spec + stream);
 		if (__hip_atomic_load(as_global(sp->ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
@@ -2476,7 +2479,38 @@ namespace rir
 			long long val = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 			if (tid == 0 || tid == 2)
 				val |= (red[0][c + 2] + red[1][c + 2] + red[2][c + 2] + red[3][c + 2]) << 32;
-			as_global(sp->rows)[((size_t)k * nslabs + slab) * 4 + tid] = (unsigned long long)val;
+			__hip_atomic_store(as_global(sp->rows) + ((size_t)k * nslabs + slab) * 4 + tid, (unsigned long long)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		if (!lossy_last_arriver(sp->tickets + k, (unsigned int)nslabs, &sh_last))
+			return;
+		// the frame's rows, a lane each (64 lanes x 4 words: up to 64 slabs a round), summed over the wave
+		if (tid >= 64)
+			return;
+		long long tfd = 0, tfn = 0, tbd = 0, tbn = 0, tf2 = 0, tb2 = 0;
+		RIR_GLOBAL(unsigned long long) *rows = as_global(sp->rows) + (size_t)k * nslabs * 4;
+		for (int q = tid; q < nslabs; q += 64)
+		{
+			const unsigned long long w0 = __hip_atomic_load(rows + q * 4 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w1 = __hip_atomic_load(rows + q * 4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const unsigned long long w2 = __hip_atomic_load(rows + q * 4 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w3 = __hip_atomic_load(rows + q * 4 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			tfd += (long long)(w0 & 0xffffffffull), tfn += (long long)(w0 >> 32), tf2 += (long long)w1;
+			tbd += (long long)(w2 & 0xffffffffull), tbn += (long long)(w2 >> 32), tb2 += (long long)w3;
+		}
+		tfd = lossy_wave_sum(tfd), tfn = lossy_wave_sum(tfn), tf2 = lossy_wave_sum(tf2), tbd = lossy_wave_sum(tbd), tbn = lossy_wave_sum(tbn), tb2 = lossy_wave_sum(tb2);
+		if (tid == 0)
+		{ // stdDev (h264.cpp:1993-2036), as lossy_budget: unsplit while the window is not full
+			RIR_GLOBAL(double) *gsd = as_global(sp->sd);
+			const int n_win0 = as_global(r->budget)->n_win;
+			if (n_win0 + k < 40)
+			{
+				const double sum_diff = (double)(tfd + tbd), sum_diff2 = (double)(tf2 + tb2);
+				gsd[2 * k] = gsd[2 * k + 1] = sqrt(sum_diff * sum_diff - sum_diff2) / s;
+			}
+			else
+			{
+				const double dfd = (double)tfd, dfd2 = (double)tf2, dbd = (double)tbd, dbd2 = (double)tb2;
+				gsd[2 * k] = sqrt(dbd * dbd - dbd2) / (int)tbn;
+				gsd[2 * k + 1] = sqrt(dfd * dfd - dfd2) / (int)tfn;
+			}
 		}
 	}
 
@@ -2522,7 +2556,7 @@ namespace rir
 			low_error = high_error;
 		return lossy_spec_pack(low_error, high_error);
 	}
-	__global__ __launch_bounds__(1024) void lossy_spec_verify_kernel(const LossyRun *__restrict__ table, const LossySpec *__restrict__ spec, int nslabs)
+	__global__ __launch_bounds__(1024) void lossy_spec_verify_kernel(const LossyRun *__restrict__ table, const LossySpec *__restrict__ spec)
 	{
 		__shared__ double sd[kLossyConstMaxFrames][2];
 		__shared__ LossySpecWindow w;
@@ -2549,29 +2583,10 @@ namespace rir
 			w.first[0] = bud->first_std[0], w.first[1] = bud->first_std[1];
 			sh_m = n;
 		}
-		RIR_GLOBAL(const lossy_v4u) *rows = reinterpret_cast<RIR_GLOBAL(const lossy_v4u) *>(as_global(sp->rows));
+		// the statistics of the frames (lossy_spec_stats_kernel's last arrivers)
+		RIR_GLOBAL(double) *gsd = as_global(sp->sd);
 		for (int k = tid; k < n; k += 1024)
-		{
-			long long fd = 0, fn = 0, bd = 0, bn = 0, f2 = 0, b2 = 0;
-			for (int q = 0; q < nslabs; ++q)
-			{
-				const lossy_v4u lo = rows[((size_t)k * nslabs + q) * 2], hi = rows[((size_t)k * nslabs + q) * 2 + 1];
-				fd += (long long)lo.x, fn += (long long)lo.y, f2 += (long long)(((unsigned long long)lo.w << 32) | lo.z);
-				bd += (long long)hi.x, bn += (long long)hi.y, b2 += (long long)(((unsigned long long)hi.w << 32) | hi.z);
-			}
-			// stdDev (h264.cpp:1993-2036), as lossy_budget: unsplit while the window is not full
-			if (n_win0 + k < 40)
-			{
-				const double sum_diff = (double)(fd + bd), sum_diff2 = (double)(f2 + b2);
-				sd[k][0] = sd[k][1] = sqrt(sum_diff * sum_diff - sum_diff2) / s;
-			}
-			else
-			{
-				const double dfd = (double)fd, dfd2 = (double)f2, dbd = (double)bd, dbd2 = (double)b2;
-				sd[k][0] = sqrt(dbd * dbd - dbd2) / (int)bn;
-				sd[k][1] = sqrt(dfd * dfd - dfd2) / (int)fn;
-			}
-		}
+			sd[k][0] = gsd[2 * k], sd[k][1] = gsd[2 * k + 1];
 		__syncthreads();
 		RIR_GLOBAL(uint32_t) *tab = as_global(sp->budgets);
 		uint32_t mine[2] = {0u, 0u};
@@ -2584,10 +2599,7 @@ namespace rir
 		__syncthreads();
 		const int m = sh_m;
 		if (m == n)
-		{ // every budget of the table is the reference's: the statistics go to the commit
-			RIR_GLOBAL(double) *gsd = as_global(sp->sd);
-			for (int k = tid; k < n; k += 1024)
-				gsd[2 * k] = sd[k][0], gsd[2 * k + 1] = sd[k][1];
+		{ // every budget of the table is the reference's (the statistics stay where they are for the commit)
 			if (tid == 0)
 			{
 				ctl[1] = ctl[1] + 1u, ctl[2] = (unsigned int)n;
@@ -2677,35 +2689,26 @@ namespace rir
 		RIR_GLOBAL(LossyBudget) *bud = as_global(r->budget);
 		RIR_GLOBAL(const double) *gsd = as_global(sp->sd);
 		RIR_GLOBAL(const uint32_t) *tab = as_global(sp->budgets);
-		if (tid == 0)
+		// (every thread reads the counters before anybody moves them)
+		const int n_first0 = bud->n_first, n_win0 = bud->n_win, head0 = bud->head;
+		__syncthreads();
+		// Frame k's statistic goes where lossy_budget would have put it: appended while the window fills, then round the ring from its head (a window
+		// that is not full has its head at 0).  Only the group's last 40 frames are still there afterwards - a thread each, all to different places.
+		if (tid < 40 && tid < n)
 		{
-			if (bud->n_first < 1)
+			const int k = n - 1 - tid;
+			const int pos = n_win0 + k < 40 ? n_win0 + k : (head0 + k - (40 - n_win0)) % 40;
+			bud->win[pos][0] = gsd[2 * k], bud->win[pos][1] = gsd[2 * k + 1];
+		}
+		if (tid == 64)
+		{
+			if (n_first0 < 1)
 			{
 				bud->first_std[0] = gsd[0], bud->first_std[1] = gsd[1];
 				bud->n_first = 1;
 			}
-			int n_win = bud->n_win, head = bud->head;
-			// (frames that have left the window by the end of the group only move the counters)
-			const int tail0 = n > 40 ? n - 40 : 0;
-			{
-				const int fill = tail0 < 40 - n_win ? tail0 : 40 - n_win;
-				n_win += fill;
-				head = (head + (tail0 - fill)) % 40;
-			}
-			for (int k = tail0; k < n; ++k)
-			{
-				if (n_win < 40)
-				{
-					bud->win[n_win][0] = gsd[2 * k], bud->win[n_win][1] = gsd[2 * k + 1];
-					++n_win;
-				}
-				else
-				{
-					bud->win[head][0] = gsd[2 * k], bud->win[head][1] = gsd[2 * k + 1];
-					head = head == 39 ? 0 : head + 1;
-				}
-			}
-			bud->n_win = n_win, bud->head = head;
+			bud->n_win = n_win0 + n < 40 ? n_win0 + n : 40;
+			bud->head = n_win0 + n <= 40 ? head0 : (head0 + n - (40 - n_win0)) % 40;
 			RIR_GLOBAL(LossyDecision) *gd = as_global(r->decision);
 			gd->background = (uint32_t)as_global(r->bg)[(size_t)(n - 1) * r->bg_stride];
 			gd->low_error = (int)(tab[n - 1] & 0xffffu), gd->high_error = (int)(tab[n - 1] >> 16);
@@ -2928,15 +2931,15 @@ namespace rir
 #undef RIR_SPEC_LAUNCH
 		const int nslabs = lossy_spec_stat_workgroups(s);
 		hipLaunchKernelGGL(lossy_spec_stats_kernel, dim3((unsigned)nslabs, (unsigned)max_frames, (unsigned)nstreams), dim3(256), 0, st, d_table, d_spec);
-		hipLaunchKernelGGL(lossy_spec_verify_kernel, dim3((unsigned)nstreams), dim3(1024), 0, st, d_table, d_spec, nslabs);
+		hipLaunchKernelGGL(lossy_spec_verify_kernel, dim3((unsigned)nstreams), dim3(1024), 0, st, d_table, d_spec);
 		return hipGetLastError();
 	}
 	hipError_t launch_lossy_spec_commit(const LossyRun *d_table, const LossySpec *d_spec, int nstreams, int s, int full, unsigned int *d_ok, hipStream_t st)
 	{
 		(void)s;
-		int nb = (full / 8 + 255) / 256; // 16 bytes a thread
-		if (nb > 256)
-			nb = 256;
+		int nb = (full / 8 + 255) / 256; // 16 bytes a thread and round
+		if (nb > 1024)
+			nb = 1024;
 		hipLaunchKernelGGL(lossy_spec_commit_kernel, dim3((unsigned)nb, (unsigned)nstreams), dim3(256), 0, st, d_table, d_spec, nstreams, d_ok);
 		return hipGetLastError();
 	}

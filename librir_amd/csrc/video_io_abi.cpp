@@ -383,7 +383,7 @@ namespace
 	int const_groups = 0;						// groups of the last run call that were OFFERED to the constant-budget form (0: it was not eligible)
 	// speculative form (lossy_kernels.h: LossySpec): the budget tables, sums and statistics of a group (reused group after group), the control
 	// words of every group and stream of the last call, and - for good - the back-off words of the calls this stream leads
-	DeviceBuffer spec_budgets, spec_rows, spec_sd, spec_ctl, spec_backoff;
+	DeviceBuffer spec_budgets, spec_rows, spec_sd, spec_ctl, spec_backoff, spec_tickets;
 	int spec_groups = 0, spec_streams = 0;		// groups (and streams) of the last run call that went through the speculative launches (0: not eligible)
 		PinnedBuffer multi_stage;
 		hipEvent_t multi_copied = nullptr; // the copy out of multi_stage of the last call (whatever its stream) has completed
@@ -3452,11 +3452,14 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 				const size_t spec_group = (size_t)std::min(nsteps, group);
 				if (spec_form)
 				{
-					const size_t bk_cap = lead.spec_backoff.cap;
+					const size_t bk_cap = lead.spec_backoff.cap, tk_cap = lead.spec_tickets.cap;
 					if (!lead.const_ok.reserve((size_t)ngroups * 4) || !hip_ok(hipMemsetAsync(lead.const_ok.ptr, 0, (size_t)ngroups * 4, st), "memset") ||
 						!lead.spec_budgets.reserve((size_t)nstreams * (spec_group + 8) * 4) || !lead.spec_rows.reserve((size_t)nstreams * spec_group * spec_slabs * 32) ||
 						!lead.spec_sd.reserve((size_t)nstreams * spec_group * 16) || !lead.spec_ctl.reserve((size_t)ngroups * nstreams * 32) ||
-						!hip_ok(hipMemsetAsync(lead.spec_ctl.ptr, 0, (size_t)ngroups * nstreams * 32, st), "memset") || !lead.spec_backoff.reserve(8))
+						!hip_ok(hipMemsetAsync(lead.spec_ctl.ptr, 0, (size_t)ngroups * nstreams * 32, st), "memset") || !lead.spec_backoff.reserve(8) ||
+						!lead.spec_tickets.reserve((size_t)nstreams * spec_group * 4))
+						return -1;
+					if (lead.spec_tickets.cap != tk_cap && !hip_ok(hipMemsetAsync(lead.spec_tickets.ptr, 0, lead.spec_tickets.cap, st), "memset"))
 						return -1;
 					if (lead.spec_backoff.cap != bk_cap && !hip_ok(hipMemsetAsync(lead.spec_backoff.ptr, 0, 8, st), "memset"))
 						return -1;
@@ -3498,6 +3501,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 							sp.budgets = lead.spec_budgets.as<uint32_t>() + (size_t)i * (spec_group + 8);
 							sp.rows = lead.spec_rows.as<unsigned long long>() + (size_t)i * spec_group * spec_slabs * 4;
 							sp.sd = lead.spec_sd.as<double>() + (size_t)i * spec_group * 2;
+							sp.tickets = lead.spec_tickets.as<unsigned int>() + (size_t)i * spec_group;
 							sp.ctl = lead.spec_ctl.as<unsigned int>() + ((size_t)g * nstreams + i) * 8;
 							sp.backoff = lead.spec_backoff.as<unsigned int>();
 							hsp[(size_t)g * nstreams + i] = sp;

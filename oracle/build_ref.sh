@@ -60,3 +60,28 @@ g++ -std=c++14 -O3 -DNDEBUG -fPIC -shared -ffunction-sections -fdata-sections \
 	-static-libstdc++ -static-libgcc -lpthread "${ATTR_FLAGS[@]}" \
 	-o "$OUT/librir_ref.so"
 echo "build_ref: built $OUT/librir_ref.so"
+
+# The reference's ZFile container (video_io/ZFile.cpp: the one video format both libraries exchange) as a library of its
+# own: unmodified ZFile.cpp + tools/{ReadFileChunk,FileAttributes,Log,Misc}.cpp + oracle/ref_zfile_driver.cpp (ours: forwarders).  Its
+# zstd_* calls (tools.h:185-188; the reference's tools.cpp, which defines them, needs minizip's unzip.h and is not built) are resolved from
+# THIS build's libtools.so alias - reference video_io code on this build's `tools`, the drop-in situation.  Needs zstd.h (for
+# FileAttributes.cpp) and the product library; left out when either is missing.
+LIBS_DIR=$(cd "$HERE/.." && pwd)/librir_amd/libs
+if [ ${#ATTR_SRC[@]} -gt 0 ] && [ -e "$LIBS_DIR/libtools.so" ]; then
+	cat >"$OUT/exports_zfile.map" <<'EOF2'
+{
+  global: ref_zfile_*;
+  local: *;
+};
+EOF2
+	g++ -std=c++14 -O3 -DNDEBUG -fPIC -shared -ffunction-sections -fdata-sections \
+		-DBUILD_IO_LIB -DBUILD_TOOLS_LIB \
+		-I"$OUT" -I"$R/src/cpp/tools" -I"$R/src/cpp/video_io" \
+		"$R/src/cpp/video_io/ZFile.cpp" "$R/src/cpp/tools/ReadFileChunk.cpp" "$R/src/cpp/tools/FileAttributes.cpp" \
+		"$R/src/cpp/tools/Log.cpp" "$R/src/cpp/tools/Misc.cpp" "$HERE/ref_zfile_driver.cpp" \
+		-Wl,--gc-sections -Wl,--version-script="$OUT/exports_zfile.map" -Wl,--no-undefined \
+		-static-libstdc++ -static-libgcc -lpthread "${ATTR_FLAGS[@]}" \
+		-L"$LIBS_DIR" -l:libtools.so -Wl,-rpath,'$ORIGIN/../../librir_amd/libs' \
+		-o "$OUT/librir_ref_zfile.so"
+	echo "build_ref: built $OUT/librir_ref_zfile.so"
+fi

@@ -384,6 +384,43 @@ class RefAttrs:
         return cnt, list(T[:max(cnt, 0)]), (buf.raw[: n.value] if n.value >= 0 else None), ng.value
 
 
+class RefZFile:
+    """The reference's ZFile container (oracle/_ref/librir_ref_zfile.so: its unmodified ZFile.cpp, with zstd_* resolved from this build's
+    libtools.so alias - oracle/build_ref.sh); raises FileNotFoundError where it was not built."""
+
+    def __init__(self, path=None):
+        path = path or os.path.join(_HERE, "_ref", "librir_ref_zfile.so")
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = ct.CDLL(path)
+        self.lib.ref_zfile_write.restype = ct.c_longlong
+        self.lib.ref_zfile_write.argtypes = [ct.c_char_p, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_int, ct.c_void_p, ct.c_void_p]
+        self.lib.ref_zfile_read.restype = ct.c_int
+        self.lib.ref_zfile_read.argtypes = [ct.c_char_p, ct.POINTER(ct.c_int), ct.POINTER(ct.c_int), ct.c_void_p, ct.c_void_p, ct.c_int]
+
+    def write(self, filename, frames, times, rate=50, method=1, clevel=2):
+        fr = np.ascontiguousarray(frames, dtype=np.uint16)
+        n, h, w = fr.shape
+        ts = np.ascontiguousarray(times, dtype=np.int64)
+        size = self.lib.ref_zfile_write(str(filename).encode(), w, h, rate, method, clevel, n, _p(fr), _p(ts))
+        if size < 0:
+            raise RuntimeError("ref_zfile_write failed")
+        return int(size)
+
+    def read(self, filename, cap, shape):
+        """(count, frames (min(count, cap), h, w), raw timestamps) as the reference's reader gives them"""
+        h, w = shape
+        fr = np.zeros((cap, h, w), np.uint16)
+        ts = np.zeros(cap, np.int64)
+        cw, ch = ct.c_int(0), ct.c_int(0)
+        n = self.lib.ref_zfile_read(str(filename).encode(), ct.byref(cw), ct.byref(ch), _p(fr), _p(ts), cap)
+        if n < 0:
+            raise RuntimeError("ref_zfile_read failed (%d)" % n)
+        if (ch.value, cw.value) != (h, w):
+            raise RuntimeError("ref_zfile_read: the file holds %dx%d images" % (cw.value, ch.value))
+        return n, fr[: min(n, cap)], ts[: min(n, cap)].tolist()
+
+
 class OracleLossy:
     """Stateful loss injection of the lossy saver (oracle/rir_oracle.c: orc_lossy_*)."""
 

@@ -1,6 +1,6 @@
 """The speculative form of the bounded-loss step (stdFactor 5: the reference's defaults) on 640x512 frames in HBM - a static scene (committed),
 the S1 recipe (budgets move every frame: general form, back-off) - beside the constant-budget form (stdFactor 0) and the general form alone:
-    python tests/perf/lossy_spec_time.py [frames per call] [streams]"""
+    python tests/perf/lossy_spec_time.py [frames per call] [streams] [only: a word of the line wanted, e.g. speculative,static]"""
 import os
 import sys
 import time
@@ -14,6 +14,7 @@ from librir_amd.synthetic import s1_noisy_background  # noqa: E402
 
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+only = sys.argv[3].split(",") if len(sys.argv) > 3 else []
 h, w = 512, 640
 
 
@@ -38,6 +39,8 @@ scenes = {"static": static_scene(m), "S1": torch.from_numpy(s1_noisy_background(
 for label, scene, sf, env in (("constant budgets (stdFactor 0)", "static", 0.0, {}), ("speculative, static scene (6/2/5/32)", "static", 5.0, {}),
                               ("general form alone, static scene", "static", 5.0, {"RIR_LOSSY_NO_SPEC": "1"}),
                               ("speculative, S1 (budgets move)", "S1", 5.0, {}), ("general form alone, S1", "S1", 5.0, {"RIR_LOSSY_NO_SPEC": "1"})):
+    if only and not all(o in label for o in only):
+        continue
     for k in ("RIR_LOSSY_NO_SPEC",):
         os.environ.pop(k, None)
     os.environ.update(env)

@@ -344,6 +344,49 @@ def test_zfile_written_here_has_the_reference_layout(tmp_path):
         rv.open_video_write(tmp_path / "big.bin", 3000, 10, method=rv.METHOD_ZSTD)
 
 
+def test_zfile_cross_read_with_reference(tmp_path):
+    """The ZFile container against the reference's own reader and writer (its unmodified ZFile.cpp, compiled by oracle/build_ref.sh with
+    zstd_* resolved from this build's libtools.so: reference video_io code on this build's `tools`): a file written by
+    open_video_write(method = zstd) is read by z_open_file_read / z_read_image / z_get_timestamps (ZFile.cpp:273-330,544-629), and a file
+    written by z_open_file_write / z_write_image (:332-372,483-542) is read by open_camera_file, with the timestamps as the reference's
+    loader presents them: (t - t0) x 10^6 for small values, IRFileLoader.cpp:345-372.  Skipped where /root/reference is absent."""
+    from oracle.pyoracle import RefZFile
+
+    try:
+        RZ = RefZFile()
+    except FileNotFoundError:
+        pytest.skip("oracle/_ref/librir_ref_zfile.so not built here (needs /root/reference and zstd.h)")
+    rng = np.random.default_rng(15)
+    n, h, w = 7, 24, 40
+    fr = (rng.random((n, h, w)) * 900 + 10 * np.arange(n)[:, None, None]).astype(np.uint16)
+    # this build writes, the reference reads
+    ts = [2_000_000_000 + 20_000_000 * i for i in range(n)]
+    p = tmp_path / "ours.bin"
+    wr = rv.open_video_write(p, w, h, rate=50, method=rv.METHOD_ZSTD, clevel=3)
+    for f, t in zip(fr, ts):
+        rv.image_write(wr, f, t)
+    rv.close_video(wr)
+    cnt, got, times = RZ.read(p, n + 2, (h, w))
+    assert cnt == n and np.array_equal(got, fr) and times == ts
+    # the reference writes, this build reads (format 4); small timestamps: milliseconds from the first image, presented as nanoseconds
+    ts_ms = [1000 + 40 * i for i in range(n)]
+    q = tmp_path / "ref.bin"
+    size = RZ.write(q, fr, ts_ms, rate=25, method=1, clevel=2)
+    assert 0 < size <= os.path.getsize(q)
+    assert rv.video_file_format(q) == rv.FILE_FORMAT_ZSTD_COMPRESSED
+    cam = rv.open_camera_file(q)
+    assert rv.get_image_count(cam) == n and rv.get_image_size(cam) == (h, w)
+    for i in (3, 0, 6, 1):
+        assert np.array_equal(rv.load_image(cam, i), fr[i])
+    assert [rv.get_image_time(cam, i) for i in range(n)] == [(t - ts_ms[0]) * 1_000_000 for t in ts_ms]
+    rv.close_camera(cam)
+    # and the reference reads its own file the same way this build's independent parser does (the layout tests above rest on that parser)
+    cnt, got, times = RZ.read(q, n, (h, w))
+    assert cnt == n and np.array_equal(got, fr) and times == ts_ms
+    info, frames, ptimes, _, _ = parse_zfile(q.read_bytes())
+    assert (info["w"], info["h"], info["rate"], info["samples"]) == (w, h, 25, n) and np.array_equal(frames, fr) and ptimes == ts_ms
+
+
 @pytest.mark.parametrize("samples", [None, 0])
 def test_zfile_without_trailer_is_walked_record_by_record(tmp_path, samples):
     """Files from a writer that stored no trailer (or no image count): the index comes from walking the records
