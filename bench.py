@@ -325,6 +325,21 @@ def other_paths(D, frames, h, w):
     st.status()
     res["bounded_loss_groups_offered_to_and_taken_by_the_constant_budget_form"] = list(st.path_stats())
     st.close()
+    # the reference's DEFAULT parameters (6 / 2 / stdFactor 5 / 32, h264.cpp:1662-1665): budgets that follow the statistics.  On a scene that does
+    # not move the speculative form's guess verifies and the streaming kernel steps the group; on S1 (one level up per frame) the budgets move
+    # nearly every frame and the general (resident) form steps it - both bit-exact against the oracle (tests/test_gpu_lossy_spec.py)
+    if frames.shape[0] > m:
+        g = torch.Generator(device=frames.device).manual_seed(5)
+        static = (torch.rand((h, w), generator=g, device=frames.device) * 1000 + 10)[None] + 0.7 * torch.randn((frames.shape[0], h, w), generator=g, device=frames.device)
+        static = static.to(torch.int32).to(torch.uint16)
+        for name, scene in (("static_scene", static), ("S1", frames)):
+            sd = D.LossyStream(w, h, h - 3, 6, 2, 5.0, 32)
+            sd.step(scene, errors=False)
+            res["bounded_loss_default_parameters_%s_fps_one_stream_%d_frame_calls" % (name, frames.shape[0])] = rate(lambda: sd.step(scene, errors=False), frames.shape[0])
+            sd.status()
+            res["bounded_loss_default_parameters_%s_speculative_groups_through_offered_committed_passes" % name] = list(sd.spec_stats())
+            sd.close()
+        del static
     for S in (7, 9):  # (7: what one launch of the run kernel's first form holds; 9: its second form - state parked in LDS, 6 waves per SIMD)
         streams = [D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32) for _ in range(S)]
         ins = [fr.clone() for _ in range(S)]
@@ -357,6 +372,54 @@ def other_paths(D, frames, h, w):
     res["ecc_tracked_8_sequences_fps"] = rate(track8, S8 * (nreg - 1))
     res["note"] = "best of 3; %d-frame calls of the bounded-loss step (low = high = 3, stdFactor 0, 509 lossy rows), %d float32 S3 frames for the registration" % (m, nreg)
     return res
+
+
+def check_world(ranks_seen, gpus, bus_ids, share_gpu):
+    """The N > 1 line must be able to prove what it ran on: the communicator saw every rank, and no two ranks sat on one GPU.
+    -> None, or the reason the run is refused (no `value` is printed then, exit status 3)."""
+    if int(ranks_seen) != int(gpus):
+        return "the communicator's all-reduce saw %d rank(s), --gpus says %d" % (int(ranks_seen), int(gpus))
+    if not share_gpu and len(set(bus_ids)) != len(bus_ids):
+        return "two ranks report the same device (%s) - set RIR_BENCH_SHARE_GPU=1 for a rehearsal on one GPU" % ", ".join(sorted(bus_ids))
+    return None
+
+
+def world_identity(dist, torch, dev, world, rank, backend):
+    """ranks_seen (an all-reduce of ones on the communicator `value` is measured with), the collective library's version, and every rank's
+    device name / PCI bus id gathered to all ranks."""
+    one = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    if dev is not None and getattr(dev, "type", "cpu") == "cuda":
+        pr = torch.cuda.get_device_properties(dev)
+        bus = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1) & 0xff, getattr(pr, "pci_device_id", 0)) if hasattr(pr, "pci_bus_id") \
+            else str(getattr(pr, "uuid", "gpu%d" % dev.index))
+        mine = {"rank": rank, "device_name": pr.name, "pci_bus_id": bus, "device_index": dev.index}
+    else:
+        mine = {"rank": rank, "device_name": "cpu", "pci_bus_id": "cpu", "device_index": -1}
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    version = None
+    if backend == "nccl":
+        try:
+            version = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as e:
+            version = "unknown (%s)" % repr(e)[:80]
+    return int(one.item()), version, everyone
+
+
+def newest_n1_value():
+    """`value` of the newest BENCH_r*.json the driver left at the repo root (the N = 1 line of an earlier round), or None"""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            p_ = d.get("parsed") or {}
+            if p_.get("n_gpus") == 1 and p_.get("value"):
+                return {"file": os.path.basename(f), "value": float(p_["value"])}
+        except Exception:
+            continue
+    return None
 
 
 def main():
@@ -430,6 +493,20 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+
+    identity = None
+    if world > 1:
+        # the line proves what it ran on, or there is no line: every rank on the communicator, every rank a GPU of its own
+        ranks_seen, coll_version, everyone = world_identity(dist, torch, dev, world, rank, backend)
+        why = check_world(ranks_seen, args.gpus, [e["pci_bus_id"] for e in everyone], bool(os.environ.get("RIR_BENCH_SHARE_GPU")))
+        if why:
+            if rank == 0:
+                sys.stderr.write("bench.py: refusing to run: %s\n" % why)
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(3)
+        identity = {"ranks_seen": ranks_seen, "rccl_version" if backend == "nccl" else "collective_backend": coll_version if backend == "nccl" else backend,
+                    "ranks": everyone, "gpu_shared_by_ranks (rehearsal)": True if os.environ.get("RIR_BENCH_SHARE_GPU") else None}
 
     from librir_amd import device as D
     from librir_amd.distributed import CompressedGather, FrameGather, shard_plan
@@ -518,21 +595,22 @@ def main():
     if not ok:
         raise SystemExit("bench.py: decode(encode(x)) != x - refusing to report a number")
 
-    # ---- spread, and a GPU that is visibly busy: the same K-step region again and again until 2 s of it have run (a utilisation
-    # sampler with a period of seconds sees nothing of a 5 ms region); `value` stays the first region above ----
+    # ---- spread, and a GPU that is visibly busy: the same K-step region again and again until BUSY_S seconds of it have run (a utilisation
+    # sampler with a period of 5 s sees nothing of a 5 ms region, and may miss 2 s); `value` stays the first region above ----
+    BUSY_S = 6.5
     reps = []
     t_busy = time.perf_counter()
-    while len(reps) < (1 if args.profile else 5) or (not args.profile and time.perf_counter() - t_busy < 2.0 and len(reps) < 2000):
+    while len(reps) < (1 if args.profile else 5) or (not args.profile and time.perf_counter() - t_busy < BUSY_S and len(reps) < 20000):
         reps.append(max_over_ranks(k_steps(K)) / K * 1e3)
         if world > 1 and len(reps) >= 5 and not args.profile:  # (every rank must leave the loop in the same round: the region count is rank 0's decision)
-            go = torch.tensor([1 if time.perf_counter() - t_busy < 2.0 else 0], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            go = torch.tensor([1 if time.perf_counter() - t_busy < BUSY_S else 0], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
             dist.broadcast(go, 0)
             if int(go.item()) == 0:
                 break
     nreg = len(reps)
     reps.sort()
     spread = {"ms_per_step_min": reps[0], "ms_per_step_median": reps[nreg // 2], "ms_per_step_max": reps[-1], "repeats": nreg,
-              "note": "further K-step regions after the one `value` is computed from, repeated until the GPU had been busy for 2 s"}
+              "note": "further K-step regions after the one `value` is computed from, repeated until the GPU had been busy for %.1f s" % BUSY_S}
 
     if args.profile:
         if rank == 0:
@@ -768,6 +846,11 @@ def main():
         res.update(extra)
         if exchange:
             res.update(exchange)
+        if identity:
+            res.update(identity)
+            ref1 = newest_n1_value()
+            res["n1_reference_value"] = ref1
+            res["scaling_factor_vs_n1_reference"] = (fps / ref1["value"]) if ref1 else None
         if cpu is not None:
             res["cpu_baseline"] = cpu
         print(json.dumps(res))

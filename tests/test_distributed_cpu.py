@@ -225,3 +225,46 @@ def test_compressed_chunks_gathered_and_decoded_on_arrival_world4(nframes, gop, 
     ret = mp.Manager().dict()
     mp.spawn(_compressed_worker, args=(world, port, nframes, gop, shape[0], shape[1], per_piece, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+# ---- the N > 1 bench line proves what it ran on (bench.py: world_identity / check_world) ------------------------------------
+def _identity_worker(rank, world, port, ret):
+    import bench
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seen, version, everyone = bench.world_identity(dist, torch, None, world, rank, "gloo")
+        ids = [e["pci_bus_id"] for e in everyone]
+        ret[rank] = (seen, version, [e["rank"] for e in everyone], bench.check_world(seen, world, ids, False), bench.check_world(seen, world, ids, True))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_refuses_a_world_it_cannot_vouch_for():
+    import bench
+
+    # every rank on the communicator, every rank a device of its own: accepted
+    assert bench.check_world(8, 8, ["0000:%02x:00" % i for i in range(8)], False) is None
+    # a communicator that saw fewer ranks than --gpus, or two ranks on one GPU (unless the rehearsal switch says so): refused
+    assert "saw 7 rank(s)" in bench.check_world(7, 8, ["0000:%02x:00" % i for i in range(8)], False)
+    assert "same device" in bench.check_world(2, 2, ["0000:05:00", "0000:05:00"], False)
+    assert bench.check_world(2, 2, ["0000:05:00", "0000:05:00"], True) is None
+    # two gloo ranks on this CPU: the all-reduce sees both, both report the same "device" - refused without the switch, accepted with it
+    world = 2
+    port = 29500 + (os.getpid() + 977) % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_identity_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        seen, version, ranks, refused, rehearsal = ret[r]
+        assert seen == 2 and version is None and ranks == [0, 1]
+        assert refused is not None and "same device" in refused and rehearsal is None
+
+
+def test_bench_reads_the_newest_n1_record():
+    import bench
+
+    ref1 = bench.newest_n1_value()
+    assert ref1 is None or (ref1["file"].startswith("BENCH_r") and ref1["value"] > 0)
