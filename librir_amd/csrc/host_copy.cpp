@@ -142,9 +142,11 @@ namespace rir
 				int want = dflt;
 				if (const char *e = std::getenv(var))
 					want = std::atoi(e);
+				if (want < 0)
+					want = 0; // (before the unsigned comparison below: a negative value is no helper, not all of them - ADVICE r5)
 				if (hw && (unsigned)want > hw - 1)
 					want = (int)hw - 1; // never more threads than other cores
-				return want < 0 ? 0 : (want > kMaxHelpers ? kMaxHelpers : want);
+				return want > kMaxHelpers ? kMaxHelpers : want;
 			}
 			Pool()
 			{
@@ -273,8 +275,11 @@ namespace rir
 			for (int i = 0; i < k; ++i)
 				for (unsigned spins = 0; mine[i]->done.load(std::memory_order_acquire) < want[i]; ++spins)
 				{
-					if (g == 1 && spins > 2000)
-						std::this_thread::yield(); // (a file job: the writer thread / a read-ahead lane waits, for as long as the file system takes)
+					// a file job: the writer thread / a read-ahead lane waits, for as long as the file system takes.  A copy job takes 8 us - a
+					// few thousand spins; a caller still waiting after 20 000 has a helper that was descheduled (a container with a CPU quota):
+					// it gives its time slice up instead of spinning through it
+					if (spins > (g == 1 ? 2000u : 20000u))
+						std::this_thread::yield();
 					else
 						cpu_relax();
 				}

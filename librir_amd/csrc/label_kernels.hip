@@ -438,7 +438,9 @@ namespace rir
 			k.n = w * h;
 			k.nb = (k.n + kBlock - 1) / kBlock;
 			k.pitch = pitch_of(w, h, table);
-			char *p = static_cast<char *>(d_work);
+			// (the planes are read with 16-byte loads: the workspace is used from its first 64-byte boundary on - label_workspace_bytes holds
+			// 64 spare bytes for that; the callers only promise 8-byte alignment)
+			char *p = reinterpret_cast<char *>((reinterpret_cast<uintptr_t>(d_work) + 63) & ~(uintptr_t)63);
 			const size_t f = (size_t)frames;
 			k.L = reinterpret_cast<int *>(p);
 			k.cnt = reinterpret_cast<int *>(p += f * k.pitch.plane * sizeof(int));

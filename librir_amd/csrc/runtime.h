@@ -6,6 +6,7 @@
 //   handle registry     src/cpp/tools/tools.cpp:40-84  (ints >= 1, smallest free slot reused,
 //                       one namespace for cameras, savers, bad-pixel and attribute objects)
 #pragma once
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -62,6 +63,11 @@ namespace rir
 #else
 	inline const char *test_hook(const char *) { return nullptr; }
 #endif
+	inline bool test_hook_is(const char *name, const char *value)
+	{
+		const char *v = test_hook(name);
+		return v && std::strcmp(v, value) == 0;
+	}
 	bool device_ready();
 	// gaussian_filter as the 2-D sum in the reference's own order (signal_processing.cpp:101-148: dx outer, dy inner, one rounding per product
 	// and per sum) instead of the separable form: bit-identical results instead of results within 2e-6, three times the time.  Process-wide,

@@ -789,7 +789,22 @@ namespace
 		{
 			if (!failed)
 				return true;
-			log_error("h264 saver: a bounded-loss step failed earlier; this saver takes no more frames (close it: the chunks written before the failure are kept)");
+			log_error("h264 saver: a chunk failed earlier (bounded-loss step or encode); this saver takes no more frames (close it: the chunks written before the failure are kept)");
+			return false;
+		}
+		// A chunk that was handed in but cannot be written (its encode failed, its event could not be waited for, the encoder left no
+		// plausible length): the recording ends with the chunk before it.  Its frames and whatever came after them leave the books - a chunk
+		// that is counted but has no index entry would be a hole whose positions fail on read - and the saver takes no more frames.
+		bool abandon_from(int64_t first_frame)
+		{
+			failed = true;
+			nframes = (decltype(nframes))first_frame;
+			times.resize((size_t)nframes);
+			frame_attrs.resize((size_t)nframes);
+			pending = 0, uploaded = 0, raw_from = -1, raw_uploaded = 0;
+			deferred.clear();
+			flying.defs.clear();
+			flying.active = false;
 			return false;
 		}
 		// budgets `e` (pairs, in the order of `defs`) into the error lists and the per-frame attributes; gave_up: the error word of the run
@@ -1089,19 +1104,21 @@ namespace
 			const OutLayout o = out_layout(L.ntiles);
 			PinnedBuffer &hob = h_out[next_buf]; // (free: the writer's job in flight, if any, reads the other buffer - queue_write waits for the job before)
 			const size_t fb = (size_t)width * height * 2 * chunk_gop;
-			if (!hob.reserve(o.total()) || !h_stage_b.reserve(fb))
-				return false;
-			if (!fly_ev && !hip_ok(hipEventCreateWithFlags(&fly_ev, hipEventDisableTiming), "hipEventCreate"))
-				return false;
+			if (!hob.reserve(o.total()) || !h_stage_b.reserve(fb) || (!fly_ev && !hip_ok(hipEventCreateWithFlags(&fly_ev, hipEventDisableTiming), "hipEventCreate")))
+				return abandon_from((int64_t)nframes - pending); // (the chunk's budgets have left `deferred`)
 			char *hb = hob.as<char>();
 			uint64_t *coff = reinterpret_cast<uint64_t *>(hb + o.coff_at());
 			coff[0] = 0, coff[1] = ~0ull; // (what the kernels leave is checked against the buffer before it is believed)
-			if (rir_codec_encode_device(chunk_frames, width, height, pending, chunk_gop,
+			if (test_hook_is("RIR_DEBUG_SAVER_FAIL_FLYING", "encode") ||
+				rir_codec_encode_device(chunk_frames, width, height, pending, chunk_gop,
 										reinterpret_cast<unsigned long long *>(hb), reinterpret_cast<unsigned int *>(hb + o.hdr_b),
 										reinterpret_cast<unsigned long long *>(coff), reinterpret_cast<unsigned long long *>(hb + o.hdr_b + o.toff_b), cc.d_ws.ptr,
 										(long long)cc.d_ws.cap, st) != 0 ||
 				!hip_ok(hipEventRecord(fly_ev, st), "hipEventRecord"))
-				return false;
+			{ // (the chunk's budgets have left `deferred`: they would never be filed) the recording ends with the chunk before this one
+				log_error("h264 saver: a chunk could not be encoded");
+				return abandon_from((int64_t)nframes - pending);
+			}
 			flying.active = true, flying.buf = next_buf, flying.nframes = pending, flying.ntiles = L.ntiles, flying.first_frame = nframes - pending;
 			next_buf ^= 1;
 			cur_stage ^= 1;
@@ -1118,8 +1135,8 @@ namespace
 #ifdef RIR_SAVER_DIAG
 			const double tw = dg_now();
 #endif
-			if (!hip_ok(wait_event(fly_ev), "sync"))
-				return false;
+			if (!hip_ok(wait_event(fly_ev), "sync") || test_hook_is("RIR_DEBUG_SAVER_FAIL_FLYING", "wait"))
+				return abandon_from(flying.first_frame);
 #ifdef RIR_SAVER_DIAG
 			dg_wait_ev += dg_now() - tw;
 #endif
@@ -1129,27 +1146,22 @@ namespace
 				const unsigned int *words = reinterpret_cast<const unsigned int *>(h_errs.as<char>() + (size_t)ERR_SLOTS * 2 * sizeof(int));
 				const bool ok = file_errors(flying.defs, e, words[0] | words[1], flying.have_run);
 				flying.defs.clear();
-				if (!ok)
-				{ // (`failed` is set) this chunk and whatever has been handed in since are invalid: the recording ends with the chunk before it
-					nframes = flying.first_frame;
-					times.resize((size_t)nframes);
-					frame_attrs.resize((size_t)nframes);
-					pending = 0, uploaded = 0, raw_from = -1, raw_uploaded = 0;
-					deferred.clear();
-					return false;
-				}
+				if (!ok) // (`failed` is set) this chunk and whatever has been handed in since are invalid: the recording ends with the chunk before it
+					return abandon_from(flying.first_frame);
 			}
 			const OutLayout o = out_layout(flying.ntiles);
 			const char *hb = h_out[flying.buf].as<char>();
 			const uint64_t *coff = reinterpret_cast<const uint64_t *>(hb + o.coff_at());
-			if (coff[0] != 0 || coff[1] > o.pay_max / 8)
+			if (coff[0] != 0 || coff[1] > o.pay_max / 8 || test_hook_is("RIR_DEBUG_SAVER_FAIL_FLYING", "length"))
 			{
 				log_error("h264 saver: the encoder left no chunk length");
-				return false;
+				return abandon_from(flying.first_frame);
 			}
 			WriteJob j;
 			j.hdr_n = o.hdr_n, j.toff_n = o.toff_n, j.hdr_b = o.hdr_b, j.toff_b = o.toff_b, j.words = coff[1], j.buf = flying.buf;
-			return queue_write(j, flying.nframes, flying.first_frame, flying.ntiles);
+			if (!queue_write(j, flying.nframes, flying.first_frame, flying.ntiles))
+				return abandon_from(flying.first_frame);
+			return true;
 		}
 
 		// frames [uploaded, upto) of the chunk being assembled: page-locked staging -> device

@@ -81,7 +81,9 @@ class touch_ahead:
     that copy each image in - for the stack of a 1 000-image slice, twice the time of the reads themselves.  One thread makes pages at
     about 25 GB/s, the reads fill 40 GB/s: three threads take the array's 16 MiB pieces in turn, so that the made part grows from the front.
     The threads hold the array until they are through; contents are left as they are (``rir_host_touch``: an atomic compare-and-swap of a
-    byte with itself per page)."""
+    byte with itself per page).  By the letter of the C++ memory model that is a data race with the plain stores of the copies that may be
+    filling the same page; it is meant: a locked read-modify-write that puts back what it read is serialised with those stores per cache line
+    on x86-64 (the only host this library is built for) and cannot change what they leave."""
 
     PIECE = 16 << 20
     THREADS = 3

@@ -108,6 +108,50 @@ def sticky(tmp_path):
             assert np.array_equal(mov.data, good.data)
 
 
+def flying_chunk_fails(tmp_path, how):
+    """a chunk in flight that cannot be written - its encode fails, its event cannot be waited for, the encoder left no plausible
+    length (forced through RIR_DEBUG_SAVER_FAIL_FLYING=encode / wait / length) - ends the recording with the chunk before it: the saver takes
+    no more frames, the frames of the failed chunk and whatever came after leave the books (a chunk that is counted but has no index entry
+    would be a hole), and close() leaves a file whose frame count, time stamps and index agree - lossless and bounded-loss frames alike."""
+    from librir_amd.video_io import IRMovie, IRSaver
+
+    n, h, w = 40, 64, 96
+    data = s1_noisy_background(n, h, w, seed=21)
+    for lossy in (False, True):
+        p = str(tmp_path / ("fly_%s_%d.h264" % (how, lossy)))
+        s = IRSaver(p, w, h, h - 3)
+        s.set_parameter("GOP", 5)
+        add = (lambda i: s.add_image_lossy(data[i], 1000 * i, {"idx": str(i)})) if lossy else (lambda i: s.add_image(data[i], 1000 * i, {"idx": str(i)}))
+        for i in range(12):  # two chunks written or in flight, two frames pending
+            add(i)
+        os.environ["RIR_DEBUG_SAVER_FAIL_FLYING"] = how
+        failed_at = None
+        for i in range(12, 26):
+            try:
+                add(i)
+            except RuntimeError:
+                failed_at = i
+                break
+        del os.environ["RIR_DEBUG_SAVER_FAIL_FLYING"]
+        assert failed_at is not None, (how, lossy)
+        for i in range(failed_at, failed_at + 3):  # sticky: nothing more is taken, by either entry point
+            with raises(RuntimeError):
+                s.add_image(data[i], 1000 * i)
+            with raises(RuntimeError):
+                s.add_image_lossy(data[i], 1000 * i)
+        s.close()
+        with IRMovie.from_filename(p) as mov:
+            m = mov.images
+            assert m % 5 == 0 and 5 <= m <= 15, (how, lossy, m)  # whole chunks only, all from before the failure
+            assert len(mov.timestamps) == m and np.allclose(mov.timestamps, np.arange(m) * 1e-6)
+            got = mov.data  # every counted frame is there: no hole
+            assert got.shape == (m, h, w)
+            if not lossy:
+                assert np.array_equal(got, data[:m])
+            mov.load_pos(m - 1)
+            assert mov.frame_attributes["idx"] in (str(m - 1), str(m - 1).encode())
+
+
 def multi_repeated_smaller():
     """ecc_run_multi_kernel finds out at its start whether all its workgroups are on the chip (resident_device.h); a launch that is
     not - forced here through RIR_DEBUG_ECC_BAIL: the first attempt of every launch is called off - has written nothing and is
@@ -244,6 +288,9 @@ if __name__ == "__main__":
     if case == "sticky":
         with tempfile.TemporaryDirectory() as d:
             sticky(_Path(d))
+    elif case == "flying_chunk_fails":
+        with tempfile.TemporaryDirectory() as d:
+            flying_chunk_fails(_Path(d), sys.argv[2])
     elif case == "multi_repeated_smaller":
         multi_repeated_smaller()
     elif case == "const_pairs":

@@ -97,7 +97,7 @@ def _hook_case(*args):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RIR_LIBRARY_VARIANT="testhooks")
-    for k in ("RIR_DEBUG_LOSSY_GIVE_UP", "RIR_DEBUG_LOSSY_BAIL", "RIR_DEBUG_ECC_BAIL"):
+    for k in ("RIR_DEBUG_LOSSY_GIVE_UP", "RIR_DEBUG_LOSSY_BAIL", "RIR_DEBUG_ECC_BAIL", "RIR_DEBUG_SAVER_FAIL_FLYING"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "hook_cases.py")] + [str(a) for a in args], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=600)
@@ -110,6 +110,14 @@ def test_a_run_that_gave_up_is_sticky():
     goes on; a saver in that state takes no more frames, writes nothing of the chunk that was being assembled and closes into a
     readable file that ends with the last complete chunk.  (tests/hook_cases.py: sticky)"""
     _hook_case("sticky")
+
+
+@pytest.mark.parametrize("how", ["encode", "wait", "length"])
+def test_a_chunk_in_flight_that_fails_ends_the_recording_before_it(how):
+    """a failure of the saver's chunk in flight - at its encode call, at the wait for its event, at the check of the
+    length the encoder left - is sticky and rolls the books back to the chunk's first frame: the file close() leaves has as many frames as
+    its index holds, and every one of them reads.  (tests/hook_cases.py: flying_chunk_fails)"""
+    _hook_case("flying_chunk_fails", how)
 
 
 def test_images_kept_by_the_caller_survive_later_reads(tmp_path):
