@@ -248,6 +248,20 @@ extern "C"
 	int rir_keep_largest_area_device(int type, const void *d_src, int *d_dst, int w, int h, const void *background, int foreground, void *d_work,
 									 size_t work_bytes, void *stream);
 
+	/* ---- page-locked memory for the caller's images ------------------------------------------------------
+	 * The reference's entry points take host pointers and hand the buffers back on return: every image crosses host memory
+	 * once more than the link asks for (a copy into page-locked staging, a copy out of it).  A caller that keeps its images in memory
+	 * from rir_host_alloc spares both: translate / gaussian_filter / bad_pixels_correct / rir_filter_chain / rir_gaussian_filter_u16 find such
+	 * buffers (a registry of this library's blocks) and run their kernel on them in place.  The Python mirror returns its results in such
+	 * memory, so the result of one call is the next call's input without a copy.  rir_host_alloc: NULL without a device or when the blocks
+	 * handed out would exceed RIR_HOST_ALLOC_MAX_MB (256).  rir_host_free: only blocks of rir_host_alloc (anything else is left alone).
+	 * rir_gaussian_filter_u16: gaussian_filter (reference signal_processing.cpp:79-148) of a uint16 image, bit-identical to converting it to
+	 * float32 first as the reference's wrapper does (rir_signal_processing.py:85-113); radius <= 4, -1 otherwise. */
+	void *rir_host_alloc(long long bytes);
+	void rir_host_free(void *p);
+	int rir_host_is_page_locked(const void *p, long long bytes);
+	int rir_gaussian_filter_u16(unsigned short *src, float *dst, int w, int h, float sigma);
+
 	/* ---- bounded-loss step on a device-resident stream -------------------------------------------------
 	 * The loss injection of H264_Saver::addImageLossyNoCamera / addLoss (reference src/cpp/video_io/h264.cpp:2253-2607)
 	 * as a stream operator: uint16 frames [n][h][w] in HBM in and out (distinct buffers), one state object per

@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <tuple>
 
 #ifndef RIR_SPIN_WAIT
@@ -428,6 +430,79 @@ namespace rir
 			return f;
 		}
 	} // namespace
+	namespace
+	{
+		struct HostBlocks
+		{
+			std::mutex mu;
+			std::map<uintptr_t, size_t> live; // start -> bytes
+			size_t total = 0;
+		};
+		HostBlocks &host_blocks()
+		{
+			static HostBlocks *b = new HostBlocks; // (leaked on purpose: blocks may be freed by finalisers at process exit)
+			return *b;
+		}
+		size_t host_blocks_limit()
+		{
+			static const size_t lim = [] {
+				const char *e = std::getenv("RIR_HOST_ALLOC_MAX_MB");
+				const long mb = e ? std::atol(e) : 256;
+				return (size_t)(mb < 0 ? 0 : mb) << 20;
+			}();
+			return lim;
+		}
+	} // namespace
+	void *host_block_alloc(size_t bytes)
+	{
+		if (bytes == 0 || !device_ready())
+			return nullptr;
+		HostBlocks &b = host_blocks();
+		{
+			std::lock_guard<std::mutex> g(b.mu);
+			if (b.total + bytes > host_blocks_limit())
+				return nullptr;
+			b.total += bytes; // (reserved before the slow call below)
+		}
+		void *p = nullptr;
+		if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess || !p)
+		{
+			(void)hipGetLastError();
+			std::lock_guard<std::mutex> g(b.mu);
+			b.total -= bytes;
+			return nullptr;
+		}
+		std::lock_guard<std::mutex> g(b.mu);
+		b.live[(uintptr_t)p] = bytes;
+		return p;
+	}
+	void host_block_free(void *p)
+	{
+		if (!p)
+			return;
+		HostBlocks &b = host_blocks();
+		{
+			std::lock_guard<std::mutex> g(b.mu);
+			auto it = b.live.find((uintptr_t)p);
+			if (it == b.live.end())
+				return; // (not one of ours: left alone)
+			b.total -= it->second;
+			b.live.erase(it);
+		}
+		(void)hipHostFree(p);
+	}
+	bool host_block_contains(const void *p, size_t bytes)
+	{
+		HostBlocks &b = host_blocks();
+		std::lock_guard<std::mutex> g(b.mu);
+		if (b.live.empty())
+			return false;
+		auto it = b.live.upper_bound((uintptr_t)p);
+		if (it == b.live.begin())
+			return false;
+		--it;
+		return (uintptr_t)p >= it->first && (uintptr_t)p + bytes <= it->first + it->second;
+	}
 	bool abi_zero_copy()
 	{
 		static const bool on = [] {
@@ -449,6 +524,11 @@ namespace rir
 	}
 	void set_gaussian_reference_order(bool on) { gauss_order_flag().store(on ? 1 : 0, std::memory_order_relaxed); }
 } // namespace rir
+// Page-locked memory for the caller's own images (include/rir_amd_device.h): an entry point that is given buffers inside such a block
+// works on them in place.  NULL when there is no device, or when the blocks handed out would exceed RIR_HOST_ALLOC_MAX_MB.
+RIR_EXPORT void *rir_host_alloc(int64_t bytes) { return bytes > 0 ? rir::host_block_alloc((size_t)bytes) : nullptr; }
+RIR_EXPORT void rir_host_free(void *p) { rir::host_block_free(p); }
+RIR_EXPORT int rir_host_is_page_locked(const void *p, int64_t bytes) { return p && bytes > 0 && rir::host_block_contains(p, (size_t)bytes) ? 1 : 0; }
 RIR_EXPORT void rir_set_gaussian_reference_order(int on) { rir::set_gaussian_reference_order(on != 0); }
 RIR_EXPORT int rir_gaussian_reference_order() { return rir::gaussian_reference_order() ? 1 : 0; }
 

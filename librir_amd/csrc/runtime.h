@@ -158,5 +158,13 @@ namespace rir
 	// tables and payload written, the loader's frames written over the link by the kernels themselves: no copy calls, no device round trip
 	// per chunk).  RIR_ABI_ZERO_COPY=0 turns that off (copies through device buffers, as before round 5).
 	bool abi_zero_copy();
+	// Page-locked memory handed OUT to callers (rir_host_alloc: the Python mirror builds the arrays it returns on such blocks).  An entry
+	// point that finds a caller's buffer wholly inside a live block runs its kernel on that memory as it is - nothing is staged, nothing is
+	// copied back - as it does on its own staging buffers.  A registry of this library's own blocks (a map under a mutex: ~0.1 us a look-up),
+	// not a query of the runtime.  The blocks together stay below RIR_HOST_ALLOC_MAX_MB (256): beyond that host_block_alloc says no and
+	// the caller takes ordinary memory.
+	void *host_block_alloc(size_t bytes);
+	void host_block_free(void *p);
+	bool host_block_contains(const void *p, size_t bytes);
 
 } // namespace rir

@@ -165,8 +165,12 @@ namespace
 	// before the copy calls' own cost): no copy call, one launch, one wait.  RIR_ABI_ZERO_COPY=0: a transfer into / out of device buffers
 	// around the kernel, as before.  `slot`: byte offset in the input staging buffer (a call may stage two images).
 	// -> the address the kernel reads (nullptr on failure)
+	// A caller's buffer that lies in page-locked memory of this library (rir_host_alloc: the arrays the Python mirror returns, which are the
+	// next call's input) is worked on where it is: no staging copy in, no copy back (round 6: the reference's three-call configs[2] path).
 	const void *stage_in(HostScratch &s, DeviceBuffer &d, const void *h_src, size_t bytes, size_t slot, hipStream_t st)
 	{
+		if (abi_zero_copy() && host_block_contains(h_src, bytes))
+			return h_src;
 		if (!s.h_in.ptr || s.h_in.cap < slot + bytes)
 			return nullptr;
 		char *stage = s.h_in.as<char>() + slot;
@@ -179,8 +183,15 @@ namespace
 	}
 	// -> the address the kernel writes its result to (nullptr on failure); keep: the caller's buffer holds values the kernel keeps
 	// (translate "noborder"), it goes in first
-	void *stage_out(HostScratch &s, DeviceBuffer &d, void *h_dst, size_t bytes, bool keep, hipStream_t st)
+	// in / in_bytes: what the kernel reads (stage_in's answer): a destination that overlaps it is staged, the kernels do not work in place
+	void *stage_out(HostScratch &s, DeviceBuffer &d, void *h_dst, size_t bytes, bool keep, hipStream_t st, const void *in = nullptr, size_t in_bytes = 0)
 	{
+		if (abi_zero_copy() && host_block_contains(h_dst, bytes))
+		{
+			const char *a = static_cast<const char *>(in), *b = static_cast<const char *>(h_dst);
+			if (!in || a + in_bytes <= b || b + bytes <= a)
+				return h_dst; // (keep: the caller's values are where the kernel finds them)
+		}
 		if (!s.h_out.reserve(bytes))
 			return nullptr;
 		if (keep)
@@ -194,6 +205,8 @@ namespace
 	// the call's result (at `from`, what stage_out returned) -> the caller: waits for the stream (the call is synchronous)
 	bool hand_out(HostScratch &s, void *h_dst, const void *from, size_t bytes, hipStream_t st)
 	{
+		if (from == h_dst) // the kernel wrote into the caller's page-locked buffer
+			return hip_ok(wait_stream(st), "sync");
 		if (from != s.h_out.ptr && !hip_ok(hipMemcpyAsync(s.h_out.ptr, from, bytes, hipMemcpyDeviceToHost, st), "D2H"))
 			return false;
 		if (!hip_ok(wait_stream(st), "sync"))
@@ -625,7 +638,7 @@ RIR_EXPORT int translate(int type, void *src, void *dst, int w, int h, float dx,
 	float *off = reinterpret_cast<float *>(s.h_in.as<char>() + off_at); // (page-locked: the kernel reads the two floats from there)
 	off[0] = dx, off[1] = dy;
 	const void *in = stage_in(s, s.a, src, bytes, 0, st);
-	void *out = in ? stage_out(s, s.b, dst, bytes, keeps_dst, st) : nullptr;
+	void *out = in ? stage_out(s, s.b, dst, bytes, keeps_dst, st, in, bytes) : nullptr;
 	if (!in || !out)
 		return -1;
 	if (rir_translate_device(type, in, out, w, h, 1, off, 0, background, strategy, st) != 0)
@@ -646,10 +659,34 @@ RIR_EXPORT int gaussian_filter(float *src, float *dst, int w, int h, float sigma
 	if (!s.h_in.reserve(bytes))
 		return -1;
 	const void *in = stage_in(s, s.a, src, bytes, 0, st);
-	void *out = in ? stage_out(s, s.b, dst, bytes, false, st) : nullptr;
+	void *out = in ? stage_out(s, s.b, dst, bytes, false, st, in, bytes) : nullptr;
 	if (!in || !out)
 		return -1;
 	if (rir_gaussian_filter_device(static_cast<const float *>(in), static_cast<float *>(out), w, h, 1, sigma, st) != 0)
+		return -1;
+	return hand_out(s, dst, out, bytes, st) ? 0 : -1;
+}
+
+// Extension: gaussian_filter of a uint16 image - what the reference's wrapper computes for one (it converts to float32 first,
+// rir_signal_processing.py:85-113; every uint16 is a float32, so the conversion inside the kernel gives the same bits) - with half the bytes
+// up the link.  Radius <= 4 (sigma < 2.5); -1 otherwise: the caller converts and takes gaussian_filter.
+RIR_EXPORT int rir_gaussian_filter_u16(unsigned short *src, float *dst, int w, int h, float sigma)
+{
+	if (!device_ready())
+		return -1;
+	if (!src || !dst || w <= 0 || h <= 0 || !(sigma > 0) || gaussian_radius(sigma) > 4)
+		return -1;
+	HostScratch &s = scratch();
+	std::lock_guard<std::mutex> g(s.mu);
+	const size_t in_bytes = (size_t)w * h * 2, bytes = (size_t)w * h * sizeof(float);
+	hipStream_t st = default_stream();
+	if (!s.h_in.reserve(in_bytes))
+		return -1;
+	const void *in = stage_in(s, s.a, src, in_bytes, 0, st);
+	void *out = in ? stage_out(s, s.b, dst, bytes, false, st, in, in_bytes) : nullptr;
+	if (!in || !out)
+		return -1;
+	if (rir_gaussian_filter_u16_device(static_cast<const unsigned short *>(in), static_cast<float *>(out), w, h, 1, sigma, st) != 0)
 		return -1;
 	return hand_out(s, dst, out, bytes, st) ? 0 : -1;
 }
@@ -721,7 +758,7 @@ RIR_EXPORT int bad_pixels_correct(int handle, unsigned short *in, unsigned short
 	if (!s.h_in.reserve(bytes))
 		return -1;
 	const void *src = stage_in(s, s.a, in, bytes, 0, st);
-	void *dst = src ? stage_out(s, s.b, out, bytes, false, st) : nullptr;
+	void *dst = src ? stage_out(s, s.b, out, bytes, false, st, src, bytes) : nullptr;
 	if (!src || !dst)
 		return -1;
 	if (rir_bad_pixels_correct_device(handle, static_cast<const unsigned short *>(src), static_cast<unsigned short *>(dst), 1, st) != 0)
@@ -750,7 +787,7 @@ RIR_EXPORT int rir_filter_chain(int bad_pixels_handle, unsigned short *in, unsig
 	float *off = reinterpret_cast<float *>(s.h_in.as<char>() + off_at); // (page-locked: the kernel reads the two floats from there)
 	off[0] = dx, off[1] = dy;
 	const void *src = stage_in(s, s.a, in, bytes, 0, st);
-	void *dst = src ? stage_out(s, s.b, out, bytes, false, st) : nullptr;
+	void *dst = src ? stage_out(s, s.b, out, bytes, false, st, src, bytes) : nullptr;
 	if (!src || !dst)
 		return -1;
 	if (rir_filter_chain_device(bad_pixels_handle, static_cast<const unsigned short *>(src), static_cast<unsigned short *>(dst), w, h, 1, sigma, off, 0,

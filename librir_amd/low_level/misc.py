@@ -36,6 +36,13 @@ def _load():
 
 
 _lib = _load()
+_has_host_alloc = hasattr(_lib, "rir_host_alloc")
+if _has_host_alloc:
+    _lib.rir_host_alloc.restype = ct.c_void_p
+    _lib.rir_host_alloc.argtypes = [ct.c_int64]
+    _lib.rir_host_free.restype = None
+    _lib.rir_host_free.argtypes = [ct.c_void_p]
+    _lib.rir_host_is_page_locked.argtypes = [ct.c_void_p, ct.c_int64]
 # same module-level names as the reference wrapper
 _tools = _lib
 _geometry = None  # (the polygon library is not part of this build: a drop-in keeps the reference's own)
@@ -155,3 +162,72 @@ def last_error():
         buf = ct.create_string_buffer(n.value + 1)
         _lib.get_last_log_error(buf, ct.byref(n))
     return buf.raw[: n.value].decode("utf-8", errors="replace")
+
+
+# ---- result arrays in page-locked memory (opt-in) ------------------------------------------------------------------------------------
+_free_result_blocks = {}  # nbytes -> a few memory blocks whose arrays have died
+# RIR_PINNED_RESULTS=1 in the environment or results_in_page_locked_memory(True): see result_buffer
+_pinned_results = [os.environ.get("RIR_PINNED_RESULTS", "0") == "1"]
+
+
+def results_in_page_locked_memory(on=True):
+    """The arrays that ``translate`` / ``gaussian_filter`` / ``BadPixels.correct`` / ``filter_chain`` return are built on page-locked memory of the
+    library (``rir_host_alloc``) from now on (or, ``on=False``, on ordinary memory again: the default).  The library's entry points find buffers
+    that lie in such memory and run their kernels on them in place - no staging copy in, none out - so a chain of calls in which one call's
+    result is the next call's input (the reference's ``translate(gaussian_filter(bad_pixels.correct(img)))``) stages only the first image:
+    5.0-5.1 k images/s instead of 3.9-4.0 k for 640x512 (tests/perf/three_call_probe.py).  Not the default because a result that is consumed by
+    numpy code instead is read cold - the GPU wrote it, and page-locked memory lies on the GPU's NUMA node - where the staged copy leaves it in
+    the caches of the copying cores: ``x.astype(...)`` of such a result takes 80-220 us instead of 110.  Returns the previous setting."""
+    old = _pinned_results[0]
+    _pinned_results[0] = bool(on) and _has_host_alloc
+    return old
+
+
+class _PinnedBlock:
+    """a block of rir_host_alloc (page-locked memory of the library) with the buffer interface numpy builds an array on"""
+
+    __slots__ = ("ptr", "buf")
+
+    def __init__(self, ptr, n):
+        self.ptr = ptr
+        self.buf = (ct.c_char * n).from_address(ptr)
+
+    def __del__(self):
+        try:
+            _lib.rir_host_free(ct.c_void_p(self.ptr))
+        except Exception:  # (interpreter shutdown)
+            pass
+
+
+def result_buffer(shape, dtype):
+    """A fresh C-contiguous array for the result of a library call, as the reference's wrappers return (a new array per call; contents NOT
+    cleared: the library writes every element or fails).  Ordinary memory by default.  With ``results_in_page_locked_memory`` the memory of a
+    result of 64 KB or more is a block of ``rir_host_alloc``, recycled where that is safe: the array handed out is built directly on the block
+    (views of it keep IT alive: numpy stops collapsing ``base`` chains at the first non-array), and a weak-reference finaliser returns the block
+    to a small pool when the array object is collected - when neither the caller nor any view refers to it any more.  No reference counts are
+    inspected: an array the caller keeps is never written to again.  Where the library says no (no device, its limit on such memory reached):
+    ordinary memory."""
+    dt = np.dtype(dtype)
+    shape = tuple(int(x) for x in shape)
+    n = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    if n < (64 << 10) or not _pinned_results[0]:
+        return np.empty(shape, dtype=dt)
+    import weakref
+
+    pool = _free_result_blocks.setdefault(n, [])
+    try:
+        block = pool.pop()
+    except IndexError:
+        ptr = _lib.rir_host_alloc(ct.c_int64(n))
+        if not ptr:
+            return np.empty(shape, dtype=dt)
+        block = _PinnedBlock(ptr, n)
+    a = np.ndarray(shape, dtype=dt, buffer=block.buf)
+    f = weakref.finalize(a, _recycle_result_block, pool, block)
+    f.atexit = False
+    return a
+
+
+def _recycle_result_block(pool, block):
+    if len(pool) < 4:
+        pool.append(block)

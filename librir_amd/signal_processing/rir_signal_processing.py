@@ -9,7 +9,7 @@ import ctypes as ct
 import numpy as np
 
 from ..low_level.misc import _signal_processing as _sp
-from ..low_level.misc import last_error, toCharP
+from ..low_level.misc import last_error, result_buffer, toCharP
 
 # numpy dtype -> type character of the C entry point.  The reference maps int64 to 'L'
 # (duplicated dict key, rir_signal_processing.py:15-16); both int64 and uint64 are accepted here
@@ -30,6 +30,7 @@ _DTYPES = {
 
 _sp.translate.argtypes = [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_float, ct.c_float, ct.c_void_p, ct.c_char_p]
 _sp.gaussian_filter.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_float]
+_sp.rir_gaussian_filter_u16.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_int, ct.c_float]
 _sp.find_median_pixel.argtypes = [ct.c_void_p, ct.c_int, ct.c_float]
 _sp.find_median_pixel_mask.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_int, ct.c_float]
 _sp.bad_pixels_create.argtypes = [ct.c_void_p, ct.c_int, ct.c_int]
@@ -57,7 +58,9 @@ def translate(image, dx, dy, strategy=str(), background=None):
         strat = b"background"
     src = np.ascontiguousarray(image)  # (the library reads it and leaves it alone: no copy of an array that is contiguous already)
     # "noborder" leaves the values of the pixels it does not reach in place: only then does the result start as a copy of the image
-    dst = np.array(image, order="C", copy=True) if strat in (b"", b"noborder") else np.empty(src.shape, dtype=src.dtype)
+    dst = result_buffer(src.shape, src.dtype)
+    if strat in (b"", b"noborder"):
+        np.copyto(dst, src)
     back = np.zeros(1, dtype=image.dtype)
     if background is not None:
         back[0] = background
@@ -73,9 +76,16 @@ def gaussian_filter(image, sigma=1.0):
     image = np.asarray(image)
     if image.ndim != 2:
         raise RuntimeError("gaussian_filter: wrong input image dimension")
-    src = np.ascontiguousarray(image, dtype=np.float32)
-    dst = np.empty(image.shape, dtype=np.float32)  # (the library writes every pixel or fails)
-    r = _sp.gaussian_filter(src.ctypes.data, dst.ctypes.data, src.shape[1], src.shape[0], np.float32(sigma))
+    dst = result_buffer(image.shape, np.float32)  # (the library writes every pixel or fails)
+    r = -1
+    if image.dtype == np.uint16 and 0 < float(sigma) < 2.5:
+        # every uint16 is a float32: the kernel converts as it reads - the same bits as converting first (what the reference's wrapper does,
+        # rir_signal_processing.py:85-113), half the bytes up the link and no float copy of the image on the host
+        src = np.ascontiguousarray(image)
+        r = _sp.rir_gaussian_filter_u16(src.ctypes.data, dst.ctypes.data, src.shape[1], src.shape[0], np.float32(sigma))
+    if r < 0:
+        src = np.ascontiguousarray(image, dtype=np.float32)
+        r = _sp.gaussian_filter(src.ctypes.data, dst.ctypes.data, src.shape[1], src.shape[0], np.float32(sigma))
     if r < 0:
         raise RuntimeError("An error occured while calling 'gaussian_filter': " + last_error())
     return dst
@@ -113,7 +123,7 @@ def bad_pixels_correct(handle, img):
     if img.ndim != 2:
         raise RuntimeError("bad_pixels_correct: wrong input image dimension")
     src = np.ascontiguousarray(img, dtype=np.uint16)
-    out = np.empty(src.shape, dtype=np.uint16)  # (the library writes every pixel or fails)
+    out = result_buffer(src.shape, np.uint16)  # (the library writes every pixel or fails)
     r = _sp.bad_pixels_correct(handle, src.ctypes.data, out.ctypes.data)
     if r < 0:
         raise RuntimeError("An error occured while calling 'bad_pixels_correct': " + last_error())
@@ -138,7 +148,7 @@ def filter_chain(image, bad_pixels, sigma, dx, dy, strategy="nearest", backgroun
     if strategy == "constant":
         strategy = "background"
     handle = 0 if bad_pixels is None else int(getattr(bad_pixels, "handle", bad_pixels))
-    out = np.empty(img.shape, dtype=np.uint16)
+    out = result_buffer(img.shape, np.uint16)
     back = np.array([background], dtype=np.uint16)
     if _sp.rir_filter_chain(handle, img.ctypes.data, out.ctypes.data, img.shape[1], img.shape[0], float(sigma), float(dx), float(dy), back.ctypes.data,
                             toCharP(strategy)) < 0:

@@ -385,3 +385,67 @@ def test_the_three_filters_in_one_call_per_host_image(oracle):
             filter_chain(fr[1].astype(np.float32), bp, 0.75, 0, 0)
         with pytest.raises(RuntimeError):
             filter_chain(fr[1][:, :-1], bp, 0.75, 0, 0)  # the repair object was made for another image size
+
+
+def test_results_in_page_locked_memory_are_worked_on_in_place(oracle, lib):
+    """Round 6: the Python mirror returns its results in page-locked memory of the library (low_level.misc.result_buffer over rir_host_alloc) and an
+    entry point that finds its input or output there runs its kernel on it in place - the reference's three-call configs[2] chain then stages
+    only the caller's own image.  Same results as through ordinary memory, whichever of the buffers is page-locked; an output that overlaps its
+    input is staged; results the caller keeps are never written to again; gaussian_filter of a uint16 image = of its float32 copy, bit for bit.
+    (results_in_page_locked_memory: opt-in, see its docstring for why)"""
+    import ctypes as ct
+
+    from librir_amd.low_level.misc import _lib, result_buffer, results_in_page_locked_memory
+    from librir_amd.signal_processing import BadPixels, gaussian_filter, translate
+    from librir_amd.synthetic import inject_bad_pixels, s1_noisy_background
+
+    before = results_in_page_locked_memory(True)  # (opt-in: by default results are ordinary memory)
+    try:
+        _page_locked_results_case(oracle, lib, _lib, result_buffer, BadPixels, gaussian_filter, translate, inject_bad_pixels, s1_noisy_background, ct)
+    finally:
+        results_in_page_locked_memory(before)
+    a = BadPixels(s1_noisy_background(1, 512, 640, seed=1)[0]).correct(s1_noisy_background(1, 512, 640, seed=2)[0])
+    assert not _lib.rir_host_is_page_locked(ct.c_void_p(a.ctypes.data), ct.c_int64(a.nbytes))  # the default again
+
+
+def _page_locked_results_case(oracle, lib, _lib, result_buffer, BadPixels, gaussian_filter, translate, inject_bad_pixels, s1_noisy_background, ct):
+    h, w = 512, 640
+    fr = inject_bad_pixels(s1_noisy_background(6, h, w, seed=77), 40)
+    bp = BadPixels(fr[0])
+    xy = oracle.bad_pixels_detect(fr[0])
+    _, fc = oracle.bad_pixels_stats(fr[0])
+    locked = lambda a: bool(_lib.rir_host_is_page_locked(ct.c_void_p(a.ctypes.data), ct.c_int64(a.nbytes)))
+    kept = []
+    for i in range(1, 6):
+        a = bp.correct(fr[i])
+        assert locked(a) and not locked(fr[i]) and np.array_equal(a, oracle.bad_pixels_correct(fr[i], xy, fc))
+        g = gaussian_filter(a, 0.75)  # uint16 in page-locked memory -> the uint16 kernel, in place
+        g32 = gaussian_filter(fr[i].astype(np.float32) * 0 + a, 0.75)  # the same values as ordinary float32 memory -> staged
+        assert locked(g) and g.dtype == np.float32 and np.array_equal(g, g32)
+        assert np.allclose(g, oracle.gaussian_filter(a.astype(np.float32), 0.75), rtol=1e-5, atol=0)
+        t = translate(g, 1.25, -2.5, "nearest")  # float32 in page-locked memory in, page-locked out
+        assert locked(t) and np.array_equal(t, oracle.translate(g, 1.25, -2.5, "nearest"))
+        n = translate(g, 3.0, 0.0, "noborder")  # keeps what the wrapper put into the result: the source's values
+        assert np.array_equal(n, oracle.translate(g, 3.0, 0.0, "noborder"))
+        kept.append((a.copy(), a, g.copy(), g, t.copy(), t))
+    for a0, a, g0, g, t0, t in kept:  # nothing handed out earlier was written to by a later call
+        assert np.array_equal(a0, a) and np.array_equal(g0, g) and np.array_equal(t0, t)
+    # raw entry points on buffers of the caller's choice: page-locked in / ordinary out, the reverse, and one buffer for both (staged)
+    src = result_buffer((h, w), np.float32)
+    src[:] = fr[2]
+    exp = oracle.translate(np.array(src), -0.75, 0.1, "nearest")
+    back = np.zeros(1, np.float32)
+    for dst in (np.empty((h, w), np.float32), result_buffer((h, w), np.float32)):
+        assert lib.translate(ord("f"), src.ctypes.data, dst.ctypes.data, w, h, ct.c_float(-0.75), ct.c_float(0.1), back.ctypes.data, b"nearest") == 0
+        assert np.array_equal(dst, exp)
+    plain = np.array(src)
+    dst = result_buffer((h, w), np.float32)
+    assert lib.translate(ord("f"), plain.ctypes.data, dst.ctypes.data, w, h, ct.c_float(-0.75), ct.c_float(0.1), back.ctypes.data, b"nearest") == 0
+    assert np.array_equal(dst, exp)
+    same = result_buffer((h, w), np.float32)
+    same[:] = fr[2]
+    assert lib.translate(ord("f"), same.ctypes.data, same.ctypes.data, w, h, ct.c_float(-0.75), ct.c_float(0.1), back.ctypes.data, b"nearest") == 0
+    assert np.array_equal(same, exp)
+    # sigma beyond the uint16 kernel's radius: the wrapper converts and takes the float entry
+    big = gaussian_filter(fr[1][:67, :83], 3.0)
+    assert np.allclose(big, oracle.gaussian_filter(fr[1][:67, :83].astype(np.float32), 3.0), rtol=1e-5, atol=0)
