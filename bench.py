@@ -204,7 +204,7 @@ def abi_numbers(frames_np, D, ctx, frames, out, n, h, w):
     from librir_amd.video_io import IRMovie, IRSaver
 
     # (a full collection of Python's garbage collector walks every object of the process - a million with torch imported: 35 ms, as much as
-    # recording 2 000 frames - and one of the recordings below would pay it (tests/perf/first_run_probe.py: a single IRMovie[i] of 34.9 ms);
+    # recording 2 000 frames - and one of the recordings below would pay it (measured in round 5: a single IRMovie[i] of 34.9 ms);
     # what exists now is moved out of the collector's sight, the loops' own garbage is still collected)
     import gc
 

@@ -1867,12 +1867,13 @@ namespace rir
 		}
 		constexpr int WAVES = RIR_PACKED_WAVES;
 		const int cap = packed_lds_words(gop);
-		static int diag = -1;
-		if (diag < 0)
-		{
-			const char *ev = getenv("RIR_PACKED_ONE_CURSOR"); // measurement aid (tests/perf/packed_time.py): 1 = every segment through the low cursor
-			diag = ev ? (atoi(ev) != 0) : 0;
-		}
+		// (a build with -DRIR_PACKED_ONE_CURSOR sends every segment through the low cursor: the measurement of DESIGN.md §3 - 207 us a launch
+		// against 162-165 with two; the product library reads no such switch)
+#ifdef RIR_PACKED_ONE_CURSOR
+		constexpr int diag = 1;
+#else
+		constexpr int diag = 0;
+#endif
 		const size_t lds = (size_t)WAVES * cap * 8 + (1 + WAVES) * 8 + 2 * WAVES * 4;
 		const bool aligned = ((npx & 7) == 0) && ((((uintptr_t)d_frames) & 15) == 0);
 		const int nfast = aligned ? (int)(npx / RIRB1_TILE_PX) : 0; // tiles that lie whole inside the frame

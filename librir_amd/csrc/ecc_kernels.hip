@@ -111,7 +111,7 @@ namespace rir
                                  their 8 service workgroups.  (The first form of the kernel - no service workgroups, the adding done by each sequence's
                                  slice 0 - at 128 VGPRs, 4 workgroups per CU, (pixels per round, waves per SIMD): (1, 4) 70-75 k frames/s over 8
                                  sequences, (2, 4) 65-69, (3, 4) 62-66, (5, 3) 62-65.)  The pixel loop is bound by latency - 44 % of its L2 accesses miss:
-                                 a sequence's four arrays are 5.2 MB, an XCD's L2 4 MB (scripts/ecc_pmc.sh) - which more pixels per round did not hide */
+                                 a sequence's four arrays are 5.2 MB, an XCD's L2 4 MB (profiles/r04_pmc_ecc.json) - which more pixels per round did not hide */
 #endif
 #ifndef RIR_ECC_MULTI_MARGIN
 #define RIR_ECC_MULTI_MARGIN 0

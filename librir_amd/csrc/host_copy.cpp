@@ -312,7 +312,7 @@ RIR_EXPORT int rir_host_file_rw(int fd, void *buf, int64_t bytes, int64_t file_o
 // First touch of fresh memory, ahead of whoever fills it: one atomic compare-and-swap of a byte with itself per 4 KiB page of [buf, buf + bytes), on the calling thread.
 // A stack that a slice of a movie is read into is fresh memory: its pages are made (zeroed, 2 MiB at a time where the allocator asked for
 // huge pages) under the threads that copy the images in - 25-35 us per 640x512 image on top of a 17 us read.  Called from a thread of its own
-// while the images are being read, the pages are there before the copies arrive (tests/perf/slice_probe.py).  It is an atomic
+// while the images are being read, the pages are there before the copies arrive (profiles/r05_movie_bulk.txt).  It is an atomic
 // read-modify-write that changes nothing: a byte the reader has stored already stays what the reader stored, whichever comes first.
 // (MADV_POPULATE_WRITE over the helper threads was measured too: 23-30 ms per 655 MB against 15 ms for this loop - not kept.)
 RIR_EXPORT int rir_host_touch(void *buf, int64_t bytes)

@@ -32,7 +32,7 @@ namespace rir
 		constexpr int kBlock = 256;		 // 4 wavefronts
 		constexpr int kScanBlock = 1024; // the one workgroup that turns per-block root counts into offsets
 // Tile of the first launch: 64 columns (a wavefront per row piece) x RIR_LABEL_TILE_H rows, RIR_LABEL_TILE_THREADS threads.  Measured on 640x512
-// images (scripts/variants.py, tests/perf/label_time.py): heights 8 / 16 / 32 / 64 with 256 / 512 / 1024 threads are within 8 % of each other on
+// images (scripts/variants.py; profiles/r05_label_time.txt): heights 8 / 16 / 32 / 64 with 256 / 512 / 1024 threads are within 8 % of each other on
 // every kind of image; 32 rows with 1024 threads (two rows a wavefront) is the best by a few per cent (regions 25.4 us against 27.3 for 16 rows
 // and 256 threads, vertical stripes 31.6 against 36.0, the spiral 183 against 206).
 #ifndef RIR_LABEL_TILE_H

@@ -161,7 +161,7 @@ namespace
 	// The caller's images are pageable memory.  Handed to hipMemcpyAsync as they are, the runtime stages them itself, a chunk at a time on
 	// the calling thread (measured, one 640x512 image: 70-130 us each way).  Here an image is staged in page-locked memory - the copy cut
 	// over the helper threads (host_copy.cpp) - and the KERNEL works on the staging buffers themselves, reading its input and writing its
-	// result over the link (tests/perf/zero_copy_probe.py: translate of a float image 54 us that way, 89 us with a copy in and a copy out,
+	// result over the link (profiles/r05_zero_copy_probe.txt: translate of a float image 54 us that way, 89 us with a copy in and a copy out,
 	// before the copy calls' own cost): no copy call, one launch, one wait.  RIR_ABI_ZERO_COPY=0: a transfer into / out of device buffers
 	// around the kernel, as before.  `slot`: byte offset in the input staging buffer (a call may stage two images).
 	// -> the address the kernel reads (nullptr on failure)

@@ -522,7 +522,7 @@ namespace
 		uint64_t nframes = 0;
 		// Lossless chunks straight from page-locked memory.  A chunk whose frames all came through add_image is encoded where it lies: the
 		// kernels read the staged frames over the link themselves and write tables and payload into the writer's page-locked buffer - no
-		// upload calls, no read-back, no wait in the call that completes the chunk (tests/perf/zero_copy_probe.py: 711 us for 50 frames
+		// upload calls, no read-back, no wait in the call that completes the chunk (profiles/r05_zero_copy_probe.txt: 711 us for 50 frames
 		// of 640x512, the link's rate).  The caller fills the OTHER staging buffer meanwhile; one chunk is in flight at most, the call
 		// that completes the next one collects it (and waits for it: the link is then the limit).
 		// (decided at open(): the switch, and a chunk of at most kInFlightMaxChunkBytes - the second staging buffer and the second raw
@@ -1892,7 +1892,7 @@ namespace
 			flags[0] = 0, flags[1] = 0;
 			// A chunk that is only wanted on the host (the read-ahead of a sequential reader, no read-back filter in play) is decoded where
 			// it lies: the kernel reads tables and payload from this page-locked buffer and writes the images into ctx.h_frames, both over
-			// the link, at the link's rate (tests/perf/zero_copy_probe.py: 667 us for 50 frames of 640x512 against 590 for the bare copy of
+			// the link, at the link's rate (profiles/r05_zero_copy_probe.txt: 667 us for 50 frames of 640x512 against 590 for the bare copy of
 			// the images) - no upload calls, no device copy of the chunk, no copy back.  ctx.on_device says which it was.
 			const bool host_only = to_host && abi_zero_copy() && ctx.h_frames.ptr && !(min_T && min_T_rows > 0) && !bp_enabled && !motion_enabled;
 			ctx.on_device = !host_only;

@@ -165,11 +165,9 @@ _sp.keep_largest_area.argtypes = [ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int, 
 
 def extract_times(time_series, strategy="union"):
     """
-    Create a unique time vector from several ones (reference rir_signal_processing.py:150-207).
-    time_series is a list of input time series
-    strategy is either 'union' (take the union of all time series) or 'inter'
-    Returns a growing time vector containing all different time values given in
-    time_series, without redundant times.
+    One time axis out of several (same call as reference rir_signal_processing.py:150-207): ``time_series`` is a list of time vectors,
+    ``strategy`` says which span the result covers - 'union': from the earliest to the latest sample of any series, 'inter': only the span
+    all of them share.  The result is increasing and holds every distinct sample time of the inputs inside that span once.
 
     Where the reference never returns (an empty series, a NaN at either end of one or two NaN in one, a series with no sample inside the
     common range of 'inter') the library refuses and this raises RuntimeError.
@@ -195,13 +193,9 @@ def extract_times(time_series, strategy="union"):
 
 def resample_time_serie(x, y, time_vector, padd=None, interp=True):
     """
-    Resample a time serie based on a new time vector (reference rir_signal_processing.py:210-270)
-    - x: time vector of the time serie
-    - y: values associated to the time serie
-    - time_vector: new time vector
-    - padd: if not None, padd the output serie with this value at boundaries
-    - interp: if True, interpolate values.
-    Returns the new y values corresponding to the new time vector.
+    The series (``x`` sample times, ``y`` values) read off at the times of ``time_vector`` (same call as reference
+    rir_signal_processing.py:210-270).  ``interp`` true: linear interpolation between the two samples around each new time, false: the value of
+    the nearer of the two.  New times outside the series get ``padd`` when it is given, the first / last value otherwise.  Returns the values.
 
     (The reference gives the library room for 2 * len(x) values and raises "unknown error" for a longer time_vector; here the room is
     the time vector's length.)
@@ -243,11 +237,8 @@ def _labelling_input(image, background_value, name):
 
 def label_image(image: np.ndarray, background_value=0):
     """
-    Closed Component Labelling algorithm (reference rir_signal_processing.py:319-370)
-    Returns a tuple (image,areas, first_points), each index of the list corresponding
-    to the label value.
-    The index 0 corresponds to the background, and does not contain meaningful
-    information.
+    Connected components of ``image`` (same call as reference rir_signal_processing.py:319-370): -> (labels int32 of the image's shape, areas,
+    first_points); entry ``k`` of the two tables belongs to label ``k``, entry 0 to the background (nothing useful in it).
 
     Pixels differing from background_value form the components; vertical neighbours are joined whatever their values, horizontal
     neighbours when their values are equal (as upstream); labels follow the raster order of the components' first pixels.  As upstream,
@@ -266,9 +257,8 @@ def label_image(image: np.ndarray, background_value=0):
 
 def keep_largest_area(image, background_value=0, foreground_value=1):
     """
-    Returns an image where the largest closed region of input image is set to
-    foreground_value,
-    the rest to background_value (reference rir_signal_processing.py:373-415)
+    int32 image with ``foreground_value`` on the component of ``image`` that has the most pixels and ``background_value`` everywhere else (same
+    call as reference rir_signal_processing.py:373-415; among equals the component met first in raster order wins).
     """
     img, background, dt = _labelling_input(image, background_value, "keep_largest_area")
     res = np.empty(img.shape, dtype=np.int32)

@@ -428,7 +428,7 @@ class IRMovie(object):
             # chunk's encode reading its frames from host memory (705 us) and a chunk's decode writing its frames there (660 us) take
             # 1 210-1 270 us together on two streams, with or without disjoint compute-unit masks, while the copy engines' transfers up and
             # down do overlap (587 + 585 -> 686 us), and so do a copy call upwards and the decode's writes (581 + 660 -> 812): it is the
-            # kernels' reads of host memory that do not share the link.  tests/perf/link_duplex_probe.py, profiles/r05_link_duplex.txt.)
+            # kernels' reads of host memory that do not share the link.  profiles/r05_link_duplex.txt.)
             for written, pos in enumerate(range(start_img, start_img + count)):
                 image = self.load_pos(pos, 0)
                 saver.add_image(image, stamps[pos], attributes=self.frame_attributes if frame_attributes is None else frame_attributes[written])

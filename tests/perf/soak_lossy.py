@@ -1,4 +1,4 @@
-"""One-off soak: random parameters of the bounded-loss step, device stream operator against the oracle.
+"""Soak: random parameters of the bounded-loss step (every form: constant budgets, speculative with 1..8 passes, general), device stream operator against the oracle.
     python tests/perf/soak_lossy.py [cases] [seed] [longest run, default 70 frames]"""
 import os, sys
 import numpy as np, torch
@@ -11,6 +11,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 nmax = int(sys.argv[3]) if len(sys.argv) > 3 else 70  # (the constant-budget kernel has three phases: a run of 45 + ring length frames or more goes through all of them)
 bad = 0
 const_offered = const_taken = 0
+spec = np.zeros(4, np.int64)  # groups through the speculative launches, offered, committed, passes
 for k in range(cases):
     h, w = int(rng.integers(4, 50)), int(rng.integers(8, 120))
     if rng.integers(0, 2):
@@ -29,6 +30,7 @@ for k in range(cases):
         fr = (1000 + (fr >> int(rng.integers(6, 12)))).astype(np.uint16)
         for j in rng.integers(0, n, 3):
             fr[j] = 1000
+    os.environ["RIR_LOSSY_SPEC_PASSES"] = str(int(rng.integers(1, 9)))
     L = OracleLossy(O, w, h, hl, low_err=low, high_err=high, std_factor=sf, running_average=ra, subtract_min=smin)
     exp, elo, ehi = [], [], []
     for i in range(n):
@@ -43,11 +45,13 @@ for k in range(cases):
         o_, t_ = ls.path_stats()
         const_offered += o_
         const_taken += t_
+        spec += np.array(ls.spec_stats())
     got = torch.cat([p_[0] for p_ in parts]).cpu().numpy()
     ok = np.array_equal(got, np.stack(exp)) and np.concatenate([p_[1] for p_ in parts]).tolist() == elo and np.concatenate([p_[2] for p_ in parts]).tolist() == ehi
     if not ok:
         bad += 1
         print("FAIL", k, dict(h=h, w=w, hl=hl, n=n, low=low, high=high, sf=sf, ra=ra, smin=smin, add=add), int((got != np.stack(exp)).sum()))
     ls.close()
-print("soak: %d cases, %d failures; groups offered to the constant-budget form %d, taken %d" % (cases, bad, const_offered, const_taken))
+print("soak: %d cases, %d failures; groups offered to the constant-budget form %d, taken %d; through the speculative launches %d, offered %d, committed %d, passes %d"
+      % (cases, bad, const_offered, const_taken, spec[0], spec[1], spec[2], spec[3]))
 sys.exit(1 if bad else 0)
