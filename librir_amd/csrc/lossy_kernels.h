@@ -137,7 +137,7 @@ namespace rir
 	// window mean of frame k is its own chain of 40 additions over statistics that are all known).  The sums are right up to and including the first
 	// frame m whose true budget is not the table's; that entry is corrected and the group is stepped again, up to `passes` times; a group whose table
 	// then verifies is committed (shadow -> state, window, budgets), any other is left to the resident kernel behind, exactly as a declined
-	// constant-budget group is.  A stream whose groups keep failing is not offered for a while (a counter on the device: 1, 3, 7, 15 groups).
+	// constant-budget group is.  A stream whose groups keep failing is not offered for a while (a counter on the device: 1, 3, 7 ... 63 groups).
 	struct LossySpec
 	{
 		LossyDeviceState shadow;   // where a pass leaves the state after the group (ring: the slots the group writes)

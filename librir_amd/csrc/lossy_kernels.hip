@@ -2648,7 +2648,7 @@ namespace rir
 				bk[1] = 0u;
 			else if (offered)
 			{ // (a group that was not offered - precondition, back-off - does not count)
-				const unsigned int streak = bk[1] < 4u ? bk[1] + 1u : 4u;
+				const unsigned int streak = bk[1] < 6u ? bk[1] + 1u : 6u; // 1, 3, 7, 15, 31, 63 groups without an offer
 				bk[1] = streak, bk[0] = (1u << streak) - 1u;
 			}
 			__hip_atomic_store(as_global(ok_word), all ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
