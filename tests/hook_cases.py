@@ -280,6 +280,43 @@ def const_pairs(pairs):
     del os.environ["RIR_LOSSY_CONST_PAIRS"]
 
 
+def spec_pairs(pairs):
+    """The speculative form's instantiations of the streaming kernel for 4 and 8 pixels per thread (lossy_const_pairs picks them for many
+    streams; small test frames would only ever see 2): forced through RIR_LOSSY_CONST_PAIRS on static scenes with stdFactor 5 - committed,
+    frames and budgets the oracle's - and on S1 (the group goes to the general form)."""
+    import torch
+
+    from librir_amd import device as D
+    from oracle.pyoracle import Oracle
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_lossy import CONST_CASES, _oracle_track
+    from test_gpu_lossy_spec import static_scene
+
+    oracle = Oracle()
+    os.environ["RIR_LOSSY_CONST_PAIRS"] = str(pairs)
+    os.environ["RIR_LOSSY_SPEC_PASSES"] = "8"
+    for name in ("ra8", "subtract_min", "ra64_longer_than_the_calls", "high_above_low", "ra0", "ra1"):
+        c = CONST_CASES[name]
+        h, w, hl = 64, 96, 64 - (c["h"] - c["hl"])
+        for scene in ("static", "S1"):
+            arr = static_scene(c["n"], h, w, seed=53) if scene == "static" else s1_noisy_background(c["n"], h, w, seed=53)
+            for add_loss in (False, True):
+                exp, elo, ehi = _oracle_track(oracle, arr, w, h, hl, c["low"], c["high"], 5.0, c["ra"], c.get("subtract_min", False), add_loss)
+                ls = D.LossyStream(w, h, hl, c["low"], c["high"], 5.0, c["ra"], subtract_min=c.get("subtract_min", False))
+                t = torch.from_numpy(arr).cuda()
+                got, lo, hi, committed = [], [], [], 0
+                for c0, c1 in zip(c["cuts"][:-1], c["cuts"][1:]):
+                    o, l_, h_ = ls.step(t[c0:c1], add_loss=add_loss and c0 > 0)
+                    got.append(o), lo.append(l_), hi.append(h_)
+                    committed += ls.spec_stats()[2]
+                assert np.array_equal(torch.cat(got).cpu().numpy(), exp), (name, scene, pairs, add_loss)
+                assert np.concatenate(lo).tolist() == elo and np.concatenate(hi).tolist() == ehi, (name, scene, pairs, add_loss)
+                assert committed >= 1 if scene == "static" else True, (name, scene, pairs, add_loss, committed)
+                ls.close()
+    del os.environ["RIR_LOSSY_CONST_PAIRS"], os.environ["RIR_LOSSY_SPEC_PASSES"]
+
+
 if __name__ == "__main__":
     from librir_amd.low_level.misc import _LIB_PATH
 
@@ -295,6 +332,8 @@ if __name__ == "__main__":
         multi_repeated_smaller()
     elif case == "const_pairs":
         const_pairs(int(sys.argv[2]))
+    elif case == "spec_pairs":
+        spec_pairs(int(sys.argv[2]))
     elif case == "loss_run_stepped_again":
         from oracle.pyoracle import Oracle
 

@@ -197,3 +197,67 @@ def test_default_parameters_through_the_saver(tmp_path, oracle):
     assert low == elo and high == ehi
     with IRMovie.from_filename(dst) as mov:
         assert np.array_equal(mov.data, exp)
+
+
+@pytest.mark.parametrize("pairs", [2, 4])
+def test_speculative_form_with_more_pixels_per_thread(pairs):
+    """The streaming kernel's speculative instantiations for 4 and 8 pixels per thread, forced through the test hook RIR_LOSSY_CONST_PAIRS in a
+    process that loads the build with the hooks (tests/hook_cases.py: spec_pairs): same frames, same budgets as the oracle's."""
+    from test_gpu_resident import _hook_case
+
+    _hook_case("spec_pairs", pairs)
+
+
+def test_speculative_form_full_size_many_streams(oracle):
+    """Seventeen 640x512 streams of static scenes with stdFactor != 0 in one call - the launch that takes 8 pixels per thread by itself - rings
+    of several lengths, subtractMin, different budgets and factors side by side: committed together, each stream its own oracle's."""
+    import torch
+
+    from librir_amd import device as D
+
+    h, w, n, S = 512, 640, 56, 17
+    base = static_scene(n, h, w, seed=29)
+    streams, ins, exps = [], [], []
+    for i in range(S):
+        ra, smin, sf = (0, 3, 8, 32)[i % 4], i % 3 == 0, (5.0, 2.5, 1.0)[i % 3]
+        arr = base if i == 0 else (base + np.uint16(7 * i)).astype(np.uint16)
+        if i % 5 == 2:
+            arr = arr[:, ::-1].copy()
+        exps.append(_oracle_track(oracle, arr, w, h, h - 3, 4 + i % 3, 2, sf, ra, smin))
+        streams.append(D.LossyStream(w, h, h - 3, 4 + i % 3, 2, sf, ra, subtract_min=smin))
+        ins.append(torch.from_numpy(arr).cuda())
+    o1, lo1, hi1 = D.LossyStream.step_many(streams, [t[:1] for t in ins])
+    o2, lo2, hi2 = D.LossyStream.step_many(streams, [t[1:] for t in ins])
+    through, offered, committed, passes = streams[0].spec_stats()
+    moved = max(sum(1 for k in range(1, n) if (e[1][k], e[2][k]) != (e[1][0], e[2][0])) for e in exps)
+    assert through >= 1 and offered == through and (committed == through or moved >= 3), (through, offered, committed, passes, moved)
+    for i in range(S):
+        exp, elo, ehi = exps[i]
+        got = torch.cat([o1[i], o2[i]]).cpu().numpy()
+        bad = [k for k in range(n) if not np.array_equal(got[k], exp[k])]
+        assert not bad, (i, bad)
+        assert np.concatenate([lo1[i], lo2[i]]).tolist() == elo and np.concatenate([hi1[i], hi2[i]]).tolist() == ehi, i
+    for s_ in streams:
+        s_.close()
+
+
+@pytest.mark.parametrize("shape", [(768, 1024, 765), (600, 800, 600), (513, 648, 511)], ids=["1024x768", "800x600", "648x513"])
+def test_speculative_form_other_full_sizes(oracle, shape):
+    """configs[3]'s geometry and two others (a lossy height that is the whole frame; a width that is a multiple of 8 but not of 64): 70 frames in
+    two calls, ring of 8, subtractMin, the reference's default errors and factor - committed, frames and budgets the oracle's."""
+    import torch
+
+    from librir_amd import device as D
+
+    h, w, hl = shape
+    n = 70
+    arr = static_scene(n, h, w, seed=31)
+    exp, elo, ehi = _oracle_track(oracle, arr, w, h, hl, 6, 2, 5.0, 8, True)
+    ls = D.LossyStream(w, h, hl, 6, 2, 5.0, 8, subtract_min=True)
+    got, lo, hi, books = _run_cuts(ls, torch.from_numpy(arr).cuda(), [0, 9, n])
+    bad = [k for k in range(n) if not np.array_equal(got[k], exp[k])]
+    assert not bad, bad
+    assert lo == elo and hi == ehi
+    moved = sum(1 for k in range(n) if (elo[k], ehi[k]) != (6, 2))
+    assert all(b[0] == 1 and b[1] == 1 for b in books) and (moved > 2 or all(b[2] == 1 for b in books)), (books, moved)
+    ls.close()
