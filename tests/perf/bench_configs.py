@@ -226,6 +226,24 @@ with tempfile.TemporaryDirectory() as d:
             tr = sp.translate(g, 1.25, -2.5, "nearest")
             s.add_image(tr.astype(np.uint16), i * 1000)
     c2["per_frame_abi_fps"] = nabi2 / (time.perf_counter() - t0)
+    # the three filter calls alone (no recording), as the reference's wrapper is used: the caller converts / gaussian_filter converts (round 6: a
+    # uint16 image goes to the uint16 kernel as it is) / the same with the mirror's results kept in the library's page-locked memory (opt-in)
+    from librir_amd.low_level.misc import results_in_page_locked_memory
+
+    def three_calls(convert):
+        t0_ = time.perf_counter()
+        for i in range(nabi2):
+            a = sp.bad_pixels_correct(hbp, fr2[i])
+            sp.translate(sp.gaussian_filter(a.astype(np.float32) if convert else a, 0.75), 1.25, -2.5, "nearest")
+        return nabi2 / (time.perf_counter() - t0_)
+
+    three_calls(False)
+    c2["three_filter_calls_fps_caller_converts"] = three_calls(True)
+    c2["three_filter_calls_fps"] = three_calls(False)
+    was = results_in_page_locked_memory(True)
+    three_calls(False)
+    c2["three_filter_calls_fps_page_locked_results"] = three_calls(False)
+    results_in_page_locked_memory(was)
     sp.bad_pixels_destroy(hbp)
 if R is not None:
     import ctypes as ct
@@ -417,13 +435,25 @@ if not args.quick:  # the same in calls of 1 000 frames (the call's fixed cost -
     c4["lossy_then_encode_device_resident_fps_open_stream_1000_frame_calls"] = best_rate(chain_1000, 1000)
     del pc1000
     ls1.close()
-    os.environ["RIR_LOSSY_NO_CONST"] = "1"  # the general (resident) form on the same call, for comparison
+    os.environ["RIR_LOSSY_NO_CONST"] = os.environ["RIR_LOSSY_NO_SPEC"] = "1"  # the general (resident) form on the same call, for comparison
     ls1 = D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32)
     ls1.step(s1_1000[:60], errors=False)
     c4["lossy_step_device_resident_fps_one_stream_1000_frame_calls_general_form"] = best_rate(lambda: ls1.step(s1_1000, errors=False), 1000)
     ls1.status()
     ls1.close()
-    del os.environ["RIR_LOSSY_NO_CONST"]
+    del os.environ["RIR_LOSSY_NO_CONST"], os.environ["RIR_LOSSY_NO_SPEC"]
+    # the reference's DEFAULT parameters (6 / 2 / stdFactor 5 / 32): budgets that follow the statistics - the speculative form (round 6) on a
+    # scene that does not move (committed) and on S1 (budgets move every frame: the general form steps it), with the form's own books
+    g_ = torch.Generator(device=dev).manual_seed(5)
+    static = ((torch.rand((h, w), generator=g_, device=dev) * 1000 + 10)[None] + 0.7 * torch.randn((1000, h, w), generator=g_, device=dev)).to(torch.int32).to(torch.uint16)
+    for name_, scene_ in (("static_scene", static), ("S1", s1_1000)):
+        ls1 = D.LossyStream(w, h, h - 3, 6, 2, 5.0, 32)
+        ls1.step(scene_, errors=False)
+        c4["lossy_step_default_parameters_%s_fps_one_stream_1000_frame_calls" % name_] = best_rate(lambda: ls1.step(scene_, errors=False), 1000)
+        ls1.status()
+        c4["lossy_step_default_parameters_%s_speculative_groups_through_offered_committed_passes" % name_] = list(ls1.spec_stats())
+        ls1.close()
+    del static
     del s1_1000
 # independent streams in shared launches (rir_lossy_step_multi_device): the loss state is sequential in time, streams run side by side
 for S in (7, 9, 32):  # 7 streams of this size share one resident launch of the first form of the run kernel, 9 one of the second; more go a batch after the other
@@ -448,6 +478,10 @@ for st_ in streams:
 del ins
 with tempfile.TemporaryDirectory() as d:
     dst = os.path.join(d, "lossy.h264")
+    with IRSaver(os.path.join(d, "warm4.h264"), w, h, h - 3) as s:  # (the first bounded-loss recording of a process pays one-off set-up costs: 0.2 s)
+        s.set_parameter("stdFactor", 0)
+        for i in range(60):
+            s.add_image_lossy(reg[i], i * 1000)
     t0 = time.perf_counter()
     with IRSaver(dst, w, h, h - 3) as s:
         s.set_parameter("lowValueError", 3)

@@ -29,10 +29,11 @@ def rate(fn, count, reps=5):
 
 
 for label, env in (("general form ", "1"), ("constant form", None)):
-    if env:
-        os.environ["RIR_LOSSY_NO_CONST"] = env
+    if env:  # (the general form alone: neither the constant-budget nor the speculative launches)
+        os.environ["RIR_LOSSY_NO_CONST"] = os.environ["RIR_LOSSY_NO_SPEC"] = env
     else:
         os.environ.pop("RIR_LOSSY_NO_CONST", None)
+        os.environ.pop("RIR_LOSSY_NO_SPEC", None)
     streams = [D.LossyStream(w, h, h - 3, 3, 3, 0.0, 32) for _ in range(S)]
     ins = [fr.clone() for _ in range(S)]
     D.LossyStream.step_many(streams, ins, errors=False)
