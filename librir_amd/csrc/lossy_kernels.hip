@@ -1878,7 +1878,8 @@ namespace rir
 		__shared__ unsigned int sh_flag;
 		__shared__ long long red[4][6];
 		__shared__ __attribute__((aligned(16))) uint32_t sh_bg[kLossyConstMaxFrames + 8];
-		__shared__ __attribute__((aligned(16))) uint32_t sh_err[SPEC ? kLossyConstMaxFrames + 8 : 4]; // SPEC: the budgets of the group's frames, low | high << 16
+		// SPEC: the budgets of the group's frames, each in both halves of a word (what the packed comparisons take: no scalar arithmetic per frame)
+		__shared__ __attribute__((aligned(16))) uint32_t sh_low2[SPEC ? kLossyConstMaxFrames + 8 : 4], sh_high2[SPEC ? kLossyConstMaxFrames + 8 : 4];
 		__shared__ long long red_tail[SPEC ? 1 : kLossyConstTail][4][6]; // the sums of the last frames of a group, per wave (const_frame_sums_wave)
 		const int tid = threadIdx.x, b = blockIdx.x, stream = blockIdx.y, nb = gridDim.x;
 		LossyDeviceState sto; // where the state goes after the group
@@ -1939,7 +1940,10 @@ namespace rir
 		{
 			RIR_GLOBAL(const uint32_t) *bud = as_global(as_global(spec + stream)->budgets);
 			for (int k = tid; k < n + 8; k += 256)
-				sh_err[k] = k < n ? bud[k] : 0u;
+			{
+				const uint32_t e = k < n ? bud[k] : 0u;
+				sh_low2[k] = lossy_both(e & 0xffffu), sh_high2[k] = lossy_both(e >> 16);
+			}
 		}
 		__syncthreads();
 
@@ -1999,7 +2003,7 @@ namespace rir
 		for (int j = 0; j < D; ++j)
 			request(V[j], O[j]);
 		uint32_t bg_next = sh_bg[0]; // (a frame's background is read from LDS a frame ahead)
-		uint32_t err_next = SPEC ? sh_err[0] : 0u;
+		uint32_t low_next = SPEC ? sh_low2[0] : 0u, high_next = SPEC ? sh_high2[0] : 0u;
 		// per-frame constants that only move while the ring fills
 		auto ring_consts = [&]() {
 			const int n_after = ra > 0 ? (count == ra ? ra : count + 1) : 0;
@@ -2029,9 +2033,8 @@ namespace rir
 			bg_next = sh_bg[k + 1 < n ? k + 1 : k];
 			if constexpr (SPEC)
 			{
-				const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)err_next);
-				err_next = sh_err[k + 1 < n ? k + 1 : k];
-				pc.low2 = lossy_both(e & 0xffffu), pc.high2 = lossy_both(e >> 16);
+				pc.low2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)low_next), pc.high2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)high_next);
+				low_next = sh_low2[k + 1 < n ? k + 1 : k], high_next = sh_high2[k + 1 < n ? k + 1 : k];
 			}
 			request(Vj, Oj);
 			// the frame's sums, if its statistic will be in the window (or seeds it): against the previous output, per workgroup (out of
@@ -2099,7 +2102,7 @@ namespace rir
 															 ra > 0 ? (uint32_t)(group_bytes - (uint64_t)D * frame_bytes + ra_back) : 0u);
 			const __amdgpu_buffer_rsrc_t rs_out = lossy_rsrc((const void *)(uint64_t)rp.out, (uint32_t)group_bytes);
 			uint32_t so = (uint32_t)mid0 * fb;
-			uint32_t bgq[D], bgn[D], erq[D], ern[D];
+			uint32_t bgq[D], bgn[D], loq[D], lon[D], hiq[D], hin[D];
 			auto backgrounds = [&](int k) { // of frames k .. k + D - 1 (k a multiple of D; the array is padded) - SPEC: and their budgets
 				if constexpr (D == 4)
 				{
@@ -2107,8 +2110,9 @@ namespace rir
 					bgn[0] = q.x, bgn[1] = q.y, bgn[2] = q.z, bgn[3] = q.w;
 					if constexpr (SPEC)
 					{
-						const lossy_v4u e = *reinterpret_cast<const lossy_v4u *>(&sh_err[k]);
-						ern[0] = e.x, ern[1] = e.y, ern[2] = e.z, ern[3] = e.w;
+						const lossy_v4u lo = *reinterpret_cast<const lossy_v4u *>(&sh_low2[k]), hi = *reinterpret_cast<const lossy_v4u *>(&sh_high2[k]);
+						lon[0] = lo.x, lon[1] = lo.y, lon[2] = lo.z, lon[3] = lo.w;
+						hin[0] = hi.x, hin[1] = hi.y, hin[2] = hi.z, hin[3] = hi.w;
 					}
 				}
 				else
@@ -2118,7 +2122,7 @@ namespace rir
 					{
 						bgn[j] = sh_bg[k + j];
 						if constexpr (SPEC)
-							ern[j] = sh_err[k + j];
+							lon[j] = sh_low2[k + j], hin[j] = sh_high2[k + j];
 					}
 				}
 			};
@@ -2128,7 +2132,7 @@ namespace rir
 				{
 					bgq[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)bgn[j]);
 					if constexpr (SPEC)
-						erq[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ern[j]);
+						loq[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)lon[j]), hiq[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)hin[j]);
 				}
 			};
 			backgrounds(mid0);
@@ -2152,7 +2156,7 @@ namespace rir
 					const_frame_sums_wave<NP>(v, o, bgq[j], lossy, st.subtract_min, st.min, &red_tail[k - tail0][tid >> 6][0]);
 				pc.bg2 = lossy_both(bgq[j]);
 				if constexpr (SPEC)
-					pc.low2 = lossy_both(erq[j] & 0xffffu), pc.high2 = lossy_both(erq[j] >> 16);
+					pc.low2 = loq[j], pc.high2 = hiq[j];
 				const Px before = V[(j + D - 1) % D]; // the frame before this one: still in its slot
 				Px ov;
 #pragma unroll
