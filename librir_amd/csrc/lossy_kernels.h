@@ -135,7 +135,8 @@ namespace rir
 	// SHADOW state (the stream's state stays what it was), a second kernel takes every frame's six exact sums from the frames where they lie
 	// (input k against output k - 1: fully parallel), and a third runs the reference's double arithmetic for every frame (a thread per frame: the
 	// window mean of frame k is its own chain of 40 additions over statistics that are all known).  The sums are right up to and including the first
-	// frame m whose true budget is not the table's; that entry is corrected and the group is stepped again, up to `passes` times; a group whose table
+	// frame m whose true budget is not the table's; that entry is corrected and the group is stepped again, up to `passes` times (not at all when
+	// more than eight frames per remaining pass are off the table: budgets that move, nothing to guess); a group whose table
 	// then verifies is committed (shadow -> state, window, budgets), any other is left to the resident kernel behind, exactly as a declined
 	// constant-budget group is.  A stream whose groups keep failing is not offered for a while (a counter on the device: 1, 3, 7 ... 63 groups).
 	struct LossySpec
@@ -145,8 +146,10 @@ namespace rir
 		unsigned long long *rows;  // [nsteps][stat workgroups][4] the sums of a frame, per slab of kLossySpecSlab pixels (words as lossy_const_run_kernel's partials)
 		double *sd;				   // [nsteps][2] the statistic of every frame (sums kernel -> verify, commit)
 		unsigned int *tickets;	   // [nsteps] arrival counters of the frames' slabs: zero between launches (the last arriver clears its own)
-		unsigned int *ctl;		   // [8] 0: status (0 to be stepped, 1 verified, 2 given up), 1: passes so far, 2: first mismatch of the last pass, 3: passes allowed
+		unsigned int *ctl;		   // [8] 0: status (0 to be stepped, 1 verified, 2 given up), 1: passes so far, 2: first mismatch of the last pass, 3: passes allowed, 4: offered, 5: frames off the table at the last pass
 		unsigned int *backoff;	   // [2] of the call's leading stream: groups still to skip, failures in a row
+		unsigned int *backoff_host; // [2] the same two words in page-locked host memory, written whenever they change: the host looks (without
+								   // waiting) before it queues a call, and does not queue the launches of groups that would be skipped anyway
 	};
 	constexpr int kLossySpecSlab = 16384; // pixels of a frame per workgroup of the sums kernel
 	inline int lossy_spec_stat_workgroups(int s) { return (s + kLossySpecSlab - 1) / kLossySpecSlab; }
@@ -155,6 +158,8 @@ namespace rir
 	// returns at once when there is nothing for it to do; nothing waits for the host.
 	hipError_t launch_lossy_spec_begin(const LossyRun *d_table, const LossySpec *d_spec, int nstreams, int passes, unsigned int *d_ok, const unsigned int *d_poison, hipStream_t st);
 	hipError_t launch_lossy_spec_pass(const LossyRun *d_table, const LossySpec *d_spec, int nstreams, int s, int full, int max_frames, bool any_ra, bool add_loss, hipStream_t st);
+	// groups the host did not queue because the stream backs off: taken off the device's counter (one launch per call)
+	hipError_t launch_lossy_spec_skipped(unsigned int *d_backoff, unsigned int *backoff_host, unsigned int count, hipStream_t st);
 	hipError_t launch_lossy_spec_commit(const LossyRun *d_table, const LossySpec *d_spec, int nstreams, int s, int full, unsigned int *d_ok, hipStream_t st);
 	void lossy_const_force_pairs(int np); // 4, 2, 1: that many pairs of pixels per thread whatever the launch; anything else: chosen by lossy_const_pairs (test hook RIR_LOSSY_CONST_PAIRS)
 	int lossy_const_workgroups(int full, int nstreams); // workgroups of a stream in that launch: partials holds kLossyConstSlots x this many x 4 words per stream

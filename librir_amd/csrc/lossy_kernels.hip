@@ -2388,7 +2388,11 @@ namespace rir
 		if (ok && skip > 0u)
 		{ // a stream whose groups keep failing: this one goes straight to the resident kernel
 			if (tid == 0)
+			{
 				bk[0] = skip - 1u;
+				if (as_global(spec)->backoff_host)
+					__hip_atomic_store(as_global(as_global(spec)->backoff_host), skip - 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
 			ok = false;
 		}
 		if (tid == 0)
@@ -2400,7 +2404,7 @@ namespace rir
 			if (tid == 0)
 			{
 				RIR_GLOBAL(unsigned int) *ctl = as_global(sp->ctl);
-				ctl[0] = ok ? 0u : 2u, ctl[1] = 0u, ctl[2] = 0u, ctl[3] = (unsigned int)passes;
+				ctl[0] = ok ? 0u : 2u, ctl[1] = 0u, ctl[2] = 0u, ctl[3] = (unsigned int)passes, ctl[5] = 0u;
 				ctl[4] = ok ? 1u : 0u; // (the group was offered: rir_lossy_spec_stats)
 			}
 			if (ok)
@@ -2564,7 +2568,7 @@ namespace rir
 	{
 		__shared__ double sd[kLossyConstMaxFrames][2];
 		__shared__ LossySpecWindow w;
-		__shared__ int sh_m;
+		__shared__ int sh_m, sh_off;
 		const int tid = threadIdx.x, stream = blockIdx.x;
 		RIR_GLOBAL(const LossySpec) *sp = as_global(spec + stream);
 		RIR_GLOBAL(unsigned int) *ctl = as_global(sp->ctl);
@@ -2585,7 +2589,7 @@ namespace rir
 		{
 			w.n_old = n_win0, w.have_first = bud->n_first >= 1 ? 1 : 0;
 			w.first[0] = bud->first_std[0], w.first[1] = bud->first_std[1];
-			sh_m = n;
+			sh_m = n, sh_off = 0;
 		}
 		// the statistics of the frames (lossy_spec_stats_kernel's last arrivers)
 		RIR_GLOBAL(double) *gsd = as_global(sp->sd);
@@ -2598,7 +2602,10 @@ namespace rir
 		{
 			mine[q] = lossy_spec_budget(w, sd, k, bp);
 			if (mine[q] != tab[k])
+			{
 				atomicMin(&sh_m, k);
+				atomicAdd(&sh_off, 1);
+			}
 		}
 		__syncthreads();
 		const int m = sh_m;
@@ -2616,11 +2623,23 @@ namespace rir
 				tab[k] = mine[q]; // (the sums of frame m are right - every frame before it was - and so is this budget)
 		if (tid == 0)
 		{
-			const unsigned int passes = ctl[1] + 1u;
-			ctl[1] = passes, ctl[2] = (unsigned int)m;
-			if (passes >= ctl[3])
+			// How many frames are off the table says whether further passes can get there: behind the first one the sums are only roughly
+			// right, but a scene whose budgets MOVE (S1: nearly every frame) shows hundreds, an event in a static scene a handful.  More than
+			// eight per pass that is left: the group goes to the general form now, not after the passes.
+			const unsigned int passes = ctl[1] + 1u, off = (unsigned int)sh_off;
+			ctl[1] = passes, ctl[2] = (unsigned int)m, ctl[5] = off;
+			if (passes >= ctl[3] || off > 8u * (ctl[3] - passes))
 				__hip_atomic_store(ctl, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
+	}
+
+	__global__ void lossy_spec_skipped_kernel(unsigned int *__restrict__ bk_, unsigned int *__restrict__ bh_, unsigned int count)
+	{
+		RIR_GLOBAL(unsigned int) *bk = as_global(bk_);
+		const unsigned int left = bk[0] > count ? bk[0] - count : 0u;
+		bk[0] = left;
+		if (bh_)
+			__hip_atomic_store(as_global(bh_), left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 
 	// lossy_spec_commit_kernel: grid = (workgroups, streams).  Every stream verified: the shadow state becomes the state (a copy: 14 bytes a
@@ -2654,6 +2673,11 @@ namespace rir
 			{ // (a group that was not offered - precondition, back-off - does not count)
 				const unsigned int streak = bk[1] < 6u ? bk[1] + 1u : 6u; // 1, 3, 7, 15, 31, 63 groups without an offer
 				bk[1] = streak, bk[0] = (1u << streak) - 1u;
+			}
+			if (RIR_GLOBAL(unsigned int) *bh = as_global(as_global(spec)->backoff_host))
+			{
+				__hip_atomic_store(bh, bk[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				__hip_atomic_store(bh + 1, bk[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			}
 			__hip_atomic_store(as_global(ok_word), all ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
@@ -2936,6 +2960,11 @@ namespace rir
 		const int nslabs = lossy_spec_stat_workgroups(s);
 		hipLaunchKernelGGL(lossy_spec_stats_kernel, dim3((unsigned)nslabs, (unsigned)max_frames, (unsigned)nstreams), dim3(256), 0, st, d_table, d_spec);
 		hipLaunchKernelGGL(lossy_spec_verify_kernel, dim3((unsigned)nstreams), dim3(1024), 0, st, d_table, d_spec);
+		return hipGetLastError();
+	}
+	hipError_t launch_lossy_spec_skipped(unsigned int *d_backoff, unsigned int *backoff_host, unsigned int count, hipStream_t st)
+	{
+		hipLaunchKernelGGL(lossy_spec_skipped_kernel, dim3(1), dim3(1), 0, st, d_backoff, backoff_host, count);
 		return hipGetLastError();
 	}
 	hipError_t launch_lossy_spec_commit(const LossyRun *d_table, const LossySpec *d_spec, int nstreams, int s, int full, unsigned int *d_ok, hipStream_t st)

@@ -384,6 +384,7 @@ namespace
 	// speculative form (lossy_kernels.h: LossySpec): the budget tables, sums and statistics of a group (reused group after group), the control
 	// words of every group and stream of the last call, and - for good - the back-off words of the calls this stream leads
 	DeviceBuffer spec_budgets, spec_rows, spec_sd, spec_ctl, spec_backoff, spec_tickets;
+	PinnedBuffer spec_backoff_host;				// the back-off words again, where the host can look without waiting (lossy_kernels.h: LossySpec::backoff_host)
 	int spec_groups = 0, spec_streams = 0;		// groups (and streams) of the last run call that went through the speculative launches (0: not eligible)
 		PinnedBuffer multi_stage;
 		hipEvent_t multi_copied = nullptr; // the copy out of multi_stage of the last call (whatever its stream) has completed
@@ -3475,6 +3476,12 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 						return -1;
 					if (lead.spec_backoff.cap != bk_cap && !hip_ok(hipMemsetAsync(lead.spec_backoff.ptr, 0, 8, st), "memset"))
 						return -1;
+					if (!lead.spec_backoff_host.ptr)
+					{
+						if (!lead.spec_backoff_host.reserve(64))
+							return -1;
+						std::memset(lead.spec_backoff_host.ptr, 0, 64);
+					}
 					for (int i = 0; i < nstreams; ++i)
 						if (!os[i]->st.reserve_shadow())
 							return -1;
@@ -3516,6 +3523,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 							sp.tickets = lead.spec_tickets.as<unsigned int>() + (size_t)i * spec_group;
 							sp.ctl = lead.spec_ctl.as<unsigned int>() + ((size_t)g * nstreams + i) * 8;
 							sp.backoff = lead.spec_backoff.as<unsigned int>();
+							sp.backoff_host = lead.spec_backoff_host.as<unsigned int>();
 							hsp[(size_t)g * nstreams + i] = sp;
 						}
 						for (int k = k0; k < k0 + in_group; ++k)
@@ -3541,6 +3549,19 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 				}
 				if (test_hook("RIR_DEBUG_LOSSY_GIVE_UP") && !hip_ok(hipMemsetAsync(d_error, 1, 4, st), "memset")) // (tests: as if a wait had hit its clock)
 					return -1;
+				// A stream that backs off (its groups kept failing: budgets that move) is not offered its next groups: the device's counter says how
+				// many, the host looks at its page-locked copy - without waiting, so the value may be a call or two old: then fewer groups are left
+				// out here and the device skips them itself - and does not even queue their launches (eleven small ones per group).
+				int host_skipped = 0;
+				if (spec_form)
+				{
+					const unsigned int left = *reinterpret_cast<volatile unsigned int *>(lead.spec_backoff_host.ptr);
+					host_skipped = (int)std::min<unsigned int>(left, (unsigned int)ngroups);
+					if (host_skipped > 0 && !hip_ok(launch_lossy_spec_skipped(lead.spec_backoff.as<unsigned int>(), lead.spec_backoff_host.as<unsigned int>(),
+																			  (unsigned int)host_skipped, st),
+													"lossy speculative skip"))
+						return -1;
+				}
 				for (int g = 0; g < ngroups; ++g)
 				{
 					const int k0 = g * group, in_group = std::min(group, nsteps - k0);
@@ -3557,7 +3578,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 																  d_ticket + kLossyRunCtlWord + 2, st),
 											  "lossy constant-budget run"))
 						return -1;
-					if (spec_form)
+					if (spec_form && g >= host_skipped)
 					{ // guess, (step, sums, verify) x passes, commit: every launch returns at once when the one before left it nothing to do
 						if (!hip_ok(launch_lossy_spec_begin(dr + (size_t)g * nstreams, dsp + (size_t)g * nstreams, nstreams, spec_passes, lead.const_ok.as<unsigned int>() + g,
 															 d_ticket + kLossyRunCtlWord + 2, st),
