@@ -298,8 +298,9 @@ extern "C"
 	/* Streams whose budgets follow the statistics (stdFactor != 0 - the reference's default 5, h264.cpp:1662-1665, budget :2335-2385) go through
 	 * the SPECULATIVE form: the budgets of a group are guessed (the configured errors: what a scene that does not move gets, the rounded correction
 	 * being 0), the group is stepped by the streaming launch into shadow state, the frames' exact sums are taken from the frames and the reference's
-	 * arithmetic is run for every frame; the first frame whose budget is not the table's is corrected and the group stepped again, up to
-	 * RIR_LOSSY_SPEC_PASSES (3) times; a group that verifies is committed, any other is stepped by the general form - same results either way.
+	 * arithmetic is run for every frame; from the first frame whose budget is not the table's on, the table takes the computed budgets and the group
+	 * is stepped again, up to RIR_LOSSY_SPEC_PASSES (3) times; a group that verifies is committed, any other is stepped by the general form - same
+	 * results either way.
 	 * out[0] = groups of the last batch this stream led that went through these launches (0: not eligible), out[1] = groups offered (no class that
 	 * may be empty, no NaN in a window, the stream not backing off after failures), out[2] = groups committed, out[3] = passes over all groups.
 	 * Waits for the stream. */

@@ -135,8 +135,9 @@ namespace rir
 	// SHADOW state (the stream's state stays what it was), a second kernel takes every frame's six exact sums from the frames where they lie
 	// (input k against output k - 1: fully parallel), and a third runs the reference's double arithmetic for every frame (a thread per frame: the
 	// window mean of frame k is its own chain of 40 additions over statistics that are all known).  The sums are right up to and including the first
-	// frame m whose true budget is not the table's; that entry is corrected and the group is stepped again, up to `passes` times (not at all when
-	// more than eight frames per remaining pass are off the table: budgets that move, nothing to guess); a group whose table
+	// frame m whose true budget is not the table's; from m on the table takes what was computed (right at m, roughly right behind it: a fixed-point
+	// iteration that a step change or a flash converges under in two or three passes) and the group is stepped again, up to `passes` times - not at
+	// all when the frames off the table do not halve from pass to pass: budgets that move, nothing to iterate on; a group whose table
 	// then verifies is committed (shadow -> state, window, budgets), any other is left to the resident kernel behind, exactly as a declined
 	// constant-budget group is.  A stream whose groups keep failing is not offered for a while (a counter on the device: 1, 3, 7 ... 63 groups).
 	struct LossySpec

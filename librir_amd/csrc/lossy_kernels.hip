@@ -2404,7 +2404,7 @@ namespace rir
 			if (tid == 0)
 			{
 				RIR_GLOBAL(unsigned int) *ctl = as_global(sp->ctl);
-				ctl[0] = ok ? 0u : 2u, ctl[1] = 0u, ctl[2] = 0u, ctl[3] = (unsigned int)passes, ctl[5] = 0u;
+				ctl[0] = ok ? 0u : 2u, ctl[1] = 0u, ctl[2] = 0u, ctl[3] = (unsigned int)(passes & 0xff), ctl[5] = 0u, ctl[6] = (unsigned int)passes >> 8;
 				ctl[4] = ok ? 1u : 0u; // (the group was offered: rir_lossy_spec_stats)
 			}
 			if (ok)
@@ -2618,17 +2618,24 @@ namespace rir
 			}
 			return;
 		}
+		// The sums of frame m are right - every frame before it was - and so is its budget; behind it the sums were taken against outputs that
+		// are only roughly right, and so are the budgets computed from them: roughly.  ALL of them go into the table (ctl[6] == 0; 1: only frame
+		// m's, the first form of this - kept for comparison): where the budgets follow the input more than they follow the outputs - a step
+		// change whose 40-frame echo in the window mean moves every budget, a slow drift - the table then converges in a few passes instead of
+		// one frame per pass; the verification is what it was (a table that equals what is computed from it is right frame by frame, by induction).
+		const bool only_first = (ctl[6] & 1u) != 0u;
 		for (int k = tid, q = 0; k < n; k += 1024, ++q)
-			if (k == m)
-				tab[k] = mine[q]; // (the sums of frame m are right - every frame before it was - and so is this budget)
+			if (only_first ? k == m : k >= m)
+				tab[k] = mine[q];
 		if (tid == 0)
 		{
-			// How many frames are off the table says whether further passes can get there: behind the first one the sums are only roughly
-			// right, but a scene whose budgets MOVE (S1: nearly every frame) shows hundreds, an event in a static scene a handful.  More than
-			// eight per pass that is left: the group goes to the general form now, not after the passes.
-			const unsigned int passes = ctl[1] + 1u, off = (unsigned int)sh_off;
+			// Does it converge?  The number of frames off the table must at least halve from pass to pass (and a first pass with more than
+			// half of the frames off is a scene whose budgets MOVE - S1: nearly every frame -: nothing to iterate on); otherwise the group
+			// goes to the general form now, not after the passes that are left.
+			const unsigned int passes = ctl[1] + 1u, off = (unsigned int)sh_off, before = ctl[5];
 			ctl[1] = passes, ctl[2] = (unsigned int)m, ctl[5] = off;
-			if (passes >= ctl[3] || off > 8u * (ctl[3] - passes))
+			const bool hopeless = (ctl[6] & 2u) ? false : only_first ? off > 8u * (ctl[3] - passes) : (passes == 1u ? 2u * off > (unsigned int)n : 2u * off > before);
+			if (passes >= ctl[3] || hopeless)
 				__hip_atomic_store(ctl, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}

@@ -3373,7 +3373,11 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 			spec_form = spec_form && os[i]->low <= 65535 && os[i]->high <= 65535; // (the budget table holds 16-bit fields)
 		int spec_passes = 3;
 		if (const char *pe = getenv("RIR_LOSSY_SPEC_PASSES"))
-			spec_passes = std::max(1, std::min(8, atoi(pe)));
+			spec_passes = std::max(1, std::min(16, atoi(pe)));
+		if (getenv("RIR_LOSSY_SPEC_FIRST_ONLY")) // (comparison: a pass corrects the first wrong budget only - bit 8 of the launch's pass count)
+			spec_passes |= 256;
+		if (getenv("RIR_LOSSY_SPEC_NO_GIVE_UP")) // (measurements: every pass that is allowed is made)
+			spec_passes |= 512;
 		const bool stream_form = const_form || spec_form; // a streaming kernel steps whole groups: long ones
 		// frames per histogram launch (one 64 KB histogram slice per frame and stream).  A group costs four small launches beside its
 		// frames, so streams that may take the constant-budget form - 0.1 us per stream-frame - get groups four times as long (up to
@@ -3584,7 +3588,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 															 d_ticket + kLossyRunCtlWord + 2, st),
 									"lossy speculative run"))
 							return -1;
-						for (int pass = 0; pass < spec_passes; ++pass)
+						for (int pass = 0; pass < (spec_passes & 0xff); ++pass)
 							if (!hip_ok(launch_lossy_spec_pass(dr + (size_t)g * nstreams, dsp + (size_t)g * nstreams, nstreams, s_px, full_px, in_group, any_ra, add_loss != 0, st),
 										"lossy speculative pass"))
 								return -1;

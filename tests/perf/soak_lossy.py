@@ -31,6 +31,12 @@ for k in range(cases):
         for j in rng.integers(0, n, 3):
             fr[j] = 1000
     os.environ["RIR_LOSSY_SPEC_PASSES"] = str(int(rng.integers(1, 9)))
+    os.environ.pop("RIR_LOSSY_SPEC_FIRST_ONLY", None)
+    os.environ.pop("RIR_LOSSY_SPEC_NO_GIVE_UP", None)
+    if rng.integers(0, 4) == 0:  # (the first form of the correction, one frame per pass; and passes that never give up)
+        os.environ["RIR_LOSSY_SPEC_FIRST_ONLY"] = "1"
+    if rng.integers(0, 4) == 0:
+        os.environ["RIR_LOSSY_SPEC_NO_GIVE_UP"] = "1"
     L = OracleLossy(O, w, h, hl, low_err=low, high_err=high, std_factor=sf, running_average=ra, subtract_min=smin)
     exp, elo, ehi = [], [], []
     for i in range(n):
