@@ -139,7 +139,7 @@ namespace rir
 	// iteration that a step change or a flash converges under in two or three passes) and the group is stepped again, up to `passes` times - not at
 	// all when the frames off the table do not halve from pass to pass: budgets that move, nothing to iterate on; a group whose table
 	// then verifies is committed (shadow -> state, window, budgets), any other is left to the resident kernel behind, exactly as a declined
-	// constant-budget group is.  A stream whose groups keep failing is not offered for a while (a counter on the device: 1, 3, 7 ... 63 groups).
+	// constant-budget group is.  A stream whose groups keep failing is not offered for a while (a counter on the device: 3, 15, 63 groups).
 	struct LossySpec
 	{
 		LossyDeviceState shadow;   // where a pass leaves the state after the group (ring: the slots the group writes)

@@ -2678,8 +2678,8 @@ namespace rir
 				bk[1] = 0u;
 			else if (offered)
 			{ // (a group that was not offered - precondition, back-off - does not count)
-				const unsigned int streak = bk[1] < 6u ? bk[1] + 1u : 6u; // 1, 3, 7, 15, 31, 63 groups without an offer
-				bk[1] = streak, bk[0] = (1u << streak) - 1u;
+				const unsigned int streak = bk[1] < 3u ? bk[1] + 1u : 3u; // 3, 15, 63 groups without an offer (a scene that moves goes on moving)
+				bk[1] = streak, bk[0] = (1u << (2u * streak)) - 1u;
 			}
 			if (RIR_GLOBAL(unsigned int) *bh = as_global(as_global(spec)->backoff_host))
 			{
