@@ -108,7 +108,21 @@ for i in range(m):
     x = gaussian_filter(x.astype(np.float32), 0.75)
     x = translate(x, 1.25, -2.5, "nearest")
 dt = time.perf_counter() - t0
-print("configs[2] chain, three calls per image    : %7.0f frames/s (%5.1f us)" % (m / dt, dt / m * 1e6), flush=True)
+print("configs[2] chain, three calls per image    : %7.0f frames/s (%5.1f us)   (the caller converts: x.astype(float32) is 110 us of numpy here)" % (m / dt, dt / m * 1e6), flush=True)
+# round 6: the same three entry points with the uint16 image handed to gaussian_filter as it is (the reference's wrapper converts inside,
+# rir_signal_processing.py:85-113; here the uint16 kernel takes it), then with the mirror's results in the library's page-locked memory, which
+# the next call works on in place (opt-in: low_level.misc.results_in_page_locked_memory; tests/perf/three_call_probe.py has the breakdown)
+from librir_amd.low_level.misc import results_in_page_locked_memory  # noqa: E402
+
+for label, pinned in (("gaussian_filter converts", False), ("+ results in page-locked memory", True)):
+    was = results_in_page_locked_memory(pinned)
+    translate(gaussian_filter(bp.correct(fr[0]), 0.75), 1.25, -2.5, "nearest")
+    t0 = time.perf_counter()
+    for i in range(m):
+        x = translate(gaussian_filter(bp.correct(fr[i]), 0.75), 1.25, -2.5, "nearest")
+    dt = time.perf_counter() - t0
+    results_in_page_locked_memory(was)
+    print("configs[2] chain, three calls, %-31s: %7.0f frames/s (%5.1f us)" % (label, m / dt, dt / m * 1e6), flush=True)
 t0 = time.perf_counter()
 for i in range(m):
     x = filter_chain(fr[i], bp, 0.75, 1.25, -2.5, "nearest")
