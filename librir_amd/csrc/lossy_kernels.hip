@@ -1733,24 +1733,30 @@ namespace rir
 			x.d[0] = __builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0);
 		return x;
 	}
-	template <int NP>
+	template <int NP, int AUX = 0>
 	__device__ __forceinline__ void buf_stn(const PxN<NP> &x, __amdgpu_buffer_rsrc_t r, uint32_t off, uint32_t soff = 0u)
 	{
 		if constexpr (NP == 4)
 		{
 			lossy_v4u v;
 			v.x = x.d[0], v.y = x.d[1], v.z = x.d[2], v.w = x.d[3];
-			__builtin_amdgcn_raw_buffer_store_b128(v, r, off, soff, 0);
+			__builtin_amdgcn_raw_buffer_store_b128(v, r, off, soff, AUX);
 		}
 		else if constexpr (NP == 2)
 		{
 			lossy_v2u_b v;
 			v.x = x.d[0], v.y = x.d[1];
-			__builtin_amdgcn_raw_buffer_store_b64(v, r, off, soff, 0);
+			__builtin_amdgcn_raw_buffer_store_b64(v, r, off, soff, AUX);
 		}
 		else
-			__builtin_amdgcn_raw_buffer_store_b32(x.d[0], r, off, soff, 0);
+			__builtin_amdgcn_raw_buffer_store_b32(x.d[0], r, off, soff, AUX);
 	}
+#ifndef RIR_SPEC_OUT_STORE_AUX
+#define RIR_SPEC_OUT_STORE_AUX 2 /* nt: the speculative instance's output frames are read once more, by the sums kernel, from HBM either way (+3 % on the call) */
+#endif
+#ifndef RIR_CONST_OUT_STORE_AUX
+#define RIR_CONST_OUT_STORE_AUX 0 /* cache policy of the streaming kernel's output frames (2: nt) */
+#endif
 
 	// lossy_pixel_pair without its wave-uniform branches (compile-time: a running average or none, the addLoss variant or not; run time, as
 	// masks: whether the ring is full).  Same values, bit for bit.
@@ -2062,7 +2068,7 @@ namespace rir
 				ov.d[p] = lossy_bfi(lossy_mask, o.d[p], v.d[p]); // rows past lossy_height: stored as they are
 			}
 			last = v;
-			buf_stn<NP>(ov, lossy_rsrc((const void *)out_p, full_bytes), off_in);
+			buf_stn<NP, (SPEC ? RIR_SPEC_OUT_STORE_AUX : RIR_CONST_OUT_STORE_AUX)>(ov, lossy_rsrc((const void *)out_p, full_bytes), off_in);
 			out_p += frame_bytes;
 			if (RA_ON)
 			{
@@ -2165,7 +2171,7 @@ namespace rir
 					const_pixel_pair<RA_ON, ADD_LOSS, true>(pc, v.d[p], old.d[p], before.d[p], ref.d[p], sum[2 * p], sum[2 * p + 1], cc.d[p], cv.d[p], t.d[p], o.d[p]);
 					ov.d[p] = lossy_bfi(lossy_mask, o.d[p], v.d[p]);
 				}
-				buf_stn<NP>(ov, rs_out, off_in, so);
+				buf_stn<NP, (SPEC ? RIR_SPEC_OUT_STORE_AUX : RIR_CONST_OUT_STORE_AUX)>(ov, rs_out, off_in, so);
 				if (TAIL && RA_ON)
 				{ // the ring as it must be after the group: the last `ra` inputs (less the minimum), each in the slot after the one before
 					buf_stn<NP>(t, k >= ring_from ? rs_ring_on : rs_ring_off, off_lossy, so_ring);
@@ -2424,6 +2430,9 @@ namespace rir
 	// split by input k > background k.  Per slab of kLossySpecSlab pixels four words, as lossy_const_run_kernel's partials; the LAST slab of
 	// a frame to arrive (a ticket per frame; rows written and read with agent-scope accesses, as lossy_last_arriver's callers do) adds them up and
 	// leaves the frame's statistic, stdDev's double arithmetic on the exact sums.
+#ifndef RIR_SPEC_STATS_AUX
+#define RIR_SPEC_STATS_AUX 2 /* cache policy of the sums kernel's loads: nt (every byte is read once; measured +4 % on the whole call against the default policy, sc1 no better) */
+#endif
 	__global__ __launch_bounds__(256) void lossy_spec_stats_kernel(const LossyRun *__restrict__ table, const LossySpec *__restrict__ spec)
 	{
 		__shared__ long long red[4][6];
@@ -2449,30 +2458,64 @@ namespace rir
 		long long f2 = 0, b2 = 0;
 		constexpr int kIter = kLossySpecSlab / 8 / 256; // 16-byte loads per thread and array
 		lossy_v4u a[kIter], p[kIter];
+		uint32_t valid = 0; // pixels of this thread that lie in the lossy rows
 #pragma unroll
 		for (int j = 0; j < kIter; ++j)
-		{ // (a lane past the end of the lossy rows: out of range - zeros, and nothing is counted for it below)
+		{ // (a lane past the end of the lossy rows: out of range - zeros against zeros: d = 0, counted nowhere but in `valid`)
 			const uint32_t off = (uint32_t)(i0 / 8 + j * 256 + tid) * 16u;
-			a[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, 0);
-			p[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_pv, off, 0, 0);
+			a[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, RIR_SPEC_STATS_AUX);
+			p[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_pv, off, 0, RIR_SPEC_STATS_AUX);
+			valid += (i0 / 8 + j * 256 + tid) * 8 < i1 ? 8u : 0u;
 		}
-#pragma unroll
-		for (int j = 0; j < kIter; ++j)
+		// Two pixels to an instruction, the sums through v_dot2_u32_u16: d = max - min, the foreground mask as in const_pixel_pair, sum d and
+		// sum d^2 over everything and over the foreground (the background is the difference).  Exact as long as every d is below 4 096 (64 pixels
+		// of a thread: sum d^2 < 2^30) - thermal frames are; a wave that meets a larger one does its pixels again one by one, as the host code does
+		// (h264.cpp:1993-2036: the square wraps at 32 bits and is added as a signed number).
 		{
-			const bool in = (i0 / 8 + j * 256 + tid) * 8 < i1;
+			const uint32_t min2 = subtract_min ? lossy_both(mn) : 0u, bg2 = lossy_both(background);
+			const lossy_u16x2 ones = {1, 1};
+			uint32_t sd_all = 0, sd_fg = 0, s2_all = 0, s2_fg = 0, n_fg = 0, dor = 0;
 #pragma unroll
-			for (int q = 0; q < 8; ++q)
+			for (int j = 0; j < kIter; ++j)
+#pragma unroll
+				for (int q = 0; q < 4; ++q)
+				{
+					const lossy_u16x2 v = lp2(a[j][q]), o = lp2(p[j][q]);
+					const lossy_u16x2 t = __builtin_elementwise_sub_sat(v, lp2(min2));
+					const lossy_u16x2 d = __builtin_elementwise_max(t, o) - __builtin_elementwise_min(t, o);
+					const uint32_t fgm = lossy_nz_mask(__builtin_elementwise_sub_sat(v, lp2(bg2))); // v > background
+					const lossy_u16x2 dfg = lp2(lu1(d) & fgm);
+					dor |= lu1(d);
+					sd_all = __builtin_amdgcn_udot2(d, ones, sd_all, false), sd_fg = __builtin_amdgcn_udot2(dfg, ones, sd_fg, false);
+					s2_all = __builtin_amdgcn_udot2(d, d, s2_all, false), s2_fg = __builtin_amdgcn_udot2(dfg, dfg, s2_fg, false);
+					n_fg = __builtin_amdgcn_udot2(lp2(fgm & 0x00010001u), ones, n_fg, false);
+				}
+			if (__builtin_expect(__ballot((dor & 0xf000f000u) != 0u) == 0ull, 1))
 			{
-				const uint32_t aw = a[j][q >> 1], pw = p[j][q >> 1];
-				const uint32_t v = (q & 1) ? aw >> 16 : aw & 0xffffu, o = (q & 1) ? pw >> 16 : pw & 0xffffu;
-				const uint32_t t = subtract_min ? sub_min(v, mn) : v;
-				const int32_t d = in ? abs((int32_t)t - (int32_t)o) : 0;
-				const int32_t d2 = (int32_t)((uint32_t)d * (uint32_t)d);
-				const uint32_t one = in ? 1u : 0u;
-				if (v > background)
-					fd += (uint32_t)d, f2 += d2, fn += one;
-				else
-					bd += (uint32_t)d, b2 += d2, bn += one;
+				fd = sd_fg, bd = sd_all - sd_fg, fn = n_fg, bn = valid - n_fg;
+				f2 = (long long)s2_fg, b2 = (long long)(s2_all - s2_fg);
+			}
+			else
+			{
+#pragma unroll
+				for (int j = 0; j < kIter; ++j)
+				{
+					const bool in = (i0 / 8 + j * 256 + tid) * 8 < i1;
+#pragma unroll
+					for (int q = 0; q < 8; ++q)
+					{
+						const uint32_t aw = a[j][q >> 1], pw = p[j][q >> 1];
+						const uint32_t v = (q & 1) ? aw >> 16 : aw & 0xffffu, o = (q & 1) ? pw >> 16 : pw & 0xffffu;
+						const uint32_t t = subtract_min ? sub_min(v, mn) : v;
+						const int32_t d = in ? abs((int32_t)t - (int32_t)o) : 0;
+						const int32_t d2 = (int32_t)((uint32_t)d * (uint32_t)d);
+						const uint32_t one = in ? 1u : 0u;
+						if (v > background)
+							fd += (uint32_t)d, f2 += d2, fn += one;
+						else
+							bd += (uint32_t)d, b2 += d2, bn += one;
+					}
+				}
 			}
 		}
 		const uint32_t wfd = lossy_wave_sum32(fd), wbd = lossy_wave_sum32(bd), wfn = lossy_wave_sum32(fn), wbn = lossy_wave_sum32(bn);

@@ -3333,6 +3333,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 	const bool runs = nsteps >= 2 && s_px > 0 && s_px % 8 == 0 && full_px % 8 == 0;
 	if (nsteps > 0)
 	{
+		lead.const_groups = 0, lead.spec_groups = 0; // (the books of rir_lossy_path_stats / rir_lossy_spec_stats: of THIS call, whatever path it takes)
 		// the descriptions of all launches of the call go to the device in one copy (page-locked staging: the copy is asynchronous
 		// and the host buffer must outlive it - it is kept by the leading stream's object)
 		// persistent: the whole group of frames in one launch (lossy_run_kernel) when the chip holds a stream's workgroups at once

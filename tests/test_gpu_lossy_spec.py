@@ -274,3 +274,32 @@ def test_speculative_form_other_full_sizes(oracle, shape):
     moved = sum(1 for k in range(n) if (elo[k], ehi[k]) != (6, 2))
     assert all(b[0] == 1 and b[1] == 1 for b in books) and (moved > 2 or all(b[2] == 1 for b in books)), (books, moved)
     ls.close()
+
+
+def test_sums_of_large_differences_take_the_exact_path(oracle):
+    """The sums kernel adds two pixels to an instruction as long as every difference is below 4 096; a wave that meets a larger one does its pixels
+    one by one, with the reference's own arithmetic (the square wraps at 32 bits and is added as a signed number: differences of 46 341 levels and
+    more).  A tiny stdFactor keeps the budgets at the guess whatever the statistic, so the groups are committed and their statistics go into the
+    40-frame window; the factor is then raised, and every later budget depends on what the window holds: frames and budgets the oracle's."""
+    import torch
+
+    from librir_amd import device as D
+
+    n, h, w, hl = 120, 64, 96, 61
+    arr = static_scene(n, h, w, seed=37).astype(np.int64)
+    arr[20:23, 10:30, 20:70] += 50000  # differences beyond 46 340: the wrapped square is negative
+    arr[45, 40:50, :] += 5000          # ... and beyond 4 096 only
+    arr = np.clip(arr, 0, 65535).astype(np.uint16)
+    changes = {60: (6, 2, 5.0)}
+    exp, elo, ehi = _oracle_track(oracle, arr, w, h, hl, 6, 2, 1e-9, 8, changes=changes)
+    ls = D.LossyStream(w, h, hl, 6, 2, 1e-9, 8)
+    t = torch.from_numpy(arr).cuda()
+    a = ls.step(t[:60])
+    assert ls.spec_stats()[2] == 1, ls.spec_stats()  # committed: its window entries are the sums kernel's
+    ls.set_errors(6, 2, 5.0)
+    b = ls.step(t[60:])
+    got = torch.cat([a[0], b[0]]).cpu().numpy()
+    assert np.array_equal(got, exp)
+    assert np.concatenate([a[1], b[1]]).tolist() == elo and np.concatenate([a[2], b[2]]).tolist() == ehi
+    assert any(e != 6 for e in elo[60:100]), "the window's content never mattered: the test stream does not do what it is about"
+    ls.close()
