@@ -256,8 +256,13 @@ namespace rir
 		unsigned int *tickets;
 		int s, hist_px;
 	};
+	// NT: the pixels are loaded with the non-temporal policy - for launches over more frames than the Infinity Cache holds (the streaming kernel that
+	// follows reads them from HBM either way: 1 000 frames of one 640x512 stream +5 % on the whole call); shorter groups keep the default policy,
+	// under which the streaming kernel finds the frames in the cache (50-frame groups: 2 % slower with nt)
+	template <bool NT = false>
 	__device__ __forceinline__ void lossy_hist_mode_body(const LossyHistJob &sp, uint32_t *lh)
 	{
+		constexpr int kAux = NT ? 2 : 0;
 		const int tid = threadIdx.x;
 		RIR_GLOBAL(const uint16_t) *tmp = as_global(sp.tmp);
 		RIR_GLOBAL(uint32_t) *hist = as_global(sp.hist);
@@ -281,7 +286,7 @@ namespace rir
 #pragma unroll
 			for (int a = 0; a < kHistAhead; ++a)
 			{ // (in this order, as the loop asks again: the wait at its top is one instruction for both ways in)
-				q[a] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(ib + a * 1024 + tid) * 16u, 0, 0);
+				q[a] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(ib + a * 1024 + tid) * 16u, 0, kAux);
 				__builtin_amdgcn_sched_barrier(0);
 			}
 			for (; ib < n8; ib += 1024 * kHistAhead)
@@ -299,7 +304,7 @@ namespace rir
 					for (int k = 0; k < 8; ++k)
 						asm volatile("" : "+v"(bins[k]));
 					__builtin_amdgcn_sched_barrier(0);
-					q[a] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(ib + (a + kHistAhead) * 1024 + tid) * 16u, 0, 0);
+					q[a] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(ib + (a + kHistAhead) * 1024 + tid) * 16u, 0, kAux);
 					__builtin_amdgcn_sched_barrier(0);
 					lossy_hist_add8(lh, bins, in, hw);
 				}
@@ -396,6 +401,7 @@ namespace rir
 	}
 	// The backgrounds of a group of frames of a run, straight from the runs' descriptions (no per-frame table to build and copy): entry
 	// blockIdx.y = frame k of stream i of the group (k major), its histogram slice and ticket the entry's own.
+	template <bool NT>
 	__global__ __launch_bounds__(1024) void lossy_hist_mode_runs_kernel(const LossyRun *__restrict__ runs, int nstreams, uint32_t *__restrict__ hist_base,
 																		unsigned int *__restrict__ tick_base, int s, int hist_px)
 	{
@@ -403,7 +409,7 @@ namespace rir
 		const int e = blockIdx.y, k = e / nstreams, i = e - k * nstreams;
 		RIR_GLOBAL(const LossyRun) *r = as_global(runs + i);
 		const LossyHistJob job = {r->in + (size_t)k * r->frame_px, hist_base + (size_t)e * 16384, const_cast<long long *>(r->bg) + (size_t)k * r->bg_stride, tick_base + e, s, hist_px};
-		lossy_hist_mode_body(job, lh);
+		lossy_hist_mode_body<NT>(job, lh);
 	}
 
 	// (int) of a double as the reference's x86-64 build converts it (cvttsd2si): NaN and values outside int32 give
@@ -2898,8 +2904,11 @@ namespace rir
 	{
 		if (frames <= 0 || nstreams <= 0 || s <= 0)
 			return hipSuccess;
-		hipLaunchKernelGGL(lossy_hist_mode_runs_kernel, dim3((s + hist_px - 1) / hist_px, (unsigned)(frames * nstreams)), dim3(1024), 0, st, d_runs, nstreams, d_hist, d_tickets,
-						   s, hist_px);
+		const dim3 grid((s + hist_px - 1) / hist_px, (unsigned)(frames * nstreams));
+		if ((long long)frames * nstreams * s * 2 > (192ll << 20)) // (more than the 256 MB Infinity Cache keeps beside everything else: see lossy_hist_mode_body)
+			hipLaunchKernelGGL(lossy_hist_mode_runs_kernel<true>, grid, dim3(1024), 0, st, d_runs, nstreams, d_hist, d_tickets, s, hist_px);
+		else
+			hipLaunchKernelGGL(lossy_hist_mode_runs_kernel<false>, grid, dim3(1024), 0, st, d_runs, nstreams, d_hist, d_tickets, s, hist_px);
 		return hipGetLastError();
 	}
 	hipError_t launch_lossy_frame(const LossyStep *d_table, int nstreams, int full, hipStream_t st)
