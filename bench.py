@@ -33,6 +33,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -653,10 +654,140 @@ def main():
     if int(ctx.error.item()) != 0 or not torch.equal(out.view(torch.int16), frames.view(torch.int16)) or enc.total_words() * 8 != payload_bytes:
         raise SystemExit("bench.py: the dense form does not decode to the input - refusing to report a number")
 
+    tables_bytes = batch.nbytes() - payload_bytes
+    extra = {"encoded_footprint_bytes": batch.nbytes(), "raw_bytes": int(2 * h * w * n),
+             "value_from_idle": n * K * world / dt_idle,
+             "value_from_idle_note": "the same K steps after the same W warm-up steps on a device that had been idle (no ramp): %d steps of set-up ran between "
+                                     "this region and the one `value` is computed from" % ramp_steps,
+             "encoded_batch": {"payload_bytes": payload_bytes, "tables_bytes": tables_bytes, "extent_low_bytes": low_words * 8, "extent_high_bytes": high_words * 8,
+                               "stream_buffer_bytes": pc.stream.numel() * 8, "encoder_workspace_bytes": pc.workspace.numel(), "arena_bytes_used": arena_words * 8,
+                               "note": "what the step's encoder leaves: headers + a (position, length) pair per segment + the payload without holes at the two "
+                                       "ends of a stream buffer of half the raw size (8 bit-per-pixel budget; a batch that needs more is refused, not "
+                                       "written out of bounds) - everything a file or an exchange needs, nothing else"},
+             "slotted_form": {"value": n * K * world / dt_slotted, "ms_per_step": dt_slotted / K * 1e3,
+                              "value_unplaced": n * K * world / dt_slotted_unplaced,
+                              "workspace_bytes": int(ctx.layout.workspace_bytes),
+                              "packing_us_of_the_placement_candidates": [round(x, 1) for x in placement_us],
+                              "note": "round 3's step (encode_tiles + decode_slots): the encoded batch lives in worst-case slots inside a workspace larger "
+                                      "than the input - an on-device hand-over, not an encoded batch one can keep; workspace placed by measurement (DESIGN.md §7)"},
+             "spread": spread,
+             "dense_file_form": {"value": n * K * world / dt_dense, "ms_per_step": dt_dense / K * 1e3, "ms_compact": ms_compact,
+                                 "ms_decode_from_dense": ms_decode_dense,
+                                 "note": "encode_tiles + scan/compact (the canonical ordered stream of the FILE format) + decode from it: round 2's step"}}
+    if world == 1:
+        # the single-pass (look-back) encoder beside the two-pass one that `value` is measured with: same outputs, fewer bytes
+        # through HBM, no faster (DESIGN.md §3)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            sp = ctx.encode(frames, single_pass=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(K):
+            sp = ctx.encode(frames, single_pass=True)
+        e1.record()
+        torch.cuda.synchronize()
+        ctx.decode(sp, out=out, check=False)
+        ok_sp = ctx.encode_status() == 0 and bool(torch.equal(out.view(torch.int16), frames.view(torch.int16)))
+        extra["single_pass_encoder"] = {"ms_per_launch": e0.elapsed_time(e1) / K, "bit_exact_roundtrip": ok_sp,
+                                        "kernel": "rirb1_encode_dense (memset + 1 launch): the dense stream in one pass", "two_pass_ms": ms_compact_tiles + ms_compact}
+    extra.update(extra_abi)
+
+    emitted = threading.Lock()
+
+    def emit(exchange):
+        # (one line, once: by the main thread after the exchange, or by the watchdog below when the exchange hangs)
+        if not emitted.acquire(blocking=False):
+            return
+        if rank == 0:
+            raw = 2.0 * h * w * n  # bytes of raw uint16 per batch
+            kernels = {
+                "rirb1_encode_packed": {"ms": ms_tiles, "alg_bytes": raw + payload_bytes + tables_bytes},
+                "rirb1_decode_tiles": {"ms": ms_decode, "alg_bytes": raw + payload_bytes + tables_bytes},
+            }
+            for kv in kernels.values():
+                kv["GBs"] = kv["alg_bytes"] / (kv["ms"] * 1e-3) / 1e9
+            dom = max(("rirb1_encode_packed", "rirb1_decode_tiles"), key=lambda k_: kernels[k_]["ms"])
+            traffic = None
+            import glob
+
+            tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))  # the latest round's PMC pass
+            tpath = tfiles[-1] if tfiles else ""
+            if tpath:
+                try:
+                    traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            fps = n * K * world / dt
+            res = {
+                "metric": "IR frames/sec encode+decode, 640x512 uint16",
+                "value": fps,
+                "unit": "frames/s",
+                "n_gpus": world,
+                "steps": K,
+                "warmup": args.warmup,
+                "ms_per_step": dt / K * 1e3,
+                "higher_is_better": True,
+                "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": "u16",
+                "data": "synthetic",
+                "config": {"workload": "configs[1]: %d-frame %dx%d uint16 stream (S1 noisy background, seed 1234+rank), lossless RIRB1 "
+                                       "encode+decode, device-resident, GOP %d, per GPU; two launches per step: the encoder leaves the PACKED "
+                                       "form (headers + position and length per segment + the payload without holes: encoded_footprint_bytes, "
+                                       "in a buffer of half the raw size), the decoder reads it as it is; the compressed payload (17 %% of a "
+                                       "pass's bytes) is written and read back through the 256 MiB Infinity Cache, the raw frames (655 MB "
+                                       "each way) stream from / to HBM" % (n, w, h, gop),
+                           "frames_per_gpu": n, "width": w, "height": h, "gop": gop, "sharding": "independent shard per rank"},
+                "bit_exact_roundtrip": True,
+                "value_excludes_exchange": True if world > 1 else None,
+                "step_alg_bytes": 2.0 * raw + 2.0 * (payload_bytes + tables_bytes),
+                "step_alg_frac_of_hbm_peak": (2.0 * raw + 2.0 * (payload_bytes + tables_bytes)) / (dt / K) / 1e9 / HBM_PEAK_GBS,
+                "compression_ratio": raw / cbytes,
+                "roundtrip_raw_GBs": fps * 4.0 * h * w / 1e9 / world,
+                "roundtrip_raw_frac_of_hbm_peak": fps * 4.0 * h * w / 1e9 / world / HBM_PEAK_GBS,
+                "roofline": {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": kernels[dom]["GBs"] / HBM_PEAK_GBS, "traffic": traffic,
+                             "traffic_source": ("%s (static: rocprofv3 --pmc passes of an earlier run of this command, not measured in this run)"
+                                                % os.path.relpath(tpath, ROOT)) if traffic is not None else None,
+                             "alg_bytes_per_launch": kernels[dom]["alg_bytes"], "ms_per_launch": kernels[dom]["ms"],
+                             "measured": "HIP events between the launches of a K-step region that follows the timed one (ms_per_step_with_events)"},
+                "ms_per_step_with_events": dt_events / K * 1e3,
+                "kernels": kernels,
+            }
+            res.update(extra)
+            if exchange:
+                res.update(exchange)
+            if identity:
+                res.update(identity)
+                ref1 = newest_n1_value()
+                res["n1_reference_value"] = ref1
+                res["scaling_factor_vs_n1_reference"] = (fps / ref1["value"]) if ref1 else None
+            if cpu is not None:
+                res["cpu_baseline"] = cpu
+            print(json.dumps(res))
+
+    # The exchange has never run on RCCL before a driver runs it (one-GPU boxes here): a collective that hangs must not cost the line its
+    # `value`.  Armed on every rank before the exchange: after EXCHANGE_LIMIT_S seconds rank 0 prints the line without the exchange keys and
+    # every rank leaves (a collective that hangs cannot be called off; the numbers of `value` were complete before).
+    EXCHANGE_LIMIT_S = float(os.environ.get("RIR_BENCH_EXCHANGE_LIMIT_S", "240"))
+
+    def exchange_timed_out():
+        emit({"exchange_error": "the exchange did not finish within %.0f s: the line carries the sharded path only" % EXCHANGE_LIMIT_S})
+        sys.stdout.flush()
+        os._exit(0)
+
+    watchdog = None
+    if world > 1:
+        watchdog = threading.Timer(EXCHANGE_LIMIT_S, exchange_timed_out)
+        watchdog.daemon = True
+        watchdog.start()
+
     # ---- N > 1: the same step WITH the exchange, inside its own timed bracket (same K, same barriers) ----
     exchange = None
     if world > 1:
         try:
+            if os.environ.get("RIR_BENCH_EXCHANGE_HANG"):  # (rehearsal of the watchdog: as if a collective never came back)
+                time.sleep(1e6)
             nchunks = ctx.layout.nchunks
             piece = max(gop, (args.exchange_piece // gop) * gop)
             while n % piece:
@@ -749,111 +880,9 @@ def main():
         except Exception as e:  # the exchange is an EXTRA measurement: it must not cost the line its `value` (never run on RCCL before a driver does)
             exchange = {"exchange_error": repr(e)[:400]}
 
-    tables_bytes = batch.nbytes() - payload_bytes
-    extra = {"encoded_footprint_bytes": batch.nbytes(), "raw_bytes": int(2 * h * w * n),
-             "value_from_idle": n * K * world / dt_idle,
-             "value_from_idle_note": "the same K steps after the same W warm-up steps on a device that had been idle (no ramp): %d steps of set-up ran between "
-                                     "this region and the one `value` is computed from" % ramp_steps,
-             "encoded_batch": {"payload_bytes": payload_bytes, "tables_bytes": tables_bytes, "extent_low_bytes": low_words * 8, "extent_high_bytes": high_words * 8,
-                               "stream_buffer_bytes": pc.stream.numel() * 8, "encoder_workspace_bytes": pc.workspace.numel(), "arena_bytes_used": arena_words * 8,
-                               "note": "what the step's encoder leaves: headers + a (position, length) pair per segment + the payload without holes at the two "
-                                       "ends of a stream buffer of half the raw size (8 bit-per-pixel budget; a batch that needs more is refused, not "
-                                       "written out of bounds) - everything a file or an exchange needs, nothing else"},
-             "slotted_form": {"value": n * K * world / dt_slotted, "ms_per_step": dt_slotted / K * 1e3,
-                              "value_unplaced": n * K * world / dt_slotted_unplaced,
-                              "workspace_bytes": int(ctx.layout.workspace_bytes),
-                              "packing_us_of_the_placement_candidates": [round(x, 1) for x in placement_us],
-                              "note": "round 3's step (encode_tiles + decode_slots): the encoded batch lives in worst-case slots inside a workspace larger "
-                                      "than the input - an on-device hand-over, not an encoded batch one can keep; workspace placed by measurement (DESIGN.md §7)"},
-             "spread": spread,
-             "dense_file_form": {"value": n * K * world / dt_dense, "ms_per_step": dt_dense / K * 1e3, "ms_compact": ms_compact,
-                                 "ms_decode_from_dense": ms_decode_dense,
-                                 "note": "encode_tiles + scan/compact (the canonical ordered stream of the FILE format) + decode from it: round 2's step"}}
-    if world == 1:
-        # the single-pass (look-back) encoder beside the two-pass one that `value` is measured with: same outputs, fewer bytes
-        # through HBM, no faster (DESIGN.md §3)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(3):
-            sp = ctx.encode(frames, single_pass=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(K):
-            sp = ctx.encode(frames, single_pass=True)
-        e1.record()
-        torch.cuda.synchronize()
-        ctx.decode(sp, out=out, check=False)
-        ok_sp = ctx.encode_status() == 0 and bool(torch.equal(out.view(torch.int16), frames.view(torch.int16)))
-        extra["single_pass_encoder"] = {"ms_per_launch": e0.elapsed_time(e1) / K, "bit_exact_roundtrip": ok_sp,
-                                        "kernel": "rirb1_encode_dense (memset + 1 launch): the dense stream in one pass", "two_pass_ms": ms_compact_tiles + ms_compact}
-    extra.update(extra_abi)
-
-    if rank == 0:
-        raw = 2.0 * h * w * n  # bytes of raw uint16 per batch
-        kernels = {
-            "rirb1_encode_packed": {"ms": ms_tiles, "alg_bytes": raw + payload_bytes + tables_bytes},
-            "rirb1_decode_tiles": {"ms": ms_decode, "alg_bytes": raw + payload_bytes + tables_bytes},
-        }
-        for kv in kernels.values():
-            kv["GBs"] = kv["alg_bytes"] / (kv["ms"] * 1e-3) / 1e9
-        dom = max(("rirb1_encode_packed", "rirb1_decode_tiles"), key=lambda k_: kernels[k_]["ms"])
-        traffic = None
-        import glob
-
-        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))  # the latest round's PMC pass
-        tpath = tfiles[-1] if tfiles else ""
-        if tpath:
-            try:
-                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        fps = n * K * world / dt
-        res = {
-            "metric": "IR frames/sec encode+decode, 640x512 uint16",
-            "value": fps,
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": K,
-            "warmup": args.warmup,
-            "ms_per_step": dt / K * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u16",
-            "data": "synthetic",
-            "config": {"workload": "configs[1]: %d-frame %dx%d uint16 stream (S1 noisy background, seed 1234+rank), lossless RIRB1 "
-                                   "encode+decode, device-resident, GOP %d, per GPU; two launches per step: the encoder leaves the PACKED "
-                                   "form (headers + position and length per segment + the payload without holes: encoded_footprint_bytes, "
-                                   "in a buffer of half the raw size), the decoder reads it as it is; the compressed payload (17 %% of a "
-                                   "pass's bytes) is written and read back through the 256 MiB Infinity Cache, the raw frames (655 MB "
-                                   "each way) stream from / to HBM" % (n, w, h, gop),
-                       "frames_per_gpu": n, "width": w, "height": h, "gop": gop, "sharding": "independent shard per rank"},
-            "bit_exact_roundtrip": True,
-            "value_excludes_exchange": True if world > 1 else None,
-            "step_alg_bytes": 2.0 * raw + 2.0 * (payload_bytes + tables_bytes),
-            "step_alg_frac_of_hbm_peak": (2.0 * raw + 2.0 * (payload_bytes + tables_bytes)) / (dt / K) / 1e9 / HBM_PEAK_GBS,
-            "compression_ratio": raw / cbytes,
-            "roundtrip_raw_GBs": fps * 4.0 * h * w / 1e9 / world,
-            "roundtrip_raw_frac_of_hbm_peak": fps * 4.0 * h * w / 1e9 / world / HBM_PEAK_GBS,
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": kernels[dom]["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": kernels[dom]["GBs"] / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": ("%s (static: rocprofv3 --pmc passes of an earlier run of this command, not measured in this run)"
-                                            % os.path.relpath(tpath, ROOT)) if traffic is not None else None,
-                         "alg_bytes_per_launch": kernels[dom]["alg_bytes"], "ms_per_launch": kernels[dom]["ms"],
-                         "measured": "HIP events between the launches of a K-step region that follows the timed one (ms_per_step_with_events)"},
-            "ms_per_step_with_events": dt_events / K * 1e3,
-            "kernels": kernels,
-        }
-        res.update(extra)
-        if exchange:
-            res.update(exchange)
-        if identity:
-            res.update(identity)
-            ref1 = newest_n1_value()
-            res["n1_reference_value"] = ref1
-            res["scaling_factor_vs_n1_reference"] = (fps / ref1["value"]) if ref1 else None
-        if cpu is not None:
-            res["cpu_baseline"] = cpu
-        print(json.dumps(res))
+    if watchdog is not None:
+        watchdog.cancel()
+    emit(exchange)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
