@@ -968,15 +968,23 @@ namespace rir
 		const uint32_t f2 = floor_v | (floor_v << 16);
 		if (i8 + 8 <= total && ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0)
 		{
-			uint4 v = *reinterpret_cast<const uint4 *>(in + i8);
-			uint32_t *p = reinterpret_cast<uint32_t *>(&v);
+#ifndef RIR_CLAMP_COPY_NT
+#define RIR_CLAMP_COPY_NT 2 /* 1: non-temporal load, 2: non-temporal store, 3: both.  Measured (256 frames 640x512): store alone 0.069 -> 0.0635 ms, load alone or both slower (the repair launch reads the neighbours of the flagged pixels from the cache) */
+#endif
+			typedef unsigned int clamp_v4u __attribute__((ext_vector_type(4)));
+			const clamp_v4u *src4 = reinterpret_cast<const clamp_v4u *>(in + i8);
+			clamp_v4u v = (RIR_CLAMP_COPY_NT & 1) ? __builtin_nontemporal_load(src4) : *src4;
 #pragma unroll
 			for (int k = 0; k < 4; ++k)
 			{
-				const uint32_t lo = max(p[k] & 0xffffu, f2 & 0xffffu), hi = max(p[k] >> 16, f2 >> 16);
-				p[k] = lo | (hi << 16);
+				const uint32_t lo = max(v[k] & 0xffffu, f2 & 0xffffu), hi = max(v[k] >> 16, f2 >> 16);
+				v[k] = lo | (hi << 16);
 			}
-			*reinterpret_cast<uint4 *>(out + i8) = v;
+			clamp_v4u *dst4 = reinterpret_cast<clamp_v4u *>(out + i8);
+			if (RIR_CLAMP_COPY_NT & 2)
+				__builtin_nontemporal_store(v, dst4);
+			else
+				*dst4 = v;
 		}
 		else
 		{
