@@ -527,6 +527,9 @@ namespace rir
 	// doing exactly the operations lossy_budget does for its component, in the same order.  Split in two so that the sum over the
 	// window - 40 dependent additions that do not involve the new frame - is out of the way before the frame's sums arrive:
 	// lossy_budget2_prepare (any time after the previous frame's finish), then lossy_budget2_finish.  Both lanes call; b in LDS.
+	// (The 39 additions in a row - the ORDER is the reference's and cannot change - are 1.1-1.5 us of the leader's 6 us per frame
+	// (RIR_LOSSY_DIAG: "window sum").  Asking for 13 window entries at a time instead of one brought the sum itself from 1.5 to 1.1 us and cost
+	// the rest of the frame more - 155 k frames/s against 163 k: the kernel has no registers to spare.  Not kept.)
 	__device__ __forceinline__ double lossy_budget2_prepare(const LossyBudget &b, int c)
 	{
 		double part = b.first_std[c]; // first + the window entries that stay, oldest to newest (the new entry is added last)
@@ -1267,6 +1270,9 @@ namespace rir
 		bool gave_up = false;
 		for (int k = 0; k < rp.nsteps; ++k)
 		{
+#ifdef RIR_LOSSY_DIAG
+			const unsigned long long dgA = __builtin_amdgcn_s_memrealtime();
+#endif
 			// the next frame's pixels are requested now: they arrive while this frame's sums go round
 			U16x8 vn{};
 			if (inside && k + 1 < rp.nsteps)
@@ -1300,7 +1306,7 @@ namespace rir
 #endif
 #ifdef RIR_LOSSY_DIAG
 			const unsigned long long dg0 = __builtin_amdgcn_s_memrealtime();
-			unsigned long long dg1 = 0, dg2 = 0, dg3 = 0;
+			unsigned long long dg1 = 0, dg2 = 0, dg3 = 0, dgB = 0, dgC = 0;
 #endif
 			// wave sums -> LDS; wave 0 adds the waves up, publishes, collects everybody's words and decides
 #ifndef RIR_LOSSY_PACKED_SUMS
@@ -1331,6 +1337,9 @@ namespace rir
 			if (lane < 6)
 				red[wave][lane] = lane == 0 ? ws[0] : lane == 1 ? ws[1] : lane == 2 ? ws[2] : lane == 3 ? ws[3] : lane == 4 ? ws[4] : ws[5];
 			__syncthreads();
+#ifdef RIR_LOSSY_DIAG
+			dgB = __builtin_amdgcn_s_memrealtime();
+#endif
 			const unsigned long long tag = (unsigned long long)(((unsigned)k & 0x7fffu) | 0x8000u) << 48;
 			const unsigned long long vmask = 0x0000ffffffffffffull;
 			RIR_GLOBAL(unsigned long long) *bank = exch + (size_t)(k & 1) * nb * rp.slot_words;
@@ -1355,6 +1364,9 @@ namespace rir
 															 : (unsigned long long)ws[4] & vmask;
 					__hip_atomic_store(bank + (size_t)b * rp.slot_words + lane, tag | w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
+#ifdef RIR_LOSSY_DIAG
+				dgC = __builtin_amdgcn_s_memrealtime();
+#endif
 				// while the words travel: the part of the budget that does not need them
 				if (lane < 2 && (!rp.leader || b == 0))
 					part = lossy_budget2_prepare(bl, lane);
@@ -1369,8 +1381,12 @@ namespace rir
 			long long acc[6] = {0, 0, 0, 0, 0, 0};
 			if (rp.leader && b == 0)
 				__builtin_amdgcn_s_setprio(3); // (the whole stream waits for what this workgroup does next, and it shares its CU with four others: 7 streams 561 -> 579 k frames/s)
+			// (wave 0 of a collecting workgroup is in the window sum for another microsecond - RIR_LOSSY_DIAG: "window sum" - so the other three
+			// waves take the slots between them when they can: 192 threads for the 160 workgroups of a 640x512 stream.  The round trip of the
+			// polls then runs under the window sum instead of behind it.)
+			const bool three_waves = nb <= kLossyRunThreads - 64;
 			if (collect)
-				for (int p = tid; p < nb; p += kLossyRunThreads)
+				for (int p = three_waves ? tid - 64 : tid; p >= 0 && p < nb; p += three_waves ? kLossyRunThreads - 64 : kLossyRunThreads)
 				{
 					unsigned long long w[4];
 					const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
@@ -1537,7 +1553,7 @@ namespace rir
 			{ // ticks (10 ns) of: sums + reduce + publish | poll | reduce | budget | barrier + update, summed over the frames
 				RIR_GLOBAL(unsigned long long) *dg = (RIR_GLOBAL(unsigned long long) *)as_global(rp.error_word) + 8;
 				const unsigned long long dg4 = __builtin_amdgcn_s_memrealtime();
-				dg[0] += dg1 - dg0, dg[1] += dg2 - dg1, dg[2] += dg3 - dg2, dg[3] += dg4 - dg3, dg[4] += 1;
+				dg[0] += dg1 - dg0, dg[1] += dg2 - dg1, dg[2] += dg3 - dg2, dg[3] += dg4 - dg3, dg[4] += 1, dg[5] += dg0 - dgA, dg[6] += dgB - dg0, dg[7] += dgC - dgB;
 			}
 #endif
 		}

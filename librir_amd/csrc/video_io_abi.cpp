@@ -3723,10 +3723,11 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 			return -1;
 		if (getenv("RIR_LOSSY_DIAG") && lead.run_exchange.ptr)
 		{ // (-DRIR_LOSSY_DIAG builds) where the time of a frame goes, workgroup 0 of stream 0
-			unsigned long long dg[5] = {0, 0, 0, 0, 0};
+			unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 			if (hip_ok(hipMemcpy(dg, lead.run_exchange.as<char>() + 128, sizeof(dg), hipMemcpyDeviceToHost), "D2H") && dg[4])
-				std::fprintf(stderr, "lossy run, per frame (us): sums+publish %.2f  poll %.2f  budget %.2f  barrier+update %.2f  (%llu frames)\n",
-							 dg[0] * 0.01 / dg[4], dg[1] * 0.01 / dg[4], dg[2] * 0.01 / dg[4], dg[3] * 0.01 / dg[4], dg[4]);
+				std::fprintf(stderr, "lossy run, per frame (us): loads+pixel sums %.2f  reduce+publish %.2f (wave sums + barrier %.2f, merge + publish %.2f, window sum %.2f)  poll %.2f  budget %.2f  barrier+update %.2f  (%llu frames)\n",
+							 dg[5] * 0.01 / dg[4], dg[0] * 0.01 / dg[4], dg[6] * 0.01 / dg[4], dg[7] * 0.01 / dg[4], (dg[0] - dg[6] - dg[7]) * 0.01 / dg[4], dg[1] * 0.01 / dg[4],
+							 dg[2] * 0.01 / dg[4], dg[3] * 0.01 / dg[4], dg[4]);
 		}
 		if (lead.run_exchange.ptr)
 			lead.checked(gave_up, st);
