@@ -303,3 +303,29 @@ def test_sums_of_large_differences_take_the_exact_path(oracle):
     assert np.concatenate([a[1], b[1]]).tolist() == elo and np.concatenate([a[2], b[2]]).tolist() == ehi
     assert any(e != 6 for e in elo[60:100]), "the window's content never mattered: the test stream does not do what it is about"
     ls.close()
+
+
+def test_speculative_form_declines_what_it_must_not_take(oracle):
+    """An empty foreground or background makes the reference's statistic 0 / 0, and the NaN decides the budgets of that frame and of the 39 after it:
+    groups with a frame whose classes are not surely both there, and groups stepped while a NaN sits in the window, are not offered to the
+    speculative form (the precondition of the constant-budget form) and the general form steps them; afterwards it is offered again.  stdFactor 5;
+    same frames and budgets as the oracle throughout."""
+    import torch
+
+    from librir_amd import device as D
+
+    n, h, w, hl = 260, 64, 96, 64
+    arr = static_scene(n, h, w, seed=47)
+    arr[60:64] = 1000  # uniform frames: everything in the mode bin, no foreground (from frame 41 on the statistic is split)
+    arr[64] = np.where(np.arange(h * w).reshape(h, w) % 2 == 0, 1000, 1001)  # two levels inside one bin: nothing above, nothing below
+    exp, elo, ehi = _oracle_track(oracle, arr, w, h, hl, 6, 2, 5.0, 4)
+    ls = D.LossyStream(w, h, hl, 6, 2, 5.0, 4)
+    cuts = [0, 1, 50, 70, 90, 140, 200, n]
+    got, lo, hi, books = _run_cuts(ls, torch.from_numpy(arr).cuda(), cuts)
+    assert np.array_equal(got, exp)
+    assert lo == elo and hi == ehi
+    offered = {(c0, c1): b[1] for (c0, c1), b in zip(zip(cuts[:-1], cuts[1:]), books)}
+    # the call with the uniform frames and the calls while their NaN is in the 40-frame window (frames 60 .. 103) are not offered
+    assert offered[(1, 50)] == 1 and offered[(50, 70)] == 0 and offered[(70, 90)] == 0 and offered[(90, 140)] == 0, offered
+    assert offered[(140, 200)] == 1 or offered[(200, n)] == 1, offered  # (offered again once the window is clean - unless it backs off)
+    ls.close()
