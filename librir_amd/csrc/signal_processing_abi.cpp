@@ -164,6 +164,9 @@ namespace
 	// result over the link (profiles/r05_zero_copy_probe.txt: translate of a float image 54 us that way, 89 us with a copy in and a copy out,
 	// before the copy calls' own cost): no copy call, one launch, one wait.  RIR_ABI_ZERO_COPY=0: a transfer into / out of device buffers
 	// around the kernel, as before.  `slot`: byte offset in the input staging buffer (a call may stage two images).
+	// (Round 6, tried and dropped: the image in 2-6 strips of rows - strip j's kernel queued once its rows are staged, the next strip's copy
+	// and the previous strip's copy-out under it.  gaussian_filter of a float image: 94 us in one piece, 91 / 89 / 112 / 125 us in 2 / 3 / 4 / 6
+	// strips: a launch and an event per strip cost what the overlap of two 14 us copies gains.)
 	// -> the address the kernel reads (nullptr on failure)
 	// A caller's buffer that lies in page-locked memory of this library (rir_host_alloc: the arrays the Python mirror returns, which are the
 	// next call's input) is worked on where it is: no staging copy in, no copy back (round 6: the reference's three-call configs[2] path).
