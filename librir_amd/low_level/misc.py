@@ -90,7 +90,8 @@ class touch_ahead:
     The threads hold the array until they are through; contents are left as they are (``rir_host_touch``: an atomic compare-and-swap of a
     byte with itself per page).  By the letter of the C++ memory model that is a data race with the plain stores of the copies that may be
     filling the same page; it is meant: a locked read-modify-write that puts back what it read is serialised with those stores per cache line
-    on x86-64 (the only host this library is built for) and cannot change what they leave."""
+    on x86-64 (the only host this library is built for) and cannot change what they leave (run under ThreadSanitizer beside the copies, the race
+    suppressed by name and the copied bytes checked: scripts/tsan_host_copy.sh)."""
 
     PIECE = 16 << 20
     THREADS = 3
