@@ -27,6 +27,8 @@ def worker(k, tmp):
         rng = np.random.default_rng(k)
         h, w = 40 + 8 * k, 64 + 16 * k
         for r in range(rounds):
+            if k == 0 and r % 20 == 19:
+                print("round %d of %d, %d failures so far" % (r + 1, rounds, len(errors)), flush=True)
             fr = s1_noisy_background(23, h, w, seed=100 * k + r)
             p = os.path.join(tmp, "t%d_%d.h264" % (k, r))
             with IRSaver(p, w, h, h) as s:
