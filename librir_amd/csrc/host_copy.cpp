@@ -21,6 +21,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -137,6 +138,32 @@ namespace rir
 		{
 			Helper h[2][kMaxHelpers];
 			int n[2] = {0, 0};
+			// CPUs the cgroup of this process may use at once (cgroup v2 cpu.max "quota period", v1 cfs_quota_us / cfs_period_us), rounded up;
+			// 0: no limit, or not to be found
+			static unsigned cgroup_cpus()
+			{
+				long long q = -1, per = 0;
+				if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r"))
+				{
+					char w[32] = {0};
+					if (std::fscanf(f, "%31s %lld", w, &per) == 2 && std::strcmp(w, "max") != 0)
+						q = std::atoll(w);
+					std::fclose(f);
+				}
+				else
+				{
+					FILE *a = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *b = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+					if (a && b && (std::fscanf(a, "%lld", &q) != 1 || std::fscanf(b, "%lld", &per) != 1))
+						q = -1;
+					if (a)
+						std::fclose(a);
+					if (b)
+						std::fclose(b);
+				}
+				if (q <= 0 || per <= 0)
+					return 0;
+				return (unsigned)((q + per - 1) / per);
+			}
 			static int wanted(const char *var, int dflt, unsigned hw)
 			{
 				int want = dflt;
@@ -151,7 +178,10 @@ namespace rir
 			Pool()
 			{
 				pthread_atfork(nullptr, nullptr, [] { g_forked.store(true, std::memory_order_relaxed); });
-				const unsigned hw = std::thread::hardware_concurrency();
+				unsigned hw = std::thread::hardware_concurrency(); // (respects the affinity mask)
+				const unsigned quota = cgroup_cpus();
+				if (quota && (!hw || quota < hw))
+					hw = quota; // a container's CPU quota: helpers that spin beyond it only take the caller's time slice
 				n[0] = wanted("RIR_HOST_COPY_THREADS", 3, hw);
 				n[1] = wanted("RIR_HOST_IO_THREADS", 3, hw > 4 ? hw - 3 : 1);
 				for (int g = 0; g < 2; ++g)
