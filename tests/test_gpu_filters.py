@@ -405,7 +405,7 @@ def test_results_in_page_locked_memory_are_worked_on_in_place(oracle, lib):
     finally:
         results_in_page_locked_memory(before)
     a = BadPixels(s1_noisy_background(1, 512, 640, seed=1)[0]).correct(s1_noisy_background(1, 512, 640, seed=2)[0])
-    assert not _lib.rir_host_is_page_locked(ct.c_void_p(a.ctypes.data), ct.c_int64(a.nbytes))  # the default again
+    assert bool(_lib.rir_host_is_page_locked(ct.c_void_p(a.ctypes.data), ct.c_int64(a.nbytes))) == bool(before)  # as it was (ordinary memory unless RIR_PINNED_RESULTS=1)
 
 
 def _page_locked_results_case(oracle, lib, _lib, result_buffer, BadPixels, gaussian_filter, translate, inject_bad_pixels, s1_noisy_background, ct):

@@ -97,7 +97,8 @@ def _hook_case(*args):
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RIR_LIBRARY_VARIANT="testhooks")
-    for k in ("RIR_DEBUG_LOSSY_GIVE_UP", "RIR_DEBUG_LOSSY_BAIL", "RIR_DEBUG_ECC_BAIL", "RIR_DEBUG_SAVER_FAIL_FLYING", "RIR_LOSSY_SPEC_PASSES", "RIR_LOSSY_NO_SPEC"):
+    for k in ("RIR_DEBUG_LOSSY_GIVE_UP", "RIR_DEBUG_LOSSY_BAIL", "RIR_DEBUG_ECC_BAIL", "RIR_DEBUG_SAVER_FAIL_FLYING", "RIR_LOSSY_SPEC_PASSES", "RIR_LOSSY_NO_SPEC",
+              "RIR_ABI_ZERO_COPY"):  # (the cases are about the default forms, whatever the suite is run under)
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "hook_cases.py")] + [str(a) for a in args], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                        text=True, timeout=600)
