@@ -394,9 +394,13 @@ def world_identity(dist, torch, dev, world, rank, backend):
         pr = torch.cuda.get_device_properties(dev)
         bus = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", -1) & 0xff, getattr(pr, "pci_device_id", 0)) if hasattr(pr, "pci_bus_id") \
             else str(getattr(pr, "uuid", "gpu%d" % dev.index))
-        mine = {"rank": rank, "device_name": pr.name, "pci_bus_id": bus, "device_index": dev.index}
+        # what tells two devices apart even where a driver reports no (or the same) bus id for all of them: + uuid, + the index among the devices
+        # this rank sees, + what it was allowed to see (ranks of one launcher see the same set and take different indices)
+        visible = "|".join(os.environ.get(v, "") for v in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"))
+        mine = {"rank": rank, "device_name": pr.name, "pci_bus_id": bus, "device_index": dev.index,
+                "device_key": "%s %s #%d [%s]" % (bus, getattr(pr, "uuid", ""), dev.index, visible)}
     else:
-        mine = {"rank": rank, "device_name": "cpu", "pci_bus_id": "cpu", "device_index": -1}
+        mine = {"rank": rank, "device_name": "cpu", "pci_bus_id": "cpu", "device_index": -1, "device_key": "cpu"}
     everyone = [None] * world
     dist.all_gather_object(everyone, mine)
     version = None
@@ -499,7 +503,7 @@ def main():
     if world > 1:
         # the line proves what it ran on, or there is no line: every rank on the communicator, every rank a GPU of its own
         ranks_seen, coll_version, everyone = world_identity(dist, torch, dev, world, rank, backend)
-        why = check_world(ranks_seen, args.gpus, [e["pci_bus_id"] for e in everyone], bool(os.environ.get("RIR_BENCH_SHARE_GPU")))
+        why = check_world(ranks_seen, args.gpus, [e["device_key"] for e in everyone], bool(os.environ.get("RIR_BENCH_SHARE_GPU")))
         if why:
             if rank == 0:
                 sys.stderr.write("bench.py: refusing to run: %s\n" % why)

@@ -236,7 +236,7 @@ def _identity_worker(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         seen, version, everyone = bench.world_identity(dist, torch, None, world, rank, "gloo")
-        ids = [e["pci_bus_id"] for e in everyone]
+        ids = [e["device_key"] for e in everyone]
         ret[rank] = (seen, version, [e["rank"] for e in everyone], bench.check_world(seen, world, ids, False), bench.check_world(seen, world, ids, True))
     finally:
         dist.destroy_process_group()
