@@ -492,15 +492,26 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # RIR_BENCH_RCCL_SOLO=1 (rehearsal, with --gpus 1): the N > 1 control flow - identity, barriers, the exchange - on a communicator of ONE rank, so
+    # that a one-GPU box runs every collective of this file through RCCL itself (device tensors, the uint8 views, the object gather)
+    solo = world == 1 and bool(os.environ.get("RIR_BENCH_RCCL_SOLO"))
+    dist_on = world > 1 or solo
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if solo and "MASTER_PORT" not in os.environ:
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        kw = dict(rank=0, world_size=1) if solo else {}
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
 
     identity = None
-    if world > 1:
+    if dist_on:
         # the line proves what it ran on, or there is no line: every rank on the communicator, every rank a GPU of its own
         ranks_seen, coll_version, everyone = world_identity(dist, torch, dev, world, rank, backend)
         why = check_world(ranks_seen, args.gpus, [e["device_key"] for e in everyone], bool(os.environ.get("RIR_BENCH_SHARE_GPU")))
@@ -511,7 +522,8 @@ def main():
             dist.destroy_process_group()
             sys.exit(3)
         identity = {"ranks_seen": ranks_seen, "rccl_version" if backend == "nccl" else "collective_backend": coll_version if backend == "nccl" else backend,
-                    "ranks": everyone, "gpu_shared_by_ranks (rehearsal)": True if os.environ.get("RIR_BENCH_SHARE_GPU") else None}
+                    "ranks": everyone, "gpu_shared_by_ranks (rehearsal)": True if os.environ.get("RIR_BENCH_SHARE_GPU") else None,
+                    "single_rank_communicator (rehearsal)": True if solo else None}
 
     from librir_amd import device as D
     from librir_amd.distributed import CompressedGather, FrameGather, shard_plan
@@ -540,12 +552,12 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(dt):
-        if world == 1:
+        if not dist_on:
             return dt
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -607,7 +619,7 @@ def main():
     t_busy = time.perf_counter()
     while len(reps) < (1 if args.profile else 5) or (not args.profile and time.perf_counter() - t_busy < BUSY_S and len(reps) < 20000):
         reps.append(max_over_ranks(k_steps(K)) / K * 1e3)
-        if world > 1 and len(reps) >= 5 and not args.profile:  # (every rank must leave the loop in the same round: the region count is rank 0's decision)
+        if dist_on and len(reps) >= 5 and not args.profile:  # (every rank must leave the loop in the same round: the region count is rank 0's decision)
             go = torch.tensor([1 if time.perf_counter() - t_busy < BUSY_S else 0], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
             dist.broadcast(go, 0)
             if int(go.item()) == 0:
@@ -621,7 +633,7 @@ def main():
         if rank == 0:
             print(json.dumps({"profile_run": True, "ms_per_step": dt / K * 1e3, "kernels_ms": {"rirb1_encode_packed": ms_tiles, "rirb1_decode_tiles": ms_decode},
                               "payload_bytes": payload_bytes, "encoded_footprint_bytes": batch.nbytes()}))
-        if world > 1:
+        if dist_on:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -743,7 +755,7 @@ def main():
                                        "each way) stream from / to HBM" % (n, w, h, gop),
                            "frames_per_gpu": n, "width": w, "height": h, "gop": gop, "sharding": "independent shard per rank"},
                 "bit_exact_roundtrip": True,
-                "value_excludes_exchange": True if world > 1 else None,
+                "value_excludes_exchange": True if dist_on else None,
                 "step_alg_bytes": 2.0 * raw + 2.0 * (payload_bytes + tables_bytes),
                 "step_alg_frac_of_hbm_peak": (2.0 * raw + 2.0 * (payload_bytes + tables_bytes)) / (dt / K) / 1e9 / HBM_PEAK_GBS,
                 "compression_ratio": raw / cbytes,
@@ -781,14 +793,14 @@ def main():
         os._exit(0)
 
     watchdog = None
-    if world > 1:
+    if dist_on:
         watchdog = threading.Timer(EXCHANGE_LIMIT_S, exchange_timed_out)
         watchdog.daemon = True
         watchdog.start()
 
     # ---- N > 1: the same step WITH the exchange, inside its own timed bracket (same K, same barriers) ----
     exchange = None
-    if world > 1:
+    if dist_on:
         try:
             if os.environ.get("RIR_BENCH_EXCHANGE_HANG"):  # (rehearsal of the watchdog: as if a collective never came back)
                 time.sleep(1e6)
@@ -887,7 +899,7 @@ def main():
     if watchdog is not None:
         watchdog.cancel()
     emit(exchange)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 
