@@ -147,10 +147,13 @@ namespace rir
 		unsigned long long *rows;  // [nsteps][stat workgroups][4] the sums of a frame, per slab of kLossySpecSlab pixels (words as lossy_const_run_kernel's partials)
 		double *sd;				   // [nsteps][2] the statistic of every frame (sums kernel -> verify, commit)
 		unsigned int *tickets;	   // [nsteps] arrival counters of the frames' slabs: zero between launches (the last arriver clears its own)
-		unsigned int *ctl;		   // [8] 0: status (0 to be stepped, 1 verified, 2 given up), 1: passes so far, 2: first mismatch of the last pass, 3: passes allowed, 4: offered, 5: frames off the table at the last pass
+		unsigned int *ctl;		   // [8] 0: status (0 to be stepped, 1 verified, 2 given up), 1: passes so far, 2: first mismatch of the last pass, 3: passes allowed, 4: offered, 5: frames off the table at the last pass,
+								   // 6: flags, 7: a pass met a difference of 128 or more - `dplane` does not hold it: the sums are taken from the frames
 		unsigned int *backoff;	   // [2] of the call's leading stream: groups still to skip, failures in a row
 		unsigned int *backoff_host; // [2] the same two words in page-locked host memory, written whenever they change: the host looks (without
 								   // waiting) before it queues a call, and does not queue the launches of groups that would be skipped anyway
+		uint8_t *dplane;		   // [nsteps][s] or null: a byte per pixel and frame, left by the streaming kernel for the sums kernel - |input k - output k - 1| in bits 0..6,
+								   // input k > background k in bit 7: what the sums are made of, at a quarter of the bytes of the two frames
 	};
 	constexpr int kLossySpecSlab = 16384; // pixels of a frame per workgroup of the sums kernel
 	inline int lossy_spec_stat_workgroups(int s) { return (s + kLossySpecSlab - 1) / kLossySpecSlab; }

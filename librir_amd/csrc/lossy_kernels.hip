@@ -1763,6 +1763,14 @@ namespace rir
 			lossy_v4u v;
 			v.x = x.d[0], v.y = x.d[1], v.z = x.d[2], v.w = x.d[3];
 			__builtin_amdgcn_raw_buffer_store_b128(v, r, off, soff, AUX);
+			// A 16-byte buffer store followed AT ONCE by a vector instruction that writes one of its data registers stored that instruction's
+			// result instead - on gfx950, with the scalar offset in a register (`buffer_store_dwordx4 v[44:47], v127, s[20:23], s40 offen nt` then
+			// `v_and_or_b32 v44, ...`: two pixels of a thread's eight, in a few waves of a frame, found when the speculative instance began to
+			// compute its byte plane right behind the store of the output frame; eight idle cycles between the two, or another order, and it was
+			// gone).  The ISA's table asks for wait states behind stores of more than 8 bytes but excepts those with a register offset, and so does
+			// the compiler's hazard pass (GCNHazardRecognizer::createsVALUHazard): nothing was inserted.  The data registers are kept alive until
+			// four idle cycles behind the store - whatever the compiler schedules in between cannot write them.
+			asm volatile("s_nop 3" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "memory");
 		}
 		else if constexpr (NP == 2)
 		{
@@ -1790,14 +1798,22 @@ namespace rir
 		uint32_t ra_mask;					 // this stream keeps a running average (a launch built for one may hold streams without)
 	};
 	// MID: a frame in the middle of a group - the ring is full (and stays so), see lossy_const_run_kernel
-	template <bool RA_ON, bool ADD_LOSS, bool MID = false>
+	// DIFF: also hands out what the frame's sums are made of (h264.cpp:1993-2036) - |t - previous output| of the pair in *diff2, the pair's
+	// "above the background" mask in *fg2 - for the speculative instance's byte plane (LossySpec::dplane)
+	template <bool RA_ON, bool ADD_LOSS, bool MID = false, bool DIFF = false>
 	__device__ __forceinline__ void const_pixel_pair(const ConstPairConsts &c, uint32_t v2, uint32_t old2, uint32_t last2, uint32_t &ref2, uint32_t &sum_lo, uint32_t &sum_hi,
-													 uint32_t &cc2, uint32_t &cv2, uint32_t &t_in2, uint32_t &out2)
+													 uint32_t &cc2, uint32_t &cv2, uint32_t &t_in2, uint32_t &out2, uint32_t *diff2 = nullptr, uint32_t *fg2 = nullptr)
 	{
 		const lossy_u16x2 v = lp2(v2), ref = lp2(ref2);
 		const lossy_u16x2 t = __builtin_elementwise_sub_sat(v, lp2(c.min2));
 		t_in2 = lu1(t);
 		const uint32_t fgm = lossy_nz_mask(__builtin_elementwise_sub_sat(v, lp2(c.bg2))); // v > background
+		if constexpr (DIFF)
+		{
+			const lossy_u16x2 prev = lp2(out2);
+			*diff2 = lu1(__builtin_elementwise_max(t, prev) - __builtin_elementwise_min(t, prev));
+			*fg2 = fgm;
+		}
 		const lossy_u16x2 max_error = lp2(lossy_bfi(fgm, c.high2, c.low2));
 		const lossy_u16x2 diff = __builtin_elementwise_max(t, ref) - __builtin_elementwise_min(t, ref);
 		lossy_u16x2 nk = __builtin_elementwise_sub_sat(diff, max_error); // != 0: the pixel is not kept
@@ -1952,6 +1968,35 @@ namespace rir
 		const uint64_t frame_bytes = (uint64_t)rp.frame_px * 2u, ring_bytes = (uint64_t)s * 2u;
 		const uint64_t in0 = (uint64_t)rp.in, ring0 = (uint64_t)st.ra_images;
 		const uint64_t ring_w0 = (uint64_t)sto.ra_images; // the ring the group's last images are written to (SPEC: the shadow ring, same slots)
+		// SPEC: the byte plane of the group (LossySpec::dplane; null: none - every store out of range), a frame's bytes `s` further than the frame's before
+		uint32_t dor = 0; // every difference of this thread's pixels, or-ed
+		const uint32_t off_d = (SPEC && lossy) ? (uint32_t)(ig * PX) : RIR_LOSSY_OOB;
+		__amdgpu_buffer_rsrc_t rs_d = lossy_rsrc(nullptr, 0u);
+		if constexpr (SPEC)
+		{
+			const uint8_t *pl = as_global(spec + stream)->dplane;
+			rs_d = lossy_rsrc(pl, pl ? (uint32_t)n * (uint32_t)s : 0u); // (n * s < 2^30: the host cuts groups so that n frames of 2 s bytes stay below 2^31)
+		}
+		// the bytes of a thread's pixels, from the pairs' differences and masks: byte = difference | 0x80 where the pixel is above the background
+		auto plane_store = [&](const uint32_t (&dd)[NP], const uint32_t (&fg)[NP], uint32_t soff) {
+			uint32_t w[NP];
+#pragma unroll
+			for (int p = 0; p < NP; ++p)
+			{
+				dor |= dd[p];
+				w[p] = dd[p] | (fg[p] & 0x00800080u);
+			}
+			if constexpr (NP == 1)
+				__builtin_amdgcn_raw_buffer_store_b16((short)__builtin_amdgcn_perm(w[0], w[0], 0x06040200u), rs_d, off_d, soff, 2);
+			else if constexpr (NP == 2)
+				__builtin_amdgcn_raw_buffer_store_b32(__builtin_amdgcn_perm(w[1], w[0], 0x06040200u), rs_d, off_d, soff, 2);
+			else
+			{
+				lossy_v2u_b q;
+				q.x = __builtin_amdgcn_perm(w[1], w[0], 0x06040200u), q.y = __builtin_amdgcn_perm(w[3], w[2], 0x06040200u);
+				__builtin_amdgcn_raw_buffer_store_b64(q, rs_d, off_d, soff, 2);
+			}
+		};
 		// the budget of every frame (lossy_budget with a statistic that is multiplied by zero)
 		const int high_error = rp.high_value_error < 0 ? 0 : rp.high_value_error;
 		const int low_error = rp.low_value_error < high_error ? high_error : rp.low_value_error;
@@ -2083,12 +2128,15 @@ namespace rir
 				__builtin_amdgcn_raw_buffer_store_b64(pval, part_rsrc, poff, 0, 0); // (every frame: out of range unless the frame leaves sums)
 			pc.bg2 = lossy_both(background);
 			Px ov;
+			uint32_t dd[NP], fg[NP];
 #pragma unroll
 			for (int p = 0; p < NP; ++p)
 			{
-				const_pixel_pair<RA_ON, ADD_LOSS>(pc, v.d[p], old.d[p], last.d[p], ref.d[p], sum[2 * p], sum[2 * p + 1], cc.d[p], cv.d[p], t.d[p], o.d[p]);
+				const_pixel_pair<RA_ON, ADD_LOSS, false, SPEC>(pc, v.d[p], old.d[p], last.d[p], ref.d[p], sum[2 * p], sum[2 * p + 1], cc.d[p], cv.d[p], t.d[p], o.d[p], &dd[p], &fg[p]);
 				ov.d[p] = lossy_bfi(lossy_mask, o.d[p], v.d[p]); // rows past lossy_height: stored as they are
 			}
+			if constexpr (SPEC)
+				plane_store(dd, fg, (uint32_t)k * (uint32_t)s);
 			last = v;
 			buf_stn<NP, (SPEC ? RIR_SPEC_OUT_STORE_AUX : RIR_CONST_OUT_STORE_AUX)>(ov, lossy_rsrc((const void *)out_p, full_bytes), off_in);
 			out_p += frame_bytes;
@@ -2130,6 +2178,7 @@ namespace rir
 															 ra > 0 ? (uint32_t)(group_bytes - (uint64_t)D * frame_bytes + ra_back) : 0u);
 			const __amdgpu_buffer_rsrc_t rs_out = lossy_rsrc((const void *)(uint64_t)rp.out, (uint32_t)group_bytes);
 			uint32_t so = (uint32_t)mid0 * fb;
+			uint32_t so_d = (uint32_t)mid0 * (uint32_t)s; // (SPEC: where the frame's bytes go in the plane)
 			uint32_t bgq[D], bgn[D], loq[D], lon[D], hiq[D], hin[D];
 			auto backgrounds = [&](int k) { // of frames k .. k + D - 1 (k a multiple of D; the array is padded) - SPEC: and their budgets
 				if constexpr (D == 4)
@@ -2187,13 +2236,19 @@ namespace rir
 					pc.low2 = loq[j], pc.high2 = hiq[j];
 				const Px before = V[(j + D - 1) % D]; // the frame before this one: still in its slot
 				Px ov;
+				uint32_t dd[NP], fg[NP];
 #pragma unroll
 				for (int p = 0; p < NP; ++p)
 				{
-					const_pixel_pair<RA_ON, ADD_LOSS, true>(pc, v.d[p], old.d[p], before.d[p], ref.d[p], sum[2 * p], sum[2 * p + 1], cc.d[p], cv.d[p], t.d[p], o.d[p]);
+					const_pixel_pair<RA_ON, ADD_LOSS, true, SPEC>(pc, v.d[p], old.d[p], before.d[p], ref.d[p], sum[2 * p], sum[2 * p + 1], cc.d[p], cv.d[p], t.d[p], o.d[p], &dd[p], &fg[p]);
 					ov.d[p] = lossy_bfi(lossy_mask, o.d[p], v.d[p]);
 				}
 				buf_stn<NP, (SPEC ? RIR_SPEC_OUT_STORE_AUX : RIR_CONST_OUT_STORE_AUX)>(ov, rs_out, off_in, so);
+				if constexpr (SPEC)
+				{
+					plane_store(dd, fg, so_d);
+					so_d += (uint32_t)s;
+				}
 				if (TAIL && RA_ON)
 				{ // the ring as it must be after the group: the last `ra` inputs (less the minimum), each in the slot after the one before
 					buf_stn<NP>(t, k >= ring_from ? rs_ring_on : rs_ring_off, off_lossy, so_ring);
@@ -2270,6 +2325,11 @@ namespace rir
 			for (int j = 0; j < D - 1; ++j)
 				if (k0 + j < n)
 					step(k0 + j, V[j], O[j]);
+		}
+		if constexpr (SPEC)
+		{ // a difference that does not fit its seven bits: this pass's sums are taken from the frames (lossy_spec_stats_kernel<false>)
+			if (lossy && (dor & 0xff80ff80u) != 0u)
+				__hip_atomic_store(as_global(as_global(spec + stream)->ctl) + 7, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
 		RIR_GLOBAL(uint16_t) *refT_o = as_global(sto.refT), *prevT_o = as_global(sto.prevT), *lastDL_o = as_global(sto.lastDL);
 		if (lossy)
@@ -2447,7 +2507,7 @@ namespace rir
 		}
 	}
 
-	// lossy_spec_stats_kernel: grid = (slabs of a frame, frames, streams).  The six sums of frame k (h264.cpp:1993-2036) from the frames where
+	// lossy_spec_stats_kernel: grid = (slabs of a frame, frames / kLossySpecStatFrames, streams).  The six sums of frame k (h264.cpp:1993-2036) from the frames where
 	// they lie: input k (less the minimum) against output k - 1 - the stream's prevT for the group's first frame, which a pass leaves alone -
 	// split by input k > background k.  Per slab of kLossySpecSlab pixels four words, as lossy_const_run_kernel's partials; the LAST slab of
 	// a frame to arrive (a ticket per frame; rows written and read with agent-scope accesses, as lossy_last_arriver's callers do) adds them up and
@@ -2455,87 +2515,118 @@ namespace rir
 #ifndef RIR_SPEC_STATS_AUX
 #define RIR_SPEC_STATS_AUX 2 /* cache policy of the sums kernel's loads: nt (every byte is read once; measured +4 % on the whole call against the default policy, sc1 no better) */
 #endif
-	__global__ __launch_bounds__(256) void lossy_spec_stats_kernel(const LossyRun *__restrict__ table, const LossySpec *__restrict__ spec)
+	// PLANE: the same sums from the byte plane the streaming kernel left (LossySpec::dplane: difference and class of every pixel in one byte - a
+	// quarter of the bytes of the two frames, four pixels to an instruction through v_dot4_u32_u8).  Both forms are queued behind every pass: the one
+	// from the plane does the work unless there is no plane or the pass met a difference of 128 or more (ctl[7]), then the one from the frames does.
+	// one frame's share of a workgroup (its slab): the sums, the row, and - the last slab of the frame to arrive - the frame's statistic
+	template <bool PLANE>
+	__device__ __forceinline__ void lossy_spec_stats_frame(RIR_GLOBAL(const LossySpec) *sp, RIR_GLOBAL(const LossyRun) *r, int k, int slab, int nslabs, long long (*red)[6],
+														   unsigned int *sh_last_)
 	{
-		__shared__ long long red[4][6];
-		__shared__ unsigned int sh_last;
-		const int tid = threadIdx.x, slab = blockIdx.x, k = blockIdx.y, stream = blockIdx.z, nslabs = gridDim.x;
-		RIR_GLOBAL(const LossySpec) *sp = as_global(spec + stream);
-		if (__hip_atomic_load(as_global(sp->ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
-			return;
-		RIR_GLOBAL(const LossyRun) *r = as_global(table + stream);
-		if (k >= r->nsteps)
-			return;
+		unsigned int &sh_last = *sh_last_;
+		const int tid = threadIdx.x;
 		const int s = r->s;
-		const size_t frame_px = (size_t)r->frame_px;
-		const uint16_t *in_k = r->in + (size_t)k * frame_px;
-		const uint16_t *prev = k == 0 ? (const uint16_t *)r->st.prevT : (const uint16_t *)r->out + (size_t)(k - 1) * frame_px;
-		const uint32_t background = (uint32_t)as_global(r->bg)[(size_t)k * r->bg_stride];
-		const int subtract_min = r->st.subtract_min;
-		const uint32_t mn = r->st.min;
 		const int i0 = slab * kLossySpecSlab, i1 = min(i0 + kLossySpecSlab, s); // (s is a multiple of 8: the callers' `runs`)
-		const uint32_t bytes = (uint32_t)i1 * 2u;
-		const __amdgpu_buffer_rsrc_t rs_in = lossy_rsrc(in_k, bytes), rs_pv = lossy_rsrc(prev, bytes);
 		uint32_t fd = 0, bd = 0, fn = 0, bn = 0;
 		long long f2 = 0, b2 = 0;
-		constexpr int kIter = kLossySpecSlab / 8 / 256; // 16-byte loads per thread and array
-		lossy_v4u a[kIter], p[kIter];
-		uint32_t valid = 0; // pixels of this thread that lie in the lossy rows
-#pragma unroll
-		for (int j = 0; j < kIter; ++j)
-		{ // (a lane past the end of the lossy rows: out of range - zeros against zeros: d = 0, counted nowhere but in `valid`)
-			const uint32_t off = (uint32_t)(i0 / 8 + j * 256 + tid) * 16u;
-			a[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, RIR_SPEC_STATS_AUX);
-			p[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_pv, off, 0, RIR_SPEC_STATS_AUX);
-			valid += (i0 / 8 + j * 256 + tid) * 8 < i1 ? 8u : 0u;
-		}
-		// Two pixels to an instruction, the sums through v_dot2_u32_u16: d = max - min, the foreground mask as in const_pixel_pair, sum d and
-		// sum d^2 over everything and over the foreground (the background is the difference).  Exact as long as every d is below 4 096 (64 pixels
-		// of a thread: sum d^2 < 2^30) - thermal frames are; a wave that meets a larger one does its pixels again one by one, as the host code does
-		// (h264.cpp:1993-2036: the square wraps at 32 bits and is added as a signed number).
+		if constexpr (PLANE)
 		{
-			const uint32_t min2 = subtract_min ? lossy_both(mn) : 0u, bg2 = lossy_both(background);
-			const lossy_u16x2 ones = {1, 1};
-			uint32_t sd_all = 0, sd_fg = 0, s2_all = 0, s2_fg = 0, n_fg = 0, dor = 0;
+			// 16 pixels per 16-byte load; a lane past the end of the lossy rows: out of range - zeros: no difference, no class, counted nowhere but in `valid`
+			const __amdgpu_buffer_rsrc_t rs = lossy_rsrc(sp->dplane + (size_t)k * (size_t)s, (uint32_t)i1);
+			constexpr int kIter = kLossySpecSlab / 16 / 256;
+			lossy_v4u a[kIter];
+			uint32_t valid = 0;
+#pragma unroll
+			for (int j = 0; j < kIter; ++j)
+			{
+				const uint32_t px = (uint32_t)i0 + (uint32_t)(j * 256 + tid) * 16u;
+				a[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, px, 0, RIR_SPEC_STATS_AUX);
+				valid += px < (uint32_t)i1 ? min(16u, (uint32_t)i1 - px) : 0u;
+			}
+			// (differences below 128, 64 pixels of a thread: sum d < 2^13, sum d^2 < 2^20)
+			uint32_t sd_all = 0, sd_fg = 0, s2_all = 0, s2_fg = 0, n_fg = 0;
 #pragma unroll
 			for (int j = 0; j < kIter; ++j)
 #pragma unroll
 				for (int q = 0; q < 4; ++q)
 				{
-					const lossy_u16x2 v = lp2(a[j][q]), o = lp2(p[j][q]);
-					const lossy_u16x2 t = __builtin_elementwise_sub_sat(v, lp2(min2));
-					const lossy_u16x2 d = __builtin_elementwise_max(t, o) - __builtin_elementwise_min(t, o);
-					const uint32_t fgm = lossy_nz_mask(__builtin_elementwise_sub_sat(v, lp2(bg2))); // v > background
-					const lossy_u16x2 dfg = lp2(lu1(d) & fgm);
-					dor |= lu1(d);
-					sd_all = __builtin_amdgcn_udot2(d, ones, sd_all, false), sd_fg = __builtin_amdgcn_udot2(dfg, ones, sd_fg, false);
-					s2_all = __builtin_amdgcn_udot2(d, d, s2_all, false), s2_fg = __builtin_amdgcn_udot2(dfg, dfg, s2_fg, false);
-					n_fg = __builtin_amdgcn_udot2(lp2(fgm & 0x00010001u), ones, n_fg, false);
+					const uint32_t x = a[j][q], d4 = x & 0x7f7f7f7fu, f4 = (x >> 7) & 0x01010101u, dfg4 = d4 & (f4 * 0x7fu);
+					sd_all = __builtin_amdgcn_udot4(d4, 0x01010101u, sd_all, false), sd_fg = __builtin_amdgcn_udot4(dfg4, 0x01010101u, sd_fg, false);
+					s2_all = __builtin_amdgcn_udot4(d4, d4, s2_all, false), s2_fg = __builtin_amdgcn_udot4(dfg4, dfg4, s2_fg, false);
+					n_fg = __builtin_amdgcn_udot4(f4, 0x01010101u, n_fg, false);
 				}
-			if (__builtin_expect(__ballot((dor & 0xf000f000u) != 0u) == 0ull, 1))
-			{
-				fd = sd_fg, bd = sd_all - sd_fg, fn = n_fg, bn = valid - n_fg;
-				f2 = (long long)s2_fg, b2 = (long long)(s2_all - s2_fg);
+			fd = sd_fg, bd = sd_all - sd_fg, fn = n_fg, bn = valid - n_fg;
+			f2 = (long long)s2_fg, b2 = (long long)(s2_all - s2_fg);
+		}
+		else
+		{
+			const size_t frame_px = (size_t)r->frame_px;
+			const uint16_t *in_k = r->in + (size_t)k * frame_px;
+			const uint16_t *prev = k == 0 ? (const uint16_t *)r->st.prevT : (const uint16_t *)r->out + (size_t)(k - 1) * frame_px;
+			const uint32_t background = (uint32_t)as_global(r->bg)[(size_t)k * r->bg_stride];
+			const int subtract_min = r->st.subtract_min;
+			const uint32_t mn = r->st.min;
+			const uint32_t bytes = (uint32_t)i1 * 2u;
+			const __amdgpu_buffer_rsrc_t rs_in = lossy_rsrc(in_k, bytes), rs_pv = lossy_rsrc(prev, bytes);
+			constexpr int kIter = kLossySpecSlab / 8 / 256; // 16-byte loads per thread and array
+			lossy_v4u a[kIter], p[kIter];
+			uint32_t valid = 0; // pixels of this thread that lie in the lossy rows
+#pragma unroll
+			for (int j = 0; j < kIter; ++j)
+			{ // (a lane past the end of the lossy rows: out of range - zeros against zeros: d = 0, counted nowhere but in `valid`)
+				const uint32_t off = (uint32_t)(i0 / 8 + j * 256 + tid) * 16u;
+				a[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, off, 0, RIR_SPEC_STATS_AUX);
+				p[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_pv, off, 0, RIR_SPEC_STATS_AUX);
+				valid += (i0 / 8 + j * 256 + tid) * 8 < i1 ? 8u : 0u;
 			}
-			else
+			// Two pixels to an instruction, the sums through v_dot2_u32_u16: d = max - min, the foreground mask as in const_pixel_pair, sum d and
+			// sum d^2 over everything and over the foreground (the background is the difference).  Exact as long as every d is below 4 096 (64 pixels
+			// of a thread: sum d^2 < 2^30) - thermal frames are; a wave that meets a larger one does its pixels again one by one, as the host code does
+			// (h264.cpp:1993-2036: the square wraps at 32 bits and is added as a signed number).
 			{
+				const uint32_t min2 = subtract_min ? lossy_both(mn) : 0u, bg2 = lossy_both(background);
+				const lossy_u16x2 ones = {1, 1};
+				uint32_t sd_all = 0, sd_fg = 0, s2_all = 0, s2_fg = 0, n_fg = 0, dor = 0;
 #pragma unroll
 				for (int j = 0; j < kIter; ++j)
-				{
-					const bool in = (i0 / 8 + j * 256 + tid) * 8 < i1;
 #pragma unroll
-					for (int q = 0; q < 8; ++q)
+					for (int q = 0; q < 4; ++q)
 					{
-						const uint32_t aw = a[j][q >> 1], pw = p[j][q >> 1];
-						const uint32_t v = (q & 1) ? aw >> 16 : aw & 0xffffu, o = (q & 1) ? pw >> 16 : pw & 0xffffu;
-						const uint32_t t = subtract_min ? sub_min(v, mn) : v;
-						const int32_t d = in ? abs((int32_t)t - (int32_t)o) : 0;
-						const int32_t d2 = (int32_t)((uint32_t)d * (uint32_t)d);
-						const uint32_t one = in ? 1u : 0u;
-						if (v > background)
-							fd += (uint32_t)d, f2 += d2, fn += one;
-						else
-							bd += (uint32_t)d, b2 += d2, bn += one;
+						const lossy_u16x2 v = lp2(a[j][q]), o = lp2(p[j][q]);
+						const lossy_u16x2 t = __builtin_elementwise_sub_sat(v, lp2(min2));
+						const lossy_u16x2 d = __builtin_elementwise_max(t, o) - __builtin_elementwise_min(t, o);
+						const uint32_t fgm = lossy_nz_mask(__builtin_elementwise_sub_sat(v, lp2(bg2))); // v > background
+						const lossy_u16x2 dfg = lp2(lu1(d) & fgm);
+						dor |= lu1(d);
+						sd_all = __builtin_amdgcn_udot2(d, ones, sd_all, false), sd_fg = __builtin_amdgcn_udot2(dfg, ones, sd_fg, false);
+						s2_all = __builtin_amdgcn_udot2(d, d, s2_all, false), s2_fg = __builtin_amdgcn_udot2(dfg, dfg, s2_fg, false);
+						n_fg = __builtin_amdgcn_udot2(lp2(fgm & 0x00010001u), ones, n_fg, false);
+					}
+				if (__builtin_expect(__ballot((dor & 0xf000f000u) != 0u) == 0ull, 1))
+				{
+					fd = sd_fg, bd = sd_all - sd_fg, fn = n_fg, bn = valid - n_fg;
+					f2 = (long long)s2_fg, b2 = (long long)(s2_all - s2_fg);
+				}
+				else
+				{
+#pragma unroll
+					for (int j = 0; j < kIter; ++j)
+					{
+						const bool in = (i0 / 8 + j * 256 + tid) * 8 < i1;
+#pragma unroll
+						for (int q = 0; q < 8; ++q)
+						{
+							const uint32_t aw = a[j][q >> 1], pw = p[j][q >> 1];
+							const uint32_t v = (q & 1) ? aw >> 16 : aw & 0xffffu, o = (q & 1) ? pw >> 16 : pw & 0xffffu;
+							const uint32_t t = subtract_min ? sub_min(v, mn) : v;
+							const int32_t d = in ? abs((int32_t)t - (int32_t)o) : 0;
+							const int32_t d2 = (int32_t)((uint32_t)d * (uint32_t)d);
+							const uint32_t one = in ? 1u : 0u;
+							if (v > background)
+								fd += (uint32_t)d, f2 += d2, fn += one;
+							else
+								bd += (uint32_t)d, b2 += d2, bn += one;
+						}
 					}
 				}
 			}
@@ -2584,6 +2675,35 @@ namespace rir
 				gsd[2 * k] = sqrt(dbd * dbd - dbd2) / (int)tbn;
 				gsd[2 * k + 1] = sqrt(dfd * dfd - dfd2) / (int)tfn;
 			}
+		}
+	}
+	// (a workgroup takes its slab of kLossySpecStatFrames frames, one after the other: a launch that has nothing to do - the other form's, a pass
+	// that is not needed - is a quarter of the workgroups to start and to end: 2 us instead of 8 for a group of 1 000 frames)
+	constexpr int kLossySpecStatFrames = 4;
+	template <bool PLANE>
+	__global__ __launch_bounds__(256) void lossy_spec_stats_kernel(const LossyRun *__restrict__ table, const LossySpec *__restrict__ spec)
+	{
+		__shared__ long long red[4][6];
+		__shared__ unsigned int sh_last;
+		const int slab = blockIdx.x, stream = blockIdx.z, nslabs = gridDim.x;
+		RIR_GLOBAL(const LossySpec) *sp = as_global(spec + stream);
+		if (__hip_atomic_load(as_global(sp->ctl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+			return;
+		{
+			const bool from_plane = sp->dplane != nullptr && __hip_atomic_load(as_global(sp->ctl) + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+			if (from_plane != PLANE)
+				return;
+		}
+		RIR_GLOBAL(const LossyRun) *r = as_global(table + stream);
+		const int n = r->nsteps;
+		for (int kk = 0; kk < kLossySpecStatFrames; ++kk)
+		{
+			const int k = (int)blockIdx.y * kLossySpecStatFrames + kk;
+			if (k >= n)
+				break;
+			if (kk)
+				__syncthreads(); // (`red` and `sh_last` are free again)
+			lossy_spec_stats_frame<PLANE>(sp, r, k, slab, nslabs, red, &sh_last);
 		}
 	}
 
@@ -3033,7 +3153,9 @@ namespace rir
 			RIR_SPEC_LAUNCH(1)
 #undef RIR_SPEC_LAUNCH
 		const int nslabs = lossy_spec_stat_workgroups(s);
-		hipLaunchKernelGGL(lossy_spec_stats_kernel, dim3((unsigned)nslabs, (unsigned)max_frames, (unsigned)nstreams), dim3(256), 0, st, d_table, d_spec);
+		// (the sums from the byte plane; from the frames where there is no plane or it does not hold the pass's differences: one of the two returns at once)
+		hipLaunchKernelGGL(lossy_spec_stats_kernel<true>, dim3((unsigned)nslabs, (unsigned)((max_frames + kLossySpecStatFrames - 1) / kLossySpecStatFrames), (unsigned)nstreams), dim3(256), 0, st, d_table, d_spec);
+		hipLaunchKernelGGL(lossy_spec_stats_kernel<false>, dim3((unsigned)nslabs, (unsigned)((max_frames + kLossySpecStatFrames - 1) / kLossySpecStatFrames), (unsigned)nstreams), dim3(256), 0, st, d_table, d_spec);
 		hipLaunchKernelGGL(lossy_spec_verify_kernel, dim3((unsigned)nstreams), dim3(1024), 0, st, d_table, d_spec);
 		return hipGetLastError();
 	}

@@ -383,7 +383,7 @@ namespace
 	int const_groups = 0;						// groups of the last run call that were OFFERED to the constant-budget form (0: it was not eligible)
 	// speculative form (lossy_kernels.h: LossySpec): the budget tables, sums and statistics of a group (reused group after group), the control
 	// words of every group and stream of the last call, and - for good - the back-off words of the calls this stream leads
-	DeviceBuffer spec_budgets, spec_rows, spec_sd, spec_ctl, spec_backoff, spec_tickets;
+	DeviceBuffer spec_budgets, spec_rows, spec_sd, spec_ctl, spec_backoff, spec_tickets, spec_dplane;
 	PinnedBuffer spec_backoff_host;				// the back-off words again, where the host can look without waiting (lossy_kernels.h: LossySpec::backoff_host)
 	int spec_groups = 0, spec_streams = 0;		// groups (and streams) of the last run call that went through the speculative launches (0: not eligible)
 		PinnedBuffer multi_stage;
@@ -3466,6 +3466,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 					lead.const_groups = ngroups;
 				}
 				lead.spec_groups = 0;
+				bool spec_plane = false;
 				const int spec_slabs = lossy_spec_stat_workgroups(s_px);
 				const size_t spec_group = (size_t)std::min(nsteps, group);
 				if (spec_form)
@@ -3477,6 +3478,9 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 						!hip_ok(hipMemsetAsync(lead.spec_ctl.ptr, 0, (size_t)ngroups * nstreams * 32, st), "memset") || !lead.spec_backoff.reserve(8) ||
 						!lead.spec_tickets.reserve((size_t)nstreams * spec_group * 4))
 						return -1;
+					// the byte plane the streaming kernel leaves for the sums kernel (lossy_kernels.h: LossySpec::dplane), a byte per pixel and frame of a group;
+					// RIR_LOSSY_SPEC_NO_PLANE (measurements): none - the sums are taken from the frames, as they are when the memory is not to be had
+					spec_plane = !getenv("RIR_LOSSY_SPEC_NO_PLANE") && lead.spec_dplane.reserve((size_t)nstreams * spec_group * (size_t)s_px);
 					if (lead.spec_tickets.cap != tk_cap && !hip_ok(hipMemsetAsync(lead.spec_tickets.ptr, 0, lead.spec_tickets.cap, st), "memset"))
 						return -1;
 					if (lead.spec_backoff.cap != bk_cap && !hip_ok(hipMemsetAsync(lead.spec_backoff.ptr, 0, 8, st), "memset"))
@@ -3529,6 +3533,7 @@ int lossy_step_streams(LossyObject *const *os, int nstreams, const unsigned shor
 							sp.ctl = lead.spec_ctl.as<unsigned int>() + ((size_t)g * nstreams + i) * 8;
 							sp.backoff = lead.spec_backoff.as<unsigned int>();
 							sp.backoff_host = lead.spec_backoff_host.as<unsigned int>();
+							sp.dplane = spec_plane ? lead.spec_dplane.as<uint8_t>() + (size_t)i * spec_group * (size_t)s_px : nullptr;
 							hsp[(size_t)g * nstreams + i] = sp;
 						}
 						for (int k = k0; k < k0 + in_group; ++k)

@@ -17,6 +17,9 @@ def short(name):
     m = re.match(r"lossy_const_run_kernel<(\d+), (\w+), (\w+), (\w+)>", n)
     if m:
         return "lossy_const_run_kernel<SPEC>" if m.group(4) in ("true", "1") else "lossy_const_run_kernel"
+    m = re.match(r"lossy_spec_stats_kernel<(\w+)>", n)
+    if m:  # the sums from the streaming kernel's byte plane / from the frames (one of the two returns at once)
+        return "lossy_spec_stats_kernel<PLANE>" if m.group(1) in ("true", "1") else "lossy_spec_stats_kernel<FRAMES>"
     return re.sub(r"<.*", "", n)
 
 
@@ -44,8 +47,8 @@ def hbm(k):
     return (c.get("FETCH_SIZE", 0.0) * 2 + c.get("WRITE_SIZE", 0.0)) * 1024  # FETCH_SIZE counts 64-byte halves of gfx950's 128-byte requests (MI355X_MICROARCH.md): x 2; KB -> bytes
 
 
-alg_run = 6 * W * HL + 4 * W * (H - HL)
-alg_stats = 4 * W * HL
+alg_run = 7 * W * HL + 4 * W * (H - HL)
+alg_stats = W * HL
 out = {
     "source": "scripts/lossy_spec_profile.sh: tests/perf/lossy_spec_time.py 1000 1 speculative,static (one 640x512 stream, 509 lossy rows, the reference's defaults 6 / 2 / 5 / 32, static scene, 1 000 frames per call: one pass, committed) under rocprofv3 --kernel-trace --stats and --pmc (FETCH_SIZE, WRITE_SIZE, SQ counters in passes of their own; every kernel's launches averaged - two of a call's three pass launches return at once)",
     "rates": open(os.path.join(d, "rates.txt")).read().splitlines(),
@@ -54,8 +57,8 @@ out = {
     "counters_per_dispatch (mean over working and idle launches)": pmc,
     "note": "per-dispatch means mix the one working launch of a call with the idle ones (3 streaming / sums / verify launches are queued per group, the passes allowed); totals per call = mean x launches per call",
 }
-for k, alg, what in (("lossy_const_run_kernel<SPEC>", alg_run, "6 bytes per lossy pixel and frame (pixel in, pixel out, the frame leaving the running average), 4 per pixel past lossy_height"),
-                     ("lossy_spec_stats_kernel", alg_stats, "4 bytes per lossy pixel and frame (input k, output k - 1)")):
+for k, alg, what in (("lossy_const_run_kernel<SPEC>", alg_run, "7 bytes per lossy pixel and frame (pixel in, pixel out, the frame leaving the running average, a byte of the plane), 4 per pixel past lossy_height"),
+                     ("lossy_spec_stats_kernel<PLANE>", alg_stats, "1 byte per lossy pixel and frame (the byte plane: difference and class)")):
     if k in stats and k in pmc:
         n_launch = pmc[k]["_dispatches"]
         # the working launches carry all the traffic and nearly all the time: totals over the profile / working launches

@@ -38,6 +38,9 @@ for k in range(cases):
         os.environ["RIR_LOSSY_SPEC_FIRST_ONLY"] = "1"
     if rng.integers(0, 4) == 0:
         os.environ["RIR_LOSSY_SPEC_NO_GIVE_UP"] = "1"
+    os.environ.pop("RIR_LOSSY_SPEC_NO_PLANE", None)
+    if rng.integers(0, 4) == 0:  # (the sums from the frames instead of the streaming kernel's byte plane)
+        os.environ["RIR_LOSSY_SPEC_NO_PLANE"] = "1"
     L = OracleLossy(O, w, h, hl, low_err=low, high_err=high, std_factor=sf, running_average=ra, subtract_min=smin)
     exp, elo, ehi = [], [], []
     for i in range(n):
@@ -72,6 +75,7 @@ for k in range(multi_cases):
     os.environ["RIR_LOSSY_SPEC_PASSES"] = str(int(rng.integers(1, 9)))
     os.environ.pop("RIR_LOSSY_SPEC_FIRST_ONLY", None)
     os.environ.pop("RIR_LOSSY_SPEC_NO_GIVE_UP", None)
+    os.environ.pop("RIR_LOSSY_SPEC_NO_PLANE", None)
     all_const = bool(rng.integers(0, 3) == 0)
     calm = bool(rng.integers(0, 2))  # every stream a static scene (what the speculative form commits) or a mixture
     prm, frs, exp, elo, ehi = [], [], [], [], []
