@@ -337,7 +337,7 @@ def test_speculative_form_declines_what_it_must_not_take(oracle):
 @pytest.mark.perf
 def test_speculative_form_rate_on_a_static_scene():
     """Rate floor (not part of the parity run): the reference's default parameters on a 640x512 scene that does not move, 200-frame calls, frames in
-    HBM - committed by the speculative form at 0.76 M frames/s (1.12-1.15 M in 1 000-frame calls; the general form 0.16 M:
+    HBM - committed by the speculative form at 0.82 M frames/s (1.4 M in 1 000-frame calls; the general form 0.17 M:
     tests/perf/lossy_spec_time.py).  The floor leaves a third of margin for a busy box; best of three."""
     import time
 
