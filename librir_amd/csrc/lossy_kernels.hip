@@ -1768,8 +1768,10 @@ namespace rir
 			// `v_and_or_b32 v44, ...`: two pixels of a thread's eight, in a few waves of a frame, found when the speculative instance began to
 			// compute its byte plane right behind the store of the output frame; eight idle cycles between the two, or another order, and it was
 			// gone).  The ISA's table asks for wait states behind stores of more than 8 bytes but excepts those with a register offset, and so does
-			// the compiler's hazard pass (GCNHazardRecognizer::createsVALUHazard): nothing was inserted.  The data registers are kept alive until
-			// four idle cycles behind the store - whatever the compiler schedules in between cannot write them.
+			// the compiler's hazard pass (GCNHazardRecognizer::createsVALUHazard): nothing was inserted.  scripts/ubench/store_hazard.hip issues the
+			// pair from inline assembly on a full chip: 4-7 records in 10 000 arrive overwritten with the offset in a register (nt or not), none with
+			// one idle cycle in between, none for 8-byte stores (profiles/r06_store_hazard.txt).  The data registers are kept alive until four idle
+			// cycles behind the store - whatever the compiler schedules in between cannot write them.
 			asm volatile("s_nop 3" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w) : "memory");
 		}
 		else if constexpr (NP == 2)
