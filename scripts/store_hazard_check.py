@@ -51,6 +51,14 @@ def check(unit):
     return bad
 
 
+def check_all(units=None):
+    """every unit (compiled side by side) -> the number of unprotected stores"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    units = units or sorted(f for f in os.listdir(B.CSRC) if f.endswith(".hip"))
+    with ThreadPoolExecutor(max_workers=min(6, len(units))) as pool:
+        return sum(pool.map(check, units))
+
+
 if __name__ == "__main__":
-    units = sys.argv[1:] or sorted(f for f in os.listdir(B.CSRC) if f.endswith(".hip"))
-    sys.exit(1 if sum(check(u) for u in units) else 0)
+    sys.exit(1 if check_all(sys.argv[1:]) else 0)
